@@ -1,0 +1,1086 @@
+// cc4_engine.h -- the CC4 episode transition: reset (scenario generation), step, flat observation.
+//
+// Single source for the gfx950 device build (cc4_hip.hip) and for the host build used as the CPU
+// oracle (oracle/cc4_oracle.cpp).  Each function cites the reference lines it restates
+// (paths under /root/reference/CybORG).  See docs/REFERENCE_NOTES.md for the condensed semantics.
+#pragma once
+#include "cc4_state.h"
+#include "cc4_tables.h"
+
+namespace cc4 {
+
+struct Ctx { EnvState* s; EnvCold* c; };
+
+// ------------------------------------------------------------------ small helpers
+CC4_HD int h_subnet(int h) { return h / SLOTS; }
+CC4_HD int h_slot(int h) { return h % SLOTS; }
+CC4_HD bool h_is_router(int h) { return h_slot(h) == 0; }          // incl. root_internet_host_0
+CC4_HD bool h_is_user(int h) { int sl = h_slot(h); return sl >= 1 && sl <= 10; }
+CC4_HD bool h_is_server(int h) { return h_slot(h) >= 11; }
+CC4_HD int h_make(int s, int slot) { return s * SLOTS + slot; }
+CC4_HD bool bit_get(const uint32_t* b, int i) { return (b[i >> 5] >> (i & 31)) & 1u; }
+CC4_HD void bit_set(uint32_t* b, int i) { b[i >> 5] |= 1u << (i & 31); }
+
+// Host.get_ephemeral_port (Simulator/Host.py:175-187): one re-draw on collision, then remember the port.
+CC4_HD int eph_port(Ctx x, int h) {
+  uint32_t p = rng_below(&x.s->rng, 60000 - 49152);
+  uint32_t* bm = x.c->eph[h];
+  if (bit_get(bm, (int)p)) p = rng_below(&x.s->rng, 60000 - 49152);
+  bit_set(bm, (int)p);
+  return 49152 + (int)p;
+}
+CC4_HD void eph_clear(Ctx x, int h) {
+  for (int i = 0; i < EPH_WORDS; ++i) x.c->eph[h][i] = 0;
+}
+// Host.create_pid (Simulator/Host.py:198-200)
+CC4_HD int create_pid(Ctx x, int h) {
+  const HostDyn& d = x.s->hd[h];
+  int mx = 0;
+  for (int i = 0; i < d.nproc; ++i) if (d.procs[i].pid > mx) mx = d.procs[i].pid;
+  return mx + 1 + (int)rng_below(&x.s->rng, 9);
+}
+CC4_HD bool add_proc(Ctx x, int h, int pid, int kind, int flags) {
+  HostDyn& d = x.s->hd[h];
+  if (d.nproc >= MAXP) { x.s->err |= E_PROC_OVERFLOW; return false; }
+  Proc p; p.pid = (uint16_t)pid; p.kind = (uint8_t)kind; p.flags = (uint8_t)flags;
+  d.procs[d.nproc++] = p;
+  return true;
+}
+CC4_HD int find_proc(Ctx x, int h, int pid) {
+  const HostDyn& d = x.s->hd[h];
+  for (int i = 0; i < d.nproc; ++i) if (d.procs[i].pid == pid) return i;
+  return -1;
+}
+CC4_HD void remove_proc_at(Ctx x, int h, int idx) {
+  HostDyn& d = x.s->hd[h];
+  for (int i = idx; i + 1 < d.nproc; ++i) d.procs[i] = d.procs[i + 1];
+  d.nproc--;
+}
+CC4_HD bool host_uses_port(Ctx x, int h, int pbit) {  // Host.is_using_port (Host.py:310-314)
+  const HostDyn& d = x.s->hd[h];
+  for (int i = 0; i < d.nproc; ++i) if (kind_port(d.procs[i].kind) & pbit) return true;
+  return false;
+}
+// host.events.network_connections.append(...)
+CC4_HD void ev_conn(Ctx x, int h) { x.s->hd[h].ev |= EV_CUR_CONN; }
+// host.events.process_creation.append(...); pid > 0 when the event dict carries 'pid' (ExploitAction.py:264-275)
+CC4_HD void ev_proc(Ctx x, int h, int pid) {
+  x.s->hd[h].ev |= EV_CUR_PROC;
+  if (pid > 0 && blue_of_subnet(h_subnet(h)) >= 0) {
+    if (x.s->npend >= MAX_PEND) { x.s->err |= E_PEND_OVERFLOW; return; }
+    x.s->pend[x.s->npend++] = ((uint32_t)h << 16) | (uint32_t)pid;
+  }
+}
+CC4_HD void pend_drop_host(Ctx x, int h) {
+  EnvState* s = x.s;
+  int n = 0;
+  for (int i = 0; i < s->npend; ++i) if ((int)(s->pend[i] >> 16) != h) s->pend[n++] = s->pend[i];
+  s->npend = (uint8_t)n;
+}
+// RemoteAction.blocking_host (Simulator/Actions/Action.py:126-135): only subnet-level blocks exist in CC4
+CC4_HD bool subnet_blocked(Ctx x, int src_sub, int other_sub) { return (x.s->blocks[other_sub] >> src_sub) & 1u; }
+
+// ------------------------------------------------------------------ red sessions
+CC4_HD int rs_find_id(const RedAgent& a, int id) {
+  for (int i = 0; i < a.nsess; ++i) if (a.sess[i].id == id) return i;
+  return -1;
+}
+CC4_HD int kb_alloc(Ctx x) {
+  for (int i = 0; i < MAX_KB; ++i)
+    if (!bit_get(x.s->kb_used, i)) {
+      bit_set(x.s->kb_used, i);
+      for (int h = 0; h < MAXH; ++h) x.c->kports[i][h] = 0;
+      return i;
+    }
+  x.s->err |= E_KB_OVERFLOW;
+  return 0xFF;
+}
+CC4_HD void kb_free(Ctx x, int kb) { if (kb != 0xFF) x.s->kb_used[kb >> 5] &= ~(1u << (kb & 31)); }
+// State.add_session (Simulator/State.py:305-324): ident = max(existing)+1 (0 if none); appended (dict order)
+CC4_HD int rs_add(Ctx x, int r, int host, int pid, int flags) {
+  RedAgent& a = x.s->red[r];
+  if (a.nsess >= MAX_RS) { x.s->err |= E_RSESS_OVERFLOW; return -1; }
+  int id = 0;
+  for (int i = 0; i < a.nsess; ++i) if (a.sess[i].id + 1 > id) id = a.sess[i].id + 1;
+  RSess q; q.id = (uint16_t)id; q.pid = (uint16_t)pid; q.host = (uint8_t)host; q.flags = (uint8_t)flags; q.pad = 0;
+  q.kb = (flags & RS_ABSTRACT) ? (uint8_t)kb_alloc(x) : (uint8_t)0xFF;
+  a.sess[a.nsess++] = q;
+  return a.nsess - 1;
+}
+CC4_HD void rs_remove_at(Ctx x, int r, int idx, bool free_kb) {
+  RedAgent& a = x.s->red[r];
+  if (free_kb) kb_free(x, a.sess[idx].kb);
+  for (int i = idx; i + 1 < a.nsess; ++i) a.sess[i] = a.sess[i + 1];
+  a.nsess--;
+}
+CC4_HD bool red_has_session_on(const RedAgent& a, int h) {
+  for (int i = 0; i < a.nsess; ++i) if (a.sess[i].host == h) return true;
+  return false;
+}
+// ActionSpace.update: server_session[session_id] = True (Shared/ActionSpace.py:205-211)
+CC4_HD void as_know_sid(Ctx x, int r, int id) {
+  RedAgent& a = x.s->red[r];
+  for (int i = 0; i < a.nknown; ++i) if (a.known_sid[i] == id) return;
+  if (a.nknown >= MAX_KS) { x.s->err |= E_KS_OVERFLOW; return; }
+  a.known_sid[a.nknown++] = (uint16_t)id;
+}
+// one key of the agent's step observation (Shared/Observation.py add_* / combine_obs); also applies the
+// ActionSpace.update side effects (ip / hostname / subnet known) eagerly -- nothing reads them before step end.
+CC4_HD void obs_put(Ctx x, int r, bool key_ip, int host, int flags, bool subnet_known) {
+  RedAgent& a = x.s->red[r];
+  if (flags & OE_IFACE) bit_set(a.as_ip, host);
+  if (flags & OE_SYSHN) bit_set(a.as_hn, host);
+  if (subnet_known) a.as_subnet |= (uint16_t)(1u << h_subnet(host));
+  uint8_t want = (uint8_t)(key_ip ? OE_KEY_IP : 0);
+  for (int i = 0; i < a.nobs; ++i)
+    if (a.obs[i].host == host && (a.obs[i].flags & OE_KEY_IP) == want) { a.obs[i].flags |= (uint8_t)flags; return; }
+  if (a.nobs >= MAX_OBS) { x.s->err |= E_OBS_OVERFLOW; return; }
+  a.obs[a.nobs].host = (uint8_t)host;
+  a.obs[a.nobs].flags = (uint8_t)(flags | want);
+  a.nobs++;
+}
+// observations[0] of the agent this step decides what the FSM sees as (action, success)
+CC4_HD void obs_first(Ctx x, int r, int success, int atype, int ahost, int aarg) {
+  RedAgent& a = x.s->red[r];
+  if (a.obs_success != 0) return;
+  a.obs_success = (uint8_t)success; a.obs_act_type = (uint8_t)atype; a.obs_act_host = (uint8_t)ahost; a.obs_act_arg = (uint8_t)aarg;
+}
+
+// ------------------------------------------------------------------ routes (tree of routers)
+// RemoteAction.get_route (Action.py:100-116) on the fixed link diagram (EnterpriseScenarioGenerator.py:373-416):
+// the graph is a tree, so the route is the unique path src .. dst (inclusive).
+CC4_HD int path_to_root(int h, uint8_t* out) {
+  int n = 0;
+  out[n++] = (uint8_t)h;
+  if (h == H_INTERNET) return n;
+  int s = h_subnet(h);
+  if (!h_is_router(h)) out[n++] = (uint8_t)h_make(s, 0);
+  while (true) {
+    int p = router_parent(s);
+    if (p == S_INT) { out[n++] = (uint8_t)H_INTERNET; break; }
+    out[n++] = (uint8_t)h_make(p, 0);
+    s = p;
+  }
+  return n;
+}
+CC4_HD int route(int src, int dst, uint8_t* out) {
+  uint8_t a[6], b[6];
+  int na = path_to_root(src, a), nb = path_to_root(dst, b);
+  // both end at the root; drop the shared tail but keep the lowest common ancestor
+  while (na >= 2 && nb >= 2 && a[na - 2] == b[nb - 2]) { na--; nb--; }
+  int n = 0;
+  for (int i = 0; i < na; ++i) out[n++] = a[i];
+  for (int i = nb - 2; i >= 0; --i) out[n++] = b[i];
+  return n;
+}
+
+// ------------------------------------------------------------------ reset: EnterpriseScenarioGenerator + State.__init__
+// Draw order follows create_scenario (EnterpriseScenarioGenerator.py:123-169) then State.__init__ (State.py:66-148).
+CC4_HD int gen_pid(Ctx x, uint32_t* used) {  // _generate_pid (ESG.py:564-578)
+  while (true) {
+    int pid = rng_range(&x.s->rng, 1000, 10000);
+    if (!bit_get(used, pid - 1000)) { bit_set(used, pid - 1000); return pid; }
+  }
+}
+CC4_HD void gen_host(Ctx x, int h, uint32_t* used) {  // _generate_linux_host (ESG.py:470-528)
+  EnvState* s = x.s;
+  HostStatic& st = s->hs[h];
+  st.exists = 1; st.nproc = 0; st.nsvc = 0;
+  (void)rng_below(&s->rng, 2);  // OSDistribution choice (ESG.py:494): both are LINUX, value unused downstream
+  if (h_is_router(h)) return;
+  // _generate_linux_host_services (ESG.py:530-562)
+  int kinds[5]; int pids[5]; int n = 0;
+  kinds[n] = K_SSHD; pids[n++] = gen_pid(x, used);
+  int sub = h_subnet(h);
+  if (sub == S_OZA || sub == S_OZB) { kinds[n] = K_OT; pids[n++] = gen_pid(x, used); }
+  int opt_kind[3] = {K_APACHE, K_MYSQL, K_SMTP}; int opt_pid[3];
+  for (int i = 0; i < 3; ++i) opt_pid[i] = gen_pid(x, used);
+  int n_add = (int)rng_below(&s->rng, 4);  // integers(0, 3, endpoint=True)
+  int n_opt = 3;
+  for (int k = 0; k < n_add; ++k) {
+    int c = (int)rng_below(&s->rng, (uint32_t)n_opt);
+    kinds[n] = opt_kind[c]; pids[n++] = opt_pid[c];
+    for (int j = c; j + 1 < n_opt; ++j) { opt_kind[j] = opt_kind[j + 1]; opt_pid[j] = opt_pid[j + 1]; }
+    n_opt--;
+  }
+  // _generate_linux_host_processes (ESG.py:580-629): one random() per service, never below 1.0
+  for (int i = 0; i < n; ++i) {
+    (void)rng_random(&s->rng);
+    st.svcs[i].kind = (uint8_t)kinds[i]; st.svcs[i].pid = (uint16_t)pids[i]; st.svcs[i].st = (uint8_t)(SV_ACTIVE | 5);
+    st.procs[i].kind = (uint8_t)kinds[i]; st.procs[i].pid = (uint16_t)pids[i]; st.procs[i].flags = 0;
+  }
+  st.nsvc = (uint8_t)n; st.nproc = (uint8_t)n;
+}
+// Host.add_session for a starting session (Host.py:189-196): Process(pid=create_pid(), name=session_type)
+CC4_HD int start_session_proc(Ctx x, int h, int kind) {
+  HostStatic& st = x.s->hs[h];
+  int mx = 0;
+  for (int i = 0; i < st.nproc; ++i) if (st.procs[i].pid > mx) mx = st.procs[i].pid;
+  int pid = mx + 1 + (int)rng_below(&x.s->rng, 9);
+  st.procs[st.nproc].pid = (uint16_t)pid; st.procs[st.nproc].kind = (uint8_t)kind; st.procs[st.nproc].flags = 0;
+  st.nproc++;
+  return pid;
+}
+CC4_HD void host_restore(Ctx x, int h) {  // Host.restore (Host.py:373-429)
+  EnvState* s = x.s;
+  HostDyn& d = s->hd[h];
+  const HostStatic& st = s->hs[h];
+  for (int i = 0; i < st.nproc; ++i) d.procs[i] = st.procs[i];
+  for (int i = 0; i < st.nsvc; ++i) d.svcs[i] = st.svcs[i];
+  d.nproc = st.nproc; d.nsvc = st.nsvc; d.ev = 0; d.pad = 0;
+  eph_clear(x, h);
+  pend_drop_host(x, h);
+}
+
+// continue_stream = true restates CybORG.reset(seed=None) (env.py:218-243): the same Generator keeps going.
+CC4_HD void env_reset(Ctx x, uint64_t seed, int rng_mode, int steps, bool continue_stream) {
+  EnvState* s = x.s;
+  Rng keep = s->rng;
+  {  // zero everything (POD)
+    uint32_t* w = (uint32_t*)s;
+    for (size_t i = 0; i < sizeof(EnvState) / 4; ++i) w[i] = 0;
+  }
+  if (continue_stream) s->rng = keep; else rng_seed(&s->rng, seed, (uint32_t)rng_mode);
+  s->rng_mode = (uint8_t)rng_mode;
+  rng_begin_episode(&s->rng);  // philox: the reset stream uses its own (step, episode) counter words
+  s->steps = steps;
+  {  // _generate_mission_phases (ESG.py:854-860)
+    int q = steps / 3, rem = steps % 3;
+    s->phase_len[0] = q + (rem >= 1 ? 1 : 0); s->phase_len[1] = q + (rem == 2 ? 1 : 0); s->phase_len[2] = q;
+  }
+  for (int i = 0; i < MAX_KB / 32; ++i) s->kb_used[i] = 0;
+  uint32_t* used = x.c->eph[H_INTERNET];  // scratch bitmap for used_pids (cleared by the backup below)
+  for (int i = 0; i < EPH_WORDS; ++i) used[i] = 0;
+
+  // _generate_subnets (ESG.py:171-266): choice(len(remaining /24 blocks)) per subnet, pop
+  {
+    uint8_t pool[256];
+    for (int i = 0; i < 256; ++i) pool[i] = (uint8_t)i;
+    int n = 256;
+    for (int sn = 0; sn < NSUB; ++sn) {
+      int c = (int)rng_below(&s->rng, (uint32_t)n);
+      s->cidr_octet[sn] = pool[c];
+      for (int j = c; j + 1 < n; ++j) pool[j] = pool[j + 1];
+      n--;
+    }
+  }
+  // _generate_hosts (ESG.py:312-371)
+  for (int sn = 0; sn < NSUB; ++sn) {
+    uint8_t ips[254];
+    for (int i = 0; i < 254; ++i) ips[i] = (uint8_t)(i + 1);
+    int n = 254;
+    auto pop_at = [&](int c) { uint8_t v = ips[c]; for (int j = c; j + 1 < n; ++j) ips[j] = ips[j + 1]; n--; return v; };
+    if (sn == S_INT) {
+      int c = (int)rng_below(&s->rng, (uint32_t)n);
+      s->hs[H_INTERNET].ip_octet = pop_at(c);
+      gen_host(x, H_INTERNET, used);
+      continue;
+    }
+    int hr = h_make(sn, 0);
+    { int c = (int)rng_below(&s->rng, (uint32_t)n); uint8_t ip = pop_at(c); gen_host(x, hr, used); s->hs[hr].ip_octet = ip; }
+    int nu = 3 + (int)rng_below(&s->rng, 8);  // integers(3, 10, endpoint=True)
+    for (int i = 0; i < nu; ++i) {
+      int h = h_make(sn, 1 + i);
+      int c = (int)rng_below(&s->rng, (uint32_t)n); uint8_t ip = pop_at(c);
+      gen_host(x, h, used); s->hs[h].ip_octet = ip;
+    }
+    int ns = 1 + (int)rng_below(&s->rng, 6);  // integers(1, 6, endpoint=True)
+    for (int i = 0; i < ns; ++i) {
+      int h = h_make(sn, 11 + i);
+      uint8_t ip = ips[n - 1]; n--;  // ip_addresses.pop()
+      gen_host(x, h, used); s->hs[h].ip_octet = ip;
+    }
+    s->n_users[sn] = (uint8_t)nu; s->n_servers[sn] = (uint8_t)ns;
+  }
+  // _generate_blue_agents (ESG.py:631-698)
+  for (int b = 0; b < NBLUE; ++b) {
+    int nsub = blue_nsub(b);
+    (void)rng_below(&s->rng, (uint32_t)nsub);  // starting_subnet = choice(allowed_subnets): unused
+    int cnt = 0;
+    for (int i = 0; i < nsub; ++i) { int sn = blue_subnet_alloc(b, i); cnt += 1 + s->n_users[sn] + s->n_servers[sn]; }
+    int c = (int)rng_below(&s->rng, (uint32_t)cnt);  // parent_host = choice(allowed_hosts)
+    int k = 0, ph = -1;
+    for (int i = 0; i < nsub && ph < 0; ++i) {
+      int sn = blue_subnet_alloc(b, i);
+      for (int sl = 0; sl < SLOTS; ++sl) { int h = h_make(sn, sl); if (s->hs[h].exists) { if (k == c) { ph = h; break; } k++; } }
+    }
+    s->blue[b].parent_host = (uint8_t)ph;
+  }
+  // _generate_green_agents (ESG.py:700-749): one per user host, host order
+  {
+    int g = 0;
+    for (int h = 0; h < MAXH; ++h) if (s->hs[h].exists && h_is_user(h)) s->green_host[g++] = (uint8_t)h;
+    s->n_green = (uint8_t)g;
+  }
+  // _generate_red_agents (ESG.py:751-817)
+  for (int r = 0; r < NRED; ++r) {
+    int nsub = red_nsub(r);
+    int sn = red_subnet_alloc(r, (int)rng_below(&s->rng, (uint32_t)nsub));
+    int cnt = s->n_users[sn] + s->n_servers[sn];
+    int c = (int)rng_below(&s->rng, (uint32_t)cnt);  // choice(non-router hosts): users then servers
+    int h = c < s->n_users[sn] ? h_make(sn, 1 + c) : h_make(sn, 11 + (c - s->n_users[sn]));
+    s->red[r].start_host = (uint8_t)h;
+    for (int i = 0; i < MAXH; ++i) s->red[r].fsm_state[i] = FS_NONE;
+    s->red[r].new_sess_host = 0xFF;
+    s->red[r].queue.busy = 0;
+  }
+  // State.__init__ (State.py:103-136): starting sessions in agent order; parent-less first
+  for (int b = 0; b < NBLUE; ++b) {
+    int ph = s->blue[b].parent_host;
+    s->blue_pid[ph] = (uint16_t)start_session_proc(x, ph, K_SESS_BLUE);
+    for (int i = 0; i < blue_nsub(b); ++i) {
+      int sn = blue_subnet_alloc(b, i);
+      for (int sl = 0; sl < SLOTS; ++sl) {
+        int h = h_make(sn, sl);
+        if (!s->hs[h].exists || h == ph) continue;
+        s->blue_pid[h] = (uint16_t)start_session_proc(x, h, K_SESS_BLUE);
+      }
+    }
+  }
+  for (int g = 0; g < s->n_green; ++g) { int h = s->green_host[g]; s->green_pid[h] = (uint16_t)start_session_proc(x, h, K_SESS_GREEN); }
+  int red0_pid = start_session_proc(x, s->red[0].start_host, K_SESS_RED);
+  // host.create_backup() for every host (State.py:137-138) -> dynamic state := static
+  for (int h = 0; h < MAXH; ++h) {
+    if (s->hs[h].exists) host_restore(x, h);
+    else { s->hd[h].nproc = 0; s->hd[h].nsvc = 0; s->hd[h].ev = 0; eph_clear(x, h); }
+  }
+  s->npend = 0;
+  // red_agent_0 starts active with session 0 (ESG.py:791-801)
+  {
+    int idx = rs_add(x, 0, s->red[0].start_host, red0_pid, RS_ABSTRACT | RS_ORIG);
+    (void)idx;
+    s->red[0].active = 1;
+  }
+  // AgentInterface.set_init_obs (Shared/AgentInterface.py:110-117) with the OSINT observation of the start host
+  for (int r = 0; r < NRED; ++r) {
+    RedAgent& a = s->red[r];
+    int h = a.start_host;
+    bit_set(a.as_ip, h); bit_set(a.as_hn, h); a.as_subnet |= (uint16_t)(1u << h_subnet(h));
+    a.nobs = 0; a.obs_success = 0;
+    if (r == 0) {
+      as_know_sid(x, 0, 0);
+      // SimulationController.reset_observation (SC:767-773): first FSM call sees hostname-keyed OSINT obs
+      obs_put(x, 0, false, h, OE_SESS | OE_IFACE | OE_SYSHN, true);
+      obs_first(x, 0, T_UNKNOWN, RA_NONE, 0, 0);
+    }
+    a.exec_type = RA_SLEEP;
+  }
+  s->step_count = 0; s->phase = 0; s->done = (uint8_t)(0 >= steps - 1); s->reward = 0.f;
+}
+
+// ------------------------------------------------------------------ blue actions
+// wrapper index -> action (Agents/Wrappers/BlueFixedActionWrapper.py:233-309)
+CC4_HD Act blue_decode(const EnvState* s, int b, int idx) {
+  Act a; a.type = BA_SLEEP; a.host = 0; a.arg = 0; a.ticks = 1; a.sid = 0; a.busy = 0;
+  int nsub = blue_nsub(b), nh = ZONE_HOSTS * nsub, nc = 8 * nsub;
+  int total = 4 * nh + 2 + 2 * nc;
+  if (idx < 0 || idx >= total) return a;  // padding / "no action submitted" -> Sleep
+  int t, j = 0;
+  if (idx < nh) { t = BA_ANALYSE; j = idx; }
+  else if (idx == nh) { a.type = BA_MONITOR; return a; }
+  else if (idx < 2 * nh + 1) { t = BA_REMOVE; j = idx - nh - 1; }
+  else if (idx < 3 * nh + 1) { t = BA_RESTORE; j = idx - 2 * nh - 1; }
+  else if (idx == 3 * nh + 1) { return a; }
+  else if (idx < 3 * nh + 2 + nc) { t = BA_ALLOW; j = idx - 3 * nh - 2; }
+  else if (idx < 3 * nh + 2 + 2 * nc) { t = BA_BLOCK; j = idx - 3 * nh - 2 - nc; }
+  else { t = BA_DECOY; j = idx - 3 * nh - 2 - 2 * nc; }
+  if (t == BA_ALLOW || t == BA_BLOCK) {
+    int dst = blue_subnet_sorted(b, j / 8), k = j % 8;
+    // the 8 other subnets in alphabetical order
+    int src = -1, c = 0;
+    for (int i = 0; i < NSUB; ++i) { int sn = sorted_subnet(i); if (sn == dst) continue; if (c == k) { src = sn; break; } c++; }
+    a.type = (uint8_t)t; a.host = (uint8_t)dst; a.arg = (uint8_t)src;
+    return a;
+  }
+  int sn = blue_subnet_sorted(b, j / ZONE_HOSTS), hs = j % ZONE_HOSTS;
+  int h = hs < MAX_SERVERS ? h_make(sn, 11 + hs) : h_make(sn, 1 + (hs - MAX_SERVERS));
+  if (!s->hs[h].exists) return a;  // "[Invalid] ..." slot -> Sleep() (BlueFixedActionWrapper.py:295-298)
+  a.type = (uint8_t)t; a.host = (uint8_t)h;
+  return a;
+}
+CC4_HD void blue_action_mask(const EnvState* s, uint8_t* mask /* MASK_TOTAL */) {
+  int o = 0;
+  for (int b = 0; b < NBLUE; ++b) {
+    int n = b == 4 ? ACT_LONG : ACT_SHORT;
+    for (int i = 0; i < n; ++i) {
+      Act a = blue_decode(s, b, i);
+      int nh = ZONE_HOSTS * blue_nsub(b);
+      bool is_sleep_slot = (i == 3 * nh + 1);
+      mask[o++] = (uint8_t)((a.type != BA_SLEEP) || is_sleep_slot);
+    }
+  }
+}
+
+// Monitor.execute (Simulator/Actions/AbstractActions/Monitor.py:35-74)
+CC4_HD void blue_monitor(Ctx x, int b) {
+  EnvState* s = x.s;
+  BlueAgent& A = s->blue[b];
+  for (int i = 0; i < blue_nsub(b); ++i) {
+    int sn = blue_subnet_alloc(b, i);
+    for (int sl = 0; sl < SLOTS; ++sl) {
+      int h = h_make(sn, sl);
+      if (!s->hs[h].exists) continue;
+      uint8_t ev = s->hd[h].ev;
+      uint8_t nev = 0;
+      if (ev & EV_CUR_CONN) nev |= EV_OLD_CONN;
+      if (ev & EV_CUR_PROC) nev |= EV_OLD_PROC;
+      s->hd[h].ev = nev;
+    }
+  }
+  // session.add_sus_pids for process_creation events that carry a pid
+  int n = 0;
+  for (int i = 0; i < s->npend; ++i) {
+    int h = (int)(s->pend[i] >> 16);
+    if (blue_of_subnet(h_subnet(h)) == b) {
+      if (A.nsus >= MAX_SUS) s->err |= E_SUS_OVERFLOW; else A.sus[A.nsus++] = s->pend[i];
+    } else s->pend[n++] = s->pend[i];
+  }
+  s->npend = (uint8_t)n;
+}
+// StopProcess.kill_process (ConcreteActions/StopProcess.py:36-58) after get_process / root check (:23-34)
+CC4_HD void stop_process(Ctx x, int h, int pid) {
+  EnvState* s = x.s;
+  int pi = find_proc(x, h, pid);
+  if (pi < 0) return;
+  Proc p = s->hd[h].procs[pi];
+  if (p.flags & PF_ROOT) return;
+  // state.get_session_from_pid (State.py:420-443): blue, green, then red agents in order
+  int owner = -1, owner_idx = -1;  // owner: 0 blue, 1 green, 2+r red
+  if (s->blue_pid[h] == pid) owner = 0;
+  else if (s->green_pid[h] == pid) owner = 1;
+  else for (int r = 0; r < NRED && owner < 0; ++r)
+    for (int i = 0; i < s->red[r].nsess; ++i)
+      if (s->red[r].sess[i].pid == pid && s->red[r].sess[i].host == h) { owner = 2 + r; owner_idx = i; break; }
+  remove_proc_at(x, h, pi);
+  HostDyn& d = s->hd[h];
+  int si = -1;
+  for (int i = 0; i < d.nsvc; ++i) if (d.svcs[i].pid == pid) { si = i; break; }
+  if (si >= 0) {  // service process respawns under a new pid
+    int np = create_pid(x, h);
+    add_proc(x, h, np, p.kind, p.flags);
+    d.svcs[si].pid = (uint16_t)np;
+  }
+  if (owner < 0) return;
+  if (owner < 2) { s->err |= E_BLUE_GREEN_SESSION_KILLED; return; }
+  rs_remove_at(x, owner - 2, owner_idx, true);
+  if (si >= 0) s->err |= E_UNREACHABLE;  // session re-created on a service process: never happens in CC4
+}
+// Remove.execute (AbstractActions/Remove.py:42-71)
+CC4_HD void blue_remove(Ctx x, int b, int h) {
+  BlueAgent& A = x.s->blue[b];
+  for (int i = 0; i < A.nsus; ++i)
+    if ((int)(A.sus[i] >> 16) == h) stop_process(x, h, (int)(A.sus[i] & 0xFFFF));
+}
+// Restore.execute -> RestoreFromBackup (AbstractActions/Restore.py:38-71, ConcreteActions/RestoreFromBackup.py:9-19)
+CC4_HD void blue_restore(Ctx x, int h) {
+  EnvState* s = x.s;
+  for (int r = 0; r < NRED; ++r) {
+    RedAgent& a = s->red[r];
+    int orig = -1;
+    for (int i = 0; i < a.nsess;) {
+      if (a.sess[i].host != h) { ++i; continue; }
+      if (a.sess[i].flags & RS_ORIG) { orig = i; ++i; continue; }
+      rs_remove_at(x, r, i, true);
+      if (orig > i) orig--;
+    }
+    if (orig >= 0) {  // original session: popped and re-added => moves to the end of the agent's dict
+      RSess keep = a.sess[orig];
+      rs_remove_at(x, r, orig, false);
+      a.sess[a.nsess++] = keep;
+    }
+  }
+  host_restore(x, h);
+}
+// DecoyAction.execute (ConcreteActions/DecoyActions/DecoyAction.py:47-114) with DeployDecoy candidates (DeployDecoy.py:8-31)
+CC4_HD void blue_decoy(Ctx x, int h) {
+  EnvState* s = x.s;
+  int cand[4]; int n = 0;
+  if (!host_uses_port(x, h, PB_80)) cand[n++] = K_DEC_APACHE;
+  if (!host_uses_port(x, h, PB_443)) cand[n++] = K_DEC_TOMCAT;
+  if (!host_uses_port(x, h, PB_25)) cand[n++] = K_DEC_HARAKA;
+  cand[n++] = K_DEC_VSFTPD;  // compatibility checks port 21, which nothing uses (DecoyVsftpd.py:17-20)
+  int kind = cand[rng_below(&s->rng, (uint32_t)n)];
+  int pid = create_pid(x, h);
+  if (!add_proc(x, h, pid, kind, 0)) return;
+  HostDyn& d = s->hd[h];
+  int si = -1;
+  for (int i = 0; i < d.nsvc; ++i) if (d.svcs[i].kind == kind) { si = i; break; }
+  if (si < 0) si = d.nsvc++;
+  d.svcs[si].kind = (uint8_t)kind; d.svcs[si].pid = (uint16_t)pid; d.svcs[si].st = (uint8_t)(SV_ACTIVE | 5);
+}
+CC4_HD void blue_execute(Ctx x, int b, const Act& a) {
+  EnvState* s = x.s;
+  switch (a.type) {
+    case BA_MONITOR: blue_monitor(x, b); break;
+    case BA_ANALYSE: break;  // DensityScout/SigCheck only fill the dict observation (Analyse.py:40-71)
+    case BA_REMOVE: blue_remove(x, b, a.host); break;
+    case BA_RESTORE: blue_restore(x, a.host); break;
+    case BA_DECOY: blue_decoy(x, a.host); break;
+    case BA_BLOCK: s->blocks[a.host] |= (uint16_t)(1u << a.arg); break;   // ControlTraffic.py:88-116
+    case BA_ALLOW: s->blocks[a.host] &= (uint16_t)~(1u << a.arg); break;  // ControlTraffic.py:160-185
+    default: break;
+  }
+}
+
+// ------------------------------------------------------------------ green actions
+// PhishingEmail._create_new_session (ConcreteActions/PhishingEmail.py:42-113)
+CC4_HD void phishing(Ctx x, int gh) {
+  EnvState* s = x.s;
+  for (int r = 0; r < NRED; ++r) if (red_has_session_on(s->red[r], gh)) return;
+  int src = -1;
+  uint8_t cand[NRED * MAX_RS]; int nc = 0;
+  int gsub = h_subnet(gh);
+  for (int h = 0; h < MAXH; ++h) {
+    if (!s->hs[h].exists) continue;
+    for (int r = 0; r < NRED; ++r) {
+      if (!red_has_session_on(s->red[r], h)) continue;
+      if (h_subnet(h) == gsub) { src = r; break; }
+      if (nc < NRED * MAX_RS) cand[nc++] = (uint8_t)r;
+    }
+  }
+  if (src < 0) {
+    if (nc == 0) return;
+    src = cand[rng_below(&s->rng, (uint32_t)nc)];  // choice(red_agents, replace=False): one bounded draw
+  }
+  int pid = create_pid(x, gh);
+  if (!add_proc(x, gh, pid, K_SESS_RED, 0)) return;
+  rs_add(x, src, gh, pid, RS_ABSTRACT);
+}
+// GreenLocalWork.execute (GreenActions/GreenLocalWork.py:60-125). returns success
+CC4_HD bool green_local_work(Ctx x, int gh) {
+  EnvState* s = x.s;
+  HostDyn& d = s->hd[gh];
+  int act[MAXSV]; int n = 0;
+  for (int i = 0; i < d.nsvc; ++i) if (d.svcs[i].st & SV_ACTIVE) act[n++] = i;
+  if (n == 0) return false;
+  int c = act[rng_below(&s->rng, (uint32_t)n)];
+  int rel = (d.svcs[c].st & 0x7F) * 20;
+  if ((int)rng_below(&s->rng, 100) >= rel) return false;
+  if (rng_random(&s->rng) < 0.01) { (void)eph_port(x, gh); ev_proc(x, gh, 0); }
+  if (rng_random(&s->rng) < 0.01) phishing(x, gh);
+  return true;
+}
+// GreenAccessService.execute (GreenActions/GreenAccessService.py:137-217). returns success
+CC4_HD bool green_access_service(Ctx x, int gh) {
+  EnvState* s = x.s;
+  int own = h_subnet(gh);
+  uint32_t allowed = green_allowed_mask(s->phase, own);
+  int n = 0;
+  for (int sn = 0; sn < NSUB - 1; ++sn) if ((allowed >> sn) & 1u) n += s->n_servers[sn];
+  int c = (int)rng_below(&s->rng, (uint32_t)n);
+  int dest = -1;
+  for (int sn = 0; sn < NSUB - 1 && dest < 0; ++sn) {
+    if (!((allowed >> sn) & 1u)) continue;
+    if (c < s->n_servers[sn]) dest = h_make(sn, 11 + c); else c -= s->n_servers[sn];
+  }
+  (void)eph_port(x, dest);
+  int ds = h_subnet(dest);
+  if (subnet_blocked(x, ds, own) || subnet_blocked(x, own, ds)) { ev_conn(x, dest); return false; }
+  if (rng_random(&s->rng) < 0.01) ev_conn(x, dest);
+  return true;
+}
+
+// ------------------------------------------------------------------ red actions
+CC4_HD void red_result(Ctx x, int r, const Act& a, int success) {
+  int arg = a.type == RA_DRS ? a.arg : 0;
+  obs_first(x, r, success, a.type, a.host, arg);
+}
+// DiscoverRemoteSystems -> Pingsweep.execute (ConcreteActions/Pingsweep.py:31-64)
+CC4_HD void red_drs(Ctx x, int r, const Act& a) {
+  EnvState* s = x.s;
+  int sn = a.arg; bool any = false;
+  bool allowed = (red_allowed_mask(r) >> sn) & 1u;  // SimulationController._filter_obs drops foreign-subnet interfaces
+  for (int sl = 1; sl < SLOTS; ++sl) {
+    int h = h_make(sn, sl);
+    if (!s->hs[h].exists) continue;
+    any = true;
+    if (allowed) obs_put(x, r, true, h, OE_IFACE, true);
+  }
+  red_result(x, r, a, any ? T_TRUE : T_UNKNOWN);
+}
+// DiscoverNetworkServices.execute + Portscan.execute (AbstractActions/DiscoverNetworkServices.py:44-86, Portscan.py:23-65)
+CC4_HD void red_scan(Ctx x, int r, const Act& a, double rate) {
+  EnvState* s = x.s;
+  RedAgent& A = s->red[r];
+  int si = rs_find_id(A, a.sid);
+  if (si < 0 || !(A.sess[si].flags & RS_ABSTRACT)) { red_result(x, r, a, T_FALSE); return; }
+  int src = A.sess[si].host, tgt = a.host;
+  if (subnet_blocked(x, h_subnet(src), h_subnet(tgt))) { red_result(x, r, a, T_FALSE); return; }
+  double fixed = rng_random(&s->rng);
+  int ports = 0;
+  int np = s->hd[tgt].nproc;
+  for (int i = 0; i < np; ++i) {
+    int k = s->hd[tgt].procs[i].kind;
+    int pb = kind_port(k);
+    if (!pb) continue;
+    ports |= pb;
+    if (fixed <= rate || kind_is_decoy(k)) { ev_conn(x, tgt); (void)eph_port(x, tgt); }
+  }
+  if (ports) {
+    obs_put(x, r, true, tgt, OE_IFACE, false);
+    if (A.sess[si].kb != 0xFF) x.c->kports[A.sess[si].kb][tgt] = (uint8_t)(PB_HAS | ports);
+  }
+  red_result(x, r, a, T_TRUE);
+}
+// ExploitAction._create_new_session (ExploitActions/ExploitAction.py:212-262): returns new session index or -1
+CC4_HD int exploit_new_session(Ctx x, int r, int parent_sid, int tgt) {
+  (void)parent_sid;
+  int pid = create_pid(x, tgt);
+  if (!add_proc(x, tgt, pid, K_SHELL, 0)) return -1;
+  return rs_add(x, r, tgt, pid, 0);
+}
+// ExploitRemoteService.execute (AbstractActions/ExploitRemoteService.py:149-202) + selector (:37-69)
+CC4_HD void red_exploit(Ctx x, int r, const Act& a) {
+  EnvState* s = x.s;
+  RedAgent& A = s->red[r];
+  int si = rs_find_id(A, a.sid);
+  if (si < 0 || !(A.sess[si].flags & RS_ABSTRACT) || A.sess[si].kb == 0xFF) { red_result(x, r, a, T_FALSE); return; }
+  int src = A.sess[si].host, tgt = a.host;
+  int known = x.c->kports[A.sess[si].kb][tgt];
+  if (!(known & PB_HAS)) { red_result(x, r, a, T_FALSE); return; }
+  if (subnet_blocked(x, h_subnet(src), h_subnet(tgt))) { red_result(x, r, a, T_FALSE); return; }
+  // DefaultExploitActionSelector: options in list order with non-zero weight
+  enum { X_HTTPRFI = 0, X_HTTPSRFI = 1, X_SSH = 2, X_SQLI = 3, X_HARAKA = 4 };
+  int opt[5]; int w10[5]; int n = 0;
+  if (known & PB_80) { opt[n] = X_HTTPRFI; w10[n++] = 30; }
+  if (known & PB_443) { opt[n] = X_HTTPSRFI; w10[n++] = 40; }
+  if (known & PB_22) { opt[n] = X_SSH; w10[n++] = 1; }
+  if ((known & PB_3390) && (known & (PB_80 | PB_443))) { opt[n] = X_SQLI; w10[n++] = 50; }
+  if (known & PB_25) { opt[n] = X_HARAKA; w10[n++] = 60; }
+  if (n == 0) { red_result(x, r, a, T_FALSE); return; }
+  int sel = opt[0];
+  if (n > 1) {
+    int top = 0;
+    for (int i = 1; i < n; ++i) if (w10[i] > w10[top]) top = i;
+    for (int i = top; i + 1 < n; ++i) { opt[i] = opt[i + 1]; w10[i] = w10[i + 1]; }
+    n--;
+    sel = opt[rng_below(&s->rng, (uint32_t)n)];
+    (void)rng_random(&s->rng);  // `elif random() < odds_of_top_choice` with odds 0
+  }
+  HostDyn& T = s->hd[tgt];
+  if (sel == X_SSH) {
+    // SSHBruteForce.execute (ExploitActions/SSHBruteForce.py:24-84)
+    uint8_t hops[12]; int nh = route(src, tgt, hops);
+    for (int i = 0; i < nh; ++i) if (0.050000000000000044 < rng_random(&s->rng)) ev_conn(x, hops[i]);  // 1 - 0.95 in float64
+    int vp = -1;
+    for (int i = 0; i < T.nproc; ++i) if (T.procs[i].kind == K_SSHD) { vp = i; break; }
+    if (vp < 0) { red_result(x, r, a, T_FALSE); return; }
+    obs_put(x, r, true, tgt, OE_IFACE, false);   // obs.add_process(target_process) -> interface of the target
+    (void)eph_port(x, tgt);                       // local_port
+    ev_conn(x, tgt);                              // _create_brute_force_event: 10 connection events
+    int ni = exploit_new_session(x, r, a.sid, tgt);
+    if (ni < 0) { red_result(x, r, a, T_FALSE); return; }
+    ev_proc(x, tgt, A.sess[ni].pid);              // _create_new_session_event (always for SSH)
+    obs_put(x, r, true, tgt, OE_SESS | OE_IFACE | OE_SYSHN, false);
+    obs_put(x, r, true, src, OE_IFACE, false);
+    A.new_sess_host = (uint8_t)tgt; A.new_sess_id = A.sess[ni].id;
+    red_result(x, r, a, T_TRUE);
+    return;
+  }
+  // ExploitAction.sim_exploit (ExploitActions/ExploitAction.py:48-116)
+  int vp = -1;
+  for (int i = 0; i < T.nproc && vp < 0; ++i) {
+    int k = T.procs[i].kind;
+    bool m = false;
+    if (sel == X_HTTPRFI) m = (k == K_APACHE || k == K_DEC_APACHE || k == K_DEC_VSFTPD);   // WEBSERVER @80
+    else if (sel == X_HTTPSRFI) m = (k == K_DEC_TOMCAT);                                     // WEBSERVER @443
+    else if (sel == X_SQLI) m = (k == K_MYSQL);                                              // MYSQL @3390
+    else if (sel == X_HARAKA) m = (k == K_SMTP || k == K_DEC_HARAKA);                        // SMTP @25
+    if (m) vp = i;
+  }
+  if (vp < 0) { red_result(x, r, a, T_FALSE); return; }
+  int vk = T.procs[vp].kind;
+  bool decoy = kind_is_decoy(vk);
+  if (decoy) { ev_conn(x, tgt); (void)eph_port(x, tgt); }  // _get_vulnerable_process alert (ExploitAction.py:189-196)
+  obs_put(x, r, true, tgt, OE_IFACE, false);
+  bool works = (sel == X_SQLI) || decoy;  // rfi only on decoys; real Haraka is 2.8.9 (HarakaRCE.py:19, HTTPRFI.py:18)
+  if (!works) { red_result(x, r, a, T_FALSE); return; }
+  if (0.0 >= rng_random(&s->rng)) { red_result(x, r, a, T_FALSE); return; }  // (1 - success_rate) >= random()
+  (void)eph_port(x, tgt);  // local_port
+  if (decoy) { ev_conn(x, tgt); (void)eph_port(x, tgt); red_result(x, r, a, T_FALSE); return; }
+  int ni = exploit_new_session(x, r, a.sid, tgt);
+  if (ni < 0) { red_result(x, r, a, T_FALSE); return; }
+  if (rng_random(&s->rng) > 0.050000000000000044) ev_proc(x, tgt, A.sess[ni].pid);
+  obs_put(x, r, true, tgt, OE_SESS | OE_IFACE | OE_SYSHN, false);
+  obs_put(x, r, true, src, OE_IFACE, false);
+  A.new_sess_host = (uint8_t)tgt; A.new_sess_id = A.sess[ni].id;
+  red_result(x, r, a, T_TRUE);
+}
+// PrivilegeEscalate.execute (AbstractActions/PrivilegeEscalate.py:127-179)
+CC4_HD void red_privesc(Ctx x, int r, const Act& a) {
+  EnvState* s = x.s;
+  RedAgent& A = s->red[r];
+  int h = a.host;
+  int on[MAX_RS]; int n = 0;
+  for (int i = 0; i < A.nsess; ++i) if (A.sess[i].host == h) on[n++] = i;
+  if (n == 0) { red_result(x, r, a, T_FALSE); return; }
+  int target = -1;
+  for (int i = 0; i < n; ++i) if (A.sess[on[i]].flags & RS_ROOT) { target = on[i]; break; }
+  if (target < 0) {
+    target = on[rng_below(&s->rng, (uint32_t)n)];
+    // DefaultEscalateActionSelector (PrivilegeEscalate.py:52-66): self.session must exist and be a RedAbstractSession,
+    // else no sub-action -> Observation(False); then V4L2KernelExploit via TargetedLocalAction.execute
+    { int ss = rs_find_id(A, a.sid);
+      if (ss < 0 || !(A.sess[ss].flags & RS_ABSTRACT)) { red_result(x, r, a, T_FALSE); return; } }
+    A.sess[target].flags |= RS_ROOT;  // EscalateAction.__upgrade_session (EscalateAction.py:57-87)
+    int pi = find_proc(x, h, A.sess[target].pid);
+    if (pi >= 0) s->hd[h].procs[pi].flags |= PF_ROOT;
+  }
+  obs_put(x, r, false, h, OE_SESS, false);
+  if (A.sess[target].flags & RS_ABSTRACT) as_know_sid(x, r, A.sess[target].id);
+  // ExploreHost (EscalateAction.py:90-106): host.info links exist only on server_host_0 (ESG.py:418-468)
+  if (rs_find_id(A, a.sid) >= 0 && h_slot(h) == 11) {
+    uint32_t m = info_links(h_subnet(h));
+    for (int sn = 0; sn < NSUB; ++sn) if ((m >> sn) & 1u) obs_put(x, r, false, h_make(sn, 11), OE_IFACE, false);
+  }
+  red_result(x, r, a, T_TRUE);
+}
+// Impact.execute (AbstractActions/Impact.py:38-88)
+CC4_HD void red_impact(Ctx x, int r, const Act& a) {
+  EnvState* s = x.s;
+  RedAgent& A = s->red[r];
+  int h = a.host; bool any = false, root = false;
+  for (int i = 0; i < A.nsess; ++i) if (A.sess[i].host == h) { any = true; if (A.sess[i].flags & RS_ROOT) root = true; }
+  if (!any || !root) { red_result(x, r, a, T_FALSE); return; }
+  HostDyn& d = s->hd[h];
+  int si = -1;
+  for (int i = 0; i < d.nsvc; ++i) if (d.svcs[i].kind == K_OT && (d.svcs[i].st & SV_ACTIVE)) { si = i; break; }
+  if (si < 0) { red_result(x, r, a, T_FALSE); return; }
+  if (rs_find_id(A, a.sid) < 0) { red_result(x, r, a, T_FALSE); return; }  // StopService needs self.session too
+  d.svcs[si].st &= (uint8_t)~SV_ACTIVE;                      // Host.stop_service (Host.py:295-300)
+  int pi = find_proc(x, h, d.svcs[si].pid);                   // State.remove_process (State.py:390-418)
+  if (pi >= 0) remove_proc_at(x, h, pi);
+  obs_put(x, r, false, h, 0, false);
+  red_result(x, r, a, T_TRUE);
+}
+// DegradeServices.execute (AbstractActions/DegradeServices.py:38-82)
+CC4_HD void red_degrade(Ctx x, int r, const Act& a) {
+  EnvState* s = x.s;
+  RedAgent& A = s->red[r];
+  int h = a.host; bool any = false, root = false;
+  for (int i = 0; i < A.nsess; ++i) if (A.sess[i].host == h) { any = true; if (A.sess[i].flags & RS_ROOT) root = true; }
+  if (!any || !root) { red_result(x, r, a, T_FALSE); return; }
+  HostDyn& d = s->hd[h];
+  int n = 0;
+  for (int i = 0; i < d.nsvc; ++i) if (d.svcs[i].st & SV_ACTIVE) {
+    n++;
+    int rel = d.svcs[i].st & 0x7F;
+    if (rel > 0) rel--;                                       // Service.degrade_service_reliability (Service.py:33-40)
+    d.svcs[i].st = (uint8_t)(SV_ACTIVE | rel);
+  }
+  if (n == 0) { red_result(x, r, a, T_FALSE); return; }
+  obs_put(x, r, false, h, 0, false);
+  red_result(x, r, a, T_TRUE);
+}
+// DiscoverDeception.execute (AbstractActions/DiscoverDeception.py:44-101)
+CC4_HD void red_deception(Ctx x, int r, const Act& a) {
+  EnvState* s = x.s;
+  RedAgent& A = s->red[r];
+  if (rs_find_id(A, a.sid) < 0) { red_result(x, r, a, T_FALSE); return; }
+  int tgt = a.host;
+  const HostDyn& d = s->hd[tgt];
+  for (int i = 0; i < d.nproc; ++i) {
+    bool decoy = kind_is_decoy(d.procs[i].kind);
+    bool rep = false;
+    if (rng_random(&s->rng) <= 0.5 && decoy) rep = true;
+    else if (rng_random(&s->rng) <= 0.1 && !decoy) rep = true;
+    if (rep) obs_put(x, r, false, tgt, OE_IFACE, false);
+  }
+  red_result(x, r, a, T_TRUE);
+}
+// RedSessionCheck.execute (ConcreteActions/RedSessionCheck.py:9-65)
+CC4_HD void red_session_check(Ctx x, int r) {
+  EnvState* s = x.s;
+  RedAgent& A = s->red[r];
+  obs_first(x, r, T_TRUE, RA_NONE, 0, 0);
+  if (A.nsess == 0) return;
+  if (rs_find_id(A, 0) < 0) {
+    int c = (int)rng_below(&s->rng, (uint32_t)A.nsess);
+    RSess q = A.sess[c];
+    rs_remove_at(x, r, c, false);
+    q.id = 0;
+    A.sess[A.nsess++] = q;
+  }
+  for (int i = 0; i < A.nsess; ++i) {
+    obs_put(x, r, false, A.sess[i].host, OE_SESS | OE_IFACE | OE_SYSHN, true);
+    if (A.sess[i].flags & RS_ABSTRACT) as_know_sid(x, r, A.sess[i].id);
+  }
+}
+CC4_HD void red_execute(Ctx x, int r, const Act& a) {
+  switch (a.type) {
+    case RA_DRS: red_drs(x, r, a); break;
+    case RA_AGGR: red_scan(x, r, a, 0.75); break;
+    case RA_STEALTH: red_scan(x, r, a, 0.25); break;
+    case RA_DECEPTION: red_deception(x, r, a); break;
+    case RA_EXPLOIT: red_exploit(x, r, a); break;
+    case RA_PRIVESC: red_privesc(x, r, a); break;
+    case RA_IMPACT: red_impact(x, r, a); break;
+    case RA_DEGRADE: red_degrade(x, r, a); break;
+    case RA_INVALID: obs_first(x, r, T_FALSE, RA_NONE, 0, 0); break;
+    case RA_WITHDRAW: x.s->err |= E_UNREACHABLE; obs_first(x, r, T_FALSE, RA_NONE, 0, 0); break;
+    default: obs_first(x, r, T_UNKNOWN, RA_NONE, 0, 0); break;  // Sleep -> Observation()
+  }
+}
+
+// ------------------------------------------------------------------ FiniteStateRedAgent (Agents/SimpleAgents/FiniteStateRedAgent.py)
+CC4_HD int fsm_next(int cur, int act, bool success) {
+  // state_transitions_success / _failure (:441-452, :481-492); 0xFF = None (keep)
+  const uint8_t N = 0xFF;
+  const uint8_t succ[9][9] = {
+      {FS_KD, FS_S, FS_S, N, N, N, N, N, N},   {FS_KD, FS_SD, FS_SD, N, N, N, N, N, N},
+      {FS_SD, N, N, FS_S, FS_U, N, N, N, N},   {FS_SD, N, N, FS_SD, FS_UD, N, N, N, N},
+      {FS_UD, N, N, N, N, FS_R, N, N, FS_S},   {FS_UD, N, N, N, N, FS_RD, N, N, FS_SD},
+      {FS_RD, N, N, N, N, N, FS_R, FS_R, FS_S}, {FS_RD, N, N, N, N, N, FS_RD, FS_RD, FS_SD},
+      {FS_F, N, N, N, N, N, N, N, N}};
+  const uint8_t fail[9][9] = {
+      {FS_K, FS_K, FS_K, N, N, N, N, N, N},    {FS_KD, FS_KD, FS_KD, N, N, N, N, N, N},
+      {FS_S, N, N, FS_S, FS_S, N, N, N, N},    {FS_SD, N, N, FS_SD, FS_SD, N, N, N, N},
+      {FS_U, N, N, N, N, FS_U, N, N, FS_U},    {FS_UD, N, N, N, N, FS_UD, N, N, FS_UD},
+      {FS_R, N, N, N, N, N, FS_R, FS_R, FS_R}, {FS_RD, N, N, N, N, N, FS_RD, FS_RD, FS_RD},
+      {FS_F, N, N, N, N, N, N, N, N}};
+  return success ? succ[cur][act] : fail[cur][act];
+}
+CC4_HD void fsm_apply(Ctx x, int r, int h, int act, bool success) {  // _host_state_transition inner loop (:147-167)
+  RedAgent& A = x.s->red[r];
+  int cur = A.fsm_state[h];
+  if (cur == FS_NONE) return;
+  int nx = fsm_next(cur, act, success);
+  if (nx == FS_U) nx = ((red_allowed_mask(r) >> h_subnet(h)) & 1u) ? FS_U : FS_F;
+  if (nx == 0xFF) nx = cur;
+  A.fsm_state[h] = (uint8_t)nx;
+}
+CC4_HD void fsm_observe(Ctx x, int r) {
+  RedAgent& A = x.s->red[r];
+  // 1. _host_state_transition (:124-167)
+  if (A.obs_act_type <= RA_WITHDRAW && A.obs_success != T_IN_PROGRESS && A.obs_success != 0) {
+    bool ok = A.obs_success == T_TRUE;
+    int t = A.obs_act_type;
+    if (t == RA_DRS) {
+      for (int i = 0; i < A.fsm_n; ++i) { int h = A.fsm_order[i]; if (h_subnet(h) == A.obs_act_arg) fsm_apply(x, r, h, t, ok); }
+    } else if (t == RA_PRIVESC || t == RA_IMPACT || t == RA_DEGRADE) {
+      int h = A.obs_act_host;  // matched through host_states[ip]['hostname']
+      if (A.fsm_state[h] != FS_NONE && bit_get(A.fsm_hn, h)) fsm_apply(x, r, h, t, ok);
+    } else {
+      fsm_apply(x, r, A.obs_act_host, t, ok);
+    }
+  }
+  // 2. _process_new_observations (:190-250)
+  for (int i = 0; i < A.nobs; ++i) {
+    int h = A.obs[i].host; int f = A.obs[i].flags;
+    bool hn = !(f & OE_KEY_IP) || (f & OE_SYSHN);
+    bool ip = (f & OE_KEY_IP) || (f & OE_IFACE);
+    if (!ip) {
+      // ip looked up through a known hostname; unknown -> reference would key host_states[None]
+      if (!(A.fsm_state[h] != FS_NONE && bit_get(A.fsm_hn, h))) { x.s->err |= E_UNREACHABLE; }
+      continue;
+    }
+    if (A.fsm_state[h] == FS_NONE) {
+      A.fsm_state[h] = (uint8_t)(A.fsm_step == 0 ? FS_U : FS_K);
+      A.fsm_order[A.fsm_n++] = (uint8_t)h;
+    }
+    if (hn) bit_set(A.fsm_hn, h);
+  }
+  // 3. _session_removal_state_change (:169-188)
+  for (int i = 0; i < A.fsm_n; ++i) {
+    int h = A.fsm_order[i]; int st = A.fsm_state[h];
+    if (st != FS_U && st != FS_UD && st != FS_R && st != FS_RD) continue;
+    bool seen = false;
+    for (int j = 0; j < A.nobs; ++j) if (A.obs[j].host == h && (A.obs[j].flags & OE_SESS)) { seen = true; break; }
+    if (!seen) A.fsm_state[h] = FS_KD;
+  }
+}
+// get_action (:58-122) incl. _choose_host (:252-293) and _choose_host_and_action (:296-336)
+CC4_HD Act fsm_get_action(Ctx x, int r) {
+  EnvState* s = x.s;
+  RedAgent& A = s->red[r];
+  Act out; out.type = RA_SLEEP; out.host = 0; out.arg = 0; out.ticks = 1; out.sid = 0; out.busy = 0;
+  fsm_observe(x, r);
+  if (A.obs_success == T_IN_PROGRESS) { A.fsm_step++; return out; }
+  int n = 0;
+  for (int i = 0; i < A.fsm_n; ++i) if (A.fsm_state[A.fsm_order[i]] != FS_F) n++;
+  if (n == 0) { s->err |= E_FSM_NO_HOST; A.fsm_step++; return out; }
+  int c = (int)rng_below(&s->rng, (uint32_t)n);
+  int host = -1;
+  for (int i = 0; i < A.fsm_n; ++i) { int h = A.fsm_order[i]; if (A.fsm_state[h] == FS_F) continue; if (c-- == 0) { host = h; break; } }
+  // options in red_actions list order (ESG.py:764-768) with state_transitions_probability (:540-549)
+  uint8_t acts[4]; double cdf[4]; int no = 0;
+  switch (A.fsm_state[host]) {
+    case FS_K:  acts[0] = RA_DRS; acts[1] = RA_AGGR; acts[2] = RA_STEALTH; cdf[0] = .5; cdf[1] = .75; cdf[2] = 1.; no = 3; break;
+    case FS_KD: acts[0] = RA_AGGR; acts[1] = RA_STEALTH; cdf[0] = .5; cdf[1] = 1.; no = 2; break;
+    case FS_S:  acts[0] = RA_DRS; acts[1] = RA_EXPLOIT; acts[2] = RA_DECEPTION; cdf[0] = .25; cdf[1] = .75; cdf[2] = 1.; no = 3; break;
+    case FS_SD: acts[0] = RA_EXPLOIT; acts[1] = RA_DECEPTION; cdf[0] = .75; cdf[1] = 1.; no = 2; break;
+    case FS_U:  acts[0] = RA_DRS; acts[1] = RA_PRIVESC; acts[2] = RA_WITHDRAW; cdf[0] = .5; cdf[1] = 1.; cdf[2] = 1.; no = 3; break;
+    case FS_UD: acts[0] = RA_PRIVESC; acts[1] = RA_WITHDRAW; cdf[0] = 1.; cdf[1] = 1.; no = 2; break;
+    case FS_R:  acts[0] = RA_DRS; acts[1] = RA_DEGRADE; acts[2] = RA_IMPACT; acts[3] = RA_WITHDRAW; cdf[0] = .5; cdf[1] = .75; cdf[2] = 1.; cdf[3] = 1.; no = 4; break;
+    default:    acts[0] = RA_DEGRADE; acts[1] = RA_IMPACT; acts[2] = RA_WITHDRAW; cdf[0] = .5; cdf[1] = 1.; cdf[2] = 1.; no = 3; break;  // RD
+  }
+  double u = rng_random(&s->rng);
+  int k = 0;
+  while (k < no && cdf[k] <= u) k++;  // cdf.searchsorted(u, side='right')
+  if (k >= no) k = no - 1;
+  int t = acts[k];
+  out.type = (uint8_t)t; out.host = (uint8_t)host;
+  // parameters in constructor-signature order; only `subnet` and `session` can draw
+  bool bad = false;
+  if (t == RA_DRS) {
+    int ns = 0; int subs[NSUB];
+    for (int sn = 0; sn < NSUB; ++sn) if ((A.as_subnet >> sn) & 1u) subs[ns++] = sn;
+    if (ns == 0) bad = true; else out.arg = (uint8_t)subs[rng_below(&s->rng, (uint32_t)ns)];
+  }
+  if ((t == RA_PRIVESC || t == RA_IMPACT || t == RA_DEGRADE) && !bit_get(A.fsm_hn, host)) bad = true;
+  if (!bad) {
+    if (A.nknown == 0) bad = true; else out.sid = A.known_sid[rng_below(&s->rng, (uint32_t)A.nknown)];
+  }
+  if (bad) { s->err |= E_UNREACHABLE; out.type = RA_SLEEP; }  // reference would re-draw with p not summing to 1 and raise
+  out.ticks = (uint8_t)red_duration(out.type);
+  A.fsm_step++;
+  return out;
+}
+// SimulationController.replace_action_if_invalid (SC:1068-1112) for a red action
+CC4_HD void red_validate(Ctx x, int r, Act& a) {
+  RedAgent& A = x.s->red[r];
+  if (a.type >= RA_SLEEP) return;
+  bool ok = true;
+  bool known_sid = false;
+  for (int i = 0; i < A.nknown; ++i) if (A.known_sid[i] == a.sid) known_sid = true;
+  if (!known_sid) ok = false;
+  if (a.type == RA_DRS) { if (!((A.as_subnet >> a.arg) & 1u)) ok = false; }
+  else if (a.type == RA_PRIVESC || a.type == RA_IMPACT || a.type == RA_DEGRADE) { if (!bit_get(A.as_hn, a.host)) ok = false; }
+  else { if (!bit_get(A.as_ip, a.host)) ok = false; }
+  if (!ok) { a.type = RA_INVALID; a.ticks = 1; }
+}
+
+// ------------------------------------------------------------------ different_subnet_agent_reassignment (SC:820-903)
+CC4_HD void red_reassign(Ctx x) {
+  EnvState* s = x.s;
+  struct Mv { uint8_t from, to, host; uint16_t id; };
+  Mv mv[32]; int nm = 0;
+  for (int r = 0; r < NRED; ++r) {
+    const RedAgent& A = s->red[r];
+    for (int i = 0; i < A.nsess; ++i) {
+      int sn = h_subnet(A.sess[i].host);
+      if ((red_allowed_mask(r) >> sn) & 1u) continue;
+      int to = red_of_subnet(sn);
+      if (to < 0) { s->err |= E_UNREACHABLE; continue; }
+      if (nm < 32) { mv[nm].from = (uint8_t)r; mv[nm].to = (uint8_t)to; mv[nm].host = A.sess[i].host; mv[nm].id = A.sess[i].id; nm++; }
+      else s->err |= E_RSESS_OVERFLOW;
+    }
+  }
+  for (int m = 0; m < nm; ++m) {
+    RedAgent& F = s->red[mv[m].from];
+    int i = rs_find_id(F, mv[m].id);
+    if (i < 0) continue;
+    RSess old = F.sess[i];
+    rs_remove_at(x, mv[m].from, i, true);
+    int ni = rs_add(x, mv[m].to, old.host, old.pid, RS_ABSTRACT | (old.flags & RS_ROOT));
+    if (ni < 0) continue;
+    // observation hand-over: only if the creating action's observation carries the host ip key with this session
+    if (F.new_sess_host == old.host && F.new_sess_id == old.id) {
+      obs_first(x, mv[m].to, T_UNKNOWN, RA_NONE, 0, 0);
+      obs_put(x, mv[m].to, true, old.host, OE_SESS | OE_IFACE | OE_SYSHN, false);
+      as_know_sid(x, mv[m].to, s->red[mv[m].to].sess[ni].id);
+    }
+  }
+  for (int r = 0; r < NRED; ++r) s->red[r].active = (uint8_t)(s->red[r].nsess > 0);
+}
+
+// ------------------------------------------------------------------ the step (SimulationController.step, SC:211-315)
+// actions[5]: wrapper action index per blue agent (negative = no action submitted -> SleepAgent)
+CC4_HD void env_step(Ctx x, const int32_t* actions, const uint8_t* messages /* [5][8] or null */) {
+  EnvState* s = x.s;
+  // State.check_next_phase_on_update_step (State.py:514-544)
+  {
+    int st = s->step_count, ph = -1, mn = 0, mx = 0;
+    for (int p = 0; p < 3; ++p) { mn = mx; mx = mn + s->phase_len[p]; if (st >= mn && st < mx) { ph = p; break; } }
+    if (ph < 0) { s->err |= E_STEP_PAST_END; return; }
+    if (ph > s->phase) s->phase = ph;
+  }
+  rng_begin_step(&s->rng, (uint32_t)s->step_count);
+  float action_cost = 0.f;
+  // ---- loop A: policies, validity, queue (SC:236-248)
+  for (int b = 0; b < NBLUE; ++b) {
+    Act a = blue_decode(s, b, actions ? actions[b] : -1);
+    if (a.type == BA_RESTORE) action_cost -= 1.f;  // Restore.cost, charged on submission (SC:310)
+    a.ticks = (uint8_t)blue_duration(a.type);
+    if (!s->blue[b].queue.busy) { s->blue[b].queue = a; s->blue[b].queue.busy = 1; }
+  }
+  for (int g = 0; g < s->n_green; ++g) s->green_act[g] = (uint8_t)rng_below(&s->rng, 3);  // EnterpriseGreenAgent.py:60
+  for (int r = 0; r < NRED; ++r) {
+    RedAgent& A = s->red[r];
+    Act a; a.type = RA_SLEEP; a.host = 0; a.arg = 0; a.ticks = 1; a.sid = 0; a.busy = 0;
+    if (A.active) { a = fsm_get_action(x, r); red_validate(x, r, a); }   // AgentInterface.get_action (:120-143)
+    if (!A.queue.busy) { A.queue = a; A.queue.busy = 1; }
+  }
+  // ---- observation reset + queue tick (SC:251-265)
+  Act bexec[NBLUE]; Act rexec[NRED];
+  for (int b = 0; b < NBLUE; ++b) {
+    Act& q = s->blue[b].queue;
+    q.ticks--;
+    if (q.ticks < 1) { bexec[b] = q; q.busy = 0; } else { bexec[b].type = BA_SLEEP; bexec[b].host = 0; bexec[b].arg = 0; }
+  }
+  int n_actions = NBLUE + s->n_green + NRED;
+  for (int r = 0; r < NRED; ++r) {
+    RedAgent& A = s->red[r];
+    A.nobs = 0; A.obs_success = 0; A.obs_act_type = RA_NONE; A.new_sess_host = 0xFF;
+    Act& q = A.queue;
+    q.ticks--;
+    if (q.ticks < 1) { rexec[r] = q; q.busy = 0; }
+    else { rexec[r].type = RA_SLEEP; rexec[r].sid = 0; obs_first(x, r, T_IN_PROGRESS, RA_NONE, 0, 0); }
+    A.exec_type = rexec[r].type; A.exec_host = rexec[r].host;
+    // filter_actions (SC:466-485): actions naming a dead session are dropped (Sleep/InvalidAction have no session)
+    if (rexec[r].type <= RA_WITHDRAW && rs_find_id(A, rexec[r].sid) < 0) { rexec[r].type = RA_NONE; n_actions--; }
+  }
+  // ---- sort_action_order (SC:398-464): the shuffle only consumes the stream
+  rng_shuffle_consume(&s->rng, n_actions);
+  // ---- execute: priority 1 (ControlTraffic) first, then agent order
+  for (int b = 0; b < NBLUE; ++b) if (bexec[b].type == BA_BLOCK || bexec[b].type == BA_ALLOW) blue_execute(x, b, bexec[b]);
+  for (int b = 0; b < NBLUE; ++b) if (!(bexec[b].type == BA_BLOCK || bexec[b].type == BA_ALLOW)) blue_execute(x, b, bexec[b]);
+  int brm = 0;  // BlueRewardMachine.calculate_reward accumulates here (Shared/BlueRewardMachine.py:70-121)
+  for (int g = 0; g < s->n_green; ++g) {
+    int gh = s->green_host[g];
+    int own = h_subnet(gh);
+    if (s->green_act[g] == 0) { if (!green_access_service(x, gh)) brm += reward_table(s->phase, own, RW_ASF); }
+    else if (s->green_act[g] == 1) { if (!green_local_work(x, gh)) brm += reward_table(s->phase, own, RW_LWF); }
+  }
+  for (int r = 0; r < NRED; ++r) if (rexec[r].type != RA_NONE) red_execute(x, r, rexec[r]);
+  // ---- reassignment, end-turn actions (SC:278-286)
+  red_reassign(x);
+  for (int b = 0; b < NBLUE; ++b) blue_monitor(x, b);
+  for (int r = 0; r < NRED; ++r) if (s->red[r].active) red_session_check(x, r);
+  // ---- bookkeeping, reward (SC:297-311)
+  s->step_count++;
+  s->done = (uint8_t)(s->step_count >= s->steps - 1);
+  for (int r = 0; r < NRED; ++r)
+    if (s->red[r].exec_type == RA_IMPACT && s->red[r].nsess > 0)
+      brm += reward_table(s->phase, h_subnet(s->red[r].exec_host), RW_RIA);  // charged for any executed Impact (App. B.2)
+  s->reward = (float)brm + action_cost;
+  if (messages) for (int b = 0; b < NBLUE; ++b) for (int i = 0; i < MSG_LEN; ++i) s->msg[b][i] = messages[b * MSG_LEN + i] ? 1 : 0;
+  else for (int b = 0; b < NBLUE; ++b) for (int i = 0; i < MSG_LEN; ++i) s->msg[b][i] = 0;
+}
+
+// ------------------------------------------------------------------ BlueFlatWrapper.observation_change (BlueFlatWrapper.py:172-256)
+// out: OBS_TOTAL ints, agents 0..3 (92 each) then agent 4 (210)
+template <typename T>
+CC4_HD void env_flat_obs(const EnvState* s, T* out) {
+  int o = 0;
+  for (int b = 0; b < NBLUE; ++b) {
+    out[o++] = (T)s->phase;
+    for (int i = 0; i < blue_nsub(b); ++i) {
+      int sn = blue_subnet_sorted(b, i);
+      for (int k = 0; k < NSUB; ++k) out[o++] = (T)(sorted_subnet(k) == sn);
+      for (int k = 0; k < NSUB; ++k) out[o++] = (T)((s->blocks[sn] >> sorted_subnet(k)) & 1u);
+      uint32_t adj = comms_adjacent(s->phase, sn);
+      for (int k = 0; k < NSUB; ++k) out[o++] = (T)(!((adj >> sorted_subnet(k)) & 1u));
+      for (int pass = 0; pass < 2; ++pass) {
+        int bits = pass == 0 ? (EV_CUR_PROC | EV_OLD_PROC) : (EV_CUR_CONN | EV_OLD_CONN);
+        for (int hs = 0; hs < ZONE_HOSTS; ++hs) {
+          int h = hs < MAX_SERVERS ? h_make(sn, 11 + hs) : h_make(sn, 1 + (hs - MAX_SERVERS));
+          out[o++] = (T)(s->hs[h].exists && (s->hd[h].ev & bits) != 0);
+        }
+      }
+    }
+    for (int j = 0; j < NBLUE; ++j) { if (j == b) continue; for (int i = 0; i < MSG_LEN; ++i) out[o++] = (T)s->msg[j][i]; }
+  }
+}
+
+}  // namespace cc4

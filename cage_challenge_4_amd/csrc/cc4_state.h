@@ -1,0 +1,156 @@
+// cc4_state.h -- packed per-episode state of the CC4 (CybORG v4) step engine.
+//
+// One episode ("env") = one EnvState (hot, ~20 KB) + one EnvCold (ephemeral-port bitmaps and
+// per-red-session port knowledge, touched a handful of times per step).  Everything is fixed-size
+// POD so that a whole episode can be staged with coalesced loads and snapshot with memcpy.
+//
+// Host id layout: h = subnet*17 + slot; slot 0 router, 1..10 user_host_0..9, 11..16 server_host_0..5;
+// internet root host = 136.  Subnet index = SUBNET enum order of
+// CybORG/Simulator/Scenarios/EnterpriseScenarioGenerator.py:40-51.  Iterating existing hosts by
+// increasing id == the reference's dict iteration order over state.hosts / state.ip_addresses.
+#pragma once
+#include <stdint.h>
+#include "cc4_rng.h"
+
+namespace cc4 {
+
+enum : int {
+  NSUB = 9, SLOTS = 17, MAXH = 137, H_INTERNET = 136,
+  MAX_USERS = 10, MAX_SERVERS = 6, ZONE_HOSTS = 16,
+  MAXG = 80,            // green agents (one per user host)
+  NBLUE = 5, NRED = 6,
+  MAXP = 16,            // process slots per host
+  MAXSV = 9,            // service kinds per host (5 real + 4 decoy names)
+  MAX_RS = 64,          // sessions per red agent
+  MAX_KS = 96,          // known server-session ids per red agent (ActionSpace.server_session)
+  MAX_KB = 128,         // port-knowledge blocks (one per live RedAbstractSession)
+  MAX_SUS = 192,        // sus pid entries per blue agent (VelociraptorServer.sus_pids)
+  MAX_OBS = 112,        // red observation entries per agent per step
+  MAX_PEND = 24,        // process_creation events carrying a pid, per step
+  EPH_WORDS = 340,      // 10880-bit bitmap >= 60000-49152 ephemeral ports (Host.py:183)
+  OBS_SHORT = 92, OBS_LONG = 210, OBS_TOTAL = 4 * 92 + 210,   // 578
+  ACT_SHORT = 82, ACT_LONG = 242, MASK_TOTAL = 4 * 82 + 242,  // 570
+  MSG_LEN = 8,
+};
+
+// subnet indices (SUBNET enum order)
+enum : int { S_RZA = 0, S_OZA = 1, S_RZB = 2, S_OZB = 3, S_CON = 4, S_PUB = 5, S_ADM = 6, S_OFF = 7, S_INT = 8 };
+
+// process / service kinds. Kinds 0..8 double as service-table keys (host.services dict keys).
+enum : int {
+  K_SSHD = 0, K_OT = 1, K_APACHE = 2, K_MYSQL = 3, K_SMTP = 4,
+  K_DEC_APACHE = 5, K_DEC_TOMCAT = 6, K_DEC_HARAKA = 7, K_DEC_VSFTPD = 8,
+  K_SESS_BLUE = 9, K_SESS_GREEN = 10, K_SESS_RED = 11,  // Process(name=session_type) of Host.add_session
+  K_SHELL = 12,                                          // cmd.sh of ExploitAction._create_new_session
+};
+// listening-port bit codes
+enum : int { PB_22 = 1, PB_80 = 2, PB_3390 = 4, PB_25 = 8, PB_1 = 16, PB_443 = 32, PB_HAS = 128 };
+
+// error / bound-overflow flags (cc4 never silently truncates: any bit set => results for that env are flagged)
+enum : uint32_t {
+  E_PROC_OVERFLOW = 1u << 0, E_RSESS_OVERFLOW = 1u << 1, E_KS_OVERFLOW = 1u << 2, E_KB_OVERFLOW = 1u << 3,
+  E_SUS_OVERFLOW = 1u << 4, E_OBS_OVERFLOW = 1u << 5, E_PEND_OVERFLOW = 1u << 6,
+  E_STEP_PAST_END = 1u << 7,      // reference raises ValueError (State.py:539-540)
+  E_UNREACHABLE = 1u << 8,        // a path the reference would crash on (documented in DESIGN.md)
+  E_BAD_ACTION = 1u << 9, E_BLUE_GREEN_SESSION_KILLED = 1u << 10, E_FSM_NO_HOST = 1u << 11,
+};
+
+struct Proc { uint16_t pid; uint8_t kind; uint8_t flags; };       // flags bit0: user == root
+struct Svc  { uint16_t pid; uint8_t kind; uint8_t st; };          // st bit7 active, low bits reliability/20
+enum : int { PF_ROOT = 1, SV_ACTIVE = 0x80 };
+
+enum : int { EV_CUR_CONN = 1, EV_CUR_PROC = 2, EV_OLD_CONN = 4, EV_OLD_PROC = 8 };
+
+struct HostDyn {
+  Proc procs[MAXP];
+  Svc svcs[MAXSV];
+  uint8_t nproc, nsvc, ev, pad;
+};
+struct HostStatic {                 // Host.create_backup (Host.py:316-371)
+  Proc procs[8];
+  Svc svcs[5];
+  uint8_t nproc, nsvc, exists, ip_octet;
+};
+
+// red sessions (state.sessions[red_agent_k], dict order == array order)
+enum : int { RS_ABSTRACT = 1, RS_ROOT = 2, RS_ORIG = 4 };
+struct RSess { uint16_t id; uint16_t pid; uint8_t host; uint8_t flags; uint8_t kb; uint8_t pad; };
+
+// FSM host states (FiniteStateRedAgent.py:441-452)
+enum : int { FS_K = 0, FS_KD = 1, FS_S = 2, FS_SD = 3, FS_U = 4, FS_UD = 5, FS_R = 6, FS_RD = 7, FS_F = 8, FS_NONE = 0xFF };
+// red action types in FSM action_list column order (FiniteStateRedAgent.py:393-411) + non-FSM
+enum : int { RA_DRS = 0, RA_AGGR = 1, RA_STEALTH = 2, RA_DECEPTION = 3, RA_EXPLOIT = 4, RA_PRIVESC = 5, RA_IMPACT = 6,
+             RA_DEGRADE = 7, RA_WITHDRAW = 8, RA_SLEEP = 9, RA_INVALID = 10, RA_NONE = 11 };
+// blue action types
+enum : int { BA_SLEEP = 0, BA_MONITOR = 1, BA_ANALYSE = 2, BA_REMOVE = 3, BA_RESTORE = 4, BA_DECOY = 5, BA_BLOCK = 6, BA_ALLOW = 7 };
+// TernaryEnum (Shared/Enums.py:5-25)
+enum : int { T_TRUE = 1, T_UNKNOWN = 2, T_FALSE = 3, T_IN_PROGRESS = 4 };
+
+struct Act { uint8_t type; uint8_t host; uint8_t arg; uint8_t ticks; uint16_t sid; uint16_t busy; };
+// Act.host: target host (blue/red) ; Act.arg: subnet (DRS) or from-subnet (Block/Allow) ; Act.busy: 1 if queued
+
+// red observation entry (one dict key of the agent's combined Observation)
+enum : int { OE_KEY_IP = 1, OE_SESS = 2, OE_IFACE = 4, OE_SYSHN = 8 };
+struct ObsEnt { uint8_t host; uint8_t flags; };
+
+struct RedAgent {
+  RSess sess[MAX_RS];
+  uint16_t known_sid[MAX_KS];        // ActionSpace.server_session keys with value True, insertion order
+  uint8_t fsm_order[MAXH];           // host_states dict insertion order
+  uint8_t fsm_state[MAXH];           // FS_* or FS_NONE
+  uint32_t fsm_hn[5];                // host_states[ip]['hostname'] is not None
+  uint32_t as_ip[5];                 // ActionSpace.ip_address[ip] == True
+  uint32_t as_hn[5];                 // ActionSpace.hostname[name] == True
+  ObsEnt obs[MAX_OBS];
+  Act queue;                         // actions_in_progress[agent]
+  Act chosen;                        // action produced by the policy this step (scratch)
+  uint16_t as_subnet;                // ActionSpace.subnet known bits
+  uint16_t fsm_step;
+  uint8_t nsess, nknown, fsm_n, nobs;
+  uint8_t active;                    // AgentInterface.active
+  uint8_t obs_success;               // success of observations[0]
+  uint8_t obs_act_type, obs_act_host, obs_act_arg;   // 'action' of observations[0] (RA_NONE if absent / not FSM-relevant)
+  uint8_t exec_type, exec_host;      // self.action[agent][0] of this step (for reward)
+  uint8_t new_sess_host;             // host of a session created by this agent's exploit this step (0xFF none)
+  uint16_t new_sess_id;
+  uint8_t start_host, allowed;       // static per episode; allowed = bitmask over subnets... (see red_allowed())
+  uint8_t pad[2];
+};
+
+struct BlueAgent {
+  uint32_t sus[MAX_SUS];             // (host << 16) | pid, chronological
+  Act queue;
+  uint16_t nsus;
+  uint8_t parent_host, pad;
+};
+
+struct EnvState {
+  Rng rng;
+  int32_t step_count, steps, phase;
+  int32_t phase_len[3];
+  uint32_t err;
+  float reward;                      // team reward of the last step (BlueRewardMachine + action_cost)
+  uint8_t done, rng_mode, n_green, pad0;
+  uint16_t blocks[NSUB];             // blocks[to] bit from
+  uint8_t cidr_octet[NSUB];
+  uint8_t n_users[NSUB], n_servers[NSUB];
+  uint8_t green_host[MAXG];
+  uint8_t green_act[MAXG];           // scratch: this step's green choice
+  uint16_t blue_pid[MAXH];           // pid of the blue session process on host (0 = none)
+  uint16_t green_pid[MAXH];
+  uint32_t pend[MAX_PEND];           // (host<<16)|pid process_creation events not yet seen by Monitor
+  uint8_t npend, pad1[3];
+  HostStatic hs[MAXH];
+  HostDyn hd[MAXH];
+  BlueAgent blue[NBLUE];
+  RedAgent red[NRED];
+  uint8_t msg[NBLUE][MSG_LEN];       // messages submitted with the last step
+  uint32_t kb_used[MAX_KB / 32];
+};
+
+struct EnvCold {
+  uint32_t eph[MAXH][EPH_WORDS];     // Host.ephemeral_ports as a bitmap (port-49152)
+  uint8_t kports[MAX_KB][MAXH + 7];  // RedAbstractSession.ports[ip]: PB_* bits | PB_HAS
+};
+
+}  // namespace cc4

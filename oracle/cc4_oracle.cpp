@@ -1,0 +1,112 @@
+// cc4_oracle.cpp -- CPU oracle for the CC4 step engine.  TEST INFRASTRUCTURE, NOT PRODUCT.
+//
+// Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load the library built from
+// this file (oracle/liboracle.so).  The product path (cage_challenge_4_amd/csrc/cc4_hip.hip -> libcc4.so)
+// never links or calls it and fails loudly without a GPU.
+//
+// What it is: a host (g++) build of the transition restated in cage_challenge_4_amd/csrc/cc4_engine.h
+// -- every function there cites the reference file:line it follows -- driven serially, one episode at a
+// time.  How it is pinned: in PCG mode it must reproduce, bit for bit, the golden trajectories under
+// tests/golden/ that oracle/refgen/make_golden.py recorded from the real reference (CybORG v4, imported
+// from /root/reference in the build container): per-step flat observations, rewards, dones and the PCG64
+// stream position.  tests/test_oracle_golden.py checks that on CPU; tests/test_hip_parity.py then checks
+// the HIP path both against this oracle and directly against the same golden files.
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <vector>
+#include "../cage_challenge_4_amd/csrc/cc4_engine.h"
+
+using namespace cc4;
+
+struct Oracle {
+  int n;
+  std::vector<EnvState> st;
+  std::vector<EnvCold> cold;
+};
+
+extern "C" {
+
+void* cc4o_create(int n) {
+  Oracle* o = new Oracle();
+  o->n = n;
+  o->st.resize(n);
+  o->cold.resize(n);
+  memset(o->st.data(), 0, sizeof(EnvState) * n);
+  memset(o->cold.data(), 0, sizeof(EnvCold) * n);
+  return o;
+}
+void cc4o_destroy(void* h) { delete (Oracle*)h; }
+size_t cc4o_state_bytes() { return sizeof(EnvState); }
+size_t cc4o_cold_bytes() { return sizeof(EnvCold); }
+void* cc4o_state_ptr(void* h, int i) { return &((Oracle*)h)->st[i]; }
+void* cc4o_cold_ptr(void* h, int i) { return &((Oracle*)h)->cold[i]; }
+
+void cc4o_reset(void* h, int i, uint64_t seed, int rng_mode, int steps, int continue_stream) {
+  Oracle* o = (Oracle*)h;
+  Ctx x{&o->st[i], &o->cold[i]};
+  env_reset(x, seed, rng_mode, steps, continue_stream != 0);
+}
+void cc4o_step(void* h, int i, const int32_t* actions, const uint8_t* msgs) {
+  Oracle* o = (Oracle*)h;
+  Ctx x{&o->st[i], &o->cold[i]};
+  env_step(x, actions, msgs);
+}
+// whole-batch step, OpenMP over envs when built with -fopenmp (bench.py cpu_baseline)
+void cc4o_step_all(void* h, const int32_t* actions /* [n][5] */) {
+  Oracle* o = (Oracle*)h;
+#pragma omp parallel for schedule(dynamic, 4)
+  for (int i = 0; i < o->n; ++i) {
+    Ctx x{&o->st[i], &o->cold[i]};
+    env_step(x, actions + 5 * i, nullptr);
+  }
+}
+void cc4o_obs(void* h, int i, int32_t* out) { env_flat_obs<int32_t>(&((Oracle*)h)->st[i], out); }
+float cc4o_reward(void* h, int i) { return ((Oracle*)h)->st[i].reward; }
+int cc4o_done(void* h, int i) { return ((Oracle*)h)->st[i].done; }
+uint32_t cc4o_err(void* h, int i) { return ((Oracle*)h)->st[i].err; }
+void cc4o_mask(void* h, int i, uint8_t* out) { blue_action_mask(&((Oracle*)h)->st[i], out); }
+void cc4o_rng_state(void* h, int i, uint64_t* out /* s_hi s_lo inc_hi inc_lo has32 u32 ndraw */) {
+  const Rng& r = ((Oracle*)h)->st[i].rng;
+  out[0] = r.s_hi; out[1] = r.s_lo; out[2] = r.inc_hi; out[3] = r.inc_lo; out[4] = r.has32; out[5] = r.u32; out[6] = r.ndraw;
+}
+
+// canonical text dump of one episode's state (parity bisecting against oracle/refgen/ref_dump.py)
+int cc4o_dump(void* h, int i, char* buf, int cap) {
+  const EnvState& s = ((Oracle*)h)->st[i];
+  int n = 0;
+#define P(...) do { if (n < cap) n += snprintf(buf + n, cap - n, __VA_ARGS__); } while (0)
+  P("step %d phase %d blocks", s.step_count, s.phase);
+  for (int k = 0; k < NSUB; ++k) P(" %u", s.blocks[k]);
+  P("\n");
+  for (int hh = 0; hh < MAXH; ++hh) {
+    if (!s.hs[hh].exists) continue;
+    const HostDyn& d = s.hd[hh];
+    P("host %d procs", hh);
+    for (int k = 0; k < d.nproc; ++k) P(" (%d,%d,%d)", d.procs[k].pid, d.procs[k].kind, d.procs[k].flags & 1);
+    P(" svcs");
+    for (int k = 0; k < d.nsvc; ++k) P(" (%d,%d,%d,%d)", d.svcs[k].kind, (d.svcs[k].st & SV_ACTIVE) ? 1 : 0, (d.svcs[k].st & 0x7F) * 20, d.svcs[k].pid);
+    P(" ev %d%d%d%d\n", (d.ev & EV_CUR_CONN) ? 1 : 0, (d.ev & EV_CUR_PROC) ? 1 : 0, (d.ev & EV_OLD_CONN) ? 1 : 0, (d.ev & EV_OLD_PROC) ? 1 : 0);
+  }
+  for (int r = 0; r < NRED; ++r) {
+    const RedAgent& a = s.red[r];
+    P("red %d active %d sess", r, a.active);
+    for (int k = 0; k < a.nsess; ++k) P(" (%d,%d,%d,%d,%d)", a.sess[k].id, a.sess[k].host, a.sess[k].pid, (a.sess[k].flags & RS_ABSTRACT) ? 1 : 0, (a.sess[k].flags & RS_ROOT) ? 1 : 0);
+    P(" known");
+    for (int k = 0; k < a.nknown; ++k) P(" %d", a.known_sid[k]);
+    P(" fsmstep %d fsm", a.fsm_step);
+    for (int k = 0; k < a.fsm_n; ++k) { int hh = a.fsm_order[k]; P(" (%d,%d,%d)", hh, a.fsm_state[hh], bit_get(a.fsm_hn, hh) ? 1 : 0); }
+    P(" subnets %u busy %d qt %d\n", a.as_subnet, a.queue.busy, a.queue.busy ? a.queue.type : -1);
+  }
+  for (int b = 0; b < NBLUE; ++b) {
+    const BlueAgent& a = s.blue[b];
+    P("blue %d sus", b);
+    for (int hh = 0; hh < MAXH; ++hh)  // grouped by host, chronological within a host
+      for (int k = 0; k < a.nsus; ++k) if ((int)(a.sus[k] >> 16) == hh) P(" (%d,%d)", hh, (int)(a.sus[k] & 0xFFFF));
+    P("\n");
+  }
+#undef P
+  return n;
+}
+
+}  // extern "C"
