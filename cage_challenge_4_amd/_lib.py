@@ -1,0 +1,86 @@
+"""ctypes binding of libcc4.so (include/cc4.h).  No torch, no cffi (cffi is not installed in the image).
+
+The library is built in-tree by `__graft_entry__.build()` (hipcc --offload-arch=gfx950).  There is no CPU
+fallback anywhere in this package: if the shared object is missing, or no HIP device is visible,
+loading / `cc4_create` raises."""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'libcc4.so')
+
+OBS_PER_ENV = 578
+MASK_PER_ENV = 570
+NUM_BLUE = 5
+MSG_LEN = 8
+TOPOLOGY_BYTES = 27 + 2 * 137
+OBS_LEN = (92, 92, 92, 92, 210)
+ACT_LEN = (82, 82, 82, 82, 242)
+OBS_OFF = (0, 92, 184, 276, 368)
+ACT_OFF = (0, 82, 164, 246, 328)
+
+
+class CC4Config(ctypes.Structure):
+    _fields_ = [('num_envs', ctypes.c_int32), ('steps', ctypes.c_int32), ('device_id', ctypes.c_int32),
+                ('rng_mode', ctypes.c_int32), ('autoreset', ctypes.c_int32), ('reserved', ctypes.c_int32 * 3)]
+
+
+# every entry point declared in include/cc4.h : (restype, argtypes)
+_P = ctypes.c_void_p
+SIGNATURES = {
+    'cc4_create': (ctypes.c_int, [ctypes.POINTER(CC4Config), ctypes.POINTER(_P)]),
+    'cc4_destroy': (None, [_P]),
+    'cc4_last_error': (ctypes.c_char_p, [_P]),
+    'cc4_reset': (ctypes.c_int, [_P, _P, _P]),
+    'cc4_step': (ctypes.c_int, [_P, _P, _P]),
+    'cc4_get_obs': (ctypes.c_int, [_P, _P]),
+    'cc4_get_reward_done': (ctypes.c_int, [_P, _P, _P]),
+    'cc4_get_action_mask': (ctypes.c_int, [_P, _P]),
+    'cc4_get_err': (ctypes.c_int, [_P, _P]),
+    'cc4_get_rng_state': (ctypes.c_int, [_P, _P]),
+    'cc4_step_device': (ctypes.c_int, [_P, _P, _P]),
+    'cc4_obs_device': (ctypes.c_int, [_P, ctypes.POINTER(_P)]),
+    'cc4_reward_device': (ctypes.c_int, [_P, ctypes.POINTER(_P)]),
+    'cc4_done_device': (ctypes.c_int, [_P, ctypes.POINTER(_P)]),
+    'cc4_actions_device': (ctypes.c_int, [_P, ctypes.POINTER(_P)]),
+    'cc4_random_actions_device': (ctypes.c_int, [_P, ctypes.c_uint64, ctypes.c_uint32]),
+    'cc4_synchronize': (ctypes.c_int, [_P]),
+    'cc4_run_random_steps': (ctypes.c_int, [_P, ctypes.c_uint64, ctypes.c_uint32, ctypes.c_int32, ctypes.POINTER(ctypes.c_float)]),
+    'cc4_state_bytes': (ctypes.c_size_t, []),
+    'cc4_get_state': (ctypes.c_int, [_P, ctypes.c_int32, _P]),
+    'cc4_set_state': (ctypes.c_int, [_P, ctypes.c_int32, _P]),
+    'cc4_get_topology': (ctypes.c_int, [_P, ctypes.c_int32, _P]),
+    'cc4_comm_unique_id': (ctypes.c_int, [_P]),
+    'cc4_comm_init': (ctypes.c_int, [_P, ctypes.c_int32, ctypes.c_int32, _P]),
+    'cc4_allgather_obs': (ctypes.c_int, [_P, ctypes.POINTER(_P)]),
+    'cc4_algorithmic_bytes_per_env_step': (ctypes.c_size_t, []),
+}
+
+_lib = None
+
+
+def load():
+    """Load libcc4.so and attach signatures.  Raises if the HIP extension has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                           "(hipcc --offload-arch=gfx950). cage_challenge_4_amd has no CPU fallback.")
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)   # AttributeError if the ABI lost a symbol
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+class CC4Error(RuntimeError):
+    pass
+
+
+def check(lib, handle, rc, what):
+    if rc != 0:
+        msg = lib.cc4_last_error(handle)
+        raise CC4Error(f"{what} failed (rc={rc}): {msg.decode() if msg else ''}")

@@ -589,6 +589,8 @@ CC4_HD void red_result(Ctx x, int r, const Act& a, int success) {
 CC4_HD void red_drs(Ctx x, int r, const Act& a) {
   EnvState* s = x.s;
   int sn = a.arg; bool any = false;
+  // the session can die between filter_actions and execution (a blue Remove/Restore runs earlier in the same step)
+  if (rs_find_id(s->red[r], a.sid) < 0) { red_result(x, r, a, T_FALSE); return; }
   bool allowed = (red_allowed_mask(r) >> sn) & 1u;  // SimulationController._filter_obs drops foreign-subnet interfaces
   for (int sl = 1; sl < SLOTS; ++sl) {
     int h = h_make(sn, sl);
@@ -1025,7 +1027,7 @@ CC4_HD void env_step(Ctx x, const int32_t* actions, const uint8_t* messages /* [
     Act& q = A.queue;
     q.ticks--;
     if (q.ticks < 1) { rexec[r] = q; q.busy = 0; }
-    else { rexec[r].type = RA_SLEEP; rexec[r].sid = 0; obs_first(x, r, T_IN_PROGRESS, RA_NONE, 0, 0); }
+    else { rexec[r].type = RA_SLEEP; rexec[r].host = 0; rexec[r].arg = 0; rexec[r].ticks = 0; rexec[r].sid = 0; rexec[r].busy = 0; obs_first(x, r, T_IN_PROGRESS, RA_NONE, 0, 0); }
     A.exec_type = rexec[r].type; A.exec_host = rexec[r].host;
     // filter_actions (SC:466-485): actions naming a dead session are dropped (Sleep/InvalidAction have no session)
     if (rexec[r].type <= RA_WITHDRAW && rs_find_id(A, rexec[r].sid) < 0) { rexec[r].type = RA_NONE; n_actions--; }

@@ -1,0 +1,354 @@
+// cc4_hip.hip -- gfx950 kernels + the C ABI (include/cc4.h) of libcc4.so.
+//
+// Execution model (round 1): one 64-lane wavefront per episode.  The wave stages the episode's packed
+// EnvState row (34.6 KB) HBM -> LDS with coalesced 16-byte loads, lane 0 walks the strictly ordered
+// transition (the reference's ~57 agent actions share one RNG stream, so the order is the semantics),
+// the wave encodes the 578 flat-observation values, and the row goes back LDS -> HBM coalesced.
+// The cold part of the episode (ephemeral-port bitmaps, per-session port knowledge; 205 KB) stays in HBM
+// and is touched a handful of times per step.  No MFMA: the path is integer / indexing.
+#include <hip/hip_runtime.h>
+#include <rccl/rccl.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <string>
+
+#include "../../include/cc4.h"
+#include "cc4_engine.h"
+
+using namespace cc4;
+
+static_assert(sizeof(EnvState) % 16 == 0, "EnvState rows are staged with 16-byte accesses");
+constexpr int ROW_VEC = (int)(sizeof(EnvState) / 16);
+constexpr int WAVE = 64;
+
+struct StepArgs {
+  EnvState* st; EnvCold* cold;
+  const int32_t* actions; const uint8_t* msgs;
+  int32_t* obs; float* reward; uint8_t* done; uint32_t* err;
+  int n, autoreset, steps, rng_mode;
+};
+
+// ---------------------------------------------------------------- kernels
+__global__ __launch_bounds__(WAVE) void k_step(StepArgs a) {
+  extern __shared__ uint4 lds[];
+  __shared__ uint8_t obs_lds[OBS_TOTAL + 2];
+  const int e = blockIdx.x, lane = threadIdx.x;
+  if (e >= a.n) return;
+  const uint4* src = reinterpret_cast<const uint4*>(a.st + e);
+  for (int i = lane; i < ROW_VEC; i += WAVE) lds[i] = src[i];
+  __syncthreads();
+  EnvState* s = reinterpret_cast<EnvState*>(lds);
+  if (lane == 0) {
+    Ctx x{s, a.cold + e};
+    if (a.autoreset && s->done) {
+      env_reset(x, 0, a.rng_mode, a.steps, true);   // new episode, same stream (CybORG.reset(seed=None))
+    } else {
+      env_step(x, a.actions ? a.actions + e * NBLUE : nullptr, a.msgs ? a.msgs + e * NBLUE * MSG_LEN : nullptr);
+    }
+    env_flat_obs<uint8_t>(s, obs_lds);
+    a.reward[e] = s->reward;
+    a.done[e] = s->done;
+    a.err[e] = s->err;
+  }
+  __syncthreads();
+  uint4* dst = reinterpret_cast<uint4*>(a.st + e);
+  for (int i = lane; i < ROW_VEC; i += WAVE) dst[i] = lds[i];
+  int32_t* o = a.obs + (size_t)e * OBS_TOTAL;
+  for (int i = lane; i < OBS_TOTAL; i += WAVE) o[i] = obs_lds[i];
+}
+
+struct ResetArgs {
+  EnvState* st; EnvCold* cold; const uint64_t* seeds; const uint8_t* env_mask;
+  int32_t* obs; float* reward; uint8_t* done; uint32_t* err; uint8_t* mask;
+  int n, steps, rng_mode;
+};
+__global__ __launch_bounds__(WAVE) void k_reset(ResetArgs a) {
+  __shared__ uint8_t obs_lds[OBS_TOTAL + 2];
+  __shared__ uint8_t mask_lds[MASK_TOTAL + 2];
+  const int e = blockIdx.x, lane = threadIdx.x;
+  if (e >= a.n) return;
+  if (a.env_mask && !a.env_mask[e]) return;
+  EnvState* s = a.st + e;
+  if (lane == 0) {
+    Ctx x{s, a.cold + e};
+    env_reset(x, a.seeds ? a.seeds[e] : 0, a.rng_mode, a.steps, a.seeds == nullptr);
+    env_flat_obs<uint8_t>(s, obs_lds);
+    blue_action_mask(s, mask_lds);
+    a.reward[e] = 0.f; a.done[e] = s->done; a.err[e] = s->err;
+  }
+  __syncthreads();
+  int32_t* o = a.obs + (size_t)e * OBS_TOTAL;
+  for (int i = lane; i < OBS_TOTAL; i += WAVE) o[i] = obs_lds[i];
+  uint8_t* m = a.mask + (size_t)e * MASK_TOTAL;
+  for (int i = lane; i < MASK_TOTAL; i += WAVE) m[i] = mask_lds[i];
+}
+
+// uniform blue action indices over each agent's full range: Philox key (seed0, env),
+// counter (t, agent, 0xB10E, 0)
+__global__ void k_random_actions(int32_t* actions, int n, uint64_t seed0, uint32_t t) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n * NBLUE) return;
+  int e = i / NBLUE, b = i % NBLUE;
+  uint32_t c[4] = {t, (uint32_t)b, 0xB10Eu, 0u};
+  uint64_t key = seed0 + (uint64_t)e;
+  philox4x32_10(c, (uint32_t)key, (uint32_t)(key >> 32));
+  uint32_t range = b == 4 ? ACT_LONG : ACT_SHORT;
+  actions[i] = (int32_t)(((uint64_t)c[0] * range) >> 32);
+}
+
+__global__ void k_rng_state(const EnvState* st, uint64_t* out, int n) {
+  int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= n) return;
+  const Rng& r = st[e].rng;
+  uint64_t* o = out + 7 * (size_t)e;
+  o[0] = r.s_hi; o[1] = r.s_lo; o[2] = r.inc_hi; o[3] = r.inc_lo; o[4] = r.has32; o[5] = r.u32; o[6] = r.ndraw;
+}
+
+// ---------------------------------------------------------------- handle
+struct cc4_handle {
+  cc4_config cfg;
+  hipStream_t stream = nullptr;
+  EnvState* d_state = nullptr; EnvCold* d_cold = nullptr;
+  int32_t* d_actions = nullptr; uint8_t* d_msgs = nullptr; uint64_t* d_seeds = nullptr; uint8_t* d_envmask = nullptr;
+  int32_t* d_obs = nullptr; float* d_reward = nullptr; uint8_t* d_done = nullptr; uint32_t* d_err = nullptr;
+  uint8_t* d_mask = nullptr; uint64_t* d_rng = nullptr;
+  int32_t* d_all_obs = nullptr;
+  ncclComm_t comm = nullptr; int rank = 0, world = 1;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  std::string err;
+};
+
+static thread_local std::string g_create_err;
+
+#define HIPCHK(h, call)                                                                        \
+  do {                                                                                         \
+    hipError_t _e = (call);                                                                    \
+    if (_e != hipSuccess) {                                                                    \
+      (h)->err = std::string(#call) + ": " + hipGetErrorString(_e);                            \
+      return -1;                                                                               \
+    }                                                                                          \
+  } while (0)
+
+static int launch_step(cc4_handle* h, const int32_t* d_actions, const uint8_t* d_msgs) {
+  StepArgs a{h->d_state, h->d_cold, d_actions, d_msgs, h->d_obs, h->d_reward, h->d_done, h->d_err,
+             h->cfg.num_envs, h->cfg.autoreset, h->cfg.steps, h->cfg.rng_mode};
+  hipLaunchKernelGGL(k_step, dim3(h->cfg.num_envs), dim3(WAVE), sizeof(EnvState), h->stream, a);
+  HIPCHK(h, hipGetLastError());
+  return 0;
+}
+
+extern "C" {
+
+const char* cc4_last_error(cc4_handle* h) { return h ? h->err.c_str() : g_create_err.c_str(); }
+size_t cc4_state_bytes(void) { return sizeof(EnvState); }
+size_t cc4_algorithmic_bytes_per_env_step(void) {
+  // state row in + out, flat obs out (int32), actions in, reward + done + err out (DESIGN.md "algorithmic bytes")
+  return 2 * sizeof(EnvState) + 4 * OBS_TOTAL + 4 * NBLUE + 4 + 1 + 4;
+}
+
+int cc4_create(const cc4_config* cfg, cc4_handle** out) {
+  if (!cfg || !out || cfg->num_envs <= 0 || cfg->steps <= 0) { g_create_err = "cc4_create: bad config"; return -2; }
+  int ndev = 0;
+  hipError_t e = hipGetDeviceCount(&ndev);
+  if (e != hipSuccess || ndev <= 0) {
+    g_create_err = "cc4_create: no HIP device available (libcc4 has no CPU fallback)";
+    return -3;
+  }
+  if (cfg->device_id < 0 || cfg->device_id >= ndev) { g_create_err = "cc4_create: device_id out of range"; return -2; }
+  cc4_handle* h = new cc4_handle();
+  h->cfg = *cfg;
+  *out = h;
+  HIPCHK(h, hipSetDevice(cfg->device_id));
+  HIPCHK(h, hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
+  size_t n = (size_t)cfg->num_envs;
+  HIPCHK(h, hipMalloc(&h->d_state, n * sizeof(EnvState)));
+  HIPCHK(h, hipMalloc(&h->d_cold, n * sizeof(EnvCold)));
+  HIPCHK(h, hipMalloc(&h->d_actions, n * NBLUE * sizeof(int32_t)));
+  HIPCHK(h, hipMalloc(&h->d_msgs, n * NBLUE * MSG_LEN));
+  HIPCHK(h, hipMalloc(&h->d_seeds, n * sizeof(uint64_t)));
+  HIPCHK(h, hipMalloc(&h->d_envmask, n));
+  HIPCHK(h, hipMalloc(&h->d_obs, n * OBS_TOTAL * sizeof(int32_t)));
+  HIPCHK(h, hipMalloc(&h->d_reward, n * sizeof(float)));
+  HIPCHK(h, hipMalloc(&h->d_done, n));
+  HIPCHK(h, hipMalloc(&h->d_err, n * sizeof(uint32_t)));
+  HIPCHK(h, hipMalloc(&h->d_mask, n * MASK_TOTAL));
+  HIPCHK(h, hipMalloc(&h->d_rng, n * 7 * sizeof(uint64_t)));
+  HIPCHK(h, hipMemsetAsync(h->d_state, 0, n * sizeof(EnvState), h->stream));
+  HIPCHK(h, hipMemsetAsync(h->d_cold, 0, n * sizeof(EnvCold), h->stream));
+  HIPCHK(h, hipMemsetAsync(h->d_obs, 0, n * OBS_TOTAL * sizeof(int32_t), h->stream));
+  HIPCHK(h, hipMemsetAsync(h->d_done, 0, n, h->stream));
+  HIPCHK(h, hipMemsetAsync(h->d_err, 0, n * sizeof(uint32_t), h->stream));
+  HIPCHK(h, hipEventCreate(&h->ev0));
+  HIPCHK(h, hipEventCreate(&h->ev1));
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  return 0;
+}
+
+void cc4_destroy(cc4_handle* h) {
+  if (!h) return;
+  (void)hipSetDevice(h->cfg.device_id);
+  if (h->stream) (void)hipStreamSynchronize(h->stream);
+  if (h->comm) ncclCommDestroy(h->comm);
+  void* ptrs[] = {h->d_state, h->d_cold, h->d_actions, h->d_msgs, h->d_seeds, h->d_envmask, h->d_obs, h->d_reward,
+                  h->d_done, h->d_err, h->d_mask, h->d_rng, h->d_all_obs};
+  for (void* p : ptrs) if (p) (void)hipFree(p);
+  if (h->ev0) (void)hipEventDestroy(h->ev0);
+  if (h->ev1) (void)hipEventDestroy(h->ev1);
+  if (h->stream) (void)hipStreamDestroy(h->stream);
+  delete h;
+}
+
+int cc4_reset(cc4_handle* h, const uint64_t* seeds, const uint8_t* env_mask) {
+  HIPCHK(h, hipSetDevice(h->cfg.device_id));
+  size_t n = (size_t)h->cfg.num_envs;
+  if (seeds) HIPCHK(h, hipMemcpyAsync(h->d_seeds, seeds, n * sizeof(uint64_t), hipMemcpyHostToDevice, h->stream));
+  if (env_mask) HIPCHK(h, hipMemcpyAsync(h->d_envmask, env_mask, n, hipMemcpyHostToDevice, h->stream));
+  ResetArgs a{h->d_state, h->d_cold, seeds ? h->d_seeds : nullptr, env_mask ? h->d_envmask : nullptr, h->d_obs, h->d_reward,
+              h->d_done, h->d_err, h->d_mask, h->cfg.num_envs, h->cfg.steps, h->cfg.rng_mode};
+  hipLaunchKernelGGL(k_reset, dim3(h->cfg.num_envs), dim3(WAVE), 0, h->stream, a);
+  HIPCHK(h, hipGetLastError());
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  return 0;
+}
+
+int cc4_step(cc4_handle* h, const int32_t* actions, const uint8_t* messages) {
+  HIPCHK(h, hipSetDevice(h->cfg.device_id));
+  size_t n = (size_t)h->cfg.num_envs;
+  if (actions) HIPCHK(h, hipMemcpyAsync(h->d_actions, actions, n * NBLUE * sizeof(int32_t), hipMemcpyHostToDevice, h->stream));
+  if (messages) HIPCHK(h, hipMemcpyAsync(h->d_msgs, messages, n * NBLUE * MSG_LEN, hipMemcpyHostToDevice, h->stream));
+  if (launch_step(h, actions ? h->d_actions : nullptr, messages ? h->d_msgs : nullptr)) return -1;
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  return 0;
+}
+
+int cc4_step_device(cc4_handle* h, const int32_t* d_actions, const uint8_t* d_messages) {
+  HIPCHK(h, hipSetDevice(h->cfg.device_id));
+  return launch_step(h, d_actions, d_messages);
+}
+
+int cc4_get_obs(cc4_handle* h, int32_t* obs) {
+  HIPCHK(h, hipSetDevice(h->cfg.device_id));
+  HIPCHK(h, hipMemcpyAsync(obs, h->d_obs, (size_t)h->cfg.num_envs * OBS_TOTAL * sizeof(int32_t), hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  return 0;
+}
+int cc4_get_reward_done(cc4_handle* h, float* reward, uint8_t* done) {
+  HIPCHK(h, hipSetDevice(h->cfg.device_id));
+  size_t n = (size_t)h->cfg.num_envs;
+  if (reward) HIPCHK(h, hipMemcpyAsync(reward, h->d_reward, n * sizeof(float), hipMemcpyDeviceToHost, h->stream));
+  if (done) HIPCHK(h, hipMemcpyAsync(done, h->d_done, n, hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  return 0;
+}
+int cc4_get_action_mask(cc4_handle* h, uint8_t* mask) {
+  HIPCHK(h, hipSetDevice(h->cfg.device_id));
+  HIPCHK(h, hipMemcpyAsync(mask, h->d_mask, (size_t)h->cfg.num_envs * MASK_TOTAL, hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  return 0;
+}
+int cc4_get_err(cc4_handle* h, uint32_t* err) {
+  HIPCHK(h, hipSetDevice(h->cfg.device_id));
+  HIPCHK(h, hipMemcpyAsync(err, h->d_err, (size_t)h->cfg.num_envs * sizeof(uint32_t), hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  return 0;
+}
+int cc4_get_rng_state(cc4_handle* h, uint64_t* out) {
+  HIPCHK(h, hipSetDevice(h->cfg.device_id));
+  int n = h->cfg.num_envs;
+  hipLaunchKernelGGL(k_rng_state, dim3((n + 127) / 128), dim3(128), 0, h->stream, h->d_state, h->d_rng, n);
+  HIPCHK(h, hipGetLastError());
+  HIPCHK(h, hipMemcpyAsync(out, h->d_rng, (size_t)n * 7 * sizeof(uint64_t), hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  return 0;
+}
+int cc4_obs_device(cc4_handle* h, int32_t** p) { *p = h->d_obs; return 0; }
+int cc4_reward_device(cc4_handle* h, float** p) { *p = h->d_reward; return 0; }
+int cc4_done_device(cc4_handle* h, uint8_t** p) { *p = h->d_done; return 0; }
+int cc4_actions_device(cc4_handle* h, int32_t** p) { *p = h->d_actions; return 0; }
+
+int cc4_random_actions_device(cc4_handle* h, uint64_t seed0, uint32_t t) {
+  HIPCHK(h, hipSetDevice(h->cfg.device_id));
+  int tot = h->cfg.num_envs * NBLUE;
+  hipLaunchKernelGGL(k_random_actions, dim3((tot + 255) / 256), dim3(256), 0, h->stream, h->d_actions, h->cfg.num_envs, seed0, t);
+  HIPCHK(h, hipGetLastError());
+  return 0;
+}
+int cc4_synchronize(cc4_handle* h) {
+  HIPCHK(h, hipSetDevice(h->cfg.device_id));
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  return 0;
+}
+int cc4_run_random_steps(cc4_handle* h, uint64_t seed0, uint32_t t0, int32_t k, float* ms_step_kernels) {
+  HIPCHK(h, hipSetDevice(h->cfg.device_id));
+  float total = 0.f;
+  for (int i = 0; i < k; ++i) {
+    if (cc4_random_actions_device(h, seed0, t0 + (uint32_t)i)) return -1;
+    if (ms_step_kernels) HIPCHK(h, hipEventRecord(h->ev0, h->stream));
+    if (launch_step(h, h->d_actions, nullptr)) return -1;
+    if (ms_step_kernels) {
+      HIPCHK(h, hipEventRecord(h->ev1, h->stream));
+      HIPCHK(h, hipEventSynchronize(h->ev1));
+      float ms = 0.f;
+      HIPCHK(h, hipEventElapsedTime(&ms, h->ev0, h->ev1));
+      total += ms;
+    }
+  }
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  if (ms_step_kernels) *ms_step_kernels = total;
+  return 0;
+}
+
+int cc4_get_state(cc4_handle* h, int32_t env, void* buf) {
+  if (env < 0 || env >= h->cfg.num_envs) { h->err = "cc4_get_state: env out of range"; return -2; }
+  HIPCHK(h, hipSetDevice(h->cfg.device_id));
+  HIPCHK(h, hipMemcpyAsync(buf, h->d_state + env, sizeof(EnvState), hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  return 0;
+}
+int cc4_set_state(cc4_handle* h, int32_t env, const void* buf) {
+  if (env < 0 || env >= h->cfg.num_envs) { h->err = "cc4_set_state: env out of range"; return -2; }
+  HIPCHK(h, hipSetDevice(h->cfg.device_id));
+  HIPCHK(h, hipMemcpyAsync(h->d_state + env, buf, sizeof(EnvState), hipMemcpyHostToDevice, h->stream));
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  return 0;
+}
+
+int cc4_get_topology(cc4_handle* h, int32_t env, uint8_t* out) {
+  if (env < 0 || env >= h->cfg.num_envs) { h->err = "cc4_get_topology: env out of range"; return -2; }
+  EnvState* tmp = (EnvState*)malloc(sizeof(EnvState));
+  if (cc4_get_state(h, env, tmp)) { free(tmp); return -1; }
+  for (int i = 0; i < NSUB; ++i) { out[i] = tmp->cidr_octet[i]; out[9 + i] = tmp->n_users[i]; out[18 + i] = tmp->n_servers[i]; }
+  for (int i = 0; i < MAXH; ++i) { out[27 + 2 * i] = tmp->hs[i].exists; out[28 + 2 * i] = tmp->hs[i].ip_octet; }
+  free(tmp);
+  return 0;
+}
+
+int cc4_comm_unique_id(void* id128) {
+  ncclUniqueId id;
+  if (ncclGetUniqueId(&id) != ncclSuccess) return -1;
+  static_assert(sizeof(ncclUniqueId) == 128, "ncclUniqueId is 128 bytes");
+  memcpy(id128, &id, 128);
+  return 0;
+}
+int cc4_comm_init(cc4_handle* h, int32_t rank, int32_t world, const void* id128) {
+  HIPCHK(h, hipSetDevice(h->cfg.device_id));
+  ncclUniqueId id;
+  memcpy(&id, id128, 128);
+  ncclResult_t r = ncclCommInitRank(&h->comm, world, id, rank);
+  if (r != ncclSuccess) { h->err = std::string("ncclCommInitRank: ") + ncclGetErrorString(r); return -1; }
+  h->rank = rank; h->world = world;
+  HIPCHK(h, hipMalloc(&h->d_all_obs, (size_t)world * h->cfg.num_envs * OBS_TOTAL * sizeof(int32_t)));
+  return 0;
+}
+int cc4_allgather_obs(cc4_handle* h, int32_t** d_all_obs) {
+  if (!h->comm) { h->err = "cc4_allgather_obs: cc4_comm_init was not called"; return -2; }
+  HIPCHK(h, hipSetDevice(h->cfg.device_id));
+  size_t cnt = (size_t)h->cfg.num_envs * OBS_TOTAL;
+  ncclResult_t r = ncclAllGather(h->d_obs, h->d_all_obs, cnt, ncclInt32, h->comm, h->stream);
+  if (r != ncclSuccess) { h->err = std::string("ncclAllGather: ") + ncclGetErrorString(r); return -1; }
+  if (d_all_obs) *d_all_obs = h->d_all_obs;
+  return 0;
+}
+
+}  // extern "C"

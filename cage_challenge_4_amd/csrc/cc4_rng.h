@@ -11,6 +11,7 @@
 // Every distribution helper below states the numpy routine it restates.
 #pragma once
 #include <stdint.h>
+#include <stddef.h>
 
 #if defined(__HIPCC__)
 #define CC4_HD __host__ __device__ inline

@@ -124,7 +124,7 @@ struct BlueAgent {
   uint8_t parent_host, pad;
 };
 
-struct EnvState {
+struct alignas(16) EnvState {
   Rng rng;
   int32_t step_count, steps, phase;
   int32_t phase_len[3];
@@ -148,7 +148,7 @@ struct EnvState {
   uint32_t kb_used[MAX_KB / 32];
 };
 
-struct EnvCold {
+struct alignas(16) EnvCold {
   uint32_t eph[MAXH][EPH_WORDS];     // Host.ephemeral_ports as a bitmap (port-49152)
   uint8_t kports[MAX_KB][MAXH + 7];  // RedAbstractSession.ports[ip]: PB_* bits | PB_HAS
 };

@@ -1,0 +1,148 @@
+"""CC4VecEnv -- N independent CC4 episodes stepped by the HIP engine (libcc4.so) on one MI355X.
+
+Vectorised counterpart of  BlueFlatWrapper(CybORG(EnterpriseScenarioGenerator(SleepAgent, FiniteStateRedAgent,
+EnterpriseGreenAgent, steps), seed))  (reference: CybORG/env.py:53-123, CybORG/Agents/Wrappers/BlueFlatWrapper.py).
+Observations are returned as one int32 array [N, 578] = agents 0..3 (92 each) then agent 4 (210);
+`split_obs` gives the per-agent views.  Rewards are the team reward every blue agent receives."""
+import ctypes
+import numpy as np
+from . import _lib as L
+
+RNG_PCG64 = 0    # numpy Generator(PCG64(SeedSequence(seed))): bit-exact with the reference under the same seed
+RNG_PHILOX = 1   # Philox4x32-10 keyed by seed, counter (draw, step, episode)
+
+ERR_NAMES = {0: 'PROC_OVERFLOW', 1: 'RSESS_OVERFLOW', 2: 'KNOWN_SID_OVERFLOW', 3: 'KNOWLEDGE_BLOCK_OVERFLOW',
+             4: 'SUS_OVERFLOW', 5: 'OBS_OVERFLOW', 6: 'PENDING_EVENT_OVERFLOW', 7: 'STEP_PAST_END',
+             8: 'UNREACHABLE_REFERENCE_PATH', 9: 'BAD_ACTION', 10: 'BLUE_GREEN_SESSION_KILLED', 11: 'FSM_NO_HOST'}
+
+
+class CC4VecEnv:
+    def __init__(self, num_envs, steps=500, rng_mode=RNG_PCG64, device_id=0, autoreset=False):
+        self.lib = L.load()
+        self.num_envs = int(num_envs)
+        self.steps = int(steps)
+        cfg = L.CC4Config(self.num_envs, self.steps, int(device_id), int(rng_mode), int(bool(autoreset)))
+        h = ctypes.c_void_p()
+        rc = self.lib.cc4_create(ctypes.byref(cfg), ctypes.byref(h))
+        if rc != 0:
+            msg = self.lib.cc4_last_error(h if h else None)
+            if h:
+                self.lib.cc4_destroy(h)
+            raise L.CC4Error(f"cc4_create failed (rc={rc}): {msg.decode() if msg else ''}")
+        self._h = h
+        n = self.num_envs
+        self._obs = np.zeros((n, L.OBS_PER_ENV), np.int32)
+        self._rew = np.zeros(n, np.float32)
+        self._done = np.zeros(n, np.uint8)
+        self._mask = np.zeros((n, L.MASK_PER_ENV), np.uint8)
+        self._err = np.zeros(n, np.uint32)
+
+    # -- lifecycle
+    def close(self):
+        if getattr(self, '_h', None):
+            self.lib.cc4_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _chk(self, rc, what):
+        L.check(self.lib, self._h, rc, what)
+
+    # -- API
+    def reset(self, seeds=None, env_mask=None):
+        """seeds: None (streams continue, == reference reset(seed=None)), int (seed+i per env) or array [N]."""
+        sp = None
+        if seeds is not None:
+            if np.isscalar(seeds):
+                seeds = np.uint64(seeds) + np.arange(self.num_envs, dtype=np.uint64)
+            seeds = np.ascontiguousarray(seeds, dtype=np.uint64)
+            assert seeds.shape == (self.num_envs,)
+            sp = seeds.ctypes.data_as(ctypes.c_void_p)
+        mp = None
+        if env_mask is not None:
+            env_mask = np.ascontiguousarray(env_mask, dtype=np.uint8)
+            mp = env_mask.ctypes.data_as(ctypes.c_void_p)
+        self._chk(self.lib.cc4_reset(self._h, sp, mp), 'cc4_reset')
+        return self._fetch(mask=True)[0]
+
+    def step(self, actions=None, messages=None):
+        """actions: int array [N,5] of wrapper indices (None / negative = no action -> Sleep)."""
+        ap = None
+        if actions is not None:
+            actions = np.ascontiguousarray(actions, dtype=np.int32)
+            assert actions.shape == (self.num_envs, L.NUM_BLUE)
+            ap = actions.ctypes.data_as(ctypes.c_void_p)
+        mp = None
+        if messages is not None:
+            messages = np.ascontiguousarray(messages, dtype=np.uint8)
+            assert messages.shape == (self.num_envs, L.NUM_BLUE, L.MSG_LEN)
+            mp = messages.ctypes.data_as(ctypes.c_void_p)
+        self._chk(self.lib.cc4_step(self._h, ap, mp), 'cc4_step')
+        obs, rew, done = self._fetch()
+        return obs, rew, done, {'err': self._err}
+
+    def _fetch(self, mask=False):
+        self._chk(self.lib.cc4_get_obs(self._h, self._obs.ctypes.data_as(ctypes.c_void_p)), 'cc4_get_obs')
+        self._chk(self.lib.cc4_get_reward_done(self._h, self._rew.ctypes.data_as(ctypes.c_void_p),
+                                               self._done.ctypes.data_as(ctypes.c_void_p)), 'cc4_get_reward_done')
+        self._chk(self.lib.cc4_get_err(self._h, self._err.ctypes.data_as(ctypes.c_void_p)), 'cc4_get_err')
+        if mask:
+            self._chk(self.lib.cc4_get_action_mask(self._h, self._mask.ctypes.data_as(ctypes.c_void_p)), 'cc4_get_action_mask')
+        if (self._err & (1 << 7)).any():
+            raise ValueError("Step number exceeds last mission phase step maximum. "
+                             "Use step parameter in EnterpriseScenarioGenerator.")  # State.py:539-540
+        return self._obs, self._rew, self._done.astype(bool)
+
+    @property
+    def action_mask(self):
+        return self._mask.astype(bool)
+
+    @property
+    def err(self):
+        return self._err
+
+    def rng_state(self):
+        out = np.zeros((self.num_envs, 7), np.uint64)
+        self._chk(self.lib.cc4_get_rng_state(self._h, out.ctypes.data_as(ctypes.c_void_p)), 'cc4_get_rng_state')
+        return out
+
+    def get_state(self, env):
+        buf = np.zeros(self.lib.cc4_state_bytes(), np.uint8)
+        self._chk(self.lib.cc4_get_state(self._h, int(env), buf.ctypes.data_as(ctypes.c_void_p)), 'cc4_get_state')
+        return buf
+
+    def set_state(self, env, buf):
+        buf = np.ascontiguousarray(buf, dtype=np.uint8)
+        assert buf.size == self.lib.cc4_state_bytes()
+        self._chk(self.lib.cc4_set_state(self._h, int(env), buf.ctypes.data_as(ctypes.c_void_p)), 'cc4_set_state')
+
+    # device-resident loop used by bench.py
+    def run_random_steps(self, seed0, t0, k, timed=True):
+        ms = ctypes.c_float(0.0)
+        self._chk(self.lib.cc4_run_random_steps(self._h, ctypes.c_uint64(seed0), ctypes.c_uint32(t0), int(k),
+                                                ctypes.byref(ms) if timed else None), 'cc4_run_random_steps')
+        return float(ms.value)
+
+    def synchronize(self):
+        self._chk(self.lib.cc4_synchronize(self._h), 'cc4_synchronize')
+
+
+def split_obs(obs):
+    """[N,578] -> list of 5 arrays [N,92|210] (agent order blue_agent_0..4)."""
+    return [obs[:, o:o + n] for o, n in zip(L.OBS_OFF, L.OBS_LEN)]
+
+
+def split_mask(mask):
+    return [mask[:, o:o + n] for o, n in zip(L.ACT_OFF, L.ACT_LEN)]
+
+
+def shard_range(num_envs, rank, world):
+    """Static env sharding for multi-GPU runs: contiguous ranges [lo, hi)."""
+    per = num_envs // world
+    rem = num_envs % world
+    lo = rank * per + min(rank, rem)
+    return lo, lo + per + (1 if rank < rem else 0)

@@ -11,6 +11,7 @@
 // from /root/reference in the build container): per-step flat observations, rewards, dones and the PCG64
 // stream position.  tests/test_oracle_golden.py checks that on CPU; tests/test_hip_parity.py then checks
 // the HIP path both against this oracle and directly against the same golden files.
+#include <stddef.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -69,6 +70,23 @@ void cc4o_mask(void* h, int i, uint8_t* out) { blue_action_mask(&((Oracle*)h)->s
 void cc4o_rng_state(void* h, int i, uint64_t* out /* s_hi s_lo inc_hi inc_lo has32 u32 ndraw */) {
   const Rng& r = ((Oracle*)h)->st[i].rng;
   out[0] = r.s_hi; out[1] = r.s_lo; out[2] = r.inc_hi; out[3] = r.inc_lo; out[4] = r.has32; out[5] = r.u32; out[6] = r.ndraw;
+}
+
+// "name offset" lines for EnvState members (maps a differing byte offset back to a field when bisecting)
+int cc4o_layout(char* buf, int cap) {
+  int n = 0;
+#define F(m) n += snprintf(buf + n, cap - n, #m " %zu\n", offsetof(EnvState, m))
+  F(rng); F(step_count); F(steps); F(phase); F(phase_len); F(err); F(reward); F(done); F(blocks); F(cidr_octet); F(n_users);
+  F(n_servers); F(green_host); F(green_act); F(blue_pid); F(green_pid); F(pend); F(npend); F(hs); F(hd); F(blue); F(red);
+  F(msg); F(kb_used);
+#undef F
+#define G(m) n += snprintf(buf + n, cap - n, "red." #m " %zu\n", offsetof(RedAgent, m))
+  G(sess); G(known_sid); G(fsm_order); G(fsm_state); G(fsm_hn); G(as_ip); G(as_hn); G(obs); G(queue); G(chosen); G(as_subnet);
+  G(fsm_step); G(nsess); G(active); G(obs_success); G(exec_type); G(new_sess_host); G(new_sess_id); G(start_host);
+#undef G
+  n += snprintf(buf + n, cap - n, "sizeof.RedAgent %zu\nsizeof.BlueAgent %zu\nsizeof.HostDyn %zu\nsizeof.HostStatic %zu\nsizeof.EnvState %zu\n",
+                sizeof(RedAgent), sizeof(BlueAgent), sizeof(HostDyn), sizeof(HostStatic), sizeof(EnvState));
+  return n;
 }
 
 // canonical text dump of one episode's state (parity bisecting against oracle/refgen/ref_dump.py)

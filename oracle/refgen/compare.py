@@ -14,7 +14,7 @@ RED_QT = {'DiscoverRemoteSystems': 0, 'AggressiveServiceDiscovery': 1, 'StealthS
           'ExploitRemoteService': 4, 'PrivilegeEscalate': 5, 'Impact': 6, 'DegradeServices': 7, 'Withdraw': 8, 'Sleep': 9,
           'InvalidAction': 10}
 
-lib = ctypes.CDLL(os.path.join(os.path.dirname(__file__), '..', 'liboracle.so'))
+lib = ctypes.CDLL(os.environ.get('CC4_ORACLE_LIB') or os.path.join(os.path.dirname(__file__), '..', 'liboracle.so'))
 lib.cc4o_create.restype = ctypes.c_void_p
 lib.cc4o_reward.restype = ctypes.c_float
 for f in ('cc4o_reset', 'cc4o_step', 'cc4o_obs', 'cc4o_reward', 'cc4o_done', 'cc4o_err', 'cc4o_mask', 'cc4o_rng_state', 'cc4o_dump'):

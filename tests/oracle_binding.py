@@ -1,0 +1,139 @@
+"""ctypes binding of oracle/liboracle.so -- the CPU oracle (TEST INFRASTRUCTURE).
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg import this module.  The product package
+(cage_challenge_4_amd) never does."""
+import ctypes
+import os
+import subprocess
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ORACLE_DIR = os.path.join(ROOT, 'oracle')
+LIB = os.path.join(ORACLE_DIR, 'liboracle.so')
+
+
+def build():
+    subprocess.check_call(['make', '-C', ORACLE_DIR, '-s'])
+
+
+def load():
+    if not os.path.exists(LIB):
+        build()
+    lib = ctypes.CDLL(LIB)
+    lib.cc4o_create.restype = ctypes.c_void_p
+    lib.cc4o_create.argtypes = [ctypes.c_int]
+    lib.cc4o_destroy.argtypes = [ctypes.c_void_p]
+    lib.cc4o_reset.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_uint64, ctypes.c_int, ctypes.c_int, ctypes.c_int]
+    lib.cc4o_step.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]
+    lib.cc4o_step_all.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
+    lib.cc4o_obs.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]
+    lib.cc4o_reward.restype = ctypes.c_float
+    lib.cc4o_reward.argtypes = [ctypes.c_void_p, ctypes.c_int]
+    lib.cc4o_done.argtypes = [ctypes.c_void_p, ctypes.c_int]
+    lib.cc4o_err.restype = ctypes.c_uint32
+    lib.cc4o_err.argtypes = [ctypes.c_void_p, ctypes.c_int]
+    lib.cc4o_mask.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]
+    lib.cc4o_rng_state.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]
+    lib.cc4o_state_bytes.restype = ctypes.c_size_t
+    lib.cc4o_state_ptr.restype = ctypes.c_void_p
+    lib.cc4o_state_ptr.argtypes = [ctypes.c_void_p, ctypes.c_int]
+    lib.cc4o_dump.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_int]
+    return lib
+
+
+class OracleVecEnv:
+    """Same call shape as cage_challenge_4_amd.CC4VecEnv, stepping episodes serially on the host."""
+    def __init__(self, num_envs, steps=500, rng_mode=0, autoreset=False):
+        self.lib = load()
+        self.num_envs = num_envs
+        self.steps = steps
+        self.rng_mode = rng_mode
+        self.autoreset = autoreset
+        self._h = ctypes.c_void_p(self.lib.cc4o_create(num_envs))
+        self._obs = np.zeros((num_envs, 578), np.int32)
+        self._rew = np.zeros(num_envs, np.float32)
+        self._done = np.zeros(num_envs, bool)
+        self._err = np.zeros(num_envs, np.uint32)
+
+    def close(self):
+        if self._h:
+            self.lib.cc4o_destroy(self._h)
+            self._h = None
+
+    def _collect(self, i, reward=True):
+        self.lib.cc4o_obs(self._h, i, self._obs[i].ctypes.data_as(ctypes.c_void_p))
+        self._rew[i] = self.lib.cc4o_reward(self._h, i) if reward else 0.0
+        self._done[i] = bool(self.lib.cc4o_done(self._h, i))
+        self._err[i] = self.lib.cc4o_err(self._h, i)
+
+    def reset(self, seeds=None, env_mask=None):
+        if seeds is not None and np.isscalar(seeds):
+            seeds = np.uint64(seeds) + np.arange(self.num_envs, dtype=np.uint64)
+        for i in range(self.num_envs):
+            if env_mask is not None and not env_mask[i]:
+                continue
+            if seeds is None:
+                self.lib.cc4o_reset(self._h, i, 0, self.rng_mode, self.steps, 1)
+            else:
+                self.lib.cc4o_reset(self._h, i, ctypes.c_uint64(int(seeds[i])), self.rng_mode, self.steps, 0)
+            self._collect(i, reward=False)
+        return self._obs
+
+    def step(self, actions=None, messages=None):
+        for i in range(self.num_envs):
+            if self.autoreset and self._done[i]:
+                self.lib.cc4o_reset(self._h, i, 0, self.rng_mode, self.steps, 1)
+                self._collect(i, reward=False)
+                continue
+            a = None if actions is None else np.ascontiguousarray(actions[i], np.int32)
+            m = None if messages is None else np.ascontiguousarray(messages[i], np.uint8)
+            self.lib.cc4o_step(self._h, i, None if a is None else a.ctypes.data_as(ctypes.c_void_p),
+                               None if m is None else m.ctypes.data_as(ctypes.c_void_p))
+            self._collect(i)
+        return self._obs, self._rew, self._done, {'err': self._err}
+
+    def mask(self):
+        m = np.zeros((self.num_envs, 570), np.uint8)
+        for i in range(self.num_envs):
+            self.lib.cc4o_mask(self._h, i, m[i].ctypes.data_as(ctypes.c_void_p))
+        return m.astype(bool)
+
+    def rng_state(self):
+        out = np.zeros((self.num_envs, 7), np.uint64)
+        for i in range(self.num_envs):
+            self.lib.cc4o_rng_state(self._h, i, out[i].ctypes.data_as(ctypes.c_void_p))
+        return out
+
+    def get_state(self, i):
+        n = self.lib.cc4o_state_bytes()
+        p = self.lib.cc4o_state_ptr(self._h, i)
+        return np.frombuffer((ctypes.c_uint8 * n).from_address(p), np.uint8).copy()
+
+    def dump(self, i):
+        buf = ctypes.create_string_buffer(1 << 20)
+        n = self.lib.cc4o_dump(self._h, i, buf, len(buf))
+        return buf.raw[:n].decode()
+
+
+def random_actions(seed0, t, num_envs):
+    """Host restatement of k_random_actions (csrc/cc4_hip.hip): Philox4x32-10 key (seed0+env), counter (t, agent, 0xB10E, 0)."""
+    M0, M1, W0, W1 = 0xD2511F53, 0xCD9E8D57, 0x9E3779B9, 0xBB67AE85
+    e = np.arange(num_envs, dtype=np.uint64)[:, None] + np.uint64(seed0)
+    b = np.arange(5, dtype=np.uint64)[None, :]
+    c = [np.full((num_envs, 5), t, np.uint64), np.broadcast_to(b, (num_envs, 5)).copy(),
+         np.full((num_envs, 5), 0xB10E, np.uint64), np.zeros((num_envs, 5), np.uint64)]
+    k0 = np.broadcast_to(e & np.uint64(0xFFFFFFFF), (num_envs, 5)).copy()
+    k1 = np.broadcast_to(e >> np.uint64(32), (num_envs, 5)).copy()
+    mask = np.uint64(0xFFFFFFFF)
+    for _ in range(10):
+        p0 = np.uint64(M0) * c[0]
+        p1 = np.uint64(M1) * c[2]
+        n0 = ((p1 >> np.uint64(32)) ^ c[1] ^ k0) & mask
+        n1 = p1 & mask
+        n2 = ((p0 >> np.uint64(32)) ^ c[3] ^ k1) & mask
+        n3 = p0 & mask
+        c = [n0, n1, n2, n3]
+        k0 = (k0 + np.uint64(W0)) & mask
+        k1 = (k1 + np.uint64(W1)) & mask
+    rng = np.array([82, 82, 82, 82, 242], np.uint64)[None, :]
+    return ((c[0] * rng) >> np.uint64(32)).astype(np.int32)
