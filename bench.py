@@ -1,0 +1,151 @@
+#!/usr/bin/env python
+"""bench.py -- BASELINE.json's metric: aggregate agent-env steps/s (5 blue agents x envs) of the CC4 step engine.
+
+    python bench.py --gpus N --steps K --warmup W
+    (N>1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+
+A "step" is one pass of the hot path over one batch: device-side uniform random blue actions -> k_step over the
+rank's shard (reset / full SimulationController.step transition / reward / flat observations) [-> RCCL all-gather of
+the observations when N>1].  Workload at every N: BASELINE configs[1] per GPU = 1024 concurrent episodes per GPU
+(weak scaling: 8 GPUs = configs[3], 8192 episodes), EnterpriseScenarioGenerator(steps=500), FiniteStateRedAgent red,
+EnterpriseGreenAgent green, numpy-PCG64-compatible RNG (bit-exact with the reference), autoreset on done so the
+timed region includes the scenario regeneration of finished episodes.  Inputs (state, actions) are resident in HBM.
+
+Prints ONE JSON line on rank 0.  `roofline` = algorithmic bytes per k_step launch / mean launch duration from HIP
+events recorded on the launch stream inside the timed region; `cpu_baseline` = the CPU oracle (kind "port": the
+host build of the same restatement, OpenMP over episodes) on a bounded sample of the same workload, rank 0, N=1 only.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBPS = 8000.0      # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
+
+
+def cpu_baseline(envs, seed0, budget_s=12.0):
+    """Oracle (oracle/liboracle.so) on the host cores: same seeds, same action generator, bounded sample."""
+    sys.path.insert(0, os.path.join(ROOT, 'tests'))
+    import ctypes
+    import numpy as np
+    from oracle_binding import OracleVecEnv, random_actions
+    ora = OracleVecEnv(envs, steps=500)
+    ora.reset(seeds=seed0)
+    cores = int(ora.lib.cc4o_num_threads())
+
+    def run(t0, k):
+        acts = [np.ascontiguousarray(random_actions(seed0, t0 + i, envs)) for i in range(k)]
+        t = time.perf_counter()
+        for a in acts:
+            ora.lib.cc4o_step_all(ora._h, a.ctypes.data_as(ctypes.c_void_p))
+        return time.perf_counter() - t
+
+    probe = run(0, 10)
+    k = int(max(10, min(480, budget_s / max(probe / 10, 1e-6))))
+    dt = run(10, k)
+    ora.close()
+    return {'value': 5.0 * envs * k / dt, 'unit': 'agent-env steps/s', 'cores': cores, 'kind': 'port',
+            'sample': f'{envs} episodes x {k} steps (steps 10..{10 + k} of the same seeded workload), OpenMP over episodes'}
+
+
+def load_pmc_traffic():
+    """HBM bytes per k_step launch from the committed rocprofv3 --pmc passes (profiles/r01_pmc.json), or None."""
+    p = os.path.join(ROOT, 'profiles', 'r01_pmc.json')
+    try:
+        with open(p) as f:
+            return json.load(f).get('hbm_bytes_per_launch_1024env')
+    except Exception:
+        return None
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=1500)
+    ap.add_argument('--warmup', type=int, default=100)
+    ap.add_argument('--envs-per-gpu', type=int, default=1024)
+    ap.add_argument('--episode-steps', type=int, default=500)
+    ap.add_argument('--rng', choices=['pcg64', 'philox'], default='pcg64')
+    ap.add_argument('--seed0', type=int, default=1000)
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    args = ap.parse_args()
+
+    from cage_challenge_4_amd import CC4VecEnv, RNG_PCG64, RNG_PHILOX
+    from cage_challenge_4_amd import distributed as D
+
+    rank, world, local = D.env_rank_world()
+    if args.gpus > 1 and world != args.gpus:
+        raise SystemExit(f'--gpus {args.gpus} needs torch.distributed.run with --nproc-per-node {args.gpus} (WORLD_SIZE={world})')
+    if world > 1:
+        D.init_control_plane('gloo')
+        import torch
+        import torch.distributed as dist
+    n_local = args.envs_per_gpu
+    total_envs = n_local * world
+    env = CC4VecEnv(n_local, steps=args.episode_steps, rng_mode=RNG_PCG64 if args.rng == 'pcg64' else RNG_PHILOX,
+                    device_id=local if world > 1 else 0, autoreset=True)
+    lo = rank * n_local
+    import numpy as np
+    env.reset(seeds=np.uint64(args.seed0) + np.arange(lo, lo + n_local, dtype=np.uint64))
+    if world > 1:
+        D.init_rccl(env, rank, world)
+    seed_actions = args.seed0 + lo            # action key = seed0 + global episode index
+
+    env.run_random_steps(seed_actions, 0, args.warmup, timed=False)
+    env.synchronize()
+    if world > 1:
+        dist.barrier()
+    t0 = time.perf_counter()
+    ms_kernels = env.run_random_steps(seed_actions, args.warmup, args.steps, timed=True)   # syncs the stream at the end
+    env.synchronize()
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt, ms_kernels], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt, ms_kernels = float(t[0]), float(t[1])
+    err_any = bool(env.err.any()) if False else False
+    env._fetch()
+    err_any = bool(env.err.any())
+
+    if rank == 0:
+        bytes_per_env = int(env.lib.cc4_algorithmic_bytes_per_env_step())
+        launch_ms = ms_kernels / args.steps
+        achieved = bytes_per_env * n_local / (launch_ms * 1e-3) / 1e9
+        traffic = load_pmc_traffic() if n_local == 1024 else None
+        out = {
+            'metric': 'agent-env steps/sec (5 blue agents x N envs)',
+            'value': 5.0 * total_envs * args.steps / dt,
+            'unit': 'agent-env steps/s',
+            'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+            'ms_per_step': dt / args.steps * 1e3,
+            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+            'dtype': 'int32', 'data': 'synthetic',
+            'config': {
+                'workload': f'{n_local} vectorised envs per GPU ({total_envs} total), uniform random blue actions '
+                            f'(82/82/82/82/242 incl. invalid slots), FiniteStateRedAgent, EnterpriseGreenAgent, '
+                            f'EnterpriseScenarioGenerator(steps={args.episode_steps}), autoreset incl. scenario regeneration',
+                'envs_per_gpu': n_local, 'total_envs': total_envs, 'rng': args.rng,
+                'exchange': 'RCCL all-gather of [N,578] int32 obs per step' if world > 1 else 'none',
+                'env_steps_per_sec': total_envs * args.steps / dt, 'engine_error_flags': err_any,
+            },
+            'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBPS, 'unit': 'GB/s',
+                         'frac': achieved / HBM_PEAK_GBPS, 'traffic': traffic,
+                         'kernel': 'k_step', 'launch_ms': launch_ms, 'algorithmic_bytes_per_launch': bytes_per_env * n_local},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out['cpu_baseline'] = cpu_baseline(n_local, args.seed0)
+        print(json.dumps(out), flush=True)
+    env.close()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

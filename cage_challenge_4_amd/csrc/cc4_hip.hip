@@ -12,6 +12,7 @@
 #include <stdlib.h>
 #include <string.h>
 #include <string>
+#include <vector>
 
 #include "../../include/cc4.h"
 #include "cc4_engine.h"
@@ -116,6 +117,7 @@ struct cc4_handle {
   int32_t* d_all_obs = nullptr;
   ncclComm_t comm = nullptr; int rank = 0, world = 1;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  std::vector<hipEvent_t> evs;
   std::string err;
 };
 
@@ -193,6 +195,7 @@ void cc4_destroy(cc4_handle* h) {
   void* ptrs[] = {h->d_state, h->d_cold, h->d_actions, h->d_msgs, h->d_seeds, h->d_envmask, h->d_obs, h->d_reward,
                   h->d_done, h->d_err, h->d_mask, h->d_rng, h->d_all_obs};
   for (void* p : ptrs) if (p) (void)hipFree(p);
+  for (hipEvent_t e : h->evs) if (e) (void)hipEventDestroy(e);
   if (h->ev0) (void)hipEventDestroy(h->ev0);
   if (h->ev1) (void)hipEventDestroy(h->ev1);
   if (h->stream) (void)hipStreamDestroy(h->stream);
@@ -281,21 +284,30 @@ int cc4_synchronize(cc4_handle* h) {
 }
 int cc4_run_random_steps(cc4_handle* h, uint64_t seed0, uint32_t t0, int32_t k, float* ms_step_kernels) {
   HIPCHK(h, hipSetDevice(h->cfg.device_id));
-  float total = 0.f;
+  // one event pair per step-kernel launch, recorded on the launch stream and read back after the loop:
+  // no host synchronisation inside the timed region
+  if (ms_step_kernels && (int)h->evs.size() < 2 * k) {
+    size_t old = h->evs.size();
+    h->evs.resize(2 * (size_t)k, nullptr);
+    for (size_t i = old; i < h->evs.size(); ++i) HIPCHK(h, hipEventCreate(&h->evs[i]));
+  }
   for (int i = 0; i < k; ++i) {
     if (cc4_random_actions_device(h, seed0, t0 + (uint32_t)i)) return -1;
-    if (ms_step_kernels) HIPCHK(h, hipEventRecord(h->ev0, h->stream));
+    if (ms_step_kernels) HIPCHK(h, hipEventRecord(h->evs[2 * i], h->stream));
     if (launch_step(h, h->d_actions, nullptr)) return -1;
-    if (ms_step_kernels) {
-      HIPCHK(h, hipEventRecord(h->ev1, h->stream));
-      HIPCHK(h, hipEventSynchronize(h->ev1));
-      float ms = 0.f;
-      HIPCHK(h, hipEventElapsedTime(&ms, h->ev0, h->ev1));
-      total += ms;
-    }
+    if (ms_step_kernels) HIPCHK(h, hipEventRecord(h->evs[2 * i + 1], h->stream));
+    if (h->comm) { if (cc4_allgather_obs(h, nullptr)) return -1; }
   }
   HIPCHK(h, hipStreamSynchronize(h->stream));
-  if (ms_step_kernels) *ms_step_kernels = total;
+  if (ms_step_kernels) {
+    float total = 0.f;
+    for (int i = 0; i < k; ++i) {
+      float ms = 0.f;
+      HIPCHK(h, hipEventElapsedTime(&ms, h->evs[2 * i], h->evs[2 * i + 1]));
+      total += ms;
+    }
+    *ms_step_kernels = total;
+  }
   return 0;
 }
 

@@ -1,0 +1,65 @@
+"""Multi-GPU plumbing: one process per GPU, the env batch sharded statically across ranks (no data-path collective in
+the step itself); the single exchange step is the all-gather of the flat observations, done natively over RCCL/xGMI
+by libcc4 (cc4_allgather_obs).  torch.distributed (gloo) is only the control plane: rendezvous, the RCCL unique-id
+broadcast, barriers and the max-over-ranks timing reduction."""
+import ctypes
+import os
+import numpy as np
+from .vec_env import shard_range
+
+
+def env_rank_world():
+    return int(os.environ.get('RANK', 0)), int(os.environ.get('WORLD_SIZE', 1)), int(os.environ.get('LOCAL_RANK', 0))
+
+
+def init_control_plane(backend='gloo'):
+    """Initialise torch.distributed from the torchrun environment (MASTER_ADDR/PORT, RANK, WORLD_SIZE)."""
+    import torch.distributed as dist
+    rank, world, local = env_rank_world()
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+    return rank, world, local
+
+
+def shard_seeds(seed0, num_envs_total, rank, world):
+    """Episode e of the global batch is always seeded seed0 + e, whatever the sharding."""
+    lo, hi = shard_range(num_envs_total, rank, world)
+    return lo, hi, np.uint64(seed0) + np.arange(lo, hi, dtype=np.uint64)
+
+
+def allgather_host(local, world):
+    """Concatenate equally-shaped numpy shards in rank order through the control plane (CPU tests, small metadata)."""
+    if world == 1:
+        return local.copy()
+    import torch
+    import torch.distributed as dist
+    t = torch.from_numpy(np.ascontiguousarray(local))
+    out = [torch.empty_like(t) for _ in range(world)]
+    dist.all_gather(out, t)
+    return np.concatenate([o.numpy() for o in out], axis=0)
+
+
+def init_rccl(vec_env, rank, world):
+    """Create the RCCL communicator inside libcc4 for this rank's handle (unique id travels over the control plane)."""
+    import torch
+    import torch.distributed as dist
+    ident = torch.zeros(128, dtype=torch.uint8)
+    if rank == 0:
+        buf = (ctypes.c_uint8 * 128)()
+        rc = vec_env.lib.cc4_comm_unique_id(buf)
+        if rc != 0:
+            raise RuntimeError('cc4_comm_unique_id failed')
+        ident = torch.tensor(list(buf), dtype=torch.uint8)
+    if world > 1:
+        dist.broadcast(ident, src=0)
+    raw = (ctypes.c_uint8 * 128)(*ident.tolist())
+    vec_env._chk(vec_env.lib.cc4_comm_init(vec_env._h, rank, world, raw), 'cc4_comm_init')
+
+
+def allgather_obs_device(vec_env):
+    """Enqueue the RCCL all-gather of this rank's [N,578] int32 observations on the handle's stream; returns the
+    device pointer of the [world*N,578] result (valid after vec_env.synchronize())."""
+    p = ctypes.c_void_p()
+    vec_env._chk(vec_env.lib.cc4_allgather_obs(vec_env._h, ctypes.byref(p)), 'cc4_allgather_obs')
+    return p.value

@@ -16,6 +16,9 @@
 #include <stdlib.h>
 #include <string.h>
 #include <vector>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
 #include "../cage_challenge_4_amd/csrc/cc4_engine.h"
 
 using namespace cc4;
@@ -62,6 +65,13 @@ void cc4o_step_all(void* h, const int32_t* actions /* [n][5] */) {
     env_step(x, actions + 5 * i, nullptr);
   }
 }
+int cc4o_num_threads() {
+#ifdef _OPENMP
+  return omp_get_max_threads();
+#else
+  return 1;
+#endif
+}
 void cc4o_obs(void* h, int i, int32_t* out) { env_flat_obs<int32_t>(&((Oracle*)h)->st[i], out); }
 float cc4o_reward(void* h, int i) { return ((Oracle*)h)->st[i].reward; }
 int cc4o_done(void* h, int i) { return ((Oracle*)h)->st[i].done; }
@@ -70,6 +80,21 @@ void cc4o_mask(void* h, int i, uint8_t* out) { blue_action_mask(&((Oracle*)h)->s
 void cc4o_rng_state(void* h, int i, uint64_t* out /* s_hi s_lo inc_hi inc_lo has32 u32 ndraw */) {
   const Rng& r = ((Oracle*)h)->st[i].rng;
   out[0] = r.s_hi; out[1] = r.s_lo; out[2] = r.inc_hi; out[3] = r.inc_lo; out[4] = r.has32; out[5] = r.u32; out[6] = r.ndraw;
+}
+
+// RNG conformance hook: run a script of draws on a fresh stream. ops: 0 random() 1 below(arg) 2 shuffle_consume(arg)
+// 3 next64 4 next32. out receives the value (doubles bit-cast) per op.
+void cc4o_rng_script(uint64_t seed, int mode, int n, const int32_t* ops, const uint32_t* args, uint64_t* out) {
+  Rng r; rng_seed(&r, seed, (uint32_t)mode);
+  for (int i = 0; i < n; ++i) {
+    switch (ops[i]) {
+      case 0: { double d = rng_random(&r); memcpy(&out[i], &d, 8); break; }
+      case 1: out[i] = rng_below(&r, args[i]); break;
+      case 2: rng_shuffle_consume(&r, (int)args[i]); out[i] = 0; break;
+      case 3: out[i] = rng_next64(&r); break;
+      default: out[i] = rng_next32(&r); break;
+    }
+  }
 }
 
 // "name offset" lines for EnvState members (maps a differing byte offset back to a field when bisecting)

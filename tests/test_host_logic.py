@@ -1,0 +1,61 @@
+"""CPU: host-side logic that needs no device -- sharding, observation/mask splitting, naming, spaces, argument checks."""
+import numpy as np
+import pytest
+from cage_challenge_4_amd import shard_range, split_obs, split_mask
+from cage_challenge_4_amd import wrappers as W
+from cage_challenge_4_amd.spaces import Discrete, MultiDiscrete, MultiBinary
+from oracle_binding import random_actions
+
+
+def test_shard_range_partitions_exactly():
+    for n in (1, 7, 8, 1000, 8192):
+        for world in (1, 2, 3, 8):
+            spans = [shard_range(n, r, world) for r in range(world)]
+            assert spans[0][0] == 0 and spans[-1][1] == n
+            assert all(spans[i][1] == spans[i + 1][0] for i in range(world - 1))
+            sizes = [b - a for a, b in spans]
+            assert max(sizes) - min(sizes) <= 1
+
+
+def test_split_layouts():
+    obs = np.arange(3 * 578).reshape(3, 578)
+    parts = split_obs(obs)
+    assert [p.shape[1] for p in parts] == [92, 92, 92, 92, 210]
+    assert parts[4][0, 0] == 368
+    m = split_mask(np.zeros((2, 570), bool))
+    assert [p.shape[1] for p in m] == [82, 82, 82, 82, 242]
+
+
+def test_host_names_follow_reference_scheme():
+    assert W.host_name(136) == 'root_internet_host_0'
+    assert W.host_name(0) == 'restricted_zone_a_subnet_router'
+    assert W.host_name(1) == 'restricted_zone_a_subnet_user_host_0'
+    assert W.host_name(11) == 'restricted_zone_a_subnet_server_host_0'
+    assert W.host_name(4 * 17 + 16) == 'contractor_network_subnet_server_host_5'
+
+
+def test_scenario_generator_signature_and_constants():
+    sg = W.EnterpriseScenarioGenerator(blue_agent_class=W.SleepAgent, green_agent_class=W.EnterpriseGreenAgent,
+                                       red_agent_class=W.FiniteStateRedAgent, steps=500)
+    assert (sg.MIN_USER_HOSTS, sg.MAX_USER_HOSTS, sg.MIN_SERVER_HOSTS, sg.MAX_SERVER_HOSTS) == (3, 10, 1, 6)
+    assert sg.MESSAGE_LENGTH == 8 and sg.steps == 500
+    with pytest.raises(NotImplementedError):
+        W.EnterpriseScenarioGenerator(blue_agent_class=W.SleepAgent, green_agent_class=W.SleepAgent,
+                                      red_agent_class=W.FiniteStateRedAgent)
+
+
+def test_spaces():
+    assert Discrete(82).contains(81) and not Discrete(82).contains(82)
+    md = MultiDiscrete([3] + [2] * 91)
+    assert len(md) == 92 and md.contains(np.zeros(92, int))
+    assert MultiBinary(8).contains(np.ones(8, bool)) and not MultiBinary(8).contains(np.ones(7, bool))
+
+
+def test_random_action_generator_ranges_and_determinism():
+    a = random_actions(1000, 3, 4096)
+    assert a.shape == (4096, 5) and a.min() >= 0
+    assert a[:, :4].max() <= 81 and a[:, 4].max() <= 241 and a[:, 4].max() > 200
+    assert np.array_equal(a, random_actions(1000, 3, 4096))
+    assert not np.array_equal(a, random_actions(1000, 4, 4096))
+    # shard-invariance: env e draws the same action whatever batch it sits in
+    assert np.array_equal(random_actions(1000 + 100, 3, 10), a[100:110])

@@ -1,0 +1,152 @@
+"""CPU: behaviours the reference's own tests pin (CybORG/Tests/test_cc4/*), re-expressed against the oracle.
+Each test names the reference test it follows."""
+import numpy as np
+import pytest
+from oracle_binding import OracleVecEnv
+
+SORTED_SUBNETS = ['admin', 'contractor', 'internet', 'office', 'operational_a', 'operational_b', 'public_access',
+                  'restricted_a', 'restricted_b']
+
+
+def make(seed=123, steps=100, n=1):
+    env = OracleVecEnv(n, steps=steps)
+    env.reset(seeds=np.uint64(seed) + np.arange(n, dtype=np.uint64))
+    return env
+
+
+def sleep(n=1):
+    return np.full((n, 5), -1, np.int32)
+
+
+@pytest.mark.parametrize('steps,split', [(3, (1, 1, 1)), (10, (4, 3, 3)), (11, (4, 4, 3)), (100, (34, 33, 33))])
+def test_mission_phase_split(steps, split):
+    # test_mission_phase.py:95-190: phase index in obs[0] changes exactly at the split points; stepping past `steps` raises
+    env = make(steps=steps)
+    phases = []
+    for t in range(steps):
+        obs, *_ = env.step(sleep())
+        phases.append(int(obs[0, 0]))
+    want = [0] * split[0] + [1] * split[1] + [2] * split[2]
+    assert phases == want
+    *_, info = env.step(sleep())
+    assert info['err'][0] & (1 << 7)       # reference: ValueError (State.py:539-540)
+
+
+def test_done_turns_true_at_steps_minus_one():
+    # EnterpriseScenarioGenerator.determine_done (ESG.py:862-870)
+    env = make(steps=6)
+    dones = [bool(env.step(sleep())[2][0]) for _ in range(6)]
+    assert dones == [False, False, False, False, True, True]
+
+
+def test_observation_layout_and_invariants():
+    # test_BlueEnterpriseWrapper.py:30-45 slice layout
+    env = make(seed=5, steps=50, n=8)
+    rs = np.random.default_rng(0)
+    for t in range(50):
+        a = np.stack([rs.integers(0, 82, 8), rs.integers(0, 82, 8), rs.integers(0, 82, 8), rs.integers(0, 82, 8), rs.integers(0, 242, 8)], 1)
+        obs, rew, done, info = env.step(a.astype(np.int32))
+        assert info['err'].max() == 0
+        for b, off, ns in ((0, 0, 1), (1, 92, 1), (2, 184, 1), (3, 276, 1), (4, 368, 3)):
+            v = obs[:, off:off + (92 if ns == 1 else 210)]
+            assert ((v[:, 0] >= 0) & (v[:, 0] <= 2)).all()
+            assert ((v[:, 1:] == 0) | (v[:, 1:] == 1)).all()
+            for k in range(ns):
+                blk = v[:, 1 + 59 * k: 1 + 59 * (k + 1)]
+                assert (blk[:, 0:9].sum(1) == 1).all()                       # own-subnet one-hot
+                own = blk[:, 0:9].argmax(1)
+                assert (blk[np.arange(8), 18 + own] == 1).all()             # comms policy: self bit is 1 (App. D)
+                assert (blk[np.arange(8), 9 + own] == 0).all()              # a subnet never blocks itself
+        assert (rew <= 0).all()
+
+
+def test_own_subnet_positions_match_sorted_names():
+    env = make()
+    obs = env.reset(seeds=np.array([9], np.uint64))
+    # agents 0..3: restricted_a, operational_a, restricted_b, operational_b ; agent 4: admin, office, public_access
+    want = [[7], [4], [8], [5], [0, 3, 6]]
+    for b, off in enumerate((0, 92, 184, 276, 368)):
+        for k, pos in enumerate(want[b]):
+            blk = obs[0, off + 1 + 59 * k: off + 1 + 59 * (k + 1)]
+            assert blk[0:9].argmax() == pos
+
+
+def test_block_and_allow_traffic_zone_bits():
+    # test_BlueEnterpriseWrapper.py:232-254: after BlockTrafficZone the blocked bit of the source subnet is set
+    env = make(seed=11)
+    a = sleep()
+    a[0, 0] = 58 + 2        # agent 0 (restricted_zone_a): Block <- third other subnet in sorted order = internet
+    obs, *_ = env.step(a)
+    blk = obs[0, 1:60]
+    assert blk[9:18].tolist() == [0, 0, 1, 0, 0, 0, 0, 0, 0]
+    a[0, 0] = 50 + 2        # Allow <- internet
+    obs, *_ = env.step(a)
+    assert obs[0, 1 + 9: 1 + 18].sum() == 0
+
+
+def test_restore_costs_minus_one_on_submission_even_when_busy():
+    # SURVEY Appendix B.3 (SimulationController.py:310), test_priority.py / README reward table
+    env = make(seed=2)
+    mask = env.mask()[0]
+    idx = 33 + int(np.argmax(mask[33:49]))          # first valid Restore slot of agent 0
+    base = OracleVecEnv(1, steps=100); base.reset(seeds=np.array([2], np.uint64))
+    a = sleep(); a[0, 0] = idx
+    for t in range(3):                              # Restore lasts 5 ticks: agent is busy on ticks 2,3
+        r1 = env.step(a)[1][0]
+        r0 = base.step(sleep())[1][0]
+        assert r1 <= r0 - 1 + 1e-6 or t > 0        # first tick exactly -1 apart (same stream so far)
+        if t == 0:
+            assert r1 == r0 - 1.0
+
+
+def test_invalid_host_slot_is_sleep_and_free():
+    # BlueFixedActionWrapper.py:295-298: invalid slots map to Sleep (cost 0, no RNG)
+    env = make(seed=4); ref = make(seed=4)
+    mask = env.mask()[0]
+    invalid = [i for i in range(33, 49) if not mask[i]]
+    if not invalid:
+        pytest.skip('zone is full at this seed')
+    a = sleep(); a[0, 0] = invalid[0]
+    for _ in range(5):
+        o1, r1, *_ = env.step(a)
+        o0, r0, *_ = ref.step(sleep())
+        assert np.array_equal(o1, o0) and r1[0] == r0[0]
+    assert np.array_equal(env.rng_state(), ref.rng_state())
+
+
+def test_same_seed_same_trajectory_different_seed_differs():
+    # test_cc4_seed.py:16-31 (stronger: whole observation stream)
+    a, b, c = make(seed=77, steps=60), make(seed=77, steps=60), make(seed=78, steps=60)
+    same, diff = True, False
+    for _ in range(60):
+        oa, ra, *_ = a.step(sleep()); ob, rb, *_ = b.step(sleep()); oc, rc, *_ = c.step(sleep())
+        same &= np.array_equal(oa, ob) and ra[0] == rb[0]
+        diff |= (not np.array_equal(oa, oc)) or ra[0] != rc[0]
+    assert same and diff
+
+
+def test_host_and_server_counts_within_readme_bounds():
+    # test_Acceptance: 3..10 user hosts, 1..6 servers per subnet -> mask counts per zone
+    env = make(seed=1, n=16)
+    m = env.mask()
+    for e in range(16):
+        for b, off in enumerate((0, 82, 164, 246)):
+            hosts = m[e, off:off + 16]                       # Analyse block: servers 0..5 then users 0..9
+            assert 1 <= hosts[:6].sum() <= 6 and 3 <= hosts[6:].sum() <= 10
+            assert hosts[0] and hosts[6]                     # server_host_0 / user_host_0 always exist
+            assert m[e, off + 16] and m[e, off + 49]         # Monitor, Sleep
+            assert m[e, off + 50:off + 66].all()             # Allow/Block always valid
+
+
+def test_soak_regression_seeds_run_clean():
+    # test_heuristic_agents.py:10-84 crash-regression seeds, random blue incl. invalid slots, 500 steps
+    seeds = [6065, 5712, 9283, 3669, 4095, 87, 1148, 2742, 9556, 2812, 9251]
+    env = OracleVecEnv(len(seeds), steps=500)
+    env.reset(seeds=np.array(seeds, np.uint64))
+    rs = np.random.default_rng(1)
+    n = len(seeds)
+    for t in range(500):
+        a = np.stack([rs.integers(0, 82, n), rs.integers(0, 82, n), rs.integers(0, 82, n), rs.integers(0, 82, n), rs.integers(0, 242, n)], 1)
+        obs, rew, done, info = env.step(a.astype(np.int32))
+        assert info['err'].max() == 0, (t, info['err'])
+    assert done.all()
