@@ -36,6 +36,17 @@ def cpu_baseline(envs, seed0, budget_s=12.0):
     ora = OracleVecEnv(envs, steps=500)
     ora.reset(seeds=seed0)
     cores = int(ora.lib.cc4o_num_threads())
+    try:
+        cores = min(cores, len(os.sched_getaffinity(0)))
+    except Exception:
+        pass
+    try:  # cgroup v2 CPU quota of the container ("max" or "<quota> <period>")
+        q, p = open('/sys/fs/cgroup/cpu.max').read().split()
+        if q != 'max':
+            cores = max(1, min(cores, int(int(q) / int(p))))
+    except Exception:
+        pass
+    ora.lib.cc4o_set_threads(cores)
 
     def run(t0, k):
         acts = [np.ascontiguousarray(random_actions(seed0, t0 + i, envs)) for i in range(k)]
@@ -109,7 +120,6 @@ def main():
         t = torch.tensor([dt, ms_kernels], dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt, ms_kernels = float(t[0]), float(t[1])
-    err_any = bool(env.err.any()) if False else False
     env._fetch()
     err_any = bool(env.err.any())
 

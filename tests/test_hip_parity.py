@@ -158,10 +158,16 @@ def test_drop_in_wrapper_reproduces_reference_episode():
         assert term['blue_agent_0'] == bool(fix['done'][t]) == trunc['blue_agent_0']
         total += rew['blue_agent_0']
     env.close()
-    mae = EnterpriseMAE(CybORG(sg, seed=123), pad_spaces=True)
-    o, i = mae.reset()
-    assert all(v.shape == (210,) for v in o.values()) and mae.action_space('blue_agent_0').n == 242
-    o, r, te, tr, i = mae.step({'actions': {'blue_agent_0': 241}, 'messages': {'blue_agent_1': np.ones(8, bool)}})
-    assert te['__all__'] is False and tr['__all__'] is False
+    from cage_challenge_4_amd import BlueEnterpriseWrapper
+    ent = BlueEnterpriseWrapper(CybORG(sg, seed=123), pad_spaces=True)
+    o, i = ent.reset()
+    assert all(v.shape == (210,) for v in o.values()) and ent.action_space('blue_agent_0').n == 242
+    o, r, te, tr, i = ent.step({'actions': {'blue_agent_0': 241}, 'messages': {'blue_agent_1': np.ones(8, bool)}})
     assert o['blue_agent_0'][92 - 32: 92 - 24].tolist() == [1] * 8      # agent 1's message is agent 0's first message slot
+    assert o['blue_agent_1'][92 - 32:92].sum() == 0                      # nobody else sent anything
+    ent.close()
+    mae = EnterpriseMAE(CybORG(sg, seed=123))                            # RLlib flavour: plain dict + "__all__" keys
+    mae.reset()
+    o, r, te, tr, i = mae.step({'blue_agent_0': 16})
+    assert te['__all__'] is False and tr['__all__'] is False and set(o) == set(mae.possible_agents)
     mae.close()

@@ -1,0 +1,53 @@
+#!/usr/bin/env python
+"""Summarise rocprofv3 rocpd (.db) outputs into the small text/JSON files committed under profiles/.
+usage: rocpd_summary.py stats <dir-with-db> <out.txt>
+       rocpd_summary.py pmc <fetch-dir> <write-dir> <kernel-substr> <out.json> [launch_envs]"""
+import glob
+import json
+import sqlite3
+import sys
+
+
+def db(d):
+    return sqlite3.connect(sorted(glob.glob(d + '/**/*.db', recursive=True))[0])
+
+
+def stats(d, out):
+    con = db(d)
+    rows = list(con.execute('select name,total_calls,total_duration,average,percentage from top_kernels'))
+    lines = ['# rocprofv3 --kernel-trace --stats summary (durations in us)',
+             f'{"kernel":70s} {"calls":>7s} {"total_us":>14s} {"avg_us":>12s} {"pct":>7s}']
+    for n, c, t, a, p in rows:
+        lines.append(f'{n[:70]:70s} {c:7d} {t:14.3f} {a:12.3f} {p:7.2f}')
+    k = list(con.execute("select name, vgpr_count, sgpr_count, lds_size, scratch_size, grid_x, workgroup_x, min(duration), max(duration) "
+                         "from kernels group by name"))
+    lines.append('')
+    lines.append(f'{"kernel":50s} vgpr sgpr lds scratch grid wg min_ns max_ns')
+    for r in k:
+        lines.append(f'{r[0][:50]:50s} ' + ' '.join(str(x) for x in r[1:]))
+    open(out, 'w').write('\n'.join(lines) + '\n')
+    print('\n'.join(lines))
+
+
+def pmc(fd, wd, kern, out, envs):
+    res = {}
+    for name, d in (('FETCH_SIZE', fd), ('WRITE_SIZE', wd)):
+        con = db(d)
+        r = list(con.execute("select count(*), avg(value), min(value), max(value) from counters_collection "
+                             "where counter_name=? and kernel_name like ?", (name, f'%{kern}%')))[0]
+        res[name] = {'launches': r[0], 'avg_KB': r[1], 'min_KB': r[2], 'max_KB': r[3]}
+    # MI355X_MICROARCH.md (HBM): on gfx950 FETCH_SIZE reports 1/2 of the bytes of a wide (16 B/lane) coalesced read ->
+    # double it; WRITE_SIZE calibrated here on hipMemset (fillBufferAligned of 34640 KB reports 34640.0 KB).
+    hbm = (2.0 * res['FETCH_SIZE']['avg_KB'] + res['WRITE_SIZE']['avg_KB']) * 1024.0
+    res['correction'] = 'hbm_bytes = (2*FETCH_SIZE + WRITE_SIZE) * 1024 (FETCH_SIZE halved on gfx950 for 16-B coalesced reads; WRITE_SIZE calibrated on a known-size memset in the same run)'
+    res[f'hbm_bytes_per_launch_{envs}env'] = hbm
+    res['kernel'] = kern
+    json.dump(res, open(out, 'w'), indent=1)
+    print(json.dumps(res, indent=1))
+
+
+if __name__ == '__main__':
+    if sys.argv[1] == 'stats':
+        stats(sys.argv[2], sys.argv[3])
+    else:
+        pmc(sys.argv[2], sys.argv[3], sys.argv[4], sys.argv[5], int(sys.argv[6]) if len(sys.argv) > 6 else 1024)
