@@ -50,6 +50,7 @@ SIGNATURES = {
     'cc4_get_state': (ctypes.c_int, [_P, ctypes.c_int32, _P]),
     'cc4_set_state': (ctypes.c_int, [_P, ctypes.c_int32, _P]),
     'cc4_get_topology': (ctypes.c_int, [_P, ctypes.c_int32, _P]),
+    'cc4_debug_profile': (ctypes.c_int, [_P, ctypes.c_int, _P]),
     'cc4_comm_unique_id': (ctypes.c_int, [_P]),
     'cc4_comm_init': (ctypes.c_int, [_P, ctypes.c_int32, ctypes.c_int32, _P]),
     'cc4_allgather_obs': (ctypes.c_int, [_P, ctypes.POINTER(_P)]),

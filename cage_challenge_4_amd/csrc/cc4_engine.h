@@ -9,9 +9,35 @@
 
 namespace cc4 {
 
-struct Ctx { EnvState* s; EnvCold* c; };
+struct Ctx { EnvState* s; EnvCold* c; Rng* r; unsigned long long* prof = nullptr; };
+
+// optional phase timing (device only, debug builds of the kernel pass a buffer): prof[i] += cycles since last tick
+#if defined(__HIP_DEVICE_COMPILE__)
+#define CC4_TICK(x, i) do { if ((x).prof) { unsigned long long _t = clock64(); (x).prof[(i)] += _t - (x).prof[15]; (x).prof[15] = _t; } } while (0)
+#define CC4_TICK0(x) do { if ((x).prof) (x).prof[15] = clock64(); } while (0)
+#else
+#define CC4_TICK(x, i) do { } while (0)
+#define CC4_TICK0(x) do { } while (0)
+#endif
 
 // ------------------------------------------------------------------ small helpers
+CC4_HD void set_err(Ctx x, uint32_t f) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  __hip_atomic_fetch_or(&x.s->err, f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+#else
+  x.s->err |= f;
+#endif
+}
+// OR event bits into HostDyn.ev (byte 2 of the aligned word {nproc,nsvc,ev,pad}); atomic on device because green
+// agents resolved on different lanes may raise events on the same server
+CC4_HD void ev_or(Ctx x, int h, uint32_t bits) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  uint32_t* w = reinterpret_cast<uint32_t*>(&x.s->hd[h].nproc);
+  __hip_atomic_fetch_or(w, bits << 16, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+#else
+  x.s->hd[h].ev |= (uint8_t)bits;
+#endif
+}
 CC4_HD int h_subnet(int h) { return h / SLOTS; }
 CC4_HD int h_slot(int h) { return h % SLOTS; }
 CC4_HD bool h_is_router(int h) { return h_slot(h) == 0; }          // incl. root_internet_host_0
@@ -23,9 +49,11 @@ CC4_HD void bit_set(uint32_t* b, int i) { b[i >> 5] |= 1u << (i & 31); }
 
 // Host.get_ephemeral_port (Simulator/Host.py:175-187): one re-draw on collision, then remember the port.
 CC4_HD int eph_port(Ctx x, int h) {
-  uint32_t p = rng_below(&x.s->rng, 60000 - 49152);
+  // philox mode: the port value is unobservable on this path (only its stream consumption matters to numpy parity)
+  if (x.r->mode != 0) return 49152;
+  uint32_t p = rng_below(x.r, 60000 - 49152);
   uint32_t* bm = x.c->eph[h];
-  if (bit_get(bm, (int)p)) p = rng_below(&x.s->rng, 60000 - 49152);
+  if (bit_get(bm, (int)p)) p = rng_below(x.r, 60000 - 49152);
   bit_set(bm, (int)p);
   return 49152 + (int)p;
 }
@@ -37,11 +65,11 @@ CC4_HD int create_pid(Ctx x, int h) {
   const HostDyn& d = x.s->hd[h];
   int mx = 0;
   for (int i = 0; i < d.nproc; ++i) if (d.procs[i].pid > mx) mx = d.procs[i].pid;
-  return mx + 1 + (int)rng_below(&x.s->rng, 9);
+  return mx + 1 + (int)rng_below(x.r, 9);
 }
 CC4_HD bool add_proc(Ctx x, int h, int pid, int kind, int flags) {
   HostDyn& d = x.s->hd[h];
-  if (d.nproc >= MAXP) { x.s->err |= E_PROC_OVERFLOW; return false; }
+  if (d.nproc >= MAXP) { set_err(x, E_PROC_OVERFLOW); return false; }
   Proc p; p.pid = (uint16_t)pid; p.kind = (uint8_t)kind; p.flags = (uint8_t)flags;
   d.procs[d.nproc++] = p;
   return true;
@@ -62,12 +90,12 @@ CC4_HD bool host_uses_port(Ctx x, int h, int pbit) {  // Host.is_using_port (Hos
   return false;
 }
 // host.events.network_connections.append(...)
-CC4_HD void ev_conn(Ctx x, int h) { x.s->hd[h].ev |= EV_CUR_CONN; }
+CC4_HD void ev_conn(Ctx x, int h) { ev_or(x, h, EV_CUR_CONN); }
 // host.events.process_creation.append(...); pid > 0 when the event dict carries 'pid' (ExploitAction.py:264-275)
 CC4_HD void ev_proc(Ctx x, int h, int pid) {
-  x.s->hd[h].ev |= EV_CUR_PROC;
+  ev_or(x, h, EV_CUR_PROC);
   if (pid > 0 && blue_of_subnet(h_subnet(h)) >= 0) {
-    if (x.s->npend >= MAX_PEND) { x.s->err |= E_PEND_OVERFLOW; return; }
+    if (x.s->npend >= MAX_PEND) { set_err(x, E_PEND_OVERFLOW); return; }
     x.s->pend[x.s->npend++] = ((uint32_t)h << 16) | (uint32_t)pid;
   }
 }
@@ -92,14 +120,14 @@ CC4_HD int kb_alloc(Ctx x) {
       for (int h = 0; h < MAXH; ++h) x.c->kports[i][h] = 0;
       return i;
     }
-  x.s->err |= E_KB_OVERFLOW;
+  set_err(x, E_KB_OVERFLOW);
   return 0xFF;
 }
 CC4_HD void kb_free(Ctx x, int kb) { if (kb != 0xFF) x.s->kb_used[kb >> 5] &= ~(1u << (kb & 31)); }
 // State.add_session (Simulator/State.py:305-324): ident = max(existing)+1 (0 if none); appended (dict order)
 CC4_HD int rs_add(Ctx x, int r, int host, int pid, int flags) {
   RedAgent& a = x.s->red[r];
-  if (a.nsess >= MAX_RS) { x.s->err |= E_RSESS_OVERFLOW; return -1; }
+  if (a.nsess >= MAX_RS) { set_err(x, E_RSESS_OVERFLOW); return -1; }
   int id = 0;
   for (int i = 0; i < a.nsess; ++i) if (a.sess[i].id + 1 > id) id = a.sess[i].id + 1;
   RSess q; q.id = (uint16_t)id; q.pid = (uint16_t)pid; q.host = (uint8_t)host; q.flags = (uint8_t)flags; q.pad = 0;
@@ -121,7 +149,7 @@ CC4_HD bool red_has_session_on(const RedAgent& a, int h) {
 CC4_HD void as_know_sid(Ctx x, int r, int id) {
   RedAgent& a = x.s->red[r];
   for (int i = 0; i < a.nknown; ++i) if (a.known_sid[i] == id) return;
-  if (a.nknown >= MAX_KS) { x.s->err |= E_KS_OVERFLOW; return; }
+  if (a.nknown >= MAX_KS) { set_err(x, E_KS_OVERFLOW); return; }
   a.known_sid[a.nknown++] = (uint16_t)id;
 }
 // one key of the agent's step observation (Shared/Observation.py add_* / combine_obs); also applies the
@@ -134,7 +162,7 @@ CC4_HD void obs_put(Ctx x, int r, bool key_ip, int host, int flags, bool subnet_
   uint8_t want = (uint8_t)(key_ip ? OE_KEY_IP : 0);
   for (int i = 0; i < a.nobs; ++i)
     if (a.obs[i].host == host && (a.obs[i].flags & OE_KEY_IP) == want) { a.obs[i].flags |= (uint8_t)flags; return; }
-  if (a.nobs >= MAX_OBS) { x.s->err |= E_OBS_OVERFLOW; return; }
+  if (a.nobs >= MAX_OBS) { set_err(x, E_OBS_OVERFLOW); return; }
   a.obs[a.nobs].host = (uint8_t)host;
   a.obs[a.nobs].flags = (uint8_t)(flags | want);
   a.nobs++;
@@ -178,7 +206,7 @@ CC4_HD int route(int src, int dst, uint8_t* out) {
 // Draw order follows create_scenario (EnterpriseScenarioGenerator.py:123-169) then State.__init__ (State.py:66-148).
 CC4_HD int gen_pid(Ctx x, uint32_t* used) {  // _generate_pid (ESG.py:564-578)
   while (true) {
-    int pid = rng_range(&x.s->rng, 1000, 10000);
+    int pid = rng_range(x.r, 1000, 10000);
     if (!bit_get(used, pid - 1000)) { bit_set(used, pid - 1000); return pid; }
   }
 }
@@ -186,7 +214,7 @@ CC4_HD void gen_host(Ctx x, int h, uint32_t* used) {  // _generate_linux_host (E
   EnvState* s = x.s;
   HostStatic& st = s->hs[h];
   st.exists = 1; st.nproc = 0; st.nsvc = 0;
-  (void)rng_below(&s->rng, 2);  // OSDistribution choice (ESG.py:494): both are LINUX, value unused downstream
+  (void)rng_below(x.r, 2);  // OSDistribution choice (ESG.py:494): both are LINUX, value unused downstream
   if (h_is_router(h)) return;
   // _generate_linux_host_services (ESG.py:530-562)
   int kinds[5]; int pids[5]; int n = 0;
@@ -195,17 +223,17 @@ CC4_HD void gen_host(Ctx x, int h, uint32_t* used) {  // _generate_linux_host (E
   if (sub == S_OZA || sub == S_OZB) { kinds[n] = K_OT; pids[n++] = gen_pid(x, used); }
   int opt_kind[3] = {K_APACHE, K_MYSQL, K_SMTP}; int opt_pid[3];
   for (int i = 0; i < 3; ++i) opt_pid[i] = gen_pid(x, used);
-  int n_add = (int)rng_below(&s->rng, 4);  // integers(0, 3, endpoint=True)
+  int n_add = (int)rng_below(x.r, 4);  // integers(0, 3, endpoint=True)
   int n_opt = 3;
   for (int k = 0; k < n_add; ++k) {
-    int c = (int)rng_below(&s->rng, (uint32_t)n_opt);
+    int c = (int)rng_below(x.r, (uint32_t)n_opt);
     kinds[n] = opt_kind[c]; pids[n++] = opt_pid[c];
     for (int j = c; j + 1 < n_opt; ++j) { opt_kind[j] = opt_kind[j + 1]; opt_pid[j] = opt_pid[j + 1]; }
     n_opt--;
   }
   // _generate_linux_host_processes (ESG.py:580-629): one random() per service, never below 1.0
   for (int i = 0; i < n; ++i) {
-    (void)rng_random(&s->rng);
+    (void)rng_random(x.r);
     st.svcs[i].kind = (uint8_t)kinds[i]; st.svcs[i].pid = (uint16_t)pids[i]; st.svcs[i].st = (uint8_t)(SV_ACTIVE | 5);
     st.procs[i].kind = (uint8_t)kinds[i]; st.procs[i].pid = (uint16_t)pids[i]; st.procs[i].flags = 0;
   }
@@ -216,7 +244,7 @@ CC4_HD int start_session_proc(Ctx x, int h, int kind) {
   HostStatic& st = x.s->hs[h];
   int mx = 0;
   for (int i = 0; i < st.nproc; ++i) if (st.procs[i].pid > mx) mx = st.procs[i].pid;
-  int pid = mx + 1 + (int)rng_below(&x.s->rng, 9);
+  int pid = mx + 1 + (int)rng_below(x.r, 9);
   st.procs[st.nproc].pid = (uint16_t)pid; st.procs[st.nproc].kind = (uint8_t)kind; st.procs[st.nproc].flags = 0;
   st.nproc++;
   return pid;
@@ -240,9 +268,9 @@ CC4_HD void env_reset(Ctx x, uint64_t seed, int rng_mode, int steps, bool contin
     uint32_t* w = (uint32_t*)s;
     for (size_t i = 0; i < sizeof(EnvState) / 4; ++i) w[i] = 0;
   }
-  if (continue_stream) s->rng = keep; else rng_seed(&s->rng, seed, (uint32_t)rng_mode);
+  if (continue_stream) s->rng = keep; else rng_seed(&s->rng, seed, (uint32_t)rng_mode);  // NOTE: x.r must be &s->rng here
   s->rng_mode = (uint8_t)rng_mode;
-  rng_begin_episode(&s->rng);  // philox: the reset stream uses its own (step, episode) counter words
+  rng_begin_episode(x.r);  // philox: the reset stream uses its own (step, episode) counter words
   s->steps = steps;
   {  // _generate_mission_phases (ESG.py:854-860)
     int q = steps / 3, rem = steps % 3;
@@ -258,7 +286,7 @@ CC4_HD void env_reset(Ctx x, uint64_t seed, int rng_mode, int steps, bool contin
     for (int i = 0; i < 256; ++i) pool[i] = (uint8_t)i;
     int n = 256;
     for (int sn = 0; sn < NSUB; ++sn) {
-      int c = (int)rng_below(&s->rng, (uint32_t)n);
+      int c = (int)rng_below(x.r, (uint32_t)n);
       s->cidr_octet[sn] = pool[c];
       for (int j = c; j + 1 < n; ++j) pool[j] = pool[j + 1];
       n--;
@@ -271,20 +299,20 @@ CC4_HD void env_reset(Ctx x, uint64_t seed, int rng_mode, int steps, bool contin
     int n = 254;
     auto pop_at = [&](int c) { uint8_t v = ips[c]; for (int j = c; j + 1 < n; ++j) ips[j] = ips[j + 1]; n--; return v; };
     if (sn == S_INT) {
-      int c = (int)rng_below(&s->rng, (uint32_t)n);
+      int c = (int)rng_below(x.r, (uint32_t)n);
       s->hs[H_INTERNET].ip_octet = pop_at(c);
       gen_host(x, H_INTERNET, used);
       continue;
     }
     int hr = h_make(sn, 0);
-    { int c = (int)rng_below(&s->rng, (uint32_t)n); uint8_t ip = pop_at(c); gen_host(x, hr, used); s->hs[hr].ip_octet = ip; }
-    int nu = 3 + (int)rng_below(&s->rng, 8);  // integers(3, 10, endpoint=True)
+    { int c = (int)rng_below(x.r, (uint32_t)n); uint8_t ip = pop_at(c); gen_host(x, hr, used); s->hs[hr].ip_octet = ip; }
+    int nu = 3 + (int)rng_below(x.r, 8);  // integers(3, 10, endpoint=True)
     for (int i = 0; i < nu; ++i) {
       int h = h_make(sn, 1 + i);
-      int c = (int)rng_below(&s->rng, (uint32_t)n); uint8_t ip = pop_at(c);
+      int c = (int)rng_below(x.r, (uint32_t)n); uint8_t ip = pop_at(c);
       gen_host(x, h, used); s->hs[h].ip_octet = ip;
     }
-    int ns = 1 + (int)rng_below(&s->rng, 6);  // integers(1, 6, endpoint=True)
+    int ns = 1 + (int)rng_below(x.r, 6);  // integers(1, 6, endpoint=True)
     for (int i = 0; i < ns; ++i) {
       int h = h_make(sn, 11 + i);
       uint8_t ip = ips[n - 1]; n--;  // ip_addresses.pop()
@@ -295,10 +323,10 @@ CC4_HD void env_reset(Ctx x, uint64_t seed, int rng_mode, int steps, bool contin
   // _generate_blue_agents (ESG.py:631-698)
   for (int b = 0; b < NBLUE; ++b) {
     int nsub = blue_nsub(b);
-    (void)rng_below(&s->rng, (uint32_t)nsub);  // starting_subnet = choice(allowed_subnets): unused
+    (void)rng_below(x.r, (uint32_t)nsub);  // starting_subnet = choice(allowed_subnets): unused
     int cnt = 0;
     for (int i = 0; i < nsub; ++i) { int sn = blue_subnet_alloc(b, i); cnt += 1 + s->n_users[sn] + s->n_servers[sn]; }
-    int c = (int)rng_below(&s->rng, (uint32_t)cnt);  // parent_host = choice(allowed_hosts)
+    int c = (int)rng_below(x.r, (uint32_t)cnt);  // parent_host = choice(allowed_hosts)
     int k = 0, ph = -1;
     for (int i = 0; i < nsub && ph < 0; ++i) {
       int sn = blue_subnet_alloc(b, i);
@@ -315,9 +343,9 @@ CC4_HD void env_reset(Ctx x, uint64_t seed, int rng_mode, int steps, bool contin
   // _generate_red_agents (ESG.py:751-817)
   for (int r = 0; r < NRED; ++r) {
     int nsub = red_nsub(r);
-    int sn = red_subnet_alloc(r, (int)rng_below(&s->rng, (uint32_t)nsub));
+    int sn = red_subnet_alloc(r, (int)rng_below(x.r, (uint32_t)nsub));
     int cnt = s->n_users[sn] + s->n_servers[sn];
-    int c = (int)rng_below(&s->rng, (uint32_t)cnt);  // choice(non-router hosts): users then servers
+    int c = (int)rng_below(x.r, (uint32_t)cnt);  // choice(non-router hosts): users then servers
     int h = c < s->n_users[sn] ? h_make(sn, 1 + c) : h_make(sn, 11 + (c - s->n_users[sn]));
     s->red[r].start_host = (uint8_t)h;
     for (int i = 0; i < MAXH; ++i) s->red[r].fsm_state[i] = FS_NONE;
@@ -366,6 +394,7 @@ CC4_HD void env_reset(Ctx x, uint64_t seed, int rng_mode, int steps, bool contin
     a.exec_type = RA_SLEEP;
   }
   s->step_count = 0; s->phase = 0; s->done = (uint8_t)(0 >= steps - 1); s->reward = 0.f;
+  rng_park(&s->rng);
 }
 
 // ------------------------------------------------------------------ blue actions
@@ -432,7 +461,7 @@ CC4_HD void blue_monitor(Ctx x, int b) {
   for (int i = 0; i < s->npend; ++i) {
     int h = (int)(s->pend[i] >> 16);
     if (blue_of_subnet(h_subnet(h)) == b) {
-      if (A.nsus >= MAX_SUS) s->err |= E_SUS_OVERFLOW; else A.sus[A.nsus++] = s->pend[i];
+      if (A.nsus >= MAX_SUS) set_err(x, E_SUS_OVERFLOW); else A.sus[A.nsus++] = s->pend[i];
     } else s->pend[n++] = s->pend[i];
   }
   s->npend = (uint8_t)n;
@@ -461,9 +490,9 @@ CC4_HD void stop_process(Ctx x, int h, int pid) {
     d.svcs[si].pid = (uint16_t)np;
   }
   if (owner < 0) return;
-  if (owner < 2) { s->err |= E_BLUE_GREEN_SESSION_KILLED; return; }
+  if (owner < 2) { set_err(x, E_BLUE_GREEN_SESSION_KILLED); return; }
   rs_remove_at(x, owner - 2, owner_idx, true);
-  if (si >= 0) s->err |= E_UNREACHABLE;  // session re-created on a service process: never happens in CC4
+  if (si >= 0) set_err(x, E_UNREACHABLE);  // session re-created on a service process: never happens in CC4
 }
 // Remove.execute (AbstractActions/Remove.py:42-71)
 CC4_HD void blue_remove(Ctx x, int b, int h) {
@@ -499,7 +528,7 @@ CC4_HD void blue_decoy(Ctx x, int h) {
   if (!host_uses_port(x, h, PB_443)) cand[n++] = K_DEC_TOMCAT;
   if (!host_uses_port(x, h, PB_25)) cand[n++] = K_DEC_HARAKA;
   cand[n++] = K_DEC_VSFTPD;  // compatibility checks port 21, which nothing uses (DecoyVsftpd.py:17-20)
-  int kind = cand[rng_below(&s->rng, (uint32_t)n)];
+  int kind = cand[rng_below(x.r, (uint32_t)n)];
   int pid = create_pid(x, h);
   if (!add_proc(x, h, pid, kind, 0)) return;
   HostDyn& d = s->hd[h];
@@ -540,24 +569,24 @@ CC4_HD void phishing(Ctx x, int gh) {
   }
   if (src < 0) {
     if (nc == 0) return;
-    src = cand[rng_below(&s->rng, (uint32_t)nc)];  // choice(red_agents, replace=False): one bounded draw
+    src = cand[rng_below(x.r, (uint32_t)nc)];  // choice(red_agents, replace=False): one bounded draw
   }
   int pid = create_pid(x, gh);
   if (!add_proc(x, gh, pid, K_SESS_RED, 0)) return;
   rs_add(x, src, gh, pid, RS_ABSTRACT);
 }
 // GreenLocalWork.execute (GreenActions/GreenLocalWork.py:60-125). returns success
-CC4_HD bool green_local_work(Ctx x, int gh) {
+CC4_HD bool green_local_work(Ctx x, int gh, bool* want_phish) {
   EnvState* s = x.s;
   HostDyn& d = s->hd[gh];
   int act[MAXSV]; int n = 0;
   for (int i = 0; i < d.nsvc; ++i) if (d.svcs[i].st & SV_ACTIVE) act[n++] = i;
   if (n == 0) return false;
-  int c = act[rng_below(&s->rng, (uint32_t)n)];
+  int c = act[rng_below(x.r, (uint32_t)n)];
   int rel = (d.svcs[c].st & 0x7F) * 20;
-  if ((int)rng_below(&s->rng, 100) >= rel) return false;
-  if (rng_random(&s->rng) < 0.01) { (void)eph_port(x, gh); ev_proc(x, gh, 0); }
-  if (rng_random(&s->rng) < 0.01) phishing(x, gh);
+  if ((int)rng_below(x.r, 100) >= rel) return false;
+  if (rng_random(x.r) < 0.01) { (void)eph_port(x, gh); ev_proc(x, gh, 0); }
+  if (rng_random(x.r) < 0.01) *want_phish = true;  // PhishingEmail sub-action: executed by the caller (ordering, see P5)
   return true;
 }
 // GreenAccessService.execute (GreenActions/GreenAccessService.py:137-217). returns success
@@ -567,7 +596,7 @@ CC4_HD bool green_access_service(Ctx x, int gh) {
   uint32_t allowed = green_allowed_mask(s->phase, own);
   int n = 0;
   for (int sn = 0; sn < NSUB - 1; ++sn) if ((allowed >> sn) & 1u) n += s->n_servers[sn];
-  int c = (int)rng_below(&s->rng, (uint32_t)n);
+  int c = (int)rng_below(x.r, (uint32_t)n);
   int dest = -1;
   for (int sn = 0; sn < NSUB - 1 && dest < 0; ++sn) {
     if (!((allowed >> sn) & 1u)) continue;
@@ -576,7 +605,7 @@ CC4_HD bool green_access_service(Ctx x, int gh) {
   (void)eph_port(x, dest);
   int ds = h_subnet(dest);
   if (subnet_blocked(x, ds, own) || subnet_blocked(x, own, ds)) { ev_conn(x, dest); return false; }
-  if (rng_random(&s->rng) < 0.01) ev_conn(x, dest);
+  if (rng_random(x.r) < 0.01) ev_conn(x, dest);
   return true;
 }
 
@@ -608,7 +637,7 @@ CC4_HD void red_scan(Ctx x, int r, const Act& a, double rate) {
   if (si < 0 || !(A.sess[si].flags & RS_ABSTRACT)) { red_result(x, r, a, T_FALSE); return; }
   int src = A.sess[si].host, tgt = a.host;
   if (subnet_blocked(x, h_subnet(src), h_subnet(tgt))) { red_result(x, r, a, T_FALSE); return; }
-  double fixed = rng_random(&s->rng);
+  double fixed = rng_random(x.r);
   int ports = 0;
   int np = s->hd[tgt].nproc;
   for (int i = 0; i < np; ++i) {
@@ -656,14 +685,14 @@ CC4_HD void red_exploit(Ctx x, int r, const Act& a) {
     for (int i = 1; i < n; ++i) if (w10[i] > w10[top]) top = i;
     for (int i = top; i + 1 < n; ++i) { opt[i] = opt[i + 1]; w10[i] = w10[i + 1]; }
     n--;
-    sel = opt[rng_below(&s->rng, (uint32_t)n)];
-    (void)rng_random(&s->rng);  // `elif random() < odds_of_top_choice` with odds 0
+    sel = opt[rng_below(x.r, (uint32_t)n)];
+    (void)rng_random(x.r);  // `elif random() < odds_of_top_choice` with odds 0
   }
   HostDyn& T = s->hd[tgt];
   if (sel == X_SSH) {
     // SSHBruteForce.execute (ExploitActions/SSHBruteForce.py:24-84)
     uint8_t hops[12]; int nh = route(src, tgt, hops);
-    for (int i = 0; i < nh; ++i) if (0.050000000000000044 < rng_random(&s->rng)) ev_conn(x, hops[i]);  // 1 - 0.95 in float64
+    for (int i = 0; i < nh; ++i) if (0.050000000000000044 < rng_random(x.r)) ev_conn(x, hops[i]);  // 1 - 0.95 in float64
     int vp = -1;
     for (int i = 0; i < T.nproc; ++i) if (T.procs[i].kind == K_SSHD) { vp = i; break; }
     if (vp < 0) { red_result(x, r, a, T_FALSE); return; }
@@ -697,12 +726,12 @@ CC4_HD void red_exploit(Ctx x, int r, const Act& a) {
   obs_put(x, r, true, tgt, OE_IFACE, false);
   bool works = (sel == X_SQLI) || decoy;  // rfi only on decoys; real Haraka is 2.8.9 (HarakaRCE.py:19, HTTPRFI.py:18)
   if (!works) { red_result(x, r, a, T_FALSE); return; }
-  if (0.0 >= rng_random(&s->rng)) { red_result(x, r, a, T_FALSE); return; }  // (1 - success_rate) >= random()
+  if (0.0 >= rng_random(x.r)) { red_result(x, r, a, T_FALSE); return; }  // (1 - success_rate) >= random()
   (void)eph_port(x, tgt);  // local_port
   if (decoy) { ev_conn(x, tgt); (void)eph_port(x, tgt); red_result(x, r, a, T_FALSE); return; }
   int ni = exploit_new_session(x, r, a.sid, tgt);
   if (ni < 0) { red_result(x, r, a, T_FALSE); return; }
-  if (rng_random(&s->rng) > 0.050000000000000044) ev_proc(x, tgt, A.sess[ni].pid);
+  if (rng_random(x.r) > 0.050000000000000044) ev_proc(x, tgt, A.sess[ni].pid);
   obs_put(x, r, true, tgt, OE_SESS | OE_IFACE | OE_SYSHN, false);
   obs_put(x, r, true, src, OE_IFACE, false);
   A.new_sess_host = (uint8_t)tgt; A.new_sess_id = A.sess[ni].id;
@@ -719,7 +748,7 @@ CC4_HD void red_privesc(Ctx x, int r, const Act& a) {
   int target = -1;
   for (int i = 0; i < n; ++i) if (A.sess[on[i]].flags & RS_ROOT) { target = on[i]; break; }
   if (target < 0) {
-    target = on[rng_below(&s->rng, (uint32_t)n)];
+    target = on[rng_below(x.r, (uint32_t)n)];
     // DefaultEscalateActionSelector (PrivilegeEscalate.py:52-66): self.session must exist and be a RedAbstractSession,
     // else no sub-action -> Observation(False); then V4L2KernelExploit via TargetedLocalAction.execute
     { int ss = rs_find_id(A, a.sid);
@@ -784,8 +813,8 @@ CC4_HD void red_deception(Ctx x, int r, const Act& a) {
   for (int i = 0; i < d.nproc; ++i) {
     bool decoy = kind_is_decoy(d.procs[i].kind);
     bool rep = false;
-    if (rng_random(&s->rng) <= 0.5 && decoy) rep = true;
-    else if (rng_random(&s->rng) <= 0.1 && !decoy) rep = true;
+    if (rng_random(x.r) <= 0.5 && decoy) rep = true;
+    else if (rng_random(x.r) <= 0.1 && !decoy) rep = true;
     if (rep) obs_put(x, r, false, tgt, OE_IFACE, false);
   }
   red_result(x, r, a, T_TRUE);
@@ -797,7 +826,7 @@ CC4_HD void red_session_check(Ctx x, int r) {
   obs_first(x, r, T_TRUE, RA_NONE, 0, 0);
   if (A.nsess == 0) return;
   if (rs_find_id(A, 0) < 0) {
-    int c = (int)rng_below(&s->rng, (uint32_t)A.nsess);
+    int c = (int)rng_below(x.r, (uint32_t)A.nsess);
     RSess q = A.sess[c];
     rs_remove_at(x, r, c, false);
     q.id = 0;
@@ -819,7 +848,7 @@ CC4_HD void red_execute(Ctx x, int r, const Act& a) {
     case RA_IMPACT: red_impact(x, r, a); break;
     case RA_DEGRADE: red_degrade(x, r, a); break;
     case RA_INVALID: obs_first(x, r, T_FALSE, RA_NONE, 0, 0); break;
-    case RA_WITHDRAW: x.s->err |= E_UNREACHABLE; obs_first(x, r, T_FALSE, RA_NONE, 0, 0); break;
+    case RA_WITHDRAW: set_err(x, E_UNREACHABLE); obs_first(x, r, T_FALSE, RA_NONE, 0, 0); break;
     default: obs_first(x, r, T_UNKNOWN, RA_NONE, 0, 0); break;  // Sleep -> Observation()
   }
 }
@@ -873,7 +902,7 @@ CC4_HD void fsm_observe(Ctx x, int r) {
     bool ip = (f & OE_KEY_IP) || (f & OE_IFACE);
     if (!ip) {
       // ip looked up through a known hostname; unknown -> reference would key host_states[None]
-      if (!(A.fsm_state[h] != FS_NONE && bit_get(A.fsm_hn, h))) { x.s->err |= E_UNREACHABLE; }
+      if (!(A.fsm_state[h] != FS_NONE && bit_get(A.fsm_hn, h))) { set_err(x, E_UNREACHABLE); }
       continue;
     }
     if (A.fsm_state[h] == FS_NONE) {
@@ -900,8 +929,8 @@ CC4_HD Act fsm_get_action(Ctx x, int r) {
   if (A.obs_success == T_IN_PROGRESS) { A.fsm_step++; return out; }
   int n = 0;
   for (int i = 0; i < A.fsm_n; ++i) if (A.fsm_state[A.fsm_order[i]] != FS_F) n++;
-  if (n == 0) { s->err |= E_FSM_NO_HOST; A.fsm_step++; return out; }
-  int c = (int)rng_below(&s->rng, (uint32_t)n);
+  if (n == 0) { set_err(x, E_FSM_NO_HOST); A.fsm_step++; return out; }
+  int c = (int)rng_below(x.r, (uint32_t)n);
   int host = -1;
   for (int i = 0; i < A.fsm_n; ++i) { int h = A.fsm_order[i]; if (A.fsm_state[h] == FS_F) continue; if (c-- == 0) { host = h; break; } }
   // options in red_actions list order (ESG.py:764-768) with state_transitions_probability (:540-549)
@@ -916,7 +945,7 @@ CC4_HD Act fsm_get_action(Ctx x, int r) {
     case FS_R:  acts[0] = RA_DRS; acts[1] = RA_DEGRADE; acts[2] = RA_IMPACT; acts[3] = RA_WITHDRAW; cdf[0] = .5; cdf[1] = .75; cdf[2] = 1.; cdf[3] = 1.; no = 4; break;
     default:    acts[0] = RA_DEGRADE; acts[1] = RA_IMPACT; acts[2] = RA_WITHDRAW; cdf[0] = .5; cdf[1] = 1.; cdf[2] = 1.; no = 3; break;  // RD
   }
-  double u = rng_random(&s->rng);
+  double u = rng_random(x.r);
   int k = 0;
   while (k < no && cdf[k] <= u) k++;  // cdf.searchsorted(u, side='right')
   if (k >= no) k = no - 1;
@@ -927,13 +956,13 @@ CC4_HD Act fsm_get_action(Ctx x, int r) {
   if (t == RA_DRS) {
     int ns = 0; int subs[NSUB];
     for (int sn = 0; sn < NSUB; ++sn) if ((A.as_subnet >> sn) & 1u) subs[ns++] = sn;
-    if (ns == 0) bad = true; else out.arg = (uint8_t)subs[rng_below(&s->rng, (uint32_t)ns)];
+    if (ns == 0) bad = true; else out.arg = (uint8_t)subs[rng_below(x.r, (uint32_t)ns)];
   }
   if ((t == RA_PRIVESC || t == RA_IMPACT || t == RA_DEGRADE) && !bit_get(A.fsm_hn, host)) bad = true;
   if (!bad) {
-    if (A.nknown == 0) bad = true; else out.sid = A.known_sid[rng_below(&s->rng, (uint32_t)A.nknown)];
+    if (A.nknown == 0) bad = true; else out.sid = A.known_sid[rng_below(x.r, (uint32_t)A.nknown)];
   }
-  if (bad) { s->err |= E_UNREACHABLE; out.type = RA_SLEEP; }  // reference would re-draw with p not summing to 1 and raise
+  if (bad) { set_err(x, E_UNREACHABLE); out.type = RA_SLEEP; }  // reference would re-draw with p not summing to 1 and raise
   out.ticks = (uint8_t)red_duration(out.type);
   A.fsm_step++;
   return out;
@@ -963,9 +992,9 @@ CC4_HD void red_reassign(Ctx x) {
       int sn = h_subnet(A.sess[i].host);
       if ((red_allowed_mask(r) >> sn) & 1u) continue;
       int to = red_of_subnet(sn);
-      if (to < 0) { s->err |= E_UNREACHABLE; continue; }
+      if (to < 0) { set_err(x, E_UNREACHABLE); continue; }
       if (nm < 32) { mv[nm].from = (uint8_t)r; mv[nm].to = (uint8_t)to; mv[nm].host = A.sess[i].host; mv[nm].id = A.sess[i].id; nm++; }
-      else s->err |= E_RSESS_OVERFLOW;
+      else set_err(x, E_RSESS_OVERFLOW);
     }
   }
   for (int m = 0; m < nm; ++m) {
@@ -987,38 +1016,61 @@ CC4_HD void red_reassign(Ctx x) {
 }
 
 // ------------------------------------------------------------------ the step (SimulationController.step, SC:211-315)
-// actions[5]: wrapper action index per blue agent (negative = no action submitted -> SleepAgent)
-CC4_HD void env_step(Ctx x, const int32_t* actions, const uint8_t* messages /* [5][8] or null */) {
+// The step is cut into phases that exchange data only through EnvState, so that the serial walk (env_step: the CPU
+// oracle and the PCG64 device mode) and the lane-parallel Philox kernel run the very same phase bodies.
+//   P0 step_begin            lane 0      phase check, blue decode + queue            (SC:224-248)
+//   P1 step_green_policy(g)  per green   EnterpriseGreenAgent.get_action             (EnterpriseGreenAgent.py:60)
+//   P2 step_red_policy(r)    per red     FSM get_action + validity + queue           (SC:236-248)
+//   P3 step_tick             lane 0      duration queue, filter, (pcg: shuffle), blue execution
+//   P4 step_green_exec(g)    per green   green actions except PhishingEmail          (GreenLocalWork/GreenAccessService)
+//   P5 step_phishing         lane 0      deferred PhishingEmail in agent order
+//   P6 step_red_exec         lane 0      red actions in agent order, reassignment    (SC:271-278)
+//   P7 step_monitor_host(h)  per host    end-turn Monitor event roll-over             (Monitor.py:35-74)
+//      step_monitor_pend     lane 0      sus pid hand-over
+//   P8 step_rsc(r)           per red     end-turn RedSessionCheck
+//   P9 step_end              lane 0      counters, done, reward, messages            (SC:297-311)
+// Equivalence of the per-green split with the serial order: a green action reads only its own host's services, the
+// blocks and the server counts, and writes event bits (OR) and the reward (sum); the one order-dependent effect,
+// PhishingEmail (new red session), is deferred and replayed in agent order (P5).
+
+// returns false when the episode is stepped past its end (State.py:539-540 raises ValueError)
+CC4_HD bool step_begin(Ctx x, const int32_t* actions) {
   EnvState* s = x.s;
-  // State.check_next_phase_on_update_step (State.py:514-544)
-  {
+  {  // State.check_next_phase_on_update_step (State.py:514-544)
     int st = s->step_count, ph = -1, mn = 0, mx = 0;
     for (int p = 0; p < 3; ++p) { mn = mx; mx = mn + s->phase_len[p]; if (st >= mn && st < mx) { ph = p; break; } }
-    if (ph < 0) { s->err |= E_STEP_PAST_END; return; }
+    if (ph < 0) { set_err(x, E_STEP_PAST_END); return false; }
     if (ph > s->phase) s->phase = ph;
   }
   rng_begin_step(&s->rng, (uint32_t)s->step_count);
-  float action_cost = 0.f;
-  // ---- loop A: policies, validity, queue (SC:236-248)
+  s->action_cost = 0.f; s->brm = 0;
   for (int b = 0; b < NBLUE; ++b) {
     Act a = blue_decode(s, b, actions ? actions[b] : -1);
-    if (a.type == BA_RESTORE) action_cost -= 1.f;  // Restore.cost, charged on submission (SC:310)
+    if (a.type == BA_RESTORE) s->action_cost -= 1.f;  // Restore.cost, charged on submission (SC:310)
     a.ticks = (uint8_t)blue_duration(a.type);
     if (!s->blue[b].queue.busy) { s->blue[b].queue = a; s->blue[b].queue.busy = 1; }
   }
-  for (int g = 0; g < s->n_green; ++g) s->green_act[g] = (uint8_t)rng_below(&s->rng, 3);  // EnterpriseGreenAgent.py:60
-  for (int r = 0; r < NRED; ++r) {
-    RedAgent& A = s->red[r];
-    Act a; a.type = RA_SLEEP; a.host = 0; a.arg = 0; a.ticks = 1; a.sid = 0; a.busy = 0;
-    if (A.active) { a = fsm_get_action(x, r); red_validate(x, r, a); }   // AgentInterface.get_action (:120-143)
-    if (!A.queue.busy) { A.queue = a; A.queue.busy = 1; }
-  }
+  return true;
+}
+CC4_HD void step_green_policy(Ctx x, int g) {
+  rng_set_stream(x.r, ST_GREEN_POL + (uint32_t)g);
+  x.s->green_act[g] = (uint8_t)rng_below(x.r, 3);  // choice([GreenAccessService, GreenLocalWork, Sleep])
+}
+CC4_HD void step_red_policy(Ctx x, int r) {
+  RedAgent& A = x.s->red[r];
+  Act a; a.type = RA_SLEEP; a.host = 0; a.arg = 0; a.ticks = 1; a.sid = 0; a.busy = 0;
+  rng_set_stream(x.r, ST_RED_POL + (uint32_t)r);
+  if (A.active) { a = fsm_get_action(x, r); red_validate(x, r, a); }   // AgentInterface.get_action (:120-143)
+  if (!A.queue.busy) { A.queue = a; A.queue.busy = 1; }
+}
+CC4_HD void step_tick(Ctx x) {
+  EnvState* s = x.s;
   // ---- observation reset + queue tick (SC:251-265)
-  Act bexec[NBLUE]; Act rexec[NRED];
   for (int b = 0; b < NBLUE; ++b) {
     Act& q = s->blue[b].queue;
     q.ticks--;
-    if (q.ticks < 1) { bexec[b] = q; q.busy = 0; } else { bexec[b].type = BA_SLEEP; bexec[b].host = 0; bexec[b].arg = 0; }
+    if (q.ticks < 1) { s->bexec[b] = q; q.busy = 0; }
+    else { Act z; z.type = BA_SLEEP; z.host = 0; z.arg = 0; z.ticks = 0; z.sid = 0; z.busy = 0; s->bexec[b] = z; }
   }
   int n_actions = NBLUE + s->n_green + NRED;
   for (int r = 0; r < NRED; ++r) {
@@ -1026,63 +1078,158 @@ CC4_HD void env_step(Ctx x, const int32_t* actions, const uint8_t* messages /* [
     A.nobs = 0; A.obs_success = 0; A.obs_act_type = RA_NONE; A.new_sess_host = 0xFF;
     Act& q = A.queue;
     q.ticks--;
-    if (q.ticks < 1) { rexec[r] = q; q.busy = 0; }
-    else { rexec[r].type = RA_SLEEP; rexec[r].host = 0; rexec[r].arg = 0; rexec[r].ticks = 0; rexec[r].sid = 0; rexec[r].busy = 0; obs_first(x, r, T_IN_PROGRESS, RA_NONE, 0, 0); }
-    A.exec_type = rexec[r].type; A.exec_host = rexec[r].host;
+    if (q.ticks < 1) { s->rexec[r] = q; q.busy = 0; }
+    else {
+      Act z; z.type = RA_SLEEP; z.host = 0; z.arg = 0; z.ticks = 0; z.sid = 0; z.busy = 0; s->rexec[r] = z;
+      obs_first(x, r, T_IN_PROGRESS, RA_NONE, 0, 0);
+    }
+    A.exec_type = s->rexec[r].type; A.exec_host = s->rexec[r].host;
     // filter_actions (SC:466-485): actions naming a dead session are dropped (Sleep/InvalidAction have no session)
-    if (rexec[r].type <= RA_WITHDRAW && rs_find_id(A, rexec[r].sid) < 0) { rexec[r].type = RA_NONE; n_actions--; }
+    if (s->rexec[r].type <= RA_WITHDRAW && rs_find_id(A, s->rexec[r].sid) < 0) { s->rexec[r].type = RA_NONE; n_actions--; }
   }
-  // ---- sort_action_order (SC:398-464): the shuffle only consumes the stream
-  rng_shuffle_consume(&s->rng, n_actions);
+  s->n_actions = n_actions;
+  CC4_TICK(x, 3);
+  // ---- sort_action_order (SC:398-464): the shuffle only consumes the shared numpy stream; the Philox streams are
+  // per agent, so there is nothing to consume there
+  if (x.r->mode == 0) rng_shuffle_consume(x.r, n_actions);
+  CC4_TICK(x, 4);
   // ---- execute: priority 1 (ControlTraffic) first, then agent order
-  for (int b = 0; b < NBLUE; ++b) if (bexec[b].type == BA_BLOCK || bexec[b].type == BA_ALLOW) blue_execute(x, b, bexec[b]);
-  for (int b = 0; b < NBLUE; ++b) if (!(bexec[b].type == BA_BLOCK || bexec[b].type == BA_ALLOW)) blue_execute(x, b, bexec[b]);
-  int brm = 0;  // BlueRewardMachine.calculate_reward accumulates here (Shared/BlueRewardMachine.py:70-121)
-  for (int g = 0; g < s->n_green; ++g) {
-    int gh = s->green_host[g];
-    int own = h_subnet(gh);
-    if (s->green_act[g] == 0) { if (!green_access_service(x, gh)) brm += reward_table(s->phase, own, RW_ASF); }
-    else if (s->green_act[g] == 1) { if (!green_local_work(x, gh)) brm += reward_table(s->phase, own, RW_LWF); }
+  for (int b = 0; b < NBLUE; ++b) if (s->bexec[b].type == BA_BLOCK || s->bexec[b].type == BA_ALLOW) blue_execute(x, b, s->bexec[b]);
+  for (int b = 0; b < NBLUE; ++b)
+    if (!(s->bexec[b].type == BA_BLOCK || s->bexec[b].type == BA_ALLOW)) {
+      rng_set_stream(x.r, ST_BLUE_EXE + (uint32_t)b);
+      blue_execute(x, b, s->bexec[b]);
+    }
+  CC4_TICK(x, 5);
+}
+// returns the BlueRewardMachine penalty of this green agent's action (<= 0)
+CC4_HD int step_green_exec(Ctx x, int g) {
+  EnvState* s = x.s;
+  int gh = s->green_host[g];
+  int own = h_subnet(gh);
+  s->phish_req[g] = 0;
+  rng_set_stream(x.r, ST_GREEN_EXE + (uint32_t)g);
+  if (s->green_act[g] == 0) return green_access_service(x, gh) ? 0 : reward_table(s->phase, own, RW_ASF);
+  if (s->green_act[g] == 1) {
+    bool want_phish = false;
+    bool ok = green_local_work(x, gh, &want_phish);
+    s->phish_req[g] = (uint8_t)want_phish;
+    return ok ? 0 : reward_table(s->phase, own, RW_LWF);
   }
-  for (int r = 0; r < NRED; ++r) if (rexec[r].type != RA_NONE) red_execute(x, r, rexec[r]);
-  // ---- reassignment, end-turn actions (SC:278-286)
+  return 0;
+}
+CC4_HD void step_phishing(Ctx x) {
+  EnvState* s = x.s;
+  for (int g = 0; g < s->n_green; ++g)
+    if (s->phish_req[g]) { rng_set_stream(x.r, ST_GREEN_PHISH + (uint32_t)g); phishing(x, s->green_host[g]); s->phish_req[g] = 0; }
+}
+CC4_HD void step_red_exec(Ctx x) {
+  EnvState* s = x.s;
+  for (int r = 0; r < NRED; ++r)
+    if (s->rexec[r].type != RA_NONE) { rng_set_stream(x.r, ST_RED_EXE + (uint32_t)r); red_execute(x, r, s->rexec[r]); }
+  CC4_TICK(x, 7);
   red_reassign(x);
-  for (int b = 0; b < NBLUE; ++b) blue_monitor(x, b);
-  for (int r = 0; r < NRED; ++r) if (s->red[r].active) red_session_check(x, r);
-  // ---- bookkeeping, reward (SC:297-311)
+  CC4_TICK(x, 8);
+}
+CC4_HD void step_monitor_host(Ctx x, int h) {  // the per-host part of Monitor.execute
+  EnvState* s = x.s;
+  if (!s->hs[h].exists || blue_of_subnet(h_subnet(h)) < 0) return;
+  uint8_t ev = s->hd[h].ev, nev = 0;
+  if (ev & EV_CUR_CONN) nev |= EV_OLD_CONN;
+  if (ev & EV_CUR_PROC) nev |= EV_OLD_PROC;
+  s->hd[h].ev = nev;
+}
+CC4_HD void step_monitor_pend(Ctx x) {  // session.add_sus_pids for the pid-carrying process_creation events
+  EnvState* s = x.s;
+  for (int i = 0; i < s->npend; ++i) {
+    int b = blue_of_subnet(h_subnet((int)(s->pend[i] >> 16)));
+    if (b < 0) continue;
+    BlueAgent& A = s->blue[b];
+    if (A.nsus >= MAX_SUS) set_err(x, E_SUS_OVERFLOW); else A.sus[A.nsus++] = s->pend[i];
+  }
+  s->npend = 0;
+}
+CC4_HD void step_rsc(Ctx x, int r) {
+  if (!x.s->red[r].active) return;
+  rng_set_stream(x.r, ST_RED_RSC + (uint32_t)r);
+  red_session_check(x, r);
+}
+CC4_HD void step_end(Ctx x, const uint8_t* messages) {
+  EnvState* s = x.s;
   s->step_count++;
   s->done = (uint8_t)(s->step_count >= s->steps - 1);
+  int brm = s->brm;
   for (int r = 0; r < NRED; ++r)
     if (s->red[r].exec_type == RA_IMPACT && s->red[r].nsess > 0)
       brm += reward_table(s->phase, h_subnet(s->red[r].exec_host), RW_RIA);  // charged for any executed Impact (App. B.2)
-  s->reward = (float)brm + action_cost;
+  s->reward = (float)brm + s->action_cost;
   if (messages) for (int b = 0; b < NBLUE; ++b) for (int i = 0; i < MSG_LEN; ++i) s->msg[b][i] = messages[b * MSG_LEN + i] ? 1 : 0;
   else for (int b = 0; b < NBLUE; ++b) for (int i = 0; i < MSG_LEN; ++i) s->msg[b][i] = 0;
+  rng_park(&s->rng);
+}
+
+// the serial walk: actions[5] = wrapper action index per blue agent (negative = no action submitted -> SleepAgent)
+CC4_HD void env_step(Ctx x, const int32_t* actions, const uint8_t* messages /* [5][8] or null */) {
+  EnvState* s = x.s;
+  CC4_TICK0(x);
+  if (!step_begin(x, actions)) return;
+  CC4_TICK(x, 0);
+  for (int g = 0; g < s->n_green; ++g) step_green_policy(x, g);
+  CC4_TICK(x, 1);
+  for (int r = 0; r < NRED; ++r) step_red_policy(x, r);
+  CC4_TICK(x, 2);
+  step_tick(x);
+  for (int g = 0; g < s->n_green; ++g) {
+    s->brm += step_green_exec(x, g);
+    if (s->phish_req[g]) { rng_set_stream(x.r, ST_GREEN_PHISH + (uint32_t)g); phishing(x, s->green_host[g]); s->phish_req[g] = 0; }
+  }
+  CC4_TICK(x, 6);
+  step_red_exec(x);
+  for (int h = 0; h < MAXH; ++h) step_monitor_host(x, h);
+  step_monitor_pend(x);
+  CC4_TICK(x, 9);
+  for (int r = 0; r < NRED; ++r) step_rsc(x, r);
+  CC4_TICK(x, 10);
+  step_end(x, messages);
 }
 
 // ------------------------------------------------------------------ BlueFlatWrapper.observation_change (BlueFlatWrapper.py:172-256)
-// out: OBS_TOTAL ints, agents 0..3 (92 each) then agent 4 (210)
+// out: OBS_TOTAL values, agents 0..3 (92 each) then agent 4 (210).  The vector splits into 12 independent parts:
+// parts 0..6 = the seven 59-value subnet blocks (agents 0..3 own one, agent 4 owns three), parts 7..11 = agent b's
+// phase word + 32 message bits.  The device encodes the parts on separate lanes; the host loops over them.
+enum : int { OBS_PARTS = 12 };
 template <typename T>
-CC4_HD void env_flat_obs(const EnvState* s, T* out) {
-  int o = 0;
-  for (int b = 0; b < NBLUE; ++b) {
-    out[o++] = (T)s->phase;
-    for (int i = 0; i < blue_nsub(b); ++i) {
-      int sn = blue_subnet_sorted(b, i);
-      for (int k = 0; k < NSUB; ++k) out[o++] = (T)(sorted_subnet(k) == sn);
-      for (int k = 0; k < NSUB; ++k) out[o++] = (T)((s->blocks[sn] >> sorted_subnet(k)) & 1u);
-      uint32_t adj = comms_adjacent(s->phase, sn);
-      for (int k = 0; k < NSUB; ++k) out[o++] = (T)(!((adj >> sorted_subnet(k)) & 1u));
-      for (int pass = 0; pass < 2; ++pass) {
-        int bits = pass == 0 ? (EV_CUR_PROC | EV_OLD_PROC) : (EV_CUR_CONN | EV_OLD_CONN);
-        for (int hs = 0; hs < ZONE_HOSTS; ++hs) {
-          int h = hs < MAX_SERVERS ? h_make(sn, 11 + hs) : h_make(sn, 1 + (hs - MAX_SERVERS));
-          out[o++] = (T)(s->hs[h].exists && (s->hd[h].ev & bits) != 0);
-        }
-      }
+CC4_HD void env_flat_obs_part(const EnvState* s, T* out, int part) {
+  if (part < 7) {
+    int b = part < 4 ? part : 4, i = part < 4 ? 0 : part - 4;
+    int o = (b < 4 ? b * OBS_SHORT : 4 * OBS_SHORT) + 1 + 59 * i;
+    int sn = blue_subnet_sorted(b, i);
+    uint32_t blk = s->blocks[sn];
+    uint32_t adj = comms_adjacent(s->phase, sn);
+    for (int k = 0; k < NSUB; ++k) {
+      int ss = sorted_subnet(k);
+      out[o + k] = (T)(ss == sn);
+      out[o + 9 + k] = (T)((blk >> ss) & 1u);
+      out[o + 18 + k] = (T)(!((adj >> ss) & 1u));
     }
+    for (int hs = 0; hs < ZONE_HOSTS; ++hs) {
+      int h = hs < MAX_SERVERS ? h_make(sn, 11 + hs) : h_make(sn, 1 + (hs - MAX_SERVERS));
+      int ev = s->hs[h].exists ? s->hd[h].ev : 0;
+      out[o + 27 + hs] = (T)((ev & (EV_CUR_PROC | EV_OLD_PROC)) != 0);
+      out[o + 43 + hs] = (T)((ev & (EV_CUR_CONN | EV_OLD_CONN)) != 0);
+    }
+  } else {
+    int b = part - 7;
+    int base = b < 4 ? b * OBS_SHORT : 4 * OBS_SHORT;
+    int len = b < 4 ? OBS_SHORT : OBS_LONG;
+    out[base] = (T)s->phase;
+    int o = base + len - 32;
     for (int j = 0; j < NBLUE; ++j) { if (j == b) continue; for (int i = 0; i < MSG_LEN; ++i) out[o++] = (T)s->msg[j][i]; }
   }
+}
+template <typename T>
+CC4_HD void env_flat_obs(const EnvState* s, T* out) {
+  for (int p = 0; p < OBS_PARTS; ++p) env_flat_obs_part<T>(s, out, p);
 }
 
 }  // namespace cc4

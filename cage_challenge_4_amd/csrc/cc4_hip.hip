@@ -28,6 +28,7 @@ struct StepArgs {
   const int32_t* actions; const uint8_t* msgs;
   int32_t* obs; float* reward; uint8_t* done; uint32_t* err;
   int n, autoreset, steps, rng_mode;
+  unsigned long long* prof;   // optional [n][16] cycle counters (CC4_PROFILE builds / cc4_debug_profile)
 };
 
 // ---------------------------------------------------------------- kernels
@@ -36,27 +37,112 @@ __global__ __launch_bounds__(WAVE) void k_step(StepArgs a) {
   __shared__ uint8_t obs_lds[OBS_TOTAL + 2];
   const int e = blockIdx.x, lane = threadIdx.x;
   if (e >= a.n) return;
+  unsigned long long t_begin = a.prof ? clock64() : 0;
   const uint4* src = reinterpret_cast<const uint4*>(a.st + e);
   for (int i = lane; i < ROW_VEC; i += WAVE) lds[i] = src[i];
   __syncthreads();
   EnvState* s = reinterpret_cast<EnvState*>(lds);
+  unsigned long long t_in = a.prof ? clock64() : 0;
   if (lane == 0) {
-    Ctx x{s, a.cold + e};
+    Ctx x{s, a.cold + e, &s->rng, a.prof ? a.prof + 16 * (size_t)e : nullptr};
+    if (a.prof) x.prof[11] += t_in - t_begin;
     if (a.autoreset && s->done) {
       env_reset(x, 0, a.rng_mode, a.steps, true);   // new episode, same stream (CybORG.reset(seed=None))
     } else {
       env_step(x, a.actions ? a.actions + e * NBLUE : nullptr, a.msgs ? a.msgs + e * NBLUE * MSG_LEN : nullptr);
     }
-    env_flat_obs<uint8_t>(s, obs_lds);
     a.reward[e] = s->reward;
     a.done[e] = s->done;
     a.err[e] = s->err;
   }
   __syncthreads();
+  unsigned long long t_obs = a.prof ? clock64() : 0;
+  if (lane < OBS_PARTS) env_flat_obs_part<uint8_t>(s, obs_lds, lane);   // 12 independent pieces of the flat observation
+  __syncthreads();
+  unsigned long long t_out = a.prof ? clock64() : 0;
+  if (a.prof && lane == 0) a.prof[16 * (size_t)e + 12] += t_out - t_obs;
   uint4* dst = reinterpret_cast<uint4*>(a.st + e);
   for (int i = lane; i < ROW_VEC; i += WAVE) dst[i] = lds[i];
   int32_t* o = a.obs + (size_t)e * OBS_TOTAL;
   for (int i = lane; i < OBS_TOTAL; i += WAVE) o[i] = obs_lds[i];
+  if (a.prof && lane == 0) { a.prof[16 * (size_t)e + 13] += clock64() - t_out; a.prof[16 * (size_t)e + 14] += clock64() - t_begin; }
+}
+
+// ---------------------------------------------------------------- Philox mode: lane-parallel step
+// Same phase bodies as the serial walk (cc4_engine.h P0..P9), different schedule: every (agent, phase) owns a Philox
+// counter stream, so the 6 red FSM policies, the <=80 green agents, the 137 per-host Monitor roll-overs and the 6
+// RedSessionChecks run on separate lanes; cross-lane effects are event-bit ORs and the reward sum (LDS atomics) and
+// the rare PhishingEmail spawns, which are collected per green and replayed by lane 0 in agent order.
+__global__ __launch_bounds__(WAVE) void k_step_philox(StepArgs a) {
+  extern __shared__ uint4 lds[];
+  __shared__ uint8_t obs_lds[OBS_TOTAL + 2];
+  __shared__ int ok_lds;
+  __shared__ Rng lane_rng[WAVE];   // lane-local generators live in LDS (a private copy would be spilled to scratch)
+  const int e = blockIdx.x, lane = threadIdx.x;
+  if (e >= a.n) return;
+  unsigned long long t_begin = a.prof ? clock64() : 0;
+  const uint4* src = reinterpret_cast<const uint4*>(a.st + e);
+  for (int i = lane; i < ROW_VEC; i += WAVE) lds[i] = src[i];
+  __syncthreads();
+  EnvState* s = reinterpret_cast<EnvState*>(lds);
+  unsigned long long* prof = a.prof ? a.prof + 16 * (size_t)e : nullptr;
+  if (prof && lane == 0) prof[11] += clock64() - t_begin;
+  const bool do_reset = a.autoreset && s->done;
+  if (do_reset) {
+    if (lane == 0) { Ctx x{s, a.cold + e, &s->rng}; env_reset(x, 0, a.rng_mode, a.steps, true); }
+  } else {
+    if (lane == 0) {
+      Ctx x{s, a.cold + e, &s->rng, prof};
+      CC4_TICK0(x);
+      ok_lds = step_begin(x, a.actions ? a.actions + e * NBLUE : nullptr) ? 1 : 0;
+      CC4_TICK(x, 0);
+    }
+    __syncthreads();
+    if (ok_lds) {
+      rng_fork(&lane_rng[lane], &s->rng, ST_RESET);
+      Ctx x{s, a.cold + e, &lane_rng[lane], lane == 0 ? prof : nullptr};
+      const int ng = s->n_green;
+      // P1 green policy draws (lanes 6..63) || P2 red FSM policies (lanes 0..5)
+      if (lane < NRED) step_red_policy(x, lane);
+      else for (int g = lane - NRED; g < ng; g += WAVE - NRED) step_green_policy(x, g);
+      __syncthreads();
+      CC4_TICK(x, 2);
+      // P3 duration queue + blue execution
+      if (lane == 0) step_tick(x);
+      __syncthreads();
+      // P4 green actions, one per lane
+      int pen = 0;
+      for (int g = lane; g < ng; g += WAVE) pen += step_green_exec(x, g);
+      if (pen) atomicAdd(&s->brm, pen);
+      __syncthreads();
+      CC4_TICK(x, 6);
+      // P5 deferred phishing, P6 red actions + reassignment
+      if (lane == 0) { step_phishing(x); step_red_exec(x); }
+      __syncthreads();
+      // P7 end-turn Monitor: per-host roll-over on all lanes, sus-pid hand-over on lane 0 (disjoint data)
+      for (int h = lane; h < MAXH; h += WAVE) step_monitor_host(x, h);
+      if (lane == 0) step_monitor_pend(x);
+      __syncthreads();
+      CC4_TICK(x, 9);
+      // P8 end-turn RedSessionCheck, one red agent per lane
+      if (lane < NRED) step_rsc(x, lane);
+      __syncthreads();
+      CC4_TICK(x, 10);
+      if (lane == 0) step_end(x, a.msgs ? a.msgs + e * NBLUE * MSG_LEN : nullptr);
+    }
+  }
+  __syncthreads();
+  if (lane == 0) { a.reward[e] = s->reward; a.done[e] = s->done; a.err[e] = s->err; }
+  unsigned long long t_obs = a.prof ? clock64() : 0;
+  if (lane < OBS_PARTS) env_flat_obs_part<uint8_t>(s, obs_lds, lane);
+  __syncthreads();
+  unsigned long long t_out = a.prof ? clock64() : 0;
+  if (prof && lane == 0) prof[12] += t_out - t_obs;
+  uint4* dst = reinterpret_cast<uint4*>(a.st + e);
+  for (int i = lane; i < ROW_VEC; i += WAVE) dst[i] = lds[i];
+  int32_t* o = a.obs + (size_t)e * OBS_TOTAL;
+  for (int i = lane; i < OBS_TOTAL; i += WAVE) o[i] = obs_lds[i];
+  if (prof && lane == 0) { prof[13] += clock64() - t_out; prof[14] += clock64() - t_begin; }
 }
 
 struct ResetArgs {
@@ -72,7 +158,7 @@ __global__ __launch_bounds__(WAVE) void k_reset(ResetArgs a) {
   if (a.env_mask && !a.env_mask[e]) return;
   EnvState* s = a.st + e;
   if (lane == 0) {
-    Ctx x{s, a.cold + e};
+    Ctx x{s, a.cold + e, &s->rng};
     env_reset(x, a.seeds ? a.seeds[e] : 0, a.rng_mode, a.steps, a.seeds == nullptr);
     env_flat_obs<uint8_t>(s, obs_lds);
     blue_action_mask(s, mask_lds);
@@ -115,6 +201,7 @@ struct cc4_handle {
   int32_t* d_obs = nullptr; float* d_reward = nullptr; uint8_t* d_done = nullptr; uint32_t* d_err = nullptr;
   uint8_t* d_mask = nullptr; uint64_t* d_rng = nullptr;
   int32_t* d_all_obs = nullptr;
+  unsigned long long* d_prof = nullptr;
   ncclComm_t comm = nullptr; int rank = 0, world = 1;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   std::vector<hipEvent_t> evs;
@@ -134,8 +221,9 @@ static thread_local std::string g_create_err;
 
 static int launch_step(cc4_handle* h, const int32_t* d_actions, const uint8_t* d_msgs) {
   StepArgs a{h->d_state, h->d_cold, d_actions, d_msgs, h->d_obs, h->d_reward, h->d_done, h->d_err,
-             h->cfg.num_envs, h->cfg.autoreset, h->cfg.steps, h->cfg.rng_mode};
-  hipLaunchKernelGGL(k_step, dim3(h->cfg.num_envs), dim3(WAVE), sizeof(EnvState), h->stream, a);
+             h->cfg.num_envs, h->cfg.autoreset, h->cfg.steps, h->cfg.rng_mode, h->d_prof};
+  if (h->cfg.rng_mode == 1) hipLaunchKernelGGL(k_step_philox, dim3(h->cfg.num_envs), dim3(WAVE), sizeof(EnvState), h->stream, a);
+  else hipLaunchKernelGGL(k_step, dim3(h->cfg.num_envs), dim3(WAVE), sizeof(EnvState), h->stream, a);
   HIPCHK(h, hipGetLastError());
   return 0;
 }
@@ -333,6 +421,16 @@ int cc4_get_topology(cc4_handle* h, int32_t env, uint8_t* out) {
   for (int i = 0; i < NSUB; ++i) { out[i] = tmp->cidr_octet[i]; out[9 + i] = tmp->n_users[i]; out[18 + i] = tmp->n_servers[i]; }
   for (int i = 0; i < MAXH; ++i) { out[27 + 2 * i] = tmp->hs[i].exists; out[28 + 2 * i] = tmp->hs[i].ip_octet; }
   free(tmp);
+  return 0;
+}
+
+// debug: enable (buf != NULL first call allocates) / read per-episode phase cycle counters [N][16]
+int cc4_debug_profile(cc4_handle* h, int enable, unsigned long long* out) {
+  HIPCHK(h, hipSetDevice(h->cfg.device_id));
+  size_t bytes = (size_t)h->cfg.num_envs * 16 * sizeof(unsigned long long);
+  if (enable && !h->d_prof) { HIPCHK(h, hipMalloc(&h->d_prof, bytes)); HIPCHK(h, hipMemsetAsync(h->d_prof, 0, bytes, h->stream)); }
+  if (out && h->d_prof) { HIPCHK(h, hipMemcpyAsync(out, h->d_prof, bytes, hipMemcpyDeviceToHost, h->stream)); HIPCHK(h, hipStreamSynchronize(h->stream)); }
+  if (!enable && h->d_prof) { (void)hipFree(h->d_prof); h->d_prof = nullptr; }
   return 0;
 }
 

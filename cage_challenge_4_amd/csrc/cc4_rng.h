@@ -5,7 +5,7 @@
 //   (reference: CybORG/env.py:73-77,236-237; numpy 1.26 / 2.x `_pcg64.pyx`, `pcg64.h`,
 //   `bit_generator.pyx` SeedSequence, `distributions.c` bounded integers / random_interval).
 // Mode 1 ("philox"): Philox4x32-10 keyed by (seed) with counter (draw index, step): the
-//   (counter words: draw index lo/hi, step, episode) --
+//   (counter words: draw index, stream id, step, episode) --
 //   counter-based stream BASELINE.json's north_star asks for.  Same draw *sites*, different bits.
 //
 // Every distribution helper below states the numpy routine it restates.
@@ -14,7 +14,7 @@
 #include <stddef.h>
 
 #if defined(__HIPCC__)
-#define CC4_HD __host__ __device__ inline
+#define CC4_HD __host__ __device__ __forceinline__
 #else
 #define CC4_HD inline
 #endif
@@ -35,8 +35,13 @@ struct Rng {
   uint32_t has32;           // numpy pcg64_state.has_uint32
   uint32_t u32;             // numpy pcg64_state.uinteger (buffered high half)
   uint32_t mode;            // 0 pcg, 1 philox
-  uint32_t ndraw;           // number of 64-bit advances (diagnostics / parity bisecting)
+  uint32_t ndraw;           // pcg: number of 64-bit advances (diagnostics) | philox: current stream id
 };
+
+// Philox stream ids: every (agent, phase) of a step draws from its own counter stream, so agents can be resolved on
+// separate lanes and still reproduce the serial oracle bit for bit.  Counter = (draw#, stream, step, episode).
+enum : uint32_t { ST_RESET = 0, ST_BLUE_EXE = 0x100, ST_GREEN_POL = 0x200, ST_GREEN_EXE = 0x300, ST_GREEN_PHISH = 0x400,
+                  ST_RED_POL = 0x500, ST_RED_EXE = 0x600, ST_RED_RSC = 0x700 };
 
 // ---- SeedSequence (numpy/random/bit_generator.pyx: SeedSequence.mix_entropy / generate_state) ----
 CC4_HD uint32_t ss_hashmix(uint32_t value, uint32_t* hash_const) {
@@ -132,22 +137,36 @@ CC4_HD void rng_seed(Rng* r, uint64_t seed, uint32_t mode) {
 
 // philox mode: called at the start of every env step -> counter = (draw#, step)
 CC4_HD void rng_begin_step(Rng* r, uint32_t step) {
-  if (r->mode == 1) { r->inc_lo = (uint64_t)step; r->s_hi = 0; r->has32 = 0; }
+  if (r->mode == 1) { r->inc_lo = (uint64_t)step; r->s_hi = 0; r->has32 = 0; r->ndraw = 0; }
+}
+// philox: switch to stream `id` at draw 0 (each stream is used once per step). pcg: no-op (one shared stream).
+CC4_HD void rng_set_stream(Rng* r, uint32_t id) {
+  if (r->mode == 1) { r->ndraw = id; r->s_hi = 0; r->has32 = 0; }
+}
+// philox: between steps only (key, episode) matter; park the scratch words so that the serial walk (which switches
+// streams in place) and the lane-parallel kernel (which forks lane-local generators) leave identical bytes behind
+CC4_HD void rng_park(Rng* r) {
+  if (r->mode == 1) { r->s_hi = 0; r->has32 = 0; r->u32 = 0; r->ndraw = 0; }
+}
+// philox: lane-local generator for stream `id` of the current (step, episode) of `parent`
+CC4_HD void rng_fork(Rng* r, const Rng* parent, uint32_t id) {
+  *r = *parent;
+  rng_set_stream(r, id);
 }
 // philox mode: a new episode (reset) bumps the 4th counter word so successive episodes differ
 CC4_HD void rng_begin_episode(Rng* r) {
-  if (r->mode == 1) { r->inc_hi++; r->inc_lo = 0xFFFFFFFFull; r->s_hi = 0; r->has32 = 0; }
+  if (r->mode == 1) { r->inc_hi++; r->inc_lo = 0xFFFFFFFFull; r->s_hi = 0; r->has32 = 0; r->ndraw = ST_RESET; }
 }
 
 CC4_HD uint64_t rng_next64(Rng* r) {
-  r->ndraw++;
   if (r->mode == 0) {
+    r->ndraw++;
     pcg_step(r);
     uint64_t x = r->s_hi ^ r->s_lo;
     uint32_t rot = (uint32_t)(r->s_hi >> 58);
     return (x >> rot) | (x << ((64u - rot) & 63u));
   }
-  uint32_t c[4] = {(uint32_t)r->s_hi, (uint32_t)(r->s_hi >> 32), (uint32_t)r->inc_lo, (uint32_t)r->inc_hi};
+  uint32_t c[4] = {(uint32_t)r->s_hi, r->ndraw, (uint32_t)r->inc_lo, (uint32_t)r->inc_hi};
   philox4x32_10(c, (uint32_t)r->s_lo, (uint32_t)(r->s_lo >> 32));
   r->s_hi++;
   return (uint64_t)c[0] | ((uint64_t)c[1] << 32);

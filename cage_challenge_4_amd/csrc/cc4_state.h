@@ -146,6 +146,13 @@ struct alignas(16) EnvState {
   RedAgent red[NRED];
   uint8_t msg[NBLUE][MSG_LEN];       // messages submitted with the last step
   uint32_t kb_used[MAX_KB / 32];
+  // per-step scratch shared by the phases of a step (the lane-parallel kernel hands work between lanes through it)
+  Act bexec[NBLUE];                  // self.action[blue_b][0] of this step
+  Act rexec[NRED];
+  int32_t brm;                       // BlueRewardMachine accumulator
+  float action_cost;
+  int32_t n_actions;                 // actions surviving filter_actions (length of the shuffled index list)
+  uint8_t phish_req[MAXG];           // green g's LocalWork asked for a PhishingEmail this step
 };
 
 struct alignas(16) EnvCold {

@@ -48,12 +48,12 @@ void* cc4o_cold_ptr(void* h, int i) { return &((Oracle*)h)->cold[i]; }
 
 void cc4o_reset(void* h, int i, uint64_t seed, int rng_mode, int steps, int continue_stream) {
   Oracle* o = (Oracle*)h;
-  Ctx x{&o->st[i], &o->cold[i]};
+  Ctx x{&o->st[i], &o->cold[i], &o->st[i].rng};
   env_reset(x, seed, rng_mode, steps, continue_stream != 0);
 }
 void cc4o_step(void* h, int i, const int32_t* actions, const uint8_t* msgs) {
   Oracle* o = (Oracle*)h;
-  Ctx x{&o->st[i], &o->cold[i]};
+  Ctx x{&o->st[i], &o->cold[i], &o->st[i].rng};
   env_step(x, actions, msgs);
 }
 // whole-batch step, OpenMP over envs when built with -fopenmp (bench.py cpu_baseline)
@@ -61,7 +61,7 @@ void cc4o_step_all(void* h, const int32_t* actions /* [n][5] */) {
   Oracle* o = (Oracle*)h;
 #pragma omp parallel for schedule(dynamic, 4)
   for (int i = 0; i < o->n; ++i) {
-    Ctx x{&o->st[i], &o->cold[i]};
+    Ctx x{&o->st[i], &o->cold[i], &o->st[i].rng};
     env_step(x, actions + 5 * i, nullptr);
   }
 }

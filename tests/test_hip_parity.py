@@ -62,7 +62,8 @@ def test_hip_matches_oracle_bit_for_bit(rng_mode):
         assert np.array_equal(d[3]['err'], o[3]['err']), t
     assert np.array_equal(dev.rng_state(), ora.rng_state())
     for i in range(0, n, 7):
-        assert np.array_equal(dev.get_state(i), ora.get_state(i)), f'packed state differs env {i}'
+        a_, b_ = dev.get_state(i), ora.get_state(i)
+        assert np.array_equal(a_, b_), f'packed state differs env {i} at byte offsets {np.nonzero(a_ != b_)[0][:20].tolist()}'
     dev.close()
 
 

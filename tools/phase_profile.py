@@ -1,0 +1,23 @@
+#!/usr/bin/env python
+"""Per-phase cycle breakdown of k_step (lane-0 walk) from the in-kernel counters (cc4_debug_profile)."""
+import ctypes, sys, os
+import numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from cage_challenge_4_amd import CC4VecEnv
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
+K = int(sys.argv[2]) if len(sys.argv) > 2 else 200
+mode = int(sys.argv[3]) if len(sys.argv) > 3 else 0
+env = CC4VecEnv(n, steps=500, autoreset=True, rng_mode=mode)
+env.reset(seeds=1000)
+env.run_random_steps(1000, 0, 50, timed=False)
+env.lib.cc4_debug_profile(env._h, 1, None)
+ms = env.run_random_steps(1000, 50, K, timed=True)
+out = np.zeros((n, 16), np.uint64)
+env.lib.cc4_debug_profile(env._h, 1, out.ctypes.data_as(ctypes.c_void_p))
+names = ['blue decode/queue', 'green policy draws', 'red FSM policy', 'queue tick', 'shuffle', 'blue exec', 'green exec', 'red exec',
+         'reassign', 'monitor x5', 'red session check', 'stage in', 'flat obs', 'stage out', 'TOTAL', '-']
+c = out.astype(np.float64) / K
+tot = c[:, 14].mean()
+print(f'rng_mode={mode} n={n} K={K} kernel ms/launch {ms / K:.4f}; mean cycles/step per episode {tot:.0f}; max over episodes {c[:, 14].max():.0f}')
+for i in list(range(14)):
+    print(f'{names[i]:22s} {c[:, i].mean():10.0f} cyc  {100 * c[:, i].mean() / tot:5.1f}%   (max {c[:, i].max():.0f})')
