@@ -160,8 +160,12 @@ CC4_HD void obs_put(Ctx x, int r, bool key_ip, int host, int flags, bool subnet_
   if (flags & OE_SYSHN) bit_set(a.as_hn, host);
   if (subnet_known) a.as_subnet |= (uint16_t)(1u << h_subnet(host));
   uint8_t want = (uint8_t)(key_ip ? OE_KEY_IP : 0);
-  for (int i = 0; i < a.nobs; ++i)
-    if (a.obs[i].host == host && (a.obs[i].flags & OE_KEY_IP) == want) { a.obs[i].flags |= (uint8_t)flags; return; }
+  uint32_t* has = a.obs_has[key_ip ? 1 : 0];
+  if (bit_get(has, host)) {
+    for (int i = 0; i < a.nobs; ++i)
+      if (a.obs[i].host == host && (a.obs[i].flags & OE_KEY_IP) == want) { a.obs[i].flags |= (uint8_t)flags; return; }
+  }
+  bit_set(has, host);
   if (a.nobs >= MAX_OBS) { set_err(x, E_OBS_OVERFLOW); return; }
   a.obs[a.nobs].host = (uint8_t)host;
   a.obs[a.nobs].flags = (uint8_t)(flags | want);
@@ -555,16 +559,35 @@ CC4_HD void blue_execute(Ctx x, int b, const Act& a) {
 // PhishingEmail._create_new_session (ConcreteActions/PhishingEmail.py:42-113)
 CC4_HD void phishing(Ctx x, int gh) {
   EnvState* s = x.s;
-  for (int r = 0; r < NRED; ++r) if (red_has_session_on(s->red[r], gh)) return;
+  // per-agent bitmap of hosts holding one of its sessions (one pass over the session tables instead of a
+  // hosts x agents x sessions scan)
+  uint32_t has[NRED][5];
+  uint32_t any[5] = {0, 0, 0, 0, 0};
+  for (int r = 0; r < NRED; ++r) {
+    for (int w = 0; w < 5; ++w) has[r][w] = 0;
+    const RedAgent& A = s->red[r];
+    for (int i = 0; i < A.nsess; ++i) bit_set(has[r], A.sess[i].host);
+    for (int w = 0; w < 5; ++w) any[w] |= has[r][w];
+  }
+  if (bit_get(any, gh)) return;  // a red agent already has a session on the green host (PhishingEmail.py:57-59)
   int src = -1;
   uint8_t cand[NRED * MAX_RS]; int nc = 0;
   int gsub = h_subnet(gh);
-  for (int h = 0; h < MAXH; ++h) {
-    if (!s->hs[h].exists) continue;
-    for (int r = 0; r < NRED; ++r) {
-      if (!red_has_session_on(s->red[r], h)) continue;
-      if (h_subnet(h) == gsub) { src = r; break; }
-      if (nc < NRED * MAX_RS) cand[nc++] = (uint8_t)r;
+  for (int w = 0; w < 5; ++w) {
+    uint32_t m = any[w];
+    while (m) {  // hosts with red sessions, increasing host id == state.hosts order
+#if defined(__HIP_DEVICE_COMPILE__)
+      int b = __ffs((int)m) - 1;
+#else
+      int b = __builtin_ctz(m);
+#endif
+      m &= m - 1;
+      int h = w * 32 + b;
+      for (int r = 0; r < NRED; ++r) {
+        if (!bit_get(has[r], h)) continue;
+        if (h_subnet(h) == gsub) { src = r; break; }  // `break` leaves only the inner loop (PhishingEmail.py:63-69)
+        if (nc < NRED * MAX_RS) cand[nc++] = (uint8_t)r;
+      }
     }
   }
   if (src < 0) {
@@ -879,6 +902,11 @@ CC4_HD void fsm_apply(Ctx x, int r, int h, int act, bool success) {  // _host_st
   if (nx == FS_U) nx = ((red_allowed_mask(r) >> h_subnet(h)) & 1u) ? FS_U : FS_F;
   if (nx == 0xFF) nx = cur;
   A.fsm_state[h] = (uint8_t)nx;
+  if (nx == FS_F && cur != FS_F) {  // leaves known_hosts for good
+    int n = 0;
+    for (int i = 0; i < A.fsm_n; ++i) if (A.fsm_order[i] != h) A.fsm_order[n++] = A.fsm_order[i];
+    A.fsm_n = (uint8_t)n;
+  }
 }
 CC4_HD void fsm_observe(Ctx x, int r) {
   RedAgent& A = x.s->red[r];
@@ -887,7 +915,11 @@ CC4_HD void fsm_observe(Ctx x, int r) {
     bool ok = A.obs_success == T_TRUE;
     int t = A.obs_act_type;
     if (t == RA_DRS) {
-      for (int i = 0; i < A.fsm_n; ++i) { int h = A.fsm_order[i]; if (h_subnet(h) == A.obs_act_arg) fsm_apply(x, r, h, t, ok); }
+      for (int i = 0; i < A.fsm_n;) {  // fsm_apply may drop the host from the list (next state 'F')
+        int h = A.fsm_order[i];
+        if (h_subnet(h) == A.obs_act_arg) { fsm_apply(x, r, h, t, ok); if (i < A.fsm_n && A.fsm_order[i] == h) ++i; }
+        else ++i;
+      }
     } else if (t == RA_PRIVESC || t == RA_IMPACT || t == RA_DEGRADE) {
       int h = A.obs_act_host;  // matched through host_states[ip]['hostname']
       if (A.fsm_state[h] != FS_NONE && bit_get(A.fsm_hn, h)) fsm_apply(x, r, h, t, ok);
@@ -896,8 +928,10 @@ CC4_HD void fsm_observe(Ctx x, int r) {
     }
   }
   // 2. _process_new_observations (:190-250)
+  uint32_t sess_seen[5] = {0, 0, 0, 0, 0};
   for (int i = 0; i < A.nobs; ++i) {
     int h = A.obs[i].host; int f = A.obs[i].flags;
+    if (f & OE_SESS) bit_set(sess_seen, h);
     bool hn = !(f & OE_KEY_IP) || (f & OE_SYSHN);
     bool ip = (f & OE_KEY_IP) || (f & OE_IFACE);
     if (!ip) {
@@ -915,9 +949,7 @@ CC4_HD void fsm_observe(Ctx x, int r) {
   for (int i = 0; i < A.fsm_n; ++i) {
     int h = A.fsm_order[i]; int st = A.fsm_state[h];
     if (st != FS_U && st != FS_UD && st != FS_R && st != FS_RD) continue;
-    bool seen = false;
-    for (int j = 0; j < A.nobs; ++j) if (A.obs[j].host == h && (A.obs[j].flags & OE_SESS)) { seen = true; break; }
-    if (!seen) A.fsm_state[h] = FS_KD;
+    if (!bit_get(sess_seen, h)) A.fsm_state[h] = FS_KD;
   }
 }
 // get_action (:58-122) incl. _choose_host (:252-293) and _choose_host_and_action (:296-336)
@@ -927,12 +959,9 @@ CC4_HD Act fsm_get_action(Ctx x, int r) {
   Act out; out.type = RA_SLEEP; out.host = 0; out.arg = 0; out.ticks = 1; out.sid = 0; out.busy = 0;
   fsm_observe(x, r);
   if (A.obs_success == T_IN_PROGRESS) { A.fsm_step++; return out; }
-  int n = 0;
-  for (int i = 0; i < A.fsm_n; ++i) if (A.fsm_state[A.fsm_order[i]] != FS_F) n++;
+  int n = A.fsm_n;  // fsm_order holds exactly the non-'F' hosts, in host_states insertion order
   if (n == 0) { set_err(x, E_FSM_NO_HOST); A.fsm_step++; return out; }
-  int c = (int)rng_below(x.r, (uint32_t)n);
-  int host = -1;
-  for (int i = 0; i < A.fsm_n; ++i) { int h = A.fsm_order[i]; if (A.fsm_state[h] == FS_F) continue; if (c-- == 0) { host = h; break; } }
+  int host = A.fsm_order[rng_below(x.r, (uint32_t)n)];
   // options in red_actions list order (ESG.py:764-768) with state_transitions_probability (:540-549)
   uint8_t acts[4]; double cdf[4]; int no = 0;
   switch (A.fsm_state[host]) {
@@ -1076,6 +1105,7 @@ CC4_HD void step_tick(Ctx x) {
   for (int r = 0; r < NRED; ++r) {
     RedAgent& A = s->red[r];
     A.nobs = 0; A.obs_success = 0; A.obs_act_type = RA_NONE; A.new_sess_host = 0xFF;
+    for (int w = 0; w < 5; ++w) { A.obs_has[0][w] = 0; A.obs_has[1][w] = 0; }
     Act& q = A.queue;
     q.ticks--;
     if (q.ticks < 1) { s->rexec[r] = q; q.busy = 0; }

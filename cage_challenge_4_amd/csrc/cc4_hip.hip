@@ -32,40 +32,96 @@ struct StepArgs {
 };
 
 // ---------------------------------------------------------------- kernels
+// HBM -> LDS row staging with 8 independent 16-byte loads in flight per lane (a plain copy loop serialises on vmcnt)
+__device__ __forceinline__ void stage_in(uint4* __restrict__ lds, const uint4* __restrict__ src, int lane) {
+  constexpr int U = 8;
+  int i = lane;
+  for (; i + (U - 1) * WAVE < ROW_VEC; i += U * WAVE) {
+    uint4 v[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) v[u] = src[i + u * WAVE];
+#pragma unroll
+    for (int u = 0; u < U; ++u) lds[i + u * WAVE] = v[u];
+  }
+  for (; i < ROW_VEC; i += WAVE) lds[i] = src[i];
+}
+__device__ __forceinline__ void stage_out(uint4* __restrict__ dst, const uint4* __restrict__ lds, int lane) {
+  constexpr int U = 8;
+  int i = lane;
+  for (; i + (U - 1) * WAVE < ROW_VEC; i += U * WAVE) {
+    uint4 v[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) v[u] = lds[i + u * WAVE];
+#pragma unroll
+    for (int u = 0; u < U; ++u) dst[i + u * WAVE] = v[u];
+  }
+  for (; i < ROW_VEC; i += WAVE) dst[i] = lds[i];
+}
+
 __global__ __launch_bounds__(WAVE) void k_step(StepArgs a) {
+  // numpy-PCG64 mode: one shared stream => the agent walk is strictly serial (lane 0); only the RNG-free parts
+  // (row staging, end-turn Monitor roll-over over the 137 hosts, observation encode) use the other lanes.
   extern __shared__ uint4 lds[];
   __shared__ uint8_t obs_lds[OBS_TOTAL + 2];
+  __shared__ int ok_lds;
   const int e = blockIdx.x, lane = threadIdx.x;
   if (e >= a.n) return;
   unsigned long long t_begin = a.prof ? clock64() : 0;
   const uint4* src = reinterpret_cast<const uint4*>(a.st + e);
-  for (int i = lane; i < ROW_VEC; i += WAVE) lds[i] = src[i];
+  stage_in(lds, src, lane);
   __syncthreads();
   EnvState* s = reinterpret_cast<EnvState*>(lds);
-  unsigned long long t_in = a.prof ? clock64() : 0;
+  unsigned long long* prof = a.prof ? a.prof + 16 * (size_t)e : nullptr;
+  Ctx x{s, a.cold + e, &s->rng, lane == 0 ? prof : nullptr};
+  if (prof && lane == 0) prof[11] += clock64() - t_begin;
+  const bool do_reset = a.autoreset && s->done;
   if (lane == 0) {
-    Ctx x{s, a.cold + e, &s->rng, a.prof ? a.prof + 16 * (size_t)e : nullptr};
-    if (a.prof) x.prof[11] += t_in - t_begin;
-    if (a.autoreset && s->done) {
+    ok_lds = 0;
+    if (do_reset) {
       env_reset(x, 0, a.rng_mode, a.steps, true);   // new episode, same stream (CybORG.reset(seed=None))
     } else {
-      env_step(x, a.actions ? a.actions + e * NBLUE : nullptr, a.msgs ? a.msgs + e * NBLUE * MSG_LEN : nullptr);
+      CC4_TICK0(x);
+      if (step_begin(x, a.actions ? a.actions + e * NBLUE : nullptr)) {
+        ok_lds = 1;
+        CC4_TICK(x, 0);
+        for (int g = 0; g < s->n_green; ++g) step_green_policy(x, g);
+        CC4_TICK(x, 1);
+        for (int r = 0; r < NRED; ++r) step_red_policy(x, r);
+        CC4_TICK(x, 2);
+        step_tick(x);
+        for (int g = 0; g < s->n_green; ++g) {
+          s->brm += step_green_exec(x, g);
+          if (s->phish_req[g]) { phishing(x, s->green_host[g]); s->phish_req[g] = 0; }
+        }
+        CC4_TICK(x, 6);
+        step_red_exec(x);
+      }
     }
-    a.reward[e] = s->reward;
-    a.done[e] = s->done;
-    a.err[e] = s->err;
   }
   __syncthreads();
+  if (ok_lds) {
+    for (int h = lane; h < MAXH; h += WAVE) step_monitor_host(x, h);
+    if (lane == 0) step_monitor_pend(x);
+    __syncthreads();
+    if (lane == 0) {
+      CC4_TICK(x, 9);
+      for (int r = 0; r < NRED; ++r) step_rsc(x, r);
+      CC4_TICK(x, 10);
+      step_end(x, a.msgs ? a.msgs + e * NBLUE * MSG_LEN : nullptr);
+    }
+    __syncthreads();
+  }
+  if (lane == 0) { a.reward[e] = s->reward; a.done[e] = s->done; a.err[e] = s->err; }
   unsigned long long t_obs = a.prof ? clock64() : 0;
   if (lane < OBS_PARTS) env_flat_obs_part<uint8_t>(s, obs_lds, lane);   // 12 independent pieces of the flat observation
   __syncthreads();
   unsigned long long t_out = a.prof ? clock64() : 0;
-  if (a.prof && lane == 0) a.prof[16 * (size_t)e + 12] += t_out - t_obs;
+  if (prof && lane == 0) prof[12] += t_out - t_obs;
   uint4* dst = reinterpret_cast<uint4*>(a.st + e);
-  for (int i = lane; i < ROW_VEC; i += WAVE) dst[i] = lds[i];
+  stage_out(dst, lds, lane);
   int32_t* o = a.obs + (size_t)e * OBS_TOTAL;
   for (int i = lane; i < OBS_TOTAL; i += WAVE) o[i] = obs_lds[i];
-  if (a.prof && lane == 0) { a.prof[16 * (size_t)e + 13] += clock64() - t_out; a.prof[16 * (size_t)e + 14] += clock64() - t_begin; }
+  if (prof && lane == 0) { prof[13] += clock64() - t_out; prof[14] += clock64() - t_begin; }
 }
 
 // ---------------------------------------------------------------- Philox mode: lane-parallel step
@@ -82,7 +138,7 @@ __global__ __launch_bounds__(WAVE) void k_step_philox(StepArgs a) {
   if (e >= a.n) return;
   unsigned long long t_begin = a.prof ? clock64() : 0;
   const uint4* src = reinterpret_cast<const uint4*>(a.st + e);
-  for (int i = lane; i < ROW_VEC; i += WAVE) lds[i] = src[i];
+  stage_in(lds, src, lane);
   __syncthreads();
   EnvState* s = reinterpret_cast<EnvState*>(lds);
   unsigned long long* prof = a.prof ? a.prof + 16 * (size_t)e : nullptr;
@@ -139,7 +195,7 @@ __global__ __launch_bounds__(WAVE) void k_step_philox(StepArgs a) {
   unsigned long long t_out = a.prof ? clock64() : 0;
   if (prof && lane == 0) prof[12] += t_out - t_obs;
   uint4* dst = reinterpret_cast<uint4*>(a.st + e);
-  for (int i = lane; i < ROW_VEC; i += WAVE) dst[i] = lds[i];
+  stage_out(dst, lds, lane);
   int32_t* o = a.obs + (size_t)e * OBS_TOTAL;
   for (int i = lane; i < OBS_TOTAL; i += WAVE) o[i] = obs_lds[i];
   if (prof && lane == 0) { prof[13] += clock64() - t_out; prof[14] += clock64() - t_begin; }

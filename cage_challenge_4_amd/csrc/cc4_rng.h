@@ -36,6 +36,8 @@ struct Rng {
   uint32_t u32;             // numpy pcg64_state.uinteger (buffered high half)
   uint32_t mode;            // 0 pcg, 1 philox
   uint32_t ndraw;           // pcg: number of 64-bit advances (diagnostics) | philox: current stream id
+  uint64_t buf64;           // philox: second 64-bit word of the last 128-bit block
+  uint32_t has64, pad;      // philox: buf64 is valid
 };
 
 // Philox stream ids: every (agent, phase) of a step draws from its own counter stream, so agents can be resolved on
@@ -113,7 +115,7 @@ CC4_HD void philox4x32_10(uint32_t c[4], uint32_t k0, uint32_t k1) {
 }
 
 CC4_HD void rng_seed(Rng* r, uint64_t seed, uint32_t mode) {
-  r->has32 = 0; r->u32 = 0; r->mode = mode; r->ndraw = 0;
+  r->has32 = 0; r->u32 = 0; r->mode = mode; r->ndraw = 0; r->buf64 = 0; r->has64 = 0; r->pad = 0;
   if (mode == 0) {
     uint64_t v[4];
     seed_sequence_state(seed, v);
@@ -137,16 +139,16 @@ CC4_HD void rng_seed(Rng* r, uint64_t seed, uint32_t mode) {
 
 // philox mode: called at the start of every env step -> counter = (draw#, step)
 CC4_HD void rng_begin_step(Rng* r, uint32_t step) {
-  if (r->mode == 1) { r->inc_lo = (uint64_t)step; r->s_hi = 0; r->has32 = 0; r->ndraw = 0; }
+  if (r->mode == 1) { r->inc_lo = (uint64_t)step; r->s_hi = 0; r->has32 = 0; r->has64 = 0; r->ndraw = 0; }
 }
 // philox: switch to stream `id` at draw 0 (each stream is used once per step). pcg: no-op (one shared stream).
 CC4_HD void rng_set_stream(Rng* r, uint32_t id) {
-  if (r->mode == 1) { r->ndraw = id; r->s_hi = 0; r->has32 = 0; }
+  if (r->mode == 1) { r->ndraw = id; r->s_hi = 0; r->has32 = 0; r->has64 = 0; }
 }
 // philox: between steps only (key, episode) matter; park the scratch words so that the serial walk (which switches
 // streams in place) and the lane-parallel kernel (which forks lane-local generators) leave identical bytes behind
 CC4_HD void rng_park(Rng* r) {
-  if (r->mode == 1) { r->s_hi = 0; r->has32 = 0; r->u32 = 0; r->ndraw = 0; }
+  if (r->mode == 1) { r->s_hi = 0; r->has32 = 0; r->u32 = 0; r->ndraw = 0; r->has64 = 0; r->buf64 = 0; }
 }
 // philox: lane-local generator for stream `id` of the current (step, episode) of `parent`
 CC4_HD void rng_fork(Rng* r, const Rng* parent, uint32_t id) {
@@ -155,7 +157,7 @@ CC4_HD void rng_fork(Rng* r, const Rng* parent, uint32_t id) {
 }
 // philox mode: a new episode (reset) bumps the 4th counter word so successive episodes differ
 CC4_HD void rng_begin_episode(Rng* r) {
-  if (r->mode == 1) { r->inc_hi++; r->inc_lo = 0xFFFFFFFFull; r->s_hi = 0; r->has32 = 0; r->ndraw = ST_RESET; }
+  if (r->mode == 1) { r->inc_hi++; r->inc_lo = 0xFFFFFFFFull; r->s_hi = 0; r->has32 = 0; r->has64 = 0; r->ndraw = ST_RESET; }
 }
 
 CC4_HD uint64_t rng_next64(Rng* r) {
@@ -166,9 +168,12 @@ CC4_HD uint64_t rng_next64(Rng* r) {
     uint32_t rot = (uint32_t)(r->s_hi >> 58);
     return (x >> rot) | (x << ((64u - rot) & 63u));
   }
+  if (r->has64) { r->has64 = 0; return r->buf64; }   // one Philox block = two 64-bit outputs
   uint32_t c[4] = {(uint32_t)r->s_hi, r->ndraw, (uint32_t)r->inc_lo, (uint32_t)r->inc_hi};
   philox4x32_10(c, (uint32_t)r->s_lo, (uint32_t)(r->s_lo >> 32));
   r->s_hi++;
+  r->buf64 = (uint64_t)c[2] | ((uint64_t)c[3] << 32);
+  r->has64 = 1;
   return (uint64_t)c[0] | ((uint64_t)c[1] << 32);
 }
 

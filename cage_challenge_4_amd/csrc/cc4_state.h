@@ -96,12 +96,14 @@ struct ObsEnt { uint8_t host; uint8_t flags; };
 struct RedAgent {
   RSess sess[MAX_RS];
   uint16_t known_sid[MAX_KS];        // ActionSpace.server_session keys with value True, insertion order
-  uint8_t fsm_order[MAXH];           // host_states dict insertion order
+  uint8_t fsm_order[MAXH];           // host_states dict insertion order, restricted to hosts whose state is not 'F'
+                                     // ('F' is absorbing and excluded from known_hosts, FiniteStateRedAgent.py:114)
   uint8_t fsm_state[MAXH];           // FS_* or FS_NONE
   uint32_t fsm_hn[5];                // host_states[ip]['hostname'] is not None
   uint32_t as_ip[5];                 // ActionSpace.ip_address[ip] == True
   uint32_t as_hn[5];                 // ActionSpace.hostname[name] == True
   ObsEnt obs[MAX_OBS];
+  uint32_t obs_has[2][5];            // which (key type, host) pairs are already in obs[] this step
   Act queue;                         // actions_in_progress[agent]
   Act chosen;                        // action produced by the policy this step (scratch)
   uint16_t as_subnet;                // ActionSpace.subnet known bits

@@ -146,6 +146,7 @@ int cc4o_dump(void* h, int i, char* buf, int cap) {
     for (int k = 0; k < a.nknown; ++k) P(" %d", a.known_sid[k]);
     P(" fsmstep %d fsm", a.fsm_step);
     for (int k = 0; k < a.fsm_n; ++k) { int hh = a.fsm_order[k]; P(" (%d,%d,%d)", hh, a.fsm_state[hh], bit_get(a.fsm_hn, hh) ? 1 : 0); }
+    for (int hh = 0; hh < MAXH; ++hh) if (a.fsm_state[hh] == FS_F) P(" (%d,%d,%d)", hh, FS_F, bit_get(a.fsm_hn, hh) ? 1 : 0);  // 'F' hosts after the live list
     P(" subnets %u busy %d qt %d\n", a.as_subnet, a.queue.busy, a.queue.busy ? a.queue.type : -1);
   }
   for (int b = 0; b < NBLUE; ++b) {

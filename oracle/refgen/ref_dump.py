@@ -59,7 +59,12 @@ def dump(env):
                         for sid, s in st.sessions[name].items())
         known = ' '.join(str(k) for k, v in ai.action_space.server_session.items() if v)
         ag = ai.agent
-        fsm = ' '.join(f"({ip2h[ip]},{FSM[d['state']]},{int(d['hostname'] is not None)})" for ip, d in ag.host_states.items()) if hasattr(ag, 'host_states') else ''
+        if hasattr(ag, 'host_states'):   # live (non-'F') hosts in dict order, then the 'F' hosts by host id (cc4o_dump convention)
+            ent = [(ip2h[ip], FSM[d['state']], int(d['hostname'] is not None)) for ip, d in ag.host_states.items()]
+            ent = [t for t in ent if t[1] != 8] + sorted(t for t in ent if t[1] == 8)
+            fsm = ' '.join(f"({a},{b},{c})" for a, b, c in ent)
+        else:
+            fsm = ''
         subn = 0
         cidr2s = {c: subnet_index(n) for n, c in st.subnet_name_to_cidr.items()}
         for c, v in ai.action_space.subnet.items():

@@ -122,6 +122,29 @@ def test_full_size_properties(n):
         e.close()
 
 
+def test_rccl_allgather_world_size_one():
+    """The native RCCL exchange step (cc4_comm_init / cc4_allgather_obs) on a 1-rank communicator: gathered == local."""
+    import ctypes
+    n = 256
+    dev = _dev(n, steps=50); dev.reset(seeds=3)
+    ident = (ctypes.c_uint8 * 128)()
+    assert dev.lib.cc4_comm_unique_id(ident) == 0
+    dev._chk(dev.lib.cc4_comm_init(dev._h, 0, 1, ident), 'cc4_comm_init')
+    obs, *_ = dev.step(random_actions(3, 0, n))
+    p = ctypes.c_void_p()
+    dev._chk(dev.lib.cc4_allgather_obs(dev._h, ctypes.byref(p)), 'cc4_allgather_obs')
+    dev.synchronize()
+    assert p.value
+    # the timed bench loop with the exchange enabled must keep stepping correctly
+    dev.run_random_steps(3, 1, 5, timed=True)
+    ora = OracleVecEnv(n, steps=50); ora.reset(seeds=3)
+    for t in range(6):
+        o = ora.step(random_actions(3, t, n))
+    dev._fetch()
+    assert np.array_equal(dev._obs, o[0])
+    dev.close()
+
+
 def test_snapshot_restore_replays_identically():
     dev = _dev(4, steps=100); dev.reset(seeds=9)
     for t in range(10):

@@ -150,3 +150,34 @@ def test_soak_regression_seeds_run_clean():
         obs, rew, done, info = env.step(a.astype(np.int32))
         assert info['err'].max() == 0, (t, info['err'])
     assert done.all()
+
+
+def test_philox_and_pcg_modes_agree_in_distribution(oracle_lib):
+    """BASELINE.md parity gate: the counter-based (Philox) mode draws at the same sites as the numpy-PCG64 mode, so episode
+    statistics must agree.  384 independent 150-step SleepAgent-blue episodes per mode; compare mean episode reward and
+    mean per-step fraction of hosts raising events with a z-test (|z| < 4; seeds are fixed, so this is deterministic)."""
+    import ctypes
+    n, T = 384, 150
+    stats = {}
+    for mode in (0, 1):
+        env = OracleVecEnv(n, steps=T, rng_mode=mode)
+        env.reset(seeds=np.uint64(50_000) + np.arange(n, dtype=np.uint64))
+        acts = np.full((n, 5), -1, np.int32)
+        ep = np.zeros(n); ev = np.zeros(n)
+        for t in range(T):
+            env.lib.cc4o_step_all(env._h, acts.ctypes.data_as(ctypes.c_void_p))
+            for i in range(n):
+                ep[i] += env.lib.cc4o_reward(env._h, i)
+            if t % 10 == 9:
+                for i in range(0, n, 8):
+                    env._collect(i)
+                    o = env._obs[i]
+                    ev[i] += o[28:60].sum() + o[120:152].sum() + o[212:244].sum() + o[304:336].sum()
+        assert max(env.lib.cc4o_err(env._h, i) for i in range(n)) == 0
+        stats[mode] = (ep.mean(), ep.std(ddof=1) / np.sqrt(n), ev[::8].mean(), ev[::8].std(ddof=1) / np.sqrt(n / 8))
+        env.close()
+    z_rew = (stats[0][0] - stats[1][0]) / np.hypot(stats[0][1], stats[1][1])
+    z_ev = (stats[0][2] - stats[1][2]) / max(np.hypot(stats[0][3], stats[1][3]), 1e-9)
+    assert abs(z_rew) < 4.0, (stats, z_rew)
+    assert abs(z_ev) < 4.0, (stats, z_ev)
+    assert stats[0][0] < -100 and stats[1][0] < -100       # both modes actually play the game
