@@ -8,8 +8,11 @@ A "step" is one pass of the hot path over one batch: device-side uniform random 
 rank's shard (reset / full SimulationController.step transition / reward / flat observations) [-> RCCL all-gather of
 the observations when N>1].  Workload at every N: BASELINE configs[1] per GPU = 1024 concurrent episodes per GPU
 (weak scaling: 8 GPUs = configs[3], 8192 episodes), EnterpriseScenarioGenerator(steps=500), FiniteStateRedAgent red,
-EnterpriseGreenAgent green, numpy-PCG64-compatible RNG (bit-exact with the reference), autoreset on done so the
-timed region includes the scenario regeneration of finished episodes.  Inputs (state, actions) are resident in HBM.
+EnterpriseGreenAgent green, autoreset on done so the timed region includes the scenario regeneration of finished
+episodes.  Inputs (state, actions) are resident in HBM.  RNG mode: BASELINE.md section 3 quotes the GPU runs in the
+counter-based Philox mode (lane-parallel kernel k_step_philox; bit-exact with the CPU oracle, distribution-checked
+against the PCG mode); the numpy-PCG64 mode that is bit-exact with the reference itself (serial kernel k_step) is
+measured in the same run and reported under "alt_rng".
 
 Prints ONE JSON line on rank 0.  `roofline` = algorithmic bytes per k_step launch / mean launch duration from HIP
 events recorded on the launch stream inside the timed region; `cpu_baseline` = the CPU oracle (kind "port": the
@@ -80,7 +83,8 @@ def main():
     ap.add_argument('--warmup', type=int, default=100)
     ap.add_argument('--envs-per-gpu', type=int, default=1024)
     ap.add_argument('--episode-steps', type=int, default=500)
-    ap.add_argument('--rng', choices=['pcg64', 'philox'], default='pcg64')
+    ap.add_argument('--rng', choices=['pcg64', 'philox'], default='philox')
+    ap.add_argument('--no-alt', action='store_true', help='skip the second measurement in the other RNG mode')
     ap.add_argument('--seed0', type=int, default=1000)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     args = ap.parse_args()
@@ -106,23 +110,42 @@ def main():
         D.init_rccl(env, rank, world)
     seed_actions = args.seed0 + lo            # action key = seed0 + global episode index
 
-    env.run_random_steps(seed_actions, 0, args.warmup, timed=False)
-    env.synchronize()
-    if world > 1:
-        dist.barrier()
-    t0 = time.perf_counter()
-    ms_kernels = env.run_random_steps(seed_actions, args.warmup, args.steps, timed=True)   # syncs the stream at the end
-    env.synchronize()
-    if world > 1:
-        dist.barrier()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([dt, ms_kernels], dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt, ms_kernels = float(t[0]), float(t[1])
+    def timed_run(e):
+        e.run_random_steps(seed_actions, 0, args.warmup, timed=False)
+        e.synchronize()
+        if world > 1:
+            dist.barrier()
+        t0 = time.perf_counter()
+        ms_k = e.run_random_steps(seed_actions, args.warmup, args.steps, timed=True)   # syncs the stream at the end
+        e.synchronize()
+        if world > 1:
+            dist.barrier()
+        d = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([d, ms_k], dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            d, ms_k = float(t[0]), float(t[1])
+        return d, ms_k
+
+    dt, ms_kernels = timed_run(env)
     env._fetch()
     err_any = bool(env.err.any())
 
+    alt = None
+    if not args.no_alt and world == 1:      # single-GPU runs also time the other RNG mode
+        other = 'pcg64' if args.rng == 'philox' else 'philox'
+        env2 = CC4VecEnv(n_local, steps=args.episode_steps, rng_mode=RNG_PCG64 if other == 'pcg64' else RNG_PHILOX,
+                         device_id=local if world > 1 else 0, autoreset=True)
+        env2.reset(seeds=np.uint64(args.seed0) + np.arange(lo, lo + n_local, dtype=np.uint64))
+        if world > 1:
+            D.init_rccl(env2, rank, world)
+        dt2, ms2 = timed_run(env2)
+        alt = {'rng': other, 'kernel': 'k_step' if other == 'pcg64' else 'k_step_philox',
+               'value': 5.0 * total_envs * args.steps / dt2, 'unit': 'agent-env steps/s', 'ms_per_step': dt2 / args.steps * 1e3,
+               'launch_ms': ms2 / args.steps,
+               'note': 'pcg64 = numpy Generator(PCG64) stream, bit-exact with the reference under the same seed' if other == 'pcg64'
+                       else 'philox = counter-based streams per (agent, phase, step, episode)'}
+        env2.close()
     if rank == 0:
         bytes_per_env = int(env.lib.cc4_algorithmic_bytes_per_env_step())
         launch_ms = ms_kernels / args.steps
@@ -148,6 +171,9 @@ def main():
                          'frac': achieved / HBM_PEAK_GBPS, 'traffic': traffic,
                          'kernel': 'k_step', 'launch_ms': launch_ms, 'algorithmic_bytes_per_launch': bytes_per_env * n_local},
         }
+        out['roofline']['kernel'] = 'k_step_philox' if args.rng == 'philox' else 'k_step'
+        if alt is not None:
+            out['alt_rng'] = alt
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(n_local, args.seed0)
         print(json.dumps(out), flush=True)

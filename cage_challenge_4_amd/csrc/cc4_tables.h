@@ -14,53 +14,38 @@ namespace cc4 {
 // alphabetical subnet order used by the wrappers (sorted(state.subnet_name_to_cidr.items()),
 // Agents/Wrappers/BlueFlatWrapper.py:195, BlueFixedActionWrapper.py:241): admin, contractor, internet, office,
 // operational_a, operational_b, public_access, restricted_a, restricted_b
-CC4_HD int sorted_subnet(int i) {
-  const uint8_t t[NSUB] = {S_ADM, S_CON, S_INT, S_OFF, S_OZA, S_OZB, S_PUB, S_RZA, S_RZB};
-  return t[i];
-}
-CC4_HD int subnet_rank(int s) {
-  const uint8_t t[NSUB] = {7, 4, 8, 5, 1, 6, 0, 3, 2};
-  return t[s];
-}
+// (small tables are nibble/byte-packed into immediates: a dynamically indexed local array would be a memory load
+// on the device, and these sit inside the per-agent loops)
+CC4_HD int sorted_subnet(int i) { return (int)((0x205317846ull >> (4 * i)) & 0xF); }   // {ADM,CON,INT,OFF,OZA,OZB,PUB,RZA,RZB}
+CC4_HD int subnet_rank(int s) { return (int)((0x230615847ull >> (4 * s)) & 0xF); }     // inverse permutation
 
 // blue zones, EnterpriseScenarioGenerator.py:643-649 (allowed_subnets order) -- bitmask + ordered list
 CC4_HD int blue_nsub(int b) { return b == 4 ? 3 : 1; }
-CC4_HD int blue_subnet_alloc(int b, int i) {  // allowed_subnets order (session creation order)
-  const uint8_t t4[3] = {S_PUB, S_ADM, S_OFF};
-  const uint8_t t[4] = {S_RZA, S_OZA, S_RZB, S_OZB};
-  return b == 4 ? t4[i] : t[b];
+CC4_HD int blue_subnet_alloc(int b, int i) {  // allowed_subnets order (session creation order): b<4 -> subnet b
+  return b == 4 ? (i == 0 ? S_PUB : (i == 1 ? S_ADM : S_OFF)) : b;
 }
 CC4_HD int blue_subnet_sorted(int b, int i) {  // sorted(subnets): wrappers' obs/action order
-  const uint8_t t4[3] = {S_ADM, S_OFF, S_PUB};
-  const uint8_t t[4] = {S_RZA, S_OZA, S_RZB, S_OZB};
-  return b == 4 ? t4[i] : t[b];
+  return b == 4 ? (i == 0 ? S_ADM : (i == 1 ? S_OFF : S_PUB)) : b;
 }
-CC4_HD int blue_of_subnet(int s) {
-  const int8_t t[NSUB] = {0, 1, 2, 3, -1, 4, 4, 4, -1};
-  return t[s];
+CC4_HD int blue_of_subnet(int s) {  // {0,1,2,3,-1,4,4,4,-1}
+  int v = (int)((0xf444f3210ull >> (4 * s)) & 0xF);
+  return v == 0xF ? -1 : v;
 }
 // red zones, EnterpriseScenarioGenerator.py:769-776
-CC4_HD int red_of_subnet(int s) {
-  const int8_t t[NSUB] = {1, 2, 3, 4, 0, 5, 5, 5, -1};
-  return t[s];
+CC4_HD int red_of_subnet(int s) {  // {1,2,3,4,0,5,5,5,-1}
+  int v = (int)((0xf55504321ull >> (4 * s)) & 0xF);
+  return v == 0xF ? -1 : v;
 }
 CC4_HD uint32_t red_allowed_mask(int r) {
-  const uint16_t t[NRED] = {1u << S_CON, 1u << S_RZA, 1u << S_OZA, 1u << S_RZB, 1u << S_OZB,
-                            (1u << S_PUB) | (1u << S_ADM) | (1u << S_OFF)};
-  return t[r];
+  return r == 5 ? ((1u << S_PUB) | (1u << S_ADM) | (1u << S_OFF)) : (r == 0 ? (1u << S_CON) : (1u << (r - 1)));
 }
 CC4_HD int red_nsub(int r) { return r == 5 ? 3 : 1; }
 CC4_HD int red_subnet_alloc(int r, int i) {
-  const uint8_t t5[3] = {S_PUB, S_ADM, S_OFF};
-  const uint8_t t[5] = {S_CON, S_RZA, S_OZA, S_RZB, S_OZB};
-  return r == 5 ? t5[i] : t[r];
+  return r == 5 ? (i == 0 ? S_PUB : (i == 1 ? S_ADM : S_OFF)) : (r == 0 ? S_CON : r - 1);
 }
 
 // router tree, EnterpriseScenarioGenerator.py:388-411 : parent subnet of each subnet's router (internet = root)
-CC4_HD int router_parent(int s) {
-  const uint8_t t[NSUB] = {S_INT, S_RZA, S_INT, S_RZB, S_INT, S_INT, S_PUB, S_PUB, S_INT};
-  return t[s];
-}
+CC4_HD int router_parent(int s) { return (int)((0x855882808ull >> (4 * s)) & 0xF); }  // {INT,RZA,INT,RZB,INT,INT,PUB,PUB,INT}
 // server_host_0 info links, EnterpriseScenarioGenerator.py:431-462 (bitmask of target subnets)
 CC4_HD uint32_t info_links(int s) {
   const uint16_t t[NSUB] = {
@@ -72,21 +57,11 @@ CC4_HD uint32_t info_links(int s) {
 
 // green allowed subnets per mission phase, EnterpriseScenarioGenerator.py:281-306 + SimulationController.py:747-765
 CC4_HD uint32_t green_allowed_mask(int phase, int s) {
-  // undirected pair lists
-  const uint8_t common[9][2] = {{S_PUB, S_CON}, {S_ADM, S_CON}, {S_OFF, S_CON}, {S_PUB, S_RZA}, {S_ADM, S_RZA},
-                                {S_OFF, S_RZA}, {S_PUB, S_RZB}, {S_ADM, S_RZB}, {S_OFF, S_RZB}};
-  const uint8_t p0[5][2] = {{S_RZA, S_CON}, {S_OZA, S_RZA}, {S_RZB, S_CON}, {S_RZB, S_RZA}, {S_OZB, S_RZB}};
-  const uint8_t p1[2][2] = {{S_RZB, S_CON}, {S_OZB, S_RZB}};
-  const uint8_t p2[2][2] = {{S_RZA, S_CON}, {S_OZA, S_RZA}};
-  uint32_t m = 1u << s;
-  for (int i = 0; i < 9; ++i) {
-    if (common[i][0] == s) m |= 1u << common[i][1];
-    if (common[i][1] == s) m |= 1u << common[i][0];
-  }
-  if (phase == 0) for (int i = 0; i < 5; ++i) { if (p0[i][0] == s) m |= 1u << p0[i][1]; if (p0[i][1] == s) m |= 1u << p0[i][0]; }
-  if (phase == 1) for (int i = 0; i < 2; ++i) { if (p1[i][0] == s) m |= 1u << p1[i][1]; if (p1[i][1] == s) m |= 1u << p1[i][0]; }
-  if (phase == 2) for (int i = 0; i < 2; ++i) { if (p2[i][0] == s) m |= 1u << p2[i][1]; if (p2[i][1] == s) m |= 1u << p2[i][0]; }
-  return m;
+  // own subnet + every partner in the phase's pair list (policy_1/2/3), 9-bit masks packed 7 + 2 per constant:
+  //   phase 0: {0xf7,0x03,0xfd,0x0c,0xf5,0x35,0x55,0x95,0x100}  phase 1: {0xe1,0x02,0xfc,0x0c,0xf4,...}  phase 2: {0xf3,0x03,0xe4,0x08,0xf1,...}
+  uint64_t lo = phase == 0 ? 0x1546af5063f406f7ull : (phase == 1 ? 0x1546af4063f004e1ull : 0x1546af10439006f3ull);
+  uint32_t hi = phase == 0 ? 0x20095u : (phase == 1 ? 0x20095u : 0x20095u);
+  return s < 7 ? (uint32_t)((lo >> (9 * s)) & 0x1FF) : ((hi >> (9 * (s - 7))) & 0x1FF);
 }
 
 // BlueRewardMachine.get_phase_rewards, Shared/BlueRewardMachine.py:35-65 : [phase][subnet][LWF, ASF, RIA]
@@ -123,20 +98,13 @@ CC4_HD uint32_t comms_adjacent(int phase, int s) {
 
 // listening port bit of a process kind (EnterpriseScenarioGenerator.py:597-604, Decoy*.py PORT constants;
 // VsftpdDecoyFactory.PORT = 80, DecoyVsftpd.py:10)
-CC4_HD int kind_port(int kind) {
-  const uint8_t t[13] = {PB_22, PB_1, PB_80, PB_3390, PB_25, PB_80, PB_443, PB_25, PB_80, 0, 0, 0, 0};
-  return t[kind];
+CC4_HD int kind_port(int kind) {  // {22,1,80,3390,25, 80,443,25,80, -,-,-,-} as PB_* bits, one byte per kind
+  return kind < 8 ? (int)((0x0820020804021001ull >> (8 * kind)) & 0xFF) : (kind == 8 ? PB_80 : 0);
 }
 CC4_HD bool kind_is_decoy(int kind) { return kind >= K_DEC_APACHE && kind <= K_DEC_VSFTPD; }
 
 // action durations
-CC4_HD int blue_duration(int t) {
-  const uint8_t d[8] = {1, 1, 2, 3, 5, 2, 1, 1};
-  return d[t];
-}
-CC4_HD int red_duration(int t) {
-  const uint8_t d[12] = {1, 1, 3, 2, 4, 2, 2, 2, 1, 1, 1, 1};
-  return d[t];
-}
+CC4_HD int blue_duration(int t) { return (int)((0x11253211u >> (4 * t)) & 0xF); }        // {1,1,2,3,5,2,1,1}
+CC4_HD int red_duration(int t) { return (int)((0x111122242311ull >> (4 * t)) & 0xF); }    // {1,1,3,2,4,2,2,2,1,1,1,1}
 
 }  // namespace cc4

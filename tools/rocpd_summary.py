@@ -9,7 +9,8 @@ import sys
 
 
 def db(d):
-    return sqlite3.connect(sorted(glob.glob(d + '/**/*.db', recursive=True))[0])
+    import os
+    return sqlite3.connect(max(glob.glob(d + '/**/*.db', recursive=True), key=os.path.getmtime))
 
 
 def stats(d, out):
