@@ -95,8 +95,9 @@ def main():
     rank, world, local = D.env_rank_world()
     if args.gpus > 1 and world != args.gpus:
         raise SystemExit(f'--gpus {args.gpus} needs torch.distributed.run with --nproc-per-node {args.gpus} (WORLD_SIZE={world})')
-    if world > 1:
-        D.init_control_plane('gloo')
+    dist_on = world > 1 or os.environ.get('CC4_BENCH_FORCE_DIST') == '1'   # the env var drives the N>1 code path at world 1
+    if dist_on:
+        D.init_control_plane('gloo', force=True)
         import torch
         import torch.distributed as dist
     n_local = args.envs_per_gpu
@@ -106,22 +107,22 @@ def main():
     lo = rank * n_local
     import numpy as np
     env.reset(seeds=np.uint64(args.seed0) + np.arange(lo, lo + n_local, dtype=np.uint64))
-    if world > 1:
+    if dist_on:
         D.init_rccl(env, rank, world)
     seed_actions = args.seed0 + lo            # action key = seed0 + global episode index
 
     def timed_run(e):
         e.run_random_steps(seed_actions, 0, args.warmup, timed=False)
         e.synchronize()
-        if world > 1:
+        if dist_on:
             dist.barrier()
         t0 = time.perf_counter()
         ms_k = e.run_random_steps(seed_actions, args.warmup, args.steps, timed=True)   # syncs the stream at the end
         e.synchronize()
-        if world > 1:
+        if dist_on:
             dist.barrier()
         d = time.perf_counter() - t0
-        if world > 1:
+        if dist_on:
             t = torch.tensor([d, ms_k], dtype=torch.float64)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             d, ms_k = float(t[0]), float(t[1])
@@ -132,7 +133,7 @@ def main():
     err_any = bool(env.err.any())
 
     alt = None
-    if not args.no_alt and world == 1:      # single-GPU runs also time the other RNG mode
+    if not args.no_alt and not dist_on:      # single-GPU runs also time the other RNG mode
         other = 'pcg64' if args.rng == 'philox' else 'philox'
         env2 = CC4VecEnv(n_local, steps=args.episode_steps, rng_mode=RNG_PCG64 if other == 'pcg64' else RNG_PHILOX,
                          device_id=local if world > 1 else 0, autoreset=True)
@@ -164,7 +165,7 @@ def main():
                             f'(82/82/82/82/242 incl. invalid slots), FiniteStateRedAgent, EnterpriseGreenAgent, '
                             f'EnterpriseScenarioGenerator(steps={args.episode_steps}), autoreset incl. scenario regeneration',
                 'envs_per_gpu': n_local, 'total_envs': total_envs, 'rng': args.rng,
-                'exchange': 'RCCL all-gather of [N,578] int32 obs per step' if world > 1 else 'none',
+                'exchange': 'RCCL all-gather of [N,578] int32 obs per step' if dist_on else 'none',
                 'env_steps_per_sec': total_envs * args.steps / dt, 'engine_error_flags': err_any,
             },
             'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBPS, 'unit': 'GB/s',
@@ -174,11 +175,11 @@ def main():
         out['roofline']['kernel'] = 'k_step_philox' if args.rng == 'philox' else 'k_step'
         if alt is not None:
             out['alt_rng'] = alt
-        if world == 1 and not args.no_cpu_baseline:
+        if not dist_on and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(n_local, args.seed0)
         print(json.dumps(out), flush=True)
     env.close()
-    if world > 1:
+    if dist_on:
         dist.barrier()
         dist.destroy_process_group()
 

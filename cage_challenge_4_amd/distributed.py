@@ -12,12 +12,13 @@ def env_rank_world():
     return int(os.environ.get('RANK', 0)), int(os.environ.get('WORLD_SIZE', 1)), int(os.environ.get('LOCAL_RANK', 0))
 
 
-def init_control_plane(backend='gloo'):
+def init_control_plane(backend='gloo', force=False):
     """Initialise torch.distributed from the torchrun environment (MASTER_ADDR/PORT, RANK, WORLD_SIZE)."""
     import torch.distributed as dist
     rank, world, local = env_rank_world()
-    if world > 1 and not dist.is_initialized():
+    if (world > 1 or force) and not dist.is_initialized():
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('MASTER_PORT', '29533')
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
     return rank, world, local
 
