@@ -133,6 +133,7 @@ CC4_HD int rs_add(Ctx x, int r, int host, int pid, int flags) {
   RSess q; q.id = (uint16_t)id; q.pid = (uint16_t)pid; q.host = (uint8_t)host; q.flags = (uint8_t)flags; q.pad = 0;
   q.kb = (flags & RS_ABSTRACT) ? (uint8_t)kb_alloc(x) : (uint8_t)0xFF;
   a.sess[a.nsess++] = q;
+  a.rsc_dirty = 1;
   return a.nsess - 1;
 }
 CC4_HD void rs_remove_at(Ctx x, int r, int idx, bool free_kb) {
@@ -140,6 +141,7 @@ CC4_HD void rs_remove_at(Ctx x, int r, int idx, bool free_kb) {
   if (free_kb) kb_free(x, a.sess[idx].kb);
   for (int i = idx; i + 1 < a.nsess; ++i) a.sess[i] = a.sess[i + 1];
   a.nsess--;
+  a.rsc_dirty = 1;
 }
 CC4_HD bool red_has_session_on(const RedAgent& a, int h) {
   for (int i = 0; i < a.nsess; ++i) if (a.sess[i].host == h) return true;
@@ -216,8 +218,9 @@ CC4_HD int gen_pid(Ctx x, uint32_t* used) {  // _generate_pid (ESG.py:564-578)
 }
 CC4_HD void gen_host(Ctx x, int h, uint32_t* used) {  // _generate_linux_host (ESG.py:470-528)
   EnvState* s = x.s;
-  HostStatic& st = s->hs[h];
+  HostStatic& st = x.c->hs[h];
   st.exists = 1; st.nproc = 0; st.nsvc = 0;
+  bit_set(s->exists, h);
   (void)rng_below(x.r, 2);  // OSDistribution choice (ESG.py:494): both are LINUX, value unused downstream
   if (h_is_router(h)) return;
   // _generate_linux_host_services (ESG.py:530-562)
@@ -245,7 +248,7 @@ CC4_HD void gen_host(Ctx x, int h, uint32_t* used) {  // _generate_linux_host (E
 }
 // Host.add_session for a starting session (Host.py:189-196): Process(pid=create_pid(), name=session_type)
 CC4_HD int start_session_proc(Ctx x, int h, int kind) {
-  HostStatic& st = x.s->hs[h];
+  HostStatic& st = x.c->hs[h];
   int mx = 0;
   for (int i = 0; i < st.nproc; ++i) if (st.procs[i].pid > mx) mx = st.procs[i].pid;
   int pid = mx + 1 + (int)rng_below(x.r, 9);
@@ -256,7 +259,7 @@ CC4_HD int start_session_proc(Ctx x, int h, int kind) {
 CC4_HD void host_restore(Ctx x, int h) {  // Host.restore (Host.py:373-429)
   EnvState* s = x.s;
   HostDyn& d = s->hd[h];
-  const HostStatic& st = s->hs[h];
+  const HostStatic& st = x.c->hs[h];
   for (int i = 0; i < st.nproc; ++i) d.procs[i] = st.procs[i];
   for (int i = 0; i < st.nsvc; ++i) d.svcs[i] = st.svcs[i];
   d.nproc = st.nproc; d.nsvc = st.nsvc; d.ev = 0; d.pad = 0;
@@ -281,6 +284,10 @@ CC4_HD void env_reset(Ctx x, uint64_t seed, int rng_mode, int steps, bool contin
     s->phase_len[0] = q + (rem >= 1 ? 1 : 0); s->phase_len[1] = q + (rem == 2 ? 1 : 0); s->phase_len[2] = q;
   }
   for (int i = 0; i < MAX_KB / 32; ++i) s->kb_used[i] = 0;
+  {  // backup images of the previous episode
+    uint32_t* w = (uint32_t*)x.c->hs;
+    for (size_t i = 0; i < sizeof(x.c->hs) / 4; ++i) w[i] = 0;
+  }
   uint32_t* used = x.c->eph[H_INTERNET];  // scratch bitmap for used_pids (cleared by the backup below)
   for (int i = 0; i < EPH_WORDS; ++i) used[i] = 0;
 
@@ -304,23 +311,23 @@ CC4_HD void env_reset(Ctx x, uint64_t seed, int rng_mode, int steps, bool contin
     auto pop_at = [&](int c) { uint8_t v = ips[c]; for (int j = c; j + 1 < n; ++j) ips[j] = ips[j + 1]; n--; return v; };
     if (sn == S_INT) {
       int c = (int)rng_below(x.r, (uint32_t)n);
-      s->hs[H_INTERNET].ip_octet = pop_at(c);
+      x.c->hs[H_INTERNET].ip_octet = pop_at(c);
       gen_host(x, H_INTERNET, used);
       continue;
     }
     int hr = h_make(sn, 0);
-    { int c = (int)rng_below(x.r, (uint32_t)n); uint8_t ip = pop_at(c); gen_host(x, hr, used); s->hs[hr].ip_octet = ip; }
+    { int c = (int)rng_below(x.r, (uint32_t)n); uint8_t ip = pop_at(c); gen_host(x, hr, used); x.c->hs[hr].ip_octet = ip; }
     int nu = 3 + (int)rng_below(x.r, 8);  // integers(3, 10, endpoint=True)
     for (int i = 0; i < nu; ++i) {
       int h = h_make(sn, 1 + i);
       int c = (int)rng_below(x.r, (uint32_t)n); uint8_t ip = pop_at(c);
-      gen_host(x, h, used); s->hs[h].ip_octet = ip;
+      gen_host(x, h, used); x.c->hs[h].ip_octet = ip;
     }
     int ns = 1 + (int)rng_below(x.r, 6);  // integers(1, 6, endpoint=True)
     for (int i = 0; i < ns; ++i) {
       int h = h_make(sn, 11 + i);
       uint8_t ip = ips[n - 1]; n--;  // ip_addresses.pop()
-      gen_host(x, h, used); s->hs[h].ip_octet = ip;
+      gen_host(x, h, used); x.c->hs[h].ip_octet = ip;
     }
     s->n_users[sn] = (uint8_t)nu; s->n_servers[sn] = (uint8_t)ns;
   }
@@ -334,14 +341,14 @@ CC4_HD void env_reset(Ctx x, uint64_t seed, int rng_mode, int steps, bool contin
     int k = 0, ph = -1;
     for (int i = 0; i < nsub && ph < 0; ++i) {
       int sn = blue_subnet_alloc(b, i);
-      for (int sl = 0; sl < SLOTS; ++sl) { int h = h_make(sn, sl); if (s->hs[h].exists) { if (k == c) { ph = h; break; } k++; } }
+      for (int sl = 0; sl < SLOTS; ++sl) { int h = h_make(sn, sl); if (bit_get(s->exists, h)) { if (k == c) { ph = h; break; } k++; } }
     }
     s->blue[b].parent_host = (uint8_t)ph;
   }
   // _generate_green_agents (ESG.py:700-749): one per user host, host order
   {
     int g = 0;
-    for (int h = 0; h < MAXH; ++h) if (s->hs[h].exists && h_is_user(h)) s->green_host[g++] = (uint8_t)h;
+    for (int h = 0; h < MAXH; ++h) if (bit_get(s->exists, h) && h_is_user(h)) s->green_host[g++] = (uint8_t)h;
     s->n_green = (uint8_t)g;
   }
   // _generate_red_agents (ESG.py:751-817)
@@ -364,7 +371,7 @@ CC4_HD void env_reset(Ctx x, uint64_t seed, int rng_mode, int steps, bool contin
       int sn = blue_subnet_alloc(b, i);
       for (int sl = 0; sl < SLOTS; ++sl) {
         int h = h_make(sn, sl);
-        if (!s->hs[h].exists || h == ph) continue;
+        if (!bit_get(s->exists, h) || h == ph) continue;
         s->blue_pid[h] = (uint16_t)start_session_proc(x, h, K_SESS_BLUE);
       }
     }
@@ -373,7 +380,7 @@ CC4_HD void env_reset(Ctx x, uint64_t seed, int rng_mode, int steps, bool contin
   int red0_pid = start_session_proc(x, s->red[0].start_host, K_SESS_RED);
   // host.create_backup() for every host (State.py:137-138) -> dynamic state := static
   for (int h = 0; h < MAXH; ++h) {
-    if (s->hs[h].exists) host_restore(x, h);
+    if (bit_get(s->exists, h)) host_restore(x, h);
     else { s->hd[h].nproc = 0; s->hd[h].nsvc = 0; s->hd[h].ev = 0; eph_clear(x, h); }
   }
   s->npend = 0;
@@ -427,7 +434,7 @@ CC4_HD Act blue_decode(const EnvState* s, int b, int idx) {
   }
   int sn = blue_subnet_sorted(b, j / ZONE_HOSTS), hs = j % ZONE_HOSTS;
   int h = hs < MAX_SERVERS ? h_make(sn, 11 + hs) : h_make(sn, 1 + (hs - MAX_SERVERS));
-  if (!s->hs[h].exists) return a;  // "[Invalid] ..." slot -> Sleep() (BlueFixedActionWrapper.py:295-298)
+  if (!bit_get(s->exists, h)) return a;  // "[Invalid] ..." slot -> Sleep() (BlueFixedActionWrapper.py:295-298)
   a.type = (uint8_t)t; a.host = (uint8_t)h;
   return a;
 }
@@ -452,7 +459,7 @@ CC4_HD void blue_monitor(Ctx x, int b) {
     int sn = blue_subnet_alloc(b, i);
     for (int sl = 0; sl < SLOTS; ++sl) {
       int h = h_make(sn, sl);
-      if (!s->hs[h].exists) continue;
+      if (!bit_get(s->exists, h)) continue;
       uint8_t ev = s->hd[h].ev;
       uint8_t nev = 0;
       if (ev & EV_CUR_CONN) nev |= EV_OLD_CONN;
@@ -520,6 +527,7 @@ CC4_HD void blue_restore(Ctx x, int h) {
       RSess keep = a.sess[orig];
       rs_remove_at(x, r, orig, false);
       a.sess[a.nsess++] = keep;
+      a.rsc_dirty = 1;
     }
   }
   host_restore(x, h);
@@ -646,7 +654,7 @@ CC4_HD void red_drs(Ctx x, int r, const Act& a) {
   bool allowed = (red_allowed_mask(r) >> sn) & 1u;  // SimulationController._filter_obs drops foreign-subnet interfaces
   for (int sl = 1; sl < SLOTS; ++sl) {
     int h = h_make(sn, sl);
-    if (!s->hs[h].exists) continue;
+    if (!bit_get(s->exists, h)) continue;
     any = true;
     if (allowed) obs_put(x, r, true, h, OE_IFACE, true);
   }
@@ -855,10 +863,17 @@ CC4_HD void red_session_check(Ctx x, int r) {
     q.id = 0;
     A.sess[A.nsess++] = q;
   }
+  // The observation lists every session (host, Sessions/Interface/System info).  If the session table has not changed
+  // since the last full listing, every host in it is already in the agent's ActionSpace and FSM tables, so the only
+  // thing the FSM still reads from it is "this host has a session" -- served from the cached bitmap instead.
+  if (!A.rsc_dirty) { A.rsc_skipped = 1; return; }
+  for (int w = 0; w < 5; ++w) A.sess_hosts[w] = 0;
   for (int i = 0; i < A.nsess; ++i) {
+    bit_set(A.sess_hosts, A.sess[i].host);
     obs_put(x, r, false, A.sess[i].host, OE_SESS | OE_IFACE | OE_SYSHN, true);
     if (A.sess[i].flags & RS_ABSTRACT) as_know_sid(x, r, A.sess[i].id);
   }
+  A.rsc_dirty = 0;
 }
 CC4_HD void red_execute(Ctx x, int r, const Act& a) {
   switch (a.type) {
@@ -929,6 +944,7 @@ CC4_HD void fsm_observe(Ctx x, int r) {
   }
   // 2. _process_new_observations (:190-250)
   uint32_t sess_seen[5] = {0, 0, 0, 0, 0};
+  if (A.rsc_skipped) for (int w = 0; w < 5; ++w) sess_seen[w] = A.sess_hosts[w];
   for (int i = 0; i < A.nobs; ++i) {
     int h = A.obs[i].host; int f = A.obs[i].flags;
     if (f & OE_SESS) bit_set(sess_seen, h);
@@ -1063,7 +1079,7 @@ CC4_HD void red_reassign(Ctx x) {
 // PhishingEmail (new red session), is deferred and replayed in agent order (P5).
 
 // returns false when the episode is stepped past its end (State.py:539-540 raises ValueError)
-CC4_HD bool step_begin(Ctx x, const int32_t* actions) {
+CC4_HD bool step_phase(Ctx x) {
   EnvState* s = x.s;
   {  // State.check_next_phase_on_update_step (State.py:514-544)
     int st = s->step_count, ph = -1, mn = 0, mx = 0;
@@ -1072,13 +1088,27 @@ CC4_HD bool step_begin(Ctx x, const int32_t* actions) {
     if (ph > s->phase) s->phase = ph;
   }
   rng_begin_step(&s->rng, (uint32_t)s->step_count);
-  s->action_cost = 0.f; s->brm = 0;
-  for (int b = 0; b < NBLUE; ++b) {
-    Act a = blue_decode(s, b, actions ? actions[b] : -1);
-    if (a.type == BA_RESTORE) s->action_cost -= 1.f;  // Restore.cost, charged on submission (SC:310)
-    a.ticks = (uint8_t)blue_duration(a.type);
-    if (!s->blue[b].queue.busy) { s->blue[b].queue = a; s->blue[b].queue.busy = 1; }
+  s->action_cost = 0.f; s->brm = 0; s->n_restore = 0; s->any_phish = 0;
+  s->n_actions = NBLUE + s->n_green + NRED;   // minus the actions filter_actions drops (step_tick_agent)
+  return true;
+}
+// one blue agent's submitted action: decode, cost, queue (SC:236-248); independent across agents
+CC4_HD void step_blue_submit(Ctx x, int b, int action_index) {
+  EnvState* s = x.s;
+  Act a = blue_decode(s, b, action_index);
+  if (a.type == BA_RESTORE) {  // Restore.cost = -1, charged on submission even while busy (SC:310)
+#if defined(__HIP_DEVICE_COMPILE__)
+    atomicAdd(&s->n_restore, 1);
+#else
+    s->n_restore++;
+#endif
   }
+  a.ticks = (uint8_t)blue_duration(a.type);
+  if (!s->blue[b].queue.busy) { s->blue[b].queue = a; s->blue[b].queue.busy = 1; }
+}
+CC4_HD bool step_begin(Ctx x, const int32_t* actions) {
+  if (!step_phase(x)) return false;
+  for (int b = 0; b < NBLUE; ++b) step_blue_submit(x, b, actions ? actions[b] : -1);
   return true;
 }
 CC4_HD void step_green_policy(Ctx x, int g) {
@@ -1092,36 +1122,12 @@ CC4_HD void step_red_policy(Ctx x, int r) {
   if (A.active) { a = fsm_get_action(x, r); red_validate(x, r, a); }   // AgentInterface.get_action (:120-143)
   if (!A.queue.busy) { A.queue = a; A.queue.busy = 1; }
 }
-CC4_HD void step_tick(Ctx x) {
+CC4_HD void step_blue_exec(Ctx x) {
   EnvState* s = x.s;
-  // ---- observation reset + queue tick (SC:251-265)
-  for (int b = 0; b < NBLUE; ++b) {
-    Act& q = s->blue[b].queue;
-    q.ticks--;
-    if (q.ticks < 1) { s->bexec[b] = q; q.busy = 0; }
-    else { Act z; z.type = BA_SLEEP; z.host = 0; z.arg = 0; z.ticks = 0; z.sid = 0; z.busy = 0; s->bexec[b] = z; }
-  }
-  int n_actions = NBLUE + s->n_green + NRED;
-  for (int r = 0; r < NRED; ++r) {
-    RedAgent& A = s->red[r];
-    A.nobs = 0; A.obs_success = 0; A.obs_act_type = RA_NONE; A.new_sess_host = 0xFF;
-    for (int w = 0; w < 5; ++w) { A.obs_has[0][w] = 0; A.obs_has[1][w] = 0; }
-    Act& q = A.queue;
-    q.ticks--;
-    if (q.ticks < 1) { s->rexec[r] = q; q.busy = 0; }
-    else {
-      Act z; z.type = RA_SLEEP; z.host = 0; z.arg = 0; z.ticks = 0; z.sid = 0; z.busy = 0; s->rexec[r] = z;
-      obs_first(x, r, T_IN_PROGRESS, RA_NONE, 0, 0);
-    }
-    A.exec_type = s->rexec[r].type; A.exec_host = s->rexec[r].host;
-    // filter_actions (SC:466-485): actions naming a dead session are dropped (Sleep/InvalidAction have no session)
-    if (s->rexec[r].type <= RA_WITHDRAW && rs_find_id(A, s->rexec[r].sid) < 0) { s->rexec[r].type = RA_NONE; n_actions--; }
-  }
-  s->n_actions = n_actions;
   CC4_TICK(x, 3);
   // ---- sort_action_order (SC:398-464): the shuffle only consumes the shared numpy stream; the Philox streams are
   // per agent, so there is nothing to consume there
-  if (x.r->mode == 0) rng_shuffle_consume(x.r, n_actions);
+  if (x.r->mode == 0) rng_shuffle_consume(x.r, s->n_actions);
   CC4_TICK(x, 4);
   // ---- execute: priority 1 (ControlTraffic) first, then agent order
   for (int b = 0; b < NBLUE; ++b) if (s->bexec[b].type == BA_BLOCK || s->bexec[b].type == BA_ALLOW) blue_execute(x, b, s->bexec[b]);
@@ -1131,6 +1137,36 @@ CC4_HD void step_tick(Ctx x) {
       blue_execute(x, b, s->bexec[b]);
     }
   CC4_TICK(x, 5);
+}
+// duration queue of one agent (SC:251-265): a = 0..4 blue, 5..10 red.  Returns 1 if the agent's action was dropped by
+// filter_actions (SC:466-485: it names a dead session)
+CC4_HD int step_tick_agent(Ctx x, int a) {
+  EnvState* s = x.s;
+  Act z; z.type = 0; z.host = 0; z.arg = 0; z.ticks = 0; z.sid = 0; z.busy = 0;
+  if (a < NBLUE) {
+    Act& q = s->blue[a].queue;
+    q.ticks--;
+    if (q.ticks < 1) { s->bexec[a] = q; q.busy = 0; }
+    else { z.type = BA_SLEEP; s->bexec[a] = z; }
+    return 0;
+  }
+  int r = a - NBLUE;
+  RedAgent& A = s->red[r];
+  A.nobs = 0; A.obs_success = 0; A.obs_act_type = RA_NONE; A.new_sess_host = 0xFF;
+  for (int w = 0; w < 5; ++w) { A.obs_has[0][w] = 0; A.obs_has[1][w] = 0; }
+  A.rsc_skipped = 0;
+  Act& q = A.queue;
+  q.ticks--;
+  if (q.ticks < 1) { s->rexec[r] = q; q.busy = 0; }
+  else { z.type = RA_SLEEP; s->rexec[r] = z; obs_first(x, r, T_IN_PROGRESS, RA_NONE, 0, 0); }
+  A.exec_type = s->rexec[r].type; A.exec_host = s->rexec[r].host;
+  if (s->rexec[r].type <= RA_WITHDRAW && rs_find_id(A, s->rexec[r].sid) < 0) { s->rexec[r].type = RA_NONE; return 1; }
+  return 0;
+}
+CC4_HD void step_tick(Ctx x) {
+  EnvState* s = x.s;
+  for (int a = 0; a < NBLUE + NRED; ++a) s->n_actions -= step_tick_agent(x, a);
+  step_blue_exec(x);
 }
 // returns the BlueRewardMachine penalty of this green agent's action (<= 0)
 CC4_HD int step_green_exec(Ctx x, int g) {
@@ -1144,26 +1180,40 @@ CC4_HD int step_green_exec(Ctx x, int g) {
     bool want_phish = false;
     bool ok = green_local_work(x, gh, &want_phish);
     s->phish_req[g] = (uint8_t)want_phish;
+    if (want_phish) s->any_phish = 1;
     return ok ? 0 : reward_table(s->phase, own, RW_LWF);
   }
   return 0;
 }
 CC4_HD void step_phishing(Ctx x) {
   EnvState* s = x.s;
+  if (!s->any_phish) return;
   for (int g = 0; g < s->n_green; ++g)
     if (s->phish_req[g]) { rng_set_stream(x.r, ST_GREEN_PHISH + (uint32_t)g); phishing(x, s->green_host[g]); s->phish_req[g] = 0; }
+}
+// true if red agent r holds a session outside its allowed subnets (work for different_subnet_agent_reassignment)
+CC4_HD bool red_has_foreign_session(const EnvState* s, int r) {
+  const RedAgent& A = s->red[r];
+  uint32_t m = red_allowed_mask(r);
+  for (int i = 0; i < A.nsess; ++i) if (!((m >> h_subnet(A.sess[i].host)) & 1u)) return true;
+  return false;
 }
 CC4_HD void step_red_exec(Ctx x) {
   EnvState* s = x.s;
   for (int r = 0; r < NRED; ++r)
     if (s->rexec[r].type != RA_NONE) { rng_set_stream(x.r, ST_RED_EXE + (uint32_t)r); red_execute(x, r, s->rexec[r]); }
   CC4_TICK(x, 7);
-  red_reassign(x);
+}
+// different_subnet_agent_reassignment (SC:820-903): `any_foreign` = some red agent holds a session outside its zone
+CC4_HD void step_reassign(Ctx x, bool any_foreign) {
+  EnvState* s = x.s;
+  if (any_foreign) red_reassign(x);
+  else for (int r = 0; r < NRED; ++r) s->red[r].active = (uint8_t)(s->red[r].nsess > 0);
   CC4_TICK(x, 8);
 }
 CC4_HD void step_monitor_host(Ctx x, int h) {  // the per-host part of Monitor.execute
   EnvState* s = x.s;
-  if (!s->hs[h].exists || blue_of_subnet(h_subnet(h)) < 0) return;
+  if (!bit_get(s->exists, h) || blue_of_subnet(h_subnet(h)) < 0) return;
   uint8_t ev = s->hd[h].ev, nev = 0;
   if (ev & EV_CUR_CONN) nev |= EV_OLD_CONN;
   if (ev & EV_CUR_PROC) nev |= EV_OLD_PROC;
@@ -1192,6 +1242,7 @@ CC4_HD void step_end(Ctx x, const uint8_t* messages) {
   for (int r = 0; r < NRED; ++r)
     if (s->red[r].exec_type == RA_IMPACT && s->red[r].nsess > 0)
       brm += reward_table(s->phase, h_subnet(s->red[r].exec_host), RW_RIA);  // charged for any executed Impact (App. B.2)
+  s->action_cost = -(float)s->n_restore;
   s->reward = (float)brm + s->action_cost;
   if (messages) for (int b = 0; b < NBLUE; ++b) for (int i = 0; i < MSG_LEN; ++i) s->msg[b][i] = messages[b * MSG_LEN + i] ? 1 : 0;
   else for (int b = 0; b < NBLUE; ++b) for (int i = 0; i < MSG_LEN; ++i) s->msg[b][i] = 0;
@@ -1215,6 +1266,11 @@ CC4_HD void env_step(Ctx x, const int32_t* actions, const uint8_t* messages /* [
   }
   CC4_TICK(x, 6);
   step_red_exec(x);
+  {
+    bool f = false;
+    for (int r = 0; r < NRED; ++r) f = f || red_has_foreign_session(s, r);
+    step_reassign(x, f);
+  }
   for (int h = 0; h < MAXH; ++h) step_monitor_host(x, h);
   step_monitor_pend(x);
   CC4_TICK(x, 9);
@@ -1244,7 +1300,7 @@ CC4_HD void env_flat_obs_part(const EnvState* s, T* out, int part) {
     }
     for (int hs = 0; hs < ZONE_HOSTS; ++hs) {
       int h = hs < MAX_SERVERS ? h_make(sn, 11 + hs) : h_make(sn, 1 + (hs - MAX_SERVERS));
-      int ev = s->hs[h].exists ? s->hd[h].ev : 0;
+      int ev = bit_get(s->exists, h) ? s->hd[h].ev : 0;
       out[o + 27 + hs] = (T)((ev & (EV_CUR_PROC | EV_OLD_PROC)) != 0);
       out[o + 43 + hs] = (T)((ev & (EV_CUR_CONN | EV_OLD_CONN)) != 0);
     }

@@ -95,6 +95,9 @@ __global__ __launch_bounds__(WAVE) void k_step(StepArgs a) {
         }
         CC4_TICK(x, 6);
         step_red_exec(x);
+        bool f = false;
+        for (int r = 0; r < NRED; ++r) f = f || red_has_foreign_session(s, r);
+        step_reassign(x, f);
       }
     }
   }
@@ -134,6 +137,7 @@ __global__ __launch_bounds__(WAVE) void k_step_philox(StepArgs a) {
   __shared__ uint8_t obs_lds[OBS_TOTAL + 2];
   __shared__ int ok_lds;
   __shared__ Rng lane_rng[WAVE];   // lane-local generators live in LDS (a private copy would be spilled to scratch)
+  __shared__ int flag_lds;
   const int e = blockIdx.x, lane = threadIdx.x;
   if (e >= a.n) return;
   unsigned long long t_begin = a.prof ? clock64() : 0;
@@ -150,21 +154,24 @@ __global__ __launch_bounds__(WAVE) void k_step_philox(StepArgs a) {
     if (lane == 0) {
       Ctx x{s, a.cold + e, &s->rng, prof};
       CC4_TICK0(x);
-      ok_lds = step_begin(x, a.actions ? a.actions + e * NBLUE : nullptr) ? 1 : 0;
-      CC4_TICK(x, 0);
+      ok_lds = step_phase(x) ? 1 : 0;
+      flag_lds = 0;
     }
     __syncthreads();
     if (ok_lds) {
       rng_fork(&lane_rng[lane], &s->rng, ST_RESET);
       Ctx x{s, a.cold + e, &lane_rng[lane], lane == 0 ? prof : nullptr};
       const int ng = s->n_green;
-      // P1 green policy draws (lanes 6..63) || P2 red FSM policies (lanes 0..5)
-      if (lane < NRED) step_red_policy(x, lane);
-      else for (int g = lane - NRED; g < ng; g += WAVE - NRED) step_green_policy(x, g);
+      // P0 blue submissions (lanes 0..4) || P2 red FSM policies (lanes 8..13) || P1 green policy draws (lanes 16..63)
+      if (lane < NBLUE) step_blue_submit(x, lane, a.actions ? a.actions[e * NBLUE + lane] : -1);
+      else if (lane >= 8 && lane < 8 + NRED) step_red_policy(x, lane - 8);
+      else if (lane >= 16) for (int g = lane - 16; g < ng; g += WAVE - 16) step_green_policy(x, g);
       __syncthreads();
       CC4_TICK(x, 2);
-      // P3 duration queue + blue execution
-      if (lane == 0) step_tick(x);
+      // P3 duration queues, one agent per lane; then blue execution in priority/agent order on lane 0
+      if (lane < NBLUE + NRED && step_tick_agent(x, lane)) atomicSub(&s->n_actions, 1);
+      __syncthreads();
+      if (lane == 0) step_blue_exec(x);
       __syncthreads();
       // P4 green actions, one per lane
       int pen = 0;
@@ -172,8 +179,13 @@ __global__ __launch_bounds__(WAVE) void k_step_philox(StepArgs a) {
       if (pen) atomicAdd(&s->brm, pen);
       __syncthreads();
       CC4_TICK(x, 6);
-      // P5 deferred phishing, P6 red actions + reassignment
+      // P5 deferred phishing, P6 red actions (ordered) on lane 0
       if (lane == 0) { step_phishing(x); step_red_exec(x); }
+      __syncthreads();
+      // reassignment: foreign-session scan on 6 lanes, the (rare) moves on lane 0
+      if (lane < NRED && red_has_foreign_session(s, lane)) atomicOr(&flag_lds, 1);
+      __syncthreads();
+      if (lane == 0) step_reassign(x, flag_lds != 0);
       __syncthreads();
       // P7 end-turn Monitor: per-host roll-over on all lanes, sus-pid hand-over on lane 0 (disjoint data)
       for (int h = lane; h < MAXH; h += WAVE) step_monitor_host(x, h);
@@ -473,11 +485,18 @@ int cc4_set_state(cc4_handle* h, int32_t env, const void* buf) {
 int cc4_get_topology(cc4_handle* h, int32_t env, uint8_t* out) {
   if (env < 0 || env >= h->cfg.num_envs) { h->err = "cc4_get_topology: env out of range"; return -2; }
   EnvState* tmp = (EnvState*)malloc(sizeof(EnvState));
-  if (cc4_get_state(h, env, tmp)) { free(tmp); return -1; }
-  for (int i = 0; i < NSUB; ++i) { out[i] = tmp->cidr_octet[i]; out[9 + i] = tmp->n_users[i]; out[18 + i] = tmp->n_servers[i]; }
-  for (int i = 0; i < MAXH; ++i) { out[27 + 2 * i] = tmp->hs[i].exists; out[28 + 2 * i] = tmp->hs[i].ip_octet; }
-  free(tmp);
-  return 0;
+  HostStatic* hs = (HostStatic*)malloc(sizeof(HostStatic) * MAXH);
+  int rc = cc4_get_state(h, env, tmp);
+  if (rc == 0) {
+    hipError_t e = hipMemcpy(hs, h->d_cold[env].hs, sizeof(HostStatic) * MAXH, hipMemcpyDeviceToHost);
+    if (e != hipSuccess) { h->err = std::string("cc4_get_topology: ") + hipGetErrorString(e); rc = -1; }
+  }
+  if (rc == 0) {
+    for (int i = 0; i < NSUB; ++i) { out[i] = tmp->cidr_octet[i]; out[9 + i] = tmp->n_users[i]; out[18 + i] = tmp->n_servers[i]; }
+    for (int i = 0; i < MAXH; ++i) { out[27 + 2 * i] = bit_get(tmp->exists, i) ? 1 : 0; out[28 + 2 * i] = hs[i].ip_octet; }
+  }
+  free(tmp); free(hs);
+  return rc;
 }
 
 // debug: enable (buf != NULL first call allocates) / read per-episode phase cycle counters [N][16]

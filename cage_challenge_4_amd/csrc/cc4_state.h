@@ -1,7 +1,7 @@
 // cc4_state.h -- packed per-episode state of the CC4 (CybORG v4) step engine.
 //
-// One episode ("env") = one EnvState (hot, ~20 KB) + one EnvCold (ephemeral-port bitmaps and
-// per-red-session port knowledge, touched a handful of times per step).  Everything is fixed-size
+// One episode ("env") = one EnvState (hot, ~32 KB, staged in LDS) + one EnvCold (host backup images, ephemeral-port
+// bitmaps and per-red-session port knowledge; stays in HBM, touched a handful of times per step).  Everything is fixed-size
 // POD so that a whole episode can be staged with coalesced loads and snapshot with memcpy.
 //
 // Host id layout: h = subnet*17 + slot; slot 0 router, 1..10 user_host_0..9, 11..16 server_host_0..5;
@@ -19,7 +19,7 @@ enum : int {
   MAX_USERS = 10, MAX_SERVERS = 6, ZONE_HOSTS = 16,
   MAXG = 80,            // green agents (one per user host)
   NBLUE = 5, NRED = 6,
-  MAXP = 16,            // process slots per host
+  MAXP = 24,            // process slots per host
   MAXSV = 9,            // service kinds per host (5 real + 4 decoy names)
   MAX_RS = 64,          // sessions per red agent
   MAX_KS = 96,          // known server-session ids per red agent (ActionSpace.server_session)
@@ -104,6 +104,7 @@ struct RedAgent {
   uint32_t as_hn[5];                 // ActionSpace.hostname[name] == True
   ObsEnt obs[MAX_OBS];
   uint32_t obs_has[2][5];            // which (key type, host) pairs are already in obs[] this step
+  uint32_t sess_hosts[5];            // hosts listed by the last full RedSessionCheck observation
   Act queue;                         // actions_in_progress[agent]
   Act chosen;                        // action produced by the policy this step (scratch)
   uint16_t as_subnet;                // ActionSpace.subnet known bits
@@ -115,8 +116,10 @@ struct RedAgent {
   uint8_t exec_type, exec_host;      // self.action[agent][0] of this step (for reward)
   uint8_t new_sess_host;             // host of a session created by this agent's exploit this step (0xFF none)
   uint16_t new_sess_id;
-  uint8_t start_host, allowed;       // static per episode; allowed = bitmask over subnets... (see red_allowed())
-  uint8_t pad[2];
+  uint8_t start_host;                // static per episode
+  uint8_t rsc_dirty;                 // session table changed since the last full RedSessionCheck observation
+  uint8_t rsc_skipped;               // this step's RedSessionCheck observation == the cached one (only SESS bits matter)
+  uint8_t pad[1];
 };
 
 struct BlueAgent {
@@ -142,7 +145,8 @@ struct alignas(16) EnvState {
   uint16_t green_pid[MAXH];
   uint32_t pend[MAX_PEND];           // (host<<16)|pid process_creation events not yet seen by Monitor
   uint8_t npend, pad1[3];
-  HostStatic hs[MAXH];
+  uint32_t exists[5];                // host h is part of this episode's topology
+  uint32_t pad2[3];
   HostDyn hd[MAXH];
   BlueAgent blue[NBLUE];
   RedAgent red[NRED];
@@ -155,9 +159,13 @@ struct alignas(16) EnvState {
   float action_cost;
   int32_t n_actions;                 // actions surviving filter_actions (length of the shuffled index list)
   uint8_t phish_req[MAXG];           // green g's LocalWork asked for a PhishingEmail this step
+  int32_t n_restore;                 // Restore actions submitted this step (each costs -1)
+  int32_t any_phish;                 // some phish_req[] is set
 };
 
 struct alignas(16) EnvCold {
+  HostStatic hs[MAXH];               // backup images (Host.create_backup): read by Restore and reset only
+  uint8_t hs_pad[8];
   uint32_t eph[MAXH][EPH_WORDS];     // Host.ephemeral_ports as a bitmap (port-49152)
   uint8_t kports[MAX_KB][MAXH + 7];  // RedAbstractSession.ports[ip]: PB_* bits | PB_HAS
 };

@@ -109,7 +109,7 @@ int cc4o_layout(char* buf, int cap) {
   int n = 0;
 #define F(m) n += snprintf(buf + n, cap - n, #m " %zu\n", offsetof(EnvState, m))
   F(rng); F(step_count); F(steps); F(phase); F(phase_len); F(err); F(reward); F(done); F(blocks); F(cidr_octet); F(n_users);
-  F(n_servers); F(green_host); F(green_act); F(blue_pid); F(green_pid); F(pend); F(npend); F(hs); F(hd); F(blue); F(red);
+  F(n_servers); F(green_host); F(green_act); F(blue_pid); F(green_pid); F(pend); F(npend); F(exists); F(hd); F(blue); F(red);
   F(msg); F(kb_used);
 #undef F
 #define G(m) n += snprintf(buf + n, cap - n, "red." #m " %zu\n", offsetof(RedAgent, m))
@@ -130,7 +130,7 @@ int cc4o_dump(void* h, int i, char* buf, int cap) {
   for (int k = 0; k < NSUB; ++k) P(" %u", s.blocks[k]);
   P("\n");
   for (int hh = 0; hh < MAXH; ++hh) {
-    if (!s.hs[hh].exists) continue;
+    if (!bit_get(s.exists, hh)) continue;
     const HostDyn& d = s.hd[hh];
     P("host %d procs", hh);
     for (int k = 0; k < d.nproc; ++k) P(" (%d,%d,%d)", d.procs[k].pid, d.procs[k].kind, d.procs[k].flags & 1);
