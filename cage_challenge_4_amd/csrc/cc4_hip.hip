@@ -71,7 +71,9 @@ __global__ __launch_bounds__(WAVE) void k_step(StepArgs a) {
   stage_in(lds, src, lane);
   __syncthreads();
   EnvState* s = reinterpret_cast<EnvState*>(lds);
-  unsigned long long* prof = a.prof ? a.prof + 16 * (size_t)e : nullptr;
+  __shared__ unsigned long long prof_lds[16];   // phase counters accumulate in LDS, flushed once at the end
+  unsigned long long* prof = a.prof ? prof_lds : nullptr;
+  if (prof && lane < 16) prof_lds[lane] = 0;
   Ctx x{s, a.cold + e, &s->rng, lane == 0 ? prof : nullptr};
   if (prof && lane == 0) prof[11] += clock64() - t_begin;
   const bool do_reset = a.autoreset && s->done;
@@ -125,6 +127,7 @@ __global__ __launch_bounds__(WAVE) void k_step(StepArgs a) {
   int32_t* o = a.obs + (size_t)e * OBS_TOTAL;
   for (int i = lane; i < OBS_TOTAL; i += WAVE) o[i] = obs_lds[i];
   if (prof && lane == 0) { prof[13] += clock64() - t_out; prof[14] += clock64() - t_begin; }
+  if (prof) { __syncthreads(); if (lane < 15) a.prof[16 * (size_t)e + lane] += prof_lds[lane]; }
 }
 
 // ---------------------------------------------------------------- Philox mode: lane-parallel step
@@ -145,7 +148,10 @@ __global__ __launch_bounds__(WAVE) void k_step_philox(StepArgs a) {
   stage_in(lds, src, lane);
   __syncthreads();
   EnvState* s = reinterpret_cast<EnvState*>(lds);
-  unsigned long long* prof = a.prof ? a.prof + 16 * (size_t)e : nullptr;
+  __shared__ unsigned long long prof_lds[16];   // phase counters accumulate in LDS, flushed once at the end
+  unsigned long long* prof = a.prof ? prof_lds : nullptr;
+  if (prof && lane < 16) prof_lds[lane] = 0;
+  __syncthreads();
   if (prof && lane == 0) prof[11] += clock64() - t_begin;
   const bool do_reset = a.autoreset && s->done;
   if (do_reset) {
@@ -211,6 +217,7 @@ __global__ __launch_bounds__(WAVE) void k_step_philox(StepArgs a) {
   int32_t* o = a.obs + (size_t)e * OBS_TOTAL;
   for (int i = lane; i < OBS_TOTAL; i += WAVE) o[i] = obs_lds[i];
   if (prof && lane == 0) { prof[13] += clock64() - t_out; prof[14] += clock64() - t_begin; }
+  if (prof) { __syncthreads(); if (lane < 15) a.prof[16 * (size_t)e + lane] += prof_lds[lane]; }
 }
 
 struct ResetArgs {

@@ -55,18 +55,18 @@ enum : uint32_t {
   E_BAD_ACTION = 1u << 9, E_BLUE_GREEN_SESSION_KILLED = 1u << 10, E_FSM_NO_HOST = 1u << 11,
 };
 
-struct Proc { uint16_t pid; uint8_t kind; uint8_t flags; };       // flags bit0: user == root
-struct Svc  { uint16_t pid; uint8_t kind; uint8_t st; };          // st bit7 active, low bits reliability/20
+struct alignas(4) Proc { uint16_t pid; uint8_t kind; uint8_t flags; };       // flags bit0: user == root
+struct alignas(4) Svc  { uint16_t pid; uint8_t kind; uint8_t st; };          // st bit7 active, low bits reliability/20
 enum : int { PF_ROOT = 1, SV_ACTIVE = 0x80 };
 
 enum : int { EV_CUR_CONN = 1, EV_CUR_PROC = 2, EV_OLD_CONN = 4, EV_OLD_PROC = 8 };
 
-struct HostDyn {
+struct alignas(8) HostDyn {
   Proc procs[MAXP];
   Svc svcs[MAXSV];
   uint8_t nproc, nsvc, ev, pad;
 };
-struct HostStatic {                 // Host.create_backup (Host.py:316-371)
+struct alignas(8) HostStatic {                 // Host.create_backup (Host.py:316-371)
   Proc procs[8];
   Svc svcs[5];
   uint8_t nproc, nsvc, exists, ip_octet;
@@ -74,7 +74,7 @@ struct HostStatic {                 // Host.create_backup (Host.py:316-371)
 
 // red sessions (state.sessions[red_agent_k], dict order == array order)
 enum : int { RS_ABSTRACT = 1, RS_ROOT = 2, RS_ORIG = 4 };
-struct RSess { uint16_t id; uint16_t pid; uint8_t host; uint8_t flags; uint8_t kb; uint8_t pad; };
+struct alignas(8) RSess { uint16_t id; uint16_t pid; uint8_t host; uint8_t flags; uint8_t kb; uint8_t pad; };
 
 // FSM host states (FiniteStateRedAgent.py:441-452)
 enum : int { FS_K = 0, FS_KD = 1, FS_S = 2, FS_SD = 3, FS_U = 4, FS_UD = 5, FS_R = 6, FS_RD = 7, FS_F = 8, FS_NONE = 0xFF };
@@ -86,14 +86,14 @@ enum : int { BA_SLEEP = 0, BA_MONITOR = 1, BA_ANALYSE = 2, BA_REMOVE = 3, BA_RES
 // TernaryEnum (Shared/Enums.py:5-25)
 enum : int { T_TRUE = 1, T_UNKNOWN = 2, T_FALSE = 3, T_IN_PROGRESS = 4 };
 
-struct Act { uint8_t type; uint8_t host; uint8_t arg; uint8_t ticks; uint16_t sid; uint16_t busy; };
+struct alignas(8) Act { uint8_t type; uint8_t host; uint8_t arg; uint8_t ticks; uint16_t sid; uint16_t busy; };
 // Act.host: target host (blue/red) ; Act.arg: subnet (DRS) or from-subnet (Block/Allow) ; Act.busy: 1 if queued
 
 // red observation entry (one dict key of the agent's combined Observation)
 enum : int { OE_KEY_IP = 1, OE_SESS = 2, OE_IFACE = 4, OE_SYSHN = 8 };
-struct ObsEnt { uint8_t host; uint8_t flags; };
+struct alignas(2) ObsEnt { uint8_t host; uint8_t flags; };
 
-struct RedAgent {
+struct alignas(8) RedAgent {
   RSess sess[MAX_RS];
   uint16_t known_sid[MAX_KS];        // ActionSpace.server_session keys with value True, insertion order
   uint8_t fsm_order[MAXH];           // host_states dict insertion order, restricted to hosts whose state is not 'F'
@@ -122,7 +122,7 @@ struct RedAgent {
   uint8_t pad[1];
 };
 
-struct BlueAgent {
+struct alignas(8) BlueAgent {
   uint32_t sus[MAX_SUS];             // (host << 16) | pid, chronological
   Act queue;
   uint16_t nsus;
