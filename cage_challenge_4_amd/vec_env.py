@@ -105,6 +105,12 @@ class CC4VecEnv:
     def err(self):
         return self._err
 
+    def topology(self, env=0):
+        """cc4_get_topology: 9 cidr octets, 9 user counts, 9 server counts, 137 x (exists, ip octet)."""
+        buf = np.zeros(L.TOPOLOGY_BYTES, np.uint8)
+        self._chk(self.lib.cc4_get_topology(self._h, int(env), buf.ctypes.data_as(ctypes.c_void_p)), 'cc4_get_topology')
+        return buf
+
     def rng_state(self):
         out = np.zeros((self.num_envs, 7), np.uint64)
         self._chk(self.lib.cc4_get_rng_state(self._h, out.ctypes.data_as(ctypes.c_void_p)), 'cc4_get_rng_state')

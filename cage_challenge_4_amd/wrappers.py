@@ -74,17 +74,18 @@ class EnterpriseScenarioGenerator:
 
 class CybORG:
     """CybORG(scenario_generator, agents=None, seed=None)  (env.py:53-77).  seed: int or None."""
-    def __init__(self, scenario_generator, agents=None, seed=None, device_id=0, rng_mode=RNG_PCG64):
+    def __init__(self, scenario_generator, agents=None, seed=None, device_id=0, rng_mode=RNG_PCG64, vec_factory=None):
         assert isinstance(scenario_generator, EnterpriseScenarioGenerator), \
             f'Scenario generator object of type {type(scenario_generator)} must be a subclass of ScenarioGenerator'
-        if agents:
+        if agents and not isinstance(agents, str):   # evaluation.py:69 passes the string "sim" here; it selects nothing
             raise NotImplementedError("per-agent policy overrides are not part of the accelerated path")
         self.scenario_generator = scenario_generator
         if seed is None:
             seed = int.from_bytes(os.urandom(8), 'little') >> 1
         if not isinstance(seed, (int, np.integer)):
             raise NotImplementedError("custom Generator objects cannot be injected into the device RNG; pass an int seed")
-        self.vec = CC4VecEnv(1, steps=scenario_generator.steps, rng_mode=rng_mode, device_id=device_id)
+        # vec_factory: anything with CC4VecEnv's call shape (tests inject the CPU oracle; the default is the HIP engine)
+        self.vec = (vec_factory or CC4VecEnv)(1, steps=scenario_generator.steps, rng_mode=rng_mode, device_id=device_id)
         self.vec.reset(seeds=np.array([seed], np.uint64))      # SimulationController.__init__ creates a scenario
         self.agents = [f'blue_agent_{b}' for b in range(5)]
 
@@ -97,9 +98,7 @@ class CybORG:
         return self
 
     def topology(self):
-        buf = np.zeros(L.TOPOLOGY_BYTES, np.uint8)
-        self.vec._chk(self.vec.lib.cc4_get_topology(self.vec._h, 0, buf.ctypes.data_as(ctypes.c_void_p)), 'cc4_get_topology')
-        return buf
+        return self.vec.topology(0)
 
     def get_cidr_map(self):
         t = self.topology()
@@ -198,7 +197,10 @@ class BlueFixedActionWrapper:
             assert m.shape == (MESSAGE_LENGTH,), \
                 f'{a} attempting to send message {m} that is not in the message space MultiBinary({MESSAGE_LENGTH})'
             msg[0, b] = m
-        obs, rew, done, _ = self.env.vec.step(acts, msg)
+        obs, rew, done, vinfo = self.env.vec.step(acts, msg)
+        if int(vinfo['err'][0]) & (1 << 7):   # State.check_next_phase_on_update_step (State.py:539-540)
+            raise ValueError("Step number exceeds last mission phase step maximum. "
+                             "Use step parameter in EnterpriseScenarioGenerator.")
         d = bool(done[0])
         ob = split_obs(obs)
         observations = {a: ob[b][0].astype(np.int64) for b, a in enumerate(self.possible_agents)}
@@ -308,7 +310,7 @@ class EnterpriseMAE(BlueEnterpriseWrapper):
     """EnterpriseMAE.py:10-72 -- RLlib MultiAgentEnv flavour: adds the "__all__" keys."""
     def step(self, action_dict=None, messages=None):
         obs, rew, terminated, truncated, info = BlueFlatWrapper.step(self, actions=action_dict, messages=messages)
-        done = bool(self.env.vec._done[0])
+        done = bool(truncated[self.possible_agents[0]])
         terminated['__all__'] = False
         truncated['__all__'] = done
         return obs, rew, terminated, truncated, info

@@ -79,6 +79,13 @@ void cc4o_set_threads(int n) {
   (void)n;
 #endif
 }
+// same layout as cc4_get_topology (include/cc4.h)
+void cc4o_topology(void* h, int i, uint8_t* out) {
+  Oracle* o = (Oracle*)h;
+  const EnvState& s = o->st[i];
+  for (int k = 0; k < NSUB; ++k) { out[k] = s.cidr_octet[k]; out[9 + k] = s.n_users[k]; out[18 + k] = s.n_servers[k]; }
+  for (int k = 0; k < MAXH; ++k) { out[27 + 2 * k] = bit_get(s.exists, k) ? 1 : 0; out[28 + 2 * k] = o->cold[i].hs[k].ip_octet; }
+}
 void cc4o_obs(void* h, int i, int32_t* out) { env_flat_obs<int32_t>(&((Oracle*)h)->st[i], out); }
 float cc4o_reward(void* h, int i) { return ((Oracle*)h)->st[i].reward; }
 int cc4o_done(void* h, int i) { return ((Oracle*)h)->st[i].done; }

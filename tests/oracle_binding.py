@@ -37,13 +37,14 @@ def load():
     lib.cc4o_state_bytes.restype = ctypes.c_size_t
     lib.cc4o_state_ptr.restype = ctypes.c_void_p
     lib.cc4o_state_ptr.argtypes = [ctypes.c_void_p, ctypes.c_int]
+    lib.cc4o_topology.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]
     lib.cc4o_dump.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_int]
     return lib
 
 
 class OracleVecEnv:
     """Same call shape as cage_challenge_4_amd.CC4VecEnv, stepping episodes serially on the host."""
-    def __init__(self, num_envs, steps=500, rng_mode=0, autoreset=False):
+    def __init__(self, num_envs, steps=500, rng_mode=0, autoreset=False, device_id=0):
         self.lib = load()
         self.num_envs = num_envs
         self.steps = steps
@@ -91,6 +92,15 @@ class OracleVecEnv:
                                None if m is None else m.ctypes.data_as(ctypes.c_void_p))
             self._collect(i)
         return self._obs, self._rew, self._done, {'err': self._err}
+
+    @property
+    def action_mask(self):
+        return self.mask()
+
+    def topology(self, i=0):
+        buf = np.zeros(27 + 2 * 137, np.uint8)
+        self.lib.cc4o_topology(self._h, i, buf.ctypes.data_as(ctypes.c_void_p))
+        return buf
 
     def mask(self):
         m = np.zeros((self.num_envs, 570), np.uint8)

@@ -195,3 +195,30 @@ def test_drop_in_wrapper_reproduces_reference_episode():
     o, r, te, tr, i = mae.step({'blue_agent_0': 16})
     assert te['__all__'] is False and tr['__all__'] is False and set(o) == set(mae.possible_agents)
     mae.close()
+
+
+def test_evaluation_harness_on_device():
+    """the batched evaluation loop on the HIP backend: sequential mode reproduces the reference's scores,
+    batched mode agrees with single-episode runs of the same seeds."""
+    import json, os
+    from cage_challenge_4_amd.evaluation import run_evaluation
+    from test_wrappers_cpu import make_submission
+    gold = json.load(open(os.path.join(G.GOLDEN_DIR, 'eval_seed321.json')))
+    scores = run_evaluation(make_submission(), None, max_eps=2, seed=gold['seed'], mode='sequential', write_to_file=False)
+    assert scores == gold['total_reward'][:2]
+
+    class Vec:
+        def get_actions(self, obs, mask):
+            return np.full(obs.shape[0], 49 if obs.shape[1] == 92 else 145)
+    class Sub:
+        NAME, TEAM, TECHNIQUE = 'sleep', 't', 'none'
+        AGENTS = {f'blue_agent_{k}': Vec() for k in range(5)}
+    s = run_evaluation(Sub, None, max_eps=100, seed=1000, mode='batched', episode_length=80, write_to_file=False)
+    ora = OracleVecEnv(100, steps=80); ora.reset(seeds=1000)
+    tot = np.zeros(100); alive = np.ones(100, bool)
+    acts = np.tile(np.array([[49, 49, 49, 49, 145]], np.int32), (100, 1))
+    for t in range(80):
+        _, rew, done, _ = ora.step(acts)
+        alive &= ~done
+        tot += np.where(alive, rew, 0.0)
+    assert s == [float(v) for v in tot]
