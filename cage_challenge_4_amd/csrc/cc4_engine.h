@@ -46,6 +46,39 @@ CC4_HD bool h_is_server(int h) { return h_slot(h) >= 11; }
 CC4_HD int h_make(int s, int slot) { return s * SLOTS + slot; }
 CC4_HD bool bit_get(const uint32_t* b, int i) { return (b[i >> 5] >> (i & 31)) & 1u; }
 CC4_HD void bit_set(uint32_t* b, int i) { b[i >> 5] |= 1u << (i & 31); }
+CC4_HD void bit_clr(uint32_t* b, int i) { b[i >> 5] &= ~(1u << (i & 31)); }
+CC4_HD int popc32(uint32_t v) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  return __popc(v);
+#else
+  return __builtin_popcount(v);
+#endif
+}
+CC4_HD int ctz32(uint32_t v) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  return __ffs((int)v) - 1;
+#else
+  return __builtin_ctz(v);
+#endif
+}
+// position of the n-th (0-based) set bit of a small mask
+CC4_HD int nth_bit(uint32_t m, int n) {
+  for (int i = 0; i < n; ++i) m &= m - 1;
+  return ctz32(m);
+}
+// index of the n-th (0-based) set bit of a multi-word bitmap
+CC4_HD int nth_set(const uint32_t* bm, int nwords, int n) {
+  for (int w = 0; w < nwords; ++w) {
+    int c = popc32(bm[w]);
+    if (n < c) return w * 32 + nth_bit(bm[w], n);
+    n -= c;
+  }
+  return -1;
+}
+CC4_HD int last_set(const uint32_t* bm, int nwords) {
+  for (int w = nwords - 1; w >= 0; --w) if (bm[w]) { uint32_t v = bm[w]; int b = 31; while (!((v >> b) & 1u)) --b; return w * 32 + b; }
+  return -1;
+}
 
 // Host.get_ephemeral_port (Simulator/Host.py:175-187): one re-draw on collision, then remember the port.
 CC4_HD int eph_port(Ctx x, int h) {
@@ -58,7 +91,11 @@ CC4_HD int eph_port(Ctx x, int h) {
   return 49152 + (int)p;
 }
 CC4_HD void eph_clear(Ctx x, int h) {
-  for (int i = 0; i < EPH_WORDS; ++i) x.c->eph[h][i] = 0;
+  if (x.r->mode != 0) return;   // the bitmap only exists for numpy-stream parity (see eph_port)
+  struct alignas(16) Q { uint32_t a, b, c, d; };       // EPH_WORDS * 4 = 1360 B = 85 x 16 B, 16-byte aligned rows
+  Q* p = reinterpret_cast<Q*>(x.c->eph[h]);
+  Q z; z.a = 0; z.b = 0; z.c = 0; z.d = 0;
+  for (int i = 0; i < EPH_WORDS / 4; ++i) p[i] = z;
 }
 // Host.create_pid (Simulator/Host.py:198-200)
 CC4_HD int create_pid(Ctx x, int h) {
@@ -99,6 +136,20 @@ CC4_HD void ev_proc(Ctx x, int h, int pid) {
     x.s->pend[x.s->npend++] = ((uint32_t)h << 16) | (uint32_t)pid;
   }
 }
+// red exploit variant: the pid-carrying event goes to the agent's own slot so that red agents can be resolved on different
+// waves; step_red_merge() appends the slots in agent order (== the serial append order)
+CC4_HD void ev_proc_red(Ctx x, int r, int h, int pid) {
+  ev_or(x, h, EV_CUR_PROC);
+  if (blue_of_subnet(h_subnet(h)) >= 0) x.s->pend_r[r] = ((uint32_t)h << 16) | (uint32_t)pid;
+}
+CC4_HD void step_red_merge(Ctx x) {
+  EnvState* s = x.s;
+  for (int r = 0; r < NRED; ++r) {
+    if (!s->pend_r[r]) continue;
+    if (s->npend >= MAX_PEND) set_err(x, E_PEND_OVERFLOW); else s->pend[s->npend++] = s->pend_r[r];
+    s->pend_r[r] = 0;
+  }
+}
 CC4_HD void pend_drop_host(Ctx x, int h) {
   EnvState* s = x.s;
   int n = 0;
@@ -114,12 +165,15 @@ CC4_HD int rs_find_id(const RedAgent& a, int id) {
   return -1;
 }
 CC4_HD int kb_alloc(Ctx x) {
-  for (int i = 0; i < MAX_KB; ++i)
-    if (!bit_get(x.s->kb_used, i)) {
-      bit_set(x.s->kb_used, i);
-      for (int h = 0; h < MAXH; ++h) x.c->kports[i][h] = 0;
-      return i;
-    }
+  for (int w = 0; w < MAX_KB / 32; ++w) {
+    uint32_t free_bits = ~x.s->kb_used[w];
+    if (!free_bits) continue;
+    int i = w * 32 + ctz32(free_bits);
+    x.s->kb_used[w] |= 1u << (i & 31);
+    uint64_t* row = reinterpret_cast<uint64_t*>(x.c->kports[i]);   // 144-byte rows, 8-byte aligned
+    for (int k = 0; k < (MAXH + 7) / 8; ++k) row[k] = 0;
+    return i;
+  }
   set_err(x, E_KB_OVERFLOW);
   return 0xFF;
 }
@@ -134,19 +188,21 @@ CC4_HD int rs_add(Ctx x, int r, int host, int pid, int flags) {
   q.kb = (flags & RS_ABSTRACT) ? (uint8_t)kb_alloc(x) : (uint8_t)0xFF;
   a.sess[a.nsess++] = q;
   a.rsc_dirty = 1;
+  bit_set(a.live_hosts, host);
   return a.nsess - 1;
 }
 CC4_HD void rs_remove_at(Ctx x, int r, int idx, bool free_kb) {
   RedAgent& a = x.s->red[r];
   if (free_kb) kb_free(x, a.sess[idx].kb);
+  int gone = a.sess[idx].host;
   for (int i = idx; i + 1 < a.nsess; ++i) a.sess[i] = a.sess[i + 1];
   a.nsess--;
   a.rsc_dirty = 1;
+  bool still = false;
+  for (int i = 0; i < a.nsess; ++i) if (a.sess[i].host == gone) { still = true; break; }
+  if (!still) bit_clr(a.live_hosts, gone);
 }
-CC4_HD bool red_has_session_on(const RedAgent& a, int h) {
-  for (int i = 0; i < a.nsess; ++i) if (a.sess[i].host == h) return true;
-  return false;
-}
+CC4_HD bool red_has_session_on(const RedAgent& a, int h) { return bit_get(a.live_hosts, h); }
 // ActionSpace.update: server_session[session_id] = True (Shared/ActionSpace.py:205-211)
 CC4_HD void as_know_sid(Ctx x, int r, int id) {
   RedAgent& a = x.s->red[r];
@@ -197,8 +253,9 @@ CC4_HD int path_to_root(int h, uint8_t* out) {
   }
   return n;
 }
-CC4_HD int route(int src, int dst, uint8_t* out) {
-  uint8_t a[6], b[6];
+// work: >= 24 bytes (not a private array: see EnvState.scratch); the hops end up in work[12 .. 12+n)
+CC4_HD int route(int src, int dst, uint8_t* work) {
+  uint8_t* a = work; uint8_t* b = work + 6; uint8_t* out = work + 12;
   int na = path_to_root(src, a), nb = path_to_root(dst, b);
   // both end at the root; drop the shared tail but keep the lowest common ancestor
   while (na >= 2 && nb >= 2 && a[na - 2] == b[nb - 2]) { na--; nb--; }
@@ -223,27 +280,27 @@ CC4_HD void gen_host(Ctx x, int h, uint32_t* used) {  // _generate_linux_host (E
   bit_set(s->exists, h);
   (void)rng_below(x.r, 2);  // OSDistribution choice (ESG.py:494): both are LINUX, value unused downstream
   if (h_is_router(h)) return;
-  // _generate_linux_host_services (ESG.py:530-562)
-  int kinds[5]; int pids[5]; int n = 0;
-  kinds[n] = K_SSHD; pids[n++] = gen_pid(x, used);
+  // _generate_linux_host_services (ESG.py:530-562); services dict order = SSHD, [OTSERVICE], chosen add-ons
+  int n = 0;
+  auto put = [&](int kind, int pid) {
+    st.svcs[n].kind = (uint8_t)kind; st.svcs[n].pid = (uint16_t)pid; st.svcs[n].st = (uint8_t)(SV_ACTIVE | 5);
+    st.procs[n].kind = (uint8_t)kind; st.procs[n].pid = (uint16_t)pid; st.procs[n].flags = 0;
+    n++;
+  };
+  put(K_SSHD, gen_pid(x, used));
   int sub = h_subnet(h);
-  if (sub == S_OZA || sub == S_OZB) { kinds[n] = K_OT; pids[n++] = gen_pid(x, used); }
-  int opt_kind[3] = {K_APACHE, K_MYSQL, K_SMTP}; int opt_pid[3];
-  for (int i = 0; i < 3; ++i) opt_pid[i] = gen_pid(x, used);
+  if (sub == S_OZA || sub == S_OZB) put(K_OT, gen_pid(x, used));
+  int p_apache = gen_pid(x, used), p_mysql = gen_pid(x, used), p_smtp = gen_pid(x, used);  // all three are always drawn
   int n_add = (int)rng_below(x.r, 4);  // integers(0, 3, endpoint=True)
-  int n_opt = 3;
+  uint32_t left = 7;                    // remaining add-on options {APACHE2, MYSQLD, SMTP} as a bit list
   for (int k = 0; k < n_add; ++k) {
-    int c = (int)rng_below(x.r, (uint32_t)n_opt);
-    kinds[n] = opt_kind[c]; pids[n++] = opt_pid[c];
-    for (int j = c; j + 1 < n_opt; ++j) { opt_kind[j] = opt_kind[j + 1]; opt_pid[j] = opt_pid[j + 1]; }
-    n_opt--;
+    int c = (int)rng_below(x.r, (uint32_t)popc32(left));
+    int o = nth_bit(left, c);
+    left &= ~(1u << o);
+    put(o == 0 ? K_APACHE : (o == 1 ? K_MYSQL : K_SMTP), o == 0 ? p_apache : (o == 1 ? p_mysql : p_smtp));
   }
   // _generate_linux_host_processes (ESG.py:580-629): one random() per service, never below 1.0
-  for (int i = 0; i < n; ++i) {
-    (void)rng_random(x.r);
-    st.svcs[i].kind = (uint8_t)kinds[i]; st.svcs[i].pid = (uint16_t)pids[i]; st.svcs[i].st = (uint8_t)(SV_ACTIVE | 5);
-    st.procs[i].kind = (uint8_t)kinds[i]; st.procs[i].pid = (uint16_t)pids[i]; st.procs[i].flags = 0;
-  }
+  for (int i = 0; i < n; ++i) (void)rng_random(x.r);
   st.nsvc = (uint8_t)n; st.nproc = (uint8_t)n;
 }
 // Host.add_session for a starting session (Host.py:189-196): Process(pid=create_pid(), name=session_type)
@@ -259,9 +316,11 @@ CC4_HD int start_session_proc(Ctx x, int h, int kind) {
 CC4_HD void host_restore(Ctx x, int h) {  // Host.restore (Host.py:373-429)
   EnvState* s = x.s;
   HostDyn& d = s->hd[h];
-  const HostStatic& st = x.c->hs[h];
-  for (int i = 0; i < st.nproc; ++i) d.procs[i] = st.procs[i];
-  for (int i = 0; i < st.nsvc; ++i) d.svcs[i] = st.svcs[i];
+  // the backup image lives in the cold row (HBM): fetch its 56 bytes with independent wide loads, then unpack
+  HostStatic st;
+  __builtin_memcpy(&st, &x.c->hs[h], sizeof(HostStatic));   // 8-byte aligned POD -> 7 wide loads in flight
+  for (int i = 0; i < 8; ++i) d.procs[i] = st.procs[i];
+  for (int i = 0; i < 5; ++i) d.svcs[i] = st.svcs[i];
   d.nproc = st.nproc; d.nsvc = st.nsvc; d.ev = 0; d.pad = 0;
   eph_clear(x, h);
   pend_drop_host(x, h);
@@ -291,28 +350,32 @@ CC4_HD void env_reset(Ctx x, uint64_t seed, int rng_mode, int steps, bool contin
   uint32_t* used = x.c->eph[H_INTERNET];  // scratch bitmap for used_pids (cleared by the backup below)
   for (int i = 0; i < EPH_WORDS; ++i) used[i] = 0;
 
-  // _generate_subnets (ESG.py:171-266): choice(len(remaining /24 blocks)) per subnet, pop
+  // _generate_subnets (ESG.py:171-266): choice(len(remaining /24 blocks)) per subnet, pop.  The remaining list stays
+  // ascending, so "pop(c)" is the c-th set bit of a 256-bit availability map
   {
-    uint8_t pool[256];
-    for (int i = 0; i < 256; ++i) pool[i] = (uint8_t)i;
+    uint32_t* avail = s->scratch;  // 8 words
+    for (int i = 0; i < 8; ++i) avail[i] = 0xFFFFFFFFu;
     int n = 256;
     for (int sn = 0; sn < NSUB; ++sn) {
       int c = (int)rng_below(x.r, (uint32_t)n);
-      s->cidr_octet[sn] = pool[c];
-      for (int j = c; j + 1 < n; ++j) pool[j] = pool[j + 1];
+      int v = nth_set(avail, 8, c);
+      s->cidr_octet[sn] = (uint8_t)v;
+      bit_clr(avail, v);
       n--;
     }
   }
-  // _generate_hosts (ESG.py:312-371)
+  // _generate_hosts (ESG.py:312-371): ip_addresses = hosts .1 .. .254 of the /24, ascending
   for (int sn = 0; sn < NSUB; ++sn) {
-    uint8_t ips[254];
-    for (int i = 0; i < 254; ++i) ips[i] = (uint8_t)(i + 1);
+    uint32_t* ips = s->scratch;  // bit v set <=> 10.0.X.v still unassigned
+    for (int i = 0; i < 8; ++i) ips[i] = 0xFFFFFFFFu;
+    ips[0] &= ~1u; ips[7] &= 0x7FFFFFFFu;  // .0 and .255 are not host addresses
     int n = 254;
-    auto pop_at = [&](int c) { uint8_t v = ips[c]; for (int j = c; j + 1 < n; ++j) ips[j] = ips[j + 1]; n--; return v; };
+    auto pop_at = [&](int c) { int v = nth_set(ips, 8, c); bit_clr(ips, v); n--; return (uint8_t)v; };
     if (sn == S_INT) {
       int c = (int)rng_below(x.r, (uint32_t)n);
-      x.c->hs[H_INTERNET].ip_octet = pop_at(c);
+      uint8_t ip = pop_at(c);
       gen_host(x, H_INTERNET, used);
+      x.c->hs[H_INTERNET].ip_octet = ip;
       continue;
     }
     int hr = h_make(sn, 0);
@@ -326,8 +389,8 @@ CC4_HD void env_reset(Ctx x, uint64_t seed, int rng_mode, int steps, bool contin
     int ns = 1 + (int)rng_below(x.r, 6);  // integers(1, 6, endpoint=True)
     for (int i = 0; i < ns; ++i) {
       int h = h_make(sn, 11 + i);
-      uint8_t ip = ips[n - 1]; n--;  // ip_addresses.pop()
-      gen_host(x, h, used); x.c->hs[h].ip_octet = ip;
+      int v = last_set(ips, 8); bit_clr(ips, v); n--;  // ip_addresses.pop()
+      gen_host(x, h, used); x.c->hs[h].ip_octet = (uint8_t)v;
     }
     s->n_users[sn] = (uint8_t)nu; s->n_servers[sn] = (uint8_t)ns;
   }
@@ -527,6 +590,7 @@ CC4_HD void blue_restore(Ctx x, int h) {
       RSess keep = a.sess[orig];
       rs_remove_at(x, r, orig, false);
       a.sess[a.nsess++] = keep;
+      bit_set(a.live_hosts, keep.host);
       a.rsc_dirty = 1;
     }
   }
@@ -535,12 +599,11 @@ CC4_HD void blue_restore(Ctx x, int h) {
 // DecoyAction.execute (ConcreteActions/DecoyActions/DecoyAction.py:47-114) with DeployDecoy candidates (DeployDecoy.py:8-31)
 CC4_HD void blue_decoy(Ctx x, int h) {
   EnvState* s = x.s;
-  int cand[4]; int n = 0;
-  if (!host_uses_port(x, h, PB_80)) cand[n++] = K_DEC_APACHE;
-  if (!host_uses_port(x, h, PB_443)) cand[n++] = K_DEC_TOMCAT;
-  if (!host_uses_port(x, h, PB_25)) cand[n++] = K_DEC_HARAKA;
-  cand[n++] = K_DEC_VSFTPD;  // compatibility checks port 21, which nothing uses (DecoyVsftpd.py:17-20)
-  int kind = cand[rng_below(x.r, (uint32_t)n)];
+  uint32_t cand = 8;  // bit i <=> K_DEC_APACHE + i is compatible; vsftpd checks port 21, which nothing uses (DecoyVsftpd.py:17-20)
+  if (!host_uses_port(x, h, PB_80)) cand |= 1;
+  if (!host_uses_port(x, h, PB_443)) cand |= 2;
+  if (!host_uses_port(x, h, PB_25)) cand |= 4;
+  int kind = K_DEC_APACHE + nth_bit(cand, (int)rng_below(x.r, (uint32_t)popc32(cand)));
   int pid = create_pid(x, h);
   if (!add_proc(x, h, pid, kind, 0)) return;
   HostDyn& d = s->hd[h];
@@ -567,40 +630,40 @@ CC4_HD void blue_execute(Ctx x, int b, const Act& a) {
 // PhishingEmail._create_new_session (ConcreteActions/PhishingEmail.py:42-113)
 CC4_HD void phishing(Ctx x, int gh) {
   EnvState* s = x.s;
-  // per-agent bitmap of hosts holding one of its sessions (one pass over the session tables instead of a
-  // hosts x agents x sessions scan)
-  uint32_t has[NRED][5];
-  uint32_t any[5] = {0, 0, 0, 0, 0};
-  for (int r = 0; r < NRED; ++r) {
-    for (int w = 0; w < 5; ++w) has[r][w] = 0;
-    const RedAgent& A = s->red[r];
-    for (int i = 0; i < A.nsess; ++i) bit_set(has[r], A.sess[i].host);
-    for (int w = 0; w < 5; ++w) any[w] |= has[r][w];
-  }
-  if (bit_get(any, gh)) return;  // a red agent already has a session on the green host (PhishingEmail.py:57-59)
+  // RedAgent.live_hosts[r] = hosts where agent r holds a session (host.sessions[agent] != []), kept exact incrementally
+  uint32_t any[5];
+  for (int w = 0; w < 5; ++w) { uint32_t m = 0; for (int r = 0; r < NRED; ++r) m |= s->red[r].live_hosts[w]; any[w] = m; }
+  const int gw = gh >> 5;
+  if ((gw == 0 ? any[0] : gw == 1 ? any[1] : gw == 2 ? any[2] : gw == 3 ? any[3] : any[4]) >> (gh & 31) & 1u) return;
+  // a red agent already has a session on the green host (PhishingEmail.py:57-59)
+  const int gsub = h_subnet(gh);
+  const int lo = gsub * SLOTS, hi = lo + SLOTS - 1;   // host ids of the green host's subnet
+  // hosts of the same subnet overwrite red_agent_src in host order -> the LAST such host with red sessions decides, and on
+  // it the FIRST red agent (`break` leaves only the inner loop, PhishingEmail.py:63-69)
   int src = -1;
-  uint8_t cand[NRED * MAX_RS]; int nc = 0;
-  int gsub = h_subnet(gh);
-  for (int w = 0; w < 5; ++w) {
-    uint32_t m = any[w];
-    while (m) {  // hosts with red sessions, increasing host id == state.hosts order
-#if defined(__HIP_DEVICE_COMPILE__)
-      int b = __ffs((int)m) - 1;
-#else
-      int b = __builtin_ctz(m);
-#endif
-      m &= m - 1;
-      int h = w * 32 + b;
-      for (int r = 0; r < NRED; ++r) {
-        if (!bit_get(has[r], h)) continue;
-        if (h_subnet(h) == gsub) { src = r; break; }  // `break` leaves only the inner loop (PhishingEmail.py:63-69)
-        if (nc < NRED * MAX_RS) cand[nc++] = (uint8_t)r;
-      }
-    }
+  for (int h = hi; h >= lo && src < 0; --h) {
+    const int w = h >> 5;
+    uint32_t aw = w == 0 ? any[0] : w == 1 ? any[1] : w == 2 ? any[2] : w == 3 ? any[3] : any[4];
+    if (!((aw >> (h & 31)) & 1u)) continue;
+    for (int r = 0; r < NRED; ++r) if (bit_get(s->red[r].live_hosts, h)) { src = r; break; }
   }
   if (src < 0) {
+    // red_agents = [(agent, host)] over hosts outside the subnet, host-major then agent order; choice(replace=False)
+    int nc = 0;
+    for (int w = 0; w < 5; ++w) for (int r = 0; r < NRED; ++r) nc += popc32(s->red[r].live_hosts[w]);   // no red session inside the subnet here
     if (nc == 0) return;
-    src = cand[rng_below(x.r, (uint32_t)nc)];  // choice(red_agents, replace=False): one bounded draw
+    int c = (int)rng_below(x.r, (uint32_t)nc);
+    for (int w = 0; w < 5 && src < 0; ++w) {
+      int inw = 0;
+      for (int r = 0; r < NRED; ++r) inw += popc32(s->red[r].live_hosts[w]);
+      if (c >= inw) { c -= inw; continue; }
+      uint32_t m = w == 0 ? any[0] : w == 1 ? any[1] : w == 2 ? any[2] : w == 3 ? any[3] : any[4];
+      while (m && src < 0) {
+        int b = ctz32(m); m &= m - 1;
+        for (int r = 0; r < NRED; ++r)
+          if ((s->red[r].live_hosts[w] >> b) & 1u) { if (c-- == 0) { src = r; break; } }
+      }
+    }
   }
   int pid = create_pid(x, gh);
   if (!add_proc(x, gh, pid, K_SESS_RED, 0)) return;
@@ -610,10 +673,11 @@ CC4_HD void phishing(Ctx x, int gh) {
 CC4_HD bool green_local_work(Ctx x, int gh, bool* want_phish) {
   EnvState* s = x.s;
   HostDyn& d = s->hd[gh];
-  int act[MAXSV]; int n = 0;
-  for (int i = 0; i < d.nsvc; ++i) if (d.svcs[i].st & SV_ACTIVE) act[n++] = i;
+  int n = 0;
+  for (int i = 0; i < d.nsvc; ++i) if (d.svcs[i].st & SV_ACTIVE) n++;
   if (n == 0) return false;
-  int c = act[rng_below(x.r, (uint32_t)n)];
+  int k = (int)rng_below(x.r, (uint32_t)n), c = 0;
+  for (int i = 0; i < d.nsvc; ++i) if (d.svcs[i].st & SV_ACTIVE) { if (k-- == 0) { c = i; break; } }
   int rel = (d.svcs[c].st & 0x7F) * 20;
   if ((int)rng_below(x.r, 100) >= rel) return false;
   if (rng_random(x.r) < 0.01) { (void)eph_port(x, gh); ev_proc(x, gh, 0); }
@@ -702,28 +766,29 @@ CC4_HD void red_exploit(Ctx x, int r, const Act& a) {
   if (!(known & PB_HAS)) { red_result(x, r, a, T_FALSE); return; }
   if (subnet_blocked(x, h_subnet(src), h_subnet(tgt))) { red_result(x, r, a, T_FALSE); return; }
   // DefaultExploitActionSelector: options in list order with non-zero weight
+  // option list order: HTTPRFI(3.0) HTTPSRFI(4.0) SSH(0.1) SQLi(5.0) Haraka(6.0) -> bit i of `opts`
   enum { X_HTTPRFI = 0, X_HTTPSRFI = 1, X_SSH = 2, X_SQLI = 3, X_HARAKA = 4 };
-  int opt[5]; int w10[5]; int n = 0;
-  if (known & PB_80) { opt[n] = X_HTTPRFI; w10[n++] = 30; }
-  if (known & PB_443) { opt[n] = X_HTTPSRFI; w10[n++] = 40; }
-  if (known & PB_22) { opt[n] = X_SSH; w10[n++] = 1; }
-  if ((known & PB_3390) && (known & (PB_80 | PB_443))) { opt[n] = X_SQLI; w10[n++] = 50; }
-  if (known & PB_25) { opt[n] = X_HARAKA; w10[n++] = 60; }
-  if (n == 0) { red_result(x, r, a, T_FALSE); return; }
-  int sel = opt[0];
-  if (n > 1) {
-    int top = 0;
-    for (int i = 1; i < n; ++i) if (w10[i] > w10[top]) top = i;
-    for (int i = top; i + 1 < n; ++i) { opt[i] = opt[i + 1]; w10[i] = w10[i + 1]; }
-    n--;
-    sel = opt[rng_below(x.r, (uint32_t)n)];
+  uint32_t opts = 0;
+  if (known & PB_80) opts |= 1u << X_HTTPRFI;
+  if (known & PB_443) opts |= 1u << X_HTTPSRFI;
+  if (known & PB_22) opts |= 1u << X_SSH;
+  if ((known & PB_3390) && (known & (PB_80 | PB_443))) opts |= 1u << X_SQLI;
+  if (known & PB_25) opts |= 1u << X_HARAKA;
+  if (opts == 0) { red_result(x, r, a, T_FALSE); return; }
+  int sel = ctz32(opts);
+  if (popc32(opts) > 1) {
+    // top weight: Haraka > SQLi > HTTPSRFI > HTTPRFI > SSH; it is discarded, then a uniform choice among the rest
+    int top = (opts >> X_HARAKA) & 1u ? X_HARAKA : ((opts >> X_SQLI) & 1u ? X_SQLI : ((opts >> X_HTTPSRFI) & 1u ? X_HTTPSRFI : X_HTTPRFI));
+    opts &= ~(1u << top);
+    sel = nth_bit(opts, (int)rng_below(x.r, (uint32_t)popc32(opts)));
     (void)rng_random(x.r);  // `elif random() < odds_of_top_choice` with odds 0
   }
   HostDyn& T = s->hd[tgt];
   if (sel == X_SSH) {
     // SSHBruteForce.execute (ExploitActions/SSHBruteForce.py:24-84)
-    uint8_t hops[12]; int nh = route(src, tgt, hops);
-    for (int i = 0; i < nh; ++i) if (0.050000000000000044 < rng_random(x.r)) ev_conn(x, hops[i]);  // 1 - 0.95 in float64
+    uint8_t* work = reinterpret_cast<uint8_t*>(s->scratch + 6 * r);   // 24 bytes per red agent
+    int nh = route(src, tgt, work);
+    for (int i = 0; i < nh; ++i) if (0.050000000000000044 < rng_random(x.r)) ev_conn(x, work[12 + i]);  // 1 - 0.95 in float64
     int vp = -1;
     for (int i = 0; i < T.nproc; ++i) if (T.procs[i].kind == K_SSHD) { vp = i; break; }
     if (vp < 0) { red_result(x, r, a, T_FALSE); return; }
@@ -732,7 +797,7 @@ CC4_HD void red_exploit(Ctx x, int r, const Act& a) {
     ev_conn(x, tgt);                              // _create_brute_force_event: 10 connection events
     int ni = exploit_new_session(x, r, a.sid, tgt);
     if (ni < 0) { red_result(x, r, a, T_FALSE); return; }
-    ev_proc(x, tgt, A.sess[ni].pid);              // _create_new_session_event (always for SSH)
+    ev_proc_red(x, r, tgt, A.sess[ni].pid);       // _create_new_session_event (always for SSH)
     obs_put(x, r, true, tgt, OE_SESS | OE_IFACE | OE_SYSHN, false);
     obs_put(x, r, true, src, OE_IFACE, false);
     A.new_sess_host = (uint8_t)tgt; A.new_sess_id = A.sess[ni].id;
@@ -762,7 +827,7 @@ CC4_HD void red_exploit(Ctx x, int r, const Act& a) {
   if (decoy) { ev_conn(x, tgt); (void)eph_port(x, tgt); red_result(x, r, a, T_FALSE); return; }
   int ni = exploit_new_session(x, r, a.sid, tgt);
   if (ni < 0) { red_result(x, r, a, T_FALSE); return; }
-  if (rng_random(x.r) > 0.050000000000000044) ev_proc(x, tgt, A.sess[ni].pid);
+  if (rng_random(x.r) > 0.050000000000000044) ev_proc_red(x, r, tgt, A.sess[ni].pid);
   obs_put(x, r, true, tgt, OE_SESS | OE_IFACE | OE_SYSHN, false);
   obs_put(x, r, true, src, OE_IFACE, false);
   A.new_sess_host = (uint8_t)tgt; A.new_sess_id = A.sess[ni].id;
@@ -773,13 +838,13 @@ CC4_HD void red_privesc(Ctx x, int r, const Act& a) {
   EnvState* s = x.s;
   RedAgent& A = s->red[r];
   int h = a.host;
-  int on[MAX_RS]; int n = 0;
-  for (int i = 0; i < A.nsess; ++i) if (A.sess[i].host == h) on[n++] = i;
+  int n = 0, target = -1;
+  for (int i = 0; i < A.nsess; ++i)
+    if (A.sess[i].host == h) { n++; if (target < 0 && (A.sess[i].flags & RS_ROOT)) target = i; }
   if (n == 0) { red_result(x, r, a, T_FALSE); return; }
-  int target = -1;
-  for (int i = 0; i < n; ++i) if (A.sess[on[i]].flags & RS_ROOT) { target = on[i]; break; }
   if (target < 0) {
-    target = on[rng_below(x.r, (uint32_t)n)];
+    int k = (int)rng_below(x.r, (uint32_t)n);   // choice(sessions on the host)
+    for (int i = 0; i < A.nsess; ++i) if (A.sess[i].host == h) { if (k-- == 0) { target = i; break; } }
     // DefaultEscalateActionSelector (PrivilegeEscalate.py:52-66): self.session must exist and be a RedAbstractSession,
     // else no sub-action -> Observation(False); then V4L2KernelExploit via TargetedLocalAction.execute
     { int ss = rs_find_id(A, a.sid);
@@ -862,6 +927,7 @@ CC4_HD void red_session_check(Ctx x, int r) {
     rs_remove_at(x, r, c, false);
     q.id = 0;
     A.sess[A.nsess++] = q;
+    bit_set(A.live_hosts, q.host);
   }
   // The observation lists every session (host, Sessions/Interface/System info).  If the session table has not changed
   // since the last full listing, every host in it is already in the agent's ActionSpace and FSM tables, so the only
@@ -943,8 +1009,8 @@ CC4_HD void fsm_observe(Ctx x, int r) {
     }
   }
   // 2. _process_new_observations (:190-250)
-  uint32_t sess_seen[5] = {0, 0, 0, 0, 0};
-  if (A.rsc_skipped) for (int w = 0; w < 5; ++w) sess_seen[w] = A.sess_hosts[w];
+  uint32_t* sess_seen = A.sess_seen;
+  for (int w = 0; w < 5; ++w) sess_seen[w] = A.rsc_skipped ? A.sess_hosts[w] : 0u;
   for (int i = 0; i < A.nobs; ++i) {
     int h = A.obs[i].host; int f = A.obs[i].flags;
     if (f & OE_SESS) bit_set(sess_seen, h);
@@ -978,30 +1044,31 @@ CC4_HD Act fsm_get_action(Ctx x, int r) {
   int n = A.fsm_n;  // fsm_order holds exactly the non-'F' hosts, in host_states insertion order
   if (n == 0) { set_err(x, E_FSM_NO_HOST); A.fsm_step++; return out; }
   int host = A.fsm_order[rng_below(x.r, (uint32_t)n)];
-  // options in red_actions list order (ESG.py:764-768) with state_transitions_probability (:540-549)
-  uint8_t acts[4]; double cdf[4]; int no = 0;
+  // options in red_actions list order (ESG.py:764-768) with state_transitions_probability (:540-549).  All probabilities
+  // are multiples of 1/4, so cdf.searchsorted(u, 'right') == #{i : 4*cdf[i] <= floor(4u)}.  Packed per state:
+  // low 16 bits = option nibbles, high 16 bits = 4*cdf nibbles (unused slots = 15)
+  uint32_t pk;
   switch (A.fsm_state[host]) {
-    case FS_K:  acts[0] = RA_DRS; acts[1] = RA_AGGR; acts[2] = RA_STEALTH; cdf[0] = .5; cdf[1] = .75; cdf[2] = 1.; no = 3; break;
-    case FS_KD: acts[0] = RA_AGGR; acts[1] = RA_STEALTH; cdf[0] = .5; cdf[1] = 1.; no = 2; break;
-    case FS_S:  acts[0] = RA_DRS; acts[1] = RA_EXPLOIT; acts[2] = RA_DECEPTION; cdf[0] = .25; cdf[1] = .75; cdf[2] = 1.; no = 3; break;
-    case FS_SD: acts[0] = RA_EXPLOIT; acts[1] = RA_DECEPTION; cdf[0] = .75; cdf[1] = 1.; no = 2; break;
-    case FS_U:  acts[0] = RA_DRS; acts[1] = RA_PRIVESC; acts[2] = RA_WITHDRAW; cdf[0] = .5; cdf[1] = 1.; cdf[2] = 1.; no = 3; break;
-    case FS_UD: acts[0] = RA_PRIVESC; acts[1] = RA_WITHDRAW; cdf[0] = 1.; cdf[1] = 1.; no = 2; break;
-    case FS_R:  acts[0] = RA_DRS; acts[1] = RA_DEGRADE; acts[2] = RA_IMPACT; acts[3] = RA_WITHDRAW; cdf[0] = .5; cdf[1] = .75; cdf[2] = 1.; cdf[3] = 1.; no = 4; break;
-    default:    acts[0] = RA_DEGRADE; acts[1] = RA_IMPACT; acts[2] = RA_WITHDRAW; cdf[0] = .5; cdf[1] = 1.; cdf[2] = 1.; no = 3; break;  // RD
+    case FS_K:  pk = 0xF432u << 16 | (RA_DRS | RA_AGGR << 4 | RA_STEALTH << 8); break;                          // .5 .25 .25
+    case FS_KD: pk = 0xFF42u << 16 | (RA_AGGR | RA_STEALTH << 4); break;                                         // .5 .5
+    case FS_S:  pk = 0xF431u << 16 | (RA_DRS | RA_EXPLOIT << 4 | RA_DECEPTION << 8); break;                     // .25 .5 .25
+    case FS_SD: pk = 0xFF43u << 16 | (RA_EXPLOIT | RA_DECEPTION << 4); break;                                    // .75 .25
+    case FS_U:  pk = 0xF442u << 16 | (RA_DRS | RA_PRIVESC << 4 | RA_WITHDRAW << 8); break;                      // .5 .5 0
+    case FS_UD: pk = 0xFF44u << 16 | (RA_PRIVESC | RA_WITHDRAW << 4); break;                                     // 1 0
+    case FS_R:  pk = 0x4432u << 16 | (RA_DRS | RA_DEGRADE << 4 | RA_IMPACT << 8 | RA_WITHDRAW << 12); break;    // .5 .25 .25 0
+    default:    pk = 0xF442u << 16 | (RA_DEGRADE | RA_IMPACT << 4 | RA_WITHDRAW << 8); break;                   // RD: .5 .5 0
   }
   double u = rng_random(x.r);
+  int fl = (int)(u * 4.0);  // exact: scaling by a power of two
   int k = 0;
-  while (k < no && cdf[k] <= u) k++;  // cdf.searchsorted(u, side='right')
-  if (k >= no) k = no - 1;
-  int t = acts[k];
+  for (int i = 0; i < 4; ++i) if ((int)((pk >> (16 + 4 * i)) & 0xF) <= fl) k++;
+  int t = (int)((pk >> (4 * k)) & 0xF);
   out.type = (uint8_t)t; out.host = (uint8_t)host;
   // parameters in constructor-signature order; only `subnet` and `session` can draw
   bool bad = false;
   if (t == RA_DRS) {
-    int ns = 0; int subs[NSUB];
-    for (int sn = 0; sn < NSUB; ++sn) if ((A.as_subnet >> sn) & 1u) subs[ns++] = sn;
-    if (ns == 0) bad = true; else out.arg = (uint8_t)subs[rng_below(x.r, (uint32_t)ns)];
+    uint32_t known = A.as_subnet;  // known subnets in dict (= SUBNET enum) order
+    if (known == 0) bad = true; else out.arg = (uint8_t)nth_bit(known, (int)rng_below(x.r, (uint32_t)popc32(known)));
   }
   if ((t == RA_PRIVESC || t == RA_IMPACT || t == RA_DEGRADE) && !bit_get(A.fsm_hn, host)) bad = true;
   if (!bad) {
@@ -1198,10 +1265,28 @@ CC4_HD bool red_has_foreign_session(const EnvState* s, int r) {
   for (int i = 0; i < A.nsess; ++i) if (!((m >> h_subnet(A.sess[i].host)) & 1u)) return true;
   return false;
 }
-CC4_HD void step_red_exec(Ctx x) {
+CC4_HD void step_red_exec_agent(Ctx x, int r) {
   EnvState* s = x.s;
-  for (int r = 0; r < NRED; ++r)
-    if (s->rexec[r].type != RA_NONE) { rng_set_stream(x.r, ST_RED_EXE + (uint32_t)r); red_execute(x, r, s->rexec[r]); }
+  if (s->rexec[r].type == RA_NONE) return;
+  rng_set_stream(x.r, ST_RED_EXE + (uint32_t)r);
+  red_execute(x, r, s->rexec[r]);
+}
+// Red actions of different agents commute when they name different hosts (each action reads/writes its own agent's
+// tables, its target host and commutative event bits); DiscoverRemoteSystems only reads the topology.
+CC4_HD bool red_targets_conflict(const EnvState* s) {
+  for (int a = 0; a < NRED; ++a) {
+    int ta = s->rexec[a].type;
+    if (!(ta >= RA_AGGR && ta <= RA_DEGRADE)) continue;
+    for (int b = a + 1; b < NRED; ++b) {
+      int tb = s->rexec[b].type;
+      if (tb >= RA_AGGR && tb <= RA_DEGRADE && s->rexec[a].host == s->rexec[b].host) return true;
+    }
+  }
+  return false;
+}
+CC4_HD void step_red_exec(Ctx x) {
+  for (int r = 0; r < NRED; ++r) step_red_exec_agent(x, r);
+  step_red_merge(x);
   CC4_TICK(x, 7);
 }
 // different_subnet_agent_reassignment (SC:820-903): `any_foreign` = some red agent holds a session outside its zone

@@ -130,94 +130,146 @@ __global__ __launch_bounds__(WAVE) void k_step(StepArgs a) {
   if (prof) { __syncthreads(); if (lane < 15) a.prof[16 * (size_t)e + lane] += prof_lds[lane]; }
 }
 
-// ---------------------------------------------------------------- Philox mode: lane-parallel step
-// Same phase bodies as the serial walk (cc4_engine.h P0..P9), different schedule: every (agent, phase) owns a Philox
-// counter stream, so the 6 red FSM policies, the <=80 green agents, the 137 per-host Monitor roll-overs and the 6
-// RedSessionChecks run on separate lanes; cross-lane effects are event-bit ORs and the reward sum (LDS atomics) and
-// the rare PhishingEmail spawns, which are collected per green and replayed by lane 0 in agent order.
-__global__ __launch_bounds__(WAVE) void k_step_philox(StepArgs a) {
+// ---------------------------------------------------------------- Philox mode: wave- and lane-parallel step
+// Same phase bodies as the serial walk (cc4_engine.h P0..P9), different schedule.  One block of 4 wavefronts per episode:
+// every (agent, phase) owns a Philox counter stream, so heterogeneous agents can run concurrently.  Work that differs in
+// control flow goes to different WAVES (a wave executes divergent lanes one after the other): the 6 red FSM policies, the
+// 6 red actions (when they name distinct hosts, else serial), the 6 RedSessionChecks (agent r -> wave r % 4, lane r / 4;
+// measured on MI355X: 3..5 waves per block are equivalent, 6 is 30 % slower), and the two green action types
+// (AccessService / LocalWork lists built with wave ballots + LDS counters).  Work that is uniform goes to LANES: row
+// staging, per-agent queue ticks, green agents within a type, the 137 Monitor roll-overs, the observation encode.
+// Cross-thread effects are event-bit ORs and the reward sum (LDS atomics); the rare order-dependent spawns (PhishingEmail,
+// cross-subnet session reassignment) are collected and replayed by thread 0 in agent order.
+#ifndef CC4_PW
+#define CC4_PW 4
+#endif
+constexpr int PW = CC4_PW;         // waves per episode block; red agent r runs on wave r % PW, lane r / PW
+static_assert(PW >= 3 && PW <= 6, "waves 0/1 run the two green action lists, wave 2 the Sleep bookkeeping");
+constexpr int PT = PW * WAVE;      // 384 threads
+constexpr int RNG_SLOTS = 96;      // 6 red + 80 green + spare generators
+
+__device__ __forceinline__ void stage_in_n(uint4* __restrict__ lds, const uint4* __restrict__ src, int tid) {
+  constexpr int U = 6;
+  int i = tid;
+  for (; i + (U - 1) * PT < ROW_VEC; i += U * PT) {
+    uint4 v[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) v[u] = src[i + u * PT];
+#pragma unroll
+    for (int u = 0; u < U; ++u) lds[i + u * PT] = v[u];
+  }
+  for (; i < ROW_VEC; i += PT) lds[i] = src[i];
+}
+
+__global__ __launch_bounds__(PT) void k_step_philox(StepArgs a) {
   extern __shared__ uint4 lds[];
   __shared__ uint8_t obs_lds[OBS_TOTAL + 2];
-  __shared__ int ok_lds;
-  __shared__ Rng lane_rng[WAVE];   // lane-local generators live in LDS (a private copy would be spilled to scratch)
-  __shared__ int flag_lds;
-  const int e = blockIdx.x, lane = threadIdx.x;
+  __shared__ int ok_lds, flag_lds, conflict_lds;
+  __shared__ int glist_n[2];
+  __shared__ uint8_t glist[2][MAXG];  // green agents by action type (0 AccessService, 1 LocalWork)
+  __shared__ Rng rngs[RNG_SLOTS];     // per-agent generators live in LDS (a private copy would be spilled to scratch)
+  __shared__ unsigned long long prof_lds[16];
+  const int e = blockIdx.x, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   if (e >= a.n) return;
   unsigned long long t_begin = a.prof ? clock64() : 0;
-  const uint4* src = reinterpret_cast<const uint4*>(a.st + e);
-  stage_in(lds, src, lane);
+  stage_in_n(lds, reinterpret_cast<const uint4*>(a.st + e), tid);
+  unsigned long long* prof = a.prof ? prof_lds : nullptr;
+  if (prof && tid < 16) prof_lds[tid] = 0;
+  if (tid == 0) { glist_n[0] = 0; glist_n[1] = 0; flag_lds = 0; conflict_lds = 0; ok_lds = 0; }
   __syncthreads();
   EnvState* s = reinterpret_cast<EnvState*>(lds);
-  __shared__ unsigned long long prof_lds[16];   // phase counters accumulate in LDS, flushed once at the end
-  unsigned long long* prof = a.prof ? prof_lds : nullptr;
-  if (prof && lane < 16) prof_lds[lane] = 0;
-  __syncthreads();
-  if (prof && lane == 0) prof[11] += clock64() - t_begin;
+  if (prof && tid == 0) prof[11] += clock64() - t_begin;
   const bool do_reset = a.autoreset && s->done;
   if (do_reset) {
-    if (lane == 0) { Ctx x{s, a.cold + e, &s->rng}; env_reset(x, 0, a.rng_mode, a.steps, true); }
+    if (tid == 0) { Ctx x{s, a.cold + e, &s->rng}; env_reset(x, 0, a.rng_mode, a.steps, true); }
   } else {
-    if (lane == 0) {
+    if (tid == 0) {
       Ctx x{s, a.cold + e, &s->rng, prof};
       CC4_TICK0(x);
       ok_lds = step_phase(x) ? 1 : 0;
-      flag_lds = 0;
     }
     __syncthreads();
     if (ok_lds) {
-      rng_fork(&lane_rng[lane], &s->rng, ST_RESET);
-      Ctx x{s, a.cold + e, &lane_rng[lane], lane == 0 ? prof : nullptr};
       const int ng = s->n_green;
-      // P0 blue submissions (lanes 0..4) || P2 red FSM policies (lanes 8..13) || P1 green policy draws (lanes 16..63)
-      if (lane < NBLUE) step_blue_submit(x, lane, a.actions ? a.actions[e * NBLUE + lane] : -1);
-      else if (lane >= 8 && lane < 8 + NRED) step_red_policy(x, lane - 8);
-      else if (lane >= 16) for (int g = lane - 16; g < ng; g += WAVE - 16) step_green_policy(x, g);
+      // generator slots: red r -> r, green g -> 8 + g, thread 0 (ordered sections) -> 6
+      const int slot = (lane == 0) ? (wave == 0 ? 6 : wave) : 0;
+      Ctx x0{s, a.cold + e, &rngs[6], tid == 0 ? prof : nullptr};               // thread 0
+      const int ragent = lane * PW + wave;                                        // lanes 0..(6/PW-1) of each wave own a red agent
+      const bool is_red = lane < (NRED + PW - 1) / PW && ragent < NRED;
+      Ctx xr{s, a.cold + e, &rngs[is_red ? ragent : 0], nullptr};
+      (void)slot;
+      // ---- P0 blue submissions (wave 0 lanes 1..5) | P2 red FSM policy r on wave r lane 0 | P1 green draws on lanes >= 8
+      if (is_red) rng_fork(&rngs[ragent], &s->rng, ST_RESET);
+      if (tid == 0) rng_fork(&rngs[6], &s->rng, ST_RESET);
+      if (is_red) step_red_policy(xr, ragent);
+      else if (wave == PW - 1 && lane >= 2 && lane < 2 + NBLUE) step_blue_submit(x0, lane - 2, a.actions ? a.actions[e * NBLUE + lane - 2] : -1);
+      else if (lane >= 8) {
+        for (int g = wave * (WAVE - 8) + (lane - 8); g < ng; g += PW * (WAVE - 8)) {
+          rng_fork(&rngs[8 + g], &s->rng, ST_RESET);
+          Ctx xg{s, a.cold + e, &rngs[8 + g], nullptr};
+          step_green_policy(xg, g);
+          int t = s->green_act[g];
+          if (t < 2) glist[t][atomicAdd(&glist_n[t], 1)] = (uint8_t)g;       // compaction by action type
+        }
+      }
       __syncthreads();
-      CC4_TICK(x, 2);
-      // P3 duration queues, one agent per lane; then blue execution in priority/agent order on lane 0
-      if (lane < NBLUE + NRED && step_tick_agent(x, lane)) atomicSub(&s->n_actions, 1);
+      CC4_TICK(x0, 2);
+      // ---- P3 duration queues, one agent per lane of wave 0; then blue execution in priority/agent order on thread 0
+      if (wave == 0 && lane < NBLUE + NRED && step_tick_agent(x0, lane)) atomicSub(&s->n_actions, 1);
       __syncthreads();
-      if (lane == 0) step_blue_exec(x);
+      if (tid == 0) step_blue_exec(x0);
       __syncthreads();
-      // P4 green actions, one per lane
-      int pen = 0;
-      for (int g = lane; g < ng; g += WAVE) pen += step_green_exec(x, g);
-      if (pen) atomicAdd(&s->brm, pen);
+      // ---- P4 green actions: wave 0 = AccessService list, wave 1 = LocalWork list (uniform control flow per wave)
+      if (wave < 2) {
+        int pen = 0;
+        for (int i = lane; i < glist_n[wave]; i += WAVE) {
+          int g = glist[wave][i];
+          Ctx xg{s, a.cold + e, &rngs[8 + g], nullptr};
+          pen += step_green_exec(xg, g);
+        }
+        if (pen) atomicAdd(&s->brm, pen);
+      } else if (wave == 2) {
+        for (int g = lane; g < ng; g += WAVE) if (s->green_act[g] == 2) s->phish_req[g] = 0;   // Sleep: step_green_exec's reset
+      }
       __syncthreads();
-      CC4_TICK(x, 6);
-      // P5 deferred phishing, P6 red actions (ordered) on lane 0
-      if (lane == 0) { step_phishing(x); step_red_exec(x); }
+      CC4_TICK(x0, 6);
+      // ---- P5 deferred phishing (ordered), then P6 red actions: one per wave when they name distinct hosts
+      if (tid == 0) { step_phishing(x0); CC4_TICK(x0, 1); conflict_lds = red_targets_conflict(s) ? 1 : 0; if (prof && conflict_lds) prof[4] += 1000000; }
       __syncthreads();
-      // reassignment: foreign-session scan on 6 lanes, the (rare) moves on lane 0
-      if (lane < NRED && red_has_foreign_session(s, lane)) atomicOr(&flag_lds, 1);
+      if (conflict_lds) { if (tid == 0) for (int r = 0; r < NRED; ++r) step_red_exec_agent(x0, r); }
+      else if (is_red) step_red_exec_agent(xr, ragent);
       __syncthreads();
-      if (lane == 0) step_reassign(x, flag_lds != 0);
+      if (tid == 0) { step_red_merge(x0); CC4_TICK(x0, 7); }
+      // ---- reassignment: foreign-session scan per agent, the (rare) moves on thread 0
+      if (is_red && red_has_foreign_session(s, ragent)) atomicOr(&flag_lds, 1);
       __syncthreads();
-      // P7 end-turn Monitor: per-host roll-over on all lanes, sus-pid hand-over on lane 0 (disjoint data)
-      for (int h = lane; h < MAXH; h += WAVE) step_monitor_host(x, h);
-      if (lane == 0) step_monitor_pend(x);
+      if (tid == 0) step_reassign(x0, flag_lds != 0);
       __syncthreads();
-      CC4_TICK(x, 9);
-      // P8 end-turn RedSessionCheck, one red agent per lane
-      if (lane < NRED) step_rsc(x, lane);
+      // ---- P7 end-turn Monitor: per-host roll-over on all threads, sus-pid hand-over on thread 0 (disjoint data)
+      for (int h = tid; h < MAXH; h += PT) step_monitor_host(x0, h);
+      if (tid == 0) step_monitor_pend(x0);
       __syncthreads();
-      CC4_TICK(x, 10);
-      if (lane == 0) step_end(x, a.msgs ? a.msgs + e * NBLUE * MSG_LEN : nullptr);
+      CC4_TICK(x0, 9);
+      // ---- P8 end-turn RedSessionCheck, one red agent per wave
+      if (is_red) step_rsc(xr, ragent);
+      __syncthreads();
+      CC4_TICK(x0, 10);
+      if (tid == 0) step_end(x0, a.msgs ? a.msgs + e * NBLUE * MSG_LEN : nullptr);
     }
   }
   __syncthreads();
-  if (lane == 0) { a.reward[e] = s->reward; a.done[e] = s->done; a.err[e] = s->err; }
+  if (tid == 0) { a.reward[e] = s->reward; a.done[e] = s->done; a.err[e] = s->err; }
   unsigned long long t_obs = a.prof ? clock64() : 0;
-  if (lane < OBS_PARTS) env_flat_obs_part<uint8_t>(s, obs_lds, lane);
+  if (lane < (OBS_PARTS + PW - 1) / PW) { int p = lane * PW + wave; if (p < OBS_PARTS) env_flat_obs_part<uint8_t>(s, obs_lds, p); }   // 12 parts over the waves
   __syncthreads();
   unsigned long long t_out = a.prof ? clock64() : 0;
-  if (prof && lane == 0) prof[12] += t_out - t_obs;
+  if (prof && tid == 0) prof[12] += t_out - t_obs;
   uint4* dst = reinterpret_cast<uint4*>(a.st + e);
-  stage_out(dst, lds, lane);
+  for (int i = tid; i < ROW_VEC; i += PT) dst[i] = lds[i];
   int32_t* o = a.obs + (size_t)e * OBS_TOTAL;
-  for (int i = lane; i < OBS_TOTAL; i += WAVE) o[i] = obs_lds[i];
-  if (prof && lane == 0) { prof[13] += clock64() - t_out; prof[14] += clock64() - t_begin; }
-  if (prof) { __syncthreads(); if (lane < 15) a.prof[16 * (size_t)e + lane] += prof_lds[lane]; }
+  for (int i = tid; i < OBS_TOTAL; i += PT) o[i] = obs_lds[i];
+  if (prof && tid == 0) { prof[13] += clock64() - t_out; prof[14] += clock64() - t_begin; }
+  if (prof) { __syncthreads(); if (tid < 15) a.prof[16 * (size_t)e + tid] += prof_lds[tid]; }
 }
 
 struct ResetArgs {
@@ -297,7 +349,7 @@ static thread_local std::string g_create_err;
 static int launch_step(cc4_handle* h, const int32_t* d_actions, const uint8_t* d_msgs) {
   StepArgs a{h->d_state, h->d_cold, d_actions, d_msgs, h->d_obs, h->d_reward, h->d_done, h->d_err,
              h->cfg.num_envs, h->cfg.autoreset, h->cfg.steps, h->cfg.rng_mode, h->d_prof};
-  if (h->cfg.rng_mode == 1) hipLaunchKernelGGL(k_step_philox, dim3(h->cfg.num_envs), dim3(WAVE), sizeof(EnvState), h->stream, a);
+  if (h->cfg.rng_mode == 1) hipLaunchKernelGGL(k_step_philox, dim3(h->cfg.num_envs), dim3(PT), sizeof(EnvState), h->stream, a);
   else hipLaunchKernelGGL(k_step, dim3(h->cfg.num_envs), dim3(WAVE), sizeof(EnvState), h->stream, a);
   HIPCHK(h, hipGetLastError());
   return 0;

@@ -27,7 +27,7 @@ enum : int {
   MAX_SUS = 192,        // sus pid entries per blue agent (VelociraptorServer.sus_pids)
   MAX_OBS = 112,        // red observation entries per agent per step
   MAX_PEND = 24,        // process_creation events carrying a pid, per step
-  EPH_WORDS = 340,      // 10880-bit bitmap >= 60000-49152 ephemeral ports (Host.py:183)
+  EPH_WORDS = 340,      // 10880-bit bitmap >= 60000-49152 ephemeral ports (Host.py:183); 1360 B = 85 x 16 B
   OBS_SHORT = 92, OBS_LONG = 210, OBS_TOTAL = 4 * 92 + 210,   // 578
   ACT_SHORT = 82, ACT_LONG = 242, MASK_TOTAL = 4 * 82 + 242,  // 570
   MSG_LEN = 8,
@@ -105,6 +105,8 @@ struct alignas(8) RedAgent {
   ObsEnt obs[MAX_OBS];
   uint32_t obs_has[2][5];            // which (key type, host) pairs are already in obs[] this step
   uint32_t sess_hosts[5];            // hosts listed by the last full RedSessionCheck observation
+  uint32_t sess_seen[5];             // work bitmap of fsm_observe
+  uint32_t live_hosts[5];            // hosts currently holding >= 1 session of this agent (kept exact by rs_add / rs_remove_at)
   Act queue;                         // actions_in_progress[agent]
   Act chosen;                        // action produced by the policy this step (scratch)
   uint16_t as_subnet;                // ActionSpace.subnet known bits
@@ -144,6 +146,7 @@ struct alignas(16) EnvState {
   uint16_t blue_pid[MAXH];           // pid of the blue session process on host (0 = none)
   uint16_t green_pid[MAXH];
   uint32_t pend[MAX_PEND];           // (host<<16)|pid process_creation events not yet seen by Monitor
+  uint32_t pend_r[NRED];             // this step's pid-carrying event of red agent r (0 = none); merged into pend[] in agent order
   uint8_t npend, pad1[3];
   uint32_t exists[5];                // host h is part of this episode's topology
   uint32_t pad2[3];
@@ -160,12 +163,14 @@ struct alignas(16) EnvState {
   int32_t n_actions;                 // actions surviving filter_actions (length of the shuffled index list)
   uint8_t phish_req[MAXG];           // green g's LocalWork asked for a PhishingEmail this step
   int32_t n_restore;                 // Restore actions submitted this step (each costs -1)
+  uint32_t scratch[128];             // work area of the ordered (lane 0) sections: small temporaries that would otherwise
+                                     // be dynamically indexed private arrays (= scratch memory on the device)
   int32_t any_phish;                 // some phish_req[] is set
 };
 
 struct alignas(16) EnvCold {
   HostStatic hs[MAXH];               // backup images (Host.create_backup): read by Restore and reset only
-  uint8_t hs_pad[8];
+  uint8_t hs_pad[8];                 // keeps eph[] 16-byte aligned (137 * 56 + 8 = 7680)
   uint32_t eph[MAXH][EPH_WORDS];     // Host.ephemeral_ports as a bitmap (port-49152)
   uint8_t kports[MAX_KB][MAXH + 7];  // RedAbstractSession.ports[ip]: PB_* bits | PB_HAS
 };
