@@ -188,7 +188,8 @@ CC4_HD int rs_add(Ctx x, int r, int host, int pid, int flags) {
   q.kb = (flags & RS_ABSTRACT) ? (uint8_t)kb_alloc(x) : (uint8_t)0xFF;
   a.sess[a.nsess++] = q;
   a.rsc_dirty = 1;
-  bit_set(a.live_hosts, host);
+  if (!bit_get(a.live_hosts, host)) { bit_set(a.live_hosts, host); a.nlive++; }
+  bit_set(x.s->red_hosts, host);
   return a.nsess - 1;
 }
 CC4_HD void rs_remove_at(Ctx x, int r, int idx, bool free_kb) {
@@ -200,7 +201,12 @@ CC4_HD void rs_remove_at(Ctx x, int r, int idx, bool free_kb) {
   a.rsc_dirty = 1;
   bool still = false;
   for (int i = 0; i < a.nsess; ++i) if (a.sess[i].host == gone) { still = true; break; }
-  if (!still) bit_clr(a.live_hosts, gone);
+  if (!still) {
+    bit_clr(a.live_hosts, gone); a.nlive--;
+    bool other = false;
+    for (int q = 0; q < NRED; ++q) if (bit_get(x.s->red[q].live_hosts, gone)) { other = true; break; }
+    if (!other) bit_clr(x.s->red_hosts, gone);
+  }
 }
 CC4_HD bool red_has_session_on(const RedAgent& a, int h) { return bit_get(a.live_hosts, h); }
 // ActionSpace.update: server_session[session_id] = True (Shared/ActionSpace.py:205-211)
@@ -535,7 +541,7 @@ CC4_HD void blue_monitor(Ctx x, int b) {
   for (int i = 0; i < s->npend; ++i) {
     int h = (int)(s->pend[i] >> 16);
     if (blue_of_subnet(h_subnet(h)) == b) {
-      if (A.nsus >= MAX_SUS) set_err(x, E_SUS_OVERFLOW); else A.sus[A.nsus++] = s->pend[i];
+      if (A.nsus >= MAX_SUS) set_err(x, E_SUS_OVERFLOW); else { A.sus[A.nsus++] = s->pend[i]; bit_set(A.sus_hosts, h); }
     } else s->pend[n++] = s->pend[i];
   }
   s->npend = (uint8_t)n;
@@ -571,6 +577,7 @@ CC4_HD void stop_process(Ctx x, int h, int pid) {
 // Remove.execute (AbstractActions/Remove.py:42-71)
 CC4_HD void blue_remove(Ctx x, int b, int h) {
   BlueAgent& A = x.s->blue[b];
+  if (!bit_get(A.sus_hosts, h)) return;   // parent_session.sus_pids has no entry for this hostname
   for (int i = 0; i < A.nsus; ++i)
     if ((int)(A.sus[i] >> 16) == h) stop_process(x, h, (int)(A.sus[i] & 0xFFFF));
 }
@@ -579,6 +586,7 @@ CC4_HD void blue_restore(Ctx x, int h) {
   EnvState* s = x.s;
   for (int r = 0; r < NRED; ++r) {
     RedAgent& a = s->red[r];
+    if (!bit_get(a.live_hosts, h)) continue;
     int orig = -1;
     for (int i = 0; i < a.nsess;) {
       if (a.sess[i].host != h) { ++i; continue; }
@@ -590,7 +598,8 @@ CC4_HD void blue_restore(Ctx x, int h) {
       RSess keep = a.sess[orig];
       rs_remove_at(x, r, orig, false);
       a.sess[a.nsess++] = keep;
-      bit_set(a.live_hosts, keep.host);
+      if (!bit_get(a.live_hosts, keep.host)) { bit_set(a.live_hosts, keep.host); a.nlive++; }
+      bit_set(s->red_hosts, keep.host);
       a.rsc_dirty = 1;
     }
   }
@@ -600,9 +609,11 @@ CC4_HD void blue_restore(Ctx x, int h) {
 CC4_HD void blue_decoy(Ctx x, int h) {
   EnvState* s = x.s;
   uint32_t cand = 8;  // bit i <=> K_DEC_APACHE + i is compatible; vsftpd checks port 21, which nothing uses (DecoyVsftpd.py:17-20)
-  if (!host_uses_port(x, h, PB_80)) cand |= 1;
-  if (!host_uses_port(x, h, PB_443)) cand |= 2;
-  if (!host_uses_port(x, h, PB_25)) cand |= 4;
+  int used = 0;
+  for (int i = 0; i < s->hd[h].nproc; ++i) used |= kind_port(s->hd[h].procs[i].kind);   // Host.is_using_port per factory
+  if (!(used & PB_80)) cand |= 1;
+  if (!(used & PB_443)) cand |= 2;
+  if (!(used & PB_25)) cand |= 4;
   int kind = K_DEC_APACHE + nth_bit(cand, (int)rng_below(x.r, (uint32_t)popc32(cand)));
   int pid = create_pid(x, h);
   if (!add_proc(x, h, pid, kind, 0)) return;
@@ -630,34 +641,35 @@ CC4_HD void blue_execute(Ctx x, int b, const Act& a) {
 // PhishingEmail._create_new_session (ConcreteActions/PhishingEmail.py:42-113)
 CC4_HD void phishing(Ctx x, int gh) {
   EnvState* s = x.s;
-  // RedAgent.live_hosts[r] = hosts where agent r holds a session (host.sessions[agent] != []), kept exact incrementally
-  uint32_t any[5];
-  for (int w = 0; w < 5; ++w) { uint32_t m = 0; for (int r = 0; r < NRED; ++r) m |= s->red[r].live_hosts[w]; any[w] = m; }
-  const int gw = gh >> 5;
-  if ((gw == 0 ? any[0] : gw == 1 ? any[1] : gw == 2 ? any[2] : gw == 3 ? any[3] : any[4]) >> (gh & 31) & 1u) return;
-  // a red agent already has a session on the green host (PhishingEmail.py:57-59)
+  // EnvState.red_hosts = hosts where some red agent holds a session; RedAgent.live_hosts the same per agent (both exact)
+  if (bit_get(s->red_hosts, gh)) return;  // a red agent already has a session on the green host (PhishingEmail.py:57-59)
   const int gsub = h_subnet(gh);
   const int lo = gsub * SLOTS, hi = lo + SLOTS - 1;   // host ids of the green host's subnet
   // hosts of the same subnet overwrite red_agent_src in host order -> the LAST such host with red sessions decides, and on
   // it the FIRST red agent (`break` leaves only the inner loop, PhishingEmail.py:63-69)
   int src = -1;
-  for (int h = hi; h >= lo && src < 0; --h) {
-    const int w = h >> 5;
-    uint32_t aw = w == 0 ? any[0] : w == 1 ? any[1] : w == 2 ? any[2] : w == 3 ? any[3] : any[4];
-    if (!((aw >> (h & 31)) & 1u)) continue;
-    for (int r = 0; r < NRED; ++r) if (bit_get(s->red[r].live_hosts, h)) { src = r; break; }
+  {
+    // the 17 ids lo..hi straddle at most two bitmap words
+    int wl = lo >> 5, wh = hi >> 5;
+    uint32_t mh = s->red_hosts[wh] & (0xFFFFFFFFu >> (31 - (hi & 31))) & (wl == wh ? (0xFFFFFFFFu << (lo & 31)) : 0xFFFFFFFFu);
+    int best = -1;
+    if (mh) best = wh * 32 + (31 - __builtin_clz(mh));
+    else if (wl != wh) { uint32_t ml = s->red_hosts[wl] & (0xFFFFFFFFu << (lo & 31)); if (ml) best = wl * 32 + (31 - __builtin_clz(ml)); }
+    if (best >= 0) for (int r = 0; r < NRED; ++r) if (bit_get(s->red[r].live_hosts, best)) { src = r; break; }
   }
   if (src < 0) {
-    // red_agents = [(agent, host)] over hosts outside the subnet, host-major then agent order; choice(replace=False)
+    // red_agents = [(agent, host)] over hosts outside the subnet (there is no red session inside it here), host-major then
+    // agent order; choice(red_agents, replace=False) is one bounded draw
     int nc = 0;
-    for (int w = 0; w < 5; ++w) for (int r = 0; r < NRED; ++r) nc += popc32(s->red[r].live_hosts[w]);   // no red session inside the subnet here
+    for (int r = 0; r < NRED; ++r) nc += s->red[r].nlive;
     if (nc == 0) return;
     int c = (int)rng_below(x.r, (uint32_t)nc);
     for (int w = 0; w < 5 && src < 0; ++w) {
+      uint32_t m = s->red_hosts[w];
+      if (!m) continue;
       int inw = 0;
       for (int r = 0; r < NRED; ++r) inw += popc32(s->red[r].live_hosts[w]);
       if (c >= inw) { c -= inw; continue; }
-      uint32_t m = w == 0 ? any[0] : w == 1 ? any[1] : w == 2 ? any[2] : w == 3 ? any[3] : any[4];
       while (m && src < 0) {
         int b = ctz32(m); m &= m - 1;
         for (int r = 0; r < NRED; ++r)
@@ -927,7 +939,8 @@ CC4_HD void red_session_check(Ctx x, int r) {
     rs_remove_at(x, r, c, false);
     q.id = 0;
     A.sess[A.nsess++] = q;
-    bit_set(A.live_hosts, q.host);
+    if (!bit_get(A.live_hosts, q.host)) { bit_set(A.live_hosts, q.host); A.nlive++; }
+    bit_set(s->red_hosts, q.host);
   }
   // The observation lists every session (host, Sessions/Interface/System info).  If the session table has not changed
   // since the last full listing, every host in it is already in the agent's ActionSpace and FSM tables, so the only
@@ -1310,7 +1323,7 @@ CC4_HD void step_monitor_pend(Ctx x) {  // session.add_sus_pids for the pid-carr
     int b = blue_of_subnet(h_subnet((int)(s->pend[i] >> 16)));
     if (b < 0) continue;
     BlueAgent& A = s->blue[b];
-    if (A.nsus >= MAX_SUS) set_err(x, E_SUS_OVERFLOW); else A.sus[A.nsus++] = s->pend[i];
+    if (A.nsus >= MAX_SUS) set_err(x, E_SUS_OVERFLOW); else { A.sus[A.nsus++] = s->pend[i]; bit_set(A.sus_hosts, (int)(s->pend[i] >> 16)); }
   }
   s->npend = 0;
 }

@@ -112,6 +112,7 @@ struct alignas(8) RedAgent {
   uint16_t as_subnet;                // ActionSpace.subnet known bits
   uint16_t fsm_step;
   uint8_t nsess, nknown, fsm_n, nobs;
+  uint8_t nlive, pad_n[3];           // popcount(live_hosts)
   uint8_t active;                    // AgentInterface.active
   uint8_t obs_success;               // success of observations[0]
   uint8_t obs_act_type, obs_act_host, obs_act_arg;   // 'action' of observations[0] (RA_NONE if absent / not FSM-relevant)
@@ -126,6 +127,8 @@ struct alignas(8) RedAgent {
 
 struct alignas(8) BlueAgent {
   uint32_t sus[MAX_SUS];             // (host << 16) | pid, chronological
+  uint32_t sus_hosts[5];             // hosts that have at least one entry in sus[] (entries are never removed)
+  uint32_t pad2;
   Act queue;
   uint16_t nsus;
   uint8_t parent_host, pad;
@@ -155,6 +158,8 @@ struct alignas(16) EnvState {
   RedAgent red[NRED];
   uint8_t msg[NBLUE][MSG_LEN];       // messages submitted with the last step
   uint32_t kb_used[MAX_KB / 32];
+  uint32_t red_hosts[5];             // hosts holding a session of ANY red agent (OR of RedAgent.live_hosts, kept incrementally)
+  uint32_t pad3[3];
   // per-step scratch shared by the phases of a step (the lane-parallel kernel hands work between lanes through it)
   Act bexec[NBLUE];                  // self.action[blue_b][0] of this step
   Act rexec[NRED];

@@ -45,6 +45,7 @@ def init_rccl(vec_env, rank, world):
     """Create the RCCL communicator inside libcc4 for this rank's handle (unique id travels over the control plane)."""
     import torch
     import torch.distributed as dist
+    os.environ.setdefault('NCCL_SOCKET_IFNAME', 'lo')   # single-node job: bootstrap over loopback, no NIC probing
     ident = torch.zeros(128, dtype=torch.uint8)
     if rank == 0:
         buf = (ctypes.c_uint8 * 128)()

@@ -124,7 +124,8 @@ def test_full_size_properties(n):
 
 def test_rccl_allgather_world_size_one():
     """The native RCCL exchange step (cc4_comm_init / cc4_allgather_obs) on a 1-rank communicator: gathered == local."""
-    import ctypes
+    import ctypes, os
+    os.environ.setdefault('NCCL_SOCKET_IFNAME', 'lo')
     n = 256
     dev = _dev(n, steps=50); dev.reset(seeds=3)
     ident = (ctypes.c_uint8 * 128)()
