@@ -47,6 +47,21 @@ CC4_HD int h_make(int s, int slot) { return s * SLOTS + slot; }
 CC4_HD bool bit_get(const uint32_t* b, int i) { return (b[i >> 5] >> (i & 31)) & 1u; }
 CC4_HD void bit_set(uint32_t* b, int i) { b[i >> 5] |= 1u << (i & 31); }
 CC4_HD void bit_clr(uint32_t* b, int i) { b[i >> 5] &= ~(1u << (i & 31)); }
+// for bitmaps shared by agents that may be resolved on different waves (EnvState.red_hosts)
+CC4_HD void bit_set_shared(uint32_t* b, int i) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  __hip_atomic_fetch_or(&b[i >> 5], 1u << (i & 31), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+#else
+  b[i >> 5] |= 1u << (i & 31);
+#endif
+}
+CC4_HD void bit_clr_shared(uint32_t* b, int i) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  __hip_atomic_fetch_and(&b[i >> 5], ~(1u << (i & 31)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+#else
+  b[i >> 5] &= ~(1u << (i & 31));
+#endif
+}
 CC4_HD int popc32(uint32_t v) {
 #if defined(__HIP_DEVICE_COMPILE__)
   return __popc(v);
@@ -189,7 +204,7 @@ CC4_HD int rs_add(Ctx x, int r, int host, int pid, int flags) {
   a.sess[a.nsess++] = q;
   a.rsc_dirty = 1;
   if (!bit_get(a.live_hosts, host)) { bit_set(a.live_hosts, host); a.nlive++; }
-  bit_set(x.s->red_hosts, host);
+  bit_set_shared(x.s->red_hosts, host);
   return a.nsess - 1;
 }
 CC4_HD void rs_remove_at(Ctx x, int r, int idx, bool free_kb) {
@@ -205,8 +220,17 @@ CC4_HD void rs_remove_at(Ctx x, int r, int idx, bool free_kb) {
     bit_clr(a.live_hosts, gone); a.nlive--;
     bool other = false;
     for (int q = 0; q < NRED; ++q) if (bit_get(x.s->red[q].live_hosts, gone)) { other = true; break; }
-    if (!other) bit_clr(x.s->red_hosts, gone);
+    if (!other) bit_clr_shared(x.s->red_hosts, gone);
   }
+}
+// dict pop + re-insert of the same session object (RedSessionCheck promotion, RestoreFromBackup of an original session):
+// the record moves to the end of the agent's order; which hosts hold sessions does not change
+CC4_HD void rs_move_to_end(RedAgent& a, int idx, int new_id) {
+  RSess q = a.sess[idx];
+  for (int i = idx; i + 1 < a.nsess; ++i) a.sess[i] = a.sess[i + 1];
+  if (new_id >= 0) q.id = (uint16_t)new_id;
+  a.sess[a.nsess - 1] = q;
+  a.rsc_dirty = 1;
 }
 CC4_HD bool red_has_session_on(const RedAgent& a, int h) { return bit_get(a.live_hosts, h); }
 // ActionSpace.update: server_session[session_id] = True (Shared/ActionSpace.py:205-211)
@@ -333,7 +357,7 @@ CC4_HD void host_restore(Ctx x, int h) {  // Host.restore (Host.py:373-429)
 }
 
 // continue_stream = true restates CybORG.reset(seed=None) (env.py:218-243): the same Generator keeps going.
-CC4_HD void env_reset(Ctx x, uint64_t seed, int rng_mode, int steps, bool continue_stream) {
+CC4_HD void env_reset(Ctx x, uint64_t seed, int rng_mode, int steps, bool continue_stream, int policy = 0) {
   EnvState* s = x.s;
   Rng keep = s->rng;
   {  // zero everything (POD)
@@ -342,6 +366,7 @@ CC4_HD void env_reset(Ctx x, uint64_t seed, int rng_mode, int steps, bool contin
   }
   if (continue_stream) s->rng = keep; else rng_seed(&s->rng, seed, (uint32_t)rng_mode);  // NOTE: x.r must be &s->rng here
   s->rng_mode = (uint8_t)rng_mode;
+  s->policy = (uint8_t)policy;
   rng_begin_episode(x.r);  // philox: the reset stream uses its own (step, episode) counter words
   s->steps = steps;
   {  // _generate_mission_phases (ESG.py:854-860)
@@ -594,14 +619,7 @@ CC4_HD void blue_restore(Ctx x, int h) {
       rs_remove_at(x, r, i, true);
       if (orig > i) orig--;
     }
-    if (orig >= 0) {  // original session: popped and re-added => moves to the end of the agent's dict
-      RSess keep = a.sess[orig];
-      rs_remove_at(x, r, orig, false);
-      a.sess[a.nsess++] = keep;
-      if (!bit_get(a.live_hosts, keep.host)) { bit_set(a.live_hosts, keep.host); a.nlive++; }
-      bit_set(s->red_hosts, keep.host);
-      a.rsc_dirty = 1;
-    }
+    if (orig >= 0) rs_move_to_end(a, orig, -1);  // original session: popped and re-added => moves to the end of the agent's dict
   }
   host_restore(x, h);
 }
@@ -935,12 +953,7 @@ CC4_HD void red_session_check(Ctx x, int r) {
   if (A.nsess == 0) return;
   if (rs_find_id(A, 0) < 0) {
     int c = (int)rng_below(x.r, (uint32_t)A.nsess);
-    RSess q = A.sess[c];
-    rs_remove_at(x, r, c, false);
-    q.id = 0;
-    A.sess[A.nsess++] = q;
-    if (!bit_get(A.live_hosts, q.host)) { bit_set(A.live_hosts, q.host); A.nlive++; }
-    bit_set(s->red_hosts, q.host);
+    rs_move_to_end(A, c, 0);   // active_sessions.pop(old_id); ident = 0; re-inserted last (RedSessionCheck.py:36-45)
   }
   // The observation lists every session (host, Sessions/Interface/System info).  If the session table has not changed
   // since the last full listing, every host in it is already in the agent's ActionSpace and FSM tables, so the only
@@ -1047,6 +1060,59 @@ CC4_HD void fsm_observe(Ctx x, int r) {
     if (!bit_get(sess_seen, h)) A.fsm_state[h] = FS_KD;
   }
 }
+// DiscoveryFSRed._choose_host (FiniteStateRedAgent.py:252-293 with FSMRedVariants.py:95-110): host-state priorities
+// {K,KD,S,SD: 20, U,UD: 10, R,RD: 0} and prioritise_servers.  The float arithmetic restates the Python expressions
+// operation by operation (probs = (p/100) * (1/(sum/100)); numpy choice(p) = cumsum, /= last, searchsorted right).
+CC4_HD int fsm_choose_host_discovery(Ctx x, int r) {
+  RedAgent& A = x.s->red[r];
+  // available_states in order of first appearance among the known hosts, packed as nibbles
+  uint32_t order = 0; int nst = 0; uint32_t seen = 0;
+  for (int i = 0; i < A.fsm_n && nst < 8; ++i) {
+    int st = A.fsm_state[A.fsm_order[i]];
+    if (!((seen >> st) & 1u)) { seen |= 1u << st; order |= (uint32_t)st << (4 * nst); nst++; }
+  }
+  int sum = 0;
+  for (int k = 0; k < nst; ++k) { int st = (order >> (4 * k)) & 0xF; sum += st <= FS_SD ? 20 : (st <= FS_UD ? 10 : 0); }
+  int chosen_state;
+  if (sum > 0) {
+    double mult = 1.0 / ((double)sum / 100.0);
+    double last = 0.0;
+    for (int k = 0; k < nst; ++k) { int st = (order >> (4 * k)) & 0xF; int p = st <= FS_SD ? 20 : (st <= FS_UD ? 10 : 0); last = last + ((double)p / 100.0) * mult; }
+    double u = rng_random(x.r);
+    double run = 0.0; int idx = 0;
+    for (int k = 0; k < nst; ++k) {
+      int st = (order >> (4 * k)) & 0xF; int p = st <= FS_SD ? 20 : (st <= FS_UD ? 10 : 0);
+      run = run + ((double)p / 100.0) * mult;
+      if (run / last <= u) idx++;
+    }
+    if (idx >= nst) idx = nst - 1;
+    chosen_state = (order >> (4 * idx)) & 0xF;
+  } else {
+    chosen_state = (order >> (4 * (int)rng_below(x.r, (uint32_t)nst))) & 0xF;
+  }
+  int n_all = 0, n_srv = 0;
+  for (int i = 0; i < A.fsm_n; ++i) {
+    int h = A.fsm_order[i];
+    if (A.fsm_state[h] != chosen_state) continue;
+    n_all++;
+    if (h_is_server(h) && bit_get(A.fsm_hn, h)) n_srv++;
+  }
+  int want_srv = -1;  // -1: any host of the state, 1: servers only, 0: non-servers only
+  if (n_all > 1 && n_srv > 0) {
+    double i01 = rng_random(x.r);
+    want_srv = (i01 <= 0.75 || n_srv == n_all) ? 1 : 0;
+  }
+  int cnt = want_srv < 0 ? n_all : (want_srv ? n_srv : n_all - n_srv);
+  int c = (int)rng_below(x.r, (uint32_t)cnt);
+  for (int i = 0; i < A.fsm_n; ++i) {
+    int h = A.fsm_order[i];
+    if (A.fsm_state[h] != chosen_state) continue;
+    bool srv = h_is_server(h) && bit_get(A.fsm_hn, h);
+    if (want_srv >= 0 && (int)srv != want_srv) continue;
+    if (c-- == 0) return h;
+  }
+  return A.fsm_order[0];
+}
 // get_action (:58-122) incl. _choose_host (:252-293) and _choose_host_and_action (:296-336)
 CC4_HD Act fsm_get_action(Ctx x, int r) {
   EnvState* s = x.s;
@@ -1056,12 +1122,15 @@ CC4_HD Act fsm_get_action(Ctx x, int r) {
   if (A.obs_success == T_IN_PROGRESS) { A.fsm_step++; return out; }
   int n = A.fsm_n;  // fsm_order holds exactly the non-'F' hosts, in host_states insertion order
   if (n == 0) { set_err(x, E_FSM_NO_HOST); A.fsm_step++; return out; }
-  int host = A.fsm_order[rng_below(x.r, (uint32_t)n)];
+  const bool discovery = (s->policy & 3) == RP_DISCOVERY;
+  int host;
+  if (!discovery) host = A.fsm_order[rng_below(x.r, (uint32_t)n)];
+  else host = fsm_choose_host_discovery(x, r);
   // options in red_actions list order (ESG.py:764-768) with state_transitions_probability (:540-549).  All probabilities
   // are multiples of 1/4, so cdf.searchsorted(u, 'right') == #{i : 4*cdf[i] <= floor(4u)}.  Packed per state:
   // low 16 bits = option nibbles, high 16 bits = 4*cdf nibbles (unused slots = 15)
   uint32_t pk;
-  switch (A.fsm_state[host]) {
+  if (!discovery) switch (A.fsm_state[host]) {
     case FS_K:  pk = 0xF432u << 16 | (RA_DRS | RA_AGGR << 4 | RA_STEALTH << 8); break;                          // .5 .25 .25
     case FS_KD: pk = 0xFF42u << 16 | (RA_AGGR | RA_STEALTH << 4); break;                                         // .5 .5
     case FS_S:  pk = 0xF431u << 16 | (RA_DRS | RA_EXPLOIT << 4 | RA_DECEPTION << 8); break;                     // .25 .5 .25
@@ -1069,6 +1138,15 @@ CC4_HD Act fsm_get_action(Ctx x, int r) {
     case FS_U:  pk = 0xF442u << 16 | (RA_DRS | RA_PRIVESC << 4 | RA_WITHDRAW << 8); break;                      // .5 .5 0
     case FS_UD: pk = 0xFF44u << 16 | (RA_PRIVESC | RA_WITHDRAW << 4); break;                                     // 1 0
     case FS_R:  pk = 0x4432u << 16 | (RA_DRS | RA_DEGRADE << 4 | RA_IMPACT << 8 | RA_WITHDRAW << 12); break;    // .5 .25 .25 0
+    default:    pk = 0xF442u << 16 | (RA_DEGRADE | RA_IMPACT << 4 | RA_WITHDRAW << 8); break;                   // RD: .5 .5 0
+  } else switch (A.fsm_state[host]) {  // DiscoveryFSRed.state_transitions_probability (FSMRedVariants.py:111-122)
+    case FS_K:  pk = 0xF441u << 16 | (RA_DRS | RA_AGGR << 4 | RA_STEALTH << 8); break;                          // .25 .75 0
+    case FS_KD: pk = 0xFF44u << 16 | (RA_AGGR | RA_STEALTH << 4); break;                                         // 1 0
+    case FS_S:  pk = 0xF441u << 16 | (RA_DRS | RA_EXPLOIT << 4 | RA_DECEPTION << 8); break;                     // .25 .75 0
+    case FS_SD: pk = 0xFF44u << 16 | (RA_EXPLOIT | RA_DECEPTION << 4); break;                                    // 1 0
+    case FS_U:  pk = 0xF440u << 16 | (RA_DRS | RA_PRIVESC << 4 | RA_WITHDRAW << 8); break;                      // 0 1 0
+    case FS_UD: pk = 0xFF44u << 16 | (RA_PRIVESC | RA_WITHDRAW << 4); break;                                     // 1 0
+    case FS_R:  pk = 0x4444u << 16 | (RA_DRS | RA_DEGRADE << 4 | RA_IMPACT << 8 | RA_WITHDRAW << 12); break;    // 1 0 0 0
     default:    pk = 0xF442u << 16 | (RA_DEGRADE | RA_IMPACT << 4 | RA_WITHDRAW << 8); break;                   // RD: .5 .5 0
   }
   double u = rng_random(x.r);
@@ -1192,6 +1270,7 @@ CC4_HD bool step_begin(Ctx x, const int32_t* actions) {
   return true;
 }
 CC4_HD void step_green_policy(Ctx x, int g) {
+  if (x.s->policy & GP_SLEEP_BIT) { x.s->green_act[g] = 2; return; }   // green_agent_class=SleepAgent: no draw, Sleep
   rng_set_stream(x.r, ST_GREEN_POL + (uint32_t)g);
   x.s->green_act[g] = (uint8_t)rng_below(x.r, 3);  // choice([GreenAccessService, GreenLocalWork, Sleep])
 }
@@ -1199,7 +1278,7 @@ CC4_HD void step_red_policy(Ctx x, int r) {
   RedAgent& A = x.s->red[r];
   Act a; a.type = RA_SLEEP; a.host = 0; a.arg = 0; a.ticks = 1; a.sid = 0; a.busy = 0;
   rng_set_stream(x.r, ST_RED_POL + (uint32_t)r);
-  if (A.active) { a = fsm_get_action(x, r); red_validate(x, r, a); }   // AgentInterface.get_action (:120-143)
+  if (A.active && (x.s->policy & 3) != RP_SLEEP) { a = fsm_get_action(x, r); red_validate(x, r, a); }   // AgentInterface.get_action (:120-143); SleepAgent -> Sleep
   if (!A.queue.busy) { A.queue = a; A.queue.busy = 1; }
 }
 CC4_HD void step_blue_exec(Ctx x) {

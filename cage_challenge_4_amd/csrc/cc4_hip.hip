@@ -27,7 +27,7 @@ struct StepArgs {
   EnvState* st; EnvCold* cold;
   const int32_t* actions; const uint8_t* msgs;
   int32_t* obs; float* reward; uint8_t* done; uint32_t* err;
-  int n, autoreset, steps, rng_mode;
+  int n, autoreset, steps, rng_mode, policy;
   unsigned long long* prof;   // optional [n][16] cycle counters (CC4_PROFILE builds / cc4_debug_profile)
 };
 
@@ -80,7 +80,7 @@ __global__ __launch_bounds__(WAVE) void k_step(StepArgs a) {
   if (lane == 0) {
     ok_lds = 0;
     if (do_reset) {
-      env_reset(x, 0, a.rng_mode, a.steps, true);   // new episode, same stream (CybORG.reset(seed=None))
+      env_reset(x, 0, a.rng_mode, a.steps, true, a.policy);   // new episode, same stream (CybORG.reset(seed=None))
     } else {
       CC4_TICK0(x);
       if (step_begin(x, a.actions ? a.actions + e * NBLUE : nullptr)) {
@@ -181,7 +181,7 @@ __global__ __launch_bounds__(PT) void k_step_philox(StepArgs a) {
   if (prof && tid == 0) prof[11] += clock64() - t_begin;
   const bool do_reset = a.autoreset && s->done;
   if (do_reset) {
-    if (tid == 0) { Ctx x{s, a.cold + e, &s->rng}; env_reset(x, 0, a.rng_mode, a.steps, true); }
+    if (tid == 0) { Ctx x{s, a.cold + e, &s->rng}; env_reset(x, 0, a.rng_mode, a.steps, true, a.policy); }
   } else {
     if (tid == 0) {
       Ctx x{s, a.cold + e, &s->rng, prof};
@@ -275,7 +275,7 @@ __global__ __launch_bounds__(PT) void k_step_philox(StepArgs a) {
 struct ResetArgs {
   EnvState* st; EnvCold* cold; const uint64_t* seeds; const uint8_t* env_mask;
   int32_t* obs; float* reward; uint8_t* done; uint32_t* err; uint8_t* mask;
-  int n, steps, rng_mode;
+  int n, steps, rng_mode, policy;
 };
 __global__ __launch_bounds__(WAVE) void k_reset(ResetArgs a) {
   __shared__ uint8_t obs_lds[OBS_TOTAL + 2];
@@ -286,7 +286,7 @@ __global__ __launch_bounds__(WAVE) void k_reset(ResetArgs a) {
   EnvState* s = a.st + e;
   if (lane == 0) {
     Ctx x{s, a.cold + e, &s->rng};
-    env_reset(x, a.seeds ? a.seeds[e] : 0, a.rng_mode, a.steps, a.seeds == nullptr);
+    env_reset(x, a.seeds ? a.seeds[e] : 0, a.rng_mode, a.steps, a.seeds == nullptr, a.policy);
     env_flat_obs<uint8_t>(s, obs_lds);
     blue_action_mask(s, mask_lds);
     a.reward[e] = 0.f; a.done[e] = s->done; a.err[e] = s->err;
@@ -348,7 +348,8 @@ static thread_local std::string g_create_err;
 
 static int launch_step(cc4_handle* h, const int32_t* d_actions, const uint8_t* d_msgs) {
   StepArgs a{h->d_state, h->d_cold, d_actions, d_msgs, h->d_obs, h->d_reward, h->d_done, h->d_err,
-             h->cfg.num_envs, h->cfg.autoreset, h->cfg.steps, h->cfg.rng_mode, h->d_prof};
+             h->cfg.num_envs, h->cfg.autoreset, h->cfg.steps, h->cfg.rng_mode,
+             (h->cfg.red_policy & 3) | (h->cfg.green_policy ? GP_SLEEP_BIT : 0), h->d_prof};
   if (h->cfg.rng_mode == 1) hipLaunchKernelGGL(k_step_philox, dim3(h->cfg.num_envs), dim3(PT), sizeof(EnvState), h->stream, a);
   else hipLaunchKernelGGL(k_step, dim3(h->cfg.num_envs), dim3(WAVE), sizeof(EnvState), h->stream, a);
   HIPCHK(h, hipGetLastError());
@@ -365,7 +366,8 @@ size_t cc4_algorithmic_bytes_per_env_step(void) {
 }
 
 int cc4_create(const cc4_config* cfg, cc4_handle** out) {
-  if (!cfg || !out || cfg->num_envs <= 0 || cfg->steps <= 0) { g_create_err = "cc4_create: bad config"; return -2; }
+  if (!cfg || !out || cfg->num_envs <= 0 || cfg->steps <= 0 || cfg->red_policy < 0 || cfg->red_policy > 2 ||
+      cfg->green_policy < 0 || cfg->green_policy > 1) { g_create_err = "cc4_create: bad config"; return -2; }
   int ndev = 0;
   hipError_t e = hipGetDeviceCount(&ndev);
   if (e != hipSuccess || ndev <= 0) {
@@ -423,7 +425,8 @@ int cc4_reset(cc4_handle* h, const uint64_t* seeds, const uint8_t* env_mask) {
   if (seeds) HIPCHK(h, hipMemcpyAsync(h->d_seeds, seeds, n * sizeof(uint64_t), hipMemcpyHostToDevice, h->stream));
   if (env_mask) HIPCHK(h, hipMemcpyAsync(h->d_envmask, env_mask, n, hipMemcpyHostToDevice, h->stream));
   ResetArgs a{h->d_state, h->d_cold, seeds ? h->d_seeds : nullptr, env_mask ? h->d_envmask : nullptr, h->d_obs, h->d_reward,
-              h->d_done, h->d_err, h->d_mask, h->cfg.num_envs, h->cfg.steps, h->cfg.rng_mode};
+              h->d_done, h->d_err, h->d_mask, h->cfg.num_envs, h->cfg.steps, h->cfg.rng_mode,
+              (h->cfg.red_policy & 3) | (h->cfg.green_policy ? GP_SLEEP_BIT : 0)};
   hipLaunchKernelGGL(k_reset, dim3(h->cfg.num_envs), dim3(WAVE), 0, h->stream, a);
   HIPCHK(h, hipGetLastError());
   HIPCHK(h, hipStreamSynchronize(h->stream));

@@ -83,6 +83,8 @@ enum : int { RA_DRS = 0, RA_AGGR = 1, RA_STEALTH = 2, RA_DECEPTION = 3, RA_EXPLO
              RA_DEGRADE = 7, RA_WITHDRAW = 8, RA_SLEEP = 9, RA_INVALID = 10, RA_NONE = 11 };
 // blue action types
 enum : int { BA_SLEEP = 0, BA_MONITOR = 1, BA_ANALYSE = 2, BA_REMOVE = 3, BA_RESTORE = 4, BA_DECOY = 5, BA_BLOCK = 6, BA_ALLOW = 7 };
+// built-in policies selectable through EnterpriseScenarioGenerator(red_agent_class=, green_agent_class=)
+enum : int { RP_FSM = 0, RP_SLEEP = 1, RP_DISCOVERY = 2, GP_SLEEP_BIT = 0x10 };
 // TernaryEnum (Shared/Enums.py:5-25)
 enum : int { T_TRUE = 1, T_UNKNOWN = 2, T_FALSE = 3, T_IN_PROGRESS = 4 };
 
@@ -140,7 +142,8 @@ struct alignas(16) EnvState {
   int32_t phase_len[3];
   uint32_t err;
   float reward;                      // team reward of the last step (BlueRewardMachine + action_cost)
-  uint8_t done, rng_mode, n_green, pad0;
+  uint8_t done, rng_mode, n_green;
+  uint8_t policy;                    // bits 0-1 red policy (RP_*), bit 4 green policy (1 = SleepAgent)
   uint16_t blocks[NSUB];             // blocks[to] bit from
   uint8_t cidr_octet[NSUB];
   uint8_t n_users[NSUB], n_servers[NSUB];

@@ -9,7 +9,9 @@ import numpy as np
 from . import _lib as L
 
 RNG_PCG64 = 0    # numpy Generator(PCG64(SeedSequence(seed))): bit-exact with the reference under the same seed
-RNG_PHILOX = 1   # Philox4x32-10 keyed by seed, counter (draw, step, episode)
+RNG_PHILOX = 1   # Philox4x32-10 keyed by seed, counter (draw, stream, step, episode)
+RED_FSM, RED_SLEEP, RED_DISCOVERY = 0, 1, 2     # red_agent_class: FiniteStateRedAgent / SleepAgent / DiscoveryFSRed
+GREEN_ENTERPRISE, GREEN_SLEEP = 0, 1            # green_agent_class: EnterpriseGreenAgent / SleepAgent
 
 ERR_NAMES = {0: 'PROC_OVERFLOW', 1: 'RSESS_OVERFLOW', 2: 'KNOWN_SID_OVERFLOW', 3: 'KNOWLEDGE_BLOCK_OVERFLOW',
              4: 'SUS_OVERFLOW', 5: 'OBS_OVERFLOW', 6: 'PENDING_EVENT_OVERFLOW', 7: 'STEP_PAST_END',
@@ -17,11 +19,12 @@ ERR_NAMES = {0: 'PROC_OVERFLOW', 1: 'RSESS_OVERFLOW', 2: 'KNOWN_SID_OVERFLOW', 3
 
 
 class CC4VecEnv:
-    def __init__(self, num_envs, steps=500, rng_mode=RNG_PCG64, device_id=0, autoreset=False):
+    def __init__(self, num_envs, steps=500, rng_mode=RNG_PCG64, device_id=0, autoreset=False, red_policy=0, green_policy=0):
         self.lib = L.load()
         self.num_envs = int(num_envs)
         self.steps = int(steps)
-        cfg = L.CC4Config(self.num_envs, self.steps, int(device_id), int(rng_mode), int(bool(autoreset)))
+        cfg = L.CC4Config(self.num_envs, self.steps, int(device_id), int(rng_mode), int(bool(autoreset)),
+                          int(red_policy), int(green_policy), 0)
         h = ctypes.c_void_p()
         rc = self.lib.cc4_create(ctypes.byref(cfg), ctypes.byref(h))
         if rc != 0:

@@ -46,6 +46,10 @@ class FiniteStateRedAgent:
     """CybORG/Agents/SimpleAgents/FiniteStateRedAgent.py:15-550"""
 
 
+class DiscoveryFSRed(FiniteStateRedAgent):
+    """CybORG/Agents/SimpleAgents/FSMRedVariants.py:80-122 (host-state priorities, prioritise_servers, own probability matrix)"""
+
+
 class EnterpriseScenarioGenerator:
     """Configuration holder with the reference's constructor (ESG.py:95-121) and class constants (:87-93)."""
     MIN_USER_HOSTS = 3
@@ -59,10 +63,14 @@ class EnterpriseScenarioGenerator:
     def __init__(self, blue_agent_class=None, red_agent_class=None, green_agent_class=None, steps: int = 100):
         if blue_agent_class not in (None, SleepAgent) and getattr(blue_agent_class, '__name__', '') != 'SleepAgent':
             raise NotImplementedError("blue default policy: only SleepAgent (blue actions are submitted through step())")
-        for cls, want in ((red_agent_class, 'FiniteStateRedAgent'), (green_agent_class, 'EnterpriseGreenAgent')):
-            if cls is None or getattr(cls, '__name__', '') != want:
-                raise NotImplementedError(f"the HIP engine implements {want} for this role (got {cls}); "
-                                          "other built-in policies are SURVEY 8(f) 'next' rows")
+        red = {'FiniteStateRedAgent': 0, 'SleepAgent': 1, 'DiscoveryFSRed': 2}
+        green = {'EnterpriseGreenAgent': 0, 'SleepAgent': 1}
+        rn, gn = getattr(red_agent_class, '__name__', None), getattr(green_agent_class, '__name__', None)
+        if rn not in red or gn not in green:
+            raise NotImplementedError(f"built-in policies of the HIP engine: red {list(red)}, green {list(green)} "
+                                      f"(got red={red_agent_class}, green={green_agent_class}); "
+                                      "other policies are SURVEY 8(f) 'next' rows")
+        self.red_policy, self.green_policy = red[rn], green[gn]
         self.blue_agent_class = blue_agent_class
         self.red_agent_class = red_agent_class
         self.green_agent_class = green_agent_class
@@ -85,7 +93,9 @@ class CybORG:
         if not isinstance(seed, (int, np.integer)):
             raise NotImplementedError("custom Generator objects cannot be injected into the device RNG; pass an int seed")
         # vec_factory: anything with CC4VecEnv's call shape (tests inject the CPU oracle; the default is the HIP engine)
-        self.vec = (vec_factory or CC4VecEnv)(1, steps=scenario_generator.steps, rng_mode=rng_mode, device_id=device_id)
+        self.vec = (vec_factory or CC4VecEnv)(1, steps=scenario_generator.steps, rng_mode=rng_mode, device_id=device_id,
+                                              red_policy=scenario_generator.red_policy,
+                                              green_policy=scenario_generator.green_policy)
         self.vec.reset(seeds=np.array([seed], np.uint64))      # SimulationController.__init__ creates a scenario
         self.agents = [f'blue_agent_{b}' for b in range(5)]
 

@@ -46,10 +46,10 @@ size_t cc4o_cold_bytes() { return sizeof(EnvCold); }
 void* cc4o_state_ptr(void* h, int i) { return &((Oracle*)h)->st[i]; }
 void* cc4o_cold_ptr(void* h, int i) { return &((Oracle*)h)->cold[i]; }
 
-void cc4o_reset(void* h, int i, uint64_t seed, int rng_mode, int steps, int continue_stream) {
+void cc4o_reset(void* h, int i, uint64_t seed, int rng_mode, int steps, int continue_stream, int policy) {
   Oracle* o = (Oracle*)h;
   Ctx x{&o->st[i], &o->cold[i], &o->st[i].rng};
-  env_reset(x, seed, rng_mode, steps, continue_stream != 0);
+  env_reset(x, seed, rng_mode, steps, continue_stream != 0, policy);
 }
 void cc4o_step(void* h, int i, const int32_t* actions, const uint8_t* msgs) {
   Oracle* o = (Oracle*)h;

@@ -7,7 +7,9 @@ import ref_shim  # noqa
 from ref_dump import dump
 from CybORG import CybORG
 from CybORG.Simulator.Scenarios import EnterpriseScenarioGenerator
-from CybORG.Agents import SleepAgent, EnterpriseGreenAgent, FiniteStateRedAgent
+from CybORG.Agents import SleepAgent, EnterpriseGreenAgent, FiniteStateRedAgent, DiscoveryFSRed
+RED = {'fsm': (FiniteStateRedAgent, 0), 'sleep': (SleepAgent, 1), 'discovery': (DiscoveryFSRed, 2)}
+GREEN = {'enterprise': (EnterpriseGreenAgent, 0), 'sleep': (SleepAgent, 1)}
 from CybORG.Agents.Wrappers import BlueFlatWrapper
 
 RED_QT = {'DiscoverRemoteSystems': 0, 'AggressiveServiceDiscovery': 1, 'StealthServiceDiscovery': 2, 'DiscoverDeception': 3,
@@ -25,19 +27,20 @@ def canon_ref(txt):
     return re.sub(r'qt (\w+)', lambda m: 'qt ' + str(RED_QT.get(m.group(1), m.group(1))), txt)
 
 
-def run(seed, steps=500, blue='sleep', init='ctor', verbose=True, max_steps=None):
-    sg = EnterpriseScenarioGenerator(blue_agent_class=SleepAgent, green_agent_class=EnterpriseGreenAgent,
-                                     red_agent_class=FiniteStateRedAgent, steps=steps)
+def run(seed, steps=500, blue='sleep', init='ctor', verbose=True, max_steps=None, red='fsm', green='enterprise'):
+    sg = EnterpriseScenarioGenerator(blue_agent_class=SleepAgent, green_agent_class=GREEN[green][0],
+                                     red_agent_class=RED[red][0], steps=steps)
+    pol = RED[red][1] | (0x10 if GREEN[green][1] else 0)
     env = CybORG(sg, seed=seed)
     w = BlueFlatWrapper(env)
     H = ctypes.c_void_p(lib.cc4o_create(1))
-    lib.cc4o_reset(H, 0, ctypes.c_uint64(seed), 0, steps, 0)
+    lib.cc4o_reset(H, 0, ctypes.c_uint64(seed), 0, steps, 0, pol)
     if init == 'ctor':
         obs, info = w.reset()
-        lib.cc4o_reset(H, 0, ctypes.c_uint64(seed), 0, steps, 1)
+        lib.cc4o_reset(H, 0, ctypes.c_uint64(seed), 0, steps, 1, pol)
     else:
         obs, info = w.reset(seed=seed + 1)
-        lib.cc4o_reset(H, 0, ctypes.c_uint64(seed + 1), 0, steps, 0)
+        lib.cc4o_reset(H, 0, ctypes.c_uint64(seed + 1), 0, steps, 0, pol)
     arng = np.random.default_rng(seed ^ 0xB10E)
     buf = ctypes.create_string_buffer(1 << 20)
 
@@ -108,4 +111,6 @@ if __name__ == '__main__':
     steps = int(sys.argv[2]) if len(sys.argv) > 2 else 500
     blue = sys.argv[3] if len(sys.argv) > 3 else 'sleep'
     init = sys.argv[4] if len(sys.argv) > 4 else 'ctor'
-    run(seed, steps, blue, init)
+    red = sys.argv[5] if len(sys.argv) > 5 else 'fsm'
+    green = sys.argv[6] if len(sys.argv) > 6 else 'enterprise'
+    run(seed, steps, blue, init, red=red, green=green)

@@ -15,7 +15,9 @@ sys.path.insert(0, os.path.dirname(__file__))
 import ref_shim  # noqa
 from CybORG import CybORG
 from CybORG.Simulator.Scenarios import EnterpriseScenarioGenerator
-from CybORG.Agents import SleepAgent, EnterpriseGreenAgent, FiniteStateRedAgent
+from CybORG.Agents import SleepAgent, EnterpriseGreenAgent, FiniteStateRedAgent, DiscoveryFSRed
+RED = {'fsm': (FiniteStateRedAgent, 0), 'sleep': (SleepAgent, 1), 'discovery': (DiscoveryFSRed, 2)}
+GREEN = {'enterprise': (EnterpriseGreenAgent, 0), 'sleep': (SleepAgent, 1)}
 from CybORG.Agents.Wrappers import BlueFlatWrapper
 
 OUT = os.path.join(os.path.dirname(__file__), '..', '..', 'tests', 'golden')
@@ -31,9 +33,9 @@ def flat(obs):
     return np.concatenate([obs[f'blue_agent_{b}'] for b in range(5)]).astype(np.uint8)
 
 
-def record(seed, steps, blue, init, nsteps=None, msgs=False):
-    sg = EnterpriseScenarioGenerator(blue_agent_class=SleepAgent, green_agent_class=EnterpriseGreenAgent,
-                                     red_agent_class=FiniteStateRedAgent, steps=steps)
+def record(seed, steps, blue, init, nsteps=None, msgs=False, red='fsm', green='enterprise'):
+    sg = EnterpriseScenarioGenerator(blue_agent_class=SleepAgent, green_agent_class=GREEN[green][0],
+                                     red_agent_class=RED[red][0], steps=steps)
     env = CybORG(sg, seed=seed)
     w = BlueFlatWrapper(env)
     if init == 'ctor':      # CybORG(seed=s); wrapper.reset()  -> second scenario drawn from the running stream
@@ -68,17 +70,24 @@ def record(seed, steps, blue, init, nsteps=None, msgs=False):
         assert len(set(rew.values())) == 1
         D[t] = term['blue_agent_0']
         G[t + 1] = rng_words(env)
-    name = f"traj_seed{seed}_{blue}_{init}_{steps}{'_msg' if msgs else ''}.npz"
+    pol = ('' if red == 'fsm' else f'_red{red}') + ('' if green == 'enterprise' else f'_green{green}')
+    name = f"traj_seed{seed}_{blue}_{init}_{steps}{'_msg' if msgs else ''}{pol}.npz"
     np.savez_compressed(os.path.join(OUT, name), seed=np.int64(seed), reset_seed=np.int64(reset_seed), steps=np.int32(steps),
                         actions=A, obs_bits=np.packbits(O[:, 1:] if False else (O > 0).astype(np.uint8), axis=1), phase=O[:, 0].copy(),
                         phase_cols=np.array([0, 92, 184, 276, 368], np.int32), obs_phase_vals=O[:, [0, 92, 184, 276, 368]].copy(),
                         reward=R, done=D, rng=G, mask=mask, messages=M if msgs else np.zeros(0, np.uint8),
+                        red_policy=np.int32(RED[red][1]), green_policy=np.int32(GREEN[green][1]),
                         numpy_version=np.bytes_(np.__version__), n_hosts=np.int32(len(env.environment_controller.state.hosts)))
     print(name, 'sum reward', float(R.sum()), 'hosts', len(env.environment_controller.state.hosts), flush=True)
 
 
 if __name__ == '__main__':
     os.makedirs(OUT, exist_ok=True)
+    if len(sys.argv) > 1 and sys.argv[1] == 'policies':   # built-in policy variants
+        record(41, 500, 'random', 'ctor', red='discovery')
+        record(42, 300, 'random', 'reset', red='sleep')
+        record(43, 200, 'random', 'ctor', red='discovery', green='sleep')
+        sys.exit(0)
     # BASELINE config 1 (SleepAgent blue, FSM red, 500 steps) + seeded random blue; regression seeds of
     # CybORG/Tests/test_cc4/test_heuristic_agents.py
     record(123, 500, 'sleep', 'ctor')

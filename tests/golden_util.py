@@ -20,6 +20,8 @@ def load(path):
         'name': os.path.basename(path), 'seed': int(z['seed']), 'reset_seed': int(z['reset_seed']), 'steps': int(z['steps']),
         'actions': z['actions'].astype(np.int32), 'obs': obs, 'reward': z['reward'], 'done': z['done'].astype(bool),
         'rng': z['rng'], 'mask': z['mask'].astype(bool), 'messages': msgs if msgs.size else None,
+        'red_policy': int(z['red_policy']) if 'red_policy' in z else 0,
+        'green_policy': int(z['green_policy']) if 'green_policy' in z else 0,
     }
 
 

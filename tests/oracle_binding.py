@@ -23,7 +23,7 @@ def load():
     lib.cc4o_create.restype = ctypes.c_void_p
     lib.cc4o_create.argtypes = [ctypes.c_int]
     lib.cc4o_destroy.argtypes = [ctypes.c_void_p]
-    lib.cc4o_reset.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_uint64, ctypes.c_int, ctypes.c_int, ctypes.c_int]
+    lib.cc4o_reset.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_uint64, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int]
     lib.cc4o_step.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]
     lib.cc4o_step_all.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
     lib.cc4o_obs.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]
@@ -44,8 +44,9 @@ def load():
 
 class OracleVecEnv:
     """Same call shape as cage_challenge_4_amd.CC4VecEnv, stepping episodes serially on the host."""
-    def __init__(self, num_envs, steps=500, rng_mode=0, autoreset=False, device_id=0):
+    def __init__(self, num_envs, steps=500, rng_mode=0, autoreset=False, device_id=0, red_policy=0, green_policy=0):
         self.lib = load()
+        self.policy = (red_policy & 3) | (0x10 if green_policy else 0)
         self.num_envs = num_envs
         self.steps = steps
         self.rng_mode = rng_mode
@@ -74,16 +75,16 @@ class OracleVecEnv:
             if env_mask is not None and not env_mask[i]:
                 continue
             if seeds is None:
-                self.lib.cc4o_reset(self._h, i, 0, self.rng_mode, self.steps, 1)
+                self.lib.cc4o_reset(self._h, i, 0, self.rng_mode, self.steps, 1, self.policy)
             else:
-                self.lib.cc4o_reset(self._h, i, ctypes.c_uint64(int(seeds[i])), self.rng_mode, self.steps, 0)
+                self.lib.cc4o_reset(self._h, i, ctypes.c_uint64(int(seeds[i])), self.rng_mode, self.steps, 0, self.policy)
             self._collect(i, reward=False)
         return self._obs
 
     def step(self, actions=None, messages=None):
         for i in range(self.num_envs):
             if self.autoreset and self._done[i]:
-                self.lib.cc4o_reset(self._h, i, 0, self.rng_mode, self.steps, 1)
+                self.lib.cc4o_reset(self._h, i, 0, self.rng_mode, self.steps, 1, self.policy)
                 self._collect(i, reward=False)
                 continue
             a = None if actions is None else np.ascontiguousarray(actions[i], np.int32)

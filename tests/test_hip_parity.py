@@ -17,7 +17,7 @@ def _dev(n, **kw):
 def test_hip_matches_reference_golden_trajectories():
     """All golden episodes stepped together in ONE batch: each env its own seed / init mode / action script."""
     fixes = [G.load(p) for p in G.list_fixtures()]
-    fixes = [f for f in fixes if f['steps'] == 500]
+    fixes = [f for f in fixes if f['steps'] == 500 and f['red_policy'] == 0 and f['green_policy'] == 0]
     n = len(fixes)
     env = _dev(n, steps=500)
     env.reset(seeds=np.array([f['seed'] for f in fixes], np.uint64))
@@ -43,11 +43,30 @@ def test_hip_matches_reference_golden_trajectories():
     env.close()
 
 
+def test_hip_policy_variants_match_reference_golden():
+    """DiscoveryFSRed / SleepAgent red / SleepAgent green episodes recorded from the reference, on the HIP path."""
+    import test_oracle_golden as T
+    from cage_challenge_4_amd import CC4VecEnv
+    todo = [f for f in (G.load(p) for p in G.list_fixtures()) if f['red_policy'] or f['green_policy']]
+    assert len(todo) >= 3
+    for fix in todo:
+        env, obs = T.replay(CC4VecEnv, fix, red_policy=fix['red_policy'], green_policy=fix['green_policy'])
+        assert np.array_equal(obs[0], fix['obs'][0]) and np.array_equal(env.action_mask[0], fix['mask'])
+        for t in range(fix['actions'].shape[0]):
+            obs, rew, done, info = env.step(fix['actions'][t][None])
+            assert np.array_equal(obs[0], fix['obs'][t + 1]), (fix['name'], t)
+            assert rew[0] == fix['reward'][t] and bool(done[0]) == bool(fix['done'][t]), (fix['name'], t)
+            assert G.rng_words_match(fix['rng'][t + 1], env.rng_state()[0]), (fix['name'], t)
+        env.close()
+
+
+@pytest.mark.parametrize('policies', [(0, 0), (2, 0), (1, 1)], ids=['fsm', 'discovery', 'sleep'])
 @pytest.mark.parametrize('rng_mode', [0, 1], ids=['pcg64', 'philox'])
-def test_hip_matches_oracle_bit_for_bit(rng_mode):
+def test_hip_matches_oracle_bit_for_bit(rng_mode, policies):
     n, T = 96, 160
-    dev = _dev(n, steps=150, rng_mode=rng_mode, autoreset=True)
-    ora = OracleVecEnv(n, steps=150, rng_mode=rng_mode, autoreset=True)
+    rp, gp = policies
+    dev = _dev(n, steps=150, rng_mode=rng_mode, autoreset=True, red_policy=rp, green_policy=gp)
+    ora = OracleVecEnv(n, steps=150, rng_mode=rng_mode, autoreset=True, red_policy=rp, green_policy=gp)
     assert np.array_equal(dev.reset(seeds=31337), ora.reset(seeds=31337))
     assert np.array_equal(dev.action_mask, ora.mask())
     rs = np.random.default_rng(5)

@@ -39,9 +39,15 @@ def test_scenario_generator_signature_and_constants():
                                        red_agent_class=W.FiniteStateRedAgent, steps=500)
     assert (sg.MIN_USER_HOSTS, sg.MAX_USER_HOSTS, sg.MIN_SERVER_HOSTS, sg.MAX_SERVER_HOSTS) == (3, 10, 1, 6)
     assert sg.MESSAGE_LENGTH == 8 and sg.steps == 500
+    sg2 = W.EnterpriseScenarioGenerator(blue_agent_class=W.SleepAgent, green_agent_class=W.SleepAgent,
+                                        red_agent_class=W.DiscoveryFSRed)
+    assert (sg2.red_policy, sg2.green_policy) == (2, 1)
+
+    class RandomSelectRedAgent:      # not one of the engine's built-in policies
+        pass
     with pytest.raises(NotImplementedError):
-        W.EnterpriseScenarioGenerator(blue_agent_class=W.SleepAgent, green_agent_class=W.SleepAgent,
-                                      red_agent_class=W.FiniteStateRedAgent)
+        W.EnterpriseScenarioGenerator(blue_agent_class=W.SleepAgent, green_agent_class=W.EnterpriseGreenAgent,
+                                      red_agent_class=RandomSelectRedAgent)
 
 
 def test_spaces():
