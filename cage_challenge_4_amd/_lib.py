@@ -50,6 +50,9 @@ SIGNATURES = {
     'cc4_state_bytes': (ctypes.c_size_t, []),
     'cc4_get_state': (ctypes.c_int, [_P, ctypes.c_int32, _P]),
     'cc4_set_state': (ctypes.c_int, [_P, ctypes.c_int32, _P]),
+    'cc4_cold_bytes': (ctypes.c_size_t, []),
+    'cc4_get_cold': (ctypes.c_int, [_P, ctypes.c_int32, _P]),
+    'cc4_set_cold': (ctypes.c_int, [_P, ctypes.c_int32, _P]),
     'cc4_get_topology': (ctypes.c_int, [_P, ctypes.c_int32, _P]),
     'cc4_debug_profile': (ctypes.c_int, [_P, ctypes.c_int, _P]),
     'cc4_comm_unique_id': (ctypes.c_int, [_P]),

@@ -566,7 +566,7 @@ CC4_HD void blue_monitor(Ctx x, int b) {
   for (int i = 0; i < s->npend; ++i) {
     int h = (int)(s->pend[i] >> 16);
     if (blue_of_subnet(h_subnet(h)) == b) {
-      if (A.nsus >= MAX_SUS) set_err(x, E_SUS_OVERFLOW); else { A.sus[A.nsus++] = s->pend[i]; bit_set(A.sus_hosts, h); }
+      if (A.nsus >= MAX_SUS) set_err(x, E_SUS_OVERFLOW); else { x.c->sus[b][A.nsus++] = s->pend[i]; bit_set(A.sus_hosts, h); }
     } else s->pend[n++] = s->pend[i];
   }
   s->npend = (uint8_t)n;
@@ -604,7 +604,10 @@ CC4_HD void blue_remove(Ctx x, int b, int h) {
   BlueAgent& A = x.s->blue[b];
   if (!bit_get(A.sus_hosts, h)) return;   // parent_session.sus_pids has no entry for this hostname
   for (int i = 0; i < A.nsus; ++i)
-    if ((int)(A.sus[i] >> 16) == h) stop_process(x, h, (int)(A.sus[i] & 0xFFFF));
+  {
+    uint32_t e = x.c->sus[b][i];
+    if ((int)(e >> 16) == h) stop_process(x, h, (int)(e & 0xFFFF));
+  }
 }
 // Restore.execute -> RestoreFromBackup (AbstractActions/Restore.py:38-71, ConcreteActions/RestoreFromBackup.py:9-19)
 CC4_HD void blue_restore(Ctx x, int h) {
@@ -1402,7 +1405,7 @@ CC4_HD void step_monitor_pend(Ctx x) {  // session.add_sus_pids for the pid-carr
     int b = blue_of_subnet(h_subnet((int)(s->pend[i] >> 16)));
     if (b < 0) continue;
     BlueAgent& A = s->blue[b];
-    if (A.nsus >= MAX_SUS) set_err(x, E_SUS_OVERFLOW); else { A.sus[A.nsus++] = s->pend[i]; bit_set(A.sus_hosts, (int)(s->pend[i] >> 16)); }
+    if (A.nsus >= MAX_SUS) set_err(x, E_SUS_OVERFLOW); else { x.c->sus[b][A.nsus++] = s->pend[i]; bit_set(A.sus_hosts, (int)(s->pend[i] >> 16)); }
   }
   s->npend = 0;
 }

@@ -146,7 +146,7 @@ __global__ __launch_bounds__(WAVE) void k_step(StepArgs a) {
 constexpr int PW = CC4_PW;         // waves per episode block; red agent r runs on wave r % PW, lane r / PW
 static_assert(PW >= 3 && PW <= 6, "waves 0/1 run the two green action lists, wave 2 the Sleep bookkeeping");
 constexpr int PT = PW * WAVE;      // 384 threads
-constexpr int RNG_SLOTS = 96;      // 6 red + 80 green + spare generators
+constexpr int RNG_SLOTS = 8;       // 6 red agents + thread 0 (ordered sections); green agents use thread-private generators
 
 __device__ __forceinline__ void stage_in_n(uint4* __restrict__ lds, const uint4* __restrict__ src, int tid) {
   constexpr int U = 6;
@@ -191,7 +191,7 @@ __global__ __launch_bounds__(PT) void k_step_philox(StepArgs a) {
     __syncthreads();
     if (ok_lds) {
       const int ng = s->n_green;
-      // generator slots: red r -> r, green g -> 8 + g, thread 0 (ordered sections) -> 6
+      // generator slots in LDS: red r -> r, thread 0 (ordered sections) -> 6
       const int slot = (lane == 0) ? (wave == 0 ? 6 : wave) : 0;
       Ctx x0{s, a.cold + e, &rngs[6], tid == 0 ? prof : nullptr};               // thread 0
       const int ragent = lane * PW + wave;                                        // lanes 0..(6/PW-1) of each wave own a red agent
@@ -205,8 +205,9 @@ __global__ __launch_bounds__(PT) void k_step_philox(StepArgs a) {
       else if (wave == PW - 1 && lane >= 2 && lane < 2 + NBLUE) step_blue_submit(x0, lane - 2, a.actions ? a.actions[e * NBLUE + lane - 2] : -1);
       else if (lane >= 8) {
         for (int g = wave * (WAVE - 8) + (lane - 8); g < ng; g += PW * (WAVE - 8)) {
-          rng_fork(&rngs[8 + g], &s->rng, ST_RESET);
-          Ctx xg{s, a.cold + e, &rngs[8 + g], nullptr};
+          Rng gl;
+          rng_fork(&gl, &s->rng, ST_RESET);
+          Ctx xg{s, a.cold + e, &gl, nullptr};
           step_green_policy(xg, g);
           int t = s->green_act[g];
           if (t < 2) glist[t][atomicAdd(&glist_n[t], 1)] = (uint8_t)g;       // compaction by action type
@@ -224,7 +225,9 @@ __global__ __launch_bounds__(PT) void k_step_philox(StepArgs a) {
         int pen = 0;
         for (int i = lane; i < glist_n[wave]; i += WAVE) {
           int g = glist[wave][i];
-          Ctx xg{s, a.cold + e, &rngs[8 + g], nullptr};
+          Rng gl;
+          rng_fork(&gl, &s->rng, ST_RESET);
+          Ctx xg{s, a.cold + e, &gl, nullptr};
           pen += step_green_exec(xg, g);
         }
         if (pen) atomicAdd(&s->brm, pen);
@@ -540,6 +543,22 @@ int cc4_set_state(cc4_handle* h, int32_t env, const void* buf) {
   if (env < 0 || env >= h->cfg.num_envs) { h->err = "cc4_set_state: env out of range"; return -2; }
   HIPCHK(h, hipSetDevice(h->cfg.device_id));
   HIPCHK(h, hipMemcpyAsync(h->d_state + env, buf, sizeof(EnvState), hipMemcpyHostToDevice, h->stream));
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  return 0;
+}
+
+size_t cc4_cold_bytes(void) { return sizeof(EnvCold); }
+int cc4_get_cold(cc4_handle* h, int32_t env, void* buf) {
+  if (env < 0 || env >= h->cfg.num_envs) { h->err = "cc4_get_cold: env out of range"; return -2; }
+  HIPCHK(h, hipSetDevice(h->cfg.device_id));
+  HIPCHK(h, hipMemcpyAsync(buf, h->d_cold + env, sizeof(EnvCold), hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  return 0;
+}
+int cc4_set_cold(cc4_handle* h, int32_t env, const void* buf) {
+  if (env < 0 || env >= h->cfg.num_envs) { h->err = "cc4_set_cold: env out of range"; return -2; }
+  HIPCHK(h, hipSetDevice(h->cfg.device_id));
+  HIPCHK(h, hipMemcpyAsync(h->d_cold + env, buf, sizeof(EnvCold), hipMemcpyHostToDevice, h->stream));
   HIPCHK(h, hipStreamSynchronize(h->stream));
   return 0;
 }

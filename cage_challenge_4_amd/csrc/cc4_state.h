@@ -128,7 +128,6 @@ struct alignas(8) RedAgent {
 };
 
 struct alignas(8) BlueAgent {
-  uint32_t sus[MAX_SUS];             // (host << 16) | pid, chronological
   uint32_t sus_hosts[5];             // hosts that have at least one entry in sus[] (entries are never removed)
   uint32_t pad2;
   Act queue;
@@ -171,12 +170,14 @@ struct alignas(16) EnvState {
   int32_t n_actions;                 // actions surviving filter_actions (length of the shuffled index list)
   uint8_t phish_req[MAXG];           // green g's LocalWork asked for a PhishingEmail this step
   int32_t n_restore;                 // Restore actions submitted this step (each costs -1)
-  uint32_t scratch[128];             // work area of the ordered (lane 0) sections: small temporaries that would otherwise
+  uint32_t scratch[64];              // work area of the ordered (lane 0) sections: small temporaries that would otherwise
                                      // be dynamically indexed private arrays (= scratch memory on the device)
   int32_t any_phish;                 // some phish_req[] is set
 };
 
 struct alignas(16) EnvCold {
+  uint32_t sus[NBLUE][MAX_SUS];      // VelociraptorServer.sus_pids of blue agent b: (host << 16) | pid, chronological
+                                     // (appended by Monitor, read by Remove; counts and per-host presence stay hot)
   HostStatic hs[MAXH];               // backup images (Host.create_backup): read by Restore and reset only
   uint8_t hs_pad[8];                 // keeps eph[] 16-byte aligned (137 * 56 + 8 = 7680)
   uint32_t eph[MAXH][EPH_WORDS];     // Host.ephemeral_ports as a bitmap (port-49152)

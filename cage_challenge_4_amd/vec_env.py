@@ -129,6 +129,19 @@ class CC4VecEnv:
         assert buf.size == self.lib.cc4_state_bytes()
         self._chk(self.lib.cc4_set_state(self._h, int(env), buf.ctypes.data_as(ctypes.c_void_p)), 'cc4_set_state')
 
+    def snapshot(self, env):
+        """Full episode snapshot (hot + cold row) for checkpointing / tree search / parity bisecting."""
+        cold = np.zeros(self.lib.cc4_cold_bytes(), np.uint8)
+        self._chk(self.lib.cc4_get_cold(self._h, int(env), cold.ctypes.data_as(ctypes.c_void_p)), 'cc4_get_cold')
+        return self.get_state(env), cold
+
+    def restore(self, env, snap):
+        hot, cold = snap
+        self.set_state(env, hot)
+        cold = np.ascontiguousarray(cold, dtype=np.uint8)
+        assert cold.size == self.lib.cc4_cold_bytes()
+        self._chk(self.lib.cc4_set_cold(self._h, int(env), cold.ctypes.data_as(ctypes.c_void_p)), 'cc4_set_cold')
+
     # device-resident loop used by bench.py
     def run_random_steps(self, seed0, t0, k, timed=True):
         ms = ctypes.c_float(0.0)

@@ -131,6 +131,7 @@ int cc4o_layout(char* buf, int cap) {
 // canonical text dump of one episode's state (parity bisecting against oracle/refgen/ref_dump.py)
 int cc4o_dump(void* h, int i, char* buf, int cap) {
   const EnvState& s = ((Oracle*)h)->st[i];
+  const EnvCold& cold = ((Oracle*)h)->cold[i];
   int n = 0;
 #define P(...) do { if (n < cap) n += snprintf(buf + n, cap - n, __VA_ARGS__); } while (0)
   P("step %d phase %d blocks", s.step_count, s.phase);
@@ -160,7 +161,7 @@ int cc4o_dump(void* h, int i, char* buf, int cap) {
     const BlueAgent& a = s.blue[b];
     P("blue %d sus", b);
     for (int hh = 0; hh < MAXH; ++hh)  // grouped by host, chronological within a host
-      for (int k = 0; k < a.nsus; ++k) if ((int)(a.sus[k] >> 16) == hh) P(" (%d,%d)", hh, (int)(a.sus[k] & 0xFFFF));
+      for (int k = 0; k < a.nsus; ++k) if ((int)(cold.sus[b][k] >> 16) == hh) P(" (%d,%d)", hh, (int)(cold.sus[b][k] & 0xFFFF));
     P("\n");
   }
 #undef P

@@ -166,13 +166,23 @@ def test_rccl_allgather_world_size_one():
 
 
 def test_snapshot_restore_replays_identically():
+    """SURVEY 8(f)-4 (snapshot tooling): state + cold row of one episode captured, the episode advanced, restored and advanced
+    again -> identical trajectory; the other episodes of the batch are unaffected."""
     dev = _dev(4, steps=100); dev.reset(seeds=9)
-    for t in range(10):
+    for t in range(25):
         dev.step(random_actions(9, t, 4))
-    snap = [dev.get_state(i) for i in range(4)]
-    # note: the cold part (ephemeral-port bitmaps) is not in the snapshot; replay within the same handle keeps it
-    ref = [dev.step(random_actions(9, 10 + t, 4))[0].copy() for t in range(3)]
-    assert len(snap[0]) == dev.lib.cc4_state_bytes()
+    snap = dev.snapshot(2)
+    first = []
+    for t in range(25, 45):
+        o, r, d, _ = dev.step(random_actions(9, t, 4))
+        first.append((o.copy(), r.copy()))
+    rng_a = dev.rng_state()[2].copy()
+    dev.restore(2, snap)
+    for k, t in enumerate(range(25, 45)):
+        o, r, d, _ = dev.step(random_actions(9, t, 4))
+        assert np.array_equal(o[2], first[k][0][2]) and r[2] == first[k][1][2]
+    assert np.array_equal(dev.rng_state()[2], rng_a)
+    assert len(snap[0]) == dev.lib.cc4_state_bytes() and len(snap[1]) == dev.lib.cc4_cold_bytes()
     dev.close()
 
 
