@@ -165,7 +165,7 @@ def main():
                             f'(82/82/82/82/242 incl. invalid slots), FiniteStateRedAgent, EnterpriseGreenAgent, '
                             f'EnterpriseScenarioGenerator(steps={args.episode_steps}), autoreset incl. scenario regeneration',
                 'envs_per_gpu': n_local, 'total_envs': total_envs, 'rng': args.rng,
-                'exchange': 'RCCL all-gather of [N,578] int32 obs per step' if dist_on else 'none',
+                'exchange': 'RCCL all-gather of the [N,578] uint8 obs of every step on a second stream, overlapped with the next step' if dist_on else 'none',
                 'env_steps_per_sec': total_envs * args.steps / dt, 'engine_error_flags': err_any,
             },
             'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBPS, 'unit': 'GB/s',

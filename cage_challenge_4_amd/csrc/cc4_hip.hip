@@ -27,9 +27,21 @@ struct StepArgs {
   EnvState* st; EnvCold* cold;
   const int32_t* actions; const uint8_t* msgs;
   int32_t* obs; float* reward; uint8_t* done; uint32_t* err;
+  uint8_t* obs8;               // the same observations as bytes (what the multi-GPU all-gather moves), or null
+  int32_t* rand_out;           // when non-null: draw the blue actions in-kernel (k_random_actions fused) and record them here
+  uint64_t rand_seed0; uint32_t rand_t;
   int n, autoreset, steps, rng_mode, policy;
   unsigned long long* prof;   // optional [n][16] cycle counters (CC4_PROFILE builds / cc4_debug_profile)
 };
+
+// uniform blue action index of (episode e, agent b) at step t: Philox key (seed0 + e), counter (t, b, 0xB10E, 0)
+__device__ __forceinline__ int32_t random_blue_action(uint64_t seed0, uint32_t t, int e, int b) {
+  uint32_t c[4] = {t, (uint32_t)b, 0xB10Eu, 0u};
+  uint64_t key = seed0 + (uint64_t)e;
+  philox4x32_10(c, (uint32_t)key, (uint32_t)(key >> 32));
+  uint32_t range = b == 4 ? ACT_LONG : ACT_SHORT;
+  return (int32_t)(((uint64_t)c[0] * range) >> 32);
+}
 
 // ---------------------------------------------------------------- kernels
 // HBM -> LDS row staging with 8 independent 16-byte loads in flight per lane (a plain copy loop serialises on vmcnt)
@@ -83,7 +95,13 @@ __global__ __launch_bounds__(WAVE) void k_step(StepArgs a) {
       env_reset(x, 0, a.rng_mode, a.steps, true, a.policy);   // new episode, same stream (CybORG.reset(seed=None))
     } else {
       CC4_TICK0(x);
-      if (step_begin(x, a.actions ? a.actions + e * NBLUE : nullptr)) {
+      int32_t racts[NBLUE];
+      const int32_t* acts = a.actions ? a.actions + e * NBLUE : nullptr;
+      if (a.rand_out) {
+        for (int b = 0; b < NBLUE; ++b) { racts[b] = random_blue_action(a.rand_seed0, a.rand_t, e, b); a.rand_out[e * NBLUE + b] = racts[b]; }
+        acts = racts;
+      }
+      if (step_begin(x, acts)) {
         ok_lds = 1;
         CC4_TICK(x, 0);
         for (int g = 0; g < s->n_green; ++g) step_green_policy(x, g);
@@ -126,6 +144,7 @@ __global__ __launch_bounds__(WAVE) void k_step(StepArgs a) {
   stage_out(dst, lds, lane);
   int32_t* o = a.obs + (size_t)e * OBS_TOTAL;
   for (int i = lane; i < OBS_TOTAL; i += WAVE) o[i] = obs_lds[i];
+  if (a.obs8) { uint8_t* o8 = a.obs8 + (size_t)e * OBS_TOTAL; for (int i = lane; i < OBS_TOTAL; i += WAVE) o8[i] = obs_lds[i]; }
   if (prof && lane == 0) { prof[13] += clock64() - t_out; prof[14] += clock64() - t_begin; }
   if (prof) { __syncthreads(); if (lane < 15) a.prof[16 * (size_t)e + lane] += prof_lds[lane]; }
 }
@@ -202,7 +221,12 @@ __global__ __launch_bounds__(PT) void k_step_philox(StepArgs a) {
       if (is_red) rng_fork(&rngs[ragent], &s->rng, ST_RESET);
       if (tid == 0) rng_fork(&rngs[6], &s->rng, ST_RESET);
       if (is_red) step_red_policy(xr, ragent);
-      else if (wave == PW - 1 && lane >= 2 && lane < 2 + NBLUE) step_blue_submit(x0, lane - 2, a.actions ? a.actions[e * NBLUE + lane - 2] : -1);
+      else if (wave == PW - 1 && lane >= 2 && lane < 2 + NBLUE) {
+        const int b = lane - 2;
+        int32_t act = a.actions ? a.actions[e * NBLUE + b] : -1;
+        if (a.rand_out) { act = random_blue_action(a.rand_seed0, a.rand_t, e, b); a.rand_out[e * NBLUE + b] = act; }
+        step_blue_submit(x0, b, act);
+      }
       else if (lane >= 8) {
         for (int g = wave * (WAVE - 8) + (lane - 8); g < ng; g += PW * (WAVE - 8)) {
           Rng gl;
@@ -271,6 +295,7 @@ __global__ __launch_bounds__(PT) void k_step_philox(StepArgs a) {
   for (int i = tid; i < ROW_VEC; i += PT) dst[i] = lds[i];
   int32_t* o = a.obs + (size_t)e * OBS_TOTAL;
   for (int i = tid; i < OBS_TOTAL; i += PT) o[i] = obs_lds[i];
+  if (a.obs8) { uint8_t* o8 = a.obs8 + (size_t)e * OBS_TOTAL; for (int i = tid; i < OBS_TOTAL; i += PT) o8[i] = obs_lds[i]; }
   if (prof && tid == 0) { prof[13] += clock64() - t_out; prof[14] += clock64() - t_begin; }
   if (prof) { __syncthreads(); if (tid < 15) a.prof[16 * (size_t)e + tid] += prof_lds[tid]; }
 }
@@ -307,11 +332,7 @@ __global__ void k_random_actions(int32_t* actions, int n, uint64_t seed0, uint32
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n * NBLUE) return;
   int e = i / NBLUE, b = i % NBLUE;
-  uint32_t c[4] = {t, (uint32_t)b, 0xB10Eu, 0u};
-  uint64_t key = seed0 + (uint64_t)e;
-  philox4x32_10(c, (uint32_t)key, (uint32_t)(key >> 32));
-  uint32_t range = b == 4 ? ACT_LONG : ACT_SHORT;
-  actions[i] = (int32_t)(((uint64_t)c[0] * range) >> 32);
+  actions[i] = random_blue_action(seed0, t, e, b);
 }
 
 __global__ void k_rng_state(const EnvState* st, uint64_t* out, int n) {
@@ -330,7 +351,11 @@ struct cc4_handle {
   int32_t* d_actions = nullptr; uint8_t* d_msgs = nullptr; uint64_t* d_seeds = nullptr; uint8_t* d_envmask = nullptr;
   int32_t* d_obs = nullptr; float* d_reward = nullptr; uint8_t* d_done = nullptr; uint32_t* d_err = nullptr;
   uint8_t* d_mask = nullptr; uint64_t* d_rng = nullptr;
-  int32_t* d_all_obs = nullptr;
+  uint8_t* d_obs8[2] = {nullptr, nullptr};      // byte observations, double-buffered against the overlapped all-gather
+  uint8_t* d_all_obs8[2] = {nullptr, nullptr};  // [world*N][578] gathered observations
+  hipStream_t comm_stream = nullptr;
+  hipEvent_t ev_step[2] = {nullptr, nullptr}, ev_comm[2] = {nullptr, nullptr};
+  int obs_buf = 0;                               // buffer written by the most recent step
   unsigned long long* d_prof = nullptr;
   ncclComm_t comm = nullptr; int rank = 0, world = 1;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -349,13 +374,20 @@ static thread_local std::string g_create_err;
     }                                                                                          \
   } while (0)
 
-static int launch_step(cc4_handle* h, const int32_t* d_actions, const uint8_t* d_msgs) {
+// rand: draw the blue actions inside the step kernel from (seed0, t) and record them in the handle's action buffer
+static int launch_step(cc4_handle* h, const int32_t* d_actions, const uint8_t* d_msgs, bool rand = false, uint64_t seed0 = 0,
+                       uint32_t t = 0) {
+  // the byte-observation buffer about to be overwritten may still be read by an overlapped all-gather
+  int buf = h->comm ? (h->obs_buf ^ 1) : 0;
+  if (h->comm) HIPCHK(h, hipStreamWaitEvent(h->stream, h->ev_comm[buf], 0));
   StepArgs a{h->d_state, h->d_cold, d_actions, d_msgs, h->d_obs, h->d_reward, h->d_done, h->d_err,
+             h->comm ? h->d_obs8[buf] : nullptr, rand ? h->d_actions : nullptr, seed0, t,
              h->cfg.num_envs, h->cfg.autoreset, h->cfg.steps, h->cfg.rng_mode,
              (h->cfg.red_policy & 3) | (h->cfg.green_policy ? GP_SLEEP_BIT : 0), h->d_prof};
   if (h->cfg.rng_mode == 1) hipLaunchKernelGGL(k_step_philox, dim3(h->cfg.num_envs), dim3(PT), sizeof(EnvState), h->stream, a);
   else hipLaunchKernelGGL(k_step, dim3(h->cfg.num_envs), dim3(WAVE), sizeof(EnvState), h->stream, a);
   HIPCHK(h, hipGetLastError());
+  h->obs_buf = buf;
   return 0;
 }
 
@@ -411,9 +443,12 @@ void cc4_destroy(cc4_handle* h) {
   if (!h) return;
   (void)hipSetDevice(h->cfg.device_id);
   if (h->stream) (void)hipStreamSynchronize(h->stream);
+  if (h->comm_stream) (void)hipStreamSynchronize(h->comm_stream);
   if (h->comm) ncclCommDestroy(h->comm);
+  for (int b = 0; b < 2; ++b) { if (h->ev_step[b]) (void)hipEventDestroy(h->ev_step[b]); if (h->ev_comm[b]) (void)hipEventDestroy(h->ev_comm[b]); }
+  if (h->comm_stream) (void)hipStreamDestroy(h->comm_stream);
   void* ptrs[] = {h->d_state, h->d_cold, h->d_actions, h->d_msgs, h->d_seeds, h->d_envmask, h->d_obs, h->d_reward,
-                  h->d_done, h->d_err, h->d_mask, h->d_rng, h->d_all_obs};
+                  h->d_done, h->d_err, h->d_mask, h->d_rng, h->d_obs8[0], h->d_obs8[1], h->d_all_obs8[0], h->d_all_obs8[1]};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   for (hipEvent_t e : h->evs) if (e) (void)hipEventDestroy(e);
   if (h->ev0) (void)hipEventDestroy(h->ev0);
@@ -513,12 +548,12 @@ int cc4_run_random_steps(cc4_handle* h, uint64_t seed0, uint32_t t0, int32_t k, 
     for (size_t i = old; i < h->evs.size(); ++i) HIPCHK(h, hipEventCreate(&h->evs[i]));
   }
   for (int i = 0; i < k; ++i) {
-    if (cc4_random_actions_device(h, seed0, t0 + (uint32_t)i)) return -1;
     if (ms_step_kernels) HIPCHK(h, hipEventRecord(h->evs[2 * i], h->stream));
-    if (launch_step(h, h->d_actions, nullptr)) return -1;
+    if (launch_step(h, nullptr, nullptr, true, seed0, t0 + (uint32_t)i)) return -1;   // actions drawn in-kernel
     if (ms_step_kernels) HIPCHK(h, hipEventRecord(h->evs[2 * i + 1], h->stream));
-    if (h->comm) { if (cc4_allgather_obs(h, nullptr)) return -1; }
+    if (h->comm) { if (cc4_allgather_obs(h, nullptr)) return -1; }                       // overlaps the next step
   }
+  if (h->comm) HIPCHK(h, hipStreamSynchronize(h->comm_stream));
   HIPCHK(h, hipStreamSynchronize(h->stream));
   if (ms_step_kernels) {
     float total = 0.f;
@@ -604,16 +639,49 @@ int cc4_comm_init(cc4_handle* h, int32_t rank, int32_t world, const void* id128)
   ncclResult_t r = ncclCommInitRank(&h->comm, world, id, rank);
   if (r != ncclSuccess) { h->err = std::string("ncclCommInitRank: ") + ncclGetErrorString(r); return -1; }
   h->rank = rank; h->world = world;
-  HIPCHK(h, hipMalloc(&h->d_all_obs, (size_t)world * h->cfg.num_envs * OBS_TOTAL * sizeof(int32_t)));
+  size_t nb = (size_t)h->cfg.num_envs * OBS_TOTAL;
+  HIPCHK(h, hipStreamCreateWithFlags(&h->comm_stream, hipStreamNonBlocking));
+  for (int b = 0; b < 2; ++b) {
+    HIPCHK(h, hipMalloc(&h->d_obs8[b], nb));
+    HIPCHK(h, hipMalloc(&h->d_all_obs8[b], nb * (size_t)world));
+    HIPCHK(h, hipMemsetAsync(h->d_obs8[b], 0, nb, h->stream));
+    HIPCHK(h, hipEventCreateWithFlags(&h->ev_step[b], hipEventDisableTiming));
+    HIPCHK(h, hipEventCreateWithFlags(&h->ev_comm[b], hipEventDisableTiming));
+    HIPCHK(h, hipEventRecord(h->ev_comm[b], h->comm_stream));   // "no all-gather pending on this buffer"
+  }
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  HIPCHK(h, hipStreamSynchronize(h->comm_stream));
   return 0;
 }
-int cc4_allgather_obs(cc4_handle* h, int32_t** d_all_obs) {
+// All-gather of the observations written by the most recent step (as bytes, [world*N][578]) over RCCL/xGMI on the
+// handle's communication stream: it waits for that step's kernel, runs concurrently with whatever is enqueued next on
+// the compute stream (the next step writes the other byte buffer), and is awaited by cc4_allgather_wait / the second
+// next step.  *d_all_obs8 is valid after cc4_allgather_wait().
+int cc4_allgather_obs(cc4_handle* h, uint8_t** d_all_obs8) {
   if (!h->comm) { h->err = "cc4_allgather_obs: cc4_comm_init was not called"; return -2; }
   HIPCHK(h, hipSetDevice(h->cfg.device_id));
+  const int buf = h->obs_buf;
+  HIPCHK(h, hipEventRecord(h->ev_step[buf], h->stream));
+  HIPCHK(h, hipStreamWaitEvent(h->comm_stream, h->ev_step[buf], 0));
   size_t cnt = (size_t)h->cfg.num_envs * OBS_TOTAL;
-  ncclResult_t r = ncclAllGather(h->d_obs, h->d_all_obs, cnt, ncclInt32, h->comm, h->stream);
+  ncclResult_t r = ncclAllGather(h->d_obs8[buf], h->d_all_obs8[buf], cnt, ncclUint8, h->comm, h->comm_stream);
   if (r != ncclSuccess) { h->err = std::string("ncclAllGather: ") + ncclGetErrorString(r); return -1; }
-  if (d_all_obs) *d_all_obs = h->d_all_obs;
+  HIPCHK(h, hipEventRecord(h->ev_comm[buf], h->comm_stream));
+  if (d_all_obs8) *d_all_obs8 = h->d_all_obs8[buf];
+  return 0;
+}
+int cc4_allgather_wait(cc4_handle* h) {
+  if (!h->comm) { h->err = "cc4_allgather_wait: cc4_comm_init was not called"; return -2; }
+  HIPCHK(h, hipSetDevice(h->cfg.device_id));
+  HIPCHK(h, hipStreamSynchronize(h->comm_stream));
+  return 0;
+}
+// host copy of the gathered observations of the most recent cc4_allgather_obs (tests / debugging)
+int cc4_get_allgathered_obs(cc4_handle* h, uint8_t* out /* [world*N][578] */) {
+  if (!h->comm) { h->err = "cc4_get_allgathered_obs: cc4_comm_init was not called"; return -2; }
+  HIPCHK(h, hipSetDevice(h->cfg.device_id));
+  HIPCHK(h, hipStreamSynchronize(h->comm_stream));
+  HIPCHK(h, hipMemcpy(out, h->d_all_obs8[h->obs_buf], (size_t)h->world * h->cfg.num_envs * OBS_TOTAL, hipMemcpyDeviceToHost));
   return 0;
 }
 

@@ -60,8 +60,19 @@ def init_rccl(vec_env, rank, world):
 
 
 def allgather_obs_device(vec_env):
-    """Enqueue the RCCL all-gather of this rank's [N,578] int32 observations on the handle's stream; returns the
-    device pointer of the [world*N,578] result (valid after vec_env.synchronize())."""
+    """Enqueue the RCCL all-gather of this rank's [N,578] uint8 observations of the latest step on the handle's
+    communication stream (it overlaps the next step); returns the device pointer of the [world*N,578] result, valid after
+    allgather_wait()."""
     p = ctypes.c_void_p()
     vec_env._chk(vec_env.lib.cc4_allgather_obs(vec_env._h, ctypes.byref(p)), 'cc4_allgather_obs')
     return p.value
+
+
+def allgather_wait(vec_env):
+    vec_env._chk(vec_env.lib.cc4_allgather_wait(vec_env._h), 'cc4_allgather_wait')
+
+
+def allgathered_obs_host(vec_env, world):
+    out = np.zeros((world * vec_env.num_envs, 578), np.uint8)
+    vec_env._chk(vec_env.lib.cc4_get_allgathered_obs(vec_env._h, out.ctypes.data_as(ctypes.c_void_p)), 'cc4_get_allgathered_obs')
+    return out

@@ -150,18 +150,22 @@ def test_rccl_allgather_world_size_one():
     ident = (ctypes.c_uint8 * 128)()
     assert dev.lib.cc4_comm_unique_id(ident) == 0
     dev._chk(dev.lib.cc4_comm_init(dev._h, 0, 1, ident), 'cc4_comm_init')
-    obs, *_ = dev.step(random_actions(3, 0, n))
-    p = ctypes.c_void_p()
-    dev._chk(dev.lib.cc4_allgather_obs(dev._h, ctypes.byref(p)), 'cc4_allgather_obs')
-    dev.synchronize()
-    assert p.value
-    # the timed bench loop with the exchange enabled must keep stepping correctly
-    dev.run_random_steps(3, 1, 5, timed=True)
+    from cage_challenge_4_amd import distributed as D
     ora = OracleVecEnv(n, steps=50); ora.reset(seeds=3)
-    for t in range(6):
+    for t in range(4):
+        obs, *_ = dev.step(random_actions(3, t, n))
+        o = ora.step(random_actions(3, t, n))
+        assert D.allgather_obs_device(dev)
+        D.allgather_wait(dev)
+        got = D.allgathered_obs_host(dev, 1)
+        assert np.array_equal(got, obs.astype(np.uint8)) and np.array_equal(obs, o[0])
+    # the timed bench loop (in-kernel random actions, overlapped all-gather on the comm stream, double-buffered bytes)
+    dev.run_random_steps(3, 4, 7, timed=True)
+    for t in range(4, 11):
         o = ora.step(random_actions(3, t, n))
     dev._fetch()
     assert np.array_equal(dev._obs, o[0])
+    assert np.array_equal(D.allgathered_obs_host(dev, 1), o[0].astype(np.uint8))
     dev.close()
 
 
