@@ -786,7 +786,7 @@ CC4_HD int exploit_new_session(Ctx x, int r, int parent_sid, int tgt) {
   (void)parent_sid;
   int pid = create_pid(x, tgt);
   if (!add_proc(x, tgt, pid, K_SHELL, 0)) return -1;
-  return rs_add(x, r, tgt, pid, 0);
+  return rs_add(x, r, tgt, pid, RS_CHILD);   // Session(parent=self.session) (ExploitAction.py:250-259)
 }
 // ExploitRemoteService.execute (AbstractActions/ExploitRemoteService.py:149-202) + selector (:37-69)
 CC4_HD void red_exploit(Ctx x, int r, const Act& a) {
@@ -957,6 +957,9 @@ CC4_HD void red_session_check(Ctx x, int r) {
   if (rs_find_id(A, 0) < 0) {
     int c = (int)rng_below(x.r, (uint32_t)A.nsess);
     rs_move_to_end(A, c, 0);   // active_sessions.pop(old_id); ident = 0; re-inserted last (RedSessionCheck.py:36-45)
+    // every other session's parent becomes new_primary.name, which is None unless the promoted session is the scenario's
+    // own 'red_session_0' (never the case: that one holds id 0 from the start) (RedSessionCheck.py:52-55)
+    for (int i = 0; i < A.nsess; ++i) A.sess[i].flags &= (uint8_t)~RS_CHILD;
   }
   // The observation lists every session (host, Sessions/Interface/System info).  If the session table has not changed
   // since the last full listing, every host in it is already in the agent's ActionSpace and FSM tables, so the only
@@ -970,6 +973,53 @@ CC4_HD void red_session_check(Ctx x, int r) {
   }
   A.rsc_dirty = 0;
 }
+// Withdraw.execute (ConcreteActions/Withdraw.py:38-91) + StopProcess(stop_all=True).  a.host = ip_address (unused beyond the
+// route, which always exists), a.arg = hostname
+CC4_HD void red_withdraw(Ctx x, int r, const Act& a) {
+  EnvState* s = x.s;
+  RedAgent& A = s->red[r];
+  if (rs_find_id(A, a.sid) < 0) { red_result(x, r, a, T_FALSE); return; }
+  const int h = a.arg;
+  // all_agents_sessions = child sessions on the host + parent sessions with ident != 0 + (the acting session if it sits there)
+  // held as ids, because killing one shifts the others
+  uint16_t* ids = reinterpret_cast<uint16_t*>(s->scratch + 36);   // after the per-agent route work areas
+  int n = 0;
+  const int cap = (int)((sizeof(s->scratch) - 36 * 4) / 2);
+  for (int pass = 0; pass < 2; ++pass)
+    for (int i = 0; i < A.nsess; ++i) {
+      if (A.sess[i].host != h) continue;
+      bool child = (A.sess[i].flags & RS_CHILD) != 0;
+      if ((pass == 0 && child) || (pass == 1 && !child && A.sess[i].id != 0)) { if (n < cap) ids[n++] = A.sess[i].id; else set_err(x, E_RSESS_OVERFLOW); }
+    }
+  { int self = rs_find_id(A, a.sid); if (A.sess[self].host == h) { if (n < cap) ids[n++] = (uint16_t)a.sid; else set_err(x, E_RSESS_OVERFLOW); } }
+  if (n == 0) { red_result(x, r, a, T_FALSE); return; }
+  int ok = T_FALSE;
+  for (int k = 0; k < n; ++k) {
+    // TargetedLocalAction.execute: both sessions must still exist (the acting one may have been killed earlier in this loop)
+    int self = rs_find_id(A, a.sid), ti = rs_find_id(A, ids[k]);
+    if (self < 0 || ti < 0) { ok = T_FALSE; break; }
+    int pid = A.sess[ti].pid;
+    int pi = find_proc(x, h, pid);
+    if (pi < 0) { ok = T_FALSE; break; }
+    // StopProcess.kill_process with stop_all: root processes die too
+    Proc p = s->hd[h].procs[pi];
+    int owner = -1, owner_idx = -1;
+    if (s->blue_pid[h] == pid) owner = 0;
+    else if (s->green_pid[h] == pid) owner = 1;
+    else for (int q = 0; q < NRED && owner < 0; ++q)
+      for (int i = 0; i < s->red[q].nsess; ++i)
+        if (s->red[q].sess[i].pid == pid && s->red[q].sess[i].host == h) { owner = 2 + q; owner_idx = i; break; }
+    remove_proc_at(x, h, pi);
+    HostDyn& d = s->hd[h];
+    int si = -1;
+    for (int i = 0; i < d.nsvc; ++i) if (d.svcs[i].pid == pid) { si = i; break; }
+    if (si >= 0) { int np = create_pid(x, h); add_proc(x, h, np, p.kind, p.flags); d.svcs[si].pid = (uint16_t)np; }
+    if (owner == 0 || owner == 1) set_err(x, E_BLUE_GREEN_SESSION_KILLED);
+    else if (owner >= 2) { rs_remove_at(x, owner - 2, owner_idx, true); if (si >= 0) set_err(x, E_UNREACHABLE); }
+    ok = T_TRUE;
+  }
+  red_result(x, r, a, ok);
+}
 CC4_HD void red_execute(Ctx x, int r, const Act& a) {
   switch (a.type) {
     case RA_DRS: red_drs(x, r, a); break;
@@ -981,7 +1031,7 @@ CC4_HD void red_execute(Ctx x, int r, const Act& a) {
     case RA_IMPACT: red_impact(x, r, a); break;
     case RA_DEGRADE: red_degrade(x, r, a); break;
     case RA_INVALID: obs_first(x, r, T_FALSE, RA_NONE, 0, 0); break;
-    case RA_WITHDRAW: set_err(x, E_UNREACHABLE); obs_first(x, r, T_FALSE, RA_NONE, 0, 0); break;
+    case RA_WITHDRAW: red_withdraw(x, r, a); break;
     default: obs_first(x, r, T_UNKNOWN, RA_NONE, 0, 0); break;  // Sleep -> Observation()
   }
 }
@@ -1173,6 +1223,45 @@ CC4_HD Act fsm_get_action(Ctx x, int r) {
   A.fsm_step++;
   return out;
 }
+// RandomSelectRedAgent.get_action (Agents/SimpleAgents/RandomSelectRedAgent.py:33-103): uniform command, then uniform
+// parameters from the ActionSpace entries that are True.  Commands in red_actions order (ESG.py:764-768), parameters in
+// constructor order; a draw is made only when there is more than one option.
+CC4_HD Act random_red_get_action(Ctx x, int r) {
+  RedAgent& A = x.s->red[r];
+  Act out; out.type = RA_SLEEP; out.host = 0; out.arg = 0; out.ticks = 1; out.sid = 0; out.busy = 0;
+  const int nip = popc32(A.as_ip[0]) + popc32(A.as_ip[1]) + popc32(A.as_ip[2]) + popc32(A.as_ip[3]) + popc32(A.as_ip[4]);
+  const int nhn = popc32(A.as_hn[0]) + popc32(A.as_hn[1]) + popc32(A.as_hn[2]) + popc32(A.as_hn[3]) + popc32(A.as_hn[4]);
+  const int nsub = popc32(A.as_subnet), nsid = A.nknown;
+  // valid_commands: a command is listed only if each of its parameters has at least one True option
+  // order: DRS, Aggressive, Stealth, Exploit, PrivEsc, Degrade, DiscoverDeception, Impact, Withdraw, Sleep
+  const uint8_t types[10] = {RA_DRS, RA_AGGR, RA_STEALTH, RA_EXPLOIT, RA_PRIVESC, RA_DEGRADE, RA_DECEPTION, RA_IMPACT, RA_WITHDRAW, RA_SLEEP};
+  uint32_t valid = 0;
+  for (int c = 0; c < 10; ++c) {
+    int t = types[c];
+    bool ok = true;
+    if (t != RA_SLEEP && nsid == 0) ok = false;
+    if (t == RA_DRS && nsub == 0) ok = false;
+    if ((t == RA_AGGR || t == RA_STEALTH || t == RA_EXPLOIT || t == RA_DECEPTION || t == RA_WITHDRAW) && nip == 0) ok = false;
+    if ((t == RA_PRIVESC || t == RA_DEGRADE || t == RA_IMPACT || t == RA_WITHDRAW) && nhn == 0) ok = false;
+    if (ok) valid |= 1u << c;
+  }
+  const int t = types[nth_bit(valid, (int)rng_below(x.r, (uint32_t)popc32(valid)))];
+  auto pick_sid = [&]() { return (int)A.known_sid[rng_below(x.r, (uint32_t)nsid)]; };
+  auto pick_ip = [&]() { return nth_set(A.as_ip, 5, (int)rng_below(x.r, (uint32_t)nip)); };
+  auto pick_hn = [&]() { return nth_set(A.as_hn, 5, (int)rng_below(x.r, (uint32_t)nhn)); };
+  out.type = (uint8_t)t;
+  switch (t) {
+    case RA_DRS: out.arg = (uint8_t)nth_bit(A.as_subnet, (int)rng_below(x.r, (uint32_t)nsub)); out.sid = (uint16_t)pick_sid(); break;
+    case RA_AGGR: case RA_STEALTH: case RA_DECEPTION: out.sid = (uint16_t)pick_sid(); out.host = (uint8_t)pick_ip(); break;
+    case RA_EXPLOIT: out.host = (uint8_t)pick_ip(); out.sid = (uint16_t)pick_sid(); break;
+    case RA_PRIVESC: case RA_DEGRADE: case RA_IMPACT: out.host = (uint8_t)pick_hn(); out.sid = (uint16_t)pick_sid(); break;
+    case RA_WITHDRAW: out.sid = (uint16_t)pick_sid(); out.host = (uint8_t)pick_ip(); out.arg = (uint8_t)pick_hn(); break;
+    default: break;
+  }
+  out.ticks = (uint8_t)red_duration(out.type);
+  A.fsm_step++;   // self.step
+  return out;
+}
 // SimulationController.replace_action_if_invalid (SC:1068-1112) for a red action
 CC4_HD void red_validate(Ctx x, int r, Act& a) {
   RedAgent& A = x.s->red[r];
@@ -1183,6 +1272,7 @@ CC4_HD void red_validate(Ctx x, int r, Act& a) {
   if (!known_sid) ok = false;
   if (a.type == RA_DRS) { if (!((A.as_subnet >> a.arg) & 1u)) ok = false; }
   else if (a.type == RA_PRIVESC || a.type == RA_IMPACT || a.type == RA_DEGRADE) { if (!bit_get(A.as_hn, a.host)) ok = false; }
+  else if (a.type == RA_WITHDRAW) { if (!bit_get(A.as_ip, a.host) || !bit_get(A.as_hn, a.arg)) ok = false; }
   else { if (!bit_get(A.as_ip, a.host)) ok = false; }
   if (!ok) { a.type = RA_INVALID; a.ticks = 1; }
 }
@@ -1281,7 +1371,8 @@ CC4_HD void step_red_policy(Ctx x, int r) {
   RedAgent& A = x.s->red[r];
   Act a; a.type = RA_SLEEP; a.host = 0; a.arg = 0; a.ticks = 1; a.sid = 0; a.busy = 0;
   rng_set_stream(x.r, ST_RED_POL + (uint32_t)r);
-  if (A.active && (x.s->policy & 3) != RP_SLEEP) { a = fsm_get_action(x, r); red_validate(x, r, a); }   // AgentInterface.get_action (:120-143); SleepAgent -> Sleep
+  if (A.active && (x.s->policy & 3) == RP_RANDOM) { a = random_red_get_action(x, r); red_validate(x, r, a); }
+  else if (A.active && (x.s->policy & 3) != RP_SLEEP) { a = fsm_get_action(x, r); red_validate(x, r, a); }   // AgentInterface.get_action (:120-143); SleepAgent -> Sleep
   if (!A.queue.busy) { A.queue = a; A.queue.busy = 1; }
 }
 CC4_HD void step_blue_exec(Ctx x) {
@@ -1369,6 +1460,7 @@ CC4_HD void step_red_exec_agent(Ctx x, int r) {
 // Red actions of different agents commute when they name different hosts (each action reads/writes its own agent's
 // tables, its target host and commutative event bits); DiscoverRemoteSystems only reads the topology.
 CC4_HD bool red_targets_conflict(const EnvState* s) {
+  for (int a = 0; a < NRED; ++a) if (s->rexec[a].type == RA_WITHDRAW) return true;   // kills sessions: keep the serial order
   for (int a = 0; a < NRED; ++a) {
     int ta = s->rexec[a].type;
     if (!(ta >= RA_AGGR && ta <= RA_DEGRADE)) continue;

@@ -401,7 +401,7 @@ size_t cc4_algorithmic_bytes_per_env_step(void) {
 }
 
 int cc4_create(const cc4_config* cfg, cc4_handle** out) {
-  if (!cfg || !out || cfg->num_envs <= 0 || cfg->steps <= 0 || cfg->red_policy < 0 || cfg->red_policy > 2 ||
+  if (!cfg || !out || cfg->num_envs <= 0 || cfg->steps <= 0 || cfg->red_policy < 0 || cfg->red_policy > 3 ||
       cfg->green_policy < 0 || cfg->green_policy > 1) { g_create_err = "cc4_create: bad config"; return -2; }
   int ndev = 0;
   hipError_t e = hipGetDeviceCount(&ndev);

@@ -73,7 +73,7 @@ struct alignas(8) HostStatic {                 // Host.create_backup (Host.py:31
 };
 
 // red sessions (state.sessions[red_agent_k], dict order == array order)
-enum : int { RS_ABSTRACT = 1, RS_ROOT = 2, RS_ORIG = 4 };
+enum : int { RS_ABSTRACT = 1, RS_ROOT = 2, RS_ORIG = 4, RS_CHILD = 8 };   // RS_CHILD: session.parent is not None
 struct alignas(8) RSess { uint16_t id; uint16_t pid; uint8_t host; uint8_t flags; uint8_t kb; uint8_t pad; };
 
 // FSM host states (FiniteStateRedAgent.py:441-452)
@@ -84,7 +84,7 @@ enum : int { RA_DRS = 0, RA_AGGR = 1, RA_STEALTH = 2, RA_DECEPTION = 3, RA_EXPLO
 // blue action types
 enum : int { BA_SLEEP = 0, BA_MONITOR = 1, BA_ANALYSE = 2, BA_REMOVE = 3, BA_RESTORE = 4, BA_DECOY = 5, BA_BLOCK = 6, BA_ALLOW = 7 };
 // built-in policies selectable through EnterpriseScenarioGenerator(red_agent_class=, green_agent_class=)
-enum : int { RP_FSM = 0, RP_SLEEP = 1, RP_DISCOVERY = 2, GP_SLEEP_BIT = 0x10 };
+enum : int { RP_FSM = 0, RP_SLEEP = 1, RP_DISCOVERY = 2, RP_RANDOM = 3, GP_SLEEP_BIT = 0x10 };
 // TernaryEnum (Shared/Enums.py:5-25)
 enum : int { T_TRUE = 1, T_UNKNOWN = 2, T_FALSE = 3, T_IN_PROGRESS = 4 };
 

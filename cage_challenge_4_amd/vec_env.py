@@ -10,7 +10,7 @@ from . import _lib as L
 
 RNG_PCG64 = 0    # numpy Generator(PCG64(SeedSequence(seed))): bit-exact with the reference under the same seed
 RNG_PHILOX = 1   # Philox4x32-10 keyed by seed, counter (draw, stream, step, episode)
-RED_FSM, RED_SLEEP, RED_DISCOVERY = 0, 1, 2     # red_agent_class: FiniteStateRedAgent / SleepAgent / DiscoveryFSRed
+RED_FSM, RED_SLEEP, RED_DISCOVERY, RED_RANDOM = 0, 1, 2, 3   # red_agent_class: FiniteStateRedAgent / SleepAgent / DiscoveryFSRed / RandomSelectRedAgent
 GREEN_ENTERPRISE, GREEN_SLEEP = 0, 1            # green_agent_class: EnterpriseGreenAgent / SleepAgent
 
 ERR_NAMES = {0: 'PROC_OVERFLOW', 1: 'RSESS_OVERFLOW', 2: 'KNOWN_SID_OVERFLOW', 3: 'KNOWLEDGE_BLOCK_OVERFLOW',

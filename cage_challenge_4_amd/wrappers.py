@@ -46,6 +46,10 @@ class FiniteStateRedAgent:
     """CybORG/Agents/SimpleAgents/FiniteStateRedAgent.py:15-550"""
 
 
+class RandomSelectRedAgent:
+    """CybORG/Agents/SimpleAgents/RandomSelectRedAgent.py:8-148 (uniform command + uniform known parameters, incl. Withdraw)"""
+
+
 class DiscoveryFSRed(FiniteStateRedAgent):
     """CybORG/Agents/SimpleAgents/FSMRedVariants.py:80-122 (host-state priorities, prioritise_servers, own probability matrix)"""
 
@@ -63,7 +67,7 @@ class EnterpriseScenarioGenerator:
     def __init__(self, blue_agent_class=None, red_agent_class=None, green_agent_class=None, steps: int = 100):
         if blue_agent_class not in (None, SleepAgent) and getattr(blue_agent_class, '__name__', '') != 'SleepAgent':
             raise NotImplementedError("blue default policy: only SleepAgent (blue actions are submitted through step())")
-        red = {'FiniteStateRedAgent': 0, 'SleepAgent': 1, 'DiscoveryFSRed': 2}
+        red = {'FiniteStateRedAgent': 0, 'SleepAgent': 1, 'DiscoveryFSRed': 2, 'RandomSelectRedAgent': 3}
         green = {'EnterpriseGreenAgent': 0, 'SleepAgent': 1}
         rn, gn = getattr(red_agent_class, '__name__', None), getattr(green_agent_class, '__name__', None)
         if rn not in red or gn not in green:

@@ -7,8 +7,8 @@ import ref_shim  # noqa
 from ref_dump import dump
 from CybORG import CybORG
 from CybORG.Simulator.Scenarios import EnterpriseScenarioGenerator
-from CybORG.Agents import SleepAgent, EnterpriseGreenAgent, FiniteStateRedAgent, DiscoveryFSRed
-RED = {'fsm': (FiniteStateRedAgent, 0), 'sleep': (SleepAgent, 1), 'discovery': (DiscoveryFSRed, 2)}
+from CybORG.Agents import SleepAgent, EnterpriseGreenAgent, FiniteStateRedAgent, DiscoveryFSRed, RandomSelectRedAgent
+RED = {'fsm': (FiniteStateRedAgent, 0), 'sleep': (SleepAgent, 1), 'discovery': (DiscoveryFSRed, 2), 'random': (RandomSelectRedAgent, 3)}
 GREEN = {'enterprise': (EnterpriseGreenAgent, 0), 'sleep': (SleepAgent, 1)}
 from CybORG.Agents.Wrappers import BlueFlatWrapper
 

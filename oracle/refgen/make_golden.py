@@ -15,8 +15,8 @@ sys.path.insert(0, os.path.dirname(__file__))
 import ref_shim  # noqa
 from CybORG import CybORG
 from CybORG.Simulator.Scenarios import EnterpriseScenarioGenerator
-from CybORG.Agents import SleepAgent, EnterpriseGreenAgent, FiniteStateRedAgent, DiscoveryFSRed
-RED = {'fsm': (FiniteStateRedAgent, 0), 'sleep': (SleepAgent, 1), 'discovery': (DiscoveryFSRed, 2)}
+from CybORG.Agents import SleepAgent, EnterpriseGreenAgent, FiniteStateRedAgent, DiscoveryFSRed, RandomSelectRedAgent
+RED = {'fsm': (FiniteStateRedAgent, 0), 'sleep': (SleepAgent, 1), 'discovery': (DiscoveryFSRed, 2), 'random': (RandomSelectRedAgent, 3)}
 GREEN = {'enterprise': (EnterpriseGreenAgent, 0), 'sleep': (SleepAgent, 1)}
 from CybORG.Agents.Wrappers import BlueFlatWrapper
 
@@ -87,6 +87,7 @@ if __name__ == '__main__':
         record(41, 500, 'random', 'ctor', red='discovery')
         record(42, 300, 'random', 'reset', red='sleep')
         record(43, 200, 'random', 'ctor', red='discovery', green='sleep')
+        record(44, 500, 'random', 'ctor', red='random')
         sys.exit(0)
     # BASELINE config 1 (SleepAgent blue, FSM red, 500 steps) + seeded random blue; regression seeds of
     # CybORG/Tests/test_cc4/test_heuristic_agents.py

@@ -48,7 +48,7 @@ def test_hip_policy_variants_match_reference_golden():
     import test_oracle_golden as T
     from cage_challenge_4_amd import CC4VecEnv
     todo = [f for f in (G.load(p) for p in G.list_fixtures()) if f['red_policy'] or f['green_policy']]
-    assert len(todo) >= 3
+    assert len(todo) >= 4
     for fix in todo:
         env, obs = T.replay(CC4VecEnv, fix, red_policy=fix['red_policy'], green_policy=fix['green_policy'])
         assert np.array_equal(obs[0], fix['obs'][0]) and np.array_equal(env.action_mask[0], fix['mask'])
@@ -60,7 +60,7 @@ def test_hip_policy_variants_match_reference_golden():
         env.close()
 
 
-@pytest.mark.parametrize('policies', [(0, 0), (2, 0), (1, 1)], ids=['fsm', 'discovery', 'sleep'])
+@pytest.mark.parametrize('policies', [(0, 0), (2, 0), (1, 1), (3, 0)], ids=['fsm', 'discovery', 'sleep', 'randomselect'])
 @pytest.mark.parametrize('rng_mode', [0, 1], ids=['pcg64', 'philox'])
 def test_hip_matches_oracle_bit_for_bit(rng_mode, policies):
     n, T = 96, 160

@@ -43,11 +43,11 @@ def test_scenario_generator_signature_and_constants():
                                         red_agent_class=W.DiscoveryFSRed)
     assert (sg2.red_policy, sg2.green_policy) == (2, 1)
 
-    class RandomSelectRedAgent:      # not one of the engine's built-in policies
+    class KeyboardAgent:             # not one of the engine's built-in policies
         pass
     with pytest.raises(NotImplementedError):
         W.EnterpriseScenarioGenerator(blue_agent_class=W.SleepAgent, green_agent_class=W.EnterpriseGreenAgent,
-                                      red_agent_class=RandomSelectRedAgent)
+                                      red_agent_class=KeyboardAgent)
 
 
 def test_spaces():
