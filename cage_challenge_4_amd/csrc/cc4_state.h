@@ -52,7 +52,8 @@ enum : uint32_t {
   E_SUS_OVERFLOW = 1u << 4, E_OBS_OVERFLOW = 1u << 5, E_PEND_OVERFLOW = 1u << 6,
   E_STEP_PAST_END = 1u << 7,      // reference raises ValueError (State.py:539-540)
   E_UNREACHABLE = 1u << 8,        // a path the reference would crash on (documented in DESIGN.md)
-  E_BAD_ACTION = 1u << 9, E_BLUE_GREEN_SESSION_KILLED = 1u << 10, E_FSM_NO_HOST = 1u << 11,
+  E_BLUE_GREEN_SESSION_KILLED = 1u << 10,   // a stale sus pid / Withdraw hit a blue or green session process (not modelled)
+  E_FSM_NO_HOST = 1u << 11,                 // FSM agent with no selectable host (reference: choice([]) raises)
 };
 
 struct alignas(4) Proc { uint16_t pid; uint8_t kind; uint8_t flags; };       // flags bit0: user == root
@@ -110,7 +111,6 @@ struct alignas(8) RedAgent {
   uint32_t sess_seen[5];             // work bitmap of fsm_observe
   uint32_t live_hosts[5];            // hosts currently holding >= 1 session of this agent (kept exact by rs_add / rs_remove_at)
   Act queue;                         // actions_in_progress[agent]
-  Act chosen;                        // action produced by the policy this step (scratch)
   uint16_t as_subnet;                // ActionSpace.subnet known bits
   uint16_t fsm_step;
   uint8_t nsess, nknown, fsm_n, nobs;

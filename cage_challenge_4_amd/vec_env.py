@@ -15,7 +15,7 @@ GREEN_ENTERPRISE, GREEN_SLEEP = 0, 1            # green_agent_class: EnterpriseG
 
 ERR_NAMES = {0: 'PROC_OVERFLOW', 1: 'RSESS_OVERFLOW', 2: 'KNOWN_SID_OVERFLOW', 3: 'KNOWLEDGE_BLOCK_OVERFLOW',
              4: 'SUS_OVERFLOW', 5: 'OBS_OVERFLOW', 6: 'PENDING_EVENT_OVERFLOW', 7: 'STEP_PAST_END',
-             8: 'UNREACHABLE_REFERENCE_PATH', 9: 'BAD_ACTION', 10: 'BLUE_GREEN_SESSION_KILLED', 11: 'FSM_NO_HOST'}
+             8: 'UNREACHABLE_REFERENCE_PATH', 10: 'BLUE_GREEN_SESSION_KILLED', 11: 'FSM_NO_HOST'}
 
 
 class CC4VecEnv:

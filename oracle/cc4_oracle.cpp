@@ -120,7 +120,7 @@ int cc4o_layout(char* buf, int cap) {
   F(msg); F(kb_used);
 #undef F
 #define G(m) n += snprintf(buf + n, cap - n, "red." #m " %zu\n", offsetof(RedAgent, m))
-  G(sess); G(known_sid); G(fsm_order); G(fsm_state); G(fsm_hn); G(as_ip); G(as_hn); G(obs); G(queue); G(chosen); G(as_subnet);
+  G(sess); G(known_sid); G(fsm_order); G(fsm_state); G(fsm_hn); G(as_ip); G(as_hn); G(obs); G(queue); G(as_subnet);
   G(fsm_step); G(nsess); G(active); G(obs_success); G(exec_type); G(new_sess_host); G(new_sess_id); G(start_host);
 #undef G
   n += snprintf(buf + n, cap - n, "sizeof.RedAgent %zu\nsizeof.BlueAgent %zu\nsizeof.HostDyn %zu\nsizeof.HostStatic %zu\nsizeof.EnvState %zu\n",
