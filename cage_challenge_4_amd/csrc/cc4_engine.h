@@ -961,14 +961,14 @@ CC4_HD void red_session_check(Ctx x, int r) {
     // own 'red_session_0' (never the case: that one holds id 0 from the start) (RedSessionCheck.py:52-55)
     for (int i = 0; i < A.nsess; ++i) A.sess[i].flags &= (uint8_t)~RS_CHILD;
   }
-  // The observation lists every session (host, Sessions/Interface/System info).  If the session table has not changed
-  // since the last full listing, every host in it is already in the agent's ActionSpace and FSM tables, so the only
-  // thing the FSM still reads from it is "this host has a session" -- served from the cached bitmap instead.
-  if (!A.rsc_dirty) { A.rsc_skipped = 1; return; }
-  for (int w = 0; w < 5; ++w) A.sess_hosts[w] = 0;
+  // The observation lists every session as a hostname-keyed entry with Sessions / Interface{ip, Subnet} / System info.
+  // Instead of materialising one entry per session, its three effects are applied in bulk from RedAgent.live_hosts (the
+  // exact set of hosts in the listing): ActionSpace knowledge here, FSM knowledge in fsm_observe (rsc_listed).
+  A.rsc_listed = 1;
+  if (!A.rsc_dirty) return;      // same session table as at the last listing: nothing new to learn
+  for (int w = 0; w < 5; ++w) { A.as_ip[w] |= A.live_hosts[w]; A.as_hn[w] |= A.live_hosts[w]; }
   for (int i = 0; i < A.nsess; ++i) {
-    bit_set(A.sess_hosts, A.sess[i].host);
-    obs_put(x, r, false, A.sess[i].host, OE_SESS | OE_IFACE | OE_SYSHN, true);
+    A.as_subnet |= (uint16_t)(1u << h_subnet(A.sess[i].host));
     if (A.sess[i].flags & RS_ABSTRACT) as_know_sid(x, r, A.sess[i].id);
   }
   A.rsc_dirty = 0;
@@ -1038,21 +1038,34 @@ CC4_HD void red_execute(Ctx x, int r, const Act& a) {
 
 // ------------------------------------------------------------------ FiniteStateRedAgent (Agents/SimpleAgents/FiniteStateRedAgent.py)
 CC4_HD int fsm_next(int cur, int act, bool success) {
-  // state_transitions_success / _failure (:441-452, :481-492); 0xFF = None (keep)
-  const uint8_t N = 0xFF;
-  const uint8_t succ[9][9] = {
-      {FS_KD, FS_S, FS_S, N, N, N, N, N, N},   {FS_KD, FS_SD, FS_SD, N, N, N, N, N, N},
-      {FS_SD, N, N, FS_S, FS_U, N, N, N, N},   {FS_SD, N, N, FS_SD, FS_UD, N, N, N, N},
-      {FS_UD, N, N, N, N, FS_R, N, N, FS_S},   {FS_UD, N, N, N, N, FS_RD, N, N, FS_SD},
-      {FS_RD, N, N, N, N, N, FS_R, FS_R, FS_S}, {FS_RD, N, N, N, N, N, FS_RD, FS_RD, FS_SD},
-      {FS_F, N, N, N, N, N, N, N, N}};
-  const uint8_t fail[9][9] = {
-      {FS_K, FS_K, FS_K, N, N, N, N, N, N},    {FS_KD, FS_KD, FS_KD, N, N, N, N, N, N},
-      {FS_S, N, N, FS_S, FS_S, N, N, N, N},    {FS_SD, N, N, FS_SD, FS_SD, N, N, N, N},
-      {FS_U, N, N, N, N, FS_U, N, N, FS_U},    {FS_UD, N, N, N, N, FS_UD, N, N, FS_UD},
-      {FS_R, N, N, N, N, N, FS_R, FS_R, FS_R}, {FS_RD, N, N, N, N, N, FS_RD, FS_RD, FS_RD},
-      {FS_F, N, N, N, N, N, N, N, N}};
-  return success ? succ[cur][act] : fail[cur][act];
+  // state_transitions_success / _failure (:441-452, :481-492), one row per state packed as 9 nibbles (column = action index
+  // in action_list order, 0xF = None = keep), selected without a memory table:
+  //   success  K:[KD,S,S,-,-,-,-,-,-] KD:[KD,SD,SD,..] S:[SD,-,-,S,U,..] SD:[SD,-,-,SD,UD,..] U:[UD,-,-,-,-,R,-,-,S]
+  //            UD:[UD,..,RD,-,-,SD] R:[RD,-,-,-,-,-,R,R,S] RD:[RD,..,RD,RD,SD] F:[F,-..]
+  //   failure  every defined entry keeps the current state
+  uint64_t row;
+  if (success) switch (cur) {
+    case FS_K: row = 0xffffff221ull; break;  case FS_KD: row = 0xffffff331ull; break;
+    case FS_S: row = 0xffff42ff3ull; break;  case FS_SD: row = 0xffff53ff3ull; break;
+    case FS_U: row = 0x2ff6ffff5ull; break;  case FS_UD: row = 0x3ff7ffff5ull; break;
+    case FS_R: row = 0x266fffff7ull; break;  case FS_RD: row = 0x377fffff7ull; break;
+    default: row = 0xffffffff8ull; break;
+  } else switch (cur) {
+    case FS_K: row = 0xffffff000ull; break;  case FS_KD: row = 0xffffff111ull; break;
+    case FS_S: row = 0xffff22ff2ull; break;  case FS_SD: row = 0xffff33ff3ull; break;
+    case FS_U: row = 0x4ff4ffff4ull; break;  case FS_UD: row = 0x5ff5ffff5ull; break;
+    case FS_R: row = 0x666fffff6ull; break;  case FS_RD: row = 0x777fffff7ull; break;
+    default: row = 0xffffffff8ull; break;
+  }
+  int v = (int)((row >> (4 * act)) & 0xF);
+  return v == 0xF ? 0xFF : v;
+}
+// (bitmap first, byte store last: with the opposite order hipcc 7.2 -O3 turns the uniform `fsm_step == 0 ? U : K` select
+// feeding the byte store into an s_cselect on a stale SCC in one unrolled copy of the caller's loop -- tools/isa_scan.py
+// checks the built ISA for that pattern)
+CC4_HD void fsm_set_state(RedAgent& A, int h, int st) {
+  if (st >= FS_U && st <= FS_RD) bit_set(A.fsm_ur, h); else bit_clr(A.fsm_ur, h);
+  A.fsm_state[h] = (uint8_t)st;
 }
 CC4_HD void fsm_apply(Ctx x, int r, int h, int act, bool success) {  // _host_state_transition inner loop (:147-167)
   RedAgent& A = x.s->red[r];
@@ -1061,7 +1074,7 @@ CC4_HD void fsm_apply(Ctx x, int r, int h, int act, bool success) {  // _host_st
   int nx = fsm_next(cur, act, success);
   if (nx == FS_U) nx = ((red_allowed_mask(r) >> h_subnet(h)) & 1u) ? FS_U : FS_F;
   if (nx == 0xFF) nx = cur;
-  A.fsm_state[h] = (uint8_t)nx;
+  if (nx != cur) fsm_set_state(A, h, nx);
   if (nx == FS_F && cur != FS_F) {  // leaves known_hosts for good
     int n = 0;
     for (int i = 0; i < A.fsm_n; ++i) if (A.fsm_order[i] != h) A.fsm_order[n++] = A.fsm_order[i];
@@ -1075,11 +1088,9 @@ CC4_HD void fsm_observe(Ctx x, int r) {
     bool ok = A.obs_success == T_TRUE;
     int t = A.obs_act_type;
     if (t == RA_DRS) {
-      for (int i = 0; i < A.fsm_n;) {  // fsm_apply may drop the host from the list (next state 'F')
-        int h = A.fsm_order[i];
-        if (h_subnet(h) == A.obs_act_arg) { fsm_apply(x, r, h, t, ok); if (i < A.fsm_n && A.fsm_order[i] == h) ++i; }
-        else ++i;
-      }
+      // every known host of the pinged subnet (ids subnet*17 .. +16); the order of the per-host transitions is immaterial
+      for (int h = A.obs_act_arg * SLOTS; h < A.obs_act_arg * SLOTS + SLOTS && h < MAXH; ++h)
+        if (bit_get(A.fsm_known, h)) fsm_apply(x, r, h, t, ok);
     } else if (t == RA_PRIVESC || t == RA_IMPACT || t == RA_DEGRADE) {
       int h = A.obs_act_host;  // matched through host_states[ip]['hostname']
       if (A.fsm_state[h] != FS_NONE && bit_get(A.fsm_hn, h)) fsm_apply(x, r, h, t, ok);
@@ -1089,7 +1100,7 @@ CC4_HD void fsm_observe(Ctx x, int r) {
   }
   // 2. _process_new_observations (:190-250)
   uint32_t* sess_seen = A.sess_seen;
-  for (int w = 0; w < 5; ++w) sess_seen[w] = A.rsc_skipped ? A.sess_hosts[w] : 0u;
+  for (int w = 0; w < 5; ++w) sess_seen[w] = 0u;
   for (int i = 0; i < A.nobs; ++i) {
     int h = A.obs[i].host; int f = A.obs[i].flags;
     if (f & OE_SESS) bit_set(sess_seen, h);
@@ -1101,16 +1112,31 @@ CC4_HD void fsm_observe(Ctx x, int r) {
       continue;
     }
     if (A.fsm_state[h] == FS_NONE) {
-      A.fsm_state[h] = (uint8_t)(A.fsm_step == 0 ? FS_U : FS_K);
+      fsm_set_state(A, h, A.fsm_step == 0 ? FS_U : FS_K);
       A.fsm_order[A.fsm_n++] = (uint8_t)h;
+      bit_set(A.fsm_known, h);
     }
     if (hn) bit_set(A.fsm_hn, h);
   }
-  // 3. _session_removal_state_change (:169-188)
-  for (int i = 0; i < A.fsm_n; ++i) {
-    int h = A.fsm_order[i]; int st = A.fsm_state[h];
-    if (st != FS_U && st != FS_UD && st != FS_R && st != FS_RD) continue;
-    if (!bit_get(sess_seen, h)) A.fsm_state[h] = FS_KD;
+  // the RedSessionCheck listing (comes last in the observation's key order): every session host is hostname-known, carries
+  // Sessions, and is new to host_states iff it is not in fsm_known -- added in session (dict) order
+  if (A.rsc_listed) {
+    bool any_new = false;
+    for (int w = 0; w < 5; ++w) { sess_seen[w] |= A.live_hosts[w]; if (A.live_hosts[w] & ~A.fsm_known[w]) any_new = true; }
+    if (any_new)
+      for (int i = 0; i < A.nsess; ++i) {
+        int h = A.sess[i].host;
+        if (bit_get(A.fsm_known, h)) continue;
+        fsm_set_state(A, h, A.fsm_step == 0 ? FS_U : FS_K);
+        A.fsm_order[A.fsm_n++] = (uint8_t)h;
+        bit_set(A.fsm_known, h);
+      }
+    for (int w = 0; w < 5; ++w) A.fsm_hn[w] |= A.live_hosts[w];
+  }
+  // 3. _session_removal_state_change (:169-188): hosts in U/UD/R/RD without a Sessions entry in the observation -> KD
+  for (int w = 0; w < 5; ++w) {
+    uint32_t lost = A.fsm_ur[w] & ~sess_seen[w];
+    while (lost) { int b = ctz32(lost); lost &= lost - 1; fsm_set_state(A, w * 32 + b, FS_KD); }
   }
 }
 // DiscoveryFSRed._choose_host (FiniteStateRedAgent.py:252-293 with FSMRedVariants.py:95-110): host-state priorities
@@ -1407,7 +1433,7 @@ CC4_HD int step_tick_agent(Ctx x, int a) {
   RedAgent& A = s->red[r];
   A.nobs = 0; A.obs_success = 0; A.obs_act_type = RA_NONE; A.new_sess_host = 0xFF;
   for (int w = 0; w < 5; ++w) { A.obs_has[0][w] = 0; A.obs_has[1][w] = 0; }
-  A.rsc_skipped = 0;
+  A.rsc_listed = 0;
   Act& q = A.queue;
   q.ticks--;
   if (q.ticks < 1) { s->rexec[r] = q; q.busy = 0; }

@@ -107,7 +107,8 @@ struct alignas(8) RedAgent {
   uint32_t as_hn[5];                 // ActionSpace.hostname[name] == True
   ObsEnt obs[MAX_OBS];
   uint32_t obs_has[2][5];            // which (key type, host) pairs are already in obs[] this step
-  uint32_t sess_hosts[5];            // hosts listed by the last full RedSessionCheck observation
+  uint32_t fsm_known[5];             // hosts present in host_states (fsm_state != FS_NONE)
+  uint32_t fsm_ur[5];                // hosts whose state is U, UD, R or RD (the ones _session_removal_state_change looks at)
   uint32_t sess_seen[5];             // work bitmap of fsm_observe
   uint32_t live_hosts[5];            // hosts currently holding >= 1 session of this agent (kept exact by rs_add / rs_remove_at)
   Act queue;                         // actions_in_progress[agent]
@@ -123,7 +124,7 @@ struct alignas(8) RedAgent {
   uint16_t new_sess_id;
   uint8_t start_host;                // static per episode
   uint8_t rsc_dirty;                 // session table changed since the last full RedSessionCheck observation
-  uint8_t rsc_skipped;               // this step's RedSessionCheck observation == the cached one (only SESS bits matter)
+  uint8_t rsc_listed;                // this step's observation includes the RedSessionCheck listing of every session
   uint8_t pad[1];
 };
 

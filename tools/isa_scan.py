@@ -1,0 +1,71 @@
+#!/usr/bin/env python
+"""ISA lint for the gfx950 build of cc4_hip.hip.
+
+hipcc (ROCm 7.2, -O3) was seen to lower a wave-uniform `cond ? a : b` whose compare stayed on the VALU
+(v_cmp -> vcc) into an `s_cselect` -- which reads SCC, not VCC -- inside one unrolled copy of a loop in k_step; the
+result depended on whatever SALU compare ran last.  The parity tests caught it on the GPU; this scan catches the
+pattern at build time, without a GPU: every SCC reader (s_cselect / s_cbranch_scc* / s_addc / s_subb / s_cmov) must
+have an SCC writer before it in its straight-line block when a VALU compare (v_cmp) is the only compare in it.
+
+usage: isa_scan.py [file.s]      (no argument: compile cage_challenge_4_amd/csrc/cc4_hip.hip to ISA first)
+"""
+import os
+import re
+import subprocess
+import sys
+import tempfile
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SCC_WRITER = re.compile(r'^\s*s_(cmp|cmpk|and_|or_|xor_|andn2|orn2|nand|nor|xnor|add_|sub_|addc|subb|lshl|lshr|ashr|bfe|min_|max_|'
+                        r'abs|not_|bitcmp|absdiff|wqm|quadmask|bcnt|ff0|ff1|flbit|addk|mulk)')
+SCC_READER = re.compile(r'^\s*s_(cselect|cbranch_scc|addc|subb|cmov)')
+LABEL = re.compile(r'^\.LBB|^[A-Za-z_][\w$.]*:')
+
+
+def scan(text):
+    """Returns [(line_no, reader, context)] for SCC readers whose nearest preceding compare is a VALU compare."""
+    lines = text.split('\n')
+    bad = []
+    for i, l in enumerate(lines):
+        if not SCC_READER.match(l):
+            continue
+        j = i - 1
+        vcmp = None
+        while j >= 0:
+            t = lines[j]
+            if SCC_WRITER.match(t):
+                break                                            # a producer in straight-line code: fine
+            if LABEL.match(t) or re.match(r'^\s*s_c?branch', t):   # reached the top of the block without one
+                if vcmp is not None:
+                    bad.append((i + 1, l.strip(), vcmp))
+                break
+            if vcmp is None and re.match(r'^\s*v_cmp', t):
+                vcmp = t.strip()
+            j -= 1
+    return bad
+
+
+def compile_isa(out):
+    hipcc = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
+    src = os.path.join(ROOT, 'cage_challenge_4_amd', 'csrc', 'cc4_hip.hip')
+    subprocess.check_call([hipcc, '--offload-arch=gfx950', '-O3', '-std=c++17', '-ffp-contract=off', '-S', '--cuda-device-only',
+                           '-o', out, src], stderr=subprocess.DEVNULL)
+
+
+def main():
+    if len(sys.argv) > 1:
+        text = open(sys.argv[1]).read()
+    else:
+        with tempfile.TemporaryDirectory() as d:
+            p = os.path.join(d, 'cc4.s')
+            compile_isa(p)
+            text = open(p).read()
+    bad = scan(text)
+    for b in bad:
+        print('SCC read after VALU compare: line %d: %s   <<  %s' % b)
+    print('isa_scan: %d suspicious SCC reads' % len(bad))
+    return 1 if bad else 0
+
+
+if __name__ == '__main__':
+    sys.exit(main())
