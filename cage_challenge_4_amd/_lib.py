@@ -7,7 +7,7 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'libcc4.so')
+LIB_PATH = os.environ.get('CC4_LIB') or os.path.join(_HERE, 'libcc4.so')   # CC4_LIB: another build of the same library (kernel experiments)
 
 OBS_PER_ENV = 578
 MASK_PER_ENV = 570

@@ -9,13 +9,18 @@
 
 namespace cc4 {
 
-struct Ctx { EnvState* s; EnvCold* c; Rng* r; unsigned long long* prof = nullptr; };
+struct Ctx { EnvState* s; EnvCold* c; Rng* r; unsigned long long* prof = nullptr; unsigned long long* aprof = nullptr; };
 
 // optional phase timing (device only, debug builds of the kernel pass a buffer): prof[i] += cycles since last tick
 #if defined(__HIP_DEVICE_COMPILE__)
 #define CC4_TICK(x, i) do { if ((x).prof) { unsigned long long _t = clock64(); (x).prof[(i)] += _t - (x).prof[15]; (x).prof[15] = _t; } } while (0)
 #define CC4_TICK0(x) do { if ((x).prof) (x).prof[15] = clock64(); } while (0)
+// per-red-agent section timers (Ctx.aprof = that agent's 8 slots of the debug buffer)
+#define CC4_AT0(x) unsigned long long _at = (x).aprof ? clock64() : 0
+#define CC4_AT(x, k) do { if ((x).aprof) { unsigned long long _n = clock64(); (x).aprof[(k)] += _n - _at; _at = _n; } } while (0)
 #else
+#define CC4_AT0(x) do { } while (0)
+#define CC4_AT(x, k) do { } while (0)
 #define CC4_TICK(x, i) do { } while (0)
 #define CC4_TICK0(x) do { } while (0)
 #endif
@@ -179,20 +184,20 @@ CC4_HD int rs_find_id(const RedAgent& a, int id) {
   for (int i = 0; i < a.nsess; ++i) if (a.sess[i].id == id) return i;
   return -1;
 }
-CC4_HD int kb_alloc(Ctx x) {
+CC4_HD int kb_alloc(Ctx x, int r) {
   for (int w = 0; w < MAX_KB / 32; ++w) {
-    uint32_t free_bits = ~x.s->kb_used[w];
+    uint32_t free_bits = ~x.s->kb_used[r][w];
     if (!free_bits) continue;
     int i = w * 32 + ctz32(free_bits);
-    x.s->kb_used[w] |= 1u << (i & 31);
-    uint64_t* row = reinterpret_cast<uint64_t*>(x.c->kports[i]);   // 144-byte rows, 8-byte aligned
+    x.s->kb_used[r][w] |= 1u << (i & 31);
+    uint64_t* row = reinterpret_cast<uint64_t*>(x.c->kports[r * MAX_KB + i]);   // 144-byte rows, 8-byte aligned
     for (int k = 0; k < (MAXH + 7) / 8; ++k) row[k] = 0;
     return i;
   }
   set_err(x, E_KB_OVERFLOW);
   return 0xFF;
 }
-CC4_HD void kb_free(Ctx x, int kb) { if (kb != 0xFF) x.s->kb_used[kb >> 5] &= ~(1u << (kb & 31)); }
+CC4_HD void kb_free(Ctx x, int r, int kb) { if (kb != 0xFF) x.s->kb_used[r][kb >> 5] &= ~(1u << (kb & 31)); }
 // State.add_session (Simulator/State.py:305-324): ident = max(existing)+1 (0 if none); appended (dict order)
 CC4_HD int rs_add(Ctx x, int r, int host, int pid, int flags) {
   RedAgent& a = x.s->red[r];
@@ -200,7 +205,7 @@ CC4_HD int rs_add(Ctx x, int r, int host, int pid, int flags) {
   int id = 0;
   for (int i = 0; i < a.nsess; ++i) if (a.sess[i].id + 1 > id) id = a.sess[i].id + 1;
   RSess q; q.id = (uint16_t)id; q.pid = (uint16_t)pid; q.host = (uint8_t)host; q.flags = (uint8_t)flags; q.pad = 0;
-  q.kb = (flags & RS_ABSTRACT) ? (uint8_t)kb_alloc(x) : (uint8_t)0xFF;
+  q.kb = (flags & RS_ABSTRACT) ? (uint8_t)kb_alloc(x, r) : (uint8_t)0xFF;
   a.sess[a.nsess++] = q;
   a.rsc_dirty = 1;
   if (!bit_get(a.live_hosts, host)) { bit_set(a.live_hosts, host); a.nlive++; }
@@ -209,7 +214,7 @@ CC4_HD int rs_add(Ctx x, int r, int host, int pid, int flags) {
 }
 CC4_HD void rs_remove_at(Ctx x, int r, int idx, bool free_kb) {
   RedAgent& a = x.s->red[r];
-  if (free_kb) kb_free(x, a.sess[idx].kb);
+  if (free_kb) kb_free(x, r, a.sess[idx].kb);
   int gone = a.sess[idx].host;
   for (int i = idx; i + 1 < a.nsess; ++i) a.sess[i] = a.sess[i + 1];
   a.nsess--;
@@ -233,12 +238,18 @@ CC4_HD void rs_move_to_end(RedAgent& a, int idx, int new_id) {
   a.rsc_dirty = 1;
 }
 CC4_HD bool red_has_session_on(const RedAgent& a, int h) { return bit_get(a.live_hosts, h); }
+CC4_HD bool sid_known(const RedAgent& a, int id) {
+  if (id < 256) return bit_get(a.known_bm, id);
+  for (int i = 0; i < a.nknown; ++i) if (a.known_sid[i] == id) return true;
+  return false;
+}
 // ActionSpace.update: server_session[session_id] = True (Shared/ActionSpace.py:205-211)
 CC4_HD void as_know_sid(Ctx x, int r, int id) {
   RedAgent& a = x.s->red[r];
-  for (int i = 0; i < a.nknown; ++i) if (a.known_sid[i] == id) return;
+  if (sid_known(a, id)) return;
   if (a.nknown >= MAX_KS) { set_err(x, E_KS_OVERFLOW); return; }
   a.known_sid[a.nknown++] = (uint16_t)id;
+  if (id < 256) bit_set(a.known_bm, id);
 }
 // one key of the agent's step observation (Shared/Observation.py add_* / combine_obs); also applies the
 // ActionSpace.update side effects (ip / hostname / subnet known) eagerly -- nothing reads them before step end.
@@ -373,7 +384,7 @@ CC4_HD void env_reset(Ctx x, uint64_t seed, int rng_mode, int steps, bool contin
     int q = steps / 3, rem = steps % 3;
     s->phase_len[0] = q + (rem >= 1 ? 1 : 0); s->phase_len[1] = q + (rem == 2 ? 1 : 0); s->phase_len[2] = q;
   }
-  for (int i = 0; i < MAX_KB / 32; ++i) s->kb_used[i] = 0;
+  for (int r = 0; r < NRED; ++r) for (int i = 0; i < MAX_KB / 32; ++i) s->kb_used[r][i] = 0;
   {  // backup images of the previous episode
     uint32_t* w = (uint32_t*)x.c->hs;
     for (size_t i = 0; i < sizeof(x.c->hs) / 4; ++i) w[i] = 0;
@@ -777,7 +788,7 @@ CC4_HD void red_scan(Ctx x, int r, const Act& a, double rate) {
   }
   if (ports) {
     obs_put(x, r, true, tgt, OE_IFACE, false);
-    if (A.sess[si].kb != 0xFF) x.c->kports[A.sess[si].kb][tgt] = (uint8_t)(PB_HAS | ports);
+    if (A.sess[si].kb != 0xFF) x.c->kports[r * MAX_KB + A.sess[si].kb][tgt] = (uint8_t)(PB_HAS | ports);
   }
   red_result(x, r, a, T_TRUE);
 }
@@ -795,7 +806,7 @@ CC4_HD void red_exploit(Ctx x, int r, const Act& a) {
   int si = rs_find_id(A, a.sid);
   if (si < 0 || !(A.sess[si].flags & RS_ABSTRACT) || A.sess[si].kb == 0xFF) { red_result(x, r, a, T_FALSE); return; }
   int src = A.sess[si].host, tgt = a.host;
-  int known = x.c->kports[A.sess[si].kb][tgt];
+  int known = x.c->kports[r * MAX_KB + A.sess[si].kb][tgt];
   if (!(known & PB_HAS)) { red_result(x, r, a, T_FALSE); return; }
   if (subnet_blocked(x, h_subnet(src), h_subnet(tgt))) { red_result(x, r, a, T_FALSE); return; }
   // DefaultExploitActionSelector: options in list order with non-zero weight
@@ -954,7 +965,8 @@ CC4_HD void red_session_check(Ctx x, int r) {
   RedAgent& A = s->red[r];
   obs_first(x, r, T_TRUE, RA_NONE, 0, 0);
   if (A.nsess == 0) return;
-  if (rs_find_id(A, 0) < 0) {
+  // the primary (id 0) sits first, or last after a promotion / restore re-insert: look there before scanning
+  if (A.sess[0].id != 0 && A.sess[A.nsess - 1].id != 0 && rs_find_id(A, 0) < 0) {
     int c = (int)rng_below(x.r, (uint32_t)A.nsess);
     rs_move_to_end(A, c, 0);   // active_sessions.pop(old_id); ident = 0; re-inserted last (RedSessionCheck.py:36-45)
     // every other session's parent becomes new_primary.name, which is None unless the promoted session is the scenario's
@@ -1083,6 +1095,7 @@ CC4_HD void fsm_apply(Ctx x, int r, int h, int act, bool success) {  // _host_st
 }
 CC4_HD void fsm_observe(Ctx x, int r) {
   RedAgent& A = x.s->red[r];
+  CC4_AT0(x);
   // 1. _host_state_transition (:124-167)
   if (A.obs_act_type <= RA_WITHDRAW && A.obs_success != T_IN_PROGRESS && A.obs_success != 0) {
     bool ok = A.obs_success == T_TRUE;
@@ -1098,6 +1111,7 @@ CC4_HD void fsm_observe(Ctx x, int r) {
       fsm_apply(x, r, A.obs_act_host, t, ok);
     }
   }
+  CC4_AT(x, 3);
   // 2. _process_new_observations (:190-250)
   uint32_t* sess_seen = A.sess_seen;
   for (int w = 0; w < 5; ++w) sess_seen[w] = 0u;
@@ -1118,6 +1132,7 @@ CC4_HD void fsm_observe(Ctx x, int r) {
     }
     if (hn) bit_set(A.fsm_hn, h);
   }
+  CC4_AT(x, 4);
   // the RedSessionCheck listing (comes last in the observation's key order): every session host is hostname-known, carries
   // Sessions, and is new to host_states iff it is not in fsm_known -- added in session (dict) order
   if (A.rsc_listed) {
@@ -1133,11 +1148,13 @@ CC4_HD void fsm_observe(Ctx x, int r) {
       }
     for (int w = 0; w < 5; ++w) A.fsm_hn[w] |= A.live_hosts[w];
   }
+  CC4_AT(x, 5);
   // 3. _session_removal_state_change (:169-188): hosts in U/UD/R/RD without a Sessions entry in the observation -> KD
   for (int w = 0; w < 5; ++w) {
     uint32_t lost = A.fsm_ur[w] & ~sess_seen[w];
     while (lost) { int b = ctz32(lost); lost &= lost - 1; fsm_set_state(A, w * 32 + b, FS_KD); }
   }
+  CC4_AT(x, 6);
 }
 // DiscoveryFSRed._choose_host (FiniteStateRedAgent.py:252-293 with FSMRedVariants.py:95-110): host-state priorities
 // {K,KD,S,SD: 20, U,UD: 10, R,RD: 0} and prioritise_servers.  The float arithmetic restates the Python expressions
@@ -1293,9 +1310,7 @@ CC4_HD void red_validate(Ctx x, int r, Act& a) {
   RedAgent& A = x.s->red[r];
   if (a.type >= RA_SLEEP) return;
   bool ok = true;
-  bool known_sid = false;
-  for (int i = 0; i < A.nknown; ++i) if (A.known_sid[i] == a.sid) known_sid = true;
-  if (!known_sid) ok = false;
+  if (!sid_known(A, a.sid)) ok = false;
   if (a.type == RA_DRS) { if (!((A.as_subnet >> a.arg) & 1u)) ok = false; }
   else if (a.type == RA_PRIVESC || a.type == RA_IMPACT || a.type == RA_DEGRADE) { if (!bit_get(A.as_hn, a.host)) ok = false; }
   else if (a.type == RA_WITHDRAW) { if (!bit_get(A.as_ip, a.host) || !bit_get(A.as_hn, a.arg)) ok = false; }
@@ -1365,7 +1380,7 @@ CC4_HD bool step_phase(Ctx x) {
     if (ph > s->phase) s->phase = ph;
   }
   rng_begin_step(&s->rng, (uint32_t)s->step_count);
-  s->action_cost = 0.f; s->brm = 0; s->n_restore = 0; s->any_phish = 0;
+  s->action_cost = 0.f; s->brm = 0; s->n_restore = 0;
   s->n_actions = NBLUE + s->n_green + NRED;   // minus the actions filter_actions drops (step_tick_agent)
   return true;
 }
@@ -1398,7 +1413,7 @@ CC4_HD void step_red_policy(Ctx x, int r) {
   Act a; a.type = RA_SLEEP; a.host = 0; a.arg = 0; a.ticks = 1; a.sid = 0; a.busy = 0;
   rng_set_stream(x.r, ST_RED_POL + (uint32_t)r);
   if (A.active && (x.s->policy & 3) == RP_RANDOM) { a = random_red_get_action(x, r); red_validate(x, r, a); }
-  else if (A.active && (x.s->policy & 3) != RP_SLEEP) { a = fsm_get_action(x, r); red_validate(x, r, a); }   // AgentInterface.get_action (:120-143); SleepAgent -> Sleep
+  else if (A.active && (x.s->policy & 3) != RP_SLEEP) { a = fsm_get_action(x, r); CC4_AT0(x); red_validate(x, r, a); CC4_AT(x, 7); }   // AgentInterface.get_action (:120-143); SleepAgent -> Sleep
   if (!A.queue.busy) { A.queue = a; A.queue.busy = 1; }
 }
 CC4_HD void step_blue_exec(Ctx x) {
@@ -1416,6 +1431,18 @@ CC4_HD void step_blue_exec(Ctx x) {
       blue_execute(x, b, s->bexec[b]);
     }
   CC4_TICK(x, 5);
+}
+// One blue agent's action on its own generator stream.  Blue agents own disjoint zones: their actions touch only hosts of the
+// zone, the session table of the zone's red agent and commutative shared bits, so in the counter-based RNG mode they can be
+// resolved concurrently -- except Monitor, which edits the shared pending-event list (step_blue_exec keeps the serial order).
+CC4_HD void step_blue_exec_agent(Ctx x, int b) {
+  rng_set_stream(x.r, ST_BLUE_EXE + (uint32_t)b);
+  blue_execute(x, b, x.s->bexec[b]);
+}
+CC4_HD bool blue_exec_independent(const EnvState* s) {
+  if (s->npend) return false;
+  for (int b = 0; b < NBLUE; ++b) if (s->bexec[b].type == BA_MONITOR) return false;
+  return true;
 }
 // duration queue of one agent (SC:251-265): a = 0..4 blue, 5..10 red.  Returns 1 if the agent's action was dropped by
 // filter_actions (SC:466-485: it names a dead session)
@@ -1452,23 +1479,28 @@ CC4_HD int step_green_exec(Ctx x, int g) {
   EnvState* s = x.s;
   int gh = s->green_host[g];
   int own = h_subnet(gh);
-  s->phish_req[g] = 0;
   rng_set_stream(x.r, ST_GREEN_EXE + (uint32_t)g);
   if (s->green_act[g] == 0) return green_access_service(x, gh) ? 0 : reward_table(s->phase, own, RW_ASF);
   if (s->green_act[g] == 1) {
     bool want_phish = false;
     bool ok = green_local_work(x, gh, &want_phish);
-    s->phish_req[g] = (uint8_t)want_phish;
-    if (want_phish) s->any_phish = 1;
+    if (want_phish) bit_set_shared(s->phish_mask, g);   // green agents may be resolved on different lanes
     return ok ? 0 : reward_table(s->phase, own, RW_LWF);
   }
   return 0;
 }
 CC4_HD void step_phishing(Ctx x) {
   EnvState* s = x.s;
-  if (!s->any_phish) return;
-  for (int g = 0; g < s->n_green; ++g)
-    if (s->phish_req[g]) { rng_set_stream(x.r, ST_GREEN_PHISH + (uint32_t)g); phishing(x, s->green_host[g]); s->phish_req[g] = 0; }
+  for (int w = 0; w < 3; ++w) {   // green agent order
+    uint32_t m = s->phish_mask[w];
+    if (!m) continue;
+    s->phish_mask[w] = 0;
+    while (m) {
+      int g = w * 32 + ctz32(m); m &= m - 1;
+      rng_set_stream(x.r, ST_GREEN_PHISH + (uint32_t)g);
+      phishing(x, s->green_host[g]);
+    }
+  }
 }
 // true if red agent r holds a session outside its allowed subnets (work for different_subnet_agent_reassignment)
 CC4_HD bool red_has_foreign_session(const EnvState* s, int r) {
@@ -1560,7 +1592,7 @@ CC4_HD void env_step(Ctx x, const int32_t* actions, const uint8_t* messages /* [
   step_tick(x);
   for (int g = 0; g < s->n_green; ++g) {
     s->brm += step_green_exec(x, g);
-    if (s->phish_req[g]) { rng_set_stream(x.r, ST_GREEN_PHISH + (uint32_t)g); phishing(x, s->green_host[g]); s->phish_req[g] = 0; }
+    if (bit_get(s->phish_mask, g)) { bit_clr(s->phish_mask, g); rng_set_stream(x.r, ST_GREEN_PHISH + (uint32_t)g); phishing(x, s->green_host[g]); }
   }
   CC4_TICK(x, 6);
   step_red_exec(x);

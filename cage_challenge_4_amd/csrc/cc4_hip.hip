@@ -22,6 +22,7 @@ using namespace cc4;
 static_assert(sizeof(EnvState) % 16 == 0, "EnvState rows are staged with 16-byte accesses");
 constexpr int ROW_VEC = (int)(sizeof(EnvState) / 16);
 constexpr int WAVE = 64;
+constexpr int PROF_SLOTS = 64;
 
 struct StepArgs {
   EnvState* st; EnvCold* cold;
@@ -31,7 +32,7 @@ struct StepArgs {
   int32_t* rand_out;           // when non-null: draw the blue actions in-kernel (k_random_actions fused) and record them here
   uint64_t rand_seed0; uint32_t rand_t;
   int n, autoreset, steps, rng_mode, policy;
-  unsigned long long* prof;   // optional [n][16] cycle counters (CC4_PROFILE builds / cc4_debug_profile)
+  unsigned long long* prof;   // optional [n][PROF_SLOTS] cycle counters (cc4_debug_profile): 16 phase slots + 8 per red agent
 };
 
 // uniform blue action index of (episode e, agent b) at step t: Philox key (seed0 + e), counter (t, b, 0xB10E, 0)
@@ -111,7 +112,7 @@ __global__ __launch_bounds__(WAVE) void k_step(StepArgs a) {
         step_tick(x);
         for (int g = 0; g < s->n_green; ++g) {
           s->brm += step_green_exec(x, g);
-          if (s->phish_req[g]) { phishing(x, s->green_host[g]); s->phish_req[g] = 0; }
+          if (bit_get(s->phish_mask, g)) { bit_clr(s->phish_mask, g); phishing(x, s->green_host[g]); }
         }
         CC4_TICK(x, 6);
         step_red_exec(x);
@@ -146,7 +147,7 @@ __global__ __launch_bounds__(WAVE) void k_step(StepArgs a) {
   for (int i = lane; i < OBS_TOTAL; i += WAVE) o[i] = obs_lds[i];
   if (a.obs8) { uint8_t* o8 = a.obs8 + (size_t)e * OBS_TOTAL; for (int i = lane; i < OBS_TOTAL; i += WAVE) o8[i] = obs_lds[i]; }
   if (prof && lane == 0) { prof[13] += clock64() - t_out; prof[14] += clock64() - t_begin; }
-  if (prof) { __syncthreads(); if (lane < 15) a.prof[16 * (size_t)e + lane] += prof_lds[lane]; }
+  if (prof) { __syncthreads(); if (lane < 15) a.prof[PROF_SLOTS * (size_t)e + lane] += prof_lds[lane]; }
 }
 
 // ---------------------------------------------------------------- Philox mode: wave- and lane-parallel step
@@ -168,7 +169,7 @@ constexpr int PT = PW * WAVE;      // 384 threads
 constexpr int RNG_SLOTS = 8;       // 6 red agents + thread 0 (ordered sections); green agents use thread-private generators
 
 __device__ __forceinline__ void stage_in_n(uint4* __restrict__ lds, const uint4* __restrict__ src, int tid) {
-  constexpr int U = 6;
+  constexpr int U = (ROW_VEC / PT) < 6 ? (ROW_VEC / PT) : 6;   // loads in flight per thread (the whole row in one or two rounds)
   int i = tid;
   for (; i + (U - 1) * PT < ROW_VEC; i += U * PT) {
     uint4 v[U];
@@ -215,12 +216,13 @@ __global__ __launch_bounds__(PT) void k_step_philox(StepArgs a) {
       Ctx x0{s, a.cold + e, &rngs[6], tid == 0 ? prof : nullptr};               // thread 0
       const int ragent = lane * PW + wave;                                        // lanes 0..(6/PW-1) of each wave own a red agent
       const bool is_red = lane < (NRED + PW - 1) / PW && ragent < NRED;
-      Ctx xr{s, a.cold + e, &rngs[is_red ? ragent : 0], nullptr};
+      unsigned long long* ap = (a.prof && is_red) ? a.prof + PROF_SLOTS * (size_t)e + 16 + 8 * ragent : nullptr;
+      Ctx xr{s, a.cold + e, &rngs[is_red ? ragent : 0], nullptr, ap};
       (void)slot;
       // ---- P0 blue submissions (wave 0 lanes 1..5) | P2 red FSM policy r on wave r lane 0 | P1 green draws on lanes >= 8
       if (is_red) rng_fork(&rngs[ragent], &s->rng, ST_RESET);
       if (tid == 0) rng_fork(&rngs[6], &s->rng, ST_RESET);
-      if (is_red) step_red_policy(xr, ragent);
+      if (is_red) { unsigned long long t0 = ap ? clock64() : 0; step_red_policy(xr, ragent); if (ap) ap[0] += clock64() - t0; }
       else if (wave == PW - 1 && lane >= 2 && lane < 2 + NBLUE) {
         const int b = lane - 2;
         int32_t act = a.actions ? a.actions[e * NBLUE + b] : -1;
@@ -242,8 +244,16 @@ __global__ __launch_bounds__(PT) void k_step_philox(StepArgs a) {
       // ---- P3 duration queues, one agent per lane of wave 0; then blue execution in priority/agent order on thread 0
       if (wave == 0 && lane < NBLUE + NRED && step_tick_agent(x0, lane)) atomicSub(&s->n_actions, 1);
       __syncthreads();
-      if (tid == 0) step_blue_exec(x0);
-      __syncthreads();
+      if (blue_exec_independent(s)) {      // uniform: every thread reads the same five action types
+        if (tid == 0) CC4_TICK(x0, 3);
+        const int bagent = lane * PW + wave;                                      // blue agent b on wave b % PW, lane b / PW
+        if (lane < (NBLUE + PW - 1) / PW && bagent < NBLUE) { Ctx xb{s, a.cold + e, &rngs[bagent], nullptr}; step_blue_exec_agent(xb, bagent); }
+        __syncthreads();
+        if (tid == 0) CC4_TICK(x0, 5);
+      } else {
+        if (tid == 0) step_blue_exec(x0);
+        __syncthreads();
+      }
       // ---- P4 green actions: wave 0 = AccessService list, wave 1 = LocalWork list (uniform control flow per wave)
       if (wave < 2) {
         int pen = 0;
@@ -255,8 +265,6 @@ __global__ __launch_bounds__(PT) void k_step_philox(StepArgs a) {
           pen += step_green_exec(xg, g);
         }
         if (pen) atomicAdd(&s->brm, pen);
-      } else if (wave == 2) {
-        for (int g = lane; g < ng; g += WAVE) if (s->green_act[g] == 2) s->phish_req[g] = 0;   // Sleep: step_green_exec's reset
       }
       __syncthreads();
       CC4_TICK(x0, 6);
@@ -264,7 +272,7 @@ __global__ __launch_bounds__(PT) void k_step_philox(StepArgs a) {
       if (tid == 0) { step_phishing(x0); CC4_TICK(x0, 1); conflict_lds = red_targets_conflict(s) ? 1 : 0; if (prof && conflict_lds) prof[4] += 1000000; }
       __syncthreads();
       if (conflict_lds) { if (tid == 0) for (int r = 0; r < NRED; ++r) step_red_exec_agent(x0, r); }
-      else if (is_red) step_red_exec_agent(xr, ragent);
+      else if (is_red) { unsigned long long t0 = ap ? clock64() : 0; step_red_exec_agent(xr, ragent); if (ap) ap[1] += clock64() - t0; }
       __syncthreads();
       if (tid == 0) { step_red_merge(x0); CC4_TICK(x0, 7); }
       // ---- reassignment: foreign-session scan per agent, the (rare) moves on thread 0
@@ -278,7 +286,7 @@ __global__ __launch_bounds__(PT) void k_step_philox(StepArgs a) {
       __syncthreads();
       CC4_TICK(x0, 9);
       // ---- P8 end-turn RedSessionCheck, one red agent per wave
-      if (is_red) step_rsc(xr, ragent);
+      if (is_red) { unsigned long long t0 = ap ? clock64() : 0; step_rsc(xr, ragent); if (ap) ap[2] += clock64() - t0; }
       __syncthreads();
       CC4_TICK(x0, 10);
       if (tid == 0) step_end(x0, a.msgs ? a.msgs + e * NBLUE * MSG_LEN : nullptr);
@@ -297,7 +305,7 @@ __global__ __launch_bounds__(PT) void k_step_philox(StepArgs a) {
   for (int i = tid; i < OBS_TOTAL; i += PT) o[i] = obs_lds[i];
   if (a.obs8) { uint8_t* o8 = a.obs8 + (size_t)e * OBS_TOTAL; for (int i = tid; i < OBS_TOTAL; i += PT) o8[i] = obs_lds[i]; }
   if (prof && tid == 0) { prof[13] += clock64() - t_out; prof[14] += clock64() - t_begin; }
-  if (prof) { __syncthreads(); if (tid < 15) a.prof[16 * (size_t)e + tid] += prof_lds[tid]; }
+  if (prof) { __syncthreads(); if (tid < 15) a.prof[PROF_SLOTS * (size_t)e + tid] += prof_lds[tid]; }
 }
 
 struct ResetArgs {
@@ -615,10 +623,10 @@ int cc4_get_topology(cc4_handle* h, int32_t env, uint8_t* out) {
   return rc;
 }
 
-// debug: enable (buf != NULL first call allocates) / read per-episode phase cycle counters [N][16]
+// debug: enable (buf != NULL first call allocates) / read per-episode cycle counters [N][64] (16 phase slots, then 8 per red agent)
 int cc4_debug_profile(cc4_handle* h, int enable, unsigned long long* out) {
   HIPCHK(h, hipSetDevice(h->cfg.device_id));
-  size_t bytes = (size_t)h->cfg.num_envs * 16 * sizeof(unsigned long long);
+  size_t bytes = (size_t)h->cfg.num_envs * PROF_SLOTS * sizeof(unsigned long long);
   if (enable && !h->d_prof) { HIPCHK(h, hipMalloc(&h->d_prof, bytes)); HIPCHK(h, hipMemsetAsync(h->d_prof, 0, bytes, h->stream)); }
   if (out && h->d_prof) { HIPCHK(h, hipMemcpyAsync(out, h->d_prof, bytes, hipMemcpyDeviceToHost, h->stream)); HIPCHK(h, hipStreamSynchronize(h->stream)); }
   if (!enable && h->d_prof) { (void)hipFree(h->d_prof); h->d_prof = nullptr; }

@@ -23,7 +23,7 @@ enum : int {
   MAXSV = 9,            // service kinds per host (5 real + 4 decoy names)
   MAX_RS = 64,          // sessions per red agent
   MAX_KS = 96,          // known server-session ids per red agent (ActionSpace.server_session)
-  MAX_KB = 128,         // port-knowledge blocks (one per live RedAbstractSession)
+  MAX_KB = 64,          // port-knowledge blocks per red agent (one per live RedAbstractSession; = MAX_RS)
   MAX_SUS = 192,        // sus pid entries per blue agent (VelociraptorServer.sus_pids)
   MAX_OBS = 112,        // red observation entries per agent per step
   MAX_PEND = 24,        // process_creation events carrying a pid, per step
@@ -99,6 +99,7 @@ struct alignas(2) ObsEnt { uint8_t host; uint8_t flags; };
 struct alignas(8) RedAgent {
   RSess sess[MAX_RS];
   uint16_t known_sid[MAX_KS];        // ActionSpace.server_session keys with value True, insertion order
+  uint32_t known_bm[8];              // the same set as a bitmap over ids 0..255 (larger ids fall back to the list scan)
   uint8_t fsm_order[MAXH];           // host_states dict insertion order, restricted to hosts whose state is not 'F'
                                      // ('F' is absorbing and excluded from known_hosts, FiniteStateRedAgent.py:114)
   uint8_t fsm_state[MAXH];           // FS_* or FS_NONE
@@ -160,7 +161,7 @@ struct alignas(16) EnvState {
   BlueAgent blue[NBLUE];
   RedAgent red[NRED];
   uint8_t msg[NBLUE][MSG_LEN];       // messages submitted with the last step
-  uint32_t kb_used[MAX_KB / 32];
+  uint32_t kb_used[NRED][MAX_KB / 32];   // per agent, so agents resolved on different waves allocate independently and in the same order as a serial walk
   uint32_t red_hosts[5];             // hosts holding a session of ANY red agent (OR of RedAgent.live_hosts, kept incrementally)
   uint32_t pad3[3];
   // per-step scratch shared by the phases of a step (the lane-parallel kernel hands work between lanes through it)
@@ -169,11 +170,10 @@ struct alignas(16) EnvState {
   int32_t brm;                       // BlueRewardMachine accumulator
   float action_cost;
   int32_t n_actions;                 // actions surviving filter_actions (length of the shuffled index list)
-  uint8_t phish_req[MAXG];           // green g's LocalWork asked for a PhishingEmail this step
+  uint32_t phish_mask[4];            // bit g: green g's LocalWork asked for a PhishingEmail this step (word 3 unused)
   int32_t n_restore;                 // Restore actions submitted this step (each costs -1)
   uint32_t scratch[64];              // work area of the ordered (lane 0) sections: small temporaries that would otherwise
                                      // be dynamically indexed private arrays (= scratch memory on the device)
-  int32_t any_phish;                 // some phish_req[] is set
 };
 
 struct alignas(16) EnvCold {
@@ -182,7 +182,7 @@ struct alignas(16) EnvCold {
   HostStatic hs[MAXH];               // backup images (Host.create_backup): read by Restore and reset only
   uint8_t hs_pad[8];                 // keeps eph[] 16-byte aligned (137 * 56 + 8 = 7680)
   uint32_t eph[MAXH][EPH_WORDS];     // Host.ephemeral_ports as a bitmap (port-49152)
-  uint8_t kports[MAX_KB][MAXH + 7];  // RedAbstractSession.ports[ip]: PB_* bits | PB_HAS
+  uint8_t kports[NRED * MAX_KB][MAXH + 7];  // RedAbstractSession.ports[ip]: PB_* bits | PB_HAS; row = agent * MAX_KB + RSess.kb
 };
 
 }  // namespace cc4

@@ -5,8 +5,7 @@ import sys, os, ctypes
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'tests'))
-from cage_challenge_4_amd import CC4VecEnv, _lib
-if os.environ.get('CC4_LIB'): _lib.LIB_PATH = os.environ['CC4_LIB']
+from cage_challenge_4_amd import CC4VecEnv
 from oracle_binding import OracleVecEnv, random_actions
 mode = int(sys.argv[1]) if len(sys.argv) > 1 else 0
 rp = int(sys.argv[2]) if len(sys.argv) > 2 else 0

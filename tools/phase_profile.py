@@ -12,7 +12,7 @@ env.reset(seeds=1000)
 env.run_random_steps(1000, 0, 50, timed=False)
 env.lib.cc4_debug_profile(env._h, 1, None)
 ms = env.run_random_steps(1000, 50, K, timed=True)
-out = np.zeros((n, 16), np.uint64)
+out = np.zeros((n, 64), np.uint64)
 env.lib.cc4_debug_profile(env._h, 1, out.ctypes.data_as(ctypes.c_void_p))
 names = ['blue decode/queue', 'green policy draws', 'red FSM policy', 'queue tick', 'shuffle', 'blue exec', 'green exec', 'red exec',
          'reassign', 'monitor x5', 'red session check', 'stage in', 'flat obs', 'stage out', 'TOTAL', '-']
