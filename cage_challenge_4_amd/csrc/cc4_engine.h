@@ -67,6 +67,19 @@ CC4_HD void bit_clr_shared(uint32_t* b, int i) {
   b[i >> 5] &= ~(1u << (i & 31));
 #endif
 }
+// a 137-bit host bitmap held in registers: loaded / stored as one batch of independent LDS accesses (a `for w` loop that
+// alternates loads and stores pays one LDS round trip per word)
+struct B5 { uint32_t w[5]; };
+CC4_HD B5 b5_load(const uint32_t* p) { B5 r; r.w[0] = p[0]; r.w[1] = p[1]; r.w[2] = p[2]; r.w[3] = p[3]; r.w[4] = p[4]; return r; }
+CC4_HD void b5_store(uint32_t* p, const B5& v) { p[0] = v.w[0]; p[1] = v.w[1]; p[2] = v.w[2]; p[3] = v.w[3]; p[4] = v.w[4]; }
+CC4_HD B5 b5_zero() { B5 r; r.w[0] = r.w[1] = r.w[2] = r.w[3] = r.w[4] = 0; return r; }
+CC4_HD B5 b5_or(const B5& a, const B5& b) { B5 r; CC4_UNROLL for (int i = 0; i < 5; ++i) r.w[i] = a.w[i] | b.w[i]; return r; }
+CC4_HD B5 b5_andn(const B5& a, const B5& b) { B5 r; CC4_UNROLL for (int i = 0; i < 5; ++i) r.w[i] = a.w[i] & ~b.w[i]; return r; }
+CC4_HD bool b5_any(const B5& a) { return (a.w[0] | a.w[1] | a.w[2] | a.w[3] | a.w[4]) != 0; }
+CC4_HD void b5_set(B5& a, int i) {   // constant word indices only: a dynamically indexed register array would live in scratch memory
+  const uint32_t bit = 1u << (i & 31); const int wi = i >> 5;
+  CC4_UNROLL for (int k = 0; k < 5; ++k) a.w[k] |= (wi == k) ? bit : 0u;
+}
 CC4_HD int popc32(uint32_t v) {
 #if defined(__HIP_DEVICE_COMPILE__)
   return __popc(v);
@@ -614,10 +627,27 @@ CC4_HD void stop_process(Ctx x, int h, int pid) {
 CC4_HD void blue_remove(Ctx x, int b, int h) {
   BlueAgent& A = x.s->blue[b];
   if (!bit_get(A.sus_hosts, h)) return;   // parent_session.sus_pids has no entry for this hostname
-  for (int i = 0; i < A.nsus; ++i)
-  {
-    uint32_t e = x.c->sus[b][i];
-    if ((int)(e >> 16) == h) stop_process(x, h, (int)(e & 0xFFFF));
+  // The list lives in the cold row (HBM).  It is filtered with 8 independent loads in flight per round into a small LDS
+  // work area (12 words per blue agent), then the matching pids are stopped in list order.
+  const uint32_t* list = x.c->sus[b];
+  uint16_t* hit = reinterpret_cast<uint16_t*>(x.s->scratch + 12 * b);
+  const int cap = 24, n = A.nsus;
+  int i0 = 0;
+  while (i0 < n) {
+    int nh = 0;
+    for (; i0 < n && nh + 8 <= cap; i0 += 8) {   // MAX_SUS is a multiple of 8: the tail of a round reads allocated slots
+      uint32_t v0 = list[i0], v1 = list[i0 + 1], v2 = list[i0 + 2], v3 = list[i0 + 3];
+      uint32_t v4 = list[i0 + 4], v5 = list[i0 + 5], v6 = list[i0 + 6], v7 = list[i0 + 7];
+      if (i0 + 0 < n && (int)(v0 >> 16) == h) hit[nh++] = (uint16_t)v0;
+      if (i0 + 1 < n && (int)(v1 >> 16) == h) hit[nh++] = (uint16_t)v1;
+      if (i0 + 2 < n && (int)(v2 >> 16) == h) hit[nh++] = (uint16_t)v2;
+      if (i0 + 3 < n && (int)(v3 >> 16) == h) hit[nh++] = (uint16_t)v3;
+      if (i0 + 4 < n && (int)(v4 >> 16) == h) hit[nh++] = (uint16_t)v4;
+      if (i0 + 5 < n && (int)(v5 >> 16) == h) hit[nh++] = (uint16_t)v5;
+      if (i0 + 6 < n && (int)(v6 >> 16) == h) hit[nh++] = (uint16_t)v6;
+      if (i0 + 7 < n && (int)(v7 >> 16) == h) hit[nh++] = (uint16_t)v7;
+    }
+    for (int k = 0; k < nh; ++k) stop_process(x, h, (int)hit[k]);
   }
 }
 // Restore.execute -> RestoreFromBackup (AbstractActions/Restore.py:38-71, ConcreteActions/RestoreFromBackup.py:9-19)
@@ -716,13 +746,19 @@ CC4_HD void phishing(Ctx x, int gh) {
 // GreenLocalWork.execute (GreenActions/GreenLocalWork.py:60-125). returns success
 CC4_HD bool green_local_work(Ctx x, int gh, bool* want_phish) {
   EnvState* s = x.s;
-  HostDyn& d = s->hd[gh];
-  int n = 0;
-  for (int i = 0; i < d.nsvc; ++i) if (d.svcs[i].st & SV_ACTIVE) n++;
-  if (n == 0) return false;
-  int k = (int)rng_below(x.r, (uint32_t)n), c = 0;
-  for (int i = 0; i < d.nsvc; ++i) if (d.svcs[i].st & SV_ACTIVE) { if (k-- == 0) { c = i; break; } }
-  int rel = (d.svcs[c].st & 0x7F) * 20;
+  const HostDyn& d = s->hd[gh];
+  // the whole service table in one batch of independent loads (each Svc is one little-endian word: pid | kind << 16 | st << 24);
+  // everything after that works on registers with constant indices
+  uint32_t sv[MAXSV];
+  __builtin_memcpy(sv, d.svcs, sizeof(sv));
+  const int nsvc = d.nsvc;
+  uint32_t act = 0;
+  CC4_UNROLL for (int i = 0; i < MAXSV; ++i) if (i < nsvc && ((sv[i] >> 24) & SV_ACTIVE)) act |= 1u << i;
+  if (!act) return false;
+  const int c = nth_bit(act, (int)rng_below(x.r, (uint32_t)popc32(act)));   // choice over the active services, table order
+  uint32_t st = 0;
+  CC4_UNROLL for (int i = 0; i < MAXSV; ++i) if (i == c) st = sv[i] >> 24;
+  int rel = (int)(st & 0x7F) * 20;
   if ((int)rng_below(x.r, 100) >= rel) return false;
   if (rng_random(x.r) < 0.01) { (void)eph_port(x, gh); ev_proc(x, gh, 0); }
   if (rng_random(x.r) < 0.01) *want_phish = true;  // PhishingEmail sub-action: executed by the caller (ordering, see P5)
@@ -733,13 +769,16 @@ CC4_HD bool green_access_service(Ctx x, int gh) {
   EnvState* s = x.s;
   int own = h_subnet(gh);
   uint32_t allowed = green_allowed_mask(s->phase, own);
+  uint64_t ns;   // server counts of subnets 0..7 (the internet subnet has none), one batch of loads
+  __builtin_memcpy(&ns, s->n_servers, 8);
   int n = 0;
-  for (int sn = 0; sn < NSUB - 1; ++sn) if ((allowed >> sn) & 1u) n += s->n_servers[sn];
+  CC4_UNROLL for (int sn = 0; sn < NSUB - 1; ++sn) if ((allowed >> sn) & 1u) n += (int)((ns >> (8 * sn)) & 0xFF);
   int c = (int)rng_below(x.r, (uint32_t)n);
   int dest = -1;
-  for (int sn = 0; sn < NSUB - 1 && dest < 0; ++sn) {
-    if (!((allowed >> sn) & 1u)) continue;
-    if (c < s->n_servers[sn]) dest = h_make(sn, 11 + c); else c -= s->n_servers[sn];
+  for (int sn = 0; sn < NSUB - 1; ++sn) {
+    if (dest >= 0 || !((allowed >> sn) & 1u)) continue;
+    int cnt = (int)((ns >> (8 * sn)) & 0xFF);
+    if (c < cnt) dest = h_make(sn, 11 + c); else c -= cnt;
   }
   (void)eph_port(x, dest);
   int ds = h_subnet(dest);
@@ -1077,6 +1116,7 @@ CC4_HD int fsm_next(int cur, int act, bool success) {
 // checks the built ISA for that pattern)
 CC4_HD void fsm_set_state(RedAgent& A, int h, int st) {
   if (st >= FS_U && st <= FS_RD) bit_set(A.fsm_ur, h); else bit_clr(A.fsm_ur, h);
+  if ((st & 1) || st == FS_F) bit_set(A.fsm_nodrs, h); else bit_clr(A.fsm_nodrs, h);
   A.fsm_state[h] = (uint8_t)st;
 }
 CC4_HD void fsm_apply(Ctx x, int r, int h, int act, bool success) {  // _host_state_transition inner loop (:147-167)
@@ -1102,8 +1142,16 @@ CC4_HD void fsm_observe(Ctx x, int r) {
     int t = A.obs_act_type;
     if (t == RA_DRS) {
       // every known host of the pinged subnet (ids subnet*17 .. +16); the order of the per-host transitions is immaterial
-      for (int h = A.obs_act_arg * SLOTS; h < A.obs_act_arg * SLOTS + SLOTS && h < MAXH; ++h)
-        if (bit_get(A.fsm_known, h)) fsm_apply(x, r, h, t, ok);
+      // on success only K, S, U, R move (to KD, SD, UD, RD): visit just those hosts
+      const int lo = A.obs_act_arg * SLOTS, hi = lo + SLOTS - 1;
+      for (int w = lo >> 5; w <= (hi >> 5) && w < 5; ++w) {
+        uint32_t m = A.fsm_known[w];
+        if (ok) m &= ~A.fsm_nodrs[w];
+        const int l = lo - 32 * w, u = hi - 32 * w;
+        if (l > 0) m &= 0xFFFFFFFFu << l;
+        if (u < 31) m &= (2u << u) - 1u;
+        while (m) { int b = ctz32(m); m &= m - 1; fsm_apply(x, r, w * 32 + b, t, ok); }
+      }
     } else if (t == RA_PRIVESC || t == RA_IMPACT || t == RA_DEGRADE) {
       int h = A.obs_act_host;  // matched through host_states[ip]['hostname']
       if (A.fsm_state[h] != FS_NONE && bit_get(A.fsm_hn, h)) fsm_apply(x, r, h, t, ok);
@@ -1113,11 +1161,10 @@ CC4_HD void fsm_observe(Ctx x, int r) {
   }
   CC4_AT(x, 3);
   // 2. _process_new_observations (:190-250)
-  uint32_t* sess_seen = A.sess_seen;
-  for (int w = 0; w < 5; ++w) sess_seen[w] = 0u;
+  B5 seen = b5_zero();   // hosts whose observation entry carries Sessions
   for (int i = 0; i < A.nobs; ++i) {
     int h = A.obs[i].host; int f = A.obs[i].flags;
-    if (f & OE_SESS) bit_set(sess_seen, h);
+    if (f & OE_SESS) b5_set(seen, h);
     bool hn = !(f & OE_KEY_IP) || (f & OE_SYSHN);
     bool ip = (f & OE_KEY_IP) || (f & OE_IFACE);
     if (!ip) {
@@ -1136,9 +1183,9 @@ CC4_HD void fsm_observe(Ctx x, int r) {
   // the RedSessionCheck listing (comes last in the observation's key order): every session host is hostname-known, carries
   // Sessions, and is new to host_states iff it is not in fsm_known -- added in session (dict) order
   if (A.rsc_listed) {
-    bool any_new = false;
-    for (int w = 0; w < 5; ++w) { sess_seen[w] |= A.live_hosts[w]; if (A.live_hosts[w] & ~A.fsm_known[w]) any_new = true; }
-    if (any_new)
+    const B5 live = b5_load(A.live_hosts), known = b5_load(A.fsm_known), hn = b5_load(A.fsm_hn);
+    seen = b5_or(seen, live);
+    if (b5_any(b5_andn(live, known)))
       for (int i = 0; i < A.nsess; ++i) {
         int h = A.sess[i].host;
         if (bit_get(A.fsm_known, h)) continue;
@@ -1146,13 +1193,17 @@ CC4_HD void fsm_observe(Ctx x, int r) {
         A.fsm_order[A.fsm_n++] = (uint8_t)h;
         bit_set(A.fsm_known, h);
       }
-    for (int w = 0; w < 5; ++w) A.fsm_hn[w] |= A.live_hosts[w];
+    b5_store(A.fsm_hn, b5_or(hn, live));
   }
   CC4_AT(x, 5);
   // 3. _session_removal_state_change (:169-188): hosts in U/UD/R/RD without a Sessions entry in the observation -> KD
-  for (int w = 0; w < 5; ++w) {
-    uint32_t lost = A.fsm_ur[w] & ~sess_seen[w];
-    while (lost) { int b = ctz32(lost); lost &= lost - 1; fsm_set_state(A, w * 32 + b, FS_KD); }
+  {
+    const B5 lost = b5_andn(b5_load(A.fsm_ur), seen);
+    if (b5_any(lost))
+      CC4_UNROLL for (int w = 0; w < 5; ++w) {
+        uint32_t m = lost.w[w];
+        while (m) { int b = ctz32(m); m &= m - 1; fsm_set_state(A, w * 32 + b, FS_KD); }
+      }
   }
   CC4_AT(x, 6);
 }
@@ -1319,34 +1370,52 @@ CC4_HD void red_validate(Ctx x, int r, Act& a) {
 }
 
 // ------------------------------------------------------------------ different_subnet_agent_reassignment (SC:820-903)
+// word w of the host-id bitmap of the hosts in red agent r's allowed subnets
+CC4_HD uint32_t red_zone_hosts(int r, int w) {
+  uint32_t m = 0;
+  for (int i = 0; i < red_nsub(r); ++i) {
+    int lo = red_subnet_alloc(r, i) * SLOTS - 32 * w, hi = lo + SLOTS - 1;   // the subnet's id range relative to this word
+    if (hi < 0 || lo > 31) continue;
+    uint32_t up = hi >= 31 ? 0xFFFFFFFFu : ((2u << hi) - 1u);
+    uint32_t dn = lo <= 0 ? 0xFFFFFFFFu : (0xFFFFFFFFu << lo);
+    m |= up & dn;
+  }
+  return m;
+}
 CC4_HD void red_reassign(Ctx x) {
   EnvState* s = x.s;
-  struct Mv { uint8_t from, to, host; uint16_t id; };
-  Mv mv[32]; int nm = 0;
+  // moves are collected first (the reference builds the list, then applies it), one packed word each in the shared work
+  // area: from | to << 3 | host << 8 | session id << 16
+  uint32_t* mv = s->scratch; int nm = 0;
+  const int cap = (int)(sizeof(s->scratch) / 4);
   for (int r = 0; r < NRED; ++r) {
     const RedAgent& A = s->red[r];
+    bool foreign = false;
+    for (int w = 0; w < 5; ++w) if (A.live_hosts[w] & ~red_zone_hosts(r, w)) foreign = true;
+    if (!foreign) continue;
     for (int i = 0; i < A.nsess; ++i) {
       int sn = h_subnet(A.sess[i].host);
       if ((red_allowed_mask(r) >> sn) & 1u) continue;
       int to = red_of_subnet(sn);
       if (to < 0) { set_err(x, E_UNREACHABLE); continue; }
-      if (nm < 32) { mv[nm].from = (uint8_t)r; mv[nm].to = (uint8_t)to; mv[nm].host = A.sess[i].host; mv[nm].id = A.sess[i].id; nm++; }
+      if (nm < cap) mv[nm++] = (uint32_t)r | ((uint32_t)to << 3) | ((uint32_t)A.sess[i].host << 8) | ((uint32_t)A.sess[i].id << 16);
       else set_err(x, E_RSESS_OVERFLOW);
     }
   }
   for (int m = 0; m < nm; ++m) {
-    RedAgent& F = s->red[mv[m].from];
-    int i = rs_find_id(F, mv[m].id);
+    const int from = (int)(mv[m] & 7u), to = (int)((mv[m] >> 3) & 7u), id = (int)(mv[m] >> 16);
+    RedAgent& F = s->red[from];
+    int i = rs_find_id(F, id);
     if (i < 0) continue;
-    RSess old = F.sess[i];
-    rs_remove_at(x, mv[m].from, i, true);
-    int ni = rs_add(x, mv[m].to, old.host, old.pid, RS_ABSTRACT | (old.flags & RS_ROOT));
+    const int old_host = F.sess[i].host, old_pid = F.sess[i].pid, old_flags = F.sess[i].flags, old_id = F.sess[i].id;
+    rs_remove_at(x, from, i, true);
+    int ni = rs_add(x, to, old_host, old_pid, RS_ABSTRACT | (old_flags & RS_ROOT));
     if (ni < 0) continue;
     // observation hand-over: only if the creating action's observation carries the host ip key with this session
-    if (F.new_sess_host == old.host && F.new_sess_id == old.id) {
-      obs_first(x, mv[m].to, T_UNKNOWN, RA_NONE, 0, 0);
-      obs_put(x, mv[m].to, true, old.host, OE_SESS | OE_IFACE | OE_SYSHN, false);
-      as_know_sid(x, mv[m].to, s->red[mv[m].to].sess[ni].id);
+    if (F.new_sess_host == old_host && F.new_sess_id == old_id) {
+      obs_first(x, to, T_UNKNOWN, RA_NONE, 0, 0);
+      obs_put(x, to, true, old_host, OE_SESS | OE_IFACE | OE_SYSHN, false);
+      as_know_sid(x, to, s->red[to].sess[ni].id);
     }
   }
   for (int r = 0; r < NRED; ++r) s->red[r].active = (uint8_t)(s->red[r].nsess > 0);
@@ -1502,11 +1571,11 @@ CC4_HD void step_phishing(Ctx x) {
     }
   }
 }
-// true if red agent r holds a session outside its allowed subnets (work for different_subnet_agent_reassignment)
+// true if red agent r holds a session outside its allowed subnets (work for different_subnet_agent_reassignment):
+// live_hosts against the host-id ranges of the agent's subnets (subnet sn = ids sn*17 .. sn*17+16)
 CC4_HD bool red_has_foreign_session(const EnvState* s, int r) {
   const RedAgent& A = s->red[r];
-  uint32_t m = red_allowed_mask(r);
-  for (int i = 0; i < A.nsess; ++i) if (!((m >> h_subnet(A.sess[i].host)) & 1u)) return true;
+  for (int w = 0; w < 5; ++w) if (A.live_hosts[w] & ~red_zone_hosts(r, w)) return true;
   return false;
 }
 CC4_HD void step_red_exec_agent(Ctx x, int r) {
@@ -1516,18 +1585,20 @@ CC4_HD void step_red_exec_agent(Ctx x, int r) {
   red_execute(x, r, s->rexec[r]);
 }
 // Red actions of different agents commute when they name different hosts (each action reads/writes its own agent's
-// tables, its target host and commutative event bits); DiscoverRemoteSystems only reads the topology.
-CC4_HD bool red_targets_conflict(const EnvState* s) {
-  for (int a = 0; a < NRED; ++a) if (s->rexec[a].type == RA_WITHDRAW) return true;   // kills sessions: keep the serial order
+// tables, its target host and commutative event bits); DiscoverRemoteSystems only reads the topology.  Returns the set of
+// agents whose actions do NOT commute with some other agent's and therefore keep the serial agent order among themselves.
+CC4_HD uint32_t red_conflict_mask(const EnvState* s) {
+  for (int a = 0; a < NRED; ++a) if (s->rexec[a].type == RA_WITHDRAW) return (1u << NRED) - 1u;   // kills sessions: everything serial
+  uint32_t m = 0;
   for (int a = 0; a < NRED; ++a) {
     int ta = s->rexec[a].type;
     if (!(ta >= RA_AGGR && ta <= RA_DEGRADE)) continue;
     for (int b = a + 1; b < NRED; ++b) {
       int tb = s->rexec[b].type;
-      if (tb >= RA_AGGR && tb <= RA_DEGRADE && s->rexec[a].host == s->rexec[b].host) return true;
+      if (tb >= RA_AGGR && tb <= RA_DEGRADE && s->rexec[a].host == s->rexec[b].host) m |= (1u << a) | (1u << b);
     }
   }
-  return false;
+  return m;
 }
 CC4_HD void step_red_exec(Ctx x) {
   for (int r = 0; r < NRED; ++r) step_red_exec_agent(x, r);
@@ -1642,6 +1713,26 @@ CC4_HD void env_flat_obs_part(const EnvState* s, T* out, int part) {
     int o = base + len - 32;
     for (int j = 0; j < NBLUE; ++j) { if (j == b) continue; for (int i = 0; i < MSG_LEN; ++i) out[o++] = (T)s->msg[j][i]; }
   }
+}
+// the same vector, one value at a time (value `idx` of the 578): what the device encodes with one value per thread
+CC4_HD int env_flat_obs_at(const EnvState* s, int idx) {
+  const int b = idx < 4 * OBS_SHORT ? idx / OBS_SHORT : 4;
+  const int j = idx - (b < 4 ? b * OBS_SHORT : 4 * OBS_SHORT);
+  const int len = b < 4 ? OBS_SHORT : OBS_LONG;
+  if (j == 0) return s->phase;
+  if (j >= len - 32) {
+    const int m = j - (len - 32), jj = m / MSG_LEN;
+    return s->msg[jj < b ? jj : jj + 1][m % MSG_LEN];
+  }
+  const int q = j - 1, i = q / 59, k = q % 59;
+  const int sn = blue_subnet_sorted(b, i);
+  if (k < 9) return sorted_subnet(k) == sn;
+  if (k < 18) return (s->blocks[sn] >> sorted_subnet(k - 9)) & 1u;
+  if (k < 27) return !((comms_adjacent(s->phase, sn) >> sorted_subnet(k - 18)) & 1u);
+  const int hs = k < 43 ? k - 27 : k - 43;
+  const int h = hs < MAX_SERVERS ? h_make(sn, 11 + hs) : h_make(sn, 1 + (hs - MAX_SERVERS));
+  const int ev = bit_get(s->exists, h) ? s->hd[h].ev : 0;
+  return k < 43 ? ((ev & (EV_CUR_PROC | EV_OLD_PROC)) != 0) : ((ev & (EV_CUR_CONN | EV_OLD_CONN)) != 0);
 }
 template <typename T>
 CC4_HD void env_flat_obs(const EnvState* s, T* out) {

@@ -183,7 +183,6 @@ __device__ __forceinline__ void stage_in_n(uint4* __restrict__ lds, const uint4*
 
 __global__ __launch_bounds__(PT) void k_step_philox(StepArgs a) {
   extern __shared__ uint4 lds[];
-  __shared__ uint8_t obs_lds[OBS_TOTAL + 2];
   __shared__ int ok_lds, flag_lds, conflict_lds;
   __shared__ int glist_n[2];
   __shared__ uint8_t glist[2][MAXG];  // green agents by action type (0 AccessService, 1 LocalWork)
@@ -269,11 +268,15 @@ __global__ __launch_bounds__(PT) void k_step_philox(StepArgs a) {
       __syncthreads();
       CC4_TICK(x0, 6);
       // ---- P5 deferred phishing (ordered), then P6 red actions: one per wave when they name distinct hosts
-      if (tid == 0) { step_phishing(x0); CC4_TICK(x0, 1); conflict_lds = red_targets_conflict(s) ? 1 : 0; if (prof && conflict_lds) prof[4] += 1000000; }
+      if (tid == 0) { step_phishing(x0); CC4_TICK(x0, 1); conflict_lds = (int)red_conflict_mask(s); if (prof && conflict_lds) prof[4] += 1000000; }
       __syncthreads();
-      if (conflict_lds) { if (tid == 0) for (int r = 0; r < NRED; ++r) step_red_exec_agent(x0, r); }
-      else if (is_red) { unsigned long long t0 = ap ? clock64() : 0; step_red_exec_agent(xr, ragent); if (ap) ap[1] += clock64() - t0; }
+      const uint32_t serial_red = (uint32_t)conflict_lds;
+      if (is_red && !((serial_red >> ragent) & 1u)) { unsigned long long t0 = ap ? clock64() : 0; step_red_exec_agent(xr, ragent); if (ap) ap[1] += clock64() - t0; }
       __syncthreads();
+      if (serial_red) {   // same-host actions (and everything when some agent withdraws): agent order on thread 0
+        if (tid == 0) for (int r = 0; r < NRED; ++r) if ((serial_red >> r) & 1u) step_red_exec_agent(x0, r);
+        __syncthreads();
+      }
       if (tid == 0) { step_red_merge(x0); CC4_TICK(x0, 7); }
       // ---- reassignment: foreign-session scan per agent, the (rare) moves on thread 0
       if (is_red && red_has_foreign_session(s, ragent)) atomicOr(&flag_lds, 1);
@@ -295,15 +298,16 @@ __global__ __launch_bounds__(PT) void k_step_philox(StepArgs a) {
   __syncthreads();
   if (tid == 0) { a.reward[e] = s->reward; a.done[e] = s->done; a.err[e] = s->err; }
   unsigned long long t_obs = a.prof ? clock64() : 0;
-  if (lane < (OBS_PARTS + PW - 1) / PW) { int p = lane * PW + wave; if (p < OBS_PARTS) env_flat_obs_part<uint8_t>(s, obs_lds, p); }   // 12 parts over the waves
-  __syncthreads();
+  // flat observations: one value per thread straight to HBM (int32 for the host API, bytes for the all-gather)
+  {
+    int32_t* o = a.obs + (size_t)e * OBS_TOTAL;
+    uint8_t* o8 = a.obs8 ? a.obs8 + (size_t)e * OBS_TOTAL : nullptr;
+    for (int i = tid; i < OBS_TOTAL; i += PT) { int v = env_flat_obs_at(s, i); o[i] = v; if (o8) o8[i] = (uint8_t)v; }
+  }
   unsigned long long t_out = a.prof ? clock64() : 0;
   if (prof && tid == 0) prof[12] += t_out - t_obs;
   uint4* dst = reinterpret_cast<uint4*>(a.st + e);
   for (int i = tid; i < ROW_VEC; i += PT) dst[i] = lds[i];
-  int32_t* o = a.obs + (size_t)e * OBS_TOTAL;
-  for (int i = tid; i < OBS_TOTAL; i += PT) o[i] = obs_lds[i];
-  if (a.obs8) { uint8_t* o8 = a.obs8 + (size_t)e * OBS_TOTAL; for (int i = tid; i < OBS_TOTAL; i += PT) o8[i] = obs_lds[i]; }
   if (prof && tid == 0) { prof[13] += clock64() - t_out; prof[14] += clock64() - t_begin; }
   if (prof) { __syncthreads(); if (tid < 15) a.prof[PROF_SLOTS * (size_t)e + tid] += prof_lds[tid]; }
 }

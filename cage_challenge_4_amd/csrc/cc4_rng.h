@@ -15,8 +15,10 @@
 
 #if defined(__HIPCC__)
 #define CC4_HD __host__ __device__ __forceinline__
-#else
+#define CC4_UNROLL _Pragma("unroll")     // small fixed-trip loops over register arrays must be fully unrolled on the device:
+#else                                     // a dynamically indexed local array lives in scratch (global) memory there
 #define CC4_HD inline
+#define CC4_UNROLL
 #endif
 
 namespace cc4 {

@@ -110,7 +110,7 @@ struct alignas(8) RedAgent {
   uint32_t obs_has[2][5];            // which (key type, host) pairs are already in obs[] this step
   uint32_t fsm_known[5];             // hosts present in host_states (fsm_state != FS_NONE)
   uint32_t fsm_ur[5];                // hosts whose state is U, UD, R or RD (the ones _session_removal_state_change looks at)
-  uint32_t sess_seen[5];             // work bitmap of fsm_observe
+  uint32_t fsm_nodrs[5];             // hosts whose state a successful DiscoverRemoteSystems leaves alone (KD, SD, UD, RD, F)
   uint32_t live_hosts[5];            // hosts currently holding >= 1 session of this agent (kept exact by rs_add / rs_remove_at)
   Act queue;                         // actions_in_progress[agent]
   uint16_t as_subnet;                // ActionSpace.subnet known bits
@@ -147,7 +147,8 @@ struct alignas(16) EnvState {
   uint8_t policy;                    // bits 0-1 red policy (RP_*), bit 4 green policy (1 = SleepAgent)
   uint16_t blocks[NSUB];             // blocks[to] bit from
   uint8_t cidr_octet[NSUB];
-  uint8_t n_users[NSUB], n_servers[NSUB];
+  uint8_t n_users[NSUB];
+  alignas(8) uint8_t n_servers[NSUB];   // read as one 8-byte word by GreenAccessService
   uint8_t green_host[MAXG];
   uint8_t green_act[MAXG];           // scratch: this step's green choice
   uint16_t blue_pid[MAXH];           // pid of the blue session process on host (0 = none)

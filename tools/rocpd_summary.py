@@ -1,7 +1,8 @@
 #!/usr/bin/env python
 """Summarise rocprofv3 rocpd (.db) outputs into the small text/JSON files committed under profiles/.
 usage: rocpd_summary.py stats <dir-with-db> <out.txt>
-       rocpd_summary.py pmc <fetch-dir> <write-dir> <kernel-substr> <out.json> [launch_envs]"""
+       rocpd_summary.py pmc <fetch-dir> <write-dir> <kernel-substr> <out.json> [launch_envs]
+       rocpd_summary.py counters <kernel-substr> <out.json> <dir> [<dir> ...]   (per-launch averages of every counter found)"""
 import glob
 import json
 import sqlite3
@@ -47,8 +48,22 @@ def pmc(fd, wd, kern, out, envs):
     print(json.dumps(res, indent=1))
 
 
+def counters(kern, out, dirs):
+    res = {}
+    for d in dirs:
+        con = db(d)
+        for name, n, avg in con.execute("select counter_name, count(*), avg(value) from counters_collection "
+                                        "where kernel_name like ? group by counter_name", (f'%{kern}%',)):
+            res[name] = {'launches': n, 'avg_per_launch': avg}
+    res['kernel'] = kern
+    json.dump(res, open(out, 'w'), indent=1)
+    print(json.dumps(res, indent=1))
+
+
 if __name__ == '__main__':
-    if sys.argv[1] == 'stats':
+    if sys.argv[1] == 'counters':
+        counters(sys.argv[2], sys.argv[3], sys.argv[4:])
+    elif sys.argv[1] == 'stats':
         stats(sys.argv[2], sys.argv[3])
     else:
         pmc(sys.argv[2], sys.argv[3], sys.argv[4], sys.argv[5], int(sys.argv[6]) if len(sys.argv) > 6 else 1024)
