@@ -166,7 +166,6 @@ __global__ __launch_bounds__(WAVE) void k_step(StepArgs a) {
 constexpr int PW = CC4_PW;         // waves per episode block; red agent r runs on wave r % PW, lane r / PW
 static_assert(PW >= 3 && PW <= 6, "waves 0/1 run the two green action lists, wave 2 the Sleep bookkeeping");
 constexpr int PT = PW * WAVE;      // 384 threads
-constexpr int RNG_SLOTS = 8;       // 6 red agents + thread 0 (ordered sections); green agents use thread-private generators
 
 __device__ __forceinline__ void stage_in_n(uint4* __restrict__ lds, const uint4* __restrict__ src, int tid) {
   constexpr int U = (ROW_VEC / PT) < 6 ? (ROW_VEC / PT) : 6;   // loads in flight per thread (the whole row in one or two rounds)
@@ -186,7 +185,6 @@ __global__ __launch_bounds__(PT) void k_step_philox(StepArgs a) {
   __shared__ int ok_lds, flag_lds, conflict_lds;
   __shared__ int glist_n[2];
   __shared__ uint8_t glist[2][MAXG];  // green agents by action type (0 AccessService, 1 LocalWork)
-  __shared__ Rng rngs[RNG_SLOTS];     // per-agent generators live in LDS (a private copy would be spilled to scratch)
   __shared__ unsigned long long prof_lds[16];
   const int e = blockIdx.x, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   if (e >= a.n) return;
@@ -210,17 +208,17 @@ __global__ __launch_bounds__(PT) void k_step_philox(StepArgs a) {
     __syncthreads();
     if (ok_lds) {
       const int ng = s->n_green;
-      // generator slots in LDS: red r -> r, thread 0 (ordered sections) -> 6
-      const int slot = (lane == 0) ? (wave == 0 ? 6 : wave) : 0;
-      Ctx x0{s, a.cold + e, &rngs[6], tid == 0 ? prof : nullptr};               // thread 0
+      // one thread-private generator per thread, in registers: every use starts with rng_set_stream(), which fully
+      // determines the stream from (key, step, episode, stream id); mode pinned so the PCG paths fold away
+      Rng rl;
+      rng_fork(&rl, &s->rng, ST_RESET);
+      rl.mode = 1;
+      Ctx x0{s, a.cold + e, &rl, tid == 0 ? prof : nullptr};                     // thread 0
       const int ragent = lane * PW + wave;                                        // lanes 0..(6/PW-1) of each wave own a red agent
       const bool is_red = lane < (NRED + PW - 1) / PW && ragent < NRED;
       unsigned long long* ap = (a.prof && is_red) ? a.prof + PROF_SLOTS * (size_t)e + 16 + 8 * ragent : nullptr;
-      Ctx xr{s, a.cold + e, &rngs[is_red ? ragent : 0], nullptr, ap};
-      (void)slot;
+      Ctx xr{s, a.cold + e, &rl, nullptr, ap};
       // ---- P0 blue submissions (wave 0 lanes 1..5) | P2 red FSM policy r on wave r lane 0 | P1 green draws on lanes >= 8
-      if (is_red) rng_fork(&rngs[ragent], &s->rng, ST_RESET);
-      if (tid == 0) rng_fork(&rngs[6], &s->rng, ST_RESET);
       if (is_red) { unsigned long long t0 = ap ? clock64() : 0; step_red_policy(xr, ragent); if (ap) ap[0] += clock64() - t0; }
       else if (wave == PW - 1 && lane >= 2 && lane < 2 + NBLUE) {
         const int b = lane - 2;
@@ -230,9 +228,7 @@ __global__ __launch_bounds__(PT) void k_step_philox(StepArgs a) {
       }
       else if (lane >= 8) {
         for (int g = wave * (WAVE - 8) + (lane - 8); g < ng; g += PW * (WAVE - 8)) {
-          Rng gl;
-          rng_fork(&gl, &s->rng, ST_RESET);
-          Ctx xg{s, a.cold + e, &gl, nullptr};
+          Ctx xg{s, a.cold + e, &rl, nullptr};
           step_green_policy(xg, g);
           int t = s->green_act[g];
           if (t < 2) glist[t][atomicAdd(&glist_n[t], 1)] = (uint8_t)g;       // compaction by action type
@@ -246,7 +242,7 @@ __global__ __launch_bounds__(PT) void k_step_philox(StepArgs a) {
       if (blue_exec_independent(s)) {      // uniform: every thread reads the same five action types
         if (tid == 0) CC4_TICK(x0, 3);
         const int bagent = lane * PW + wave;                                      // blue agent b on wave b % PW, lane b / PW
-        if (lane < (NBLUE + PW - 1) / PW && bagent < NBLUE) { Ctx xb{s, a.cold + e, &rngs[bagent], nullptr}; step_blue_exec_agent(xb, bagent); }
+        if (lane < (NBLUE + PW - 1) / PW && bagent < NBLUE) { Ctx xb{s, a.cold + e, &rl, nullptr}; step_blue_exec_agent(xb, bagent); }
         __syncthreads();
         if (tid == 0) CC4_TICK(x0, 5);
       } else {
@@ -258,9 +254,7 @@ __global__ __launch_bounds__(PT) void k_step_philox(StepArgs a) {
         int pen = 0;
         for (int i = lane; i < glist_n[wave]; i += WAVE) {
           int g = glist[wave][i];
-          Rng gl;
-          rng_fork(&gl, &s->rng, ST_RESET);
-          Ctx xg{s, a.cold + e, &gl, nullptr};
+          Ctx xg{s, a.cold + e, &rl, nullptr};
           pen += step_green_exec(xg, g);
         }
         if (pen) atomicAdd(&s->brm, pen);
