@@ -87,7 +87,11 @@ __global__ __launch_bounds__(WAVE) void k_step(StepArgs a) {
   __shared__ unsigned long long prof_lds[16];   // phase counters accumulate in LDS, flushed once at the end
   unsigned long long* prof = a.prof ? prof_lds : nullptr;
   if (prof && lane < 16) prof_lds[lane] = 0;
-  Ctx x{s, a.cold + e, &s->rng, lane == 0 ? prof : nullptr};
+  // the shared numpy stream is walked on a register copy (this kernel serves the PCG mode only; mode pinned so the Philox
+  // paths fold away) and written back once, before the row leaves LDS
+  Rng rl = s->rng;
+  rl.mode = 0;
+  Ctx x{s, a.cold + e, &rl, lane == 0 ? prof : nullptr};
   if (prof && lane == 0) prof[11] += clock64() - t_begin;
   const bool do_reset = a.autoreset && s->done;
   if (lane == 0) {
@@ -135,7 +139,7 @@ __global__ __launch_bounds__(WAVE) void k_step(StepArgs a) {
     }
     __syncthreads();
   }
-  if (lane == 0) { a.reward[e] = s->reward; a.done[e] = s->done; a.err[e] = s->err; }
+  if (lane == 0) { s->rng = rl; a.reward[e] = s->reward; a.done[e] = s->done; a.err[e] = s->err; }
   unsigned long long t_obs = a.prof ? clock64() : 0;
   if (lane < OBS_PARTS) env_flat_obs_part<uint8_t>(s, obs_lds, lane);   // 12 independent pieces of the flat observation
   __syncthreads();
