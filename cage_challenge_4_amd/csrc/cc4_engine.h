@@ -193,9 +193,76 @@ CC4_HD void pend_drop_host(Ctx x, int h) {
 CC4_HD bool subnet_blocked(Ctx x, int src_sub, int other_sub) { return (x.s->blocks[other_sub] >> src_sub) & 1u; }
 
 // ------------------------------------------------------------------ red sessions
+// Session-table scans read 8 records per round with independent 8-byte loads (one LDS round trip per 8 sessions instead of
+// one per session).  A record as a little-endian word: id | pid << 16 | host << 32 | flags << 40 | kb << 48.  MAX_RS is a
+// multiple of 8, so a round may read past nsess inside the array; those lanes are masked by the index test.
+struct S8 { uint64_t v[8]; };
+CC4_HD S8 rs_load8(const RedAgent& a, int i0) {
+  S8 q;
+  CC4_UNROLL for (int k = 0; k < 8; ++k) __builtin_memcpy(&q.v[k], &a.sess[i0 + k], 8);
+  return q;
+}
+CC4_HD int rsw_id(uint64_t v) { return (int)(v & 0xFFFF); }
+CC4_HD int rsw_pid(uint64_t v) { return (int)((v >> 16) & 0xFFFF); }
+CC4_HD int rsw_host(uint64_t v) { return (int)((v >> 32) & 0xFF); }
+CC4_HD int rsw_flags(uint64_t v) { return (int)((v >> 40) & 0xFF); }
 CC4_HD int rs_find_id(const RedAgent& a, int id) {
-  for (int i = 0; i < a.nsess; ++i) if (a.sess[i].id == id) return i;
+  const int n = a.nsess;
+  for (int i0 = 0; i0 < n; i0 += 8) {
+    const S8 q = rs_load8(a, i0);
+    int hit = -1;
+    CC4_UNROLL for (int k = 7; k >= 0; --k) if (i0 + k < n && rsw_id(q.v[k]) == id) hit = i0 + k;
+    if (hit >= 0) return hit;
+  }
   return -1;
+}
+// sessions of the agent on host h: how many, the first one, the first root one
+struct HostSess { int n, first, first_root; };
+CC4_HD HostSess rs_on_host(const RedAgent& a, int h) {
+  HostSess r; r.n = 0; r.first = -1; r.first_root = -1;
+  const int n = a.nsess;
+  for (int i0 = 0; i0 < n; i0 += 8) {
+    const S8 q = rs_load8(a, i0);
+    CC4_UNROLL for (int k = 0; k < 8; ++k)
+      if (i0 + k < n && rsw_host(q.v[k]) == h) {
+        r.n++;
+        if (r.first < 0) r.first = i0 + k;
+        if (r.first_root < 0 && (rsw_flags(q.v[k]) & RS_ROOT)) r.first_root = i0 + k;
+      }
+  }
+  return r;
+}
+// index of the k-th (0-based) session on host h, or -1
+CC4_HD int rs_kth_on_host(const RedAgent& a, int h, int kth) {
+  const int n = a.nsess;
+  for (int i0 = 0; i0 < n; i0 += 8) {
+    const S8 q = rs_load8(a, i0);
+    int hit = -1;
+    CC4_UNROLL for (int k = 0; k < 8; ++k)
+      if (hit < 0 && i0 + k < n && rsw_host(q.v[k]) == h) { if (kth == 0) hit = i0 + k; kth--; }
+    if (hit >= 0) return hit;
+  }
+  return -1;
+}
+// index of the session with this (host, pid), or -1 (State.get_session_from_pid)
+CC4_HD int rs_find_host_pid(const RedAgent& a, int h, int pid) {
+  const int n = a.nsess;
+  for (int i0 = 0; i0 < n; i0 += 8) {
+    const S8 q = rs_load8(a, i0);
+    int hit = -1;
+    CC4_UNROLL for (int k = 7; k >= 0; --k) if (i0 + k < n && rsw_host(q.v[k]) == h && rsw_pid(q.v[k]) == pid) hit = i0 + k;
+    if (hit >= 0) return hit;
+  }
+  return -1;
+}
+// records idx+1 .. nsess-1 move down by one (8 per round: loads first, then stores)
+CC4_HD void rs_shift_down(RedAgent& a, int idx) {
+  const int n = a.nsess;
+  for (int i0 = idx; i0 + 1 < n; i0 += 8) {
+    uint64_t v[8];
+    CC4_UNROLL for (int k = 0; k < 8; ++k) if (i0 + 1 + k < MAX_RS) __builtin_memcpy(&v[k], &a.sess[i0 + 1 + k], 8); else v[k] = 0;
+    CC4_UNROLL for (int k = 0; k < 8; ++k) if (i0 + 1 + k < n) __builtin_memcpy(&a.sess[i0 + k], &v[k], 8);
+  }
 }
 CC4_HD int kb_alloc(Ctx x, int r) {
   for (int w = 0; w < MAX_KB / 32; ++w) {
@@ -216,7 +283,10 @@ CC4_HD int rs_add(Ctx x, int r, int host, int pid, int flags) {
   RedAgent& a = x.s->red[r];
   if (a.nsess >= MAX_RS) { set_err(x, E_RSESS_OVERFLOW); return -1; }
   int id = 0;
-  for (int i = 0; i < a.nsess; ++i) if (a.sess[i].id + 1 > id) id = a.sess[i].id + 1;
+  for (int i0 = 0; i0 < a.nsess; i0 += 8) {
+    const S8 q = rs_load8(a, i0);
+    CC4_UNROLL for (int k = 0; k < 8; ++k) if (i0 + k < a.nsess && rsw_id(q.v[k]) + 1 > id) id = rsw_id(q.v[k]) + 1;
+  }
   RSess q; q.id = (uint16_t)id; q.pid = (uint16_t)pid; q.host = (uint8_t)host; q.flags = (uint8_t)flags; q.pad = 0;
   q.kb = (flags & RS_ABSTRACT) ? (uint8_t)kb_alloc(x, r) : (uint8_t)0xFF;
   a.sess[a.nsess++] = q;
@@ -229,12 +299,10 @@ CC4_HD void rs_remove_at(Ctx x, int r, int idx, bool free_kb) {
   RedAgent& a = x.s->red[r];
   if (free_kb) kb_free(x, r, a.sess[idx].kb);
   int gone = a.sess[idx].host;
-  for (int i = idx; i + 1 < a.nsess; ++i) a.sess[i] = a.sess[i + 1];
+  rs_shift_down(a, idx);
   a.nsess--;
   a.rsc_dirty = 1;
-  bool still = false;
-  for (int i = 0; i < a.nsess; ++i) if (a.sess[i].host == gone) { still = true; break; }
-  if (!still) {
+  if (rs_on_host(a, gone).n == 0) {
     bit_clr(a.live_hosts, gone); a.nlive--;
     bool other = false;
     for (int q = 0; q < NRED; ++q) if (bit_get(x.s->red[q].live_hosts, gone)) { other = true; break; }
@@ -244,10 +312,11 @@ CC4_HD void rs_remove_at(Ctx x, int r, int idx, bool free_kb) {
 // dict pop + re-insert of the same session object (RedSessionCheck promotion, RestoreFromBackup of an original session):
 // the record moves to the end of the agent's order; which hosts hold sessions does not change
 CC4_HD void rs_move_to_end(RedAgent& a, int idx, int new_id) {
-  RSess q = a.sess[idx];
-  for (int i = idx; i + 1 < a.nsess; ++i) a.sess[i] = a.sess[i + 1];
-  if (new_id >= 0) q.id = (uint16_t)new_id;
-  a.sess[a.nsess - 1] = q;
+  uint64_t q;   // the record as one word (a struct temporary ends up in scratch memory on the device)
+  __builtin_memcpy(&q, &a.sess[idx], 8);
+  rs_shift_down(a, idx);
+  if (new_id >= 0) q = (q & ~0xFFFFull) | (uint64_t)(new_id & 0xFFFF);
+  __builtin_memcpy(&a.sess[a.nsess - 1], &q, 8);
   a.rsc_dirty = 1;
 }
 CC4_HD bool red_has_session_on(const RedAgent& a, int h) { return bit_get(a.live_hosts, h); }
@@ -606,9 +675,11 @@ CC4_HD void stop_process(Ctx x, int h, int pid) {
   int owner = -1, owner_idx = -1;  // owner: 0 blue, 1 green, 2+r red
   if (s->blue_pid[h] == pid) owner = 0;
   else if (s->green_pid[h] == pid) owner = 1;
-  else for (int r = 0; r < NRED && owner < 0; ++r)
-    for (int i = 0; i < s->red[r].nsess; ++i)
-      if (s->red[r].sess[i].pid == pid && s->red[r].sess[i].host == h) { owner = 2 + r; owner_idx = i; break; }
+  else for (int r = 0; r < NRED && owner < 0; ++r) {
+    if (!bit_get(s->red[r].live_hosts, h)) continue;
+    int i = rs_find_host_pid(s->red[r], h, pid);
+    if (i >= 0) { owner = 2 + r; owner_idx = i; }
+  }
   remove_proc_at(x, h, pi);
   HostDyn& d = s->hd[h];
   int si = -1;
@@ -921,13 +992,12 @@ CC4_HD void red_privesc(Ctx x, int r, const Act& a) {
   EnvState* s = x.s;
   RedAgent& A = s->red[r];
   int h = a.host;
-  int n = 0, target = -1;
-  for (int i = 0; i < A.nsess; ++i)
-    if (A.sess[i].host == h) { n++; if (target < 0 && (A.sess[i].flags & RS_ROOT)) target = i; }
+  const HostSess hs = rs_on_host(A, h);
+  const int n = hs.n;
+  int target = hs.first_root;
   if (n == 0) { red_result(x, r, a, T_FALSE); return; }
   if (target < 0) {
-    int k = (int)rng_below(x.r, (uint32_t)n);   // choice(sessions on the host)
-    for (int i = 0; i < A.nsess; ++i) if (A.sess[i].host == h) { if (k-- == 0) { target = i; break; } }
+    target = rs_kth_on_host(A, h, (int)rng_below(x.r, (uint32_t)n));   // choice(sessions on the host)
     // DefaultEscalateActionSelector (PrivilegeEscalate.py:52-66): self.session must exist and be a RedAbstractSession,
     // else no sub-action -> Observation(False); then V4L2KernelExploit via TargetedLocalAction.execute
     { int ss = rs_find_id(A, a.sid);
@@ -949,9 +1019,8 @@ CC4_HD void red_privesc(Ctx x, int r, const Act& a) {
 CC4_HD void red_impact(Ctx x, int r, const Act& a) {
   EnvState* s = x.s;
   RedAgent& A = s->red[r];
-  int h = a.host; bool any = false, root = false;
-  for (int i = 0; i < A.nsess; ++i) if (A.sess[i].host == h) { any = true; if (A.sess[i].flags & RS_ROOT) root = true; }
-  if (!any || !root) { red_result(x, r, a, T_FALSE); return; }
+  int h = a.host;
+  if (rs_on_host(A, h).first_root < 0) { red_result(x, r, a, T_FALSE); return; }   // no session, or none of them root
   HostDyn& d = s->hd[h];
   int si = -1;
   for (int i = 0; i < d.nsvc; ++i) if (d.svcs[i].kind == K_OT && (d.svcs[i].st & SV_ACTIVE)) { si = i; break; }
@@ -967,9 +1036,8 @@ CC4_HD void red_impact(Ctx x, int r, const Act& a) {
 CC4_HD void red_degrade(Ctx x, int r, const Act& a) {
   EnvState* s = x.s;
   RedAgent& A = s->red[r];
-  int h = a.host; bool any = false, root = false;
-  for (int i = 0; i < A.nsess; ++i) if (A.sess[i].host == h) { any = true; if (A.sess[i].flags & RS_ROOT) root = true; }
-  if (!any || !root) { red_result(x, r, a, T_FALSE); return; }
+  int h = a.host;
+  if (rs_on_host(A, h).first_root < 0) { red_result(x, r, a, T_FALSE); return; }   // no session, or none of them root
   HostDyn& d = s->hd[h];
   int n = 0;
   for (int i = 0; i < d.nsvc; ++i) if (d.svcs[i].st & SV_ACTIVE) {

@@ -22,7 +22,7 @@ using namespace cc4;
 static_assert(sizeof(EnvState) % 16 == 0, "EnvState rows are staged with 16-byte accesses");
 constexpr int ROW_VEC = (int)(sizeof(EnvState) / 16);
 constexpr int WAVE = 64;
-constexpr int PROF_SLOTS = 64;
+constexpr int PROF_SLOTS = 128;   // 16 phase slots, 8 per red agent (16..63), then (cycles, count) per red action type (64..)
 
 struct StepArgs {
   EnvState* st; EnvCold* cold;
@@ -269,7 +269,12 @@ __global__ __launch_bounds__(PT) void k_step_philox(StepArgs a) {
       if (tid == 0) { step_phishing(x0); CC4_TICK(x0, 1); conflict_lds = (int)red_conflict_mask(s); if (prof && conflict_lds) prof[4] += 1000000; }
       __syncthreads();
       const uint32_t serial_red = (uint32_t)conflict_lds;
-      if (is_red && !((serial_red >> ragent) & 1u)) { unsigned long long t0 = ap ? clock64() : 0; step_red_exec_agent(xr, ragent); if (ap) ap[1] += clock64() - t0; }
+      if (is_red && !((serial_red >> ragent) & 1u)) {
+        unsigned long long t0 = ap ? clock64() : 0;
+        const int ty = s->rexec[ragent].type;
+        step_red_exec_agent(xr, ragent);
+        if (ap) { unsigned long long dt = clock64() - t0; ap[1] += dt; unsigned long long* tp = a.prof + PROF_SLOTS * (size_t)e + 64 + 2 * (ty & 15); atomicAdd(tp, dt); atomicAdd(tp + 1, 1ull); }
+      }
       __syncthreads();
       if (serial_red) {   // same-host actions (and everything when some agent withdraws): agent order on thread 0
         if (tid == 0) for (int r = 0; r < NRED; ++r) if ((serial_red >> r) & 1u) step_red_exec_agent(x0, r);

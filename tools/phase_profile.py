@@ -12,7 +12,7 @@ env.reset(seeds=1000)
 env.run_random_steps(1000, 0, 50, timed=False)
 env.lib.cc4_debug_profile(env._h, 1, None)
 ms = env.run_random_steps(1000, 50, K, timed=True)
-out = np.zeros((n, 64), np.uint64)
+out = np.zeros((n, 128), np.uint64)
 env.lib.cc4_debug_profile(env._h, 1, out.ctypes.data_as(ctypes.c_void_p))
 names = ['blue decode/queue', 'green policy draws', 'red FSM policy', 'queue tick', 'shuffle', 'blue exec', 'green exec', 'red exec',
          'reassign', 'monitor x5', 'red session check', 'stage in', 'flat obs', 'stage out', 'TOTAL', '-']
@@ -21,3 +21,10 @@ tot = c[:, 14].mean()
 print(f'rng_mode={mode} n={n} K={K} kernel ms/launch {ms / K:.4f}; mean cycles/step per episode {tot:.0f}; max over episodes {c[:, 14].max():.0f}')
 for i in list(range(14)):
     print(f'{names[i]:22s} {c[:, i].mean():10.0f} cyc  {100 * c[:, i].mean() / tot:5.1f}%   (max {c[:, i].max():.0f})')
+ty = ['DRS', 'Aggressive', 'Stealth', 'Deception', 'Exploit', 'PrivEsc', 'Impact', 'Degrade', 'Withdraw', 'Sleep', 'Invalid', 'None', '12', '13', '14', '15']
+tt = out[:, 64:96].astype(np.float64).reshape(n, 16, 2).sum(0)
+if tt[:, 1].sum() > 0:
+    print('red action execution (own-wave, non-conflicting): type, count per episode-step, mean cycles')
+    for i in range(16):
+        if tt[i, 1] > 0:
+            print(f'  {ty[i]:10s} {tt[i, 1] / (n * K):6.3f}  {tt[i, 0] / tt[i, 1]:8.0f}')

@@ -11,8 +11,8 @@ env = CC4VecEnv(n, steps=500, autoreset=True, rng_mode=mode)
 env.reset(seeds=1000)
 env.run_random_steps(1000, 0, 50, timed=False)
 env.lib.cc4_debug_profile(env._h, 1, None)
-prev = np.zeros((n, 64), np.uint64)
-out = np.zeros((n, 64), np.uint64)
+prev = np.zeros((n, 128), np.uint64)
+out = np.zeros((n, 128), np.uint64)
 rows = []
 names = ['decode', 'phish', 'fsm', 'tick', 'shuf', 'bexec', 'gexec', 'rexec', 'reasg', 'mon', 'rsc', 'in', 'obs', 'out']
 for t in range(K):
@@ -35,14 +35,14 @@ env2 = CC4VecEnv(n, steps=500, autoreset=True, rng_mode=mode)
 env2.reset(seeds=1000)
 env2.run_random_steps(1000, 0, 250, timed=False)
 env2.lib.cc4_debug_profile(env2._h, 1, None)
-prev = np.zeros((n, 64), np.uint64); out = np.zeros((n, 64), np.uint64)
+prev = np.zeros((n, 128), np.uint64); out = np.zeros((n, 128), np.uint64)
 sec = ['policy', 'exec', 'rsc', 'fsm.trans', 'fsm.newobs', 'fsm.listing', 'fsm.removal', 'validate']
 acc = np.zeros((6, 8)); cnt = np.zeros(6); mx = np.zeros((6, 8)); worst = []
 for t in range(K):
     env2.run_random_steps(1000, 250 + t, 1, timed=False)
     env2.lib.cc4_debug_profile(env2._h, 1, out.ctypes.data_as(ctypes.c_void_p))
     d = (out - prev).astype(np.float64); prev = out.copy()
-    a = d[:, 16:].reshape(n, 6, 8)
+    a = d[:, 16:64].reshape(n, 6, 8)
     act = a[:, :, 0] > 0
     for r in range(6):
         if act[:, r].any():
