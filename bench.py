@@ -97,6 +97,10 @@ def main():
         raise SystemExit(f'--gpus {args.gpus} needs torch.distributed.run with --nproc-per-node {args.gpus} (WORLD_SIZE={world})')
     dist_on = world > 1 or os.environ.get('CC4_BENCH_FORCE_DIST') == '1'   # the env var drives the N>1 code path at world 1
     if dist_on:
+        # gloo / RCCL print banners on fd 1 from C++; keep stdout for the one JSON line
+        sys.stdout.flush()
+        saved_fd = os.dup(1)
+        os.dup2(2, 1)
         D.init_control_plane('gloo', force=True)
         import torch
         import torch.distributed as dist
@@ -109,6 +113,13 @@ def main():
     env.reset(seeds=np.uint64(args.seed0) + np.arange(lo, lo + n_local, dtype=np.uint64))
     if dist_on:
         D.init_rccl(env, rank, world)
+        env.run_random_steps(args.seed0 + lo, 0, 1, timed=False)   # first collective (RCCL prints its banner lazily)
+        env.reset(seeds=np.uint64(args.seed0) + np.arange(lo, lo + n_local, dtype=np.uint64))
+        import ctypes
+        ctypes.CDLL(None).fflush(None)           # C stdio buffers written while fd 1 pointed at stderr
+        sys.stdout.flush()
+        os.dup2(saved_fd, 1)
+        os.close(saved_fd)
     seed_actions = args.seed0 + lo            # action key = seed0 + global episode index
 
     def timed_run(e):

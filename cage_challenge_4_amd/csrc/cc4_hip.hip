@@ -12,6 +12,9 @@
 #include <stdlib.h>
 #include <string.h>
 #include <string>
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
 #include <vector>
 
 #include "../../include/cc4.h"
@@ -366,10 +369,16 @@ struct cc4_handle {
   int32_t* d_actions = nullptr; uint8_t* d_msgs = nullptr; uint64_t* d_seeds = nullptr; uint8_t* d_envmask = nullptr;
   int32_t* d_obs = nullptr; float* d_reward = nullptr; uint8_t* d_done = nullptr; uint32_t* d_err = nullptr;
   uint8_t* d_mask = nullptr; uint64_t* d_rng = nullptr;
-  uint8_t* d_obs8[2] = {nullptr, nullptr};      // byte observations, double-buffered against the overlapped all-gather
-  uint8_t* d_all_obs8[2] = {nullptr, nullptr};  // [world*N][578] gathered observations
+  // byte observations and gathered observations ([world*N][578]) in a ring of OBS_RING buffers: the all-gather of step t
+  // overlaps later steps, and the compute stream waits for the communication stream only once per OBS_WAIT_EVERY steps
+  // (a cross-stream wait in front of every launch costs the stream ~10 us)
+  static constexpr int OBS_RING = 8, OBS_WAIT_EVERY = 4;
+  uint8_t* d_obs8[OBS_RING] = {};
+  uint8_t* d_all_obs8[OBS_RING] = {};
+  long long gather_seq[OBS_RING] = {};           // sequence number of the last all-gather that read buffer b (0 = none)
+  long long gathers_issued = 0, gathers_waited = 0;
   hipStream_t comm_stream = nullptr;
-  hipEvent_t ev_step[2] = {nullptr, nullptr}, ev_comm[2] = {nullptr, nullptr};
+  hipEvent_t ev_step[OBS_RING] = {}, ev_comm[OBS_RING] = {};   // ev_comm[q % OBS_RING]: all-gather number q has completed
   int obs_buf = 0;                               // buffer written by the most recent step
   unsigned long long* d_prof = nullptr;
   ncclComm_t comm = nullptr; int rank = 0, world = 1;
@@ -393,8 +402,17 @@ static thread_local std::string g_create_err;
 static int launch_step(cc4_handle* h, const int32_t* d_actions, const uint8_t* d_msgs, bool rand = false, uint64_t seed0 = 0,
                        uint32_t t = 0) {
   // the byte-observation buffer about to be overwritten may still be read by an overlapped all-gather
-  int buf = h->comm ? (h->obs_buf ^ 1) : 0;
-  if (h->comm) HIPCHK(h, hipStreamWaitEvent(h->stream, h->ev_comm[buf], 0));
+  int buf = h->comm ? (h->obs_buf + 1) % cc4_handle::OBS_RING : 0;
+  if (h->comm && h->gather_seq[buf] > h->gathers_waited) {
+    // the last all-gather that read this buffer must be complete; wait for a slightly newer one (the communication stream is
+    // in order), so the next OBS_WAIT_EVERY-1 launches need no wait of their own -- but never for the newest one, which is
+    // the one meant to overlap this step
+    long long q = h->gather_seq[buf] + cc4_handle::OBS_WAIT_EVERY - 1;
+    if (q > h->gathers_issued - 1) q = h->gathers_issued - 1;
+    if (q < h->gather_seq[buf]) q = h->gather_seq[buf];
+    HIPCHK(h, hipStreamWaitEvent(h->stream, h->ev_comm[q % cc4_handle::OBS_RING], 0));
+    h->gathers_waited = q;
+  }
   StepArgs a{h->d_state, h->d_cold, d_actions, d_msgs, h->d_obs, h->d_reward, h->d_done, h->d_err,
              h->comm ? h->d_obs8[buf] : nullptr, rand ? h->d_actions : nullptr, seed0, t,
              h->cfg.num_envs, h->cfg.autoreset, h->cfg.steps, h->cfg.rng_mode,
@@ -460,11 +478,12 @@ void cc4_destroy(cc4_handle* h) {
   if (h->stream) (void)hipStreamSynchronize(h->stream);
   if (h->comm_stream) (void)hipStreamSynchronize(h->comm_stream);
   if (h->comm) ncclCommDestroy(h->comm);
-  for (int b = 0; b < 2; ++b) { if (h->ev_step[b]) (void)hipEventDestroy(h->ev_step[b]); if (h->ev_comm[b]) (void)hipEventDestroy(h->ev_comm[b]); }
+  for (int b = 0; b < cc4_handle::OBS_RING; ++b) { if (h->ev_step[b]) (void)hipEventDestroy(h->ev_step[b]); if (h->ev_comm[b]) (void)hipEventDestroy(h->ev_comm[b]); }
   if (h->comm_stream) (void)hipStreamDestroy(h->comm_stream);
   void* ptrs[] = {h->d_state, h->d_cold, h->d_actions, h->d_msgs, h->d_seeds, h->d_envmask, h->d_obs, h->d_reward,
-                  h->d_done, h->d_err, h->d_mask, h->d_rng, h->d_obs8[0], h->d_obs8[1], h->d_all_obs8[0], h->d_all_obs8[1]};
+                  h->d_done, h->d_err, h->d_mask, h->d_rng};
   for (void* p : ptrs) if (p) (void)hipFree(p);
+  for (int b = 0; b < cc4_handle::OBS_RING; ++b) { if (h->d_obs8[b]) (void)hipFree(h->d_obs8[b]); if (h->d_all_obs8[b]) (void)hipFree(h->d_all_obs8[b]); }
   for (hipEvent_t e : h->evs) if (e) (void)hipEventDestroy(e);
   if (h->ev0) (void)hipEventDestroy(h->ev0);
   if (h->ev1) (void)hipEventDestroy(h->ev1);
@@ -555,26 +574,38 @@ int cc4_synchronize(cc4_handle* h) {
 }
 int cc4_run_random_steps(cc4_handle* h, uint64_t seed0, uint32_t t0, int32_t k, float* ms_step_kernels) {
   HIPCHK(h, hipSetDevice(h->cfg.device_id));
-  // one event pair per step-kernel launch, recorded on the launch stream and read back after the loop:
-  // no host synchronisation inside the timed region
-  if (ms_step_kernels && (int)h->evs.size() < 2 * k) {
+  // Timing: HIP events on the launch stream around groups of TIMED_GROUP consecutive step launches (an event pair around
+  // every single launch costs the stream ~5 us of idle time per step); the sum over the groups is the on-stream time of the
+  // k launches, read back after the loop -- no host synchronisation inside the timed region.
+  constexpr int TIMED_GROUP = 25;
+  const int ngroups = ms_step_kernels ? (k + TIMED_GROUP - 1) / TIMED_GROUP : 0;
+  if ((int)h->evs.size() < 2 * ngroups) {
     size_t old = h->evs.size();
-    h->evs.resize(2 * (size_t)k, nullptr);
+    h->evs.resize(2 * (size_t)ngroups, nullptr);
     for (size_t i = old; i < h->evs.size(); ++i) HIPCHK(h, hipEventCreate(&h->evs[i]));
   }
+  const bool hp = getenv("CC4_HOST_PROF") != nullptr;
+  double t_launch = 0, t_ag = 0;
   for (int i = 0; i < k; ++i) {
-    if (ms_step_kernels) HIPCHK(h, hipEventRecord(h->evs[2 * i], h->stream));
+    if (ms_step_kernels && i % TIMED_GROUP == 0) HIPCHK(h, hipEventRecord(h->evs[2 * (i / TIMED_GROUP)], h->stream));
+    auto c0 = std::chrono::steady_clock::now();
     if (launch_step(h, nullptr, nullptr, true, seed0, t0 + (uint32_t)i)) return -1;   // actions drawn in-kernel
-    if (ms_step_kernels) HIPCHK(h, hipEventRecord(h->evs[2 * i + 1], h->stream));
+    auto c1 = std::chrono::steady_clock::now();
+    if (ms_step_kernels && (i % TIMED_GROUP == TIMED_GROUP - 1 || i == k - 1)) HIPCHK(h, hipEventRecord(h->evs[2 * (i / TIMED_GROUP) + 1], h->stream));
+    auto c2 = std::chrono::steady_clock::now();
     if (h->comm) { if (cc4_allgather_obs(h, nullptr)) return -1; }                       // overlaps the next step
+    auto c3 = std::chrono::steady_clock::now();
+    t_launch += std::chrono::duration<double, std::micro>(c1 - c0).count();
+    t_ag += std::chrono::duration<double, std::micro>(c3 - c2).count();
   }
+  if (hp) fprintf(stderr, "[cc4 host prof] k=%d launch_step %.2f us/step, allgather enqueue %.2f us/step\n", k, t_launch / k, t_ag / k);
   if (h->comm) HIPCHK(h, hipStreamSynchronize(h->comm_stream));
   HIPCHK(h, hipStreamSynchronize(h->stream));
   if (ms_step_kernels) {
     float total = 0.f;
-    for (int i = 0; i < k; ++i) {
+    for (int g = 0; g < ngroups; ++g) {
       float ms = 0.f;
-      HIPCHK(h, hipEventElapsedTime(&ms, h->evs[2 * i], h->evs[2 * i + 1]));
+      HIPCHK(h, hipEventElapsedTime(&ms, h->evs[2 * g], h->evs[2 * g + 1]));
       total += ms;
     }
     *ms_step_kernels = total;
@@ -656,13 +687,12 @@ int cc4_comm_init(cc4_handle* h, int32_t rank, int32_t world, const void* id128)
   h->rank = rank; h->world = world;
   size_t nb = (size_t)h->cfg.num_envs * OBS_TOTAL;
   HIPCHK(h, hipStreamCreateWithFlags(&h->comm_stream, hipStreamNonBlocking));
-  for (int b = 0; b < 2; ++b) {
+  for (int b = 0; b < cc4_handle::OBS_RING; ++b) {
     HIPCHK(h, hipMalloc(&h->d_obs8[b], nb));
     HIPCHK(h, hipMalloc(&h->d_all_obs8[b], nb * (size_t)world));
     HIPCHK(h, hipMemsetAsync(h->d_obs8[b], 0, nb, h->stream));
     HIPCHK(h, hipEventCreateWithFlags(&h->ev_step[b], hipEventDisableTiming));
     HIPCHK(h, hipEventCreateWithFlags(&h->ev_comm[b], hipEventDisableTiming));
-    HIPCHK(h, hipEventRecord(h->ev_comm[b], h->comm_stream));   // "no all-gather pending on this buffer"
   }
   HIPCHK(h, hipStreamSynchronize(h->stream));
   HIPCHK(h, hipStreamSynchronize(h->comm_stream));
@@ -670,8 +700,8 @@ int cc4_comm_init(cc4_handle* h, int32_t rank, int32_t world, const void* id128)
 }
 // All-gather of the observations written by the most recent step (as bytes, [world*N][578]) over RCCL/xGMI on the
 // handle's communication stream: it waits for that step's kernel, runs concurrently with whatever is enqueued next on
-// the compute stream (the next step writes the other byte buffer), and is awaited by cc4_allgather_wait / the second
-// next step.  *d_all_obs8 is valid after cc4_allgather_wait().
+// the compute stream (later steps write other buffers of the ring), and is awaited by cc4_allgather_wait / the step that
+// reuses its buffer.  *d_all_obs8 is valid after cc4_allgather_wait().
 int cc4_allgather_obs(cc4_handle* h, uint8_t** d_all_obs8) {
   if (!h->comm) { h->err = "cc4_allgather_obs: cc4_comm_init was not called"; return -2; }
   HIPCHK(h, hipSetDevice(h->cfg.device_id));
@@ -681,7 +711,9 @@ int cc4_allgather_obs(cc4_handle* h, uint8_t** d_all_obs8) {
   size_t cnt = (size_t)h->cfg.num_envs * OBS_TOTAL;
   ncclResult_t r = ncclAllGather(h->d_obs8[buf], h->d_all_obs8[buf], cnt, ncclUint8, h->comm, h->comm_stream);
   if (r != ncclSuccess) { h->err = std::string("ncclAllGather: ") + ncclGetErrorString(r); return -1; }
-  HIPCHK(h, hipEventRecord(h->ev_comm[buf], h->comm_stream));
+  const long long q = ++h->gathers_issued;
+  h->gather_seq[buf] = q;
+  HIPCHK(h, hipEventRecord(h->ev_comm[q % cc4_handle::OBS_RING], h->comm_stream));
   if (d_all_obs8) *d_all_obs8 = h->d_all_obs8[buf];
   return 0;
 }
