@@ -9,4 +9,6 @@ from .wrappers import (CybORG, EnterpriseScenarioGenerator, SleepAgent, Enterpri
                        DiscoveryFSRed, RandomSelectRedAgent,
                        BlueFixedActionWrapper, BlueFlatWrapper, BlueEnterpriseWrapper, EnterpriseMAE)
 
+from .true_state import TrueStateTableWrapper  # noqa: F401
+
 __version__ = '0.1.0'

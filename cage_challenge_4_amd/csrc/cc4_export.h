@@ -1,0 +1,60 @@
+// cc4_export.h -- true-state export of one episode (host code): the packed EnvState row decoded into a JSON document
+// with the content of the reference's CybORG.get_true_state() that the simulator tracks (State.get_true_state,
+// Simulator/State.py:150-224; consumer: Agents/Wrappers/TrueStateWrapper.py:25-243).
+//
+//   {"step":t,"phase":p,"blocks":[9 masks: bit f of blocks[to] = traffic from subnet f to subnet `to` is blocked],
+//    "cidr":[9 third octets: subnet s is 10.0.X.0/24], "n_green":g,
+//    "hosts":[{"h":host id (subnet*17+slot, 136 = internet root),"ip":last octet,
+//              "procs":[[pid,kind,root]...] (Host.processes order),
+//              "svcs":[[kind,active,reliability percent,pid]...] (Host.services order), "ev":event bits,
+//              "blue":pid of the blue session process (0 none),"green":pid of the green session process (0 none)}...],
+//    "red":[{"active":0/1,"sessions":[[id,host,pid,flags]...] (state.sessions[red_agent_r] order; flags = RS_* bits)}...x6],
+//    "blue":[{"parent":host id of the VelociraptorServer,"sus":[[host,pid]...]}...x5],"green_hosts":[host id of green_agent_g...]}
+#pragma once
+#include <stdio.h>
+#include <string>
+#include "cc4_engine.h"
+
+namespace cc4 {
+
+inline std::string export_true_state(const EnvState& s, const HostStatic* hs, const uint32_t (*sus)[MAX_SUS]) {
+  std::string o;
+  char b[256];
+  auto add = [&](const char* fmt, auto... a) { snprintf(b, sizeof(b), fmt, a...); o += b; };
+  add("{\"step\":%d,\"phase\":%d,\"blocks\":[", s.step_count, s.phase);
+  for (int i = 0; i < NSUB; ++i) add("%s%u", i ? "," : "", (unsigned)s.blocks[i]);
+  o += "],\"cidr\":[";
+  for (int i = 0; i < NSUB; ++i) add("%s%u", i ? "," : "", (unsigned)s.cidr_octet[i]);
+  add("],\"n_green\":%d,\"hosts\":[", (int)s.n_green);
+  bool first = true;
+  for (int h = 0; h < MAXH; ++h) {
+    if (!bit_get(s.exists, h)) continue;
+    const HostDyn& d = s.hd[h];
+    add("%s{\"h\":%d,\"ip\":%u,\"procs\":[", first ? "" : ",", h, (unsigned)hs[h].ip_octet);
+    first = false;
+    for (int i = 0; i < d.nproc; ++i) add("%s[%u,%u,%u]", i ? "," : "", (unsigned)d.procs[i].pid, (unsigned)d.procs[i].kind, (unsigned)(d.procs[i].flags & PF_ROOT));
+    o += "],\"svcs\":[";
+    for (int i = 0; i < d.nsvc; ++i)
+      add("%s[%u,%u,%u,%u]", i ? "," : "", (unsigned)d.svcs[i].kind, (unsigned)((d.svcs[i].st & SV_ACTIVE) ? 1 : 0), (unsigned)(d.svcs[i].st & 0x7F) * 20u, (unsigned)d.svcs[i].pid);
+    add("],\"ev\":%u,\"blue\":%u,\"green\":%u}", (unsigned)d.ev, (unsigned)s.blue_pid[h], (unsigned)s.green_pid[h]);
+  }
+  o += "],\"red\":[";
+  for (int r = 0; r < NRED; ++r) {
+    const RedAgent& A = s.red[r];
+    add("%s{\"active\":%u,\"sessions\":[", r ? "," : "", (unsigned)A.active);
+    for (int i = 0; i < A.nsess; ++i) add("%s[%u,%u,%u,%u]", i ? "," : "", (unsigned)A.sess[i].id, (unsigned)A.sess[i].host, (unsigned)A.sess[i].pid, (unsigned)A.sess[i].flags);
+    o += "]}";
+  }
+  o += "],\"blue\":[";
+  for (int k = 0; k < NBLUE; ++k) {
+    add("%s{\"parent\":%u,\"sus\":[", k ? "," : "", (unsigned)s.blue[k].parent_host);
+    for (int i = 0; i < s.blue[k].nsus; ++i) add("%s[%u,%u]", i ? "," : "", (unsigned)(sus[k][i] >> 16), (unsigned)(sus[k][i] & 0xFFFF));
+    o += "]}";
+  }
+  o += "],\"green_hosts\":[";
+  for (int g = 0; g < s.n_green; ++g) add("%s%u", g ? "," : "", (unsigned)s.green_host[g]);
+  o += "]}";
+  return o;
+}
+
+}  // namespace cc4

@@ -19,6 +19,7 @@
 
 #include "../../include/cc4.h"
 #include "cc4_engine.h"
+#include "cc4_export.h"
 
 using namespace cc4;
 
@@ -658,6 +659,21 @@ int cc4_get_topology(cc4_handle* h, int32_t env, uint8_t* out) {
     for (int i = 0; i < MAXH; ++i) { out[27 + 2 * i] = bit_get(tmp->exists, i) ? 1 : 0; out[28 + 2 * i] = hs[i].ip_octet; }
   }
   free(tmp); free(hs);
+  return rc;
+}
+
+int64_t cc4_get_true_state(cc4_handle* h, int32_t env, char* json, size_t cap) {
+  if (env < 0 || env >= h->cfg.num_envs) { h->err = "cc4_get_true_state: env out of range"; return -2; }
+  EnvState* st = (EnvState*)malloc(sizeof(EnvState));
+  EnvCold* cold = (EnvCold*)malloc(sizeof(EnvCold));
+  int64_t rc = cc4_get_state(h, env, st);
+  if (rc == 0) rc = cc4_get_cold(h, env, cold);
+  if (rc == 0) {
+    std::string doc = export_true_state(*st, cold->hs, cold->sus);
+    rc = (int64_t)doc.size() + 1;
+    if (json && cap >= doc.size() + 1) memcpy(json, doc.c_str(), doc.size() + 1);
+  }
+  free(st); free(cold);
   return rc;
 }
 

@@ -1,0 +1,179 @@
+"""True-state view of an episode, decoded from the packed state.
+
+Mirrors what the reference exposes through `CybORG.get_true_state(info)` (CybORG/env.py:297-309 ->
+State.get_true_state, Simulator/State.py:150-224) and `TrueStateTableWrapper`
+(Agents/Wrappers/TrueStateWrapper.py:25-243): per hostname a dict with 'Interface', 'Processes', 'Sessions',
+'System info' (plus 'Services', which the reference reports through the same call).  Only what the simulator tracks is
+reported; the reference's static decorations (paths, OS versions, user tables, files) are not modelled.
+
+`decode(json_text)` works on the document produced by `cc4_get_true_state` (schema: csrc/cc4_export.h).
+"""
+import json
+from ipaddress import IPv4Address, IPv4Network
+
+SUBNETS = ('restricted_zone_a_subnet', 'operational_zone_a_subnet', 'restricted_zone_b_subnet',
+           'operational_zone_b_subnet', 'contractor_network_subnet', 'public_access_zone_subnet',
+           'admin_network_subnet', 'office_network_subnet', 'internet_subnet')
+# process / service kinds (csrc/cc4_state.h K_*): name reported as process_name, listening port of the service
+KIND_NAME = ('SSHD', 'OTSERVICE', 'APACHE2', 'MYSQLD', 'SMTP', 'apache2', 'tomcat', 'haraka', 'vsftpd',
+             'VELOCIRAPTOR_SERVER', 'GREY_SESSION', 'RED_ABSTRACT_SESSION', 'cmd.sh')
+KIND_PORT = (22, 1, 80, 3390, 25, 80, 443, 25, 80, None, None, None, None)
+DECOY_KINDS = (5, 6, 7, 8)
+RS_ABSTRACT, RS_ROOT, RS_ORIG, RS_CHILD = 1, 2, 4, 8
+
+
+def hostname_of(h):
+    """Host id (subnet*17 + slot; 136 = internet root) -> the reference's hostname (EnterpriseScenarioGenerator.py:313-371)."""
+    if h == 136:
+        return 'root_internet_host_0'
+    s, slot = divmod(h, 17)
+    if slot == 0:
+        return f'{SUBNETS[s]}_router'
+    if slot <= 10:
+        return f'{SUBNETS[s]}_user_host_{slot - 1}'
+    return f'{SUBNETS[s]}_server_host_{slot - 11}'
+
+
+class TrueState:
+    """One episode's decoded state.  `.hosts[hostname]` is the reference-shaped dict; `.raw` the parsed document."""
+
+    def __init__(self, doc):
+        self.raw = doc if isinstance(doc, dict) else json.loads(doc)
+        d = self.raw
+        self.step, self.phase = d['step'], d['phase']
+        self.cidr = {SUBNETS[s]: IPv4Network(f'10.0.{d["cidr"][s]}.0/24') for s in range(9)}
+        self.blocks = {SUBNETS[to]: [SUBNETS[f] for f in range(9) if (d['blocks'][to] >> f) & 1] for to in range(9) if d['blocks'][to]}
+        green_of = {h: g for g, h in enumerate(d['green_hosts'])}
+        blue_zone = {0: 0, 1: 1, 2: 2, 3: 3, 5: 4, 6: 4, 7: 4}    # subnet -> blue agent (ESG.py:643-649)
+        sess_by_host = {}
+        for r, ag in enumerate(d['red']):
+            for sid, h, pid, fl in ag['sessions']:
+                sess_by_host.setdefault(h, []).append({
+                    'agent': f'red_agent_{r}', 'session_id': sid, 'PID': pid,
+                    'Type': 'RED_ABSTRACT_SESSION' if fl & RS_ABSTRACT else 'UNKNOWN',
+                    'username': 'root' if fl & RS_ROOT else 'user'})
+        # blue session ids: the VelociraptorServer is 0, the clients count up in creation order (State.py:103-136)
+        blue_sid = {}
+        for b, ag in enumerate(d['blue']):
+            blue_sid[ag['parent']] = 0
+        counters = [1] * 5
+        for hd in d['hosts']:     # creation order = allowed_subnets order then host order; recomputed below per agent
+            pass
+        self.hosts = {}
+        self.ip_map = {}
+        order = {b: [] for b in range(5)}
+        for hd in d['hosts']:
+            s = hd['h'] // 17
+            if hd['blue'] and s in blue_zone:
+                order[blue_zone[s]].append(hd['h'])
+        alloc = {0: [0], 1: [1], 2: [2], 3: [3], 4: [5, 6, 7]}    # allowed_subnets order of each blue agent
+        for b in range(5):
+            parent = d['blue'][b]['parent']
+            k = 1
+            for sn in alloc[b]:
+                for h in sorted(x for x in order[b] if x // 17 == sn):
+                    if h == parent:
+                        continue
+                    blue_sid[h] = k
+                    k += 1
+        for hd in d['hosts']:
+            h = hd['h']
+            name = hostname_of(h)
+            s = h // 17
+            ip = IPv4Address(f'10.0.{d["cidr"][s]}.{hd["ip"]}')
+            self.ip_map[name] = ip
+            procs = []
+            for pid, kind, root in hd['procs']:
+                p = {'PID': pid, 'process_name': KIND_NAME[kind], 'username': 'root' if root else 'user'}
+                if KIND_PORT[kind] is not None:
+                    p['Connections'] = [{'local_port': KIND_PORT[kind], 'local_address': IPv4Address('0.0.0.0')}]
+                if kind in DECOY_KINDS:
+                    p['Properties'] = ['decoy']
+                procs.append(p)
+            # a service whose process is gone (stopped by Impact, or replaced by a restore) still reports its PID: the
+            # reference's true state lists such a PID as a bare process entry (State.get_true_state merges 'Services')
+            have = {p['PID'] for p in procs}
+            for k, a, rel, pid in hd['svcs']:
+                if pid not in have:
+                    procs.append({'PID': pid})
+                    have.add(pid)
+            sessions = []
+            if hd['blue'] and s in blue_zone:
+                sessions.append({'agent': f'blue_agent_{blue_zone[s]}', 'session_id': blue_sid.get(h, 0), 'PID': hd['blue'],
+                                 'Type': 'VELOCIRAPTOR_SERVER' if d['blue'][blue_zone[s]]['parent'] == h else 'UNKNOWN', 'username': 'ubuntu'})
+            if hd['green'] and h in green_of:
+                sessions.append({'agent': f'green_agent_{green_of[h]}', 'session_id': 0, 'PID': hd['green'], 'Type': 'GREY_SESSION', 'username': 'ubuntu'})
+            sessions += sess_by_host.get(h, [])
+            entry = {'Interface': [{'interface_name': 'eth0', 'ip_address': ip, 'Subnet': self.cidr[SUBNETS[s]]}],
+                     'Processes': procs,
+                     'Services': {KIND_NAME[k]: {'active': bool(a), 'reliability': rel, 'PID': pid} for k, a, rel, pid in hd['svcs']},
+                     'System info': {'Hostname': name},
+                     'Events': {'network_connections': bool(hd['ev'] & 1), 'process_creation': bool(hd['ev'] & 2),
+                                'old_network_connections': bool(hd['ev'] & 4), 'old_process_creation': bool(hd['ev'] & 8)}}
+            if sessions:
+                entry['Sessions'] = sessions
+            self.hosts[name] = entry
+        self.sus_pids = {f'blue_agent_{b}': {} for b in range(5)}
+        for b, ag in enumerate(d['blue']):
+            for h, pid in ag['sus']:
+                self.sus_pids[f'blue_agent_{b}'].setdefault(hostname_of(h), []).append(pid)
+
+    def as_dict(self, info=None):
+        """`get_true_state(info)` shape: {hostname: {...}, 'success': TRUE}; `info` (hostname -> wanted keys) filters hosts."""
+        out = {n: v for n, v in self.hosts.items() if info is None or n in info}
+        out['success'] = True
+        return out
+
+
+def decode(doc):
+    return TrueState(doc)
+
+
+class _Table:
+    """Minimal stand-in for prettytable.PrettyTable (not installed in the image): field names, rows, str()."""
+    def __init__(self, field_names):
+        self.field_names = list(field_names)
+        self.rows = []
+
+    def add_row(self, row):
+        self.rows.append([str(c) for c in row])
+
+    def __str__(self):
+        w = [max(len(self.field_names[i]), *(len(r[i]) for r in self.rows)) if self.rows else len(self.field_names[i])
+             for i in range(len(self.field_names))]
+        line = '+' + '+'.join('-' * (x + 2) for x in w) + '+'
+        fmt = lambda r: '|' + '|'.join(' ' + r[i].ljust(w[i]) + ' ' for i in range(len(w))) + '|'   # noqa: E731
+        return '\n'.join([line, fmt(self.field_names), line] + [fmt(r) for r in self.rows] + [line])
+
+
+class TrueStateTableWrapper:
+    """Counterpart of the reference's TrueStateTableWrapper (TrueStateWrapper.py:6-243) over a cage_challenge_4_amd
+    `CybORG` (or anything with `.get_true_state()`): host overview and per-subnet process tables."""
+
+    def __init__(self, env):
+        self.env = env
+        self.hostnames = [n for n in env.get_true_state() if n != 'success']
+
+    def get_raw_full_true_state(self):
+        return self.env.get_true_state()
+
+    def get_host_overview_table(self):
+        t = _Table(['Hostname', 'IP Address', 'Sessions', 'No. Processes'])
+        ts = self.env.get_true_state()
+        ts.pop('success')
+        for hostname, st in ts.items():
+            sess = [s['agent'] for s in st['Sessions']] if 'Sessions' in st else '-'
+            t.add_row([hostname, st['Interface'][0]['ip_address'], sess, len(st.get('Processes', []))])
+        return t
+
+    def get_host_processes_tables(self):
+        ts = self.env.get_true_state()
+        ts.pop('success')
+        tables = {sn: _Table(['Hostname', 'PID', 'Name', 'Username', 'Session', 'SID']) for sn in SUBNETS}
+        for hostname, st in ts.items():
+            sn = next(s for s in SUBNETS if hostname.startswith(s) or (s == 'internet_subnet' and hostname == 'root_internet_host_0'))
+            by_pid = {s['PID']: s for s in st.get('Sessions', [])}
+            for p in st.get('Processes', []):
+                s = by_pid.get(p['PID'])
+                tables[sn].add_row([hostname, p['PID'], p.get('process_name', '-'), p.get('username', '-'), s['agent'] if s else '-', s['session_id'] if s else '-'])
+        return tables

@@ -114,6 +114,14 @@ class CC4VecEnv:
         self._chk(self.lib.cc4_get_topology(self._h, int(env), buf.ctypes.data_as(ctypes.c_void_p)), 'cc4_get_topology')
         return buf
 
+    def true_state_json(self, env=0):
+        """cc4_get_true_state: the episode's packed state as the JSON document described in csrc/cc4_export.h."""
+        need = int(self.lib.cc4_get_true_state(self._h, int(env), None, 0))
+        self._chk(0 if need > 0 else need, 'cc4_get_true_state')
+        buf = ctypes.create_string_buffer(need)
+        self._chk(0 if self.lib.cc4_get_true_state(self._h, int(env), buf, need) > 0 else -1, 'cc4_get_true_state')
+        return buf.value.decode()
+
     def rng_state(self):
         out = np.zeros((self.num_envs, 7), np.uint64)
         self._chk(self.lib.cc4_get_rng_state(self._h, out.ctypes.data_as(ctypes.c_void_p)), 'cc4_get_rng_state')

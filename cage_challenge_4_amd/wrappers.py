@@ -69,7 +69,9 @@ class EnterpriseScenarioGenerator:
             raise NotImplementedError("blue default policy: only SleepAgent (blue actions are submitted through step())")
         red = {'FiniteStateRedAgent': 0, 'SleepAgent': 1, 'DiscoveryFSRed': 2, 'RandomSelectRedAgent': 3}
         green = {'EnterpriseGreenAgent': 0, 'SleepAgent': 1}
-        rn, gn = getattr(red_agent_class, '__name__', None), getattr(green_agent_class, '__name__', None)
+        # None -> SleepAgent, as the reference's generators do (ESG.py:745-748, :815-817)
+        rn = 'SleepAgent' if red_agent_class is None else getattr(red_agent_class, '__name__', None)
+        gn = 'SleepAgent' if green_agent_class is None else getattr(green_agent_class, '__name__', None)
         if rn not in red or gn not in green:
             raise NotImplementedError(f"built-in policies of the HIP engine: red {list(red)}, green {list(green)} "
                                       f"(got red={red_agent_class}, green={green_agent_class}); "
@@ -117,6 +119,13 @@ class CybORG:
     def get_cidr_map(self):
         t = self.topology()
         return {SUBNET_NAMES[i]: f"10.0.{int(t[i])}.0/24" for i in range(9)}
+
+    def get_true_state(self, info=None):
+        """env.py:297-309 -> State.get_true_state: {hostname: {'Interface', 'Processes', 'Sessions', 'Services',
+        'System info', ...}, 'success': True}, decoded from the packed episode state (true_state.py).  `info`
+        (hostname -> wanted fields) only selects hosts."""
+        from .true_state import decode
+        return decode(self.vec.true_state_json(0)).as_dict(info)
 
     def get_ip_map(self):
         t = self.topology()

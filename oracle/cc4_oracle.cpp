@@ -20,6 +20,7 @@
 #include <omp.h>
 #endif
 #include "../cage_challenge_4_amd/csrc/cc4_engine.h"
+#include "../cage_challenge_4_amd/csrc/cc4_export.h"
 
 using namespace cc4;
 
@@ -78,6 +79,13 @@ void cc4o_set_threads(int n) {
 #else
   (void)n;
 #endif
+}
+// same document as cc4_get_true_state (include/cc4.h); returns bytes needed incl. NUL
+long long cc4o_true_state(void* h, int i, char* json, size_t cap) {
+  Oracle* o = (Oracle*)h;
+  std::string doc = export_true_state(o->st[i], o->cold[i].hs, o->cold[i].sus);
+  if (json && cap >= doc.size() + 1) memcpy(json, doc.c_str(), doc.size() + 1);
+  return (long long)doc.size() + 1;
 }
 // same layout as cc4_get_topology (include/cc4.h)
 void cc4o_topology(void* h, int i, uint8_t* out) {

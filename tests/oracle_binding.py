@@ -39,6 +39,8 @@ def load():
     lib.cc4o_state_ptr.argtypes = [ctypes.c_void_p, ctypes.c_int]
     lib.cc4o_topology.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]
     lib.cc4o_dump.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_int]
+    lib.cc4o_true_state.restype = ctypes.c_longlong
+    lib.cc4o_true_state.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_char_p, ctypes.c_size_t]
     return lib
 
 
@@ -119,6 +121,12 @@ class OracleVecEnv:
         n = self.lib.cc4o_state_bytes()
         p = self.lib.cc4o_state_ptr(self._h, i)
         return np.frombuffer((ctypes.c_uint8 * n).from_address(p), np.uint8).copy()
+
+    def true_state_json(self, i=0):
+        need = int(self.lib.cc4o_true_state(self._h, i, None, 0))
+        buf = ctypes.create_string_buffer(need)
+        self.lib.cc4o_true_state(self._h, i, buf, need)
+        return buf.value.decode()
 
     def dump(self, i):
         buf = ctypes.create_string_buffer(1 << 20)
