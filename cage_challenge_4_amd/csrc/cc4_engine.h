@@ -177,9 +177,11 @@ CC4_HD void ev_proc_red(Ctx x, int r, int h, int pid) {
 }
 CC4_HD void step_red_merge(Ctx x) {
   EnvState* s = x.s;
-  for (int r = 0; r < NRED; ++r) {
-    if (!s->pend_r[r]) continue;
-    if (s->npend >= MAX_PEND) set_err(x, E_PEND_OVERFLOW); else s->pend[s->npend++] = s->pend_r[r];
+  uint32_t pr[NRED];
+  CC4_UNROLL for (int r = 0; r < NRED; ++r) pr[r] = s->pend_r[r];
+  CC4_UNROLL for (int r = 0; r < NRED; ++r) {
+    if (!pr[r]) continue;
+    if (s->npend >= MAX_PEND) set_err(x, E_PEND_OVERFLOW); else s->pend[s->npend++] = pr[r];
     s->pend_r[r] = 0;
   }
 }
@@ -1646,6 +1648,14 @@ CC4_HD bool red_has_foreign_session(const EnvState* s, int r) {
   for (int w = 0; w < 5; ++w) if (A.live_hosts[w] & ~red_zone_hosts(r, w)) return true;
   return false;
 }
+// the same test for all six agents at once: 30 independent loads, masks folded to constants by the unrolling
+CC4_HD bool red_any_foreign_session(const EnvState* s) {
+  uint32_t acc = 0;
+  CC4_UNROLL for (int r = 0; r < NRED; ++r) {
+    CC4_UNROLL for (int w = 0; w < 5; ++w) acc |= s->red[r].live_hosts[w] & ~red_zone_hosts(r, w);
+  }
+  return acc != 0;
+}
 CC4_HD void step_red_exec_agent(Ctx x, int r) {
   EnvState* s = x.s;
   if (s->rexec[r].type == RA_NONE) return;
@@ -1656,17 +1666,16 @@ CC4_HD void step_red_exec_agent(Ctx x, int r) {
 // tables, its target host and commutative event bits); DiscoverRemoteSystems only reads the topology.  Returns the set of
 // agents whose actions do NOT commute with some other agent's and therefore keep the serial agent order among themselves.
 CC4_HD uint32_t red_conflict_mask(const EnvState* s) {
-  for (int a = 0; a < NRED; ++a) if (s->rexec[a].type == RA_WITHDRAW) return (1u << NRED) - 1u;   // kills sessions: everything serial
+  int ty[NRED], ho[NRED];   // the six actions in one batch of loads (Act = type | host << 8 | ... as one 8-byte record)
+  CC4_UNROLL for (int a = 0; a < NRED; ++a) { uint64_t v; __builtin_memcpy(&v, &s->rexec[a], 8); ty[a] = (int)(v & 0xFF); ho[a] = (int)((v >> 8) & 0xFF); }
   uint32_t m = 0;
-  for (int a = 0; a < NRED; ++a) {
-    int ta = s->rexec[a].type;
-    if (!(ta >= RA_AGGR && ta <= RA_DEGRADE)) continue;
-    for (int b = a + 1; b < NRED; ++b) {
-      int tb = s->rexec[b].type;
-      if (tb >= RA_AGGR && tb <= RA_DEGRADE && s->rexec[a].host == s->rexec[b].host) m |= (1u << a) | (1u << b);
-    }
+  bool withdraw = false;
+  CC4_UNROLL for (int a = 0; a < NRED; ++a) {
+    if (ty[a] == RA_WITHDRAW) withdraw = true;   // kills sessions: everything serial
+    CC4_UNROLL for (int b = a + 1; b < NRED; ++b)
+      if (ty[a] >= RA_AGGR && ty[a] <= RA_DEGRADE && ty[b] >= RA_AGGR && ty[b] <= RA_DEGRADE && ho[a] == ho[b]) m |= (1u << a) | (1u << b);
   }
-  return m;
+  return withdraw ? (1u << NRED) - 1u : m;
 }
 CC4_HD void step_red_exec(Ctx x) {
   for (int r = 0; r < NRED; ++r) step_red_exec_agent(x, r);
@@ -1677,7 +1686,11 @@ CC4_HD void step_red_exec(Ctx x) {
 CC4_HD void step_reassign(Ctx x, bool any_foreign) {
   EnvState* s = x.s;
   if (any_foreign) red_reassign(x);
-  else for (int r = 0; r < NRED; ++r) s->red[r].active = (uint8_t)(s->red[r].nsess > 0);
+  else {
+    int ns[NRED];
+    CC4_UNROLL for (int r = 0; r < NRED; ++r) ns[r] = s->red[r].nsess;
+    CC4_UNROLL for (int r = 0; r < NRED; ++r) s->red[r].active = (uint8_t)(ns[r] > 0);
+  }
   CC4_TICK(x, 8);
 }
 CC4_HD void step_monitor_host(Ctx x, int h) {  // the per-host part of Monitor.execute
@@ -1708,8 +1721,10 @@ CC4_HD void step_end(Ctx x, const uint8_t* messages) {
   s->step_count++;
   s->done = (uint8_t)(s->step_count >= s->steps - 1);
   int brm = s->brm;
-  for (int r = 0; r < NRED; ++r)
-    if (s->red[r].exec_type == RA_IMPACT && s->red[r].nsess > 0)
+  int et[NRED], ns[NRED];
+  CC4_UNROLL for (int r = 0; r < NRED; ++r) { et[r] = s->red[r].exec_type; ns[r] = s->red[r].nsess; }
+  CC4_UNROLL for (int r = 0; r < NRED; ++r)
+    if (et[r] == RA_IMPACT && ns[r] > 0)
       brm += reward_table(s->phase, h_subnet(s->red[r].exec_host), RW_RIA);  // charged for any executed Impact (App. B.2)
   s->action_cost = -(float)s->n_restore;
   s->reward = (float)brm + s->action_cost;
@@ -1736,9 +1751,7 @@ CC4_HD void env_step(Ctx x, const int32_t* actions, const uint8_t* messages /* [
   CC4_TICK(x, 6);
   step_red_exec(x);
   {
-    bool f = false;
-    for (int r = 0; r < NRED; ++r) f = f || red_has_foreign_session(s, r);
-    step_reassign(x, f);
+    step_reassign(x, red_any_foreign_session(s));
   }
   for (int h = 0; h < MAXH; ++h) step_monitor_host(x, h);
   step_monitor_pend(x);

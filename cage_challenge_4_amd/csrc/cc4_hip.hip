@@ -95,6 +95,7 @@ __global__ __launch_bounds__(WAVE) void k_step(StepArgs a) {
   // paths fold away) and written back once, before the row leaves LDS
   Rng rl = s->rng;
   rl.mode = 0;
+  rl.pad = 0;
   Ctx x{s, a.cold + e, &rl, lane == 0 ? prof : nullptr};
   if (prof && lane == 0) prof[11] += clock64() - t_begin;
   const bool do_reset = a.autoreset && s->done;
@@ -124,9 +125,7 @@ __global__ __launch_bounds__(WAVE) void k_step(StepArgs a) {
         }
         CC4_TICK(x, 6);
         step_red_exec(x);
-        bool f = false;
-        for (int r = 0; r < NRED; ++r) f = f || red_has_foreign_session(s, r);
-        step_reassign(x, f);
+        step_reassign(x, red_any_foreign_session(s));
       }
     }
   }
@@ -190,7 +189,7 @@ __device__ __forceinline__ void stage_in_n(uint4* __restrict__ lds, const uint4*
 
 __global__ __launch_bounds__(PT) void k_step_philox(StepArgs a) {
   extern __shared__ uint4 lds[];
-  __shared__ int ok_lds, flag_lds, conflict_lds;
+  __shared__ int ok_lds, conflict_lds;
   __shared__ int glist_n[2];
   __shared__ uint8_t glist[2][MAXG];  // green agents by action type (0 AccessService, 1 LocalWork)
   __shared__ unsigned long long prof_lds[16];
@@ -200,7 +199,7 @@ __global__ __launch_bounds__(PT) void k_step_philox(StepArgs a) {
   stage_in_n(lds, reinterpret_cast<const uint4*>(a.st + e), tid);
   unsigned long long* prof = a.prof ? prof_lds : nullptr;
   if (prof && tid < 16) prof_lds[tid] = 0;
-  if (tid == 0) { glist_n[0] = 0; glist_n[1] = 0; flag_lds = 0; conflict_lds = 0; ok_lds = 0; }
+  if (tid == 0) { glist_n[0] = 0; glist_n[1] = 0; conflict_lds = 0; ok_lds = 0; }
   __syncthreads();
   EnvState* s = reinterpret_cast<EnvState*>(lds);
   if (prof && tid == 0) prof[11] += clock64() - t_begin;
@@ -215,9 +214,11 @@ __global__ __launch_bounds__(PT) void k_step_philox(StepArgs a) {
     }
     __syncthreads();
     if (ok_lds) {
+      Ctx x0p{s, a.cold + e, nullptr, tid == 0 ? prof : nullptr};
       const int ng = s->n_green;
       // one thread-private generator per thread, in registers: every use starts with rng_set_stream(), which fully
       // determines the stream from (key, step, episode, stream id); mode pinned so the PCG paths fold away
+      if (tid == 0) CC4_TICK(x0p, 0);   // slot 0: step_phase + first barrier
       Rng rl;
       rng_fork(&rl, &s->rng, ST_RESET);
       rl.mode = 1;
@@ -226,16 +227,25 @@ __global__ __launch_bounds__(PT) void k_step_philox(StepArgs a) {
       const bool is_red = lane < (NRED + PW - 1) / PW && ragent < NRED;
       unsigned long long* ap = (a.prof && is_red) ? a.prof + PROF_SLOTS * (size_t)e + 16 + 8 * ragent : nullptr;
       Ctx xr{s, a.cold + e, &rl, nullptr, ap};
-      // ---- P0 blue submissions (wave 0 lanes 1..5) | P2 red FSM policy r on wave r lane 0 | P1 green draws on lanes >= 8
-      if (is_red) { unsigned long long t0 = ap ? clock64() : 0; step_red_policy(xr, ragent); if (ap) ap[0] += clock64() - t0; }
+      // ---- P0-P3a: every agent's policy / submission followed by its own duration-queue tick (SC:236-265), all on the
+      // agent's thread: red r on wave r%PW lane r/PW, blue on wave PW-1 lanes 2..6, green draws on lanes >= 8 of the waves
+      // that carry a single red agent.  A tick touches only its own agent (queue, observation reset, filter_actions
+      // against its own session table, which no other agent edits before the barrier below).
+      if (is_red) {
+        unsigned long long t0 = ap ? clock64() : 0;
+        step_red_policy(xr, ragent);
+        if (ap) ap[0] += clock64() - t0;
+        if (step_tick_agent(xr, NBLUE + ragent)) atomicSub(&s->n_actions, 1);
+      }
       else if (wave == PW - 1 && lane >= 2 && lane < 2 + NBLUE) {
         const int b = lane - 2;
         int32_t act = a.actions ? a.actions[e * NBLUE + b] : -1;
         if (a.rand_out) { act = random_blue_action(a.rand_seed0, a.rand_t, e, b); a.rand_out[e * NBLUE + b] = act; }
         step_blue_submit(x0, b, act);
+        (void)step_tick_agent(x0, b);
       }
-      else if (lane >= 8) {
-        for (int g = wave * (WAVE - 8) + (lane - 8); g < ng; g += PW * (WAVE - 8)) {
+      else if (lane >= 8 && wave >= 2) {
+        for (int g = (wave - 2) * (WAVE - 8) + (lane - 8); g < ng; g += (PW - 2) * (WAVE - 8)) {
           Ctx xg{s, a.cold + e, &rl, nullptr};
           step_green_policy(xg, g);
           int t = s->green_act[g];
@@ -244,9 +254,7 @@ __global__ __launch_bounds__(PT) void k_step_philox(StepArgs a) {
       }
       __syncthreads();
       CC4_TICK(x0, 2);
-      // ---- P3 duration queues, one agent per lane of wave 0; then blue execution in priority/agent order on thread 0
-      if (wave == 0 && lane < NBLUE + NRED && step_tick_agent(x0, lane)) atomicSub(&s->n_actions, 1);
-      __syncthreads();
+      // ---- P3b blue execution
       if (blue_exec_independent(s)) {      // uniform: every thread reads the same five action types
         if (tid == 0) CC4_TICK(x0, 3);
         const int bagent = lane * PW + wave;                                      // blue agent b on wave b % PW, lane b / PW
@@ -284,18 +292,17 @@ __global__ __launch_bounds__(PT) void k_step_philox(StepArgs a) {
         if (tid == 0) for (int r = 0; r < NRED; ++r) if ((serial_red >> r) & 1u) step_red_exec_agent(x0, r);
         __syncthreads();
       }
-      if (tid == 0) { step_red_merge(x0); CC4_TICK(x0, 7); }
-      // ---- reassignment: foreign-session scan per agent, the (rare) moves on thread 0
-      if (is_red && red_has_foreign_session(s, ragent)) atomicOr(&flag_lds, 1);
+      // ---- pid-event merge and reassignment on thread 0 (the foreign-session test is 5 words per agent)
+      if (tid == 0) {
+        step_red_merge(x0);
+        CC4_TICK(x0, 7);
+        step_reassign(x0, red_any_foreign_session(s));
+      }
       __syncthreads();
-      if (tid == 0) step_reassign(x0, flag_lds != 0);
-      __syncthreads();
-      // ---- P7 end-turn Monitor: per-host roll-over on all threads, sus-pid hand-over on thread 0 (disjoint data)
+      // ---- P7 end-turn Monitor (per-host roll-over on all threads, sus-pid hand-over on thread 0) and P8 end-turn
+      // RedSessionCheck (one red agent per wave) touch disjoint data (host event flags / blue lists vs red agent tables)
       for (int h = tid; h < MAXH; h += PT) step_monitor_host(x0, h);
-      if (tid == 0) step_monitor_pend(x0);
-      __syncthreads();
-      CC4_TICK(x0, 9);
-      // ---- P8 end-turn RedSessionCheck, one red agent per wave
+      if (tid == 0) { step_monitor_pend(x0); CC4_TICK(x0, 9); }
       if (is_red) { unsigned long long t0 = ap ? clock64() : 0; step_rsc(xr, ragent); if (ap) ap[2] += clock64() - t0; }
       __syncthreads();
       CC4_TICK(x0, 10);
