@@ -187,6 +187,22 @@ __device__ __forceinline__ void stage_in_n(uint4* __restrict__ lds, const uint4*
   for (; i < ROW_VEC; i += PT) lds[i] = src[i];
 }
 
+// The host table (EnvState.hd, two thirds of the row) is not read before the first action executes.  Its 16-byte vectors
+// go HBM -> LDS directly (global_load_lds_dwordx4: 1 KiB per wave-instruction, no staging registers) and stay in flight
+// while the rest of the row is staged through registers and the policy phase runs; `dma_wait` drains them before the
+// barrier that precedes the first action.  The instruction is issued from inline asm: the compiler would otherwise put a
+// vmcnt(0) in front of every LDS read that might alias the DMA destination, i.e. right away.
+constexpr int HD_V0 = (int)((offsetof(EnvState, hd) + 15) / 16);                             // first 16-byte vector fully inside hd
+constexpr int HD_CHUNKS = (int)(((offsetof(EnvState, hd) + sizeof(HostDyn) * MAXH) / 16 - HD_V0) / 64);   // whole 64-vector chunks
+constexpr int HD_V1 = HD_V0 + 64 * HD_CHUNKS;                                                // one past the DMA'd range
+__device__ __forceinline__ void dma_chunk(const uint4* gsrc_lane, uint4* lds_chunk_base) {
+  const uint32_t dst = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(__attribute__((address_space(3))) void*)lds_chunk_base);
+  uint32_t keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "v"(gsrc_lane), "s"(dst) : "memory");
+}
+__device__ __forceinline__ void dma_wait() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+
 __global__ __launch_bounds__(PT) void k_step_philox(StepArgs a) {
   extern __shared__ uint4 lds[];
   __shared__ int ok_lds, conflict_lds;
@@ -196,7 +212,18 @@ __global__ __launch_bounds__(PT) void k_step_philox(StepArgs a) {
   const int e = blockIdx.x, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   if (e >= a.n) return;
   unsigned long long t_begin = a.prof ? clock64() : 0;
-  stage_in_n(lds, reinterpret_cast<const uint4*>(a.st + e), tid);
+  const uint4* src = reinterpret_cast<const uint4*>(a.st + e);
+  // the part outside the host table through registers (3 vectors per thread), then the host-table chunks by DMA
+  constexpr int NA = HD_V0 + ROW_VEC - HD_V1;   // indexed 0..NA-1: [0,HD_V0) then [HD_V1,ROW_VEC)
+  constexpr int NA_U = (NA + PT - 1) / PT;
+  {
+    uint4 va[NA_U];
+#pragma unroll
+    for (int u = 0; u < NA_U; ++u) { int k = tid + u * PT; k = k < NA ? k : NA - 1; int i = k < HD_V0 ? k : k - HD_V0 + HD_V1; va[u] = src[i]; }
+#pragma unroll
+    for (int u = 0; u < NA_U; ++u) { int k = tid + u * PT; int i = k < HD_V0 ? k : k - HD_V0 + HD_V1; if (k < NA) lds[i] = va[u]; }
+  }
+  for (int c = wave; c < HD_CHUNKS; c += PW) dma_chunk(src + HD_V0 + 64 * c + lane, lds + HD_V0 + 64 * c);
   unsigned long long* prof = a.prof ? prof_lds : nullptr;
   if (prof && tid < 16) prof_lds[tid] = 0;
   if (tid == 0) { glist_n[0] = 0; glist_n[1] = 0; conflict_lds = 0; ok_lds = 0; }
@@ -205,6 +232,8 @@ __global__ __launch_bounds__(PT) void k_step_philox(StepArgs a) {
   if (prof && tid == 0) prof[11] += clock64() - t_begin;
   const bool do_reset = a.autoreset && s->done;
   if (do_reset) {
+    dma_wait();
+    __syncthreads();
     if (tid == 0) { Ctx x{s, a.cold + e, &s->rng}; env_reset(x, 0, a.rng_mode, a.steps, true, a.policy); }
   } else {
     if (tid == 0) {
@@ -252,6 +281,7 @@ __global__ __launch_bounds__(PT) void k_step_philox(StepArgs a) {
           if (t < 2) glist[t][atomicAdd(&glist_n[t], 1)] = (uint8_t)g;       // compaction by action type
         }
       }
+      dma_wait();          // the host table has landed in LDS behind the policy phase
       __syncthreads();
       CC4_TICK(x0, 2);
       // ---- P3b blue execution
@@ -307,7 +337,7 @@ __global__ __launch_bounds__(PT) void k_step_philox(StepArgs a) {
       __syncthreads();
       CC4_TICK(x0, 10);
       if (tid == 0) step_end(x0, a.msgs ? a.msgs + e * NBLUE * MSG_LEN : nullptr);
-    }
+    } else dma_wait();
   }
   __syncthreads();
   if (tid == 0) { a.reward[e] = s->reward; a.done[e] = s->done; a.err[e] = s->err; }
