@@ -1812,8 +1812,38 @@ CC4_HD int env_flat_obs_at(const EnvState* s, int idx) {
   if (k < 27) return !((comms_adjacent(s->phase, sn) >> sorted_subnet(k - 18)) & 1u);
   const int hs = k < 43 ? k - 27 : k - 43;
   const int h = hs < MAX_SERVERS ? h_make(sn, 11 + hs) : h_make(sn, 1 + (hs - MAX_SERVERS));
-  const int ev = bit_get(s->exists, h) ? s->hd[h].ev : 0;
+  const int ev = s->hd[h].ev;   // rows of hosts that do not exist stay zero (env_reset), so no existence test is needed
   return k < 43 ? ((ev & (EV_CUR_PROC | EV_OLD_PROC)) != 0) : ((ev & (EV_CUR_CONN | EV_OLD_CONN)) != 0);
+}
+// The same 578 values enumerated kind by kind (v = 0..577), so that the lanes of a wave take the same branch:
+//   [0,224) host events (7 subnet blocks x {16 process, 16 connection}), [224,287) blocked bits, [287,350) comms policy,
+//   [350,413) subnet one-hot, [413,573) message bits (5 agents x 32), [573,578) the 5 phase words.  *idx = position in the vector.
+CC4_HD int env_flat_obs_sorted(const EnvState* s, int v, int* idx) {
+  if (v < 413) {
+    int sb, k;       // subnet block 0..6 (agents 0..3 own one, agent 4 owns three), offset inside the 59-value block
+    if (v < 224) { sb = v >> 5; const int r = v & 31; k = 27 + (r & 15) + ((r >> 4) ? 16 : 0); }
+    else { const int w = v - 224, kind = w / 63, q = w % 63; sb = q / 9; k = 9 * (kind == 0 ? 1 : (kind == 1 ? 2 : 0)) + q % 9; }
+    const int b = sb < 4 ? sb : 4, i = sb < 4 ? 0 : sb - 4;
+    *idx = (b < 4 ? b * OBS_SHORT : 4 * OBS_SHORT) + 1 + 59 * i + k;
+    const int sn = blue_subnet_sorted(b, i);
+    if (k >= 27) {
+      const int hs = k < 43 ? k - 27 : k - 43;
+      const int h = hs < MAX_SERVERS ? h_make(sn, 11 + hs) : h_make(sn, 1 + (hs - MAX_SERVERS));
+      const int ev = s->hd[h].ev;   // rows of hosts that do not exist stay zero (env_reset)
+      return k < 43 ? ((ev & (EV_CUR_PROC | EV_OLD_PROC)) != 0) : ((ev & (EV_CUR_CONN | EV_OLD_CONN)) != 0);
+    }
+    if (k < 9) return sorted_subnet(k) == sn;
+    if (k < 18) return (s->blocks[sn] >> sorted_subnet(k - 9)) & 1u;
+    return !((comms_adjacent(s->phase, sn) >> sorted_subnet(k - 18)) & 1u);
+  }
+  if (v < 573) {
+    const int w = v - 413, b = w >> 5, m = w & 31, jj = m / MSG_LEN;
+    *idx = (b < 4 ? b * OBS_SHORT + OBS_SHORT : 4 * OBS_SHORT + OBS_LONG) - 32 + m;
+    return s->msg[jj < b ? jj : jj + 1][m % MSG_LEN];
+  }
+  const int b = v - 573;
+  *idx = b < 4 ? b * OBS_SHORT : 4 * OBS_SHORT;
+  return s->phase;
 }
 template <typename T>
 CC4_HD void env_flat_obs(const EnvState* s, T* out) {

@@ -346,7 +346,7 @@ __global__ __launch_bounds__(PT) void k_step_philox(StepArgs a) {
   {
     int32_t* o = a.obs + (size_t)e * OBS_TOTAL;
     uint8_t* o8 = a.obs8 ? a.obs8 + (size_t)e * OBS_TOTAL : nullptr;
-    for (int i = tid; i < OBS_TOTAL; i += PT) { int v = env_flat_obs_at(s, i); o[i] = v; if (o8) o8[i] = (uint8_t)v; }
+    for (int v = tid; v < OBS_TOTAL; v += PT) { int i; int val = env_flat_obs_sorted(s, v, &i); o[i] = val; if (o8) o8[i] = (uint8_t)val; }   // kind-sorted enumeration: uniform branches per wave
   }
   unsigned long long t_out = a.prof ? clock64() : 0;
   if (prof && tid == 0) prof[12] += t_out - t_obs;

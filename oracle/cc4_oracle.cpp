@@ -95,6 +95,12 @@ void cc4o_topology(void* h, int i, uint8_t* out) {
   for (int k = 0; k < MAXH; ++k) { out[27 + 2 * k] = bit_get(s.exists, k) ? 1 : 0; out[28 + 2 * k] = o->cold[i].hs[k].ip_octet; }
 }
 void cc4o_obs(void* h, int i, int32_t* out) { env_flat_obs<int32_t>(&((Oracle*)h)->st[i], out); }
+// the two per-value enumerations of the same vector (by position / by kind), for the host-logic test
+void cc4o_obs_variants(void* h, int i, int32_t* by_pos, int32_t* by_kind) {
+  const EnvState* s = &((Oracle*)h)->st[i];
+  for (int k = 0; k < OBS_TOTAL; ++k) by_pos[k] = env_flat_obs_at(s, k);
+  for (int v = 0; v < OBS_TOTAL; ++v) { int idx = -1; int val = env_flat_obs_sorted(s, v, &idx); by_kind[idx] = val; }
+}
 float cc4o_reward(void* h, int i) { return ((Oracle*)h)->st[i].reward; }
 int cc4o_done(void* h, int i) { return ((Oracle*)h)->st[i].done; }
 uint32_t cc4o_err(void* h, int i) { return ((Oracle*)h)->st[i].err; }

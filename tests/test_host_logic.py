@@ -65,3 +65,21 @@ def test_random_action_generator_ranges_and_determinism():
     assert not np.array_equal(a, random_actions(1000, 4, 4096))
     # shard-invariance: env e draws the same action whatever batch it sits in
     assert np.array_equal(random_actions(1000 + 100, 3, 10), a[100:110])
+
+
+def test_flat_obs_enumerations_agree():
+    """env_flat_obs (12 parts, the oracle's encoder), env_flat_obs_at (by position) and env_flat_obs_sorted (by kind, what
+    the device encodes) describe the same vector -- checked through the oracle build on a few evolved states."""
+    import ctypes
+    import numpy as np
+    from oracle_binding import OracleVecEnv, random_actions
+    o = OracleVecEnv(4, steps=60)
+    o.reset(seeds=5)
+    o.lib.cc4o_obs_variants.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]
+    for t in range(40):
+        obs, _, _, _ = o.step(random_actions(5, t, 4))
+        for i in range(4):
+            a = np.full(578, -1, np.int32)
+            b = np.full(578, -1, np.int32)
+            o.lib.cc4o_obs_variants(o._h, i, a.ctypes.data_as(ctypes.c_void_p), b.ctypes.data_as(ctypes.c_void_p))
+            assert np.array_equal(a, obs[i]) and np.array_equal(b, obs[i]), (t, i)
