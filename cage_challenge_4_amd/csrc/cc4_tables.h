@@ -48,11 +48,10 @@ CC4_HD int red_subnet_alloc(int r, int i) {
 CC4_HD int router_parent(int s) { return (int)((0x855882808ull >> (4 * s)) & 0xF); }  // {INT,RZA,INT,RZB,INT,INT,PUB,PUB,INT}
 // server_host_0 info links, EnterpriseScenarioGenerator.py:431-462 (bitmask of target subnets)
 CC4_HD uint32_t info_links(int s) {
-  const uint16_t t[NSUB] = {
-      (1u << S_OZA) | (1u << S_CON), (1u << S_RZA), (1u << S_OZB) | (1u << S_CON), (1u << S_RZB),
-      (1u << S_RZA) | (1u << S_RZB) | (1u << S_PUB), (1u << S_ADM) | (1u << S_OFF) | (1u << S_CON),
-      (1u << S_PUB), (1u << S_PUB), 0};
-  return t[s];
+  // {OZA|CON, RZA, OZB|CON, RZB, RZA|RZB|PUB, ADM|OFF|CON, PUB, PUB, 0} as nine 8-bit masks in one immediate
+  // (subnet bits RZA=0 OZA=1 RZB=2 OZB=3 CON=4 PUB=5 ADM=6 OFF=7)
+  const uint64_t t = 0x12ull | (0x01ull << 8) | (0x18ull << 16) | (0x04ull << 24) | (0x25ull << 32) | (0xD0ull << 40) | (0x20ull << 48) | (0x20ull << 56);
+  return s < 8 ? (uint32_t)((t >> (8 * s)) & 0xFF) : 0u;
 }
 
 // green allowed subnets per mission phase, EnterpriseScenarioGenerator.py:281-306 + SimulationController.py:747-765
@@ -66,11 +65,16 @@ CC4_HD uint32_t green_allowed_mask(int phase, int s) {
 
 // BlueRewardMachine.get_phase_rewards, Shared/BlueRewardMachine.py:35-65 : [phase][subnet][LWF, ASF, RIA]
 CC4_HD int reward_table(int phase, int s, int what) {
-  const int8_t t[3][NSUB][3] = {
-      {{-1, -3, -1}, {-1, -1, -1}, {-1, -3, -1}, {-1, -1, -1}, {0, -5, -5}, {-1, -1, -3}, {-1, -1, -3}, {-1, -1, -3}, {0, 0, -1}},
-      {{-2, -1, -3}, {-10, 0, -10}, {-1, -1, -1}, {-1, -1, -1}, {0, 0, 0}, {-1, -1, -3}, {-1, -1, -3}, {-1, -1, -3}, {0, 0, 0}},
-      {{-1, -3, -3}, {-1, -1, -1}, {-2, -1, -3}, {-10, 0, -10}, {0, 0, 0}, {-1, -1, -3}, {-1, -1, -3}, {-1, -1, -3}, {0, 0, 0}}};
-  return t[phase][s][what];
+  // phase 0: {{-1,-3,-1},{-1,-1,-1},{-1,-3,-1},{-1,-1,-1},{0,-5,-5},{-1,-1,-3},{-1,-1,-3},{-1,-1,-3},{0,0,-1}}
+  // phase 1: {{-2,-1,-3},{-10,0,-10},{-1,-1,-1},{-1,-1,-1},{0,0,0},{-1,-1,-3},{-1,-1,-3},{-1,-1,-3},{0,0,0}}
+  // phase 2: {{-1,-3,-3},{-1,-1,-1},{-2,-1,-3},{-10,0,-10},{0,0,0},{-1,-1,-3},{-1,-1,-3},{-1,-1,-3},{0,0,0}}
+  // as 27 nibble codes per phase (entry s*3+what; code 0..5 = 0,-1,-2,-3,-5,-10) in immediates: a const array would be a
+  // constant-memory load on the device, inside the green-action and end-of-step paths
+  const uint64_t lo = phase == 0 ? 0x1440111131111131ull : (phase == 1 ? 0x1000111111505312ull : 0x1000505312111331ull);
+  const uint64_t hi = phase == 0 ? 0x10031131131ull : 0x31131131ull;
+  const int e = s * 3 + what;
+  const int c = (int)(((e < 16 ? lo >> (4 * e) : hi >> (4 * (e - 16)))) & 0xF);
+  return c < 4 ? -c : (c == 4 ? -5 : -10);
 }
 enum : int { RW_LWF = 0, RW_ASF = 1, RW_RIA = 2 };
 
