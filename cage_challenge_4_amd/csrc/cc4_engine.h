@@ -134,7 +134,12 @@ CC4_HD void eph_clear(Ctx x, int h) {
 CC4_HD int create_pid(Ctx x, int h) {
   const HostDyn& d = x.s->hd[h];
   int mx = 0;
-  for (int i = 0; i < d.nproc; ++i) if (d.procs[i].pid > mx) mx = d.procs[i].pid;
+  const int n = d.nproc;
+  for (int i0 = 0; i0 < n; i0 += 8) {   // 8 process records (pid | kind << 16 | flags << 24) per round; MAXP is a multiple of 8
+    uint32_t v[8];
+    CC4_UNROLL for (int k = 0; k < 8; ++k) __builtin_memcpy(&v[k], &d.procs[i0 + k], 4);
+    CC4_UNROLL for (int k = 0; k < 8; ++k) if (i0 + k < n && (int)(v[k] & 0xFFFF) > mx) mx = (int)(v[k] & 0xFFFF);
+  }
   return mx + 1 + (int)rng_below(x.r, 9);
 }
 CC4_HD bool add_proc(Ctx x, int h, int pid, int kind, int flags) {
@@ -146,7 +151,14 @@ CC4_HD bool add_proc(Ctx x, int h, int pid, int kind, int flags) {
 }
 CC4_HD int find_proc(Ctx x, int h, int pid) {
   const HostDyn& d = x.s->hd[h];
-  for (int i = 0; i < d.nproc; ++i) if (d.procs[i].pid == pid) return i;
+  const int n = d.nproc;
+  for (int i0 = 0; i0 < n; i0 += 8) {
+    uint32_t v[8];
+    CC4_UNROLL for (int k = 0; k < 8; ++k) __builtin_memcpy(&v[k], &d.procs[i0 + k], 4);
+    int hit = -1;
+    CC4_UNROLL for (int k = 7; k >= 0; --k) if (i0 + k < n && (int)(v[k] & 0xFFFF) == pid) hit = i0 + k;
+    if (hit >= 0) return hit;
+  }
   return -1;
 }
 CC4_HD void remove_proc_at(Ctx x, int h, int idx) {
@@ -156,7 +168,12 @@ CC4_HD void remove_proc_at(Ctx x, int h, int idx) {
 }
 CC4_HD bool host_uses_port(Ctx x, int h, int pbit) {  // Host.is_using_port (Host.py:310-314)
   const HostDyn& d = x.s->hd[h];
-  for (int i = 0; i < d.nproc; ++i) if (kind_port(d.procs[i].kind) & pbit) return true;
+  const int n = d.nproc;
+  for (int i0 = 0; i0 < n; i0 += 8) {
+    uint32_t v[8];
+    CC4_UNROLL for (int k = 0; k < 8; ++k) __builtin_memcpy(&v[k], &d.procs[i0 + k], 4);
+    CC4_UNROLL for (int k = 0; k < 8; ++k) if (i0 + k < n && (kind_port((int)((v[k] >> 16) & 0xFF)) & pbit)) return true;
+  }
   return false;
 }
 // host.events.network_connections.append(...)
@@ -726,17 +743,31 @@ CC4_HD void blue_remove(Ctx x, int b, int h) {
 // Restore.execute -> RestoreFromBackup (AbstractActions/Restore.py:38-71, ConcreteActions/RestoreFromBackup.py:9-19)
 CC4_HD void blue_restore(Ctx x, int h) {
   EnvState* s = x.s;
-  for (int r = 0; r < NRED; ++r) {
+  uint32_t lw[NRED];   // which agents hold sessions on the host: one batch of loads
+  CC4_UNROLL for (int r = 0; r < NRED; ++r) lw[r] = s->red[r].live_hosts[h >> 5];
+  CC4_UNROLL for (int r = 0; r < NRED; ++r) {
+    if (!((lw[r] >> (h & 31)) & 1u)) continue;
     RedAgent& a = s->red[r];
-    if (!bit_get(a.live_hosts, h)) continue;
-    int orig = -1;
-    for (int i = 0; i < a.nsess;) {
-      if (a.sess[i].host != h) { ++i; continue; }
-      if (a.sess[i].flags & RS_ORIG) { orig = i; ++i; continue; }
-      rs_remove_at(x, r, i, true);
-      if (orig > i) orig--;
+    // every non-original session on the host goes, in table order; an original one is popped and re-added => moves to the end
+    for (;;) {
+      const int n = a.nsess;
+      int victim = -1;
+      for (int i0 = 0; i0 < n && victim < 0; i0 += 8) {
+        const S8 q = rs_load8(a, i0);
+        CC4_UNROLL for (int k = 7; k >= 0; --k) if (i0 + k < n && rsw_host(q.v[k]) == h && !(rsw_flags(q.v[k]) & RS_ORIG)) victim = i0 + k;
+      }
+      if (victim < 0) break;
+      rs_remove_at(x, r, victim, true);
     }
-    if (orig >= 0) rs_move_to_end(a, orig, -1);  // original session: popped and re-added => moves to the end of the agent's dict
+    {
+      const int n = a.nsess;
+      int orig = -1;
+      for (int i0 = 0; i0 < n; i0 += 8) {
+        const S8 q = rs_load8(a, i0);
+        CC4_UNROLL for (int k = 0; k < 8; ++k) if (i0 + k < n && rsw_host(q.v[k]) == h && (rsw_flags(q.v[k]) & RS_ORIG)) orig = i0 + k;   // the last one, as the walk left it
+      }
+      if (orig >= 0) rs_move_to_end(a, orig, -1);
+    }
   }
   host_restore(x, h);
 }
@@ -744,8 +775,16 @@ CC4_HD void blue_restore(Ctx x, int h) {
 CC4_HD void blue_decoy(Ctx x, int h) {
   EnvState* s = x.s;
   uint32_t cand = 8;  // bit i <=> K_DEC_APACHE + i is compatible; vsftpd checks port 21, which nothing uses (DecoyVsftpd.py:17-20)
-  int used = 0;
-  for (int i = 0; i < s->hd[h].nproc; ++i) used |= kind_port(s->hd[h].procs[i].kind);   // Host.is_using_port per factory
+  int used = 0;   // Host.is_using_port per factory, 8 process records per round
+  {
+    const HostDyn& dd = s->hd[h];
+    const int n = dd.nproc;
+    for (int i0 = 0; i0 < n; i0 += 8) {
+      uint32_t v[8];
+      CC4_UNROLL for (int k = 0; k < 8; ++k) __builtin_memcpy(&v[k], &dd.procs[i0 + k], 4);
+      CC4_UNROLL for (int k = 0; k < 8; ++k) if (i0 + k < n) used |= kind_port((int)((v[k] >> 16) & 0xFF));
+    }
+  }
   if (!(used & PB_80)) cand |= 1;
   if (!(used & PB_443)) cand |= 2;
   if (!(used & PB_25)) cand |= 4;
@@ -790,25 +829,33 @@ CC4_HD void phishing(Ctx x, int gh) {
     int best = -1;
     if (mh) best = wh * 32 + (31 - __builtin_clz(mh));
     else if (wl != wh) { uint32_t ml = s->red_hosts[wl] & (0xFFFFFFFFu << (lo & 31)); if (ml) best = wl * 32 + (31 - __builtin_clz(ml)); }
-    if (best >= 0) for (int r = 0; r < NRED; ++r) if (bit_get(s->red[r].live_hosts, best)) { src = r; break; }
+    if (best >= 0) {
+      uint32_t lw[NRED];   // the six agents' bitmap words for that host, one batch of loads
+      CC4_UNROLL for (int r = 0; r < NRED; ++r) lw[r] = s->red[r].live_hosts[best >> 5];
+      CC4_UNROLL for (int r = NRED - 1; r >= 0; --r) if ((lw[r] >> (best & 31)) & 1u) src = r;   // first agent in order
+    }
   }
   if (src < 0) {
     // red_agents = [(agent, host)] over hosts outside the subnet (there is no red session inside it here), host-major then
-    // agent order; choice(red_agents, replace=False) is one bounded draw
+    // agent order; choice(red_agents, replace=False) is one bounded draw.  All counts and bitmaps are read up front.
+    int nl[NRED]; uint32_t lh[NRED][5], rh[5];
+    CC4_UNROLL for (int r = 0; r < NRED; ++r) nl[r] = s->red[r].nlive;
+    CC4_UNROLL for (int w = 0; w < 5; ++w) rh[w] = s->red_hosts[w];
+    CC4_UNROLL for (int r = 0; r < NRED; ++r) { CC4_UNROLL for (int w = 0; w < 5; ++w) lh[r][w] = s->red[r].live_hosts[w]; }
     int nc = 0;
-    for (int r = 0; r < NRED; ++r) nc += s->red[r].nlive;
+    CC4_UNROLL for (int r = 0; r < NRED; ++r) nc += nl[r];
     if (nc == 0) return;
     int c = (int)rng_below(x.r, (uint32_t)nc);
-    for (int w = 0; w < 5 && src < 0; ++w) {
-      uint32_t m = s->red_hosts[w];
-      if (!m) continue;
+    CC4_UNROLL for (int w = 0; w < 5; ++w) {
+      uint32_t m = rh[w];
+      if (src >= 0 || !m) continue;
       int inw = 0;
-      for (int r = 0; r < NRED; ++r) inw += popc32(s->red[r].live_hosts[w]);
+      CC4_UNROLL for (int r = 0; r < NRED; ++r) inw += popc32(lh[r][w]);
       if (c >= inw) { c -= inw; continue; }
       while (m && src < 0) {
         int b = ctz32(m); m &= m - 1;
-        for (int r = 0; r < NRED; ++r)
-          if ((s->red[r].live_hosts[w] >> b) & 1u) { if (c-- == 0) { src = r; break; } }
+        CC4_UNROLL for (int r = 0; r < NRED; ++r)
+          if (src < 0 && ((lh[r][w] >> b) & 1u)) { if (c-- == 0) src = r; }
       }
     }
   }
@@ -1458,18 +1505,28 @@ CC4_HD void red_reassign(Ctx x) {
   // area: from | to << 3 | host << 8 | session id << 16
   uint32_t* mv = s->scratch; int nm = 0;
   const int cap = (int)(sizeof(s->scratch) / 4);
+  uint32_t foreign = 0;   // agents holding a session outside their zone: all 30 bitmap words in one batch of loads
+  CC4_UNROLL for (int r = 0; r < NRED; ++r) {
+    uint32_t acc = 0;
+    CC4_UNROLL for (int w = 0; w < 5; ++w) acc |= s->red[r].live_hosts[w] & ~red_zone_hosts(r, w);
+    if (acc) foreign |= 1u << r;
+  }
   for (int r = 0; r < NRED; ++r) {
+    if (!((foreign >> r) & 1u)) continue;
     const RedAgent& A = s->red[r];
-    bool foreign = false;
-    for (int w = 0; w < 5; ++w) if (A.live_hosts[w] & ~red_zone_hosts(r, w)) foreign = true;
-    if (!foreign) continue;
-    for (int i = 0; i < A.nsess; ++i) {
-      int sn = h_subnet(A.sess[i].host);
-      if ((red_allowed_mask(r) >> sn) & 1u) continue;
-      int to = red_of_subnet(sn);
-      if (to < 0) { set_err(x, E_UNREACHABLE); continue; }
-      if (nm < cap) mv[nm++] = (uint32_t)r | ((uint32_t)to << 3) | ((uint32_t)A.sess[i].host << 8) | ((uint32_t)A.sess[i].id << 16);
-      else set_err(x, E_RSESS_OVERFLOW);
+    const int n = A.nsess;
+    for (int i0 = 0; i0 < n; i0 += 8) {   // 8 session records per round (see rs_load8)
+      const S8 q = rs_load8(A, i0);
+      CC4_UNROLL for (int k = 0; k < 8; ++k) {
+        if (i0 + k >= n) continue;
+        const int host = rsw_host(q.v[k]);
+        const int sn = h_subnet(host);
+        if ((red_allowed_mask(r) >> sn) & 1u) continue;
+        const int to = red_of_subnet(sn);
+        if (to < 0) { set_err(x, E_UNREACHABLE); continue; }
+        if (nm < cap) mv[nm++] = (uint32_t)r | ((uint32_t)to << 3) | ((uint32_t)host << 8) | ((uint32_t)rsw_id(q.v[k]) << 16);
+        else set_err(x, E_RSESS_OVERFLOW);
+      }
     }
   }
   for (int m = 0; m < nm; ++m) {

@@ -297,6 +297,7 @@ __global__ __launch_bounds__(PT) void k_step_philox(StepArgs a) {
       }
       // ---- P4 green actions: wave 0 = AccessService list, wave 1 = LocalWork list (uniform control flow per wave)
       if (wave < 2) {
+        unsigned long long tg0 = a.prof ? clock64() : 0;
         int pen = 0;
         for (int i = lane; i < glist_n[wave]; i += WAVE) {
           int g = glist[wave][i];
@@ -304,6 +305,7 @@ __global__ __launch_bounds__(PT) void k_step_philox(StepArgs a) {
           pen += step_green_exec(xg, g);
         }
         if (pen) atomicAdd(&s->brm, pen);
+        if (a.prof && lane == 0) a.prof[PROF_SLOTS * (size_t)e + 96 + wave] += clock64() - tg0;   // debug: per-wave green action time
       }
       __syncthreads();
       CC4_TICK(x0, 6);

@@ -86,6 +86,30 @@ def test_hip_matches_oracle_bit_for_bit(rng_mode, policies):
     dev.close()
 
 
+@pytest.mark.parametrize('rng_mode', [0, 1], ids=['pcg64', 'philox'])
+def test_full_batch_matches_oracle_every_step(rng_mode):
+    """BASELINE configs[1] size: all 1024 episodes against the oracle at every step (observations, rewards, dones, error
+    flags), across an episode end (autoreset), and the packed state of every episode at the end.  A batch this size meets
+    the rare interleavings (same-step phishing + reassignment, concurrent blue Restore / red exploit on neighbouring
+    tables) that the 96-episode matrix can miss."""
+    n, T = 1024, 260
+    dev = _dev(n, steps=220, rng_mode=rng_mode, autoreset=True)
+    ora = OracleVecEnv(n, steps=220, rng_mode=rng_mode, autoreset=True)
+    assert np.array_equal(dev.reset(seeds=777), ora.reset(seeds=777))
+    for t in range(T):
+        a = random_actions(777, t, n)
+        d = dev.step(a)
+        o = ora.step(a)
+        bad = np.nonzero((d[0] != o[0]).any(axis=1) | (d[1] != o[1]) | (d[2] != o[2]))[0]
+        assert bad.size == 0, (t, bad[:10].tolist())
+        assert not d[3]['err'].any(), t
+    assert np.array_equal(dev.rng_state(), ora.rng_state())
+    for i in range(n):
+        a_, b_ = dev.get_state(i), ora.get_state(i)
+        assert np.array_equal(a_, b_), f'packed state differs env {i} at byte offsets {np.nonzero(a_ != b_)[0][:20].tolist()}'
+    dev.close()
+
+
 def test_device_random_action_kernel_matches_host_restatement():
     import ctypes
     n = 1024

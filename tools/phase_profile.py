@@ -28,3 +28,4 @@ if tt[:, 1].sum() > 0:
     for i in range(16):
         if tt[i, 1] > 0:
             print(f'  {ty[i]:10s} {tt[i, 1] / (n * K):6.3f}  {tt[i, 0] / tt[i, 1]:8.0f}')
+print('green action waves (AccessService list, LocalWork list): mean cycles', (out[:, 96].mean() / K).round(), (out[:, 97].mean() / K).round())
