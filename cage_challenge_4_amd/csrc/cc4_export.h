@@ -9,7 +9,9 @@
 //              "svcs":[[kind,active,reliability percent,pid]...] (Host.services order), "ev":event bits,
 //              "blue":pid of the blue session process (0 none),"green":pid of the green session process (0 none)}...],
 //    "red":[{"active":0/1,"sessions":[[id,host,pid,flags]...] (state.sessions[red_agent_r] order; flags = RS_* bits)}...x6],
-//    "blue":[{"parent":host id of the VelociraptorServer,"sus":[[host,pid]...]}...x5],"green_hosts":[host id of green_agent_g...]}
+//    "blue":[{"parent":host id of the VelociraptorServer,"sus":[[host,pid]...]}...x5],
+//    "last_blue":[[BA_* type,host or to-subnet,from-subnet]...x5],"last_red":[[RA_* type,host,subnet,executed (0 = dropped by filter_actions)]...x6] (the actions
+//    that resolved in the last step, i.e. CybORG.get_last_action), "green_hosts":[host id of green_agent_g...]}
 #pragma once
 #include <stdio.h>
 #include <string>
@@ -51,6 +53,10 @@ inline std::string export_true_state(const EnvState& s, const HostStatic* hs, co
     for (int i = 0; i < s.blue[k].nsus; ++i) add("%s[%u,%u]", i ? "," : "", (unsigned)(sus[k][i] >> 16), (unsigned)(sus[k][i] & 0xFFFF));
     o += "]}";
   }
+  o += "],\"last_blue\":[";   // self.action[blue_agent_b][0] of the last step: [BA_* type, host (or to-subnet), arg (from-subnet)]
+  for (int k = 0; k < NBLUE; ++k) add("%s[%u,%u,%u]", k ? "," : "", (unsigned)s.bexec[k].type, (unsigned)s.bexec[k].host, (unsigned)s.bexec[k].arg);
+  o += "],\"last_red\":[";    // self.action[red_agent_r][0]: [RA_* type, host, arg (subnet of DiscoverRemoteSystems), executed]
+  for (int r = 0; r < NRED; ++r) add("%s[%u,%u,%u,%u]", r ? "," : "", (unsigned)s.red[r].exec_type, (unsigned)s.red[r].exec_host, (unsigned)s.rexec[r].arg, (unsigned)(s.rexec[r].type != RA_NONE));
   o += "],\"green_hosts\":[";
   for (int g = 0; g < s.n_green; ++g) add("%s%u", g ? "," : "", (unsigned)s.green_host[g]);
   o += "]}";

@@ -34,6 +34,30 @@ def hostname_of(h):
     return f'{SUBNETS[s]}_server_host_{slot - 11}'
 
 
+BLUE_ACTION = ('Sleep', 'Monitor', 'Analyse', 'Remove', 'Restore', 'DeployDecoy', 'BlockTrafficZone', 'AllowTrafficZone')
+RED_ACTION = ('DiscoverRemoteSystems', 'AggressiveServiceDiscovery', 'StealthServiceDiscovery', 'DiscoverDeception',
+              'ExploitRemoteService', 'PrivilegeEscalate', 'Impact', 'DegradeServices', 'Withdraw', 'Sleep', 'InvalidAction', 'Sleep')
+
+
+class LastAction:
+    """What CybORG.get_last_action(agent) reports for the accelerated path: the action's class name and parameters, with the
+    reference's str() form (Action.__str__: class name followed by hostname / ip_address / subnet when it has one)."""
+
+    def __init__(self, name, agent, **params):
+        self.name, self.agent, self.session = name, agent, 0
+        self.__dict__.update(params)
+        self._params = params
+
+    def __str__(self):
+        for k in ('hostname', 'ip_address', 'subnet'):
+            if k in self._params and self.name not in ('BlockTrafficZone', 'AllowTrafficZone'):
+                return f'{self.name} {self._params[k]}'
+        return self.name
+
+    def __repr__(self):
+        return f'LastAction({self})'
+
+
 class TrueState:
     """One episode's decoded state.  `.hosts[hostname]` is the reference-shaped dict; `.raw` the parsed document."""
 
@@ -113,6 +137,27 @@ class TrueState:
             if sessions:
                 entry['Sessions'] = sessions
             self.hosts[name] = entry
+        self.last_action = {}
+        for b, (ty, host, arg) in enumerate(d.get('last_blue', [])):
+            name, agent = BLUE_ACTION[ty], f'blue_agent_{b}'
+            if ty in (2, 3, 4, 5):
+                self.last_action[agent] = LastAction(name, agent, hostname=hostname_of(host))
+            elif ty in (6, 7):
+                self.last_action[agent] = LastAction(name, agent, to_subnet=SUBNETS[host], from_subnet=SUBNETS[arg])
+            else:
+                self.last_action[agent] = LastAction(name, agent)
+        for r, (ty, host, arg, executed) in enumerate(d.get('last_red', [])):
+            name, agent = RED_ACTION[min(ty, 11)], f'red_agent_{r}'
+            if ty == 0:
+                self.last_action[agent] = LastAction(name, agent, subnet=self.cidr[SUBNETS[arg]])
+            elif ty in (1, 2, 4):
+                self.last_action[agent] = LastAction(name, agent, ip_address=IPv4Address(f'10.0.{d["cidr"][host // 17]}.{next(x["ip"] for x in d["hosts"] if x["h"] == host)}'))
+            elif ty == 3:     # DiscoverDeception carries an ip_address and prints the hostname its execute() resolved (None if it never ran)
+                self.last_action[agent] = LastAction(name, agent, hostname=hostname_of(host) if executed else None)
+            elif ty in (5, 6, 7):
+                self.last_action[agent] = LastAction(name, agent, hostname=hostname_of(host))
+            else:
+                self.last_action[agent] = LastAction(name, agent)
         self.sus_pids = {f'blue_agent_{b}': {} for b in range(5)}
         for b, ag in enumerate(d['blue']):
             for h, pid in ag['sus']:

@@ -127,6 +127,12 @@ class CybORG:
         from .true_state import decode
         return decode(self.vec.true_state_json(0)).as_dict(info)
 
+    def get_last_action(self, agent):
+        """env.py:300-314: the action of `agent` (blue_agent_b / red_agent_r) that resolved in the last step, as an object
+        whose str() equals the reference action's ('Restore <hostname>', 'ExploitRemoteService <ip>', 'Sleep', ...)."""
+        from .true_state import decode
+        return decode(self.vec.true_state_json(0)).last_action[agent]
+
     def get_ip_map(self):
         t = self.topology()
         out = {}

@@ -67,5 +67,32 @@ def main():
     print('wrote truestate_seed123.json', {k: len(v['hosts']) for k, v in cps.items()})
 
 
-if __name__ == '__main__':
+if __name__ == '__main__' and len(sys.argv) == 1:
     main()
+
+
+def last_actions():
+    """tests/golden/lastaction_seed123.json: str() of CybORG.get_last_action for every blue and red agent, 200 steps."""
+    z = np.load(os.path.join(OUT, 'traj_seed123_random_ctor_500.npz'))
+    A = z['actions'].astype(int)
+    sg = EnterpriseScenarioGenerator(blue_agent_class=SleepAgent, green_agent_class=EnterpriseGreenAgent, red_agent_class=FiniteStateRedAgent, steps=500)
+    env = CybORG(sg, seed=123)
+    w = BlueFlatWrapper(env)
+    w.reset()
+    agents = [f'blue_agent_{b}' for b in range(5)] + [f'red_agent_{r}' for r in range(6)]
+    rows = []
+    for t in range(200):
+        w.step({f'blue_agent_{b}': int(A[t, b]) for b in range(5)})
+        row = []
+        for ag in agents:
+            la = env.get_last_action(ag)
+            la = la if isinstance(la, list) else [la]
+            row.append(' | '.join(str(a) for a in la))
+        rows.append(row)
+    with open(os.path.join(OUT, 'lastaction_seed123.json'), 'w') as f:
+        json.dump({'fixture': 'traj_seed123_random_ctor_500.npz', 'agents': agents, 'steps': rows}, f, separators=(',', ':'))
+    print('wrote lastaction_seed123.json', len(rows))
+
+
+if __name__ == '__main__' and len(sys.argv) > 1 and sys.argv[1] == 'lastaction':
+    last_actions()

@@ -107,3 +107,38 @@ def test_cyborg_get_true_state_surface():
     sub = env.get_true_state({next(iter(ts)): 'All'})
     assert len(sub) == 2
     assert 'Hostname' in str(TrueStateTableWrapper(env).get_host_overview_table())
+
+
+def _check_last_actions(make_env):
+    doc = json.load(open(os.path.join(golden_util.GOLDEN_DIR, 'lastaction_seed123.json')))
+    fix = golden_util.load(os.path.join(golden_util.GOLDEN_DIR, doc['fixture']))
+    env = make_env(fix)
+    for t, want in enumerate(doc['steps']):
+        env.step(fix['actions'][t][None, :])
+        ts = T.decode(env.true_state_json(0))
+        got = [str(ts.last_action[a]) for a in doc['agents']]
+        assert got == want, (t, [(a, g, w) for a, g, w in zip(doc['agents'], got, want) if g != w])
+
+
+def test_last_action_matches_reference_oracle_build():
+    """CybORG.get_last_action (env.py:300-314): str() of the resolved action of all 11 stateful agents, 200 steps."""
+    from oracle_binding import OracleVecEnv
+
+    def make(fix):
+        e = OracleVecEnv(1, steps=fix['steps'])
+        e.reset(seeds=fix['seed'])
+        e.reset(seeds=None)
+        return e
+    _check_last_actions(make)
+
+
+@pytest.mark.gpu
+def test_last_action_matches_reference_hip():
+    from cage_challenge_4_amd import CC4VecEnv
+
+    def make(fix):
+        e = CC4VecEnv(1, steps=fix['steps'])
+        e.reset(seeds=fix['seed'])
+        e.reset(seeds=None)
+        return e
+    _check_last_actions(make)
