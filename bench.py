@@ -158,6 +158,16 @@ def main():
                'note': 'pcg64 = numpy Generator(PCG64) stream, bit-exact with the reference under the same seed' if other == 'pcg64'
                        else 'philox = counter-based streams per (agent, phase, step, episode)'}
         env2.close()
+    uni = None
+    if not args.no_alt and not dist_on and args.rng == 'philox':
+        # BASELINE configs 2-4 vs 5: the same workload with ONE topology shared by all episodes (dynamics still keyed per
+        # episode); the headline run above randomises the topology per episode and per reset, as the reference does
+        env3 = CC4VecEnv(n_local, steps=args.episode_steps, rng_mode=RNG_PHILOX, device_id=0, autoreset=True, topology_seed=args.seed0)
+        env3.reset(seeds=np.uint64(args.seed0) + np.arange(lo, lo + n_local, dtype=np.uint64))
+        dt3, ms3 = timed_run(env3)
+        uni = {'value': 5.0 * total_envs * args.steps / dt3, 'unit': 'agent-env steps/s', 'ms_per_step': dt3 / args.steps * 1e3,
+               'launch_ms': ms3 / args.steps, 'note': 'uniform topology: every episode draws its scenario from one shared key (cc4_config.topology_seed)'}
+        env3.close()
     if rank == 0:
         bytes_per_env = int(env.lib.cc4_algorithmic_bytes_per_env_step())
         launch_ms = ms_kernels / args.steps
@@ -174,7 +184,7 @@ def main():
             'config': {
                 'workload': f'{n_local} vectorised envs per GPU ({total_envs} total), uniform random blue actions '
                             f'(82/82/82/82/242 incl. invalid slots), FiniteStateRedAgent, EnterpriseGreenAgent, '
-                            f'EnterpriseScenarioGenerator(steps={args.episode_steps}), autoreset incl. scenario regeneration',
+                            f'EnterpriseScenarioGenerator(steps={args.episode_steps}), autoreset incl. scenario regeneration, topology randomised per episode and reset',
                 'envs_per_gpu': n_local, 'total_envs': total_envs, 'rng': args.rng,
                 'exchange': 'RCCL all-gather of the [N,578] uint8 obs of every step on a second stream, overlapped with the next step' if dist_on else 'none',
                 'env_steps_per_sec': total_envs * args.steps / dt, 'engine_error_flags': err_any,
@@ -186,6 +196,8 @@ def main():
         out['roofline']['kernel'] = 'k_step_philox' if args.rng == 'philox' else 'k_step'
         if alt is not None:
             out['alt_rng'] = alt
+        if uni is not None:
+            out['uniform_topology'] = uni
         if not dist_on and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(n_local, args.seed0)
         print(json.dumps(out), flush=True)

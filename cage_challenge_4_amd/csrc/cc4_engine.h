@@ -469,7 +469,10 @@ CC4_HD void host_restore(Ctx x, int h) {  // Host.restore (Host.py:373-429)
 }
 
 // continue_stream = true restates CybORG.reset(seed=None) (env.py:218-243): the same Generator keeps going.
-CC4_HD void env_reset(Ctx x, uint64_t seed, int rng_mode, int steps, bool continue_stream, int policy = 0) {
+// topo_seed != 0 (counter-based RNG mode only): every episode draws its scenario from the reset stream of the key
+// `topo_seed` instead of its own key, i.e. all episodes of a batch share topology, services and pids and differ only in
+// their dynamics (SURVEY 8(d)-5 "uniform topology" contrast; the reference always randomises per reset).
+CC4_HD void env_reset(Ctx x, uint64_t seed, int rng_mode, int steps, bool continue_stream, int policy = 0, uint32_t topo_seed = 0) {
   EnvState* s = x.s;
   Rng keep = s->rng;
   {  // zero everything (POD)
@@ -480,6 +483,8 @@ CC4_HD void env_reset(Ctx x, uint64_t seed, int rng_mode, int steps, bool contin
   s->rng_mode = (uint8_t)rng_mode;
   s->policy = (uint8_t)policy;
   rng_begin_episode(x.r);  // philox: the reset stream uses its own (step, episode) counter words
+  const uint64_t env_key = x.r->s_lo;
+  if (topo_seed && rng_mode == 1) x.r->s_lo = (uint64_t)topo_seed;
   s->steps = steps;
   {  // _generate_mission_phases (ESG.py:854-860)
     int q = steps / 3, rem = steps % 3;
@@ -611,6 +616,7 @@ CC4_HD void env_reset(Ctx x, uint64_t seed, int rng_mode, int steps, bool contin
     a.exec_type = RA_SLEEP;
   }
   s->step_count = 0; s->phase = 0; s->done = (uint8_t)(0 >= steps - 1); s->reward = 0.f;
+  if (topo_seed && rng_mode == 1) x.r->s_lo = env_key;
   rng_park(&s->rng);
 }
 

@@ -36,6 +36,7 @@ struct StepArgs {
   int32_t* rand_out;           // when non-null: draw the blue actions in-kernel (k_random_actions fused) and record them here
   uint64_t rand_seed0; uint32_t rand_t;
   int n, autoreset, steps, rng_mode, policy;
+  uint32_t topo;              // cc4_config.topology_seed
   unsigned long long* prof;   // optional [n][PROF_SLOTS] cycle counters (cc4_debug_profile): 16 phase slots + 8 per red agent
 };
 
@@ -102,7 +103,7 @@ __global__ __launch_bounds__(WAVE) void k_step(StepArgs a) {
   if (lane == 0) {
     ok_lds = 0;
     if (do_reset) {
-      env_reset(x, 0, a.rng_mode, a.steps, true, a.policy);   // new episode, same stream (CybORG.reset(seed=None))
+      env_reset(x, 0, a.rng_mode, a.steps, true, a.policy, a.topo);   // new episode, same stream (CybORG.reset(seed=None))
     } else {
       CC4_TICK0(x);
       int32_t racts[NBLUE];
@@ -234,7 +235,7 @@ __global__ __launch_bounds__(PT) void k_step_philox(StepArgs a) {
   if (do_reset) {
     dma_wait();
     __syncthreads();
-    if (tid == 0) { Ctx x{s, a.cold + e, &s->rng}; env_reset(x, 0, a.rng_mode, a.steps, true, a.policy); }
+    if (tid == 0) { Ctx x{s, a.cold + e, &s->rng}; env_reset(x, 0, a.rng_mode, a.steps, true, a.policy, a.topo); }
   } else {
     if (tid == 0) {
       Ctx x{s, a.cold + e, &s->rng, prof};
@@ -362,6 +363,7 @@ struct ResetArgs {
   EnvState* st; EnvCold* cold; const uint64_t* seeds; const uint8_t* env_mask;
   int32_t* obs; float* reward; uint8_t* done; uint32_t* err; uint8_t* mask;
   int n, steps, rng_mode, policy;
+  uint32_t topo;
 };
 __global__ __launch_bounds__(WAVE) void k_reset(ResetArgs a) {
   __shared__ uint8_t obs_lds[OBS_TOTAL + 2];
@@ -372,7 +374,7 @@ __global__ __launch_bounds__(WAVE) void k_reset(ResetArgs a) {
   EnvState* s = a.st + e;
   if (lane == 0) {
     Ctx x{s, a.cold + e, &s->rng};
-    env_reset(x, a.seeds ? a.seeds[e] : 0, a.rng_mode, a.steps, a.seeds == nullptr, a.policy);
+    env_reset(x, a.seeds ? a.seeds[e] : 0, a.rng_mode, a.steps, a.seeds == nullptr, a.policy, a.topo);
     env_flat_obs<uint8_t>(s, obs_lds);
     blue_action_mask(s, mask_lds);
     a.reward[e] = 0.f; a.done[e] = s->done; a.err[e] = s->err;
@@ -456,7 +458,7 @@ static int launch_step(cc4_handle* h, const int32_t* d_actions, const uint8_t* d
   StepArgs a{h->d_state, h->d_cold, d_actions, d_msgs, h->d_obs, h->d_reward, h->d_done, h->d_err,
              h->comm ? h->d_obs8[buf] : nullptr, rand ? h->d_actions : nullptr, seed0, t,
              h->cfg.num_envs, h->cfg.autoreset, h->cfg.steps, h->cfg.rng_mode,
-             (h->cfg.red_policy & 3) | (h->cfg.green_policy ? GP_SLEEP_BIT : 0), h->d_prof};
+             (h->cfg.red_policy & 3) | (h->cfg.green_policy ? GP_SLEEP_BIT : 0), (uint32_t)h->cfg.topology_seed, h->d_prof};
   if (h->cfg.rng_mode == 1) hipLaunchKernelGGL(k_step_philox, dim3(h->cfg.num_envs), dim3(PT), sizeof(EnvState), h->stream, a);
   else hipLaunchKernelGGL(k_step, dim3(h->cfg.num_envs), dim3(WAVE), sizeof(EnvState), h->stream, a);
   HIPCHK(h, hipGetLastError());
@@ -476,6 +478,7 @@ size_t cc4_algorithmic_bytes_per_env_step(void) {
 int cc4_create(const cc4_config* cfg, cc4_handle** out) {
   if (!cfg || !out || cfg->num_envs <= 0 || cfg->steps <= 0 || cfg->red_policy < 0 || cfg->red_policy > 3 ||
       cfg->green_policy < 0 || cfg->green_policy > 1) { g_create_err = "cc4_create: bad config"; return -2; }
+  if (cfg->topology_seed != 0 && cfg->rng_mode != 1) { g_create_err = "cc4_create: topology_seed needs rng_mode 1 (the numpy stream draws scenario and dynamics from one generator)"; return -2; }
   int ndev = 0;
   hipError_t e = hipGetDeviceCount(&ndev);
   if (e != hipSuccess || ndev <= 0) {
@@ -538,7 +541,7 @@ int cc4_reset(cc4_handle* h, const uint64_t* seeds, const uint8_t* env_mask) {
   if (env_mask) HIPCHK(h, hipMemcpyAsync(h->d_envmask, env_mask, n, hipMemcpyHostToDevice, h->stream));
   ResetArgs a{h->d_state, h->d_cold, seeds ? h->d_seeds : nullptr, env_mask ? h->d_envmask : nullptr, h->d_obs, h->d_reward,
               h->d_done, h->d_err, h->d_mask, h->cfg.num_envs, h->cfg.steps, h->cfg.rng_mode,
-              (h->cfg.red_policy & 3) | (h->cfg.green_policy ? GP_SLEEP_BIT : 0)};
+              (h->cfg.red_policy & 3) | (h->cfg.green_policy ? GP_SLEEP_BIT : 0), (uint32_t)h->cfg.topology_seed};
   hipLaunchKernelGGL(k_reset, dim3(h->cfg.num_envs), dim3(WAVE), 0, h->stream, a);
   HIPCHK(h, hipGetLastError());
   HIPCHK(h, hipStreamSynchronize(h->stream));

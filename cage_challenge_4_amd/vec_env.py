@@ -19,12 +19,14 @@ ERR_NAMES = {0: 'PROC_OVERFLOW', 1: 'RSESS_OVERFLOW', 2: 'KNOWN_SID_OVERFLOW', 3
 
 
 class CC4VecEnv:
-    def __init__(self, num_envs, steps=500, rng_mode=RNG_PCG64, device_id=0, autoreset=False, red_policy=0, green_policy=0):
+    def __init__(self, num_envs, steps=500, rng_mode=RNG_PCG64, device_id=0, autoreset=False, red_policy=0, green_policy=0,
+                 topology_seed=0):
+        """topology_seed != 0 (RNG_PHILOX only): all episodes share the scenario drawn from that key (uniform topology)."""
         self.lib = L.load()
         self.num_envs = int(num_envs)
         self.steps = int(steps)
         cfg = L.CC4Config(self.num_envs, self.steps, int(device_id), int(rng_mode), int(bool(autoreset)),
-                          int(red_policy), int(green_policy), 0)
+                          int(red_policy), int(green_policy), int(topology_seed))
         h = ctypes.c_void_p()
         rc = self.lib.cc4_create(ctypes.byref(cfg), ctypes.byref(h))
         if rc != 0:

@@ -26,6 +26,7 @@ using namespace cc4;
 
 struct Oracle {
   int n;
+  uint32_t topo = 0;   // cc4_config.topology_seed
   std::vector<EnvState> st;
   std::vector<EnvCold> cold;
 };
@@ -50,8 +51,9 @@ void* cc4o_cold_ptr(void* h, int i) { return &((Oracle*)h)->cold[i]; }
 void cc4o_reset(void* h, int i, uint64_t seed, int rng_mode, int steps, int continue_stream, int policy) {
   Oracle* o = (Oracle*)h;
   Ctx x{&o->st[i], &o->cold[i], &o->st[i].rng};
-  env_reset(x, seed, rng_mode, steps, continue_stream != 0, policy);
+  env_reset(x, seed, rng_mode, steps, continue_stream != 0, policy, o->topo);
 }
+void cc4o_set_topology_seed(void* h, uint32_t seed) { ((Oracle*)h)->topo = seed; }
 void cc4o_step(void* h, int i, const int32_t* actions, const uint8_t* msgs) {
   Oracle* o = (Oracle*)h;
   Ctx x{&o->st[i], &o->cold[i], &o->st[i].rng};

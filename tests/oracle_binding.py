@@ -46,7 +46,7 @@ def load():
 
 class OracleVecEnv:
     """Same call shape as cage_challenge_4_amd.CC4VecEnv, stepping episodes serially on the host."""
-    def __init__(self, num_envs, steps=500, rng_mode=0, autoreset=False, device_id=0, red_policy=0, green_policy=0):
+    def __init__(self, num_envs, steps=500, rng_mode=0, autoreset=False, device_id=0, red_policy=0, green_policy=0, topology_seed=0):
         self.lib = load()
         self.policy = (red_policy & 3) | (0x10 if green_policy else 0)
         self.num_envs = num_envs
@@ -54,6 +54,8 @@ class OracleVecEnv:
         self.rng_mode = rng_mode
         self.autoreset = autoreset
         self._h = ctypes.c_void_p(self.lib.cc4o_create(num_envs))
+        self.lib.cc4o_set_topology_seed.argtypes = [ctypes.c_void_p, ctypes.c_uint32]
+        self.lib.cc4o_set_topology_seed(self._h, int(topology_seed))
         self._obs = np.zeros((num_envs, 578), np.int32)
         self._rew = np.zeros(num_envs, np.float32)
         self._done = np.zeros(num_envs, bool)

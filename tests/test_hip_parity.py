@@ -303,3 +303,25 @@ def test_philox_and_pcg_modes_agree_in_distribution_on_device():
     z_ev = (stats[0][2] - stats[1][2]) / np.hypot(stats[0][3], stats[1][3])
     assert abs(z_rew) < 4.0 and abs(z_ev) < 4.0, (stats, z_rew, z_ev)
     assert stats[0][0] < -50
+
+
+def test_shared_topology_mode_matches_oracle():
+    """cc4_config.topology_seed: all episodes share the scenario (also after autoreset), dynamics differ, == oracle."""
+    n, T = 64, 70
+    dev = _dev(n, steps=50, rng_mode=1, autoreset=True, topology_seed=4242)
+    ora = OracleVecEnv(n, steps=50, rng_mode=1, autoreset=True, topology_seed=4242)
+    assert np.array_equal(dev.reset(seeds=9000), ora.reset(seeds=9000))
+    assert len({dev.topology(i).tobytes() for i in range(n)}) == 1
+    rew = []
+    for t in range(T):
+        a = random_actions(9000, t, n)
+        d = dev.step(a); o = ora.step(a)
+        assert np.array_equal(d[0], o[0]) and np.array_equal(d[1], o[1]) and np.array_equal(d[2], o[2]), t
+        rew.append(d[1].copy())
+    assert len({dev.topology(i).tobytes() for i in range(n)}) == 1          # the regenerated scenario is shared too
+    assert (np.array(rew).std(axis=1) > 0).any()                            # ... while the dynamics are per episode
+    for i in range(0, n, 9):
+        assert np.array_equal(dev.get_state(i), ora.get_state(i))
+    with pytest.raises(Exception):
+        _dev(4, steps=50, rng_mode=0, topology_seed=1)                    # the numpy stream cannot split scenario from dynamics
+    dev.close()

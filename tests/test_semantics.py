@@ -181,3 +181,23 @@ def test_philox_and_pcg_modes_agree_in_distribution(oracle_lib):
     assert abs(z_rew) < 4.0, (stats, z_rew)
     assert abs(z_ev) < 4.0, (stats, z_ev)
     assert stats[0][0] < -100 and stats[1][0] < -100       # both modes actually play the game
+
+
+def test_shared_topology_seed_semantics():
+    """topology_seed (Philox mode): identical scenario across the batch at every (auto)reset, per-episode dynamics."""
+    import numpy as np
+    from oracle_binding import OracleVecEnv, random_actions
+    o = OracleVecEnv(6, steps=25, rng_mode=1, autoreset=True, topology_seed=77)
+    o.reset(seeds=300)
+    first = o.topology(0).tobytes()
+    assert all(o.topology(i).tobytes() == first for i in range(6))
+    assert all(np.array_equal(o.get_state(0)[64:], o.get_state(i)[64:]) for i in range(1, 6))   # all but the generator key
+    rew = []
+    for t in range(30):
+        rew.append(o.step(random_actions(300, t, 6))[1].copy())
+    assert (np.array(rew).std(axis=1) > 0).any()
+    again = o.topology(0).tobytes()
+    assert again != first and all(o.topology(i).tobytes() == again for i in range(6))
+    p = OracleVecEnv(6, steps=25, rng_mode=1, topology_seed=0)
+    p.reset(seeds=300)
+    assert len({p.topology(i).tobytes() for i in range(6)}) > 1                                     # default: per-episode topology
