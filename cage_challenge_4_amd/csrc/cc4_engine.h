@@ -415,10 +415,13 @@ CC4_HD int gen_pid(Ctx x, uint32_t* used) {  // _generate_pid (ESG.py:564-578)
     if (!bit_get(used, pid - 1000)) { bit_set(used, pid - 1000); return pid; }
   }
 }
+// The scenario is generated into the dynamic host rows (EnvState.hd: LDS on the device), and the backup images
+// (Host.create_backup -> EnvCold.hs, HBM) are written from them once, with stores only: generating into the cold row
+// made every read-modify-write of the build a global-memory round trip.
 CC4_HD void gen_host(Ctx x, int h, uint32_t* used) {  // _generate_linux_host (ESG.py:470-528)
   EnvState* s = x.s;
-  HostStatic& st = x.c->hs[h];
-  st.exists = 1; st.nproc = 0; st.nsvc = 0;
+  HostDyn& st = s->hd[h];
+  st.nproc = 0; st.nsvc = 0;
   bit_set(s->exists, h);
   (void)rng_below(x.r, 2);  // OSDistribution choice (ESG.py:494): both are LINUX, value unused downstream
   if (h_is_router(h)) return;
@@ -447,13 +450,23 @@ CC4_HD void gen_host(Ctx x, int h, uint32_t* used) {  // _generate_linux_host (E
 }
 // Host.add_session for a starting session (Host.py:189-196): Process(pid=create_pid(), name=session_type)
 CC4_HD int start_session_proc(Ctx x, int h, int kind) {
-  HostStatic& st = x.c->hs[h];
+  HostDyn& st = x.s->hd[h];
   int mx = 0;
   for (int i = 0; i < st.nproc; ++i) if (st.procs[i].pid > mx) mx = st.procs[i].pid;
   int pid = mx + 1 + (int)rng_below(x.r, 9);
   st.procs[st.nproc].pid = (uint16_t)pid; st.procs[st.nproc].kind = (uint8_t)kind; st.procs[st.nproc].flags = 0;
   st.nproc++;
   return pid;
+}
+// Host.create_backup (Host.py:316-371): the freshly generated dynamic row becomes the backup image (stores only)
+CC4_HD void host_backup(Ctx x, int h, int ip_octet) {
+  const HostDyn& d = x.s->hd[h];
+  HostStatic st;
+  for (int i = 0; i < 8; ++i) st.procs[i] = d.procs[i];
+  for (int i = 0; i < 5; ++i) st.svcs[i] = d.svcs[i];
+  st.nproc = d.nproc; st.nsvc = d.nsvc; st.exists = 1; st.ip_octet = (uint8_t)ip_octet;
+  if (d.nproc > 8 || d.nsvc > 5) set_err(x, E_PROC_OVERFLOW);
+  __builtin_memcpy(&x.c->hs[h], &st, sizeof(HostStatic));
 }
 CC4_HD void host_restore(Ctx x, int h) {  // Host.restore (Host.py:373-429)
   EnvState* s = x.s;
@@ -472,14 +485,18 @@ CC4_HD void host_restore(Ctx x, int h) {  // Host.restore (Host.py:373-429)
 // topo_seed != 0 (counter-based RNG mode only): every episode draws its scenario from the reset stream of the key
 // `topo_seed` instead of its own key, i.e. all episodes of a batch share topology, services and pids and differ only in
 // their dynamics (SURVEY 8(d)-5 "uniform topology" contrast; the reference always randomises per reset).
-CC4_HD void env_reset(Ctx x, uint64_t seed, int rng_mode, int steps, bool continue_stream, int policy = 0, uint32_t topo_seed = 0) {
+// pid_ws: optional 288-word work area for the used-pid bitmap of the generation (the device kernels pass LDS); by default
+// the internet host's ephemeral-port map in the cold row serves (it is cleared again before the episode starts).
+CC4_HD void env_reset(Ctx x, uint64_t seed, int rng_mode, int steps, bool continue_stream, int policy = 0, uint32_t topo_seed = 0,
+                      uint32_t* pid_ws = nullptr, bool rng_is_copy = false) {
   EnvState* s = x.s;
   Rng keep = s->rng;
   {  // zero everything (POD)
     uint32_t* w = (uint32_t*)s;
     for (size_t i = 0; i < sizeof(EnvState) / 4; ++i) w[i] = 0;
   }
-  if (continue_stream) s->rng = keep; else rng_seed(&s->rng, seed, (uint32_t)rng_mode);  // NOTE: x.r must be &s->rng here
+  if (continue_stream) s->rng = keep; else rng_seed(&s->rng, seed, (uint32_t)rng_mode);  // NOTE: a fresh seed needs x.r == &s->rng;
+                                                                                          // a continued stream may be walked on a copy of it
   s->rng_mode = (uint8_t)rng_mode;
   s->policy = (uint8_t)policy;
   rng_begin_episode(x.r);  // philox: the reset stream uses its own (step, episode) counter words
@@ -495,8 +512,8 @@ CC4_HD void env_reset(Ctx x, uint64_t seed, int rng_mode, int steps, bool contin
     uint32_t* w = (uint32_t*)x.c->hs;
     for (size_t i = 0; i < sizeof(x.c->hs) / 4; ++i) w[i] = 0;
   }
-  uint32_t* used = x.c->eph[H_INTERNET];  // scratch bitmap for used_pids (cleared by the backup below)
-  for (int i = 0; i < EPH_WORDS; ++i) used[i] = 0;
+  uint32_t* used = pid_ws ? pid_ws : x.c->eph[H_INTERNET];  // bitmap of used_pids over 1000..9999 (the cold one is cleared by the backup below)
+  for (int i = 0; i < 288; ++i) used[i] = 0;
 
   // _generate_subnets (ESG.py:171-266): choice(len(remaining /24 blocks)) per subnet, pop.  The remaining list stays
   // ascending, so "pop(c)" is the c-th set bit of a 256-bit availability map
@@ -523,22 +540,22 @@ CC4_HD void env_reset(Ctx x, uint64_t seed, int rng_mode, int steps, bool contin
       int c = (int)rng_below(x.r, (uint32_t)n);
       uint8_t ip = pop_at(c);
       gen_host(x, H_INTERNET, used);
-      x.c->hs[H_INTERNET].ip_octet = ip;
+      s->hd[H_INTERNET].pad = ip;   // parked in the row's pad byte until the backup image is written
       continue;
     }
     int hr = h_make(sn, 0);
-    { int c = (int)rng_below(x.r, (uint32_t)n); uint8_t ip = pop_at(c); gen_host(x, hr, used); x.c->hs[hr].ip_octet = ip; }
+    { int c = (int)rng_below(x.r, (uint32_t)n); uint8_t ip = pop_at(c); gen_host(x, hr, used); s->hd[hr].pad = ip; }
     int nu = 3 + (int)rng_below(x.r, 8);  // integers(3, 10, endpoint=True)
     for (int i = 0; i < nu; ++i) {
       int h = h_make(sn, 1 + i);
       int c = (int)rng_below(x.r, (uint32_t)n); uint8_t ip = pop_at(c);
-      gen_host(x, h, used); x.c->hs[h].ip_octet = ip;
+      gen_host(x, h, used); s->hd[h].pad = ip;
     }
     int ns = 1 + (int)rng_below(x.r, 6);  // integers(1, 6, endpoint=True)
     for (int i = 0; i < ns; ++i) {
       int h = h_make(sn, 11 + i);
       int v = last_set(ips, 8); bit_clr(ips, v); n--;  // ip_addresses.pop()
-      gen_host(x, h, used); x.c->hs[h].ip_octet = (uint8_t)v;
+      gen_host(x, h, used); s->hd[h].pad = (uint8_t)v;
     }
     s->n_users[sn] = (uint8_t)nu; s->n_servers[sn] = (uint8_t)ns;
   }
@@ -591,8 +608,8 @@ CC4_HD void env_reset(Ctx x, uint64_t seed, int rng_mode, int steps, bool contin
   int red0_pid = start_session_proc(x, s->red[0].start_host, K_SESS_RED);
   // host.create_backup() for every host (State.py:137-138) -> dynamic state := static
   for (int h = 0; h < MAXH; ++h) {
-    if (bit_get(s->exists, h)) host_restore(x, h);
-    else { s->hd[h].nproc = 0; s->hd[h].nsvc = 0; s->hd[h].ev = 0; eph_clear(x, h); }
+    if (bit_get(s->exists, h)) { host_backup(x, h, s->hd[h].pad); s->hd[h].pad = 0; s->hd[h].ev = 0; }
+    eph_clear(x, h);
   }
   s->npend = 0;
   // red_agent_0 starts active with session 0 (ESG.py:791-801)
@@ -617,6 +634,7 @@ CC4_HD void env_reset(Ctx x, uint64_t seed, int rng_mode, int steps, bool contin
   }
   s->step_count = 0; s->phase = 0; s->done = (uint8_t)(0 >= steps - 1); s->reward = 0.f;
   if (topo_seed && rng_mode == 1) x.r->s_lo = env_key;
+  if (rng_is_copy) s->rng = *x.r;      // the generator was walked on a caller-side (register) copy
   rng_park(&s->rng);
 }
 

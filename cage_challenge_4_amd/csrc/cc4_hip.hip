@@ -82,6 +82,7 @@ __global__ __launch_bounds__(WAVE) void k_step(StepArgs a) {
   extern __shared__ uint4 lds[];
   __shared__ uint8_t obs_lds[OBS_TOTAL + 2];
   __shared__ int ok_lds;
+  __shared__ uint32_t reset_ws[288];   // used-pid bitmap of the scenario generation (autoreset)
   const int e = blockIdx.x, lane = threadIdx.x;
   if (e >= a.n) return;
   unsigned long long t_begin = a.prof ? clock64() : 0;
@@ -103,7 +104,7 @@ __global__ __launch_bounds__(WAVE) void k_step(StepArgs a) {
   if (lane == 0) {
     ok_lds = 0;
     if (do_reset) {
-      env_reset(x, 0, a.rng_mode, a.steps, true, a.policy, a.topo);   // new episode, same stream (CybORG.reset(seed=None))
+      env_reset(x, 0, a.rng_mode, a.steps, true, a.policy, a.topo, reset_ws);   // new episode, same stream (CybORG.reset(seed=None))
     } else {
       CC4_TICK0(x);
       int32_t racts[NBLUE];
@@ -207,6 +208,7 @@ __device__ __forceinline__ void dma_wait() { asm volatile("s_waitcnt vmcnt(0)" :
 __global__ __launch_bounds__(PT) void k_step_philox(StepArgs a) {
   extern __shared__ uint4 lds[];
   __shared__ int ok_lds, conflict_lds;
+  __shared__ uint32_t reset_ws[288];   // used-pid bitmap of the scenario generation (autoreset)
   __shared__ int glist_n[2];
   __shared__ uint8_t glist[2][MAXG];  // green agents by action type (0 AccessService, 1 LocalWork)
   __shared__ unsigned long long prof_lds[16];
@@ -235,7 +237,7 @@ __global__ __launch_bounds__(PT) void k_step_philox(StepArgs a) {
   if (do_reset) {
     dma_wait();
     __syncthreads();
-    if (tid == 0) { Ctx x{s, a.cold + e, &s->rng}; env_reset(x, 0, a.rng_mode, a.steps, true, a.policy, a.topo); }
+    if (tid == 0) { Rng rr = s->rng; rr.mode = 1; Ctx x{s, a.cold + e, &rr}; env_reset(x, 0, a.rng_mode, a.steps, true, a.policy, a.topo, reset_ws, true); }   // generator in registers
   } else {
     if (tid == 0) {
       Ctx x{s, a.cold + e, &s->rng, prof};
