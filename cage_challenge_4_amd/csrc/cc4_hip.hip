@@ -162,19 +162,21 @@ __global__ __launch_bounds__(WAVE) void k_step(StepArgs a) {
 // ---------------------------------------------------------------- Philox mode: wave- and lane-parallel step
 // Same phase bodies as the serial walk (cc4_engine.h P0..P9), different schedule.  One block of 4 wavefronts per episode:
 // every (agent, phase) owns a Philox counter stream, so heterogeneous agents can run concurrently.  Work that differs in
-// control flow goes to different WAVES (a wave executes divergent lanes one after the other): the 6 red FSM policies, the
-// 6 red actions (when they name distinct hosts, else serial), the 6 RedSessionChecks (agent r -> wave r % 4, lane r / 4;
-// measured on MI355X: 3..5 waves per block are equivalent, 6 is 30 % slower), and the two green action types
-// (AccessService / LocalWork lists built with wave ballots + LDS counters).  Work that is uniform goes to LANES: row
-// staging, per-agent queue ticks, green agents within a type, the 137 Monitor roll-overs, the observation encode.
+// control flow goes to different WAVES (a wave executes divergent lanes one after the other): the 6 red FSM policies with
+// their queue ticks, the 5 blue actions (disjoint zones), the 6 red actions (those naming the same host are held back and
+// run in order on thread 0), the 6 RedSessionChecks (agent r -> wave r % 4, lane r / 4), and the two green action types
+// (AccessService / LocalWork lists built with LDS counters).  Work that is uniform goes to LANES: row staging, green agents
+// within a type, the 137 Monitor roll-overs, the observation encode (enumerated kind by kind).  Measured on MI355X: 4..8
+// waves per block are equivalent at 1024 episodes when the register budget allows 4 blocks per CU; 6 waves without a
+// waves-per-EU hint lose a resident block to SGPR granularity.
 // Cross-thread effects are event-bit ORs and the reward sum (LDS atomics); the rare order-dependent spawns (PhishingEmail,
 // cross-subnet session reassignment) are collected and replayed by thread 0 in agent order.
 #ifndef CC4_PW
 #define CC4_PW 4
 #endif
 constexpr int PW = CC4_PW;         // waves per episode block; red agent r runs on wave r % PW, lane r / PW
-static_assert(PW >= 3 && PW <= 6, "waves 0/1 run the two green action lists, wave 2 the Sleep bookkeeping");
-constexpr int PT = PW * WAVE;      // 384 threads
+static_assert(PW >= 4 && PW <= 6, "waves 0/1 run the two green action lists, waves 2.. the green draws, wave PW-1 the blue submissions");
+constexpr int PT = PW * WAVE;      // threads per episode block (256)
 
 __device__ __forceinline__ void stage_in_n(uint4* __restrict__ lds, const uint4* __restrict__ src, int tid) {
   constexpr int U = (ROW_VEC / PT) < 6 ? (ROW_VEC / PT) : 6;   // loads in flight per thread (the whole row in one or two rounds)
