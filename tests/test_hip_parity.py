@@ -325,3 +325,22 @@ def test_shared_topology_mode_matches_oracle():
     with pytest.raises(Exception):
         _dev(4, steps=50, rng_mode=0, topology_seed=1)                    # the numpy stream cannot split scenario from dynamics
     dev.close()
+
+
+@pytest.mark.parametrize('rng_mode,red_policy', [(1, 0), (0, 0), (1, 2), (1, 3)], ids=['philox-fsm', 'pcg64-fsm', 'philox-discovery', 'philox-randomselect'])
+def test_soak_bounded_containers_never_overflow(rng_mode, red_policy):
+    """4096 episodes x 1500 steps (three full 500-step episodes each, autoreset) of device-side random blue actions: no
+    engine error flag (container overflow, reference-crash path) may ever be raised, rewards stay <= 0, observations stay
+    in range, and every episode finishes exactly on the autoreset cadence."""
+    n = 4096
+    dev = _dev(n, steps=500, rng_mode=rng_mode, autoreset=True, red_policy=red_policy)
+    dev.reset(seeds=20000)
+    done_count = np.zeros(n, np.int64)
+    for chunk in range(15):
+        dev.run_random_steps(20000, chunk * 100, 100, timed=False)
+        obs, rew, done = dev._fetch()
+        assert not dev.err.any(), (chunk, np.unique(dev.err[dev.err != 0])[:5])
+        assert (rew <= 0).all() and ((obs >= 0) & (obs <= 2)).all()
+        done_count += done
+    assert done_count.sum() == 0 or (done_count == done_count[0]).all()      # lock-step episodes: all done flags coincide
+    dev.close()
