@@ -201,3 +201,79 @@ def test_shared_topology_seed_semantics():
     p = OracleVecEnv(6, steps=25, rng_mode=1, topology_seed=0)
     p.reset(seeds=300)
     assert len({p.topology(i).tobytes() for i in range(6)}) > 1                                     # default: per-episode topology
+
+
+# comms policies of the three mission phases as the reference's own regression test states them
+# (CybORG/Tests/test_cc4/test_issue22_blocks.py:24-55: rows/cols = [HQ(public, admin, office), contractor, RZA, OZA, RZB, OZB];
+# 1 = green expects to communicate).  Data only.
+_GROUPS = [[5, 6, 7], [4], [0], [1], [2], [3]]       # subnet indices (SUBNET enum order used by the engine)
+_POLICY = [
+    [[1, 1, 1, 0, 1, 0], [1, 1, 1, 0, 1, 0], [1, 1, 1, 1, 1, 0], [0, 0, 1, 1, 0, 0], [1, 1, 1, 0, 1, 1], [0, 0, 0, 0, 1, 1]],
+    [[1, 1, 1, 0, 1, 0], [1, 1, 0, 0, 1, 0], [1, 0, 1, 0, 0, 0], [0, 0, 0, 1, 0, 0], [1, 1, 0, 0, 1, 1], [0, 0, 0, 0, 1, 1]],
+    [[1, 1, 1, 0, 1, 0], [1, 1, 1, 0, 0, 0], [1, 1, 1, 1, 0, 0], [0, 0, 1, 1, 0, 0], [1, 0, 0, 0, 1, 0], [0, 0, 0, 0, 0, 1]],
+]
+
+
+@pytest.mark.parametrize('mission_phase', [0, 1, 2])
+def test_blocks_outside_the_comms_policy_do_not_touch_green(mission_phase, oracle_lib):
+    """The property of the reference's test_issue22_blocks.py: with red asleep, blocking every subnet pair the phase's
+    comms policy does not expect traffic on costs nothing -- green never picks those destinations.  Blocking a pair the
+    policy does expect must cost something (the check that the test would notice a wrong allowed-subnet table)."""
+    import ctypes
+    from oracle_binding import OracleVecEnv
+    buf = ctypes.create_string_buffer(8192)
+    oracle_lib.cc4o_layout(buf, 8192)
+    off = {ln.split()[0]: int(ln.split()[1]) for ln in buf.value.decode().splitlines() if len(ln.split()) == 2}
+
+    def run(block_expected):
+        o = OracleVecEnv(4, steps=300, red_policy=1)           # red_agent_class=SleepAgent
+        o.reset(seeds=3)
+        n = o.lib.cc4o_state_bytes()
+        for i in range(4):
+            st = np.frombuffer((ctypes.c_uint8 * n).from_address(o.lib.cc4o_state_ptr(o._h, i)), np.uint8)
+            blocks = st[off['blocks']:off['blocks'] + 18].view(np.uint16)      # blocks[to] bit from
+            for r, rg in enumerate(_GROUPS):
+                for c, cg in enumerate(_GROUPS):
+                    if _POLICY[mission_phase][r][c] == (1 if block_expected else 0) and (not block_expected or r != c):
+                        for to in rg:
+                            for fr in cg:
+                                if to != fr:
+                                    blocks[to] |= np.uint16(1 << fr)
+            st[off['step_count']:off['step_count'] + 4].view(np.int32)[0] = 100 * mission_phase
+        tot = 0.0
+        for _ in range(99):
+            tot += float(o.step(np.full((4, 5), -1, np.int32))[1].sum())
+        return tot
+    assert run(False) == 0.0
+    assert run(True) < 0.0
+
+
+def test_monitor_sees_events_on_the_server_host_and_on_client_hosts(oracle_lib):
+    """The property of the reference's test_issue26_monitor.py: a network-connection / process-creation event is reported
+    by the end-of-turn Monitor whether it sits on the blue agent's VelociraptorServer host or on a client host of the zone."""
+    import ctypes
+    from oracle_binding import OracleVecEnv
+    buf = ctypes.create_string_buffer(8192)
+    oracle_lib.cc4o_layout(buf, 8192)
+    off = {ln.split()[0]: int(ln.split()[1]) for ln in buf.value.decode().splitlines() if len(ln.split()) == 2}
+    o = OracleVecEnv(1, steps=300, red_policy=1, green_policy=1)          # everybody asleep: nothing else raises events
+    o.reset(seeds=11)
+    n = o.lib.cc4o_state_bytes()
+    st = np.frombuffer((ctypes.c_uint8 * n).from_address(o.lib.cc4o_state_ptr(o._h, 0)), np.uint8)
+    topo = o.topology(0)
+    exists = lambda h: bool(topo[27 + 2 * h])                              # noqa: E731
+    blue_base, blue_size = off['blue'], (off['red'] - off['blue']) // 5
+    for b in range(4):                                                      # agents 0..3 own subnet b
+        parent = int(st[blue_base + b * blue_size + 34])                   # BlueAgent.parent_host (csrc/cc4_state.h)
+        assert parent // 17 == b and exists(parent)
+        other = next(h for h in range(b * 17 + 1, b * 17 + 17) if exists(h) and h != parent)
+        for h, bit in ((parent, 1), (other, 2)):                           # EV_CUR_CONN on one, EV_CUR_PROC on the other
+            st[off['hd'] + h * 136 + 134] |= bit
+        obs = o.step(np.full((1, 5), -1, np.int32))[0][0]
+        blk = obs[b * 92 + 1: b * 92 + 60]
+
+        def slot(h):
+            s_ = h % 17
+            return (s_ - 11) if s_ >= 11 else 6 + (s_ - 1)                  # servers first, then users (BlueFlatWrapper order)
+        assert blk[43 + slot(parent)] == 1 and blk[27 + slot(other)] == 1   # connection flag / process flag
+        assert blk[27:59].sum() == 2
