@@ -189,7 +189,13 @@ CC4_HD uint32_t rng_next32(Rng* r) {
 }
 
 // Generator.random(): next_double = (next_uint64 >> 11) * 2^-53
-CC4_HD double rng_random(Rng* r) { return (double)(rng_next64(r) >> 11) * (1.0 / 9007199254740992.0); }
+CC4_HD uint32_t rng_next32(Rng* r);
+CC4_HD double rng_random(Rng* r) {
+  // counter-based mode: one 32-bit word per uniform (every threshold on the path is a multiple of 1/100 or 1/4), so that a
+  // typical agent-phase (a bounded int, a uniform, two more bounded ints) fits one Philox block instead of two
+  if (r->mode == 1) return (double)rng_next32(r) * (1.0 / 4294967296.0);
+  return (double)(rng_next64(r) >> 11) * (1.0 / 9007199254740992.0);
+}
 
 // Generator.integers(0, n) / Generator.choice(n) for 1 <= n <= 2^32:
 // distributions.c random_bounded_uint64_fill -> buffered_bounded_lemire_uint32 (rng = n-1); rng==0 draws nothing.
