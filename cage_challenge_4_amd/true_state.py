@@ -163,6 +163,16 @@ class TrueState:
             for h, pid in ag['sus']:
                 self.sus_pids[f'blue_agent_{b}'].setdefault(hostname_of(h), []).append(pid)
 
+    def red_access(self):
+        """The feed of the reference's VisualiseRedExpansion (Agents/Wrappers/VisualiseRedExpansion.py): hostname ->
+        'root' | 'user' for every host on which some red agent holds a shell (the strongest one counts)."""
+        out = {}
+        for name, e in self.hosts.items():
+            lv = [s['username'] for s in e.get('Sessions', []) if s['agent'].startswith('red')]
+            if lv:
+                out[name] = 'root' if 'root' in lv else 'user'
+        return out
+
     def as_dict(self, info=None):
         """`get_true_state(info)` shape: {hostname: {...}, 'success': TRUE}; `info` (hostname -> wanted keys) filters hosts."""
         out = {n: v for n, v in self.hosts.items() if info is None or n in info}

@@ -49,6 +49,12 @@ def check(make_env):
                 gs = [[a, i, p, ty == 'RED_ABSTRACT_SESSION', r] if a.startswith('red') else [a, i, p] for a, i, p, ty, r in g['sessions']]
                 ws = [[a, i, p, ty == 'RED_ABSTRACT_SESSION', r] if a.startswith('red') else [a, i, p] for a, i, p, ty, r in w['sessions']]
                 assert gs == ws, (t, h, gs, ws)
+            want_access = {}
+            for h, w in want['hosts'].items():
+                lv = [r for a, i, p, ty, r in w['sessions'] if a.startswith('red')]
+                if lv:
+                    want_access[h] = 'root' if any(lv) else 'user'
+            assert ts.red_access() == want_access, t
             blocks = {k: sorted(v) for k, v in ts.blocks.items()}
             assert blocks == want['blocks'], (t, blocks, want['blocks'])
         if t < len(fix['actions']):
