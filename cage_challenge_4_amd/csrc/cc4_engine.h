@@ -166,16 +166,6 @@ CC4_HD void remove_proc_at(Ctx x, int h, int idx) {
   for (int i = idx; i + 1 < d.nproc; ++i) d.procs[i] = d.procs[i + 1];
   d.nproc--;
 }
-CC4_HD bool host_uses_port(Ctx x, int h, int pbit) {  // Host.is_using_port (Host.py:310-314)
-  const HostDyn& d = x.s->hd[h];
-  const int n = d.nproc;
-  for (int i0 = 0; i0 < n; i0 += 8) {
-    uint32_t v[8];
-    CC4_UNROLL for (int k = 0; k < 8; ++k) __builtin_memcpy(&v[k], &d.procs[i0 + k], 4);
-    CC4_UNROLL for (int k = 0; k < 8; ++k) if (i0 + k < n && (kind_port((int)((v[k] >> 16) & 0xFF)) & pbit)) return true;
-  }
-  return false;
-}
 // host.events.network_connections.append(...)
 CC4_HD void ev_conn(Ctx x, int h) { ev_or(x, h, EV_CUR_CONN); }
 // host.events.process_creation.append(...); pid > 0 when the event dict carries 'pid' (ExploitAction.py:264-275)
@@ -338,7 +328,6 @@ CC4_HD void rs_move_to_end(RedAgent& a, int idx, int new_id) {
   __builtin_memcpy(&a.sess[a.nsess - 1], &q, 8);
   a.rsc_dirty = 1;
 }
-CC4_HD bool red_has_session_on(const RedAgent& a, int h) { return bit_get(a.live_hosts, h); }
 CC4_HD bool sid_known(const RedAgent& a, int id) {
   if (id < 256) return bit_get(a.known_bm, id);
   for (int i = 0; i < a.nknown; ++i) if (a.known_sid[i] == id) return true;
@@ -1722,14 +1711,9 @@ CC4_HD void step_phishing(Ctx x) {
     }
   }
 }
-// true if red agent r holds a session outside its allowed subnets (work for different_subnet_agent_reassignment):
-// live_hosts against the host-id ranges of the agent's subnets (subnet sn = ids sn*17 .. sn*17+16)
-CC4_HD bool red_has_foreign_session(const EnvState* s, int r) {
-  const RedAgent& A = s->red[r];
-  for (int w = 0; w < 5; ++w) if (A.live_hosts[w] & ~red_zone_hosts(r, w)) return true;
-  return false;
-}
-// the same test for all six agents at once: 30 independent loads, masks folded to constants by the unrolling
+// true if some red agent holds a session outside its allowed subnets (work for different_subnet_agent_reassignment): live_hosts
+// against the host-id ranges of each agent's subnets (subnet sn = ids sn*17 .. sn*17+16); all six agents at once:
+// 30 independent loads, masks folded to constants by the unrolling
 CC4_HD bool red_any_foreign_session(const EnvState* s) {
   uint32_t acc = 0;
   CC4_UNROLL for (int r = 0; r < NRED; ++r) {
