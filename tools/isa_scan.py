@@ -68,4 +68,8 @@ def main():
 
 
 if __name__ == '__main__':
-    sys.exit(main())
+    try:
+        sys.exit(main())            # 0 clean, 1 findings
+    except Exception as exc:        # the lint itself could not run (compile step failed, no temp dir, ...)
+        print('isa_scan: could not run:', exc)
+        sys.exit(2)
