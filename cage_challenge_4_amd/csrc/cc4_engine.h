@@ -9,7 +9,8 @@
 
 namespace cc4 {
 
-struct Ctx { EnvState* s; EnvCold* c; Rng* r; unsigned long long* prof = nullptr; unsigned long long* aprof = nullptr; };
+struct Ctx { EnvState* s; EnvCold* c; Rng* r; unsigned long long* prof = nullptr; unsigned long long* aprof = nullptr;
+             EvLog* lg = nullptr; };   // lg: the episode's event log when it is enabled (the callers know that without a memory read)
 
 // optional phase timing (device only, debug builds of the kernel pass a buffer): prof[i] += cycles since last tick
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -42,6 +43,21 @@ CC4_HD void ev_or(Ctx x, int h, uint32_t bits) {
 #else
   x.s->hd[h].ev |= (uint8_t)bits;
 #endif
+}
+// optional event log (EnvCold.evlog, enabled through cc4_enable_event_log): the content of the HostEvents entry behind an
+// event flag.  `order` orders entries of different agents as the serial walk would (greens by host id, then reds by index).
+CC4_HD void ev_log(Ctx x, int order, int host, int kind, int laddr, int lport, int raddr, int rport, int pid, int rep = 1) {
+  if (!x.lg) return;
+  EvLog& L = *x.lg;
+#if defined(__HIP_DEVICE_COMPILE__)
+  uint32_t i = atomicAdd(&L.n, 1u);
+#else
+  uint32_t i = L.n++;
+#endif
+  if (i >= (uint32_t)MAX_EV) return;   // the count keeps growing: the reader sees n > MAX_EV and reports truncation
+  EvRec e; e.host = (uint8_t)host; e.kind = (uint8_t)kind; e.laddr = (uint8_t)laddr; e.raddr = (uint8_t)raddr;
+  e.lport = (uint16_t)lport; e.rport = (uint16_t)rport; e.pid = (uint16_t)pid; e.rep = (uint8_t)rep; e.order = (uint8_t)order;
+  L.rec[i] = e;
 }
 CC4_HD int h_subnet(int h) { return h / SLOTS; }
 CC4_HD int h_slot(int h) { return h % SLOTS; }
@@ -412,7 +428,7 @@ CC4_HD void gen_host(Ctx x, int h, uint32_t* used) {  // _generate_linux_host (E
   HostDyn& st = s->hd[h];
   st.nproc = 0; st.nsvc = 0;
   bit_set(s->exists, h);
-  (void)rng_below(x.r, 2);  // OSDistribution choice (ESG.py:494): both are LINUX, value unused downstream
+  st.ev = (uint8_t)rng_below(x.r, 2);  // OSDistribution choice (ESG.py:488-494): 0 UBUNTU, 1 KALI; parked in ev until the backup is written
   if (h_is_router(h)) return;
   // _generate_linux_host_services (ESG.py:530-562); services dict order = SSHD, [OTSERVICE], chosen add-ons
   int n = 0;
@@ -453,7 +469,7 @@ CC4_HD void host_backup(Ctx x, int h, int ip_octet) {
   HostStatic st;
   for (int i = 0; i < 8; ++i) st.procs[i] = d.procs[i];
   for (int i = 0; i < 5; ++i) st.svcs[i] = d.svcs[i];
-  st.nproc = d.nproc; st.nsvc = d.nsvc; st.exists = 1; st.ip_octet = (uint8_t)ip_octet;
+  st.nproc = d.nproc; st.nsvc = d.nsvc; st.exists = (uint8_t)(1 | ((d.ev & 1) << 1)); st.ip_octet = (uint8_t)ip_octet;
   if (d.nproc > 8 || d.nsvc > 5) set_err(x, E_PROC_OVERFLOW);
   __builtin_memcpy(&x.c->hs[h], &st, sizeof(HostStatic));
 }
@@ -893,7 +909,7 @@ CC4_HD bool green_local_work(Ctx x, int gh, bool* want_phish) {
   CC4_UNROLL for (int i = 0; i < MAXSV; ++i) if (i == c) st = sv[i] >> 24;
   int rel = (int)(st & 0x7F) * 20;
   if ((int)rng_below(x.r, 100) >= rel) return false;
-  if (rng_random(x.r) < 0.01) { (void)eph_port(x, gh); ev_proc(x, gh, 0); }
+  if (rng_random(x.r) < 0.01) { int port = eph_port(x, gh); ev_proc(x, gh, 0); ev_log(x, gh, gh, 1, gh, port, 0xFF, 0, 0); }   // pc = {local_address, local_port} (GreenLocalWork.py:112-115)
   if (rng_random(x.r) < 0.01) *want_phish = true;  // PhishingEmail sub-action: executed by the caller (ordering, see P5)
   return true;
 }
@@ -913,10 +929,11 @@ CC4_HD bool green_access_service(Ctx x, int gh) {
     int cnt = (int)((ns >> (8 * sn)) & 0xFF);
     if (c < cnt) dest = h_make(sn, 11 + c); else c -= cnt;
   }
-  (void)eph_port(x, dest);
+  const int dest_port = eph_port(x, dest);
   int ds = h_subnet(dest);
-  if (subnet_blocked(x, ds, own) || subnet_blocked(x, own, ds)) { ev_conn(x, dest); return false; }
-  if (rng_random(x.r) < 0.01) ev_conn(x, dest);
+  // events land on the destination server (`from_host` in the reference, GreenAccessService.py:176-214)
+  if (subnet_blocked(x, ds, own) || subnet_blocked(x, own, ds)) { ev_conn(x, dest); ev_log(x, gh, dest, 0, dest, 0, gh, 8800, 0); return false; }
+  if (rng_random(x.r) < 0.01) { ev_conn(x, dest); ev_log(x, gh, dest, 0, gh, 0, dest, dest_port, 0); }
   return true;
 }
 
@@ -941,6 +958,7 @@ CC4_HD void red_drs(Ctx x, int r, const Act& a) {
   red_result(x, r, a, any ? T_TRUE : T_UNKNOWN);
 }
 // DiscoverNetworkServices.execute + Portscan.execute (AbstractActions/DiscoverNetworkServices.py:44-86, Portscan.py:23-65)
+CC4_HD int port_of_bit(int pb) { return pb == PB_22 ? 22 : (pb == PB_80 ? 80 : (pb == PB_3390 ? 3390 : (pb == PB_25 ? 25 : (pb == PB_1 ? 1 : 443)))); }
 CC4_HD void red_scan(Ctx x, int r, const Act& a, double rate) {
   EnvState* s = x.s;
   RedAgent& A = s->red[r];
@@ -956,7 +974,7 @@ CC4_HD void red_scan(Ctx x, int r, const Act& a, double rate) {
     int pb = kind_port(k);
     if (!pb) continue;
     ports |= pb;
-    if (fixed <= rate || kind_is_decoy(k)) { ev_conn(x, tgt); (void)eph_port(x, tgt); }
+    if (fixed <= rate || kind_is_decoy(k)) { ev_conn(x, tgt); int ep = eph_port(x, tgt); ev_log(x, 200 + r, tgt, 0, tgt, port_of_bit(pb), src, ep, 0); }   // Portscan.py:59-64
   }
   if (ports) {
     obs_put(x, r, true, tgt, OE_IFACE, false);
@@ -1004,16 +1022,18 @@ CC4_HD void red_exploit(Ctx x, int r, const Act& a) {
     // SSHBruteForce.execute (ExploitActions/SSHBruteForce.py:24-84)
     uint8_t* work = reinterpret_cast<uint8_t*>(s->scratch + 6 * r);   // 24 bytes per red agent
     int nh = route(src, tgt, work);
-    for (int i = 0; i < nh; ++i) if (0.050000000000000044 < rng_random(x.r)) ev_conn(x, work[12 + i]);  // 1 - 0.95 in float64
+    for (int i = 0; i < nh; ++i) if (0.050000000000000044 < rng_random(x.r)) { ev_conn(x, work[12 + i]); ev_log(x, 200 + r, work[12 + i], 0, tgt, 0, src, 22, 0); }  // 1 - 0.95 in float64
     int vp = -1;
     for (int i = 0; i < T.nproc; ++i) if (T.procs[i].kind == K_SSHD) { vp = i; break; }
     if (vp < 0) { red_result(x, r, a, T_FALSE); return; }
     obs_put(x, r, true, tgt, OE_IFACE, false);   // obs.add_process(target_process) -> interface of the target
-    (void)eph_port(x, tgt);                       // local_port
+    const int bf_port = eph_port(x, tgt);         // local_port
     ev_conn(x, tgt);                              // _create_brute_force_event: 10 connection events
+    ev_log(x, 200 + r, tgt, 0, tgt, 22, src, bf_port, 0, 10);
     int ni = exploit_new_session(x, r, a.sid, tgt);
     if (ni < 0) { red_result(x, r, a, T_FALSE); return; }
     ev_proc_red(x, r, tgt, A.sess[ni].pid);       // _create_new_session_event (always for SSH)
+    ev_log(x, 200 + r, tgt, 1, 0xFF, 0, 0xFF, 0, A.sess[ni].pid);
     obs_put(x, r, true, tgt, OE_SESS | OE_IFACE | OE_SYSHN, false);
     obs_put(x, r, true, src, OE_IFACE, false);
     A.new_sess_host = (uint8_t)tgt; A.new_sess_id = A.sess[ni].id;
@@ -1034,16 +1054,17 @@ CC4_HD void red_exploit(Ctx x, int r, const Act& a) {
   if (vp < 0) { red_result(x, r, a, T_FALSE); return; }
   int vk = T.procs[vp].kind;
   bool decoy = kind_is_decoy(vk);
-  if (decoy) { ev_conn(x, tgt); (void)eph_port(x, tgt); }  // _get_vulnerable_process alert (ExploitAction.py:189-196)
+  const int xport = sel == X_HTTPRFI ? 80 : (sel == X_HTTPSRFI ? 443 : (sel == X_SQLI ? 3390 : 25));
+  if (decoy) { ev_conn(x, tgt); int ep = eph_port(x, tgt); ev_log(x, 200 + r, tgt, 0, tgt, xport, src, ep, 0); }  // _get_vulnerable_process alert (ExploitAction.py:189-196)
   obs_put(x, r, true, tgt, OE_IFACE, false);
   bool works = (sel == X_SQLI) || decoy;  // rfi only on decoys; real Haraka is 2.8.9 (HarakaRCE.py:19, HTTPRFI.py:18)
   if (!works) { red_result(x, r, a, T_FALSE); return; }
   if (0.0 >= rng_random(x.r)) { red_result(x, r, a, T_FALSE); return; }  // (1 - success_rate) >= random()
-  (void)eph_port(x, tgt);  // local_port
-  if (decoy) { ev_conn(x, tgt); (void)eph_port(x, tgt); red_result(x, r, a, T_FALSE); return; }
+  const int lport = eph_port(x, tgt);  // local_port
+  if (decoy) { ev_conn(x, tgt); int ep = eph_port(x, tgt); ev_log(x, 200 + r, tgt, 0, tgt, lport, src, ep, 0); red_result(x, r, a, T_FALSE); return; }
   int ni = exploit_new_session(x, r, a.sid, tgt);
   if (ni < 0) { red_result(x, r, a, T_FALSE); return; }
-  if (rng_random(x.r) > 0.050000000000000044) ev_proc_red(x, r, tgt, A.sess[ni].pid);
+  if (rng_random(x.r) > 0.050000000000000044) { ev_proc_red(x, r, tgt, A.sess[ni].pid); ev_log(x, 200 + r, tgt, 1, 0xFF, 0, 0xFF, 0, A.sess[ni].pid); }
   obs_put(x, r, true, tgt, OE_SESS | OE_IFACE | OE_SYSHN, false);
   obs_put(x, r, true, src, OE_IFACE, false);
   A.new_sess_host = (uint8_t)tgt; A.new_sess_id = A.sess[ni].id;
@@ -1589,6 +1610,7 @@ CC4_HD bool step_phase(Ctx x) {
     if (ph > s->phase) s->phase = ph;
   }
   rng_begin_step(&s->rng, (uint32_t)s->step_count);
+  if (x.lg) { x.lg->n = 0; x.lg->step = (uint32_t)s->step_count; }
   s->action_cost = 0.f; s->brm = 0; s->n_restore = 0;
   s->n_actions = NBLUE + s->n_green + NRED;   // minus the actions filter_actions drops (step_tick_agent)
   return true;

@@ -9,9 +9,12 @@
 //              "svcs":[[kind,active,reliability percent,pid]...] (Host.services order), "ev":event bits,
 //              "blue":pid of the blue session process (0 none),"green":pid of the green session process (0 none)}...],
 //    "red":[{"active":0/1,"sessions":[[id,host,pid,flags]...] (state.sessions[red_agent_r] order; flags = RS_* bits)}...x6],
-//    "blue":[{"parent":host id of the VelociraptorServer,"sus":[[host,pid]...]}...x5],
+//    "blue":[{"parent":host id of the VelociraptorServer,"busy":1 while a multi-tick action is in progress,"sus":[[host,pid]...]}...x5],
 //    "last_blue":[[BA_* type,host or to-subnet,from-subnet]...x5],"last_red":[[RA_* type,host,subnet,executed (0 = dropped by filter_actions)]...x6] (the actions
-//    that resolved in the last step, i.e. CybORG.get_last_action), "green_hosts":[host id of green_agent_g...]}
+//    that resolved in the last step, i.e. CybORG.get_last_action),
+//    "events":[[order, seq, host, kind (0 network_connections / 1 process_creation), local_address host, local_port,
+//               remote_address host (255 none), remote_port, pid, repeat]...] (only with cc4_enable_event_log; 0 = absent field),
+//    "green_hosts":[host id of green_agent_g...]}    hosts[].os: OSDistribution 0 UBUNTU / 1 KALI
 #pragma once
 #include <stdio.h>
 #include <string>
@@ -19,7 +22,7 @@
 
 namespace cc4 {
 
-inline std::string export_true_state(const EnvState& s, const HostStatic* hs, const uint32_t (*sus)[MAX_SUS]) {
+inline std::string export_true_state(const EnvState& s, const HostStatic* hs, const uint32_t (*sus)[MAX_SUS], const EvLog* lg = nullptr) {
   std::string o;
   char b[256];
   auto add = [&](const char* fmt, auto... a) { snprintf(b, sizeof(b), fmt, a...); o += b; };
@@ -32,7 +35,7 @@ inline std::string export_true_state(const EnvState& s, const HostStatic* hs, co
   for (int h = 0; h < MAXH; ++h) {
     if (!bit_get(s.exists, h)) continue;
     const HostDyn& d = s.hd[h];
-    add("%s{\"h\":%d,\"ip\":%u,\"procs\":[", first ? "" : ",", h, (unsigned)hs[h].ip_octet);
+    add("%s{\"h\":%d,\"ip\":%u,\"os\":%u,\"procs\":[", first ? "" : ",", h, (unsigned)hs[h].ip_octet, (unsigned)((hs[h].exists >> 1) & 1));
     first = false;
     for (int i = 0; i < d.nproc; ++i) add("%s[%u,%u,%u]", i ? "," : "", (unsigned)d.procs[i].pid, (unsigned)d.procs[i].kind, (unsigned)(d.procs[i].flags & PF_ROOT));
     o += "],\"svcs\":[";
@@ -49,7 +52,7 @@ inline std::string export_true_state(const EnvState& s, const HostStatic* hs, co
   }
   o += "],\"blue\":[";
   for (int k = 0; k < NBLUE; ++k) {
-    add("%s{\"parent\":%u,\"sus\":[", k ? "," : "", (unsigned)s.blue[k].parent_host);
+    add("%s{\"parent\":%u,\"busy\":%u,\"sus\":[", k ? "," : "", (unsigned)s.blue[k].parent_host, (unsigned)(s.blue[k].queue.busy ? 1 : 0));
     for (int i = 0; i < s.blue[k].nsus; ++i) add("%s[%u,%u]", i ? "," : "", (unsigned)(sus[k][i] >> 16), (unsigned)(sus[k][i] & 0xFFFF));
     o += "]}";
   }
@@ -57,6 +60,15 @@ inline std::string export_true_state(const EnvState& s, const HostStatic* hs, co
   for (int k = 0; k < NBLUE; ++k) add("%s[%u,%u,%u]", k ? "," : "", (unsigned)s.bexec[k].type, (unsigned)s.bexec[k].host, (unsigned)s.bexec[k].arg);
   o += "],\"last_red\":[";    // self.action[red_agent_r][0]: [RA_* type, host, arg (subnet of DiscoverRemoteSystems), executed]
   for (int r = 0; r < NRED; ++r) add("%s[%u,%u,%u,%u]", r ? "," : "", (unsigned)s.red[r].exec_type, (unsigned)s.red[r].exec_host, (unsigned)s.rexec[r].arg, (unsigned)(s.rexec[r].type != RA_NONE));
+  if (lg && lg->enabled) {   // the HostEvents entries of the last step (cc4_enable_event_log), in append order
+    add("],\"events_step\":%u,\"events_total\":%u,\"events\":[", lg->step, lg->n);
+    const uint32_t n = lg->n < (uint32_t)MAX_EV ? lg->n : (uint32_t)MAX_EV;
+    for (uint32_t i = 0; i < n; ++i) {
+      const EvRec& e = lg->rec[i];
+      add("%s[%u,%u,%u,%u,%u,%u,%u,%u,%u,%u]", i ? "," : "", (unsigned)e.order, i, (unsigned)e.host, (unsigned)e.kind, (unsigned)e.laddr,
+          (unsigned)e.lport, (unsigned)e.raddr, (unsigned)e.rport, (unsigned)e.pid, (unsigned)e.rep);
+    }
+  }
   o += "],\"green_hosts\":[";
   for (int g = 0; g < s.n_green; ++g) add("%s%u", g ? "," : "", (unsigned)s.green_host[g]);
   o += "]}";

@@ -76,6 +76,9 @@ __device__ __forceinline__ void stage_out(uint4* __restrict__ dst, const uint4* 
   for (; i < ROW_VEC; i += WAVE) dst[i] = lds[i];
 }
 
+// LOG: record the HostEvents entries of the step (cc4_enable_event_log).  A template parameter rather than a run-time flag: even
+// a never-taken logging branch at the eleven event sites costs the serial walk 10 %.
+template <bool LOG>
 __global__ __launch_bounds__(WAVE) void k_step(StepArgs a) {
   // numpy-PCG64 mode: one shared stream => the agent walk is strictly serial (lane 0); only the RNG-free parts
   // (row staging, end-turn Monitor roll-over over the 137 hosts, observation encode) use the other lanes.
@@ -99,6 +102,7 @@ __global__ __launch_bounds__(WAVE) void k_step(StepArgs a) {
   rl.mode = 0;
   rl.pad = 0;
   Ctx x{s, a.cold + e, &rl, lane == 0 ? prof : nullptr};
+  x.lg = LOG ? &a.cold[e].evlog : nullptr;
   if (prof && lane == 0) prof[11] += clock64() - t_begin;
   const bool do_reset = a.autoreset && s->done;
   if (lane == 0) {
@@ -207,6 +211,7 @@ __device__ __forceinline__ void dma_chunk(const uint4* gsrc_lane, uint4* lds_chu
 }
 __device__ __forceinline__ void dma_wait() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 
+template <bool LOG>
 __global__ __launch_bounds__(PT) void k_step_philox(StepArgs a) {
   extern __shared__ uint4 lds[];
   __shared__ int ok_lds, conflict_lds;
@@ -243,6 +248,7 @@ __global__ __launch_bounds__(PT) void k_step_philox(StepArgs a) {
   } else {
     if (tid == 0) {
       Ctx x{s, a.cold + e, &s->rng, prof};
+      x.lg = LOG ? &a.cold[e].evlog : nullptr;
       CC4_TICK0(x);
       ok_lds = step_phase(x) ? 1 : 0;
     }
@@ -256,11 +262,13 @@ __global__ __launch_bounds__(PT) void k_step_philox(StepArgs a) {
       Rng rl;
       rng_fork(&rl, &s->rng, ST_RESET);
       rl.mode = 1;
+      EvLog* const lg = LOG ? &a.cold[e].evlog : nullptr;
       Ctx x0{s, a.cold + e, &rl, tid == 0 ? prof : nullptr};                     // thread 0
+      x0.lg = lg;
       const int ragent = lane * PW + wave;                                        // lanes 0..(6/PW-1) of each wave own a red agent
       const bool is_red = lane < (NRED + PW - 1) / PW && ragent < NRED;
       unsigned long long* ap = (a.prof && is_red) ? a.prof + PROF_SLOTS * (size_t)e + 16 + 8 * ragent : nullptr;
-      Ctx xr{s, a.cold + e, &rl, nullptr, ap};
+      Ctx xr{s, a.cold + e, &rl, nullptr, ap, lg};
       // ---- P0-P3a: every agent's policy / submission followed by its own duration-queue tick (SC:236-265), all on the
       // agent's thread: red r on wave r%PW lane r/PW, blue on wave PW-1 lanes 2..6, green draws on lanes >= 8 of the waves
       // that carry a single red agent.  A tick touches only its own agent (queue, observation reset, filter_actions
@@ -280,7 +288,7 @@ __global__ __launch_bounds__(PT) void k_step_philox(StepArgs a) {
       }
       else if (lane >= 8 && wave >= 2) {
         for (int g = (wave - 2) * (WAVE - 8) + (lane - 8); g < ng; g += (PW - 2) * (WAVE - 8)) {
-          Ctx xg{s, a.cold + e, &rl, nullptr};
+          Ctx xg{s, a.cold + e, &rl, nullptr, nullptr, lg};
           step_green_policy(xg, g);
           int t = s->green_act[g];
           if (t < 2) glist[t][atomicAdd(&glist_n[t], 1)] = (uint8_t)g;       // compaction by action type
@@ -293,7 +301,7 @@ __global__ __launch_bounds__(PT) void k_step_philox(StepArgs a) {
       if (blue_exec_independent(s)) {      // uniform: every thread reads the same five action types
         if (tid == 0) CC4_TICK(x0, 3);
         const int bagent = lane * PW + wave;                                      // blue agent b on wave b % PW, lane b / PW
-        if (lane < (NBLUE + PW - 1) / PW && bagent < NBLUE) { Ctx xb{s, a.cold + e, &rl, nullptr}; step_blue_exec_agent(xb, bagent); }
+        if (lane < (NBLUE + PW - 1) / PW && bagent < NBLUE) { Ctx xb{s, a.cold + e, &rl, nullptr, nullptr, lg}; step_blue_exec_agent(xb, bagent); }
         __syncthreads();
         if (tid == 0) CC4_TICK(x0, 5);
       } else {
@@ -306,7 +314,7 @@ __global__ __launch_bounds__(PT) void k_step_philox(StepArgs a) {
         int pen = 0;
         for (int i = lane; i < glist_n[wave]; i += WAVE) {
           int g = glist[wave][i];
-          Ctx xg{s, a.cold + e, &rl, nullptr};
+          Ctx xg{s, a.cold + e, &rl, nullptr, nullptr, lg};
           pen += step_green_exec(xg, g);
         }
         if (pen) atomicAdd(&s->brm, pen);
@@ -427,6 +435,7 @@ struct cc4_handle {
   hipEvent_t ev_step[OBS_RING] = {}, ev_comm[OBS_RING] = {};   // ev_comm[q % OBS_RING]: all-gather number q has completed
   int obs_buf = 0;                               // buffer written by the most recent step
   unsigned long long* d_prof = nullptr;
+  int evlog_on = 0;               // cc4_enable_event_log
   ncclComm_t comm = nullptr; int rank = 0, world = 1;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   std::vector<hipEvent_t> evs;
@@ -463,8 +472,14 @@ static int launch_step(cc4_handle* h, const int32_t* d_actions, const uint8_t* d
              h->comm ? h->d_obs8[buf] : nullptr, rand ? h->d_actions : nullptr, seed0, t,
              h->cfg.num_envs, h->cfg.autoreset, h->cfg.steps, h->cfg.rng_mode,
              (h->cfg.red_policy & 3) | (h->cfg.green_policy ? GP_SLEEP_BIT : 0), (uint32_t)h->cfg.topology_seed, h->d_prof};
-  if (h->cfg.rng_mode == 1) hipLaunchKernelGGL(k_step_philox, dim3(h->cfg.num_envs), dim3(PT), sizeof(EnvState), h->stream, a);
-  else hipLaunchKernelGGL(k_step, dim3(h->cfg.num_envs), dim3(WAVE), sizeof(EnvState), h->stream, a);
+  const dim3 grid(h->cfg.num_envs);
+  if (h->cfg.rng_mode == 1) {
+    if (h->evlog_on) hipLaunchKernelGGL(k_step_philox<true>, grid, dim3(PT), sizeof(EnvState), h->stream, a);
+    else hipLaunchKernelGGL(k_step_philox<false>, grid, dim3(PT), sizeof(EnvState), h->stream, a);
+  } else {
+    if (h->evlog_on) hipLaunchKernelGGL(k_step<true>, grid, dim3(WAVE), sizeof(EnvState), h->stream, a);
+    else hipLaunchKernelGGL(k_step<false>, grid, dim3(WAVE), sizeof(EnvState), h->stream, a);
+  }
   HIPCHK(h, hipGetLastError());
   h->obs_buf = buf;
   return 0;
@@ -708,6 +723,18 @@ int cc4_get_topology(cc4_handle* h, int32_t env, uint8_t* out) {
   return rc;
 }
 
+__global__ void k_set_evlog(EnvCold* cold, int n, uint32_t on) {
+  int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e < n) { cold[e].evlog.enabled = on; cold[e].evlog.n = 0; }
+}
+int cc4_enable_event_log(cc4_handle* h, int32_t enable) {
+  HIPCHK(h, hipSetDevice(h->cfg.device_id));
+  hipLaunchKernelGGL(k_set_evlog, dim3((h->cfg.num_envs + 255) / 256), dim3(256), 0, h->stream, h->d_cold, h->cfg.num_envs, enable ? 1u : 0u);
+  HIPCHK(h, hipGetLastError());
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  h->evlog_on = enable ? 1 : 0;
+  return 0;
+}
 int64_t cc4_get_true_state(cc4_handle* h, int32_t env, char* json, size_t cap) {
   if (env < 0 || env >= h->cfg.num_envs) { h->err = "cc4_get_true_state: env out of range"; return -2; }
   EnvState* st = (EnvState*)malloc(sizeof(EnvState));
@@ -715,7 +742,7 @@ int64_t cc4_get_true_state(cc4_handle* h, int32_t env, char* json, size_t cap) {
   int64_t rc = cc4_get_state(h, env, st);
   if (rc == 0) rc = cc4_get_cold(h, env, cold);
   if (rc == 0) {
-    std::string doc = export_true_state(*st, cold->hs, cold->sus);
+    std::string doc = export_true_state(*st, cold->hs, cold->sus, &cold->evlog);
     rc = (int64_t)doc.size() + 1;
     if (json && cap >= doc.size() + 1) memcpy(json, doc.c_str(), doc.size() + 1);
   }

@@ -70,7 +70,7 @@ struct alignas(8) HostDyn {
 struct alignas(8) HostStatic {                 // Host.create_backup (Host.py:316-371)
   Proc procs[8];
   Svc svcs[5];
-  uint8_t nproc, nsvc, exists, ip_octet;
+  uint8_t nproc, nsvc, exists, ip_octet;   // exists: bit 0 host exists, bit 1 OSDistribution (0 UBUNTU, 1 KALI: ESG.py:488-494)
 };
 
 // red sessions (state.sessions[red_agent_k], dict order == array order)
@@ -177,12 +177,29 @@ struct alignas(16) EnvState {
                                      // be dynamically indexed private arrays (= scratch memory on the device)
 };
 
+// optional per-step event log (decoded Monitor observations with ports / peers / pids).  One record per
+// HostEvents entry the step produced; the engine itself only needs the flags in HostDyn.ev.
+enum : int { MAX_EV = 160 };
+struct alignas(4) EvRec {
+  uint8_t host;        // host whose events list receives the entry
+  uint8_t kind;        // 0 network_connections, 1 process_creation
+  uint8_t laddr;       // host whose address is the event's local_address
+  uint8_t raddr;       // host whose address is the remote_address (0xFF: none)
+  uint16_t lport;      // local_port (0: none)
+  uint16_t rport;      // remote_port (0: none)
+  uint16_t pid;        // pid (0: none)
+  uint8_t rep;         // the entry is appended this many times (SSHBruteForce: 10)
+  uint8_t order;       // acting agent in execution order: green host id (0..136), red 200 + r
+};
+struct alignas(16) EvLog { uint32_t n, step, enabled, pad; EvRec rec[MAX_EV]; };
+
 struct alignas(16) EnvCold {
   uint32_t sus[NBLUE][MAX_SUS];      // VelociraptorServer.sus_pids of blue agent b: (host << 16) | pid, chronological
                                      // (appended by Monitor, read by Remove; counts and per-host presence stay hot)
   HostStatic hs[MAXH];               // backup images (Host.create_backup): read by Restore and reset only
   uint8_t hs_pad[8];                 // keeps eph[] 16-byte aligned (137 * 56 + 8 = 7680)
   uint32_t eph[MAXH][EPH_WORDS];     // Host.ephemeral_ports as a bitmap (port-49152)
+  EvLog evlog;                       // events of the last step when EvLog.enabled (cc4_enable_event_log)
   uint8_t kports[NRED * MAX_KB][MAXH + 7];  // RedAbstractSession.ports[ip]: PB_* bits | PB_HAS; row = agent * MAX_KB + RSess.kb
 };
 

@@ -184,6 +184,126 @@ def decode(doc):
     return TrueState(doc)
 
 
+# ---------------------------------------------------------------------------------------------------------------------
+# Blue dict observations: what CybORG.get_observation('blue_agent_b') returns after a step, rebuilt from
+# the per-step event log (cc4_enable_event_log).  The end-of-turn Monitor (Monitor.py:35-74) reports, per host of the
+# agent's zone, the network_connections entries and then the process_creation entries through Observation.add_process
+# (Shared/Observation.py:56-209); the agent's ObservationSet then combines that observation with itself once
+# (Observation.combine_obs, :646-679), which is why connection entries appear twice and pid entries once, last.
+_BLUE_ZONE = {0: (0,), 1: (1,), 2: (2,), 3: (3,), 4: (5, 6, 7)}
+_OS = ({'OSDistribution': 'UBUNTU', 'OSVersion': 'UNKNOWN'}, {'OSDistribution': 'KALI', 'OSVersion': 'K2019_4'})
+
+
+class _Obs:
+    """The subset of Shared/Observation.py the Monitor path exercises (add_process / add_interface_info / add_system_info)."""
+
+    def __init__(self):
+        self.data = {}
+
+    def add_interface(self, hostid, ip):
+        lst = self.data.setdefault(hostid, {}).setdefault('Interface', [])
+        new = {}
+        for itf in list(lst):                      # an entry with the same address is replaced and moves to the end
+            if itf.get('ip_address') == ip:
+                if len(itf) > len(new):
+                    new = itf
+                lst.remove(itf)
+        new['ip_address'] = ip
+        lst.append(new)
+
+    def add_process(self, hostid, pid=None, local_port=None, remote_port=None, local_address=None, remote_address=None):
+        procs = self.data.setdefault(hostid, {}).setdefault('Processes', [])
+        new = {}
+        if pid is not None:
+            for old in procs:
+                if old.get('PID') == pid:
+                    new = old
+                    procs.remove(old)
+                    break
+            new['PID'] = pid
+        conn = {}
+        new.setdefault('Connections', [])
+        if local_port is not None:
+            conn['local_port'] = local_port
+        if remote_port is not None:
+            conn['remote_port'] = remote_port
+        if local_address is not None:
+            conn['local_address'] = local_address
+            self.add_interface(hostid, local_address)
+        if remote_address is not None:
+            conn['remote_address'] = remote_address
+        if conn:
+            new['Connections'].append(conn)
+        elif new['Connections'] == []:
+            new.pop('Connections')
+        procs.append(new)
+
+    def add_system_info(self, hostid, info):
+        self.data.setdefault(hostid, {}).setdefault('System info', {}).update(info)
+
+    def combine(self, other):
+        for key, info in other.items():
+            for p in info.get('Processes', []):
+                if 'Connections' in p:
+                    for c in p['Connections']:
+                        self.add_process(key, pid=p.get('PID'), **c)
+                else:
+                    self.add_process(key, pid=p.get('PID'))
+            for itf in info.get('Interface', []):
+                self.add_interface(key, itf['ip_address'])
+            if 'System info' in info:
+                self.add_system_info(key, info['System info'])
+
+
+def blue_observations(ts):
+    """{agent: observation dict} of the five blue agents for the step the TrueState was taken after.  Needs the event log
+    (CC4VecEnv.enable_event_log()); the keys follow the reference: 'success', 'action', then one entry per host with events."""
+    d = ts.raw
+    if 'events' not in d:
+        raise RuntimeError('blue_observations needs the event log: call enable_event_log() before stepping')
+    if d['events_total'] > len(d['events']):
+        raise RuntimeError(f"event log truncated: {d['events_total']} entries in step {d['events_step']}")
+    ip_of = {hd['h']: IPv4Address(f'10.0.{d["cidr"][hd["h"] // 17]}.{hd["ip"]}') for hd in d['hosts']}
+    os_of = {hd['h']: hd['os'] for hd in d['hosts']}
+    by_host = {}
+    for order, seq, host, kind, laddr, lport, raddr, rport, pid, rep in sorted(d['events'], key=lambda e: (e[0], e[1])):
+        by_host.setdefault(host, ([], []))[kind].extend([(laddr, lport, raddr, rport, pid)] * rep)
+    out = {}
+    for b in range(5):
+        agent = f'blue_agent_{b}'
+        parent = d['blue'][b]['parent']
+        zone = [hd['h'] for hd in d['hosts'] if hd['h'] // 17 in _BLUE_ZONE[b]]
+        hosts = [h for h in zone if h != parent] + [parent]       # the child sessions' hosts, then the server's own
+        m = _Obs()
+        for h in hosts:
+            conns, procs = by_host.get(h, ([], []))
+            name = hostname_of(h)
+            info = dict(Architecture='x64', Hostname=name, OSType='LINUX', position=[0.0, 0.0], **_OS[os_of[h]])
+            for lst in (conns, procs):
+                if lst:
+                    m.add_system_info(name, info)
+                for laddr, lport, raddr, rport, pid in lst:
+                    m.add_process(name, pid=pid or None, local_port=lport or None, remote_port=rport or None,
+                                  local_address=ip_of[laddr] if laddr != 255 else None,
+                                  remote_address=ip_of[raddr] if raddr != 255 else None)
+        obs = _Obs()
+        obs.combine(m.data)
+        obs.combine(m.data)
+        # 'success' / 'action' of the agent's own action: IN_PROGRESS (and no 'action' key) while a multi-tick action runs;
+        # Sleep reports UNKNOWN; Monitor, Analyse, Remove, Restore and DeployDecoy report TRUE once they resolve (their
+        # parameters are validated on submission).  Block/AllowTrafficZone report whether the pair's state changed, which the
+        # engine does not keep: None.  Analyse's file list and DeployDecoy's process entry are not modelled.
+        la = ts.last_action[agent]
+        if d['blue'][b].get('busy'):
+            res = {'success': 'IN_PROGRESS'}
+        else:
+            res = {'success': {'Sleep': 'UNKNOWN', 'Monitor': 'TRUE', 'Analyse': 'TRUE', 'Remove': 'TRUE', 'Restore': 'TRUE',
+                               'DeployDecoy': 'TRUE'}.get(la.name), 'action': la}
+        res.update(obs.data)
+        out[agent] = res
+    return out
+
+
 class _Table:
     """Minimal stand-in for prettytable.PrettyTable (not installed in the image): field names, rows, str()."""
     def __init__(self, field_names):

@@ -116,6 +116,10 @@ class CC4VecEnv:
         self._chk(self.lib.cc4_get_topology(self._h, int(env), buf.ctypes.data_as(ctypes.c_void_p)), 'cc4_get_topology')
         return buf
 
+    def enable_event_log(self, on=True):
+        """cc4_enable_event_log: record the HostEvents entries of every step (for decoded blue dict observations)."""
+        self._chk(self.lib.cc4_enable_event_log(self._h, int(bool(on))), 'cc4_enable_event_log')
+
     def true_state_json(self, env=0):
         """cc4_get_true_state: the episode's packed state as the JSON document described in csrc/cc4_export.h."""
         need = int(self.lib.cc4_get_true_state(self._h, int(env), None, 0))

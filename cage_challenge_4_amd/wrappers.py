@@ -102,6 +102,7 @@ class CybORG:
         self.vec = (vec_factory or CC4VecEnv)(1, steps=scenario_generator.steps, rng_mode=rng_mode, device_id=device_id,
                                               red_policy=scenario_generator.red_policy,
                                               green_policy=scenario_generator.green_policy)
+        self.vec.enable_event_log(True)                        # single episode: keep the per-step event detail for get_observation
         self.vec.reset(seeds=np.array([seed], np.uint64))      # SimulationController.__init__ creates a scenario
         self.agents = [f'blue_agent_{b}' for b in range(5)]
 
@@ -126,6 +127,14 @@ class CybORG:
         (hostname -> wanted fields) only selects hosts."""
         from .true_state import decode
         return decode(self.vec.true_state_json(0)).as_dict(info)
+
+    def get_observation(self, agent):
+        """env.py:270-283: the dict observation of a blue agent after the last step -- 'success', 'action' and, per host of
+        its zone with events, 'Interface' / 'Processes' (connections with addresses and ports, pids) / 'System info', as the
+        end-of-turn Monitor reports them (true_state.blue_observations; exact against the reference for Sleep / Monitor /
+        Remove / Restore / Block / Allow steps)."""
+        from .true_state import decode, blue_observations
+        return blue_observations(decode(self.vec.true_state_json(0)))[agent]
 
     def get_last_action(self, agent):
         """env.py:300-314: the action of `agent` (blue_agent_b / red_agent_r) that resolved in the last step, as an object

@@ -27,6 +27,7 @@ using namespace cc4;
 struct Oracle {
   int n;
   uint32_t topo = 0;   // cc4_config.topology_seed
+  int evlog = 0;       // cc4_enable_event_log
   std::vector<EnvState> st;
   std::vector<EnvCold> cold;
 };
@@ -54,9 +55,11 @@ void cc4o_reset(void* h, int i, uint64_t seed, int rng_mode, int steps, int cont
   env_reset(x, seed, rng_mode, steps, continue_stream != 0, policy, o->topo);
 }
 void cc4o_set_topology_seed(void* h, uint32_t seed) { ((Oracle*)h)->topo = seed; }
+void cc4o_enable_event_log(void* h, int on) { Oracle* o = (Oracle*)h; o->evlog = on ? 1 : 0; for (int i = 0; i < o->n; ++i) { o->cold[i].evlog.enabled = on ? 1u : 0u; o->cold[i].evlog.n = 0; } }
 void cc4o_step(void* h, int i, const int32_t* actions, const uint8_t* msgs) {
   Oracle* o = (Oracle*)h;
   Ctx x{&o->st[i], &o->cold[i], &o->st[i].rng};
+  x.lg = o->evlog ? &o->cold[i].evlog : nullptr;
   env_step(x, actions, msgs);
 }
 // whole-batch step, OpenMP over envs when built with -fopenmp (bench.py cpu_baseline)
@@ -65,6 +68,7 @@ void cc4o_step_all(void* h, const int32_t* actions /* [n][5] */) {
 #pragma omp parallel for schedule(dynamic, 4)
   for (int i = 0; i < o->n; ++i) {
     Ctx x{&o->st[i], &o->cold[i], &o->st[i].rng};
+    x.lg = o->evlog ? &o->cold[i].evlog : nullptr;
     env_step(x, actions + 5 * i, nullptr);
   }
 }
@@ -85,7 +89,7 @@ void cc4o_set_threads(int n) {
 // same document as cc4_get_true_state (include/cc4.h); returns bytes needed incl. NUL
 long long cc4o_true_state(void* h, int i, char* json, size_t cap) {
   Oracle* o = (Oracle*)h;
-  std::string doc = export_true_state(o->st[i], o->cold[i].hs, o->cold[i].sus);
+  std::string doc = export_true_state(o->st[i], o->cold[i].hs, o->cold[i].sus, &o->cold[i].evlog);
   if (json && cap >= doc.size() + 1) memcpy(json, doc.c_str(), doc.size() + 1);
   return (long long)doc.size() + 1;
 }

@@ -124,6 +124,10 @@ class OracleVecEnv:
         p = self.lib.cc4o_state_ptr(self._h, i)
         return np.frombuffer((ctypes.c_uint8 * n).from_address(p), np.uint8).copy()
 
+    def enable_event_log(self, on=True):
+        self.lib.cc4o_enable_event_log.argtypes = [ctypes.c_void_p, ctypes.c_int]
+        self.lib.cc4o_enable_event_log(self._h, int(bool(on)))
+
     def true_state_json(self, i=0):
         need = int(self.lib.cc4o_true_state(self._h, i, None, 0))
         buf = ctypes.create_string_buffer(need)

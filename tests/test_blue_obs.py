@@ -1,0 +1,101 @@
+"""Blue dict observations decoded from the per-step event log against the reference's own
+CybORG.get_observation for 300 steps (oracle/refgen/make_blueobs_golden.py -> tests/golden/blueobs_seed123.json)."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+import golden_util
+from cage_challenge_4_amd import true_state as T
+
+GOLD = os.path.join(golden_util.GOLDEN_DIR, 'blueobs_seed123.json')
+
+
+def _canon(v):
+    if isinstance(v, dict):
+        return {str(k): _canon(x) for k, x in v.items()}
+    if isinstance(v, (list, tuple)):
+        return [_canon(x) for x in v]
+    if isinstance(v, (bool, int, float, str)) or v is None:
+        return v
+    return str(v)
+
+
+def _check(make_env):
+    doc = json.load(open(GOLD))
+    fix = golden_util.load(os.path.join(golden_util.GOLDEN_DIR, doc['fixture']))
+    env = make_env(fix)
+    env.enable_event_log(True)
+    for t, want in enumerate(doc['steps']):
+        env.step(np.full((1, 5), -1, np.int32))
+        got = T.blue_observations(T.decode(env.true_state_json(0)))
+        for agent, w in want.items():
+            g = _canon(got[agent])
+            assert g == w, (t, agent, {k: (g.get(k), w.get(k)) for k in set(g) | set(w) if g.get(k) != w.get(k)})
+
+
+def test_blue_dict_observations_match_reference_oracle_build():
+    from oracle_binding import OracleVecEnv
+
+    def make(fix):
+        e = OracleVecEnv(1, steps=fix['steps'])
+        e.reset(seeds=fix['seed'])
+        e.reset(seeds=None)
+        return e
+    _check(make)
+
+
+@pytest.mark.gpu
+def test_blue_dict_observations_match_reference_hip():
+    from cage_challenge_4_amd import CC4VecEnv
+
+    def make(fix):
+        e = CC4VecEnv(1, steps=fix['steps'])
+        e.reset(seeds=fix['seed'])
+        e.reset(seeds=None)
+        return e
+    _check(make)
+
+
+def test_blue_dict_observations_with_random_blue_actions_oracle_build():
+    """The same under random blue actions (fixture traj_seed123_random_ctor_500): 'action' string, 'success' where the
+    engine reports one, and the host entries -- except in the steps where the agent's own DeployDecoy / Analyse resolves,
+    whose observation carries a process / file list the engine does not model."""
+    from oracle_binding import OracleVecEnv
+    doc = json.load(open(os.path.join(golden_util.GOLDEN_DIR, 'blueobs_seed123_random.json')))
+    fix = golden_util.load(os.path.join(golden_util.GOLDEN_DIR, doc['fixture']))
+    e = OracleVecEnv(1, steps=fix['steps'])
+    e.reset(seeds=fix['seed'])
+    e.reset(seeds=None)
+    e.enable_event_log(True)
+    checked = 0
+    for t, want in enumerate(doc['steps']):
+        e.step(fix['actions'][t][None, :])
+        got = T.blue_observations(T.decode(e.true_state_json(0)))
+        for agent, w in want.items():
+            g = _canon(got[agent])
+            assert g.get('action') == w['action'], (t, agent)
+            if g['success'] is not None:
+                assert g['success'] == w['success'], (t, agent)
+            if w['action'] and w['action'].split(' ')[0] in ('DeployDecoy', 'Analyse'):
+                continue
+            hosts_g = {k: v for k, v in g.items() if k not in ('success', 'action')}
+            hosts_w = {k: v for k, v in w.items() if k not in ('success', 'action')}
+            assert hosts_g == hosts_w, (t, agent)
+            checked += 1
+    assert checked > 400
+
+
+def test_cyborg_get_observation_surface():
+    from oracle_binding import OracleVecEnv
+    from cage_challenge_4_amd import CybORG, EnterpriseScenarioGenerator, EnterpriseGreenAgent, FiniteStateRedAgent, SleepAgent, BlueFlatWrapper
+    doc = json.load(open(GOLD))
+    sg = EnterpriseScenarioGenerator(blue_agent_class=SleepAgent, green_agent_class=EnterpriseGreenAgent, red_agent_class=FiniteStateRedAgent, steps=500)
+    env = CybORG(sg, seed=123, vec_factory=OracleVecEnv)
+    w = BlueFlatWrapper(env)
+    w.reset()
+    for t in range(12):
+        w.step({})
+        for b in range(5):
+            assert _canon(env.get_observation(f'blue_agent_{b}')) == doc['steps'][t][f'blue_agent_{b}'], (t, b)
