@@ -820,6 +820,7 @@ CC4_HD void blue_decoy(Ctx x, int h) {
   int kind = K_DEC_APACHE + nth_bit(cand, (int)rng_below(x.r, (uint32_t)popc32(cand)));
   int pid = create_pid(x, h);
   if (!add_proc(x, h, pid, kind, 0)) return;
+  ev_log(x, 250, h, 2, kind, 0, 0xFF, 0, pid);   // the action's own observation: obs.add_process(pid, parent_pid=1, ...) (DecoyAction.py:105-113)
   HostDyn& d = s->hd[h];
   int si = -1;
   for (int i = 0; i < d.nsvc; ++i) if (d.svcs[i].kind == kind) { si = i; break; }
@@ -834,8 +835,11 @@ CC4_HD void blue_execute(Ctx x, int b, const Act& a) {
     case BA_REMOVE: blue_remove(x, b, a.host); break;
     case BA_RESTORE: blue_restore(x, a.host); break;
     case BA_DECOY: blue_decoy(x, a.host); break;
-    case BA_BLOCK: s->blocks[a.host] |= (uint16_t)(1u << a.arg); break;   // ControlTraffic.py:88-116
-    case BA_ALLOW: s->blocks[a.host] &= (uint16_t)~(1u << a.arg); break;  // ControlTraffic.py:160-185
+    // Observation(False) when the pair is already blocked / not blocked (ControlTraffic.py:111-113, :176-178)
+    case BA_BLOCK: s->blue[b].last_ok = (uint8_t)(((s->blocks[a.host] >> a.arg) & 1u) ? T_FALSE : T_TRUE);
+                   s->blocks[a.host] |= (uint16_t)(1u << a.arg); break;   // ControlTraffic.py:88-116
+    case BA_ALLOW: s->blue[b].last_ok = (uint8_t)(((s->blocks[a.host] >> a.arg) & 1u) ? T_TRUE : T_FALSE);
+                   s->blocks[a.host] &= (uint16_t)~(1u << a.arg); break;  // ControlTraffic.py:160-185
     default: break;
   }
 }
@@ -987,6 +991,7 @@ CC4_HD int exploit_new_session(Ctx x, int r, int parent_sid, int tgt) {
   (void)parent_sid;
   int pid = create_pid(x, tgt);
   if (!add_proc(x, tgt, pid, K_SHELL, 0)) return -1;
+  x.s->hd[tgt].pad = (uint8_t)((x.s->hd[tgt].pad | HF_CMD) & ~HF_ESC_LAST);   // target_host.files.append(File('cmd.sh', density 0.9)) (ExploitAction.py:230-238)
   return rs_add(x, r, tgt, pid, RS_CHILD);   // Session(parent=self.session) (ExploitAction.py:250-259)
 }
 // ExploitRemoteService.execute (AbstractActions/ExploitRemoteService.py:149-202) + selector (:37-69)
@@ -1086,6 +1091,7 @@ CC4_HD void red_privesc(Ctx x, int r, const Act& a) {
     { int ss = rs_find_id(A, a.sid);
       if (ss < 0 || !(A.sess[ss].flags & RS_ABSTRACT)) { red_result(x, r, a, T_FALSE); return; } }
     A.sess[target].flags |= RS_ROOT;  // EscalateAction.__upgrade_session (EscalateAction.py:57-87)
+    s->hd[h].pad |= (uint8_t)(HF_ESC | HF_ESC_LAST);   // ... which also drops File('escalate.sh', density 0.9) on the host (:70-77)
     int pi = find_proc(x, h, A.sess[target].pid);
     if (pi >= 0) s->hd[h].procs[pi].flags |= PF_ROOT;
   }

@@ -7,12 +7,14 @@
 //    "hosts":[{"h":host id (subnet*17+slot, 136 = internet root),"ip":last octet,
 //              "procs":[[pid,kind,root]...] (Host.processes order),
 //              "svcs":[[kind,active,reliability percent,pid]...] (Host.services order), "ev":event bits,
+//              "files":HF_* bits (1 cmd.sh, 2 escalate.sh, 4 escalate.sh appended last),
 //              "blue":pid of the blue session process (0 none),"green":pid of the green session process (0 none)}...],
 //    "red":[{"active":0/1,"sessions":[[id,host,pid,flags]...] (state.sessions[red_agent_r] order; flags = RS_* bits)}...x6],
-//    "blue":[{"parent":host id of the VelociraptorServer,"busy":1 while a multi-tick action is in progress,"sus":[[host,pid]...]}...x5],
+//    "blue":[{"parent":host id of the VelociraptorServer,"busy":1 while a multi-tick action is in progress,"traffic_ok":outcome of the last Block/Allow (1 TRUE, 3 FALSE),"sus":[[host,pid]...]}...x5],
 //    "last_blue":[[BA_* type,host or to-subnet,from-subnet]...x5],"last_red":[[RA_* type,host,subnet,executed (0 = dropped by filter_actions)]...x6] (the actions
 //    that resolved in the last step, i.e. CybORG.get_last_action),
-//    "events":[[order, seq, host, kind (0 network_connections / 1 process_creation), local_address host, local_port,
+//    "events":[[order, seq, host, kind (0 network_connections / 1 process_creation / 2 decoy deployed: local_address host = K_* kind),
+//               local_address host, local_port,
 //               remote_address host (255 none), remote_port, pid, repeat]...] (only with cc4_enable_event_log; 0 = absent field),
 //    "green_hosts":[host id of green_agent_g...]}    hosts[].os: OSDistribution 0 UBUNTU / 1 KALI
 #pragma once
@@ -41,7 +43,7 @@ inline std::string export_true_state(const EnvState& s, const HostStatic* hs, co
     o += "],\"svcs\":[";
     for (int i = 0; i < d.nsvc; ++i)
       add("%s[%u,%u,%u,%u]", i ? "," : "", (unsigned)d.svcs[i].kind, (unsigned)((d.svcs[i].st & SV_ACTIVE) ? 1 : 0), (unsigned)(d.svcs[i].st & 0x7F) * 20u, (unsigned)d.svcs[i].pid);
-    add("],\"ev\":%u,\"blue\":%u,\"green\":%u}", (unsigned)d.ev, (unsigned)s.blue_pid[h], (unsigned)s.green_pid[h]);
+    add("],\"ev\":%u,\"files\":%u,\"blue\":%u,\"green\":%u}", (unsigned)d.ev, (unsigned)d.pad, (unsigned)s.blue_pid[h], (unsigned)s.green_pid[h]);
   }
   o += "],\"red\":[";
   for (int r = 0; r < NRED; ++r) {
@@ -52,7 +54,7 @@ inline std::string export_true_state(const EnvState& s, const HostStatic* hs, co
   }
   o += "],\"blue\":[";
   for (int k = 0; k < NBLUE; ++k) {
-    add("%s{\"parent\":%u,\"busy\":%u,\"sus\":[", k ? "," : "", (unsigned)s.blue[k].parent_host, (unsigned)(s.blue[k].queue.busy ? 1 : 0));
+    add("%s{\"parent\":%u,\"busy\":%u,\"traffic_ok\":%u,\"sus\":[", k ? "," : "", (unsigned)s.blue[k].parent_host, (unsigned)(s.blue[k].queue.busy ? 1 : 0), (unsigned)s.blue[k].last_ok);
     for (int i = 0; i < s.blue[k].nsus; ++i) add("%s[%u,%u]", i ? "," : "", (unsigned)(sus[k][i] >> 16), (unsigned)(sus[k][i] & 0xFFFF));
     o += "]}";
   }

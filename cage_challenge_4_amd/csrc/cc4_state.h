@@ -62,6 +62,9 @@ enum : int { PF_ROOT = 1, SV_ACTIVE = 0x80 };
 
 enum : int { EV_CUR_CONN = 1, EV_CUR_PROC = 2, EV_OLD_CONN = 4, EV_OLD_PROC = 8 };
 
+// HostDyn.pad: the malware files Analyse reports (Host.files; cleared by Restore): cmd.sh present, escalate.sh present, and
+// which of the two was appended last (Observation.add_file_info re-appends a repeated name, so only that order survives)
+enum : int { HF_CMD = 1, HF_ESC = 2, HF_ESC_LAST = 4 };
 struct alignas(8) HostDyn {
   Proc procs[MAXP];
   Svc svcs[MAXSV];
@@ -134,7 +137,8 @@ struct alignas(8) BlueAgent {
   uint32_t pad2;
   Act queue;
   uint16_t nsus;
-  uint8_t parent_host, pad;
+  uint8_t parent_host;
+  uint8_t last_ok;                   // outcome of the last Block/AllowTrafficZone this agent resolved: 1 TRUE, 3 FALSE (T_*), 0 none
 };
 
 struct alignas(16) EnvState {

@@ -255,9 +255,12 @@ class _Obs:
                 self.add_system_info(key, info['System info'])
 
 
-def blue_observations(ts):
+def blue_observations(ts, combined=2):
     """{agent: observation dict} of the five blue agents for the step the TrueState was taken after.  Needs the event log
-    (CC4VecEnv.enable_event_log()); the keys follow the reference: 'success', 'action', then one entry per host with events."""
+    (CC4VecEnv.enable_event_log()); the keys follow the reference: 'success', 'action', then one entry per host with events.
+    `combined`: ObservationSet.get_combined_observation (Shared/ObservationSet.py:22-31) folds the end-of-turn Monitor's
+    observation into the action's observation object in place, every time it is called: the dicts returned by the step
+    carry it once (combined=1), a later CybORG.get_observation(agent) twice (the default, what the goldens record)."""
     d = ts.raw
     if 'events' not in d:
         raise RuntimeError('blue_observations needs the event log: call enable_event_log() before stepping')
@@ -266,8 +269,12 @@ def blue_observations(ts):
     ip_of = {hd['h']: IPv4Address(f'10.0.{d["cidr"][hd["h"] // 17]}.{hd["ip"]}') for hd in d['hosts']}
     os_of = {hd['h']: hd['os'] for hd in d['hosts']}
     by_host = {}
+    decoys = {}
     for order, seq, host, kind, laddr, lport, raddr, rport, pid, rep in sorted(d['events'], key=lambda e: (e[0], e[1])):
-        by_host.setdefault(host, ([], []))[kind].extend([(laddr, lport, raddr, rport, pid)] * rep)
+        if kind == 2:
+            decoys[host] = (laddr, pid)               # DeployDecoy resolved on this host: (K_* kind, pid)
+        else:
+            by_host.setdefault(host, ([], []))[kind].extend([(laddr, lport, raddr, rport, pid)] * rep)
     out = {}
     for b in range(5):
         agent = f'blue_agent_{b}'
@@ -287,18 +294,37 @@ def blue_observations(ts):
                                   local_address=ip_of[laddr] if laddr != 255 else None,
                                   remote_address=ip_of[raddr] if raddr != 255 else None)
         obs = _Obs()
-        obs.combine(m.data)
-        obs.combine(m.data)
+        la = ts.last_action[agent]
+        if la.name == 'DeployDecoy' and not d['blue'][b].get('busy'):
+            h = next((hd['h'] for hd in d['hosts'] if hostname_of(hd['h']) == la.hostname), None)
+            if h in decoys:                           # the action's own observation comes first (DecoyAction.py:105-113)
+                kind, pid = decoys[h]
+                p = {'PID': pid, 'PPID': 1, 'service_name': KIND_NAME[kind], 'username': 'ubuntu'}
+                if kind != 7:                         # HarakaDecoyFactory has no PROPERTIES
+                    p['Properties'] = ['rfi']
+                obs.data.setdefault(la.hostname, {}).setdefault('Processes', []).append(p)
+        if la.name == 'Analyse' and not d['blue'][b].get('busy'):
+            bits = next((hd.get('files', 0) for hd in d['hosts'] if hostname_of(hd['h']) == la.hostname), 0)
+            names = [n for n, bit in (('cmd.sh', 1), ('escalate.sh', 2)) if bits & bit]
+            if len(names) == 2 and not bits & 4:      # the name appended last is listed last (add_file_info re-appends)
+                names.reverse()
+            if names:                                 # DensityScout + SigCheck over Host.files (Analyse.py:55-71)
+                obs.data.setdefault(la.hostname, {})['Files'] = [
+                    {'Density': 0.9, 'File Name': n, 'Known File': 'UNKNOWN', 'Known Path': 'TEMP', 'Path': '/tmp/'} for n in names]
+        for _ in range(combined):
+            obs.combine(m.data)
         # 'success' / 'action' of the agent's own action: IN_PROGRESS (and no 'action' key) while a multi-tick action runs;
         # Sleep reports UNKNOWN; Monitor, Analyse, Remove, Restore and DeployDecoy report TRUE once they resolve (their
-        # parameters are validated on submission).  Block/AllowTrafficZone report whether the pair's state changed, which the
-        # engine does not keep: None.  Analyse's file list and DeployDecoy's process entry are not modelled.
-        la = ts.last_action[agent]
+        # parameters are validated on submission); Block/AllowTrafficZone report whether the pair's state changed
+        # (BlueAgent.last_ok).
         if d['blue'][b].get('busy'):
             res = {'success': 'IN_PROGRESS'}
         else:
-            res = {'success': {'Sleep': 'UNKNOWN', 'Monitor': 'TRUE', 'Analyse': 'TRUE', 'Remove': 'TRUE', 'Restore': 'TRUE',
-                               'DeployDecoy': 'TRUE'}.get(la.name), 'action': la}
+            ok = {'Sleep': 'UNKNOWN', 'Monitor': 'TRUE', 'Analyse': 'TRUE', 'Remove': 'TRUE', 'Restore': 'TRUE',
+                  'DeployDecoy': 'TRUE'}.get(la.name)
+            if la.name in ('BlockTrafficZone', 'AllowTrafficZone'):
+                ok = {1: 'TRUE', 3: 'FALSE'}.get(d['blue'][b].get('traffic_ok'))
+            res = {'success': ok, 'action': la}
         res.update(obs.data)
         out[agent] = res
     return out

@@ -7,7 +7,7 @@ where /root/reference exists.
 
 usage: python make_blueobs_golden.py [steps]   # writes tests/golden/blueobs_seed123.json
 """
-import json, os, sys
+import hashlib, json, os, sys
 import numpy as np
 sys.path.insert(0, os.path.dirname(__file__))
 import ref_shim  # noqa
@@ -17,6 +17,11 @@ from CybORG.Agents import SleepAgent, EnterpriseGreenAgent, FiniteStateRedAgent
 from CybORG.Agents.Wrappers import BlueFlatWrapper
 
 OUT = os.path.join(os.path.dirname(__file__), '..', '..', 'tests', 'golden')
+DIGEST_UNTIL = 450      # beyond the fully recorded steps, a 64-bit digest of each canonical observation up to this step
+
+
+def digest(d):
+    return hashlib.sha256(json.dumps(d, sort_keys=True, separators=(',', ':')).encode()).hexdigest()[:16]
 
 
 def canon(v):
@@ -51,8 +56,17 @@ def main():
             d.pop('message', None)
             row[f'blue_agent_{b}'] = d
         rows.append(row)
+    digs = []
+    for t in range(steps, DIGEST_UNTIL):
+        w.step({})
+        row = []
+        for b in range(5):
+            d = canon(env.get_observation(f'blue_agent_{b}'))
+            d.pop('message', None)
+            row.append(digest(d))
+        digs.append(row)
     with open(os.path.join(OUT, 'blueobs_seed123.json'), 'w') as f:
-        json.dump({'fixture': 'traj_seed123_sleep_ctor_500.npz', 'steps': rows, 'numpy_version': np.__version__}, f, separators=(',', ':'), sort_keys=True)
+        json.dump({'fixture': 'traj_seed123_sleep_ctor_500.npz', 'steps': rows, 'digests': digs, 'numpy_version': np.__version__}, f, separators=(',', ':'), sort_keys=True)
     import collections
     c = collections.Counter()
     for r in rows:
@@ -86,8 +100,19 @@ def random_blue(steps=120):
             d['action'] = None if act is None else str(act)
             row[f'blue_agent_{b}'] = d
         rows.append(row)
+    digs = []
+    for t in range(steps, DIGEST_UNTIL):
+        w.step({f'blue_agent_{b}': int(A[t, b]) for b in range(5)})
+        row = []
+        for b in range(5):
+            o = env.get_observation(f'blue_agent_{b}')
+            act = o.get('action')
+            d = canon({k: v for k, v in o.items() if k not in ('message', 'action')})
+            d['action'] = None if act is None else str(act)
+            row.append(digest(d))
+        digs.append(row)
     with open(os.path.join(OUT, 'blueobs_seed123_random.json'), 'w') as f:
-        json.dump({'fixture': 'traj_seed123_random_ctor_500.npz', 'steps': rows, 'numpy_version': np.__version__}, f, separators=(',', ':'), sort_keys=True)
+        json.dump({'fixture': 'traj_seed123_random_ctor_500.npz', 'steps': rows, 'digests': digs, 'numpy_version': np.__version__}, f, separators=(',', ':'), sort_keys=True)
     print('wrote blueobs_seed123_random.json', len(rows), os.path.getsize(os.path.join(OUT, 'blueobs_seed123_random.json')))
 
 

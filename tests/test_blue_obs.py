@@ -1,5 +1,6 @@
 """Blue dict observations decoded from the per-step event log against the reference's own
 CybORG.get_observation for 300 steps (oracle/refgen/make_blueobs_golden.py -> tests/golden/blueobs_seed123.json)."""
+import hashlib
 import json
 import os
 
@@ -22,6 +23,10 @@ def _canon(v):
     return str(v)
 
 
+def _digest(d):
+    return hashlib.sha256(json.dumps(d, sort_keys=True, separators=(',', ':')).encode()).hexdigest()[:16]
+
+
 def _check(make_env):
     doc = json.load(open(GOLD))
     fix = golden_util.load(os.path.join(golden_util.GOLDEN_DIR, doc['fixture']))
@@ -33,6 +38,11 @@ def _check(make_env):
         for agent, w in want.items():
             g = _canon(got[agent])
             assert g == w, (t, agent, {k: (g.get(k), w.get(k)) for k in set(g) | set(w) if g.get(k) != w.get(k)})
+    for i, row in enumerate(doc['digests']):        # steps 200..449: a digest of each canonical observation
+        env.step(np.full((1, 5), -1, np.int32))
+        got = T.blue_observations(T.decode(env.true_state_json(0)))
+        for b in range(5):
+            assert _digest(_canon(got[f'blue_agent_{b}'])) == row[b], (len(doc['steps']) + i, b)
 
 
 def test_blue_dict_observations_match_reference_oracle_build():
@@ -59,9 +69,8 @@ def test_blue_dict_observations_match_reference_hip():
 
 
 def test_blue_dict_observations_with_random_blue_actions_oracle_build():
-    """The same under random blue actions (fixture traj_seed123_random_ctor_500): 'action' string, 'success' where the
-    engine reports one, and the host entries -- except in the steps where the agent's own DeployDecoy / Analyse resolves,
-    whose observation carries a process / file list the engine does not model."""
+    """The same under random blue actions (fixture traj_seed123_random_ctor_500): 'action' string, 'success', and the
+    host entries, incl. the process entry of a resolved DeployDecoy and the file list of a resolved Analyse."""
     from oracle_binding import OracleVecEnv
     doc = json.load(open(os.path.join(golden_util.GOLDEN_DIR, 'blueobs_seed123_random.json')))
     fix = golden_util.load(os.path.join(golden_util.GOLDEN_DIR, doc['fixture']))
@@ -76,15 +85,20 @@ def test_blue_dict_observations_with_random_blue_actions_oracle_build():
         for agent, w in want.items():
             g = _canon(got[agent])
             assert g.get('action') == w['action'], (t, agent)
-            if g['success'] is not None:
-                assert g['success'] == w['success'], (t, agent)
-            if w['action'] and w['action'].split(' ')[0] in ('DeployDecoy', 'Analyse'):
-                continue
+            assert g['success'] == w['success'], (t, agent)
             hosts_g = {k: v for k, v in g.items() if k not in ('success', 'action')}
             hosts_w = {k: v for k, v in w.items() if k not in ('success', 'action')}
             assert hosts_g == hosts_w, (t, agent)
             checked += 1
-    assert checked > 400
+    assert checked > 550
+    t0 = len(doc['steps'])
+    for i, row in enumerate(doc['digests']):        # steps 120..449 by digest (covers late-episode Restore/Analyse/decoys)
+        e.step(fix['actions'][t0 + i][None, :])
+        got = T.blue_observations(T.decode(e.true_state_json(0)))
+        for b in range(5):
+            g = _canon(got[f'blue_agent_{b}'])
+            g.setdefault('action', None)
+            assert _digest(g) == row[b], (t0 + i, b)
 
 
 def test_cyborg_get_observation_surface():
