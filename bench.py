@@ -111,9 +111,35 @@ def main():
     lo = rank * n_local
     import numpy as np
     env.reset(seeds=np.uint64(args.seed0) + np.arange(lo, lo + n_local, dtype=np.uint64))
+    exchange_note = None
     if dist_on:
-        D.init_rccl(env, rank, world)
-        env.run_random_steps(args.seed0 + lo, 0, 1, timed=False)   # first collective (RCCL prints its banner lazily)
+        # RCCL setup + first collective under a watchdog: if any rank fails or stalls, every rank drops the exchange and
+        # the run is reported with "exchange": "none (...)" instead of dying without a number
+        import threading
+        res = {}
+
+        def _setup():
+            try:
+                if os.environ.get('CC4_RCCL_SETUP_FAIL') == '1':      # exercises the fallback below
+                    raise RuntimeError('CC4_RCCL_SETUP_FAIL=1')
+                D.init_rccl(env, rank, world)
+                env.run_random_steps(args.seed0 + lo, 0, 1, timed=False)   # first collective (RCCL prints its banner lazily)
+                env.synchronize()
+                res['ok'] = True
+            except Exception as ex:      # noqa: BLE001 - reported below
+                res['err'] = repr(ex)
+        th = threading.Thread(target=_setup, daemon=True)
+        th.start()
+        th.join(float(os.environ.get('CC4_RCCL_SETUP_TIMEOUT', '240')))
+        ok = torch.tensor([1 if res.get('ok') else 0], dtype=torch.int32)
+        if world > 1:
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+        if int(ok[0]) == 0:
+            exchange_note = 'none (RCCL setup failed or timed out on a rank: %s)' % res.get('err', 'ok here' if res.get('ok') else 'timeout')
+            print('bench.py: ' + exchange_note, file=sys.stderr)
+            env.close = lambda: None                                                # the old handle is abandoned, not destroyed
+            env = CC4VecEnv(n_local, steps=args.episode_steps, rng_mode=RNG_PCG64 if args.rng == 'pcg64' else RNG_PHILOX,
+                            device_id=local if world > 1 else 0, autoreset=True)
         env.reset(seeds=np.uint64(args.seed0) + np.arange(lo, lo + n_local, dtype=np.uint64))
         import ctypes
         ctypes.CDLL(None).fflush(None)           # C stdio buffers written while fd 1 pointed at stderr
@@ -186,7 +212,7 @@ def main():
                             f'(82/82/82/82/242 incl. invalid slots), FiniteStateRedAgent, EnterpriseGreenAgent, '
                             f'EnterpriseScenarioGenerator(steps={args.episode_steps}), autoreset incl. scenario regeneration, topology randomised per episode and reset',
                 'envs_per_gpu': n_local, 'total_envs': total_envs, 'rng': args.rng,
-                'exchange': 'RCCL all-gather of the [N,578] uint8 obs of every step on a second stream, overlapped with the next step' if dist_on else 'none',
+                'exchange': exchange_note or ('RCCL all-gather of the [N,578] uint8 obs of every step on a second stream, overlapped with the next step' if dist_on else 'none'),
                 'env_steps_per_sec': total_envs * args.steps / dt, 'engine_error_flags': err_any,
             },
             'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBPS, 'unit': 'GB/s',
@@ -205,6 +231,9 @@ def main():
     if dist_on:
         dist.barrier()
         dist.destroy_process_group()
+    if exchange_note:                 # a stalled RCCL setup thread must not keep the process alive
+        sys.stdout.flush()
+        os._exit(0)
 
 
 if __name__ == '__main__':
