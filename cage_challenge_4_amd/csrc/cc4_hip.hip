@@ -7,6 +7,7 @@
 // The cold part of the episode (ephemeral-port bitmaps, per-session port knowledge; 205 KB) stays in HBM
 // and is touched a handful of times per step.  No MFMA: the path is integer / indexing.
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <rccl/rccl.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -434,6 +435,7 @@ struct cc4_handle {
   hipStream_t comm_stream = nullptr;
   hipEvent_t ev_step[OBS_RING] = {}, ev_comm[OBS_RING] = {};   // ev_comm[q % OBS_RING]: all-gather number q has completed
   int obs_buf = 0;                               // buffer written by the most recent step
+  bool step_event_attached = false;              // ev_step[obs_buf] was recorded by the launch of that step itself
   unsigned long long* d_prof = nullptr;
   int evlog_on = 0;               // cc4_enable_event_log
   ncclComm_t comm = nullptr; int rank = 0, world = 1;
@@ -465,7 +467,11 @@ static int launch_step(cc4_handle* h, const int32_t* d_actions, const uint8_t* d
     long long q = h->gather_seq[buf] + cc4_handle::OBS_WAIT_EVERY - 1;
     if (q > h->gathers_issued - 1) q = h->gathers_issued - 1;
     if (q < h->gather_seq[buf]) q = h->gather_seq[buf];
-    HIPCHK(h, hipStreamWaitEvent(h->stream, h->ev_comm[q % cc4_handle::OBS_RING], 0));
+    // waited for by the host, not by the stream: the all-gather in question is several steps old and normally complete, and
+    // a wait packet in the compute queue costs stream time whether or not it has to wait
+    hipError_t qs = hipEventQuery(h->ev_comm[q % cc4_handle::OBS_RING]);
+    if (qs == hipErrorNotReady) HIPCHK(h, hipEventSynchronize(h->ev_comm[q % cc4_handle::OBS_RING]));
+    else HIPCHK(h, qs);
     h->gathers_waited = q;
   }
   StepArgs a{h->d_state, h->d_cold, d_actions, d_msgs, h->d_obs, h->d_reward, h->d_done, h->d_err,
@@ -473,12 +479,16 @@ static int launch_step(cc4_handle* h, const int32_t* d_actions, const uint8_t* d
              h->cfg.num_envs, h->cfg.autoreset, h->cfg.steps, h->cfg.rng_mode,
              (h->cfg.red_policy & 3) | (h->cfg.green_policy ? GP_SLEEP_BIT : 0), (uint32_t)h->cfg.topology_seed, h->d_prof};
   const dim3 grid(h->cfg.num_envs);
+  // with a communicator, the launch carries ev_step[buf] as its stop event: the event rides on the kernel's own completion
+  // signal, where a separate hipEventRecord would put a marker packet between two step kernels (~5 us of idle stream time)
+  hipEvent_t stop = h->comm ? h->ev_step[buf] : nullptr;
+  h->step_event_attached = stop != nullptr;
   if (h->cfg.rng_mode == 1) {
-    if (h->evlog_on) hipLaunchKernelGGL(k_step_philox<true>, grid, dim3(PT), sizeof(EnvState), h->stream, a);
-    else hipLaunchKernelGGL(k_step_philox<false>, grid, dim3(PT), sizeof(EnvState), h->stream, a);
+    if (h->evlog_on) hipExtLaunchKernelGGL(k_step_philox<true>, grid, dim3(PT), sizeof(EnvState), h->stream, nullptr, stop, 0, a);
+    else hipExtLaunchKernelGGL(k_step_philox<false>, grid, dim3(PT), sizeof(EnvState), h->stream, nullptr, stop, 0, a);
   } else {
-    if (h->evlog_on) hipLaunchKernelGGL(k_step<true>, grid, dim3(WAVE), sizeof(EnvState), h->stream, a);
-    else hipLaunchKernelGGL(k_step<false>, grid, dim3(WAVE), sizeof(EnvState), h->stream, a);
+    if (h->evlog_on) hipExtLaunchKernelGGL(k_step<true>, grid, dim3(WAVE), sizeof(EnvState), h->stream, nullptr, stop, 0, a);
+    else hipExtLaunchKernelGGL(k_step<false>, grid, dim3(WAVE), sizeof(EnvState), h->stream, nullptr, stop, 0, a);
   }
   HIPCHK(h, hipGetLastError());
   h->obs_buf = buf;
@@ -795,7 +805,7 @@ int cc4_allgather_obs(cc4_handle* h, uint8_t** d_all_obs8) {
   if (!h->comm) { h->err = "cc4_allgather_obs: cc4_comm_init was not called"; return -2; }
   HIPCHK(h, hipSetDevice(h->cfg.device_id));
   const int buf = h->obs_buf;
-  HIPCHK(h, hipEventRecord(h->ev_step[buf], h->stream));
+  if (!h->step_event_attached) HIPCHK(h, hipEventRecord(h->ev_step[buf], h->stream));   // e.g. the observations of a reset
   HIPCHK(h, hipStreamWaitEvent(h->comm_stream, h->ev_step[buf], 0));
   size_t cnt = (size_t)h->cfg.num_envs * OBS_TOTAL;
   ncclResult_t r = ncclAllGather(h->d_obs8[buf], h->d_all_obs8[buf], cnt, ncclUint8, h->comm, h->comm_stream);
