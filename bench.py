@@ -104,10 +104,11 @@ def main():
         D.init_control_plane('gloo', force=True)
         import torch
         import torch.distributed as dist
+    dev_id = int(os.environ.get('CC4_BENCH_DEVICE', local if world > 1 else 0))   # override: several ranks on one GPU (tests the N>1 plumbing on a 1-GPU box)
     n_local = args.envs_per_gpu
     total_envs = n_local * world
     env = CC4VecEnv(n_local, steps=args.episode_steps, rng_mode=RNG_PCG64 if args.rng == 'pcg64' else RNG_PHILOX,
-                    device_id=local if world > 1 else 0, autoreset=True)
+                    device_id=dev_id, autoreset=True)
     lo = rank * n_local
     import numpy as np
     env.reset(seeds=np.uint64(args.seed0) + np.arange(lo, lo + n_local, dtype=np.uint64))
@@ -139,7 +140,7 @@ def main():
             print('bench.py: ' + exchange_note, file=sys.stderr)
             env.close = lambda: None                                                # the old handle is abandoned, not destroyed
             env = CC4VecEnv(n_local, steps=args.episode_steps, rng_mode=RNG_PCG64 if args.rng == 'pcg64' else RNG_PHILOX,
-                            device_id=local if world > 1 else 0, autoreset=True)
+                            device_id=dev_id, autoreset=True)
         env.reset(seeds=np.uint64(args.seed0) + np.arange(lo, lo + n_local, dtype=np.uint64))
         import ctypes
         ctypes.CDLL(None).fflush(None)           # C stdio buffers written while fd 1 pointed at stderr
@@ -173,7 +174,7 @@ def main():
     if not args.no_alt and not dist_on:      # single-GPU runs also time the other RNG mode
         other = 'pcg64' if args.rng == 'philox' else 'philox'
         env2 = CC4VecEnv(n_local, steps=args.episode_steps, rng_mode=RNG_PCG64 if other == 'pcg64' else RNG_PHILOX,
-                         device_id=local if world > 1 else 0, autoreset=True)
+                         device_id=dev_id, autoreset=True)
         env2.reset(seeds=np.uint64(args.seed0) + np.arange(lo, lo + n_local, dtype=np.uint64))
         if world > 1:
             D.init_rccl(env2, rank, world)
