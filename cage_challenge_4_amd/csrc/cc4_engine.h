@@ -83,6 +83,13 @@ CC4_HD void bit_clr_shared(uint32_t* b, int i) {
   b[i >> 5] &= ~(1u << (i & 31));
 #endif
 }
+CC4_HD uint32_t or_shared(uint32_t* p, uint32_t v) {   // returns the previous word
+#if defined(__HIP_DEVICE_COMPILE__)
+  return __hip_atomic_fetch_or(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+#else
+  uint32_t o = *p; *p = o | v; return o;
+#endif
+}
 // a 137-bit host bitmap held in registers: loaded / stored as one batch of independent LDS accesses (a `for w` loop that
 // alternates loads and stores pays one LDS round trip per word)
 struct B5 { uint32_t w[5]; };
@@ -486,6 +493,222 @@ CC4_HD void host_restore(Ctx x, int h) {  // Host.restore (Host.py:373-429)
   pend_drop_host(x, h);
 }
 
+// ------------------------------------------------------------------ counter-mode scenario generation, in phases
+// The numpy-stream mode above is serial by definition (one shared generator).  In the counter-based mode every host draws
+// from its own streams (ST_GEN_HOST / ST_GEN_REDRAW / ST_GEN_SESS + host id), so the generation is cut into phases whose
+// per-host parts are independent: the device runs them one host per thread, env_reset runs the same phases as loops (the
+// oracle), and both leave identical bytes.  Same scenario distribution as _generate_* (ESG.py:171-817); pids are unique
+// network-wide as in _generate_pid: a pid drawn by several services stays with the first of them in host order, the
+// others draw again.
+struct ResetCarry { uint64_t env_key; };
+enum : int { RESET_WS_SEEN = 0, RESET_WS_DUP = 288, RESET_WS_HOSTS = 576, RESET_WS_WORDS = 584 };   // work area (LDS on the device)
+
+// phase 0, all threads: clear the row (except the generator) and the backup images
+CC4_HD void reset_zero(EnvState* s, EnvCold* c, int t, int nt) {
+  static_assert(offsetof(EnvState, rng) == 0, "the generator leads the row");
+  uint32_t* w = (uint32_t*)s;
+  for (size_t i = sizeof(Rng) / 4 + (size_t)t; i < sizeof(EnvState) / 4; i += (size_t)nt) w[i] = 0;
+  uint32_t* b = (uint32_t*)c->hs;
+  for (size_t i = (size_t)t; i < sizeof(c->hs) / 4; i += (size_t)nt) b[i] = 0;
+}
+// phase 1, one thread: generator, mission phases, subnets, host counts and addresses (main reset stream)
+CC4_HD ResetCarry reset_topology(Ctx x, uint64_t seed, int steps, bool continue_stream, int policy, uint32_t topo_seed, uint32_t* ws,
+                                 bool rng_is_copy) {
+  EnvState* s = x.s;
+  if (!continue_stream) rng_seed(&s->rng, seed, 1u);   // a fresh seed needs x.r == &s->rng (see env_reset)
+  s->rng_mode = 1;
+  s->policy = (uint8_t)policy;
+  rng_begin_episode(x.r);
+  ResetCarry k; k.env_key = x.r->s_lo;
+  if (topo_seed) x.r->s_lo = (uint64_t)topo_seed;
+  s->steps = steps;
+  { int q = steps / 3, rem = steps % 3; s->phase_len[0] = q + (rem >= 1 ? 1 : 0); s->phase_len[1] = q + (rem == 2 ? 1 : 0); s->phase_len[2] = q; }
+  for (int i = 0; i < RESET_WS_WORDS; ++i) ws[i] = 0;
+  {
+    uint32_t* avail = s->scratch;
+    for (int i = 0; i < 8; ++i) avail[i] = 0xFFFFFFFFu;
+    int n = 256;
+    for (int sn = 0; sn < NSUB; ++sn) {
+      int v = nth_set(avail, 8, (int)rng_below(x.r, (uint32_t)n));
+      s->cidr_octet[sn] = (uint8_t)v;
+      bit_clr(avail, v);
+      n--;
+    }
+  }
+  for (int sn = 0; sn < NSUB; ++sn) {
+    uint32_t* ips = s->scratch;
+    for (int i = 0; i < 8; ++i) ips[i] = 0xFFFFFFFFu;
+    ips[0] &= ~1u; ips[7] &= 0x7FFFFFFFu;
+    int n = 254;
+    auto place = [&](int h, int v) { bit_clr(ips, v); n--; bit_set(s->exists, h); s->hd[h].pad = (uint8_t)v; };   // ip parked in pad until the backup
+    if (sn == S_INT) { place(H_INTERNET, nth_set(ips, 8, (int)rng_below(x.r, (uint32_t)n))); continue; }
+    place(h_make(sn, 0), nth_set(ips, 8, (int)rng_below(x.r, (uint32_t)n)));
+    int nu = 3 + (int)rng_below(x.r, 8);
+    for (int i = 0; i < nu; ++i) place(h_make(sn, 1 + i), nth_set(ips, 8, (int)rng_below(x.r, (uint32_t)n)));
+    int ns = 1 + (int)rng_below(x.r, 6);
+    for (int i = 0; i < ns; ++i) place(h_make(sn, 11 + i), last_set(ips, 8));
+    s->n_users[sn] = (uint8_t)nu; s->n_servers[sn] = (uint8_t)ns;
+  }
+  if (rng_is_copy) s->rng = *x.r;   // the per-host generators fork from the row (key, episode, reset step word)
+  return k;
+}
+// phase 2, per host: services and candidate pids (_generate_linux_host, ESG.py:470-629) from the host's own stream
+CC4_HD void reset_gen_host(Ctx x, int h) {
+  EnvState* s = x.s;
+  for (int r = 0; r < NRED; ++r) s->red[r].fsm_state[h] = FS_NONE;
+  if (!bit_get(s->exists, h)) return;
+  rng_set_stream(x.r, ST_GEN_HOST + (uint32_t)h);
+  HostDyn& st = s->hd[h];
+  st.ev = (uint8_t)rng_below(x.r, 2);   // OSDistribution, parked in ev until the backup
+  if (h_is_router(h)) return;
+  int n = 0;
+  auto put = [&](int kind, int pid) {
+    st.svcs[n].kind = (uint8_t)kind; st.svcs[n].pid = (uint16_t)pid; st.svcs[n].st = (uint8_t)(SV_ACTIVE | 5);
+    st.procs[n].kind = (uint8_t)kind; st.procs[n].pid = (uint16_t)pid; st.procs[n].flags = 0;
+    n++;
+  };
+  put(K_SSHD, rng_range(x.r, 1000, 10000));
+  int sub = h_subnet(h);
+  if (sub == S_OZA || sub == S_OZB) put(K_OT, rng_range(x.r, 1000, 10000));
+  int p_apache = rng_range(x.r, 1000, 10000), p_mysql = rng_range(x.r, 1000, 10000), p_smtp = rng_range(x.r, 1000, 10000);
+  int n_add = (int)rng_below(x.r, 4);
+  uint32_t left = 7;
+  for (int k = 0; k < n_add; ++k) {
+    int o = nth_bit(left, (int)rng_below(x.r, (uint32_t)popc32(left)));
+    left &= ~(1u << o);
+    put(o == 0 ? K_APACHE : (o == 1 ? K_MYSQL : K_SMTP), o == 0 ? p_apache : (o == 1 ? p_mysql : p_smtp));
+  }
+  for (int i = 0; i < n; ++i) (void)rng_random(x.r);
+  st.nsvc = (uint8_t)n; st.nproc = (uint8_t)n;
+}
+// phase 3a, per host: enter the pids into the network-wide set; a value entered twice is contested
+CC4_HD void reset_pid_mark(Ctx x, int h, uint32_t* ws) {
+  const HostDyn& st = x.s->hd[h];
+  for (int i = 0; i < st.nsvc; ++i) {
+    int v = st.svcs[i].pid - 1000;
+    if (or_shared(&ws[RESET_WS_SEEN + (v >> 5)], 1u << (v & 31)) & (1u << (v & 31))) (void)or_shared(&ws[RESET_WS_DUP + (v >> 5)], 1u << (v & 31));
+  }
+}
+// phase 3b, per host: which of the host's services hold a contested pid (ev bits 1..5), which hosts have any
+CC4_HD void reset_pid_flag(Ctx x, int h, uint32_t* ws) {
+  HostDyn& st = x.s->hd[h];
+  uint32_t m = 0;
+  for (int i = 0; i < st.nsvc; ++i) { int v = st.svcs[i].pid - 1000; if (bit_get(ws + RESET_WS_DUP, v)) m |= 1u << i; }
+  if (m) { st.ev = (uint8_t)(st.ev | (m << 1)); (void)or_shared(&ws[RESET_WS_HOSTS + (h >> 5)], 1u << (h & 31)); }
+}
+// phase 3c, one thread: contested pids in host / service order -- the first holder keeps the value, later ones draw again
+CC4_HD void reset_pid_resolve(Ctx x, uint32_t* ws) {
+  EnvState* s = x.s;
+  for (int w = 0; w < 5; ++w) {
+    uint32_t hm = ws[RESET_WS_HOSTS + w];
+    while (hm) {
+      const int h = w * 32 + ctz32(hm); hm &= hm - 1;
+      HostDyn& st = s->hd[h];
+      uint32_t cm = (uint32_t)st.ev >> 1;
+      st.ev &= 1;
+      Rng t; bool forked = false;
+      while (cm) {
+        const int i = ctz32(cm); cm &= cm - 1;
+        const int v = st.svcs[i].pid - 1000;
+        if (bit_get(ws + RESET_WS_DUP, v)) { bit_clr(ws + RESET_WS_DUP, v); continue; }
+        if (!forked) { rng_fork(&t, x.r, ST_GEN_REDRAW + (uint32_t)h); forked = true; }
+        int nv;
+        do nv = (int)rng_below(&t, 9000); while (bit_get(ws + RESET_WS_SEEN, nv));
+        bit_set(ws + RESET_WS_SEEN, nv);
+        st.svcs[i].pid = (uint16_t)(nv + 1000); st.procs[i].pid = (uint16_t)(nv + 1000);
+      }
+    }
+  }
+}
+// phase 4, one thread: blue parents, green agents, red start hosts (_generate_blue/green/red_agents; main reset stream)
+CC4_HD void reset_agents(Ctx x) {
+  EnvState* s = x.s;
+  for (int b = 0; b < NBLUE; ++b) {
+    int nsub = blue_nsub(b);
+    (void)rng_below(x.r, (uint32_t)nsub);
+    int cnt = 0;
+    for (int i = 0; i < nsub; ++i) { int sn = blue_subnet_alloc(b, i); cnt += 1 + s->n_users[sn] + s->n_servers[sn]; }
+    int c = (int)rng_below(x.r, (uint32_t)cnt);
+    int ph = -1;
+    for (int i = 0; i < nsub && ph < 0; ++i) {   // existing slots of a subnet: 0, 1..nu, 11..11+ns-1
+      int sn = blue_subnet_alloc(b, i), nu = s->n_users[sn], ns = s->n_servers[sn];
+      if (c < 1 + nu) ph = h_make(sn, c);
+      else if (c < 1 + nu + ns) ph = h_make(sn, 11 + (c - 1 - nu));
+      else c -= 1 + nu + ns;
+    }
+    s->blue[b].parent_host = (uint8_t)ph;
+  }
+  {
+    int g = 0;
+    for (int sn = 0; sn < NSUB - 1; ++sn) for (int i = 0; i < s->n_users[sn]; ++i) s->green_host[g++] = (uint8_t)h_make(sn, 1 + i);
+    s->n_green = (uint8_t)g;
+  }
+  for (int r = 0; r < NRED; ++r) {
+    int sn = red_subnet_alloc(r, (int)rng_below(x.r, (uint32_t)red_nsub(r)));
+    int c = (int)rng_below(x.r, (uint32_t)(s->n_users[sn] + s->n_servers[sn]));
+    s->red[r].start_host = (uint8_t)(c < s->n_users[sn] ? h_make(sn, 1 + c) : h_make(sn, 11 + (c - s->n_users[sn])));
+    s->red[r].new_sess_host = 0xFF;
+  }
+}
+// phase 5, per host: starting sessions (State.__init__, State.py:103-136) from the host's stream, then the backup image
+CC4_HD void reset_host_sessions(Ctx x, int h) {
+  EnvState* s = x.s;
+  if (!bit_get(s->exists, h)) return;
+  rng_set_stream(x.r, ST_GEN_SESS + (uint32_t)h);
+  if (blue_of_subnet(h_subnet(h)) >= 0) s->blue_pid[h] = (uint16_t)start_session_proc(x, h, K_SESS_BLUE);
+  if (h != H_INTERNET && h_is_user(h)) s->green_pid[h] = (uint16_t)start_session_proc(x, h, K_SESS_GREEN);
+  if (h == s->red[0].start_host) (void)start_session_proc(x, h, K_SESS_RED);
+  host_backup(x, h, s->hd[h].pad);
+  s->hd[h].pad = 0; s->hd[h].ev = 0;
+}
+// phase 6, one thread: red_agent_0's session, initial observations, counters
+CC4_HD void reset_finish(Ctx x, ResetCarry k, int steps, uint32_t topo_seed, bool rng_is_copy) {
+  EnvState* s = x.s;
+  {
+    const HostDyn& d = s->hd[s->red[0].start_host];
+    int red0_pid = 0;
+    for (int i = 0; i < d.nproc; ++i) if (d.procs[i].kind == K_SESS_RED) red0_pid = d.procs[i].pid;
+    (void)rs_add(x, 0, s->red[0].start_host, red0_pid, RS_ABSTRACT | RS_ORIG);
+    s->red[0].active = 1;
+  }
+  for (int r = 0; r < NRED; ++r) {
+    RedAgent& a = s->red[r];
+    int h = a.start_host;
+    bit_set(a.as_ip, h); bit_set(a.as_hn, h); a.as_subnet |= (uint16_t)(1u << h_subnet(h));
+    if (r == 0) {
+      as_know_sid(x, 0, 0);
+      obs_put(x, 0, false, h, OE_SESS | OE_IFACE | OE_SYSHN, true);
+      obs_first(x, 0, T_UNKNOWN, RA_NONE, 0, 0);
+    }
+    a.exec_type = RA_SLEEP;
+  }
+  s->done = (uint8_t)(0 >= steps - 1);
+  if (topo_seed) x.r->s_lo = k.env_key;
+  if (rng_is_copy) s->rng = *x.r;
+  rng_park(&s->rng);
+}
+// the same phases as loops (the oracle; any single-threaded caller)
+CC4_HD void env_reset_counter_mode(Ctx x, uint64_t seed, int steps, bool continue_stream, int policy, uint32_t topo_seed, uint32_t* ws,
+                                   bool rng_is_copy) {
+  reset_zero(x.s, x.c, 0, 1);
+  ResetCarry k = reset_topology(x, seed, steps, continue_stream, policy, topo_seed, ws, rng_is_copy);
+  {
+    Rng t; rng_fork(&t, x.r, ST_GEN_HOST);
+    Ctx xh = x; xh.r = &t;
+    for (int h = 0; h < MAXH; ++h) reset_gen_host(xh, h);
+    for (int h = 0; h < MAXH; ++h) reset_pid_mark(xh, h, ws);
+    for (int h = 0; h < MAXH; ++h) reset_pid_flag(xh, h, ws);
+  }
+  reset_pid_resolve(x, ws);
+  reset_agents(x);
+  {
+    Rng t; rng_fork(&t, x.r, ST_GEN_SESS);
+    Ctx xh = x; xh.r = &t;
+    for (int h = 0; h < MAXH; ++h) reset_host_sessions(xh, h);
+  }
+  reset_finish(x, k, steps, topo_seed, rng_is_copy);
+}
+
 // continue_stream = true restates CybORG.reset(seed=None) (env.py:218-243): the same Generator keeps going.
 // topo_seed != 0 (counter-based RNG mode only): every episode draws its scenario from the reset stream of the key
 // `topo_seed` instead of its own key, i.e. all episodes of a batch share topology, services and pids and differ only in
@@ -495,6 +718,10 @@ CC4_HD void host_restore(Ctx x, int h) {  // Host.restore (Host.py:373-429)
 CC4_HD void env_reset(Ctx x, uint64_t seed, int rng_mode, int steps, bool continue_stream, int policy = 0, uint32_t topo_seed = 0,
                       uint32_t* pid_ws = nullptr, bool rng_is_copy = false) {
   EnvState* s = x.s;
+  if (rng_mode == 1) {   // counter-based mode: generation in per-host phases; pid_ws must then hold RESET_WS_WORDS words
+    env_reset_counter_mode(x, seed, steps, continue_stream, policy, topo_seed, pid_ws, rng_is_copy);
+    return;
+  }
   Rng keep = s->rng;
   {  // zero everything (POD)
     uint32_t* w = (uint32_t*)s;

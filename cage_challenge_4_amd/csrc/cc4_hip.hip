@@ -109,7 +109,7 @@ __global__ __launch_bounds__(WAVE) void k_step(StepArgs a) {
   if (lane == 0) {
     ok_lds = 0;
     if (do_reset) {
-      env_reset(x, 0, a.rng_mode, a.steps, true, a.policy, a.topo, reset_ws);   // new episode, same stream (CybORG.reset(seed=None))
+      env_reset(x, 0, 0, a.steps, true, a.policy, a.topo, reset_ws);   // new episode, same stream (CybORG.reset(seed=None)); this kernel serves the numpy-stream mode only
     } else {
       CC4_TICK0(x);
       int32_t racts[NBLUE];
@@ -216,7 +216,7 @@ template <bool LOG>
 __global__ __launch_bounds__(PT) void k_step_philox(StepArgs a) {
   extern __shared__ uint4 lds[];
   __shared__ int ok_lds, conflict_lds;
-  __shared__ uint32_t reset_ws[288];   // used-pid bitmap of the scenario generation (autoreset)
+  __shared__ uint32_t reset_ws[RESET_WS_WORDS];   // pid bitmaps of the scenario generation (autoreset)
   __shared__ int glist_n[2];
   __shared__ uint8_t glist[2][MAXG];  // green agents by action type (0 AccessService, 1 LocalWork)
   __shared__ unsigned long long prof_lds[16];
@@ -245,7 +245,26 @@ __global__ __launch_bounds__(PT) void k_step_philox(StepArgs a) {
   if (do_reset) {
     dma_wait();
     __syncthreads();
-    if (tid == 0) { Rng rr = s->rng; rr.mode = 1; Ctx x{s, a.cold + e, &rr}; env_reset(x, 0, a.rng_mode, a.steps, true, a.policy, a.topo, reset_ws, true); }   // generator in registers
+    // new episode on the same key (CybORG.reset(seed=None)): the phases of env_reset_counter_mode, hosts on threads
+    reset_zero(s, a.cold + e, tid, PT);
+    __syncthreads();
+    Rng rr; ResetCarry carry; carry.env_key = 0;     // thread 0: main reset stream in registers, across the phases
+    Ctx xm{s, a.cold + e, &rr};
+    if (tid == 0) { rr = s->rng; rr.mode = 1; carry = reset_topology(xm, 0, a.steps, true, a.policy, a.topo, reset_ws, true); }
+    __syncthreads();
+    Rng rh; rng_fork(&rh, &s->rng, ST_GEN_HOST); rh.mode = 1;
+    Ctx xh{s, a.cold + e, &rh};
+    if (tid < MAXH) reset_gen_host(xh, tid);
+    __syncthreads();
+    if (tid < MAXH) reset_pid_mark(xh, tid, reset_ws);
+    __syncthreads();
+    if (tid < MAXH) reset_pid_flag(xh, tid, reset_ws);
+    __syncthreads();
+    if (tid == 0) { reset_pid_resolve(xm, reset_ws); reset_agents(xm); }
+    __syncthreads();
+    if (tid < MAXH) reset_host_sessions(xh, tid);
+    __syncthreads();
+    if (tid == 0) reset_finish(xm, carry, a.steps, a.topo, true);
   } else {
     if (tid == 0) {
       Ctx x{s, a.cold + e, &s->rng, prof};
@@ -385,9 +404,33 @@ __global__ __launch_bounds__(WAVE) void k_reset(ResetArgs a) {
   if (e >= a.n) return;
   if (a.env_mask && !a.env_mask[e]) return;
   EnvState* s = a.st + e;
-  if (lane == 0) {
+  if (a.rng_mode == 1) {   // counter-based mode: the phases of env_reset_counter_mode, hosts on lanes (the row stays in HBM here)
+    __shared__ uint32_t ws[RESET_WS_WORDS];
+    Ctx xm{s, a.cold + e, &s->rng};
+    ResetCarry carry; carry.env_key = 0;
+    reset_zero(s, a.cold + e, lane, WAVE);
+    __syncthreads();
+    if (lane == 0) carry = reset_topology(xm, a.seeds ? a.seeds[e] : 0, a.steps, a.seeds == nullptr, a.policy, a.topo, ws, false);
+    __syncthreads();
+    Rng rh; rng_fork(&rh, &s->rng, ST_GEN_HOST); rh.mode = 1;
+    Ctx xh{s, a.cold + e, &rh};
+    for (int h = lane; h < MAXH; h += WAVE) reset_gen_host(xh, h);
+    __syncthreads();
+    for (int h = lane; h < MAXH; h += WAVE) reset_pid_mark(xh, h, ws);
+    __syncthreads();
+    for (int h = lane; h < MAXH; h += WAVE) reset_pid_flag(xh, h, ws);
+    __syncthreads();
+    if (lane == 0) { reset_pid_resolve(xm, ws); reset_agents(xm); }
+    __syncthreads();
+    for (int h = lane; h < MAXH; h += WAVE) reset_host_sessions(xh, h);
+    __syncthreads();
+    if (lane == 0) reset_finish(xm, carry, a.steps, a.topo, false);
+    __syncthreads();
+  } else if (lane == 0) {
     Ctx x{s, a.cold + e, &s->rng};
-    env_reset(x, a.seeds ? a.seeds[e] : 0, a.rng_mode, a.steps, a.seeds == nullptr, a.policy, a.topo);
+    env_reset(x, a.seeds ? a.seeds[e] : 0, 0, a.steps, a.seeds == nullptr, a.policy, a.topo);
+  }
+  if (lane == 0) {
     env_flat_obs<uint8_t>(s, obs_lds);
     blue_action_mask(s, mask_lds);
     a.reward[e] = 0.f; a.done[e] = s->done; a.err[e] = s->err;

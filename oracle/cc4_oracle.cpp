@@ -52,7 +52,8 @@ void* cc4o_cold_ptr(void* h, int i) { return &((Oracle*)h)->cold[i]; }
 void cc4o_reset(void* h, int i, uint64_t seed, int rng_mode, int steps, int continue_stream, int policy) {
   Oracle* o = (Oracle*)h;
   Ctx x{&o->st[i], &o->cold[i], &o->st[i].rng};
-  env_reset(x, seed, rng_mode, steps, continue_stream != 0, policy, o->topo);
+  uint32_t ws[RESET_WS_WORDS];   // work area of the counter-mode generation (the device kernels use LDS)
+  env_reset(x, seed, rng_mode, steps, continue_stream != 0, policy, o->topo, rng_mode == 1 ? ws : nullptr);
 }
 void cc4o_set_topology_seed(void* h, uint32_t seed) { ((Oracle*)h)->topo = seed; }
 void cc4o_enable_event_log(void* h, int on) { Oracle* o = (Oracle*)h; o->evlog = on ? 1 : 0; for (int i = 0; i < o->n; ++i) { o->cold[i].evlog.enabled = on ? 1u : 0u; o->cold[i].evlog.n = 0; } }
