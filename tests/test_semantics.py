@@ -278,3 +278,51 @@ def test_monitor_sees_events_on_the_server_host_and_on_client_hosts(oracle_lib):
             return (s_ - 11) if s_ >= 11 else 6 + (s_ - 1)                  # servers first, then users (BlueFlatWrapper order)
         assert blk[43 + slot(parent)] == 1 and blk[27 + slot(other)] == 1   # connection flag / process flag
         assert blk[27:59].sum() == 2
+
+
+def test_counter_mode_scenario_generation_properties():
+    """The per-host-phase generation of the counter-based mode (csrc/cc4_engine.h env_reset_counter_mode) keeps what
+    EnterpriseScenarioGenerator guarantees: 3..10 user hosts and 1..6 servers per subnet, distinct addresses inside a subnet,
+    network-wide unique service pids (_generate_pid, ESG.py:564-578), session pids above every service pid of their host
+    (Host.create_pid, Host.py:198-200), and the same service statistics as the numpy-stream mode."""
+    import json
+    from oracle_binding import OracleVecEnv
+    n = 192
+    stats = {}
+    for mode in (1, 0):
+        o = OracleVecEnv(n, steps=100, rng_mode=mode)
+        o.reset(seeds=4242)
+        nsvc, nhosts, contested = [], [], 0
+        for i in range(n):
+            d = json.loads(o.true_state_json(i))
+            hosts = d['hosts']
+            by_subnet = {}
+            pids = []
+            for hd in hosts:
+                h = hd['h']
+                by_subnet.setdefault(h // 17, []).append(hd)
+                svc_pids = [s[3] for s in hd['svcs']]
+                pids += svc_pids
+                assert all(1000 <= p < 10000 for p in svc_pids)
+                for sess in ('blue', 'green'):
+                    if hd.get(sess):
+                        assert not svc_pids or hd[sess] > max(svc_pids)
+                if h % 17 != 0:
+                    nsvc.append(len(svc_pids))
+            assert len(pids) == len(set(pids)), 'service pids are unique across the whole network'
+            for sn, hs in by_subnet.items():
+                if sn == 8:
+                    assert [x['h'] for x in hs] == [136]
+                    continue
+                slots = [x['h'] % 17 for x in hs]
+                users = [s for s in slots if 1 <= s <= 10]
+                servers = [s for s in slots if s >= 11]
+                assert 0 in slots and 3 <= len(users) <= 10 and 1 <= len(servers) <= 6
+                assert users == list(range(1, 1 + len(users))) and servers == list(range(11, 11 + len(servers)))
+                ips = [x['ip'] for x in hs]
+                assert len(set(ips)) == len(ips) and all(1 <= ip <= 254 for ip in ips)
+            assert len(set(d['cidr'])) == 9
+            nhosts.append(len(hosts))
+        stats[mode] = (np.mean(nsvc), np.mean(nhosts))
+    # SSHD + Binomial-like add-ons (0..3 uniformly) + OT service in the two operational zones: the two modes agree closely
+    assert abs(stats[0][0] - stats[1][0]) < 0.06 and abs(stats[0][1] - stats[1][1]) < 2.5, stats
