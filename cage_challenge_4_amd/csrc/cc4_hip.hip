@@ -1,11 +1,12 @@
 // cc4_hip.hip -- gfx950 kernels + the C ABI (include/cc4.h) of libcc4.so.
 //
-// Execution model (round 1): one 64-lane wavefront per episode.  The wave stages the episode's packed
-// EnvState row (34.6 KB) HBM -> LDS with coalesced 16-byte loads, lane 0 walks the strictly ordered
+// Execution model of the numpy-stream kernel (k_step): one 64-lane wavefront per episode.  The wave stages the episode's packed
+// EnvState row (28.4 KB) HBM -> LDS with coalesced 16-byte loads, lane 0 walks the strictly ordered
 // transition (the reference's ~57 agent actions share one RNG stream, so the order is the semantics),
 // the wave encodes the 578 flat-observation values, and the row goes back LDS -> HBM coalesced.
-// The cold part of the episode (ephemeral-port bitmaps, per-session port knowledge; 205 KB) stays in HBM
-// and is touched a handful of times per step.  No MFMA: the path is integer / indexing.
+// The cold part of the episode (ephemeral-port bitmaps, per-session port knowledge; 249 KB) stays in HBM
+// and is touched a handful of times per step.  The counter-mode kernel (k_step_philox, below) runs four wavefronts per episode.
+// No MFMA: the path is integer / indexing.
 #include <hip/hip_runtime.h>
 #include <hip/hip_ext.h>
 #include <rccl/rccl.h>
