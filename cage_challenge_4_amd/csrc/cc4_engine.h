@@ -2036,7 +2036,12 @@ CC4_HD void step_rsc(Ctx x, int r) {
   rng_set_stream(x.r, ST_RED_RSC + (uint32_t)r);
   red_session_check(x, r);
 }
-CC4_HD void step_end(Ctx x, const uint8_t* messages) {
+// the messages submitted with this step, agent b's row (read back by the observation encode of the same step only, so the
+// lane-parallel kernel stores them when the actions are submitted and step_end skips the copy)
+CC4_HD void step_messages(EnvState* s, const uint8_t* messages, int b) {
+  for (int i = 0; i < MSG_LEN; ++i) s->msg[b][i] = (uint8_t)((messages && messages[b * MSG_LEN + i]) ? 1 : 0);
+}
+CC4_HD void step_end(Ctx x, const uint8_t* messages, bool copy_msgs = true) {
   EnvState* s = x.s;
   s->step_count++;
   s->done = (uint8_t)(s->step_count >= s->steps - 1);
@@ -2048,8 +2053,7 @@ CC4_HD void step_end(Ctx x, const uint8_t* messages) {
       brm += reward_table(s->phase, h_subnet(s->red[r].exec_host), RW_RIA);  // charged for any executed Impact (App. B.2)
   s->action_cost = -(float)s->n_restore;
   s->reward = (float)brm + s->action_cost;
-  if (messages) for (int b = 0; b < NBLUE; ++b) for (int i = 0; i < MSG_LEN; ++i) s->msg[b][i] = messages[b * MSG_LEN + i] ? 1 : 0;
-  else for (int b = 0; b < NBLUE; ++b) for (int i = 0; i < MSG_LEN; ++i) s->msg[b][i] = 0;
+  if (copy_msgs) for (int b = 0; b < NBLUE; ++b) step_messages(s, messages, b);
   rng_park(&s->rng);
 }
 

@@ -265,7 +265,8 @@ __global__ __launch_bounds__(PT) void k_step_philox(StepArgs a) {
     __syncthreads();
     if (tid < MAXH) reset_host_sessions(xh, tid);
     __syncthreads();
-    if (tid == 0) reset_finish(xm, carry, a.steps, a.topo, true);
+    if (tid == 0) { reset_finish(xm, carry, a.steps, a.topo, true); a.reward[e] = s->reward; a.done[e] = s->done; }
+    __syncthreads();
   } else {
     if (tid == 0) {
       Ctx x{s, a.cold + e, &s->rng, prof};
@@ -306,6 +307,7 @@ __global__ __launch_bounds__(PT) void k_step_philox(StepArgs a) {
         if (a.rand_out) { act = random_blue_action(a.rand_seed0, a.rand_t, e, b); a.rand_out[e * NBLUE + b] = act; }
         step_blue_submit(x0, b, act);
         (void)step_tick_agent(x0, b);
+        step_messages(s, a.msgs ? a.msgs + e * NBLUE * MSG_LEN : nullptr, b);   // read back by this step's observation encode only
       }
       else if (lane >= 8 && wave >= 2) {
         for (int g = (wave - 2) * (WAVE - 8) + (lane - 8); g < ng; g += (PW - 2) * (WAVE - 8)) {
@@ -358,25 +360,29 @@ __global__ __launch_bounds__(PT) void k_step_philox(StepArgs a) {
         if (tid == 0) for (int r = 0; r < NRED; ++r) if ((serial_red >> r) & 1u) step_red_exec_agent(x0, r);
         __syncthreads();
       }
-      // ---- pid-event merge and reassignment on thread 0 (the foreign-session test is 5 words per agent)
+      // ---- pid-event merge and reassignment on thread 0 (the foreign-session test is 5 words per agent); meanwhile P7, the
+      // per-host roll-over of the end-turn Monitor, on all threads (host event flags: nothing the reassignment touches)
       if (tid == 0) {
         step_red_merge(x0);
         CC4_TICK(x0, 7);
         step_reassign(x0, red_any_foreign_session(s));
       }
-      __syncthreads();
-      // ---- P7 end-turn Monitor (per-host roll-over on all threads, sus-pid hand-over on thread 0) and P8 end-turn
-      // RedSessionCheck (one red agent per wave) touch disjoint data (host event flags / blue lists vs red agent tables)
       for (int h = tid; h < MAXH; h += PT) step_monitor_host(x0, h);
-      if (tid == 0) { step_monitor_pend(x0); CC4_TICK(x0, 9); }
-      if (is_red) { unsigned long long t0 = ap ? clock64() : 0; step_rsc(xr, ragent); if (ap) ap[2] += clock64() - t0; }
       __syncthreads();
+      CC4_TICK(x0, 9);
+      // ---- P8 end-turn RedSessionCheck (one red agent per wave), and on the last thread the Monitor's sus-pid hand-over and
+      // the step's bookkeeping: disjoint data (red agent tables / blue lists, counters, reward).  The observation encode below
+      // reads none of it, so there is no barrier in between.
+      if (is_red) { unsigned long long t0 = ap ? clock64() : 0; step_rsc(xr, ragent); if (ap) ap[2] += clock64() - t0; }
+      if (tid == PT - 1) {
+        Ctx xe{s, a.cold + e, &rl, nullptr, nullptr, lg};
+        step_monitor_pend(xe);
+        step_end(xe, nullptr, false);
+        a.reward[e] = s->reward; a.done[e] = s->done;
+      }
       CC4_TICK(x0, 10);
-      if (tid == 0) step_end(x0, a.msgs ? a.msgs + e * NBLUE * MSG_LEN : nullptr);
-    } else dma_wait();
+    } else { dma_wait(); if (tid == 0) { a.reward[e] = s->reward; a.done[e] = s->done; } }
   }
-  __syncthreads();
-  if (tid == 0) { a.reward[e] = s->reward; a.done[e] = s->done; a.err[e] = s->err; }
   unsigned long long t_obs = a.prof ? clock64() : 0;
   // flat observations: one value per thread straight to HBM (int32 for the host API, bytes for the all-gather)
   {
@@ -384,6 +390,8 @@ __global__ __launch_bounds__(PT) void k_step_philox(StepArgs a) {
     uint8_t* o8 = a.obs8 ? a.obs8 + (size_t)e * OBS_TOTAL : nullptr;
     for (int v = tid; v < OBS_TOTAL; v += PT) { int i; int val = env_flat_obs_sorted(s, v, &i); o[i] = val; if (o8) o8[i] = (uint8_t)val; }   // kind-sorted enumeration: uniform branches per wave
   }
+  __syncthreads();    // the row is final: RedSessionCheck and the step bookkeeping ran beside the encode
+  if (tid == 0) a.err[e] = s->err;
   unsigned long long t_out = a.prof ? clock64() : 0;
   if (prof && tid == 0) prof[12] += t_out - t_obs;
   uint4* dst = reinterpret_cast<uint4*>(a.st + e);
