@@ -683,6 +683,7 @@ CC4_HD void reset_finish(Ctx x, ResetCarry k, int steps, uint32_t topo_seed, boo
     a.exec_type = RA_SLEEP;
   }
   s->done = (uint8_t)(0 >= steps - 1);
+  s->n_actions = NBLUE + s->n_green + NRED;
   if (topo_seed) x.r->s_lo = k.env_key;
   if (rng_is_copy) s->rng = *x.r;
   rng_park(&s->rng);
@@ -865,6 +866,7 @@ CC4_HD void env_reset(Ctx x, uint64_t seed, int rng_mode, int steps, bool contin
     a.exec_type = RA_SLEEP;
   }
   s->step_count = 0; s->phase = 0; s->done = (uint8_t)(0 >= steps - 1); s->reward = 0.f;
+  s->n_actions = NBLUE + s->n_green + NRED;
   if (topo_seed && rng_mode == 1) x.r->s_lo = env_key;
   if (rng_is_copy) s->rng = *x.r;      // the generator was walked on a caller-side (register) copy
   rng_park(&s->rng);
@@ -1834,18 +1836,30 @@ CC4_HD void red_reassign(Ctx x) {
 // PhishingEmail (new red session), is deferred and replayed in agent order (P5).
 
 // returns false when the episode is stepped past its end (State.py:539-540 raises ValueError)
-CC4_HD bool step_phase(Ctx x) {
+// State.check_next_phase_on_update_step (State.py:514-544): the mission phase of step `st`, or -1 past the last phase
+CC4_HD int step_phase_of(int st, int len0, int len1, int len2) {
+  if (st < len0) return 0;
+  if (st < len0 + len1) return 1;
+  if (st < len0 + len1 + len2) return 2;
+  return -1;
+}
+// The accumulators of a step (brm, n_restore, n_actions) are also left initialised by step_end / the reset, so the
+// lane-parallel kernel may add to them before its thread 0 has finished this function's writes.
+CC4_HD bool step_phase(Ctx x, bool init_accumulators = true) {
   EnvState* s = x.s;
-  {  // State.check_next_phase_on_update_step (State.py:514-544)
-    int st = s->step_count, ph = -1, mn = 0, mx = 0;
-    for (int p = 0; p < 3; ++p) { mn = mx; mx = mn + s->phase_len[p]; if (st >= mn && st < mx) { ph = p; break; } }
+  {
+    const int st = s->step_count;
+    const int ph = step_phase_of(st, s->phase_len[0], s->phase_len[1], s->phase_len[2]);
     if (ph < 0) { set_err(x, E_STEP_PAST_END); return false; }
     if (ph > s->phase) s->phase = ph;
   }
   rng_begin_step(&s->rng, (uint32_t)s->step_count);
   if (x.lg) { x.lg->n = 0; x.lg->step = (uint32_t)s->step_count; }
-  s->action_cost = 0.f; s->brm = 0; s->n_restore = 0;
-  s->n_actions = NBLUE + s->n_green + NRED;   // minus the actions filter_actions drops (step_tick_agent)
+  s->action_cost = 0.f;
+  if (init_accumulators) {
+    s->brm = 0; s->n_restore = 0;
+    s->n_actions = NBLUE + s->n_green + NRED;   // minus the actions filter_actions drops (step_tick_agent)
+  }
   return true;
 }
 // one blue agent's submitted action: decode, cost, queue (SC:236-248); independent across agents
@@ -2054,6 +2068,7 @@ CC4_HD void step_end(Ctx x, const uint8_t* messages, bool copy_msgs = true) {
   s->action_cost = -(float)s->n_restore;
   s->reward = (float)brm + s->action_cost;
   if (copy_msgs) for (int b = 0; b < NBLUE; ++b) step_messages(s, messages, b);
+  s->brm = 0; s->n_restore = 0; s->n_actions = NBLUE + s->n_green + NRED;   // the next step's accumulators (see step_phase)
   rng_park(&s->rng);
 }
 

@@ -216,7 +216,7 @@ __device__ __forceinline__ void dma_wait() { asm volatile("s_waitcnt vmcnt(0)" :
 template <bool LOG>
 __global__ __launch_bounds__(PT) void k_step_philox(StepArgs a) {
   extern __shared__ uint4 lds[];
-  __shared__ int ok_lds, conflict_lds;
+  __shared__ int conflict_lds;
   __shared__ uint32_t reset_ws[RESET_WS_WORDS];   // pid bitmaps of the scenario generation (autoreset)
   __shared__ int glist_n[2];
   __shared__ uint8_t glist[2][MAXG];  // green agents by action type (0 AccessService, 1 LocalWork)
@@ -238,7 +238,7 @@ __global__ __launch_bounds__(PT) void k_step_philox(StepArgs a) {
   for (int c = wave; c < HD_CHUNKS; c += PW) dma_chunk(src + HD_V0 + 64 * c + lane, lds + HD_V0 + 64 * c);
   unsigned long long* prof = a.prof ? prof_lds : nullptr;
   if (prof && tid < 16) prof_lds[tid] = 0;
-  if (tid == 0) { glist_n[0] = 0; glist_n[1] = 0; conflict_lds = 0; ok_lds = 0; }
+  if (tid == 0) { glist_n[0] = 0; glist_n[1] = 0; conflict_lds = 0; }
   __syncthreads();
   EnvState* s = reinterpret_cast<EnvState*>(lds);
   if (prof && tid == 0) prof[11] += clock64() - t_begin;
@@ -268,22 +268,27 @@ __global__ __launch_bounds__(PT) void k_step_philox(StepArgs a) {
     if (tid == 0) { reset_finish(xm, carry, a.steps, a.topo, true); a.reward[e] = s->reward; a.done[e] = s->done; }
     __syncthreads();
   } else {
+    // the mission phase of this step, evaluated by every thread (four words of the row); thread 0 alone stores what
+    // step_phase stores -- nothing the policy phase reads, and the step's accumulators were left initialised by step_end --
+    // so no barrier follows
+    const int st_now = s->step_count;
+    const bool step_ok = step_phase_of(st_now, s->phase_len[0], s->phase_len[1], s->phase_len[2]) >= 0;
     if (tid == 0) {
       Ctx x{s, a.cold + e, &s->rng, prof};
       x.lg = LOG ? &a.cold[e].evlog : nullptr;
       CC4_TICK0(x);
-      ok_lds = step_phase(x) ? 1 : 0;
+      (void)step_phase(x, false);
     }
-    __syncthreads();
-    if (ok_lds) {
+    if (step_ok) {
       Ctx x0p{s, a.cold + e, nullptr, tid == 0 ? prof : nullptr};
       const int ng = s->n_green;
       // one thread-private generator per thread, in registers: every use starts with rng_set_stream(), which fully
       // determines the stream from (key, step, episode, stream id); mode pinned so the PCG paths fold away
-      if (tid == 0) CC4_TICK(x0p, 0);   // slot 0: step_phase + first barrier
+      if (tid == 0) CC4_TICK(x0p, 0);   // slot 0: step_phase
       Rng rl;
       rng_fork(&rl, &s->rng, ST_RESET);
       rl.mode = 1;
+      rng_begin_step(&rl, (uint32_t)st_now);   // not read from the row: thread 0 may still be storing it there
       EvLog* const lg = LOG ? &a.cold[e].evlog : nullptr;
       Ctx x0{s, a.cold + e, &rl, tid == 0 ? prof : nullptr};                     // thread 0
       x0.lg = lg;
