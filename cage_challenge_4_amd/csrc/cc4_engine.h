@@ -1403,10 +1403,31 @@ CC4_HD void red_session_check(Ctx x, int r) {
   // exact set of hosts in the listing): ActionSpace knowledge here, FSM knowledge in fsm_observe (rsc_listed).
   A.rsc_listed = 1;
   if (!A.rsc_dirty) return;      // same session table as at the last listing: nothing new to learn
-  for (int w = 0; w < 5; ++w) { A.as_ip[w] |= A.live_hosts[w]; A.as_hn[w] |= A.live_hosts[w]; }
-  for (int i = 0; i < A.nsess; ++i) {
-    A.as_subnet |= (uint16_t)(1u << h_subnet(A.sess[i].host));
-    if (A.sess[i].flags & RS_ABSTRACT) as_know_sid(x, r, A.sess[i].id);
+  const B5 live = b5_load(A.live_hosts);
+  { const B5 ip = b5_load(A.as_ip), hn = b5_load(A.as_hn); b5_store(A.as_ip, b5_or(ip, live)); b5_store(A.as_hn, b5_or(hn, live)); }
+  {  // the subnets of the session hosts = the subnets with a live host (ids 17 sn .. 17 sn + 16)
+    uint32_t sub = 0;
+    CC4_UNROLL for (int sn = 0; sn < NSUB; ++sn) {
+      const int lo = sn * SLOTS, w = lo >> 5, off = lo & 31;
+      uint32_t bits = live.w[w] >> off;
+      if (off > 32 - SLOTS && w + 1 < 5) bits |= live.w[w + 1] << (32 - off);
+      if (bits & ((1u << SLOTS) - 1u)) sub |= 1u << sn;
+    }
+    A.as_subnet |= (uint16_t)sub;
+  }
+  // session ids new to the ActionSpace, in session order: eight records and their eight known-id words per round, so the
+  // common case (everything known) costs two LDS round trips per eight sessions
+  const int n = A.nsess;
+  for (int i0 = 0; i0 < n; i0 += 8) {
+    const S8 q = rs_load8(A, i0);
+    uint32_t kw[8];
+    CC4_UNROLL for (int k = 0; k < 8; ++k) kw[k] = A.known_bm[(rsw_id(q.v[k]) >> 5) & 7];
+    CC4_UNROLL for (int k = 0; k < 8; ++k) {
+      if (i0 + k >= n || !(rsw_flags(q.v[k]) & RS_ABSTRACT)) continue;
+      const int id = rsw_id(q.v[k]);
+      if (id < 256 && ((kw[k] >> (id & 31)) & 1u)) continue;
+      as_know_sid(x, r, id);   // rare; two new records of one round never share an id, so the words read above stay valid
+    }
   }
   A.rsc_dirty = 0;
 }
