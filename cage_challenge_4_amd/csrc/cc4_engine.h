@@ -341,6 +341,34 @@ CC4_HD void rs_remove_at(Ctx x, int r, int idx, bool free_kb) {
     if (!other) bit_clr_shared(x.s->red_hosts, gone);
   }
 }
+// Every non-original session of agent r on host h, in one compaction pass (== rs_remove_at on each of them in table order:
+// the survivors keep their order).  RestoreFromBackup.
+CC4_HD void rs_remove_on_host(Ctx x, int r, int h) {
+  RedAgent& a = x.s->red[r];
+  const int n = a.nsess;
+  int out = 0, removed = 0;
+  bool left = false;
+  for (int i0 = 0; i0 < n; i0 += 8) {
+    const S8 q = rs_load8(a, i0);      // the round is in registers before any of its slots is overwritten (out <= i0 + k)
+    CC4_UNROLL for (int k = 0; k < 8; ++k) {
+      if (i0 + k >= n) continue;
+      const bool here = rsw_host(q.v[k]) == h;
+      if (here && !(rsw_flags(q.v[k]) & RS_ORIG)) { kb_free(x, r, (int)((q.v[k] >> 48) & 0xFF)); removed++; continue; }
+      if (here) left = true;
+      if (out != i0 + k) __builtin_memcpy(&a.sess[out], &q.v[k], 8);
+      out++;
+    }
+  }
+  if (!removed) return;
+  a.nsess = (uint8_t)out;
+  a.rsc_dirty = 1;
+  if (!left) {
+    bit_clr(a.live_hosts, h); a.nlive--;
+    bool other = false;
+    for (int q = 0; q < NRED; ++q) if (bit_get(x.s->red[q].live_hosts, h)) { other = true; break; }
+    if (!other) bit_clr_shared(x.s->red_hosts, h);
+  }
+}
 // dict pop + re-insert of the same session object (RedSessionCheck promotion, RestoreFromBackup of an original session):
 // the record moves to the end of the agent's order; which hosts hold sessions does not change
 CC4_HD void rs_move_to_end(RedAgent& a, int idx, int new_id) {
@@ -975,7 +1003,7 @@ CC4_HD void stop_process(Ctx x, int h, int pid) {
 CC4_HD void blue_remove(Ctx x, int b, int h) {
   BlueAgent& A = x.s->blue[b];
   if (!bit_get(A.sus_hosts, h)) return;   // parent_session.sus_pids has no entry for this hostname
-  // The list lives in the cold row (HBM).  It is filtered with 8 independent loads in flight per round into a small LDS
+  // The list lives in the cold row (HBM).  It is filtered with 16 independent loads in flight per round into a small LDS
   // work area (12 words per blue agent), then the matching pids are stopped in list order.
   const uint32_t* list = x.c->sus[b];
   uint16_t* hit = reinterpret_cast<uint16_t*>(x.s->scratch + 12 * b);
@@ -983,17 +1011,10 @@ CC4_HD void blue_remove(Ctx x, int b, int h) {
   int i0 = 0;
   while (i0 < n) {
     int nh = 0;
-    for (; i0 < n && nh + 8 <= cap; i0 += 8) {   // MAX_SUS is a multiple of 8: the tail of a round reads allocated slots
-      uint32_t v0 = list[i0], v1 = list[i0 + 1], v2 = list[i0 + 2], v3 = list[i0 + 3];
-      uint32_t v4 = list[i0 + 4], v5 = list[i0 + 5], v6 = list[i0 + 6], v7 = list[i0 + 7];
-      if (i0 + 0 < n && (int)(v0 >> 16) == h) hit[nh++] = (uint16_t)v0;
-      if (i0 + 1 < n && (int)(v1 >> 16) == h) hit[nh++] = (uint16_t)v1;
-      if (i0 + 2 < n && (int)(v2 >> 16) == h) hit[nh++] = (uint16_t)v2;
-      if (i0 + 3 < n && (int)(v3 >> 16) == h) hit[nh++] = (uint16_t)v3;
-      if (i0 + 4 < n && (int)(v4 >> 16) == h) hit[nh++] = (uint16_t)v4;
-      if (i0 + 5 < n && (int)(v5 >> 16) == h) hit[nh++] = (uint16_t)v5;
-      if (i0 + 6 < n && (int)(v6 >> 16) == h) hit[nh++] = (uint16_t)v6;
-      if (i0 + 7 < n && (int)(v7 >> 16) == h) hit[nh++] = (uint16_t)v7;
+    for (; i0 < n && nh + 16 <= cap; i0 += 16) {   // MAX_SUS is a multiple of 16: the tail of a round reads allocated slots
+      uint32_t v[16];                              // 16 independent loads in flight: one HBM round trip per 16 entries
+      CC4_UNROLL for (int k = 0; k < 16; ++k) v[k] = list[i0 + k];
+      CC4_UNROLL for (int k = 0; k < 16; ++k) if (i0 + k < n && (int)(v[k] >> 16) == h) hit[nh++] = (uint16_t)v[k];
     }
     for (int k = 0; k < nh; ++k) stop_process(x, h, (int)hit[k]);
   }
@@ -1006,17 +1027,8 @@ CC4_HD void blue_restore(Ctx x, int h) {
   CC4_UNROLL for (int r = 0; r < NRED; ++r) {
     if (!((lw[r] >> (h & 31)) & 1u)) continue;
     RedAgent& a = s->red[r];
-    // every non-original session on the host goes, in table order; an original one is popped and re-added => moves to the end
-    for (;;) {
-      const int n = a.nsess;
-      int victim = -1;
-      for (int i0 = 0; i0 < n && victim < 0; i0 += 8) {
-        const S8 q = rs_load8(a, i0);
-        CC4_UNROLL for (int k = 7; k >= 0; --k) if (i0 + k < n && rsw_host(q.v[k]) == h && !(rsw_flags(q.v[k]) & RS_ORIG)) victim = i0 + k;
-      }
-      if (victim < 0) break;
-      rs_remove_at(x, r, victim, true);
-    }
+    // every non-original session on the host goes; an original one is popped and re-added => moves to the end
+    rs_remove_on_host(x, r, h);
     {
       const int n = a.nsess;
       int orig = -1;
