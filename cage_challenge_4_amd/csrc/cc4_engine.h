@@ -1194,11 +1194,32 @@ CC4_HD void red_drs(Ctx x, int r, const Act& a) {
   // the session can die between filter_actions and execution (a blue Remove/Restore runs earlier in the same step)
   if (rs_find_id(s->red[r], a.sid) < 0) { red_result(x, r, a, T_FALSE); return; }
   bool allowed = (red_allowed_mask(r) >> sn) & 1u;  // SimulationController._filter_obs drops foreign-subnet interfaces
-  for (int sl = 1; sl < SLOTS; ++sl) {
-    int h = h_make(sn, sl);
-    if (!bit_get(s->exists, h)) continue;
-    any = true;
-    if (allowed) obs_put(x, r, true, h, OE_IFACE, true);
+  // the subnet's non-router hosts are the 16 ids lo .. lo+15; they straddle at most two bitmap words.  All of them get the same
+  // observation entry (obs_put(ip key, OE_IFACE, subnet known)), so the bitmaps are updated per word and the new entries
+  // are appended with independent stores, in host order
+  RedAgent& A = s->red[r];
+  const int lo = sn * SLOTS + 1, w0 = lo >> 5, off = lo & 31, w1 = (w0 + 1 < 5) ? w0 + 1 : w0;
+  const uint32_t e0 = s->exists[w0], e1 = s->exists[w1], h0 = A.obs_has[1][w0], h1 = A.obs_has[1][w1];
+  auto field = [&](uint32_t a0, uint32_t a1) { uint32_t v = a0 >> off; if (off > 16 && w1 != w0) v |= a1 << (32 - off); return v & 0xFFFFu; };
+  const uint32_t ex = field(e0, e1);
+  any = ex != 0;
+  if (allowed && ex) {
+    const uint32_t had = field(h0, h1) & ex;
+    uint32_t fresh = ex & ~had;
+    const uint32_t m0 = ex << off, m1 = (off > 16 && w1 != w0) ? ex >> (32 - off) : 0u;
+    A.as_ip[w0] |= m0; A.obs_has[1][w0] = h0 | m0;
+    if (m1) { A.as_ip[w1] |= m1; A.obs_has[1][w1] = h1 | m1; }
+    A.as_subnet |= (uint16_t)(1u << sn);
+    int n = A.nobs;
+    while (fresh) {
+      const int b = ctz32(fresh); fresh &= fresh - 1;
+      if (n >= MAX_OBS) { set_err(x, E_OBS_OVERFLOW); break; }
+      A.obs[n].host = (uint8_t)(lo + b); A.obs[n].flags = (uint8_t)(OE_IFACE | OE_KEY_IP);
+      n++;
+    }
+    A.nobs = (uint8_t)n;
+    uint32_t again = had;   // already keyed this step (does not happen on the FSM path: the list is empty when an action starts)
+    while (again) { const int b = ctz32(again); again &= again - 1; obs_put(x, r, true, lo + b, OE_IFACE, true); }
   }
   red_result(x, r, a, any ? T_TRUE : T_UNKNOWN);
 }
