@@ -336,9 +336,11 @@ CC4_HD void rs_remove_at(Ctx x, int r, int idx, bool free_kb) {
   a.rsc_dirty = 1;
   if (rs_on_host(a, gone).n == 0) {
     bit_clr(a.live_hosts, gone); a.nlive--;
-    bool other = false;
-    for (int q = 0; q < NRED; ++q) if (bit_get(x.s->red[q].live_hosts, gone)) { other = true; break; }
-    if (!other) bit_clr_shared(x.s->red_hosts, gone);
+    uint32_t lw[NRED];   // the six agents' words for that host in one batch of loads (this agent's bit is already clear)
+    CC4_UNROLL for (int q = 0; q < NRED; ++q) lw[q] = x.s->red[q].live_hosts[gone >> 5];
+    uint32_t any_other = 0;
+    CC4_UNROLL for (int q = 0; q < NRED; ++q) any_other |= lw[q];
+    if (!((any_other >> (gone & 31)) & 1u)) bit_clr_shared(x.s->red_hosts, gone);
   }
 }
 // Every non-original session of agent r on host h, in one compaction pass (== rs_remove_at on each of them in table order:
@@ -364,9 +366,11 @@ CC4_HD void rs_remove_on_host(Ctx x, int r, int h) {
   a.rsc_dirty = 1;
   if (!left) {
     bit_clr(a.live_hosts, h); a.nlive--;
-    bool other = false;
-    for (int q = 0; q < NRED; ++q) if (bit_get(x.s->red[q].live_hosts, h)) { other = true; break; }
-    if (!other) bit_clr_shared(x.s->red_hosts, h);
+    uint32_t lw[NRED];
+    CC4_UNROLL for (int q = 0; q < NRED; ++q) lw[q] = x.s->red[q].live_hosts[h >> 5];
+    uint32_t any_other = 0;
+    CC4_UNROLL for (int q = 0; q < NRED; ++q) any_other |= lw[q];
+    if (!((any_other >> (h & 31)) & 1u)) bit_clr_shared(x.s->red_hosts, h);
   }
 }
 // dict pop + re-insert of the same session object (RedSessionCheck promotion, RestoreFromBackup of an original session):
@@ -1822,18 +1826,12 @@ CC4_HD uint32_t red_zone_hosts(int r, int w) {
   }
   return m;
 }
-CC4_HD void red_reassign(Ctx x) {
+CC4_HD void red_reassign(Ctx x, uint32_t foreign) {   // foreign: red_foreign_agents(s), != 0
   EnvState* s = x.s;
   // moves are collected first (the reference builds the list, then applies it), one packed word each in the shared work
-  // area: from | to << 3 | host << 8 | session id << 16
+  // area: from | to << 3 | session index << 8 | session id << 16
   uint32_t* mv = s->scratch; int nm = 0;
   const int cap = (int)(sizeof(s->scratch) / 4);
-  uint32_t foreign = 0;   // agents holding a session outside their zone: all 30 bitmap words in one batch of loads
-  CC4_UNROLL for (int r = 0; r < NRED; ++r) {
-    uint32_t acc = 0;
-    CC4_UNROLL for (int w = 0; w < 5; ++w) acc |= s->red[r].live_hosts[w] & ~red_zone_hosts(r, w);
-    if (acc) foreign |= 1u << r;
-  }
   for (int r = 0; r < NRED; ++r) {
     if (!((foreign >> r) & 1u)) continue;
     const RedAgent& A = s->red[r];
@@ -1847,17 +1845,27 @@ CC4_HD void red_reassign(Ctx x) {
         if ((red_allowed_mask(r) >> sn) & 1u) continue;
         const int to = red_of_subnet(sn);
         if (to < 0) { set_err(x, E_UNREACHABLE); continue; }
-        if (nm < cap) mv[nm++] = (uint32_t)r | ((uint32_t)to << 3) | ((uint32_t)host << 8) | ((uint32_t)rsw_id(q.v[k]) << 16);
+        if (nm < cap) mv[nm++] = (uint32_t)r | ((uint32_t)to << 3) | ((uint32_t)(i0 + k) << 8) | ((uint32_t)rsw_id(q.v[k]) << 16);
         else set_err(x, E_RSESS_OVERFLOW);
       }
     }
   }
+  // A source agent's moves come in table order, and sessions gained on the way are appended behind: the record sits at its
+  // collection index minus the number of this agent's earlier removals (checked against the id; the scan is the fallback)
+  int gone_from[NRED];
+  CC4_UNROLL for (int r = 0; r < NRED; ++r) gone_from[r] = 0;
   for (int m = 0; m < nm; ++m) {
-    const int from = (int)(mv[m] & 7u), to = (int)((mv[m] >> 3) & 7u), id = (int)(mv[m] >> 16);
+    const uint32_t w = mv[m];
+    const int from = (int)(w & 7u), to = (int)((w >> 3) & 7u), id = (int)(w >> 16);
     RedAgent& F = s->red[from];
-    int i = rs_find_id(F, id);
-    if (i < 0) continue;
-    const int old_host = F.sess[i].host, old_pid = F.sess[i].pid, old_flags = F.sess[i].flags, old_id = F.sess[i].id;
+    int shift = 0;
+    CC4_UNROLL for (int r = 0; r < NRED; ++r) if (r == from) shift = gone_from[r];
+    int i = (int)((w >> 8) & 0xFFu) - shift;
+    uint64_t rec;
+    __builtin_memcpy(&rec, &F.sess[i < 0 ? 0 : i], 8);
+    if (i < 0 || i >= F.nsess || rsw_id(rec) != id) { i = rs_find_id(F, id); if (i < 0) continue; __builtin_memcpy(&rec, &F.sess[i], 8); }
+    CC4_UNROLL for (int r = 0; r < NRED; ++r) if (r == from) gone_from[r]++;
+    const int old_host = rsw_host(rec), old_pid = rsw_pid(rec), old_flags = rsw_flags(rec), old_id = id;
     rs_remove_at(x, from, i, true);
     int ni = rs_add(x, to, old_host, old_pid, RS_ABSTRACT | (old_flags & RS_ROOT));
     if (ni < 0) continue;
@@ -1868,7 +1876,9 @@ CC4_HD void red_reassign(Ctx x) {
       as_know_sid(x, to, s->red[to].sess[ni].id);
     }
   }
-  for (int r = 0; r < NRED; ++r) s->red[r].active = (uint8_t)(s->red[r].nsess > 0);
+  int ns[NRED];
+  CC4_UNROLL for (int r = 0; r < NRED; ++r) ns[r] = s->red[r].nsess;
+  CC4_UNROLL for (int r = 0; r < NRED; ++r) s->red[r].active = (uint8_t)(ns[r] > 0);
 }
 
 // ------------------------------------------------------------------ the step (SimulationController.step, SC:211-315)
@@ -2037,13 +2047,16 @@ CC4_HD void step_phishing(Ctx x) {
 // true if some red agent holds a session outside its allowed subnets (work for different_subnet_agent_reassignment): live_hosts
 // against the host-id ranges of each agent's subnets (subnet sn = ids sn*17 .. sn*17+16); all six agents at once:
 // 30 independent loads, masks folded to constants by the unrolling
-CC4_HD bool red_any_foreign_session(const EnvState* s) {
-  uint32_t acc = 0;
+CC4_HD uint32_t red_foreign_agents(const EnvState* s) {   // bit r: agent r holds a session outside its zone
+  uint32_t foreign = 0;
   CC4_UNROLL for (int r = 0; r < NRED; ++r) {
+    uint32_t acc = 0;
     CC4_UNROLL for (int w = 0; w < 5; ++w) acc |= s->red[r].live_hosts[w] & ~red_zone_hosts(r, w);
+    if (acc) foreign |= 1u << r;
   }
-  return acc != 0;
+  return foreign;
 }
+CC4_HD bool red_any_foreign_session(const EnvState* s) { return red_foreign_agents(s) != 0; }
 CC4_HD void step_red_exec_agent(Ctx x, int r) {
   EnvState* s = x.s;
   if (s->rexec[r].type == RA_NONE) return;
@@ -2071,9 +2084,9 @@ CC4_HD void step_red_exec(Ctx x) {
   CC4_TICK(x, 7);
 }
 // different_subnet_agent_reassignment (SC:820-903): `any_foreign` = some red agent holds a session outside its zone
-CC4_HD void step_reassign(Ctx x, bool any_foreign) {
+CC4_HD void step_reassign(Ctx x, uint32_t foreign) {   // foreign = red_foreign_agents(s)
   EnvState* s = x.s;
-  if (any_foreign) red_reassign(x);
+  if (foreign) red_reassign(x, foreign);
   else {
     int ns[NRED];
     CC4_UNROLL for (int r = 0; r < NRED; ++r) ns[r] = s->red[r].nsess;
@@ -2144,7 +2157,7 @@ CC4_HD void env_step(Ctx x, const int32_t* actions, const uint8_t* messages /* [
   CC4_TICK(x, 6);
   step_red_exec(x);
   {
-    step_reassign(x, red_any_foreign_session(s));
+    step_reassign(x, red_foreign_agents(s));
   }
   for (int h = 0; h < MAXH; ++h) step_monitor_host(x, h);
   step_monitor_pend(x);

@@ -133,7 +133,7 @@ __global__ __launch_bounds__(WAVE) void k_step(StepArgs a) {
         }
         CC4_TICK(x, 6);
         step_red_exec(x);
-        step_reassign(x, red_any_foreign_session(s));
+        step_reassign(x, red_foreign_agents(s));
       }
     }
   }
@@ -370,7 +370,7 @@ __global__ __launch_bounds__(PT) void k_step_philox(StepArgs a) {
       if (tid == 0) {
         step_red_merge(x0);
         CC4_TICK(x0, 7);
-        step_reassign(x0, red_any_foreign_session(s));
+        step_reassign(x0, red_foreign_agents(s));
       }
       for (int h = tid; h < MAXH; h += PT) step_monitor_host(x0, h);
       __syncthreads();
