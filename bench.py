@@ -157,9 +157,9 @@ def main():
         t0 = time.perf_counter()
         ms_k = e.run_random_steps(seed_actions, args.warmup, args.steps, timed=True)   # syncs the stream at the end
         e.synchronize()
-        if dist_on:
+        d = time.perf_counter() - t0      # this rank's K steps; the slowest rank decides (MAX below), the control-plane
+        if dist_on:                       # barrier that closes the bracket is not part of the steps
             dist.barrier()
-        d = time.perf_counter() - t0
         if dist_on:
             t = torch.tensor([d, ms_k], dtype=torch.float64)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
