@@ -2017,11 +2017,13 @@ CC4_HD void step_tick(Ctx x) {
   step_blue_exec(x);
 }
 // returns the BlueRewardMachine penalty of this green agent's action (<= 0)
-CC4_HD int step_green_exec(Ctx x, int g) {
+// pre: block 0 of the agent's stream when the caller has it already (rng_preload), else null
+CC4_HD int step_green_exec(Ctx x, int g, const uint32_t* pre = nullptr) {
   EnvState* s = x.s;
   int gh = s->green_host[g];
   int own = h_subnet(gh);
   rng_set_stream(x.r, ST_GREEN_EXE + (uint32_t)g);
+  if (pre) rng_preload(x.r, pre);
   if (s->green_act[g] == 0) return green_access_service(x, gh) ? 0 : reward_table(s->phase, own, RW_ASF);
   if (s->green_act[g] == 1) {
     bool want_phish = false;

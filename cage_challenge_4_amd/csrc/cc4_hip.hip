@@ -217,7 +217,8 @@ template <bool LOG>
 __global__ __launch_bounds__(PT) void k_step_philox(StepArgs a) {
   extern __shared__ uint4 lds[];
   __shared__ int conflict_lds;
-  __shared__ uint32_t reset_ws[RESET_WS_WORDS];   // pid bitmaps of the scenario generation (autoreset)
+  __shared__ alignas(16) uint32_t reset_ws[RESET_WS_WORDS];   // pid bitmaps of the scenario generation (autoreset); during a step: the green agents' pre-computed blocks
+  static_assert(RESET_WS_WORDS >= 4 * MAXG, "one 16-byte block per green agent");
   __shared__ int glist_n[2];
   __shared__ uint8_t glist[2][MAXG];  // green agents by action type (0 AccessService, 1 LocalWork)
   __shared__ unsigned long long prof_lds[16];
@@ -319,7 +320,14 @@ __global__ __launch_bounds__(PT) void k_step_philox(StepArgs a) {
           Ctx xg{s, a.cold + e, &rl, nullptr, nullptr, lg};
           step_green_policy(xg, g);
           int t = s->green_act[g];
-          if (t < 2) glist[t][atomicAdd(&glist_n[t], 1)] = (uint8_t)g;       // compaction by action type
+          if (t < 2) {
+            glist[t][atomicAdd(&glist_n[t], 1)] = (uint8_t)g;       // compaction by action type
+            // the first block of the agent's action stream, computed here -- behind the red policies -- and handed to the
+            // lane that resolves the action (the generation work area is idle during a step)
+            uint32_t c[4];
+            rng_block(&rl, ST_GREEN_EXE + (uint32_t)g, 0, c);
+            reinterpret_cast<uint4*>(reset_ws)[g] = make_uint4(c[0], c[1], c[2], c[3]);
+          }
         }
       }
       dma_wait();          // the host table has landed in LDS behind the policy phase
@@ -343,7 +351,9 @@ __global__ __launch_bounds__(PT) void k_step_philox(StepArgs a) {
         for (int i = lane; i < glist_n[wave]; i += WAVE) {
           int g = glist[wave][i];
           Ctx xg{s, a.cold + e, &rl, nullptr, nullptr, lg};
-          pen += step_green_exec(xg, g);
+          const uint4 blk = reinterpret_cast<const uint4*>(reset_ws)[g];
+          const uint32_t pre[4] = {blk.x, blk.y, blk.z, blk.w};
+          pen += step_green_exec(xg, g, pre);
         }
         if (pen) atomicAdd(&s->brm, pen);
         if (a.prof && lane == 0) a.prof[PROF_SLOTS * (size_t)e + 96 + wave] += clock64() - tg0;   // debug: per-wave green action time

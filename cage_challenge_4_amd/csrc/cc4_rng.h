@@ -172,7 +172,10 @@ CC4_HD uint64_t rng_next64(Rng* r) {
     uint32_t rot = (uint32_t)(r->s_hi >> 58);
     return (x >> rot) | (x << ((64u - rot) & 63u));
   }
-  if (r->has64) { r->has64 = 0; return r->buf64; }   // one Philox block = two 64-bit outputs
+  if (r->has64) {                                     // one Philox block = two 64-bit outputs
+    if (r->has64 == 3) { r->has64 = 1; r->s_hi++; return (uint64_t)r->u32 | ((uint64_t)r->pad << 32); }   // rng_preload
+    r->has64 = 0; return r->buf64;
+  }
   uint32_t c[4] = {(uint32_t)r->s_hi, r->ndraw, (uint32_t)r->inc_lo, (uint32_t)r->inc_hi};
   philox4x32_10(c, (uint32_t)r->s_lo, (uint32_t)(r->s_lo >> 32));
   r->s_hi++;
@@ -181,6 +184,16 @@ CC4_HD uint64_t rng_next64(Rng* r) {
   return (uint64_t)c[0] | ((uint64_t)c[1] << 32);
 }
 
+// philox: block `ctr` of stream `stream` of r's (key, step, episode) -- what rng_next64 would compute there
+CC4_HD void rng_block(const Rng* r, uint32_t stream, uint32_t ctr, uint32_t c[4]) {
+  c[0] = ctr; c[1] = stream; c[2] = (uint32_t)r->inc_lo; c[3] = (uint32_t)r->inc_hi;
+  philox4x32_10(c, (uint32_t)r->s_lo, (uint32_t)(r->s_lo >> 32));
+}
+// philox, right after rng_set_stream: block 0 of the stream was computed elsewhere (rng_block; the lane-parallel kernel
+// computes it where a thread has slack); the generator hands out these words instead of computing them
+CC4_HD void rng_preload(Rng* r, const uint32_t c[4]) {
+  r->u32 = c[0]; r->pad = c[1]; r->buf64 = (uint64_t)c[2] | ((uint64_t)c[3] << 32); r->has64 = 3; r->has32 = 0;
+}
 // pcg64_next32: low half first, high half buffered (numpy pcg64.h)
 CC4_HD uint32_t rng_next32(Rng* r) {
   if (r->has32) { r->has32 = 0; return r->u32; }
