@@ -104,7 +104,12 @@ def main():
         D.init_control_plane('gloo', force=True)
         import torch
         import torch.distributed as dist
-    dev_id = int(os.environ.get('CC4_BENCH_DEVICE', local if world > 1 else 0))   # override: several ranks on one GPU (tests the N>1 plumbing on a 1-GPU box)
+    dev_id = local if world > 1 else 0
+    if dist_on and world > 1:
+        ndev = torch.cuda.device_count()      # a launcher may expose one GPU per rank (then it is device 0) or all of them
+        if ndev > 0:
+            dev_id = local % ndev
+    dev_id = int(os.environ.get('CC4_BENCH_DEVICE', dev_id))   # override: several ranks on one GPU (tests the N>1 plumbing on a 1-GPU box)
     n_local = args.envs_per_gpu
     total_envs = n_local * world
     env = CC4VecEnv(n_local, steps=args.episode_steps, rng_mode=RNG_PCG64 if args.rng == 'pcg64' else RNG_PHILOX,
