@@ -24,6 +24,9 @@ import os
 import sys
 import time
 
+# multi-process GPU work on these hosts needs dmabuf IPC (the driver has no legacy IPC): set before any HIP / RCCL library loads
+os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 

@@ -46,6 +46,7 @@ def init_rccl(vec_env, rank, world):
     import torch
     import torch.distributed as dist
     os.environ.setdefault('NCCL_SOCKET_IFNAME', 'lo')   # single-node job: bootstrap over loopback, no NIC probing
+    os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')   # dmabuf IPC (normally exported already; read when the runtime loads)
     ident = torch.zeros(128, dtype=torch.uint8)
     if rank == 0:
         buf = (ctypes.c_uint8 * 128)()
