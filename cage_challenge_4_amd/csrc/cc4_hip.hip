@@ -330,6 +330,7 @@ __global__ __launch_bounds__(PT) void k_step_philox(StepArgs a) {
           }
         }
       }
+      if (a.prof && lane == 63) a.prof[PROF_SLOTS * (size_t)e + 100 + wave] += clock64() - t_begin;   // debug: when each wave reaches the end of the policy phase
       dma_wait();          // the host table has landed in LDS behind the policy phase
       __syncthreads();
       CC4_TICK(x0, 2);
