@@ -574,7 +574,7 @@ size_t cc4_algorithmic_bytes_per_env_step(void) {
 
 int cc4_create(const cc4_config* cfg, cc4_handle** out) {
   if (!cfg || !out || cfg->num_envs <= 0 || cfg->steps <= 0 || cfg->red_policy < 0 || cfg->red_policy > 3 ||
-      cfg->green_policy < 0 || cfg->green_policy > 1) { g_create_err = "cc4_create: bad config"; return -2; }
+      cfg->green_policy < 0 || cfg->green_policy > 1 || cfg->rng_mode < 0 || cfg->rng_mode > 1) { g_create_err = "cc4_create: bad config"; return -2; }
   if (cfg->topology_seed != 0 && cfg->rng_mode != 1) { g_create_err = "cc4_create: topology_seed needs rng_mode 1 (the numpy stream draws scenario and dynamics from one generator)"; return -2; }
   int ndev = 0;
   hipError_t e = hipGetDeviceCount(&ndev);

@@ -344,3 +344,31 @@ def test_soak_bounded_containers_never_overflow(rng_mode, red_policy):
         done_count += done
     assert done_count.sum() == 0 or (done_count == done_count[0]).all()      # lock-step episodes: all done flags coincide
     dev.close()
+
+
+@pytest.mark.gpu
+def test_c_abi_error_behaviour():
+    """Bad arguments fail loudly with a message (include/cc4.h: negative return + cc4_last_error), never with a crash or a
+    silent fallback: invalid configurations, an out-of-range device or episode index, a step past the last mission phase
+    (the reference raises ValueError there, State.py:539-540)."""
+    import ctypes
+    from cage_challenge_4_amd import CC4VecEnv, _lib as L
+    for kw in (dict(num_envs=0), dict(num_envs=4, steps=0), dict(num_envs=4, rng_mode=7), dict(num_envs=4, red_policy=9),
+               dict(num_envs=4, device_id=99), dict(num_envs=4, topology_seed=5, rng_mode=0)):
+        with pytest.raises(L.CC4Error):
+            CC4VecEnv(**kw)
+    env = CC4VecEnv(4, steps=6, rng_mode=1)
+    env.reset(seeds=3)
+    buf = np.zeros(env.lib.cc4_state_bytes(), np.uint8)
+    assert env.lib.cc4_get_state(env._h, 4, buf.ctypes.data_as(ctypes.c_void_p)) != 0
+    assert env.lib.cc4_get_state(env._h, -1, buf.ctypes.data_as(ctypes.c_void_p)) != 0
+    assert b'range' in env.lib.cc4_last_error(env._h)
+    assert int(env.lib.cc4_get_true_state(env._h, 9, None, 0)) < 0
+    for _ in range(5):                                   # steps 0..4 of a 6-step episode are the whole episode
+        env.step(np.full((4, 5), -1, np.int32))
+    assert env._done.all()
+    with pytest.raises(ValueError):                      # no autoreset: stepping on raises like the reference
+        for _ in range(3):
+            env.step(np.full((4, 5), -1, np.int32))
+    env.reset(seeds=3)                                   # and the handle is still usable
+    assert not env.step(np.full((4, 5), -1, np.int32))[2].any()
