@@ -372,3 +372,35 @@ def test_c_abi_error_behaviour():
             env.step(np.full((4, 5), -1, np.int32))
     env.reset(seeds=3)                                   # and the handle is still usable
     assert not env.step(np.full((4, 5), -1, np.int32))[2].any()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('rng_mode', [0, 1])
+def test_masked_reset_touches_only_the_masked_episodes(rng_mode):
+    """cc4_reset(seeds, env_mask): the masked episodes become what a fresh handle generates from the same seeds (in the
+    counter mode that is the per-host-phase generation of k_reset), the others keep every byte of their state."""
+    from cage_challenge_4_amd import CC4VecEnv
+    from oracle_binding import random_actions
+    n = 24
+    env = CC4VecEnv(n, steps=60, rng_mode=rng_mode)
+    env.reset(seeds=900)
+    for t in range(9):
+        env.step(random_actions(77, t, n))
+    before = [env.get_state(i).copy() for i in range(n)]
+    mask = (np.arange(n) % 3 == 0).astype(np.uint8)
+    seeds = np.uint64(5000) + np.arange(n, dtype=np.uint64)
+    obs = env.reset(seeds=seeds, env_mask=mask).copy()
+    fresh = CC4VecEnv(n, steps=60, rng_mode=rng_mode)
+    obs_fresh = fresh.reset(seeds=seeds)
+    for i in range(n):
+        if mask[i]:
+            assert np.array_equal(env.get_state(i), fresh.get_state(i)), i
+            assert np.array_equal(obs[i], obs_fresh[i]), i
+        else:
+            assert np.array_equal(env.get_state(i), before[i]), i
+    a = random_actions(78, 0, n)
+    o1, r1, d1, _ = env.step(a)
+    o2, r2, d2, _ = fresh.step(a)
+    sel = mask.astype(bool)
+    assert np.array_equal(o1[sel], o2[sel]) and np.array_equal(r1[sel], r2[sel])
+    assert not env.err.any()
