@@ -221,7 +221,7 @@ def main():
                             f'(82/82/82/82/242 incl. invalid slots), FiniteStateRedAgent, EnterpriseGreenAgent, '
                             f'EnterpriseScenarioGenerator(steps={args.episode_steps}), autoreset incl. scenario regeneration, topology randomised per episode and reset',
                 'envs_per_gpu': n_local, 'total_envs': total_envs, 'rng': args.rng,
-                'exchange': exchange_note or ('RCCL all-gather of the [N,578] uint8 obs of every step on a second stream, overlapped with the next step' if dist_on else 'none'),
+                'exchange': exchange_note or ('RCCL all-gather of the observations of every step (2 bits per value, 148 B per episode) on a second stream, overlapped with the next step' if dist_on else 'none'),
                 'env_steps_per_sec': total_envs * args.steps / dt, 'engine_error_flags': err_any,
             },
             'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBPS, 'unit': 'GB/s',

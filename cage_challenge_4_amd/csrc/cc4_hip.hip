@@ -28,13 +28,16 @@ using namespace cc4;
 static_assert(sizeof(EnvState) % 16 == 0, "EnvState rows are staged with 16-byte accesses");
 constexpr int ROW_VEC = (int)(sizeof(EnvState) / 16);
 constexpr int WAVE = 64;
+constexpr int OBS_PACKED = CC4_OBS_PACKED_BYTES;   // every flat-observation value is 0, 1 or 2: the exchange moves 2 bits per value
+static_assert(OBS_PACKED % 4 == 0 && OBS_PACKED * 4 >= OBS_TOTAL, "packed observation row: whole words, four values per byte");
 constexpr int PROF_SLOTS = 128;   // 16 phase slots, 8 per red agent (16..63), then (cycles, count) per red action type (64..)
 
 struct StepArgs {
   EnvState* st; EnvCold* cold;
   const int32_t* actions; const uint8_t* msgs;
   int32_t* obs; float* reward; uint8_t* done; uint32_t* err;
-  uint8_t* obs8;               // the same observations as bytes (what the multi-GPU all-gather moves), or null
+  uint8_t* obs8;               // the same observations packed 2 bits per value, OBS_PACKED bytes per episode (what the multi-GPU
+                               // all-gather moves), or null
   int32_t* rand_out;           // when non-null: draw the blue actions in-kernel (k_random_actions fused) and record them here
   uint64_t rand_seed0; uint32_t rand_t;
   int n, autoreset, steps, rng_mode, policy;
@@ -80,6 +83,14 @@ __device__ __forceinline__ void stage_out(uint4* __restrict__ dst, const uint4* 
 
 // LOG: record the HostEvents entries of the step (cc4_enable_event_log).  A template parameter rather than a run-time flag: even
 // a never-taken logging branch at the eleven event sites costs the serial walk 10 %.
+// byte j of an episode's packed observation row: values 4j .. 4j+3 (from a byte-per-value row in LDS), 2 bits each, low bits first
+__device__ __forceinline__ uint8_t pack_obs_byte(const uint8_t* vals, int j) {
+  uint32_t b = 0;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) { const int i = 4 * j + k; if (i < OBS_TOTAL) b |= (uint32_t)(vals[i] & 3u) << (2 * k); }
+  return (uint8_t)b;
+}
+
 template <bool LOG>
 __global__ __launch_bounds__(WAVE) void k_step(StepArgs a) {
   // numpy-PCG64 mode: one shared stream => the agent walk is strictly serial (lane 0); only the RNG-free parts
@@ -160,7 +171,7 @@ __global__ __launch_bounds__(WAVE) void k_step(StepArgs a) {
   stage_out(dst, lds, lane);
   int32_t* o = a.obs + (size_t)e * OBS_TOTAL;
   for (int i = lane; i < OBS_TOTAL; i += WAVE) o[i] = obs_lds[i];
-  if (a.obs8) { uint8_t* o8 = a.obs8 + (size_t)e * OBS_TOTAL; for (int i = lane; i < OBS_TOTAL; i += WAVE) o8[i] = obs_lds[i]; }
+  if (a.obs8) { uint8_t* o8 = a.obs8 + (size_t)e * OBS_PACKED; for (int j = lane; j < OBS_PACKED; j += WAVE) o8[j] = pack_obs_byte(obs_lds, j); }
   if (prof && lane == 0) { prof[13] += clock64() - t_out; prof[14] += clock64() - t_begin; }
   if (prof) { __syncthreads(); if (lane < 15) a.prof[PROF_SLOTS * (size_t)e + lane] += prof_lds[lane]; }
 }
@@ -220,6 +231,7 @@ __global__ __launch_bounds__(PT) void k_step_philox(StepArgs a) {
   __shared__ alignas(16) uint32_t reset_ws[RESET_WS_WORDS];   // pid bitmaps of the scenario generation (autoreset); during a step: the green agents' pre-computed blocks
   static_assert(RESET_WS_WORDS >= 4 * MAXG, "one 16-byte block per green agent");
   __shared__ int glist_n[2];
+  __shared__ uint8_t obs_bytes[OBS_TOTAL + 2];   // byte-per-value copy of the observations, only for the packed exchange row
   __shared__ uint8_t glist[2][MAXG];  // green agents by action type (0 AccessService, 1 LocalWork)
   __shared__ unsigned long long prof_lds[16];
   const int e = blockIdx.x, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
@@ -403,11 +415,12 @@ __global__ __launch_bounds__(PT) void k_step_philox(StepArgs a) {
   // flat observations: one value per thread straight to HBM (int32 for the host API, bytes for the all-gather)
   {
     int32_t* o = a.obs + (size_t)e * OBS_TOTAL;
-    uint8_t* o8 = a.obs8 ? a.obs8 + (size_t)e * OBS_TOTAL : nullptr;
-    for (int v = tid; v < OBS_TOTAL; v += PT) { int i; int val = env_flat_obs_sorted(s, v, &i); o[i] = val; if (o8) o8[i] = (uint8_t)val; }   // kind-sorted enumeration: uniform branches per wave
+    const bool pack = a.obs8 != nullptr;   // the exchange copy goes through a byte row in LDS and is packed after the barrier below
+    for (int v = tid; v < OBS_TOTAL; v += PT) { int i; int val = env_flat_obs_sorted(s, v, &i); o[i] = val; if (pack) obs_bytes[i] = (uint8_t)val; }   // kind-sorted enumeration: uniform branches per wave
   }
   __syncthreads();    // the row is final: RedSessionCheck and the step bookkeeping ran beside the encode
   if (tid == 0) a.err[e] = s->err;
+  if (a.obs8) { uint8_t* o8 = a.obs8 + (size_t)e * OBS_PACKED; for (int j = tid; j < OBS_PACKED; j += PT) o8[j] = pack_obs_byte(obs_bytes, j); }
   unsigned long long t_out = a.prof ? clock64() : 0;
   if (prof && tid == 0) prof[12] += t_out - t_obs;
   uint4* dst = reinterpret_cast<uint4*>(a.st + e);
@@ -852,7 +865,7 @@ int cc4_comm_init(cc4_handle* h, int32_t rank, int32_t world, const void* id128)
   ncclResult_t r = ncclCommInitRank(&h->comm, world, id, rank);
   if (r != ncclSuccess) { h->err = std::string("ncclCommInitRank: ") + ncclGetErrorString(r); return -1; }
   h->rank = rank; h->world = world;
-  size_t nb = (size_t)h->cfg.num_envs * OBS_TOTAL;
+  size_t nb = (size_t)h->cfg.num_envs * OBS_PACKED;
   HIPCHK(h, hipStreamCreateWithFlags(&h->comm_stream, hipStreamNonBlocking));
   for (int b = 0; b < cc4_handle::OBS_RING; ++b) {
     HIPCHK(h, hipMalloc(&h->d_obs8[b], nb));
@@ -875,7 +888,7 @@ int cc4_allgather_obs(cc4_handle* h, uint8_t** d_all_obs8) {
   const int buf = h->obs_buf;
   if (!h->step_event_attached) HIPCHK(h, hipEventRecord(h->ev_step[buf], h->stream));   // e.g. the observations of a reset
   HIPCHK(h, hipStreamWaitEvent(h->comm_stream, h->ev_step[buf], 0));
-  size_t cnt = (size_t)h->cfg.num_envs * OBS_TOTAL;
+  size_t cnt = (size_t)h->cfg.num_envs * OBS_PACKED;
   ncclResult_t r = ncclAllGather(h->d_obs8[buf], h->d_all_obs8[buf], cnt, ncclUint8, h->comm, h->comm_stream);
   if (r != ncclSuccess) { h->err = std::string("ncclAllGather: ") + ncclGetErrorString(r); return -1; }
   const long long q = ++h->gathers_issued;
@@ -895,7 +908,11 @@ int cc4_get_allgathered_obs(cc4_handle* h, uint8_t* out /* [world*N][578] */) {
   if (!h->comm) { h->err = "cc4_get_allgathered_obs: cc4_comm_init was not called"; return -2; }
   HIPCHK(h, hipSetDevice(h->cfg.device_id));
   HIPCHK(h, hipStreamSynchronize(h->comm_stream));
-  HIPCHK(h, hipMemcpy(out, h->d_all_obs8[h->obs_buf], (size_t)h->world * h->cfg.num_envs * OBS_TOTAL, hipMemcpyDeviceToHost));
+  const size_t rows = (size_t)h->world * h->cfg.num_envs;
+  std::vector<uint8_t> packed(rows * OBS_PACKED);
+  HIPCHK(h, hipMemcpy(packed.data(), h->d_all_obs8[h->obs_buf], packed.size(), hipMemcpyDeviceToHost));
+  for (size_t r = 0; r < rows; ++r)      // unpack to one byte per value for the host caller
+    for (int i = 0; i < OBS_TOTAL; ++i) out[r * OBS_TOTAL + i] = (uint8_t)((packed[r * OBS_PACKED + (i >> 2)] >> (2 * (i & 3))) & 3u);
   return 0;
 }
 

@@ -41,6 +41,16 @@ def allgather_host(local, world):
     return np.concatenate([o.numpy() for o in out], axis=0)
 
 
+OBS_PACKED_BYTES = 148   # CC4_OBS_PACKED_BYTES: value i of an episode = (row[i >> 2] >> (2 * (i & 3))) & 3
+
+
+def unpack_obs(rows):
+    """[M, OBS_PACKED_BYTES] uint8 packed rows -> [M, 578] uint8 values."""
+    rows = np.asarray(rows, np.uint8)
+    i = np.arange(578)
+    return (rows[:, i >> 2] >> (2 * (i & 3)).astype(np.uint8)) & 3
+
+
 def init_rccl(vec_env, rank, world):
     """Create the RCCL communicator inside libcc4 for this rank's handle (unique id travels over the control plane)."""
     import torch
@@ -61,9 +71,9 @@ def init_rccl(vec_env, rank, world):
 
 
 def allgather_obs_device(vec_env):
-    """Enqueue the RCCL all-gather of this rank's [N,578] uint8 observations of the latest step on the handle's
-    communication stream (it overlaps the next step); returns the device pointer of the [world*N,578] result, valid after
-    allgather_wait()."""
+    """Enqueue the RCCL all-gather of this rank's observations of the latest step -- packed 2 bits per value, OBS_PACKED_BYTES
+    per episode (include/cc4.h) -- on the handle's communication stream (it overlaps the next step); returns the device pointer
+    of the gathered [world*N, OBS_PACKED_BYTES] rows, valid after allgather_wait().  allgathered_obs_host() unpacks them."""
     p = ctypes.c_void_p()
     vec_env._chk(vec_env.lib.cc4_allgather_obs(vec_env._h, ctypes.byref(p)), 'cc4_allgather_obs')
     return p.value
