@@ -183,9 +183,8 @@ __global__ __launch_bounds__(WAVE) void k_step(StepArgs a) {
 // their queue ticks, the 5 blue actions (disjoint zones), the 6 red actions (those naming the same host are held back and
 // run in order on thread 0), the 6 RedSessionChecks (agent r -> wave r % 4, lane r / 4), and the two green action types
 // (AccessService / LocalWork lists built with LDS counters).  Work that is uniform goes to LANES: row staging, green agents
-// within a type, the 137 Monitor roll-overs, the observation encode (enumerated kind by kind).  Measured on MI355X: 4..8
-// waves per block are equivalent at 1024 episodes when the register budget allows 4 blocks per CU; 6 waves without a
-// waves-per-EU hint lose a resident block to SGPR granularity.
+// within a type, the 137 Monitor roll-overs, the observation encode (enumerated kind by kind).  Measured on MI355X (r01): 4 waves per
+// episode is the build; 5 and 6 (fewer red agents sharing a wave) run 25-30 % slower at 1024 episodes, DESIGN.md 7.
 // Cross-thread effects are event-bit ORs and the reward sum (LDS atomics); the rare order-dependent spawns (PhishingEmail,
 // cross-subnet session reassignment) are collected and replayed by thread 0 in agent order.
 #ifndef CC4_PW
