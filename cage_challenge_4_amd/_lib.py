@@ -48,6 +48,7 @@ SIGNATURES = {
     'cc4_synchronize': (ctypes.c_int, [_P]),
     'cc4_run_random_steps': (ctypes.c_int, [_P, ctypes.c_uint64, ctypes.c_uint32, ctypes.c_int32, ctypes.POINTER(ctypes.c_float)]),
     'cc4_state_bytes': (ctypes.c_size_t, []),
+    'cc4_hot_bytes': (ctypes.c_size_t, []),
     'cc4_get_state': (ctypes.c_int, [_P, ctypes.c_int32, _P]),
     'cc4_set_state': (ctypes.c_int, [_P, ctypes.c_int32, _P]),
     'cc4_cold_bytes': (ctypes.c_size_t, []),
@@ -62,6 +63,8 @@ SIGNATURES = {
     'cc4_allgather_obs': (ctypes.c_int, [_P, ctypes.POINTER(_P)]),
     'cc4_allgather_wait': (ctypes.c_int, [_P]),
     'cc4_get_allgathered_obs': (ctypes.c_int, [_P, _P]),
+    'cc4_unpack_obs_device': (ctypes.c_int, [_P, ctypes.POINTER(_P)]),
+    'cc4_get_unpacked_obs': (ctypes.c_int, [_P, _P]),
     'cc4_algorithmic_bytes_per_env_step': (ctypes.c_size_t, []),
 }
 

@@ -9,8 +9,11 @@
 
 namespace cc4 {
 
-struct Ctx { EnvState* s; EnvCold* c; Rng* r; unsigned long long* prof = nullptr; unsigned long long* aprof = nullptr;
-             EvLog* lg = nullptr; };   // lg: the episode's event log when it is enabled (the callers know that without a memory read)
+// s: the episode's row (the device kernels pass their LDS copy); hd: its host table -- &s->hd[0] when the whole row is staged,
+// the HBM row's table when only the part in front of it is (numpy-stream kernel); w: the step's work area;
+// lg: the episode's event log when it is enabled (the callers know that without a memory read)
+struct Ctx { EnvState* s; EnvCold* c; Rng* r; HostDyn* hd; StepWork* w; unsigned long long* prof = nullptr;
+             unsigned long long* aprof = nullptr; EvLog* lg = nullptr; };
 
 // optional phase timing (device only, debug builds of the kernel pass a buffer): prof[i] += cycles since last tick
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -38,10 +41,10 @@ CC4_HD void set_err(Ctx x, uint32_t f) {
 // agents resolved on different lanes may raise events on the same server
 CC4_HD void ev_or(Ctx x, int h, uint32_t bits) {
 #if defined(__HIP_DEVICE_COMPILE__)
-  uint32_t* w = reinterpret_cast<uint32_t*>(&x.s->hd[h].nproc);
+  uint32_t* w = reinterpret_cast<uint32_t*>(&x.hd[h].nproc);
   __hip_atomic_fetch_or(w, bits << 16, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 #else
-  x.s->hd[h].ev |= (uint8_t)bits;
+  x.hd[h].ev |= (uint8_t)bits;
 #endif
 }
 // optional event log (EnvCold.evlog, enabled through cc4_enable_event_log): the content of the HostEvents entry behind an
@@ -153,41 +156,82 @@ CC4_HD void eph_clear(Ctx x, int h) {
   Q z; z.a = 0; z.b = 0; z.c = 0; z.d = 0;
   for (int i = 0; i < EPH_WORDS / 4; ++i) p[i] = z;
 }
+// ---- Host.processes: entries 0..PIN-1 in the hot row, PIN.. in the cold row (EnvCold.povf[h]).  Every scan reads eight
+// records per round as independent word loads (pid | kind << 16 | flags << 24); PIN and POVF are multiples of eight, so a
+// round never straddles the two parts and may read allocated slots past the end of the list (masked by the index test).
+CC4_HD int hd_nsvc(const HostDyn& d) { return d.nsf & 0xF; }
+CC4_HD void hd_set_nsvc(HostDyn& d, int n) { d.nsf = (uint8_t)((d.nsf & 0xF0) | n); }
+CC4_HD int hd_files(const HostDyn& d) { return d.nsf >> 4; }
+CC4_HD void hd_set_files(HostDyn& d, int f) { d.nsf = (uint8_t)((d.nsf & 0x0F) | (f << 4)); }
+struct P8 { uint32_t v[8]; };
+CC4_HD const uint32_t* proc_round_ptr(Ctx x, int h, int i0) {
+  return i0 < PIN ? reinterpret_cast<const uint32_t*>(x.hd[h].procs) + i0 : reinterpret_cast<const uint32_t*>(x.c->povf[h]) + (i0 - PIN);
+}
+CC4_HD P8 proc_load8(Ctx x, int h, int i0) {
+  const uint32_t* p = proc_round_ptr(x, h, i0);
+  P8 q;
+  CC4_UNROLL for (int k = 0; k < 8; ++k) q.v[k] = p[k];
+  return q;
+}
+CC4_HD int pw_pid(uint32_t v) { return (int)(v & 0xFFFF); }
+CC4_HD int pw_kind(uint32_t v) { return (int)((v >> 16) & 0xFF); }
+CC4_HD int pw_flags(uint32_t v) { return (int)(v >> 24); }
+CC4_HD uint32_t proc_get(Ctx x, int h, int i) { return proc_round_ptr(x, h, i & ~7)[i & 7]; }
+CC4_HD void proc_put(Ctx x, int h, int i, uint32_t v) { const_cast<uint32_t*>(proc_round_ptr(x, h, i & ~7))[i & 7] = v; }
 // Host.create_pid (Simulator/Host.py:198-200)
 CC4_HD int create_pid(Ctx x, int h) {
-  const HostDyn& d = x.s->hd[h];
   int mx = 0;
-  const int n = d.nproc;
-  for (int i0 = 0; i0 < n; i0 += 8) {   // 8 process records (pid | kind << 16 | flags << 24) per round; MAXP is a multiple of 8
-    uint32_t v[8];
-    CC4_UNROLL for (int k = 0; k < 8; ++k) __builtin_memcpy(&v[k], &d.procs[i0 + k], 4);
-    CC4_UNROLL for (int k = 0; k < 8; ++k) if (i0 + k < n && (int)(v[k] & 0xFFFF) > mx) mx = (int)(v[k] & 0xFFFF);
+  const int n = x.hd[h].nproc;
+  for (int i0 = 0; i0 < n; i0 += 8) {
+    const P8 q = proc_load8(x, h, i0);
+    CC4_UNROLL for (int k = 0; k < 8; ++k) if (i0 + k < n && pw_pid(q.v[k]) > mx) mx = pw_pid(q.v[k]);
   }
   return mx + 1 + (int)rng_below(x.r, 9);
 }
 CC4_HD bool add_proc(Ctx x, int h, int pid, int kind, int flags) {
-  HostDyn& d = x.s->hd[h];
-  if (d.nproc >= MAXP) { set_err(x, E_PROC_OVERFLOW); return false; }
-  Proc p; p.pid = (uint16_t)pid; p.kind = (uint8_t)kind; p.flags = (uint8_t)flags;
-  d.procs[d.nproc++] = p;
+  HostDyn& d = x.hd[h];
+  const int n = d.nproc;
+  if (n >= MAXP) { set_err(x, E_PROC_OVERFLOW); return false; }
+  proc_put(x, h, n, (uint32_t)pid | ((uint32_t)kind << 16) | ((uint32_t)flags << 24));
+  d.nproc = (uint16_t)(n + 1);
   return true;
 }
 CC4_HD int find_proc(Ctx x, int h, int pid) {
-  const HostDyn& d = x.s->hd[h];
-  const int n = d.nproc;
+  const int n = x.hd[h].nproc;
   for (int i0 = 0; i0 < n; i0 += 8) {
-    uint32_t v[8];
-    CC4_UNROLL for (int k = 0; k < 8; ++k) __builtin_memcpy(&v[k], &d.procs[i0 + k], 4);
+    const P8 q = proc_load8(x, h, i0);
     int hit = -1;
-    CC4_UNROLL for (int k = 7; k >= 0; --k) if (i0 + k < n && (int)(v[k] & 0xFFFF) == pid) hit = i0 + k;
+    CC4_UNROLL for (int k = 7; k >= 0; --k) if (i0 + k < n && pw_pid(q.v[k]) == pid) hit = i0 + k;
     if (hit >= 0) return hit;
   }
   return -1;
 }
+// the union of the listening-port bits of the host's processes (Host.is_using_port over all ports at once)
+CC4_HD int proc_ports(Ctx x, int h) {
+  const int n = x.hd[h].nproc;
+  int used = 0;
+  for (int i0 = 0; i0 < n; i0 += 8) {
+    const P8 q = proc_load8(x, h, i0);
+    CC4_UNROLL for (int k = 0; k < 8; ++k) if (i0 + k < n) used |= kind_port(pw_kind(q.v[k]));
+  }
+  return used;
+}
+// records idx+1 .. n-1 move down by one: per round, the round and the first record of the next one are read before the
+// round is rewritten
 CC4_HD void remove_proc_at(Ctx x, int h, int idx) {
-  HostDyn& d = x.s->hd[h];
-  for (int i = idx; i + 1 < d.nproc; ++i) d.procs[i] = d.procs[i + 1];
-  d.nproc--;
+  HostDyn& d = x.hd[h];
+  const int n = d.nproc;
+  for (int i0 = idx & ~7; i0 < n; i0 += 8) {
+    const P8 q = proc_load8(x, h, i0);
+    const uint32_t nxt = (i0 + 8 < n) ? proc_get(x, h, i0 + 8) : 0u;
+    uint32_t* p = const_cast<uint32_t*>(proc_round_ptr(x, h, i0));
+    CC4_UNROLL for (int k = 0; k < 8; ++k) {
+      const int i = i0 + k;
+      if (i < idx || i + 1 >= n) continue;
+      p[k] = k < 7 ? q.v[(k + 1) & 7] : nxt;
+    }
+  }
+  d.nproc = (uint16_t)(n - 1);
 }
 // host.events.network_connections.append(...)
 CC4_HD void ev_conn(Ctx x, int h) { ev_or(x, h, EV_CUR_CONN); }
@@ -203,16 +247,16 @@ CC4_HD void ev_proc(Ctx x, int h, int pid) {
 // waves; step_red_merge() appends the slots in agent order (== the serial append order)
 CC4_HD void ev_proc_red(Ctx x, int r, int h, int pid) {
   ev_or(x, h, EV_CUR_PROC);
-  if (blue_of_subnet(h_subnet(h)) >= 0) x.s->pend_r[r] = ((uint32_t)h << 16) | (uint32_t)pid;
+  if (blue_of_subnet(h_subnet(h)) >= 0) x.w->pend_r[r] = ((uint32_t)h << 16) | (uint32_t)pid;
 }
 CC4_HD void step_red_merge(Ctx x) {
   EnvState* s = x.s;
   uint32_t pr[NRED];
-  CC4_UNROLL for (int r = 0; r < NRED; ++r) pr[r] = s->pend_r[r];
+  CC4_UNROLL for (int r = 0; r < NRED; ++r) pr[r] = x.w->pend_r[r];
   CC4_UNROLL for (int r = 0; r < NRED; ++r) {
     if (!pr[r]) continue;
     if (s->npend >= MAX_PEND) set_err(x, E_PEND_OVERFLOW); else s->pend[s->npend++] = pr[r];
-    s->pend_r[r] = 0;
+    x.w->pend_r[r] = 0;
   }
 }
 CC4_HD void pend_drop_host(Ctx x, int h) {
@@ -225,23 +269,33 @@ CC4_HD void pend_drop_host(Ctx x, int h) {
 CC4_HD bool subnet_blocked(Ctx x, int src_sub, int other_sub) { return (x.s->blocks[other_sub] >> src_sub) & 1u; }
 
 // ------------------------------------------------------------------ red sessions
-// Session-table scans read 8 records per round with independent 8-byte loads (one LDS round trip per 8 sessions instead of
-// one per session).  A record as a little-endian word: id | pid << 16 | host << 32 | flags << 40 | kb << 48.  MAX_RS is a
-// multiple of 8, so a round may read past nsess inside the array; those lanes are masked by the index test.
-struct S8 { uint64_t v[8]; };
-CC4_HD S8 rs_load8(const RedAgent& a, int i0) {
+// state.sessions[red_agent_r] is RedAgent.sord: pool slots in dict order.  A scan reads eight list bytes as one word, then the
+// eight records with independent 8-byte loads (two LDS round trips per eight sessions).  A record as a little-endian word:
+// id | pid << 16 | host << 32 | flags << 40.  MAX_RS is a multiple of 8 and list bytes are always valid slots, so a round may
+// read past nsess; those lanes are masked by the index test.
+struct S8 { uint64_t v[8]; uint64_t slots; };
+CC4_HD uint64_t rs_word(const EnvState* s, int slot) { uint64_t v; __builtin_memcpy(&v, &s->spool[slot], 8); return v; }
+CC4_HD void rs_word_put(EnvState* s, int slot, uint64_t v) { __builtin_memcpy(&s->spool[slot], &v, 8); }
+CC4_HD S8 rs_load8(const EnvState* s, const RedAgent& a, int i0) {
   S8 q;
-  CC4_UNROLL for (int k = 0; k < 8; ++k) __builtin_memcpy(&q.v[k], &a.sess[i0 + k], 8);
+  __builtin_memcpy(&q.slots, &a.sord[i0], 8);
+  CC4_UNROLL for (int k = 0; k < 8; ++k) q.v[k] = rs_word(s, (int)((q.slots >> (8 * k)) & 0xFF));
   return q;
 }
+CC4_HD int s8_slot(const S8& q, int k) { return (int)((q.slots >> (8 * k)) & 0xFF); }
 CC4_HD int rsw_id(uint64_t v) { return (int)(v & 0xFFFF); }
 CC4_HD int rsw_pid(uint64_t v) { return (int)((v >> 16) & 0xFFFF); }
 CC4_HD int rsw_host(uint64_t v) { return (int)((v >> 32) & 0xFF); }
 CC4_HD int rsw_flags(uint64_t v) { return (int)((v >> 40) & 0xFF); }
-CC4_HD int rs_find_id(const RedAgent& a, int id) {
+CC4_HD uint64_t rsw_make(int id, int pid, int host, int flags) {
+  return (uint64_t)(id & 0xFFFF) | ((uint64_t)(pid & 0xFFFF) << 16) | ((uint64_t)(host & 0xFF) << 32) | ((uint64_t)(flags & 0xFF) << 40);
+}
+// the i-th session of the agent (list position -> record)
+CC4_HD uint64_t rs_at(const EnvState* s, const RedAgent& a, int i) { return rs_word(s, a.sord[i]); }
+CC4_HD int rs_find_id(const EnvState* s, const RedAgent& a, int id) {
   const int n = a.nsess;
   for (int i0 = 0; i0 < n; i0 += 8) {
-    const S8 q = rs_load8(a, i0);
+    const S8 q = rs_load8(s, a, i0);
     int hit = -1;
     CC4_UNROLL for (int k = 7; k >= 0; --k) if (i0 + k < n && rsw_id(q.v[k]) == id) hit = i0 + k;
     if (hit >= 0) return hit;
@@ -250,11 +304,11 @@ CC4_HD int rs_find_id(const RedAgent& a, int id) {
 }
 // sessions of the agent on host h: how many, the first one, the first root one
 struct HostSess { int n, first, first_root; };
-CC4_HD HostSess rs_on_host(const RedAgent& a, int h) {
+CC4_HD HostSess rs_on_host(const EnvState* s, const RedAgent& a, int h) {
   HostSess r; r.n = 0; r.first = -1; r.first_root = -1;
   const int n = a.nsess;
   for (int i0 = 0; i0 < n; i0 += 8) {
-    const S8 q = rs_load8(a, i0);
+    const S8 q = rs_load8(s, a, i0);
     CC4_UNROLL for (int k = 0; k < 8; ++k)
       if (i0 + k < n && rsw_host(q.v[k]) == h) {
         r.n++;
@@ -265,10 +319,10 @@ CC4_HD HostSess rs_on_host(const RedAgent& a, int h) {
   return r;
 }
 // index of the k-th (0-based) session on host h, or -1
-CC4_HD int rs_kth_on_host(const RedAgent& a, int h, int kth) {
+CC4_HD int rs_kth_on_host(const EnvState* s, const RedAgent& a, int h, int kth) {
   const int n = a.nsess;
   for (int i0 = 0; i0 < n; i0 += 8) {
-    const S8 q = rs_load8(a, i0);
+    const S8 q = rs_load8(s, a, i0);
     int hit = -1;
     CC4_UNROLL for (int k = 0; k < 8; ++k)
       if (hit < 0 && i0 + k < n && rsw_host(q.v[k]) == h) { if (kth == 0) hit = i0 + k; kth--; }
@@ -277,110 +331,133 @@ CC4_HD int rs_kth_on_host(const RedAgent& a, int h, int kth) {
   return -1;
 }
 // index of the session with this (host, pid), or -1 (State.get_session_from_pid)
-CC4_HD int rs_find_host_pid(const RedAgent& a, int h, int pid) {
+CC4_HD int rs_find_host_pid(const EnvState* s, const RedAgent& a, int h, int pid) {
   const int n = a.nsess;
   for (int i0 = 0; i0 < n; i0 += 8) {
-    const S8 q = rs_load8(a, i0);
+    const S8 q = rs_load8(s, a, i0);
     int hit = -1;
     CC4_UNROLL for (int k = 7; k >= 0; --k) if (i0 + k < n && rsw_host(q.v[k]) == h && rsw_pid(q.v[k]) == pid) hit = i0 + k;
     if (hit >= 0) return hit;
   }
   return -1;
 }
-// records idx+1 .. nsess-1 move down by one (8 per round: loads first, then stores)
-CC4_HD void rs_shift_down(RedAgent& a, int idx) {
-  const int n = a.nsess;
-  for (int i0 = idx; i0 + 1 < n; i0 += 8) {
-    uint64_t v[8];
-    CC4_UNROLL for (int k = 0; k < 8; ++k) if (i0 + 1 + k < MAX_RS) __builtin_memcpy(&v[k], &a.sess[i0 + 1 + k], 8); else v[k] = 0;
-    CC4_UNROLL for (int k = 0; k < 8; ++k) if (i0 + 1 + k < n) __builtin_memcpy(&a.sess[i0 + k], &v[k], 8);
+// list entries idx+1 .. nsess-1 move down by one: the 64-byte list is eight words, read as one batch and funnel-shifted
+CC4_HD void rs_list_remove(RedAgent& a, int idx) {
+  uint64_t w[MAX_RS / 8];
+  __builtin_memcpy(w, a.sord, MAX_RS);
+  const int wi = idx >> 3, sh = 8 * (idx & 7);
+  CC4_UNROLL for (int k = 0; k < MAX_RS / 8; ++k) {
+    if (k < wi) continue;
+    const uint64_t nxt = k + 1 < MAX_RS / 8 ? w[k + 1] : 0ull;
+    uint64_t v = (w[k] >> 8) | (nxt << 56);                                        // the whole word moves down one byte
+    if (k == wi && sh) v = (w[k] & ((1ull << sh) - 1ull)) | (v & ~((1ull << sh) - 1ull));   // bytes below idx stay
+    w[k] = v;
+  }
+  __builtin_memcpy(a.sord, w, MAX_RS);
+}
+// A free pool record.  Allocation order must not depend on how the red agents are spread over waves, so the one session an
+// agent's exploit may create in a step gets its slot before the red actions run (rs_reserve, StepWork.rs_slot); every other
+// creation site (reset, PhishingEmail) runs on one thread and takes the lowest free slot.
+CC4_HD int rs_alloc_lowest(Ctx x) {
+  for (int w = 0; w < RS_POOL / 32; ++w) {
+    const uint32_t fr = ~x.s->spool_used[w];
+    if (fr) return w * 32 + ctz32(fr);
+  }
+  return -1;
+}
+CC4_HD void rs_reserve(Ctx x) {
+  uint32_t used[RS_POOL / 32];
+  CC4_UNROLL for (int w = 0; w < RS_POOL / 32; ++w) used[w] = x.s->spool_used[w];
+  int ty[NRED];
+  CC4_UNROLL for (int r = 0; r < NRED; ++r) ty[r] = x.s->rexec[r].type;
+  CC4_UNROLL for (int r = 0; r < NRED; ++r) {
+    int slot = 0xFF;
+    if (ty[r] == RA_EXPLOIT) {
+      CC4_UNROLL for (int w = 0; w < RS_POOL / 32; ++w) {
+        const uint32_t fr = ~used[w];
+        if (slot == 0xFF && fr) { slot = w * 32 + ctz32(fr); used[w] |= 1u << (slot & 31); }
+      }
+    }
+    x.w->rs_slot[r] = (uint8_t)slot;
   }
 }
-CC4_HD int kb_alloc(Ctx x, int r) {
-  for (int w = 0; w < MAX_KB / 32; ++w) {
-    uint32_t free_bits = ~x.s->kb_used[r][w];
-    if (!free_bits) continue;
-    int i = w * 32 + ctz32(free_bits);
-    x.s->kb_used[r][w] |= 1u << (i & 31);
-    uint64_t* row = reinterpret_cast<uint64_t*>(x.c->kports[r * MAX_KB + i]);   // 144-byte rows, 8-byte aligned
-    for (int k = 0; k < (MAXH + 7) / 8; ++k) row[k] = 0;
-    return i;
-  }
-  set_err(x, E_KB_OVERFLOW);
-  return 0xFF;
-}
-CC4_HD void kb_free(Ctx x, int r, int kb) { if (kb != 0xFF) x.s->kb_used[r][kb >> 5] &= ~(1u << (kb & 31)); }
-// State.add_session (Simulator/State.py:305-324): ident = max(existing)+1 (0 if none); appended (dict order)
-CC4_HD int rs_add(Ctx x, int r, int host, int pid, int flags) {
-  RedAgent& a = x.s->red[r];
-  if (a.nsess >= MAX_RS) { set_err(x, E_RSESS_OVERFLOW); return -1; }
+// State.add_session (Simulator/State.py:305-324): ident = max(existing)+1 (0 if none); appended (dict order).
+// slot: the pool record to use (< 0: lowest free).  Returns the list index, or -1.
+CC4_HD int rs_add(Ctx x, int r, int host, int pid, int flags, int slot = -1) {
+  EnvState* s = x.s;
+  RedAgent& a = s->red[r];
+  if (slot < 0) slot = rs_alloc_lowest(x);
+  if (a.nsess >= MAX_RS || slot < 0 || slot >= RS_POOL) { set_err(x, E_RSESS_OVERFLOW); return -1; }
   int id = 0;
   for (int i0 = 0; i0 < a.nsess; i0 += 8) {
-    const S8 q = rs_load8(a, i0);
+    const S8 q = rs_load8(s, a, i0);
     CC4_UNROLL for (int k = 0; k < 8; ++k) if (i0 + k < a.nsess && rsw_id(q.v[k]) + 1 > id) id = rsw_id(q.v[k]) + 1;
   }
-  RSess q; q.id = (uint16_t)id; q.pid = (uint16_t)pid; q.host = (uint8_t)host; q.flags = (uint8_t)flags; q.pad = 0;
-  q.kb = (flags & RS_ABSTRACT) ? (uint8_t)kb_alloc(x, r) : (uint8_t)0xFF;
-  a.sess[a.nsess++] = q;
+  (void)or_shared(&s->spool_used[slot >> 5], 1u << (slot & 31));
+  rs_word_put(s, slot, rsw_make(id, pid, host, flags));
+  if (flags & RS_ABSTRACT) {   // a fresh RedAbstractSession knows no ports
+    uint64_t* row = reinterpret_cast<uint64_t*>(x.c->kports[slot]);   // 144-byte rows, 8-byte aligned
+    for (int k = 0; k < (MAXH + 7) / 8; ++k) row[k] = 0;
+  }
+  a.sord[a.nsess++] = (uint8_t)slot;
   a.rsc_dirty = 1;
   if (!bit_get(a.live_hosts, host)) { bit_set(a.live_hosts, host); a.nlive++; }
-  bit_set_shared(x.s->red_hosts, host);
+  bit_set_shared(s->red_hosts, host);
   return a.nsess - 1;
 }
-CC4_HD void rs_remove_at(Ctx x, int r, int idx, bool free_kb) {
+// the agent no longer holds a session on `gone`: its own bitmap, and the episode's if no other agent does either
+CC4_HD void rs_host_left(Ctx x, int r, int gone) {
   RedAgent& a = x.s->red[r];
-  if (free_kb) kb_free(x, r, a.sess[idx].kb);
-  int gone = a.sess[idx].host;
-  rs_shift_down(a, idx);
+  bit_clr(a.live_hosts, gone); a.nlive--;
+  uint32_t lw[NRED];   // the six agents' words for that host in one batch of loads (this agent's bit is already clear)
+  CC4_UNROLL for (int q = 0; q < NRED; ++q) lw[q] = x.s->red[q].live_hosts[gone >> 5];
+  uint32_t any_other = 0;
+  CC4_UNROLL for (int q = 0; q < NRED; ++q) any_other |= lw[q];
+  if (!((any_other >> (gone & 31)) & 1u)) bit_clr_shared(x.s->red_hosts, gone);
+}
+// the list entry goes; the pool record is released unless it moves on to another agent (keep_record)
+CC4_HD void rs_remove_at(Ctx x, int r, int idx, bool keep_record = false) {
+  EnvState* s = x.s;
+  RedAgent& a = s->red[r];
+  const int slot = a.sord[idx];
+  const int gone = rsw_host(rs_word(s, slot));
+  if (!keep_record) bit_clr_shared(s->spool_used, slot);
+  rs_list_remove(a, idx);
   a.nsess--;
   a.rsc_dirty = 1;
-  if (rs_on_host(a, gone).n == 0) {
-    bit_clr(a.live_hosts, gone); a.nlive--;
-    uint32_t lw[NRED];   // the six agents' words for that host in one batch of loads (this agent's bit is already clear)
-    CC4_UNROLL for (int q = 0; q < NRED; ++q) lw[q] = x.s->red[q].live_hosts[gone >> 5];
-    uint32_t any_other = 0;
-    CC4_UNROLL for (int q = 0; q < NRED; ++q) any_other |= lw[q];
-    if (!((any_other >> (gone & 31)) & 1u)) bit_clr_shared(x.s->red_hosts, gone);
-  }
+  if (rs_on_host(s, a, gone).n == 0) rs_host_left(x, r, gone);
 }
-// Every non-original session of agent r on host h, in one compaction pass (== rs_remove_at on each of them in table order:
+// Every non-original session of agent r on host h, in one compaction pass (== rs_remove_at on each of them in list order:
 // the survivors keep their order).  RestoreFromBackup.
 CC4_HD void rs_remove_on_host(Ctx x, int r, int h) {
-  RedAgent& a = x.s->red[r];
+  EnvState* s = x.s;
+  RedAgent& a = s->red[r];
   const int n = a.nsess;
   int out = 0, removed = 0;
   bool left = false;
   for (int i0 = 0; i0 < n; i0 += 8) {
-    const S8 q = rs_load8(a, i0);      // the round is in registers before any of its slots is overwritten (out <= i0 + k)
+    const S8 q = rs_load8(s, a, i0);      // the round is in registers before any of its list bytes is overwritten (out <= i0 + k)
     CC4_UNROLL for (int k = 0; k < 8; ++k) {
       if (i0 + k >= n) continue;
       const bool here = rsw_host(q.v[k]) == h;
-      if (here && !(rsw_flags(q.v[k]) & RS_ORIG)) { kb_free(x, r, (int)((q.v[k] >> 48) & 0xFF)); removed++; continue; }
+      if (here && !(rsw_flags(q.v[k]) & RS_ORIG)) { bit_clr_shared(s->spool_used, s8_slot(q, k)); removed++; continue; }
       if (here) left = true;
-      if (out != i0 + k) __builtin_memcpy(&a.sess[out], &q.v[k], 8);
+      if (out != i0 + k) a.sord[out] = (uint8_t)s8_slot(q, k);
       out++;
     }
   }
   if (!removed) return;
   a.nsess = (uint8_t)out;
   a.rsc_dirty = 1;
-  if (!left) {
-    bit_clr(a.live_hosts, h); a.nlive--;
-    uint32_t lw[NRED];
-    CC4_UNROLL for (int q = 0; q < NRED; ++q) lw[q] = x.s->red[q].live_hosts[h >> 5];
-    uint32_t any_other = 0;
-    CC4_UNROLL for (int q = 0; q < NRED; ++q) any_other |= lw[q];
-    if (!((any_other >> (h & 31)) & 1u)) bit_clr_shared(x.s->red_hosts, h);
-  }
+  if (!left) rs_host_left(x, r, h);
 }
 // dict pop + re-insert of the same session object (RedSessionCheck promotion, RestoreFromBackup of an original session):
-// the record moves to the end of the agent's order; which hosts hold sessions does not change
-CC4_HD void rs_move_to_end(RedAgent& a, int idx, int new_id) {
-  uint64_t q;   // the record as one word (a struct temporary ends up in scratch memory on the device)
-  __builtin_memcpy(&q, &a.sess[idx], 8);
-  rs_shift_down(a, idx);
-  if (new_id >= 0) q = (q & ~0xFFFFull) | (uint64_t)(new_id & 0xFFFF);
-  __builtin_memcpy(&a.sess[a.nsess - 1], &q, 8);
+// the entry moves to the end of the agent's order; which hosts hold sessions does not change
+CC4_HD void rs_move_to_end(EnvState* s, RedAgent& a, int idx, int new_id) {
+  const int slot = a.sord[idx];
+  rs_list_remove(a, idx);
+  a.sord[a.nsess - 1] = (uint8_t)slot;
+  if (new_id >= 0) rs_word_put(s, slot, (rs_word(s, slot) & ~0xFFFFull) | (uint64_t)(new_id & 0xFFFF));
   a.rsc_dirty = 1;
 }
 CC4_HD bool sid_known(const RedAgent& a, int id) {
@@ -464,8 +541,8 @@ CC4_HD int gen_pid(Ctx x, uint32_t* used) {  // _generate_pid (ESG.py:564-578)
 // made every read-modify-write of the build a global-memory round trip.
 CC4_HD void gen_host(Ctx x, int h, uint32_t* used) {  // _generate_linux_host (ESG.py:470-528)
   EnvState* s = x.s;
-  HostDyn& st = s->hd[h];
-  st.nproc = 0; st.nsvc = 0;
+  HostDyn& st = x.hd[h];
+  st.nproc = 0; st.nsf = 0;
   bit_set(s->exists, h);
   st.ev = (uint8_t)rng_below(x.r, 2);  // OSDistribution choice (ESG.py:488-494): 0 UBUNTU, 1 KALI; parked in ev until the backup is written
   if (h_is_router(h)) return;
@@ -490,11 +567,11 @@ CC4_HD void gen_host(Ctx x, int h, uint32_t* used) {  // _generate_linux_host (E
   }
   // _generate_linux_host_processes (ESG.py:580-629): one random() per service, never below 1.0
   for (int i = 0; i < n; ++i) (void)rng_random(x.r);
-  st.nsvc = (uint8_t)n; st.nproc = (uint8_t)n;
+  hd_set_nsvc(st, n); st.nproc = (uint16_t)n;
 }
 // Host.add_session for a starting session (Host.py:189-196): Process(pid=create_pid(), name=session_type)
-CC4_HD int start_session_proc(Ctx x, int h, int kind) {
-  HostDyn& st = x.s->hd[h];
+CC4_HD int start_session_proc(Ctx x, int h, int kind) {   // at generation time a host holds fewer than PIN processes
+  HostDyn& st = x.hd[h];
   int mx = 0;
   for (int i = 0; i < st.nproc; ++i) if (st.procs[i].pid > mx) mx = st.procs[i].pid;
   int pid = mx + 1 + (int)rng_below(x.r, 9);
@@ -504,23 +581,22 @@ CC4_HD int start_session_proc(Ctx x, int h, int kind) {
 }
 // Host.create_backup (Host.py:316-371): the freshly generated dynamic row becomes the backup image (stores only)
 CC4_HD void host_backup(Ctx x, int h, int ip_octet) {
-  const HostDyn& d = x.s->hd[h];
+  const HostDyn& d = x.hd[h];
   HostStatic st;
   for (int i = 0; i < 8; ++i) st.procs[i] = d.procs[i];
   for (int i = 0; i < 5; ++i) st.svcs[i] = d.svcs[i];
-  st.nproc = d.nproc; st.nsvc = d.nsvc; st.exists = (uint8_t)(1 | ((d.ev & 1) << 1)); st.ip_octet = (uint8_t)ip_octet;
-  if (d.nproc > 8 || d.nsvc > 5) set_err(x, E_PROC_OVERFLOW);
+  st.nproc = (uint8_t)d.nproc; st.nsvc = (uint8_t)hd_nsvc(d); st.exists = (uint8_t)(1 | ((d.ev & 1) << 1)); st.ip_octet = (uint8_t)ip_octet;
+  if (d.nproc > PIN - 1 || hd_nsvc(d) > 5) set_err(x, E_PROC_OVERFLOW);   // slot PIN-1 carried the address during generation
   __builtin_memcpy(&x.c->hs[h], &st, sizeof(HostStatic));
 }
 CC4_HD void host_restore(Ctx x, int h) {  // Host.restore (Host.py:373-429)
-  EnvState* s = x.s;
-  HostDyn& d = s->hd[h];
+  HostDyn& d = x.hd[h];
   // the backup image lives in the cold row (HBM): fetch its 56 bytes with independent wide loads, then unpack
   HostStatic st;
   __builtin_memcpy(&st, &x.c->hs[h], sizeof(HostStatic));   // 8-byte aligned POD -> 7 wide loads in flight
   for (int i = 0; i < 8; ++i) d.procs[i] = st.procs[i];
   for (int i = 0; i < 5; ++i) d.svcs[i] = st.svcs[i];
-  d.nproc = st.nproc; d.nsvc = st.nsvc; d.ev = 0; d.pad = 0;
+  d.nproc = st.nproc; d.ev = 0; d.nsf = st.nsvc;   // the cold part of the list is simply abandoned; Host.files is cleared
   eph_clear(x, h);
   pend_drop_host(x, h);
 }
@@ -536,10 +612,12 @@ struct ResetCarry { uint64_t env_key; };
 enum : int { RESET_WS_SEEN = 0, RESET_WS_DUP = 288, RESET_WS_HOSTS = 576, RESET_WS_WORDS = 584 };   // work area (LDS on the device)
 
 // phase 0, all threads: clear the row (except the generator) and the backup images
-CC4_HD void reset_zero(EnvState* s, EnvCold* c, int t, int nt) {
+CC4_HD void reset_zero(EnvState* s, HostDyn* hd, EnvCold* c, int t, int nt) {
   static_assert(offsetof(EnvState, rng) == 0, "the generator leads the row");
   uint32_t* w = (uint32_t*)s;
-  for (size_t i = sizeof(Rng) / 4 + (size_t)t; i < sizeof(EnvState) / 4; i += (size_t)nt) w[i] = 0;
+  for (size_t i = sizeof(Rng) / 4 + (size_t)t; i < offsetof(EnvState, hd) / 4; i += (size_t)nt) w[i] = 0;
+  uint32_t* hw = (uint32_t*)hd;
+  for (size_t i = (size_t)t; i < sizeof(HostDyn) * MAXH / 4; i += (size_t)nt) hw[i] = 0;
   uint32_t* b = (uint32_t*)c->hs;
   for (size_t i = (size_t)t; i < sizeof(c->hs) / 4; i += (size_t)nt) b[i] = 0;
 }
@@ -557,7 +635,7 @@ CC4_HD ResetCarry reset_topology(Ctx x, uint64_t seed, int steps, bool continue_
   { int q = steps / 3, rem = steps % 3; s->phase_len[0] = q + (rem >= 1 ? 1 : 0); s->phase_len[1] = q + (rem == 2 ? 1 : 0); s->phase_len[2] = q; }
   for (int i = 0; i < RESET_WS_WORDS; ++i) ws[i] = 0;
   {
-    uint32_t* avail = s->scratch;
+    uint32_t* avail = x.w->scratch;
     for (int i = 0; i < 8; ++i) avail[i] = 0xFFFFFFFFu;
     int n = 256;
     for (int sn = 0; sn < NSUB; ++sn) {
@@ -568,11 +646,11 @@ CC4_HD ResetCarry reset_topology(Ctx x, uint64_t seed, int steps, bool continue_
     }
   }
   for (int sn = 0; sn < NSUB; ++sn) {
-    uint32_t* ips = s->scratch;
+    uint32_t* ips = x.w->scratch;
     for (int i = 0; i < 8; ++i) ips[i] = 0xFFFFFFFFu;
     ips[0] &= ~1u; ips[7] &= 0x7FFFFFFFu;
     int n = 254;
-    auto place = [&](int h, int v) { bit_clr(ips, v); n--; bit_set(s->exists, h); s->hd[h].pad = (uint8_t)v; };   // ip parked in pad until the backup
+    auto place = [&](int h, int v) { bit_clr(ips, v); n--; bit_set(s->exists, h); x.hd[h].procs[PIN - 1].pid = (uint16_t)v; };   // ip parked in the last inline process slot until the backup
     if (sn == S_INT) { place(H_INTERNET, nth_set(ips, 8, (int)rng_below(x.r, (uint32_t)n))); continue; }
     place(h_make(sn, 0), nth_set(ips, 8, (int)rng_below(x.r, (uint32_t)n)));
     int nu = 3 + (int)rng_below(x.r, 8);
@@ -587,10 +665,9 @@ CC4_HD ResetCarry reset_topology(Ctx x, uint64_t seed, int steps, bool continue_
 // phase 2, per host: services and candidate pids (_generate_linux_host, ESG.py:470-629) from the host's own stream
 CC4_HD void reset_gen_host(Ctx x, int h) {
   EnvState* s = x.s;
-  for (int r = 0; r < NRED; ++r) s->red[r].fsm_state[h] = FS_NONE;
   if (!bit_get(s->exists, h)) return;
   rng_set_stream(x.r, ST_GEN_HOST + (uint32_t)h);
-  HostDyn& st = s->hd[h];
+  HostDyn& st = x.hd[h];
   st.ev = (uint8_t)rng_below(x.r, 2);   // OSDistribution, parked in ev until the backup
   if (h_is_router(h)) return;
   int n = 0;
@@ -611,31 +688,30 @@ CC4_HD void reset_gen_host(Ctx x, int h) {
     put(o == 0 ? K_APACHE : (o == 1 ? K_MYSQL : K_SMTP), o == 0 ? p_apache : (o == 1 ? p_mysql : p_smtp));
   }
   for (int i = 0; i < n; ++i) (void)rng_random(x.r);
-  st.nsvc = (uint8_t)n; st.nproc = (uint8_t)n;
+  hd_set_nsvc(st, n); st.nproc = (uint16_t)n;
 }
 // phase 3a, per host: enter the pids into the network-wide set; a value entered twice is contested
 CC4_HD void reset_pid_mark(Ctx x, int h, uint32_t* ws) {
-  const HostDyn& st = x.s->hd[h];
-  for (int i = 0; i < st.nsvc; ++i) {
+  const HostDyn& st = x.hd[h];
+  for (int i = 0; i < hd_nsvc(st); ++i) {
     int v = st.svcs[i].pid - 1000;
     if (or_shared(&ws[RESET_WS_SEEN + (v >> 5)], 1u << (v & 31)) & (1u << (v & 31))) (void)or_shared(&ws[RESET_WS_DUP + (v >> 5)], 1u << (v & 31));
   }
 }
 // phase 3b, per host: which of the host's services hold a contested pid (ev bits 1..5), which hosts have any
 CC4_HD void reset_pid_flag(Ctx x, int h, uint32_t* ws) {
-  HostDyn& st = x.s->hd[h];
+  HostDyn& st = x.hd[h];
   uint32_t m = 0;
-  for (int i = 0; i < st.nsvc; ++i) { int v = st.svcs[i].pid - 1000; if (bit_get(ws + RESET_WS_DUP, v)) m |= 1u << i; }
+  for (int i = 0; i < hd_nsvc(st); ++i) { int v = st.svcs[i].pid - 1000; if (bit_get(ws + RESET_WS_DUP, v)) m |= 1u << i; }
   if (m) { st.ev = (uint8_t)(st.ev | (m << 1)); (void)or_shared(&ws[RESET_WS_HOSTS + (h >> 5)], 1u << (h & 31)); }
 }
 // phase 3c, one thread: contested pids in host / service order -- the first holder keeps the value, later ones draw again
 CC4_HD void reset_pid_resolve(Ctx x, uint32_t* ws) {
-  EnvState* s = x.s;
   for (int w = 0; w < 5; ++w) {
     uint32_t hm = ws[RESET_WS_HOSTS + w];
     while (hm) {
       const int h = w * 32 + ctz32(hm); hm &= hm - 1;
-      HostDyn& st = s->hd[h];
+      HostDyn& st = x.hd[h];
       uint32_t cm = (uint32_t)st.ev >> 1;
       st.ev &= 1;
       Rng t; bool forked = false;
@@ -687,17 +763,17 @@ CC4_HD void reset_host_sessions(Ctx x, int h) {
   EnvState* s = x.s;
   if (!bit_get(s->exists, h)) return;
   rng_set_stream(x.r, ST_GEN_SESS + (uint32_t)h);
-  if (blue_of_subnet(h_subnet(h)) >= 0) s->blue_pid[h] = (uint16_t)start_session_proc(x, h, K_SESS_BLUE);
-  if (h != H_INTERNET && h_is_user(h)) s->green_pid[h] = (uint16_t)start_session_proc(x, h, K_SESS_GREEN);
+  if (blue_of_subnet(h_subnet(h)) >= 0) (void)start_session_proc(x, h, K_SESS_BLUE);
+  if (h != H_INTERNET && h_is_user(h)) (void)start_session_proc(x, h, K_SESS_GREEN);
   if (h == s->red[0].start_host) (void)start_session_proc(x, h, K_SESS_RED);
-  host_backup(x, h, s->hd[h].pad);
-  s->hd[h].pad = 0; s->hd[h].ev = 0;
+  host_backup(x, h, x.hd[h].procs[PIN - 1].pid);
+  x.hd[h].procs[PIN - 1].pid = 0; x.hd[h].ev = 0;
 }
 // phase 6, one thread: red_agent_0's session, initial observations, counters
 CC4_HD void reset_finish(Ctx x, ResetCarry k, int steps, uint32_t topo_seed, bool rng_is_copy) {
   EnvState* s = x.s;
   {
-    const HostDyn& d = s->hd[s->red[0].start_host];
+    const HostDyn& d = x.hd[s->red[0].start_host];
     int red0_pid = 0;
     for (int i = 0; i < d.nproc; ++i) if (d.procs[i].kind == K_SESS_RED) red0_pid = d.procs[i].pid;
     (void)rs_add(x, 0, s->red[0].start_host, red0_pid, RS_ABSTRACT | RS_ORIG);
@@ -723,7 +799,7 @@ CC4_HD void reset_finish(Ctx x, ResetCarry k, int steps, uint32_t topo_seed, boo
 // the same phases as loops (the oracle; any single-threaded caller)
 CC4_HD void env_reset_counter_mode(Ctx x, uint64_t seed, int steps, bool continue_stream, int policy, uint32_t topo_seed, uint32_t* ws,
                                    bool rng_is_copy) {
-  reset_zero(x.s, x.c, 0, 1);
+  reset_zero(x.s, x.hd, x.c, 0, 1);
   ResetCarry k = reset_topology(x, seed, steps, continue_stream, policy, topo_seed, ws, rng_is_copy);
   {
     Rng t; rng_fork(&t, x.r, ST_GEN_HOST);
@@ -746,8 +822,8 @@ CC4_HD void env_reset_counter_mode(Ctx x, uint64_t seed, int steps, bool continu
 // topo_seed != 0 (counter-based RNG mode only): every episode draws its scenario from the reset stream of the key
 // `topo_seed` instead of its own key, i.e. all episodes of a batch share topology, services and pids and differ only in
 // their dynamics (SURVEY 8(d)-5 "uniform topology" contrast; the reference always randomises per reset).
-// pid_ws: optional 288-word work area for the used-pid bitmap of the generation (the device kernels pass LDS); by default
-// the internet host's ephemeral-port map in the cold row serves (it is cleared again before the episode starts).
+// pid_ws: counter mode: RESET_WS_WORDS words of work area; numpy-stream mode: optional 288-word area for the used-pid bitmap
+// of the generation (default: lent from the idle session pool of the row).
 CC4_HD void env_reset(Ctx x, uint64_t seed, int rng_mode, int steps, bool continue_stream, int policy = 0, uint32_t topo_seed = 0,
                       uint32_t* pid_ws = nullptr, bool rng_is_copy = false) {
   EnvState* s = x.s;
@@ -758,7 +834,9 @@ CC4_HD void env_reset(Ctx x, uint64_t seed, int rng_mode, int steps, bool contin
   Rng keep = s->rng;
   {  // zero everything (POD)
     uint32_t* w = (uint32_t*)s;
-    for (size_t i = 0; i < sizeof(EnvState) / 4; ++i) w[i] = 0;
+    for (size_t i = 0; i < offsetof(EnvState, hd) / 4; ++i) w[i] = 0;
+    uint32_t* hw = (uint32_t*)x.hd;
+    for (size_t i = 0; i < sizeof(HostDyn) * MAXH / 4; ++i) hw[i] = 0;
   }
   if (continue_stream) s->rng = keep; else rng_seed(&s->rng, seed, (uint32_t)rng_mode);  // NOTE: a fresh seed needs x.r == &s->rng;
                                                                                           // a continued stream may be walked on a copy of it
@@ -772,18 +850,20 @@ CC4_HD void env_reset(Ctx x, uint64_t seed, int rng_mode, int steps, bool contin
     int q = steps / 3, rem = steps % 3;
     s->phase_len[0] = q + (rem >= 1 ? 1 : 0); s->phase_len[1] = q + (rem == 2 ? 1 : 0); s->phase_len[2] = q;
   }
-  for (int r = 0; r < NRED; ++r) for (int i = 0; i < MAX_KB / 32; ++i) s->kb_used[r][i] = 0;
   {  // backup images of the previous episode
     uint32_t* w = (uint32_t*)x.c->hs;
     for (size_t i = 0; i < sizeof(x.c->hs) / 4; ++i) w[i] = 0;
   }
-  uint32_t* used = pid_ws ? pid_ws : x.c->eph[H_INTERNET];  // bitmap of used_pids over 1000..9999 (the cold one is cleared by the backup below)
+  // bitmap of used_pids over 1000..9999: by default lent from the session pool, which stays empty until red_agent_0's
+  // session is added at the very end (records 8 .. 151; zeroed again below)
+  static_assert(8 + 288 * 4 / sizeof(RSess) <= RS_POOL, "the used-pid bitmap fits the idle session pool");
+  uint32_t* used = pid_ws ? pid_ws : reinterpret_cast<uint32_t*>(&s->spool[8]);
   for (int i = 0; i < 288; ++i) used[i] = 0;
 
   // _generate_subnets (ESG.py:171-266): choice(len(remaining /24 blocks)) per subnet, pop.  The remaining list stays
   // ascending, so "pop(c)" is the c-th set bit of a 256-bit availability map
   {
-    uint32_t* avail = s->scratch;  // 8 words
+    uint32_t* avail = x.w->scratch;  // 8 words
     for (int i = 0; i < 8; ++i) avail[i] = 0xFFFFFFFFu;
     int n = 256;
     for (int sn = 0; sn < NSUB; ++sn) {
@@ -796,7 +876,7 @@ CC4_HD void env_reset(Ctx x, uint64_t seed, int rng_mode, int steps, bool contin
   }
   // _generate_hosts (ESG.py:312-371): ip_addresses = hosts .1 .. .254 of the /24, ascending
   for (int sn = 0; sn < NSUB; ++sn) {
-    uint32_t* ips = s->scratch;  // bit v set <=> 10.0.X.v still unassigned
+    uint32_t* ips = x.w->scratch;  // bit v set <=> 10.0.X.v still unassigned
     for (int i = 0; i < 8; ++i) ips[i] = 0xFFFFFFFFu;
     ips[0] &= ~1u; ips[7] &= 0x7FFFFFFFu;  // .0 and .255 are not host addresses
     int n = 254;
@@ -805,22 +885,22 @@ CC4_HD void env_reset(Ctx x, uint64_t seed, int rng_mode, int steps, bool contin
       int c = (int)rng_below(x.r, (uint32_t)n);
       uint8_t ip = pop_at(c);
       gen_host(x, H_INTERNET, used);
-      s->hd[H_INTERNET].pad = ip;   // parked in the row's pad byte until the backup image is written
+      x.hd[H_INTERNET].procs[PIN - 1].pid = ip;   // parked in the last inline process slot until the backup image is written
       continue;
     }
     int hr = h_make(sn, 0);
-    { int c = (int)rng_below(x.r, (uint32_t)n); uint8_t ip = pop_at(c); gen_host(x, hr, used); s->hd[hr].pad = ip; }
+    { int c = (int)rng_below(x.r, (uint32_t)n); uint8_t ip = pop_at(c); gen_host(x, hr, used); x.hd[hr].procs[PIN - 1].pid = ip; }
     int nu = 3 + (int)rng_below(x.r, 8);  // integers(3, 10, endpoint=True)
     for (int i = 0; i < nu; ++i) {
       int h = h_make(sn, 1 + i);
       int c = (int)rng_below(x.r, (uint32_t)n); uint8_t ip = pop_at(c);
-      gen_host(x, h, used); s->hd[h].pad = ip;
+      gen_host(x, h, used); x.hd[h].procs[PIN - 1].pid = ip;
     }
     int ns = 1 + (int)rng_below(x.r, 6);  // integers(1, 6, endpoint=True)
     for (int i = 0; i < ns; ++i) {
       int h = h_make(sn, 11 + i);
       int v = last_set(ips, 8); bit_clr(ips, v); n--;  // ip_addresses.pop()
-      gen_host(x, h, used); s->hd[h].pad = (uint8_t)v;
+      gen_host(x, h, used); x.hd[h].procs[PIN - 1].pid = (uint16_t)v;
     }
     s->n_users[sn] = (uint8_t)nu; s->n_servers[sn] = (uint8_t)ns;
   }
@@ -852,31 +932,31 @@ CC4_HD void env_reset(Ctx x, uint64_t seed, int rng_mode, int steps, bool contin
     int c = (int)rng_below(x.r, (uint32_t)cnt);  // choice(non-router hosts): users then servers
     int h = c < s->n_users[sn] ? h_make(sn, 1 + c) : h_make(sn, 11 + (c - s->n_users[sn]));
     s->red[r].start_host = (uint8_t)h;
-    for (int i = 0; i < MAXH; ++i) s->red[r].fsm_state[i] = FS_NONE;
     s->red[r].new_sess_host = 0xFF;
     s->red[r].queue.busy = 0;
   }
   // State.__init__ (State.py:103-136): starting sessions in agent order; parent-less first
   for (int b = 0; b < NBLUE; ++b) {
     int ph = s->blue[b].parent_host;
-    s->blue_pid[ph] = (uint16_t)start_session_proc(x, ph, K_SESS_BLUE);
+    (void)start_session_proc(x, ph, K_SESS_BLUE);
     for (int i = 0; i < blue_nsub(b); ++i) {
       int sn = blue_subnet_alloc(b, i);
       for (int sl = 0; sl < SLOTS; ++sl) {
         int h = h_make(sn, sl);
         if (!bit_get(s->exists, h) || h == ph) continue;
-        s->blue_pid[h] = (uint16_t)start_session_proc(x, h, K_SESS_BLUE);
+        (void)start_session_proc(x, h, K_SESS_BLUE);
       }
     }
   }
-  for (int g = 0; g < s->n_green; ++g) { int h = s->green_host[g]; s->green_pid[h] = (uint16_t)start_session_proc(x, h, K_SESS_GREEN); }
+  for (int g = 0; g < s->n_green; ++g) (void)start_session_proc(x, s->green_host[g], K_SESS_GREEN);
   int red0_pid = start_session_proc(x, s->red[0].start_host, K_SESS_RED);
   // host.create_backup() for every host (State.py:137-138) -> dynamic state := static
   for (int h = 0; h < MAXH; ++h) {
-    if (bit_get(s->exists, h)) { host_backup(x, h, s->hd[h].pad); s->hd[h].pad = 0; s->hd[h].ev = 0; }
+    if (bit_get(s->exists, h)) { host_backup(x, h, x.hd[h].procs[PIN - 1].pid); x.hd[h].procs[PIN - 1].pid = 0; x.hd[h].ev = 0; }
     eph_clear(x, h);
   }
   s->npend = 0;
+  if (!pid_ws) for (int i = 0; i < 288; ++i) used[i] = 0;
   // red_agent_0 starts active with session 0 (ESG.py:791-801)
   {
     int idx = rs_add(x, 0, s->red[0].start_host, red0_pid, RS_ABSTRACT | RS_ORIG);
@@ -956,11 +1036,11 @@ CC4_HD void blue_monitor(Ctx x, int b) {
     for (int sl = 0; sl < SLOTS; ++sl) {
       int h = h_make(sn, sl);
       if (!bit_get(s->exists, h)) continue;
-      uint8_t ev = s->hd[h].ev;
+      uint8_t ev = x.hd[h].ev;
       uint8_t nev = 0;
       if (ev & EV_CUR_CONN) nev |= EV_OLD_CONN;
       if (ev & EV_CUR_PROC) nev |= EV_OLD_PROC;
-      s->hd[h].ev = nev;
+      x.hd[h].ev = nev;
     }
   }
   // session.add_sus_pids for process_creation events that carry a pid
@@ -974,34 +1054,53 @@ CC4_HD void blue_monitor(Ctx x, int b) {
   s->npend = (uint8_t)n;
 }
 // StopProcess.kill_process (ConcreteActions/StopProcess.py:36-58) after get_process / root check (:23-34)
-CC4_HD void stop_process(Ctx x, int h, int pid) {
+// the table index of the host's service whose process is `pid`, or -1
+CC4_HD int svc_of_pid(const HostDyn& d, int pid) {
+  uint32_t sv[MAXSV];
+  __builtin_memcpy(sv, d.svcs, sizeof(sv));
+  const int n = hd_nsvc(d);
+  int si = -1;
+  CC4_UNROLL for (int i = MAXSV - 1; i >= 0; --i) if (i < n && (int)(sv[i] & 0xFFFF) == pid) si = i;
+  return si;
+}
+// The process `pi` of host h (record word pw) dies, whoever asked: the list entry goes, a service process respawns under a
+// new pid, and the session running in it ends (state.get_session_from_pid, State.py:420-443: a blue or green session is
+// recognised by the process kind Host.add_session gave it, a red one by its (host, pid)).
+CC4_HD void kill_process(Ctx x, int h, int pi, uint32_t pw) {
   EnvState* s = x.s;
-  int pi = find_proc(x, h, pid);
-  if (pi < 0) return;
-  Proc p = s->hd[h].procs[pi];
-  if (p.flags & PF_ROOT) return;
-  // state.get_session_from_pid (State.py:420-443): blue, green, then red agents in order
+  const int pid = pw_pid(pw), kind = pw_kind(pw);
   int owner = -1, owner_idx = -1;  // owner: 0 blue, 1 green, 2+r red
-  if (s->blue_pid[h] == pid) owner = 0;
-  else if (s->green_pid[h] == pid) owner = 1;
-  else for (int r = 0; r < NRED && owner < 0; ++r) {
-    if (!bit_get(s->red[r].live_hosts, h)) continue;
-    int i = rs_find_host_pid(s->red[r], h, pid);
-    if (i >= 0) { owner = 2 + r; owner_idx = i; }
+  if (kind == K_SESS_BLUE) owner = 0;
+  else if (kind == K_SESS_GREEN) owner = 1;
+  else if (bit_get(s->red_hosts, h)) {
+    uint32_t lw[NRED];
+    CC4_UNROLL for (int r = 0; r < NRED; ++r) lw[r] = s->red[r].live_hosts[h >> 5];
+    for (int r = 0; r < NRED && owner < 0; ++r) {
+      if (!((lw[r] >> (h & 31)) & 1u)) continue;
+      int i = rs_find_host_pid(s, s->red[r], h, pid);
+      if (i >= 0) { owner = 2 + r; owner_idx = i; }
+    }
   }
   remove_proc_at(x, h, pi);
-  HostDyn& d = s->hd[h];
-  int si = -1;
-  for (int i = 0; i < d.nsvc; ++i) if (d.svcs[i].pid == pid) { si = i; break; }
+  HostDyn& d = x.hd[h];
+  const int si = svc_of_pid(d, pid);
   if (si >= 0) {  // service process respawns under a new pid
     int np = create_pid(x, h);
-    add_proc(x, h, np, p.kind, p.flags);
+    add_proc(x, h, np, kind, pw_flags(pw));
     d.svcs[si].pid = (uint16_t)np;
   }
   if (owner < 0) return;
   if (owner < 2) { set_err(x, E_BLUE_GREEN_SESSION_KILLED); return; }
-  rs_remove_at(x, owner - 2, owner_idx, true);
+  rs_remove_at(x, owner - 2, owner_idx);
   if (si >= 0) set_err(x, E_UNREACHABLE);  // session re-created on a service process: never happens in CC4
+}
+// StopProcess.kill_process (ConcreteActions/StopProcess.py:36-58) after get_process / root check (:23-34)
+CC4_HD void stop_process(Ctx x, int h, int pid) {
+  int pi = find_proc(x, h, pid);
+  if (pi < 0) return;
+  const uint32_t pw = proc_get(x, h, pi);
+  if (pw_flags(pw) & PF_ROOT) return;
+  kill_process(x, h, pi, pw);
 }
 // Remove.execute (AbstractActions/Remove.py:42-71)
 CC4_HD void blue_remove(Ctx x, int b, int h) {
@@ -1010,7 +1109,7 @@ CC4_HD void blue_remove(Ctx x, int b, int h) {
   // The list lives in the cold row (HBM).  It is filtered with 16 independent loads in flight per round into a small LDS
   // work area (12 words per blue agent), then the matching pids are stopped in list order.
   const uint32_t* list = x.c->sus[b];
-  uint16_t* hit = reinterpret_cast<uint16_t*>(x.s->scratch + 12 * b);
+  uint16_t* hit = reinterpret_cast<uint16_t*>(x.w->scratch + 12 * b);
   const int cap = 24, n = A.nsus;
   int i0 = 0;
   while (i0 < n) {
@@ -1037,28 +1136,18 @@ CC4_HD void blue_restore(Ctx x, int h) {
       const int n = a.nsess;
       int orig = -1;
       for (int i0 = 0; i0 < n; i0 += 8) {
-        const S8 q = rs_load8(a, i0);
+        const S8 q = rs_load8(s, a, i0);
         CC4_UNROLL for (int k = 0; k < 8; ++k) if (i0 + k < n && rsw_host(q.v[k]) == h && (rsw_flags(q.v[k]) & RS_ORIG)) orig = i0 + k;   // the last one, as the walk left it
       }
-      if (orig >= 0) rs_move_to_end(a, orig, -1);
+      if (orig >= 0) rs_move_to_end(s, a, orig, -1);
     }
   }
   host_restore(x, h);
 }
 // DecoyAction.execute (ConcreteActions/DecoyActions/DecoyAction.py:47-114) with DeployDecoy candidates (DeployDecoy.py:8-31)
 CC4_HD void blue_decoy(Ctx x, int h) {
-  EnvState* s = x.s;
   uint32_t cand = 8;  // bit i <=> K_DEC_APACHE + i is compatible; vsftpd checks port 21, which nothing uses (DecoyVsftpd.py:17-20)
-  int used = 0;   // Host.is_using_port per factory, 8 process records per round
-  {
-    const HostDyn& dd = s->hd[h];
-    const int n = dd.nproc;
-    for (int i0 = 0; i0 < n; i0 += 8) {
-      uint32_t v[8];
-      CC4_UNROLL for (int k = 0; k < 8; ++k) __builtin_memcpy(&v[k], &dd.procs[i0 + k], 4);
-      CC4_UNROLL for (int k = 0; k < 8; ++k) if (i0 + k < n) used |= kind_port((int)((v[k] >> 16) & 0xFF));
-    }
-  }
+  const int used = proc_ports(x, h);   // Host.is_using_port per factory
   if (!(used & PB_80)) cand |= 1;
   if (!(used & PB_443)) cand |= 2;
   if (!(used & PB_25)) cand |= 4;
@@ -1066,10 +1155,14 @@ CC4_HD void blue_decoy(Ctx x, int h) {
   int pid = create_pid(x, h);
   if (!add_proc(x, h, pid, kind, 0)) return;
   ev_log(x, 250, h, 2, kind, 0, 0xFF, 0, pid);   // the action's own observation: obs.add_process(pid, parent_pid=1, ...) (DecoyAction.py:105-113)
-  HostDyn& d = s->hd[h];
+  HostDyn& d = x.hd[h];
   int si = -1;
-  for (int i = 0; i < d.nsvc; ++i) if (d.svcs[i].kind == kind) { si = i; break; }
-  if (si < 0) si = d.nsvc++;
+  const int nsv = hd_nsvc(d);
+  for (int i = 0; i < nsv; ++i) if (d.svcs[i].kind == kind) { si = i; break; }
+  if (si < 0) {
+    if (nsv >= MAXSV) { set_err(x, E_UNREACHABLE); return; }   // excluded by the port checks (see MAXSV)
+    si = nsv; hd_set_nsvc(d, nsv + 1);
+  }
   d.svcs[si].kind = (uint8_t)kind; d.svcs[si].pid = (uint16_t)pid; d.svcs[si].st = (uint8_t)(SV_ACTIVE | 5);
 }
 CC4_HD void blue_execute(Ctx x, int b, const Act& a) {
@@ -1143,13 +1236,12 @@ CC4_HD void phishing(Ctx x, int gh) {
 }
 // GreenLocalWork.execute (GreenActions/GreenLocalWork.py:60-125). returns success
 CC4_HD bool green_local_work(Ctx x, int gh, bool* want_phish) {
-  EnvState* s = x.s;
-  const HostDyn& d = s->hd[gh];
+  const HostDyn& d = x.hd[gh];
   // the whole service table in one batch of independent loads (each Svc is one little-endian word: pid | kind << 16 | st << 24);
   // everything after that works on registers with constant indices
   uint32_t sv[MAXSV];
   __builtin_memcpy(sv, d.svcs, sizeof(sv));
-  const int nsvc = d.nsvc;
+  const int nsvc = hd_nsvc(d);
   uint32_t act = 0;
   CC4_UNROLL for (int i = 0; i < MAXSV; ++i) if (i < nsvc && ((sv[i] >> 24) & SV_ACTIVE)) act |= 1u << i;
   if (!act) return false;
@@ -1196,7 +1288,7 @@ CC4_HD void red_drs(Ctx x, int r, const Act& a) {
   EnvState* s = x.s;
   int sn = a.arg; bool any = false;
   // the session can die between filter_actions and execution (a blue Remove/Restore runs earlier in the same step)
-  if (rs_find_id(s->red[r], a.sid) < 0) { red_result(x, r, a, T_FALSE); return; }
+  if (rs_find_id(s, s->red[r], a.sid) < 0) { red_result(x, r, a, T_FALSE); return; }
   bool allowed = (red_allowed_mask(r) >> sn) & 1u;  // SimulationController._filter_obs drops foreign-subnet interfaces
   // the subnet's non-router hosts are the 16 ids lo .. lo+15; they straddle at most two bitmap words.  All of them get the same
   // observation entry (obs_put(ip key, OE_IFACE, subnet known)), so the bitmaps are updated per word and the new entries
@@ -1232,23 +1324,30 @@ CC4_HD int port_of_bit(int pb) { return pb == PB_22 ? 22 : (pb == PB_80 ? 80 : (
 CC4_HD void red_scan(Ctx x, int r, const Act& a, double rate) {
   EnvState* s = x.s;
   RedAgent& A = s->red[r];
-  int si = rs_find_id(A, a.sid);
-  if (si < 0 || !(A.sess[si].flags & RS_ABSTRACT)) { red_result(x, r, a, T_FALSE); return; }
-  int src = A.sess[si].host, tgt = a.host;
+  int si = rs_find_id(s, A, a.sid);
+  if (si < 0) { red_result(x, r, a, T_FALSE); return; }
+  const int slot = A.sord[si];
+  const uint64_t sw = rs_word(s, slot);
+  if (!(rsw_flags(sw) & RS_ABSTRACT)) { red_result(x, r, a, T_FALSE); return; }
+  int src = rsw_host(sw), tgt = a.host;
   if (subnet_blocked(x, h_subnet(src), h_subnet(tgt))) { red_result(x, r, a, T_FALSE); return; }
   double fixed = rng_random(x.r);
   int ports = 0;
-  int np = s->hd[tgt].nproc;
-  for (int i = 0; i < np; ++i) {
-    int k = s->hd[tgt].procs[i].kind;
-    int pb = kind_port(k);
-    if (!pb) continue;
-    ports |= pb;
-    if (fixed <= rate || kind_is_decoy(k)) { ev_conn(x, tgt); int ep = eph_port(x, tgt); ev_log(x, 200 + r, tgt, 0, tgt, port_of_bit(pb), src, ep, 0); }   // Portscan.py:59-64
+  const int np = x.hd[tgt].nproc;
+  for (int i0 = 0; i0 < np; i0 += 8) {
+    const P8 q = proc_load8(x, tgt, i0);
+    CC4_UNROLL for (int k8 = 0; k8 < 8; ++k8) {
+      if (i0 + k8 >= np) continue;
+      int k = pw_kind(q.v[k8]);
+      int pb = kind_port(k);
+      if (!pb) continue;
+      ports |= pb;
+      if (fixed <= rate || kind_is_decoy(k)) { ev_conn(x, tgt); int ep = eph_port(x, tgt); ev_log(x, 200 + r, tgt, 0, tgt, port_of_bit(pb), src, ep, 0); }   // Portscan.py:59-64
+    }
   }
   if (ports) {
     obs_put(x, r, true, tgt, OE_IFACE, false);
-    if (A.sess[si].kb != 0xFF) x.c->kports[r * MAX_KB + A.sess[si].kb][tgt] = (uint8_t)(PB_HAS | ports);
+    x.c->kports[slot][tgt] = (uint8_t)(PB_HAS | ports);
   }
   red_result(x, r, a, T_TRUE);
 }
@@ -1257,17 +1356,20 @@ CC4_HD int exploit_new_session(Ctx x, int r, int parent_sid, int tgt) {
   (void)parent_sid;
   int pid = create_pid(x, tgt);
   if (!add_proc(x, tgt, pid, K_SHELL, 0)) return -1;
-  x.s->hd[tgt].pad = (uint8_t)((x.s->hd[tgt].pad | HF_CMD) & ~HF_ESC_LAST);   // target_host.files.append(File('cmd.sh', density 0.9)) (ExploitAction.py:230-238)
-  return rs_add(x, r, tgt, pid, RS_CHILD);   // Session(parent=self.session) (ExploitAction.py:250-259)
+  hd_set_files(x.hd[tgt], (hd_files(x.hd[tgt]) | HF_CMD) & ~HF_ESC_LAST);   // target_host.files.append(File('cmd.sh', density 0.9)) (ExploitAction.py:230-238)
+  return rs_add(x, r, tgt, pid, RS_CHILD, x.w->rs_slot[r]);   // Session(parent=self.session) (ExploitAction.py:250-259); slot reserved by rs_reserve
 }
 // ExploitRemoteService.execute (AbstractActions/ExploitRemoteService.py:149-202) + selector (:37-69)
 CC4_HD void red_exploit(Ctx x, int r, const Act& a) {
   EnvState* s = x.s;
   RedAgent& A = s->red[r];
-  int si = rs_find_id(A, a.sid);
-  if (si < 0 || !(A.sess[si].flags & RS_ABSTRACT) || A.sess[si].kb == 0xFF) { red_result(x, r, a, T_FALSE); return; }
-  int src = A.sess[si].host, tgt = a.host;
-  int known = x.c->kports[r * MAX_KB + A.sess[si].kb][tgt];
+  int si = rs_find_id(s, A, a.sid);
+  if (si < 0) { red_result(x, r, a, T_FALSE); return; }
+  const int slot = A.sord[si];
+  const uint64_t sw = rs_word(s, slot);
+  if (!(rsw_flags(sw) & RS_ABSTRACT)) { red_result(x, r, a, T_FALSE); return; }
+  int src = rsw_host(sw), tgt = a.host;
+  int known = x.c->kports[slot][tgt];
   if (!(known & PB_HAS)) { red_result(x, r, a, T_FALSE); return; }
   if (subnet_blocked(x, h_subnet(src), h_subnet(tgt))) { red_result(x, r, a, T_FALSE); return; }
   // DefaultExploitActionSelector: options in list order with non-zero weight
@@ -1288,14 +1390,17 @@ CC4_HD void red_exploit(Ctx x, int r, const Act& a) {
     sel = nth_bit(opts, (int)rng_below(x.r, (uint32_t)popc32(opts)));
     (void)rng_random(x.r);  // `elif random() < odds_of_top_choice` with odds 0
   }
-  HostDyn& T = s->hd[tgt];
+  const int tnp = x.hd[tgt].nproc;
   if (sel == X_SSH) {
     // SSHBruteForce.execute (ExploitActions/SSHBruteForce.py:24-84)
-    uint8_t* work = reinterpret_cast<uint8_t*>(s->scratch + 6 * r);   // 24 bytes per red agent
+    uint8_t* work = reinterpret_cast<uint8_t*>(x.w->scratch + 6 * r);   // 24 bytes per red agent
     int nh = route(src, tgt, work);
     for (int i = 0; i < nh; ++i) if (0.050000000000000044 < rng_random(x.r)) { ev_conn(x, work[12 + i]); ev_log(x, 200 + r, work[12 + i], 0, tgt, 0, src, 22, 0); }  // 1 - 0.95 in float64
     int vp = -1;
-    for (int i = 0; i < T.nproc; ++i) if (T.procs[i].kind == K_SSHD) { vp = i; break; }
+    for (int i0 = 0; i0 < tnp && vp < 0; i0 += 8) {
+      const P8 q = proc_load8(x, tgt, i0);
+      CC4_UNROLL for (int k = 7; k >= 0; --k) if (i0 + k < tnp && pw_kind(q.v[k]) == K_SSHD) vp = i0 + k;
+    }
     if (vp < 0) { red_result(x, r, a, T_FALSE); return; }
     obs_put(x, r, true, tgt, OE_IFACE, false);   // obs.add_process(target_process) -> interface of the target
     const int bf_port = eph_port(x, tgt);         // local_port
@@ -1303,27 +1408,29 @@ CC4_HD void red_exploit(Ctx x, int r, const Act& a) {
     ev_log(x, 200 + r, tgt, 0, tgt, 22, src, bf_port, 0, 10);
     int ni = exploit_new_session(x, r, a.sid, tgt);
     if (ni < 0) { red_result(x, r, a, T_FALSE); return; }
-    ev_proc_red(x, r, tgt, A.sess[ni].pid);       // _create_new_session_event (always for SSH)
-    ev_log(x, 200 + r, tgt, 1, 0xFF, 0, 0xFF, 0, A.sess[ni].pid);
+    const uint64_t nw = rs_at(s, A, ni);
+    ev_proc_red(x, r, tgt, rsw_pid(nw));       // _create_new_session_event (always for SSH)
+    ev_log(x, 200 + r, tgt, 1, 0xFF, 0, 0xFF, 0, rsw_pid(nw));
     obs_put(x, r, true, tgt, OE_SESS | OE_IFACE | OE_SYSHN, false);
     obs_put(x, r, true, src, OE_IFACE, false);
-    A.new_sess_host = (uint8_t)tgt; A.new_sess_id = A.sess[ni].id;
+    A.new_sess_host = (uint8_t)tgt; A.new_sess_id = (uint16_t)rsw_id(nw);
     red_result(x, r, a, T_TRUE);
     return;
   }
   // ExploitAction.sim_exploit (ExploitActions/ExploitAction.py:48-116)
-  int vp = -1;
-  for (int i = 0; i < T.nproc && vp < 0; ++i) {
-    int k = T.procs[i].kind;
-    bool m = false;
-    if (sel == X_HTTPRFI) m = (k == K_APACHE || k == K_DEC_APACHE || k == K_DEC_VSFTPD);   // WEBSERVER @80
-    else if (sel == X_HTTPSRFI) m = (k == K_DEC_TOMCAT);                                     // WEBSERVER @443
-    else if (sel == X_SQLI) m = (k == K_MYSQL);                                              // MYSQL @3390
-    else if (sel == X_HARAKA) m = (k == K_SMTP || k == K_DEC_HARAKA);                        // SMTP @25
-    if (m) vp = i;
+  int vp = -1, vk = 0;
+  {
+    // the process kinds that answer the chosen exploit, as a bit set over K_*
+    const uint32_t want = sel == X_HTTPRFI ? ((1u << K_APACHE) | (1u << K_DEC_APACHE) | (1u << K_DEC_VSFTPD))   // WEBSERVER @80
+                        : sel == X_HTTPSRFI ? (1u << K_DEC_TOMCAT)                                              // WEBSERVER @443
+                        : sel == X_SQLI ? (1u << K_MYSQL)                                                       // MYSQL @3390
+                        : ((1u << K_SMTP) | (1u << K_DEC_HARAKA));                                              // SMTP @25
+    for (int i0 = 0; i0 < tnp && vp < 0; i0 += 8) {
+      const P8 q = proc_load8(x, tgt, i0);
+      CC4_UNROLL for (int k = 7; k >= 0; --k) if (i0 + k < tnp && ((want >> pw_kind(q.v[k])) & 1u)) { vp = i0 + k; vk = pw_kind(q.v[k]); }
+    }
   }
   if (vp < 0) { red_result(x, r, a, T_FALSE); return; }
-  int vk = T.procs[vp].kind;
   bool decoy = kind_is_decoy(vk);
   const int xport = sel == X_HTTPRFI ? 80 : (sel == X_HTTPSRFI ? 443 : (sel == X_SQLI ? 3390 : 25));
   if (decoy) { ev_conn(x, tgt); int ep = eph_port(x, tgt); ev_log(x, 200 + r, tgt, 0, tgt, xport, src, ep, 0); }  // _get_vulnerable_process alert (ExploitAction.py:189-196)
@@ -1335,10 +1442,11 @@ CC4_HD void red_exploit(Ctx x, int r, const Act& a) {
   if (decoy) { ev_conn(x, tgt); int ep = eph_port(x, tgt); ev_log(x, 200 + r, tgt, 0, tgt, lport, src, ep, 0); red_result(x, r, a, T_FALSE); return; }
   int ni = exploit_new_session(x, r, a.sid, tgt);
   if (ni < 0) { red_result(x, r, a, T_FALSE); return; }
-  if (rng_random(x.r) > 0.050000000000000044) { ev_proc_red(x, r, tgt, A.sess[ni].pid); ev_log(x, 200 + r, tgt, 1, 0xFF, 0, 0xFF, 0, A.sess[ni].pid); }
+  const uint64_t nw = rs_at(s, A, ni);
+  if (rng_random(x.r) > 0.050000000000000044) { ev_proc_red(x, r, tgt, rsw_pid(nw)); ev_log(x, 200 + r, tgt, 1, 0xFF, 0, 0xFF, 0, rsw_pid(nw)); }
   obs_put(x, r, true, tgt, OE_SESS | OE_IFACE | OE_SYSHN, false);
   obs_put(x, r, true, src, OE_IFACE, false);
-  A.new_sess_host = (uint8_t)tgt; A.new_sess_id = A.sess[ni].id;
+  A.new_sess_host = (uint8_t)tgt; A.new_sess_id = (uint16_t)rsw_id(nw);
   red_result(x, r, a, T_TRUE);
 }
 // PrivilegeEscalate.execute (AbstractActions/PrivilegeEscalate.py:127-179)
@@ -1346,25 +1454,26 @@ CC4_HD void red_privesc(Ctx x, int r, const Act& a) {
   EnvState* s = x.s;
   RedAgent& A = s->red[r];
   int h = a.host;
-  const HostSess hs = rs_on_host(A, h);
+  const HostSess hs = rs_on_host(s, A, h);
   const int n = hs.n;
   int target = hs.first_root;
   if (n == 0) { red_result(x, r, a, T_FALSE); return; }
   if (target < 0) {
-    target = rs_kth_on_host(A, h, (int)rng_below(x.r, (uint32_t)n));   // choice(sessions on the host)
+    target = rs_kth_on_host(s, A, h, (int)rng_below(x.r, (uint32_t)n));   // choice(sessions on the host)
     // DefaultEscalateActionSelector (PrivilegeEscalate.py:52-66): self.session must exist and be a RedAbstractSession,
     // else no sub-action -> Observation(False); then V4L2KernelExploit via TargetedLocalAction.execute
-    { int ss = rs_find_id(A, a.sid);
-      if (ss < 0 || !(A.sess[ss].flags & RS_ABSTRACT)) { red_result(x, r, a, T_FALSE); return; } }
-    A.sess[target].flags |= RS_ROOT;  // EscalateAction.__upgrade_session (EscalateAction.py:57-87)
-    s->hd[h].pad |= (uint8_t)(HF_ESC | HF_ESC_LAST);   // ... which also drops File('escalate.sh', density 0.9) on the host (:70-77)
-    int pi = find_proc(x, h, A.sess[target].pid);
-    if (pi >= 0) s->hd[h].procs[pi].flags |= PF_ROOT;
+    { int ss = rs_find_id(s, A, a.sid);
+      if (ss < 0 || !(rsw_flags(rs_at(s, A, ss)) & RS_ABSTRACT)) { red_result(x, r, a, T_FALSE); return; } }
+    const int tslot = A.sord[target];
+    s->spool[tslot].flags |= RS_ROOT;  // EscalateAction.__upgrade_session (EscalateAction.py:57-87)
+    hd_set_files(x.hd[h], hd_files(x.hd[h]) | HF_ESC | HF_ESC_LAST);   // ... which also drops File('escalate.sh', density 0.9) on the host (:70-77)
+    int pi = find_proc(x, h, s->spool[tslot].pid);
+    if (pi >= 0) proc_put(x, h, pi, proc_get(x, h, pi) | ((uint32_t)PF_ROOT << 24));
   }
   obs_put(x, r, false, h, OE_SESS, false);
-  if (A.sess[target].flags & RS_ABSTRACT) as_know_sid(x, r, A.sess[target].id);
+  { const uint64_t tw = rs_at(s, A, target); if (rsw_flags(tw) & RS_ABSTRACT) as_know_sid(x, r, rsw_id(tw)); }
   // ExploreHost (EscalateAction.py:90-106): host.info links exist only on server_host_0 (ESG.py:418-468)
-  if (rs_find_id(A, a.sid) >= 0 && h_slot(h) == 11) {
+  if (rs_find_id(s, A, a.sid) >= 0 && h_slot(h) == 11) {
     uint32_t m = info_links(h_subnet(h));
     for (int sn = 0; sn < NSUB; ++sn) if ((m >> sn) & 1u) obs_put(x, r, false, h_make(sn, 11), OE_IFACE, false);
   }
@@ -1375,12 +1484,12 @@ CC4_HD void red_impact(Ctx x, int r, const Act& a) {
   EnvState* s = x.s;
   RedAgent& A = s->red[r];
   int h = a.host;
-  if (rs_on_host(A, h).first_root < 0) { red_result(x, r, a, T_FALSE); return; }   // no session, or none of them root
-  HostDyn& d = s->hd[h];
+  if (rs_on_host(s, A, h).first_root < 0) { red_result(x, r, a, T_FALSE); return; }   // no session, or none of them root
+  HostDyn& d = x.hd[h];
   int si = -1;
-  for (int i = 0; i < d.nsvc; ++i) if (d.svcs[i].kind == K_OT && (d.svcs[i].st & SV_ACTIVE)) { si = i; break; }
+  for (int i = 0; i < hd_nsvc(d); ++i) if (d.svcs[i].kind == K_OT && (d.svcs[i].st & SV_ACTIVE)) { si = i; break; }
   if (si < 0) { red_result(x, r, a, T_FALSE); return; }
-  if (rs_find_id(A, a.sid) < 0) { red_result(x, r, a, T_FALSE); return; }  // StopService needs self.session too
+  if (rs_find_id(s, A, a.sid) < 0) { red_result(x, r, a, T_FALSE); return; }  // StopService needs self.session too
   d.svcs[si].st &= (uint8_t)~SV_ACTIVE;                      // Host.stop_service (Host.py:295-300)
   int pi = find_proc(x, h, d.svcs[si].pid);                   // State.remove_process (State.py:390-418)
   if (pi >= 0) remove_proc_at(x, h, pi);
@@ -1392,10 +1501,10 @@ CC4_HD void red_degrade(Ctx x, int r, const Act& a) {
   EnvState* s = x.s;
   RedAgent& A = s->red[r];
   int h = a.host;
-  if (rs_on_host(A, h).first_root < 0) { red_result(x, r, a, T_FALSE); return; }   // no session, or none of them root
-  HostDyn& d = s->hd[h];
+  if (rs_on_host(s, A, h).first_root < 0) { red_result(x, r, a, T_FALSE); return; }   // no session, or none of them root
+  HostDyn& d = x.hd[h];
   int n = 0;
-  for (int i = 0; i < d.nsvc; ++i) if (d.svcs[i].st & SV_ACTIVE) {
+  for (int i = 0; i < hd_nsvc(d); ++i) if (d.svcs[i].st & SV_ACTIVE) {
     n++;
     int rel = d.svcs[i].st & 0x7F;
     if (rel > 0) rel--;                                       // Service.degrade_service_reliability (Service.py:33-40)
@@ -1409,15 +1518,19 @@ CC4_HD void red_degrade(Ctx x, int r, const Act& a) {
 CC4_HD void red_deception(Ctx x, int r, const Act& a) {
   EnvState* s = x.s;
   RedAgent& A = s->red[r];
-  if (rs_find_id(A, a.sid) < 0) { red_result(x, r, a, T_FALSE); return; }
+  if (rs_find_id(s, A, a.sid) < 0) { red_result(x, r, a, T_FALSE); return; }
   int tgt = a.host;
-  const HostDyn& d = s->hd[tgt];
-  for (int i = 0; i < d.nproc; ++i) {
-    bool decoy = kind_is_decoy(d.procs[i].kind);
-    bool rep = false;
-    if (rng_random(x.r) <= 0.5 && decoy) rep = true;
-    else if (rng_random(x.r) <= 0.1 && !decoy) rep = true;
-    if (rep) obs_put(x, r, false, tgt, OE_IFACE, false);
+  const int np = x.hd[tgt].nproc;
+  for (int i0 = 0; i0 < np; i0 += 8) {
+    const P8 q = proc_load8(x, tgt, i0);
+    CC4_UNROLL for (int k = 0; k < 8; ++k) {
+      if (i0 + k >= np) continue;
+      bool decoy = kind_is_decoy(pw_kind(q.v[k]));
+      bool rep = false;
+      if (rng_random(x.r) <= 0.5 && decoy) rep = true;
+      else if (rng_random(x.r) <= 0.1 && !decoy) rep = true;
+      if (rep) obs_put(x, r, false, tgt, OE_IFACE, false);
+    }
   }
   red_result(x, r, a, T_TRUE);
 }
@@ -1428,12 +1541,12 @@ CC4_HD void red_session_check(Ctx x, int r) {
   obs_first(x, r, T_TRUE, RA_NONE, 0, 0);
   if (A.nsess == 0) return;
   // the primary (id 0) sits first, or last after a promotion / restore re-insert: look there before scanning
-  if (A.sess[0].id != 0 && A.sess[A.nsess - 1].id != 0 && rs_find_id(A, 0) < 0) {
+  if (rsw_id(rs_at(s, A, 0)) != 0 && rsw_id(rs_at(s, A, A.nsess - 1)) != 0 && rs_find_id(s, A, 0) < 0) {
     int c = (int)rng_below(x.r, (uint32_t)A.nsess);
-    rs_move_to_end(A, c, 0);   // active_sessions.pop(old_id); ident = 0; re-inserted last (RedSessionCheck.py:36-45)
+    rs_move_to_end(s, A, c, 0);   // active_sessions.pop(old_id); ident = 0; re-inserted last (RedSessionCheck.py:36-45)
     // every other session's parent becomes new_primary.name, which is None unless the promoted session is the scenario's
     // own 'red_session_0' (never the case: that one holds id 0 from the start) (RedSessionCheck.py:52-55)
-    for (int i = 0; i < A.nsess; ++i) A.sess[i].flags &= (uint8_t)~RS_CHILD;
+    for (int i = 0; i < A.nsess; ++i) s->spool[A.sord[i]].flags &= (uint8_t)~RS_CHILD;
   }
   // The observation lists every session as a hostname-keyed entry with Sessions / Interface{ip, Subnet} / System info.
   // Instead of materialising one entry per session, its three effects are applied in bulk from RedAgent.live_hosts (the
@@ -1456,7 +1569,7 @@ CC4_HD void red_session_check(Ctx x, int r) {
   // common case (everything known) costs two LDS round trips per eight sessions
   const int n = A.nsess;
   for (int i0 = 0; i0 < n; i0 += 8) {
-    const S8 q = rs_load8(A, i0);
+    const S8 q = rs_load8(s, A, i0);
     uint32_t kw[8];
     CC4_UNROLL for (int k = 0; k < 8; ++k) kw[k] = A.known_bm[(rsw_id(q.v[k]) >> 5) & 7];
     CC4_UNROLL for (int k = 0; k < 8; ++k) {
@@ -1473,44 +1586,31 @@ CC4_HD void red_session_check(Ctx x, int r) {
 CC4_HD void red_withdraw(Ctx x, int r, const Act& a) {
   EnvState* s = x.s;
   RedAgent& A = s->red[r];
-  if (rs_find_id(A, a.sid) < 0) { red_result(x, r, a, T_FALSE); return; }
+  if (rs_find_id(s, A, a.sid) < 0) { red_result(x, r, a, T_FALSE); return; }
   const int h = a.arg;
   // all_agents_sessions = child sessions on the host + parent sessions with ident != 0 + (the acting session if it sits there)
   // held as ids, because killing one shifts the others
-  uint16_t* ids = reinterpret_cast<uint16_t*>(s->scratch + 36);   // after the per-agent route work areas
+  uint16_t* ids = reinterpret_cast<uint16_t*>(x.w->scratch + 36);   // after the per-agent route work areas
   int n = 0;
-  const int cap = (int)((sizeof(s->scratch) - 36 * 4) / 2);
+  const int cap = (int)((sizeof(x.w->scratch) - 36 * 4) / 2);
   for (int pass = 0; pass < 2; ++pass)
     for (int i = 0; i < A.nsess; ++i) {
-      if (A.sess[i].host != h) continue;
-      bool child = (A.sess[i].flags & RS_CHILD) != 0;
-      if ((pass == 0 && child) || (pass == 1 && !child && A.sess[i].id != 0)) { if (n < cap) ids[n++] = A.sess[i].id; else set_err(x, E_RSESS_OVERFLOW); }
+      const uint64_t w = rs_at(s, A, i);
+      if (rsw_host(w) != h) continue;
+      bool child = (rsw_flags(w) & RS_CHILD) != 0;
+      if ((pass == 0 && child) || (pass == 1 && !child && rsw_id(w) != 0)) { if (n < cap) ids[n++] = (uint16_t)rsw_id(w); else set_err(x, E_RSESS_OVERFLOW); }
     }
-  { int self = rs_find_id(A, a.sid); if (A.sess[self].host == h) { if (n < cap) ids[n++] = (uint16_t)a.sid; else set_err(x, E_RSESS_OVERFLOW); } }
+  { int self = rs_find_id(s, A, a.sid); if (rsw_host(rs_at(s, A, self)) == h) { if (n < cap) ids[n++] = (uint16_t)a.sid; else set_err(x, E_RSESS_OVERFLOW); } }
   if (n == 0) { red_result(x, r, a, T_FALSE); return; }
   int ok = T_FALSE;
   for (int k = 0; k < n; ++k) {
     // TargetedLocalAction.execute: both sessions must still exist (the acting one may have been killed earlier in this loop)
-    int self = rs_find_id(A, a.sid), ti = rs_find_id(A, ids[k]);
+    int self = rs_find_id(s, A, a.sid), ti = rs_find_id(s, A, ids[k]);
     if (self < 0 || ti < 0) { ok = T_FALSE; break; }
-    int pid = A.sess[ti].pid;
+    int pid = rsw_pid(rs_at(s, A, ti));
     int pi = find_proc(x, h, pid);
     if (pi < 0) { ok = T_FALSE; break; }
-    // StopProcess.kill_process with stop_all: root processes die too
-    Proc p = s->hd[h].procs[pi];
-    int owner = -1, owner_idx = -1;
-    if (s->blue_pid[h] == pid) owner = 0;
-    else if (s->green_pid[h] == pid) owner = 1;
-    else for (int q = 0; q < NRED && owner < 0; ++q)
-      for (int i = 0; i < s->red[q].nsess; ++i)
-        if (s->red[q].sess[i].pid == pid && s->red[q].sess[i].host == h) { owner = 2 + q; owner_idx = i; break; }
-    remove_proc_at(x, h, pi);
-    HostDyn& d = s->hd[h];
-    int si = -1;
-    for (int i = 0; i < d.nsvc; ++i) if (d.svcs[i].pid == pid) { si = i; break; }
-    if (si >= 0) { int np = create_pid(x, h); add_proc(x, h, np, p.kind, p.flags); d.svcs[si].pid = (uint16_t)np; }
-    if (owner == 0 || owner == 1) set_err(x, E_BLUE_GREEN_SESSION_KILLED);
-    else if (owner >= 2) { rs_remove_at(x, owner - 2, owner_idx, true); if (si >= 0) set_err(x, E_UNREACHABLE); }
+    kill_process(x, h, pi, proc_get(x, h, pi));   // StopProcess.kill_process with stop_all: root processes die too
     ok = T_TRUE;
   }
   red_result(x, r, a, ok);
@@ -1558,14 +1658,23 @@ CC4_HD int fsm_next(int cur, int act, bool success) {
 // (bitmap first, byte store last: with the opposite order hipcc 7.2 -O3 turns the uniform `fsm_step == 0 ? U : K` select
 // feeding the byte store into an s_cselect on a stale SCC in one unrolled copy of the caller's loop -- tools/isa_scan.py
 // checks the built ISA for that pattern)
+// host_states[h] as a nibble: FS_* + 1, 0 = absent (so a zeroed row knows no host)
+CC4_HD int fsm_get(const RedAgent& A, int h) {
+  const int v = (A.fsm_st4[h >> 1] >> (4 * (h & 1))) & 0xF;
+  return v ? v - 1 : FS_NONE;
+}
+CC4_HD void fsm_put(RedAgent& A, int h, int st) {
+  const int sh = 4 * (h & 1);
+  A.fsm_st4[h >> 1] = (uint8_t)((A.fsm_st4[h >> 1] & ~(0xF << sh)) | ((st + 1) << sh));
+}
 CC4_HD void fsm_set_state(RedAgent& A, int h, int st) {
   if (st >= FS_U && st <= FS_RD) bit_set(A.fsm_ur, h); else bit_clr(A.fsm_ur, h);
   if ((st & 1) || st == FS_F) bit_set(A.fsm_nodrs, h); else bit_clr(A.fsm_nodrs, h);
-  A.fsm_state[h] = (uint8_t)st;
+  fsm_put(A, h, st);
 }
 CC4_HD void fsm_apply(Ctx x, int r, int h, int act, bool success) {  // _host_state_transition inner loop (:147-167)
   RedAgent& A = x.s->red[r];
-  int cur = A.fsm_state[h];
+  int cur = fsm_get(A, h);
   if (cur == FS_NONE) return;
   int nx = fsm_next(cur, act, success);
   if (nx == FS_U) nx = ((red_allowed_mask(r) >> h_subnet(h)) & 1u) ? FS_U : FS_F;
@@ -1598,7 +1707,7 @@ CC4_HD void fsm_observe(Ctx x, int r) {
       }
     } else if (t == RA_PRIVESC || t == RA_IMPACT || t == RA_DEGRADE) {
       int h = A.obs_act_host;  // matched through host_states[ip]['hostname']
-      if (A.fsm_state[h] != FS_NONE && bit_get(A.fsm_hn, h)) fsm_apply(x, r, h, t, ok);
+      if (bit_get(A.fsm_known, h) && bit_get(A.fsm_hn, h)) fsm_apply(x, r, h, t, ok);
     } else {
       fsm_apply(x, r, A.obs_act_host, t, ok);
     }
@@ -1613,10 +1722,10 @@ CC4_HD void fsm_observe(Ctx x, int r) {
     bool ip = (f & OE_KEY_IP) || (f & OE_IFACE);
     if (!ip) {
       // ip looked up through a known hostname; unknown -> reference would key host_states[None]
-      if (!(A.fsm_state[h] != FS_NONE && bit_get(A.fsm_hn, h))) { set_err(x, E_UNREACHABLE); }
+      if (!(bit_get(A.fsm_known, h) && bit_get(A.fsm_hn, h))) { set_err(x, E_UNREACHABLE); }
       continue;
     }
-    if (A.fsm_state[h] == FS_NONE) {
+    if (!bit_get(A.fsm_known, h)) {
       fsm_set_state(A, h, A.fsm_step == 0 ? FS_U : FS_K);
       A.fsm_order[A.fsm_n++] = (uint8_t)h;
       bit_set(A.fsm_known, h);
@@ -1631,7 +1740,7 @@ CC4_HD void fsm_observe(Ctx x, int r) {
     seen = b5_or(seen, live);
     if (b5_any(b5_andn(live, known)))
       for (int i = 0; i < A.nsess; ++i) {
-        int h = A.sess[i].host;
+        int h = rsw_host(rs_at(x.s, A, i));
         if (bit_get(A.fsm_known, h)) continue;
         fsm_set_state(A, h, A.fsm_step == 0 ? FS_U : FS_K);
         A.fsm_order[A.fsm_n++] = (uint8_t)h;
@@ -1659,7 +1768,7 @@ CC4_HD int fsm_choose_host_discovery(Ctx x, int r) {
   // available_states in order of first appearance among the known hosts, packed as nibbles
   uint32_t order = 0; int nst = 0; uint32_t seen = 0;
   for (int i = 0; i < A.fsm_n && nst < 8; ++i) {
-    int st = A.fsm_state[A.fsm_order[i]];
+    int st = fsm_get(A, A.fsm_order[i]);
     if (!((seen >> st) & 1u)) { seen |= 1u << st; order |= (uint32_t)st << (4 * nst); nst++; }
   }
   int sum = 0;
@@ -1684,7 +1793,7 @@ CC4_HD int fsm_choose_host_discovery(Ctx x, int r) {
   int n_all = 0, n_srv = 0;
   for (int i = 0; i < A.fsm_n; ++i) {
     int h = A.fsm_order[i];
-    if (A.fsm_state[h] != chosen_state) continue;
+    if (fsm_get(A, h) != chosen_state) continue;
     n_all++;
     if (h_is_server(h) && bit_get(A.fsm_hn, h)) n_srv++;
   }
@@ -1697,7 +1806,7 @@ CC4_HD int fsm_choose_host_discovery(Ctx x, int r) {
   int c = (int)rng_below(x.r, (uint32_t)cnt);
   for (int i = 0; i < A.fsm_n; ++i) {
     int h = A.fsm_order[i];
-    if (A.fsm_state[h] != chosen_state) continue;
+    if (fsm_get(A, h) != chosen_state) continue;
     bool srv = h_is_server(h) && bit_get(A.fsm_hn, h);
     if (want_srv >= 0 && (int)srv != want_srv) continue;
     if (c-- == 0) return h;
@@ -1721,7 +1830,8 @@ CC4_HD Act fsm_get_action(Ctx x, int r) {
   // are multiples of 1/4, so cdf.searchsorted(u, 'right') == #{i : 4*cdf[i] <= floor(4u)}.  Packed per state:
   // low 16 bits = option nibbles, high 16 bits = 4*cdf nibbles (unused slots = 15)
   uint32_t pk;
-  if (!discovery) switch (A.fsm_state[host]) {
+  const int host_state = fsm_get(A, host);
+  if (!discovery) switch (host_state) {
     case FS_K:  pk = 0xF432u << 16 | (RA_DRS | RA_AGGR << 4 | RA_STEALTH << 8); break;                          // .5 .25 .25
     case FS_KD: pk = 0xFF42u << 16 | (RA_AGGR | RA_STEALTH << 4); break;                                         // .5 .5
     case FS_S:  pk = 0xF431u << 16 | (RA_DRS | RA_EXPLOIT << 4 | RA_DECEPTION << 8); break;                     // .25 .5 .25
@@ -1730,7 +1840,7 @@ CC4_HD Act fsm_get_action(Ctx x, int r) {
     case FS_UD: pk = 0xFF44u << 16 | (RA_PRIVESC | RA_WITHDRAW << 4); break;                                     // 1 0
     case FS_R:  pk = 0x4432u << 16 | (RA_DRS | RA_DEGRADE << 4 | RA_IMPACT << 8 | RA_WITHDRAW << 12); break;    // .5 .25 .25 0
     default:    pk = 0xF442u << 16 | (RA_DEGRADE | RA_IMPACT << 4 | RA_WITHDRAW << 8); break;                   // RD: .5 .5 0
-  } else switch (A.fsm_state[host]) {  // DiscoveryFSRed.state_transitions_probability (FSMRedVariants.py:111-122)
+  } else switch (host_state) {  // DiscoveryFSRed.state_transitions_probability (FSMRedVariants.py:111-122)
     case FS_K:  pk = 0xF441u << 16 | (RA_DRS | RA_AGGR << 4 | RA_STEALTH << 8); break;                          // .25 .75 0
     case FS_KD: pk = 0xFF44u << 16 | (RA_AGGR | RA_STEALTH << 4); break;                                         // 1 0
     case FS_S:  pk = 0xF441u << 16 | (RA_DRS | RA_EXPLOIT << 4 | RA_DECEPTION << 8); break;                     // .25 .75 0
@@ -1829,15 +1939,15 @@ CC4_HD uint32_t red_zone_hosts(int r, int w) {
 CC4_HD void red_reassign(Ctx x, uint32_t foreign) {   // foreign: red_foreign_agents(s), != 0
   EnvState* s = x.s;
   // moves are collected first (the reference builds the list, then applies it), one packed word each in the shared work
-  // area: from | to << 3 | session index << 8 | session id << 16
-  uint32_t* mv = s->scratch; int nm = 0;
-  const int cap = (int)(sizeof(s->scratch) / 4);
+  // area: from | to << 3 | list index << 6 | pool slot << 12
+  uint32_t* mv = x.w->scratch; int nm = 0;
+  const int cap = (int)(sizeof(x.w->scratch) / 4);
   for (int r = 0; r < NRED; ++r) {
     if (!((foreign >> r) & 1u)) continue;
     const RedAgent& A = s->red[r];
     const int n = A.nsess;
     for (int i0 = 0; i0 < n; i0 += 8) {   // 8 session records per round (see rs_load8)
-      const S8 q = rs_load8(A, i0);
+      const S8 q = rs_load8(s, A, i0);
       CC4_UNROLL for (int k = 0; k < 8; ++k) {
         if (i0 + k >= n) continue;
         const int host = rsw_host(q.v[k]);
@@ -1845,35 +1955,40 @@ CC4_HD void red_reassign(Ctx x, uint32_t foreign) {   // foreign: red_foreign_ag
         if ((red_allowed_mask(r) >> sn) & 1u) continue;
         const int to = red_of_subnet(sn);
         if (to < 0) { set_err(x, E_UNREACHABLE); continue; }
-        if (nm < cap) mv[nm++] = (uint32_t)r | ((uint32_t)to << 3) | ((uint32_t)(i0 + k) << 8) | ((uint32_t)rsw_id(q.v[k]) << 16);
+        if (nm < cap) mv[nm++] = (uint32_t)r | ((uint32_t)to << 3) | ((uint32_t)(i0 + k) << 6) | ((uint32_t)s8_slot(q, k) << 12);
         else set_err(x, E_RSESS_OVERFLOW);
       }
     }
   }
-  // A source agent's moves come in table order, and sessions gained on the way are appended behind: the record sits at its
-  // collection index minus the number of this agent's earlier removals (checked against the id; the scan is the fallback)
+  // A move takes the entry out of the source agent's list and appends the same pool record to the target's (new ident, a fresh
+  // RedAbstractSession: no port knowledge).  A source agent's moves come in list order and sessions gained on the way are
+  // appended behind, so the entry sits at its collection index minus the number of this agent's earlier removals (checked
+  // against the slot; the scan is the fallback).
   int gone_from[NRED];
   CC4_UNROLL for (int r = 0; r < NRED; ++r) gone_from[r] = 0;
   for (int m = 0; m < nm; ++m) {
     const uint32_t w = mv[m];
-    const int from = (int)(w & 7u), to = (int)((w >> 3) & 7u), id = (int)(w >> 16);
+    const int from = (int)(w & 7u), to = (int)((w >> 3) & 7u), slot = (int)((w >> 12) & 0xFFu);
     RedAgent& F = s->red[from];
     int shift = 0;
     CC4_UNROLL for (int r = 0; r < NRED; ++r) if (r == from) shift = gone_from[r];
-    int i = (int)((w >> 8) & 0xFFu) - shift;
-    uint64_t rec;
-    __builtin_memcpy(&rec, &F.sess[i < 0 ? 0 : i], 8);
-    if (i < 0 || i >= F.nsess || rsw_id(rec) != id) { i = rs_find_id(F, id); if (i < 0) continue; __builtin_memcpy(&rec, &F.sess[i], 8); }
+    int i = (int)((w >> 6) & 0x3Fu) - shift;
+    if (i < 0 || i >= F.nsess || F.sord[i] != slot) {
+      i = -1;
+      for (int k = 0; k < F.nsess; ++k) if (F.sord[k] == slot) { i = k; break; }
+      if (i < 0) continue;
+    }
     CC4_UNROLL for (int r = 0; r < NRED; ++r) if (r == from) gone_from[r]++;
-    const int old_host = rsw_host(rec), old_pid = rsw_pid(rec), old_flags = rsw_flags(rec), old_id = id;
+    const uint64_t rec = rs_word(s, slot);
+    const int old_host = rsw_host(rec), old_pid = rsw_pid(rec), old_flags = rsw_flags(rec), old_id = rsw_id(rec);
     rs_remove_at(x, from, i, true);
-    int ni = rs_add(x, to, old_host, old_pid, RS_ABSTRACT | (old_flags & RS_ROOT));
-    if (ni < 0) continue;
+    int ni = rs_add(x, to, old_host, old_pid, RS_ABSTRACT | (old_flags & RS_ROOT), slot);
+    if (ni < 0) { bit_clr_shared(s->spool_used, slot); continue; }
     // observation hand-over: only if the creating action's observation carries the host ip key with this session
     if (F.new_sess_host == old_host && F.new_sess_id == old_id) {
       obs_first(x, to, T_UNKNOWN, RA_NONE, 0, 0);
       obs_put(x, to, true, old_host, OE_SESS | OE_IFACE | OE_SYSHN, false);
-      as_know_sid(x, to, s->red[to].sess[ni].id);
+      as_know_sid(x, to, rsw_id(rs_at(s, s->red[to], ni)));
     }
   }
   int ns[NRED];
@@ -1946,9 +2061,9 @@ CC4_HD bool step_begin(Ctx x, const int32_t* actions) {
   return true;
 }
 CC4_HD void step_green_policy(Ctx x, int g) {
-  if (x.s->policy & GP_SLEEP_BIT) { x.s->green_act[g] = 2; return; }   // green_agent_class=SleepAgent: no draw, Sleep
+  if (x.s->policy & GP_SLEEP_BIT) { x.w->green_act[g] = 2; return; }   // green_agent_class=SleepAgent: no draw, Sleep
   rng_set_stream(x.r, ST_GREEN_POL + (uint32_t)g);
-  x.s->green_act[g] = (uint8_t)rng_below(x.r, 3);  // choice([GreenAccessService, GreenLocalWork, Sleep])
+  x.w->green_act[g] = (uint8_t)rng_below(x.r, 3);  // choice([GreenAccessService, GreenLocalWork, Sleep])
 }
 CC4_HD void step_red_policy(Ctx x, int r) {
   RedAgent& A = x.s->red[r];
@@ -2008,7 +2123,7 @@ CC4_HD int step_tick_agent(Ctx x, int a) {
   if (q.ticks < 1) { s->rexec[r] = q; q.busy = 0; }
   else { z.type = RA_SLEEP; s->rexec[r] = z; obs_first(x, r, T_IN_PROGRESS, RA_NONE, 0, 0); }
   A.exec_type = s->rexec[r].type; A.exec_host = s->rexec[r].host;
-  if (s->rexec[r].type <= RA_WITHDRAW && rs_find_id(A, s->rexec[r].sid) < 0) { s->rexec[r].type = RA_NONE; return 1; }
+  if (s->rexec[r].type <= RA_WITHDRAW && rs_find_id(s, A, s->rexec[r].sid) < 0) { s->rexec[r].type = RA_NONE; return 1; }
   return 0;
 }
 CC4_HD void step_tick(Ctx x) {
@@ -2024,11 +2139,12 @@ CC4_HD int step_green_exec(Ctx x, int g, const uint32_t* pre = nullptr) {
   int own = h_subnet(gh);
   rng_set_stream(x.r, ST_GREEN_EXE + (uint32_t)g);
   if (pre) rng_preload(x.r, pre);
-  if (s->green_act[g] == 0) return green_access_service(x, gh) ? 0 : reward_table(s->phase, own, RW_ASF);
-  if (s->green_act[g] == 1) {
+  const int act = x.w->green_act[g];
+  if (act == 0) return green_access_service(x, gh) ? 0 : reward_table(s->phase, own, RW_ASF);
+  if (act == 1) {
     bool want_phish = false;
     bool ok = green_local_work(x, gh, &want_phish);
-    if (want_phish) bit_set_shared(s->phish_mask, g);   // green agents may be resolved on different lanes
+    if (want_phish) bit_set_shared(x.w->phish_mask, g);   // green agents may be resolved on different lanes
     return ok ? 0 : reward_table(s->phase, own, RW_LWF);
   }
   return 0;
@@ -2036,9 +2152,9 @@ CC4_HD int step_green_exec(Ctx x, int g, const uint32_t* pre = nullptr) {
 CC4_HD void step_phishing(Ctx x) {
   EnvState* s = x.s;
   for (int w = 0; w < 3; ++w) {   // green agent order
-    uint32_t m = s->phish_mask[w];
+    uint32_t m = x.w->phish_mask[w];
     if (!m) continue;
-    s->phish_mask[w] = 0;
+    x.w->phish_mask[w] = 0;
     while (m) {
       int g = w * 32 + ctz32(m); m &= m - 1;
       rng_set_stream(x.r, ST_GREEN_PHISH + (uint32_t)g);
@@ -2081,6 +2197,7 @@ CC4_HD uint32_t red_conflict_mask(const EnvState* s) {
   return withdraw ? (1u << NRED) - 1u : m;
 }
 CC4_HD void step_red_exec(Ctx x) {
+  rs_reserve(x);
   for (int r = 0; r < NRED; ++r) step_red_exec_agent(x, r);
   step_red_merge(x);
   CC4_TICK(x, 7);
@@ -2099,10 +2216,10 @@ CC4_HD void step_reassign(Ctx x, uint32_t foreign) {   // foreign = red_foreign_
 CC4_HD void step_monitor_host(Ctx x, int h) {  // the per-host part of Monitor.execute
   EnvState* s = x.s;
   if (!bit_get(s->exists, h) || blue_of_subnet(h_subnet(h)) < 0) return;
-  uint8_t ev = s->hd[h].ev, nev = 0;
+  uint8_t ev = x.hd[h].ev, nev = 0;
   if (ev & EV_CUR_CONN) nev |= EV_OLD_CONN;
   if (ev & EV_CUR_PROC) nev |= EV_OLD_PROC;
-  s->hd[h].ev = nev;
+  x.hd[h].ev = nev;
 }
 CC4_HD void step_monitor_pend(Ctx x) {  // session.add_sus_pids for the pid-carrying process_creation events
   EnvState* s = x.s;
@@ -2154,7 +2271,7 @@ CC4_HD void env_step(Ctx x, const int32_t* actions, const uint8_t* messages /* [
   step_tick(x);
   for (int g = 0; g < s->n_green; ++g) {
     s->brm += step_green_exec(x, g);
-    if (bit_get(s->phish_mask, g)) { bit_clr(s->phish_mask, g); rng_set_stream(x.r, ST_GREEN_PHISH + (uint32_t)g); phishing(x, s->green_host[g]); }
+    if (bit_get(x.w->phish_mask, g)) { bit_clr(x.w->phish_mask, g); rng_set_stream(x.r, ST_GREEN_PHISH + (uint32_t)g); phishing(x, s->green_host[g]); }
   }
   CC4_TICK(x, 6);
   step_red_exec(x);
@@ -2175,7 +2292,7 @@ CC4_HD void env_step(Ctx x, const int32_t* actions, const uint8_t* messages /* [
 // phase word + 32 message bits.  The device encodes the parts on separate lanes; the host loops over them.
 enum : int { OBS_PARTS = 12 };
 template <typename T>
-CC4_HD void env_flat_obs_part(const EnvState* s, T* out, int part) {
+CC4_HD void env_flat_obs_part(const EnvState* s, const HostDyn* hd, T* out, int part) {
   if (part < 7) {
     int b = part < 4 ? part : 4, i = part < 4 ? 0 : part - 4;
     int o = (b < 4 ? b * OBS_SHORT : 4 * OBS_SHORT) + 1 + 59 * i;
@@ -2190,7 +2307,7 @@ CC4_HD void env_flat_obs_part(const EnvState* s, T* out, int part) {
     }
     for (int hs = 0; hs < ZONE_HOSTS; ++hs) {
       int h = hs < MAX_SERVERS ? h_make(sn, 11 + hs) : h_make(sn, 1 + (hs - MAX_SERVERS));
-      int ev = bit_get(s->exists, h) ? s->hd[h].ev : 0;
+      int ev = bit_get(s->exists, h) ? hd[h].ev : 0;
       out[o + 27 + hs] = (T)((ev & (EV_CUR_PROC | EV_OLD_PROC)) != 0);
       out[o + 43 + hs] = (T)((ev & (EV_CUR_CONN | EV_OLD_CONN)) != 0);
     }
@@ -2204,7 +2321,7 @@ CC4_HD void env_flat_obs_part(const EnvState* s, T* out, int part) {
   }
 }
 // the same vector, one value at a time (value `idx` of the 578): what the device encodes with one value per thread
-CC4_HD int env_flat_obs_at(const EnvState* s, int idx) {
+CC4_HD int env_flat_obs_at(const EnvState* s, const HostDyn* hd, int idx) {
   const int b = idx < 4 * OBS_SHORT ? idx / OBS_SHORT : 4;
   const int j = idx - (b < 4 ? b * OBS_SHORT : 4 * OBS_SHORT);
   const int len = b < 4 ? OBS_SHORT : OBS_LONG;
@@ -2220,13 +2337,13 @@ CC4_HD int env_flat_obs_at(const EnvState* s, int idx) {
   if (k < 27) return !((comms_adjacent(s->phase, sn) >> sorted_subnet(k - 18)) & 1u);
   const int hs = k < 43 ? k - 27 : k - 43;
   const int h = hs < MAX_SERVERS ? h_make(sn, 11 + hs) : h_make(sn, 1 + (hs - MAX_SERVERS));
-  const int ev = s->hd[h].ev;   // rows of hosts that do not exist stay zero (env_reset), so no existence test is needed
+  const int ev = hd[h].ev;   // rows of hosts that do not exist stay zero (env_reset), so no existence test is needed
   return k < 43 ? ((ev & (EV_CUR_PROC | EV_OLD_PROC)) != 0) : ((ev & (EV_CUR_CONN | EV_OLD_CONN)) != 0);
 }
 // The same 578 values enumerated kind by kind (v = 0..577), so that the lanes of a wave take the same branch:
 //   [0,224) host events (7 subnet blocks x {16 process, 16 connection}), [224,287) blocked bits, [287,350) comms policy,
 //   [350,413) subnet one-hot, [413,573) message bits (5 agents x 32), [573,578) the 5 phase words.  *idx = position in the vector.
-CC4_HD int env_flat_obs_sorted(const EnvState* s, int v, int* idx) {
+CC4_HD int env_flat_obs_sorted(const EnvState* s, const HostDyn* hd, int v, int* idx) {
   if (v < 413) {
     int sb, k;       // subnet block 0..6 (agents 0..3 own one, agent 4 owns three), offset inside the 59-value block
     if (v < 224) { sb = v >> 5; const int r = v & 31; k = 27 + (r & 15) + ((r >> 4) ? 16 : 0); }
@@ -2237,7 +2354,7 @@ CC4_HD int env_flat_obs_sorted(const EnvState* s, int v, int* idx) {
     if (k >= 27) {
       const int hs = k < 43 ? k - 27 : k - 43;
       const int h = hs < MAX_SERVERS ? h_make(sn, 11 + hs) : h_make(sn, 1 + (hs - MAX_SERVERS));
-      const int ev = s->hd[h].ev;   // rows of hosts that do not exist stay zero (env_reset)
+      const int ev = hd[h].ev;   // rows of hosts that do not exist stay zero (env_reset)
       return k < 43 ? ((ev & (EV_CUR_PROC | EV_OLD_PROC)) != 0) : ((ev & (EV_CUR_CONN | EV_OLD_CONN)) != 0);
     }
     if (k < 9) return sorted_subnet(k) == sn;
@@ -2254,8 +2371,8 @@ CC4_HD int env_flat_obs_sorted(const EnvState* s, int v, int* idx) {
   return s->phase;
 }
 template <typename T>
-CC4_HD void env_flat_obs(const EnvState* s, T* out) {
-  for (int p = 0; p < OBS_PARTS; ++p) env_flat_obs_part<T>(s, out, p);
+CC4_HD void env_flat_obs(const EnvState* s, const HostDyn* hd, T* out) {
+  for (int p = 0; p < OBS_PARTS; ++p) env_flat_obs_part<T>(s, hd, out, p);
 }
 
 }  // namespace cc4

@@ -24,7 +24,13 @@
 
 namespace cc4 {
 
-inline std::string export_true_state(const EnvState& s, const HostStatic* hs, const uint32_t (*sus)[MAX_SUS], const EvLog* lg = nullptr) {
+// process i of host h: the hot part of the list, then the cold part (EnvCold.povf)
+inline Proc export_proc(const EnvState& s, const EnvCold& c, int h, int i) { return i < PIN ? s.hd[h].procs[i] : c.povf[h][i - PIN]; }
+
+inline std::string export_true_state(const EnvState& s, const EnvCold& cold, bool with_log = true) {
+  const HostStatic* hs = cold.hs;
+  const uint32_t (*sus)[MAX_SUS] = cold.sus;
+  const EvLog* lg = with_log ? &cold.evlog : nullptr;
   std::string o;
   char b[256];
   auto add = [&](const char* fmt, auto... a) { snprintf(b, sizeof(b), fmt, a...); o += b; };
@@ -39,17 +45,23 @@ inline std::string export_true_state(const EnvState& s, const HostStatic* hs, co
     const HostDyn& d = s.hd[h];
     add("%s{\"h\":%d,\"ip\":%u,\"os\":%u,\"procs\":[", first ? "" : ",", h, (unsigned)hs[h].ip_octet, (unsigned)((hs[h].exists >> 1) & 1));
     first = false;
-    for (int i = 0; i < d.nproc; ++i) add("%s[%u,%u,%u]", i ? "," : "", (unsigned)d.procs[i].pid, (unsigned)d.procs[i].kind, (unsigned)(d.procs[i].flags & PF_ROOT));
+    unsigned blue_pid = 0, green_pid = 0;   // the session processes Host.add_session created for the blue / green agent
+    for (int i = 0; i < d.nproc; ++i) {
+      const Proc pr = export_proc(s, cold, h, i);
+      add("%s[%u,%u,%u]", i ? "," : "", (unsigned)pr.pid, (unsigned)pr.kind, (unsigned)(pr.flags & PF_ROOT));
+      if (pr.kind == K_SESS_BLUE) blue_pid = pr.pid;
+      if (pr.kind == K_SESS_GREEN) green_pid = pr.pid;
+    }
     o += "],\"svcs\":[";
-    for (int i = 0; i < d.nsvc; ++i)
+    for (int i = 0; i < hd_nsvc(d); ++i)
       add("%s[%u,%u,%u,%u]", i ? "," : "", (unsigned)d.svcs[i].kind, (unsigned)((d.svcs[i].st & SV_ACTIVE) ? 1 : 0), (unsigned)(d.svcs[i].st & 0x7F) * 20u, (unsigned)d.svcs[i].pid);
-    add("],\"ev\":%u,\"files\":%u,\"blue\":%u,\"green\":%u}", (unsigned)d.ev, (unsigned)d.pad, (unsigned)s.blue_pid[h], (unsigned)s.green_pid[h]);
+    add("],\"ev\":%u,\"files\":%u,\"blue\":%u,\"green\":%u}", (unsigned)d.ev, (unsigned)hd_files(d), blue_pid, green_pid);
   }
   o += "],\"red\":[";
   for (int r = 0; r < NRED; ++r) {
     const RedAgent& A = s.red[r];
     add("%s{\"active\":%u,\"sessions\":[", r ? "," : "", (unsigned)A.active);
-    for (int i = 0; i < A.nsess; ++i) add("%s[%u,%u,%u,%u]", i ? "," : "", (unsigned)A.sess[i].id, (unsigned)A.sess[i].host, (unsigned)A.sess[i].pid, (unsigned)A.sess[i].flags);
+    for (int i = 0; i < A.nsess; ++i) { const RSess& q = s.spool[A.sord[i]]; add("%s[%u,%u,%u,%u]", i ? "," : "", (unsigned)q.id, (unsigned)q.host, (unsigned)q.pid, (unsigned)q.flags); }
     o += "]}";
   }
   o += "],\"blue\":[";

@@ -1,11 +1,14 @@
 // cc4_hip.hip -- gfx950 kernels + the C ABI (include/cc4.h) of libcc4.so.
 //
-// Execution model of the numpy-stream kernel (k_step): one 64-lane wavefront per episode.  The wave stages the episode's packed
-// EnvState row (28.4 KB) HBM -> LDS with coalesced 16-byte loads, lane 0 walks the strictly ordered
-// transition (the reference's ~57 agent actions share one RNG stream, so the order is the semantics),
-// the wave encodes the 578 flat-observation values, and the row goes back LDS -> HBM coalesced.
-// The cold part of the episode (ephemeral-port bitmaps, per-session port knowledge; 249 KB) stays in HBM
-// and is touched a handful of times per step.  The counter-mode kernel (k_step_philox, below) runs four wavefronts per episode.
+// Execution model of the numpy-stream kernel (k_step): one 64-lane wavefront per episode.  The wave stages the agent part of the
+// episode's packed EnvState row (everything in front of the host table: 6.9 KB) HBM -> LDS with coalesced 16-byte loads and
+// leaves the host table (8.8 KB, of which a step visits a few dozen rows) in HBM/L2 -- LDS is what bounds the number of
+// resident waves of this kernel, and its one working lane hides memory latency only through them.  Lane 0 walks the
+// strictly ordered transition (the reference's ~57 agent actions share one RNG stream, so the order is the semantics),
+// the wave encodes the 578 flat-observation values, and the agent part goes back LDS -> HBM coalesced.
+// The cold part of the episode (process-list overflow, ephemeral-port bitmaps, per-session port knowledge) stays in HBM
+// and is touched a handful of times per step.  The counter-mode kernel (k_step_philox, below) stages the whole row and
+// runs four wavefronts per episode.
 // No MFMA: the path is integer / indexing.
 #include <hip/hip_runtime.h>
 #include <hip/hip_ext.h>
@@ -25,8 +28,9 @@
 
 using namespace cc4;
 
-static_assert(sizeof(EnvState) % 16 == 0, "EnvState rows are staged with 16-byte accesses");
+static_assert(sizeof(EnvState) % 16 == 0 && offsetof(EnvState, hd) % 16 == 0, "EnvState rows are staged with 16-byte accesses");
 constexpr int ROW_VEC = (int)(sizeof(EnvState) / 16);
+constexpr int HOT_VEC = (int)(offsetof(EnvState, hd) / 16);   // the part in front of the host table
 constexpr int WAVE = 64;
 constexpr int OBS_PACKED = CC4_OBS_PACKED_BYTES;   // every flat-observation value is 0, 1 or 2: the exchange moves 2 bits per value
 static_assert(OBS_PACKED % 4 == 0 && OBS_PACKED * 4 >= OBS_TOTAL, "packed observation row: whole words, four values per byte");
@@ -56,29 +60,31 @@ __device__ __forceinline__ int32_t random_blue_action(uint64_t seed0, uint32_t t
 
 // ---------------------------------------------------------------- kernels
 // HBM -> LDS row staging with 8 independent 16-byte loads in flight per lane (a plain copy loop serialises on vmcnt)
+template <int NVEC>
 __device__ __forceinline__ void stage_in(uint4* __restrict__ lds, const uint4* __restrict__ src, int lane) {
-  constexpr int U = 8;
+  constexpr int U = NVEC / WAVE < 8 ? (NVEC / WAVE > 0 ? NVEC / WAVE : 1) : 8;
   int i = lane;
-  for (; i + (U - 1) * WAVE < ROW_VEC; i += U * WAVE) {
+  for (; i + (U - 1) * WAVE < NVEC; i += U * WAVE) {
     uint4 v[U];
 #pragma unroll
     for (int u = 0; u < U; ++u) v[u] = src[i + u * WAVE];
 #pragma unroll
     for (int u = 0; u < U; ++u) lds[i + u * WAVE] = v[u];
   }
-  for (; i < ROW_VEC; i += WAVE) lds[i] = src[i];
+  for (; i < NVEC; i += WAVE) lds[i] = src[i];
 }
+template <int NVEC>
 __device__ __forceinline__ void stage_out(uint4* __restrict__ dst, const uint4* __restrict__ lds, int lane) {
-  constexpr int U = 8;
+  constexpr int U = NVEC / WAVE < 8 ? (NVEC / WAVE > 0 ? NVEC / WAVE : 1) : 8;
   int i = lane;
-  for (; i + (U - 1) * WAVE < ROW_VEC; i += U * WAVE) {
+  for (; i + (U - 1) * WAVE < NVEC; i += U * WAVE) {
     uint4 v[U];
 #pragma unroll
     for (int u = 0; u < U; ++u) v[u] = lds[i + u * WAVE];
 #pragma unroll
     for (int u = 0; u < U; ++u) dst[i + u * WAVE] = v[u];
   }
-  for (; i < ROW_VEC; i += WAVE) dst[i] = lds[i];
+  for (; i < NVEC; i += WAVE) dst[i] = lds[i];
 }
 
 // LOG: record the HostEvents entries of the step (cc4_enable_event_log).  A template parameter rather than a run-time flag: even
@@ -98,14 +104,16 @@ __global__ __launch_bounds__(WAVE) void k_step(StepArgs a) {
   extern __shared__ uint4 lds[];
   __shared__ uint8_t obs_lds[OBS_TOTAL + 2];
   __shared__ int ok_lds;
-  __shared__ uint32_t reset_ws[288];   // used-pid bitmap of the scenario generation (autoreset)
+  __shared__ StepWork work;
   const int e = blockIdx.x, lane = threadIdx.x;
   if (e >= a.n) return;
   unsigned long long t_begin = a.prof ? clock64() : 0;
   const uint4* src = reinterpret_cast<const uint4*>(a.st + e);
-  stage_in(lds, src, lane);
+  stage_in<HOT_VEC>(lds, src, lane);
+  for (int i = lane; i < (int)(sizeof(StepWork) / 4); i += WAVE) reinterpret_cast<uint32_t*>(&work)[i] = 0;
   __syncthreads();
-  EnvState* s = reinterpret_cast<EnvState*>(lds);
+  EnvState* s = reinterpret_cast<EnvState*>(lds);   // only the part in front of EnvState.hd is valid here
+  HostDyn* const hd = a.st[e].hd;                   // the host table stays in HBM / L2
   __shared__ unsigned long long prof_lds[16];   // phase counters accumulate in LDS, flushed once at the end
   unsigned long long* prof = a.prof ? prof_lds : nullptr;
   if (prof && lane < 16) prof_lds[lane] = 0;
@@ -114,14 +122,14 @@ __global__ __launch_bounds__(WAVE) void k_step(StepArgs a) {
   Rng rl = s->rng;
   rl.mode = 0;
   rl.pad = 0;
-  Ctx x{s, a.cold + e, &rl, lane == 0 ? prof : nullptr};
+  Ctx x{s, a.cold + e, &rl, hd, &work, lane == 0 ? prof : nullptr};
   x.lg = LOG ? &a.cold[e].evlog : nullptr;
   if (prof && lane == 0) prof[11] += clock64() - t_begin;
   const bool do_reset = a.autoreset && s->done;
   if (lane == 0) {
     ok_lds = 0;
     if (do_reset) {
-      env_reset(x, 0, 0, a.steps, true, a.policy, a.topo, reset_ws);   // new episode, same stream (CybORG.reset(seed=None)); this kernel serves the numpy-stream mode only
+      env_reset(x, 0, 0, a.steps, true, a.policy, a.topo);   // new episode, same stream (CybORG.reset(seed=None)); this kernel serves the numpy-stream mode only
     } else {
       CC4_TICK0(x);
       int32_t racts[NBLUE];
@@ -140,7 +148,7 @@ __global__ __launch_bounds__(WAVE) void k_step(StepArgs a) {
         step_tick(x);
         for (int g = 0; g < s->n_green; ++g) {
           s->brm += step_green_exec(x, g);
-          if (bit_get(s->phish_mask, g)) { bit_clr(s->phish_mask, g); phishing(x, s->green_host[g]); }
+          if (bit_get(work.phish_mask, g)) { bit_clr(work.phish_mask, g); phishing(x, s->green_host[g]); }
         }
         CC4_TICK(x, 6);
         step_red_exec(x);
@@ -163,12 +171,12 @@ __global__ __launch_bounds__(WAVE) void k_step(StepArgs a) {
   }
   if (lane == 0) { s->rng = rl; a.reward[e] = s->reward; a.done[e] = s->done; a.err[e] = s->err; }
   unsigned long long t_obs = a.prof ? clock64() : 0;
-  if (lane < OBS_PARTS) env_flat_obs_part<uint8_t>(s, obs_lds, lane);   // 12 independent pieces of the flat observation
+  if (lane < OBS_PARTS) env_flat_obs_part<uint8_t>(s, hd, obs_lds, lane);   // 12 independent pieces of the flat observation
   __syncthreads();
   unsigned long long t_out = a.prof ? clock64() : 0;
   if (prof && lane == 0) prof[12] += t_out - t_obs;
   uint4* dst = reinterpret_cast<uint4*>(a.st + e);
-  stage_out(dst, lds, lane);
+  stage_out<HOT_VEC>(dst, lds, lane);
   int32_t* o = a.obs + (size_t)e * OBS_TOTAL;
   for (int i = lane; i < OBS_TOTAL; i += WAVE) o[i] = obs_lds[i];
   if (a.obs8) { uint8_t* o8 = a.obs8 + (size_t)e * OBS_PACKED; for (int j = lane; j < OBS_PACKED; j += WAVE) o8[j] = pack_obs_byte(obs_lds, j); }
@@ -230,6 +238,7 @@ __global__ __launch_bounds__(PT) void k_step_philox(StepArgs a) {
   __shared__ alignas(16) uint32_t reset_ws[RESET_WS_WORDS];   // pid bitmaps of the scenario generation (autoreset); during a step: the green agents' pre-computed blocks
   static_assert(RESET_WS_WORDS >= 4 * MAXG, "one 16-byte block per green agent");
   __shared__ int glist_n[2];
+  __shared__ StepWork work;
   __shared__ uint8_t obs_bytes[OBS_TOTAL + 2];   // byte-per-value copy of the observations, only for the packed exchange row
   __shared__ uint8_t glist[2][MAXG];  // green agents by action type (0 AccessService, 1 LocalWork)
   __shared__ unsigned long long prof_lds[16];
@@ -251,22 +260,25 @@ __global__ __launch_bounds__(PT) void k_step_philox(StepArgs a) {
   unsigned long long* prof = a.prof ? prof_lds : nullptr;
   if (prof && tid < 16) prof_lds[tid] = 0;
   if (tid == 0) { glist_n[0] = 0; glist_n[1] = 0; conflict_lds = 0; }
+  if (tid >= 64 && tid < 64 + 4 + NRED) (&work.phish_mask[0])[tid - 64] = 0;   // phish_mask[4] and pend_r[NRED] are adjacent
+  static_assert(offsetof(StepWork, pend_r) == offsetof(StepWork, phish_mask) + 16, "phish_mask and pend_r are cleared as one run of words");
   __syncthreads();
   EnvState* s = reinterpret_cast<EnvState*>(lds);
+  HostDyn* const hd = s->hd;
   if (prof && tid == 0) prof[11] += clock64() - t_begin;
   const bool do_reset = a.autoreset && s->done;
   if (do_reset) {
     dma_wait();
     __syncthreads();
     // new episode on the same key (CybORG.reset(seed=None)): the phases of env_reset_counter_mode, hosts on threads
-    reset_zero(s, a.cold + e, tid, PT);
+    reset_zero(s, hd, a.cold + e, tid, PT);
     __syncthreads();
     Rng rr; ResetCarry carry; carry.env_key = 0;     // thread 0: main reset stream in registers, across the phases
-    Ctx xm{s, a.cold + e, &rr};
+    Ctx xm{s, a.cold + e, &rr, hd, &work};
     if (tid == 0) { rr = s->rng; rr.mode = 1; carry = reset_topology(xm, 0, a.steps, true, a.policy, a.topo, reset_ws, true); }
     __syncthreads();
     Rng rh; rng_fork(&rh, &s->rng, ST_GEN_HOST); rh.mode = 1;
-    Ctx xh{s, a.cold + e, &rh};
+    Ctx xh{s, a.cold + e, &rh, hd, &work};
     if (tid < MAXH) reset_gen_host(xh, tid);
     __syncthreads();
     if (tid < MAXH) reset_pid_mark(xh, tid, reset_ws);
@@ -286,13 +298,13 @@ __global__ __launch_bounds__(PT) void k_step_philox(StepArgs a) {
     const int st_now = s->step_count;
     const bool step_ok = step_phase_of(st_now, s->phase_len[0], s->phase_len[1], s->phase_len[2]) >= 0;
     if (tid == 0) {
-      Ctx x{s, a.cold + e, &s->rng, prof};
+      Ctx x{s, a.cold + e, &s->rng, hd, &work, prof};
       x.lg = LOG ? &a.cold[e].evlog : nullptr;
       CC4_TICK0(x);
       (void)step_phase(x, false);
     }
     if (step_ok) {
-      Ctx x0p{s, a.cold + e, nullptr, tid == 0 ? prof : nullptr};
+      Ctx x0p{s, a.cold + e, nullptr, hd, &work, tid == 0 ? prof : nullptr};
       const int ng = s->n_green;
       // one thread-private generator per thread, in registers: every use starts with rng_set_stream(), which fully
       // determines the stream from (key, step, episode, stream id); mode pinned so the PCG paths fold away
@@ -302,12 +314,12 @@ __global__ __launch_bounds__(PT) void k_step_philox(StepArgs a) {
       rl.mode = 1;
       rng_begin_step(&rl, (uint32_t)st_now);   // not read from the row: thread 0 may still be storing it there
       EvLog* const lg = LOG ? &a.cold[e].evlog : nullptr;
-      Ctx x0{s, a.cold + e, &rl, tid == 0 ? prof : nullptr};                     // thread 0
+      Ctx x0{s, a.cold + e, &rl, hd, &work, tid == 0 ? prof : nullptr};         // thread 0
       x0.lg = lg;
       const int ragent = lane * PW + wave;                                        // lanes 0..(6/PW-1) of each wave own a red agent
       const bool is_red = lane < (NRED + PW - 1) / PW && ragent < NRED;
       unsigned long long* ap = (a.prof && is_red) ? a.prof + PROF_SLOTS * (size_t)e + 16 + 8 * ragent : nullptr;
-      Ctx xr{s, a.cold + e, &rl, nullptr, ap, lg};
+      Ctx xr{s, a.cold + e, &rl, hd, &work, nullptr, ap, lg};
       // ---- P0-P3a: every agent's policy / submission followed by its own duration-queue tick (SC:236-265), all on the
       // agent's thread: red r on wave r%PW lane r/PW, blue on wave PW-1 lanes 2..6, green draws on lanes >= 8 of the waves
       // that carry a single red agent.  A tick touches only its own agent (queue, observation reset, filter_actions
@@ -328,9 +340,9 @@ __global__ __launch_bounds__(PT) void k_step_philox(StepArgs a) {
       }
       else if (lane >= 8 && wave >= 2) {
         for (int g = (wave - 2) * (WAVE - 8) + (lane - 8); g < ng; g += (PW - 2) * (WAVE - 8)) {
-          Ctx xg{s, a.cold + e, &rl, nullptr, nullptr, lg};
+          Ctx xg{s, a.cold + e, &rl, hd, &work, nullptr, nullptr, lg};
           step_green_policy(xg, g);
-          int t = s->green_act[g];
+          int t = work.green_act[g];
           if (t < 2) {
             glist[t][atomicAdd(&glist_n[t], 1)] = (uint8_t)g;       // compaction by action type
             // the first block of the agent's action stream, computed here -- behind the red policies -- and handed to the
@@ -349,7 +361,7 @@ __global__ __launch_bounds__(PT) void k_step_philox(StepArgs a) {
       if (blue_exec_independent(s)) {      // uniform: every thread reads the same five action types
         if (tid == 0) CC4_TICK(x0, 3);
         const int bagent = lane * PW + wave;                                      // blue agent b on wave b % PW, lane b / PW
-        if (lane < (NBLUE + PW - 1) / PW && bagent < NBLUE) { Ctx xb{s, a.cold + e, &rl, nullptr, nullptr, lg}; step_blue_exec_agent(xb, bagent); }
+        if (lane < (NBLUE + PW - 1) / PW && bagent < NBLUE) { Ctx xb{s, a.cold + e, &rl, hd, &work, nullptr, nullptr, lg}; step_blue_exec_agent(xb, bagent); }
         __syncthreads();
         if (tid == 0) CC4_TICK(x0, 5);
       } else {
@@ -362,7 +374,7 @@ __global__ __launch_bounds__(PT) void k_step_philox(StepArgs a) {
         int pen = 0;
         for (int i = lane; i < glist_n[wave]; i += WAVE) {
           int g = glist[wave][i];
-          Ctx xg{s, a.cold + e, &rl, nullptr, nullptr, lg};
+          Ctx xg{s, a.cold + e, &rl, hd, &work, nullptr, nullptr, lg};
           const uint4 blk = reinterpret_cast<const uint4*>(reset_ws)[g];
           const uint32_t pre[4] = {blk.x, blk.y, blk.z, blk.w};
           pen += step_green_exec(xg, g, pre);
@@ -373,7 +385,7 @@ __global__ __launch_bounds__(PT) void k_step_philox(StepArgs a) {
       __syncthreads();
       CC4_TICK(x0, 6);
       // ---- P5 deferred phishing (ordered), then P6 red actions: one per wave when they name distinct hosts
-      if (tid == 0) { step_phishing(x0); CC4_TICK(x0, 1); conflict_lds = (int)red_conflict_mask(s); if (prof && conflict_lds) prof[4] += 1000000; }
+      if (tid == 0) { step_phishing(x0); CC4_TICK(x0, 1); rs_reserve(x0); conflict_lds = (int)red_conflict_mask(s); if (prof && conflict_lds) prof[4] += 1000000; }
       __syncthreads();
       const uint32_t serial_red = (uint32_t)conflict_lds;
       if (is_red && !((serial_red >> ragent) & 1u)) {
@@ -402,7 +414,7 @@ __global__ __launch_bounds__(PT) void k_step_philox(StepArgs a) {
       // reads none of it, so there is no barrier in between.
       if (is_red) { unsigned long long t0 = ap ? clock64() : 0; step_rsc(xr, ragent); if (ap) ap[2] += clock64() - t0; }
       if (tid == PT - 1) {
-        Ctx xe{s, a.cold + e, &rl, nullptr, nullptr, lg};
+        Ctx xe{s, a.cold + e, &rl, hd, &work, nullptr, nullptr, lg};
         step_monitor_pend(xe);
         step_end(xe, nullptr, false);
         a.reward[e] = s->reward; a.done[e] = s->done;
@@ -415,7 +427,7 @@ __global__ __launch_bounds__(PT) void k_step_philox(StepArgs a) {
   {
     int32_t* o = a.obs + (size_t)e * OBS_TOTAL;
     const bool pack = a.obs8 != nullptr;   // the exchange copy goes through a byte row in LDS and is packed after the barrier below
-    for (int v = tid; v < OBS_TOTAL; v += PT) { int i; int val = env_flat_obs_sorted(s, v, &i); o[i] = val; if (pack) obs_bytes[i] = (uint8_t)val; }   // kind-sorted enumeration: uniform branches per wave
+    for (int v = tid; v < OBS_TOTAL; v += PT) { int i; int val = env_flat_obs_sorted(s, hd, v, &i); o[i] = val; if (pack) obs_bytes[i] = (uint8_t)val; }   // kind-sorted enumeration: uniform branches per wave
   }
   __syncthreads();    // the row is final: RedSessionCheck and the step bookkeeping ran beside the encode
   if (tid == 0) a.err[e] = s->err;
@@ -433,24 +445,29 @@ struct ResetArgs {
   int32_t* obs; float* reward; uint8_t* done; uint32_t* err; uint8_t* mask;
   int n, steps, rng_mode, policy;
   uint32_t topo;
+  uint8_t* obs8;               // packed exchange row of the reset observations (multi-GPU), or null
 };
 __global__ __launch_bounds__(WAVE) void k_reset(ResetArgs a) {
   __shared__ uint8_t obs_lds[OBS_TOTAL + 2];
   __shared__ uint8_t mask_lds[MASK_TOTAL + 2];
+  __shared__ StepWork work;
   const int e = blockIdx.x, lane = threadIdx.x;
   if (e >= a.n) return;
   if (a.env_mask && !a.env_mask[e]) return;
   EnvState* s = a.st + e;
+  HostDyn* const hd = s->hd;
+  for (int i = lane; i < (int)(sizeof(StepWork) / 4); i += WAVE) reinterpret_cast<uint32_t*>(&work)[i] = 0;
+  __syncthreads();
   if (a.rng_mode == 1) {   // counter-based mode: the phases of env_reset_counter_mode, hosts on lanes (the row stays in HBM here)
     __shared__ uint32_t ws[RESET_WS_WORDS];
-    Ctx xm{s, a.cold + e, &s->rng};
+    Ctx xm{s, a.cold + e, &s->rng, hd, &work};
     ResetCarry carry; carry.env_key = 0;
-    reset_zero(s, a.cold + e, lane, WAVE);
+    reset_zero(s, hd, a.cold + e, lane, WAVE);
     __syncthreads();
     if (lane == 0) carry = reset_topology(xm, a.seeds ? a.seeds[e] : 0, a.steps, a.seeds == nullptr, a.policy, a.topo, ws, false);
     __syncthreads();
     Rng rh; rng_fork(&rh, &s->rng, ST_GEN_HOST); rh.mode = 1;
-    Ctx xh{s, a.cold + e, &rh};
+    Ctx xh{s, a.cold + e, &rh, hd, &work};
     for (int h = lane; h < MAXH; h += WAVE) reset_gen_host(xh, h);
     __syncthreads();
     for (int h = lane; h < MAXH; h += WAVE) reset_pid_mark(xh, h, ws);
@@ -464,11 +481,11 @@ __global__ __launch_bounds__(WAVE) void k_reset(ResetArgs a) {
     if (lane == 0) reset_finish(xm, carry, a.steps, a.topo, false);
     __syncthreads();
   } else if (lane == 0) {
-    Ctx x{s, a.cold + e, &s->rng};
+    Ctx x{s, a.cold + e, &s->rng, hd, &work};
     env_reset(x, a.seeds ? a.seeds[e] : 0, 0, a.steps, a.seeds == nullptr, a.policy, a.topo);
   }
   if (lane == 0) {
-    env_flat_obs<uint8_t>(s, obs_lds);
+    env_flat_obs<uint8_t>(s, hd, obs_lds);
     blue_action_mask(s, mask_lds);
     a.reward[e] = 0.f; a.done[e] = s->done; a.err[e] = s->err;
   }
@@ -477,6 +494,7 @@ __global__ __launch_bounds__(WAVE) void k_reset(ResetArgs a) {
   for (int i = lane; i < OBS_TOTAL; i += WAVE) o[i] = obs_lds[i];
   uint8_t* m = a.mask + (size_t)e * MASK_TOTAL;
   for (int i = lane; i < MASK_TOTAL; i += WAVE) m[i] = mask_lds[i];
+  if (a.obs8) { uint8_t* o8 = a.obs8 + (size_t)e * OBS_PACKED; for (int j = lane; j < OBS_PACKED; j += WAVE) o8[j] = pack_obs_byte(obs_lds, j); }
 }
 
 // uniform blue action indices over each agent's full range: Philox key (seed0, env),
@@ -486,6 +504,16 @@ __global__ void k_random_actions(int32_t* actions, int n, uint64_t seed0, uint32
   if (i >= n * NBLUE) return;
   int e = i / NBLUE, b = i % NBLUE;
   actions[i] = random_blue_action(seed0, t, e, b);
+}
+
+// one block per gathered row: 148 packed bytes -> 578 byte values (thread j unpacks byte j into values 4j .. 4j+3)
+__global__ void k_unpack_obs(const uint8_t* __restrict__ packed, uint8_t* __restrict__ out, int rows) {
+  const int r = blockIdx.x, j = threadIdx.x;
+  if (r >= rows || j >= OBS_PACKED) return;
+  const uint32_t b = packed[(size_t)r * OBS_PACKED + j];
+  uint8_t* o = out + (size_t)r * OBS_TOTAL + 4 * j;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) if (4 * j + k < OBS_TOTAL) o[k] = (uint8_t)((b >> (2 * k)) & 3u);
 }
 
 __global__ void k_rng_state(const EnvState* st, uint64_t* out, int n) {
@@ -515,8 +543,10 @@ struct cc4_handle {
   hipStream_t comm_stream = nullptr;
   hipEvent_t ev_step[OBS_RING] = {}, ev_comm[OBS_RING] = {};   // ev_comm[q % OBS_RING]: all-gather number q has completed
   int obs_buf = 0;                               // buffer written by the most recent step
+  int gather_buf = -1;                           // buffer of the most recent all-gather (-1: none issued)
   bool step_event_attached = false;              // ev_step[obs_buf] was recorded by the launch of that step itself
   unsigned long long* d_prof = nullptr;
+  uint8_t* d_unpacked = nullptr;                 // [world*N][578] bytes: cc4_unpack_obs_device
   int evlog_on = 0;               // cc4_enable_event_log
   ncclComm_t comm = nullptr; int rank = 0, world = 1;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -567,8 +597,8 @@ static int launch_step(cc4_handle* h, const int32_t* d_actions, const uint8_t* d
     if (h->evlog_on) hipExtLaunchKernelGGL(k_step_philox<true>, grid, dim3(PT), sizeof(EnvState), h->stream, nullptr, stop, 0, a);
     else hipExtLaunchKernelGGL(k_step_philox<false>, grid, dim3(PT), sizeof(EnvState), h->stream, nullptr, stop, 0, a);
   } else {
-    if (h->evlog_on) hipExtLaunchKernelGGL(k_step<true>, grid, dim3(WAVE), sizeof(EnvState), h->stream, nullptr, stop, 0, a);
-    else hipExtLaunchKernelGGL(k_step<false>, grid, dim3(WAVE), sizeof(EnvState), h->stream, nullptr, stop, 0, a);
+    if (h->evlog_on) hipExtLaunchKernelGGL(k_step<true>, grid, dim3(WAVE), offsetof(EnvState, hd), h->stream, nullptr, stop, 0, a);
+    else hipExtLaunchKernelGGL(k_step<false>, grid, dim3(WAVE), offsetof(EnvState, hd), h->stream, nullptr, stop, 0, a);
   }
   HIPCHK(h, hipGetLastError());
   h->obs_buf = buf;
@@ -583,6 +613,7 @@ size_t cc4_algorithmic_bytes_per_env_step(void) {
   // state row in + out, flat obs out (int32), actions in, reward + done + err out (DESIGN.md "algorithmic bytes")
   return 2 * sizeof(EnvState) + 4 * OBS_TOTAL + 4 * NBLUE + 4 + 1 + 4;
 }
+size_t cc4_hot_bytes(void) { return offsetof(EnvState, hd); }
 
 int cc4_create(const cc4_config* cfg, cc4_handle** out) {
   if (!cfg || !out || cfg->num_envs <= 0 || cfg->steps <= 0 || cfg->red_policy < 0 || cfg->red_policy > 3 ||
@@ -636,6 +667,7 @@ void cc4_destroy(cc4_handle* h) {
                   h->d_done, h->d_err, h->d_mask, h->d_rng};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   for (int b = 0; b < cc4_handle::OBS_RING; ++b) { if (h->d_obs8[b]) (void)hipFree(h->d_obs8[b]); if (h->d_all_obs8[b]) (void)hipFree(h->d_all_obs8[b]); }
+  if (h->d_unpacked) (void)hipFree(h->d_unpacked);
   for (hipEvent_t e : h->evs) if (e) (void)hipEventDestroy(e);
   if (h->ev0) (void)hipEventDestroy(h->ev0);
   if (h->ev1) (void)hipEventDestroy(h->ev1);
@@ -650,9 +682,14 @@ int cc4_reset(cc4_handle* h, const uint64_t* seeds, const uint8_t* env_mask) {
   if (env_mask) HIPCHK(h, hipMemcpyAsync(h->d_envmask, env_mask, n, hipMemcpyHostToDevice, h->stream));
   ResetArgs a{h->d_state, h->d_cold, seeds ? h->d_seeds : nullptr, env_mask ? h->d_envmask : nullptr, h->d_obs, h->d_reward,
               h->d_done, h->d_err, h->d_mask, h->cfg.num_envs, h->cfg.steps, h->cfg.rng_mode,
-              (h->cfg.red_policy & 3) | (h->cfg.green_policy ? GP_SLEEP_BIT : 0), (uint32_t)h->cfg.topology_seed};
+              (h->cfg.red_policy & 3) | (h->cfg.green_policy ? GP_SLEEP_BIT : 0), (uint32_t)h->cfg.topology_seed,
+              h->comm ? h->d_obs8[h->obs_buf] : nullptr};
+  // with a communicator the reset also writes the packed exchange row of its observations into the current ring buffer; an
+  // overlapped all-gather may still be reading that buffer
+  if (h->comm && h->gathers_issued > h->gathers_waited) { HIPCHK(h, hipStreamSynchronize(h->comm_stream)); h->gathers_waited = h->gathers_issued; }
   hipLaunchKernelGGL(k_reset, dim3(h->cfg.num_envs), dim3(WAVE), 0, h->stream, a);
   HIPCHK(h, hipGetLastError());
+  h->step_event_attached = false;   // the buffer's event must be recorded again before the next all-gather
   HIPCHK(h, hipStreamSynchronize(h->stream));
   return 0;
 }
@@ -832,7 +869,7 @@ int64_t cc4_get_true_state(cc4_handle* h, int32_t env, char* json, size_t cap) {
   int64_t rc = cc4_get_state(h, env, st);
   if (rc == 0) rc = cc4_get_cold(h, env, cold);
   if (rc == 0) {
-    std::string doc = export_true_state(*st, cold->hs, cold->sus, &cold->evlog);
+    std::string doc = export_true_state(*st, *cold);
     rc = (int64_t)doc.size() + 1;
     if (json && cap >= doc.size() + 1) memcpy(json, doc.c_str(), doc.size() + 1);
   }
@@ -892,6 +929,7 @@ int cc4_allgather_obs(cc4_handle* h, uint8_t** d_all_obs8) {
   if (r != ncclSuccess) { h->err = std::string("ncclAllGather: ") + ncclGetErrorString(r); return -1; }
   const long long q = ++h->gathers_issued;
   h->gather_seq[buf] = q;
+  h->gather_buf = buf;
   HIPCHK(h, hipEventRecord(h->ev_comm[q % cc4_handle::OBS_RING], h->comm_stream));
   if (d_all_obs8) *d_all_obs8 = h->d_all_obs8[buf];
   return 0;
@@ -905,13 +943,37 @@ int cc4_allgather_wait(cc4_handle* h) {
 // host copy of the gathered observations of the most recent cc4_allgather_obs (tests / debugging)
 int cc4_get_allgathered_obs(cc4_handle* h, uint8_t* out /* [world*N][578] */) {
   if (!h->comm) { h->err = "cc4_get_allgathered_obs: cc4_comm_init was not called"; return -2; }
+  if (h->gather_buf < 0) { h->err = "cc4_get_allgathered_obs: no all-gather has been issued"; return -2; }
   HIPCHK(h, hipSetDevice(h->cfg.device_id));
   HIPCHK(h, hipStreamSynchronize(h->comm_stream));
   const size_t rows = (size_t)h->world * h->cfg.num_envs;
   std::vector<uint8_t> packed(rows * OBS_PACKED);
-  HIPCHK(h, hipMemcpy(packed.data(), h->d_all_obs8[h->obs_buf], packed.size(), hipMemcpyDeviceToHost));
+  HIPCHK(h, hipMemcpy(packed.data(), h->d_all_obs8[h->gather_buf], packed.size(), hipMemcpyDeviceToHost));
   for (size_t r = 0; r < rows; ++r)      // unpack to one byte per value for the host caller
     for (int i = 0; i < OBS_TOTAL; ++i) out[r * OBS_TOTAL + i] = (uint8_t)((packed[r * OBS_PACKED + (i >> 2)] >> (2 * (i & 3))) & 3u);
+  return 0;
+}
+// Device-side consumer of the exchange format: the gathered rows of the most recent cc4_allgather_obs ([world*N] rows of
+// CC4_OBS_PACKED_BYTES, 2 bits per value) unpacked to [world*N][578] bytes in a buffer owned by the handle -- what a shared
+// on-GPU policy reads.  Enqueued on the communication stream behind the all-gather; *d_obs_u8 is valid after
+// cc4_allgather_wait() (or after any later operation ordered behind ev_comm of that gather).
+int cc4_unpack_obs_device(cc4_handle* h, uint8_t** d_obs_u8) {
+  if (!h->comm) { h->err = "cc4_unpack_obs_device: cc4_comm_init was not called"; return -2; }
+  if (h->gather_buf < 0) { h->err = "cc4_unpack_obs_device: no all-gather has been issued"; return -2; }
+  HIPCHK(h, hipSetDevice(h->cfg.device_id));
+  const size_t rows = (size_t)h->world * h->cfg.num_envs;
+  if (!h->d_unpacked) HIPCHK(h, hipMalloc(&h->d_unpacked, rows * OBS_TOTAL));
+  hipLaunchKernelGGL(k_unpack_obs, dim3((unsigned)rows), dim3(192), 0, h->comm_stream, h->d_all_obs8[h->gather_buf], h->d_unpacked, (int)rows);
+  HIPCHK(h, hipGetLastError());
+  if (d_obs_u8) *d_obs_u8 = h->d_unpacked;
+  return 0;
+}
+// host copy of that buffer (tests)
+int cc4_get_unpacked_obs(cc4_handle* h, uint8_t* out /* [world*N][578] */) {
+  if (!h->d_unpacked) { h->err = "cc4_get_unpacked_obs: cc4_unpack_obs_device was not called"; return -2; }
+  HIPCHK(h, hipSetDevice(h->cfg.device_id));
+  HIPCHK(h, hipStreamSynchronize(h->comm_stream));
+  HIPCHK(h, hipMemcpy(out, h->d_unpacked, (size_t)h->world * h->cfg.num_envs * OBS_TOTAL, hipMemcpyDeviceToHost));
   return 0;
 }
 

@@ -1,8 +1,14 @@
 // cc4_state.h -- packed per-episode state of the CC4 (CybORG v4) step engine.
 //
-// One episode ("env") = one EnvState (hot, ~32 KB, staged in LDS) + one EnvCold (host backup images, ephemeral-port
-// bitmaps and per-red-session port knowledge; stays in HBM, touched a handful of times per step).  Everything is fixed-size
-// POD so that a whole episode can be staged with coalesced loads and snapshot with memcpy.
+// One episode ("env") = one EnvState (hot, < 16 KB, staged in LDS) + one EnvCold (host backup images, process-list overflow,
+// ephemeral-port bitmaps and per-red-session port knowledge; stays in HBM, touched a handful of times per step).  Everything
+// is fixed-size POD so that a whole episode can be staged with coalesced loads and snapshot with memcpy.
+//
+// Process lists (Host.processes) are unbounded in the reference (a blue agent may stack decoys on one host without limit,
+// DecoyAction.py:47-114 / DecoyVsftpd.py:10-20): the first PIN entries of a host's list live in the hot row, entries
+// PIN .. PIN+POVF-1 in the cold row (EnvCold.povf).  DeployDecoy takes two ticks, so a 500-step episode can stack at most 250
+// decoys on one host; with the <= 7 generated processes that leaves MAXP = 384 room for 127 red shells on that same host
+// (the differential fuzz reached 257 with a decoy-only blue policy).  E_PROC_OVERFLOW beyond.
 //
 // Host id layout: h = subnet*17 + slot; slot 0 router, 1..10 user_host_0..9, 11..16 server_host_0..5;
 // internet root host = 136.  Subnet index = SUBNET enum order of
@@ -10,6 +16,7 @@
 // increasing id == the reference's dict iteration order over state.hosts / state.ip_addresses.
 #pragma once
 #include <stdint.h>
+#include <stddef.h>
 #include "cc4_rng.h"
 
 namespace cc4 {
@@ -19,14 +26,17 @@ enum : int {
   MAX_USERS = 10, MAX_SERVERS = 6, ZONE_HOSTS = 16,
   MAXG = 80,            // green agents (one per user host)
   NBLUE = 5, NRED = 6,
-  MAXP = 24,            // process slots per host
-  MAXSV = 9,            // service kinds per host (5 real + 4 decoy names)
-  MAX_RS = 64,          // sessions per red agent
+  PIN = 8,              // process slots per host in the hot row (every freshly generated host fits: <= 7 processes)
+  POVF = 376,           // further process slots per host in the cold row
+  MAXP = PIN + POVF,    // 384
+  MAXSV = 7,            // services per host: sshd, OT, {apache | decoy apache} + decoy vsftpd (both port 80), mysql,
+                        // decoy tomcat, {smtp | decoy haraka} -- the port checks of DecoyAction exclude any eighth
+  MAX_RS = 64,          // sessions per red agent (its ordered list of pool slots)
+  RS_POOL = 192,        // red session records per episode, shared by the six agents
   MAX_KS = 96,          // known server-session ids per red agent (ActionSpace.server_session)
-  MAX_KB = 64,          // port-knowledge blocks per red agent (one per live RedAbstractSession; = MAX_RS)
-  MAX_SUS = 192,        // sus pid entries per blue agent (VelociraptorServer.sus_pids)
-  MAX_OBS = 112,        // red observation entries per agent per step
-  MAX_PEND = 24,        // process_creation events carrying a pid, per step
+  MAX_SUS = 768,        // sus pid entries per blue agent (VelociraptorServer.sus_pids): <= 6 agents x 125 exploits in 500 steps
+  MAX_OBS = 32,         // red observation entries per agent per step (a subnet sweep adds 16, every other source <= 4)
+  MAX_PEND = 8,         // process_creation events carrying a pid, per step (one per red agent)
   EPH_WORDS = 340,      // 10880-bit bitmap >= 60000-49152 ephemeral ports (Host.py:183); 1360 B = 85 x 16 B
   OBS_SHORT = 92, OBS_LONG = 210, OBS_TOTAL = 4 * 92 + 210,   // 578
   ACT_SHORT = 82, ACT_LONG = 242, MASK_TOTAL = 4 * 82 + 242,  // 570
@@ -48,7 +58,7 @@ enum : int { PB_22 = 1, PB_80 = 2, PB_3390 = 4, PB_25 = 8, PB_1 = 16, PB_443 = 3
 
 // error / bound-overflow flags (cc4 never silently truncates: any bit set => results for that env are flagged)
 enum : uint32_t {
-  E_PROC_OVERFLOW = 1u << 0, E_RSESS_OVERFLOW = 1u << 1, E_KS_OVERFLOW = 1u << 2, E_KB_OVERFLOW = 1u << 3,
+  E_PROC_OVERFLOW = 1u << 0, E_RSESS_OVERFLOW = 1u << 1, E_KS_OVERFLOW = 1u << 2, E_KB_OVERFLOW = 1u << 3 /* unused since r02 */,
   E_SUS_OVERFLOW = 1u << 4, E_OBS_OVERFLOW = 1u << 5, E_PEND_OVERFLOW = 1u << 6,
   E_STEP_PAST_END = 1u << 7,      // reference raises ValueError (State.py:539-540)
   E_UNREACHABLE = 1u << 8,        // a path the reference would crash on (documented in DESIGN.md)
@@ -62,14 +72,17 @@ enum : int { PF_ROOT = 1, SV_ACTIVE = 0x80 };
 
 enum : int { EV_CUR_CONN = 1, EV_CUR_PROC = 2, EV_OLD_CONN = 4, EV_OLD_PROC = 8 };
 
-// HostDyn.pad: the malware files Analyse reports (Host.files; cleared by Restore): cmd.sh present, escalate.sh present, and
+// HostDyn.nsf high nibble: the malware files Analyse reports (Host.files; cleared by Restore): cmd.sh present, escalate.sh present, and
 // which of the two was appended last (Observation.add_file_info re-appends a repeated name, so only that order survives)
 enum : int { HF_CMD = 1, HF_ESC = 2, HF_ESC_LAST = 4 };
-struct alignas(8) HostDyn {
-  Proc procs[MAXP];
+struct alignas(16) HostDyn {        // 64 bytes = four 16-byte vectors
+  Proc procs[PIN];                  // entries 0 .. PIN-1 of Host.processes; the rest in EnvCold.povf[h]
   Svc svcs[MAXSV];
-  uint8_t nproc, nsvc, ev, pad;
+  uint16_t nproc;                   // length of the whole list (hot + cold part)
+  uint8_t ev;                       // EV_* bits (byte 2 of the aligned word: ev_or)
+  uint8_t nsf;                      // low nibble: number of services; high nibble: HF_* bits
 };
+static_assert(sizeof(HostDyn) == 64, "HostDyn is four 16-byte vectors");
 struct alignas(8) HostStatic {                 // Host.create_backup (Host.py:316-371)
   Proc procs[8];
   Svc svcs[5];
@@ -78,7 +91,10 @@ struct alignas(8) HostStatic {                 // Host.create_backup (Host.py:31
 
 // red sessions (state.sessions[red_agent_k], dict order == array order)
 enum : int { RS_ABSTRACT = 1, RS_ROOT = 2, RS_ORIG = 4, RS_CHILD = 8 };   // RS_CHILD: session.parent is not None
-struct alignas(8) RSess { uint16_t id; uint16_t pid; uint8_t host; uint8_t flags; uint8_t kb; uint8_t pad; };
+// One record of the episode's session pool (EnvState.spool).  An agent's sessions are the pool slots listed in
+// RedAgent.sord, in dict order; moving a session between agents (different_subnet_agent_reassignment) moves a list entry,
+// not the record.  The port knowledge of an abstract session (RedAbstractSession.ports) is the cold row EnvCold.kports[slot].
+struct alignas(8) RSess { uint16_t id; uint16_t pid; uint8_t host; uint8_t flags; uint8_t pad[2]; };
 
 // FSM host states (FiniteStateRedAgent.py:441-452)
 enum : int { FS_K = 0, FS_KD = 1, FS_S = 2, FS_SD = 3, FS_U = 4, FS_UD = 5, FS_R = 6, FS_RD = 7, FS_F = 8, FS_NONE = 0xFF };
@@ -100,12 +116,12 @@ enum : int { OE_KEY_IP = 1, OE_SESS = 2, OE_IFACE = 4, OE_SYSHN = 8 };
 struct alignas(2) ObsEnt { uint8_t host; uint8_t flags; };
 
 struct alignas(8) RedAgent {
-  RSess sess[MAX_RS];
+  alignas(8) uint8_t sord[MAX_RS];   // state.sessions[agent] in dict order: pool slots (read eight at a time)
   uint16_t known_sid[MAX_KS];        // ActionSpace.server_session keys with value True, insertion order
   uint32_t known_bm[8];              // the same set as a bitmap over ids 0..255 (larger ids fall back to the list scan)
   uint8_t fsm_order[MAXH];           // host_states dict insertion order, restricted to hosts whose state is not 'F'
                                      // ('F' is absorbing and excluded from known_hosts, FiniteStateRedAgent.py:114)
-  uint8_t fsm_state[MAXH];           // FS_* or FS_NONE
+  uint8_t fsm_st4[(MAXH + 1) / 2];   // host_states[h]: one nibble per host, FS_* + 1 (0 = not in host_states): fsm_get / fsm_put
   uint32_t fsm_hn[5];                // host_states[ip]['hostname'] is not None
   uint32_t as_ip[5];                 // ActionSpace.ip_address[ip] == True
   uint32_t as_hn[5];                 // ActionSpace.hostname[name] == True
@@ -154,31 +170,34 @@ struct alignas(16) EnvState {
   uint8_t n_users[NSUB];
   alignas(8) uint8_t n_servers[NSUB];   // read as one 8-byte word by GreenAccessService
   uint8_t green_host[MAXG];
-  uint8_t green_act[MAXG];           // scratch: this step's green choice
-  uint16_t blue_pid[MAXH];           // pid of the blue session process on host (0 = none)
-  uint16_t green_pid[MAXH];
   uint32_t pend[MAX_PEND];           // (host<<16)|pid process_creation events not yet seen by Monitor
-  uint32_t pend_r[NRED];             // this step's pid-carrying event of red agent r (0 = none); merged into pend[] in agent order
   uint8_t npend, pad1[3];
   uint32_t exists[5];                // host h is part of this episode's topology
-  uint32_t pad2[3];
-  HostDyn hd[MAXH];
-  BlueAgent blue[NBLUE];
-  RedAgent red[NRED];
-  uint8_t msg[NBLUE][MSG_LEN];       // messages submitted with the last step
-  uint32_t kb_used[NRED][MAX_KB / 32];   // per agent, so agents resolved on different waves allocate independently and in the same order as a serial walk
   uint32_t red_hosts[5];             // hosts holding a session of ANY red agent (OR of RedAgent.live_hosts, kept incrementally)
-  uint32_t pad3[3];
-  // per-step scratch shared by the phases of a step (the lane-parallel kernel hands work between lanes through it)
-  Act bexec[NBLUE];                  // self.action[blue_b][0] of this step
+  uint32_t spool_used[RS_POOL / 32]; // which records of spool[] are live
+  uint8_t msg[NBLUE][MSG_LEN];       // messages submitted with the last step
+  Act bexec[NBLUE];                  // self.action[blue_b][0] of the last step (also CybORG.get_last_action)
   Act rexec[NRED];
   int32_t brm;                       // BlueRewardMachine accumulator
   float action_cost;
   int32_t n_actions;                 // actions surviving filter_actions (length of the shuffled index list)
-  uint32_t phish_mask[4];            // bit g: green g's LocalWork asked for a PhishingEmail this step (word 3 unused)
   int32_t n_restore;                 // Restore actions submitted this step (each costs -1)
-  uint32_t scratch[64];              // work area of the ordered (lane 0) sections: small temporaries that would otherwise
-                                     // be dynamically indexed private arrays (= scratch memory on the device)
+  BlueAgent blue[NBLUE];
+  RSess spool[RS_POOL];              // red session records of all six agents
+  RedAgent red[NRED];
+  alignas(16) HostDyn hd[MAXH];      // last member: the numpy-stream kernel stages only the part in front of it
+};
+static_assert(offsetof(EnvState, hd) % 16 == 0 && sizeof(EnvState) == offsetof(EnvState, hd) + sizeof(HostDyn) * MAXH, "the host table closes the row");
+
+// Work area of one step / one reset: temporaries the phases hand to each other.  Not part of the episode's state (LDS on the
+// device, the caller's stack on the host); everything in it is dead between steps.
+struct alignas(16) StepWork {
+  uint32_t scratch[64];              // ordered (lane 0) sections: small temporaries that would otherwise be dynamically
+                                     // indexed private arrays (= scratch memory on the device)
+  uint32_t phish_mask[4];            // bit g: green g's LocalWork asked for a PhishingEmail this step (word 3 unused)
+  uint32_t pend_r[NRED];             // this step's pid-carrying event of red agent r (0 = none); merged into pend[] in agent order
+  uint8_t rs_slot[NRED + 2];         // pool slot reserved for the session red agent r's exploit may create this step (rs_reserve)
+  uint8_t green_act[MAXG];           // this step's green choice
 };
 
 // optional per-step event log (decoded Monitor observations with ports / peers / pids).  One record per
@@ -201,10 +220,11 @@ struct alignas(16) EnvCold {
   uint32_t sus[NBLUE][MAX_SUS];      // VelociraptorServer.sus_pids of blue agent b: (host << 16) | pid, chronological
                                      // (appended by Monitor, read by Remove; counts and per-host presence stay hot)
   HostStatic hs[MAXH];               // backup images (Host.create_backup): read by Restore and reset only
-  uint8_t hs_pad[8];                 // keeps eph[] 16-byte aligned (137 * 56 + 8 = 7680)
+  uint8_t hs_pad[8];                 // keeps what follows 16-byte aligned (137 * 56 + 8 = 7680)
+  Proc povf[MAXH][POVF];             // entries PIN.. of each host's process list (HostDyn.nproc > PIN)
   uint32_t eph[MAXH][EPH_WORDS];     // Host.ephemeral_ports as a bitmap (port-49152)
   EvLog evlog;                       // events of the last step when EvLog.enabled (cc4_enable_event_log)
-  uint8_t kports[NRED * MAX_KB][MAXH + 7];  // RedAbstractSession.ports[ip]: PB_* bits | PB_HAS; row = agent * MAX_KB + RSess.kb
+  uint8_t kports[RS_POOL][MAXH + 7]; // RedAbstractSession.ports[ip]: PB_* bits | PB_HAS; row = pool slot of the session
 };
 
 }  // namespace cc4

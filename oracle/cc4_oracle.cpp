@@ -51,7 +51,8 @@ void* cc4o_cold_ptr(void* h, int i) { return &((Oracle*)h)->cold[i]; }
 
 void cc4o_reset(void* h, int i, uint64_t seed, int rng_mode, int steps, int continue_stream, int policy) {
   Oracle* o = (Oracle*)h;
-  Ctx x{&o->st[i], &o->cold[i], &o->st[i].rng};
+  StepWork w; memset(&w, 0, sizeof(w));
+  Ctx x{&o->st[i], &o->cold[i], &o->st[i].rng, o->st[i].hd, &w};
   uint32_t ws[RESET_WS_WORDS];   // work area of the counter-mode generation (the device kernels use LDS)
   env_reset(x, seed, rng_mode, steps, continue_stream != 0, policy, o->topo, rng_mode == 1 ? ws : nullptr);
 }
@@ -59,7 +60,8 @@ void cc4o_set_topology_seed(void* h, uint32_t seed) { ((Oracle*)h)->topo = seed;
 void cc4o_enable_event_log(void* h, int on) { Oracle* o = (Oracle*)h; o->evlog = on ? 1 : 0; for (int i = 0; i < o->n; ++i) { o->cold[i].evlog.enabled = on ? 1u : 0u; o->cold[i].evlog.n = 0; } }
 void cc4o_step(void* h, int i, const int32_t* actions, const uint8_t* msgs) {
   Oracle* o = (Oracle*)h;
-  Ctx x{&o->st[i], &o->cold[i], &o->st[i].rng};
+  StepWork w; memset(&w, 0, sizeof(w));
+  Ctx x{&o->st[i], &o->cold[i], &o->st[i].rng, o->st[i].hd, &w};
   x.lg = o->evlog ? &o->cold[i].evlog : nullptr;
   env_step(x, actions, msgs);
 }
@@ -68,7 +70,8 @@ void cc4o_step_all(void* h, const int32_t* actions /* [n][5] */) {
   Oracle* o = (Oracle*)h;
 #pragma omp parallel for schedule(dynamic, 4)
   for (int i = 0; i < o->n; ++i) {
-    Ctx x{&o->st[i], &o->cold[i], &o->st[i].rng};
+    StepWork w; memset(&w, 0, sizeof(w));
+    Ctx x{&o->st[i], &o->cold[i], &o->st[i].rng, o->st[i].hd, &w};
     x.lg = o->evlog ? &o->cold[i].evlog : nullptr;
     env_step(x, actions + 5 * i, nullptr);
   }
@@ -90,7 +93,7 @@ void cc4o_set_threads(int n) {
 // same document as cc4_get_true_state (include/cc4.h); returns bytes needed incl. NUL
 long long cc4o_true_state(void* h, int i, char* json, size_t cap) {
   Oracle* o = (Oracle*)h;
-  std::string doc = export_true_state(o->st[i], o->cold[i].hs, o->cold[i].sus, &o->cold[i].evlog);
+  std::string doc = export_true_state(o->st[i], o->cold[i]);
   if (json && cap >= doc.size() + 1) memcpy(json, doc.c_str(), doc.size() + 1);
   return (long long)doc.size() + 1;
 }
@@ -101,12 +104,12 @@ void cc4o_topology(void* h, int i, uint8_t* out) {
   for (int k = 0; k < NSUB; ++k) { out[k] = s.cidr_octet[k]; out[9 + k] = s.n_users[k]; out[18 + k] = s.n_servers[k]; }
   for (int k = 0; k < MAXH; ++k) { out[27 + 2 * k] = bit_get(s.exists, k) ? 1 : 0; out[28 + 2 * k] = o->cold[i].hs[k].ip_octet; }
 }
-void cc4o_obs(void* h, int i, int32_t* out) { env_flat_obs<int32_t>(&((Oracle*)h)->st[i], out); }
+void cc4o_obs(void* h, int i, int32_t* out) { const EnvState* s = &((Oracle*)h)->st[i]; env_flat_obs<int32_t>(s, s->hd, out); }
 // the two per-value enumerations of the same vector (by position / by kind), for the host-logic test
 void cc4o_obs_variants(void* h, int i, int32_t* by_pos, int32_t* by_kind) {
   const EnvState* s = &((Oracle*)h)->st[i];
-  for (int k = 0; k < OBS_TOTAL; ++k) by_pos[k] = env_flat_obs_at(s, k);
-  for (int v = 0; v < OBS_TOTAL; ++v) { int idx = -1; int val = env_flat_obs_sorted(s, v, &idx); by_kind[idx] = val; }
+  for (int k = 0; k < OBS_TOTAL; ++k) by_pos[k] = env_flat_obs_at(s, s->hd, k);
+  for (int v = 0; v < OBS_TOTAL; ++v) { int idx = -1; int val = env_flat_obs_sorted(s, s->hd, v, &idx); by_kind[idx] = val; }
 }
 float cc4o_reward(void* h, int i) { return ((Oracle*)h)->st[i].reward; }
 int cc4o_done(void* h, int i) { return ((Oracle*)h)->st[i].done; }
@@ -137,12 +140,12 @@ int cc4o_layout(char* buf, int cap) {
   int n = 0;
 #define F(m) n += snprintf(buf + n, cap - n, #m " %zu\n", offsetof(EnvState, m))
   F(rng); F(step_count); F(steps); F(phase); F(phase_len); F(err); F(reward); F(done); F(blocks); F(cidr_octet); F(n_users);
-  F(n_servers); F(green_host); F(green_act); F(blue_pid); F(green_pid); F(pend); F(npend); F(exists); F(hd); F(blue); F(red);
-  F(msg); F(kb_used);
+  F(n_servers); F(green_host); F(pend); F(npend); F(exists); F(red_hosts); F(spool_used); F(msg); F(bexec); F(rexec); F(brm);
+  F(blue); F(spool); F(red); F(hd);
 #undef F
 #define G(m) n += snprintf(buf + n, cap - n, "red." #m " %zu\n", offsetof(RedAgent, m))
-  G(sess); G(known_sid); G(fsm_order); G(fsm_state); G(fsm_hn); G(as_ip); G(as_hn); G(obs); G(queue); G(as_subnet);
-  G(fsm_step); G(nsess); G(active); G(obs_success); G(exec_type); G(new_sess_host); G(new_sess_id); G(start_host);
+  G(sord); G(known_sid); G(fsm_order); G(fsm_st4); G(fsm_hn); G(as_ip); G(as_hn); G(obs); G(queue); G(as_subnet);
+  G(fsm_step); G(nsess); G(nknown); G(fsm_n); G(nobs); G(active); G(obs_success); G(exec_type); G(new_sess_host); G(new_sess_id); G(start_host);
 #undef G
   n += snprintf(buf + n, cap - n, "sizeof.RedAgent %zu\nsizeof.BlueAgent %zu\nsizeof.HostDyn %zu\nsizeof.HostStatic %zu\nsizeof.EnvState %zu\n",
                 sizeof(RedAgent), sizeof(BlueAgent), sizeof(HostDyn), sizeof(HostStatic), sizeof(EnvState));
@@ -162,20 +165,20 @@ int cc4o_dump(void* h, int i, char* buf, int cap) {
     if (!bit_get(s.exists, hh)) continue;
     const HostDyn& d = s.hd[hh];
     P("host %d procs", hh);
-    for (int k = 0; k < d.nproc; ++k) P(" (%d,%d,%d)", d.procs[k].pid, d.procs[k].kind, d.procs[k].flags & 1);
+    for (int k = 0; k < d.nproc; ++k) { const Proc pr = export_proc(s, cold, hh, k); P(" (%d,%d,%d)", pr.pid, pr.kind, pr.flags & 1); }
     P(" svcs");
-    for (int k = 0; k < d.nsvc; ++k) P(" (%d,%d,%d,%d)", d.svcs[k].kind, (d.svcs[k].st & SV_ACTIVE) ? 1 : 0, (d.svcs[k].st & 0x7F) * 20, d.svcs[k].pid);
+    for (int k = 0; k < hd_nsvc(d); ++k) P(" (%d,%d,%d,%d)", d.svcs[k].kind, (d.svcs[k].st & SV_ACTIVE) ? 1 : 0, (d.svcs[k].st & 0x7F) * 20, d.svcs[k].pid);
     P(" ev %d%d%d%d\n", (d.ev & EV_CUR_CONN) ? 1 : 0, (d.ev & EV_CUR_PROC) ? 1 : 0, (d.ev & EV_OLD_CONN) ? 1 : 0, (d.ev & EV_OLD_PROC) ? 1 : 0);
   }
   for (int r = 0; r < NRED; ++r) {
     const RedAgent& a = s.red[r];
     P("red %d active %d sess", r, a.active);
-    for (int k = 0; k < a.nsess; ++k) P(" (%d,%d,%d,%d,%d)", a.sess[k].id, a.sess[k].host, a.sess[k].pid, (a.sess[k].flags & RS_ABSTRACT) ? 1 : 0, (a.sess[k].flags & RS_ROOT) ? 1 : 0);
+    for (int k = 0; k < a.nsess; ++k) { const RSess& q = s.spool[a.sord[k]]; P(" (%d,%d,%d,%d,%d)", q.id, q.host, q.pid, (q.flags & RS_ABSTRACT) ? 1 : 0, (q.flags & RS_ROOT) ? 1 : 0); }
     P(" known");
     for (int k = 0; k < a.nknown; ++k) P(" %d", a.known_sid[k]);
     P(" fsmstep %d fsm", a.fsm_step);
-    for (int k = 0; k < a.fsm_n; ++k) { int hh = a.fsm_order[k]; P(" (%d,%d,%d)", hh, a.fsm_state[hh], bit_get(a.fsm_hn, hh) ? 1 : 0); }
-    for (int hh = 0; hh < MAXH; ++hh) if (a.fsm_state[hh] == FS_F) P(" (%d,%d,%d)", hh, FS_F, bit_get(a.fsm_hn, hh) ? 1 : 0);  // 'F' hosts after the live list
+    for (int k = 0; k < a.fsm_n; ++k) { int hh = a.fsm_order[k]; P(" (%d,%d,%d)", hh, fsm_get(a, hh), bit_get(a.fsm_hn, hh) ? 1 : 0); }
+    for (int hh = 0; hh < MAXH; ++hh) if (fsm_get(a, hh) == FS_F) P(" (%d,%d,%d)", hh, FS_F, bit_get(a.fsm_hn, hh) ? 1 : 0);  // 'F' hosts after the live list
     P(" subnets %u busy %d qt %d\n", a.as_subnet, a.queue.busy, a.queue.busy ? a.queue.type : -1);
   }
   for (int b = 0; b < NBLUE; ++b) {

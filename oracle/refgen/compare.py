@@ -1,10 +1,12 @@
 """Differential test: reference CybORG (this container only) vs the CPU oracle, step by step.
-usage: python compare.py <seed> [steps] [blue: sleep|random] [init: ctor|reset]"""
+usage: python compare.py <seed> [steps] [blue: sleep|random|<blue_policies.KINDS>] [init: ctor|reset]"""
 import sys, os, ctypes, re
 import numpy as np
 sys.path.insert(0, os.path.dirname(__file__))
 import ref_shim  # noqa
 from ref_dump import dump
+from blue_policies import BluePolicy, KINDS
+from blue_policies import BluePolicy, KINDS
 from CybORG import CybORG
 from CybORG.Simulator.Scenarios import EnterpriseScenarioGenerator
 from CybORG.Agents import SleepAgent, EnterpriseGreenAgent, FiniteStateRedAgent, DiscoveryFSRed, RandomSelectRedAgent
@@ -42,6 +44,7 @@ def run(seed, steps=500, blue='sleep', init='ctor', verbose=True, max_steps=None
         obs, info = w.reset(seed=seed + 1)
         lib.cc4o_reset(H, 0, ctypes.c_uint64(seed + 1), 0, steps, 0, pol)
     arng = np.random.default_rng(seed ^ 0xB10E)
+    bpol = BluePolicy(blue, {f'blue_agent_{b}': w.action_labels(f'blue_agent_{b}') for b in range(5)}, seed) if blue in KINDS else None
     buf = ctypes.create_string_buffer(1 << 20)
 
     def check(tag, obs, rew=None, done=None):
@@ -89,6 +92,9 @@ def run(seed, steps=500, blue='sleep', init='ctor', verbose=True, max_steps=None
         if blue == 'sleep':
             acts = {}
             a = np.full(5, -1, np.int32)
+        elif bpol is not None:
+            a = bpol.act(t)
+            acts = {f'blue_agent_{b}': int(a[b]) for b in range(5)}
         else:
             a = np.array([arng.integers(82), arng.integers(82), arng.integers(82), arng.integers(82), arng.integers(242)], np.int32)
             acts = {f'blue_agent_{b}': int(a[b]) for b in range(5)}

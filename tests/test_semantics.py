@@ -262,8 +262,8 @@ def test_monitor_sees_events_on_the_server_host_and_on_client_hosts(oracle_lib):
     st = np.frombuffer((ctypes.c_uint8 * n).from_address(o.lib.cc4o_state_ptr(o._h, 0)), np.uint8)
     topo = o.topology(0)
     exists = lambda h: bool(topo[27 + 2 * h])                              # noqa: E731
-    blue_base, blue_size = off['blue'], (off['red'] - off['blue']) // 5
-    hd_size = (off['blue'] - off['hd']) // 137                             # sizeof(HostDyn); its last four bytes: nproc, nsvc, ev, pad
+    blue_base, blue_size = off['blue'], off['sizeof.BlueAgent']
+    hd_size = off['sizeof.HostDyn']                                        # its last four bytes: nproc (u16), ev, nsvc | files << 4
     for b in range(4):                                                      # agents 0..3 own subnet b
         parent = int(st[blue_base + b * blue_size + 34])                   # BlueAgent.parent_host (csrc/cc4_state.h)
         assert parent // 17 == b and exists(parent)
