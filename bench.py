@@ -6,17 +6,24 @@
 
 A "step" is one pass of the hot path over one batch: device-side uniform random blue actions -> k_step over the
 rank's shard (reset / full SimulationController.step transition / reward / flat observations) [-> RCCL all-gather of
-the observations when N>1].  Workload at every N: BASELINE configs[1] per GPU = 1024 concurrent episodes per GPU
-(weak scaling: 8 GPUs = configs[3], 8192 episodes), EnterpriseScenarioGenerator(steps=500), FiniteStateRedAgent red,
-EnterpriseGreenAgent green, autoreset on done so the timed region includes the scenario regeneration of finished
-episodes.  Inputs (state, actions) are resident in HBM.  RNG mode: BASELINE.md section 3 quotes the GPU runs in the
-counter-based Philox mode (lane-parallel kernel k_step_philox; bit-exact with the CPU oracle, distribution-checked
-against the PCG mode); the numpy-PCG64 mode that is bit-exact with the reference itself (serial kernel k_step) is
-measured in the same run and reported under "alt_rng".
+the observations when N>1].  Workload at every N: **8192 concurrent episodes in total** -- BASELINE configs[2] on one
+GPU (the configuration the metric's target is quoted on), configs[3] on eight (1024 per GPU): strong scaling.
+EnterpriseScenarioGenerator(steps=500), FiniteStateRedAgent red, EnterpriseGreenAgent green, topology randomised per
+episode and per reset, autoreset on done.  Inputs (state, actions) are resident in HBM.  RNG mode: the counter-based
+Philox mode (lane-parallel kernel k_step_philox; bit-exact with the CPU oracle, distribution-checked against the PCG
+mode); the numpy-PCG64 mode that is bit-exact with the reference itself (serial kernel k_step) is measured in the same
+run and reported under "alt_rng", and the 1024-episode batch (configs[1], the per-GPU share of an 8-GPU job) under
+"envs_1024".
+
+Timing: W untimed warm-up steps, then regions of EXACTLY K steps, each bracketed by barrier + device synchronise on
+both sides, repeated back to back (the episodes keep running across regions) until at least --min-seconds of timed
+work has accumulated, so that a small K still averages over whole episodes including their scenario regenerations.
+Region time = MAX over ranks.  `value` = steps of all regions / sum of the region times; the median region is
+reported beside it.
 
 Prints ONE JSON line on rank 0.  `roofline` = algorithmic bytes per k_step launch / mean launch duration from HIP
-events recorded on the launch stream inside the timed region; `cpu_baseline` = the CPU oracle (kind "port": the
-host build of the same restatement, OpenMP over episodes) on a bounded sample of the same workload, rank 0, N=1 only.
+events recorded on the launch stream inside the timed regions; `cpu_baseline` = the CPU oracle (kind "port": the
+host build of the same restatement) on a bounded sample of the same workload, rank 0, N=1 only.
 """
 import argparse
 import json
@@ -31,10 +38,60 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBPS = 8000.0      # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
+TOTAL_ENVS = 8192           # BASELINE configs[2] / configs[3]
+# reference Python on one core (survey container, Intel Xeon 2.10 GHz, CPython 3.10): a stated
+# constant -- the reference never travels to the GPU box
+REFERENCE_PYTHON = {'value': 172.0, 'unit': 'agent-env steps/s', 'cores': 1, 'kind': 'reference',
+                    'sample': 'BASELINE.md section 2: EnterpriseScenarioGenerator seed 123, 500 steps, measured in the build container, not on this box'}
 
 
-def cpu_baseline(envs, seed0, budget_s=12.0):
-    """Oracle (oracle/liboracle.so) on the host cores: same seeds, same action generator, bounded sample."""
+def plan_shard(total_envs, rank, world):
+    """This rank's contiguous share [lo, hi) of the global episode batch (cage_challenge_4_amd.vec_env.shard_range)."""
+    from cage_challenge_4_amd.vec_env import shard_range
+    return shard_range(total_envs, rank, world)
+
+
+def timed_regions(run_k, steps, warmup, min_seconds, sync, barrier=None, reduce_max=None, max_regions=4000):
+    """The timing protocol of this bench (also driven by tests/_gloo_worker.py with a CPU step function).
+
+    run_k(t0, k, timed) runs k steps starting at action-time t0 and returns the on-stream kernel milliseconds (or 0.0).
+    Returns (region_seconds, region_kernel_ms): one entry per K-step region, each already MAX-reduced over ranks."""
+    barrier = barrier or (lambda: None)
+    reduce_max = reduce_max or (lambda v: v)
+    run_k(0, warmup, False)
+    sync()
+    t = warmup
+    secs, kms = [], []
+    while True:
+        barrier()
+        sync()
+        t0 = time.perf_counter()
+        ms = run_k(t, steps, True)
+        sync()
+        d = time.perf_counter() - t0
+        barrier()
+        d, ms = reduce_max([d, ms])
+        secs.append(d)
+        kms.append(ms)
+        t += steps
+        if sum(secs) >= min_seconds or len(secs) >= max_regions:      # `secs` is rank-reduced: every rank stops together
+            return secs, kms
+
+
+def summarise(secs, kms, steps, total_envs):
+    import statistics
+    n = len(secs)
+    tot = sum(secs)
+    med = statistics.median(secs)
+    return {'value': 5.0 * total_envs * steps * n / tot, 'ms_per_step': tot / (n * steps) * 1e3,
+            'ms_per_step_median_region': med / steps * 1e3, 'regions': n,
+            'region_spread': (max(secs) - min(secs)) / med if n > 1 else 0.0,
+            'launch_ms': sum(kms) / (n * steps)}
+
+
+def cpu_baseline(envs, seed0, budget_s=10.0):
+    """Oracle (oracle/liboracle.so) on the host cores: same seeds, same action generator, bounded sample; all cores
+    (OpenMP over episodes) and one core."""
     sys.path.insert(0, os.path.join(ROOT, 'tests'))
     import ctypes
     import numpy as np
@@ -52,7 +109,6 @@ def cpu_baseline(envs, seed0, budget_s=12.0):
             cores = max(1, min(cores, int(int(q) / int(p))))
     except Exception:
         pass
-    ora.lib.cc4o_set_threads(cores)
 
     def run(t0, k):
         acts = [np.ascontiguousarray(random_actions(seed0, t0 + i, envs)) for i in range(k)]
@@ -61,39 +117,58 @@ def cpu_baseline(envs, seed0, budget_s=12.0):
             ora.lib.cc4o_step_all(ora._h, a.ctypes.data_as(ctypes.c_void_p))
         return time.perf_counter() - t
 
+    ora.lib.cc4o_set_threads(cores)
     probe = run(0, 10)
-    k = int(max(10, min(480, budget_s / max(probe / 10, 1e-6))))
+    k = int(max(10, min(400, budget_s / max(probe / 10, 1e-6))))
     dt = run(10, k)
+    out = {'value': 5.0 * envs * k / dt, 'unit': 'agent-env steps/s', 'cores': cores, 'kind': 'port',
+           'sample': f'{envs} episodes x {k} steps (steps 10..{10 + k} of the same seeded workload), OpenMP over episodes'}
+    # one core: the rest of the same episodes' life, a shorter stretch
+    ora.lib.cc4o_set_threads(1)
+    t1 = 10 + k
+    probe1 = run(t1, 2)
+    k1 = int(max(2, min(489 - t1 - 2, (budget_s / 2) / max(probe1 / 2, 1e-6))))
+    if k1 >= 2:
+        dt1 = run(t1 + 2, k1)
+        out['one_core'] = {'value': 5.0 * envs * k1 / dt1, 'unit': 'agent-env steps/s', 'cores': 1, 'kind': 'port',
+                           'sample': f'{envs} episodes x {k1} steps (steps {t1 + 2}..{t1 + 2 + k1}), one thread'}
+    out['reference_python'] = REFERENCE_PYTHON
     ora.close()
-    return {'value': 5.0 * envs * k / dt, 'unit': 'agent-env steps/s', 'cores': cores, 'kind': 'port',
-            'sample': f'{envs} episodes x {k} steps (steps 10..{10 + k} of the same seeded workload), OpenMP over episodes'}
+    return out
 
 
-def load_pmc_traffic():
-    """HBM bytes per k_step launch from the committed rocprofv3 --pmc passes (profiles/r01_pmc.json), or None."""
-    p = os.path.join(ROOT, 'profiles', 'r01_pmc.json')
-    try:
-        with open(p) as f:
-            return json.load(f).get('hbm_bytes_per_launch_1024env')
-    except Exception:
-        return None
+def load_pmc_traffic(envs):
+    """HBM bytes per k_step_philox launch from the committed rocprofv3 --pmc passes, with their source, or (None, None)."""
+    for name in ('r02_pmc.json', 'r01_pmc.json'):
+        p = os.path.join(ROOT, 'profiles', name)
+        try:
+            with open(p) as f:
+                v = json.load(f).get(f'hbm_bytes_per_launch_{envs}env')
+            if v is not None:
+                return v, f'profiles/{name} (rocprofv3 --pmc passes of this bench command; a committed figure, not measured in this run)'
+        except Exception:
+            pass
+    return None, None
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=1500)
-    ap.add_argument('--warmup', type=int, default=100)
-    ap.add_argument('--envs-per-gpu', type=int, default=1024)
+    ap.add_argument('--steps', type=int, default=500)
+    ap.add_argument('--warmup', type=int, default=50)
+    ap.add_argument('--total-envs', type=int, default=TOTAL_ENVS)
+    ap.add_argument('--envs-per-gpu', type=int, default=0, help='override: total = envs-per-gpu x gpus (weak-scaled run)')
     ap.add_argument('--episode-steps', type=int, default=500)
+    ap.add_argument('--min-seconds', type=float, default=0.3, help='timed regions are repeated until this much timed work has accumulated')
     ap.add_argument('--rng', choices=['pcg64', 'philox'], default='philox')
-    ap.add_argument('--no-alt', action='store_true', help='skip the second measurement in the other RNG mode')
+    ap.add_argument('--no-alt', action='store_true', help='skip the sub-entries (other RNG mode, 1024 episodes, uniform topology)')
     ap.add_argument('--seed0', type=int, default=1000)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     args = ap.parse_args()
 
     from cage_challenge_4_amd import CC4VecEnv, RNG_PCG64, RNG_PHILOX
     from cage_challenge_4_amd import distributed as D
+    import numpy as np
 
     rank, world, local = D.env_rank_world()
     if args.gpus > 1 and world != args.gpus:
@@ -113,13 +188,18 @@ def main():
         if ndev > 0:
             dev_id = local % ndev
     dev_id = int(os.environ.get('CC4_BENCH_DEVICE', dev_id))   # override: several ranks on one GPU (tests the N>1 plumbing on a 1-GPU box)
-    n_local = args.envs_per_gpu
-    total_envs = n_local * world
-    env = CC4VecEnv(n_local, steps=args.episode_steps, rng_mode=RNG_PCG64 if args.rng == 'pcg64' else RNG_PHILOX,
-                    device_id=dev_id, autoreset=True)
-    lo = rank * n_local
-    import numpy as np
-    env.reset(seeds=np.uint64(args.seed0) + np.arange(lo, lo + n_local, dtype=np.uint64))
+    total_envs = args.envs_per_gpu * world if args.envs_per_gpu else args.total_envs
+    scaling = 'weak' if args.envs_per_gpu else 'strong'
+    lo, hi = plan_shard(total_envs, rank, world)
+    n_local = hi - lo
+    mode = RNG_PCG64 if args.rng == 'pcg64' else RNG_PHILOX
+
+    def make_env(n, rng_mode, first, **kw):
+        e = CC4VecEnv(n, steps=args.episode_steps, rng_mode=rng_mode, device_id=dev_id, autoreset=True, **kw)
+        e.reset(seeds=np.uint64(args.seed0) + np.arange(first, first + n, dtype=np.uint64))
+        return e
+
+    env = make_env(n_local, mode, lo)
     exchange_note = None
     if dist_on:
         # RCCL setup + first collective under a watchdog: if any rank fails or stalls, every rank drops the exchange and
@@ -147,94 +227,102 @@ def main():
             exchange_note = 'none (RCCL setup failed or timed out on a rank: %s)' % res.get('err', 'ok here' if res.get('ok') else 'timeout')
             print('bench.py: ' + exchange_note, file=sys.stderr)
             env.close = lambda: None                                                # the old handle is abandoned, not destroyed
-            env = CC4VecEnv(n_local, steps=args.episode_steps, rng_mode=RNG_PCG64 if args.rng == 'pcg64' else RNG_PHILOX,
-                            device_id=dev_id, autoreset=True)
-        env.reset(seeds=np.uint64(args.seed0) + np.arange(lo, lo + n_local, dtype=np.uint64))
+            env = make_env(n_local, mode, lo)
+        else:
+            env.reset(seeds=np.uint64(args.seed0) + np.arange(lo, hi, dtype=np.uint64))
         import ctypes
         ctypes.CDLL(None).fflush(None)           # C stdio buffers written while fd 1 pointed at stderr
         sys.stdout.flush()
         os.dup2(saved_fd, 1)
         os.close(saved_fd)
-    seed_actions = args.seed0 + lo            # action key = seed0 + global episode index
 
-    def timed_run(e):
-        e.run_random_steps(seed_actions, 0, args.warmup, timed=False)
-        e.synchronize()
-        if dist_on:
-            dist.barrier()
-        t0 = time.perf_counter()
-        ms_k = e.run_random_steps(seed_actions, args.warmup, args.steps, timed=True)   # syncs the stream at the end
-        e.synchronize()
-        d = time.perf_counter() - t0      # this rank's K steps; the slowest rank decides (MAX below), the control-plane
-        if dist_on:                       # barrier that closes the bracket is not part of the steps
-            dist.barrier()
-        if dist_on:
-            t = torch.tensor([d, ms_k], dtype=torch.float64)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            d, ms_k = float(t[0]), float(t[1])
-        return d, ms_k
+    def reduce_max(v):
+        if not dist_on or world == 1:
+            return v
+        t = torch.tensor(v, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return [float(a) for a in t]
 
-    dt, ms_kernels = timed_run(env)
+    def measure(e, first, n_total):
+        key = args.seed0 + first            # action key = seed0 + global episode index
+        secs, kms = timed_regions(lambda t0, k, timed: e.run_random_steps(key, t0, k, timed=timed), args.steps, args.warmup,
+                                  args.min_seconds, e.synchronize, dist.barrier if dist_on else None, reduce_max)
+        out = summarise(secs, kms, args.steps, n_total)
+        t_end = args.warmup + len(secs) * args.steps        # launches so far; episodes regenerate on every (episode_steps)-th
+        out['autoreset_launches_in_timed_regions'] = t_end // args.episode_steps - args.warmup // args.episode_steps
+        return out
+
+    main_res = measure(env, lo, total_envs)
     env._fetch()
     err_any = bool(env.err.any())
+    mean_hosts = float(np.mean([int(env.topology(i)[27::2].sum()) for i in range(0, n_local, max(1, n_local // 64))]))
 
-    alt = None
-    if not args.no_alt and not dist_on:      # single-GPU runs also time the other RNG mode
+    subs = {}
+    if not args.no_alt and not dist_on:      # single-GPU runs also time the other RNG mode and the small batch
         other = 'pcg64' if args.rng == 'philox' else 'philox'
-        env2 = CC4VecEnv(n_local, steps=args.episode_steps, rng_mode=RNG_PCG64 if other == 'pcg64' else RNG_PHILOX,
-                         device_id=dev_id, autoreset=True)
-        env2.reset(seeds=np.uint64(args.seed0) + np.arange(lo, lo + n_local, dtype=np.uint64))
-        if world > 1:
-            D.init_rccl(env2, rank, world)
-        dt2, ms2 = timed_run(env2)
-        alt = {'rng': other, 'kernel': 'k_step' if other == 'pcg64' else 'k_step_philox',
-               'value': 5.0 * total_envs * args.steps / dt2, 'unit': 'agent-env steps/s', 'ms_per_step': dt2 / args.steps * 1e3,
-               'launch_ms': ms2 / args.steps,
-               'note': 'pcg64 = numpy Generator(PCG64) stream, bit-exact with the reference under the same seed' if other == 'pcg64'
-                       else 'philox = counter-based streams per (agent, phase, step, episode)'}
-        env2.close()
-    uni = None
-    if not args.no_alt and not dist_on and args.rng == 'philox':
-        # BASELINE configs 2-4 vs 5: the same workload with ONE topology shared by all episodes (dynamics still keyed per
-        # episode); the headline run above randomises the topology per episode and per reset, as the reference does
-        env3 = CC4VecEnv(n_local, steps=args.episode_steps, rng_mode=RNG_PHILOX, device_id=0, autoreset=True, topology_seed=args.seed0)
-        env3.reset(seeds=np.uint64(args.seed0) + np.arange(lo, lo + n_local, dtype=np.uint64))
-        dt3, ms3 = timed_run(env3)
-        uni = {'value': 5.0 * total_envs * args.steps / dt3, 'unit': 'agent-env steps/s', 'ms_per_step': dt3 / args.steps * 1e3,
-               'launch_ms': ms3 / args.steps, 'note': 'uniform topology: every episode draws its scenario from one shared key (cc4_config.topology_seed)'}
-        env3.close()
+        e2 = make_env(n_local, RNG_PCG64 if other == 'pcg64' else RNG_PHILOX, lo)
+        r2 = measure(e2, lo, total_envs)
+        e2.close()
+        r2.update({'rng': other, 'kernel': 'k_step' if other == 'pcg64' else 'k_step_philox', 'unit': 'agent-env steps/s', 'total_envs': total_envs,
+                   'note': 'pcg64 = numpy Generator(PCG64) stream, bit-exact with the reference under the same seed' if other == 'pcg64'
+                           else 'philox = counter-based streams per (agent, phase, step, episode)'})
+        subs['alt_rng'] = r2
+        if total_envs != 1024:
+            e4 = make_env(1024, mode, 0)
+            r4 = measure(e4, 0, 1024)
+            e4.close()
+            r4.update({'rng': args.rng, 'unit': 'agent-env steps/s', 'total_envs': 1024,
+                       'note': 'BASELINE configs[1]: 1024 episodes on one GPU = the per-GPU share of the 8-GPU job (latency regime: 4 blocks per CU, one round)'})
+            subs['envs_1024'] = r4
+        if args.rng == 'philox':
+            # BASELINE configs 2-4 vs 5: the same workload with ONE topology shared by all episodes (dynamics still keyed per
+            # episode); the headline run above randomises the topology per episode and per reset, as the reference does
+            e3 = make_env(n_local, RNG_PHILOX, lo, topology_seed=args.seed0)
+            r3 = measure(e3, lo, total_envs)
+            e3.close()
+            r3.update({'unit': 'agent-env steps/s', 'note': 'uniform topology: every episode draws its scenario from one shared key (cc4_config.topology_seed)'})
+            subs['uniform_topology'] = r3
     if rank == 0:
         bytes_per_env = int(env.lib.cc4_algorithmic_bytes_per_env_step())
-        launch_ms = ms_kernels / args.steps
+        hot = int(env.lib.cc4_hot_bytes())
+        state_bytes = int(env.lib.cc4_state_bytes())
+        if args.rng == 'pcg64':   # k_step stages the agent part only; of the host table it touches the rows it visits
+            bytes_per_env = 2 * hot + (state_bytes - hot) + 4 * 578 + 29
+        launch_ms = main_res['launch_ms']
         achieved = bytes_per_env * n_local / (launch_ms * 1e-3) / 1e9
-        traffic = load_pmc_traffic() if n_local == 1024 else None
+        # live bytes: the agent part + the 64-byte rows of the hosts that exist in the episode (the grid has 137 positions)
+        useful = 2 * (hot + 64.0 * mean_hosts) + 4 * 578 + 29
+        traffic, traffic_src = load_pmc_traffic(n_local) if args.rng == 'philox' else (None, None)
         out = {
             'metric': 'agent-env steps/sec (5 blue agents x N envs)',
-            'value': 5.0 * total_envs * args.steps / dt,
+            'value': main_res['value'],
             'unit': 'agent-env steps/s',
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
-            'ms_per_step': dt / args.steps * 1e3,
-            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+            'ms_per_step': main_res['ms_per_step'],
+            'higher_is_better': True, 'scaling': scaling, 'vs_baseline': None,
             'dtype': 'int32', 'data': 'synthetic',
             'config': {
-                'workload': f'{n_local} vectorised envs per GPU ({total_envs} total), uniform random blue actions '
+                'workload': f'{total_envs} vectorised envs in total ({n_local} per GPU), uniform random blue actions '
                             f'(82/82/82/82/242 incl. invalid slots), FiniteStateRedAgent, EnterpriseGreenAgent, '
                             f'EnterpriseScenarioGenerator(steps={args.episode_steps}), autoreset incl. scenario regeneration, topology randomised per episode and reset',
                 'envs_per_gpu': n_local, 'total_envs': total_envs, 'rng': args.rng,
                 'exchange': exchange_note or ('RCCL all-gather of the observations of every step (2 bits per value, 148 B per episode) on a second stream, overlapped with the next step' if dist_on else 'none'),
-                'env_steps_per_sec': total_envs * args.steps / dt, 'engine_error_flags': err_any,
+                'env_steps_per_sec': main_res['value'] / 5.0, 'engine_error_flags': err_any,
+                'timed_regions': main_res['regions'], 'region_steps': args.steps, 'ms_per_step_median_region': main_res['ms_per_step_median_region'],
+                'region_spread': main_res['region_spread'],
+                'autoreset_in_timed_region': main_res['autoreset_launches_in_timed_regions'] > 0,
+                'autoreset_launches_in_timed_regions': main_res['autoreset_launches_in_timed_regions'],
             },
             'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBPS, 'unit': 'GB/s',
-                         'frac': achieved / HBM_PEAK_GBPS, 'traffic': traffic,
-                         'kernel': 'k_step', 'launch_ms': launch_ms, 'algorithmic_bytes_per_launch': bytes_per_env * n_local},
+                         'frac': achieved / HBM_PEAK_GBPS, 'traffic': traffic, 'traffic_source': traffic_src,
+                         'kernel': 'k_step_philox' if args.rng == 'philox' else 'k_step', 'launch_ms': launch_ms,
+                         'algorithmic_bytes_per_launch': bytes_per_env * n_local,
+                         'useful_bytes_per_launch': useful * n_local, 'useful_frac': useful * n_local / (launch_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
+                         'useful_note': f'live bytes only: agent part {hot} B + 64 B x {mean_hosts:.1f} existing hosts (of 137 grid positions), in and out'},
         }
-        out['roofline']['kernel'] = 'k_step_philox' if args.rng == 'philox' else 'k_step'
-        if alt is not None:
-            out['alt_rng'] = alt
-        if uni is not None:
-            out['uniform_topology'] = uni
+        out.update(subs)
         if not dist_on and not args.no_cpu_baseline:
-            out['cpu_baseline'] = cpu_baseline(n_local, args.seed0)
+            out['cpu_baseline'] = cpu_baseline(1024, args.seed0)
         print(json.dumps(out), flush=True)
     env.close()
     if dist_on:

@@ -2060,6 +2060,17 @@ CC4_HD bool step_begin(Ctx x, const int32_t* actions) {
   for (int b = 0; b < NBLUE; ++b) step_blue_submit(x, b, actions ? actions[b] : -1);
   return true;
 }
+// The policies' generator while a set_seed split is in force (EnvState.rng2): the walking generator and rng2 trade places
+// around the policy loops.  In the counter mode the step word travels with the walking generator.
+CC4_HD void rng_policy_swap(Ctx x, bool back) {
+  EnvState* s = x.s;
+  if (!s->rng_split) return;
+  Rng t = *x.r;
+  *x.r = s->rng2;
+  if (t.mode == 1) { x.r->inc_lo = t.inc_lo; x.r->mode = 1; }
+  s->rng2 = t;
+  if (back && t.mode == 1) { rng_park(&s->rng2); s->rng2.inc_lo = 0; }   // counter mode: only (key, episode) of the parked one matter
+}
 CC4_HD void step_green_policy(Ctx x, int g) {
   if (x.s->policy & GP_SLEEP_BIT) { x.w->green_act[g] = 2; return; }   // green_agent_class=SleepAgent: no draw, Sleep
   rng_set_stream(x.r, ST_GREEN_POL + (uint32_t)g);
@@ -2264,9 +2275,11 @@ CC4_HD void env_step(Ctx x, const int32_t* actions, const uint8_t* messages /* [
   CC4_TICK0(x);
   if (!step_begin(x, actions)) return;
   CC4_TICK(x, 0);
+  rng_policy_swap(x, false);
   for (int g = 0; g < s->n_green; ++g) step_green_policy(x, g);
   CC4_TICK(x, 1);
   for (int r = 0; r < NRED; ++r) step_red_policy(x, r);
+  rng_policy_swap(x, true);
   CC4_TICK(x, 2);
   step_tick(x);
   for (int g = 0; g < s->n_green; ++g) {

@@ -2,7 +2,8 @@
 // with the content of the reference's CybORG.get_true_state() that the simulator tracks (State.get_true_state,
 // Simulator/State.py:150-224; consumer: Agents/Wrappers/TrueStateWrapper.py:25-243).
 //
-//   {"step":t,"phase":p,"blocks":[9 masks: bit f of blocks[to] = traffic from subnet f to subnet `to` is blocked],
+//   {"step":t,"phase":p,"done":0/1,"reward":team reward of the last step (BlueRewardMachine + action_cost),"action_cost":its
+//    action-cost part (SimulationController.py:303-311),"blocks":[9 masks: bit f of blocks[to] = traffic from subnet f to subnet `to` is blocked],
 //    "cidr":[9 third octets: subnet s is 10.0.X.0/24], "n_green":g,
 //    "hosts":[{"h":host id (subnet*17+slot, 136 = internet root),"ip":last octet,
 //              "procs":[[pid,kind,root]...] (Host.processes order),
@@ -34,7 +35,7 @@ inline std::string export_true_state(const EnvState& s, const EnvCold& cold, boo
   std::string o;
   char b[256];
   auto add = [&](const char* fmt, auto... a) { snprintf(b, sizeof(b), fmt, a...); o += b; };
-  add("{\"step\":%d,\"phase\":%d,\"blocks\":[", s.step_count, s.phase);
+  add("{\"step\":%d,\"phase\":%d,\"done\":%d,\"reward\":%.9g,\"action_cost\":%.9g,\"blocks\":[", s.step_count, s.phase, (int)s.done, (double)s.reward, (double)s.action_cost);
   for (int i = 0; i < NSUB; ++i) add("%s%u", i ? "," : "", (unsigned)s.blocks[i]);
   o += "],\"cidr\":[";
   for (int i = 0; i < NSUB; ++i) add("%s%u", i ? "," : "", (unsigned)s.cidr_octet[i]);

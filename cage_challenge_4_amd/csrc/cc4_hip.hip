@@ -141,9 +141,11 @@ __global__ __launch_bounds__(WAVE) void k_step(StepArgs a) {
       if (step_begin(x, acts)) {
         ok_lds = 1;
         CC4_TICK(x, 0);
+        rng_policy_swap(x, false);     // CybORG.set_seed split: the policies draw from the old stream (EnvState.rng2)
         for (int g = 0; g < s->n_green; ++g) step_green_policy(x, g);
         CC4_TICK(x, 1);
         for (int r = 0; r < NRED; ++r) step_red_policy(x, r);
+        rng_policy_swap(x, true);
         CC4_TICK(x, 2);
         step_tick(x);
         for (int g = 0; g < s->n_green; ++g) {
@@ -231,8 +233,13 @@ __device__ __forceinline__ void dma_chunk(const uint4* gsrc_lane, uint4* lds_chu
 }
 __device__ __forceinline__ void dma_wait() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 
-template <bool LOG>
-__global__ __launch_bounds__(PT) void k_step_philox(StepArgs a) {
+// MINW = minimum waves per SIMD the register allocation must allow (= resident episode blocks per CU): 1 lets the compiler
+// take what it likes (86 VGPRs, 106 SGPRs: 5 blocks per CU) and is the fastest single block -- the build for batches that
+// fit the chip in one round (<= 5 x 256 episodes, the per-GPU share of an 8-GPU job); 8 caps the kernel at 64 VGPRs / 80
+// SGPRs (a few spills) so that 8 blocks are resident per CU -- the build for large batches, which are throughput-bound
+// (MI355X, 8192 episodes: 313 M agent-env steps/s with MINW 1, 352 M with 6, 378 M with 8; 1024 episodes: 165 / 166 / 156 M).
+template <bool LOG, int MINW>
+__global__ __launch_bounds__(PT, MINW) void k_step_philox(StepArgs a) {
   extern __shared__ uint4 lds[];
   __shared__ int conflict_lds;
   __shared__ alignas(16) uint32_t reset_ws[RESET_WS_WORDS];   // pid bitmaps of the scenario generation (autoreset); during a step: the green agents' pre-computed blocks
@@ -324,10 +331,15 @@ __global__ __launch_bounds__(PT) void k_step_philox(StepArgs a) {
       // agent's thread: red r on wave r%PW lane r/PW, blue on wave PW-1 lanes 2..6, green draws on lanes >= 8 of the waves
       // that carry a single red agent.  A tick touches only its own agent (queue, observation reset, filter_actions
       // against its own session table, which no other agent edits before the barrier below).
+      // CybORG.set_seed split (EnvState.rng2): the green / red policy streams are keyed by the old generator
+      const uint64_t key_main = rl.s_lo, epi_main = rl.inc_hi;
+      const bool split = s->rng_split != 0;
+      if (split && (is_red || (lane >= 8 && wave >= 2))) { rl.s_lo = s->rng2.s_lo; rl.inc_hi = s->rng2.inc_hi; }
       if (is_red) {
         unsigned long long t0 = ap ? clock64() : 0;
         step_red_policy(xr, ragent);
         if (ap) ap[0] += clock64() - t0;
+        if (split) { rl.s_lo = key_main; rl.inc_hi = epi_main; }
         if (step_tick_agent(xr, NBLUE + ragent)) atomicSub(&s->n_actions, 1);
       }
       else if (wave == PW - 1 && lane >= 2 && lane < 2 + NBLUE) {
@@ -343,6 +355,7 @@ __global__ __launch_bounds__(PT) void k_step_philox(StepArgs a) {
           Ctx xg{s, a.cold + e, &rl, hd, &work, nullptr, nullptr, lg};
           step_green_policy(xg, g);
           int t = work.green_act[g];
+          if (split) { rl.s_lo = key_main; rl.inc_hi = epi_main; }      // the action stream below belongs to the new generator
           if (t < 2) {
             glist[t][atomicAdd(&glist_n[t], 1)] = (uint8_t)g;       // compaction by action type
             // the first block of the agent's action stream, computed here -- behind the red policies -- and handed to the
@@ -351,7 +364,9 @@ __global__ __launch_bounds__(PT) void k_step_philox(StepArgs a) {
             rng_block(&rl, ST_GREEN_EXE + (uint32_t)g, 0, c);
             reinterpret_cast<uint4*>(reset_ws)[g] = make_uint4(c[0], c[1], c[2], c[3]);
           }
+          if (split) { rl.s_lo = s->rng2.s_lo; rl.inc_hi = s->rng2.inc_hi; }
         }
+        if (split) { rl.s_lo = key_main; rl.inc_hi = epi_main; }
       }
       if (a.prof && lane == 63) a.prof[PROF_SLOTS * (size_t)e + 100 + wave] += clock64() - t_begin;   // debug: when each wave reaches the end of the policy phase
       dma_wait();          // the host table has landed in LDS behind the policy phase
@@ -516,6 +531,20 @@ __global__ void k_unpack_obs(const uint8_t* __restrict__ packed, uint8_t* __rest
   for (int k = 0; k < 4; ++k) if (4 * j + k < OBS_TOTAL) o[k] = (uint8_t)((b >> (2 * k)) & 3u);
 }
 
+// CybORG.set_seed (env.py:316-325): a fresh generator for the controller, the state and the hosts; the agents' policies keep
+// the old one until the next reset (EnvState.rng2); the episode itself stays as it is
+__global__ void k_set_seed(EnvState* st, const uint64_t* seeds, int n, int rng_mode) {
+  int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= n) return;
+  if (!st[e].rng_split) {     // the agents' policies stay on the stream they were created with (see EnvState.rng2)
+    st[e].rng2 = st[e].rng;
+    if (rng_mode == 1) { rng_park(&st[e].rng2); st[e].rng2.inc_lo = 0; }
+  }
+  st[e].rng_split = 1;
+  rng_seed(&st[e].rng, seeds[e], (uint32_t)rng_mode);
+  if (rng_mode == 1) { rng_begin_episode(&st[e].rng); rng_park(&st[e].rng); }   // counter mode: the words a reset leaves behind
+}
+
 __global__ void k_rng_state(const EnvState* st, uint64_t* out, int n) {
   int e = blockIdx.x * blockDim.x + threadIdx.x;
   if (e >= n) return;
@@ -548,6 +577,7 @@ struct cc4_handle {
   unsigned long long* d_prof = nullptr;
   uint8_t* d_unpacked = nullptr;                 // [world*N][578] bytes: cc4_unpack_obs_device
   int evlog_on = 0;               // cc4_enable_event_log
+  int one_round_blocks = 5 * 256; // episode blocks the low-occupancy build of k_step_philox keeps resident at once (5 per CU)
   ncclComm_t comm = nullptr; int rank = 0, world = 1;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   std::vector<hipEvent_t> evs;
@@ -594,8 +624,9 @@ static int launch_step(cc4_handle* h, const int32_t* d_actions, const uint8_t* d
   hipEvent_t stop = h->comm ? h->ev_step[buf] : nullptr;
   h->step_event_attached = stop != nullptr;
   if (h->cfg.rng_mode == 1) {
-    if (h->evlog_on) hipExtLaunchKernelGGL(k_step_philox<true>, grid, dim3(PT), sizeof(EnvState), h->stream, nullptr, stop, 0, a);
-    else hipExtLaunchKernelGGL(k_step_philox<false>, grid, dim3(PT), sizeof(EnvState), h->stream, nullptr, stop, 0, a);
+    if (h->evlog_on) hipExtLaunchKernelGGL((k_step_philox<true, 1>), grid, dim3(PT), sizeof(EnvState), h->stream, nullptr, stop, 0, a);
+    else if (h->cfg.num_envs > h->one_round_blocks) hipExtLaunchKernelGGL((k_step_philox<false, 8>), grid, dim3(PT), sizeof(EnvState), h->stream, nullptr, stop, 0, a);
+    else hipExtLaunchKernelGGL((k_step_philox<false, 1>), grid, dim3(PT), sizeof(EnvState), h->stream, nullptr, stop, 0, a);
   } else {
     if (h->evlog_on) hipExtLaunchKernelGGL(k_step<true>, grid, dim3(WAVE), offsetof(EnvState, hd), h->stream, nullptr, stop, 0, a);
     else hipExtLaunchKernelGGL(k_step<false>, grid, dim3(WAVE), offsetof(EnvState, hd), h->stream, nullptr, stop, 0, a);
@@ -630,6 +661,12 @@ int cc4_create(const cc4_config* cfg, cc4_handle** out) {
   h->cfg = *cfg;
   *out = h;
   HIPCHK(h, hipSetDevice(cfg->device_id));
+  {
+    hipDeviceProp_t prop;
+    HIPCHK(h, hipGetDeviceProperties(&prop, cfg->device_id));
+    h->one_round_blocks = 5 * prop.multiProcessorCount;
+    if (const char* v = getenv("CC4_PHILOX_OCCUPANCY_SWITCH")) h->one_round_blocks = atoi(v);   // tuning: batch size above which the 8-blocks-per-CU build runs
+  }
   HIPCHK(h, hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
   size_t n = (size_t)cfg->num_envs;
   HIPCHK(h, hipMalloc(&h->d_state, n * sizeof(EnvState)));
@@ -741,6 +778,15 @@ int cc4_get_rng_state(cc4_handle* h, uint64_t* out) {
   hipLaunchKernelGGL(k_rng_state, dim3((n + 127) / 128), dim3(128), 0, h->stream, h->d_state, h->d_rng, n);
   HIPCHK(h, hipGetLastError());
   HIPCHK(h, hipMemcpyAsync(out, h->d_rng, (size_t)n * 7 * sizeof(uint64_t), hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  return 0;
+}
+int cc4_set_seed(cc4_handle* h, const uint64_t* seeds) {
+  HIPCHK(h, hipSetDevice(h->cfg.device_id));
+  int n = h->cfg.num_envs;
+  HIPCHK(h, hipMemcpyAsync(h->d_seeds, seeds, (size_t)n * sizeof(uint64_t), hipMemcpyHostToDevice, h->stream));
+  hipLaunchKernelGGL(k_set_seed, dim3((n + 127) / 128), dim3(128), 0, h->stream, h->d_state, h->d_seeds, n, h->cfg.rng_mode);
+  HIPCHK(h, hipGetLastError());
   HIPCHK(h, hipStreamSynchronize(h->stream));
   return 0;
 }

@@ -165,6 +165,7 @@ struct alignas(16) EnvState {
   float reward;                      // team reward of the last step (BlueRewardMachine + action_cost)
   uint8_t done, rng_mode, n_green;
   uint8_t policy;                    // bits 0-1 red policy (RP_*), bit 4 green policy (1 = SleepAgent)
+  uint8_t rng_split, pad0[3];        // 1 after CybORG.set_seed: the agents' policies keep drawing from rng2 (see there)
   uint16_t blocks[NSUB];             // blocks[to] bit from
   uint8_t cidr_octet[NSUB];
   uint8_t n_users[NSUB];
@@ -182,6 +183,11 @@ struct alignas(16) EnvState {
   float action_cost;
   int32_t n_actions;                 // actions surviving filter_actions (length of the shuffled index list)
   int32_t n_restore;                 // Restore actions submitted this step (each costs -1)
+  // CybORG.set_seed (env.py:316-325) hands the new Generator to the controller, the state and the hosts
+  // (SimulationController.set_np_random, SC:317-320; State.set_np_random, State.py:241-251) but not to the agent objects,
+  // whose np_random was bound when they were created (SC:1041): until the next reset the green / red POLICIES keep drawing
+  // from the old stream while everything else draws from the new one.  rng2 is that old stream while rng_split is set.
+  Rng rng2;
   BlueAgent blue[NBLUE];
   RSess spool[RS_POOL];              // red session records of all six agents
   RedAgent red[NRED];

@@ -36,7 +36,7 @@ def _headers(submission):
     return version_header, author_header
 
 
-def _write(submission, log_path, total_reward, seed, max_eps, start, end, episode_length):
+def _write(submission, log_path, total_reward, seed, max_eps, start, end, episode_length, actions_log=None, obs_log=None):
     if not log_path.endswith('/'):
         log_path += '/'
     os.makedirs(log_path, exist_ok=True)
@@ -55,6 +55,15 @@ def _write(submission, log_path, total_reward, seed, max_eps, start, end, episod
     with open(log_path + 'scores.txt', 'w') as f:
         f.write(f"reward_mean: {reward_mean}\n")
         f.write(f"reward_stdev: {reward_stdev}\n")
+    if actions_log is not None:      # evaluation.py:158-176: the per-episode action and observation logs
+        with open(log_path + 'full.txt', 'w') as f:
+            f.write(version_header + '\n' + author_header + '\n' + reward_string + '\n')
+            for act, obs, sum_rew in zip(actions_log, obs_log, total_reward):
+                f.write(f"actions: {act},\n observations: {obs},\n total reward: {sum_rew}\n")
+        with open(log_path + 'actions.txt', 'w') as f:
+            f.write(version_header + '\n' + author_header + '\n' + reward_string + '\n')
+            for act in zip(actions_log):
+                f.write(f"actions: {act}")
 
 
 def run_evaluation(submission, log_path=None, max_eps=100, write_to_file=True, seed=None, mode='batched',
@@ -67,9 +76,10 @@ def run_evaluation(submission, log_path=None, max_eps=100, write_to_file=True, s
         cyborg = CybORG(sg, 'sim', seed=seed, vec_factory=vec_factory, device_id=device_id)
         env = submission.wrap(cyborg)
         total_reward = []
+        actions_log, obs_log = ([], []) if (write_to_file and log_path) else (None, None)
         for _ in range(max_eps):
             observations, _info = env.reset()
-            r = []
+            r, a_log, o_log = [], [], []
             for _j in range(episode_length):
                 actions = {name: agent.get_action(observations[name], env.action_space(name))
                            for name, agent in submission.AGENTS.items() if name in env.agents}
@@ -78,7 +88,13 @@ def run_evaluation(submission, log_path=None, max_eps=100, write_to_file=True, s
                 if all(done.values()):
                     break
                 r.append(mean(rew.values()))
+                if actions_log is not None:     # evaluation.py:111-124: what resolved this step (get_last_action) and what the agents saw
+                    a_log.append({name: cyborg.get_last_action(name) for name in env.agents})
+                    o_log.append({name: observations[name] for name in observations.keys()})
             total_reward.append(sum(r))
+            if actions_log is not None:
+                actions_log.append(a_log)
+                obs_log.append(o_log)
     elif mode == 'batched':
         if seed is None:
             seed = int.from_bytes(os.urandom(8), 'little') >> 1
@@ -90,6 +106,9 @@ def run_evaluation(submission, log_path=None, max_eps=100, write_to_file=True, s
         spaces = [Discrete(82), Discrete(82), Discrete(82), Discrete(82), Discrete(242)]
         score = np.zeros(n, np.float64)
         alive = np.ones(n, bool)
+        # batched mode logs what was SUBMITTED per episode and step (labels of the fixed action list) and the observations;
+        # the sequential mode logs what resolved (get_last_action), as the reference does
+        actions_log, obs_log = ([[] for _ in range(n)], [[] for _ in range(n)]) if (write_to_file and log_path) else (None, None)
         for _j in range(episode_length):
             parts = split_obs(obs)
             acts = np.full((n, 5), -1, np.int32)
@@ -103,9 +122,14 @@ def run_evaluation(submission, log_path=None, max_eps=100, write_to_file=True, s
                     for i in range(n):
                         if alive[i]:
                             acts[i, b] = int(agent.get_action(parts[b][i].astype(np.int64), spaces[b]))
-            obs, rew, done, _info = vec.step(acts)
+            obs, rew, done, _info = vec.step(acts)       # raises on any engine error flag (CC4VecEnv strict mode)
             alive &= ~done
             score += np.where(alive, rew, 0.0)           # the step that raises done is not counted (evaluation.py:108-110)
+            if actions_log is not None:
+                po = split_obs(obs)
+                for i in np.nonzero(alive)[0]:
+                    actions_log[i].append({name: int(acts[i, b]) for b, name in enumerate(names) if name in submission.AGENTS})
+                    obs_log[i].append({name: po[b][i].astype(np.int64) for b, name in enumerate(names)})
             if not alive.any():
                 break
         total_reward = [float(x) for x in score]
@@ -118,5 +142,5 @@ def run_evaluation(submission, log_path=None, max_eps=100, write_to_file=True, s
     reward_stdev = stdev(total_reward) if len(total_reward) > 1 else 0.0
     print(f"Average reward is: {reward_mean} with a standard deviation of {reward_stdev}")
     if write_to_file and log_path:
-        _write(submission, log_path, total_reward, seed, max_eps, start, end, episode_length)
+        _write(submission, log_path, total_reward, seed, max_eps, start, end, episode_length, actions_log, obs_log)
     return total_reward

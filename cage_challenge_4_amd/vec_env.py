@@ -18,10 +18,36 @@ ERR_NAMES = {0: 'PROC_OVERFLOW', 1: 'RSESS_OVERFLOW', 2: 'KNOWN_SID_OVERFLOW', 3
              8: 'UNREACHABLE_REFERENCE_PATH', 10: 'BLUE_GREEN_SESSION_KILLED', 11: 'FSM_NO_HOST'}
 
 
+class CC4EngineError(RuntimeError):
+    """An episode left the part of the reference's behaviour the engine reproduces (a fixed-size container overflowed, or the
+    reference itself would have crashed): its results can no longer be trusted to equal the reference's."""
+
+
+def err_names(bits):
+    return [ERR_NAMES.get(i, f'bit{i}') for i in range(32) if (int(bits) >> i) & 1]
+
+
+def raise_on_engine_error(err):
+    """err: uint32 flags per episode (cc4_get_err).  Bit 7 is the reference's own ValueError (State.py:539-540); any other bit
+    raises CC4EngineError -- nothing is ever dropped silently."""
+    err = np.asarray(err)
+    if not err.any():
+        return
+    if (err & (1 << 7)).any():
+        raise ValueError("Step number exceeds last mission phase step maximum. "
+                         "Use step parameter in EnterpriseScenarioGenerator.")  # State.py:539-540
+    bad = np.nonzero(err)[0]
+    raise CC4EngineError(f"engine error flags on {bad.size} episode(s), first: episode {int(bad[0])} {err_names(err[bad[0]])} "
+                         f"(see ERR_NAMES / include/cc4.h; results of a flagged episode may differ from the reference)")
+
+
 class CC4VecEnv:
     def __init__(self, num_envs, steps=500, rng_mode=RNG_PCG64, device_id=0, autoreset=False, red_policy=0, green_policy=0,
-                 topology_seed=0):
-        """topology_seed != 0 (RNG_PHILOX only): all episodes share the scenario drawn from that key (uniform topology)."""
+                 topology_seed=0, strict=True):
+        """topology_seed != 0 (RNG_PHILOX only): all episodes share the scenario drawn from that key (uniform topology).
+        strict: raise (ValueError for a step past the episode's end, as the reference does; CC4EngineError otherwise) as soon as
+        any episode carries an error flag.  strict=False leaves the flags to the caller (`err`, `info['err']`)."""
+        self.strict = bool(strict)
         self.lib = L.load()
         self.num_envs = int(num_envs)
         self.steps = int(steps)
@@ -97,7 +123,9 @@ class CC4VecEnv:
         self._chk(self.lib.cc4_get_err(self._h, self._err.ctypes.data_as(ctypes.c_void_p)), 'cc4_get_err')
         if mask:
             self._chk(self.lib.cc4_get_action_mask(self._h, self._mask.ctypes.data_as(ctypes.c_void_p)), 'cc4_get_action_mask')
-        if (self._err & (1 << 7)).any():
+        if self.strict:
+            raise_on_engine_error(self._err)
+        elif (self._err & (1 << 7)).any():
             raise ValueError("Step number exceeds last mission phase step maximum. "
                              "Use step parameter in EnterpriseScenarioGenerator.")  # State.py:539-540
         return self._obs, self._rew, self._done.astype(bool)
@@ -127,6 +155,14 @@ class CC4VecEnv:
         buf = ctypes.create_string_buffer(need)
         self._chk(0 if self.lib.cc4_get_true_state(self._h, int(env), buf, need) > 0 else -1, 'cc4_get_true_state')
         return buf.value.decode()
+
+    def set_seed(self, seeds):
+        """cc4_set_seed: fresh generators (CybORG.set_seed) without touching the episodes."""
+        if np.isscalar(seeds):
+            seeds = np.uint64(seeds) + np.arange(self.num_envs, dtype=np.uint64)
+        seeds = np.ascontiguousarray(seeds, dtype=np.uint64)
+        assert seeds.shape == (self.num_envs,)
+        self._chk(self.lib.cc4_set_seed(self._h, seeds.ctypes.data_as(ctypes.c_void_p)), 'cc4_set_seed')
 
     def rng_state(self):
         out = np.zeros((self.num_envs, 7), np.uint64)

@@ -17,8 +17,9 @@ import os
 import ctypes
 import numpy as np
 from . import _lib as L
-from .vec_env import CC4VecEnv, RNG_PCG64, split_obs, split_mask
+from .vec_env import CC4VecEnv, RNG_PCG64, split_obs, split_mask, raise_on_engine_error
 from .spaces import Discrete, MultiDiscrete, MultiBinary
+from . import actions as A
 
 SUBNET_NAMES = ['restricted_zone_a_subnet', 'operational_zone_a_subnet', 'restricted_zone_b_subnet',
                 'operational_zone_b_subnet', 'contractor_network_subnet', 'public_access_zone_subnet',
@@ -105,14 +106,146 @@ class CybORG:
         self.vec.enable_event_log(True)                        # single episode: keep the per-step event detail for get_observation
         self.vec.reset(seeds=np.array([seed], np.uint64))      # SimulationController.__init__ creates a scenario
         self.agents = [f'blue_agent_{b}' for b in range(5)]
+        self._labels = None
 
     def reset(self, agent=None, seed=None):
         """env.py:218-243: seed=None keeps the running stream; an int seed starts a fresh Generator."""
         self.vec.reset(seeds=None if seed is None else np.array([seed], np.uint64))
+        self._labels = None
 
     @property
     def unwrapped(self):
         return self
+
+    # ---- the raw CybORG surface around the step (env.py:95-161, 202-216, 266-283, 316-372, 405-415)
+    def _state(self):
+        from .true_state import decode
+        return decode(self.vec.true_state_json(0))
+
+    def _action_labels(self):
+        """The fixed action lists of the five blue agents (BlueFixedActionWrapper.py:233-309) for this episode's topology."""
+        if getattr(self, '_labels', None) is None:
+            self._labels = build_action_labels(self.get_cidr_map(), split_mask(self.vec.action_mask))
+        return self._labels
+
+    def _submit(self, actions, messages):
+        """actions: {blue agent: wrapper index | action object (cage_challenge_4_amd.actions or any object with the same
+        class name and attributes)}; red and green agents run their built-in policies on the device."""
+        acts = np.full((1, 5), -1, np.int32)
+        for a, v in (actions or {}).items():
+            if a not in self.agents_blue:
+                raise NotImplementedError(f"{a}: only the blue agents take external actions on the accelerated path "
+                                          "(red and green run the scenario's built-in policies on the device)")
+            b = self.agents_blue.index(a)
+            labels = self._action_labels()[a]['labels']
+            idx = A.action_index(v, labels)
+            idx = range(len(labels))[idx]                   # list semantics: a negative index counts from the end, out of range raises IndexError
+            acts[0, b] = idx if idx < (242 if b == 4 else 82) else -1
+        msg = np.zeros((1, 5, MESSAGE_LENGTH), np.uint8)
+        for b, a in enumerate(self.agents_blue):
+            m = np.asarray((messages or {}).get(a, EMPTY_MESSAGE)).astype(bool)
+            assert m.shape == (MESSAGE_LENGTH,), \
+                f'{a} attempting to send message {m} that is not in the message space MultiBinary({MESSAGE_LENGTH})'
+            msg[0, b] = m
+        obs, rew, done, vinfo = self.vec.step(acts, msg)
+        raise_on_engine_error(vinfo['err'])               # ValueError past the last step (State.py:539-540); anything else is loud too
+        return obs, rew, done
+
+    def parallel_step(self, actions=None, messages=None, skip_valid_action_check=False):
+        """env.py:95-123: ({agent: dict observation}, {agent: reward components of its team}, {agent: done}, {}) for the
+        agents that acted plus the active ones.  Blue agents get their full dict observation (get_observation); red and
+        green agents -- internal policies here -- are listed with their team's reward and the done flag, and an observation
+        that only carries 'success'."""
+        self._submit(actions, messages)
+        st = self._state()
+        rewards = self.get_rewards()
+        agents = list(dict.fromkeys(list((actions or {}).keys()) + self.active_agents))
+        obs = {}
+        for a in agents:
+            obs[a] = self.get_observation(a) if a.startswith('blue') else {'success': 'UNKNOWN'}
+        team = lambda a: 'Blue' if a.startswith('blue') else ('Red' if a.startswith('red') else 'Green')   # noqa: E731
+        return obs, {a: dict(rewards[team(a)]) for a in agents}, {a: bool(st.raw['done']) for a in agents}, {}
+
+    def step(self, agent=None, action=None, messages=None, skip_valid_action_check=False):
+        """env.py:125-161: the single-agent step of older challenges; returns a Results-like object."""
+        self._submit({} if (agent is None or action is None) else {agent: action}, messages)
+        if agent is None:
+            return Results(observation={})
+        st = self._state()
+        rew = self.get_rewards()['Blue' if agent.startswith('blue') else ('Red' if agent.startswith('red') else 'Green')]
+        return Results(observation=self.get_observation(agent) if agent.startswith('blue') else {'success': 'UNKNOWN'},
+                       done=bool(st.raw['done']), reward=round(sum(rew.values()), 1),
+                       action_space=self.get_action_space(agent) if agent.startswith('blue') else None,
+                       action=[st.last_action[agent]] if agent in st.last_action else None)
+
+    def set_seed(self, seed):
+        """env.py:316-325: a fresh Generator for all further randomness; the episode itself is untouched."""
+        self.vec.set_seed(np.array([seed], np.uint64))
+
+    def get_rewards(self):
+        """env.py:348-357: the last step's rewards by team and component (SimulationController.py:303-311)."""
+        d = self._state().raw
+        ac = d['action_cost']
+        brm = d['reward'] - ac
+        blue = {'BlueRewardMachine': int(brm) if float(brm).is_integer() else brm}
+        red, green = {'None': 0.0}, {'None': 0.0}
+        if d['step'] > 0:                      # 'action_cost' appears with the first step (SimulationController.py:311)
+            blue['action_cost'] = int(ac) if float(ac).is_integer() else ac
+            red['action_cost'] = 0
+            green['action_cost'] = 0
+        return {'Blue': blue, 'Red': red, 'Green': green}
+
+    def get_reward_breakdown(self, agent):
+        """env.py:359-372 -> SimulationController.get_reward_breakdown (SC:1114-1116), which reads an attribute AgentInterface
+        does not have: the reference raises AttributeError for every agent, and so does this mirror."""
+        raise AttributeError("'AgentInterface' object has no attribute 'reward_calculator'")
+
+    @property
+    def agents_blue(self):
+        return [f'blue_agent_{b}' for b in range(5)]
+
+    @property
+    def active_agents(self):
+        """env.py:405-415 -> SimulationController.get_active_agents (SC:373-388): agents holding an active parent-less session:
+        the five blue agents, every green agent, and the red agents that currently own a session without a parent."""
+        d = self._state().raw
+        out = list(self.agents_blue) + [f'green_agent_{g}' for g in range(d['n_green'])]
+        for r, ag in enumerate(d['red']):
+            if any(not (fl & 8) for _sid, _h, _pid, fl in ag['sessions']):   # RS_CHILD: session.parent is not None
+                out.append(f'red_agent_{r}')
+        return out
+
+    def get_action_space(self, agent):
+        """env.py:266-283 for a blue agent: the parameter dictionaries of its ActionSpace (Shared/ActionSpace.py:105-126) that
+        the fixed-index wrappers are built from: the action classes, its subnets, and the known hostnames / addresses."""
+        if agent not in self.agents_blue:
+            raise ValueError(f'Agent {agent} not in agent list {self.agents_blue}')
+        b = self.agents_blue.index(agent)
+        t = self.topology()
+        cidr = self.get_cidr_map()
+        ips = self.get_ip_map()
+        from ipaddress import IPv4Network, IPv4Address
+        mine = {h for h in ips if any(h.startswith(sn) for sn in BLUE_SUBNETS[b])}
+        return {'action': {c: True for c in A.BLUE_ACTIONS},
+                'allowed_subnets': list(BLUE_SUBNETS[b]),
+                'subnet': {IPv4Network(cidr[sn]): sn in BLUE_SUBNETS[b] for sn in SUBNET_NAMES},
+                'ip_address': {IPv4Address(ip): h in mine for h, ip in ips.items()},
+                'session': {0: True},
+                'username': {'root': True, 'user': True}, 'password': {},
+                'agent': {agent: True},
+                'hostname': {h: h in mine for h in ips}}
+
+    def get_agent_state(self, agent_name):
+        """env.py:202-216: the true state restricted to what the scenario's INFO_DICT lists for the agent ('True' = all)."""
+        from .true_state import decode
+        st = decode(self.vec.true_state_json(0))
+        if agent_name == 'True' or agent_name not in self.agents_blue:
+            return st.as_dict()
+        b = self.agents_blue.index(agent_name)
+        return st.as_dict({h: None for h in st.hosts if any(h.startswith(sn) for sn in BLUE_SUBNETS[b])})
+
+    def get_attr(self, attribute):
+        return getattr(self, attribute) if hasattr(self, attribute) else None
 
     def topology(self):
         return self.vec.topology(0)
@@ -137,10 +270,11 @@ class CybORG:
         return blue_observations(decode(self.vec.true_state_json(0)))[agent]
 
     def get_last_action(self, agent):
-        """env.py:300-314: the action of `agent` (blue_agent_b / red_agent_r) that resolved in the last step, as an object
-        whose str() equals the reference action's ('Restore <hostname>', 'ExploitRemoteService <ip>', 'Sleep', ...)."""
+        """env.py:300-314: the actions of `agent` (blue_agent_b / red_agent_r) that resolved in the last step -- a list, as the
+        reference returns (one entry here) -- as objects whose str() equals the reference action's ('Restore <hostname>',
+        'ExploitRemoteService <ip>', 'Sleep', ...) and whose .name is the action class name."""
         from .true_state import decode
-        return decode(self.vec.true_state_json(0)).last_action[agent]
+        return [decode(self.vec.true_state_json(0)).last_action[agent]]
 
     def get_ip_map(self):
         t = self.topology()
@@ -149,6 +283,48 @@ class CybORG:
             if t[27 + 2 * h]:
                 out[host_name(h)] = f"10.0.{int(t[h // 17])}.{int(t[28 + 2 * h])}"
         return out
+
+
+class Results:
+    """Shared/Results.py:21-60, the fields CybORG.step fills."""
+    def __init__(self, observation=None, done=None, reward=None, action_space=None, action=None, info=None, error=None):
+        self.observation, self.done, self.reward = observation, done, reward
+        self.action_space, self.action, self.info, self.error = action_space, action, info, error
+
+
+def build_action_labels(cidr, masks, pad_spaces=False, max_size=242):
+    """The fixed action list of every blue agent as labels + mask (BlueFixedActionWrapper.py:233-309): Analyse / Monitor /
+    Remove / Restore / Sleep / AllowTrafficZone / BlockTrafficZone / DeployDecoy over the agent's sorted hosts and subnets;
+    the mask comes from the engine (which host slots exist in this episode)."""
+    out = {}
+    for b in range(5):
+        a = f'blue_agent_{b}'
+        mask = [bool(v) for v in masks[b][0]]
+        hosts = sorted(f'{sn}_{kind}_host_{i}' for sn in BLUE_SUBNETS[b]
+                       for kind, n in (('user', MAX_USER_HOSTS), ('server', MAX_SERVER_HOSTS)) for i in range(n))
+        subnets = sorted(BLUE_SUBNETS[b])
+        labels = []
+
+        def host_block(cmd):
+            base = len(labels)
+            for i, h in enumerate(hosts):
+                labels.append(f"{cmd} {h}" if mask[base + i] else f"[Invalid] {cmd} {h}")
+
+        def zone_block(cmd):
+            for dst in subnets:
+                for src in sorted(SUBNET_NAMES):
+                    if src == dst:
+                        continue
+                    labels.append(f"{cmd} {dst} ({cidr[dst]}) <- {src} ({cidr[src]})")
+        host_block('Analyse'); labels.append('Monitor'); host_block('Remove'); host_block('Restore'); labels.append('Sleep')
+        zone_block('AllowTrafficZone'); zone_block('BlockTrafficZone'); host_block('DeployDecoy')
+        assert len(labels) == len(mask)
+        if pad_spaces and len(labels) < max_size:
+            pad = max_size - len(labels)
+            labels += ['[Padding] Sleep'] * pad
+            mask += [False] * pad
+        out[a] = {'actions': list(range(len(labels))), 'labels': labels, 'mask': mask}
+    return out
 
 
 def host_name(h):
@@ -181,32 +357,8 @@ class BlueFixedActionWrapper:
 
     # -- action space bookkeeping (mask comes from the engine, labels are rebuilt from the topology)
     def _refresh_action_space(self):
-        masks = split_mask(self.env.vec.action_mask)
-        cidr = self.env.get_cidr_map()
-        self._action_space = {}
-        for b, a in enumerate(self.possible_agents):
-            mask = [bool(v) for v in masks[b][0]]
-            hosts = [h for h in self._agent_metadata[a]['hosts'] if 'router' not in h]
-            subnets = self._agent_metadata[a]['subnets']
-            labels = []
-            def host_block(cmd):
-                base = len(labels)
-                for i, h in enumerate(hosts):
-                    labels.append(f"{cmd} {h}" if mask[base + i] else f"[Invalid] {cmd} {h}")
-            def zone_block(cmd):
-                for dst in subnets:
-                    for src in sorted(SUBNET_NAMES):
-                        if src == dst:
-                            continue
-                        labels.append(f"{cmd} {dst} ({cidr[dst]}) <- {src} ({cidr[src]})")
-            host_block('Analyse'); labels.append('Monitor'); host_block('Remove'); host_block('Restore'); labels.append('Sleep')
-            zone_block('AllowTrafficZone'); zone_block('BlockTrafficZone'); host_block('DeployDecoy')
-            assert len(labels) == len(mask)
-            if self._pad_spaces and len(labels) < self._max_act_space_size:
-                pad = self._max_act_space_size - len(labels)
-                labels += ['[Padding] Sleep'] * pad
-                mask += [False] * pad
-            self._action_space[a] = {'actions': list(range(len(labels))), 'labels': labels, 'mask': mask}
+        self._action_space = build_action_labels(self.env.get_cidr_map(), split_mask(self.env.vec.action_mask),
+                                                 self._pad_spaces, self._max_act_space_size)
 
     def reset(self, *args, **kwargs):
         self.env.reset(*args, **kwargs)
@@ -221,13 +373,14 @@ class BlueFixedActionWrapper:
         action_dict = {} if actions is None else actions
         acts = np.full((1, 5), -1, np.int32)
         for a, v in action_dict.items():
-            if not isinstance(v, (int, np.integer)):
-                raise NotImplementedError("the accelerated path takes wrapper action indices, not Action objects")
             b = self.possible_agents.index(a)
             n = 242 if b == 4 else 82
-            acts[0, b] = int(v) if 0 <= int(v) < n else -1      # padded slots are Sleep (BlueFixedActionWrapper.py:320-332)
-            if not 0 <= int(v) < len(self._action_space[a]['labels']):
-                raise IndexError('list index out of range')       # same failure as indexing the reference's action list
+            labels = self._action_space[a]['labels']
+            # an index into the agent's action list (Python list semantics: negative counts from the end, out of range raises
+            # IndexError), or an action object, which the reference forwards as it is (BlueFixedActionWrapper.py:142-148)
+            v = A.action_index(v, labels)
+            v = range(len(labels))[v]
+            acts[0, b] = v if v < n else -1                       # padded slots are Sleep (BlueFixedActionWrapper.py:320-332)
         messages = {} if messages is None else messages
         msg = np.zeros((1, 5, MESSAGE_LENGTH), np.uint8)
         for b, a in enumerate(self.possible_agents):
@@ -236,9 +389,9 @@ class BlueFixedActionWrapper:
                 f'{a} attempting to send message {m} that is not in the message space MultiBinary({MESSAGE_LENGTH})'
             msg[0, b] = m
         obs, rew, done, vinfo = self.env.vec.step(acts, msg)
-        if int(vinfo['err'][0]) & (1 << 7):   # State.check_next_phase_on_update_step (State.py:539-540)
-            raise ValueError("Step number exceeds last mission phase step maximum. "
-                             "Use step parameter in EnterpriseScenarioGenerator.")
+        # State.check_next_phase_on_update_step (State.py:539-540) raises ValueError past the last step; any other engine flag
+        # (a container bound, a path the reference would crash on) raises CC4EngineError: never a silently different result
+        raise_on_engine_error(vinfo['err'])
         d = bool(done[0])
         ob = split_obs(obs)
         observations = {a: ob[b][0].astype(np.int64) for b, a in enumerate(self.possible_agents)}

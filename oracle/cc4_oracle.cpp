@@ -56,6 +56,14 @@ void cc4o_reset(void* h, int i, uint64_t seed, int rng_mode, int steps, int cont
   uint32_t ws[RESET_WS_WORDS];   // work area of the counter-mode generation (the device kernels use LDS)
   env_reset(x, seed, rng_mode, steps, continue_stream != 0, policy, o->topo, rng_mode == 1 ? ws : nullptr);
 }
+void cc4o_set_seed(void* h, int i, uint64_t seed, int rng_mode) {   // CybORG.set_seed: the restatement of k_set_seed (csrc/cc4_hip.hip)
+  EnvState& st = ((Oracle*)h)->st[i];
+  if (!st.rng_split) { st.rng2 = st.rng; if (rng_mode == 1) { rng_park(&st.rng2); st.rng2.inc_lo = 0; } }
+  st.rng_split = 1;
+  Rng* r = &st.rng;
+  rng_seed(r, seed, (uint32_t)rng_mode);
+  if (rng_mode == 1) { rng_begin_episode(r); rng_park(r); }
+}
 void cc4o_set_topology_seed(void* h, uint32_t seed) { ((Oracle*)h)->topo = seed; }
 void cc4o_enable_event_log(void* h, int on) { Oracle* o = (Oracle*)h; o->evlog = on ? 1 : 0; for (int i = 0; i < o->n; ++i) { o->cold[i].evlog.enabled = on ? 1u : 0u; o->cold[i].evlog.n = 0; } }
 void cc4o_step(void* h, int i, const int32_t* actions, const uint8_t* msgs) {

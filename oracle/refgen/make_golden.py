@@ -19,6 +19,7 @@ from CybORG.Agents import SleepAgent, EnterpriseGreenAgent, FiniteStateRedAgent,
 RED = {'fsm': (FiniteStateRedAgent, 0), 'sleep': (SleepAgent, 1), 'discovery': (DiscoveryFSRed, 2), 'random': (RandomSelectRedAgent, 3)}
 GREEN = {'enterprise': (EnterpriseGreenAgent, 0), 'sleep': (SleepAgent, 1)}
 from CybORG.Agents.Wrappers import BlueFlatWrapper
+from blue_policies import BluePolicy, KINDS
 
 OUT = os.path.join(os.path.dirname(__file__), '..', '..', 'tests', 'golden')
 
@@ -45,6 +46,7 @@ def record(seed, steps, blue, init, nsteps=None, msgs=False, red='fsm', green='e
         obs, info = w.reset(seed=seed + 1)
         reset_seed = seed + 1
     arng = np.random.default_rng(seed ^ 0xB10E)
+    bpol = BluePolicy(blue, {f'blue_agent_{b}': w.action_labels(f'blue_agent_{b}') for b in range(5)}, seed) if blue in KINDS else None
     nsteps = nsteps or steps
     A = np.full((nsteps, 5), -1, np.int16)
     O = np.zeros((nsteps + 1, 578), np.uint8)
@@ -59,6 +61,9 @@ def record(seed, steps, blue, init, nsteps=None, msgs=False, red='fsm', green='e
         acts = {}
         if blue == 'random':
             A[t] = [arng.integers(82), arng.integers(82), arng.integers(82), arng.integers(82), arng.integers(242)]
+            acts = {f'blue_agent_{b}': int(A[t, b]) for b in range(5)}
+        elif bpol is not None:          # structured blue policy (blue_policies.py): one kind of action per agent
+            A[t] = bpol.act(t)
             acts = {f'blue_agent_{b}': int(A[t, b]) for b in range(5)}
         messages = None
         if msgs:
@@ -88,6 +93,17 @@ if __name__ == '__main__':
         record(42, 300, 'random', 'reset', red='sleep')
         record(43, 200, 'random', 'ctor', red='discovery', green='sleep')
         record(44, 500, 'random', 'ctor', red='random')
+        sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == 'structured':   # structured blue policies (r02: the process lists are unbounded)
+        record(321, 500, 'decoy_one', 'ctor')        # every agent stacks decoys on one host: 257 processes on it at the end
+        record(322, 500, 'decoy', 'reset')
+        record(323, 500, 'decoy_restore', 'ctor')
+        record(324, 500, 'block_allow', 'ctor')
+        record(325, 500, 'remove', 'reset')
+        record(326, 500, 'restore', 'ctor')
+        record(327, 500, 'mix', 'ctor')
+        record(328, 300, 'decoy', 'ctor', red='random')
+        record(329, 300, 'mix', 'reset', red='discovery')
         sys.exit(0)
     # BASELINE config 1 (SleepAgent blue, FSM red, 500 steps) + seeded random blue; regression seeds of
     # CybORG/Tests/test_cc4/test_heuristic_agents.py

@@ -98,6 +98,13 @@ class OracleVecEnv:
             self._collect(i)
         return self._obs, self._rew, self._done, {'err': self._err}
 
+    def set_seed(self, seeds):
+        if np.isscalar(seeds):
+            seeds = np.uint64(seeds) + np.arange(self.num_envs, dtype=np.uint64)
+        self.lib.cc4o_set_seed.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_uint64, ctypes.c_int]
+        for i in range(self.num_envs):
+            self.lib.cc4o_set_seed(self._h, i, ctypes.c_uint64(int(seeds[i])), self.rng_mode)
+
     @property
     def action_mask(self):
         return self.mask()

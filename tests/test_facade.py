@@ -1,0 +1,112 @@
+"""The raw CybORG surface around the step (parallel_step with action OBJECTS, step(agent, action), set_seed, get_rewards,
+active_agents, get_action_space, get_agent_state, get_last_action) against tests/golden/facade_seed123.json, recorded from
+the real reference by oracle/refgen/make_facade_golden.py.  CPU: the oracle as backend; GPU: the HIP engine."""
+import json
+import os
+import numpy as np
+import pytest
+import golden_util as G
+from cage_challenge_4_amd import CybORG, EnterpriseScenarioGenerator, SleepAgent, EnterpriseGreenAgent, FiniteStateRedAgent, BlueFlatWrapper
+from cage_challenge_4_amd import actions as A
+
+
+def _compact(names):
+    return {'blue': sum(n.startswith('blue') for n in names), 'green': sum(n.startswith('green') for n in names),
+            'red': sorted(n for n in names if n.startswith('red'))}
+
+
+def _replay(vec_factory):
+    doc = json.load(open(os.path.join(G.GOLDEN_DIR, 'facade_seed123.json')))
+    sg = EnterpriseScenarioGenerator(blue_agent_class=SleepAgent, green_agent_class=EnterpriseGreenAgent,
+                                     red_agent_class=FiniteStateRedAgent, steps=doc['steps'])
+    env = CybORG(sg, seed=doc['seed'], vec_factory=vec_factory)
+    env.reset()                                   # the generator wrapped the env and reset it once (BlueFlatWrapper.reset)
+    assert env.get_rewards() == {'Blue': {'BlueRewardMachine': 0}, 'Red': {'None': 0.0}, 'Green': {'None': 0.0}}
+    for t, row in enumerate(doc['rows']):
+        if t == doc['reseed_at']:
+            env.set_seed(doc['reseed'])
+        acts = {}
+        for b, (idx, cls, params, submitted) in enumerate(row['actions']):
+            if not submitted:
+                continue
+            agent = f'blue_agent_{b}'
+            kw = dict(params)
+            if cls not in ('Sleep',):
+                kw.update(session=0, agent=agent)
+            acts[agent] = getattr(A, cls)(**kw) if cls != 'Sleep' else A.Sleep()
+            assert A.action_index(acts[agent], env._action_labels()[agent]['labels']) == idx    # object -> the reference's own list index
+        obs, rew, done, info = env.parallel_step(acts, messages=None)
+        assert info == {}
+        assert _compact(obs.keys()) == row['returned_agents'], t
+        assert {a: rew[a] for a in sorted(rew) if a.startswith('blue')} == row['rewards_blue'], t
+        assert sorted({json.dumps(rew[a], sort_keys=True) for a in rew if not a.startswith('blue')}) == row['rewards_other']
+        assert sorted(set(done.values())) == row['dones']
+        assert env.get_rewards() == row['get_rewards'], t
+        assert _compact(env.active_agents) == row['active_agents'], t
+        for r in range(6):
+            assert ' | '.join(str(a) for a in env.get_last_action(f'red_agent_{r}')) == row['last_red'][f'red_agent_{r}'], (t, r)
+        for b in range(5):
+            assert ' | '.join(str(a) for a in env.get_last_action(f'blue_agent_{b}')) == row['last_blue'][f'blue_agent_{b}'], (t, b)
+    return env
+
+
+def _other_surface(vec_factory):
+    sg = EnterpriseScenarioGenerator(blue_agent_class=SleepAgent, green_agent_class=EnterpriseGreenAgent,
+                                     red_agent_class=FiniteStateRedAgent, steps=10)
+    env = CybORG(scenario_generator=sg, vec_factory=vec_factory)
+    # CybORG/Tests/test_cc4/test_cc4_seed.py:16-31: the same seed gives the same actions
+    runs = []
+    for _ in range(2):
+        env.reset(seed=123)
+        seen = []
+        for _step in range(5):
+            env.step()
+            seen.append({a: env.get_last_action(a)[0].name for a in env.agents + [f'red_agent_{r}' for r in range(6)]})
+        runs.append(seen)
+    assert runs[0] == runs[1]
+    # step(agent, action): Results with the reference's fields (env.py:125-161)
+    env.reset(seed=5)
+    host = next(h for h in env.get_ip_map() if h.startswith('restricted_zone_a_subnet_user_host'))
+    res = env.step('blue_agent_0', A.Restore(session=0, agent='blue_agent_0', hostname=host))
+    assert res.reward == -1.0 and res.done is False and isinstance(res.observation, dict) and 'success' in res.observation
+    assert str(res.action[0]) == 'Sleep'                       # Restore takes five ticks: nothing resolved yet
+    for _ in range(4):
+        res = env.step('blue_agent_0', None)
+    assert str(res.action[0]) == f'Restore {host}'
+    sp = env.get_action_space('blue_agent_0')
+    assert set(sp) >= {'action', 'allowed_subnets', 'subnet', 'ip_address', 'session', 'hostname', 'agent'}
+    assert sp['allowed_subnets'] == ['restricted_zone_a_subnet'] and sum(sp['subnet'].values()) == 1 and sp['session'] == {0: True}
+    assert sp['hostname'][host] is True and len(sp['action']) == 8
+    st = env.get_agent_state('blue_agent_0')
+    assert st['success'] is True and all(k == 'success' or k.startswith('restricted_zone_a_subnet') for k in st)
+    assert len(env.get_agent_state('True')) > len(st)
+    with pytest.raises(AttributeError):
+        env.get_reward_breakdown('blue_agent_0')               # the reference raises the same (SimulationController.py:1114-1116)
+    with pytest.raises(ValueError):
+        for _ in range(20):
+            env.parallel_step({})                              # State.py:539-540: stepping past the last mission phase
+    # wrapper: action objects and negative indices behave like the reference's list indexing (BlueFixedActionWrapper.py:142-148)
+    w = BlueFlatWrapper(CybORG(EnterpriseScenarioGenerator(blue_agent_class=SleepAgent, green_agent_class=SleepAgent,
+                                                           red_agent_class=SleepAgent, steps=6), seed=3, vec_factory=vec_factory))
+    w.reset()
+    o, *_ = w.step(actions={'blue_agent_0': A.BlockTrafficZone(session=0, agent='blue_agent_0', from_subnet='office_network_subnet',
+                                                                 to_subnet='restricted_zone_a_subnet')})
+    blocked = o['blue_agent_0'][10:19]                          # BLOCKED_SUBNETS_SLICE of test_BlueEnterpriseWrapper.py:30-45
+    names = sorted(['restricted_zone_a_subnet', 'operational_zone_a_subnet', 'restricted_zone_b_subnet', 'operational_zone_b_subnet',
+                    'contractor_network_subnet', 'public_access_zone_subnet', 'admin_network_subnet', 'office_network_subnet', 'internet_subnet'])
+    assert list(blocked) == [int(n == 'office_network_subnet') for n in names]
+    w.step(actions={'blue_agent_4': -1})                        # the last action of the list (a DeployDecoy slot), not an error
+    with pytest.raises(IndexError):
+        w.step(actions={'blue_agent_0': 82})
+
+
+def test_facade_matches_reference_oracle_backend(oracle_lib):
+    from oracle_binding import OracleVecEnv
+    _replay(OracleVecEnv)
+    _other_surface(OracleVecEnv)
+
+
+@pytest.mark.gpu
+def test_facade_matches_reference_hip():
+    _replay(None)
+    _other_surface(None)

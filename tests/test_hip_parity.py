@@ -404,3 +404,118 @@ def test_masked_reset_touches_only_the_masked_episodes(rng_mode):
     sel = mask.astype(bool)
     assert np.array_equal(o1[sel], o2[sel]) and np.array_equal(r1[sel], r2[sel])
     assert not env.err.any()
+
+
+def _kind_actions(mask, kind, rng, one_host=False):
+    """[N,5] wrapper indices: every agent plays `kind` ('decoy' | 'restore' | 'remove') on a random valid host of its zone
+    (one_host: always its first valid one).  mask: [N,570] action mask of the batch."""
+    n = mask.shape[0]
+    a = np.zeros((n, 5), np.int32)
+    for b in range(5):
+        nsub = 3 if b == 4 else 1
+        nh, nc = 16 * nsub, 8 * nsub
+        base = {'remove': nh + 1, 'restore': 2 * nh + 1, 'decoy': 3 * nh + 2 + 2 * nc}[kind]
+        m = mask[:, (82 * b if b < 4 else 328) + base:(82 * b if b < 4 else 328) + base + nh]
+        if one_host:
+            a[:, b] = base + m.argmax(axis=1)
+        else:
+            r = rng.random((n, nh)) * m                       # a random valid slot per episode
+            a[:, b] = base + r.argmax(axis=1)
+    return a
+
+
+@pytest.mark.parametrize('rng_mode', [0, 1], ids=['pcg64', 'philox'])
+def test_soak_decoy_only_blue_never_overflows(rng_mode):
+    """4096 episodes x 500 steps with every blue agent deploying decoys (random valid host; one fixed host for
+    the first 256 episodes, which stacks ~250 decoys on it): process lists grow past the hot row into EnvCold.povf, no
+    engine error flag is ever raised, and the first episodes stay bit-identical to the CPU oracle including the packed state."""
+    n, k = 4096, 8
+    dev = _dev(n, steps=500, rng_mode=rng_mode); dev.reset(seeds=31000)
+    ora = OracleVecEnv(k, steps=500, rng_mode=rng_mode); ora.reset(seeds=31000)
+    mask = dev.action_mask
+    rng = np.random.default_rng(5)
+    fixed = np.arange(n) < 256
+    for t in range(499):
+        a = np.where(fixed[:, None], _kind_actions(mask, 'decoy', rng, one_host=True), _kind_actions(mask, 'decoy', rng))
+        obs, rew, done, info = dev.step(a)                    # strict mode: raises on any error flag
+        o = ora.step(a[:k])
+        assert np.array_equal(obs[:k], o[0]) and np.array_equal(rew[:k], o[1]), t
+    assert not dev.err.any() and not ora._err.any()
+    for i in range(k):
+        assert np.array_equal(dev.get_state(i), ora.get_state(i)), i
+    import json
+    nproc = max(len(h['procs']) for h in json.loads(dev.true_state_json(0))['hosts'])
+    assert nproc >= 240, nproc                                # the stack really went far beyond the 8 hot-row slots
+    dev.close()
+
+
+@pytest.mark.parametrize('kind', ['restore', 'remove'])
+def test_structured_blue_policies_match_oracle(kind):
+    """Restore-only / Remove-only blue (both RNG modes): HIP == oracle every step and in the packed state."""
+    n = 64
+    for rng_mode in (0, 1):
+        dev = _dev(n, steps=300, rng_mode=rng_mode); dev.reset(seeds=32000)
+        ora = OracleVecEnv(n, steps=300, rng_mode=rng_mode); ora.reset(seeds=32000)
+        mask = dev.action_mask
+        rng = np.random.default_rng(6)
+        for t in range(299):
+            a = _kind_actions(mask, kind, rng)
+            obs, rew, done, info = dev.step(a)
+            o = ora.step(a)
+            assert np.array_equal(obs, o[0]) and np.array_equal(rew, o[1]), (rng_mode, t)
+        for i in range(n):
+            assert np.array_equal(dev.get_state(i), ora.get_state(i)), (rng_mode, i)
+        dev.close()
+
+
+def test_exchange_row_of_a_reset_and_device_unpack():
+    """cc4_allgather_obs right after cc4_reset gathers the RESET observations (k_reset writes the packed exchange
+    row); cc4_get_allgathered_obs reads the buffer of the last all-gather, not of the last step; cc4_unpack_obs_device turns
+    the gathered 2-bit rows into [world*N, 578] bytes on the device."""
+    import ctypes, os
+    os.environ.setdefault('NCCL_SOCKET_IFNAME', 'lo')
+    from cage_challenge_4_amd import distributed as D
+    n = 192
+    dev = _dev(n, steps=50, rng_mode=1)
+    dev.reset(seeds=9)
+    out = np.zeros((n, 578), np.uint8)
+    assert dev.lib.cc4_get_allgathered_obs(dev._h, out.ctypes.data_as(ctypes.c_void_p)) != 0      # no communicator yet
+    ident = (ctypes.c_uint8 * 128)()
+    assert dev.lib.cc4_comm_unique_id(ident) == 0
+    dev._chk(dev.lib.cc4_comm_init(dev._h, 0, 1, ident), 'cc4_comm_init')
+    assert dev.lib.cc4_get_allgathered_obs(dev._h, out.ctypes.data_as(ctypes.c_void_p)) != 0      # nothing gathered yet
+    obs0 = dev.reset(seeds=9).copy()
+    assert D.allgather_obs_device(dev)
+    D.allgather_wait(dev)
+    assert np.array_equal(D.allgathered_obs_host(dev, 1), obs0.astype(np.uint8))
+    for t in range(3):
+        obs, *_ = dev.step(random_actions(9, t, n))
+        obs = obs.copy()
+        assert D.allgather_obs_device(dev)
+        p = ctypes.c_void_p()
+        dev._chk(dev.lib.cc4_unpack_obs_device(dev._h, ctypes.byref(p)), 'cc4_unpack_obs_device')
+        assert p.value
+        D.allgather_wait(dev)
+        dev._chk(dev.lib.cc4_get_unpacked_obs(dev._h, out.ctypes.data_as(ctypes.c_void_p)), 'cc4_get_unpacked_obs')
+        assert np.array_equal(out, obs.astype(np.uint8)), t
+    newer, *_ = dev.step(random_actions(9, 3, n))             # a step after the last gather: the gathered copy must not move
+    assert np.array_equal(D.allgathered_obs_host(dev, 1), obs.astype(np.uint8))
+    assert not np.array_equal(newer.astype(np.uint8), obs.astype(np.uint8))
+    dev.close()
+
+
+def test_set_seed_matches_oracle():
+    """cc4_set_seed (CybORG.set_seed): HIP == oracle after a mid-episode reseed, both RNG modes, incl. the packed state."""
+    n = 32
+    for rng_mode in (0, 1):
+        dev = _dev(n, steps=100, rng_mode=rng_mode); dev.reset(seeds=400)
+        ora = OracleVecEnv(n, steps=100, rng_mode=rng_mode); ora.reset(seeds=400)
+        for t in range(60):
+            if t in (20, 35):
+                dev.set_seed(7000 + t); ora.set_seed(7000 + t)
+            a = random_actions(400, t, n)
+            d, o = dev.step(a), ora.step(a)
+            assert np.array_equal(d[0], o[0]) and np.array_equal(d[1], o[1]), (rng_mode, t)
+        for i in range(n):
+            assert np.array_equal(dev.get_state(i), ora.get_state(i)), (rng_mode, i)
+        dev.close()
