@@ -195,7 +195,7 @@ def main():
     mode = RNG_PCG64 if args.rng == 'pcg64' else RNG_PHILOX
 
     def make_env(n, rng_mode, first, **kw):
-        e = CC4VecEnv(n, steps=args.episode_steps, rng_mode=rng_mode, device_id=dev_id, autoreset=True, **kw)
+        e = CC4VecEnv(n, steps=args.episode_steps, rng_mode=rng_mode, device_id=dev_id, autoreset=True, strict=False, **kw)
         e.reset(seeds=np.uint64(args.seed0) + np.arange(first, first + n, dtype=np.uint64))
         return e
 
@@ -255,6 +255,14 @@ def main():
     main_res = measure(env, lo, total_envs)
     env._fetch()
     err_any = bool(env.err.any())
+    # a sharding-independent digest of where the batch stands after the run (episodes are seeded and driven by their GLOBAL
+    # index): the last step's rewards and done flags summed over all ranks -- equal for any world size at equal step counts
+    digest = [float(env._rew.astype(np.float64).sum()), float(env._done.sum()), float(err_any)]
+    if dist_on and world > 1:
+        t = torch.tensor(digest, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        digest = [float(a) for a in t]
+        err_any = digest[2] > 0
     mean_hosts = float(np.mean([int(env.topology(i)[27::2].sum()) for i in range(0, n_local, max(1, n_local // 64))]))
 
     subs = {}
@@ -308,6 +316,8 @@ def main():
                 'envs_per_gpu': n_local, 'total_envs': total_envs, 'rng': args.rng,
                 'exchange': exchange_note or ('RCCL all-gather of the observations of every step (2 bits per value, 148 B per episode) on a second stream, overlapped with the next step' if dist_on else 'none'),
                 'env_steps_per_sec': main_res['value'] / 5.0, 'engine_error_flags': err_any,
+                'last_step_reward_sum': digest[0], 'last_step_done_count': digest[1],
+                'steps_run': args.warmup + main_res['regions'] * args.steps,
                 'timed_regions': main_res['regions'], 'region_steps': args.steps, 'ms_per_step_median_region': main_res['ms_per_step_median_region'],
                 'region_spread': main_res['region_spread'],
                 'autoreset_in_timed_region': main_res['autoreset_launches_in_timed_regions'] > 0,

@@ -140,9 +140,18 @@ CC4_HD int last_set(const uint32_t* bm, int nwords) {
 }
 
 // Host.get_ephemeral_port (Simulator/Host.py:175-187): one re-draw on collision, then remember the port.
-CC4_HD int eph_port(Ctx x, int h) {
-  // philox mode: the port value is unobservable on this path (only its stream consumption matters to numpy parity)
-  if (x.r->mode != 0) return 49152;
+CC4_HD int eph_port(Ctx x, int h, int salt = 0) {
+  // Counter mode: the port value is unobservable on the flat-observation path, so nothing is drawn.  With the event log on
+  // (dict observations) it is taken from a sibling of the acting agent's stream -- block (current draw position, salt) of stream
+  // id | 0x8000 -- which consumes nothing of the agent's own stream: logging never changes a trajectory.  `salt` tells apart
+  // the ports one action draws between two draws of its stream.  (No per-host uniqueness re-draw: agents resolved on different
+  // lanes would race for it; a collision among 10848 ports is as unobservable as it is rare.)
+  if (x.r->mode != 0) {
+    if (!x.lg) return 49152;
+    uint32_t c[4];
+    rng_block(x.r, x.r->ndraw | 0x8000u, (uint32_t)(x.r->s_hi * 64u + (uint32_t)salt), c);
+    return 49152 + (int)(((uint64_t)c[0] * (60000u - 49152u)) >> 32);
+  }
   uint32_t p = rng_below(x.r, 60000 - 49152);
   uint32_t* bm = x.c->eph[h];
   if (bit_get(bm, (int)p)) p = rng_below(x.r, 60000 - 49152);
@@ -1342,7 +1351,7 @@ CC4_HD void red_scan(Ctx x, int r, const Act& a, double rate) {
       int pb = kind_port(k);
       if (!pb) continue;
       ports |= pb;
-      if (fixed <= rate || kind_is_decoy(k)) { ev_conn(x, tgt); int ep = eph_port(x, tgt); ev_log(x, 200 + r, tgt, 0, tgt, port_of_bit(pb), src, ep, 0); }   // Portscan.py:59-64
+      if (fixed <= rate || kind_is_decoy(k)) { ev_conn(x, tgt); int ep = eph_port(x, tgt, (i0 + k8) & 63); ev_log(x, 200 + r, tgt, 0, tgt, port_of_bit(pb), src, ep, 0); }   // Portscan.py:59-64
     }
   }
   if (ports) {
@@ -1433,13 +1442,13 @@ CC4_HD void red_exploit(Ctx x, int r, const Act& a) {
   if (vp < 0) { red_result(x, r, a, T_FALSE); return; }
   bool decoy = kind_is_decoy(vk);
   const int xport = sel == X_HTTPRFI ? 80 : (sel == X_HTTPSRFI ? 443 : (sel == X_SQLI ? 3390 : 25));
-  if (decoy) { ev_conn(x, tgt); int ep = eph_port(x, tgt); ev_log(x, 200 + r, tgt, 0, tgt, xport, src, ep, 0); }  // _get_vulnerable_process alert (ExploitAction.py:189-196)
+  if (decoy) { ev_conn(x, tgt); int ep = eph_port(x, tgt, 1); ev_log(x, 200 + r, tgt, 0, tgt, xport, src, ep, 0); }  // _get_vulnerable_process alert (ExploitAction.py:189-196)
   obs_put(x, r, true, tgt, OE_IFACE, false);
   bool works = (sel == X_SQLI) || decoy;  // rfi only on decoys; real Haraka is 2.8.9 (HarakaRCE.py:19, HTTPRFI.py:18)
   if (!works) { red_result(x, r, a, T_FALSE); return; }
   if (0.0 >= rng_random(x.r)) { red_result(x, r, a, T_FALSE); return; }  // (1 - success_rate) >= random()
-  const int lport = eph_port(x, tgt);  // local_port
-  if (decoy) { ev_conn(x, tgt); int ep = eph_port(x, tgt); ev_log(x, 200 + r, tgt, 0, tgt, lport, src, ep, 0); red_result(x, r, a, T_FALSE); return; }
+  const int lport = eph_port(x, tgt, 2);  // local_port
+  if (decoy) { ev_conn(x, tgt); int ep = eph_port(x, tgt, 3); ev_log(x, 200 + r, tgt, 0, tgt, lport, src, ep, 0); red_result(x, r, a, T_FALSE); return; }
   int ni = exploit_new_session(x, r, a.sid, tgt);
   if (ni < 0) { red_result(x, r, a, T_FALSE); return; }
   const uint64_t nw = rs_at(s, A, ni);
@@ -2060,16 +2069,15 @@ CC4_HD bool step_begin(Ctx x, const int32_t* actions) {
   for (int b = 0; b < NBLUE; ++b) step_blue_submit(x, b, actions ? actions[b] : -1);
   return true;
 }
-// The policies' generator while a set_seed split is in force (EnvState.rng2): the walking generator and rng2 trade places
-// around the policy loops.  In the counter mode the step word travels with the walking generator.
+// The policies' generator while a set_seed split is in force (EnvState.rng2; numpy-stream mode only -- in the counter mode
+// cc4_set_seed re-keys every stream): the walking generator and rng2 trade places around the policy loops.
 CC4_HD void rng_policy_swap(Ctx x, bool back) {
   EnvState* s = x.s;
+  (void)back;
   if (!s->rng_split) return;
   Rng t = *x.r;
   *x.r = s->rng2;
-  if (t.mode == 1) { x.r->inc_lo = t.inc_lo; x.r->mode = 1; }
   s->rng2 = t;
-  if (back && t.mode == 1) { rng_park(&s->rng2); s->rng2.inc_lo = 0; }   // counter mode: only (key, episode) of the parked one matter
 }
 CC4_HD void step_green_policy(Ctx x, int g) {
   if (x.s->policy & GP_SLEEP_BIT) { x.w->green_act[g] = 2; return; }   // green_agent_class=SleepAgent: no draw, Sleep

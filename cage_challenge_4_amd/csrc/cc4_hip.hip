@@ -331,15 +331,11 @@ __global__ __launch_bounds__(PT, MINW) void k_step_philox(StepArgs a) {
       // agent's thread: red r on wave r%PW lane r/PW, blue on wave PW-1 lanes 2..6, green draws on lanes >= 8 of the waves
       // that carry a single red agent.  A tick touches only its own agent (queue, observation reset, filter_actions
       // against its own session table, which no other agent edits before the barrier below).
-      // CybORG.set_seed split (EnvState.rng2): the green / red policy streams are keyed by the old generator
-      const uint64_t key_main = rl.s_lo, epi_main = rl.inc_hi;
-      const bool split = s->rng_split != 0;
-      if (split && (is_red || (lane >= 8 && wave >= 2))) { rl.s_lo = s->rng2.s_lo; rl.inc_hi = s->rng2.inc_hi; }
+
       if (is_red) {
         unsigned long long t0 = ap ? clock64() : 0;
         step_red_policy(xr, ragent);
         if (ap) ap[0] += clock64() - t0;
-        if (split) { rl.s_lo = key_main; rl.inc_hi = epi_main; }
         if (step_tick_agent(xr, NBLUE + ragent)) atomicSub(&s->n_actions, 1);
       }
       else if (wave == PW - 1 && lane >= 2 && lane < 2 + NBLUE) {
@@ -355,7 +351,6 @@ __global__ __launch_bounds__(PT, MINW) void k_step_philox(StepArgs a) {
           Ctx xg{s, a.cold + e, &rl, hd, &work, nullptr, nullptr, lg};
           step_green_policy(xg, g);
           int t = work.green_act[g];
-          if (split) { rl.s_lo = key_main; rl.inc_hi = epi_main; }      // the action stream below belongs to the new generator
           if (t < 2) {
             glist[t][atomicAdd(&glist_n[t], 1)] = (uint8_t)g;       // compaction by action type
             // the first block of the agent's action stream, computed here -- behind the red policies -- and handed to the
@@ -364,9 +359,7 @@ __global__ __launch_bounds__(PT, MINW) void k_step_philox(StepArgs a) {
             rng_block(&rl, ST_GREEN_EXE + (uint32_t)g, 0, c);
             reinterpret_cast<uint4*>(reset_ws)[g] = make_uint4(c[0], c[1], c[2], c[3]);
           }
-          if (split) { rl.s_lo = s->rng2.s_lo; rl.inc_hi = s->rng2.inc_hi; }
         }
-        if (split) { rl.s_lo = key_main; rl.inc_hi = epi_main; }
       }
       if (a.prof && lane == 63) a.prof[PROF_SLOTS * (size_t)e + 100 + wave] += clock64() - t_begin;   // debug: when each wave reaches the end of the policy phase
       dma_wait();          // the host table has landed in LDS behind the policy phase
@@ -536,11 +529,10 @@ __global__ void k_unpack_obs(const uint8_t* __restrict__ packed, uint8_t* __rest
 __global__ void k_set_seed(EnvState* st, const uint64_t* seeds, int n, int rng_mode) {
   int e = blockIdx.x * blockDim.x + threadIdx.x;
   if (e >= n) return;
-  if (!st[e].rng_split) {     // the agents' policies stay on the stream they were created with (see EnvState.rng2)
-    st[e].rng2 = st[e].rng;
-    if (rng_mode == 1) { rng_park(&st[e].rng2); st[e].rng2.inc_lo = 0; }
+  if (rng_mode == 0) {        // numpy stream: the agents' policies stay on the stream they were created with (see EnvState.rng2)
+    if (!st[e].rng_split) st[e].rng2 = st[e].rng;
+    st[e].rng_split = 1;
   }
-  st[e].rng_split = 1;
   rng_seed(&st[e].rng, seeds[e], (uint32_t)rng_mode);
   if (rng_mode == 1) { rng_begin_episode(&st[e].rng); rng_park(&st[e].rng); }   // counter mode: the words a reset leaves behind
 }

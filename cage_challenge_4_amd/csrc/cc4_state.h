@@ -186,7 +186,8 @@ struct alignas(16) EnvState {
   // CybORG.set_seed (env.py:316-325) hands the new Generator to the controller, the state and the hosts
   // (SimulationController.set_np_random, SC:317-320; State.set_np_random, State.py:241-251) but not to the agent objects,
   // whose np_random was bound when they were created (SC:1041): until the next reset the green / red POLICIES keep drawing
-  // from the old stream while everything else draws from the new one.  rng2 is that old stream while rng_split is set.
+  // from the old stream while everything else draws from the new one.  rng2 is that old stream while rng_split is set
+  // (numpy-stream mode; the counter mode, which is not bit-comparable with the reference anyway, re-keys all streams).
   Rng rng2;
   BlueAgent blue[NBLUE];
   RSess spool[RS_POOL];              // red session records of all six agents

@@ -58,8 +58,7 @@ void cc4o_reset(void* h, int i, uint64_t seed, int rng_mode, int steps, int cont
 }
 void cc4o_set_seed(void* h, int i, uint64_t seed, int rng_mode) {   // CybORG.set_seed: the restatement of k_set_seed (csrc/cc4_hip.hip)
   EnvState& st = ((Oracle*)h)->st[i];
-  if (!st.rng_split) { st.rng2 = st.rng; if (rng_mode == 1) { rng_park(&st.rng2); st.rng2.inc_lo = 0; } }
-  st.rng_split = 1;
+  if (rng_mode == 0) { if (!st.rng_split) st.rng2 = st.rng; st.rng_split = 1; }
   Rng* r = &st.rng;
   rng_seed(r, seed, (uint32_t)rng_mode);
   if (rng_mode == 1) { rng_begin_episode(r); rng_park(r); }
