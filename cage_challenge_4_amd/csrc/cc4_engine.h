@@ -409,7 +409,7 @@ CC4_HD int rs_add(Ctx x, int r, int host, int pid, int flags, int slot = -1) {
     for (int k = 0; k < (MAXH + 7) / 8; ++k) row[k] = 0;
   }
   a.sord[a.nsess++] = (uint8_t)slot;
-  a.rsc_dirty = 1;
+  a.rsc_dirty = 1; a.fsm_dirty = 1;
   if (!bit_get(a.live_hosts, host)) { bit_set(a.live_hosts, host); a.nlive++; }
   bit_set_shared(s->red_hosts, host);
   return a.nsess - 1;
@@ -433,7 +433,7 @@ CC4_HD void rs_remove_at(Ctx x, int r, int idx, bool keep_record = false) {
   if (!keep_record) bit_clr_shared(s->spool_used, slot);
   rs_list_remove(a, idx);
   a.nsess--;
-  a.rsc_dirty = 1;
+  a.rsc_dirty = 1; a.fsm_dirty = 1;
   if (rs_on_host(s, a, gone).n == 0) rs_host_left(x, r, gone);
 }
 // Every non-original session of agent r on host h, in one compaction pass (== rs_remove_at on each of them in list order:
@@ -457,7 +457,7 @@ CC4_HD void rs_remove_on_host(Ctx x, int r, int h) {
   }
   if (!removed) return;
   a.nsess = (uint8_t)out;
-  a.rsc_dirty = 1;
+  a.rsc_dirty = 1; a.fsm_dirty = 1;
   if (!left) rs_host_left(x, r, h);
 }
 // dict pop + re-insert of the same session object (RedSessionCheck promotion, RestoreFromBackup of an original session):
@@ -1184,9 +1184,9 @@ CC4_HD void blue_execute(Ctx x, int b, const Act& a) {
     case BA_DECOY: blue_decoy(x, a.host); break;
     // Observation(False) when the pair is already blocked / not blocked (ControlTraffic.py:111-113, :176-178)
     case BA_BLOCK: s->blue[b].last_ok = (uint8_t)(((s->blocks[a.host] >> a.arg) & 1u) ? T_FALSE : T_TRUE);
-                   s->blocks[a.host] |= (uint16_t)(1u << a.arg); break;   // ControlTraffic.py:88-116
+                   s->blocks[a.host] |= (uint16_t)(1u << a.arg); s->obs_dirty = 1; break;   // ControlTraffic.py:88-116
     case BA_ALLOW: s->blue[b].last_ok = (uint8_t)(((s->blocks[a.host] >> a.arg) & 1u) ? T_TRUE : T_FALSE);
-                   s->blocks[a.host] &= (uint16_t)~(1u << a.arg); break;  // ControlTraffic.py:160-185
+                   s->blocks[a.host] &= (uint16_t)~(1u << a.arg); s->obs_dirty = 1; break;  // ControlTraffic.py:160-185
     default: break;
   }
 }
@@ -1698,6 +1698,11 @@ CC4_HD void fsm_apply(Ctx x, int r, int h, int act, bool success) {  // _host_st
 CC4_HD void fsm_observe(Ctx x, int r) {
   RedAgent& A = x.s->red[r];
   CC4_AT0(x);
+  // Mid-action agent whose observation is just the RedSessionCheck listing of an unchanged session table: nothing below can
+  // change anything.  No transition (success is IN_PROGRESS), no entry to process, the listing's hosts were merged when the
+  // table last changed (live <= known, hostnames known), and the removal check found fsm_ur & ~live empty then -- neither
+  // set has moved since (fsm_ur only moves in this function, live only with fsm_dirty).
+  if (A.obs_success == T_IN_PROGRESS && A.nobs == 0 && A.rsc_listed && !A.fsm_dirty) return;
   // 1. _host_state_transition (:124-167)
   if (A.obs_act_type <= RA_WITHDRAW && A.obs_success != T_IN_PROGRESS && A.obs_success != 0) {
     bool ok = A.obs_success == T_TRUE;
@@ -1756,6 +1761,7 @@ CC4_HD void fsm_observe(Ctx x, int r) {
         bit_set(A.fsm_known, h);
       }
     b5_store(A.fsm_hn, b5_or(hn, live));
+    A.fsm_dirty = 0;
   }
   CC4_AT(x, 5);
   // 3. _session_removal_state_change (:169-188): hosts in U/UD/R/RD without a Sessions entry in the observation -> KD
@@ -2039,6 +2045,7 @@ CC4_HD bool step_phase(Ctx x, bool init_accumulators = true) {
     const int st = s->step_count;
     const int ph = step_phase_of(st, s->phase_len[0], s->phase_len[1], s->phase_len[2]);
     if (ph < 0) { set_err(x, E_STEP_PAST_END); return false; }
+    s->obs_dirty = (uint8_t)(ph > s->phase);   // a new mission phase changes the phase words and the comms policy of the observation
     if (ph > s->phase) s->phase = ph;
   }
   rng_begin_step(&s->rng, (uint32_t)s->step_count);
@@ -2361,14 +2368,22 @@ CC4_HD int env_flat_obs_at(const EnvState* s, const HostDyn* hd, int idx) {
   const int ev = hd[h].ev;   // rows of hosts that do not exist stay zero (env_reset), so no existence test is needed
   return k < 43 ? ((ev & (EV_CUR_PROC | EV_OLD_PROC)) != 0) : ((ev & (EV_CUR_CONN | EV_OLD_CONN)) != 0);
 }
-// The same 578 values enumerated kind by kind (v = 0..577), so that the lanes of a wave take the same branch:
-//   [0,224) host events (7 subnet blocks x {16 process, 16 connection}), [224,287) blocked bits, [287,350) comms policy,
-//   [350,413) subnet one-hot, [413,573) message bits (5 agents x 32), [573,578) the 5 phase words.  *idx = position in the vector.
+// The same 578 values enumerated kind by kind (v = 0..577), so that the lanes of a wave take the same branch, the values that
+// can change every step first:
+//   [0,224) host events (7 subnet blocks x {16 process, 16 connection}), [224,384) message bits (5 agents x 32)  -- OBS_FAST --
+//   [384,447) blocked bits, [447,510) comms policy, [510,573) subnet one-hot, [573,578) the 5 phase words (EnvState.obs_dirty).
+// *idx = position in the vector.
+enum : int { OBS_FAST = 384 };
 CC4_HD int env_flat_obs_sorted(const EnvState* s, const HostDyn* hd, int v, int* idx) {
-  if (v < 413) {
+  if (v >= 224 && v < OBS_FAST) {
+    const int w = v - 224, b = w >> 5, m = w & 31, jj = m / MSG_LEN;
+    *idx = (b < 4 ? b * OBS_SHORT + OBS_SHORT : 4 * OBS_SHORT + OBS_LONG) - 32 + m;
+    return s->msg[jj < b ? jj : jj + 1][m % MSG_LEN];
+  }
+  if (v < 573) {
     int sb, k;       // subnet block 0..6 (agents 0..3 own one, agent 4 owns three), offset inside the 59-value block
     if (v < 224) { sb = v >> 5; const int r = v & 31; k = 27 + (r & 15) + ((r >> 4) ? 16 : 0); }
-    else { const int w = v - 224, kind = w / 63, q = w % 63; sb = q / 9; k = 9 * (kind == 0 ? 1 : (kind == 1 ? 2 : 0)) + q % 9; }
+    else { const int w = v - OBS_FAST, kind = w / 63, q = w % 63; sb = q / 9; k = 9 * (kind == 0 ? 1 : (kind == 1 ? 2 : 0)) + q % 9; }
     const int b = sb < 4 ? sb : 4, i = sb < 4 ? 0 : sb - 4;
     *idx = (b < 4 ? b * OBS_SHORT : 4 * OBS_SHORT) + 1 + 59 * i + k;
     const int sn = blue_subnet_sorted(b, i);
@@ -2381,11 +2396,6 @@ CC4_HD int env_flat_obs_sorted(const EnvState* s, const HostDyn* hd, int v, int*
     if (k < 9) return sorted_subnet(k) == sn;
     if (k < 18) return (s->blocks[sn] >> sorted_subnet(k - 9)) & 1u;
     return !((comms_adjacent(s->phase, sn) >> sorted_subnet(k - 18)) & 1u);
-  }
-  if (v < 573) {
-    const int w = v - 413, b = w >> 5, m = w & 31, jj = m / MSG_LEN;
-    *idx = (b < 4 ? b * OBS_SHORT + OBS_SHORT : 4 * OBS_SHORT + OBS_LONG) - 32 + m;
-    return s->msg[jj < b ? jj : jj + 1][m % MSG_LEN];
   }
   const int b = v - 573;
   *idx = b < 4 ? b * OBS_SHORT : 4 * OBS_SHORT;

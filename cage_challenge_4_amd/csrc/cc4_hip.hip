@@ -45,6 +45,7 @@ struct StepArgs {
   int32_t* rand_out;           // when non-null: draw the blue actions in-kernel (k_random_actions fused) and record them here
   uint64_t rand_seed0; uint32_t rand_t;
   int n, autoreset, steps, rng_mode, policy;
+  int full_obs;               // rewrite every observation value (the output buffer may hold another episode's slowly varying part)
   uint32_t topo;              // cc4_config.topology_seed
   unsigned long long* prof;   // optional [n][PROF_SLOTS] cycle counters (cc4_debug_profile): 16 phase slots + 8 per red agent
 };
@@ -244,10 +245,10 @@ __global__ __launch_bounds__(PT, MINW) void k_step_philox(StepArgs a) {
   __shared__ int conflict_lds;
   __shared__ alignas(16) uint32_t reset_ws[RESET_WS_WORDS];   // pid bitmaps of the scenario generation (autoreset); during a step: the green agents' pre-computed blocks
   static_assert(RESET_WS_WORDS >= 4 * MAXG, "one 16-byte block per green agent");
-  __shared__ int glist_n[2];
+  __shared__ int glist_n[2][2];       // [action type][drawing wave]
   __shared__ StepWork work;
   __shared__ uint8_t obs_bytes[OBS_TOTAL + 2];   // byte-per-value copy of the observations, only for the packed exchange row
-  __shared__ uint8_t glist[2][MAXG];  // green agents by action type (0 AccessService, 1 LocalWork)
+  __shared__ uint8_t glist[2][2][MAXG];  // green agents by action type (0 AccessService, 1 LocalWork) and drawing wave
   __shared__ unsigned long long prof_lds[16];
   const int e = blockIdx.x, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   if (e >= a.n) return;
@@ -266,7 +267,8 @@ __global__ __launch_bounds__(PT, MINW) void k_step_philox(StepArgs a) {
   for (int c = wave; c < HD_CHUNKS; c += PW) dma_chunk(src + HD_V0 + 64 * c + lane, lds + HD_V0 + 64 * c);
   unsigned long long* prof = a.prof ? prof_lds : nullptr;
   if (prof && tid < 16) prof_lds[tid] = 0;
-  if (tid == 0) { glist_n[0] = 0; glist_n[1] = 0; conflict_lds = 0; }
+  if (tid < 4) (&glist_n[0][0])[tid] = 0;
+  if (tid == 0) conflict_lds = 0;
   if (tid >= 64 && tid < 64 + 4 + NRED) (&work.phish_mask[0])[tid - 64] = 0;   // phish_mask[4] and pend_r[NRED] are adjacent
   static_assert(offsetof(StepWork, pend_r) == offsetof(StepWork, phish_mask) + 16, "phish_mask and pend_r are cleared as one run of words");
   __syncthreads();
@@ -347,12 +349,20 @@ __global__ __launch_bounds__(PT, MINW) void k_step_philox(StepArgs a) {
         step_messages(s, a.msgs ? a.msgs + e * NBLUE * MSG_LEN : nullptr, b);   // read back by this step's observation encode only
       }
       else if (lane >= 8 && wave >= 2) {
-        for (int g = (wave - 2) * (WAVE - 8) + (lane - 8); g < ng; g += (PW - 2) * (WAVE - 8)) {
+        static_assert(PW == 4 && MAXG <= 2 * (WAVE - 8), "every green agent has its own lane on wave 2 or 3: one pass, one ballot per type");
+        const int g = (wave - 2) * (WAVE - 8) + (lane - 8);
+        if (g < ng) {
           Ctx xg{s, a.cold + e, &rl, hd, &work, nullptr, nullptr, lg};
           step_green_policy(xg, g);
-          int t = work.green_act[g];
+          const int t = work.green_act[g];
+          // compaction by action type with a wavefront ballot + prefix count (agent order, no LDS atomics): each drawing wave
+          // fills its own sub-list; the resolving wave walks the two sub-lists one after the other
+          const unsigned long long m0 = __ballot(t == 0), m1 = __ballot(t == 1);
+          const unsigned long long below = (1ull << lane) - 1ull;
           if (t < 2) {
-            glist[t][atomicAdd(&glist_n[t], 1)] = (uint8_t)g;       // compaction by action type
+            const unsigned long long m = t == 0 ? m0 : m1;
+            glist[t][wave - 2][__popcll(m & below)] = (uint8_t)g;
+            if ((m & below) == 0) glist_n[t][wave - 2] = __popcll(m);      // the first lane of the type publishes the count
             // the first block of the agent's action stream, computed here -- behind the red policies -- and handed to the
             // lane that resolves the action (the generation work area is idle during a step)
             uint32_t c[4];
@@ -380,8 +390,9 @@ __global__ __launch_bounds__(PT, MINW) void k_step_philox(StepArgs a) {
       if (wave < 2) {
         unsigned long long tg0 = a.prof ? clock64() : 0;
         int pen = 0;
-        for (int i = lane; i < glist_n[wave]; i += WAVE) {
-          int g = glist[wave][i];
+        const int n0 = glist_n[wave][0], n1 = glist_n[wave][1];
+        for (int i = lane; i < n0 + n1; i += WAVE) {
+          int g = i < n0 ? glist[wave][0][i] : glist[wave][1][i - n0];
           Ctx xg{s, a.cold + e, &rl, hd, &work, nullptr, nullptr, lg};
           const uint4 blk = reinterpret_cast<const uint4*>(reset_ws)[g];
           const uint32_t pre[4] = {blk.x, blk.y, blk.z, blk.w};
@@ -435,7 +446,10 @@ __global__ __launch_bounds__(PT, MINW) void k_step_philox(StepArgs a) {
   {
     int32_t* o = a.obs + (size_t)e * OBS_TOTAL;
     const bool pack = a.obs8 != nullptr;   // the exchange copy goes through a byte row in LDS and is packed after the barrier below
-    for (int v = tid; v < OBS_TOTAL; v += PT) { int i; int val = env_flat_obs_sorted(s, hd, v, &i); o[i] = val; if (pack) obs_bytes[i] = (uint8_t)val; }   // kind-sorted enumeration: uniform branches per wave
+    // the values that can change with every step (host events, messages) always; blocks, comms policy, subnet one-hots and phase
+    // words only when the step changed them (EnvState.obs_dirty), after a reset, or when the caller asks (the buffer persists)
+    const int nv = (do_reset || a.full_obs || pack || s->obs_dirty) ? OBS_TOTAL : OBS_FAST;
+    for (int v = tid; v < nv; v += PT) { int i; int val = env_flat_obs_sorted(s, hd, v, &i); o[i] = val; if (pack) obs_bytes[i] = (uint8_t)val; }   // kind-sorted enumeration: uniform branches per wave
   }
   __syncthreads();    // the row is final: RedSessionCheck and the step bookkeeping ran beside the encode
   if (tid == 0) a.err[e] = s->err;
@@ -569,6 +583,7 @@ struct cc4_handle {
   unsigned long long* d_prof = nullptr;
   uint8_t* d_unpacked = nullptr;                 // [world*N][578] bytes: cc4_unpack_obs_device
   int evlog_on = 0;               // cc4_enable_event_log
+  bool full_obs_next = true;      // the next step launch rewrites every observation value (fresh handle, restored state)
   int one_round_blocks = 5 * 256; // episode blocks the low-occupancy build of k_step_philox keeps resident at once (5 per CU)
   ncclComm_t comm = nullptr; int rank = 0, world = 1;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -609,7 +624,9 @@ static int launch_step(cc4_handle* h, const int32_t* d_actions, const uint8_t* d
   StepArgs a{h->d_state, h->d_cold, d_actions, d_msgs, h->d_obs, h->d_reward, h->d_done, h->d_err,
              h->comm ? h->d_obs8[buf] : nullptr, rand ? h->d_actions : nullptr, seed0, t,
              h->cfg.num_envs, h->cfg.autoreset, h->cfg.steps, h->cfg.rng_mode,
-             (h->cfg.red_policy & 3) | (h->cfg.green_policy ? GP_SLEEP_BIT : 0), (uint32_t)h->cfg.topology_seed, h->d_prof};
+             (h->cfg.red_policy & 3) | (h->cfg.green_policy ? GP_SLEEP_BIT : 0), h->full_obs_next ? 1 : 0,
+             (uint32_t)h->cfg.topology_seed, h->d_prof};
+  h->full_obs_next = false;
   const dim3 grid(h->cfg.num_envs);
   // with a communicator, the launch carries ev_step[buf] as its stop event: the event rides on the kernel's own completion
   // signal, where a separate hipEventRecord would put a marker packet between two step kernels (~5 us of idle stream time)
@@ -852,6 +869,7 @@ int cc4_set_state(cc4_handle* h, int32_t env, const void* buf) {
   HIPCHK(h, hipSetDevice(h->cfg.device_id));
   HIPCHK(h, hipMemcpyAsync(h->d_state + env, buf, sizeof(EnvState), hipMemcpyHostToDevice, h->stream));
   HIPCHK(h, hipStreamSynchronize(h->stream));
+  h->full_obs_next = true;      // the observation buffer still holds the previous occupant's slowly varying values
   return 0;
 }
 

@@ -145,7 +145,7 @@ struct alignas(8) RedAgent {
   uint8_t start_host;                // static per episode
   uint8_t rsc_dirty;                 // session table changed since the last full RedSessionCheck observation
   uint8_t rsc_listed;                // this step's observation includes the RedSessionCheck listing of every session
-  uint8_t pad[1];
+  uint8_t fsm_dirty;                 // the set of session hosts may have changed since fsm_observe last merged a listing
 };
 
 struct alignas(8) BlueAgent {
@@ -165,7 +165,10 @@ struct alignas(16) EnvState {
   float reward;                      // team reward of the last step (BlueRewardMachine + action_cost)
   uint8_t done, rng_mode, n_green;
   uint8_t policy;                    // bits 0-1 red policy (RP_*), bit 4 green policy (1 = SleepAgent)
-  uint8_t rng_split, pad0[3];        // 1 after CybORG.set_seed: the agents' policies keep drawing from rng2 (see there)
+  uint8_t rng_split;                 // 1 after CybORG.set_seed: the agents' policies keep drawing from rng2 (see there)
+  uint8_t obs_dirty;                 // this step changed a slowly varying part of the flat observation (blocks, mission phase):
+                                     // the lane-parallel kernel rewrites those values only then (the output buffer persists)
+  uint8_t pad0[2];
   uint16_t blocks[NSUB];             // blocks[to] bit from
   uint8_t cidr_octet[NSUB];
   uint8_t n_users[NSUB];
