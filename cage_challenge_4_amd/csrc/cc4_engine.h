@@ -301,8 +301,7 @@ CC4_HD uint64_t rsw_make(int id, int pid, int host, int flags) {
 }
 // the i-th session of the agent (list position -> record)
 CC4_HD uint64_t rs_at(const EnvState* s, const RedAgent& a, int i) { return rs_word(s, a.sord[i]); }
-CC4_HD int rs_find_id(const EnvState* s, const RedAgent& a, int id) {
-  const int n = a.nsess;
+CC4_HD int rs_find_id(const EnvState* s, const RedAgent& a, int id, int n) {
   for (int i0 = 0; i0 < n; i0 += 8) {
     const S8 q = rs_load8(s, a, i0);
     int hit = -1;
@@ -311,11 +310,12 @@ CC4_HD int rs_find_id(const EnvState* s, const RedAgent& a, int id) {
   }
   return -1;
 }
+CC4_HD int rs_find_id(const EnvState* s, const RedAgent& a, int id) { return rs_find_id(s, a, id, a.h.nsess); }
 // sessions of the agent on host h: how many, the first one, the first root one
 struct HostSess { int n, first, first_root; };
 CC4_HD HostSess rs_on_host(const EnvState* s, const RedAgent& a, int h) {
   HostSess r; r.n = 0; r.first = -1; r.first_root = -1;
-  const int n = a.nsess;
+  const int n = a.h.nsess;
   for (int i0 = 0; i0 < n; i0 += 8) {
     const S8 q = rs_load8(s, a, i0);
     CC4_UNROLL for (int k = 0; k < 8; ++k)
@@ -329,7 +329,7 @@ CC4_HD HostSess rs_on_host(const EnvState* s, const RedAgent& a, int h) {
 }
 // index of the k-th (0-based) session on host h, or -1
 CC4_HD int rs_kth_on_host(const EnvState* s, const RedAgent& a, int h, int kth) {
-  const int n = a.nsess;
+  const int n = a.h.nsess;
   for (int i0 = 0; i0 < n; i0 += 8) {
     const S8 q = rs_load8(s, a, i0);
     int hit = -1;
@@ -341,7 +341,7 @@ CC4_HD int rs_kth_on_host(const EnvState* s, const RedAgent& a, int h, int kth) 
 }
 // index of the session with this (host, pid), or -1 (State.get_session_from_pid)
 CC4_HD int rs_find_host_pid(const EnvState* s, const RedAgent& a, int h, int pid) {
-  const int n = a.nsess;
+  const int n = a.h.nsess;
   for (int i0 = 0; i0 < n; i0 += 8) {
     const S8 q = rs_load8(s, a, i0);
     int hit = -1;
@@ -396,11 +396,11 @@ CC4_HD int rs_add(Ctx x, int r, int host, int pid, int flags, int slot = -1) {
   EnvState* s = x.s;
   RedAgent& a = s->red[r];
   if (slot < 0) slot = rs_alloc_lowest(x);
-  if (a.nsess >= MAX_RS || slot < 0 || slot >= RS_POOL) { set_err(x, E_RSESS_OVERFLOW); return -1; }
+  if (a.h.nsess >= MAX_RS || slot < 0 || slot >= RS_POOL) { set_err(x, E_RSESS_OVERFLOW); return -1; }
   int id = 0;
-  for (int i0 = 0; i0 < a.nsess; i0 += 8) {
+  for (int i0 = 0; i0 < a.h.nsess; i0 += 8) {
     const S8 q = rs_load8(s, a, i0);
-    CC4_UNROLL for (int k = 0; k < 8; ++k) if (i0 + k < a.nsess && rsw_id(q.v[k]) + 1 > id) id = rsw_id(q.v[k]) + 1;
+    CC4_UNROLL for (int k = 0; k < 8; ++k) if (i0 + k < a.h.nsess && rsw_id(q.v[k]) + 1 > id) id = rsw_id(q.v[k]) + 1;
   }
   (void)or_shared(&s->spool_used[slot >> 5], 1u << (slot & 31));
   rs_word_put(s, slot, rsw_make(id, pid, host, flags));
@@ -408,16 +408,16 @@ CC4_HD int rs_add(Ctx x, int r, int host, int pid, int flags, int slot = -1) {
     uint64_t* row = reinterpret_cast<uint64_t*>(x.c->kports[slot]);   // 144-byte rows, 8-byte aligned
     for (int k = 0; k < (MAXH + 7) / 8; ++k) row[k] = 0;
   }
-  a.sord[a.nsess++] = (uint8_t)slot;
-  a.rsc_dirty = 1; a.fsm_dirty = 1;
-  if (!bit_get(a.live_hosts, host)) { bit_set(a.live_hosts, host); a.nlive++; }
+  a.sord[a.h.nsess++] = (uint8_t)slot;
+  a.h.rsc_dirty = 1; a.h.fsm_dirty = 1;
+  if (!bit_get(a.live_hosts, host)) { bit_set(a.live_hosts, host); a.h.nlive++; }
   bit_set_shared(s->red_hosts, host);
-  return a.nsess - 1;
+  return a.h.nsess - 1;
 }
 // the agent no longer holds a session on `gone`: its own bitmap, and the episode's if no other agent does either
 CC4_HD void rs_host_left(Ctx x, int r, int gone) {
   RedAgent& a = x.s->red[r];
-  bit_clr(a.live_hosts, gone); a.nlive--;
+  bit_clr(a.live_hosts, gone); a.h.nlive--;
   uint32_t lw[NRED];   // the six agents' words for that host in one batch of loads (this agent's bit is already clear)
   CC4_UNROLL for (int q = 0; q < NRED; ++q) lw[q] = x.s->red[q].live_hosts[gone >> 5];
   uint32_t any_other = 0;
@@ -432,8 +432,8 @@ CC4_HD void rs_remove_at(Ctx x, int r, int idx, bool keep_record = false) {
   const int gone = rsw_host(rs_word(s, slot));
   if (!keep_record) bit_clr_shared(s->spool_used, slot);
   rs_list_remove(a, idx);
-  a.nsess--;
-  a.rsc_dirty = 1; a.fsm_dirty = 1;
+  a.h.nsess--;
+  a.h.rsc_dirty = 1; a.h.fsm_dirty = 1;
   if (rs_on_host(s, a, gone).n == 0) rs_host_left(x, r, gone);
 }
 // Every non-original session of agent r on host h, in one compaction pass (== rs_remove_at on each of them in list order:
@@ -441,7 +441,7 @@ CC4_HD void rs_remove_at(Ctx x, int r, int idx, bool keep_record = false) {
 CC4_HD void rs_remove_on_host(Ctx x, int r, int h) {
   EnvState* s = x.s;
   RedAgent& a = s->red[r];
-  const int n = a.nsess;
+  const int n = a.h.nsess;
   int out = 0, removed = 0;
   bool left = false;
   for (int i0 = 0; i0 < n; i0 += 8) {
@@ -456,8 +456,8 @@ CC4_HD void rs_remove_on_host(Ctx x, int r, int h) {
     }
   }
   if (!removed) return;
-  a.nsess = (uint8_t)out;
-  a.rsc_dirty = 1; a.fsm_dirty = 1;
+  a.h.nsess = (uint8_t)out;
+  a.h.rsc_dirty = 1; a.h.fsm_dirty = 1;
   if (!left) rs_host_left(x, r, h);
 }
 // dict pop + re-insert of the same session object (RedSessionCheck promotion, RestoreFromBackup of an original session):
@@ -465,21 +465,22 @@ CC4_HD void rs_remove_on_host(Ctx x, int r, int h) {
 CC4_HD void rs_move_to_end(EnvState* s, RedAgent& a, int idx, int new_id) {
   const int slot = a.sord[idx];
   rs_list_remove(a, idx);
-  a.sord[a.nsess - 1] = (uint8_t)slot;
+  a.sord[a.h.nsess - 1] = (uint8_t)slot;
   if (new_id >= 0) rs_word_put(s, slot, (rs_word(s, slot) & ~0xFFFFull) | (uint64_t)(new_id & 0xFFFF));
-  a.rsc_dirty = 1;
+  a.h.rsc_dirty = 1;
 }
-CC4_HD bool sid_known(const RedAgent& a, int id) {
+CC4_HD bool sid_known(const RedAgent& a, int id, int nknown) {
   if (id < 256) return bit_get(a.known_bm, id);
-  for (int i = 0; i < a.nknown; ++i) if (a.known_sid[i] == id) return true;
+  for (int i = 0; i < nknown; ++i) if (a.known_sid[i] == id) return true;
   return false;
 }
+CC4_HD bool sid_known(const RedAgent& a, int id) { return sid_known(a, id, a.h.nknown); }
 // ActionSpace.update: server_session[session_id] = True (Shared/ActionSpace.py:205-211)
 CC4_HD void as_know_sid(Ctx x, int r, int id) {
   RedAgent& a = x.s->red[r];
   if (sid_known(a, id)) return;
-  if (a.nknown >= MAX_KS) { set_err(x, E_KS_OVERFLOW); return; }
-  a.known_sid[a.nknown++] = (uint16_t)id;
+  if (a.h.nknown >= MAX_KS) { set_err(x, E_KS_OVERFLOW); return; }
+  a.known_sid[a.h.nknown++] = (uint16_t)id;
   if (id < 256) bit_set(a.known_bm, id);
 }
 // one key of the agent's step observation (Shared/Observation.py add_* / combine_obs); also applies the
@@ -488,24 +489,24 @@ CC4_HD void obs_put(Ctx x, int r, bool key_ip, int host, int flags, bool subnet_
   RedAgent& a = x.s->red[r];
   if (flags & OE_IFACE) bit_set(a.as_ip, host);
   if (flags & OE_SYSHN) bit_set(a.as_hn, host);
-  if (subnet_known) a.as_subnet |= (uint16_t)(1u << h_subnet(host));
+  if (subnet_known) a.h.as_subnet |= (uint16_t)(1u << h_subnet(host));
   uint8_t want = (uint8_t)(key_ip ? OE_KEY_IP : 0);
   uint32_t* has = a.obs_has[key_ip ? 1 : 0];
   if (bit_get(has, host)) {
-    for (int i = 0; i < a.nobs; ++i)
+    for (int i = 0; i < a.h.nobs; ++i)
       if (a.obs[i].host == host && (a.obs[i].flags & OE_KEY_IP) == want) { a.obs[i].flags |= (uint8_t)flags; return; }
   }
   bit_set(has, host);
-  if (a.nobs >= MAX_OBS) { set_err(x, E_OBS_OVERFLOW); return; }
-  a.obs[a.nobs].host = (uint8_t)host;
-  a.obs[a.nobs].flags = (uint8_t)(flags | want);
-  a.nobs++;
+  if (a.h.nobs >= MAX_OBS) { set_err(x, E_OBS_OVERFLOW); return; }
+  a.obs[a.h.nobs].host = (uint8_t)host;
+  a.obs[a.h.nobs].flags = (uint8_t)(flags | want);
+  a.h.nobs++;
 }
 // observations[0] of the agent this step decides what the FSM sees as (action, success)
 CC4_HD void obs_first(Ctx x, int r, int success, int atype, int ahost, int aarg) {
   RedAgent& a = x.s->red[r];
-  if (a.obs_success != 0) return;
-  a.obs_success = (uint8_t)success; a.obs_act_type = (uint8_t)atype; a.obs_act_host = (uint8_t)ahost; a.obs_act_arg = (uint8_t)aarg;
+  if (a.h.obs_success != 0) return;
+  a.h.obs_success = (uint8_t)success; a.h.obs_act_type = (uint8_t)atype; a.h.obs_act_host = (uint8_t)ahost; a.h.obs_act_arg = (uint8_t)aarg;
 }
 
 // ------------------------------------------------------------------ routes (tree of routers)
@@ -763,8 +764,8 @@ CC4_HD void reset_agents(Ctx x) {
   for (int r = 0; r < NRED; ++r) {
     int sn = red_subnet_alloc(r, (int)rng_below(x.r, (uint32_t)red_nsub(r)));
     int c = (int)rng_below(x.r, (uint32_t)(s->n_users[sn] + s->n_servers[sn]));
-    s->red[r].start_host = (uint8_t)(c < s->n_users[sn] ? h_make(sn, 1 + c) : h_make(sn, 11 + (c - s->n_users[sn])));
-    s->red[r].new_sess_host = 0xFF;
+    s->red[r].h.start_host = (uint8_t)(c < s->n_users[sn] ? h_make(sn, 1 + c) : h_make(sn, 11 + (c - s->n_users[sn])));
+    s->red[r].h.new_sess_host = 0xFF;
   }
 }
 // phase 5, per host: starting sessions (State.__init__, State.py:103-136) from the host's stream, then the backup image
@@ -774,7 +775,7 @@ CC4_HD void reset_host_sessions(Ctx x, int h) {
   rng_set_stream(x.r, ST_GEN_SESS + (uint32_t)h);
   if (blue_of_subnet(h_subnet(h)) >= 0) (void)start_session_proc(x, h, K_SESS_BLUE);
   if (h != H_INTERNET && h_is_user(h)) (void)start_session_proc(x, h, K_SESS_GREEN);
-  if (h == s->red[0].start_host) (void)start_session_proc(x, h, K_SESS_RED);
+  if (h == s->red[0].h.start_host) (void)start_session_proc(x, h, K_SESS_RED);
   host_backup(x, h, x.hd[h].procs[PIN - 1].pid);
   x.hd[h].procs[PIN - 1].pid = 0; x.hd[h].ev = 0;
 }
@@ -782,22 +783,22 @@ CC4_HD void reset_host_sessions(Ctx x, int h) {
 CC4_HD void reset_finish(Ctx x, ResetCarry k, int steps, uint32_t topo_seed, bool rng_is_copy) {
   EnvState* s = x.s;
   {
-    const HostDyn& d = x.hd[s->red[0].start_host];
+    const HostDyn& d = x.hd[s->red[0].h.start_host];
     int red0_pid = 0;
     for (int i = 0; i < d.nproc; ++i) if (d.procs[i].kind == K_SESS_RED) red0_pid = d.procs[i].pid;
-    (void)rs_add(x, 0, s->red[0].start_host, red0_pid, RS_ABSTRACT | RS_ORIG);
-    s->red[0].active = 1;
+    (void)rs_add(x, 0, s->red[0].h.start_host, red0_pid, RS_ABSTRACT | RS_ORIG);
+    s->red[0].h.active = 1;
   }
   for (int r = 0; r < NRED; ++r) {
     RedAgent& a = s->red[r];
-    int h = a.start_host;
-    bit_set(a.as_ip, h); bit_set(a.as_hn, h); a.as_subnet |= (uint16_t)(1u << h_subnet(h));
+    int h = a.h.start_host;
+    bit_set(a.as_ip, h); bit_set(a.as_hn, h); a.h.as_subnet |= (uint16_t)(1u << h_subnet(h));
     if (r == 0) {
       as_know_sid(x, 0, 0);
       obs_put(x, 0, false, h, OE_SESS | OE_IFACE | OE_SYSHN, true);
       obs_first(x, 0, T_UNKNOWN, RA_NONE, 0, 0);
     }
-    a.exec_type = RA_SLEEP;
+    a.h.exec_type = RA_SLEEP;
   }
   s->done = (uint8_t)(0 >= steps - 1);
   s->n_actions = NBLUE + s->n_green + NRED;
@@ -940,9 +941,9 @@ CC4_HD void env_reset(Ctx x, uint64_t seed, int rng_mode, int steps, bool contin
     int cnt = s->n_users[sn] + s->n_servers[sn];
     int c = (int)rng_below(x.r, (uint32_t)cnt);  // choice(non-router hosts): users then servers
     int h = c < s->n_users[sn] ? h_make(sn, 1 + c) : h_make(sn, 11 + (c - s->n_users[sn]));
-    s->red[r].start_host = (uint8_t)h;
-    s->red[r].new_sess_host = 0xFF;
-    s->red[r].queue.busy = 0;
+    s->red[r].h.start_host = (uint8_t)h;
+    s->red[r].h.new_sess_host = 0xFF;
+    s->red[r].h.queue.busy = 0;
   }
   // State.__init__ (State.py:103-136): starting sessions in agent order; parent-less first
   for (int b = 0; b < NBLUE; ++b) {
@@ -958,7 +959,7 @@ CC4_HD void env_reset(Ctx x, uint64_t seed, int rng_mode, int steps, bool contin
     }
   }
   for (int g = 0; g < s->n_green; ++g) (void)start_session_proc(x, s->green_host[g], K_SESS_GREEN);
-  int red0_pid = start_session_proc(x, s->red[0].start_host, K_SESS_RED);
+  int red0_pid = start_session_proc(x, s->red[0].h.start_host, K_SESS_RED);
   // host.create_backup() for every host (State.py:137-138) -> dynamic state := static
   for (int h = 0; h < MAXH; ++h) {
     if (bit_get(s->exists, h)) { host_backup(x, h, x.hd[h].procs[PIN - 1].pid); x.hd[h].procs[PIN - 1].pid = 0; x.hd[h].ev = 0; }
@@ -968,23 +969,23 @@ CC4_HD void env_reset(Ctx x, uint64_t seed, int rng_mode, int steps, bool contin
   if (!pid_ws) for (int i = 0; i < 288; ++i) used[i] = 0;
   // red_agent_0 starts active with session 0 (ESG.py:791-801)
   {
-    int idx = rs_add(x, 0, s->red[0].start_host, red0_pid, RS_ABSTRACT | RS_ORIG);
+    int idx = rs_add(x, 0, s->red[0].h.start_host, red0_pid, RS_ABSTRACT | RS_ORIG);
     (void)idx;
-    s->red[0].active = 1;
+    s->red[0].h.active = 1;
   }
   // AgentInterface.set_init_obs (Shared/AgentInterface.py:110-117) with the OSINT observation of the start host
   for (int r = 0; r < NRED; ++r) {
     RedAgent& a = s->red[r];
-    int h = a.start_host;
-    bit_set(a.as_ip, h); bit_set(a.as_hn, h); a.as_subnet |= (uint16_t)(1u << h_subnet(h));
-    a.nobs = 0; a.obs_success = 0;
+    int h = a.h.start_host;
+    bit_set(a.as_ip, h); bit_set(a.as_hn, h); a.h.as_subnet |= (uint16_t)(1u << h_subnet(h));
+    a.h.nobs = 0; a.h.obs_success = 0;
     if (r == 0) {
       as_know_sid(x, 0, 0);
       // SimulationController.reset_observation (SC:767-773): first FSM call sees hostname-keyed OSINT obs
       obs_put(x, 0, false, h, OE_SESS | OE_IFACE | OE_SYSHN, true);
       obs_first(x, 0, T_UNKNOWN, RA_NONE, 0, 0);
     }
-    a.exec_type = RA_SLEEP;
+    a.h.exec_type = RA_SLEEP;
   }
   s->step_count = 0; s->phase = 0; s->done = (uint8_t)(0 >= steps - 1); s->reward = 0.f;
   s->n_actions = NBLUE + s->n_green + NRED;
@@ -1142,7 +1143,7 @@ CC4_HD void blue_restore(Ctx x, int h) {
     // every non-original session on the host goes; an original one is popped and re-added => moves to the end
     rs_remove_on_host(x, r, h);
     {
-      const int n = a.nsess;
+      const int n = a.h.nsess;
       int orig = -1;
       for (int i0 = 0; i0 < n; i0 += 8) {
         const S8 q = rs_load8(s, a, i0);
@@ -1219,7 +1220,7 @@ CC4_HD void phishing(Ctx x, int gh) {
     // red_agents = [(agent, host)] over hosts outside the subnet (there is no red session inside it here), host-major then
     // agent order; choice(red_agents, replace=False) is one bounded draw.  All counts and bitmaps are read up front.
     int nl[NRED]; uint32_t lh[NRED][5], rh[5];
-    CC4_UNROLL for (int r = 0; r < NRED; ++r) nl[r] = s->red[r].nlive;
+    CC4_UNROLL for (int r = 0; r < NRED; ++r) nl[r] = s->red[r].h.nlive;
     CC4_UNROLL for (int w = 0; w < 5; ++w) rh[w] = s->red_hosts[w];
     CC4_UNROLL for (int r = 0; r < NRED; ++r) { CC4_UNROLL for (int w = 0; w < 5; ++w) lh[r][w] = s->red[r].live_hosts[w]; }
     int nc = 0;
@@ -1314,15 +1315,15 @@ CC4_HD void red_drs(Ctx x, int r, const Act& a) {
     const uint32_t m0 = ex << off, m1 = (off > 16 && w1 != w0) ? ex >> (32 - off) : 0u;
     A.as_ip[w0] |= m0; A.obs_has[1][w0] = h0 | m0;
     if (m1) { A.as_ip[w1] |= m1; A.obs_has[1][w1] = h1 | m1; }
-    A.as_subnet |= (uint16_t)(1u << sn);
-    int n = A.nobs;
+    A.h.as_subnet |= (uint16_t)(1u << sn);
+    int n = A.h.nobs;
     while (fresh) {
       const int b = ctz32(fresh); fresh &= fresh - 1;
       if (n >= MAX_OBS) { set_err(x, E_OBS_OVERFLOW); break; }
       A.obs[n].host = (uint8_t)(lo + b); A.obs[n].flags = (uint8_t)(OE_IFACE | OE_KEY_IP);
       n++;
     }
-    A.nobs = (uint8_t)n;
+    A.h.nobs = (uint8_t)n;
     uint32_t again = had;   // already keyed this step (does not happen on the FSM path: the list is empty when an action starts)
     while (again) { const int b = ctz32(again); again &= again - 1; obs_put(x, r, true, lo + b, OE_IFACE, true); }
   }
@@ -1422,7 +1423,7 @@ CC4_HD void red_exploit(Ctx x, int r, const Act& a) {
     ev_log(x, 200 + r, tgt, 1, 0xFF, 0, 0xFF, 0, rsw_pid(nw));
     obs_put(x, r, true, tgt, OE_SESS | OE_IFACE | OE_SYSHN, false);
     obs_put(x, r, true, src, OE_IFACE, false);
-    A.new_sess_host = (uint8_t)tgt; A.new_sess_id = (uint16_t)rsw_id(nw);
+    A.h.new_sess_host = (uint8_t)tgt; A.h.new_sess_id = (uint16_t)rsw_id(nw);
     red_result(x, r, a, T_TRUE);
     return;
   }
@@ -1455,7 +1456,7 @@ CC4_HD void red_exploit(Ctx x, int r, const Act& a) {
   if (rng_random(x.r) > 0.050000000000000044) { ev_proc_red(x, r, tgt, rsw_pid(nw)); ev_log(x, 200 + r, tgt, 1, 0xFF, 0, 0xFF, 0, rsw_pid(nw)); }
   obs_put(x, r, true, tgt, OE_SESS | OE_IFACE | OE_SYSHN, false);
   obs_put(x, r, true, src, OE_IFACE, false);
-  A.new_sess_host = (uint8_t)tgt; A.new_sess_id = (uint16_t)rsw_id(nw);
+  A.h.new_sess_host = (uint8_t)tgt; A.h.new_sess_id = (uint16_t)rsw_id(nw);
   red_result(x, r, a, T_TRUE);
 }
 // PrivilegeEscalate.execute (AbstractActions/PrivilegeEscalate.py:127-179)
@@ -1548,20 +1549,20 @@ CC4_HD void red_session_check(Ctx x, int r) {
   EnvState* s = x.s;
   RedAgent& A = s->red[r];
   obs_first(x, r, T_TRUE, RA_NONE, 0, 0);
-  if (A.nsess == 0) return;
+  if (A.h.nsess == 0) return;
   // the primary (id 0) sits first, or last after a promotion / restore re-insert: look there before scanning
-  if (rsw_id(rs_at(s, A, 0)) != 0 && rsw_id(rs_at(s, A, A.nsess - 1)) != 0 && rs_find_id(s, A, 0) < 0) {
-    int c = (int)rng_below(x.r, (uint32_t)A.nsess);
+  if (rsw_id(rs_at(s, A, 0)) != 0 && rsw_id(rs_at(s, A, A.h.nsess - 1)) != 0 && rs_find_id(s, A, 0) < 0) {
+    int c = (int)rng_below(x.r, (uint32_t)A.h.nsess);
     rs_move_to_end(s, A, c, 0);   // active_sessions.pop(old_id); ident = 0; re-inserted last (RedSessionCheck.py:36-45)
     // every other session's parent becomes new_primary.name, which is None unless the promoted session is the scenario's
     // own 'red_session_0' (never the case: that one holds id 0 from the start) (RedSessionCheck.py:52-55)
-    for (int i = 0; i < A.nsess; ++i) s->spool[A.sord[i]].flags &= (uint8_t)~RS_CHILD;
+    for (int i = 0; i < A.h.nsess; ++i) s->spool[A.sord[i]].flags &= (uint8_t)~RS_CHILD;
   }
   // The observation lists every session as a hostname-keyed entry with Sessions / Interface{ip, Subnet} / System info.
   // Instead of materialising one entry per session, its three effects are applied in bulk from RedAgent.live_hosts (the
   // exact set of hosts in the listing): ActionSpace knowledge here, FSM knowledge in fsm_observe (rsc_listed).
-  A.rsc_listed = 1;
-  if (!A.rsc_dirty) return;      // same session table as at the last listing: nothing new to learn
+  A.h.rsc_listed = 1;
+  if (!A.h.rsc_dirty) return;      // same session table as at the last listing: nothing new to learn
   const B5 live = b5_load(A.live_hosts);
   { const B5 ip = b5_load(A.as_ip), hn = b5_load(A.as_hn); b5_store(A.as_ip, b5_or(ip, live)); b5_store(A.as_hn, b5_or(hn, live)); }
   {  // the subnets of the session hosts = the subnets with a live host (ids 17 sn .. 17 sn + 16)
@@ -1572,11 +1573,11 @@ CC4_HD void red_session_check(Ctx x, int r) {
       if (off > 32 - SLOTS && w + 1 < 5) bits |= live.w[w + 1] << (32 - off);
       if (bits & ((1u << SLOTS) - 1u)) sub |= 1u << sn;
     }
-    A.as_subnet |= (uint16_t)sub;
+    A.h.as_subnet |= (uint16_t)sub;
   }
   // session ids new to the ActionSpace, in session order: eight records and their eight known-id words per round, so the
   // common case (everything known) costs two LDS round trips per eight sessions
-  const int n = A.nsess;
+  const int n = A.h.nsess;
   for (int i0 = 0; i0 < n; i0 += 8) {
     const S8 q = rs_load8(s, A, i0);
     uint32_t kw[8];
@@ -1588,7 +1589,7 @@ CC4_HD void red_session_check(Ctx x, int r) {
       as_know_sid(x, r, id);   // rare; two new records of one round never share an id, so the words read above stay valid
     }
   }
-  A.rsc_dirty = 0;
+  A.h.rsc_dirty = 0;
 }
 // Withdraw.execute (ConcreteActions/Withdraw.py:38-91) + StopProcess(stop_all=True).  a.host = ip_address (unused beyond the
 // route, which always exists), a.arg = hostname
@@ -1603,7 +1604,7 @@ CC4_HD void red_withdraw(Ctx x, int r, const Act& a) {
   int n = 0;
   const int cap = (int)((sizeof(x.w->scratch) - 36 * 4) / 2);
   for (int pass = 0; pass < 2; ++pass)
-    for (int i = 0; i < A.nsess; ++i) {
+    for (int i = 0; i < A.h.nsess; ++i) {
       const uint64_t w = rs_at(s, A, i);
       if (rsw_host(w) != h) continue;
       bool child = (rsw_flags(w) & RS_CHILD) != 0;
@@ -1681,7 +1682,7 @@ CC4_HD void fsm_set_state(RedAgent& A, int h, int st) {
   if ((st & 1) || st == FS_F) bit_set(A.fsm_nodrs, h); else bit_clr(A.fsm_nodrs, h);
   fsm_put(A, h, st);
 }
-CC4_HD void fsm_apply(Ctx x, int r, int h, int act, bool success) {  // _host_state_transition inner loop (:147-167)
+CC4_HD void fsm_apply(Ctx x, int r, RedHdr& H, int h, int act, bool success) {  // _host_state_transition inner loop (:147-167)
   RedAgent& A = x.s->red[r];
   int cur = fsm_get(A, h);
   if (cur == FS_NONE) return;
@@ -1691,45 +1692,46 @@ CC4_HD void fsm_apply(Ctx x, int r, int h, int act, bool success) {  // _host_st
   if (nx != cur) fsm_set_state(A, h, nx);
   if (nx == FS_F && cur != FS_F) {  // leaves known_hosts for good
     int n = 0;
-    for (int i = 0; i < A.fsm_n; ++i) if (A.fsm_order[i] != h) A.fsm_order[n++] = A.fsm_order[i];
-    A.fsm_n = (uint8_t)n;
+    for (int i = 0; i < H.fsm_n; ++i) if (A.fsm_order[i] != h) A.fsm_order[n++] = A.fsm_order[i];
+    H.fsm_n = (uint8_t)n;
   }
 }
-CC4_HD void fsm_observe(Ctx x, int r) {
+// H: the agent's scalar fields in registers (RedHdr); the caller loaded them and stores them back
+CC4_HD void fsm_observe(Ctx x, int r, RedHdr& H) {
   RedAgent& A = x.s->red[r];
   CC4_AT0(x);
   // Mid-action agent whose observation is just the RedSessionCheck listing of an unchanged session table: nothing below can
   // change anything.  No transition (success is IN_PROGRESS), no entry to process, the listing's hosts were merged when the
   // table last changed (live <= known, hostnames known), and the removal check found fsm_ur & ~live empty then -- neither
   // set has moved since (fsm_ur only moves in this function, live only with fsm_dirty).
-  if (A.obs_success == T_IN_PROGRESS && A.nobs == 0 && A.rsc_listed && !A.fsm_dirty) return;
+  if (H.obs_success == T_IN_PROGRESS && H.nobs == 0 && H.rsc_listed && !H.fsm_dirty) return;
   // 1. _host_state_transition (:124-167)
-  if (A.obs_act_type <= RA_WITHDRAW && A.obs_success != T_IN_PROGRESS && A.obs_success != 0) {
-    bool ok = A.obs_success == T_TRUE;
-    int t = A.obs_act_type;
+  if (H.obs_act_type <= RA_WITHDRAW && H.obs_success != T_IN_PROGRESS && H.obs_success != 0) {
+    bool ok = H.obs_success == T_TRUE;
+    int t = H.obs_act_type;
     if (t == RA_DRS) {
       // every known host of the pinged subnet (ids subnet*17 .. +16); the order of the per-host transitions is immaterial
       // on success only K, S, U, R move (to KD, SD, UD, RD): visit just those hosts
-      const int lo = A.obs_act_arg * SLOTS, hi = lo + SLOTS - 1;
+      const int lo = H.obs_act_arg * SLOTS, hi = lo + SLOTS - 1;
       for (int w = lo >> 5; w <= (hi >> 5) && w < 5; ++w) {
         uint32_t m = A.fsm_known[w];
         if (ok) m &= ~A.fsm_nodrs[w];
         const int l = lo - 32 * w, u = hi - 32 * w;
         if (l > 0) m &= 0xFFFFFFFFu << l;
         if (u < 31) m &= (2u << u) - 1u;
-        while (m) { int b = ctz32(m); m &= m - 1; fsm_apply(x, r, w * 32 + b, t, ok); }
+        while (m) { int b = ctz32(m); m &= m - 1; fsm_apply(x, r, H, w * 32 + b, t, ok); }
       }
     } else if (t == RA_PRIVESC || t == RA_IMPACT || t == RA_DEGRADE) {
-      int h = A.obs_act_host;  // matched through host_states[ip]['hostname']
-      if (bit_get(A.fsm_known, h) && bit_get(A.fsm_hn, h)) fsm_apply(x, r, h, t, ok);
+      int h = H.obs_act_host;  // matched through host_states[ip]['hostname']
+      if (bit_get(A.fsm_known, h) && bit_get(A.fsm_hn, h)) fsm_apply(x, r, H, h, t, ok);
     } else {
-      fsm_apply(x, r, A.obs_act_host, t, ok);
+      fsm_apply(x, r, H, H.obs_act_host, t, ok);
     }
   }
   CC4_AT(x, 3);
   // 2. _process_new_observations (:190-250)
   B5 seen = b5_zero();   // hosts whose observation entry carries Sessions
-  for (int i = 0; i < A.nobs; ++i) {
+  for (int i = 0; i < H.nobs; ++i) {
     int h = A.obs[i].host; int f = A.obs[i].flags;
     if (f & OE_SESS) b5_set(seen, h);
     bool hn = !(f & OE_KEY_IP) || (f & OE_SYSHN);
@@ -1740,8 +1742,8 @@ CC4_HD void fsm_observe(Ctx x, int r) {
       continue;
     }
     if (!bit_get(A.fsm_known, h)) {
-      fsm_set_state(A, h, A.fsm_step == 0 ? FS_U : FS_K);
-      A.fsm_order[A.fsm_n++] = (uint8_t)h;
+      fsm_set_state(A, h, H.fsm_step == 0 ? FS_U : FS_K);
+      A.fsm_order[H.fsm_n++] = (uint8_t)h;
       bit_set(A.fsm_known, h);
     }
     if (hn) bit_set(A.fsm_hn, h);
@@ -1749,19 +1751,19 @@ CC4_HD void fsm_observe(Ctx x, int r) {
   CC4_AT(x, 4);
   // the RedSessionCheck listing (comes last in the observation's key order): every session host is hostname-known, carries
   // Sessions, and is new to host_states iff it is not in fsm_known -- added in session (dict) order
-  if (A.rsc_listed) {
+  if (H.rsc_listed) {
     const B5 live = b5_load(A.live_hosts), known = b5_load(A.fsm_known), hn = b5_load(A.fsm_hn);
     seen = b5_or(seen, live);
     if (b5_any(b5_andn(live, known)))
-      for (int i = 0; i < A.nsess; ++i) {
+      for (int i = 0; i < H.nsess; ++i) {
         int h = rsw_host(rs_at(x.s, A, i));
         if (bit_get(A.fsm_known, h)) continue;
-        fsm_set_state(A, h, A.fsm_step == 0 ? FS_U : FS_K);
-        A.fsm_order[A.fsm_n++] = (uint8_t)h;
+        fsm_set_state(A, h, H.fsm_step == 0 ? FS_U : FS_K);
+        A.fsm_order[H.fsm_n++] = (uint8_t)h;
         bit_set(A.fsm_known, h);
       }
     b5_store(A.fsm_hn, b5_or(hn, live));
-    A.fsm_dirty = 0;
+    H.fsm_dirty = 0;
   }
   CC4_AT(x, 5);
   // 3. _session_removal_state_change (:169-188): hosts in U/UD/R/RD without a Sessions entry in the observation -> KD
@@ -1778,11 +1780,11 @@ CC4_HD void fsm_observe(Ctx x, int r) {
 // DiscoveryFSRed._choose_host (FiniteStateRedAgent.py:252-293 with FSMRedVariants.py:95-110): host-state priorities
 // {K,KD,S,SD: 20, U,UD: 10, R,RD: 0} and prioritise_servers.  The float arithmetic restates the Python expressions
 // operation by operation (probs = (p/100) * (1/(sum/100)); numpy choice(p) = cumsum, /= last, searchsorted right).
-CC4_HD int fsm_choose_host_discovery(Ctx x, int r) {
+CC4_HD int fsm_choose_host_discovery(Ctx x, int r, RedHdr& H) {
   RedAgent& A = x.s->red[r];
   // available_states in order of first appearance among the known hosts, packed as nibbles
   uint32_t order = 0; int nst = 0; uint32_t seen = 0;
-  for (int i = 0; i < A.fsm_n && nst < 8; ++i) {
+  for (int i = 0; i < H.fsm_n && nst < 8; ++i) {
     int st = fsm_get(A, A.fsm_order[i]);
     if (!((seen >> st) & 1u)) { seen |= 1u << st; order |= (uint32_t)st << (4 * nst); nst++; }
   }
@@ -1806,7 +1808,7 @@ CC4_HD int fsm_choose_host_discovery(Ctx x, int r) {
     chosen_state = (order >> (4 * (int)rng_below(x.r, (uint32_t)nst))) & 0xF;
   }
   int n_all = 0, n_srv = 0;
-  for (int i = 0; i < A.fsm_n; ++i) {
+  for (int i = 0; i < H.fsm_n; ++i) {
     int h = A.fsm_order[i];
     if (fsm_get(A, h) != chosen_state) continue;
     n_all++;
@@ -1819,7 +1821,7 @@ CC4_HD int fsm_choose_host_discovery(Ctx x, int r) {
   }
   int cnt = want_srv < 0 ? n_all : (want_srv ? n_srv : n_all - n_srv);
   int c = (int)rng_below(x.r, (uint32_t)cnt);
-  for (int i = 0; i < A.fsm_n; ++i) {
+  for (int i = 0; i < H.fsm_n; ++i) {
     int h = A.fsm_order[i];
     if (fsm_get(A, h) != chosen_state) continue;
     bool srv = h_is_server(h) && bit_get(A.fsm_hn, h);
@@ -1829,18 +1831,18 @@ CC4_HD int fsm_choose_host_discovery(Ctx x, int r) {
   return A.fsm_order[0];
 }
 // get_action (:58-122) incl. _choose_host (:252-293) and _choose_host_and_action (:296-336)
-CC4_HD Act fsm_get_action(Ctx x, int r) {
+CC4_HD Act fsm_get_action(Ctx x, int r, RedHdr& H) {
   EnvState* s = x.s;
   RedAgent& A = s->red[r];
   Act out; out.type = RA_SLEEP; out.host = 0; out.arg = 0; out.ticks = 1; out.sid = 0; out.busy = 0;
-  fsm_observe(x, r);
-  if (A.obs_success == T_IN_PROGRESS) { A.fsm_step++; return out; }
-  int n = A.fsm_n;  // fsm_order holds exactly the non-'F' hosts, in host_states insertion order
-  if (n == 0) { set_err(x, E_FSM_NO_HOST); A.fsm_step++; return out; }
+  fsm_observe(x, r, H);
+  if (H.obs_success == T_IN_PROGRESS) { H.fsm_step++; return out; }
+  int n = H.fsm_n;  // fsm_order holds exactly the non-'F' hosts, in host_states insertion order
+  if (n == 0) { set_err(x, E_FSM_NO_HOST); H.fsm_step++; return out; }
   const bool discovery = (s->policy & 3) == RP_DISCOVERY;
   int host;
   if (!discovery) host = A.fsm_order[rng_below(x.r, (uint32_t)n)];
-  else host = fsm_choose_host_discovery(x, r);
+  else host = fsm_choose_host_discovery(x, r, H);
   // options in red_actions list order (ESG.py:764-768) with state_transitions_probability (:540-549).  All probabilities
   // are multiples of 1/4, so cdf.searchsorted(u, 'right') == #{i : 4*cdf[i] <= floor(4u)}.  Packed per state:
   // low 16 bits = option nibbles, high 16 bits = 4*cdf nibbles (unused slots = 15)
@@ -1874,27 +1876,27 @@ CC4_HD Act fsm_get_action(Ctx x, int r) {
   // parameters in constructor-signature order; only `subnet` and `session` can draw
   bool bad = false;
   if (t == RA_DRS) {
-    uint32_t known = A.as_subnet;  // known subnets in dict (= SUBNET enum) order
+    uint32_t known = H.as_subnet;  // known subnets in dict (= SUBNET enum) order
     if (known == 0) bad = true; else out.arg = (uint8_t)nth_bit(known, (int)rng_below(x.r, (uint32_t)popc32(known)));
   }
   if ((t == RA_PRIVESC || t == RA_IMPACT || t == RA_DEGRADE) && !bit_get(A.fsm_hn, host)) bad = true;
   if (!bad) {
-    if (A.nknown == 0) bad = true; else out.sid = A.known_sid[rng_below(x.r, (uint32_t)A.nknown)];
+    if (H.nknown == 0) bad = true; else out.sid = A.known_sid[rng_below(x.r, (uint32_t)H.nknown)];
   }
   if (bad) { set_err(x, E_UNREACHABLE); out.type = RA_SLEEP; }  // reference would re-draw with p not summing to 1 and raise
   out.ticks = (uint8_t)red_duration(out.type);
-  A.fsm_step++;
+  H.fsm_step++;
   return out;
 }
 // RandomSelectRedAgent.get_action (Agents/SimpleAgents/RandomSelectRedAgent.py:33-103): uniform command, then uniform
 // parameters from the ActionSpace entries that are True.  Commands in red_actions order (ESG.py:764-768), parameters in
 // constructor order; a draw is made only when there is more than one option.
-CC4_HD Act random_red_get_action(Ctx x, int r) {
+CC4_HD Act random_red_get_action(Ctx x, int r, RedHdr& H) {
   RedAgent& A = x.s->red[r];
   Act out; out.type = RA_SLEEP; out.host = 0; out.arg = 0; out.ticks = 1; out.sid = 0; out.busy = 0;
   const int nip = popc32(A.as_ip[0]) + popc32(A.as_ip[1]) + popc32(A.as_ip[2]) + popc32(A.as_ip[3]) + popc32(A.as_ip[4]);
   const int nhn = popc32(A.as_hn[0]) + popc32(A.as_hn[1]) + popc32(A.as_hn[2]) + popc32(A.as_hn[3]) + popc32(A.as_hn[4]);
-  const int nsub = popc32(A.as_subnet), nsid = A.nknown;
+  const int nsub = popc32(H.as_subnet), nsid = H.nknown;
   // valid_commands: a command is listed only if each of its parameters has at least one True option
   // order: DRS, Aggressive, Stealth, Exploit, PrivEsc, Degrade, DiscoverDeception, Impact, Withdraw, Sleep
   const uint8_t types[10] = {RA_DRS, RA_AGGR, RA_STEALTH, RA_EXPLOIT, RA_PRIVESC, RA_DEGRADE, RA_DECEPTION, RA_IMPACT, RA_WITHDRAW, RA_SLEEP};
@@ -1914,7 +1916,7 @@ CC4_HD Act random_red_get_action(Ctx x, int r) {
   auto pick_hn = [&]() { return nth_set(A.as_hn, 5, (int)rng_below(x.r, (uint32_t)nhn)); };
   out.type = (uint8_t)t;
   switch (t) {
-    case RA_DRS: out.arg = (uint8_t)nth_bit(A.as_subnet, (int)rng_below(x.r, (uint32_t)nsub)); out.sid = (uint16_t)pick_sid(); break;
+    case RA_DRS: out.arg = (uint8_t)nth_bit(H.as_subnet, (int)rng_below(x.r, (uint32_t)nsub)); out.sid = (uint16_t)pick_sid(); break;
     case RA_AGGR: case RA_STEALTH: case RA_DECEPTION: out.sid = (uint16_t)pick_sid(); out.host = (uint8_t)pick_ip(); break;
     case RA_EXPLOIT: out.host = (uint8_t)pick_ip(); out.sid = (uint16_t)pick_sid(); break;
     case RA_PRIVESC: case RA_DEGRADE: case RA_IMPACT: out.host = (uint8_t)pick_hn(); out.sid = (uint16_t)pick_sid(); break;
@@ -1922,16 +1924,16 @@ CC4_HD Act random_red_get_action(Ctx x, int r) {
     default: break;
   }
   out.ticks = (uint8_t)red_duration(out.type);
-  A.fsm_step++;   // self.step
+  H.fsm_step++;   // self.step
   return out;
 }
 // SimulationController.replace_action_if_invalid (SC:1068-1112) for a red action
-CC4_HD void red_validate(Ctx x, int r, Act& a) {
+CC4_HD void red_validate(Ctx x, int r, const RedHdr& H, Act& a) {
   RedAgent& A = x.s->red[r];
   if (a.type >= RA_SLEEP) return;
   bool ok = true;
-  if (!sid_known(A, a.sid)) ok = false;
-  if (a.type == RA_DRS) { if (!((A.as_subnet >> a.arg) & 1u)) ok = false; }
+  if (!sid_known(A, a.sid, H.nknown)) ok = false;
+  if (a.type == RA_DRS) { if (!((H.as_subnet >> a.arg) & 1u)) ok = false; }
   else if (a.type == RA_PRIVESC || a.type == RA_IMPACT || a.type == RA_DEGRADE) { if (!bit_get(A.as_hn, a.host)) ok = false; }
   else if (a.type == RA_WITHDRAW) { if (!bit_get(A.as_ip, a.host) || !bit_get(A.as_hn, a.arg)) ok = false; }
   else { if (!bit_get(A.as_ip, a.host)) ok = false; }
@@ -1960,7 +1962,7 @@ CC4_HD void red_reassign(Ctx x, uint32_t foreign) {   // foreign: red_foreign_ag
   for (int r = 0; r < NRED; ++r) {
     if (!((foreign >> r) & 1u)) continue;
     const RedAgent& A = s->red[r];
-    const int n = A.nsess;
+    const int n = A.h.nsess;
     for (int i0 = 0; i0 < n; i0 += 8) {   // 8 session records per round (see rs_load8)
       const S8 q = rs_load8(s, A, i0);
       CC4_UNROLL for (int k = 0; k < 8; ++k) {
@@ -1988,9 +1990,9 @@ CC4_HD void red_reassign(Ctx x, uint32_t foreign) {   // foreign: red_foreign_ag
     int shift = 0;
     CC4_UNROLL for (int r = 0; r < NRED; ++r) if (r == from) shift = gone_from[r];
     int i = (int)((w >> 6) & 0x3Fu) - shift;
-    if (i < 0 || i >= F.nsess || F.sord[i] != slot) {
+    if (i < 0 || i >= F.h.nsess || F.sord[i] != slot) {
       i = -1;
-      for (int k = 0; k < F.nsess; ++k) if (F.sord[k] == slot) { i = k; break; }
+      for (int k = 0; k < F.h.nsess; ++k) if (F.sord[k] == slot) { i = k; break; }
       if (i < 0) continue;
     }
     CC4_UNROLL for (int r = 0; r < NRED; ++r) if (r == from) gone_from[r]++;
@@ -2000,15 +2002,15 @@ CC4_HD void red_reassign(Ctx x, uint32_t foreign) {   // foreign: red_foreign_ag
     int ni = rs_add(x, to, old_host, old_pid, RS_ABSTRACT | (old_flags & RS_ROOT), slot);
     if (ni < 0) { bit_clr_shared(s->spool_used, slot); continue; }
     // observation hand-over: only if the creating action's observation carries the host ip key with this session
-    if (F.new_sess_host == old_host && F.new_sess_id == old_id) {
+    if (F.h.new_sess_host == old_host && F.h.new_sess_id == old_id) {
       obs_first(x, to, T_UNKNOWN, RA_NONE, 0, 0);
       obs_put(x, to, true, old_host, OE_SESS | OE_IFACE | OE_SYSHN, false);
       as_know_sid(x, to, rsw_id(rs_at(s, s->red[to], ni)));
     }
   }
   int ns[NRED];
-  CC4_UNROLL for (int r = 0; r < NRED; ++r) ns[r] = s->red[r].nsess;
-  CC4_UNROLL for (int r = 0; r < NRED; ++r) s->red[r].active = (uint8_t)(ns[r] > 0);
+  CC4_UNROLL for (int r = 0; r < NRED; ++r) ns[r] = s->red[r].h.nsess;
+  CC4_UNROLL for (int r = 0; r < NRED; ++r) s->red[r].h.active = (uint8_t)(ns[r] > 0);
 }
 
 // ------------------------------------------------------------------ the step (SimulationController.step, SC:211-315)
@@ -2016,8 +2018,8 @@ CC4_HD void red_reassign(Ctx x, uint32_t foreign) {   // foreign: red_foreign_ag
 // oracle and the PCG64 device mode) and the lane-parallel Philox kernel run the very same phase bodies.
 //   P0 step_begin            lane 0      phase check, blue decode + queue            (SC:224-248)
 //   P1 step_green_policy(g)  per green   EnterpriseGreenAgent.get_action             (EnterpriseGreenAgent.py:60)
-//   P2 step_red_policy(r)    per red     FSM get_action + validity + queue           (SC:236-248)
-//   P3 step_tick             lane 0      duration queue, filter, (pcg: shuffle), blue execution
+//   P2 step_red_policy_tick(r) per red   FSM get_action + validity + queue, then the agent's duration-queue tick (SC:236-265)
+//   P3 step_tick_blue(b), step_blue_exec   duration queue of the blue agents, (pcg: shuffle), blue execution
 //   P4 step_green_exec(g)    per green   green actions except PhishingEmail          (GreenLocalWork/GreenAccessService)
 //   P5 step_phishing         lane 0      deferred PhishingEmail in agent order
 //   P6 step_red_exec         lane 0      red actions in agent order, reassignment    (SC:271-278)
@@ -2091,13 +2093,36 @@ CC4_HD void step_green_policy(Ctx x, int g) {
   rng_set_stream(x.r, ST_GREEN_POL + (uint32_t)g);
   x.w->green_act[g] = (uint8_t)rng_below(x.r, 3);  // choice([GreenAccessService, GreenLocalWork, Sleep])
 }
-CC4_HD void step_red_policy(Ctx x, int r) {
-  RedAgent& A = x.s->red[r];
+// One red agent's policy (AgentInterface.get_action, SC:236-248) followed by its own duration-queue tick (SC:251-265; a tick
+// touches only its agent: queue, observation reset, filter_actions against its own session table).  The agent's scalar fields
+// (RedHdr) are read once into registers, worked on there and written back once.  Returns 1 if the agent's action was dropped
+// by filter_actions (SC:466-485: it names a dead session).
+CC4_HD int step_red_policy_tick(Ctx x, int r) {
+  EnvState* s = x.s;
+  RedAgent& A = s->red[r];
+  RedHdr H = A.h;
   Act a; a.type = RA_SLEEP; a.host = 0; a.arg = 0; a.ticks = 1; a.sid = 0; a.busy = 0;
   rng_set_stream(x.r, ST_RED_POL + (uint32_t)r);
-  if (A.active && (x.s->policy & 3) == RP_RANDOM) { a = random_red_get_action(x, r); red_validate(x, r, a); }
-  else if (A.active && (x.s->policy & 3) != RP_SLEEP) { a = fsm_get_action(x, r); CC4_AT0(x); red_validate(x, r, a); CC4_AT(x, 7); }   // AgentInterface.get_action (:120-143); SleepAgent -> Sleep
-  if (!A.queue.busy) { A.queue = a; A.queue.busy = 1; }
+  if (H.active && (s->policy & 3) == RP_RANDOM) { a = random_red_get_action(x, r, H); red_validate(x, r, H, a); }
+  else if (H.active && (s->policy & 3) != RP_SLEEP) { a = fsm_get_action(x, r, H); CC4_AT0(x); red_validate(x, r, H, a); CC4_AT(x, 7); }   // AgentInterface.get_action (:120-143); SleepAgent -> Sleep
+  if (!H.queue.busy) { H.queue = a; H.queue.busy = 1; }
+  // ---- tick: a new step's observation starts empty
+  H.nobs = 0; H.obs_success = 0; H.obs_act_type = RA_NONE; H.new_sess_host = 0xFF; H.rsc_listed = 0;
+  for (int w = 0; w < 5; ++w) { A.obs_has[0][w] = 0; A.obs_has[1][w] = 0; }
+  Act q = H.queue, ex;
+  q.ticks--;
+  if (q.ticks < 1) { ex = q; q.busy = 0; }
+  else {
+    ex.type = RA_SLEEP; ex.host = 0; ex.arg = 0; ex.ticks = 0; ex.sid = 0; ex.busy = 0;
+    H.obs_success = T_IN_PROGRESS; H.obs_act_type = RA_NONE; H.obs_act_host = 0; H.obs_act_arg = 0;   // obs_first(IN_PROGRESS)
+  }
+  H.queue = q;
+  H.exec_type = ex.type; H.exec_host = ex.host;
+  int dropped = 0;
+  if (ex.type <= RA_WITHDRAW && rs_find_id(s, A, ex.sid, H.nsess) < 0) { ex.type = RA_NONE; dropped = 1; }
+  s->rexec[r] = ex;
+  A.h = H;
+  return dropped;
 }
 CC4_HD void step_blue_exec(Ctx x) {
   EnvState* s = x.s;
@@ -2127,35 +2152,13 @@ CC4_HD bool blue_exec_independent(const EnvState* s) {
   for (int b = 0; b < NBLUE; ++b) if (s->bexec[b].type == BA_MONITOR) return false;
   return true;
 }
-// duration queue of one agent (SC:251-265): a = 0..4 blue, 5..10 red.  Returns 1 if the agent's action was dropped by
-// filter_actions (SC:466-485: it names a dead session)
-CC4_HD int step_tick_agent(Ctx x, int a) {
+// duration queue of one blue agent (SC:251-265)
+CC4_HD void step_tick_blue(Ctx x, int b) {
   EnvState* s = x.s;
-  Act z; z.type = 0; z.host = 0; z.arg = 0; z.ticks = 0; z.sid = 0; z.busy = 0;
-  if (a < NBLUE) {
-    Act& q = s->blue[a].queue;
-    q.ticks--;
-    if (q.ticks < 1) { s->bexec[a] = q; q.busy = 0; }
-    else { z.type = BA_SLEEP; s->bexec[a] = z; }
-    return 0;
-  }
-  int r = a - NBLUE;
-  RedAgent& A = s->red[r];
-  A.nobs = 0; A.obs_success = 0; A.obs_act_type = RA_NONE; A.new_sess_host = 0xFF;
-  for (int w = 0; w < 5; ++w) { A.obs_has[0][w] = 0; A.obs_has[1][w] = 0; }
-  A.rsc_listed = 0;
-  Act& q = A.queue;
+  Act& q = s->blue[b].queue;
   q.ticks--;
-  if (q.ticks < 1) { s->rexec[r] = q; q.busy = 0; }
-  else { z.type = RA_SLEEP; s->rexec[r] = z; obs_first(x, r, T_IN_PROGRESS, RA_NONE, 0, 0); }
-  A.exec_type = s->rexec[r].type; A.exec_host = s->rexec[r].host;
-  if (s->rexec[r].type <= RA_WITHDRAW && rs_find_id(s, A, s->rexec[r].sid) < 0) { s->rexec[r].type = RA_NONE; return 1; }
-  return 0;
-}
-CC4_HD void step_tick(Ctx x) {
-  EnvState* s = x.s;
-  for (int a = 0; a < NBLUE + NRED; ++a) s->n_actions -= step_tick_agent(x, a);
-  step_blue_exec(x);
+  if (q.ticks < 1) { s->bexec[b] = q; q.busy = 0; }
+  else { Act z; z.type = BA_SLEEP; z.host = 0; z.arg = 0; z.ticks = 0; z.sid = 0; z.busy = 0; s->bexec[b] = z; }
 }
 // returns the BlueRewardMachine penalty of this green agent's action (<= 0)
 // pre: block 0 of the agent's stream when the caller has it already (rng_preload), else null
@@ -2234,8 +2237,8 @@ CC4_HD void step_reassign(Ctx x, uint32_t foreign) {   // foreign = red_foreign_
   if (foreign) red_reassign(x, foreign);
   else {
     int ns[NRED];
-    CC4_UNROLL for (int r = 0; r < NRED; ++r) ns[r] = s->red[r].nsess;
-    CC4_UNROLL for (int r = 0; r < NRED; ++r) s->red[r].active = (uint8_t)(ns[r] > 0);
+    CC4_UNROLL for (int r = 0; r < NRED; ++r) ns[r] = s->red[r].h.nsess;
+    CC4_UNROLL for (int r = 0; r < NRED; ++r) s->red[r].h.active = (uint8_t)(ns[r] > 0);
   }
   CC4_TICK(x, 8);
 }
@@ -2258,7 +2261,7 @@ CC4_HD void step_monitor_pend(Ctx x) {  // session.add_sus_pids for the pid-carr
   s->npend = 0;
 }
 CC4_HD void step_rsc(Ctx x, int r) {
-  if (!x.s->red[r].active) return;
+  if (!x.s->red[r].h.active) return;
   rng_set_stream(x.r, ST_RED_RSC + (uint32_t)r);
   red_session_check(x, r);
 }
@@ -2273,10 +2276,10 @@ CC4_HD void step_end(Ctx x, const uint8_t* messages, bool copy_msgs = true) {
   s->done = (uint8_t)(s->step_count >= s->steps - 1);
   int brm = s->brm;
   int et[NRED], ns[NRED];
-  CC4_UNROLL for (int r = 0; r < NRED; ++r) { et[r] = s->red[r].exec_type; ns[r] = s->red[r].nsess; }
+  CC4_UNROLL for (int r = 0; r < NRED; ++r) { et[r] = s->red[r].h.exec_type; ns[r] = s->red[r].h.nsess; }
   CC4_UNROLL for (int r = 0; r < NRED; ++r)
     if (et[r] == RA_IMPACT && ns[r] > 0)
-      brm += reward_table(s->phase, h_subnet(s->red[r].exec_host), RW_RIA);  // charged for any executed Impact (App. B.2)
+      brm += reward_table(s->phase, h_subnet(s->red[r].h.exec_host), RW_RIA);  // charged for any executed Impact (App. B.2)
   s->action_cost = -(float)s->n_restore;
   s->reward = (float)brm + s->action_cost;
   if (copy_msgs) for (int b = 0; b < NBLUE; ++b) step_messages(s, messages, b);
@@ -2293,10 +2296,11 @@ CC4_HD void env_step(Ctx x, const int32_t* actions, const uint8_t* messages /* [
   rng_policy_swap(x, false);
   for (int g = 0; g < s->n_green; ++g) step_green_policy(x, g);
   CC4_TICK(x, 1);
-  for (int r = 0; r < NRED; ++r) step_red_policy(x, r);
+  for (int r = 0; r < NRED; ++r) s->n_actions -= step_red_policy_tick(x, r);
   rng_policy_swap(x, true);
   CC4_TICK(x, 2);
-  step_tick(x);
+  for (int b = 0; b < NBLUE; ++b) step_tick_blue(x, b);
+  step_blue_exec(x);
   for (int g = 0; g < s->n_green; ++g) {
     s->brm += step_green_exec(x, g);
     if (bit_get(x.w->phish_mask, g)) { bit_clr(x.w->phish_mask, g); rng_set_stream(x.r, ST_GREEN_PHISH + (uint32_t)g); phishing(x, s->green_host[g]); }

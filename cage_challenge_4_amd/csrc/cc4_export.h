@@ -61,8 +61,8 @@ inline std::string export_true_state(const EnvState& s, const EnvCold& cold, boo
   o += "],\"red\":[";
   for (int r = 0; r < NRED; ++r) {
     const RedAgent& A = s.red[r];
-    add("%s{\"active\":%u,\"sessions\":[", r ? "," : "", (unsigned)A.active);
-    for (int i = 0; i < A.nsess; ++i) { const RSess& q = s.spool[A.sord[i]]; add("%s[%u,%u,%u,%u]", i ? "," : "", (unsigned)q.id, (unsigned)q.host, (unsigned)q.pid, (unsigned)q.flags); }
+    add("%s{\"active\":%u,\"sessions\":[", r ? "," : "", (unsigned)A.h.active);
+    for (int i = 0; i < A.h.nsess; ++i) { const RSess& q = s.spool[A.sord[i]]; add("%s[%u,%u,%u,%u]", i ? "," : "", (unsigned)q.id, (unsigned)q.host, (unsigned)q.pid, (unsigned)q.flags); }
     o += "]}";
   }
   o += "],\"blue\":[";
@@ -74,7 +74,7 @@ inline std::string export_true_state(const EnvState& s, const EnvCold& cold, boo
   o += "],\"last_blue\":[";   // self.action[blue_agent_b][0] of the last step: [BA_* type, host (or to-subnet), arg (from-subnet)]
   for (int k = 0; k < NBLUE; ++k) add("%s[%u,%u,%u]", k ? "," : "", (unsigned)s.bexec[k].type, (unsigned)s.bexec[k].host, (unsigned)s.bexec[k].arg);
   o += "],\"last_red\":[";    // self.action[red_agent_r][0]: [RA_* type, host, arg (subnet of DiscoverRemoteSystems), executed]
-  for (int r = 0; r < NRED; ++r) add("%s[%u,%u,%u,%u]", r ? "," : "", (unsigned)s.red[r].exec_type, (unsigned)s.red[r].exec_host, (unsigned)s.rexec[r].arg, (unsigned)(s.rexec[r].type != RA_NONE));
+  for (int r = 0; r < NRED; ++r) add("%s[%u,%u,%u,%u]", r ? "," : "", (unsigned)s.red[r].h.exec_type, (unsigned)s.red[r].h.exec_host, (unsigned)s.rexec[r].arg, (unsigned)(s.rexec[r].type != RA_NONE));
   if (lg && lg->enabled) {   // the HostEvents entries of the last step (cc4_enable_event_log), in append order
     add("],\"events_step\":%u,\"events_total\":%u,\"events\":[", lg->step, lg->n);
     const uint32_t n = lg->n < (uint32_t)MAX_EV ? lg->n : (uint32_t)MAX_EV;

@@ -145,10 +145,11 @@ __global__ __launch_bounds__(WAVE) void k_step(StepArgs a) {
         rng_policy_swap(x, false);     // CybORG.set_seed split: the policies draw from the old stream (EnvState.rng2)
         for (int g = 0; g < s->n_green; ++g) step_green_policy(x, g);
         CC4_TICK(x, 1);
-        for (int r = 0; r < NRED; ++r) step_red_policy(x, r);
+        for (int r = 0; r < NRED; ++r) s->n_actions -= step_red_policy_tick(x, r);
         rng_policy_swap(x, true);
         CC4_TICK(x, 2);
-        step_tick(x);
+        for (int b = 0; b < NBLUE; ++b) step_tick_blue(x, b);
+        step_blue_exec(x);
         for (int g = 0; g < s->n_green; ++g) {
           s->brm += step_green_exec(x, g);
           if (bit_get(work.phish_mask, g)) { bit_clr(work.phish_mask, g); phishing(x, s->green_host[g]); }
@@ -336,16 +337,16 @@ __global__ __launch_bounds__(PT, MINW) void k_step_philox(StepArgs a) {
 
       if (is_red) {
         unsigned long long t0 = ap ? clock64() : 0;
-        step_red_policy(xr, ragent);
+        const int dropped = step_red_policy_tick(xr, ragent);
         if (ap) ap[0] += clock64() - t0;
-        if (step_tick_agent(xr, NBLUE + ragent)) atomicSub(&s->n_actions, 1);
+        if (dropped) atomicSub(&s->n_actions, 1);
       }
       else if (wave == PW - 1 && lane >= 2 && lane < 2 + NBLUE) {
         const int b = lane - 2;
         int32_t act = a.actions ? a.actions[e * NBLUE + b] : -1;
         if (a.rand_out) { act = random_blue_action(a.rand_seed0, a.rand_t, e, b); a.rand_out[e * NBLUE + b] = act; }
         step_blue_submit(x0, b, act);
-        (void)step_tick_agent(x0, b);
+        step_tick_blue(x0, b);
         step_messages(s, a.msgs ? a.msgs + e * NBLUE * MSG_LEN : nullptr, b);   // read back by this step's observation encode only
       }
       else if (lane >= 8 && wave >= 2) {

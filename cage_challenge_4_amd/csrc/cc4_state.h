@@ -115,7 +115,29 @@ struct alignas(8) Act { uint8_t type; uint8_t host; uint8_t arg; uint8_t ticks; 
 enum : int { OE_KEY_IP = 1, OE_SESS = 2, OE_IFACE = 4, OE_SYSHN = 8 };
 struct alignas(2) ObsEnt { uint8_t host; uint8_t flags; };
 
-struct alignas(8) RedAgent {
+// A red agent's scalar fields, 32 bytes = two 16-byte vectors: the policy / tick path of a step reads them as one batch into
+// registers, works there, and writes them back once (every field read separately is an LDS round trip on the agent's
+// dependency chain).
+struct alignas(16) RedHdr {
+  Act queue;                         // actions_in_progress[agent]
+  uint16_t as_subnet;                // ActionSpace.subnet known bits
+  uint16_t fsm_step;
+  uint16_t new_sess_id;
+  uint8_t nsess, nknown, fsm_n, nobs;
+  uint8_t nlive;                     // popcount(live_hosts)
+  uint8_t active;                    // AgentInterface.active
+  uint8_t obs_success;               // success of observations[0]
+  uint8_t obs_act_type, obs_act_host, obs_act_arg;   // 'action' of observations[0] (RA_NONE if absent / not FSM-relevant)
+  uint8_t exec_type, exec_host;      // self.action[agent][0] of this step (for reward)
+  uint8_t new_sess_host;             // host of a session created by this agent's exploit this step (0xFF none)
+  uint8_t start_host;                // static per episode
+  uint8_t rsc_dirty;                 // session table changed since the last full RedSessionCheck observation
+  uint8_t rsc_listed;                // this step's observation includes the RedSessionCheck listing of every session
+  uint8_t fsm_dirty;                 // the set of session hosts may have changed since fsm_observe last merged a listing
+  uint8_t pad[1];
+};
+static_assert(sizeof(RedHdr) == 32, "RedHdr is two 16-byte vectors");
+struct alignas(16) RedAgent {
   alignas(8) uint8_t sord[MAX_RS];   // state.sessions[agent] in dict order: pool slots (read eight at a time)
   uint16_t known_sid[MAX_KS];        // ActionSpace.server_session keys with value True, insertion order
   uint32_t known_bm[8];              // the same set as a bitmap over ids 0..255 (larger ids fall back to the list scan)
@@ -131,21 +153,7 @@ struct alignas(8) RedAgent {
   uint32_t fsm_ur[5];                // hosts whose state is U, UD, R or RD (the ones _session_removal_state_change looks at)
   uint32_t fsm_nodrs[5];             // hosts whose state a successful DiscoverRemoteSystems leaves alone (KD, SD, UD, RD, F)
   uint32_t live_hosts[5];            // hosts currently holding >= 1 session of this agent (kept exact by rs_add / rs_remove_at)
-  Act queue;                         // actions_in_progress[agent]
-  uint16_t as_subnet;                // ActionSpace.subnet known bits
-  uint16_t fsm_step;
-  uint8_t nsess, nknown, fsm_n, nobs;
-  uint8_t nlive, pad_n[3];           // popcount(live_hosts)
-  uint8_t active;                    // AgentInterface.active
-  uint8_t obs_success;               // success of observations[0]
-  uint8_t obs_act_type, obs_act_host, obs_act_arg;   // 'action' of observations[0] (RA_NONE if absent / not FSM-relevant)
-  uint8_t exec_type, exec_host;      // self.action[agent][0] of this step (for reward)
-  uint8_t new_sess_host;             // host of a session created by this agent's exploit this step (0xFF none)
-  uint16_t new_sess_id;
-  uint8_t start_host;                // static per episode
-  uint8_t rsc_dirty;                 // session table changed since the last full RedSessionCheck observation
-  uint8_t rsc_listed;                // this step's observation includes the RedSessionCheck listing of every session
-  uint8_t fsm_dirty;                 // the set of session hosts may have changed since fsm_observe last merged a listing
+  RedHdr h;                          // the agent's scalars (32 bytes)
 };
 
 struct alignas(8) BlueAgent {

@@ -151,8 +151,10 @@ int cc4o_layout(char* buf, int cap) {
   F(blue); F(spool); F(red); F(hd);
 #undef F
 #define G(m) n += snprintf(buf + n, cap - n, "red." #m " %zu\n", offsetof(RedAgent, m))
-  G(sord); G(known_sid); G(fsm_order); G(fsm_st4); G(fsm_hn); G(as_ip); G(as_hn); G(obs); G(queue); G(as_subnet);
-  G(fsm_step); G(nsess); G(nknown); G(fsm_n); G(nobs); G(active); G(obs_success); G(exec_type); G(new_sess_host); G(new_sess_id); G(start_host);
+  G(sord); G(known_sid); G(fsm_order); G(fsm_st4); G(fsm_hn); G(as_ip); G(as_hn); G(obs);
+#undef G
+#define G(m) n += snprintf(buf + n, cap - n, "red." #m " %zu\n", offsetof(RedAgent, h) + offsetof(RedHdr, m))
+  G(queue); G(as_subnet); G(fsm_step); G(nsess); G(nknown); G(fsm_n); G(nobs); G(active); G(obs_success); G(exec_type); G(new_sess_host); G(new_sess_id); G(start_host);
 #undef G
   n += snprintf(buf + n, cap - n, "sizeof.RedAgent %zu\nsizeof.BlueAgent %zu\nsizeof.HostDyn %zu\nsizeof.HostStatic %zu\nsizeof.EnvState %zu\n",
                 sizeof(RedAgent), sizeof(BlueAgent), sizeof(HostDyn), sizeof(HostStatic), sizeof(EnvState));
@@ -179,14 +181,14 @@ int cc4o_dump(void* h, int i, char* buf, int cap) {
   }
   for (int r = 0; r < NRED; ++r) {
     const RedAgent& a = s.red[r];
-    P("red %d active %d sess", r, a.active);
-    for (int k = 0; k < a.nsess; ++k) { const RSess& q = s.spool[a.sord[k]]; P(" (%d,%d,%d,%d,%d)", q.id, q.host, q.pid, (q.flags & RS_ABSTRACT) ? 1 : 0, (q.flags & RS_ROOT) ? 1 : 0); }
+    P("red %d active %d sess", r, a.h.active);
+    for (int k = 0; k < a.h.nsess; ++k) { const RSess& q = s.spool[a.sord[k]]; P(" (%d,%d,%d,%d,%d)", q.id, q.host, q.pid, (q.flags & RS_ABSTRACT) ? 1 : 0, (q.flags & RS_ROOT) ? 1 : 0); }
     P(" known");
-    for (int k = 0; k < a.nknown; ++k) P(" %d", a.known_sid[k]);
-    P(" fsmstep %d fsm", a.fsm_step);
-    for (int k = 0; k < a.fsm_n; ++k) { int hh = a.fsm_order[k]; P(" (%d,%d,%d)", hh, fsm_get(a, hh), bit_get(a.fsm_hn, hh) ? 1 : 0); }
+    for (int k = 0; k < a.h.nknown; ++k) P(" %d", a.known_sid[k]);
+    P(" fsmstep %d fsm", a.h.fsm_step);
+    for (int k = 0; k < a.h.fsm_n; ++k) { int hh = a.fsm_order[k]; P(" (%d,%d,%d)", hh, fsm_get(a, hh), bit_get(a.fsm_hn, hh) ? 1 : 0); }
     for (int hh = 0; hh < MAXH; ++hh) if (fsm_get(a, hh) == FS_F) P(" (%d,%d,%d)", hh, FS_F, bit_get(a.fsm_hn, hh) ? 1 : 0);  // 'F' hosts after the live list
-    P(" subnets %u busy %d qt %d\n", a.as_subnet, a.queue.busy, a.queue.busy ? a.queue.type : -1);
+    P(" subnets %u busy %d qt %d\n", a.h.as_subnet, a.h.queue.busy, a.h.queue.busy ? a.h.queue.type : -1);
   }
   for (int b = 0; b < NBLUE; ++b) {
     const BlueAgent& a = s.blue[b];
