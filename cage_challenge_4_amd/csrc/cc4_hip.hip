@@ -237,9 +237,13 @@ __device__ __forceinline__ void dma_wait() { asm volatile("s_waitcnt vmcnt(0)" :
 
 // MINW = minimum waves per SIMD the register allocation must allow (= resident episode blocks per CU): 1 lets the compiler
 // take what it likes (86 VGPRs, 106 SGPRs: 5 blocks per CU) and is the fastest single block -- the build for batches that
-// fit the chip in one round (<= 5 x 256 episodes, the per-GPU share of an 8-GPU job); 8 caps the kernel at 64 VGPRs / 80
-// SGPRs (a few spills) so that 8 blocks are resident per CU -- the build for large batches, which are throughput-bound
-// (MI355X, 8192 episodes: 313 M agent-env steps/s with MINW 1, 352 M with 6, 378 M with 8; 1024 episodes: 165 / 166 / 156 M).
+// fit the chip in one round (<= 5 x 256 episodes, the per-GPU share of an 8-GPU job); CC4_PHILOX_BIG_MINW caps the registers so
+// that more blocks are resident per CU -- the build for large batches, which are throughput-bound.  Measured on MI355X at 8192
+// episodes (r02, same box, +-0.1 %): MINW 5: 315 M agent-env steps/s, 6: 353 M, 7: 376 M (72 VGPRs, a handful of spills),
+// 8: 360 M (64 VGPRs, ~30 spills); at 1024 episodes the MINW 1 build wins (167 M vs 156 M for MINW 8).
+#ifndef CC4_PHILOX_BIG_MINW
+#define CC4_PHILOX_BIG_MINW 7
+#endif
 template <bool LOG, int MINW>
 __global__ __launch_bounds__(PT, MINW) void k_step_philox(StepArgs a) {
   extern __shared__ uint4 lds[];
@@ -635,7 +639,7 @@ static int launch_step(cc4_handle* h, const int32_t* d_actions, const uint8_t* d
   h->step_event_attached = stop != nullptr;
   if (h->cfg.rng_mode == 1) {
     if (h->evlog_on) hipExtLaunchKernelGGL((k_step_philox<true, 1>), grid, dim3(PT), sizeof(EnvState), h->stream, nullptr, stop, 0, a);
-    else if (h->cfg.num_envs > h->one_round_blocks) hipExtLaunchKernelGGL((k_step_philox<false, 8>), grid, dim3(PT), sizeof(EnvState), h->stream, nullptr, stop, 0, a);
+    else if (h->cfg.num_envs > h->one_round_blocks) hipExtLaunchKernelGGL((k_step_philox<false, CC4_PHILOX_BIG_MINW>), grid, dim3(PT), sizeof(EnvState), h->stream, nullptr, stop, 0, a);
     else hipExtLaunchKernelGGL((k_step_philox<false, 1>), grid, dim3(PT), sizeof(EnvState), h->stream, nullptr, stop, 0, a);
   } else {
     if (h->evlog_on) hipExtLaunchKernelGGL(k_step<true>, grid, dim3(WAVE), offsetof(EnvState, hd), h->stream, nullptr, stop, 0, a);

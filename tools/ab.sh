@@ -1,0 +1,22 @@
+#!/bin/bash
+# A/B harness for kernel experiments: builds variants of libcc4.so from the working tree with extra -D flags into build_var/
+# (travels with gpurun), and benches them back to back on one box (run-to-run spread on one box is ~0.1 %, between boxes ~3 %).
+#   bash tools/ab.sh build NAME [-DFLAG ...]      (in the build container; several may run in parallel)
+#   bash tools/ab.sh bench NAME [NAME ...]        (through gpurun)
+set -u
+cd "$(dirname "$0")/.."
+mkdir -p build_var
+if [ "$1" = build ]; then
+  name=$2; shift 2
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -shared -fPIC "$@" -o build_var/$name.so cage_challenge_4_amd/csrc/cc4_hip.hip -lrccl
+else
+  shift
+  for round in 1 2; do for v in "$@"; do for n in 8192 1024; do
+    CC4_LIB=$PWD/build_var/$v.so python bench.py --no-alt --no-cpu-baseline --total-envs $n --min-seconds 0.4 2>/dev/null | python -c "
+import sys,json
+for l in sys.stdin:
+    if l.startswith('{'):
+        d=json.loads(l); print('$v', $n, round(d['value']/1e6,1), 'M  launch_ms', round(d['roofline']['launch_ms'],4), 'err', d['config']['engine_error_flags'])
+"
+  done; done; done
+fi
