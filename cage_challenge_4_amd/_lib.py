@@ -40,6 +40,7 @@ SIGNATURES = {
     'cc4_get_err': (ctypes.c_int, [_P, _P]),
     'cc4_get_rng_state': (ctypes.c_int, [_P, _P]),
     'cc4_set_seed': (ctypes.c_int, [_P, _P]),
+    'cc4_set_rng_state': (ctypes.c_int, [_P, _P]),
     'cc4_step_device': (ctypes.c_int, [_P, _P, _P]),
     'cc4_obs_device': (ctypes.c_int, [_P, ctypes.POINTER(_P)]),
     'cc4_reward_device': (ctypes.c_int, [_P, ctypes.POINTER(_P)]),

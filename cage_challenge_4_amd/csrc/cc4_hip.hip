@@ -556,6 +556,19 @@ __global__ void k_set_seed(EnvState* st, const uint64_t* seeds, int n, int rng_m
   if (rng_mode == 1) { rng_begin_episode(&st[e].rng); rng_park(&st[e].rng); }   // counter mode: the words a reset leaves behind
 }
 
+// an externally built numpy Generator(PCG64) handed over as CybORG(seed=generator) (env.py:73-76): its bit-generator state
+// becomes the episode's stream (words per episode: state high, state low, increment high, increment low, has_uint32, uinteger)
+__global__ void k_set_rng_state(EnvState* st, const uint64_t* w, int n) {
+  int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= n) return;
+  Rng r;
+  rng_seed(&r, 0, 0);
+  r.s_hi = w[6 * e]; r.s_lo = w[6 * e + 1]; r.inc_hi = w[6 * e + 2]; r.inc_lo = w[6 * e + 3];
+  r.has32 = (uint32_t)w[6 * e + 4]; r.u32 = (uint32_t)w[6 * e + 5];
+  st[e].rng = r;
+  st[e].rng_split = 0;
+}
+
 __global__ void k_rng_state(const EnvState* st, uint64_t* out, int n) {
   int e = blockIdx.x * blockDim.x + threadIdx.x;
   if (e >= n) return;
@@ -800,6 +813,16 @@ int cc4_set_seed(cc4_handle* h, const uint64_t* seeds) {
   int n = h->cfg.num_envs;
   HIPCHK(h, hipMemcpyAsync(h->d_seeds, seeds, (size_t)n * sizeof(uint64_t), hipMemcpyHostToDevice, h->stream));
   hipLaunchKernelGGL(k_set_seed, dim3((n + 127) / 128), dim3(128), 0, h->stream, h->d_state, h->d_seeds, n, h->cfg.rng_mode);
+  HIPCHK(h, hipGetLastError());
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  return 0;
+}
+int cc4_set_rng_state(cc4_handle* h, const uint64_t* words) {
+  if (h->cfg.rng_mode != 0) { h->err = "cc4_set_rng_state: a numpy PCG64 state needs rng_mode 0"; return -2; }
+  HIPCHK(h, hipSetDevice(h->cfg.device_id));
+  int n = h->cfg.num_envs;
+  HIPCHK(h, hipMemcpyAsync(h->d_rng, words, (size_t)n * 6 * sizeof(uint64_t), hipMemcpyHostToDevice, h->stream));   // d_rng holds 7 words per episode
+  hipLaunchKernelGGL(k_set_rng_state, dim3((n + 127) / 128), dim3(128), 0, h->stream, h->d_state, h->d_rng, n);
   HIPCHK(h, hipGetLastError());
   HIPCHK(h, hipStreamSynchronize(h->stream));
   return 0;

@@ -18,6 +18,16 @@ ERR_NAMES = {0: 'PROC_OVERFLOW', 1: 'RSESS_OVERFLOW', 2: 'KNOWN_SID_OVERFLOW', 3
              8: 'UNREACHABLE_REFERENCE_PATH', 10: 'BLUE_GREEN_SESSION_KILLED', 11: 'FSM_NO_HOST'}
 
 
+def pcg64_words(gen):
+    """numpy Generator(PCG64) -> the six words cc4_set_rng_state takes."""
+    st = gen.bit_generator.state
+    if st.get('bit_generator') != 'PCG64':
+        raise NotImplementedError(f"only numpy Generator(PCG64) streams can be adopted by the device RNG (got {st.get('bit_generator')})")
+    m = (1 << 64) - 1
+    return [st['state']['state'] >> 64, st['state']['state'] & m, st['state']['inc'] >> 64, st['state']['inc'] & m,
+            int(st['has_uint32']), int(st['uinteger'])]
+
+
 class CC4EngineError(RuntimeError):
     """An episode left the part of the reference's behaviour the engine reproduces (a fixed-size container overflowed, or the
     reference itself would have crashed): its results can no longer be trusted to equal the reference's."""
@@ -163,6 +173,14 @@ class CC4VecEnv:
         seeds = np.ascontiguousarray(seeds, dtype=np.uint64)
         assert seeds.shape == (self.num_envs,)
         self._chk(self.lib.cc4_set_seed(self._h, seeds.ctypes.data_as(ctypes.c_void_p)), 'cc4_set_seed')
+
+    def set_generators(self, generators):
+        """cc4_set_rng_state: adopt the streams of numpy Generator(PCG64) objects (one per episode).  The objects themselves are
+        not advanced afterwards: the stream continues on the device."""
+        w = np.zeros((self.num_envs, 6), np.uint64)
+        for i, g in enumerate(generators):
+            w[i] = pcg64_words(g)
+        self._chk(self.lib.cc4_set_rng_state(self._h, w.ctypes.data_as(ctypes.c_void_p)), 'cc4_set_rng_state')
 
     def rng_state(self):
         out = np.zeros((self.num_envs, 7), np.uint64)

@@ -97,14 +97,24 @@ class CybORG:
         self.scenario_generator = scenario_generator
         if seed is None:
             seed = int.from_bytes(os.urandom(8), 'little') >> 1
+        generator = None
         if not isinstance(seed, (int, np.integer)):
-            raise NotImplementedError("custom Generator objects cannot be injected into the device RNG; pass an int seed")
+            # env.py:73-76 also takes a ready generator.  A numpy Generator(PCG64) is adopted (its stream continues on the device;
+            # the Python object is not advanced); anything else -- e.g. the AlwaysTrue / AlwaysFalse stubs of CybORG/Tests/utils.py
+            # -- is Python code the device cannot call
+            if not isinstance(seed, np.random.Generator):
+                raise NotImplementedError("only int seeds and numpy Generator(PCG64) objects can drive the device RNG")
+            generator, seed = seed, 0
         # vec_factory: anything with CC4VecEnv's call shape (tests inject the CPU oracle; the default is the HIP engine)
         self.vec = (vec_factory or CC4VecEnv)(1, steps=scenario_generator.steps, rng_mode=rng_mode, device_id=device_id,
                                               red_policy=scenario_generator.red_policy,
                                               green_policy=scenario_generator.green_policy)
         self.vec.enable_event_log(True)                        # single episode: keep the per-step event detail for get_observation
-        self.vec.reset(seeds=np.array([seed], np.uint64))      # SimulationController.__init__ creates a scenario
+        if generator is not None:
+            self.vec.set_generators([generator])
+            self.vec.reset(seeds=None)                           # the scenario is drawn from the adopted stream
+        else:
+            self.vec.reset(seeds=np.array([seed], np.uint64))  # SimulationController.__init__ creates a scenario
         self.agents = [f'blue_agent_{b}' for b in range(5)]
         self._labels = None
 

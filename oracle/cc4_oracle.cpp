@@ -63,6 +63,12 @@ void cc4o_set_seed(void* h, int i, uint64_t seed, int rng_mode) {   // CybORG.se
   rng_seed(r, seed, (uint32_t)rng_mode);
   if (rng_mode == 1) { rng_begin_episode(r); rng_park(r); }
 }
+void cc4o_set_rng_state(void* h, int i, const uint64_t* w) {   // restatement of k_set_rng_state (csrc/cc4_hip.hip)
+  EnvState& st = ((Oracle*)h)->st[i];
+  Rng r; rng_seed(&r, 0, 0);
+  r.s_hi = w[0]; r.s_lo = w[1]; r.inc_hi = w[2]; r.inc_lo = w[3]; r.has32 = (uint32_t)w[4]; r.u32 = (uint32_t)w[5];
+  st.rng = r; st.rng_split = 0;
+}
 void cc4o_set_topology_seed(void* h, uint32_t seed) { ((Oracle*)h)->topo = seed; }
 void cc4o_enable_event_log(void* h, int on) { Oracle* o = (Oracle*)h; o->evlog = on ? 1 : 0; for (int i = 0; i < o->n; ++i) { o->cold[i].evlog.enabled = on ? 1u : 0u; o->cold[i].evlog.n = 0; } }
 void cc4o_step(void* h, int i, const int32_t* actions, const uint8_t* msgs) {

@@ -105,6 +105,13 @@ class OracleVecEnv:
         for i in range(self.num_envs):
             self.lib.cc4o_set_seed(self._h, i, ctypes.c_uint64(int(seeds[i])), self.rng_mode)
 
+    def set_generators(self, generators):
+        from cage_challenge_4_amd.vec_env import pcg64_words
+        self.lib.cc4o_set_rng_state.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]
+        for i, g in enumerate(generators):
+            w = np.array(pcg64_words(g), np.uint64)
+            self.lib.cc4o_set_rng_state(self._h, i, w.ctypes.data_as(ctypes.c_void_p))
+
     @property
     def action_mask(self):
         return self.mask()

@@ -85,6 +85,19 @@ def _other_surface(vec_factory):
     with pytest.raises(ValueError):
         for _ in range(20):
             env.parallel_step({})                              # State.py:539-540: stepping past the last mission phase
+    # CybORG(seed=<numpy Generator>) (env.py:73-76): a PCG64 generator is adopted and gives the episode of its int seed
+    mk = lambda seed: BlueFlatWrapper(CybORG(EnterpriseScenarioGenerator(blue_agent_class=SleepAgent, green_agent_class=EnterpriseGreenAgent,   # noqa: E731
+                                                                         red_agent_class=FiniteStateRedAgent, steps=40), seed=seed, vec_factory=vec_factory))
+    ga, gb = mk(np.random.Generator(np.random.PCG64(np.random.SeedSequence(123)))), mk(123)
+    oa, ob = ga.reset()[0], gb.reset()[0]
+    assert all(np.array_equal(oa[k], ob[k]) for k in oa)
+    for _ in range(25):
+        ra, rb = ga.step({}), gb.step({})
+        assert all(np.array_equal(ra[0][k], rb[0][k]) for k in ra[0]) and ra[1] == rb[1]
+    with pytest.raises(NotImplementedError):
+        mk(np.random.Generator(np.random.MT19937(5)))
+    with pytest.raises(NotImplementedError):
+        mk(object())
     # wrapper: action objects and negative indices behave like the reference's list indexing (BlueFixedActionWrapper.py:142-148)
     w = BlueFlatWrapper(CybORG(EnterpriseScenarioGenerator(blue_agent_class=SleepAgent, green_agent_class=SleepAgent,
                                                            red_agent_class=SleepAgent, steps=6), seed=3, vec_factory=vec_factory))
