@@ -255,7 +255,8 @@ __global__ __launch_bounds__(PT, MINW) void k_step_philox(StepArgs a) {
   __shared__ uint8_t obs_bytes[OBS_TOTAL + 2];   // byte-per-value copy of the observations, only for the packed exchange row
   __shared__ uint8_t glist[2][2][MAXG];  // green agents by action type (0 AccessService, 1 LocalWork) and drawing wave
   __shared__ unsigned long long prof_lds[16];
-  const int e = blockIdx.x, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int e = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform by construction: kept in an SGPR
   if (e >= a.n) return;
   unsigned long long t_begin = a.prof ? clock64() : 0;
   const uint4* src = reinterpret_cast<const uint4*>(a.st + e);
@@ -330,8 +331,12 @@ __global__ __launch_bounds__(PT, MINW) void k_step_philox(StepArgs a) {
       EvLog* const lg = LOG ? &a.cold[e].evlog : nullptr;
       Ctx x0{s, a.cold + e, &rl, hd, &work, tid == 0 ? prof : nullptr};         // thread 0
       x0.lg = lg;
-      const int ragent = lane * PW + wave;                                        // lanes 0..(6/PW-1) of each wave own a red agent
-      const bool is_red = lane < (NRED + PW - 1) / PW && ragent < NRED;
+#ifndef CC4_RED_WAVES
+#define CC4_RED_WAVES 2
+#endif
+      constexpr int RW = CC4_RED_WAVES;                                           // red agent r on wave r % RW, lane r / RW
+      const int ragent = lane * RW + wave;
+      const bool is_red = wave < RW && lane < (NRED + RW - 1) / RW && ragent < NRED;
       unsigned long long* ap = (a.prof && is_red) ? a.prof + PROF_SLOTS * (size_t)e + 16 + 8 * ragent : nullptr;
       Ctx xr{s, a.cold + e, &rl, hd, &work, nullptr, ap, lg};
       // ---- P0-P3a: every agent's policy / submission followed by its own duration-queue tick (SC:236-265), all on the
@@ -383,8 +388,12 @@ __global__ __launch_bounds__(PT, MINW) void k_step_philox(StepArgs a) {
       // ---- P3b blue execution
       if (blue_exec_independent(s)) {      // uniform: every thread reads the same five action types
         if (tid == 0) CC4_TICK(x0, 3);
-        const int bagent = lane * PW + wave;                                      // blue agent b on wave b % PW, lane b / PW
-        if (lane < (NBLUE + PW - 1) / PW && bagent < NBLUE) { Ctx xb{s, a.cold + e, &rl, hd, &work, nullptr, nullptr, lg}; step_blue_exec_agent(xb, bagent); }
+#ifndef CC4_BLUE_WAVES
+#define CC4_BLUE_WAVES PW
+#endif
+        constexpr int BW = CC4_BLUE_WAVES;
+        const int bagent = lane * BW + wave;                                      // blue agent b on wave b % BW, lane b / BW
+        if (wave < BW && lane < (NBLUE + BW - 1) / BW && bagent < NBLUE) { Ctx xb{s, a.cold + e, &rl, hd, &work, nullptr, nullptr, lg}; step_blue_exec_agent(xb, bagent); }
         __syncthreads();
         if (tid == 0) CC4_TICK(x0, 5);
       } else {
