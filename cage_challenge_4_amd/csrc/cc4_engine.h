@@ -12,8 +12,10 @@ namespace cc4 {
 // s: the episode's row (the device kernels pass their LDS copy); hd: its host table -- &s->hd[0] when the whole row is staged,
 // the HBM row's table when only the part in front of it is (numpy-stream kernel); w: the step's work area;
 // lg: the episode's event log when it is enabled (the callers know that without a memory read)
+// gpre: per green agent, what its action needs from the state (green_prepare), computed ahead by other lanes; null: computed
+// where it is needed
 struct Ctx { EnvState* s; EnvCold* c; Rng* r; HostDyn* hd; StepWork* w; unsigned long long* prof = nullptr;
-             unsigned long long* aprof = nullptr; EvLog* lg = nullptr; };
+             unsigned long long* aprof = nullptr; EvLog* lg = nullptr; const uint64_t* gpre = nullptr; };
 
 // optional phase timing (device only, debug builds of the kernel pass a buffer): prof[i] += cycles since last tick
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -1244,44 +1246,54 @@ CC4_HD void phishing(Ctx x, int gh) {
   if (!add_proc(x, gh, pid, K_SESS_RED, 0)) return;
   rs_add(x, src, gh, pid, RS_ABSTRACT);
 }
-// GreenLocalWork.execute (GreenActions/GreenLocalWork.py:60-125). returns success
-CC4_HD bool green_local_work(Ctx x, int gh, bool* want_phish) {
-  const HostDyn& d = x.hd[gh];
-  // the whole service table in one batch of independent loads (each Svc is one little-endian word: pid | kind << 16 | st << 24);
-  // everything after that works on registers with constant indices
-  uint32_t sv[MAXSV];
-  __builtin_memcpy(sv, d.svcs, sizeof(sv));
-  const int nsvc = hd_nsvc(d);
+// What a green agent's action reads from the state, as one 8-byte word that can be computed ahead of the (ordered) resolution
+// by any lane -- the numpy-stream kernel does that for all agents at once while its walking lane would otherwise do it agent by
+// agent between draws.  Nothing a green action writes (event bits, rewards, phishing sessions) feeds into these words.
+//   GreenLocalWork:     byte i = status byte of service i of the agent's host (active bit | reliability/20), 0 beyond the table
+//   GreenAccessService: byte sn = number of servers in the allowed subnets 0..sn (running total; byte 7 = all candidates)
+CC4_HD uint64_t green_prepare(Ctx x, int g, int act) {
+  EnvState* s = x.s;
+  const int gh = s->green_host[g];
+  uint64_t w = 0;
+  if (act == 1) {
+    const HostDyn& d = x.hd[gh];
+    uint32_t sv[MAXSV];
+    __builtin_memcpy(sv, d.svcs, sizeof(sv));
+    const int nsvc = hd_nsvc(d);
+    CC4_UNROLL for (int i = 0; i < MAXSV; ++i) if (i < nsvc) w |= (uint64_t)(sv[i] >> 24) << (8 * i);
+  } else if (act == 0) {
+    const uint32_t allowed = green_allowed_mask(s->phase, h_subnet(gh));
+    uint64_t ns;   // server counts of subnets 0..7 (the internet subnet has none), one batch of loads
+    __builtin_memcpy(&ns, s->n_servers, 8);
+    int n = 0;
+    CC4_UNROLL for (int sn = 0; sn < NSUB - 1; ++sn) { if ((allowed >> sn) & 1u) n += (int)((ns >> (8 * sn)) & 0xFF); w |= (uint64_t)n << (8 * sn); }
+  }
+  return w;
+}
+// GreenLocalWork.execute (GreenActions/GreenLocalWork.py:60-125). returns success.  pre: green_prepare's word
+CC4_HD bool green_local_work(Ctx x, int gh, uint64_t pre, bool* want_phish) {
   uint32_t act = 0;
-  CC4_UNROLL for (int i = 0; i < MAXSV; ++i) if (i < nsvc && ((sv[i] >> 24) & SV_ACTIVE)) act |= 1u << i;
+  CC4_UNROLL for (int i = 0; i < MAXSV; ++i) if ((pre >> (8 * i)) & SV_ACTIVE) act |= 1u << i;
   if (!act) return false;
   const int c = nth_bit(act, (int)rng_below(x.r, (uint32_t)popc32(act)));   // choice over the active services, table order
-  uint32_t st = 0;
-  CC4_UNROLL for (int i = 0; i < MAXSV; ++i) if (i == c) st = sv[i] >> 24;
+  const uint32_t st = (uint32_t)(pre >> (8 * c)) & 0xFF;
   int rel = (int)(st & 0x7F) * 20;
   if ((int)rng_below(x.r, 100) >= rel) return false;
   if (rng_random(x.r) < 0.01) { int port = eph_port(x, gh); ev_proc(x, gh, 0); ev_log(x, gh, gh, 1, gh, port, 0xFF, 0, 0); }   // pc = {local_address, local_port} (GreenLocalWork.py:112-115)
   if (rng_random(x.r) < 0.01) *want_phish = true;  // PhishingEmail sub-action: executed by the caller (ordering, see P5)
   return true;
 }
-// GreenAccessService.execute (GreenActions/GreenAccessService.py:137-217). returns success
-CC4_HD bool green_access_service(Ctx x, int gh) {
-  EnvState* s = x.s;
+// GreenAccessService.execute (GreenActions/GreenAccessService.py:137-217). returns success.  pre: green_prepare's word
+CC4_HD bool green_access_service(Ctx x, int gh, uint64_t pre) {
   int own = h_subnet(gh);
-  uint32_t allowed = green_allowed_mask(s->phase, own);
-  uint64_t ns;   // server counts of subnets 0..7 (the internet subnet has none), one batch of loads
-  __builtin_memcpy(&ns, s->n_servers, 8);
-  int n = 0;
-  CC4_UNROLL for (int sn = 0; sn < NSUB - 1; ++sn) if ((allowed >> sn) & 1u) n += (int)((ns >> (8 * sn)) & 0xFF);
-  int c = (int)rng_below(x.r, (uint32_t)n);
-  int dest = -1;
-  for (int sn = 0; sn < NSUB - 1; ++sn) {
-    if (dest >= 0 || !((allowed >> sn) & 1u)) continue;
-    int cnt = (int)((ns >> (8 * sn)) & 0xFF);
-    if (c < cnt) dest = h_make(sn, 11 + c); else c -= cnt;
-  }
+  const int n = (int)(pre >> 56);
+  const int c = (int)rng_below(x.r, (uint32_t)n);
+  // the c-th server over the allowed subnets in subnet order: the first subnet whose running total exceeds c
+  int sn = 0, before = 0;
+  CC4_UNROLL for (int k = 0; k < NSUB - 2; ++k) { const int tot = (int)((pre >> (8 * k)) & 0xFF); if (tot <= c) { sn = k + 1; before = tot; } }
+  const int dest = h_make(sn, 11 + (c - before));
   const int dest_port = eph_port(x, dest);
-  int ds = h_subnet(dest);
+  int ds = sn;
   // events land on the destination server (`from_host` in the reference, GreenAccessService.py:176-214)
   if (subnet_blocked(x, ds, own) || subnet_blocked(x, own, ds)) { ev_conn(x, dest); ev_log(x, gh, dest, 0, dest, 0, gh, 8800, 0); return false; }
   if (rng_random(x.r) < 0.01) { ev_conn(x, dest); ev_log(x, gh, dest, 0, gh, 0, dest, dest_port, 0); }
@@ -2169,10 +2181,12 @@ CC4_HD int step_green_exec(Ctx x, int g, const uint32_t* pre = nullptr) {
   rng_set_stream(x.r, ST_GREEN_EXE + (uint32_t)g);
   if (pre) rng_preload(x.r, pre);
   const int act = x.w->green_act[g];
-  if (act == 0) return green_access_service(x, gh) ? 0 : reward_table(s->phase, own, RW_ASF);
+  if (act >= 2) return 0;
+  const uint64_t gp = x.gpre ? x.gpre[g] : green_prepare(x, g, act);
+  if (act == 0) return green_access_service(x, gh, gp) ? 0 : reward_table(s->phase, own, RW_ASF);
   if (act == 1) {
     bool want_phish = false;
-    bool ok = green_local_work(x, gh, &want_phish);
+    bool ok = green_local_work(x, gh, gp, &want_phish);
     if (want_phish) bit_set_shared(x.w->phish_mask, g);   // green agents may be resolved on different lanes
     return ok ? 0 : reward_table(s->phase, own, RW_LWF);
   }

@@ -106,6 +106,7 @@ __global__ __launch_bounds__(WAVE) void k_step(StepArgs a) {
   __shared__ uint8_t obs_lds[OBS_TOTAL + 2];
   __shared__ int ok_lds;
   __shared__ StepWork work;
+  __shared__ uint64_t gpre_lds[MAXG];
   const int e = blockIdx.x, lane = threadIdx.x;
   if (e >= a.n) return;
   unsigned long long t_begin = a.prof ? clock64() : 0;
@@ -150,14 +151,24 @@ __global__ __launch_bounds__(WAVE) void k_step(StepArgs a) {
         CC4_TICK(x, 2);
         for (int b = 0; b < NBLUE; ++b) step_tick_blue(x, b);
         step_blue_exec(x);
-        for (int g = 0; g < s->n_green; ++g) {
-          s->brm += step_green_exec(x, g);
-          if (bit_get(work.phish_mask, g)) { bit_clr(work.phish_mask, g); phishing(x, s->green_host[g]); }
-        }
-        CC4_TICK(x, 6);
-        step_red_exec(x);
-        step_reassign(x, red_foreign_agents(s));
       }
+    }
+  }
+  __syncthreads();
+  if (ok_lds) {
+    // what the green actions read from the state (service tables of their hosts -- HBM here --, allowed server counts), for all
+    // agents at once on the idle lanes: the walking lane then only draws and applies (green_prepare)
+    for (int g = lane; g < s->n_green; g += WAVE) { const int act = work.green_act[g]; if (act < 2) gpre_lds[g] = green_prepare(x, g, act); }
+    __syncthreads();
+    if (lane == 0) {
+      Ctx xg = x; xg.gpre = gpre_lds;
+      for (int g = 0; g < s->n_green; ++g) {
+        s->brm += step_green_exec(xg, g);
+        if (bit_get(work.phish_mask, g)) { bit_clr(work.phish_mask, g); phishing(x, s->green_host[g]); }
+      }
+      CC4_TICK(x, 6);
+      step_red_exec(x);
+      step_reassign(x, red_foreign_agents(s));
     }
   }
   __syncthreads();
