@@ -2143,13 +2143,16 @@ CC4_HD int step_red_policy_tick(Ctx x, int r) {
   A.h = H;
   return dropped;
 }
-CC4_HD void step_blue_exec(Ctx x) {
+// shuffle_done: the caller has already consumed the shuffle's draws (the numpy-stream kernel does that across the wave)
+CC4_HD void step_blue_exec(Ctx x, bool shuffle_done = false) {
   EnvState* s = x.s;
-  CC4_TICK(x, 3);
-  // ---- sort_action_order (SC:398-464): the shuffle only consumes the shared numpy stream; the Philox streams are
-  // per agent, so there is nothing to consume there
-  if (x.r->mode == 0) rng_shuffle_consume(x.r, s->n_actions);
-  CC4_TICK(x, 4);
+  if (!shuffle_done) {
+    CC4_TICK(x, 3);
+    // ---- sort_action_order (SC:398-464): the shuffle only consumes the shared numpy stream; the Philox streams are
+    // per agent, so there is nothing to consume there
+    if (x.r->mode == 0) rng_shuffle_consume(x.r, s->n_actions);
+    CC4_TICK(x, 4);
+  }
   // ---- execute: priority 1 (ControlTraffic) first, then agent order
   for (int b = 0; b < NBLUE; ++b) if (s->bexec[b].type == BA_BLOCK || s->bexec[b].type == BA_ALLOW) blue_execute(x, b, s->bexec[b]);
   for (int b = 0; b < NBLUE; ++b)

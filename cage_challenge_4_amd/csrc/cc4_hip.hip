@@ -98,6 +98,101 @@ __device__ __forceinline__ uint8_t pack_obs_byte(const uint8_t* vals, int j) {
   return (uint8_t)b;
 }
 
+// ---------------------------------------------------------------- numpy stream: the two draw-only phases across the wave
+// PCG64 is a 128-bit LCG, so the state k steps ahead is A_k * state + B_k * increment (A_k = M^k, B_k = 1 + M + .. + M^(k-1),
+// mod 2^128; table filled by cc4_create).  Two phases of a step only CONSUME the stream -- the green agents' policy draws
+// (one bounded draw each) and the action-order shuffle (SimulationController.py:418: ~90 masked-rejection draws whose results
+// are never used) -- so lane j computes output j+1 directly and the consumption is replayed on the 128 ready words with a
+// few wave-wide compares per draw instead of a 128-bit multiply per draw on the walking lane.  Bit-exact with the serial
+// walk (rng_below / rng_interval in cc4_rng.h), including has_uint32 / uinteger buffering and the advance counter.
+struct PcgJump { uint64_t a_hi, a_lo, b_hi, b_lo; };
+__device__ PcgJump g_pcg_jump[WAVE + 1];          // [k]: k = 0 .. 64 steps ahead
+__device__ __forceinline__ uint64_t bcast64(uint64_t v) {
+  return (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)v) | ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(v >> 32)) << 32);
+}
+__device__ __forceinline__ uint64_t lane64(uint64_t v, int src) {
+  return (uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)v, src) | ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(v >> 32), src) << 32);
+}
+__device__ __forceinline__ void pcg_ahead(const PcgJump& J, uint64_t s_hi, uint64_t s_lo, uint64_t i_hi, uint64_t i_lo, uint64_t* o_hi, uint64_t* o_lo) {
+  // (a * s + b * inc) mod 2^128
+  const uint64_t p_lo = J.a_lo * s_lo, p_hi = __umul64hi(J.a_lo, s_lo) + J.a_hi * s_lo + J.a_lo * s_hi;
+  const uint64_t q_lo = J.b_lo * i_lo, q_hi = __umul64hi(J.b_lo, i_lo) + J.b_hi * i_lo + J.b_lo * i_hi;
+  const uint64_t lo = p_lo + q_lo;
+  *o_lo = lo; *o_hi = p_hi + q_hi + (lo < p_lo ? 1ull : 0ull);
+}
+__device__ __forceinline__ uint64_t pcg_output(uint64_t hi, uint64_t lo) {   // XSL-RR 128/64
+  const uint64_t v = hi ^ lo; const uint32_t rot = (uint32_t)(hi >> 58);
+  return (v >> rot) | (v << ((64u - rot) & 63u));
+}
+// Green policy draws of one step (EnterpriseGreenAgent.get_action: choice of 3 per agent, agent order), all lanes.  `rl` is the
+// walking lane's generator (valid on lane 0, updated there).  Returns false without touching anything when a draw would need
+// Lemire's re-draw (a zero word: 2^-32 per agent) -- the caller then walks the phase serially.
+__device__ __forceinline__ bool wave_green_policy(Rng& rl, int n, uint8_t* green_act, int lane) {
+  const uint64_t s_hi = bcast64(rl.s_hi), s_lo = bcast64(rl.s_lo), i_hi = bcast64(rl.inc_hi), i_lo = bcast64(rl.inc_lo);
+  const uint32_t has32 = (uint32_t)__builtin_amdgcn_readfirstlane((int)rl.has32), u32 = (uint32_t)__builtin_amdgcn_readfirstlane((int)rl.u32);
+  uint64_t h, l;
+  pcg_ahead(g_pcg_jump[lane + 1], s_hi, s_lo, i_hi, i_lo, &h, &l);
+  const uint64_t out = pcg_output(h, l);
+  const uint32_t w0 = (uint32_t)out, w1 = (uint32_t)(out >> 32);
+  const int base = (int)has32;                       // agent 0 takes the buffered half word when there is one
+  const int g0 = base + 2 * lane, g1 = g0 + 1;
+  bool zero = (g0 < n && w0 == 0) || (g1 < n && w1 == 0) || (has32 && u32 == 0);
+  if (__ballot(zero)) return false;
+  // Lemire, range 3: (word * 3) >> 32 (the leftover test can only fail for word == 0)
+  if (g0 < n) green_act[g0] = (uint8_t)(((uint64_t)w0 * 3u) >> 32);
+  if (g1 < n) green_act[g1] = (uint8_t)(((uint64_t)w1 * 3u) >> 32);
+  if (has32 && lane == 0) green_act[0] = (uint8_t)(((uint64_t)u32 * 3u) >> 32);
+  const int fresh = n - base;                        // words taken from new outputs
+  const int K = (fresh + 1) >> 1;                    // outputs consumed
+  if (K > 0) {
+    const uint64_t nh = lane64(h, K - 1), nl = lane64(l, K - 1);
+    const uint32_t nu = (uint32_t)__builtin_amdgcn_readlane((int)w1, K - 1);
+    if (lane == 0) { rl.s_hi = nh; rl.s_lo = nl; rl.u32 = nu; rl.has32 = (uint32_t)(fresh & 1); rl.ndraw += (uint32_t)K; }
+  } else if (lane == 0) rl.has32 = 0;
+  return true;
+}
+// Generator.shuffle of an n-item list, consumption only (rng_shuffle_consume): for i = n-1 .. 1 one masked-rejection draw
+// (random_interval).  All lanes; `rl` as above.
+__device__ __forceinline__ void wave_shuffle_consume(Rng& rl, int n, int lane) {
+  if (n <= 1) return;
+  uint64_t s_hi = bcast64(rl.s_hi), s_lo = bcast64(rl.s_lo);
+  const uint64_t i_hi = bcast64(rl.inc_hi), i_lo = bcast64(rl.inc_lo);
+  uint32_t has32 = (uint32_t)__builtin_amdgcn_readfirstlane((int)rl.has32), u32 = (uint32_t)__builtin_amdgcn_readfirstlane((int)rl.u32);
+  uint32_t adv = 0;
+  int i = n - 1;
+  auto mask_of = [](uint32_t m) { m |= m >> 1; m |= m >> 2; m |= m >> 4; m |= m >> 8; m |= m >> 16; return m; };
+  if (has32) {                                       // the buffered half word is the first candidate
+    has32 = 0;
+    if ((u32 & mask_of((uint32_t)i)) <= (uint32_t)i) --i;
+  }
+  while (i >= 1) {
+    // a window of 64 outputs = 128 words: word p = half (p & 1) of output (p >> 1) + 1
+    uint64_t h, l;
+    pcg_ahead(g_pcg_jump[lane + 1], s_hi, s_lo, i_hi, i_lo, &h, &l);
+    const uint64_t out = pcg_output(h, l);
+    const uint32_t w0 = (uint32_t)out, w1 = (uint32_t)(out >> 32);
+    int cur = 0;                                     // first unconsumed word of the window
+    while (i >= 1 && cur < 2 * WAVE) {
+      const uint32_t m = mask_of((uint32_t)i);
+      const unsigned long long a0 = __ballot((w0 & m) <= (uint32_t)i), a1 = __ballot((w1 & m) <= (uint32_t)i);
+      const int j0 = (cur + 1) >> 1, j1 = cur >> 1;  // first lane whose low / high word is still unconsumed
+      const unsigned long long m0 = j0 >= WAVE ? 0ull : (a0 & (~0ull << j0)), m1 = j1 >= WAVE ? 0ull : (a1 & (~0ull << j1));
+      const int p0 = m0 ? 2 * (__ffsll((long long)m0) - 1) : 4 * WAVE, p1 = m1 ? 2 * (__ffsll((long long)m1) - 1) + 1 : 4 * WAVE;
+      const int p = p0 < p1 ? p0 : p1;
+      if (p >= 2 * WAVE) { cur = 2 * WAVE; break; }  // every remaining word of the window is rejected for this i
+      cur = p + 1; --i;
+    }
+    const int K = (cur + 1) >> 1;                    // outputs of this window that were touched
+    if (K > 0) {
+      s_hi = lane64(h, K - 1); s_lo = lane64(l, K - 1);
+      u32 = (uint32_t)__builtin_amdgcn_readlane((int)w1, K - 1);
+      has32 = (uint32_t)(cur & 1);
+      adv += (uint32_t)K;
+    }
+  }
+  if (lane == 0) { rl.s_hi = s_hi; rl.s_lo = s_lo; rl.has32 = has32; rl.u32 = u32; rl.ndraw += adv; }
+}
+
 template <bool LOG>
 __global__ __launch_bounds__(WAVE) void k_step(StepArgs a) {
   // numpy-PCG64 mode: one shared stream => the agent walk is strictly serial (lane 0); only the RNG-free parts
@@ -128,6 +223,8 @@ __global__ __launch_bounds__(WAVE) void k_step(StepArgs a) {
   x.lg = LOG ? &a.cold[e].evlog : nullptr;
   if (prof && lane == 0) prof[11] += clock64() - t_begin;
   const bool do_reset = a.autoreset && s->done;
+  // The ordered walk is lane 0's; between its stretches the whole wave does what needs no order: the two draw-only phases
+  // (green policy draws, action-order shuffle) straight from the LCG's closed form, and the green actions' state reads.
   if (lane == 0) {
     ok_lds = 0;
     if (do_reset) {
@@ -144,15 +241,25 @@ __global__ __launch_bounds__(WAVE) void k_step(StepArgs a) {
         ok_lds = 1;
         CC4_TICK(x, 0);
         rng_policy_swap(x, false);     // CybORG.set_seed split: the policies draw from the old stream (EnvState.rng2)
-        for (int g = 0; g < s->n_green; ++g) step_green_policy(x, g);
-        CC4_TICK(x, 1);
-        for (int r = 0; r < NRED; ++r) s->n_actions -= step_red_policy_tick(x, r);
-        rng_policy_swap(x, true);
-        CC4_TICK(x, 2);
-        for (int b = 0; b < NBLUE; ++b) step_tick_blue(x, b);
-        step_blue_exec(x);
       }
     }
+  }
+  __syncthreads();
+  if (ok_lds) {
+    bool drawn = false;
+    if (!(s->policy & GP_SLEEP_BIT)) drawn = wave_green_policy(rl, s->n_green, work.green_act, lane);
+    if (lane == 0) {
+      if (!drawn) for (int g = 0; g < s->n_green; ++g) step_green_policy(x, g);   // SleepAgent greens, or the 2^-32 re-draw case
+      CC4_TICK(x, 1);
+      for (int r = 0; r < NRED; ++r) s->n_actions -= step_red_policy_tick(x, r);
+      rng_policy_swap(x, true);
+      CC4_TICK(x, 2);
+      for (int b = 0; b < NBLUE; ++b) step_tick_blue(x, b);
+      CC4_TICK(x, 3);
+    }
+    __syncthreads();
+    wave_shuffle_consume(rl, s->n_actions, lane);   // sort_action_order's shuffle (SC:398-464) only consumes the stream
+    if (lane == 0) { CC4_TICK(x, 4); step_blue_exec(x, true); }
   }
   __syncthreads();
   if (ok_lds) {
@@ -708,6 +815,16 @@ int cc4_create(const cc4_config* cfg, cc4_handle** out) {
   h->cfg = *cfg;
   *out = h;
   HIPCHK(h, hipSetDevice(cfg->device_id));
+  {   // PCG64 jump table of the numpy-stream kernel (see wave_green_policy): A_k = M^k, B_k = 1 + M + .. + M^(k-1) mod 2^128
+    PcgJump tab[WAVE + 1];
+    const unsigned __int128 M = ((unsigned __int128)CC4_PCG_MULT_HI << 64) | CC4_PCG_MULT_LO;
+    unsigned __int128 A = 1, B = 0;
+    for (int k = 0; k <= WAVE; ++k) {
+      tab[k].a_hi = (uint64_t)(A >> 64); tab[k].a_lo = (uint64_t)A; tab[k].b_hi = (uint64_t)(B >> 64); tab[k].b_lo = (uint64_t)B;
+      B = B * M + 1; A = A * M;
+    }
+    HIPCHK(h, hipMemcpyToSymbol(HIP_SYMBOL(g_pcg_jump), tab, sizeof(tab)));
+  }
   {
     hipDeviceProp_t prop;
     HIPCHK(h, hipGetDeviceProperties(&prop, cfg->device_id));
