@@ -1843,11 +1843,12 @@ CC4_HD int fsm_choose_host_discovery(Ctx x, int r, RedHdr& H) {
   return A.fsm_order[0];
 }
 // get_action (:58-122) incl. _choose_host (:252-293) and _choose_host_and_action (:296-336)
-CC4_HD Act fsm_get_action(Ctx x, int r, RedHdr& H) {
+// observed: fsm_observe (which draws nothing) has already run for this step (step_red_observe)
+CC4_HD Act fsm_get_action(Ctx x, int r, RedHdr& H, bool observed = false) {
   EnvState* s = x.s;
   RedAgent& A = s->red[r];
   Act out; out.type = RA_SLEEP; out.host = 0; out.arg = 0; out.ticks = 1; out.sid = 0; out.busy = 0;
-  fsm_observe(x, r, H);
+  if (!observed) fsm_observe(x, r, H);
   if (H.obs_success == T_IN_PROGRESS) { H.fsm_step++; return out; }
   int n = H.fsm_n;  // fsm_order holds exactly the non-'F' hosts, in host_states insertion order
   if (n == 0) { set_err(x, E_FSM_NO_HOST); H.fsm_step++; return out; }
@@ -2116,14 +2117,31 @@ CC4_HD void step_green_policy(Ctx x, int g) {
 // touches only its agent: queue, observation reset, filter_actions against its own session table).  The agent's scalar fields
 // (RedHdr) are read once into registers, worked on there and written back once.  Returns 1 if the agent's action was dropped
 // by filter_actions (SC:466-485: it names a dead session).
-CC4_HD int step_red_policy_tick(Ctx x, int r) {
+// The observation half of an FSM agent's policy on its own (no draws, only the agent's own tables): the numpy-stream kernel
+// runs it for the six agents side by side before its walking lane draws their choices in order.
+CC4_HD void step_red_observe(Ctx x, int r) {
+  EnvState* s = x.s;
+  RedAgent& A = s->red[r];
+  const int pol = s->policy & 3;
+  if (!A.h.active || pol == RP_RANDOM || pol == RP_SLEEP) return;
+  RedHdr H = A.h;
+  fsm_observe(x, r, H);
+  A.h = H;
+}
+// True if agent r's end-of-turn RedSessionCheck will draw (it promotes a session to primary: no session holds ident 0)
+CC4_HD bool rsc_draws(const EnvState* s, int r) {
+  const RedAgent& A = s->red[r];
+  if (!A.h.active || A.h.nsess == 0) return false;
+  return rsw_id(rs_at(s, A, 0)) != 0 && rsw_id(rs_at(s, A, A.h.nsess - 1)) != 0 && rs_find_id(s, A, 0) < 0;
+}
+CC4_HD int step_red_policy_tick(Ctx x, int r, bool observed = false) {
   EnvState* s = x.s;
   RedAgent& A = s->red[r];
   RedHdr H = A.h;
   Act a; a.type = RA_SLEEP; a.host = 0; a.arg = 0; a.ticks = 1; a.sid = 0; a.busy = 0;
   rng_set_stream(x.r, ST_RED_POL + (uint32_t)r);
   if (H.active && (s->policy & 3) == RP_RANDOM) { a = random_red_get_action(x, r, H); red_validate(x, r, H, a); }
-  else if (H.active && (s->policy & 3) != RP_SLEEP) { a = fsm_get_action(x, r, H); CC4_AT0(x); red_validate(x, r, H, a); CC4_AT(x, 7); }   // AgentInterface.get_action (:120-143); SleepAgent -> Sleep
+  else if (H.active && (s->policy & 3) != RP_SLEEP) { a = fsm_get_action(x, r, H, observed); CC4_AT0(x); red_validate(x, r, H, a); CC4_AT(x, 7); }   // AgentInterface.get_action (:120-143); SleepAgent -> Sleep
   if (!H.queue.busy) { H.queue = a; H.queue.busy = 1; }
   // ---- tick: a new step's observation starts empty
   H.nobs = 0; H.obs_success = 0; H.obs_act_type = RA_NONE; H.new_sess_host = 0xFF; H.rsc_listed = 0;

@@ -225,33 +225,37 @@ __global__ __launch_bounds__(WAVE) void k_step(StepArgs a) {
   const bool do_reset = a.autoreset && s->done;
   // The ordered walk is lane 0's; between its stretches the whole wave does what needs no order: the two draw-only phases
   // (green policy draws, action-order shuffle) straight from the LCG's closed form, and the green actions' state reads.
+  // every lane evaluates the mission-phase check (four words of the row); the accumulators of the step were left initialised by
+  // step_end / the reset, so the blue submissions (lanes 1..5: in-kernel action draw, decode, queue) run beside lane 0's step_phase
+  const bool step_ok = !do_reset && step_phase_of(s->step_count, s->phase_len[0], s->phase_len[1], s->phase_len[2]) >= 0;
   if (lane == 0) {
-    ok_lds = 0;
+    ok_lds = step_ok ? 1 : 0;
     if (do_reset) {
       env_reset(x, 0, 0, a.steps, true, a.policy, a.topo);   // new episode, same stream (CybORG.reset(seed=None)); this kernel serves the numpy-stream mode only
     } else {
       CC4_TICK0(x);
-      int32_t racts[NBLUE];
-      const int32_t* acts = a.actions ? a.actions + e * NBLUE : nullptr;
-      if (a.rand_out) {
-        for (int b = 0; b < NBLUE; ++b) { racts[b] = random_blue_action(a.rand_seed0, a.rand_t, e, b); a.rand_out[e * NBLUE + b] = racts[b]; }
-        acts = racts;
-      }
-      if (step_begin(x, acts)) {
-        ok_lds = 1;
-        CC4_TICK(x, 0);
-        rng_policy_swap(x, false);     // CybORG.set_seed split: the policies draw from the old stream (EnvState.rng2)
-      }
+      (void)step_phase(x, false);    // sets E_STEP_PAST_END when !step_ok
+      CC4_TICK(x, 0);
+      if (step_ok) rng_policy_swap(x, false);     // CybORG.set_seed split: the policies draw from the old stream (EnvState.rng2)
     }
+  } else if (step_ok && lane <= NBLUE) {
+    const int b = lane - 1;
+    int32_t act = a.actions ? a.actions[e * NBLUE + b] : -1;
+    if (a.rand_out) { act = random_blue_action(a.rand_seed0, a.rand_t, e, b); a.rand_out[e * NBLUE + b] = act; }
+    Ctx xb{s, a.cold + e, &rl, hd, &work};
+    step_blue_submit(xb, b, act);
   }
   __syncthreads();
   if (ok_lds) {
     bool drawn = false;
     if (!(s->policy & GP_SLEEP_BIT)) drawn = wave_green_policy(rl, s->n_green, work.green_act, lane);
+    // the observation half of the six red policies draws nothing and touches only its own agent: side by side on six lanes
+    if (lane < NRED) { Ctx xo{s, a.cold + e, &rl, hd, &work}; step_red_observe(xo, lane); }
+    __syncthreads();
     if (lane == 0) {
       if (!drawn) for (int g = 0; g < s->n_green; ++g) step_green_policy(x, g);   // SleepAgent greens, or the 2^-32 re-draw case
       CC4_TICK(x, 1);
-      for (int r = 0; r < NRED; ++r) s->n_actions -= step_red_policy_tick(x, r);
+      for (int r = 0; r < NRED; ++r) s->n_actions -= step_red_policy_tick(x, r, (s->policy & 3) != RP_RANDOM);
       rng_policy_swap(x, true);
       CC4_TICK(x, 2);
       for (int b = 0; b < NBLUE; ++b) step_tick_blue(x, b);
@@ -283,17 +287,25 @@ __global__ __launch_bounds__(WAVE) void k_step(StepArgs a) {
     for (int h = lane; h < MAXH; h += WAVE) step_monitor_host(x, h);
     if (lane == 0) step_monitor_pend(x);
     __syncthreads();
-    if (lane == 0) {
-      CC4_TICK(x, 9);
-      for (int r = 0; r < NRED; ++r) step_rsc(x, r);
-      CC4_TICK(x, 10);
-      step_end(x, a.msgs ? a.msgs + e * NBLUE * MSG_LEN : nullptr);
+    {
+      // end-turn RedSessionCheck: it draws only when it has to promote a session to primary; when no agent needs that (the
+      // usual case) the six checks run side by side, else in order on the walking lane
+      const bool need = lane < NRED && rsc_draws(s, lane);
+      const bool serial = __ballot(need) != 0ull;
+      if (!serial && lane < NRED) { Ctx xc{s, a.cold + e, &rl, hd, &work, nullptr, nullptr, x.lg}; step_rsc(xc, lane); }
+      if (lane == 0) CC4_TICK(x, 9);
+      __syncthreads();
+      if (lane == 0) {
+        if (serial) for (int r = 0; r < NRED; ++r) step_rsc(x, r);
+        CC4_TICK(x, 10);
+        step_end(x, a.msgs ? a.msgs + e * NBLUE * MSG_LEN : nullptr);
+      }
     }
     __syncthreads();
   }
   if (lane == 0) { s->rng = rl; a.reward[e] = s->reward; a.done[e] = s->done; a.err[e] = s->err; }
   unsigned long long t_obs = a.prof ? clock64() : 0;
-  if (lane < OBS_PARTS) env_flat_obs_part<uint8_t>(s, hd, obs_lds, lane);   // 12 independent pieces of the flat observation
+  for (int v = lane; v < OBS_TOTAL; v += WAVE) { int i; const int val = env_flat_obs_sorted(s, hd, v, &i); obs_lds[i] = (uint8_t)val; }   // kind-sorted: uniform branches
   __syncthreads();
   unsigned long long t_out = a.prof ? clock64() : 0;
   if (prof && lane == 0) prof[12] += t_out - t_obs;
