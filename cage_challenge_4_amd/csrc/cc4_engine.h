@@ -2284,13 +2284,16 @@ CC4_HD void step_reassign(Ctx x, uint32_t foreign) {   // foreign = red_foreign_
   }
   CC4_TICK(x, 8);
 }
-CC4_HD void step_monitor_host(Ctx x, int h) {  // the per-host part of Monitor.execute
+CC4_HD int step_monitor_host(Ctx x, int h) {  // the per-host part of Monitor.execute; returns the host's event bits afterwards
   EnvState* s = x.s;
-  if (!bit_get(s->exists, h) || blue_of_subnet(h_subnet(h)) < 0) return;
-  uint8_t ev = x.hd[h].ev, nev = 0;
+  if (!bit_get(s->exists, h)) return 0;                     // rows of hosts that do not exist stay zero
+  const uint8_t ev = x.hd[h].ev;
+  if (blue_of_subnet(h_subnet(h)) < 0) return ev;
+  uint8_t nev = 0;
   if (ev & EV_CUR_CONN) nev |= EV_OLD_CONN;
   if (ev & EV_CUR_PROC) nev |= EV_OLD_PROC;
   x.hd[h].ev = nev;
+  return nev;
 }
 CC4_HD void step_monitor_pend(Ctx x) {  // session.add_sus_pids for the pid-carrying process_creation events
   EnvState* s = x.s;
@@ -2420,7 +2423,8 @@ CC4_HD int env_flat_obs_at(const EnvState* s, const HostDyn* hd, int idx) {
 //   [384,447) blocked bits, [447,510) comms policy, [510,573) subnet one-hot, [573,578) the 5 phase words (EnvState.obs_dirty).
 // *idx = position in the vector.
 enum : int { OBS_FAST = 384 };
-CC4_HD int env_flat_obs_sorted(const EnvState* s, const HostDyn* hd, int v, int* idx) {
+// evb: the hosts' event bytes when the caller holds a copy of them (the numpy-stream kernel, whose host table is in HBM)
+CC4_HD int env_flat_obs_sorted(const EnvState* s, const HostDyn* hd, int v, int* idx, const uint8_t* evb = nullptr) {
   if (v >= 224 && v < OBS_FAST) {
     const int w = v - 224, b = w >> 5, m = w & 31, jj = m / MSG_LEN;
     *idx = (b < 4 ? b * OBS_SHORT + OBS_SHORT : 4 * OBS_SHORT + OBS_LONG) - 32 + m;
@@ -2436,7 +2440,7 @@ CC4_HD int env_flat_obs_sorted(const EnvState* s, const HostDyn* hd, int v, int*
     if (k >= 27) {
       const int hs = k < 43 ? k - 27 : k - 43;
       const int h = hs < MAX_SERVERS ? h_make(sn, 11 + hs) : h_make(sn, 1 + (hs - MAX_SERVERS));
-      const int ev = hd[h].ev;   // rows of hosts that do not exist stay zero (env_reset)
+      const int ev = evb ? evb[h] : hd[h].ev;   // rows of hosts that do not exist stay zero (env_reset)
       return k < 43 ? ((ev & (EV_CUR_PROC | EV_OLD_PROC)) != 0) : ((ev & (EV_CUR_CONN | EV_OLD_CONN)) != 0);
     }
     if (k < 9) return sorted_subnet(k) == sn;

@@ -171,16 +171,17 @@ __device__ __forceinline__ void wave_shuffle_consume(Rng& rl, int n, int lane) {
     pcg_ahead(g_pcg_jump[lane + 1], s_hi, s_lo, i_hi, i_lo, &h, &l);
     const uint64_t out = pcg_output(h, l);
     const uint32_t w0 = (uint32_t)out, w1 = (uint32_t)(out >> 32);
+    // the walk over the window's words, in stream order, on the scalar unit: word p is accepted for the current i iff
+    // (word & mask(i)) <= i, and an accepted word ends draw i (one readlane and three scalar ops per word; the only chain
+    // from word to word is i itself)
     int cur = 0;                                     // first unconsumed word of the window
-    while (i >= 1 && cur < 2 * WAVE) {
-      const uint32_t m = mask_of((uint32_t)i);
-      const unsigned long long a0 = __ballot((w0 & m) <= (uint32_t)i), a1 = __ballot((w1 & m) <= (uint32_t)i);
-      const int j0 = (cur + 1) >> 1, j1 = cur >> 1;  // first lane whose low / high word is still unconsumed
-      const unsigned long long m0 = j0 >= WAVE ? 0ull : (a0 & (~0ull << j0)), m1 = j1 >= WAVE ? 0ull : (a1 & (~0ull << j1));
-      const int p0 = m0 ? 2 * (__ffsll((long long)m0) - 1) : 4 * WAVE, p1 = m1 ? 2 * (__ffsll((long long)m1) - 1) + 1 : 4 * WAVE;
-      const int p = p0 < p1 ? p0 : p1;
-      if (p >= 2 * WAVE) { cur = 2 * WAVE; break; }  // every remaining word of the window is rejected for this i
-      cur = p + 1; --i;
+    for (int j = 0; j < WAVE && i >= 1; ++j) {
+      const uint32_t a = (uint32_t)__builtin_amdgcn_readlane((int)w0, j), b = (uint32_t)__builtin_amdgcn_readlane((int)w1, j);
+      if ((a & mask_of((uint32_t)i)) <= (uint32_t)i) --i;
+      cur = 2 * j + 1;
+      if (i < 1) break;
+      if ((b & mask_of((uint32_t)i)) <= (uint32_t)i) --i;
+      cur = 2 * j + 2;
     }
     const int K = (cur + 1) >> 1;                    // outputs of this window that were touched
     if (K > 0) {
@@ -202,6 +203,7 @@ __global__ __launch_bounds__(WAVE) void k_step(StepArgs a) {
   __shared__ int ok_lds;
   __shared__ StepWork work;
   __shared__ uint64_t gpre_lds[MAXG];
+  __shared__ uint8_t ev_lds[MAXH + 3];   // the hosts' event bits after the end-turn roll-over: what the observation encode reads
   const int e = blockIdx.x, lane = threadIdx.x;
   if (e >= a.n) return;
   unsigned long long t_begin = a.prof ? clock64() : 0;
@@ -284,7 +286,7 @@ __global__ __launch_bounds__(WAVE) void k_step(StepArgs a) {
   }
   __syncthreads();
   if (ok_lds) {
-    for (int h = lane; h < MAXH; h += WAVE) step_monitor_host(x, h);
+    for (int h = lane; h < MAXH; h += WAVE) ev_lds[h] = (uint8_t)step_monitor_host(x, h);
     if (lane == 0) step_monitor_pend(x);
     __syncthreads();
     {
@@ -305,7 +307,8 @@ __global__ __launch_bounds__(WAVE) void k_step(StepArgs a) {
   }
   if (lane == 0) { s->rng = rl; a.reward[e] = s->reward; a.done[e] = s->done; a.err[e] = s->err; }
   unsigned long long t_obs = a.prof ? clock64() : 0;
-  for (int v = lane; v < OBS_TOTAL; v += WAVE) { int i; const int val = env_flat_obs_sorted(s, hd, v, &i); obs_lds[i] = (uint8_t)val; }   // kind-sorted: uniform branches
+  if (!ok_lds) { for (int h = lane; h < MAXH; h += WAVE) ev_lds[h] = hd[h].ev; __syncthreads(); }   // after a reset / a refused step
+  for (int v = lane; v < OBS_TOTAL; v += WAVE) { int i; const int val = env_flat_obs_sorted(s, hd, v, &i, ev_lds); obs_lds[i] = (uint8_t)val; }   // kind-sorted: uniform branches
   __syncthreads();
   unsigned long long t_out = a.prof ? clock64() : 0;
   if (prof && lane == 0) prof[12] += t_out - t_obs;
