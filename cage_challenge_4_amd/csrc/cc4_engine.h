@@ -2183,8 +2183,9 @@ CC4_HD void step_blue_exec(Ctx x, bool shuffle_done = false) {
 // One blue agent's action on its own generator stream.  Blue agents own disjoint zones: their actions touch only hosts of the
 // zone, the session table of the zone's red agent and commutative shared bits, so in the counter-based RNG mode they can be
 // resolved concurrently -- except Monitor, which edits the shared pending-event list (step_blue_exec keeps the serial order).
-CC4_HD void step_blue_exec_agent(Ctx x, int b) {
+CC4_HD void step_blue_exec_agent(Ctx x, int b, const uint32_t* pre = nullptr) {
   rng_set_stream(x.r, ST_BLUE_EXE + (uint32_t)b);
+  if (pre) rng_preload(x.r, pre);
   blue_execute(x, b, x.s->bexec[b]);
 }
 CC4_HD bool blue_exec_independent(const EnvState* s) {
@@ -2246,10 +2247,12 @@ CC4_HD uint32_t red_foreign_agents(const EnvState* s) {   // bit r: agent r hold
   return foreign;
 }
 CC4_HD bool red_any_foreign_session(const EnvState* s) { return red_foreign_agents(s) != 0; }
-CC4_HD void step_red_exec_agent(Ctx x, int r) {
+// pre: block 0 of the agent's action stream when the caller has it already (rng_preload), else null
+CC4_HD void step_red_exec_agent(Ctx x, int r, const uint32_t* pre = nullptr) {
   EnvState* s = x.s;
   if (s->rexec[r].type == RA_NONE) return;
   rng_set_stream(x.r, ST_RED_EXE + (uint32_t)r);
+  if (pre) rng_preload(x.r, pre);
   red_execute(x, r, s->rexec[r]);
 }
 // Red actions of different agents commute when they name different hosts (each action reads/writes its own agent's

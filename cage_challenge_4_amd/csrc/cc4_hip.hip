@@ -382,7 +382,7 @@ __global__ __launch_bounds__(PT, MINW) void k_step_philox(StepArgs a) {
   extern __shared__ uint4 lds[];
   __shared__ int conflict_lds;
   __shared__ alignas(16) uint32_t reset_ws[RESET_WS_WORDS];   // pid bitmaps of the scenario generation (autoreset); during a step: the green agents' pre-computed blocks
-  static_assert(RESET_WS_WORDS >= 4 * MAXG, "one 16-byte block per green agent");
+  static_assert(RESET_WS_WORDS >= 4 * (MAXG + NRED + NBLUE), "one 16-byte block per green agent, red action stream and blue action stream");
   __shared__ int glist_n[2][2];       // [action type][drawing wave]
   __shared__ StepWork work;
   __shared__ uint8_t obs_bytes[OBS_TOTAL + 2];   // byte-per-value copy of the observations, only for the packed exchange row
@@ -490,6 +490,11 @@ __global__ __launch_bounds__(PT, MINW) void k_step_philox(StepArgs a) {
         step_blue_submit(x0, b, act);
         step_tick_blue(x0, b);
         step_messages(s, a.msgs ? a.msgs + e * NBLUE * MSG_LEN : nullptr, b);   // read back by this step's observation encode only
+        { uint32_t c[4]; rng_block(&rl, ST_BLUE_EXE + (uint32_t)b, 0, c); reinterpret_cast<uint4*>(reset_ws)[MAXG + NRED + b] = make_uint4(c[0], c[1], c[2], c[3]); }
+#endif
+      }
+      else if (wave == 2 && lane < NRED) {   // block 0 of the six red action streams, side by side on idle lanes of a wave with slack
+        uint32_t c[4]; rng_block(&rl, ST_RED_EXE + (uint32_t)lane, 0, c); reinterpret_cast<uint4*>(reset_ws)[MAXG + lane] = make_uint4(c[0], c[1], c[2], c[3]);
       }
       else if (lane >= 8 && wave >= 2) {
         static_assert(PW == 4 && MAXG <= 2 * (WAVE - 8), "every green agent has its own lane on wave 2 or 3: one pass, one ballot per type");
@@ -526,7 +531,13 @@ __global__ __launch_bounds__(PT, MINW) void k_step_philox(StepArgs a) {
 #endif
         constexpr int BW = CC4_BLUE_WAVES;
         const int bagent = lane * BW + wave;                                      // blue agent b on wave b % BW, lane b / BW
-        if (wave < BW && lane < (NBLUE + BW - 1) / BW && bagent < NBLUE) { Ctx xb{s, a.cold + e, &rl, hd, &work, nullptr, nullptr, lg}; step_blue_exec_agent(xb, bagent); }
+#ifdef CC4_EXP_PREBLK
+        if (wave < BW && lane < (NBLUE + BW - 1) / BW && bagent < NBLUE) {
+          Ctx xb{s, a.cold + e, &rl, hd, &work, nullptr, nullptr, lg};
+          const uint4 blk = reinterpret_cast<const uint4*>(reset_ws)[MAXG + NRED + bagent];
+          const uint32_t pre[4] = {blk.x, blk.y, blk.z, blk.w};
+          step_blue_exec_agent(xb, bagent, pre);
+        }
         __syncthreads();
         if (tid == 0) CC4_TICK(x0, 5);
       } else {
@@ -557,7 +568,7 @@ __global__ __launch_bounds__(PT, MINW) void k_step_philox(StepArgs a) {
       if (is_red && !((serial_red >> ragent) & 1u)) {
         unsigned long long t0 = ap ? clock64() : 0;
         const int ty = s->rexec[ragent].type;
-        step_red_exec_agent(xr, ragent);
+        { const uint4 blk = reinterpret_cast<const uint4*>(reset_ws)[MAXG + ragent]; const uint32_t pre[4] = {blk.x, blk.y, blk.z, blk.w}; step_red_exec_agent(xr, ragent, pre); }
         if (ap) { unsigned long long dt = clock64() - t0; ap[1] += dt; unsigned long long* tp = a.prof + PROF_SLOTS * (size_t)e + 64 + 2 * (ty & 15); atomicAdd(tp, dt); atomicAdd(tp + 1, 1ull); }
       }
       __syncthreads();
