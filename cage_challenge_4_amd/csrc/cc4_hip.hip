@@ -490,8 +490,8 @@ __global__ __launch_bounds__(PT, MINW) void k_step_philox(StepArgs a) {
         step_blue_submit(x0, b, act);
         step_tick_blue(x0, b);
         step_messages(s, a.msgs ? a.msgs + e * NBLUE * MSG_LEN : nullptr, b);   // read back by this step's observation encode only
+        // block 0 of the agent's action stream, for the lane that will resolve the action
         { uint32_t c[4]; rng_block(&rl, ST_BLUE_EXE + (uint32_t)b, 0, c); reinterpret_cast<uint4*>(reset_ws)[MAXG + NRED + b] = make_uint4(c[0], c[1], c[2], c[3]); }
-#endif
       }
       else if (wave == 2 && lane < NRED) {   // block 0 of the six red action streams, side by side on idle lanes of a wave with slack
         uint32_t c[4]; rng_block(&rl, ST_RED_EXE + (uint32_t)lane, 0, c); reinterpret_cast<uint4*>(reset_ws)[MAXG + lane] = make_uint4(c[0], c[1], c[2], c[3]);
@@ -531,7 +531,6 @@ __global__ __launch_bounds__(PT, MINW) void k_step_philox(StepArgs a) {
 #endif
         constexpr int BW = CC4_BLUE_WAVES;
         const int bagent = lane * BW + wave;                                      // blue agent b on wave b % BW, lane b / BW
-#ifdef CC4_EXP_PREBLK
         if (wave < BW && lane < (NBLUE + BW - 1) / BW && bagent < NBLUE) {
           Ctx xb{s, a.cold + e, &rl, hd, &work, nullptr, nullptr, lg};
           const uint4 blk = reinterpret_cast<const uint4*>(reset_ws)[MAXG + NRED + bagent];
