@@ -630,3 +630,33 @@ def test_counter_mode_event_log_ports_do_not_change_the_trajectory():
     for i in range(n):
         assert np.array_equal(plain.get_state(i), logged.get_state(i))
     plain.close(); logged.close()
+
+
+def test_bench_line_contract():
+    """`python bench.py --steps 20 --warmup 5` (what the driver runs, with its own K / W): ONE JSON line with the contract's keys,
+    BASELINE.json's metric on the 8192-episode configuration, `roofline` and `cpu_baseline` objects, consistent numbers."""
+    import json, os, subprocess, sys
+    from conftest import ROOT
+    out = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--steps', '20', '--warmup', '5', '--min-seconds', '0.05'],
+                         capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, out.stdout[-2000:]
+    d = json.loads(lines[0])
+    for k in ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better', 'scaling', 'vs_baseline', 'dtype', 'data',
+              'config', 'roofline', 'cpu_baseline'):
+        assert k in d, k
+    assert d['n_gpus'] == 1 and d['steps'] == 20 and d['warmup'] == 5 and d['higher_is_better'] is True and d['vs_baseline'] is None
+    assert d['scaling'] == 'strong' and d['data'] == 'synthetic' and d['dtype'] == 'int32' and 'model' not in d['config']
+    assert '8192 vectorised envs' in d['config']['workload'] and d['config']['total_envs'] == 8192
+    assert not d['config']['engine_error_flags'] and d['config']['timed_regions'] >= 1
+    r = d['roofline']
+    assert r['bound'] == 'hbm' and r['unit'] == 'GB/s' and r['peak'] == 8000.0 and abs(r['frac'] - r['achieved'] / r['peak']) < 1e-9
+    assert r['kernel'] == 'k_step_philox' and 0 < r['launch_ms'] <= d['ms_per_step'] * 1.02
+    assert abs(r['achieved'] - r['algorithmic_bytes_per_launch'] / (r['launch_ms'] * 1e-3) / 1e9) < 1e-6 * r['achieved']
+    assert r['traffic'] is None or ('profiles/' in r['traffic_source'])
+    assert abs(d['value'] - 5.0 * 8192 / (d['ms_per_step'] * 1e-3)) < 1e-6 * d['value']
+    c = d['cpu_baseline']
+    assert c['kind'] == 'port' and c['cores'] >= 1 and c['value'] > 0 and 'sample' in c and c['one_core']['cores'] == 1
+    assert c['reference_python']['kind'] == 'reference' and c['reference_python']['value'] == 172.0
+    assert d['alt_rng']['rng'] == 'pcg64' and d['envs_1024']['total_envs'] == 1024 and d['value'] > 50e6
