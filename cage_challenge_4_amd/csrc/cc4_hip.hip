@@ -160,7 +160,7 @@ __device__ __forceinline__ void wave_shuffle_consume(Rng& rl, int n, int lane) {
   uint32_t has32 = (uint32_t)__builtin_amdgcn_readfirstlane((int)rl.has32), u32 = (uint32_t)__builtin_amdgcn_readfirstlane((int)rl.u32);
   uint32_t adv = 0;
   int i = n - 1;
-  auto mask_of = [](uint32_t m) { m |= m >> 1; m |= m >> 2; m |= m >> 4; m |= m >> 8; m |= m >> 16; return m; };
+  auto mask_of = [](uint32_t m) { return 0xFFFFFFFFu >> __builtin_clz(m); };   // m >= 1: the smallest 2^k - 1 >= m (random_interval's mask)
   if (has32) {                                       // the buffered half word is the first candidate
     has32 = 0;
     if ((u32 & mask_of((uint32_t)i)) <= (uint32_t)i) --i;
