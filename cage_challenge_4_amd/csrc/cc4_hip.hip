@@ -368,12 +368,13 @@ __device__ __forceinline__ void dma_chunk(const uint4* gsrc_lane, uint4* lds_chu
 }
 __device__ __forceinline__ void dma_wait() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 
-// MINW = minimum waves per SIMD the register allocation must allow (= resident episode blocks per CU): 1 lets the compiler
-// take what it likes (86 VGPRs, 106 SGPRs: 5 blocks per CU) and is the fastest single block -- the build for batches that
-// fit the chip in one round (<= 5 x 256 episodes, the per-GPU share of an 8-GPU job); CC4_PHILOX_BIG_MINW caps the registers so
-// that more blocks are resident per CU -- the build for large batches, which are throughput-bound.  Measured on MI355X at 8192
-// episodes (r02, same box, +-0.1 %): MINW 5: 315 M agent-env steps/s, 6: 353 M, 7: 376 M (72 VGPRs, a handful of spills),
-// 8: 360 M (64 VGPRs, ~30 spills); at 1024 episodes the MINW 1 build wins (167 M vs 156 M for MINW 8).
+// MINW = minimum waves per SIMD the register allocation must allow (= resident episode blocks per CU).  1 lets the compiler
+// take what it likes (86 VGPRs, 106 SGPRs: 5 blocks per CU) and is the fastest single block: the build for batches that fit
+// the chip in one round of <= 5 blocks per CU (the per-GPU share of an 8-GPU job).  7 (72 VGPRs, a dozen spills) and 8 (64
+// VGPRs, ~30 spills) keep more blocks resident: the builds for larger, throughput-bound batches.  cc4_create picks per batch
+// size.  Measured on MI355X (r02, M agent-env steps/s, MINW 1 / 7 / 8): 1536 episodes 185 / 229 / 215, 2048: 222 / 233 / 261
+// (exactly one round of 8), 3072: 253 / 295 / 281, 4096: 275 / 320 / 318, 8192: 320 / 393 / 389, 16384: 332 / 414 / 399;
+// 1024 episodes: 167 with MINW 1 vs 156 with 8.
 #ifndef CC4_PHILOX_BIG_MINW
 #define CC4_PHILOX_BIG_MINW 7
 #endif
@@ -754,7 +755,7 @@ struct cc4_handle {
   uint8_t* d_unpacked = nullptr;                 // [world*N][578] bytes: cc4_unpack_obs_device
   int evlog_on = 0;               // cc4_enable_event_log
   bool full_obs_next = true;      // the next step launch rewrites every observation value (fresh handle, restored state)
-  int one_round_blocks = 5 * 256; // episode blocks the low-occupancy build of k_step_philox keeps resident at once (5 per CU)
+  int philox_minw = 1;            // which register budget of k_step_philox this batch size runs (1, 7 or 8 blocks per CU; cc4_create)
   ncclComm_t comm = nullptr; int rank = 0, world = 1;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   std::vector<hipEvent_t> evs;
@@ -804,7 +805,8 @@ static int launch_step(cc4_handle* h, const int32_t* d_actions, const uint8_t* d
   h->step_event_attached = stop != nullptr;
   if (h->cfg.rng_mode == 1) {
     if (h->evlog_on) hipExtLaunchKernelGGL((k_step_philox<true, 1>), grid, dim3(PT), sizeof(EnvState), h->stream, nullptr, stop, 0, a);
-    else if (h->cfg.num_envs > h->one_round_blocks) hipExtLaunchKernelGGL((k_step_philox<false, CC4_PHILOX_BIG_MINW>), grid, dim3(PT), sizeof(EnvState), h->stream, nullptr, stop, 0, a);
+    else if (h->philox_minw == 8) hipExtLaunchKernelGGL((k_step_philox<false, 8>), grid, dim3(PT), sizeof(EnvState), h->stream, nullptr, stop, 0, a);
+    else if (h->philox_minw == 7) hipExtLaunchKernelGGL((k_step_philox<false, 7>), grid, dim3(PT), sizeof(EnvState), h->stream, nullptr, stop, 0, a);
     else hipExtLaunchKernelGGL((k_step_philox<false, 1>), grid, dim3(PT), sizeof(EnvState), h->stream, nullptr, stop, 0, a);
   } else {
     if (h->evlog_on) hipExtLaunchKernelGGL(k_step<true>, grid, dim3(WAVE), offsetof(EnvState, hd), h->stream, nullptr, stop, 0, a);
@@ -853,8 +855,11 @@ int cc4_create(const cc4_config* cfg, cc4_handle** out) {
   {
     hipDeviceProp_t prop;
     HIPCHK(h, hipGetDeviceProperties(&prop, cfg->device_id));
-    h->one_round_blocks = 5 * prop.multiProcessorCount;
-    if (const char* v = getenv("CC4_PHILOX_OCCUPANCY_SWITCH")) h->one_round_blocks = atoi(v);   // tuning: batch size above which the 8-blocks-per-CU build runs
+    // one round of <= 5 blocks per CU: the unconstrained build; else the build whose residency fills whole rounds best
+    const int cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    const int bpc = (cfg->num_envs + cus - 1) / cus;                     // episode blocks per CU
+    h->philox_minw = bpc <= 5 ? 1 : (bpc == 8 ? 8 : 7);      // exactly 8 per CU (2048 episodes on 256 CUs) is one round of the 8-block build
+    if (const char* v = getenv("CC4_PHILOX_MINW")) h->philox_minw = atoi(v);   // tuning override: 1, 7 or 8
   }
   HIPCHK(h, hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
   size_t n = (size_t)cfg->num_envs;
