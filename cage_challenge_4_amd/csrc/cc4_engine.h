@@ -141,6 +141,19 @@ CC4_HD int last_set(const uint32_t* bm, int nwords) {
   return -1;
 }
 
+// One bit of Host.ephemeral_ports: set it, tell whether it was set.  On the device every test-and-set of these words is one
+// L2 atomic (the row is never staged): the serial walk and the lane-parallel green actions of the numpy-stream kernel
+// (wave_green_exec) then agree on one coherence point, and the walk saves the separate store.
+enum : uint32_t { EPH_RANGE = 60000 - 49152 };
+CC4_HD bool eph_test_and_set(EnvCold* c, int h, uint32_t p) {
+  uint32_t* w = &c->eph[h][p >> 5];
+  const uint32_t bit = 1u << (p & 31);
+#if defined(__HIP_DEVICE_COMPILE__)
+  return (__hip_atomic_fetch_or(w, bit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) & bit) != 0;
+#else
+  const bool was = (*w & bit) != 0; *w |= bit; return was;
+#endif
+}
 // Host.get_ephemeral_port (Simulator/Host.py:175-187): one re-draw on collision, then remember the port.
 CC4_HD int eph_port(Ctx x, int h, int salt = 0) {
   // Counter mode: the port value is unobservable on the flat-observation path, so nothing is drawn.  With the event log on
@@ -154,10 +167,8 @@ CC4_HD int eph_port(Ctx x, int h, int salt = 0) {
     rng_block(x.r, x.r->ndraw | 0x8000u, (uint32_t)(x.r->s_hi * 64u + (uint32_t)salt), c);
     return 49152 + (int)(((uint64_t)c[0] * (60000u - 49152u)) >> 32);
   }
-  uint32_t p = rng_below(x.r, 60000 - 49152);
-  uint32_t* bm = x.c->eph[h];
-  if (bit_get(bm, (int)p)) p = rng_below(x.r, 60000 - 49152);
-  bit_set(bm, (int)p);
+  uint32_t p = rng_below(x.r, EPH_RANGE);
+  if (eph_test_and_set(x.c, h, p)) { p = rng_below(x.r, EPH_RANGE); (void)eph_test_and_set(x.c, h, p); }
   return 49152 + (int)p;
 }
 CC4_HD void eph_clear(Ctx x, int h) {
@@ -1270,10 +1281,23 @@ CC4_HD uint64_t green_prepare(Ctx x, int g, int act) {
   }
   return w;
 }
-// GreenLocalWork.execute (GreenActions/GreenLocalWork.py:60-125). returns success.  pre: green_prepare's word
-CC4_HD bool green_local_work(Ctx x, int gh, uint64_t pre, bool* want_phish) {
+// the c-th server over a GreenAccessService agent's allowed subnets in subnet order (pre: green_prepare's running totals): the
+// first subnet whose total exceeds c
+CC4_HD int green_as_dest(uint64_t pre, int c, int* sn_out) {
+  int sn = 0, before = 0;
+  CC4_UNROLL for (int k = 0; k < NSUB - 2; ++k) { const int tot = (int)((pre >> (8 * k)) & 0xFF); if (tot <= c) { sn = k + 1; before = tot; } }
+  *sn_out = sn;
+  return h_make(sn, 11 + (c - before));
+}
+// the active services of a GreenLocalWork agent's host as a bit mask over the service table (pre: green_prepare's status bytes)
+CC4_HD uint32_t green_lw_active(uint64_t pre) {
   uint32_t act = 0;
   CC4_UNROLL for (int i = 0; i < MAXSV; ++i) if ((pre >> (8 * i)) & SV_ACTIVE) act |= 1u << i;
+  return act;
+}
+// GreenLocalWork.execute (GreenActions/GreenLocalWork.py:60-125). returns success.  pre: green_prepare's word
+CC4_HD bool green_local_work(Ctx x, int gh, uint64_t pre, bool* want_phish) {
+  const uint32_t act = green_lw_active(pre);
   if (!act) return false;
   const int c = nth_bit(act, (int)rng_below(x.r, (uint32_t)popc32(act)));   // choice over the active services, table order
   const uint32_t st = (uint32_t)(pre >> (8 * c)) & 0xFF;
@@ -1288,10 +1312,8 @@ CC4_HD bool green_access_service(Ctx x, int gh, uint64_t pre) {
   int own = h_subnet(gh);
   const int n = (int)(pre >> 56);
   const int c = (int)rng_below(x.r, (uint32_t)n);
-  // the c-th server over the allowed subnets in subnet order: the first subnet whose running total exceeds c
-  int sn = 0, before = 0;
-  CC4_UNROLL for (int k = 0; k < NSUB - 2; ++k) { const int tot = (int)((pre >> (8 * k)) & 0xFF); if (tot <= c) { sn = k + 1; before = tot; } }
-  const int dest = h_make(sn, 11 + (c - before));
+  int sn;
+  const int dest = green_as_dest(pre, c, &sn);
   const int dest_port = eph_port(x, dest);
   int ds = sn;
   // events land on the destination server (`from_host` in the reference, GreenAccessService.py:176-214)

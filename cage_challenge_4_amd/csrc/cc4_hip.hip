@@ -194,16 +194,257 @@ __device__ __forceinline__ void wave_shuffle_consume(Rng& rl, int n, int lane) {
   if (lane == 0) { rl.s_hi = s_hi; rl.s_lo = s_lo; rl.has32 = has32; rl.u32 = u32; rl.ndraw += adv; }
 }
 
+// ---------------------------------------------------------------- numpy stream: the green actions across the wave
+// GreenAccessService / GreenLocalWork draw from the one shared stream, agent after agent, and every agent's number of draws
+// depends on what it drew -- but on nothing it reads from the state that an earlier green action of the same step could have
+// changed, with two exceptions: an ephemeral port that is already taken (Host.py:175-187 re-draws once) and a phishing email
+// (a red session appears).  So the serial walk (50-odd agents x [a 128-bit multiply per draw + an HBM round trip for the port
+// bitmap and one per event byte]) is replaced by:
+//  (1) the next 128 outputs of the LCG from the closed form, two per lane, into LDS;
+//  (2) where in the stream each agent starts.  That is a prefix sum over the agents' draw counts, which depend on the drawn
+//      values, i.e. on the start: solved by relaxation -- every lane (one agent each) replays its action from its current
+//      start estimate, a wave scan of the counts gives the next estimates, until nothing moves.  Agent 0's start is given,
+//      so agent k is exact after k + 1 rounds at the latest; as an action's draw count rarely depends on the values (a
+//      blocked route, a failed reliability roll, the two 1 % events), three rounds are the rule;
+//  (3) the agents' effects -- the port bitmap test-and-set (one L2 atomic), the event bits, the reward -- on their lanes.
+// A taken port, a phishing email, a Lemire re-draw (n / 2^32 per draw) or the end of the window end a batch: its agents in
+// front of that point are committed, the agent at that point is resolved by the serial code on lane 0 (ports set
+// speculatively by later agents are cleared first), and the next batch starts behind it.  Bit-exact with the serial walk
+// (rng_below / rng_random / has_uint32 buffering in cc4_rng.h).
+constexpr int GW_OUT = 2 * WAVE;                           // outputs per window
+constexpr double P01_SCALED = 0.01 * 9007199254740992.0;   // Generator.random() < 0.01 on the 53-bit integer: exact scaling
+constexpr uint64_t P01_FLOOR = (uint64_t)P01_SCALED;
+static_assert((double)P01_FLOOR * (1.0 / 9007199254740992.0) < 0.01 && (double)(P01_FLOOR + 1) * (1.0 / 9007199254740992.0) >= 0.01,
+              "integer form of rng_random() < 0.01");
+enum : uint32_t { GR_VALID = 1, GR_FAIL = 2, GR_EPH = 4, GR_CONN = 8, GR_PROC = 16, GR_HARD = 32, GR_PHISH = 64 };
+__device__ __forceinline__ uint32_t rdlane(uint32_t v, int j) { return (uint32_t)__builtin_amdgcn_readlane((int)v, j); }
+// wave64 inclusive scans on the DPP network (row_shr 1/2/4/8 inside the rows of 16, then row_bcast 15 and 31 across rows) and
+// the shift by one lane that turns them into exclusive ones
+__device__ __forceinline__ uint32_t wave_scan_add(uint32_t v) {
+  int x = (int)v;
+  x += __builtin_amdgcn_update_dpp(0, x, 0x111, 0xf, 0xf, false);
+  x += __builtin_amdgcn_update_dpp(0, x, 0x112, 0xf, 0xf, false);
+  x += __builtin_amdgcn_update_dpp(0, x, 0x114, 0xf, 0xf, false);
+  x += __builtin_amdgcn_update_dpp(0, x, 0x118, 0xf, 0xf, false);
+  x += __builtin_amdgcn_update_dpp(0, x, 0x142, 0xa, 0xf, false);
+  x += __builtin_amdgcn_update_dpp(0, x, 0x143, 0xc, 0xf, false);
+  return (uint32_t)x;
+}
+__device__ __forceinline__ int wave_scan_max(int v) {   // v >= -1
+  auto mx = [](int a, int b) { return a > b ? a : b; };
+  int x = v;
+  x = mx(x, __builtin_amdgcn_update_dpp(-1, x, 0x111, 0xf, 0xf, false));
+  x = mx(x, __builtin_amdgcn_update_dpp(-1, x, 0x112, 0xf, 0xf, false));
+  x = mx(x, __builtin_amdgcn_update_dpp(-1, x, 0x114, 0xf, 0xf, false));
+  x = mx(x, __builtin_amdgcn_update_dpp(-1, x, 0x118, 0xf, 0xf, false));
+  x = mx(x, __builtin_amdgcn_update_dpp(-1, x, 0x142, 0xa, 0xf, false));
+  x = mx(x, __builtin_amdgcn_update_dpp(-1, x, 0x143, 0xc, 0xf, false));
+  return x;
+}
+__device__ __forceinline__ uint32_t wave_shr1(uint32_t v, uint32_t lane0) {   // lane k <- lane k - 1, lane 0 <- lane0
+  return (uint32_t)__builtin_amdgcn_update_dpp((int)lane0, (int)v, 0x138, 0xf, 0xf, false);
+}
+__device__ __forceinline__ void wave_green_exec(Ctx x, Rng& rl, const uint64_t* gpre, uint64_t* win, int lane, unsigned long long* gstat = nullptr) {
+  EnvState* s = x.s;
+  const int ng = s->n_green;
+  const uint64_t i_hi = bcast64(rl.inc_hi), i_lo = bcast64(rl.inc_lo);
+  int g0 = 0;
+  for (int guard = 0; g0 < ng; ++guard) {
+    if (guard > 2 * MAXG + 8) { if (lane == 0) set_err(x, E_UNREACHABLE); break; }   // every batch advances g0
+    const unsigned long long t0 = gstat ? clock64() : 0;
+    const uint64_t s_hi = bcast64(rl.s_hi), s_lo = bcast64(rl.s_lo);
+    const uint32_t has0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)rl.has32), u0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)rl.u32);
+    // (1) the window: output p (0-based) is computed on lane p & 63 (set p >> 6) and stored at win[p]
+    uint64_t h0, l0, h1, l1;
+    pcg_ahead(g_pcg_jump[lane + 1], s_hi, s_lo, i_hi, i_lo, &h0, &l0);
+    pcg_ahead(g_pcg_jump[WAVE], h0, l0, i_hi, i_lo, &h1, &l1);
+    __syncthreads();           // (one wave per block) the previous batch's window reads are done
+    win[lane] = pcg_output(h0, l0);
+    win[WAVE + lane] = pcg_output(h1, l1);
+    __syncthreads();
+    // what the agents of this batch (lane k <-> agent g0 + k) bring along
+    const int gi = g0 + lane;
+    const bool in = gi < ng;
+    const uint32_t my_act = in ? x.w->green_act[gi] : 2u;
+    const bool active = my_act < 2;
+    const uint64_t pre = active ? gpre[gi] : 0ull;
+    const uint32_t gh = in ? s->green_host[gi] : 0u;
+    uint32_t my_blk = 0;       // bit sn: traffic between the agent's subnet and subnet sn is blocked either way
+    if (active && my_act == 0) {
+      const int own = h_subnet((int)gh);
+#pragma unroll
+      for (int sn = 0; sn < NSUB - 1; ++sn) if (((s->blocks[own] >> sn) | (s->blocks[sn] >> own)) & 1u) my_blk |= 1u << sn;
+    }
+    const uint32_t lw_am = green_lw_active(pre);
+    // what decides an agent's draw COUNT, reduced to shifts: the leading 32-bit draws (a = 1 or 2; with two, the first one
+    // picks -- a server / a service -- out of `npick`), for GreenAccessService the picks that end on a blocked route (no
+    // further draw), for GreenLocalWork the reliability (/20) of the pick
+    const bool is_as = active && my_act == 0, is_lw = active && my_act == 1 && lw_am != 0;
+    uint32_t npick = 0; uint64_t pickinfo = 0;
+    if (is_as) {
+      npick = (uint32_t)(pre >> 56);
+#pragma unroll
+      for (int sn = 0; sn < NSUB - 1; ++sn) {
+        const uint32_t before = sn ? (uint32_t)((pre >> (8 * (sn - 1))) & 0xFF) : 0u, tot = (uint32_t)((pre >> (8 * sn)) & 0xFF);
+        if (((my_blk >> sn) & 1u) && tot > before) pickinfo |= ((tot >= 64 ? ~0ull : (1ull << tot) - 1ull)) & ~((1ull << before) - 1ull);
+      }
+    } else if (is_lw) {
+      npick = (uint32_t)popc32(lw_am);
+      int cnt = 0;
+#pragma unroll
+      for (int i = 0; i < MAXSV; ++i) if ((lw_am >> i) & 1u) { pickinfo |= ((pre >> (8 * i)) & 0x7Full) << (8 * cnt); ++cnt; }
+    }
+    const uint32_t lead = (is_as || is_lw) ? (npick > 1 ? 2u : 1u) : 0u;
+    // (2) relaxation.  Per lane: d = outputs taken | 32-bit draws << 16 ; q = window index of the last output a 32-bit draw
+    // fetched (its high half is numpy's buffered `uinteger`), -1: none
+    uint32_t d_cur = 0, sp = 0, sh = 0, su = 0;
+    int q_cur = -1;
+    uint32_t inc = 0; int qinc = -1;    // inclusive scans of the last round
+    int rounds = 0;
+    bool stuck = false;
+    for (;; ++rounds) {
+      inc = wave_scan_add(d_cur); qinc = wave_scan_max(q_cur);
+      const uint32_t ex = wave_shr1(inc, 0u);
+      const int exq = (int)wave_shr1((uint32_t)qinc, 0xFFFFFFFFu);
+      const int pos = (int)(ex & 0xFFFFu);
+      const uint32_t has = (has0 + (ex >> 16)) & 1u;
+      const uint32_t buf = exq < 0 ? u0 : (uint32_t)(win[exq < GW_OUT ? exq : GW_OUT - 1] >> 32);
+      sp = (uint32_t)pos; sh = has; su = buf;
+      uint32_t d_new = 0; int q_new = -1;
+      if (lead) {
+        const uint64_t f0 = win[pos < GW_OUT ? pos : GW_OUT - 1], f1 = win[pos + 1 < GW_OUT ? pos + 1 : GW_OUT - 1];
+        const uint32_t first = has ? buf : (uint32_t)f0, second = has ? (uint32_t)f0 : (uint32_t)(f0 >> 32);
+        uint32_t i = (has && lead == 1) ? 0u : 1u, n32 = lead;
+        uint32_t has2 = has ^ (lead & 1u);
+        if (i) q_new = pos;
+        const uint32_t pick = lead == 2 ? (uint32_t)(((uint64_t)first * npick) >> 32) : 0u;
+        if (is_as) {
+          if (!((pickinfo >> pick) & 1ull)) ++i;                       // not blocked: the 1 % connection-event roll
+        } else {
+          const uint32_t roll = (uint32_t)(((uint64_t)(lead == 2 ? second : first) * 100u) >> 32);
+          if (roll < (uint32_t)((pickinfo >> (8 * pick)) & 0xFF) * 20u) {
+            const uint64_t u1 = i ? f1 : f0;
+            ++i;
+            if ((u1 >> 11) <= P01_FLOOR) { ++n32; if (!has2) { q_new = pos + (int)i; ++i; } has2 ^= 1u; }   // the false-positive event's port
+            ++i;                                                        // the phishing roll
+          }
+        }
+        d_new = i | (n32 << 16);
+      }
+      const bool moved = d_new != d_cur || q_new != q_cur;
+      d_cur = d_new; q_cur = q_new;
+      if (!__ballot(moved)) break;          // the estimates the lanes just used were the fixed point
+      if (rounds > WAVE + 2) { stuck = true; break; }   // cannot happen (lane k is exact after k + 1 rounds): serial walk
+    }
+    // the agents' actions in full, from the starts found
+    uint32_t rec = 0;
+    if (active) {
+      const int pos = (int)sp;
+      uint32_t has = sh, buf = su;
+      int q_new = -1;
+      uint64_t f[5];
+#pragma unroll
+      for (int j = 0; j < 5; ++j) { const int p = pos + j; f[j] = win[p < GW_OUT ? p : GW_OUT - 1]; }
+      int i = 0; uint32_t n32 = 0; bool hard = false;
+      auto fetch = [&]() { uint64_t v = f[0]; if (i == 1) v = f[1]; if (i == 2) v = f[2]; if (i == 3) v = f[3]; if (i >= 4) v = f[4]; ++i; return v; };
+      auto take32 = [&]() { ++n32; if (has) { has = 0; return buf; } const uint64_t o = fetch(); buf = (uint32_t)(o >> 32); q_new = pos + i - 1; has = 1; return (uint32_t)o; };
+      auto below = [&](uint32_t n) { if (n <= 1) return 0u; const uint64_t m = (uint64_t)take32() * n; if ((uint32_t)m < n) hard = true; return (uint32_t)(m >> 32); };
+      uint32_t r = GR_VALID;
+      if (my_act == 0) {       // green_access_service
+        const int c = (int)below((uint32_t)(pre >> 56));
+        int sn;
+        const int dest = green_as_dest(pre, c, &sn);
+        const uint32_t p = below(EPH_RANGE);
+        r |= GR_EPH | ((uint32_t)dest << 8) | (p << 16);
+        if ((my_blk >> sn) & 1u) r |= GR_FAIL | GR_CONN;
+        else if ((fetch() >> 11) <= P01_FLOOR) r |= GR_CONN;
+      } else if (!lw_am) r |= GR_FAIL;   // green_local_work
+      else {
+        const int c = nth_bit(lw_am, (int)below((uint32_t)popc32(lw_am)));
+        const int rel = (int)((pre >> (8 * c)) & 0x7F) * 20;
+        if ((int)below(100) >= rel) r |= GR_FAIL;
+        else {
+          if ((fetch() >> 11) <= P01_FLOOR) { const uint32_t p = below(EPH_RANGE); r |= GR_EPH | GR_PROC | (gh << 8) | (p << 16); }
+          if ((fetch() >> 11) <= P01_FLOOR) r |= GR_PHISH;
+        }
+      }
+      // a Lemire re-draw, a window that may not cover this agent, or (never) a count that differs from the relaxation's
+      if (hard || pos + 5 > GW_OUT || ((uint32_t)i | (n32 << 16)) != d_cur || q_new != q_cur) r |= GR_HARD;
+      rec = r;
+    }
+    if (stuck) rec |= GR_HARD;
+    // where the batch ends: in front of the first agent the serial code has to resolve, behind the first phishing email
+    const int cnt = (ng - g0) < WAVE ? (ng - g0) : WAVE;
+    int kend = cnt;
+    enum { R_NEXT, R_HARD, R_PHISH } reason = R_NEXT;
+    const uint64_t m_hard = __ballot((rec & GR_HARD) != 0), m_phish = __ballot((rec & GR_PHISH) != 0);
+    if (m_hard) { const int k = __ffsll((unsigned long long)m_hard) - 1; if (k < kend) { kend = k; reason = R_HARD; } }
+    if (m_phish) { const int k = __ffsll((unsigned long long)m_phish) - 1; if (k < kend) { kend = k + 1; reason = R_PHISH; } }
+    const unsigned long long t1 = gstat ? clock64() : 0;
+    // (3) ports: one atomic test-and-set per agent; the first agent that finds its port taken ends the batch in front of it
+    const uint32_t eh = (rec >> 8) & 0xFFu, ep = (rec >> 16) & 0x3FFFu;
+    bool coll = false;
+    const bool has_port = lane < kend && (rec & GR_EPH);
+    if (has_port) coll = eph_test_and_set(x.c, (int)eh, ep);
+    const uint64_t cm = __ballot(coll);
+    if (cm) {
+      const int kc = __ffsll((unsigned long long)cm) - 1;
+      if (has_port && !coll && lane >= kc) __hip_atomic_fetch_and(&x.c->eph[eh][ep >> 5], ~(1u << (ep & 31)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      kend = kc; reason = R_HARD;
+    }
+    if (lane < kend && (rec & GR_VALID)) {
+      if (rec & GR_CONN) ev_or(x, (int)eh, EV_CUR_CONN);
+      if (rec & GR_PROC) ev_or(x, (int)eh, EV_CUR_PROC);
+      if (rec & GR_FAIL) __hip_atomic_fetch_add(&s->brm, reward_table(s->phase, h_subnet((int)gh), my_act == 0 ? RW_ASF : RW_LWF), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
+    // the stream behind the committed agents = where agent kend starts
+    int pos_e = 0; uint32_t has_e = has0, u_e = u0;
+    if (kend > 0) {
+      const uint32_t ie = rdlane(inc, kend - 1);
+      const int qe = (int)rdlane((uint32_t)qinc, kend - 1);
+      pos_e = (int)(ie & 0xFFFFu); has_e = (has0 + (ie >> 16)) & 1u;
+      if (qe >= 0) u_e = (uint32_t)(win[qe] >> 32);
+    }
+    uint64_t n_hi = s_hi, n_lo = s_lo;
+    if (pos_e > 0) {
+      const int j = (pos_e - 1) & 63;
+      n_hi = lane64(h0, j); n_lo = lane64(l0, j);
+      if (pos_e > WAVE) { n_hi = lane64(h1, j); n_lo = lane64(l1, j); }
+    }
+    const unsigned long long t2 = gstat ? clock64() : 0;
+    const int gend = g0 + kend;
+    if (lane == 0) {
+      rl.s_hi = n_hi; rl.s_lo = n_lo; rl.has32 = has_e; rl.u32 = u_e; rl.ndraw += (uint32_t)pos_e;
+      if (reason == R_PHISH) phishing(x, s->green_host[gend - 1]);
+      else if (reason == R_HARD) {
+        Ctx xg = x; xg.gpre = gpre;
+        s->brm += step_green_exec(xg, gend);
+        if (bit_get(x.w->phish_mask, gend)) { bit_clr(x.w->phish_mask, gend); phishing(x, s->green_host[gend]); }
+      }
+    }
+    if (gstat && lane == 0) {
+      gstat[0] += 1; gstat[1] += reason == R_PHISH; gstat[2] += m_hard != 0; gstat[3] += cm != 0;
+      gstat[4] += t1 - t0; gstat[5] += t2 - t1; gstat[6] += clock64() - t2; gstat[7] += rounds + 1;
+    }
+    g0 = reason == R_HARD ? gend + 1 : gend;
+  }
+}
+
 template <bool LOG>
 __global__ __launch_bounds__(WAVE) void k_step(StepArgs a) {
   // numpy-PCG64 mode: one shared stream => the agent walk is strictly serial (lane 0); only the RNG-free parts
   // (row staging, end-turn Monitor roll-over over the 137 hosts, observation encode) use the other lanes.
   extern __shared__ uint4 lds[];
-  __shared__ uint8_t obs_lds[OBS_TOTAL + 2];
+  // one LDS area, two lives: the LCG window of the green actions (wave_green_exec), then -- from the end-turn roll-over on --
+  // the hosts' event bits (what the observation encode reads) and the encoded observation
+  __shared__ uint64_t win_lds[GW_OUT];
+  constexpr int OBS_LDS = (OBS_TOTAL + 2 + 7) & ~7;
+  static_assert(OBS_LDS + MAXH + 3 <= (int)sizeof(uint64_t) * GW_OUT, "observation + event bytes fit the window area");
+  uint8_t* const obs_lds = reinterpret_cast<uint8_t*>(win_lds);
+  uint8_t* const ev_lds = obs_lds + OBS_LDS;
   __shared__ int ok_lds;
   __shared__ StepWork work;
   __shared__ uint64_t gpre_lds[MAXG];
-  __shared__ uint8_t ev_lds[MAXH + 3];   // the hosts' event bits after the end-turn roll-over: what the observation encode reads
   const int e = blockIdx.x, lane = threadIdx.x;
   if (e >= a.n) return;
   unsigned long long t_begin = a.prof ? clock64() : 0;
@@ -273,11 +514,15 @@ __global__ __launch_bounds__(WAVE) void k_step(StepArgs a) {
     // agents at once on the idle lanes: the walking lane then only draws and applies (green_prepare)
     for (int g = lane; g < s->n_green; g += WAVE) { const int act = work.green_act[g]; if (act < 2) gpre_lds[g] = green_prepare(x, g, act); }
     __syncthreads();
+    // the green actions: across the wave (wave_green_exec); with the event log on, on the walking lane (log entries are ordered)
+    if (!LOG) wave_green_exec(x, rl, gpre_lds, win_lds, lane, a.prof ? a.prof + PROF_SLOTS * (size_t)e + 64 : nullptr);
     if (lane == 0) {
-      Ctx xg = x; xg.gpre = gpre_lds;
-      for (int g = 0; g < s->n_green; ++g) {
-        s->brm += step_green_exec(xg, g);
-        if (bit_get(work.phish_mask, g)) { bit_clr(work.phish_mask, g); phishing(x, s->green_host[g]); }
+      if (LOG) {
+        Ctx xg = x; xg.gpre = gpre_lds;
+        for (int g = 0; g < s->n_green; ++g) {
+          s->brm += step_green_exec(xg, g);
+          if (bit_get(work.phish_mask, g)) { bit_clr(work.phish_mask, g); phishing(x, s->green_host[g]); }
+        }
       }
       CC4_TICK(x, 6);
       step_red_exec(x);
