@@ -2309,15 +2309,20 @@ CC4_HD void step_reassign(Ctx x, uint32_t foreign) {   // foreign = red_foreign_
   }
   CC4_TICK(x, 8);
 }
-CC4_HD int step_monitor_host(Ctx x, int h) {  // the per-host part of Monitor.execute; returns the host's event bits afterwards
-  EnvState* s = x.s;
-  if (!bit_get(s->exists, h)) return 0;                     // rows of hosts that do not exist stay zero
-  const uint8_t ev = x.hd[h].ev;
+// the per-host part of Monitor.execute: this step's event bits become last step's on the hosts a blue agent watches
+CC4_HD uint8_t monitor_roll(int h, uint8_t ev) {
   if (blue_of_subnet(h_subnet(h)) < 0) return ev;
   uint8_t nev = 0;
   if (ev & EV_CUR_CONN) nev |= EV_OLD_CONN;
   if (ev & EV_CUR_PROC) nev |= EV_OLD_PROC;
-  x.hd[h].ev = nev;
+  return nev;
+}
+CC4_HD int step_monitor_host(Ctx x, int h) {  // returns the host's event bits afterwards
+  EnvState* s = x.s;
+  if (!bit_get(s->exists, h)) return 0;                     // rows of hosts that do not exist stay zero
+  const uint8_t ev = x.hd[h].ev;
+  const uint8_t nev = monitor_roll(h, ev);
+  if (nev != ev) x.hd[h].ev = nev;
   return nev;
 }
 CC4_HD void step_monitor_pend(Ctx x) {  // session.add_sus_pids for the pid-carrying process_creation events

@@ -110,6 +110,7 @@ __device__ PcgJump g_pcg_jump[WAVE + 1];          // [k]: k = 0 .. 64 steps ahea
 __device__ __forceinline__ uint64_t bcast64(uint64_t v) {
   return (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)v) | ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(v >> 32)) << 32);
 }
+__device__ __forceinline__ uint32_t rdlane(uint32_t v, int j) { return (uint32_t)__builtin_amdgcn_readlane((int)v, j); }
 __device__ __forceinline__ uint64_t lane64(uint64_t v, int src) {
   return (uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)v, src) | ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(v >> 32), src) << 32);
 }
@@ -151,8 +152,37 @@ __device__ __forceinline__ bool wave_green_policy(Rng& rl, int n, uint8_t* green
   } else if (lane == 0) rl.has32 = 0;
   return true;
 }
+// wave64 inclusive scans on the DPP network (row_shr 1/2/4/8 inside the rows of 16, then row_bcast 15 and 31 across rows) and
+// the shift by one lane that turns them into exclusive ones
+__device__ __forceinline__ uint32_t wave_scan_add(uint32_t v) {
+  int x = (int)v;
+  x += __builtin_amdgcn_update_dpp(0, x, 0x111, 0xf, 0xf, false);
+  x += __builtin_amdgcn_update_dpp(0, x, 0x112, 0xf, 0xf, false);
+  x += __builtin_amdgcn_update_dpp(0, x, 0x114, 0xf, 0xf, false);
+  x += __builtin_amdgcn_update_dpp(0, x, 0x118, 0xf, 0xf, false);
+  x += __builtin_amdgcn_update_dpp(0, x, 0x142, 0xa, 0xf, false);
+  x += __builtin_amdgcn_update_dpp(0, x, 0x143, 0xc, 0xf, false);
+  return (uint32_t)x;
+}
+__device__ __forceinline__ int wave_scan_max(int v) {   // v >= -1
+  auto mx = [](int a, int b) { return a > b ? a : b; };
+  int x = v;
+  x = mx(x, __builtin_amdgcn_update_dpp(-1, x, 0x111, 0xf, 0xf, false));
+  x = mx(x, __builtin_amdgcn_update_dpp(-1, x, 0x112, 0xf, 0xf, false));
+  x = mx(x, __builtin_amdgcn_update_dpp(-1, x, 0x114, 0xf, 0xf, false));
+  x = mx(x, __builtin_amdgcn_update_dpp(-1, x, 0x118, 0xf, 0xf, false));
+  x = mx(x, __builtin_amdgcn_update_dpp(-1, x, 0x142, 0xa, 0xf, false));
+  x = mx(x, __builtin_amdgcn_update_dpp(-1, x, 0x143, 0xc, 0xf, false));
+  return x;
+}
+__device__ __forceinline__ uint32_t wave_shr1(uint32_t v, uint32_t lane0) {   // lane k <- lane k - 1, lane 0 <- lane0
+  return (uint32_t)__builtin_amdgcn_update_dpp((int)lane0, (int)v, 0x138, 0xf, 0xf, false);
+}
 // Generator.shuffle of an n-item list, consumption only (rng_shuffle_consume): for i = n-1 .. 1 one masked-rejection draw
-// (random_interval).  All lanes; `rl` as above.
+// (random_interval).  All lanes; `rl` as above.  Which i a word is tested against depends on how many words in front of it
+// were accepted: a prefix count that depends on itself, solved by relaxation (every lane tests its two words against its
+// current estimate of i, a wave scan of the accepted counts gives the next estimates; a word's verdict only moves when i
+// crosses its masked value, so a handful of rounds settle a window of 128 words).
 __device__ __forceinline__ void wave_shuffle_consume(Rng& rl, int n, int lane) {
   if (n <= 1) return;
   uint64_t s_hi = bcast64(rl.s_hi), s_lo = bcast64(rl.s_lo);
@@ -166,30 +196,38 @@ __device__ __forceinline__ void wave_shuffle_consume(Rng& rl, int n, int lane) {
     if ((u32 & mask_of((uint32_t)i)) <= (uint32_t)i) --i;
   }
   while (i >= 1) {
-    // a window of 64 outputs = 128 words: word p = half (p & 1) of output (p >> 1) + 1
+    // a window of 64 outputs = 128 words: word p = half (p & 1) of output (p >> 1) + 1, i.e. lane p >> 1
     uint64_t h, l;
     pcg_ahead(g_pcg_jump[lane + 1], s_hi, s_lo, i_hi, i_lo, &h, &l);
     const uint64_t out = pcg_output(h, l);
     const uint32_t w0 = (uint32_t)out, w1 = (uint32_t)(out >> 32);
-    // the walk over the window's words, in stream order, on the scalar unit: word p is accepted for the current i iff
-    // (word & mask(i)) <= i, and an accepted word ends draw i (one readlane and three scalar ops per word; the only chain
-    // from word to word is i itself)
-    int cur = 0;                                     // first unconsumed word of the window
-    for (int j = 0; j < WAVE && i >= 1; ++j) {
-      const uint32_t a = (uint32_t)__builtin_amdgcn_readlane((int)w0, j), b = (uint32_t)__builtin_amdgcn_readlane((int)w1, j);
-      if ((a & mask_of((uint32_t)i)) <= (uint32_t)i) --i;
-      cur = 2 * j + 1;
-      if (i < 1) break;
-      if ((b & mask_of((uint32_t)i)) <= (uint32_t)i) --i;
-      cur = 2 * j + 2;
+    uint32_t f_cur = 3, inc = 0;                     // accepted flags of the lane's two words (first guess: all accepted)
+    for (int round = 0; round < WAVE + 2; ++round) {
+      inc = wave_scan_add((f_cur & 1u) + (f_cur >> 1));
+      const int i0 = i - (int)wave_shr1(inc, 0u);    // the i word 0 of this lane is tested against
+      const uint32_t a0 = (i0 >= 1 && (w0 & mask_of((uint32_t)(i0 >= 1 ? i0 : 1))) <= (uint32_t)i0) ? 1u : 0u;
+      const int i1 = i0 - (int)a0;
+      const uint32_t a1 = (i1 >= 1 && (w1 & mask_of((uint32_t)(i1 >= 1 ? i1 : 1))) <= (uint32_t)i1) ? 1u : 0u;
+      const uint32_t f_new = a0 | (a1 << 1);
+      const bool moved = f_new != f_cur;
+      f_cur = f_new;
+      if (!__ballot(moved)) break;                   // lane k is exact after k + 1 rounds at the latest
     }
+    const int total = (int)rdlane(inc, WAVE - 1);
+    int cur = 2 * WAVE;                              // first unconsumed word of the window
+    if (total >= i) {                                // the draw for i = 1 ends inside the window: behind the i-th accepted word
+      const uint64_t m = __ballot((int)inc >= i);
+      const int L = __ffsll((unsigned long long)m) - 1;
+      const int before = L ? (int)rdlane(inc, L - 1) : 0;
+      const uint32_t fl = rdlane(f_cur, L);
+      cur = 2 * L + ((before + (int)(fl & 1u) >= i) ? 1 : 2);
+      i = 0;
+    } else i -= total;
     const int K = (cur + 1) >> 1;                    // outputs of this window that were touched
-    if (K > 0) {
-      s_hi = lane64(h, K - 1); s_lo = lane64(l, K - 1);
-      u32 = (uint32_t)__builtin_amdgcn_readlane((int)w1, K - 1);
-      has32 = (uint32_t)(cur & 1);
-      adv += (uint32_t)K;
-    }
+    s_hi = lane64(h, K - 1); s_lo = lane64(l, K - 1);
+    u32 = rdlane(w1, K - 1);
+    has32 = (uint32_t)(cur & 1);
+    adv += (uint32_t)K;
   }
   if (lane == 0) { rl.s_hi = s_hi; rl.s_lo = s_lo; rl.has32 = has32; rl.u32 = u32; rl.ndraw += adv; }
 }
@@ -217,33 +255,6 @@ constexpr uint64_t P01_FLOOR = (uint64_t)P01_SCALED;
 static_assert((double)P01_FLOOR * (1.0 / 9007199254740992.0) < 0.01 && (double)(P01_FLOOR + 1) * (1.0 / 9007199254740992.0) >= 0.01,
               "integer form of rng_random() < 0.01");
 enum : uint32_t { GR_VALID = 1, GR_FAIL = 2, GR_EPH = 4, GR_CONN = 8, GR_PROC = 16, GR_HARD = 32, GR_PHISH = 64 };
-__device__ __forceinline__ uint32_t rdlane(uint32_t v, int j) { return (uint32_t)__builtin_amdgcn_readlane((int)v, j); }
-// wave64 inclusive scans on the DPP network (row_shr 1/2/4/8 inside the rows of 16, then row_bcast 15 and 31 across rows) and
-// the shift by one lane that turns them into exclusive ones
-__device__ __forceinline__ uint32_t wave_scan_add(uint32_t v) {
-  int x = (int)v;
-  x += __builtin_amdgcn_update_dpp(0, x, 0x111, 0xf, 0xf, false);
-  x += __builtin_amdgcn_update_dpp(0, x, 0x112, 0xf, 0xf, false);
-  x += __builtin_amdgcn_update_dpp(0, x, 0x114, 0xf, 0xf, false);
-  x += __builtin_amdgcn_update_dpp(0, x, 0x118, 0xf, 0xf, false);
-  x += __builtin_amdgcn_update_dpp(0, x, 0x142, 0xa, 0xf, false);
-  x += __builtin_amdgcn_update_dpp(0, x, 0x143, 0xc, 0xf, false);
-  return (uint32_t)x;
-}
-__device__ __forceinline__ int wave_scan_max(int v) {   // v >= -1
-  auto mx = [](int a, int b) { return a > b ? a : b; };
-  int x = v;
-  x = mx(x, __builtin_amdgcn_update_dpp(-1, x, 0x111, 0xf, 0xf, false));
-  x = mx(x, __builtin_amdgcn_update_dpp(-1, x, 0x112, 0xf, 0xf, false));
-  x = mx(x, __builtin_amdgcn_update_dpp(-1, x, 0x114, 0xf, 0xf, false));
-  x = mx(x, __builtin_amdgcn_update_dpp(-1, x, 0x118, 0xf, 0xf, false));
-  x = mx(x, __builtin_amdgcn_update_dpp(-1, x, 0x142, 0xa, 0xf, false));
-  x = mx(x, __builtin_amdgcn_update_dpp(-1, x, 0x143, 0xc, 0xf, false));
-  return x;
-}
-__device__ __forceinline__ uint32_t wave_shr1(uint32_t v, uint32_t lane0) {   // lane k <- lane k - 1, lane 0 <- lane0
-  return (uint32_t)__builtin_amdgcn_update_dpp((int)lane0, (int)v, 0x138, 0xf, 0xf, false);
-}
 __device__ __forceinline__ void wave_green_exec(Ctx x, Rng& rl, const uint64_t* gpre, uint64_t* win, int lane, unsigned long long* gstat = nullptr) {
   EnvState* s = x.s;
   const int ng = s->n_green;
@@ -531,7 +542,22 @@ __global__ __launch_bounds__(WAVE) void k_step(StepArgs a) {
   }
   __syncthreads();
   if (ok_lds) {
-    for (int h = lane; h < MAXH; h += WAVE) ev_lds[h] = (uint8_t)step_monitor_host(x, h);
+    {
+      // end-turn Monitor roll-over; the host table is in HBM here: all of a lane's event bytes are requested before the first
+      // one is rolled (a plain loop waits for each round trip in turn behind the store of the previous host)
+      constexpr int NK = (MAXH + WAVE - 1) / WAVE;
+      uint8_t evv[NK];
+#pragma unroll
+      for (int k = 0; k < NK; ++k) { const int h = lane + k * WAVE; evv[k] = (h < MAXH && bit_get(s->exists, h)) ? hd[h].ev : (uint8_t)0; }
+#pragma unroll
+      for (int k = 0; k < NK; ++k) {
+        const int h = lane + k * WAVE;
+        if (h >= MAXH) continue;
+        const uint8_t nev = bit_get(s->exists, h) ? monitor_roll(h, evv[k]) : (uint8_t)0;
+        if (nev != evv[k]) hd[h].ev = nev;
+        ev_lds[h] = nev;
+      }
+    }
     if (lane == 0) step_monitor_pend(x);
     __syncthreads();
     {

@@ -13,7 +13,7 @@ T = int(sys.argv[3]) if len(sys.argv) > 3 else 220
 EP = int(sys.argv[4]) if len(sys.argv) > 4 else 150   # episode length (autoreset after it)
 bad = 0
 for k in range(rounds):
-    for mode, rp in ((1, 0), (1, 3), (0, 0), (1, 2)):
+    for mode, rp in ((1, 0), (1, 3), (0, 0), (1, 2), (0, 3), (0, 2)):
         seed = 50000 + 1000 * k + 17 * mode + rp
         dev = CC4VecEnv(n, steps=EP, rng_mode=mode, autoreset=True, red_policy=rp)
         ora = OracleVecEnv(n, steps=EP, rng_mode=mode, autoreset=True, red_policy=rp)
