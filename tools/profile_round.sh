@@ -29,5 +29,9 @@ python tools/phase_profile.py 8192 200 1 > $OUT/${TAG}_phase_cycles_philox_8192e
 python tools/phase_profile.py 1024 100 0 > $OUT/${TAG}_phase_cycles_pcg64_1024env.txt 2>&1
 python tools/tail_whatif.py 1024 200 > $OUT/${TAG}_tail_whatif.txt 2>&1
 python tools/tail_profile.py 1024 100 1 > $OUT/${TAG}_tail_philox.txt 2>&1
+# 5. numpy-stream kernel: kernel stats at 8192 episodes, what the lane-parallel green actions do per step
+rocprofv3 --kernel-trace --stats -d $OUT/statspcg -- $BENCH --rng pcg64 > $OUT/bench_statspcg.json 2> $OUT/statspcg.err
+python tools/rocpd_summary.py stats $OUT/statspcg $OUT/${TAG}_kernel_stats_8192env_pcg64.txt > /dev/null
+python tools/green_batches.py 1024 50 > $OUT/${TAG}_green_batches_pcg64_1024env.txt 2>&1
 ls -la $OUT | head -50
-rm -rf $OUT/stats8192 $OUT/stats1024 $OUT/fetch* $OUT/write* $OUT/mix?   # the raw databases are large; the summaries stay
+rm -rf $OUT/stats8192 $OUT/stats1024 $OUT/statspcg $OUT/fetch* $OUT/write* $OUT/mix?   # the raw databases are large; the summaries stay
