@@ -270,16 +270,18 @@ def main():
         other = 'pcg64' if args.rng == 'philox' else 'philox'
         e2 = make_env(n_local, RNG_PCG64 if other == 'pcg64' else RNG_PHILOX, lo)
         r2 = measure(e2, lo, total_envs)
+        k2 = e2.step_kernel
         e2.close()
-        r2.update({'rng': other, 'kernel': 'k_step' if other == 'pcg64' else 'k_step_philox', 'unit': 'agent-env steps/s', 'total_envs': total_envs,
+        r2.update({'rng': other, 'kernel': k2, 'unit': 'agent-env steps/s', 'total_envs': total_envs,
                    'note': 'pcg64 = numpy Generator(PCG64) stream, bit-exact with the reference under the same seed' if other == 'pcg64'
                            else 'philox = counter-based streams per (agent, phase, step, episode)'})
         subs['alt_rng'] = r2
         if total_envs != 1024:
             e4 = make_env(1024, mode, 0)
             r4 = measure(e4, 0, 1024)
+            k4 = e4.step_kernel
             e4.close()
-            r4.update({'rng': args.rng, 'unit': 'agent-env steps/s', 'total_envs': 1024,
+            r4.update({'rng': args.rng, 'kernel': k4, 'unit': 'agent-env steps/s', 'total_envs': 1024,
                        'note': 'BASELINE configs[1]: 1024 episodes on one GPU = the per-GPU share of the 8-GPU job (latency regime: 4 blocks per CU, one round)'})
             subs['envs_1024'] = r4
         if args.rng == 'philox':
@@ -325,7 +327,7 @@ def main():
             },
             'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBPS, 'unit': 'GB/s',
                          'frac': achieved / HBM_PEAK_GBPS, 'traffic': traffic, 'traffic_source': traffic_src,
-                         'kernel': 'k_step_philox' if args.rng == 'philox' else 'k_step', 'launch_ms': launch_ms,
+                         'kernel': env.step_kernel, 'launch_ms': launch_ms,
                          'algorithmic_bytes_per_launch': bytes_per_env * n_local,
                          'useful_bytes_per_launch': useful * n_local, 'useful_frac': useful * n_local / (launch_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
                          'useful_note': f'live bytes only: agent part {hot} B + 64 B x {mean_hosts:.1f} existing hosts (of 137 grid positions), in and out'},

@@ -891,6 +891,193 @@ __global__ __launch_bounds__(PT, MINW) void k_step_philox(StepArgs a) {
   if (prof) { __syncthreads(); if (tid < 15) a.prof[PROF_SLOTS * (size_t)e + tid] += prof_lds[tid]; }
 }
 
+// ---------------------------------------------------------------- Philox mode, one wavefront per episode
+// The same step as k_step_philox with the agents on the LANES of a single wave instead of on four waves: red agent r on lane
+// r, blue agent b on lane 8 + b for its submission and on lane b for its action, green agent g on lane g % 64.  A block of
+// four waves spends most of its resident time with three waves parked at a barrier behind the one that carries the red
+// agents; with one wave per episode every resident wave works, and as a wave64 instruction occupies its SIMD for four
+// cycles whatever the number of active lanes, what counts at large batches is the number of instructions per episode, not
+// their spread over waves.  Like the numpy-stream kernel it stages only the agent part of the row (6 992 B) and leaves the
+// host table in HBM / L2, so 16 episodes are resident per CU (LDS) instead of 7-8.  The build for throughput-bound batches;
+// k_step_philox keeps the shorter single-launch latency of small ones (cc4_create picks; CC4_PHILOX_LEAN overrides).
+template <bool LOG>
+__global__ __launch_bounds__(WAVE) void k_step_philox1(StepArgs a) {
+  extern __shared__ uint4 lds[];
+  // reset: pid bitmaps of the scenario generation; afterwards: the hosts' event bytes after the roll-over and the byte copy of
+  // the observations for the packed exchange row
+  __shared__ alignas(16) uint32_t ws[RESET_WS_WORDS];
+  constexpr int OBS_LDS = (OBS_TOTAL + 2 + 7) & ~7;
+  static_assert(OBS_LDS + MAXH + 3 <= (int)sizeof(uint32_t) * RESET_WS_WORDS, "observation + event bytes fit the reset work area");
+  uint8_t* const obs_bytes = reinterpret_cast<uint8_t*>(ws);
+  uint8_t* const ev_lds = obs_bytes + OBS_LDS;
+  __shared__ StepWork work;
+  __shared__ int conflict_lds;
+  __shared__ unsigned long long prof_lds[16];
+  const int e = blockIdx.x, lane = threadIdx.x;
+  if (e >= a.n) return;
+  unsigned long long t_begin = a.prof ? clock64() : 0;
+  const uint4* src = reinterpret_cast<const uint4*>(a.st + e);
+  stage_in<HOT_VEC>(lds, src, lane);
+  for (int i = lane; i < (int)(sizeof(StepWork) / 4); i += WAVE) reinterpret_cast<uint32_t*>(&work)[i] = 0;
+  unsigned long long* prof = a.prof ? prof_lds : nullptr;
+  if (prof && lane < 16) prof_lds[lane] = 0;
+  if (lane == 0) conflict_lds = 0;
+  __syncthreads();
+  EnvState* s = reinterpret_cast<EnvState*>(lds);   // only the part in front of EnvState.hd is valid here
+  HostDyn* const hd = a.st[e].hd;                   // the host table stays in HBM / L2
+  if (prof && lane == 0) prof[11] += clock64() - t_begin;
+  const bool do_reset = a.autoreset && s->done;
+  bool rolled = false;                              // ev_lds holds the event bytes (the end-turn roll-over ran)
+  if (do_reset) {
+    // new episode on the same key (CybORG.reset(seed=None)): the phases of env_reset_counter_mode, hosts on lanes
+    reset_zero(s, hd, a.cold + e, lane, WAVE);
+    __syncthreads();
+    Rng rr; ResetCarry carry; carry.env_key = 0;     // lane 0: main reset stream in registers, across the phases
+    Ctx xm{s, a.cold + e, &rr, hd, &work};
+    if (lane == 0) { rr = s->rng; rr.mode = 1; carry = reset_topology(xm, 0, a.steps, true, a.policy, a.topo, ws, true); }
+    __syncthreads();
+    Rng rh; rng_fork(&rh, &s->rng, ST_GEN_HOST); rh.mode = 1;
+    Ctx xh{s, a.cold + e, &rh, hd, &work};
+    for (int h = lane; h < MAXH; h += WAVE) reset_gen_host(xh, h);
+    __syncthreads();
+    for (int h = lane; h < MAXH; h += WAVE) reset_pid_mark(xh, h, ws);
+    __syncthreads();
+    for (int h = lane; h < MAXH; h += WAVE) reset_pid_flag(xh, h, ws);
+    __syncthreads();
+    if (lane == 0) { reset_pid_resolve(xm, ws); reset_agents(xm); }
+    __syncthreads();
+    for (int h = lane; h < MAXH; h += WAVE) reset_host_sessions(xh, h);
+    __syncthreads();
+    if (lane == 0) { reset_finish(xm, carry, a.steps, a.topo, true); a.reward[e] = s->reward; a.done[e] = s->done; }
+    __syncthreads();
+  } else {
+    const int st_now = s->step_count;
+    const bool step_ok = step_phase_of(st_now, s->phase_len[0], s->phase_len[1], s->phase_len[2]) >= 0;
+    if (lane == 0) {
+      Ctx x{s, a.cold + e, &s->rng, hd, &work, prof};
+      x.lg = LOG ? &a.cold[e].evlog : nullptr;
+      CC4_TICK0(x);
+      (void)step_phase(x, false);
+    }
+    if (step_ok) {
+      const int ng = s->n_green;
+      // one lane-private generator per lane, in registers: every use starts with rng_set_stream(); mode pinned so the PCG
+      // paths fold away
+      Rng rl;
+      rng_fork(&rl, &s->rng, ST_RESET);
+      rl.mode = 1;
+      rng_begin_step(&rl, (uint32_t)st_now);   // not read from the row: lane 0 may still be storing it there
+      EvLog* const lg = LOG ? &a.cold[e].evlog : nullptr;
+      Ctx x0{s, a.cold + e, &rl, hd, &work, lane == 0 ? prof : nullptr};
+      x0.lg = lg;
+      if (lane == 0) CC4_TICK(x0, 0);
+      const bool is_red = lane < NRED;
+      unsigned long long* ap = (a.prof && is_red) ? a.prof + PROF_SLOTS * (size_t)e + 16 + 8 * lane : nullptr;
+      Ctx xr{s, a.cold + e, &rl, hd, &work, nullptr, ap, lg};
+      Ctx xg{s, a.cold + e, &rl, hd, &work, nullptr, nullptr, lg};
+      // ---- P0-P3a: every agent's policy / submission and its own duration-queue tick (SC:236-265)
+      if (is_red) {
+        unsigned long long t0 = ap ? clock64() : 0;
+        const int dropped = step_red_policy_tick(xr, lane);
+        if (ap) ap[0] += clock64() - t0;
+        if (dropped) atomicSub(&s->n_actions, 1);
+      } else if (lane >= 8 && lane < 8 + NBLUE) {
+        const int b = lane - 8;
+        int32_t act = a.actions ? a.actions[e * NBLUE + b] : -1;
+        if (a.rand_out) { act = random_blue_action(a.rand_seed0, a.rand_t, e, b); a.rand_out[e * NBLUE + b] = act; }
+        step_blue_submit(xg, b, act);
+        step_tick_blue(xg, b);
+        step_messages(s, a.msgs ? a.msgs + e * NBLUE * MSG_LEN : nullptr, b);   // read back by this step's observation encode only
+      }
+      for (int g = lane; g < ng; g += WAVE) step_green_policy(xg, g);
+      __syncthreads();
+      CC4_TICK(x0, 2);
+      // ---- P3b blue actions: side by side when they are independent (no Monitor, no pending pid events)
+      if (blue_exec_independent(s)) {
+        if (lane == 0) CC4_TICK(x0, 3);
+        if (lane < NBLUE) step_blue_exec_agent(xg, lane);
+        __syncthreads();
+        if (lane == 0) CC4_TICK(x0, 5);
+      } else {
+        if (lane == 0) step_blue_exec(x0);
+        __syncthreads();
+      }
+      // ---- P4 green actions, one agent per lane
+      {
+        int pen = 0;
+        for (int g = lane; g < ng; g += WAVE) pen += step_green_exec(xg, g);
+        if (pen) atomicAdd(&s->brm, pen);
+      }
+      __syncthreads();
+      CC4_TICK(x0, 6);
+      // ---- P5 deferred phishing (ordered), then P6 red actions: side by side when they name distinct hosts
+      if (lane == 0) { step_phishing(x0); CC4_TICK(x0, 1); rs_reserve(x0); conflict_lds = (int)red_conflict_mask(s); if (prof && conflict_lds) prof[4] += 1000000; }
+      __syncthreads();
+      const uint32_t serial_red = (uint32_t)conflict_lds;
+      if (is_red && !((serial_red >> lane) & 1u)) {
+        unsigned long long t0 = ap ? clock64() : 0;
+        step_red_exec_agent(xr, lane);
+        if (ap) ap[1] += clock64() - t0;
+      }
+      __syncthreads();
+      if (serial_red) {   // same-host actions (and everything when some agent withdraws): agent order on lane 0
+        if (lane == 0) for (int r = 0; r < NRED; ++r) if ((serial_red >> r) & 1u) step_red_exec_agent(x0, r);
+        __syncthreads();
+      }
+      if (lane == 0) {
+        step_red_merge(x0);
+        CC4_TICK(x0, 7);
+        step_reassign(x0, red_foreign_agents(s));
+        CC4_TICK(x0, 8);
+      }
+      {
+        // P7 end-turn Monitor roll-over; the host table is in HBM here: all of a lane's event bytes are requested before the
+        // first one is rolled
+        constexpr int NK = (MAXH + WAVE - 1) / WAVE;
+        uint8_t evv[NK];
+#pragma unroll
+        for (int k = 0; k < NK; ++k) { const int h = lane + k * WAVE; evv[k] = (h < MAXH && bit_get(s->exists, h)) ? hd[h].ev : (uint8_t)0; }
+#pragma unroll
+        for (int k = 0; k < NK; ++k) {
+          const int h = lane + k * WAVE;
+          if (h >= MAXH) continue;
+          const uint8_t nev = bit_get(s->exists, h) ? monitor_roll(h, evv[k]) : (uint8_t)0;
+          if (nev != evv[k]) hd[h].ev = nev;
+          ev_lds[h] = nev;
+        }
+        rolled = true;
+      }
+      __syncthreads();
+      CC4_TICK(x0, 9);
+      // ---- P8 end-turn RedSessionCheck on the red lanes; the Monitor's sus-pid hand-over and the step's bookkeeping on the last
+      if (is_red) { unsigned long long t0 = ap ? clock64() : 0; step_rsc(xr, lane); if (ap) ap[2] += clock64() - t0; }
+      if (lane == WAVE - 1) {
+        step_monitor_pend(xg);
+        step_end(xg, nullptr, false);
+        a.reward[e] = s->reward; a.done[e] = s->done;
+      }
+      CC4_TICK(x0, 10);
+    } else if (lane == 0) { a.reward[e] = s->reward; a.done[e] = s->done; }
+  }
+  __syncthreads();
+  unsigned long long t_obs = a.prof ? clock64() : 0;
+  if (!rolled) { for (int h = lane; h < MAXH; h += WAVE) ev_lds[h] = hd[h].ev; __syncthreads(); }   // after a reset / a refused step
+  {
+    int32_t* o = a.obs + (size_t)e * OBS_TOTAL;
+    const bool pack = a.obs8 != nullptr;
+    const int nv = (do_reset || a.full_obs || pack || s->obs_dirty) ? OBS_TOTAL : OBS_FAST;
+    for (int v = lane; v < nv; v += WAVE) { int i; const int val = env_flat_obs_sorted(s, hd, v, &i, ev_lds); o[i] = val; if (pack) obs_bytes[i] = (uint8_t)val; }
+  }
+  __syncthreads();
+  if (lane == 0) a.err[e] = s->err;
+  if (a.obs8) { uint8_t* o8 = a.obs8 + (size_t)e * OBS_PACKED; for (int j = lane; j < OBS_PACKED; j += WAVE) o8[j] = pack_obs_byte(obs_bytes, j); }
+  unsigned long long t_out = a.prof ? clock64() : 0;
+  if (prof && lane == 0) prof[12] += t_out - t_obs;
+  stage_out<HOT_VEC>(reinterpret_cast<uint4*>(a.st + e), lds, lane);
+  if (prof && lane == 0) { prof[13] += clock64() - t_out; prof[14] += clock64() - t_begin; }
+  if (prof) { __syncthreads(); if (lane < 15) a.prof[PROF_SLOTS * (size_t)e + lane] += prof_lds[lane]; }
+}
+
 struct ResetArgs {
   EnvState* st; EnvCold* cold; const uint64_t* seeds; const uint8_t* env_mask;
   int32_t* obs; float* reward; uint8_t* done; uint32_t* err; uint8_t* mask;
@@ -1026,6 +1213,7 @@ struct cc4_handle {
   uint8_t* d_unpacked = nullptr;                 // [world*N][578] bytes: cc4_unpack_obs_device
   int evlog_on = 0;               // cc4_enable_event_log
   bool full_obs_next = true;      // the next step launch rewrites every observation value (fresh handle, restored state)
+  bool philox_lean = false;       // k_step_philox1 (one wave per episode) instead of k_step_philox (cc4_create)
   int philox_minw = 1;            // which register budget of k_step_philox this batch size runs (1, 7 or 8 blocks per CU; cc4_create)
   ncclComm_t comm = nullptr; int rank = 0, world = 1;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -1075,7 +1263,11 @@ static int launch_step(cc4_handle* h, const int32_t* d_actions, const uint8_t* d
   hipEvent_t stop = h->comm ? h->ev_step[buf] : nullptr;
   h->step_event_attached = stop != nullptr;
   if (h->cfg.rng_mode == 1) {
-    if (h->evlog_on) hipExtLaunchKernelGGL((k_step_philox<true, 1>), grid, dim3(PT), sizeof(EnvState), h->stream, nullptr, stop, 0, a);
+    if (h->philox_lean) {
+      if (h->evlog_on) hipExtLaunchKernelGGL(k_step_philox1<true>, grid, dim3(WAVE), offsetof(EnvState, hd), h->stream, nullptr, stop, 0, a);
+      else hipExtLaunchKernelGGL(k_step_philox1<false>, grid, dim3(WAVE), offsetof(EnvState, hd), h->stream, nullptr, stop, 0, a);
+    }
+    else if (h->evlog_on) hipExtLaunchKernelGGL((k_step_philox<true, 1>), grid, dim3(PT), sizeof(EnvState), h->stream, nullptr, stop, 0, a);
     else if (h->philox_minw == 8) hipExtLaunchKernelGGL((k_step_philox<false, 8>), grid, dim3(PT), sizeof(EnvState), h->stream, nullptr, stop, 0, a);
     else if (h->philox_minw == 7) hipExtLaunchKernelGGL((k_step_philox<false, 7>), grid, dim3(PT), sizeof(EnvState), h->stream, nullptr, stop, 0, a);
     else hipExtLaunchKernelGGL((k_step_philox<false, 1>), grid, dim3(PT), sizeof(EnvState), h->stream, nullptr, stop, 0, a);
@@ -1097,6 +1289,11 @@ size_t cc4_algorithmic_bytes_per_env_step(void) {
   return 2 * sizeof(EnvState) + 4 * OBS_TOTAL + 4 * NBLUE + 4 + 1 + 4;
 }
 size_t cc4_hot_bytes(void) { return offsetof(EnvState, hd); }
+const char* cc4_step_kernel(cc4_handle* h) {
+  if (!h) return "";
+  if (h->cfg.rng_mode != 1) return "k_step";
+  return h->philox_lean ? "k_step_philox1" : "k_step_philox";
+}
 
 int cc4_create(const cc4_config* cfg, cc4_handle** out) {
   if (!cfg || !out || cfg->num_envs <= 0 || cfg->steps <= 0 || cfg->red_policy < 0 || cfg->red_policy > 3 ||
@@ -1131,6 +1328,11 @@ int cc4_create(const cc4_config* cfg, cc4_handle** out) {
     const int bpc = (cfg->num_envs + cus - 1) / cus;                     // episode blocks per CU
     h->philox_minw = bpc <= 5 ? 1 : (bpc == 8 ? 8 : 7);      // exactly 8 per CU (2048 episodes on 256 CUs) is one round of the 8-block build
     if (const char* v = getenv("CC4_PHILOX_MINW")) h->philox_minw = atoi(v);   // tuning override: 1, 7 or 8
+    // more than ten episodes per CU: the one-wave-per-episode build.  Measured on MI355X (r02, M agent-env steps/s, four waves
+    // / one wave per episode): 1024 episodes 168 / 131, 1536: 228 / 185, 2048: 262 / 237, 3072: 294 / 322, 4096: 319 / 395,
+    // 8192: 391 / 479, 16384: 414 / 540, 32768: 433 / 557
+    h->philox_lean = bpc > 10;
+    if (const char* v = getenv("CC4_PHILOX_LEAN")) h->philox_lean = atoi(v) != 0;   // tuning / test override
   }
   HIPCHK(h, hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
   size_t n = (size_t)cfg->num_envs;

@@ -182,6 +182,11 @@ class CC4VecEnv:
             w[i] = pcg64_words(g)
         self._chk(self.lib.cc4_set_rng_state(self._h, w.ctypes.data_as(ctypes.c_void_p)), 'cc4_set_rng_state')
 
+    @property
+    def step_kernel(self):
+        """cc4_step_kernel: the kernel this handle's steps launch ('k_step', 'k_step_philox' or 'k_step_philox1')."""
+        return self.lib.cc4_step_kernel(self._h).decode()
+
     def rng_state(self):
         out = np.zeros((self.num_envs, 7), np.uint64)
         self._chk(self.lib.cc4_get_rng_state(self._h, out.ctypes.data_as(ctypes.c_void_p)), 'cc4_get_rng_state')

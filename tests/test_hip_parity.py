@@ -14,6 +14,14 @@ def _dev(n, **kw):
     return CC4VecEnv(n, **kw)
 
 
+@pytest.fixture(params=[0, 1], ids=['4wave', '1wave'])
+def philox_kernel(request, monkeypatch):
+    """The counter mode has two step kernels -- four wavefronts per episode (small batches) and one (more than ten episodes
+    per CU), picked by cc4_create from the batch size; CC4_PHILOX_LEAN forces one, so that the small test batches cover both."""
+    monkeypatch.setenv('CC4_PHILOX_LEAN', str(request.param))
+    return ('k_step_philox', 'k_step_philox1')[request.param]
+
+
 def test_hip_matches_reference_golden_trajectories():
     """All golden episodes stepped together in ONE batch: each env its own seed / init mode / action script."""
     fixes = [G.load(p) for p in G.list_fixtures()]
@@ -62,10 +70,13 @@ def test_hip_policy_variants_match_reference_golden():
 
 @pytest.mark.parametrize('policies', [(0, 0), (2, 0), (1, 1), (3, 0)], ids=['fsm', 'discovery', 'sleep', 'randomselect'])
 @pytest.mark.parametrize('rng_mode', [0, 1], ids=['pcg64', 'philox'])
-def test_hip_matches_oracle_bit_for_bit(rng_mode, policies):
+def test_hip_matches_oracle_bit_for_bit(rng_mode, policies, philox_kernel):
+    if rng_mode == 0 and philox_kernel != 'k_step_philox':
+        pytest.skip('one numpy-stream kernel')
     n, T = 96, 160
     rp, gp = policies
     dev = _dev(n, steps=150, rng_mode=rng_mode, autoreset=True, red_policy=rp, green_policy=gp)
+    assert dev.step_kernel == ('k_step' if rng_mode == 0 else philox_kernel)
     ora = OracleVecEnv(n, steps=150, rng_mode=rng_mode, autoreset=True, red_policy=rp, green_policy=gp)
     assert np.array_equal(dev.reset(seeds=31337), ora.reset(seeds=31337))
     assert np.array_equal(dev.action_mask, ora.mask())
@@ -87,13 +98,16 @@ def test_hip_matches_oracle_bit_for_bit(rng_mode, policies):
 
 
 @pytest.mark.parametrize('rng_mode', [0, 1], ids=['pcg64', 'philox'])
-def test_full_batch_matches_oracle_every_step(rng_mode):
+def test_full_batch_matches_oracle_every_step(rng_mode, philox_kernel):
     """BASELINE configs[1] size: all 1024 episodes against the oracle at every step (observations, rewards, dones, error
     flags), across an episode end (autoreset), and the packed state of every episode at the end.  A batch this size meets
     the rare interleavings (same-step phishing + reassignment, concurrent blue Restore / red exploit on neighbouring
     tables) that the 96-episode matrix can miss."""
+    if rng_mode == 0 and philox_kernel != 'k_step_philox':
+        pytest.skip('one numpy-stream kernel')
     n, T = 1024, 260
     dev = _dev(n, steps=220, rng_mode=rng_mode, autoreset=True)
+    assert dev.step_kernel == ('k_step' if rng_mode == 0 else philox_kernel)
     ora = OracleVecEnv(n, steps=220, rng_mode=rng_mode, autoreset=True)
     assert np.array_equal(dev.reset(seeds=777), ora.reset(seeds=777))
     for t in range(T):
@@ -193,7 +207,7 @@ def test_rccl_allgather_world_size_one():
     dev.close()
 
 
-def test_snapshot_restore_replays_identically():
+def test_snapshot_restore_replays_identically(philox_kernel):
     """SURVEY 8(f)-4 (snapshot tooling): state + cold row of one episode captured, the episode advanced, restored and advanced
     again -> identical trajectory; the other episodes of the batch are unaffected."""
     dev = _dev(4, steps=100); dev.reset(seeds=9)
@@ -499,7 +513,7 @@ def test_soak_decoy_only_blue_never_overflows(rng_mode):
 
 
 @pytest.mark.parametrize('kind', ['restore', 'remove'])
-def test_structured_blue_policies_match_oracle(kind):
+def test_structured_blue_policies_match_oracle(kind, philox_kernel):
     """Restore-only / Remove-only blue (both RNG modes): HIP == oracle every step and in the packed state."""
     n = 64
     for rng_mode in (0, 1):
@@ -517,7 +531,7 @@ def test_structured_blue_policies_match_oracle(kind):
         dev.close()
 
 
-def test_exchange_row_of_a_reset_and_device_unpack():
+def test_exchange_row_of_a_reset_and_device_unpack(philox_kernel):
     """cc4_allgather_obs right after cc4_reset gathers the RESET observations (k_reset writes the packed exchange
     row); cc4_get_allgathered_obs reads the buffer of the last all-gather, not of the last step; cc4_unpack_obs_device turns
     the gathered 2-bit rows into [world*N, 578] bytes on the device."""
@@ -605,7 +619,7 @@ def test_bench_two_ranks_on_one_gpu_shards_and_reports():
     assert d2['value'] > 0 and d2['roofline']['launch_ms'] > 0
 
 
-def test_counter_mode_event_log_ports_do_not_change_the_trajectory():
+def test_counter_mode_event_log_ports_do_not_change_the_trajectory(philox_kernel):
     """rng_mode 1 with cc4_enable_event_log: the ephemeral ports of the logged events come from side streams, so (a) the episode
     is the same with and without the log, (b) HIP and oracle write the same event records, (c) the ports are really drawn."""
     import json
