@@ -48,6 +48,8 @@ struct StepArgs {
   int full_obs;               // rewrite every observation value (the output buffer may hold another episode's slowly varying part)
   uint32_t topo;              // cc4_config.topology_seed
   unsigned long long* prof;   // optional [n][PROF_SLOTS] cycle counters (cc4_debug_profile): 16 phase slots + 8 per red agent
+  uint32_t* reset_ws;         // k_step_philox1: [n][RESET_WS_WORDS] work area of the in-kernel scenario generation (the other
+                              // kernels keep it in LDS; an episode regenerates once in steps-per-episode launches)
 };
 
 // uniform blue action index of (episode e, agent b) at step t: Philox key (seed0 + e), counter (t, b, 0xB10E, 0)
@@ -903,13 +905,8 @@ __global__ __launch_bounds__(PT, MINW) void k_step_philox(StepArgs a) {
 template <bool LOG>
 __global__ __launch_bounds__(WAVE) void k_step_philox1(StepArgs a) {
   extern __shared__ uint4 lds[];
-  // reset: pid bitmaps of the scenario generation; afterwards: the hosts' event bytes after the roll-over and the byte copy of
-  // the observations for the packed exchange row
-  __shared__ alignas(16) uint32_t ws[RESET_WS_WORDS];
-  constexpr int OBS_LDS = (OBS_TOTAL + 2 + 7) & ~7;
-  static_assert(OBS_LDS + MAXH + 3 <= (int)sizeof(uint32_t) * RESET_WS_WORDS, "observation + event bytes fit the reset work area");
-  uint8_t* const obs_bytes = reinterpret_cast<uint8_t*>(ws);
-  uint8_t* const ev_lds = obs_bytes + OBS_LDS;
+  __shared__ uint8_t obs_bytes[OBS_TOTAL + 2];   // byte copy of the observations, only for the packed exchange row
+  __shared__ uint8_t ev_lds[MAXH + 3];           // the hosts' event bytes after the end-turn roll-over: what the observation encode reads
   __shared__ StepWork work;
   __shared__ int conflict_lds;
   __shared__ unsigned long long prof_lds[16];
@@ -929,7 +926,9 @@ __global__ __launch_bounds__(WAVE) void k_step_philox1(StepArgs a) {
   const bool do_reset = a.autoreset && s->done;
   bool rolled = false;                              // ev_lds holds the event bytes (the end-turn roll-over ran)
   if (do_reset) {
-    // new episode on the same key (CybORG.reset(seed=None)): the phases of env_reset_counter_mode, hosts on lanes
+    // new episode on the same key (CybORG.reset(seed=None)): the phases of env_reset_counter_mode, hosts on lanes; the pid
+    // bitmaps of the generation live in HBM here (LDS bounds this kernel's residency, and this path runs once per episode)
+    uint32_t* const ws = a.reset_ws + (size_t)e * RESET_WS_WORDS;
     reset_zero(s, hd, a.cold + e, lane, WAVE);
     __syncthreads();
     Rng rr; ResetCarry carry; carry.env_key = 0;     // lane 0: main reset stream in registers, across the phases
@@ -1210,6 +1209,7 @@ struct cc4_handle {
   int gather_buf = -1;                           // buffer of the most recent all-gather (-1: none issued)
   bool step_event_attached = false;              // ev_step[obs_buf] was recorded by the launch of that step itself
   unsigned long long* d_prof = nullptr;
+  uint32_t* d_reset_ws = nullptr;    // k_step_philox1's generation work area, [num_envs][RESET_WS_WORDS]
   uint8_t* d_unpacked = nullptr;                 // [world*N][578] bytes: cc4_unpack_obs_device
   int evlog_on = 0;               // cc4_enable_event_log
   bool full_obs_next = true;      // the next step launch rewrites every observation value (fresh handle, restored state)
@@ -1255,7 +1255,7 @@ static int launch_step(cc4_handle* h, const int32_t* d_actions, const uint8_t* d
              h->comm ? h->d_obs8[buf] : nullptr, rand ? h->d_actions : nullptr, seed0, t,
              h->cfg.num_envs, h->cfg.autoreset, h->cfg.steps, h->cfg.rng_mode,
              (h->cfg.red_policy & 3) | (h->cfg.green_policy ? GP_SLEEP_BIT : 0), h->full_obs_next ? 1 : 0,
-             (uint32_t)h->cfg.topology_seed, h->d_prof};
+             (uint32_t)h->cfg.topology_seed, h->d_prof, h->d_reset_ws};
   h->full_obs_next = false;
   const dim3 grid(h->cfg.num_envs);
   // with a communicator, the launch carries ev_step[buf] as its stop event: the event rides on the kernel's own completion
@@ -1338,6 +1338,7 @@ int cc4_create(const cc4_config* cfg, cc4_handle** out) {
   size_t n = (size_t)cfg->num_envs;
   HIPCHK(h, hipMalloc(&h->d_state, n * sizeof(EnvState)));
   HIPCHK(h, hipMalloc(&h->d_cold, n * sizeof(EnvCold)));
+  if (h->philox_lean && cfg->rng_mode == 1) HIPCHK(h, hipMalloc(&h->d_reset_ws, n * RESET_WS_WORDS * sizeof(uint32_t)));
   HIPCHK(h, hipMalloc(&h->d_actions, n * NBLUE * sizeof(int32_t)));
   HIPCHK(h, hipMalloc(&h->d_msgs, n * NBLUE * MSG_LEN));
   HIPCHK(h, hipMalloc(&h->d_seeds, n * sizeof(uint64_t)));
@@ -1368,7 +1369,7 @@ void cc4_destroy(cc4_handle* h) {
   for (int b = 0; b < cc4_handle::OBS_RING; ++b) { if (h->ev_step[b]) (void)hipEventDestroy(h->ev_step[b]); if (h->ev_comm[b]) (void)hipEventDestroy(h->ev_comm[b]); }
   if (h->comm_stream) (void)hipStreamDestroy(h->comm_stream);
   void* ptrs[] = {h->d_state, h->d_cold, h->d_actions, h->d_msgs, h->d_seeds, h->d_envmask, h->d_obs, h->d_reward,
-                  h->d_done, h->d_err, h->d_mask, h->d_rng};
+                  h->d_done, h->d_err, h->d_mask, h->d_rng, h->d_reset_ws};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   for (int b = 0; b < cc4_handle::OBS_RING; ++b) { if (h->d_obs8[b]) (void)hipFree(h->d_obs8[b]); if (h->d_all_obs8[b]) (void)hipFree(h->d_all_obs8[b]); }
   if (h->d_unpacked) (void)hipFree(h->d_unpacked);
