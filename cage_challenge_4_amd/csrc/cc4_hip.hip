@@ -905,13 +905,16 @@ __global__ __launch_bounds__(PT, MINW) void k_step_philox(StepArgs a) {
 template <bool LOG>
 __global__ __launch_bounds__(WAVE) void k_step_philox1(StepArgs a) {
   extern __shared__ uint4 lds[];
-  __shared__ uint8_t obs_bytes[OBS_TOTAL + 2];   // byte copy of the observations, only for the packed exchange row
+  // byte copy of the observations, only for the packed exchange row; the debug phase timers borrow the area (a profiled handle
+  // has no communicator): with it, agent part + statics fit 8 KB and 20 episodes are resident per CU
+  __shared__ alignas(8) uint8_t obs_bytes[(OBS_TOTAL + 2 + 7) & ~7];
   __shared__ uint8_t ev_lds[MAXH + 3];           // the hosts' event bytes after the end-turn roll-over: what the observation encode reads
   __shared__ StepWork work;
   __shared__ int conflict_lds;
-  __shared__ unsigned long long prof_lds[16];
+  unsigned long long* const prof_lds = reinterpret_cast<unsigned long long*>(obs_bytes);
   const int e = blockIdx.x, lane = threadIdx.x;
   if (e >= a.n) return;
+  if (a.obs8) a.prof = nullptr;
   unsigned long long t_begin = a.prof ? clock64() : 0;
   const uint4* src = reinterpret_cast<const uint4*>(a.st + e);
   stage_in<HOT_VEC>(lds, src, lane);
@@ -994,7 +997,12 @@ __global__ __launch_bounds__(WAVE) void k_step_philox1(StepArgs a) {
       // ---- P3b blue actions: side by side when they are independent (no Monitor, no pending pid events)
       if (blue_exec_independent(s)) {
         if (lane == 0) CC4_TICK(x0, 3);
-        if (lane < NBLUE) step_blue_exec_agent(xg, lane);
+        if (lane < NBLUE) {
+          // block 0 of the agent's action stream ahead of the switch on the action type: the lanes compute it in lock-step
+          // instead of once per divergent path
+          uint32_t c[4]; rng_block(&rl, ST_BLUE_EXE + (uint32_t)lane, 0, c);
+          step_blue_exec_agent(xg, lane, c);
+        }
         __syncthreads();
         if (lane == 0) CC4_TICK(x0, 5);
       } else {
@@ -1004,7 +1012,10 @@ __global__ __launch_bounds__(WAVE) void k_step_philox1(StepArgs a) {
       // ---- P4 green actions, one agent per lane
       {
         int pen = 0;
-        for (int g = lane; g < ng; g += WAVE) pen += step_green_exec(xg, g);
+        for (int g = lane; g < ng; g += WAVE) {
+          uint32_t c[4]; rng_block(&rl, ST_GREEN_EXE + (uint32_t)g, 0, c);      // ahead of the AccessService / LocalWork split (see above)
+          pen += step_green_exec(xg, g, c);
+        }
         if (pen) atomicAdd(&s->brm, pen);
       }
       __syncthreads();
@@ -1015,7 +1026,8 @@ __global__ __launch_bounds__(WAVE) void k_step_philox1(StepArgs a) {
       const uint32_t serial_red = (uint32_t)conflict_lds;
       if (is_red && !((serial_red >> lane) & 1u)) {
         unsigned long long t0 = ap ? clock64() : 0;
-        step_red_exec_agent(xr, lane);
+        uint32_t c[4]; rng_block(&rl, ST_RED_EXE + (uint32_t)lane, 0, c);
+        step_red_exec_agent(xr, lane, c);
         if (ap) ap[1] += clock64() - t0;
       }
       __syncthreads();
