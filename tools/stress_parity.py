@@ -13,8 +13,10 @@ T = int(sys.argv[3]) if len(sys.argv) > 3 else 220
 EP = int(sys.argv[4]) if len(sys.argv) > 4 else 150   # episode length (autoreset after it)
 bad = 0
 for k in range(rounds):
-    for mode, rp in ((1, 0), (1, 3), (0, 0), (1, 2), (0, 3), (0, 2)):
+    # (rng mode, red policy, counter-mode kernel: 0 = four wavefronts per episode, 1 = one)
+    for mode, rp, lean in ((1, 0, 0), (1, 0, 1), (1, 3, 1), (0, 0, 0), (1, 2, 0), (1, 2, 1), (0, 3, 0), (0, 2, 0)):
         seed = 50000 + 1000 * k + 17 * mode + rp
+        os.environ['CC4_PHILOX_LEAN'] = str(lean)
         dev = CC4VecEnv(n, steps=EP, rng_mode=mode, autoreset=True, red_policy=rp)
         ora = OracleVecEnv(n, steps=EP, rng_mode=mode, autoreset=True, red_policy=rp)
         assert np.array_equal(dev.reset(seeds=seed), ora.reset(seeds=seed))
@@ -23,7 +25,7 @@ for k in range(rounds):
             a = random_actions(seed, t, n)
             d = dev.step(a); o = ora.step(a)
             if not (np.array_equal(d[0], o[0]) and np.array_equal(d[1], o[1]) and np.array_equal(d[2], o[2])):
-                print('MISMATCH round', k, 'mode', mode, 'policy', rp, 'step', t, flush=True); ok = False; bad += 1; break
+                print('MISMATCH round', k, 'mode', mode, 'policy', rp, 'kernel', dev.step_kernel, 'step', t, flush=True); ok = False; bad += 1; break
         if ok:
             for i in range(0, n, 3):
                 if not np.array_equal(dev.get_state(i), ora.get_state(i)):
