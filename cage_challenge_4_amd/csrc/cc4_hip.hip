@@ -257,7 +257,7 @@ constexpr uint64_t P01_FLOOR = (uint64_t)P01_SCALED;
 static_assert((double)P01_FLOOR * (1.0 / 9007199254740992.0) < 0.01 && (double)(P01_FLOOR + 1) * (1.0 / 9007199254740992.0) >= 0.01,
               "integer form of rng_random() < 0.01");
 enum : uint32_t { GR_VALID = 1, GR_FAIL = 2, GR_EPH = 4, GR_CONN = 8, GR_PROC = 16, GR_HARD = 32, GR_PHISH = 64 };
-__device__ __forceinline__ void wave_green_exec(Ctx x, Rng& rl, const uint64_t* gpre, uint64_t* win, int lane, unsigned long long* gstat = nullptr) {
+__device__ __forceinline__ void wave_green_exec(Ctx x, Rng& rl, uint64_t* win, int lane, unsigned long long* gstat = nullptr) {
   EnvState* s = x.s;
   const int ng = s->n_green;
   const uint64_t i_hi = bcast64(rl.inc_hi), i_lo = bcast64(rl.inc_lo);
@@ -280,7 +280,8 @@ __device__ __forceinline__ void wave_green_exec(Ctx x, Rng& rl, const uint64_t* 
     const bool in = gi < ng;
     const uint32_t my_act = in ? x.w->green_act[gi] : 2u;
     const bool active = my_act < 2;
-    const uint64_t pre = active ? gpre[gi] : 0ull;
+    // what the action reads from the state (green_prepare: the host's service table -- HBM here --, allowed server counts)
+    const uint64_t pre = active ? green_prepare(x, gi, (int)my_act) : 0ull;
     const uint32_t gh = in ? s->green_host[gi] : 0u;
     uint32_t my_blk = 0;       // bit sn: traffic between the agent's subnet and subnet sn is blocked either way
     if (active && my_act == 0) {
@@ -430,8 +431,7 @@ __device__ __forceinline__ void wave_green_exec(Ctx x, Rng& rl, const uint64_t* 
       rl.s_hi = n_hi; rl.s_lo = n_lo; rl.has32 = has_e; rl.u32 = u_e; rl.ndraw += (uint32_t)pos_e;
       if (reason == R_PHISH) phishing(x, s->green_host[gend - 1]);
       else if (reason == R_HARD) {
-        Ctx xg = x; xg.gpre = gpre;
-        s->brm += step_green_exec(xg, gend);
+        s->brm += step_green_exec(x, gend);
         if (bit_get(x.w->phish_mask, gend)) { bit_clr(x.w->phish_mask, gend); phishing(x, s->green_host[gend]); }
       }
     }
@@ -457,7 +457,6 @@ __global__ __launch_bounds__(WAVE) void k_step(StepArgs a) {
   uint8_t* const ev_lds = obs_lds + OBS_LDS;
   __shared__ int ok_lds;
   __shared__ StepWork work;
-  __shared__ uint64_t gpre_lds[MAXG];
   const int e = blockIdx.x, lane = threadIdx.x;
   if (e >= a.n) return;
   unsigned long long t_begin = a.prof ? clock64() : 0;
@@ -523,20 +522,23 @@ __global__ __launch_bounds__(WAVE) void k_step(StepArgs a) {
   }
   __syncthreads();
   if (ok_lds) {
-    // what the green actions read from the state (service tables of their hosts -- HBM here --, allowed server counts), for all
-    // agents at once on the idle lanes: the walking lane then only draws and applies (green_prepare)
-    for (int g = lane; g < s->n_green; g += WAVE) { const int act = work.green_act[g]; if (act < 2) gpre_lds[g] = green_prepare(x, g, act); }
-    __syncthreads();
-    // the green actions: across the wave (wave_green_exec); with the event log on, on the walking lane (log entries are ordered)
-    if (!LOG) wave_green_exec(x, rl, gpre_lds, win_lds, lane, a.prof ? a.prof + PROF_SLOTS * (size_t)e + 64 : nullptr);
-    if (lane == 0) {
-      if (LOG) {
+    // the green actions: across the wave (wave_green_exec)
+    if constexpr (!LOG) wave_green_exec(x, rl, win_lds, lane, a.prof ? a.prof + PROF_SLOTS * (size_t)e + 64 : nullptr);
+    else {
+      // with the event log on (log entries are ordered): on the walking lane; what the actions read from the state (service
+      // tables of their hosts -- HBM here --, allowed server counts) is prepared for all agents at once on the idle lanes
+      __shared__ uint64_t gpre_lds[MAXG];
+      for (int g = lane; g < s->n_green; g += WAVE) { const int act = work.green_act[g]; if (act < 2) gpre_lds[g] = green_prepare(x, g, act); }
+      __syncthreads();
+      if (lane == 0) {
         Ctx xg = x; xg.gpre = gpre_lds;
         for (int g = 0; g < s->n_green; ++g) {
           s->brm += step_green_exec(xg, g);
           if (bit_get(work.phish_mask, g)) { bit_clr(work.phish_mask, g); phishing(x, s->green_host[g]); }
         }
       }
+    }
+    if (lane == 0) {
       CC4_TICK(x, 6);
       step_red_exec(x);
       step_reassign(x, red_foreign_agents(s));

@@ -666,7 +666,7 @@ def test_bench_line_contract():
     assert not d['config']['engine_error_flags'] and d['config']['timed_regions'] >= 1
     r = d['roofline']
     assert r['bound'] == 'hbm' and r['unit'] == 'GB/s' and r['peak'] == 8000.0 and abs(r['frac'] - r['achieved'] / r['peak']) < 1e-9
-    assert r['kernel'] == 'k_step_philox' and 0 < r['launch_ms'] <= d['ms_per_step'] * 1.02
+    assert r['kernel'] == 'k_step_philox1' and 0 < r['launch_ms'] <= d['ms_per_step'] * 1.02
     assert abs(r['achieved'] - r['algorithmic_bytes_per_launch'] / (r['launch_ms'] * 1e-3) / 1e9) < 1e-6 * r['achieved']
     assert r['traffic'] is None or ('profiles/' in r['traffic_source'])
     assert abs(d['value'] - 5.0 * 8192 / (d['ms_per_step'] * 1e-3)) < 1e-6 * d['value']
