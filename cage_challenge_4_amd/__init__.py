@@ -6,7 +6,7 @@ environment does, and fails loudly if libcc4.so is missing or no HIP device is v
 from .vec_env import (CC4VecEnv, RNG_PCG64, RNG_PHILOX, RED_FSM, RED_SLEEP, RED_DISCOVERY, RED_RANDOM, GREEN_ENTERPRISE,  # noqa: F401
                       GREEN_SLEEP, split_obs, split_mask, shard_range)
 from .wrappers import (CybORG, EnterpriseScenarioGenerator, SleepAgent, EnterpriseGreenAgent, FiniteStateRedAgent,  # noqa: F401
-                       DiscoveryFSRed, RandomSelectRedAgent,
+                       DiscoveryFSRed, RandomSelectRedAgent, cc4BlueRandomAgent,
                        BlueFixedActionWrapper, BlueFlatWrapper, BlueEnterpriseWrapper, EnterpriseMAE)
 
 from .true_state import TrueStateTableWrapper  # noqa: F401

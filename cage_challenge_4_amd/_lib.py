@@ -23,7 +23,7 @@ ACT_OFF = (0, 82, 164, 246, 328)
 class CC4Config(ctypes.Structure):
     _fields_ = [('num_envs', ctypes.c_int32), ('steps', ctypes.c_int32), ('device_id', ctypes.c_int32),
                 ('rng_mode', ctypes.c_int32), ('autoreset', ctypes.c_int32), ('red_policy', ctypes.c_int32),
-                ('green_policy', ctypes.c_int32), ('topology_seed', ctypes.c_int32)]
+                ('green_policy', ctypes.c_int32), ('topology_seed', ctypes.c_int32), ('blue_policy', ctypes.c_int32)]
 
 
 # every entry point declared in include/cc4.h : (restype, argtypes)

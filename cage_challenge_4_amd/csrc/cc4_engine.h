@@ -2051,7 +2051,7 @@ CC4_HD void red_reassign(Ctx x, uint32_t foreign) {   // foreign: red_foreign_ag
 // ------------------------------------------------------------------ the step (SimulationController.step, SC:211-315)
 // The step is cut into phases that exchange data only through EnvState, so that the serial walk (env_step: the CPU
 // oracle and the PCG64 device mode) and the lane-parallel Philox kernel run the very same phase bodies.
-//   P0 step_begin            lane 0      phase check, blue decode + queue            (SC:224-248)
+//   P0 step_phase + submit   lane 0      phase check, blue decode (or built-in policy) + queue  (SC:224-248)
 //   P1 step_green_policy(g)  per green   EnterpriseGreenAgent.get_action             (EnterpriseGreenAgent.py:60)
 //   P2 step_red_policy_tick(r) per red   FSM get_action + validity + queue, then the agent's duration-queue tick (SC:236-265)
 //   P3 step_tick_blue(b), step_blue_exec   duration queue of the blue agents, (pcg: shuffle), blue execution
@@ -2095,10 +2095,40 @@ CC4_HD bool step_phase(Ctx x, bool init_accumulators = true) {
   return true;
 }
 // one blue agent's submitted action: decode, cost, queue (SC:236-248); independent across agents
+// cc4BlueRandomAgent.get_action (Agents/SimpleAgents/RandomAgent.py:28-52,66-69) for a blue agent nobody submitted an action
+// for (SimulationController.py:236-248 asks the scenario's agent object): epsilon = 1 still costs the random() of the test;
+// a uniform action class out of the agent's actions minus Block/AllowTrafficZone, in blue_actions order
+// (EnterpriseScenarioGenerator.py:642: Monitor, Analyse, Restore, Remove, DeployDecoy, Sleep); then one uniform value per
+// constructor parameter with more than one option: `session` and `agent` have one, `hostname` ranges over the agent's hosts
+// in ActionSpace.hostname's insertion order = the initial observation's: per allowed subnet the router, the user hosts, the
+// server hosts (routers are valid targets here, unlike in the wrapper's action list).
+CC4_HD Act blue_random_policy(Ctx x, int b) {
+  EnvState* s = x.s;
+  Act a; a.type = BA_SLEEP; a.host = 0; a.arg = 0; a.ticks = 1; a.sid = 0; a.busy = 0;
+  rng_set_stream(x.r, ST_BLUE_POL + (uint32_t)b);
+  (void)rng_random(x.r);
+  const int c = (int)rng_below(x.r, 6);
+  const int t = c == 0 ? BA_MONITOR : (c == 1 ? BA_ANALYSE : (c == 2 ? BA_RESTORE : (c == 3 ? BA_REMOVE : (c == 4 ? BA_DECOY : BA_SLEEP))));
+  a.type = (uint8_t)t;
+  if (t == BA_MONITOR || t == BA_SLEEP) return a;
+  int nh = 0;
+  for (int i = 0; i < blue_nsub(b); ++i) { const int sn = blue_subnet_alloc(b, i); nh += 1 + s->n_users[sn] + s->n_servers[sn]; }
+  int j = (int)rng_below(x.r, (uint32_t)nh);
+  for (int i = 0; i < blue_nsub(b); ++i) {
+    const int sn = blue_subnet_alloc(b, i), nu = s->n_users[sn], cnt = 1 + nu + s->n_servers[sn];
+    if (j >= cnt) { j -= cnt; continue; }
+    a.host = (uint8_t)(j == 0 ? h_make(sn, 0) : (j - 1 < nu ? h_make(sn, 1 + (j - 1)) : h_make(sn, 11 + (j - 1 - nu))));
+    break;
+  }
+  return a;
+}
 CC4_HD void step_blue_submit(Ctx x, int b, int action_index) {
   EnvState* s = x.s;
-  Act a = blue_decode(s, b, action_index);
-  if (a.type == BA_RESTORE) {  // Restore.cost = -1, charged on submission even while busy (SC:310)
+  const bool builtin = action_index < 0 && (s->policy & BP_RANDOM_BIT);
+  Act a = builtin ? blue_random_policy(x, b) : blue_decode(s, b, action_index);
+  // Restore.cost = -1, charged on submission even while busy -- for SUBMITTED actions only: the sum runs over the step's
+  // `actions` argument, which a default agent's choice never enters (SC:236-240,310)
+  if (a.type == BA_RESTORE && !builtin) {
 #if defined(__HIP_DEVICE_COMPILE__)
     atomicAdd(&s->n_restore, 1);
 #else
@@ -2107,11 +2137,6 @@ CC4_HD void step_blue_submit(Ctx x, int b, int action_index) {
   }
   a.ticks = (uint8_t)blue_duration(a.type);
   if (!s->blue[b].queue.busy) { s->blue[b].queue = a; s->blue[b].queue.busy = 1; }
-}
-CC4_HD bool step_begin(Ctx x, const int32_t* actions) {
-  if (!step_phase(x)) return false;
-  for (int b = 0; b < NBLUE; ++b) step_blue_submit(x, b, actions ? actions[b] : -1);
-  return true;
 }
 // The policies' generator while a set_seed split is in force (EnvState.rng2; numpy-stream mode only -- in the counter mode
 // cc4_set_seed re-keys every stream): the walking generator and rng2 trade places around the policy loops.
@@ -2366,9 +2391,10 @@ CC4_HD void step_end(Ctx x, const uint8_t* messages, bool copy_msgs = true) {
 CC4_HD void env_step(Ctx x, const int32_t* actions, const uint8_t* messages /* [5][8] or null */) {
   EnvState* s = x.s;
   CC4_TICK0(x);
-  if (!step_begin(x, actions)) return;
+  if (!step_phase(x)) return;
+  rng_policy_swap(x, false);     // every agent's policy -- a built-in blue one included -- draws from the generator it was created with
+  for (int b = 0; b < NBLUE; ++b) step_blue_submit(x, b, actions ? actions[b] : -1);
   CC4_TICK(x, 0);
-  rng_policy_swap(x, false);
   for (int g = 0; g < s->n_green; ++g) step_green_policy(x, g);
   CC4_TICK(x, 1);
   for (int r = 0; r < NRED; ++r) s->n_actions -= step_red_policy_tick(x, r);

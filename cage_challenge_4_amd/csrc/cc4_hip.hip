@@ -492,8 +492,14 @@ __global__ __launch_bounds__(WAVE) void k_step(StepArgs a) {
       (void)step_phase(x, false);    // sets E_STEP_PAST_END when !step_ok
       CC4_TICK(x, 0);
       if (step_ok) rng_policy_swap(x, false);     // CybORG.set_seed split: the policies draw from the old stream (EnvState.rng2)
+      if (step_ok && (s->policy & BP_RANDOM_BIT))   // built-in blue policy: its draws are the first of the step, in agent order
+        for (int b = 0; b < NBLUE; ++b) {
+          int32_t act = a.actions ? a.actions[e * NBLUE + b] : -1;
+          if (a.rand_out) { act = random_blue_action(a.rand_seed0, a.rand_t, e, b); a.rand_out[e * NBLUE + b] = act; }
+          step_blue_submit(x, b, act);
+        }
     }
-  } else if (step_ok && lane <= NBLUE) {
+  } else if (step_ok && lane <= NBLUE && !(s->policy & BP_RANDOM_BIT)) {
     const int b = lane - 1;
     int32_t act = a.actions ? a.actions[e * NBLUE + b] : -1;
     if (a.rand_out) { act = random_blue_action(a.rand_seed0, a.rand_t, e, b); a.rand_out[e * NBLUE + b] = act; }
@@ -1268,7 +1274,7 @@ static int launch_step(cc4_handle* h, const int32_t* d_actions, const uint8_t* d
   StepArgs a{h->d_state, h->d_cold, d_actions, d_msgs, h->d_obs, h->d_reward, h->d_done, h->d_err,
              h->comm ? h->d_obs8[buf] : nullptr, rand ? h->d_actions : nullptr, seed0, t,
              h->cfg.num_envs, h->cfg.autoreset, h->cfg.steps, h->cfg.rng_mode,
-             (h->cfg.red_policy & 3) | (h->cfg.green_policy ? GP_SLEEP_BIT : 0), h->full_obs_next ? 1 : 0,
+             (h->cfg.red_policy & 3) | (h->cfg.green_policy ? GP_SLEEP_BIT : 0) | (h->cfg.blue_policy ? BP_RANDOM_BIT : 0), h->full_obs_next ? 1 : 0,
              (uint32_t)h->cfg.topology_seed, h->d_prof, h->d_reset_ws};
   h->full_obs_next = false;
   const dim3 grid(h->cfg.num_envs);
@@ -1311,7 +1317,7 @@ const char* cc4_step_kernel(cc4_handle* h) {
 
 int cc4_create(const cc4_config* cfg, cc4_handle** out) {
   if (!cfg || !out || cfg->num_envs <= 0 || cfg->steps <= 0 || cfg->red_policy < 0 || cfg->red_policy > 3 ||
-      cfg->green_policy < 0 || cfg->green_policy > 1 || cfg->rng_mode < 0 || cfg->rng_mode > 1) { g_create_err = "cc4_create: bad config"; return -2; }
+      cfg->green_policy < 0 || cfg->green_policy > 1 || cfg->blue_policy < 0 || cfg->blue_policy > 1 || cfg->rng_mode < 0 || cfg->rng_mode > 1) { g_create_err = "cc4_create: bad config"; return -2; }
   if (cfg->topology_seed != 0 && cfg->rng_mode != 1) { g_create_err = "cc4_create: topology_seed needs rng_mode 1 (the numpy stream draws scenario and dynamics from one generator)"; return -2; }
   int ndev = 0;
   hipError_t e = hipGetDeviceCount(&ndev);
@@ -1401,7 +1407,7 @@ int cc4_reset(cc4_handle* h, const uint64_t* seeds, const uint8_t* env_mask) {
   if (env_mask) HIPCHK(h, hipMemcpyAsync(h->d_envmask, env_mask, n, hipMemcpyHostToDevice, h->stream));
   ResetArgs a{h->d_state, h->d_cold, seeds ? h->d_seeds : nullptr, env_mask ? h->d_envmask : nullptr, h->d_obs, h->d_reward,
               h->d_done, h->d_err, h->d_mask, h->cfg.num_envs, h->cfg.steps, h->cfg.rng_mode,
-              (h->cfg.red_policy & 3) | (h->cfg.green_policy ? GP_SLEEP_BIT : 0), (uint32_t)h->cfg.topology_seed,
+              (h->cfg.red_policy & 3) | (h->cfg.green_policy ? GP_SLEEP_BIT : 0) | (h->cfg.blue_policy ? BP_RANDOM_BIT : 0), (uint32_t)h->cfg.topology_seed,
               h->comm ? h->d_obs8[h->obs_buf] : nullptr};
   // with a communicator the reset also writes the packed exchange row of its observations into the current ring buffer; an
   // overlapped all-gather may still be reading that buffer

@@ -47,7 +47,8 @@ struct Rng {
 enum : uint32_t { ST_RESET = 0, ST_BLUE_EXE = 0x100, ST_GREEN_POL = 0x200, ST_GREEN_EXE = 0x300, ST_GREEN_PHISH = 0x400,
                   ST_RED_POL = 0x500, ST_RED_EXE = 0x600, ST_RED_RSC = 0x700,
                   // scenario generation (reset counter words): per-host streams, so hosts can be generated on separate lanes
-                  ST_GEN_HOST = 0x800, ST_GEN_REDRAW = 0x900, ST_GEN_SESS = 0xA00 };
+                  ST_GEN_HOST = 0x800, ST_GEN_REDRAW = 0x900, ST_GEN_SESS = 0xA00,
+                  ST_BLUE_POL = 0xB00 /* built-in blue policy (cc4BlueRandomAgent) */ };
 
 // ---- SeedSequence (numpy/random/bit_generator.pyx: SeedSequence.mix_entropy / generate_state) ----
 CC4_HD uint32_t ss_hashmix(uint32_t value, uint32_t* hash_const) {

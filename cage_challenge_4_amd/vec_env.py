@@ -53,8 +53,9 @@ def raise_on_engine_error(err):
 
 class CC4VecEnv:
     def __init__(self, num_envs, steps=500, rng_mode=RNG_PCG64, device_id=0, autoreset=False, red_policy=0, green_policy=0,
-                 topology_seed=0, strict=True):
+                 topology_seed=0, strict=True, blue_policy=0):
         """topology_seed != 0 (RNG_PHILOX only): all episodes share the scenario drawn from that key (uniform topology).
+        blue_policy 1: cc4BlueRandomAgent acts for every blue agent whose action index is negative (0: such an agent sleeps).
         strict: raise (ValueError for a step past the episode's end, as the reference does; CC4EngineError otherwise) as soon as
         any episode carries an error flag.  strict=False leaves the flags to the caller (`err`, `info['err']`)."""
         self.strict = bool(strict)
@@ -62,7 +63,7 @@ class CC4VecEnv:
         self.num_envs = int(num_envs)
         self.steps = int(steps)
         cfg = L.CC4Config(self.num_envs, self.steps, int(device_id), int(rng_mode), int(bool(autoreset)),
-                          int(red_policy), int(green_policy), int(topology_seed))
+                          int(red_policy), int(green_policy), int(topology_seed), int(blue_policy))
         h = ctypes.c_void_p()
         rc = self.lib.cc4_create(ctypes.byref(cfg), ctypes.byref(h))
         if rc != 0:

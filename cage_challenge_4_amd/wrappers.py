@@ -51,6 +51,14 @@ class RandomSelectRedAgent:
     """CybORG/Agents/SimpleAgents/RandomSelectRedAgent.py:8-148 (uniform command + uniform known parameters, incl. Withdraw)"""
 
 
+class cc4BlueRandomAgent:
+    """CybORG/Agents/SimpleAgents/RandomAgent.py:14-69 (epsilon = 1: a uniform action class out of Monitor, Analyse, Restore,
+    Remove, DeployDecoy, Sleep, then a uniform host of the agent's zone, routers included); as `blue_agent_class` it acts for
+    every blue agent a step gets no action for"""
+    def __init__(self, name=None, **kwargs):
+        self.name = name
+
+
 class DiscoveryFSRed(FiniteStateRedAgent):
     """CybORG/Agents/SimpleAgents/FSMRedVariants.py:80-122 (host-state priorities, prioritise_servers, own probability matrix)"""
 
@@ -66,8 +74,11 @@ class EnterpriseScenarioGenerator:
     MESSAGE_LENGTH = 8
 
     def __init__(self, blue_agent_class=None, red_agent_class=None, green_agent_class=None, steps: int = 100):
-        if blue_agent_class not in (None, SleepAgent) and getattr(blue_agent_class, '__name__', '') != 'SleepAgent':
-            raise NotImplementedError("blue default policy: only SleepAgent (blue actions are submitted through step())")
+        blue = {'SleepAgent': 0, 'cc4BlueRandomAgent': 1}
+        bn = 'SleepAgent' if blue_agent_class is None else getattr(blue_agent_class, '__name__', None)
+        if bn not in blue:
+            raise NotImplementedError(f"built-in blue policies (they act for agents no action is submitted for): {list(blue)}")
+        self.blue_policy = blue[bn]
         red = {'FiniteStateRedAgent': 0, 'SleepAgent': 1, 'DiscoveryFSRed': 2, 'RandomSelectRedAgent': 3}
         green = {'EnterpriseGreenAgent': 0, 'SleepAgent': 1}
         # None -> SleepAgent, as the reference's generators do (ESG.py:745-748, :815-817)
@@ -108,7 +119,8 @@ class CybORG:
         # vec_factory: anything with CC4VecEnv's call shape (tests inject the CPU oracle; the default is the HIP engine)
         self.vec = (vec_factory or CC4VecEnv)(1, steps=scenario_generator.steps, rng_mode=rng_mode, device_id=device_id,
                                               red_policy=scenario_generator.red_policy,
-                                              green_policy=scenario_generator.green_policy)
+                                              green_policy=scenario_generator.green_policy,
+                                              blue_policy=scenario_generator.blue_policy)
         self.vec.enable_event_log(True)                        # single episode: keep the per-step event detail for get_observation
         if generator is not None:
             self.vec.set_generators([generator])

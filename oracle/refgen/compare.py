@@ -1,5 +1,5 @@
 """Differential test: reference CybORG (this container only) vs the CPU oracle, step by step.
-usage: python compare.py <seed> [steps] [blue: sleep|random|<blue_policies.KINDS>] [init: ctor|reset]"""
+usage: python compare.py <seed> [steps] [blue: sleep|random|builtin (= blue_agent_class=cc4BlueRandomAgent, no actions submitted)|<blue_policies.KINDS>] [init: ctor|reset]"""
 import sys, os, ctypes, re
 import numpy as np
 sys.path.insert(0, os.path.dirname(__file__))
@@ -9,7 +9,7 @@ from blue_policies import BluePolicy, KINDS
 from blue_policies import BluePolicy, KINDS
 from CybORG import CybORG
 from CybORG.Simulator.Scenarios import EnterpriseScenarioGenerator
-from CybORG.Agents import SleepAgent, EnterpriseGreenAgent, FiniteStateRedAgent, DiscoveryFSRed, RandomSelectRedAgent
+from CybORG.Agents import SleepAgent, EnterpriseGreenAgent, FiniteStateRedAgent, DiscoveryFSRed, RandomSelectRedAgent, cc4BlueRandomAgent
 RED = {'fsm': (FiniteStateRedAgent, 0), 'sleep': (SleepAgent, 1), 'discovery': (DiscoveryFSRed, 2), 'random': (RandomSelectRedAgent, 3)}
 GREEN = {'enterprise': (EnterpriseGreenAgent, 0), 'sleep': (SleepAgent, 1)}
 from CybORG.Agents.Wrappers import BlueFlatWrapper
@@ -30,9 +30,9 @@ def canon_ref(txt):
 
 
 def run(seed, steps=500, blue='sleep', init='ctor', verbose=True, max_steps=None, red='fsm', green='enterprise'):
-    sg = EnterpriseScenarioGenerator(blue_agent_class=SleepAgent, green_agent_class=GREEN[green][0],
-                                     red_agent_class=RED[red][0], steps=steps)
-    pol = RED[red][1] | (0x10 if GREEN[green][1] else 0)
+    sg = EnterpriseScenarioGenerator(blue_agent_class=cc4BlueRandomAgent if blue == 'builtin' else SleepAgent,
+                                     green_agent_class=GREEN[green][0], red_agent_class=RED[red][0], steps=steps)
+    pol = RED[red][1] | (0x10 if GREEN[green][1] else 0) | (0x20 if blue == 'builtin' else 0)
     env = CybORG(sg, seed=seed)
     w = BlueFlatWrapper(env)
     H = ctypes.c_void_p(lib.cc4o_create(1))
@@ -89,7 +89,7 @@ def run(seed, steps=500, blue='sleep', init='ctor', verbose=True, max_steps=None
     total = 0.0
     nst = max_steps or steps
     for t in range(nst):
-        if blue == 'sleep':
+        if blue in ('sleep', 'builtin'):
             acts = {}
             a = np.full(5, -1, np.int32)
         elif bpol is not None:

@@ -1,5 +1,5 @@
 """Differential fuzz: many seeds, random blue, reference vs oracle.
-usage: fuzz.py start count [steps] [blue: sleep|random|decoy_one|decoy|decoy_restore|restore|remove|analyse|block|block_allow|mix] [init] [red: fsm|sleep|discovery|random] [green: enterprise|sleep]"""
+usage: fuzz.py start count [steps] [blue: sleep|random|builtin|decoy_one|decoy|decoy_restore|restore|remove|analyse|block|block_allow|mix] [init] [red: fsm|sleep|discovery|random] [green: enterprise|sleep]"""
 import sys
 from compare import run
 start, count = int(sys.argv[1]), int(sys.argv[2])

@@ -15,7 +15,7 @@ sys.path.insert(0, os.path.dirname(__file__))
 import ref_shim  # noqa
 from CybORG import CybORG
 from CybORG.Simulator.Scenarios import EnterpriseScenarioGenerator
-from CybORG.Agents import SleepAgent, EnterpriseGreenAgent, FiniteStateRedAgent, DiscoveryFSRed, RandomSelectRedAgent
+from CybORG.Agents import SleepAgent, EnterpriseGreenAgent, FiniteStateRedAgent, DiscoveryFSRed, RandomSelectRedAgent, cc4BlueRandomAgent
 RED = {'fsm': (FiniteStateRedAgent, 0), 'sleep': (SleepAgent, 1), 'discovery': (DiscoveryFSRed, 2), 'random': (RandomSelectRedAgent, 3)}
 GREEN = {'enterprise': (EnterpriseGreenAgent, 0), 'sleep': (SleepAgent, 1)}
 from CybORG.Agents.Wrappers import BlueFlatWrapper
@@ -35,8 +35,9 @@ def flat(obs):
 
 
 def record(seed, steps, blue, init, nsteps=None, msgs=False, red='fsm', green='enterprise'):
-    sg = EnterpriseScenarioGenerator(blue_agent_class=SleepAgent, green_agent_class=GREEN[green][0],
-                                     red_agent_class=RED[red][0], steps=steps)
+    # blue 'builtin': blue_agent_class=cc4BlueRandomAgent and no action submitted -- the scenario's own agent objects act
+    sg = EnterpriseScenarioGenerator(blue_agent_class=cc4BlueRandomAgent if blue == 'builtin' else SleepAgent,
+                                     green_agent_class=GREEN[green][0], red_agent_class=RED[red][0], steps=steps)
     env = CybORG(sg, seed=seed)
     w = BlueFlatWrapper(env)
     if init == 'ctor':      # CybORG(seed=s); wrapper.reset()  -> second scenario drawn from the running stream
@@ -81,7 +82,7 @@ def record(seed, steps, blue, init, nsteps=None, msgs=False, red='fsm', green='e
                         actions=A, obs_bits=np.packbits(O[:, 1:] if False else (O > 0).astype(np.uint8), axis=1), phase=O[:, 0].copy(),
                         phase_cols=np.array([0, 92, 184, 276, 368], np.int32), obs_phase_vals=O[:, [0, 92, 184, 276, 368]].copy(),
                         reward=R, done=D, rng=G, mask=mask, messages=M if msgs else np.zeros(0, np.uint8),
-                        red_policy=np.int32(RED[red][1]), green_policy=np.int32(GREEN[green][1]),
+                        red_policy=np.int32(RED[red][1]), green_policy=np.int32(GREEN[green][1]), blue_policy=np.int32(blue == 'builtin'),
                         numpy_version=np.bytes_(np.__version__), n_hosts=np.int32(len(env.environment_controller.state.hosts)))
     print(name, 'sum reward', float(R.sum()), 'hosts', len(env.environment_controller.state.hosts), flush=True)
 
@@ -93,6 +94,11 @@ if __name__ == '__main__':
         record(42, 300, 'random', 'reset', red='sleep')
         record(43, 200, 'random', 'ctor', red='discovery', green='sleep')
         record(44, 500, 'random', 'ctor', red='random')
+        sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == 'builtin':   # cc4BlueRandomAgent as the scenario's blue agent
+        record(123, 500, 'builtin', 'ctor')
+        record(87, 500, 'builtin', 'ctor', red='random')     # a seed of test_heuristic_agents.py::test_sessions_issue_with_blue
+        record(45, 300, 'builtin', 'reset', red='discovery')
         sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == 'structured':   # structured blue policies (r02: the process lists are unbounded)
         record(321, 500, 'decoy_one', 'ctor')        # every agent stacks decoys on one host: 257 processes on it at the end

@@ -22,6 +22,7 @@ def load(path):
         'rng': z['rng'], 'mask': z['mask'].astype(bool), 'messages': msgs if msgs.size else None,
         'red_policy': int(z['red_policy']) if 'red_policy' in z else 0,
         'green_policy': int(z['green_policy']) if 'green_policy' in z else 0,
+        'blue_policy': int(z['blue_policy']) if 'blue_policy' in z else 0,
     }
 
 

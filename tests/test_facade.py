@@ -6,7 +6,8 @@ import os
 import numpy as np
 import pytest
 import golden_util as G
-from cage_challenge_4_amd import CybORG, EnterpriseScenarioGenerator, SleepAgent, EnterpriseGreenAgent, FiniteStateRedAgent, BlueFlatWrapper
+from cage_challenge_4_amd import (CybORG, EnterpriseScenarioGenerator, SleepAgent, EnterpriseGreenAgent, FiniteStateRedAgent, BlueFlatWrapper,
+                                  cc4BlueRandomAgent, RandomSelectRedAgent)
 from cage_challenge_4_amd import actions as A
 
 
@@ -123,3 +124,28 @@ def test_facade_matches_reference_oracle_backend(oracle_lib):
 def test_facade_matches_reference_hip():
     _replay(None)
     _other_surface(None)
+
+
+def _builtin_blue(vec_factory, steps=120):
+    """EnterpriseScenarioGenerator(blue_agent_class=cc4BlueRandomAgent) and steps without actions -- the set-up of
+    CybORG/Tests/test_cc4/test_heuristic_agents.py:70-85 -- against the episode recorded from the reference."""
+    fix = G.load(os.path.join(G.GOLDEN_DIR, 'traj_seed87_builtin_ctor_500_redrandom.npz'))
+    sg = EnterpriseScenarioGenerator(blue_agent_class=cc4BlueRandomAgent, green_agent_class=EnterpriseGreenAgent,
+                                     red_agent_class=RandomSelectRedAgent, steps=fix['steps'])
+    w = BlueFlatWrapper(CybORG(sg, seed=fix['seed'], vec_factory=vec_factory))
+    obs, info = w.reset()
+    assert np.array_equal(np.concatenate([obs[f'blue_agent_{b}'] for b in range(5)]), fix['obs'][0])
+    for t in range(steps):
+        obs, rew, term, trunc, info = w.step({})
+        assert np.array_equal(np.concatenate([obs[f'blue_agent_{b}'] for b in range(5)]), fix['obs'][t + 1]), t
+        assert rew['blue_agent_0'] == fix['reward'][t], t
+
+
+def test_builtin_blue_policy_through_the_facade_cpu(oracle_lib):
+    from oracle_binding import OracleVecEnv
+    _builtin_blue(OracleVecEnv)
+
+
+@pytest.mark.gpu
+def test_builtin_blue_policy_through_the_facade_gpu():
+    _builtin_blue(None)

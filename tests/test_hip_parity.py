@@ -25,7 +25,7 @@ def philox_kernel(request, monkeypatch):
 def test_hip_matches_reference_golden_trajectories():
     """All golden episodes stepped together in ONE batch: each env its own seed / init mode / action script."""
     fixes = [G.load(p) for p in G.list_fixtures()]
-    fixes = [f for f in fixes if f['steps'] == 500 and f['red_policy'] == 0 and f['green_policy'] == 0]
+    fixes = [f for f in fixes if f['steps'] == 500 and f['red_policy'] == 0 and f['green_policy'] == 0 and f['blue_policy'] == 0]
     n = len(fixes)
     env = _dev(n, steps=500)
     env.reset(seeds=np.array([f['seed'] for f in fixes], np.uint64))
@@ -52,13 +52,14 @@ def test_hip_matches_reference_golden_trajectories():
 
 
 def test_hip_policy_variants_match_reference_golden():
-    """DiscoveryFSRed / SleepAgent red / SleepAgent green episodes recorded from the reference, on the HIP path."""
+    """DiscoveryFSRed / RandomSelectRedAgent / SleepAgent red / SleepAgent green / cc4BlueRandomAgent blue (acting for agents without a
+    submitted action) episodes recorded from the reference, on the HIP path."""
     import test_oracle_golden as T
     from cage_challenge_4_amd import CC4VecEnv
-    todo = [f for f in (G.load(p) for p in G.list_fixtures()) if f['red_policy'] or f['green_policy']]
-    assert len(todo) >= 4
+    todo = [f for f in (G.load(p) for p in G.list_fixtures()) if f['red_policy'] or f['green_policy'] or f['blue_policy']]
+    assert len(todo) >= 7 and sum(f['blue_policy'] for f in todo) >= 3
     for fix in todo:
-        env, obs = T.replay(CC4VecEnv, fix, red_policy=fix['red_policy'], green_policy=fix['green_policy'])
+        env, obs = T.replay(CC4VecEnv, fix, red_policy=fix['red_policy'], green_policy=fix['green_policy'], blue_policy=fix['blue_policy'])
         assert np.array_equal(obs[0], fix['obs'][0]) and np.array_equal(env.action_mask[0], fix['mask'])
         for t in range(fix['actions'].shape[0]):
             obs, rew, done, info = env.step(fix['actions'][t][None])
@@ -94,6 +95,31 @@ def test_hip_matches_oracle_bit_for_bit(rng_mode, policies, philox_kernel):
     for i in range(0, n, 7):
         a_, b_ = dev.get_state(i), ora.get_state(i)
         assert np.array_equal(a_, b_), f'packed state differs env {i} at byte offsets {np.nonzero(a_ != b_)[0][:20].tolist()}'
+    dev.close()
+
+
+@pytest.mark.parametrize('rng_mode', [0, 1], ids=['pcg64', 'philox'])
+def test_builtin_blue_policy_matches_oracle(rng_mode, philox_kernel):
+    """blue_agent_class=cc4BlueRandomAgent: the built-in policy acts for every blue agent without a submitted
+    action -- here a changing subset -- and draws from the episode's stream (its own counter streams in the Philox mode)."""
+    if rng_mode == 0 and philox_kernel != 'k_step_philox':
+        pytest.skip('one numpy-stream kernel')
+    n, T = 96, 170
+    dev = _dev(n, steps=150, rng_mode=rng_mode, autoreset=True, red_policy=3, blue_policy=1)
+    ora = OracleVecEnv(n, steps=150, rng_mode=rng_mode, autoreset=True, red_policy=3, blue_policy=1)
+    assert np.array_equal(dev.reset(seeds=4242), ora.reset(seeds=4242))
+    for t in range(T):
+        a = random_actions(4242, t, n)
+        idle = (np.arange(n)[:, None] + np.arange(5)[None, :] + t) % 3 != 0      # two thirds of the agents leave it to the policy
+        a[idle] = -1
+        if t % 7 == 0:
+            a[:] = -1
+        d = dev.step(a); o = ora.step(a)
+        assert np.array_equal(d[0], o[0]) and np.array_equal(d[1], o[1]) and np.array_equal(d[2], o[2]), t
+        assert np.array_equal(d[3]['err'], o[3]['err']), t
+    assert np.array_equal(dev.rng_state(), ora.rng_state())
+    for i in range(0, n, 5):
+        assert np.array_equal(dev.get_state(i), ora.get_state(i)), i
     dev.close()
 
 

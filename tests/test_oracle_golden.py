@@ -21,7 +21,7 @@ def replay(env_cls, fix, **kw):
 @pytest.mark.parametrize('path', G.list_fixtures(), ids=lambda p: p.split('/')[-1])
 def test_oracle_matches_reference_trajectory(path, oracle_lib):
     fix = G.load(path)
-    env, obs = replay(OracleVecEnv, fix, red_policy=fix['red_policy'], green_policy=fix['green_policy'])
+    env, obs = replay(OracleVecEnv, fix, red_policy=fix['red_policy'], green_policy=fix['green_policy'], blue_policy=fix['blue_policy'])
     assert np.array_equal(obs[0], fix['obs'][0])
     assert np.array_equal(env.mask()[0], fix['mask'])
     assert G.rng_words_match(fix['rng'][0], env.rng_state()[0])
