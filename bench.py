@@ -10,7 +10,7 @@ the observations when N>1].  Workload at every N: **8192 concurrent episodes in 
 GPU (the configuration the metric's target is quoted on), configs[3] on eight (1024 per GPU): strong scaling.
 EnterpriseScenarioGenerator(steps=500), FiniteStateRedAgent red, EnterpriseGreenAgent green, topology randomised per
 episode and per reset, autoreset on done.  Inputs (state, actions) are resident in HBM.  RNG mode: the counter-based
-Philox mode (agents resolved side by side: kernel k_step_philox1, one wavefront per episode, for batches of more than ten
+Philox mode (agents resolved side by side: kernel k_step_philox1, one wavefront per episode, for batches of more than eight
 episodes per CU, k_step_philox, four per episode, for smaller ones -- cc4_create picks, `roofline.kernel` names it;
 bit-exact with the CPU oracle, distribution-checked against the PCG mode); the numpy-PCG64 mode that is bit-exact with
 the reference itself (kernel k_step) is measured in the same run and reported under "alt_rng", and the 1024-episode batch

@@ -1348,10 +1348,11 @@ int cc4_create(const cc4_config* cfg, cc4_handle** out) {
     const int bpc = (cfg->num_envs + cus - 1) / cus;                     // episode blocks per CU
     h->philox_minw = bpc <= 5 ? 1 : (bpc == 8 ? 8 : 7);      // exactly 8 per CU (2048 episodes on 256 CUs) is one round of the 8-block build
     if (const char* v = getenv("CC4_PHILOX_MINW")) h->philox_minw = atoi(v);   // tuning override: 1, 7 or 8
-    // more than ten episodes per CU: the one-wave-per-episode build.  Measured on MI355X (r02, M agent-env steps/s, four waves
-    // / one wave per episode): 1024 episodes 168 / 131, 1536: 228 / 185, 2048: 262 / 237, 3072: 294 / 322, 4096: 319 / 395,
-    // 8192: 391 / 479, 16384: 414 / 540, 32768: 433 / 557
-    h->philox_lean = bpc > 10;
+    // more than eight episodes per CU: the one-wave-per-episode build.  Measured on MI355X (r02, M agent-env steps/s, four waves
+    // / one wave per episode): 1024 episodes 168 / 131, 1536: 229 / 187, 2048: 262 / 238, 2304: 249 / 260, 3072: 294 / 322,
+    // 4096: 319 / 395, 8192: 391 / 510, 16384: 414 / 540, 32768: 433 / 605.  (The same kernel with the host table in LDS as
+    // well -- 9 episodes per CU -- is no faster anywhere: 1024..2304 episodes 130 / 182 / 231 / 250.)
+    h->philox_lean = bpc > 8;
     if (const char* v = getenv("CC4_PHILOX_LEAN")) h->philox_lean = atoi(v) != 0;   // tuning / test override
   }
   HIPCHK(h, hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));

@@ -16,7 +16,7 @@ def _dev(n, **kw):
 
 @pytest.fixture(params=[0, 1], ids=['4wave', '1wave'])
 def philox_kernel(request, monkeypatch):
-    """The counter mode has two step kernels -- four wavefronts per episode (small batches) and one (more than ten episodes
+    """The counter mode has two step kernels -- four wavefronts per episode (small batches) and one (more than eight episodes
     per CU), picked by cc4_create from the batch size; CC4_PHILOX_LEAN forces one, so that the small test batches cover both."""
     monkeypatch.setenv('CC4_PHILOX_LEAN', str(request.param))
     return ('k_step_philox', 'k_step_philox1')[request.param]
