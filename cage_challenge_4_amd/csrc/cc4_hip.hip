@@ -589,14 +589,20 @@ __global__ __launch_bounds__(WAVE) void k_step(StepArgs a) {
   if (lane == 0) { s->rng = rl; a.reward[e] = s->reward; a.done[e] = s->done; a.err[e] = s->err; }
   unsigned long long t_obs = a.prof ? clock64() : 0;
   if (!ok_lds) { for (int h = lane; h < MAXH; h += WAVE) ev_lds[h] = hd[h].ev; __syncthreads(); }   // after a reset / a refused step
-  for (int v = lane; v < OBS_TOTAL; v += WAVE) { int i; const int val = env_flat_obs_sorted(s, hd, v, &i, ev_lds); obs_lds[i] = (uint8_t)val; }   // kind-sorted: uniform branches
+  {
+    // straight to HBM, kind-sorted (uniform branches); the output buffer persists between steps, so the values that only a
+    // Block/Allow or a new mission phase changes are written when that happened (EnvState.obs_dirty), after a reset, or when the
+    // caller asks -- as in the counter-mode kernels; the byte copy in LDS only feeds the packed exchange row
+    int32_t* o = a.obs + (size_t)e * OBS_TOTAL;
+    const bool pack = a.obs8 != nullptr;
+    const int nv = (do_reset || a.full_obs || pack || s->obs_dirty) ? OBS_TOTAL : OBS_FAST;
+    for (int v = lane; v < nv; v += WAVE) { int i; const int val = env_flat_obs_sorted(s, hd, v, &i, ev_lds); o[i] = val; if (pack) obs_lds[i] = (uint8_t)val; }
+  }
   __syncthreads();
   unsigned long long t_out = a.prof ? clock64() : 0;
   if (prof && lane == 0) prof[12] += t_out - t_obs;
   uint4* dst = reinterpret_cast<uint4*>(a.st + e);
   stage_out<HOT_VEC>(dst, lds, lane);
-  int32_t* o = a.obs + (size_t)e * OBS_TOTAL;
-  for (int i = lane; i < OBS_TOTAL; i += WAVE) o[i] = obs_lds[i];
   if (a.obs8) { uint8_t* o8 = a.obs8 + (size_t)e * OBS_PACKED; for (int j = lane; j < OBS_PACKED; j += WAVE) o8[j] = pack_obs_byte(obs_lds, j); }
   if (prof && lane == 0) { prof[13] += clock64() - t_out; prof[14] += clock64() - t_begin; }
   if (prof) { __syncthreads(); if (lane < 15) a.prof[PROF_SLOTS * (size_t)e + lane] += prof_lds[lane]; }
