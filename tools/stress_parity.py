@@ -14,15 +14,18 @@ EP = int(sys.argv[4]) if len(sys.argv) > 4 else 150   # episode length (autorese
 bad = 0
 for k in range(rounds):
     # (rng mode, red policy, counter-mode kernel: 0 = four wavefronts per episode, 1 = one)
-    for mode, rp, lean in ((1, 0, 0), (1, 0, 1), (1, 3, 1), (0, 0, 0), (1, 2, 0), (1, 2, 1), (0, 3, 0), (0, 2, 0)):
+    # ... and, last field, the built-in blue policy (acts for the agents whose action index is negative: every third here)
+    for mode, rp, lean, bp in ((1, 0, 0, 0), (1, 0, 1, 0), (1, 3, 1, 1), (0, 0, 0, 0), (1, 2, 0, 1), (1, 2, 1, 0), (0, 3, 0, 1), (0, 2, 0, 0)):
         seed = 50000 + 1000 * k + 17 * mode + rp
         os.environ['CC4_PHILOX_LEAN'] = str(lean)
-        dev = CC4VecEnv(n, steps=EP, rng_mode=mode, autoreset=True, red_policy=rp)
-        ora = OracleVecEnv(n, steps=EP, rng_mode=mode, autoreset=True, red_policy=rp)
+        dev = CC4VecEnv(n, steps=EP, rng_mode=mode, autoreset=True, red_policy=rp, blue_policy=bp)
+        ora = OracleVecEnv(n, steps=EP, rng_mode=mode, autoreset=True, red_policy=rp, blue_policy=bp)
         assert np.array_equal(dev.reset(seeds=seed), ora.reset(seeds=seed))
         ok = True
         for t in range(T):
             a = random_actions(seed, t, n)
+            if bp:
+                a[(np.arange(n)[:, None] + np.arange(5)[None, :] + t) % 3 == 0] = -1
             d = dev.step(a); o = ora.step(a)
             if not (np.array_equal(d[0], o[0]) and np.array_equal(d[1], o[1]) and np.array_equal(d[2], o[2])):
                 print('MISMATCH round', k, 'mode', mode, 'policy', rp, 'kernel', dev.step_kernel, 'step', t, flush=True); ok = False; bad += 1; break
