@@ -162,7 +162,7 @@ class CybORG:
             labels = self._action_labels()[a]['labels']
             idx = A.action_index(v, labels)
             idx = range(len(labels))[idx]                   # list semantics: a negative index counts from the end, out of range raises IndexError
-            acts[0, b] = idx if idx < (242 if b == 4 else 82) else -1
+            acts[0, b] = idx if idx < (242 if b == 4 else 82) else labels.index('Sleep')   # an explicit Sleep, not "no action" (-1)
         msg = np.zeros((1, 5, MESSAGE_LENGTH), np.uint8)
         for b, a in enumerate(self.agents_blue):
             m = np.asarray((messages or {}).get(a, EMPTY_MESSAGE)).astype(bool)
@@ -402,7 +402,9 @@ class BlueFixedActionWrapper:
             # IndexError), or an action object, which the reference forwards as it is (BlueFixedActionWrapper.py:142-148)
             v = A.action_index(v, labels)
             v = range(len(labels))[v]
-            acts[0, b] = v if v < n else -1                       # padded slots are Sleep (BlueFixedActionWrapper.py:320-332)
+            # a padded slot ('[Padding] Sleep') is an explicit Sleep() submitted by the agent (BlueFixedActionWrapper.py:142-148,
+            # 320-332) -- never -1, which means "no action submitted" and hands the agent to the scenario's built-in blue policy
+            acts[0, b] = v if v < n else labels.index('Sleep')
         messages = {} if messages is None else messages
         msg = np.zeros((1, 5, MESSAGE_LENGTH), np.uint8)
         for b, a in enumerate(self.possible_agents):

@@ -89,6 +89,28 @@ void cc4o_step_all(void* h, const int32_t* actions /* [n][5] */) {
     env_step(x, actions + 5 * i, nullptr);
   }
 }
+// whole-batch step with the results gathered in one call (OpenMP over episodes): what OracleVecEnv.step does episode by
+// episode -- an episode that reported done is regenerated instead of stepped when `autoreset` is set (CybORG.reset(seed=None):
+// the stream continues) -- so that the full-size GPU parity tests (8192 episodes, every step) finish in seconds
+void cc4o_step_batch(void* h, const int32_t* actions /* [n][5] or null */, const uint8_t* msgs /* [n][5][8] or null */, int autoreset,
+                     int rng_mode, int steps, int policy, int32_t* obs /* [n][578] */, float* rew, uint8_t* done, uint32_t* err) {
+  Oracle* o = (Oracle*)h;
+#pragma omp parallel for schedule(dynamic, 8)
+  for (int i = 0; i < o->n; ++i) {
+    StepWork w; memset(&w, 0, sizeof(w));
+    Ctx x{&o->st[i], &o->cold[i], &o->st[i].rng, o->st[i].hd, &w};
+    x.lg = o->evlog ? &o->cold[i].evlog : nullptr;
+    bool was_reset = false;
+    if (autoreset && o->st[i].done) {
+      uint32_t ws[RESET_WS_WORDS];
+      env_reset(x, 0, rng_mode, steps, true, policy, o->topo, rng_mode == 1 ? ws : nullptr);
+      was_reset = true;
+    } else env_step(x, actions ? actions + 5 * i : nullptr, msgs ? msgs + 5 * MSG_LEN * i : nullptr);
+    const EnvState* s = &o->st[i];
+    env_flat_obs<int32_t>(s, s->hd, obs + (size_t)OBS_TOTAL * i);
+    rew[i] = was_reset ? 0.f : s->reward; done[i] = s->done; err[i] = s->err;
+  }
+}
 int cc4o_num_threads() {
 #ifdef _OPENMP
   return omp_get_max_threads();

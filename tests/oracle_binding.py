@@ -26,6 +26,8 @@ def load():
     lib.cc4o_reset.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_uint64, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int]
     lib.cc4o_step.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]
     lib.cc4o_step_all.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
+    lib.cc4o_step_batch.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                    ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
     lib.cc4o_obs.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]
     lib.cc4o_reward.restype = ctypes.c_float
     lib.cc4o_reward.argtypes = [ctypes.c_void_p, ctypes.c_int]
@@ -98,6 +100,26 @@ class OracleVecEnv:
                                None if m is None else m.ctypes.data_as(ctypes.c_void_p))
             self._collect(i)
         return self._obs, self._rew, self._done, {'err': self._err}
+
+    def step_batch(self, actions=None, messages=None):
+        """step() for the whole batch in one native call (cc4o_step_batch: OpenMP over episodes, incl. the autoreset): same
+        results, seconds instead of minutes at 8192 episodes."""
+        a = None if actions is None else np.ascontiguousarray(actions, np.int32)
+        m = None if messages is None else np.ascontiguousarray(messages, np.uint8)
+        done8 = np.zeros(self.num_envs, np.uint8)
+        P = lambda v: None if v is None else v.ctypes.data_as(ctypes.c_void_p)   # noqa: E731
+        self.lib.cc4o_step_batch(self._h, P(a), P(m), int(bool(self.autoreset)), self.rng_mode, self.steps, self.policy,
+                                 P(self._obs), P(self._rew), P(done8), P(self._err))
+        self._done[:] = done8.astype(bool)
+        return self._obs, self._rew, self._done, {'err': self._err}
+
+    def reset_batch(self, seed0):
+        """reset(seeds=seed0 + i) without the per-episode observation / mask fetches of reset() (first observations come with
+        state_obs())."""
+        for i in range(self.num_envs):
+            self.lib.cc4o_reset(self._h, i, ctypes.c_uint64(int(seed0) + i), self.rng_mode, self.steps, 0, self.policy)
+            self._collect(i, reward=False)
+        return self._obs
 
     def set_seed(self, seeds):
         if np.isscalar(seeds):

@@ -150,6 +150,39 @@ def test_full_batch_matches_oracle_every_step(rng_mode, philox_kernel):
     dev.close()
 
 
+@pytest.mark.parametrize('n,red_policy,blue_policy', [(8192, 0, 0), (4096, 0, 0), (8192, 2, 0), (8192, 3, 1)],
+                         ids=['8192-fsm', '4096-fsm', '8192-discovery', '8192-randomselect-builtinblue'])
+def test_bench_configuration_matches_oracle_every_step(n, red_policy, blue_policy):
+    """the configuration bench.py times -- counter mode, autoreset, the kernel cc4_create picks for the batch
+    size with NO override (k_step_philox1 at its natural residency: > 8 episodes per CU, generation work area in HBM, host
+    rows in L2 with atomics) -- against the oracle for ALL episodes at EVERY step (observations, rewards, dones, error flags)
+    across two scenario regenerations, then the generator words and the packed state of every episode."""
+    import os
+    assert 'CC4_PHILOX_LEAN' not in os.environ and 'CC4_PHILOX_MINW' not in os.environ
+    T, steps = 330, 150
+    dev = _dev(n, steps=steps, rng_mode=1, autoreset=True, red_policy=red_policy, blue_policy=blue_policy)
+    assert dev.step_kernel == 'k_step_philox1'
+    ora = OracleVecEnv(n, steps=steps, rng_mode=1, autoreset=True, red_policy=red_policy, blue_policy=blue_policy)
+    assert np.array_equal(dev.reset(seeds=1000), ora.reset_batch(1000))
+    resets = 0
+    for t in range(T):
+        a = random_actions(1000, t, n)
+        if blue_policy:
+            a[(np.arange(n)[:, None] + np.arange(5)[None, :] + t) % 3 == 0] = -1      # a third of the agents leave it to the built-in policy
+        resets += int(ora._done.all())
+        d = dev.step(a)
+        o = ora.step_batch(a)
+        bad = np.nonzero((d[0] != o[0]).any(axis=1) | (d[1] != o[1]) | (d[2] != o[2]) | (d[3]['err'] != o[3]['err']))[0]
+        assert bad.size == 0, (t, bad[:10].tolist())
+        assert not d[3]['err'].any(), t
+    assert resets == 2
+    assert np.array_equal(dev.rng_state(), ora.rng_state())
+    for i in range(n):
+        a_, b_ = dev.get_state(i), ora.get_state(i)
+        assert np.array_equal(a_, b_), f'packed state differs env {i} at byte offsets {np.nonzero(a_ != b_)[0][:20].tolist()}'
+    dev.close()
+
+
 def test_device_random_action_kernel_matches_host_restatement():
     import ctypes
     n = 1024
@@ -169,17 +202,24 @@ def test_device_random_action_kernel_matches_host_restatement():
     dev.close()
 
 
+@pytest.mark.parametrize('rng_mode', [0, 1], ids=['pcg64', 'philox'])
 @pytest.mark.parametrize('n', [1024, 8192])
-def test_full_size_properties(n):
-    """BASELINE configs 2/3: determinism, batch-independence of every episode, observation invariants, clean flags."""
+def test_full_size_properties(n, rng_mode):
+    """BASELINE configs 2/3, both RNG modes (the kernel is the one cc4_create picks for the batch size: at 8192 episodes in the
+    counter mode the one-wave kernel, checked here against a six-episode batch on the four-wave kernel and against the
+    oracle): determinism, batch-independence of every episode, observation invariants, clean flags."""
     T = 40
-    a_env = _dev(n, steps=500); b_env = _dev(n, steps=500)
+    a_env = _dev(n, steps=500, rng_mode=rng_mode); b_env = _dev(n, steps=500, rng_mode=rng_mode)
+    if rng_mode == 1:
+        assert a_env.step_kernel == ('k_step_philox1' if n > 2048 else 'k_step_philox')
     oa = a_env.reset(seeds=1000).copy(); ob = b_env.reset(seeds=1000).copy()
     assert np.array_equal(oa, ob)
     small_idx = np.array([0, 1, n // 3, n // 2, n - 2, n - 1])
-    small = _dev(len(small_idx), steps=500)
+    small = _dev(len(small_idx), steps=500, rng_mode=rng_mode)
+    if rng_mode == 1:
+        assert small.step_kernel == 'k_step_philox'
     small.reset(seeds=np.uint64(1000) + small_idx.astype(np.uint64))
-    ora = OracleVecEnv(len(small_idx), steps=500)
+    ora = OracleVecEnv(len(small_idx), steps=500, rng_mode=rng_mode)
     ora.reset(seeds=np.uint64(1000) + small_idx.astype(np.uint64))
     digest_a = digest_b = 0
     for t in range(T):

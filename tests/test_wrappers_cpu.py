@@ -133,3 +133,24 @@ def test_batched_evaluation_runs_and_is_consistent(oracle_lib, tmp_path):
             break
         tot += float(rew[0])
     assert s[3] == tot
+
+
+def test_padded_action_slot_is_an_explicit_sleep_not_a_missing_action(oracle_lib):
+    """with blue_agent_class=cc4BlueRandomAgent an agent WITHOUT a submitted action is played by the built-in
+    policy; a padded slot ('[Padding] Sleep', index >= 82 with pad_spaces=True) is a submitted Sleep() as in the reference
+    (BlueFixedActionWrapper.py:142-148), so the built-in policy must not be asked and draws nothing."""
+    from cage_challenge_4_amd import cc4BlueRandomAgent
+    sg = EnterpriseScenarioGenerator(blue_agent_class=cc4BlueRandomAgent, green_agent_class=EnterpriseGreenAgent,
+                                     red_agent_class=FiniteStateRedAgent, steps=60)
+    pad = BlueEnterpriseWrapper(CybORG(sg, seed=77, vec_factory=OracleVecEnv), pad_spaces=True)
+    ref = BlueEnterpriseWrapper(CybORG(sg, seed=77, vec_factory=OracleVecEnv), pad_spaces=True)
+    pad.reset(); ref.reset()
+    sleep = {a: pad.action_labels(a).index('Sleep') for a in pad.possible_agents}
+    assert all(pad.action_labels(a)[100] == '[Padding] Sleep' for a in pad.possible_agents[:4])
+    for t in range(40):
+        a_pad = {a: (100 + t % 50 if b < 4 else sleep[a]) for b, a in enumerate(pad.possible_agents)}
+        o1, r1, *_ = pad.step({'actions': a_pad})
+        o2, r2, *_ = ref.step({'actions': dict(sleep)})
+        assert all(np.array_equal(o1[a], o2[a]) for a in o1) and r1 == r2, t
+    assert np.array_equal(pad.env.vec.rng_state(), ref.env.vec.rng_state())      # nothing was drawn for the padded agents
+    assert np.array_equal(pad.env.vec.get_state(0), ref.env.vec.get_state(0))
