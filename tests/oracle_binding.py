@@ -161,6 +161,26 @@ class OracleVecEnv:
         p = self.lib.cc4o_state_ptr(self._h, i)
         return np.frombuffer((ctypes.c_uint8 * n).from_address(p), np.uint8).copy()
 
+    def snapshot(self, i):
+        """(hot row, cold row) of episode i as byte arrays: the layout cc4_get_state / cc4_get_cold return."""
+        self.lib.cc4o_cold_bytes.restype = ctypes.c_size_t
+        self.lib.cc4o_cold_ptr.restype = ctypes.c_void_p
+        self.lib.cc4o_cold_ptr.argtypes = [ctypes.c_void_p, ctypes.c_int]
+        nc = self.lib.cc4o_cold_bytes()
+        cold = np.frombuffer((ctypes.c_uint8 * nc).from_address(self.lib.cc4o_cold_ptr(self._h, i)), np.uint8).copy()
+        return self.get_state(i), cold
+
+    def restore(self, i, snap):
+        hot, cold = snap
+        self.lib.cc4o_cold_bytes.restype = ctypes.c_size_t
+        self.lib.cc4o_cold_ptr.restype = ctypes.c_void_p
+        self.lib.cc4o_cold_ptr.argtypes = [ctypes.c_void_p, ctypes.c_int]
+        hot = np.ascontiguousarray(hot, np.uint8); cold = np.ascontiguousarray(cold, np.uint8)
+        assert hot.size == self.lib.cc4o_state_bytes() and cold.size == self.lib.cc4o_cold_bytes()
+        ctypes.memmove(self.lib.cc4o_state_ptr(self._h, i), hot.ctypes.data, hot.size)
+        ctypes.memmove(self.lib.cc4o_cold_ptr(self._h, i), cold.ctypes.data, cold.size)
+        self._done[i] = bool(self.lib.cc4o_done(self._h, i))
+
     def enable_event_log(self, on=True):
         self.lib.cc4o_enable_event_log.argtypes = [ctypes.c_void_p, ctypes.c_int]
         self.lib.cc4o_enable_event_log(self._h, int(bool(on)))

@@ -69,6 +69,32 @@ def test_hip_policy_variants_match_reference_golden():
         env.close()
 
 
+def test_hip_counter_mode_matches_reference_under_the_philox_proxy(philox_kernel):
+    """VERDICT r02 #2, on the device: both counter-mode step kernels replay the trajectories the real reference produced while
+    stepping under oracle/refgen/philox_proxy.PhiloxProxy (tests/golden/ctrstep_*.npz, oracle/refgen/make_ctr_golden.py): the
+    scenario from the numpy stream (a numpy-stream handle generates it, its snapshot moves to a counter-mode handle through
+    cc4_get/set_state + cc4_get/set_cold), the dynamics on the counter streams of the fixture's key (cc4_set_seed).  All
+    episodes of one length in ONE batch; observations, reward, done of every step."""
+    from cage_challenge_4_amd import CC4VecEnv
+    allf = [G.load_ctr(p) for p in G.list_ctr_fixtures()]
+    assert len(allf) >= 10
+    for steps in sorted({f['steps'] for f in allf}):
+        fixes = [f for f in allf if f['steps'] == steps]
+        env, obs0, masks = G.ctr_start(CC4VecEnv, fixes)
+        assert env.step_kernel == philox_kernel
+        for i, f in enumerate(fixes):
+            assert np.array_equal(obs0[i], f['obs'][0]) and np.array_equal(masks[i], f['mask']), f['name']
+        for t in range(steps):
+            a = np.stack([f['actions'][t] for f in fixes])
+            m = np.stack([f['messages'][t] if f['messages'] is not None else np.zeros((5, 8), np.uint8) for f in fixes])
+            obs, rew, done, info = env.step(a, m)
+            for i, f in enumerate(fixes):
+                assert np.array_equal(obs[i], f['obs'][t + 1]), (f['name'], t)
+                assert rew[i] == f['reward'][t] and bool(done[i]) == bool(f['done'][t]), (f['name'], t)
+            assert not info['err'].any()
+        env.close()
+
+
 @pytest.mark.parametrize('policies', [(0, 0), (2, 0), (1, 1), (3, 0)], ids=['fsm', 'discovery', 'sleep', 'randomselect'])
 @pytest.mark.parametrize('rng_mode', [0, 1], ids=['pcg64', 'philox'])
 def test_hip_matches_oracle_bit_for_bit(rng_mode, policies, philox_kernel):
