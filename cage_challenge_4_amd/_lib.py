@@ -49,12 +49,14 @@ SIGNATURES = {
     'cc4_random_actions_device': (ctypes.c_int, [_P, ctypes.c_uint64, ctypes.c_uint32]),
     'cc4_synchronize': (ctypes.c_int, [_P]),
     'cc4_run_random_steps': (ctypes.c_int, [_P, ctypes.c_uint64, ctypes.c_uint32, ctypes.c_int32, ctypes.POINTER(ctypes.c_float)]),
+    'cc4_launches_per_step': (ctypes.c_int, [_P]),
+    'cc4_host_stats': (ctypes.c_int, [_P, _P]),
     'cc4_state_bytes': (ctypes.c_size_t, []),
     'cc4_hot_bytes': (ctypes.c_size_t, []),
     'cc4_step_kernel': (ctypes.c_char_p, [_P]),
     'cc4_get_state': (ctypes.c_int, [_P, ctypes.c_int32, _P]),
     'cc4_set_state': (ctypes.c_int, [_P, ctypes.c_int32, _P]),
-    'cc4_cold_bytes': (ctypes.c_size_t, []),
+    'cc4_cold_bytes': (ctypes.c_size_t, [_P]),
     'cc4_get_cold': (ctypes.c_int, [_P, ctypes.c_int32, _P]),
     'cc4_set_cold': (ctypes.c_int, [_P, ctypes.c_int32, _P]),
     'cc4_get_topology': (ctypes.c_int, [_P, ctypes.c_int32, _P]),

@@ -24,7 +24,17 @@ struct Ctx { EnvState* s; EnvCold* c; Rng* r; HostDyn* hd; StepWork* w; unsigned
 // per-red-agent section timers (Ctx.aprof = that agent's 8 slots of the debug buffer)
 #define CC4_AT0(x) unsigned long long _at = (x).aprof ? clock64() : 0
 #define CC4_AT(x, k) do { if ((x).aprof) { unsigned long long _n = clock64(); (x).aprof[(k)] += _n - _at; _at = _n; } } while (0)
+#if defined(CC4_FINE)
+// finer sections of red agent 0's policy / tick (debug build -DCC4_FINE): slots 104 + k of the episode's row (aprof of agent 0 = slot 16)
+#define CC4_FT0(x, r) unsigned long long _ft = ((x).aprof && (r) == 0) ? clock64() : 0
+#define CC4_FT(x, r, k) do { if ((x).aprof && (r) == 0) { unsigned long long _n = clock64(); (x).aprof[88 + (k)] += _n - _ft; _ft = _n; } } while (0)
 #else
+#define CC4_FT0(x, r) do { } while (0)
+#define CC4_FT(x, r, k) do { } while (0)
+#endif
+#else
+#define CC4_FT0(x, r) do { } while (0)
+#define CC4_FT(x, r, k) do { } while (0)
 #define CC4_AT0(x) do { } while (0)
 #define CC4_AT(x, k) do { } while (0)
 #define CC4_TICK(x, i) do { } while (0)
@@ -178,16 +188,16 @@ CC4_HD void eph_clear(Ctx x, int h) {
   Q z; z.a = 0; z.b = 0; z.c = 0; z.d = 0;
   for (int i = 0; i < EPH_WORDS / 4; ++i) p[i] = z;
 }
-// ---- Host.processes: entries 0..PIN-1 in the hot row, PIN.. in the cold row (EnvCold.povf[h]).  Every scan reads eight
-// records per round as independent word loads (pid | kind << 16 | flags << 24); PIN and POVF are multiples of eight, so a
-// round never straddles the two parts and may read allocated slots past the end of the list (masked by the index test).
+// ---- Host.processes: entries 0..PIN-1 in the hot row, PIN.. in the cold row (cold_povf).  Every scan reads eight
+// records per round as independent word loads (pid | kind << 16 | flags << 24); PIN and the cold capacity are multiples of
+// eight, so a round never straddles the two parts and may read allocated slots past the end of the list (masked by the index test).
 CC4_HD int hd_nsvc(const HostDyn& d) { return d.nsf & 0xF; }
 CC4_HD void hd_set_nsvc(HostDyn& d, int n) { d.nsf = (uint8_t)((d.nsf & 0xF0) | n); }
 CC4_HD int hd_files(const HostDyn& d) { return d.nsf >> 4; }
 CC4_HD void hd_set_files(HostDyn& d, int f) { d.nsf = (uint8_t)((d.nsf & 0x0F) | (f << 4)); }
 struct P8 { uint32_t v[8]; };
 CC4_HD const uint32_t* proc_round_ptr(Ctx x, int h, int i0) {
-  return i0 < PIN ? reinterpret_cast<const uint32_t*>(x.hd[h].procs) + i0 : reinterpret_cast<const uint32_t*>(x.c->povf[h]) + (i0 - PIN);
+  return i0 < PIN ? reinterpret_cast<const uint32_t*>(x.hd[h].procs) + i0 : cold_povf(x.c, x.s->steps, h) + (i0 - PIN);
 }
 CC4_HD P8 proc_load8(Ctx x, int h, int i0) {
   const uint32_t* p = proc_round_ptr(x, h, i0);
@@ -213,7 +223,7 @@ CC4_HD int create_pid(Ctx x, int h) {
 CC4_HD bool add_proc(Ctx x, int h, int pid, int kind, int flags) {
   HostDyn& d = x.hd[h];
   const int n = d.nproc;
-  if (n >= MAXP) { set_err(x, E_PROC_OVERFLOW); return false; }
+  if (n >= PIN && n >= PIN + cold_povf_cap(x.s->steps)) { set_err(x, E_PROC_OVERFLOW); return false; }
   proc_put(x, h, n, (uint32_t)pid | ((uint32_t)kind << 16) | ((uint32_t)flags << 24));
   d.nproc = (uint16_t)(n + 1);
   return true;
@@ -1071,7 +1081,7 @@ CC4_HD void blue_monitor(Ctx x, int b) {
   for (int i = 0; i < s->npend; ++i) {
     int h = (int)(s->pend[i] >> 16);
     if (blue_of_subnet(h_subnet(h)) == b) {
-      if (A.nsus >= MAX_SUS) set_err(x, E_SUS_OVERFLOW); else { x.c->sus[b][A.nsus++] = s->pend[i]; bit_set(A.sus_hosts, h); }
+      if (A.nsus >= cold_sus_cap(s->steps)) set_err(x, E_SUS_OVERFLOW); else { cold_sus(x.c, s->steps, b)[A.nsus++] = s->pend[i]; bit_set(A.sus_hosts, h); }
     } else s->pend[n++] = s->pend[i];
   }
   s->npend = (uint8_t)n;
@@ -1131,13 +1141,13 @@ CC4_HD void blue_remove(Ctx x, int b, int h) {
   if (!bit_get(A.sus_hosts, h)) return;   // parent_session.sus_pids has no entry for this hostname
   // The list lives in the cold row (HBM).  It is filtered with 16 independent loads in flight per round into a small LDS
   // work area (12 words per blue agent), then the matching pids are stopped in list order.
-  const uint32_t* list = x.c->sus[b];
+  const uint32_t* list = cold_sus(x.c, x.s->steps, b);
   uint16_t* hit = reinterpret_cast<uint16_t*>(x.w->scratch + 12 * b);
   const int cap = 24, n = A.nsus;
   int i0 = 0;
   while (i0 < n) {
     int nh = 0;
-    for (; i0 < n && nh + 16 <= cap; i0 += 16) {   // MAX_SUS is a multiple of 16: the tail of a round reads allocated slots
+    for (; i0 < n && nh + 16 <= cap; i0 += 16) {   // the list's capacity is a multiple of 16: the tail of a round reads allocated slots
       uint32_t v[16];                              // 16 independent loads in flight: one HBM round trip per 16 entries
       CC4_UNROLL for (int k = 0; k < 16; ++k) v[k] = list[i0 + k];
       CC4_UNROLL for (int k = 0; k < 16; ++k) if (i0 + k < n && (int)(v[k] >> 16) == h) hit[nh++] = (uint16_t)v[k];
@@ -1870,7 +1880,9 @@ CC4_HD Act fsm_get_action(Ctx x, int r, RedHdr& H, bool observed = false) {
   EnvState* s = x.s;
   RedAgent& A = s->red[r];
   Act out; out.type = RA_SLEEP; out.host = 0; out.arg = 0; out.ticks = 1; out.sid = 0; out.busy = 0;
+  CC4_FT0(x, r);
   if (!observed) fsm_observe(x, r, H);
+  CC4_FT(x, r, 5);
   if (H.obs_success == T_IN_PROGRESS) { H.fsm_step++; return out; }
   int n = H.fsm_n;  // fsm_order holds exactly the non-'F' hosts, in host_states insertion order
   if (n == 0) { set_err(x, E_FSM_NO_HOST); H.fsm_step++; return out; }
@@ -1881,6 +1893,7 @@ CC4_HD Act fsm_get_action(Ctx x, int r, RedHdr& H, bool observed = false) {
   // options in red_actions list order (ESG.py:764-768) with state_transitions_probability (:540-549).  All probabilities
   // are multiples of 1/4, so cdf.searchsorted(u, 'right') == #{i : 4*cdf[i] <= floor(4u)}.  Packed per state:
   // low 16 bits = option nibbles, high 16 bits = 4*cdf nibbles (unused slots = 15)
+  CC4_FT(x, r, 6);
   uint32_t pk;
   const int host_state = fsm_get(A, host);
   if (!discovery) switch (host_state) {
@@ -1921,6 +1934,7 @@ CC4_HD Act fsm_get_action(Ctx x, int r, RedHdr& H, bool observed = false) {
   if (bad) { set_err(x, E_UNREACHABLE); out.type = RA_SLEEP; }  // reference would re-draw with p not summing to 1 and raise
   out.ticks = (uint8_t)red_duration(out.type);
   H.fsm_step++;
+  CC4_FT(x, r, 7);
   return out;
 }
 // RandomSelectRedAgent.get_action (Agents/SimpleAgents/RandomSelectRedAgent.py:33-103): uniform command, then uniform
@@ -2184,11 +2198,14 @@ CC4_HD bool rsc_draws(const EnvState* s, int r) {
 CC4_HD int step_red_policy_tick(Ctx x, int r, bool observed = false) {
   EnvState* s = x.s;
   RedAgent& A = s->red[r];
+  CC4_FT0(x, r);
   RedHdr H = A.h;
   Act a; a.type = RA_SLEEP; a.host = 0; a.arg = 0; a.ticks = 1; a.sid = 0; a.busy = 0;
   rng_set_stream(x.r, ST_RED_POL + (uint32_t)r);
+  CC4_FT(x, r, 0);
   if (H.active && (s->policy & 3) == RP_RANDOM) { a = random_red_get_action(x, r, H); red_validate(x, r, H, a); }
   else if (H.active && (s->policy & 3) != RP_SLEEP) { a = fsm_get_action(x, r, H, observed); CC4_AT0(x); red_validate(x, r, H, a); CC4_AT(x, 7); }   // AgentInterface.get_action (:120-143); SleepAgent -> Sleep
+  CC4_FT(x, r, 1);
   if (!H.queue.busy) { H.queue = a; H.queue.busy = 1; }
   // ---- tick: a new step's observation starts empty
   H.nobs = 0; H.obs_success = 0; H.obs_act_type = RA_NONE; H.new_sess_host = 0xFF; H.rsc_listed = 0;
@@ -2203,9 +2220,12 @@ CC4_HD int step_red_policy_tick(Ctx x, int r, bool observed = false) {
   H.queue = q;
   H.exec_type = ex.type; H.exec_host = ex.host;
   int dropped = 0;
+  CC4_FT(x, r, 2);
   if (ex.type <= RA_WITHDRAW && rs_find_id(s, A, ex.sid, H.nsess) < 0) { ex.type = RA_NONE; dropped = 1; }
+  CC4_FT(x, r, 3);
   s->rexec[r] = ex;
   A.h = H;
+  CC4_FT(x, r, 4);
   return dropped;
 }
 // shuffle_done: the caller has already consumed the shuffle's draws (the numpy-stream kernel does that across the wave)
@@ -2356,7 +2376,7 @@ CC4_HD void step_monitor_pend(Ctx x) {  // session.add_sus_pids for the pid-carr
     int b = blue_of_subnet(h_subnet((int)(s->pend[i] >> 16)));
     if (b < 0) continue;
     BlueAgent& A = s->blue[b];
-    if (A.nsus >= MAX_SUS) set_err(x, E_SUS_OVERFLOW); else { x.c->sus[b][A.nsus++] = s->pend[i]; bit_set(A.sus_hosts, (int)(s->pend[i] >> 16)); }
+    if (A.nsus >= cold_sus_cap(s->steps)) set_err(x, E_SUS_OVERFLOW); else { cold_sus(x.c, s->steps, b)[A.nsus++] = s->pend[i]; bit_set(A.sus_hosts, (int)(s->pend[i] >> 16)); }
   }
   s->npend = 0;
 }

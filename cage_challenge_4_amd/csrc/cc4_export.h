@@ -25,12 +25,17 @@
 
 namespace cc4 {
 
-// process i of host h: the hot part of the list, then the cold part (EnvCold.povf)
-inline Proc export_proc(const EnvState& s, const EnvCold& c, int h, int i) { return i < PIN ? s.hd[h].procs[i] : c.povf[h][i - PIN]; }
+// process i of host h: the hot part of the list, then the cold part (cold_povf)
+inline Proc export_proc(const EnvState& s, const EnvCold& c, int h, int i) {
+  if (i < PIN) return s.hd[h].procs[i];
+  Proc p; __builtin_memcpy(&p, cold_povf(&c, s.steps, h) + (i - PIN), sizeof(Proc));
+  return p;
+}
 
 inline std::string export_true_state(const EnvState& s, const EnvCold& cold, bool with_log = true) {
   const HostStatic* hs = cold.hs;
-  const uint32_t (*sus)[MAX_SUS] = cold.sus;
+  const uint32_t* sus[NBLUE];
+  for (int b = 0; b < NBLUE; ++b) sus[b] = cold_sus(&cold, s.steps, b);
   const EvLog* lg = with_log ? &cold.evlog : nullptr;
   std::string o;
   char b[256];

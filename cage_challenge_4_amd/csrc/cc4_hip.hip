@@ -50,6 +50,8 @@ struct StepArgs {
   unsigned long long* prof;   // optional [n][PROF_SLOTS] cycle counters (cc4_debug_profile): 16 phase slots + 8 per red agent
   uint32_t* reset_ws;         // k_step_philox1: [n][RESET_WS_WORDS] work area of the in-kernel scenario generation (the other
                               // kernels keep it in LDS; an episode regenerates once in steps-per-episode launches)
+  int e0;                     // first episode of this launch: block b steps episode e0 + b (a step of a large batch is issued as
+                              // several launches on separate streams: see cc4_handle::ngroups); n = one past its last episode
 };
 
 // uniform blue action index of (episode e, agent b) at step t: Philox key (seed0 + e), counter (t, b, 0xB10E, 0)
@@ -457,8 +459,9 @@ __global__ __launch_bounds__(WAVE) void k_step(StepArgs a) {
   uint8_t* const ev_lds = obs_lds + OBS_LDS;
   __shared__ int ok_lds;
   __shared__ StepWork work;
-  const int e = blockIdx.x, lane = threadIdx.x;
+  const int e = a.e0 + (int)blockIdx.x, lane = threadIdx.x;
   if (e >= a.n) return;
+  EnvCold* const cold_e = cold_at(a.cold, (size_t)e, cold_row_bytes(a.steps));
   unsigned long long t_begin = a.prof ? clock64() : 0;
   const uint4* src = reinterpret_cast<const uint4*>(a.st + e);
   stage_in<HOT_VEC>(lds, src, lane);
@@ -474,8 +477,8 @@ __global__ __launch_bounds__(WAVE) void k_step(StepArgs a) {
   Rng rl = s->rng;
   rl.mode = 0;
   rl.pad = 0;
-  Ctx x{s, a.cold + e, &rl, hd, &work, lane == 0 ? prof : nullptr};
-  x.lg = LOG ? &a.cold[e].evlog : nullptr;
+  Ctx x{s, cold_e, &rl, hd, &work, lane == 0 ? prof : nullptr};
+  x.lg = LOG ? &cold_e->evlog : nullptr;
   if (prof && lane == 0) prof[11] += clock64() - t_begin;
   const bool do_reset = a.autoreset && s->done;
   // The ordered walk is lane 0's; between its stretches the whole wave does what needs no order: the two draw-only phases
@@ -503,7 +506,7 @@ __global__ __launch_bounds__(WAVE) void k_step(StepArgs a) {
     const int b = lane - 1;
     int32_t act = a.actions ? a.actions[e * NBLUE + b] : -1;
     if (a.rand_out) { act = random_blue_action(a.rand_seed0, a.rand_t, e, b); a.rand_out[e * NBLUE + b] = act; }
-    Ctx xb{s, a.cold + e, &rl, hd, &work};
+    Ctx xb{s, cold_e, &rl, hd, &work};
     step_blue_submit(xb, b, act);
   }
   __syncthreads();
@@ -511,7 +514,7 @@ __global__ __launch_bounds__(WAVE) void k_step(StepArgs a) {
     bool drawn = false;
     if (!(s->policy & GP_SLEEP_BIT)) drawn = wave_green_policy(rl, s->n_green, work.green_act, lane);
     // the observation half of the six red policies draws nothing and touches only its own agent: side by side on six lanes
-    if (lane < NRED) { Ctx xo{s, a.cold + e, &rl, hd, &work}; step_red_observe(xo, lane); }
+    if (lane < NRED) { Ctx xo{s, cold_e, &rl, hd, &work}; step_red_observe(xo, lane); }
     __syncthreads();
     if (lane == 0) {
       if (!drawn) for (int g = 0; g < s->n_green; ++g) step_green_policy(x, g);   // SleepAgent greens, or the 2^-32 re-draw case
@@ -575,7 +578,7 @@ __global__ __launch_bounds__(WAVE) void k_step(StepArgs a) {
       // usual case) the six checks run side by side, else in order on the walking lane
       const bool need = lane < NRED && rsc_draws(s, lane);
       const bool serial = __ballot(need) != 0ull;
-      if (!serial && lane < NRED) { Ctx xc{s, a.cold + e, &rl, hd, &work, nullptr, nullptr, x.lg}; step_rsc(xc, lane); }
+      if (!serial && lane < NRED) { Ctx xc{s, cold_e, &rl, hd, &work, nullptr, nullptr, x.lg}; step_rsc(xc, lane); }
       if (lane == 0) CC4_TICK(x, 9);
       __syncthreads();
       if (lane == 0) {
@@ -676,9 +679,10 @@ __global__ __launch_bounds__(PT, MINW) void k_step_philox(StepArgs a) {
   __shared__ uint8_t obs_bytes[OBS_TOTAL + 2];   // byte-per-value copy of the observations, only for the packed exchange row
   __shared__ uint8_t glist[2][2][MAXG];  // green agents by action type (0 AccessService, 1 LocalWork) and drawing wave
   __shared__ unsigned long long prof_lds[16];
-  const int e = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
+  const int e = a.e0 + (int)blockIdx.x, tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform by construction: kept in an SGPR
   if (e >= a.n) return;
+  EnvCold* const cold_e = cold_at(a.cold, (size_t)e, cold_row_bytes(a.steps));
   unsigned long long t_begin = a.prof ? clock64() : 0;
   const uint4* src = reinterpret_cast<const uint4*>(a.st + e);
   // the part outside the host table through registers (3 vectors per thread), then the host-table chunks by DMA
@@ -707,14 +711,14 @@ __global__ __launch_bounds__(PT, MINW) void k_step_philox(StepArgs a) {
     dma_wait();
     __syncthreads();
     // new episode on the same key (CybORG.reset(seed=None)): the phases of env_reset_counter_mode, hosts on threads
-    reset_zero(s, hd, a.cold + e, tid, PT);
+    reset_zero(s, hd, cold_e, tid, PT);
     __syncthreads();
     Rng rr; ResetCarry carry; carry.env_key = 0;     // thread 0: main reset stream in registers, across the phases
-    Ctx xm{s, a.cold + e, &rr, hd, &work};
+    Ctx xm{s, cold_e, &rr, hd, &work};
     if (tid == 0) { rr = s->rng; rr.mode = 1; carry = reset_topology(xm, 0, a.steps, true, a.policy, a.topo, reset_ws, true); }
     __syncthreads();
     Rng rh; rng_fork(&rh, &s->rng, ST_GEN_HOST); rh.mode = 1;
-    Ctx xh{s, a.cold + e, &rh, hd, &work};
+    Ctx xh{s, cold_e, &rh, hd, &work};
     if (tid < MAXH) reset_gen_host(xh, tid);
     __syncthreads();
     if (tid < MAXH) reset_pid_mark(xh, tid, reset_ws);
@@ -734,13 +738,13 @@ __global__ __launch_bounds__(PT, MINW) void k_step_philox(StepArgs a) {
     const int st_now = s->step_count;
     const bool step_ok = step_phase_of(st_now, s->phase_len[0], s->phase_len[1], s->phase_len[2]) >= 0;
     if (tid == 0) {
-      Ctx x{s, a.cold + e, &s->rng, hd, &work, prof};
-      x.lg = LOG ? &a.cold[e].evlog : nullptr;
+      Ctx x{s, cold_e, &s->rng, hd, &work, prof};
+      x.lg = LOG ? &cold_e->evlog : nullptr;
       CC4_TICK0(x);
       (void)step_phase(x, false);
     }
     if (step_ok) {
-      Ctx x0p{s, a.cold + e, nullptr, hd, &work, tid == 0 ? prof : nullptr};
+      Ctx x0p{s, cold_e, nullptr, hd, &work, tid == 0 ? prof : nullptr};
       const int ng = s->n_green;
       // one thread-private generator per thread, in registers: every use starts with rng_set_stream(), which fully
       // determines the stream from (key, step, episode, stream id); mode pinned so the PCG paths fold away
@@ -749,8 +753,8 @@ __global__ __launch_bounds__(PT, MINW) void k_step_philox(StepArgs a) {
       rng_fork(&rl, &s->rng, ST_RESET);
       rl.mode = 1;
       rng_begin_step(&rl, (uint32_t)st_now);   // not read from the row: thread 0 may still be storing it there
-      EvLog* const lg = LOG ? &a.cold[e].evlog : nullptr;
-      Ctx x0{s, a.cold + e, &rl, hd, &work, tid == 0 ? prof : nullptr};         // thread 0
+      EvLog* const lg = LOG ? &cold_e->evlog : nullptr;
+      Ctx x0{s, cold_e, &rl, hd, &work, tid == 0 ? prof : nullptr};         // thread 0
       x0.lg = lg;
 #ifndef CC4_RED_WAVES
 #define CC4_RED_WAVES 2
@@ -759,7 +763,7 @@ __global__ __launch_bounds__(PT, MINW) void k_step_philox(StepArgs a) {
       const int ragent = lane * RW + wave;
       const bool is_red = wave < RW && lane < (NRED + RW - 1) / RW && ragent < NRED;
       unsigned long long* ap = (a.prof && is_red) ? a.prof + PROF_SLOTS * (size_t)e + 16 + 8 * ragent : nullptr;
-      Ctx xr{s, a.cold + e, &rl, hd, &work, nullptr, ap, lg};
+      Ctx xr{s, cold_e, &rl, hd, &work, nullptr, ap, lg};
       // ---- P0-P3a: every agent's policy / submission followed by its own duration-queue tick (SC:236-265), all on the
       // agent's thread: red r on wave r%PW lane r/PW, blue on wave PW-1 lanes 2..6, green draws on lanes >= 8 of the waves
       // that carry a single red agent.  A tick touches only its own agent (queue, observation reset, filter_actions
@@ -788,7 +792,7 @@ __global__ __launch_bounds__(PT, MINW) void k_step_philox(StepArgs a) {
         static_assert(PW == 4 && MAXG <= 2 * (WAVE - 8), "every green agent has its own lane on wave 2 or 3: one pass, one ballot per type");
         const int g = (wave - 2) * (WAVE - 8) + (lane - 8);
         if (g < ng) {
-          Ctx xg{s, a.cold + e, &rl, hd, &work, nullptr, nullptr, lg};
+          Ctx xg{s, cold_e, &rl, hd, &work, nullptr, nullptr, lg};
           step_green_policy(xg, g);
           const int t = work.green_act[g];
           // compaction by action type with a wavefront ballot + prefix count (agent order, no LDS atomics): each drawing wave
@@ -820,7 +824,7 @@ __global__ __launch_bounds__(PT, MINW) void k_step_philox(StepArgs a) {
         constexpr int BW = CC4_BLUE_WAVES;
         const int bagent = lane * BW + wave;                                      // blue agent b on wave b % BW, lane b / BW
         if (wave < BW && lane < (NBLUE + BW - 1) / BW && bagent < NBLUE) {
-          Ctx xb{s, a.cold + e, &rl, hd, &work, nullptr, nullptr, lg};
+          Ctx xb{s, cold_e, &rl, hd, &work, nullptr, nullptr, lg};
           const uint4 blk = reinterpret_cast<const uint4*>(reset_ws)[MAXG + NRED + bagent];
           const uint32_t pre[4] = {blk.x, blk.y, blk.z, blk.w};
           step_blue_exec_agent(xb, bagent, pre);
@@ -838,7 +842,7 @@ __global__ __launch_bounds__(PT, MINW) void k_step_philox(StepArgs a) {
         const int n0 = glist_n[wave][0], n1 = glist_n[wave][1];
         for (int i = lane; i < n0 + n1; i += WAVE) {
           int g = i < n0 ? glist[wave][0][i] : glist[wave][1][i - n0];
-          Ctx xg{s, a.cold + e, &rl, hd, &work, nullptr, nullptr, lg};
+          Ctx xg{s, cold_e, &rl, hd, &work, nullptr, nullptr, lg};
           const uint4 blk = reinterpret_cast<const uint4*>(reset_ws)[g];
           const uint32_t pre[4] = {blk.x, blk.y, blk.z, blk.w};
           pen += step_green_exec(xg, g, pre);
@@ -878,7 +882,7 @@ __global__ __launch_bounds__(PT, MINW) void k_step_philox(StepArgs a) {
       // reads none of it, so there is no barrier in between.
       if (is_red) { unsigned long long t0 = ap ? clock64() : 0; step_rsc(xr, ragent); if (ap) ap[2] += clock64() - t0; }
       if (tid == PT - 1) {
-        Ctx xe{s, a.cold + e, &rl, hd, &work, nullptr, nullptr, lg};
+        Ctx xe{s, cold_e, &rl, hd, &work, nullptr, nullptr, lg};
         step_monitor_pend(xe);
         step_end(xe, nullptr, false);
         a.reward[e] = s->reward; a.done[e] = s->done;
@@ -926,8 +930,9 @@ __global__ __launch_bounds__(WAVE) void k_step_philox1(StepArgs a) {
   __shared__ StepWork work;
   __shared__ int conflict_lds;
   unsigned long long* const prof_lds = reinterpret_cast<unsigned long long*>(obs_bytes);
-  const int e = blockIdx.x, lane = threadIdx.x;
+  const int e = a.e0 + (int)blockIdx.x, lane = threadIdx.x;
   if (e >= a.n) return;
+  EnvCold* const cold_e = cold_at(a.cold, (size_t)e, cold_row_bytes(a.steps));
   if (a.obs8) a.prof = nullptr;
   unsigned long long t_begin = a.prof ? clock64() : 0;
   const uint4* src = reinterpret_cast<const uint4*>(a.st + e);
@@ -946,14 +951,14 @@ __global__ __launch_bounds__(WAVE) void k_step_philox1(StepArgs a) {
     // new episode on the same key (CybORG.reset(seed=None)): the phases of env_reset_counter_mode, hosts on lanes; the pid
     // bitmaps of the generation live in HBM here (LDS bounds this kernel's residency, and this path runs once per episode)
     uint32_t* const ws = a.reset_ws + (size_t)e * RESET_WS_WORDS;
-    reset_zero(s, hd, a.cold + e, lane, WAVE);
+    reset_zero(s, hd, cold_e, lane, WAVE);
     __syncthreads();
     Rng rr; ResetCarry carry; carry.env_key = 0;     // lane 0: main reset stream in registers, across the phases
-    Ctx xm{s, a.cold + e, &rr, hd, &work};
+    Ctx xm{s, cold_e, &rr, hd, &work};
     if (lane == 0) { rr = s->rng; rr.mode = 1; carry = reset_topology(xm, 0, a.steps, true, a.policy, a.topo, ws, true); }
     __syncthreads();
     Rng rh; rng_fork(&rh, &s->rng, ST_GEN_HOST); rh.mode = 1;
-    Ctx xh{s, a.cold + e, &rh, hd, &work};
+    Ctx xh{s, cold_e, &rh, hd, &work};
     for (int h = lane; h < MAXH; h += WAVE) reset_gen_host(xh, h);
     __syncthreads();
     for (int h = lane; h < MAXH; h += WAVE) reset_pid_mark(xh, h, ws);
@@ -970,8 +975,8 @@ __global__ __launch_bounds__(WAVE) void k_step_philox1(StepArgs a) {
     const int st_now = s->step_count;
     const bool step_ok = step_phase_of(st_now, s->phase_len[0], s->phase_len[1], s->phase_len[2]) >= 0;
     if (lane == 0) {
-      Ctx x{s, a.cold + e, &s->rng, hd, &work, prof};
-      x.lg = LOG ? &a.cold[e].evlog : nullptr;
+      Ctx x{s, cold_e, &s->rng, hd, &work, prof};
+      x.lg = LOG ? &cold_e->evlog : nullptr;
       CC4_TICK0(x);
       (void)step_phase(x, false);
     }
@@ -983,14 +988,14 @@ __global__ __launch_bounds__(WAVE) void k_step_philox1(StepArgs a) {
       rng_fork(&rl, &s->rng, ST_RESET);
       rl.mode = 1;
       rng_begin_step(&rl, (uint32_t)st_now);   // not read from the row: lane 0 may still be storing it there
-      EvLog* const lg = LOG ? &a.cold[e].evlog : nullptr;
-      Ctx x0{s, a.cold + e, &rl, hd, &work, lane == 0 ? prof : nullptr};
+      EvLog* const lg = LOG ? &cold_e->evlog : nullptr;
+      Ctx x0{s, cold_e, &rl, hd, &work, lane == 0 ? prof : nullptr};
       x0.lg = lg;
       if (lane == 0) CC4_TICK(x0, 0);
       const bool is_red = lane < NRED;
       unsigned long long* ap = (a.prof && is_red) ? a.prof + PROF_SLOTS * (size_t)e + 16 + 8 * lane : nullptr;
-      Ctx xr{s, a.cold + e, &rl, hd, &work, nullptr, ap, lg};
-      Ctx xg{s, a.cold + e, &rl, hd, &work, nullptr, nullptr, lg};
+      Ctx xr{s, cold_e, &rl, hd, &work, nullptr, ap, lg};
+      Ctx xg{s, cold_e, &rl, hd, &work, nullptr, nullptr, lg};
       // ---- P0-P3a: every agent's policy / submission and its own duration-queue tick (SC:236-265)
       if (is_red) {
         unsigned long long t0 = ap ? clock64() : 0;
@@ -1117,20 +1122,21 @@ __global__ __launch_bounds__(WAVE) void k_reset(ResetArgs a) {
   const int e = blockIdx.x, lane = threadIdx.x;
   if (e >= a.n) return;
   if (a.env_mask && !a.env_mask[e]) return;
+  EnvCold* const cold_e = cold_at(a.cold, (size_t)e, cold_row_bytes(a.steps));
   EnvState* s = a.st + e;
   HostDyn* const hd = s->hd;
   for (int i = lane; i < (int)(sizeof(StepWork) / 4); i += WAVE) reinterpret_cast<uint32_t*>(&work)[i] = 0;
   __syncthreads();
   if (a.rng_mode == 1) {   // counter-based mode: the phases of env_reset_counter_mode, hosts on lanes (the row stays in HBM here)
     __shared__ uint32_t ws[RESET_WS_WORDS];
-    Ctx xm{s, a.cold + e, &s->rng, hd, &work};
+    Ctx xm{s, cold_e, &s->rng, hd, &work};
     ResetCarry carry; carry.env_key = 0;
-    reset_zero(s, hd, a.cold + e, lane, WAVE);
+    reset_zero(s, hd, cold_e, lane, WAVE);
     __syncthreads();
     if (lane == 0) carry = reset_topology(xm, a.seeds ? a.seeds[e] : 0, a.steps, a.seeds == nullptr, a.policy, a.topo, ws, false);
     __syncthreads();
     Rng rh; rng_fork(&rh, &s->rng, ST_GEN_HOST); rh.mode = 1;
-    Ctx xh{s, a.cold + e, &rh, hd, &work};
+    Ctx xh{s, cold_e, &rh, hd, &work};
     for (int h = lane; h < MAXH; h += WAVE) reset_gen_host(xh, h);
     __syncthreads();
     for (int h = lane; h < MAXH; h += WAVE) reset_pid_mark(xh, h, ws);
@@ -1144,7 +1150,7 @@ __global__ __launch_bounds__(WAVE) void k_reset(ResetArgs a) {
     if (lane == 0) reset_finish(xm, carry, a.steps, a.topo, false);
     __syncthreads();
   } else if (lane == 0) {
-    Ctx x{s, a.cold + e, &s->rng, hd, &work};
+    Ctx x{s, cold_e, &s->rng, hd, &work};
     env_reset(x, a.seeds ? a.seeds[e] : 0, 0, a.steps, a.seeds == nullptr, a.policy, a.topo);
   }
   if (lane == 0) {
@@ -1218,6 +1224,7 @@ struct cc4_handle {
   cc4_config cfg;
   hipStream_t stream = nullptr;
   EnvState* d_state = nullptr; EnvCold* d_cold = nullptr;
+  size_t cold_row = 0;             // bytes per cold row: fixed part + the containers sized from cfg.steps (cold_row_bytes)
   int32_t* d_actions = nullptr; uint8_t* d_msgs = nullptr; uint64_t* d_seeds = nullptr; uint8_t* d_envmask = nullptr;
   int32_t* d_obs = nullptr; float* d_reward = nullptr; uint8_t* d_done = nullptr; uint32_t* d_err = nullptr;
   uint8_t* d_mask = nullptr; uint64_t* d_rng = nullptr;
@@ -1229,11 +1236,26 @@ struct cc4_handle {
   uint8_t* d_all_obs8[OBS_RING] = {};
   long long gather_seq[OBS_RING] = {};           // sequence number of the last all-gather that read buffer b (0 = none)
   long long gathers_issued = 0, gathers_waited = 0;
+  long long gather_stalls = 0;                   // a step launch found the all-gather it had to wait for still running
+  long long stat_steps = 0; double stat_launch_us = 0, stat_gather_us = 0;   // cc4_host_stats
   hipStream_t comm_stream = nullptr;
-  hipEvent_t ev_step[OBS_RING] = {}, ev_comm[OBS_RING] = {};   // ev_comm[q % OBS_RING]: all-gather number q has completed
+  hipEvent_t ev_step[OBS_RING][4] = {}, ev_comm[OBS_RING] = {};   // ev_step[b][g]: group g's launch that wrote buffer b; ev_comm[q % OBS_RING]: all-gather number q has completed
   int obs_buf = 0;                               // buffer written by the most recent step
   int gather_buf = -1;                           // buffer of the most recent all-gather (-1: none issued)
   bool step_event_attached = false;              // ev_step[obs_buf] was recorded by the launch of that step itself
+  // A step of a large batch is issued as `ngroups` launches, one per contiguous group of episodes, each group on its own HIP
+  // stream (group 0 on `stream`): episodes are independent, a group's next step depends only on its own previous one, so while
+  // one group's launch drains -- its last blocks running on a half-empty chip -- the other group's launch fills the free
+  // slots, and the chip stays full across step boundaries.  Measured on MI355X (r03, 8192 episodes, counter mode): one launch
+  // per step 507 M agent-env steps/s, two groups of 4096 on two streams 639 M (a single 32768-episode launch per step: 605 M).
+  static constexpr int MAX_GROUPS = 4;
+  int ngroups = 1;
+  int glo[MAX_GROUPS + 1] = {};                  // group g = episodes [glo[g], glo[g + 1])
+  hipStream_t gstream[MAX_GROUPS] = {};          // gstream[0] == stream
+  hipEvent_t gev[MAX_GROUPS] = {};               // group stream -> main stream ordering (join_groups)
+  hipEvent_t mev = nullptr;                      // main stream -> group streams ordering (fork_groups)
+  bool groups_busy = false;                      // a group stream other than the main one may hold unfinished step launches
+  bool main_ahead = false;                       // the main stream holds work the group streams have not been ordered behind
   unsigned long long* d_prof = nullptr;
   uint32_t* d_reset_ws = nullptr;    // k_step_philox1's generation work area, [num_envs][RESET_WS_WORDS]
   uint8_t* d_unpacked = nullptr;                 // [world*N][578] bytes: cc4_unpack_obs_device
@@ -1243,7 +1265,7 @@ struct cc4_handle {
   int philox_minw = 1;            // which register budget of k_step_philox this batch size runs (1, 7 or 8 blocks per CU; cc4_create)
   ncclComm_t comm = nullptr; int rank = 0, world = 1;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
-  std::vector<hipEvent_t> evs;
+  std::vector<hipEvent_t> evs;                   // timing events of cc4_run_random_steps: [group][2 * timed group of launches + {start, stop}]
   std::string err;
 };
 
@@ -1257,6 +1279,27 @@ static thread_local std::string g_create_err;
       return -1;                                                                               \
     }                                                                                          \
   } while (0)
+
+// Every API call other than the step launches works on the main stream: order it behind whatever the group streams still
+// hold (device-side waits, no host synchronisation), and remember that the next step launches must be ordered behind it.
+static int join_groups(cc4_handle* h) {
+  if (h->ngroups > 1) {
+    if (h->groups_busy) {
+      for (int g = 1; g < h->ngroups; ++g) {
+        HIPCHK(h, hipEventRecord(h->gev[g], h->gstream[g]));
+        HIPCHK(h, hipStreamWaitEvent(h->stream, h->gev[g], 0));
+      }
+      h->groups_busy = false;
+    }
+    h->main_ahead = true;
+  }
+  return 0;
+}
+static int sync_all(cc4_handle* h) {
+  for (int g = h->ngroups - 1; g >= 0; --g) HIPCHK(h, hipStreamSynchronize(h->gstream[g]));
+  h->groups_busy = false;
+  return 0;
+}
 
 // rand: draw the blue actions inside the step kernel from (seed0, t) and record them in the handle's action buffer
 static int launch_step(cc4_handle* h, const int32_t* d_actions, const uint8_t* d_msgs, bool rand = false, uint64_t seed0 = 0,
@@ -1273,35 +1316,45 @@ static int launch_step(cc4_handle* h, const int32_t* d_actions, const uint8_t* d
     // waited for by the host, not by the stream: the all-gather in question is several steps old and normally complete, and
     // a wait packet in the compute queue costs stream time whether or not it has to wait
     hipError_t qs = hipEventQuery(h->ev_comm[q % cc4_handle::OBS_RING]);
-    if (qs == hipErrorNotReady) HIPCHK(h, hipEventSynchronize(h->ev_comm[q % cc4_handle::OBS_RING]));
+    if (qs == hipErrorNotReady) { h->gather_stalls++; HIPCHK(h, hipEventSynchronize(h->ev_comm[q % cc4_handle::OBS_RING])); }
     else HIPCHK(h, qs);
     h->gathers_waited = q;
+  }
+  if (h->ngroups > 1 && h->main_ahead) {   // e.g. an action upload or a reset on the main stream: the group streams start behind it
+    HIPCHK(h, hipEventRecord(h->mev, h->stream));
+    for (int g = 1; g < h->ngroups; ++g) HIPCHK(h, hipStreamWaitEvent(h->gstream[g], h->mev, 0));
+    h->main_ahead = false;
   }
   StepArgs a{h->d_state, h->d_cold, d_actions, d_msgs, h->d_obs, h->d_reward, h->d_done, h->d_err,
              h->comm ? h->d_obs8[buf] : nullptr, rand ? h->d_actions : nullptr, seed0, t,
              h->cfg.num_envs, h->cfg.autoreset, h->cfg.steps, h->cfg.rng_mode,
              (h->cfg.red_policy & 3) | (h->cfg.green_policy ? GP_SLEEP_BIT : 0) | (h->cfg.blue_policy ? BP_RANDOM_BIT : 0), h->full_obs_next ? 1 : 0,
-             (uint32_t)h->cfg.topology_seed, h->d_prof, h->d_reset_ws};
+             (uint32_t)h->cfg.topology_seed, h->d_prof, h->d_reset_ws, 0};
   h->full_obs_next = false;
-  const dim3 grid(h->cfg.num_envs);
-  // with a communicator, the launch carries ev_step[buf] as its stop event: the event rides on the kernel's own completion
-  // signal, where a separate hipEventRecord would put a marker packet between two step kernels (~5 us of idle stream time)
-  hipEvent_t stop = h->comm ? h->ev_step[buf] : nullptr;
-  h->step_event_attached = stop != nullptr;
-  if (h->cfg.rng_mode == 1) {
-    if (h->philox_lean) {
-      if (h->evlog_on) hipExtLaunchKernelGGL(k_step_philox1<true>, grid, dim3(WAVE), offsetof(EnvState, hd), h->stream, nullptr, stop, 0, a);
-      else hipExtLaunchKernelGGL(k_step_philox1<false>, grid, dim3(WAVE), offsetof(EnvState, hd), h->stream, nullptr, stop, 0, a);
+  for (int g = 0; g < h->ngroups; ++g) {
+    a.e0 = h->glo[g]; a.n = h->glo[g + 1];
+    const dim3 grid(a.n - a.e0);
+    hipStream_t st = h->gstream[g];
+    // with a communicator, the launch carries ev_step[buf][g] as its stop event: the event rides on the kernel's own completion
+    // signal, where a separate hipEventRecord would put a marker packet between two step kernels (~5 us of idle stream time)
+    hipEvent_t stop = h->comm ? h->ev_step[buf][g] : nullptr;
+    if (h->cfg.rng_mode == 1) {
+      if (h->philox_lean) {
+        if (h->evlog_on) hipExtLaunchKernelGGL(k_step_philox1<true>, grid, dim3(WAVE), offsetof(EnvState, hd), st, nullptr, stop, 0, a);
+        else hipExtLaunchKernelGGL(k_step_philox1<false>, grid, dim3(WAVE), offsetof(EnvState, hd), st, nullptr, stop, 0, a);
+      }
+      else if (h->evlog_on) hipExtLaunchKernelGGL((k_step_philox<true, 1>), grid, dim3(PT), sizeof(EnvState), st, nullptr, stop, 0, a);
+      else if (h->philox_minw == 8) hipExtLaunchKernelGGL((k_step_philox<false, 8>), grid, dim3(PT), sizeof(EnvState), st, nullptr, stop, 0, a);
+      else if (h->philox_minw == 7) hipExtLaunchKernelGGL((k_step_philox<false, 7>), grid, dim3(PT), sizeof(EnvState), st, nullptr, stop, 0, a);
+      else hipExtLaunchKernelGGL((k_step_philox<false, 1>), grid, dim3(PT), sizeof(EnvState), st, nullptr, stop, 0, a);
+    } else {
+      if (h->evlog_on) hipExtLaunchKernelGGL(k_step<true>, grid, dim3(WAVE), offsetof(EnvState, hd), st, nullptr, stop, 0, a);
+      else hipExtLaunchKernelGGL(k_step<false>, grid, dim3(WAVE), offsetof(EnvState, hd), st, nullptr, stop, 0, a);
     }
-    else if (h->evlog_on) hipExtLaunchKernelGGL((k_step_philox<true, 1>), grid, dim3(PT), sizeof(EnvState), h->stream, nullptr, stop, 0, a);
-    else if (h->philox_minw == 8) hipExtLaunchKernelGGL((k_step_philox<false, 8>), grid, dim3(PT), sizeof(EnvState), h->stream, nullptr, stop, 0, a);
-    else if (h->philox_minw == 7) hipExtLaunchKernelGGL((k_step_philox<false, 7>), grid, dim3(PT), sizeof(EnvState), h->stream, nullptr, stop, 0, a);
-    else hipExtLaunchKernelGGL((k_step_philox<false, 1>), grid, dim3(PT), sizeof(EnvState), h->stream, nullptr, stop, 0, a);
-  } else {
-    if (h->evlog_on) hipExtLaunchKernelGGL(k_step<true>, grid, dim3(WAVE), offsetof(EnvState, hd), h->stream, nullptr, stop, 0, a);
-    else hipExtLaunchKernelGGL(k_step<false>, grid, dim3(WAVE), offsetof(EnvState, hd), h->stream, nullptr, stop, 0, a);
+    HIPCHK(h, hipGetLastError());
   }
-  HIPCHK(h, hipGetLastError());
+  h->step_event_attached = h->comm != nullptr;
+  if (h->ngroups > 1) h->groups_busy = true;
   h->obs_buf = buf;
   return 0;
 }
@@ -1349,9 +1402,19 @@ int cc4_create(const cc4_config* cfg, cc4_handle** out) {
   {
     hipDeviceProp_t prop;
     HIPCHK(h, hipGetDeviceProperties(&prop, cfg->device_id));
-    // one round of <= 5 blocks per CU: the unconstrained build; else the build whose residency fills whole rounds best
     const int cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-    const int bpc = (cfg->num_envs + cus - 1) / cus;                     // episode blocks per CU
+    // Episode groups (see cc4_handle::ngroups): a step of a batch that is large enough is issued as two launches on two streams.
+    // CC4_GROUPS overrides (1 .. 4).
+    int ng = cfg->num_envs >= 16 * cus ? 2 : 1;
+    if (const char* v = getenv("CC4_GROUPS")) ng = atoi(v);
+    if (ng < 1) ng = 1;
+    if (ng > cc4_handle::MAX_GROUPS) ng = cc4_handle::MAX_GROUPS;
+    if (ng > cfg->num_envs) ng = cfg->num_envs;
+    h->ngroups = ng;
+    for (int g = 0; g <= ng; ++g) h->glo[g] = (int)(((long long)cfg->num_envs * g) / ng);
+    const int gsize = (cfg->num_envs + ng - 1) / ng;                    // episodes per launch
+    // one round of <= 5 blocks per CU: the unconstrained build; else the build whose residency fills whole rounds best
+    const int bpc = (gsize + cus - 1) / cus;                             // episode blocks of one launch per CU
     h->philox_minw = bpc <= 5 ? 1 : (bpc == 8 ? 8 : 7);      // exactly 8 per CU (2048 episodes on 256 CUs) is one round of the 8-block build
     if (const char* v = getenv("CC4_PHILOX_MINW")) h->philox_minw = atoi(v);   // tuning override: 1, 7 or 8
     // more than eight episodes per CU: the one-wave-per-episode build.  Measured on MI355X (r02, M agent-env steps/s, four waves
@@ -1362,9 +1425,16 @@ int cc4_create(const cc4_config* cfg, cc4_handle** out) {
     if (const char* v = getenv("CC4_PHILOX_LEAN")) h->philox_lean = atoi(v) != 0;   // tuning / test override
   }
   HIPCHK(h, hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
+  h->gstream[0] = h->stream;
+  for (int g = 1; g < h->ngroups; ++g) {
+    HIPCHK(h, hipStreamCreateWithFlags(&h->gstream[g], hipStreamNonBlocking));
+    HIPCHK(h, hipEventCreateWithFlags(&h->gev[g], hipEventDisableTiming));
+  }
+  if (h->ngroups > 1) HIPCHK(h, hipEventCreateWithFlags(&h->mev, hipEventDisableTiming));
   size_t n = (size_t)cfg->num_envs;
   HIPCHK(h, hipMalloc(&h->d_state, n * sizeof(EnvState)));
-  HIPCHK(h, hipMalloc(&h->d_cold, n * sizeof(EnvCold)));
+  h->cold_row = cold_row_bytes(cfg->steps);
+  HIPCHK(h, hipMalloc(&h->d_cold, n * h->cold_row));
   if (h->philox_lean && cfg->rng_mode == 1) HIPCHK(h, hipMalloc(&h->d_reset_ws, n * RESET_WS_WORDS * sizeof(uint32_t)));
   HIPCHK(h, hipMalloc(&h->d_actions, n * NBLUE * sizeof(int32_t)));
   HIPCHK(h, hipMalloc(&h->d_msgs, n * NBLUE * MSG_LEN));
@@ -1377,7 +1447,7 @@ int cc4_create(const cc4_config* cfg, cc4_handle** out) {
   HIPCHK(h, hipMalloc(&h->d_mask, n * MASK_TOTAL));
   HIPCHK(h, hipMalloc(&h->d_rng, n * 7 * sizeof(uint64_t)));
   HIPCHK(h, hipMemsetAsync(h->d_state, 0, n * sizeof(EnvState), h->stream));
-  HIPCHK(h, hipMemsetAsync(h->d_cold, 0, n * sizeof(EnvCold), h->stream));
+  HIPCHK(h, hipMemsetAsync(h->d_cold, 0, n * h->cold_row, h->stream));
   HIPCHK(h, hipMemsetAsync(h->d_obs, 0, n * OBS_TOTAL * sizeof(int32_t), h->stream));
   HIPCHK(h, hipMemsetAsync(h->d_done, 0, n, h->stream));
   HIPCHK(h, hipMemsetAsync(h->d_err, 0, n * sizeof(uint32_t), h->stream));
@@ -1390,10 +1460,10 @@ int cc4_create(const cc4_config* cfg, cc4_handle** out) {
 void cc4_destroy(cc4_handle* h) {
   if (!h) return;
   (void)hipSetDevice(h->cfg.device_id);
-  if (h->stream) (void)hipStreamSynchronize(h->stream);
+  for (int g = h->ngroups - 1; g >= 0; --g) if (h->gstream[g]) (void)hipStreamSynchronize(h->gstream[g]);
   if (h->comm_stream) (void)hipStreamSynchronize(h->comm_stream);
   if (h->comm) ncclCommDestroy(h->comm);
-  for (int b = 0; b < cc4_handle::OBS_RING; ++b) { if (h->ev_step[b]) (void)hipEventDestroy(h->ev_step[b]); if (h->ev_comm[b]) (void)hipEventDestroy(h->ev_comm[b]); }
+  for (int b = 0; b < cc4_handle::OBS_RING; ++b) { for (int g = 0; g < 4; ++g) if (h->ev_step[b][g]) (void)hipEventDestroy(h->ev_step[b][g]); if (h->ev_comm[b]) (void)hipEventDestroy(h->ev_comm[b]); }
   if (h->comm_stream) (void)hipStreamDestroy(h->comm_stream);
   void* ptrs[] = {h->d_state, h->d_cold, h->d_actions, h->d_msgs, h->d_seeds, h->d_envmask, h->d_obs, h->d_reward,
                   h->d_done, h->d_err, h->d_mask, h->d_rng, h->d_reset_ws};
@@ -1403,12 +1473,15 @@ void cc4_destroy(cc4_handle* h) {
   for (hipEvent_t e : h->evs) if (e) (void)hipEventDestroy(e);
   if (h->ev0) (void)hipEventDestroy(h->ev0);
   if (h->ev1) (void)hipEventDestroy(h->ev1);
+  for (int g = 1; g < h->ngroups; ++g) { if (h->gev[g]) (void)hipEventDestroy(h->gev[g]); if (h->gstream[g]) (void)hipStreamDestroy(h->gstream[g]); }
+  if (h->mev) (void)hipEventDestroy(h->mev);
   if (h->stream) (void)hipStreamDestroy(h->stream);
   delete h;
 }
 
 int cc4_reset(cc4_handle* h, const uint64_t* seeds, const uint8_t* env_mask) {
   HIPCHK(h, hipSetDevice(h->cfg.device_id));
+  if (join_groups(h)) return -1;
   size_t n = (size_t)h->cfg.num_envs;
   if (seeds) HIPCHK(h, hipMemcpyAsync(h->d_seeds, seeds, n * sizeof(uint64_t), hipMemcpyHostToDevice, h->stream));
   if (env_mask) HIPCHK(h, hipMemcpyAsync(h->d_envmask, env_mask, n, hipMemcpyHostToDevice, h->stream));
@@ -1428,12 +1501,12 @@ int cc4_reset(cc4_handle* h, const uint64_t* seeds, const uint8_t* env_mask) {
 
 int cc4_step(cc4_handle* h, const int32_t* actions, const uint8_t* messages) {
   HIPCHK(h, hipSetDevice(h->cfg.device_id));
+  if (join_groups(h)) return -1;
   size_t n = (size_t)h->cfg.num_envs;
   if (actions) HIPCHK(h, hipMemcpyAsync(h->d_actions, actions, n * NBLUE * sizeof(int32_t), hipMemcpyHostToDevice, h->stream));
   if (messages) HIPCHK(h, hipMemcpyAsync(h->d_msgs, messages, n * NBLUE * MSG_LEN, hipMemcpyHostToDevice, h->stream));
   if (launch_step(h, actions ? h->d_actions : nullptr, messages ? h->d_msgs : nullptr)) return -1;
-  HIPCHK(h, hipStreamSynchronize(h->stream));
-  return 0;
+  return sync_all(h);
 }
 
 int cc4_step_device(cc4_handle* h, const int32_t* d_actions, const uint8_t* d_messages) {
@@ -1443,12 +1516,14 @@ int cc4_step_device(cc4_handle* h, const int32_t* d_actions, const uint8_t* d_me
 
 int cc4_get_obs(cc4_handle* h, int32_t* obs) {
   HIPCHK(h, hipSetDevice(h->cfg.device_id));
+  if (join_groups(h)) return -1;
   HIPCHK(h, hipMemcpyAsync(obs, h->d_obs, (size_t)h->cfg.num_envs * OBS_TOTAL * sizeof(int32_t), hipMemcpyDeviceToHost, h->stream));
   HIPCHK(h, hipStreamSynchronize(h->stream));
   return 0;
 }
 int cc4_get_reward_done(cc4_handle* h, float* reward, uint8_t* done) {
   HIPCHK(h, hipSetDevice(h->cfg.device_id));
+  if (join_groups(h)) return -1;
   size_t n = (size_t)h->cfg.num_envs;
   if (reward) HIPCHK(h, hipMemcpyAsync(reward, h->d_reward, n * sizeof(float), hipMemcpyDeviceToHost, h->stream));
   if (done) HIPCHK(h, hipMemcpyAsync(done, h->d_done, n, hipMemcpyDeviceToHost, h->stream));
@@ -1457,18 +1532,21 @@ int cc4_get_reward_done(cc4_handle* h, float* reward, uint8_t* done) {
 }
 int cc4_get_action_mask(cc4_handle* h, uint8_t* mask) {
   HIPCHK(h, hipSetDevice(h->cfg.device_id));
+  if (join_groups(h)) return -1;
   HIPCHK(h, hipMemcpyAsync(mask, h->d_mask, (size_t)h->cfg.num_envs * MASK_TOTAL, hipMemcpyDeviceToHost, h->stream));
   HIPCHK(h, hipStreamSynchronize(h->stream));
   return 0;
 }
 int cc4_get_err(cc4_handle* h, uint32_t* err) {
   HIPCHK(h, hipSetDevice(h->cfg.device_id));
+  if (join_groups(h)) return -1;
   HIPCHK(h, hipMemcpyAsync(err, h->d_err, (size_t)h->cfg.num_envs * sizeof(uint32_t), hipMemcpyDeviceToHost, h->stream));
   HIPCHK(h, hipStreamSynchronize(h->stream));
   return 0;
 }
 int cc4_get_rng_state(cc4_handle* h, uint64_t* out) {
   HIPCHK(h, hipSetDevice(h->cfg.device_id));
+  if (join_groups(h)) return -1;
   int n = h->cfg.num_envs;
   hipLaunchKernelGGL(k_rng_state, dim3((n + 127) / 128), dim3(128), 0, h->stream, h->d_state, h->d_rng, n);
   HIPCHK(h, hipGetLastError());
@@ -1478,6 +1556,7 @@ int cc4_get_rng_state(cc4_handle* h, uint64_t* out) {
 }
 int cc4_set_seed(cc4_handle* h, const uint64_t* seeds) {
   HIPCHK(h, hipSetDevice(h->cfg.device_id));
+  if (join_groups(h)) return -1;
   int n = h->cfg.num_envs;
   HIPCHK(h, hipMemcpyAsync(h->d_seeds, seeds, (size_t)n * sizeof(uint64_t), hipMemcpyHostToDevice, h->stream));
   hipLaunchKernelGGL(k_set_seed, dim3((n + 127) / 128), dim3(128), 0, h->stream, h->d_state, h->d_seeds, n, h->cfg.rng_mode);
@@ -1488,6 +1567,7 @@ int cc4_set_seed(cc4_handle* h, const uint64_t* seeds) {
 int cc4_set_rng_state(cc4_handle* h, const uint64_t* words) {
   if (h->cfg.rng_mode != 0) { h->err = "cc4_set_rng_state: a numpy PCG64 state needs rng_mode 0"; return -2; }
   HIPCHK(h, hipSetDevice(h->cfg.device_id));
+  if (join_groups(h)) return -1;
   int n = h->cfg.num_envs;
   HIPCHK(h, hipMemcpyAsync(h->d_rng, words, (size_t)n * 6 * sizeof(uint64_t), hipMemcpyHostToDevice, h->stream));   // d_rng holds 7 words per episode
   hipLaunchKernelGGL(k_set_rng_state, dim3((n + 127) / 128), dim3(128), 0, h->stream, h->d_state, h->d_rng, n);
@@ -1502,6 +1582,7 @@ int cc4_actions_device(cc4_handle* h, int32_t** p) { *p = h->d_actions; return 0
 
 int cc4_random_actions_device(cc4_handle* h, uint64_t seed0, uint32_t t) {
   HIPCHK(h, hipSetDevice(h->cfg.device_id));
+  if (join_groups(h)) return -1;
   int tot = h->cfg.num_envs * NBLUE;
   hipLaunchKernelGGL(k_random_actions, dim3((tot + 255) / 256), dim3(256), 0, h->stream, h->d_actions, h->cfg.num_envs, seed0, t);
   HIPCHK(h, hipGetLastError());
@@ -1509,78 +1590,113 @@ int cc4_random_actions_device(cc4_handle* h, uint64_t seed0, uint32_t t) {
 }
 int cc4_synchronize(cc4_handle* h) {
   HIPCHK(h, hipSetDevice(h->cfg.device_id));
-  HIPCHK(h, hipStreamSynchronize(h->stream));
-  return 0;
+  return sync_all(h);
 }
 int cc4_run_random_steps(cc4_handle* h, uint64_t seed0, uint32_t t0, int32_t k, float* ms_step_kernels) {
   HIPCHK(h, hipSetDevice(h->cfg.device_id));
-  // Timing: HIP events on the launch stream around groups of TIMED_GROUP consecutive step launches (an event pair around
-  // every single launch costs the stream ~5 us of idle time per step); the sum over the groups is the on-stream time of the
-  // k launches, read back after the loop -- no host synchronisation inside the timed region.
-  constexpr int TIMED_GROUP = 25;
-  const int ngroups = ms_step_kernels ? (k + TIMED_GROUP - 1) / TIMED_GROUP : 0;
-  if ((int)h->evs.size() < 2 * ngroups) {
+  // Timing: HIP events on the launch streams around chunks of TIMED_CHUNK consecutive steps (an event pair around every single
+  // launch costs the stream ~5 us of idle time per step); per stream, the sum over the chunks is the on-stream time of its k
+  // launches, read back after the loop -- no host synchronisation inside the timed region.  With several episode groups
+  // (cc4_handle::ngroups) every group's stream is timed; the slowest stream is reported: the on-stream time of the k STEPS.
+  constexpr int TIMED_CHUNK = 25;
+  const int G = h->ngroups;
+  const int nchunks = ms_step_kernels ? (k + TIMED_CHUNK - 1) / TIMED_CHUNK : 0;
+  if ((int)h->evs.size() < 2 * nchunks * G) {
     size_t old = h->evs.size();
-    h->evs.resize(2 * (size_t)ngroups, nullptr);
+    h->evs.resize(2 * (size_t)nchunks * G, nullptr);
     for (size_t i = old; i < h->evs.size(); ++i) HIPCHK(h, hipEventCreate(&h->evs[i]));
   }
+  auto ev = [&](int chunk, int g, int which) { return h->evs[(size_t)(2 * (chunk * G + g) + which)]; };
   const bool hp = getenv("CC4_HOST_PROF") != nullptr;
   double t_launch = 0, t_ag = 0;
+  const long long stalls0 = h->gather_stalls;
   for (int i = 0; i < k; ++i) {
-    if (ms_step_kernels && i % TIMED_GROUP == 0) HIPCHK(h, hipEventRecord(h->evs[2 * (i / TIMED_GROUP)], h->stream));
+    if (ms_step_kernels && i % TIMED_CHUNK == 0) {
+      if (G > 1 && h->main_ahead) {     // the group streams' first event must not be recorded ahead of what their first launch waits for
+        HIPCHK(h, hipEventRecord(h->mev, h->stream));
+        for (int g = 1; g < G; ++g) HIPCHK(h, hipStreamWaitEvent(h->gstream[g], h->mev, 0));
+        h->main_ahead = false;
+      }
+      for (int g = 0; g < G; ++g) HIPCHK(h, hipEventRecord(ev(i / TIMED_CHUNK, g, 0), h->gstream[g]));
+    }
     auto c0 = std::chrono::steady_clock::now();
     if (launch_step(h, nullptr, nullptr, true, seed0, t0 + (uint32_t)i)) return -1;   // actions drawn in-kernel
     auto c1 = std::chrono::steady_clock::now();
-    if (ms_step_kernels && (i % TIMED_GROUP == TIMED_GROUP - 1 || i == k - 1)) HIPCHK(h, hipEventRecord(h->evs[2 * (i / TIMED_GROUP) + 1], h->stream));
+    if (ms_step_kernels && (i % TIMED_CHUNK == TIMED_CHUNK - 1 || i == k - 1))
+      for (int g = 0; g < G; ++g) HIPCHK(h, hipEventRecord(ev(i / TIMED_CHUNK, g, 1), h->gstream[g]));
     auto c2 = std::chrono::steady_clock::now();
     if (h->comm) { if (cc4_allgather_obs(h, nullptr)) return -1; }                       // overlaps the next step
     auto c3 = std::chrono::steady_clock::now();
     t_launch += std::chrono::duration<double, std::micro>(c1 - c0).count();
     t_ag += std::chrono::duration<double, std::micro>(c3 - c2).count();
   }
-  if (hp) fprintf(stderr, "[cc4 host prof] k=%d launch_step %.2f us/step, allgather enqueue %.2f us/step\n", k, t_launch / k, t_ag / k);
+  h->stat_steps += k; h->stat_launch_us += t_launch; h->stat_gather_us += t_ag;
+  if (hp) fprintf(stderr, "[cc4 host prof] k=%d launch_step %.2f us/step (%d launches per step), allgather enqueue %.2f us/step, %lld buffer-reuse stalls\n", k, t_launch / k, G, t_ag / k, h->gather_stalls - stalls0);
   if (h->comm) HIPCHK(h, hipStreamSynchronize(h->comm_stream));
-  HIPCHK(h, hipStreamSynchronize(h->stream));
+  if (sync_all(h)) return -1;
   if (ms_step_kernels) {
-    float total = 0.f;
-    for (int g = 0; g < ngroups; ++g) {
-      float ms = 0.f;
-      HIPCHK(h, hipEventElapsedTime(&ms, h->evs[2 * g], h->evs[2 * g + 1]));
-      total += ms;
+    float worst = 0.f;
+    for (int g = 0; g < G; ++g) {
+      float total = 0.f;
+      for (int c = 0; c < nchunks; ++c) {
+        float ms = 0.f;
+        HIPCHK(h, hipEventElapsedTime(&ms, ev(c, g, 0), ev(c, g, 1)));
+        total += ms;
+      }
+      if (total > worst) worst = total;
     }
-    *ms_step_kernels = total;
+    *ms_step_kernels = worst;
   }
+  return 0;
+}
+int cc4_launches_per_step(cc4_handle* h) { return h ? h->ngroups : 0; }
+// host-side counters since cc4_create: steps issued by cc4_run_random_steps, microseconds the host spent enqueueing their step
+// launches and their all-gathers, all-gathers issued, and how many times a step had to WAIT for an old all-gather before it
+// could reuse that observation buffer (0 = the exchange never held the compute stream up)
+int cc4_host_stats(cc4_handle* h, double* out /* [5] */) {
+  out[0] = (double)h->stat_steps; out[1] = h->stat_launch_us; out[2] = h->stat_gather_us; out[3] = (double)h->gathers_issued; out[4] = (double)h->gather_stalls;
   return 0;
 }
 
 int cc4_get_state(cc4_handle* h, int32_t env, void* buf) {
   if (env < 0 || env >= h->cfg.num_envs) { h->err = "cc4_get_state: env out of range"; return -2; }
   HIPCHK(h, hipSetDevice(h->cfg.device_id));
+  if (join_groups(h)) return -1;
   HIPCHK(h, hipMemcpyAsync(buf, h->d_state + env, sizeof(EnvState), hipMemcpyDeviceToHost, h->stream));
   HIPCHK(h, hipStreamSynchronize(h->stream));
   return 0;
 }
 int cc4_set_state(cc4_handle* h, int32_t env, const void* buf) {
   if (env < 0 || env >= h->cfg.num_envs) { h->err = "cc4_set_state: env out of range"; return -2; }
+  {   // the cold containers of this handle were sized from cfg.steps; the row says how long ITS episode is (EnvState.steps)
+    const int st_steps = static_cast<const EnvState*>(buf)->steps;
+    if (st_steps > 0 && cold_row_bytes(st_steps) != h->cold_row) {
+      h->err = "cc4_set_state: the row belongs to an episode of " + std::to_string(st_steps) + " steps, whose cold containers differ from this handle's (steps=" + std::to_string(h->cfg.steps) + ")";
+      return -2;
+    }
+  }
   HIPCHK(h, hipSetDevice(h->cfg.device_id));
+  if (join_groups(h)) return -1;
   HIPCHK(h, hipMemcpyAsync(h->d_state + env, buf, sizeof(EnvState), hipMemcpyHostToDevice, h->stream));
   HIPCHK(h, hipStreamSynchronize(h->stream));
   h->full_obs_next = true;      // the observation buffer still holds the previous occupant's slowly varying values
   return 0;
 }
 
-size_t cc4_cold_bytes(void) { return sizeof(EnvCold); }
+size_t cc4_cold_bytes(cc4_handle* h) { return h ? h->cold_row : 0; }
 int cc4_get_cold(cc4_handle* h, int32_t env, void* buf) {
   if (env < 0 || env >= h->cfg.num_envs) { h->err = "cc4_get_cold: env out of range"; return -2; }
   HIPCHK(h, hipSetDevice(h->cfg.device_id));
-  HIPCHK(h, hipMemcpyAsync(buf, h->d_cold + env, sizeof(EnvCold), hipMemcpyDeviceToHost, h->stream));
+  if (join_groups(h)) return -1;
+  HIPCHK(h, hipMemcpyAsync(buf, cold_at(h->d_cold, (size_t)env, h->cold_row), h->cold_row, hipMemcpyDeviceToHost, h->stream));
   HIPCHK(h, hipStreamSynchronize(h->stream));
   return 0;
 }
 int cc4_set_cold(cc4_handle* h, int32_t env, const void* buf) {
   if (env < 0 || env >= h->cfg.num_envs) { h->err = "cc4_set_cold: env out of range"; return -2; }
   HIPCHK(h, hipSetDevice(h->cfg.device_id));
-  HIPCHK(h, hipMemcpyAsync(h->d_cold + env, buf, sizeof(EnvCold), hipMemcpyHostToDevice, h->stream));
+  if (join_groups(h)) return -1;
+  HIPCHK(h, hipMemcpyAsync(cold_at(h->d_cold, (size_t)env, h->cold_row), buf, h->cold_row, hipMemcpyHostToDevice, h->stream));
   HIPCHK(h, hipStreamSynchronize(h->stream));
   return 0;
 }
@@ -1591,7 +1707,7 @@ int cc4_get_topology(cc4_handle* h, int32_t env, uint8_t* out) {
   HostStatic* hs = (HostStatic*)malloc(sizeof(HostStatic) * MAXH);
   int rc = cc4_get_state(h, env, tmp);
   if (rc == 0) {
-    hipError_t e = hipMemcpy(hs, h->d_cold[env].hs, sizeof(HostStatic) * MAXH, hipMemcpyDeviceToHost);
+    hipError_t e = hipMemcpy(hs, cold_at(h->d_cold, (size_t)env, h->cold_row)->hs, sizeof(HostStatic) * MAXH, hipMemcpyDeviceToHost);
     if (e != hipSuccess) { h->err = std::string("cc4_get_topology: ") + hipGetErrorString(e); rc = -1; }
   }
   if (rc == 0) {
@@ -1602,13 +1718,14 @@ int cc4_get_topology(cc4_handle* h, int32_t env, uint8_t* out) {
   return rc;
 }
 
-__global__ void k_set_evlog(EnvCold* cold, int n, uint32_t on) {
+__global__ void k_set_evlog(EnvCold* cold, size_t row_bytes, int n, uint32_t on) {
   int e = blockIdx.x * blockDim.x + threadIdx.x;
-  if (e < n) { cold[e].evlog.enabled = on; cold[e].evlog.n = 0; }
+  if (e < n) { EnvCold* c = cold_at(cold, (size_t)e, row_bytes); c->evlog.enabled = on; c->evlog.n = 0; }
 }
 int cc4_enable_event_log(cc4_handle* h, int32_t enable) {
   HIPCHK(h, hipSetDevice(h->cfg.device_id));
-  hipLaunchKernelGGL(k_set_evlog, dim3((h->cfg.num_envs + 255) / 256), dim3(256), 0, h->stream, h->d_cold, h->cfg.num_envs, enable ? 1u : 0u);
+  if (join_groups(h)) return -1;
+  hipLaunchKernelGGL(k_set_evlog, dim3((h->cfg.num_envs + 255) / 256), dim3(256), 0, h->stream, h->d_cold, h->cold_row, h->cfg.num_envs, enable ? 1u : 0u);
   HIPCHK(h, hipGetLastError());
   HIPCHK(h, hipStreamSynchronize(h->stream));
   h->evlog_on = enable ? 1 : 0;
@@ -1617,7 +1734,7 @@ int cc4_enable_event_log(cc4_handle* h, int32_t enable) {
 int64_t cc4_get_true_state(cc4_handle* h, int32_t env, char* json, size_t cap) {
   if (env < 0 || env >= h->cfg.num_envs) { h->err = "cc4_get_true_state: env out of range"; return -2; }
   EnvState* st = (EnvState*)malloc(sizeof(EnvState));
-  EnvCold* cold = (EnvCold*)malloc(sizeof(EnvCold));
+  EnvCold* cold = (EnvCold*)malloc(h->cold_row);
   int64_t rc = cc4_get_state(h, env, st);
   if (rc == 0) rc = cc4_get_cold(h, env, cold);
   if (rc == 0) {
@@ -1632,6 +1749,7 @@ int64_t cc4_get_true_state(cc4_handle* h, int32_t env, char* json, size_t cap) {
 // debug: enable (buf != NULL first call allocates) / read per-episode cycle counters [N][64] (16 phase slots, then 8 per red agent)
 int cc4_debug_profile(cc4_handle* h, int enable, unsigned long long* out) {
   HIPCHK(h, hipSetDevice(h->cfg.device_id));
+  if (join_groups(h)) return -1;
   size_t bytes = (size_t)h->cfg.num_envs * PROF_SLOTS * sizeof(unsigned long long);
   if (enable && !h->d_prof) { HIPCHK(h, hipMalloc(&h->d_prof, bytes)); HIPCHK(h, hipMemsetAsync(h->d_prof, 0, bytes, h->stream)); }
   if (out && h->d_prof) { HIPCHK(h, hipMemcpyAsync(out, h->d_prof, bytes, hipMemcpyDeviceToHost, h->stream)); HIPCHK(h, hipStreamSynchronize(h->stream)); }
@@ -1648,6 +1766,7 @@ int cc4_comm_unique_id(void* id128) {
 }
 int cc4_comm_init(cc4_handle* h, int32_t rank, int32_t world, const void* id128) {
   HIPCHK(h, hipSetDevice(h->cfg.device_id));
+  if (join_groups(h)) return -1;
   ncclUniqueId id;
   memcpy(&id, id128, 128);
   ncclResult_t r = ncclCommInitRank(&h->comm, world, id, rank);
@@ -1659,7 +1778,7 @@ int cc4_comm_init(cc4_handle* h, int32_t rank, int32_t world, const void* id128)
     HIPCHK(h, hipMalloc(&h->d_obs8[b], nb));
     HIPCHK(h, hipMalloc(&h->d_all_obs8[b], nb * (size_t)world));
     HIPCHK(h, hipMemsetAsync(h->d_obs8[b], 0, nb, h->stream));
-    HIPCHK(h, hipEventCreateWithFlags(&h->ev_step[b], hipEventDisableTiming));
+    for (int g = 0; g < h->ngroups; ++g) HIPCHK(h, hipEventCreateWithFlags(&h->ev_step[b][g], hipEventDisableTiming));
     HIPCHK(h, hipEventCreateWithFlags(&h->ev_comm[b], hipEventDisableTiming));
   }
   HIPCHK(h, hipStreamSynchronize(h->stream));
@@ -1674,8 +1793,13 @@ int cc4_allgather_obs(cc4_handle* h, uint8_t** d_all_obs8) {
   if (!h->comm) { h->err = "cc4_allgather_obs: cc4_comm_init was not called"; return -2; }
   HIPCHK(h, hipSetDevice(h->cfg.device_id));
   const int buf = h->obs_buf;
-  if (!h->step_event_attached) HIPCHK(h, hipEventRecord(h->ev_step[buf], h->stream));   // e.g. the observations of a reset
-  HIPCHK(h, hipStreamWaitEvent(h->comm_stream, h->ev_step[buf], 0));
+  if (!h->step_event_attached) {   // e.g. the observations of a reset: main-stream work, behind which the group streams' work was joined
+    if (join_groups(h)) return -1;
+    HIPCHK(h, hipEventRecord(h->ev_step[buf][0], h->stream));
+    HIPCHK(h, hipStreamWaitEvent(h->comm_stream, h->ev_step[buf][0], 0));
+  } else {
+    for (int g = 0; g < h->ngroups; ++g) HIPCHK(h, hipStreamWaitEvent(h->comm_stream, h->ev_step[buf][g], 0));
+  }
   size_t cnt = (size_t)h->cfg.num_envs * OBS_PACKED;
   ncclResult_t r = ncclAllGather(h->d_obs8[buf], h->d_all_obs8[buf], cnt, ncclUint8, h->comm, h->comm_stream);
   if (r != ncclSuccess) { h->err = std::string("ncclAllGather: ") + ncclGetErrorString(r); return -1; }

@@ -5,10 +5,12 @@
 // is fixed-size POD so that a whole episode can be staged with coalesced loads and snapshot with memcpy.
 //
 // Process lists (Host.processes) are unbounded in the reference (a blue agent may stack decoys on one host without limit,
-// DecoyAction.py:47-114 / DecoyVsftpd.py:10-20): the first PIN entries of a host's list live in the hot row, entries
-// PIN .. PIN+POVF-1 in the cold row (EnvCold.povf).  DeployDecoy takes two ticks, so a 500-step episode can stack at most 250
-// decoys on one host; with the <= 7 generated processes that leaves MAXP = 384 room for 127 red shells on that same host
-// (the differential fuzz reached 257 with a decoy-only blue policy).  E_PROC_OVERFLOW beyond.
+// DecoyAction.py:47-114 / DecoyVsftpd.py:10-20): the first PIN entries of a host's list live in the hot row, the rest in the
+// cold row (cold_povf).  What bounds a list is the episode length -- DeployDecoy takes two ticks, so an episode of `steps`
+// steps stacks at most steps/2 decoys on one host -- so the cold containers are sized from EnterpriseScenarioGenerator(steps=...)
+// when the handle is created (cold_povf_cap / cold_sus_cap below): 500 steps -> 376 + 8 = 384 process slots per host (250 decoys,
+// 7 generated processes, 127 red shells; the differential fuzz reached 257 with a decoy-only blue policy), 1000 steps -> 632 + 8.
+// E_PROC_OVERFLOW beyond.
 //
 // Host id layout: h = subnet*17 + slot; slot 0 router, 1..10 user_host_0..9, 11..16 server_host_0..5;
 // internet root host = 136.  Subnet index = SUBNET enum order of
@@ -27,14 +29,11 @@ enum : int {
   MAXG = 80,            // green agents (one per user host)
   NBLUE = 5, NRED = 6,
   PIN = 8,              // process slots per host in the hot row (every freshly generated host fits: <= 7 processes)
-  POVF = 376,           // further process slots per host in the cold row
-  MAXP = PIN + POVF,    // 384
   MAXSV = 7,            // services per host: sshd, OT, {apache | decoy apache} + decoy vsftpd (both port 80), mysql,
                         // decoy tomcat, {smtp | decoy haraka} -- the port checks of DecoyAction exclude any eighth
   MAX_RS = 64,          // sessions per red agent (its ordered list of pool slots)
   RS_POOL = 192,        // red session records per episode, shared by the six agents
   MAX_KS = 96,          // known server-session ids per red agent (ActionSpace.server_session)
-  MAX_SUS = 768,        // sus pid entries per blue agent (VelociraptorServer.sus_pids): <= 6 agents x 125 exploits in 500 steps
   MAX_OBS = 32,         // red observation entries per agent per step (a subnet sweep adds 16, every other source <= 4)
   MAX_PEND = 8,         // process_creation events carrying a pid, per step (one per red agent)
   EPH_WORDS = 340,      // 10880-bit bitmap >= 60000-49152 ephemeral ports (Host.py:183); 1360 B = 85 x 16 B
@@ -76,7 +75,7 @@ enum : int { EV_CUR_CONN = 1, EV_CUR_PROC = 2, EV_OLD_CONN = 4, EV_OLD_PROC = 8 
 // which of the two was appended last (Observation.add_file_info re-appends a repeated name, so only that order survives)
 enum : int { HF_CMD = 1, HF_ESC = 2, HF_ESC_LAST = 4 };
 struct alignas(16) HostDyn {        // 64 bytes = four 16-byte vectors
-  Proc procs[PIN];                  // entries 0 .. PIN-1 of Host.processes; the rest in EnvCold.povf[h]
+  Proc procs[PIN];                  // entries 0 .. PIN-1 of Host.processes; the rest in the cold row (cold_povf)
   Svc svcs[MAXSV];
   uint16_t nproc;                   // length of the whole list (hot + cold part)
   uint8_t ev;                       // EV_* bits (byte 2 of the aligned word: ev_or)
@@ -235,15 +234,39 @@ struct alignas(4) EvRec {
 };
 struct alignas(16) EvLog { uint32_t n, step, enabled, pad; EvRec rec[MAX_EV]; };
 
+// The cold row of an episode: a fixed part (this struct) followed by two containers whose capacity depends on the episode length
+// the handle was created for (EnterpriseScenarioGenerator(steps=...)):
+//   uint32_t sus[NBLUE][cold_sus_cap(steps)]    VelociraptorServer.sus_pids of blue agent b: (host << 16) | pid, chronological
+//                                               (appended by Monitor, read by Remove; counts and per-host presence stay hot)
+//   Proc     povf[MAXH][cold_povf_cap(steps)]   entries PIN.. of each host's process list (HostDyn.nproc > PIN)
+// Rows are cold_row_bytes(steps) apart (cold_at).  The capacities are pure functions of `steps`, and every use reads `steps`
+// from the episode's own row (EnvState.steps: LDS on the device), so no kernel carries them in registers; cc4_set_state refuses
+// a row whose `steps` would give other capacities than the handle's.
 struct alignas(16) EnvCold {
-  uint32_t sus[NBLUE][MAX_SUS];      // VelociraptorServer.sus_pids of blue agent b: (host << 16) | pid, chronological
-                                     // (appended by Monitor, read by Remove; counts and per-host presence stay hot)
   HostStatic hs[MAXH];               // backup images (Host.create_backup): read by Restore and reset only
   uint8_t hs_pad[8];                 // keeps what follows 16-byte aligned (137 * 56 + 8 = 7680)
-  Proc povf[MAXH][POVF];             // entries PIN.. of each host's process list (HostDyn.nproc > PIN)
   uint32_t eph[MAXH][EPH_WORDS];     // Host.ephemeral_ports as a bitmap (port-49152)
   EvLog evlog;                       // events of the last step when EvLog.enabled (cc4_enable_event_log)
   uint8_t kports[RS_POOL][MAXH + 7]; // RedAbstractSession.ports[ip]: PB_* bits | PB_HAS; row = pool slot of the session
 };
+static_assert(sizeof(EnvCold) % 16 == 0, "the containers behind the fixed part start 16-byte aligned");
+// Suspicious pids per blue agent: one per pid-carrying process_creation event in its zone, i.e. per successful red exploit
+// (ExploitAction.py:264-275); an exploit takes four ticks, so six red agents produce at most 1.5 * steps (500 steps -> 768).
+CC4_HD int cold_sus_cap(int steps) { const int c = (3 * steps) / 2 + 18; return (c + 15) & ~15; }
+// Process slots per host behind the PIN inline ones: steps / 2 decoys + 7 generated + 127 red shells (500 steps -> 376).
+CC4_HD int cold_povf_cap(int steps) { const int c = steps / 2 + 126; return (c + 7) & ~7; }
+CC4_HD size_t cold_row_bytes(int steps) {
+  return sizeof(EnvCold) + 4u * ((size_t)NBLUE * (size_t)cold_sus_cap(steps) + (size_t)MAXH * (size_t)cold_povf_cap(steps));
+}
+CC4_HD EnvCold* cold_at(EnvCold* base, size_t e, size_t row_bytes) { return reinterpret_cast<EnvCold*>(reinterpret_cast<char*>(base) + e * row_bytes); }
+CC4_HD const EnvCold* cold_at(const EnvCold* base, size_t e, size_t row_bytes) { return reinterpret_cast<const EnvCold*>(reinterpret_cast<const char*>(base) + e * row_bytes); }
+CC4_HD uint32_t* cold_sus(EnvCold* c, int steps, int b) { return reinterpret_cast<uint32_t*>(c + 1) + (size_t)b * (size_t)cold_sus_cap(steps); }
+CC4_HD const uint32_t* cold_sus(const EnvCold* c, int steps, int b) { return reinterpret_cast<const uint32_t*>(c + 1) + (size_t)b * (size_t)cold_sus_cap(steps); }
+CC4_HD uint32_t* cold_povf(EnvCold* c, int steps, int h) {   // one Proc = one word: pid | kind << 16 | flags << 24
+  return reinterpret_cast<uint32_t*>(c + 1) + (size_t)NBLUE * (size_t)cold_sus_cap(steps) + (size_t)h * (size_t)cold_povf_cap(steps);
+}
+CC4_HD const uint32_t* cold_povf(const EnvCold* c, int steps, int h) {
+  return reinterpret_cast<const uint32_t*>(c + 1) + (size_t)NBLUE * (size_t)cold_sus_cap(steps) + (size_t)h * (size_t)cold_povf_cap(steps);
+}
 
 }  // namespace cc4

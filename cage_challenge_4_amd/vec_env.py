@@ -205,7 +205,7 @@ class CC4VecEnv:
 
     def snapshot(self, env):
         """Full episode snapshot (hot + cold row) for checkpointing / tree search / parity bisecting."""
-        cold = np.zeros(self.lib.cc4_cold_bytes(), np.uint8)
+        cold = np.zeros(self.lib.cc4_cold_bytes(self._h), np.uint8)
         self._chk(self.lib.cc4_get_cold(self._h, int(env), cold.ctypes.data_as(ctypes.c_void_p)), 'cc4_get_cold')
         return self.get_state(env), cold
 
@@ -213,7 +213,7 @@ class CC4VecEnv:
         hot, cold = snap
         self.set_state(env, hot)
         cold = np.ascontiguousarray(cold, dtype=np.uint8)
-        assert cold.size == self.lib.cc4_cold_bytes()
+        assert cold.size == self.lib.cc4_cold_bytes(self._h)
         self._chk(self.lib.cc4_set_cold(self._h, int(env), cold.ctypes.data_as(ctypes.c_void_p)), 'cc4_set_cold')
 
     # device-resident loop used by bench.py

@@ -28,31 +28,38 @@ struct Oracle {
   int n;
   uint32_t topo = 0;   // cc4_config.topology_seed
   int evlog = 0;       // cc4_enable_event_log
+  int steps = 500;     // the episode length the cold rows were sized for (cc4o_create2)
+  size_t cold_row = 0;
   std::vector<EnvState> st;
-  std::vector<EnvCold> cold;
+  std::vector<unsigned char> cold_mem;   // n rows of cold_row_bytes(steps): fixed part + steps-sized containers (csrc/cc4_state.h)
+  EnvCold* cold(int i) { return cold_at(reinterpret_cast<EnvCold*>(cold_mem.data()), (size_t)i, cold_row); }
 };
 
 extern "C" {
 
-void* cc4o_create(int n) {
+// steps: EnterpriseScenarioGenerator(steps=...) of every episode this oracle will hold (sizes the cold containers, as cc4_create does)
+void* cc4o_create2(int n, int steps) {
   Oracle* o = new Oracle();
   o->n = n;
+  o->steps = steps;
+  o->cold_row = cold_row_bytes(steps);
   o->st.resize(n);
-  o->cold.resize(n);
+  o->cold_mem.assign(o->cold_row * (size_t)n + 16, 0);
   memset(o->st.data(), 0, sizeof(EnvState) * n);
-  memset(o->cold.data(), 0, sizeof(EnvCold) * n);
   return o;
 }
+void* cc4o_create(int n) { return cc4o_create2(n, 500); }
 void cc4o_destroy(void* h) { delete (Oracle*)h; }
 size_t cc4o_state_bytes() { return sizeof(EnvState); }
-size_t cc4o_cold_bytes() { return sizeof(EnvCold); }
+size_t cc4o_cold_bytes(void* h) { return ((Oracle*)h)->cold_row; }
 void* cc4o_state_ptr(void* h, int i) { return &((Oracle*)h)->st[i]; }
-void* cc4o_cold_ptr(void* h, int i) { return &((Oracle*)h)->cold[i]; }
+void* cc4o_cold_ptr(void* h, int i) { return ((Oracle*)h)->cold(i); }
 
 void cc4o_reset(void* h, int i, uint64_t seed, int rng_mode, int steps, int continue_stream, int policy) {
   Oracle* o = (Oracle*)h;
+  if (cold_row_bytes(steps) != o->cold_row) { fprintf(stderr, "cc4o_reset: steps=%d needs other cold containers than this oracle was created for (steps=%d): use cc4o_create2\n", steps, o->steps); abort(); }
   StepWork w; memset(&w, 0, sizeof(w));
-  Ctx x{&o->st[i], &o->cold[i], &o->st[i].rng, o->st[i].hd, &w};
+  Ctx x{&o->st[i], o->cold(i), &o->st[i].rng, o->st[i].hd, &w};
   uint32_t ws[RESET_WS_WORDS];   // work area of the counter-mode generation (the device kernels use LDS)
   env_reset(x, seed, rng_mode, steps, continue_stream != 0, policy, o->topo, rng_mode == 1 ? ws : nullptr);
 }
@@ -70,12 +77,12 @@ void cc4o_set_rng_state(void* h, int i, const uint64_t* w) {   // restatement of
   st.rng = r; st.rng_split = 0;
 }
 void cc4o_set_topology_seed(void* h, uint32_t seed) { ((Oracle*)h)->topo = seed; }
-void cc4o_enable_event_log(void* h, int on) { Oracle* o = (Oracle*)h; o->evlog = on ? 1 : 0; for (int i = 0; i < o->n; ++i) { o->cold[i].evlog.enabled = on ? 1u : 0u; o->cold[i].evlog.n = 0; } }
+void cc4o_enable_event_log(void* h, int on) { Oracle* o = (Oracle*)h; o->evlog = on ? 1 : 0; for (int i = 0; i < o->n; ++i) { o->cold(i)->evlog.enabled = on ? 1u : 0u; o->cold(i)->evlog.n = 0; } }
 void cc4o_step(void* h, int i, const int32_t* actions, const uint8_t* msgs) {
   Oracle* o = (Oracle*)h;
   StepWork w; memset(&w, 0, sizeof(w));
-  Ctx x{&o->st[i], &o->cold[i], &o->st[i].rng, o->st[i].hd, &w};
-  x.lg = o->evlog ? &o->cold[i].evlog : nullptr;
+  Ctx x{&o->st[i], o->cold(i), &o->st[i].rng, o->st[i].hd, &w};
+  x.lg = o->evlog ? &o->cold(i)->evlog : nullptr;
   env_step(x, actions, msgs);
 }
 // whole-batch step, OpenMP over envs when built with -fopenmp (bench.py cpu_baseline)
@@ -84,8 +91,8 @@ void cc4o_step_all(void* h, const int32_t* actions /* [n][5] */) {
 #pragma omp parallel for schedule(dynamic, 4)
   for (int i = 0; i < o->n; ++i) {
     StepWork w; memset(&w, 0, sizeof(w));
-    Ctx x{&o->st[i], &o->cold[i], &o->st[i].rng, o->st[i].hd, &w};
-    x.lg = o->evlog ? &o->cold[i].evlog : nullptr;
+    Ctx x{&o->st[i], o->cold(i), &o->st[i].rng, o->st[i].hd, &w};
+    x.lg = o->evlog ? &o->cold(i)->evlog : nullptr;
     env_step(x, actions + 5 * i, nullptr);
   }
 }
@@ -98,8 +105,8 @@ void cc4o_step_batch(void* h, const int32_t* actions /* [n][5] or null */, const
 #pragma omp parallel for schedule(dynamic, 8)
   for (int i = 0; i < o->n; ++i) {
     StepWork w; memset(&w, 0, sizeof(w));
-    Ctx x{&o->st[i], &o->cold[i], &o->st[i].rng, o->st[i].hd, &w};
-    x.lg = o->evlog ? &o->cold[i].evlog : nullptr;
+    Ctx x{&o->st[i], o->cold(i), &o->st[i].rng, o->st[i].hd, &w};
+    x.lg = o->evlog ? &o->cold(i)->evlog : nullptr;
     bool was_reset = false;
     if (autoreset && o->st[i].done) {
       uint32_t ws[RESET_WS_WORDS];
@@ -128,7 +135,7 @@ void cc4o_set_threads(int n) {
 // same document as cc4_get_true_state (include/cc4.h); returns bytes needed incl. NUL
 long long cc4o_true_state(void* h, int i, char* json, size_t cap) {
   Oracle* o = (Oracle*)h;
-  std::string doc = export_true_state(o->st[i], o->cold[i]);
+  std::string doc = export_true_state(o->st[i], *o->cold(i));
   if (json && cap >= doc.size() + 1) memcpy(json, doc.c_str(), doc.size() + 1);
   return (long long)doc.size() + 1;
 }
@@ -137,7 +144,7 @@ void cc4o_topology(void* h, int i, uint8_t* out) {
   Oracle* o = (Oracle*)h;
   const EnvState& s = o->st[i];
   for (int k = 0; k < NSUB; ++k) { out[k] = s.cidr_octet[k]; out[9 + k] = s.n_users[k]; out[18 + k] = s.n_servers[k]; }
-  for (int k = 0; k < MAXH; ++k) { out[27 + 2 * k] = bit_get(s.exists, k) ? 1 : 0; out[28 + 2 * k] = o->cold[i].hs[k].ip_octet; }
+  for (int k = 0; k < MAXH; ++k) { out[27 + 2 * k] = bit_get(s.exists, k) ? 1 : 0; out[28 + 2 * k] = o->cold(i)->hs[k].ip_octet; }
 }
 void cc4o_obs(void* h, int i, int32_t* out) { const EnvState* s = &((Oracle*)h)->st[i]; env_flat_obs<int32_t>(s, s->hd, out); }
 // the two per-value enumerations of the same vector (by position / by kind), for the host-logic test
@@ -192,7 +199,7 @@ int cc4o_layout(char* buf, int cap) {
 // canonical text dump of one episode's state (parity bisecting against oracle/refgen/ref_dump.py)
 int cc4o_dump(void* h, int i, char* buf, int cap) {
   const EnvState& s = ((Oracle*)h)->st[i];
-  const EnvCold& cold = ((Oracle*)h)->cold[i];
+  const EnvCold& cold = *((Oracle*)h)->cold(i);
   int n = 0;
 #define P(...) do { if (n < cap) n += snprintf(buf + n, cap - n, __VA_ARGS__); } while (0)
   P("step %d phase %d blocks", s.step_count, s.phase);
@@ -222,7 +229,7 @@ int cc4o_dump(void* h, int i, char* buf, int cap) {
     const BlueAgent& a = s.blue[b];
     P("blue %d sus", b);
     for (int hh = 0; hh < MAXH; ++hh)  // grouped by host, chronological within a host
-      for (int k = 0; k < a.nsus; ++k) if ((int)(cold.sus[b][k] >> 16) == hh) P(" (%d,%d)", hh, (int)(cold.sus[b][k] & 0xFFFF));
+      for (int k = 0; k < a.nsus; ++k) if ((int)(cold_sus(&cold, s.steps, b)[k] >> 16) == hh) P(" (%d,%d)", hh, (int)(cold_sus(&cold, s.steps, b)[k] & 0xFFFF));
     P("\n");
   }
 #undef P

@@ -20,6 +20,7 @@ RED_QT = {'DiscoverRemoteSystems': 0, 'AggressiveServiceDiscovery': 1, 'StealthS
 
 lib = ctypes.CDLL(os.environ.get('CC4_ORACLE_LIB') or os.path.join(os.path.dirname(__file__), '..', 'liboracle.so'))
 lib.cc4o_create.restype = ctypes.c_void_p
+lib.cc4o_create2.restype = ctypes.c_void_p
 lib.cc4o_reward.restype = ctypes.c_float
 for f in ('cc4o_reset', 'cc4o_step', 'cc4o_obs', 'cc4o_reward', 'cc4o_done', 'cc4o_err', 'cc4o_mask', 'cc4o_rng_state', 'cc4o_dump'):
     getattr(lib, f).argtypes = None
@@ -35,7 +36,7 @@ def run(seed, steps=500, blue='sleep', init='ctor', verbose=True, max_steps=None
     pol = RED[red][1] | (0x10 if GREEN[green][1] else 0) | (0x20 if blue == 'builtin' else 0)
     env = CybORG(sg, seed=seed)
     w = BlueFlatWrapper(env)
-    H = ctypes.c_void_p(lib.cc4o_create(1))
+    H = ctypes.c_void_p(lib.cc4o_create2(1, steps))
     lib.cc4o_reset(H, 0, ctypes.c_uint64(seed), 0, steps, 0, pol)
     if init == 'ctor':
         obs, info = w.reset()

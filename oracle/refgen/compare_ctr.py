@@ -32,7 +32,7 @@ def make_pair(seed, steps, blue, red, green, key):
     env = CybORG(sg, seed=proxy)
     w = BlueFlatWrapper(env)
     obs, info = w.reset()                                  # second scenario from the running numpy stream
-    H = ctypes.c_void_p(lib.cc4o_create(1))
+    H = ctypes.c_void_p(lib.cc4o_create2(1, steps))
     lib.cc4o_reset(H, 0, ctypes.c_uint64(seed), 0, steps, 0, pol)
     lib.cc4o_reset(H, 0, ctypes.c_uint64(seed), 0, steps, 1, pol)
     lib.cc4o_set_seed(H, 0, ctypes.c_uint64(key), 1)       # dynamics: counter streams of `key` (episode word 1)

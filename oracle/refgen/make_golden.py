@@ -100,6 +100,11 @@ if __name__ == '__main__':
         record(87, 500, 'builtin', 'ctor', red='random')     # a seed of test_heuristic_agents.py::test_sessions_issue_with_blue
         record(45, 300, 'builtin', 'reset', red='discovery')
         sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == 'long':   # 1000-step episodes (r03: the cold containers are sized from the episode length), as in
+        record(777, 1000, 'decoy_one', 'ctor')           # CybORG/Tests/test_cc4/test_heuristic_agents.py:10-84; 500 decoys stacked on one host
+        record(87, 1000, 'random', 'ctor', red='random')  # a seed of that test with RandomSelectRedAgent
+        record(4000, 1000, 'builtin', 'reset', red='random')   # the test's own set-up: cc4BlueRandomAgent blue, RandomSelectRedAgent red
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == 'structured':   # structured blue policies (r02: the process lists are unbounded)
         record(321, 500, 'decoy_one', 'ctor')        # every agent stacks decoys on one host: 257 processes on it at the end
         record(322, 500, 'decoy', 'reset')

@@ -56,9 +56,11 @@ def ctr_start(env_cls, fixes, **kw):
     the numpy stream of the fixture's seed (reset(seed) then reset(None), as CybORG(seed) + wrapper.reset() do) on a numpy-stream
     handle, is handed over to a counter-mode handle as a snapshot (cc4_get/set_state + cc4_get/set_cold), and cc4_set_seed puts
     the dynamics on the counter streams of the fixture's key.  Fixtures may differ in policies (one numpy-stream handle each: the
-    policy bits live in the row) and share the counter-mode handle.  Returns (env, first observations, masks)."""
+    policy bits live in the row) and share the counter-mode handle; they must agree in episode length (a handle's cold
+    containers are sized from it).  Returns (env, first observations, masks)."""
     n = len(fixes)
-    ctr = env_cls(n, steps=500, rng_mode=1, **kw)
+    assert len({f['steps'] for f in fixes}) == 1
+    ctr = env_cls(n, steps=fixes[0]['steps'], rng_mode=1, **kw)
     ctr.reset(seeds=1)
     obs0, masks = [], []
     for i, f in enumerate(fixes):

@@ -22,6 +22,12 @@ def load():
     lib = ctypes.CDLL(LIB)
     lib.cc4o_create.restype = ctypes.c_void_p
     lib.cc4o_create.argtypes = [ctypes.c_int]
+    lib.cc4o_create2.restype = ctypes.c_void_p
+    lib.cc4o_create2.argtypes = [ctypes.c_int, ctypes.c_int]
+    lib.cc4o_cold_bytes.restype = ctypes.c_size_t
+    lib.cc4o_cold_bytes.argtypes = [ctypes.c_void_p]
+    lib.cc4o_cold_ptr.restype = ctypes.c_void_p
+    lib.cc4o_cold_ptr.argtypes = [ctypes.c_void_p, ctypes.c_int]
     lib.cc4o_destroy.argtypes = [ctypes.c_void_p]
     lib.cc4o_reset.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_uint64, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int]
     lib.cc4o_step.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]
@@ -56,7 +62,7 @@ class OracleVecEnv:
         self.steps = steps
         self.rng_mode = rng_mode
         self.autoreset = autoreset
-        self._h = ctypes.c_void_p(self.lib.cc4o_create(num_envs))
+        self._h = ctypes.c_void_p(self.lib.cc4o_create2(num_envs, int(steps)))   # the cold containers are sized from the episode length
         self.lib.cc4o_set_topology_seed.argtypes = [ctypes.c_void_p, ctypes.c_uint32]
         self.lib.cc4o_set_topology_seed(self._h, int(topology_seed))
         self._obs = np.zeros((num_envs, 578), np.int32)
@@ -163,20 +169,14 @@ class OracleVecEnv:
 
     def snapshot(self, i):
         """(hot row, cold row) of episode i as byte arrays: the layout cc4_get_state / cc4_get_cold return."""
-        self.lib.cc4o_cold_bytes.restype = ctypes.c_size_t
-        self.lib.cc4o_cold_ptr.restype = ctypes.c_void_p
-        self.lib.cc4o_cold_ptr.argtypes = [ctypes.c_void_p, ctypes.c_int]
-        nc = self.lib.cc4o_cold_bytes()
+        nc = self.lib.cc4o_cold_bytes(self._h)
         cold = np.frombuffer((ctypes.c_uint8 * nc).from_address(self.lib.cc4o_cold_ptr(self._h, i)), np.uint8).copy()
         return self.get_state(i), cold
 
     def restore(self, i, snap):
         hot, cold = snap
-        self.lib.cc4o_cold_bytes.restype = ctypes.c_size_t
-        self.lib.cc4o_cold_ptr.restype = ctypes.c_void_p
-        self.lib.cc4o_cold_ptr.argtypes = [ctypes.c_void_p, ctypes.c_int]
         hot = np.ascontiguousarray(hot, np.uint8); cold = np.ascontiguousarray(cold, np.uint8)
-        assert hot.size == self.lib.cc4o_state_bytes() and cold.size == self.lib.cc4o_cold_bytes()
+        assert hot.size == self.lib.cc4o_state_bytes() and cold.size == self.lib.cc4o_cold_bytes(self._h)
         ctypes.memmove(self.lib.cc4o_state_ptr(self._h, i), hot.ctypes.data, hot.size)
         ctypes.memmove(self.lib.cc4o_cold_ptr(self._h, i), cold.ctypes.data, cold.size)
         self._done[i] = bool(self.lib.cc4o_done(self._h, i))

@@ -56,8 +56,8 @@ def test_hip_policy_variants_match_reference_golden():
     submitted action) episodes recorded from the reference, on the HIP path."""
     import test_oracle_golden as T
     from cage_challenge_4_amd import CC4VecEnv
-    todo = [f for f in (G.load(p) for p in G.list_fixtures()) if f['red_policy'] or f['green_policy'] or f['blue_policy']]
-    assert len(todo) >= 7 and sum(f['blue_policy'] for f in todo) >= 3
+    todo = [f for f in (G.load(p) for p in G.list_fixtures()) if f['red_policy'] or f['green_policy'] or f['blue_policy'] or f['steps'] != 500]
+    assert len(todo) >= 7 and sum(f['blue_policy'] for f in todo) >= 3 and sum(f['steps'] == 1000 for f in todo) >= 3   # incl. the 1000-step episodes
     for fix in todo:
         env, obs = T.replay(CC4VecEnv, fix, red_policy=fix['red_policy'], green_policy=fix['green_policy'], blue_policy=fix['blue_policy'])
         assert np.array_equal(obs[0], fix['obs'][0]) and np.array_equal(env.action_mask[0], fix['mask'])
@@ -316,7 +316,7 @@ def test_snapshot_restore_replays_identically(philox_kernel):
         o, r, d, _ = dev.step(random_actions(9, t, 4))
         assert np.array_equal(o[2], first[k][0][2]) and r[2] == first[k][1][2]
     assert np.array_equal(dev.rng_state()[2], rng_a)
-    assert len(snap[0]) == dev.lib.cc4_state_bytes() and len(snap[1]) == dev.lib.cc4_cold_bytes()
+    assert len(snap[0]) == dev.lib.cc4_state_bytes() and len(snap[1]) == dev.lib.cc4_cold_bytes(dev._h)
     dev.close()
 
 

@@ -56,26 +56,22 @@ def test_oracle_counter_mode_matches_reference_under_the_philox_proxy(oracle_lib
     the stream identified from the call site -- on scenarios generated from the numpy stream on both sides.  Every step's
     observations, reward and done flag of ten episodes (random / structured / built-in blue, three red policies, both green
     policies, messages) must match."""
+    import ctypes
     from oracle_binding import OracleVecEnv
-    fixes = [G.load_ctr(p) for p in G.list_ctr_fixtures()]
-    assert len(fixes) >= 10 and sum(f['steps'] == 500 for f in fixes) >= 9 and {f['red_policy'] for f in fixes} == {0, 2, 3}
-    env, obs0, masks = G.ctr_start(OracleVecEnv, fixes)
-    for i, f in enumerate(fixes):
-        assert np.array_equal(obs0[i], f['obs'][0]) and np.array_equal(masks[i], f['mask']), f['name']
-    T = max(f['steps'] for f in fixes)
-    alive = np.ones(len(fixes), bool)
-    for t in range(T):
-        a = np.stack([f['actions'][t] if t < f['steps'] else np.full(5, -1, np.int32) for f in fixes])
-        m = np.stack([f['messages'][t] if (f['messages'] is not None and t < f['steps']) else np.zeros((5, 8), np.uint8) for f in fixes])
-        for i, f in enumerate(fixes):            # an episode shorter than the batch stops being stepped (the reference raises past its end)
-            if t >= f['steps']:
-                alive[i] = False
+    allf = [G.load_ctr(p) for p in G.list_ctr_fixtures()]
+    assert len(allf) >= 10 and sum(f['steps'] == 500 for f in allf) >= 9 and {f['red_policy'] for f in allf} == {0, 2, 3}
+    for steps in sorted({f['steps'] for f in allf}):
+        fixes = [f for f in allf if f['steps'] == steps]
+        env, obs0, masks = G.ctr_start(OracleVecEnv, fixes)
         for i, f in enumerate(fixes):
-            if not alive[i]:
-                continue
-            env.lib.cc4o_step(env._h, i, a[i].ctypes.data_as(__import__('ctypes').c_void_p), m[i].ctypes.data_as(__import__('ctypes').c_void_p))
-            env._collect(i)
-            assert np.array_equal(env._obs[i], f['obs'][t + 1]), (f['name'], t)
-            assert env._rew[i] == f['reward'][t] and bool(env._done[i]) == bool(f['done'][t]), (f['name'], t)
-            assert env._err[i] == 0, (f['name'], t)
-    env.close()
+            assert np.array_equal(obs0[i], f['obs'][0]) and np.array_equal(masks[i], f['mask']), f['name']
+        for t in range(steps):
+            for i, f in enumerate(fixes):
+                a = np.ascontiguousarray(f['actions'][t], np.int32)
+                m = np.ascontiguousarray(f['messages'][t] if f['messages'] is not None else np.zeros((5, 8), np.uint8))
+                env.lib.cc4o_step(env._h, i, a.ctypes.data_as(ctypes.c_void_p), m.ctypes.data_as(ctypes.c_void_p))
+                env._collect(i)
+                assert np.array_equal(env._obs[i], f['obs'][t + 1]), (f['name'], t)
+                assert env._rew[i] == f['reward'][t] and bool(env._done[i]) == bool(f['done'][t]), (f['name'], t)
+                assert env._err[i] == 0, (f['name'], t)
+        env.close()
