@@ -138,15 +138,68 @@ def cpu_baseline(envs, seed0, budget_s=10.0):
     return out
 
 
-def load_pmc_traffic(envs):
-    """HBM bytes per k_step_philox launch from the committed rocprofv3 --pmc passes, with their source, or (None, None)."""
-    for name in ('r02_pmc.json', 'r01_pmc.json'):
+def host_api_rates(seed=123, steps=300, eval_eps=3):
+    """The host-API path beside the reference's own single-environment rate (34 env-steps/s = 172 agent-env
+    steps/s in reference Python): one episode stepped through the drop-in wrapper -- BlueFlatWrapper(CybORG(...)).step(dict of five
+    action indices) -> dict observations: one launch, one host synchronisation and four small copies per step -- and the
+    reference's evaluation loop (run_evaluation, mode 'sequential': one episode at a time, a Python agent call per blue agent)."""
+    import numpy as np
+    from cage_challenge_4_amd import (CybORG, EnterpriseScenarioGenerator, SleepAgent, EnterpriseGreenAgent, FiniteStateRedAgent,
+                                      BlueFlatWrapper)
+    from cage_challenge_4_amd.evaluation import run_evaluation
+    sg = EnterpriseScenarioGenerator(blue_agent_class=SleepAgent, green_agent_class=EnterpriseGreenAgent,
+                                     red_agent_class=FiniteStateRedAgent, steps=500)
+    env = BlueFlatWrapper(CybORG(sg, seed=seed))
+    obs, info = env.reset()
+    rng = np.random.default_rng(seed)
+    valid = {a: np.nonzero(info[a]['action_mask'])[0] for a in env.agents}
+    for _ in range(20):
+        env.step({a: int(valid[a][rng.integers(len(valid[a]))]) for a in env.possible_agents})
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        env.step({a: int(valid[a][rng.integers(len(valid[a]))]) for a in env.possible_agents})
+    dt = time.perf_counter() - t0
+    env.close()
+    out = {'single_env_facade': {'value': 5.0 * steps / dt, 'unit': 'agent-env steps/s', 'env_steps_per_sec': steps / dt, 'us_per_step': dt / steps * 1e6,
+                                 'sample': f'BlueFlatWrapper(CybORG(EnterpriseScenarioGenerator(steps=500), seed={seed})).step x {steps}, random valid actions, numpy-stream mode (bit-exact with the reference)',
+                                 'reference_python': REFERENCE_PYTHON['value']}}
+
+    class Agent:
+        def __init__(self, k):
+            self.sleep = 145 if k == 4 else 49
+
+        def get_action(self, obs, action_space):
+            return self.sleep
+
+    class Submission:
+        NAME, TEAM, TECHNIQUE = 'bench', 'cc4-amd', 'sleep'
+        AGENTS = {f'blue_agent_{k}': Agent(k) for k in range(5)}
+
+        @staticmethod
+        def wrap(e):
+            return BlueFlatWrapper(e)
+    t0 = time.perf_counter()
+    scores = run_evaluation(Submission, None, max_eps=eval_eps, seed=seed, mode='sequential', write_to_file=False)
+    dt = time.perf_counter() - t0
+    n_steps = eval_eps * 499          # the step that raises `done` ends the episode (evaluation.py:108-110)
+    out['eval_sequential'] = {'value': 5.0 * n_steps / dt, 'unit': 'agent-env steps/s', 'env_steps_per_sec': n_steps / dt, 'seconds': dt,
+                              'sample': f"run_evaluation(mode='sequential', max_eps={eval_eps}): {eval_eps} x 500-step episodes, Sleep blue agents, reference's per-episode protocol",
+                              'mean_score': float(sum(scores) / len(scores)), 'reference_python': REFERENCE_PYTHON['value']}
+    return out
+
+
+def load_pmc_traffic(envs, kernel, launches_per_step):
+    """HBM bytes per STEP (all launches of a step) from the committed rocprofv3 --pmc passes of this bench command, with their
+    source -- only if they were taken on the same kernel with the same number of launches per step; else (None, None)."""
+    for name in ('r03_pmc.json',):
         p = os.path.join(ROOT, 'profiles', name)
         try:
             with open(p) as f:
-                v = json.load(f).get(f'hbm_bytes_per_launch_{envs}env')
-            if v is not None:
-                return v, f'profiles/{name} (rocprofv3 --pmc passes of this bench command; a committed figure, not measured in this run)'
+                d = json.load(f)
+            v = d.get(f'hbm_bytes_per_step_{envs}env')
+            if v is None or d.get(f'kernel_{envs}env') != kernel or d.get(f'launches_per_step_{envs}env') != launches_per_step:
+                continue
+            return v, f'profiles/{name} (rocprofv3 --pmc passes of this bench command on {kernel}, {launches_per_step} launches per step; a committed figure, not measured in this run)'
         except Exception:
             pass
     return None, None
@@ -175,17 +228,16 @@ def main():
     if args.gpus > 1 and world != args.gpus:
         raise SystemExit(f'--gpus {args.gpus} needs torch.distributed.run with --nproc-per-node {args.gpus} (WORLD_SIZE={world})')
     dist_on = world > 1 or os.environ.get('CC4_BENCH_FORCE_DIST') == '1'   # the env var drives the N>1 code path at world 1
+    plane = D.control_plane(force=dist_on)      # rendezvous / barriers / reductions: a shared directory, no PyTorch (distributed.py)
     if dist_on:
-        # gloo / RCCL print banners on fd 1 from C++; keep stdout for the one JSON line
+        # RCCL prints banners on fd 1 from C++; keep stdout for the one JSON line
         sys.stdout.flush()
         saved_fd = os.dup(1)
         os.dup2(2, 1)
-        D.init_control_plane('gloo', force=True)
-        import torch
-        import torch.distributed as dist
     dev_id = local if world > 1 else 0
     if dist_on and world > 1:
-        ndev = torch.cuda.device_count()      # a launcher may expose one GPU per rank (then it is device 0) or all of them
+        from cage_challenge_4_amd import _lib
+        ndev = int(_lib.load().cc4_device_count())      # a launcher may expose one GPU per rank (then it is device 0) or all of them
         if ndev > 0:
             dev_id = local % ndev
     dev_id = int(os.environ.get('CC4_BENCH_DEVICE', dev_id))   # override: several ranks on one GPU (tests the N>1 plumbing on a 1-GPU box)
@@ -212,7 +264,7 @@ def main():
             try:
                 if os.environ.get('CC4_RCCL_SETUP_FAIL') == '1':      # exercises the fallback below
                     raise RuntimeError('CC4_RCCL_SETUP_FAIL=1')
-                D.init_rccl(env, rank, world)
+                D.init_rccl(env, rank, world, plane)
                 env.run_random_steps(args.seed0 + lo, 0, 1, timed=False)   # first collective (RCCL prints its banner lazily)
                 env.synchronize()
                 res['ok'] = True
@@ -221,9 +273,7 @@ def main():
         th = threading.Thread(target=_setup, daemon=True)
         th.start()
         th.join(float(os.environ.get('CC4_RCCL_SETUP_TIMEOUT', '240')))
-        ok = torch.tensor([1 if res.get('ok') else 0], dtype=torch.int32)
-        if world > 1:
-            dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+        ok = plane.allreduce([1.0 if res.get('ok') else 0.0], 'min')
         if int(ok[0]) == 0:
             exchange_note = 'none (RCCL setup failed or timed out on a rank: %s)' % res.get('err', 'ok here' if res.get('ok') else 'timeout')
             print('bench.py: ' + exchange_note, file=sys.stderr)
@@ -238,31 +288,32 @@ def main():
         os.close(saved_fd)
 
     def reduce_max(v):
-        if not dist_on or world == 1:
-            return v
-        t = torch.tensor(v, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        return [float(a) for a in t]
+        return plane.allreduce(v, 'max')
 
     def measure(e, first, n_total):
         key = args.seed0 + first            # action key = seed0 + global episode index
         secs, kms = timed_regions(lambda t0, k, timed: e.run_random_steps(key, t0, k, timed=timed), args.steps, args.warmup,
-                                  args.min_seconds, e.synchronize, dist.barrier if dist_on else None, reduce_max)
+                                  args.min_seconds, e.synchronize, plane.barrier, reduce_max)
         out = summarise(secs, kms, args.steps, n_total)
         t_end = args.warmup + len(secs) * args.steps        # launches so far; episodes regenerate on every (episode_steps)-th
         out['autoreset_launches_in_timed_regions'] = t_end // args.episode_steps - args.warmup // args.episode_steps
+        out['launches_per_step'] = e.launches_per_step
         return out
 
     main_res = measure(env, lo, total_envs)
+    # what this rank's host did (cc4_host_stats): a multi-GPU curve is explained by these -- the slowest rank's kernel period, the
+    # host time per step spent enqueueing launches and all-gathers, and whether an all-gather ever held a step up
+    hs = env.host_stats()
+    per_rank = plane.gather_obj({'rank': rank, 'envs': n_local, 'kernel': env.step_kernel, 'launches_per_step': env.launches_per_step,
+                                 'host_launch_us_per_step': hs['launch_us'] / max(hs['steps'], 1), 'host_allgather_enqueue_us_per_step': hs['gather_us'] / max(hs['steps'], 1),
+                                 'allgathers_issued': hs['gathers'], 'steps_that_waited_for_an_allgather': hs['gather_stalls']})
     env._fetch()
     err_any = bool(env.err.any())
     # a sharding-independent digest of where the batch stands after the run (episodes are seeded and driven by their GLOBAL
     # index): the last step's rewards and done flags summed over all ranks -- equal for any world size at equal step counts
     digest = [float(env._rew.astype(np.float64).sum()), float(env._done.sum()), float(err_any)]
     if dist_on and world > 1:
-        t = torch.tensor(digest, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.SUM)
-        digest = [float(a) for a in t]
+        digest = plane.allreduce(digest, 'sum')
         err_any = digest[2] > 0
     mean_hosts = float(np.mean([int(env.topology(i)[27::2].sum()) for i in range(0, n_local, max(1, n_local // 64))]))
 
@@ -300,10 +351,15 @@ def main():
         if args.rng == 'pcg64':   # k_step stages the agent part only; of the host table it touches the rows it visits
             bytes_per_env = 2 * hot + (state_bytes - hot) + 4 * 578 + 29
         launch_ms = main_res['launch_ms']
+        # A step of a large batch is `lps` launches, one per group of episodes, on separate streams (include/cc4.h
+        # cc4_launches_per_step): they run concurrently, so the bytes of all of them move within one launch duration.
+        # launch_ms = average launch-to-launch period on the slowest group's stream (HIP events, cc4_run_random_steps) = the
+        # kernel's average duration in rocprofv3 --stats; achieved = lps x algorithmic bytes of one launch / launch_ms
+        lps = main_res['launches_per_step']
         achieved = bytes_per_env * n_local / (launch_ms * 1e-3) / 1e9
         # live bytes: the agent part + the 64-byte rows of the hosts that exist in the episode (the grid has 137 positions)
         useful = 2 * (hot + 64.0 * mean_hosts) + 4 * 578 + 29
-        traffic, traffic_src = load_pmc_traffic(n_local) if args.rng == 'philox' else (None, None)
+        traffic, traffic_src = load_pmc_traffic(n_local, env.step_kernel, lps) if args.rng == 'philox' else (None, None)
         out = {
             'metric': 'agent-env steps/sec (5 blue agents x N envs)',
             'value': main_res['value'],
@@ -328,19 +384,24 @@ def main():
             },
             'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBPS, 'unit': 'GB/s',
                          'frac': achieved / HBM_PEAK_GBPS, 'traffic': traffic, 'traffic_source': traffic_src,
-                         'kernel': env.step_kernel, 'launch_ms': launch_ms,
-                         'algorithmic_bytes_per_launch': bytes_per_env * n_local,
+                         'kernel': env.step_kernel, 'launch_ms': launch_ms, 'launches_per_step': lps,
+                         'episodes_per_launch': n_local / lps,
+                         'algorithmic_bytes_per_launch': bytes_per_env * n_local / lps,
+                         'algorithmic_bytes_per_step': bytes_per_env * n_local,
+                         'note': f'a step = {lps} concurrent launch(es) of {env.step_kernel} on separate streams, {n_local / lps:.0f} episodes each; '
+                                 'achieved = launches_per_step x algorithmic_bytes_per_launch / launch_ms; traffic is per step too',
                          'useful_bytes_per_launch': useful * n_local, 'useful_frac': useful * n_local / (launch_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
                          'useful_note': f'live bytes only: agent part {hot} B + 64 B x {mean_hosts:.1f} existing hosts (of 137 grid positions), in and out'},
         }
+        out['config']['per_rank'] = per_rank
         out.update(subs)
+        if not dist_on and not args.no_alt:
+            out.update(host_api_rates())
         if not dist_on and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(1024, args.seed0)
         print(json.dumps(out), flush=True)
     env.close()
-    if dist_on:
-        dist.barrier()
-        dist.destroy_process_group()
+    plane.close()
     if exchange_note:                 # a stalled RCCL setup thread must not keep the process alive
         sys.stdout.flush()
         os._exit(0)

@@ -29,6 +29,7 @@ class CC4Config(ctypes.Structure):
 # every entry point declared in include/cc4.h : (restype, argtypes)
 _P = ctypes.c_void_p
 SIGNATURES = {
+    'cc4_device_count': (ctypes.c_int, []),
     'cc4_create': (ctypes.c_int, [ctypes.POINTER(CC4Config), ctypes.POINTER(_P)]),
     'cc4_destroy': (None, [_P]),
     'cc4_last_error': (ctypes.c_char_p, [_P]),

@@ -1250,6 +1250,7 @@ struct cc4_handle {
   // per step 507 M agent-env steps/s, two groups of 4096 on two streams 639 M (a single 32768-episode launch per step: 605 M).
   static constexpr int MAX_GROUPS = 4;
   int ngroups = 1;
+  int cus = 256;                                 // compute units of the device
   int glo[MAX_GROUPS + 1] = {};                  // group g = episodes [glo[g], glo[g + 1])
   hipStream_t gstream[MAX_GROUPS] = {};          // gstream[0] == stream
   hipEvent_t gev[MAX_GROUPS] = {};               // group stream -> main stream ordering (join_groups)
@@ -1279,6 +1280,31 @@ static thread_local std::string g_create_err;
       return -1;                                                                               \
     }                                                                                          \
   } while (0)
+
+// How a step of this handle is cut into launches, and which build of the counter-mode kernel they run (the kernels are
+// chosen from what one LAUNCH puts on a CU and from what the whole batch does).
+static void configure_groups(cc4_handle* h, int ng) {
+  const int n = h->cfg.num_envs, cus = h->cus;
+  if (ng < 1) ng = 1;
+  if (ng > cc4_handle::MAX_GROUPS) ng = cc4_handle::MAX_GROUPS;
+  if (ng > n) ng = n;
+  h->ngroups = ng;
+  for (int g = 0; g <= ng; ++g) h->glo[g] = (int)(((long long)n * g) / ng);
+  const int gsize = (n + ng - 1) / ng;                                 // episodes per launch
+  const int bpc = (gsize + cus - 1) / cus;                             // episode blocks of one launch per CU
+  const int bpc_all = (n + cus - 1) / cus;                             // ... of all launches of a step
+  // four-wave kernel: one round of <= 5 blocks per CU runs the unconstrained build; else the build whose residency fills whole
+  // rounds best (exactly 8 per CU -- 2048 episodes on 256 CUs -- is one round of the 8-block build)
+  h->philox_minw = bpc <= 5 ? 1 : (bpc == 8 ? 8 : 7);
+  if (const char* v = getenv("CC4_PHILOX_MINW")) h->philox_minw = atoi(v);   // tuning override: 1, 7 or 8
+  // The one-wave-per-episode build when a single launch puts more than eight episodes on a CU, or the launches of a step
+  // together more than sixteen.  Measured on MI355X (M agent-env steps/s, four waves / one wave per episode; r02, one launch per
+  // step): 1024 episodes 168 / 131, 2048: 262 / 238, 2304: 249 / 260, 3072: 294 / 322, 4096: 319 / 395, 8192: 391 / 510;
+  // (r03, three launches per step): 1024: 175 / 137, 2048: 295 / 249, 3072: 347 / 345, 4096: 442 / 422, 6144: 455 / 556,
+  // 8192: 466 / 659.  (The same kernel with the host table in LDS as well is no faster anywhere.)
+  h->philox_lean = bpc > 8 || bpc_all > 16;
+  if (const char* v = getenv("CC4_PHILOX_LEAN")) h->philox_lean = atoi(v) != 0;   // tuning / test override
+}
 
 // Every API call other than the step launches works on the main stream: order it behind whatever the group streams still
 // hold (device-side waits, no host synchronisation), and remember that the next step launches must be ordered behind it.
@@ -1363,6 +1389,7 @@ extern "C" {
 
 const char* cc4_last_error(cc4_handle* h) { return h ? h->err.c_str() : g_create_err.c_str(); }
 size_t cc4_state_bytes(void) { return sizeof(EnvState); }
+int cc4_device_count(void) { int n = 0; return hipGetDeviceCount(&n) == hipSuccess ? n : 0; }
 size_t cc4_algorithmic_bytes_per_env_step(void) {
   // state row in + out, flat obs out (int32), actions in, reward + done + err out (DESIGN.md "algorithmic bytes")
   return 2 * sizeof(EnvState) + 4 * OBS_TOTAL + 4 * NBLUE + 4 + 1 + 4;
@@ -1402,40 +1429,29 @@ int cc4_create(const cc4_config* cfg, cc4_handle** out) {
   {
     hipDeviceProp_t prop;
     HIPCHK(h, hipGetDeviceProperties(&prop, cfg->device_id));
-    const int cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-    // Episode groups (see cc4_handle::ngroups): a step of a batch that is large enough is issued as two launches on two streams.
-    // CC4_GROUPS overrides (1 .. 4).
-    int ng = cfg->num_envs >= 16 * cus ? 2 : 1;
+    h->cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+  }
+  {
+    // Episode groups (see cc4_handle::ngroups).  Measured on MI355X (r03, profiles/r03_groups_sweep_philox.txt; M agent-env steps/s,
+    // counter mode, 1 / 2 / 3 launches per step): 1024 episodes 165 / 173 / 175, 2048: 257 / 289 / 295, 4096: 392 / 413 / 442,
+    // 8192: 503 / 629 / 659, 16384: 570 / 710 / 701; numpy stream, 8192 episodes: 272 / 352 / 363.  A fourth stream halves the
+    // rate (the runtime's hardware queues), so three it is.  CC4_GROUPS overrides (1 .. 4).
+    int ng = cfg->num_envs >= 1024 ? 3 : (cfg->num_envs >= 512 ? 2 : 1);
     if (const char* v = getenv("CC4_GROUPS")) ng = atoi(v);
-    if (ng < 1) ng = 1;
-    if (ng > cc4_handle::MAX_GROUPS) ng = cc4_handle::MAX_GROUPS;
-    if (ng > cfg->num_envs) ng = cfg->num_envs;
-    h->ngroups = ng;
-    for (int g = 0; g <= ng; ++g) h->glo[g] = (int)(((long long)cfg->num_envs * g) / ng);
-    const int gsize = (cfg->num_envs + ng - 1) / ng;                    // episodes per launch
-    // one round of <= 5 blocks per CU: the unconstrained build; else the build whose residency fills whole rounds best
-    const int bpc = (gsize + cus - 1) / cus;                             // episode blocks of one launch per CU
-    h->philox_minw = bpc <= 5 ? 1 : (bpc == 8 ? 8 : 7);      // exactly 8 per CU (2048 episodes on 256 CUs) is one round of the 8-block build
-    if (const char* v = getenv("CC4_PHILOX_MINW")) h->philox_minw = atoi(v);   // tuning override: 1, 7 or 8
-    // more than eight episodes per CU: the one-wave-per-episode build.  Measured on MI355X (r02, M agent-env steps/s, four waves
-    // / one wave per episode): 1024 episodes 168 / 131, 1536: 229 / 187, 2048: 262 / 238, 2304: 249 / 260, 3072: 294 / 322,
-    // 4096: 319 / 395, 8192: 391 / 510, 16384: 414 / 540, 32768: 433 / 605.  (The same kernel with the host table in LDS as
-    // well -- 9 episodes per CU -- is no faster anywhere: 1024..2304 episodes 130 / 182 / 231 / 250.)
-    h->philox_lean = bpc > 8;
-    if (const char* v = getenv("CC4_PHILOX_LEAN")) h->philox_lean = atoi(v) != 0;   // tuning / test override
+    configure_groups(h, ng);
   }
   HIPCHK(h, hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
   h->gstream[0] = h->stream;
-  for (int g = 1; g < h->ngroups; ++g) {
+  for (int g = 1; g < h->ngroups; ++g) {   // only the streams that are used: the runtime spreads streams over few hardware queues
     HIPCHK(h, hipStreamCreateWithFlags(&h->gstream[g], hipStreamNonBlocking));
     HIPCHK(h, hipEventCreateWithFlags(&h->gev[g], hipEventDisableTiming));
   }
-  if (h->ngroups > 1) HIPCHK(h, hipEventCreateWithFlags(&h->mev, hipEventDisableTiming));
+  HIPCHK(h, hipEventCreateWithFlags(&h->mev, hipEventDisableTiming));
   size_t n = (size_t)cfg->num_envs;
   HIPCHK(h, hipMalloc(&h->d_state, n * sizeof(EnvState)));
   h->cold_row = cold_row_bytes(cfg->steps);
   HIPCHK(h, hipMalloc(&h->d_cold, n * h->cold_row));
-  if (h->philox_lean && cfg->rng_mode == 1) HIPCHK(h, hipMalloc(&h->d_reset_ws, n * RESET_WS_WORDS * sizeof(uint32_t)));
+  if (cfg->rng_mode == 1) HIPCHK(h, hipMalloc(&h->d_reset_ws, n * RESET_WS_WORDS * sizeof(uint32_t)));   // the one-wave kernel's generation work area
   HIPCHK(h, hipMalloc(&h->d_actions, n * NBLUE * sizeof(int32_t)));
   HIPCHK(h, hipMalloc(&h->d_msgs, n * NBLUE * MSG_LEN));
   HIPCHK(h, hipMalloc(&h->d_seeds, n * sizeof(uint64_t)));
@@ -1473,7 +1489,7 @@ void cc4_destroy(cc4_handle* h) {
   for (hipEvent_t e : h->evs) if (e) (void)hipEventDestroy(e);
   if (h->ev0) (void)hipEventDestroy(h->ev0);
   if (h->ev1) (void)hipEventDestroy(h->ev1);
-  for (int g = 1; g < h->ngroups; ++g) { if (h->gev[g]) (void)hipEventDestroy(h->gev[g]); if (h->gstream[g]) (void)hipStreamDestroy(h->gstream[g]); }
+  for (int g = 1; g < cc4_handle::MAX_GROUPS; ++g) { if (h->gev[g]) (void)hipEventDestroy(h->gev[g]); if (h->gstream[g]) (void)hipStreamDestroy(h->gstream[g]); }
   if (h->mev) (void)hipEventDestroy(h->mev);
   if (h->stream) (void)hipStreamDestroy(h->stream);
   delete h;

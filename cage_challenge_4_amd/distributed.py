@@ -1,11 +1,172 @@
 """Multi-GPU plumbing: one process per GPU, the env batch sharded statically across ranks (no data-path collective in
 the step itself); the single exchange step is the all-gather of the flat observations, done natively over RCCL/xGMI
-by libcc4 (cc4_allgather_obs).  torch.distributed (gloo) is only the control plane: rendezvous, the RCCL unique-id
-broadcast, barriers and the max-over-ranks timing reduction."""
+by libcc4 (cc4_allgather_obs).
+
+The control plane -- rendezvous, the 128-byte RCCL unique id, barriers, the max-over-ranks timing reduction -- needs no
+PyTorch: `control_plane()` returns a FilePlane, a rendezvous through a directory all ranks of the (single-node) job share,
+keyed by the launcher's MASTER_PORT and process id.  A GlooPlane (torch.distributed, backend gloo) offers the same five
+operations for the launch-compatibility tests and as a fall-back (CC4_CONTROL_PLANE=gloo)."""
 import ctypes
+import json
 import os
+import time
 import numpy as np
 from .vec_env import shard_range
+
+
+class SoloPlane:
+    """world size 1: nothing to exchange."""
+    rank, world = 0, 1
+    kind = 'solo'
+
+    def exchange(self, payload):
+        return [payload]
+
+    def barrier(self):
+        pass
+
+    def allreduce(self, values, op):
+        return [float(v) for v in values]
+
+    def bcast_bytes(self, payload, src=0):
+        return payload
+
+    def gather_obj(self, obj):
+        return [obj]
+
+    def close(self):
+        pass
+
+
+class FilePlane(SoloPlane):
+    """All ranks of a single-node job share a directory; one primitive -- `exchange`: every rank contributes a small byte string
+    and gets everybody's, in rank order -- carries the barrier, the reductions, the broadcast and the gather.  Operation number q
+    of rank r is the file `q_r` (written under a temporary name, then renamed: readers never see a partial file); a rank that has
+    read all files of operation q knows every rank has finished operation q - 1, and removes its own file of that one."""
+    kind = 'file'
+
+    def __init__(self, rank, world, key, root=None, timeout=900.0):
+        self.rank, self.world, self.timeout = int(rank), int(world), float(timeout)
+        root = root or os.environ.get('CC4_CONTROL_PLANE_DIR') or ('/dev/shm' if os.path.isdir('/dev/shm') else '/tmp')
+        self.dir = os.path.join(root, f'cc4_plane_{key}')
+        os.makedirs(self.dir, exist_ok=True)
+        self.seq = 0
+
+    def _path(self, q, r):
+        return os.path.join(self.dir, f'{q}_{r}')
+
+    def exchange(self, payload):
+        q = self.seq
+        self.seq += 1
+        mine = self._path(q, self.rank)
+        with open(mine + '.tmp', 'wb') as f:
+            f.write(payload)
+        os.replace(mine + '.tmp', mine)
+        out = []
+        t0 = time.monotonic()
+        for r in range(self.world):
+            p = self._path(q, r)
+            spins = 0
+            while True:
+                try:
+                    with open(p, 'rb') as f:
+                        out.append(f.read())
+                    break
+                except FileNotFoundError:
+                    spins += 1
+                    if spins > 2000:
+                        time.sleep(0.0002)
+                        if time.monotonic() - t0 > self.timeout:
+                            raise TimeoutError(f'control plane: rank {r} did not reach operation {q} within {self.timeout:.0f} s ({self.dir})')
+        if q >= 1:
+            try:
+                os.remove(self._path(q - 1, self.rank))
+            except OSError:
+                pass
+        return out
+
+    def barrier(self):
+        self.exchange(b'')
+
+    def allreduce(self, values, op):
+        rows = [json.loads(b.decode()) for b in self.exchange(json.dumps([float(v) for v in values]).encode())]
+        f = {'max': max, 'min': min, 'sum': sum}[op]
+        return [float(f(r[i] for r in rows)) for i in range(len(values))]
+
+    def bcast_bytes(self, payload, src=0):
+        return self.exchange(payload if self.rank == src else b'')[src]
+
+    def gather_obj(self, obj):
+        return [json.loads(b.decode()) for b in self.exchange(json.dumps(obj).encode())]
+
+    def close(self):
+        self.barrier()                       # nobody still reads when the files go
+        for q in (self.seq - 1, self.seq - 2):
+            try:
+                os.remove(self._path(q, self.rank))
+            except OSError:
+                pass
+        if self.rank == 0:
+            try:
+                os.rmdir(self.dir)
+            except OSError:
+                pass
+
+
+class GlooPlane(SoloPlane):
+    kind = 'gloo'
+
+    def __init__(self, rank, world):
+        import torch.distributed as dist
+        self.rank, self.world = rank, world
+        if not dist.is_initialized():
+            os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+            os.environ.setdefault('MASTER_PORT', '29533')
+            dist.init_process_group(backend='gloo', rank=rank, world_size=world)
+
+    def exchange(self, payload):
+        import torch.distributed as dist
+        out = [None] * self.world
+        dist.all_gather_object(out, payload)
+        return out
+
+    def barrier(self):
+        import torch.distributed as dist
+        dist.barrier()
+
+    def allreduce(self, values, op):
+        import torch
+        import torch.distributed as dist
+        t = torch.tensor([float(v) for v in values], dtype=torch.float64)
+        dist.all_reduce(t, op={'max': dist.ReduceOp.MAX, 'min': dist.ReduceOp.MIN, 'sum': dist.ReduceOp.SUM}[op])
+        return [float(a) for a in t]
+
+    def bcast_bytes(self, payload, src=0):
+        return self.exchange(payload if self.rank == src else b'')[src]
+
+    def gather_obj(self, obj):
+        return self.exchange(obj)
+
+    def close(self):
+        import torch.distributed as dist
+        if dist.is_initialized():
+            dist.barrier()
+            dist.destroy_process_group()
+
+
+def control_plane(kind=None, force=False):
+    """The job's control plane from the launcher's environment (RANK, WORLD_SIZE, MASTER_PORT; torch.distributed.run sets
+    them).  kind: 'file' (default; no PyTorch) or 'gloo' (CC4_CONTROL_PLANE overrides).  force: a one-rank FilePlane instead of
+    the SoloPlane (exercises the N>1 code path at world size 1)."""
+    rank, world, _ = env_rank_world()
+    kind = os.environ.get('CC4_CONTROL_PLANE', kind or 'file')
+    if world == 1 and not force:
+        return SoloPlane()
+    if kind == 'gloo':
+        return GlooPlane(rank, world)
+    # every worker of one launch is a child of the same launcher process: its pid tells launches that reuse a port apart
+    key = os.environ.get('CC4_CONTROL_PLANE_KEY') or f"{os.environ.get('MASTER_PORT', '0')}_{os.environ.get('TORCHELASTIC_RUN_ID', 'none')}_{os.getppid()}"
+    return FilePlane(rank, world, key)
 
 
 def env_rank_world():
@@ -51,22 +212,22 @@ def unpack_obs(rows):
     return (rows[:, i >> 2] >> (2 * (i & 3)).astype(np.uint8)) & 3
 
 
-def init_rccl(vec_env, rank, world):
-    """Create the RCCL communicator inside libcc4 for this rank's handle (unique id travels over the control plane)."""
-    import torch
-    import torch.distributed as dist
+def init_rccl(vec_env, rank, world, plane=None):
+    """Create the RCCL communicator inside libcc4 for this rank's handle (the 128-byte unique id travels over the control plane)."""
     os.environ.setdefault('NCCL_SOCKET_IFNAME', 'lo')   # single-node job: bootstrap over loopback, no NIC probing
     os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')   # dmabuf IPC (normally exported already; read when the runtime loads)
-    ident = torch.zeros(128, dtype=torch.uint8)
+    ident = b''
     if rank == 0:
         buf = (ctypes.c_uint8 * 128)()
         rc = vec_env.lib.cc4_comm_unique_id(buf)
         if rc != 0:
             raise RuntimeError('cc4_comm_unique_id failed')
-        ident = torch.tensor(list(buf), dtype=torch.uint8)
+        ident = bytes(buf)
     if world > 1:
-        dist.broadcast(ident, src=0)
-    raw = (ctypes.c_uint8 * 128)(*ident.tolist())
+        plane = plane or control_plane()
+        ident = plane.bcast_bytes(ident, src=0)
+    assert len(ident) == 128
+    raw = (ctypes.c_uint8 * 128).from_buffer_copy(ident)
     vec_env._chk(vec_env.lib.cc4_comm_init(vec_env._h, rank, world, raw), 'cc4_comm_init')
 
 

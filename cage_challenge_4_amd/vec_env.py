@@ -188,6 +188,17 @@ class CC4VecEnv:
         """cc4_step_kernel: the kernel this handle's steps launch ('k_step', 'k_step_philox' or 'k_step_philox1')."""
         return self.lib.cc4_step_kernel(self._h).decode()
 
+    @property
+    def launches_per_step(self):
+        """cc4_launches_per_step: a step of a large batch is several launches (episode groups on separate streams)."""
+        return int(self.lib.cc4_launches_per_step(self._h))
+
+    def host_stats(self):
+        """cc4_host_stats as a dict."""
+        out = np.zeros(5, np.float64)
+        self._chk(self.lib.cc4_host_stats(self._h, out.ctypes.data_as(ctypes.c_void_p)), 'cc4_host_stats')
+        return {'steps': int(out[0]), 'launch_us': float(out[1]), 'gather_us': float(out[2]), 'gathers': int(out[3]), 'gather_stalls': int(out[4])}
+
     def rng_state(self):
         out = np.zeros((self.num_envs, 7), np.uint64)
         self._chk(self.lib.cc4_get_rng_state(self._h, out.ctypes.data_as(ctypes.c_void_p)), 'cc4_get_rng_state')

@@ -18,3 +18,18 @@ def test_two_rank_sharding_and_allgather(oracle_lib):
     out = subprocess.run(cmd, capture_output=True, text=True, timeout=300, env=env)
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
     assert 'GLOO_OK' in out.stdout
+
+
+def test_two_ranks_over_the_torch_free_control_plane(oracle_lib, tmp_path):
+    """VERDICT r02 #8a: rendezvous, barriers, reductions, the unique-id broadcast and gathers through a shared directory
+    (cage_challenge_4_amd.distributed.FilePlane) -- two plain processes, no launcher, PyTorch never imported."""
+    worker = os.path.join(ROOT, 'tests', '_plane_worker.py')
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, OMP_NUM_THREADS='1', RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE='2', MASTER_ADDR='127.0.0.1', MASTER_PORT=str(free_port()),
+                   CC4_CONTROL_PLANE_KEY=f'test_{os.getpid()}', CC4_CONTROL_PLANE_DIR=str(tmp_path))
+        procs.append(subprocess.Popen([sys.executable, worker], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env))
+    outs = [p.communicate(timeout=300) for p in procs]
+    assert all(p.returncode == 0 for p in procs), '\n'.join(o[0][-1500:] + o[1][-1500:] for o in outs)
+    assert 'PLANE_OK' in outs[0][0]
+    assert not [f for f in os.listdir(tmp_path) if os.listdir(os.path.join(tmp_path, f))]      # the ranks cleaned up behind them

@@ -62,7 +62,7 @@ def test_hip_policy_variants_match_reference_golden():
         env, obs = T.replay(CC4VecEnv, fix, red_policy=fix['red_policy'], green_policy=fix['green_policy'], blue_policy=fix['blue_policy'])
         assert np.array_equal(obs[0], fix['obs'][0]) and np.array_equal(env.action_mask[0], fix['mask'])
         for t in range(fix['actions'].shape[0]):
-            obs, rew, done, info = env.step(fix['actions'][t][None])
+            obs, rew, done, info = env.step(fix['actions'][t][None], None if fix['messages'] is None else fix['messages'][t][None])
             assert np.array_equal(obs[0], fix['obs'][t + 1]), (fix['name'], t)
             assert rew[0] == fix['reward'][t] and bool(done[0]) == bool(fix['done'][t]), (fix['name'], t)
             assert G.rng_words_match(fix['rng'][t + 1], env.rng_state()[0]), (fix['name'], t)
@@ -180,14 +180,15 @@ def test_full_batch_matches_oracle_every_step(rng_mode, philox_kernel):
                          ids=['8192-fsm', '4096-fsm', '8192-discovery', '8192-randomselect-builtinblue'])
 def test_bench_configuration_matches_oracle_every_step(n, red_policy, blue_policy):
     """the configuration bench.py times -- counter mode, autoreset, the kernel cc4_create picks for the batch
-    size with NO override (k_step_philox1 at its natural residency: > 8 episodes per CU, generation work area in HBM, host
-    rows in L2 with atomics) -- against the oracle for ALL episodes at EVERY step (observations, rewards, dones, error flags)
+    size with NO override (at 8192 episodes k_step_philox1 at its natural residency -- generation work area in HBM, host rows in
+    L2 with atomics -- as three concurrent launches on three streams) -- against the oracle for ALL episodes at EVERY step (observations, rewards, dones, error flags)
     across two scenario regenerations, then the generator words and the packed state of every episode."""
     import os
-    assert 'CC4_PHILOX_LEAN' not in os.environ and 'CC4_PHILOX_MINW' not in os.environ
+    assert 'CC4_PHILOX_LEAN' not in os.environ and 'CC4_PHILOX_MINW' not in os.environ and 'CC4_GROUPS' not in os.environ
     T, steps = 330, 150
     dev = _dev(n, steps=steps, rng_mode=1, autoreset=True, red_policy=red_policy, blue_policy=blue_policy)
-    assert dev.step_kernel == 'k_step_philox1'
+    # 8192 episodes: three launches of the one-wave kernel per step; 4096: three launches of the four-wave kernel (cc4_create)
+    assert dev.step_kernel == ('k_step_philox1' if n == 8192 else 'k_step_philox') and dev.lib.cc4_launches_per_step(dev._h) == 3
     ora = OracleVecEnv(n, steps=steps, rng_mode=1, autoreset=True, red_policy=red_policy, blue_policy=blue_policy)
     assert np.array_equal(dev.reset(seeds=1000), ora.reset_batch(1000))
     resets = 0

@@ -326,3 +326,39 @@ def test_counter_mode_scenario_generation_properties():
         stats[mode] = (np.mean(nsvc), np.mean(nhosts))
     # SSHD + Binomial-like add-ons (0..3 uniformly) + OT service in the two operational zones: the two modes agree closely
     assert abs(stats[0][0] - stats[1][0]) < 0.06 and abs(stats[0][1] - stats[1][1]) < 2.5, stats
+
+
+def test_a_suspicious_pid_never_names_a_blue_or_green_session_process(oracle_lib):
+    """VERDICT r02 missing #5.  StopProcess.kill_process (StopProcess.py:36-58) ends whatever session owns the killed pid, blue
+    and green ones included; the engine only models the red case and raises E_BLUE_GREEN_SESSION_KILLED otherwise.  That flag
+    is unreachable: the blue / green session processes are created by State.__init__ (State.py:103-136, Host.add_session ->
+    create_pid, Host.py:189-200) and never removed or re-created (they are no service processes, and Host.restore puts them
+    back under their original pids, Host.py:373-429), while every other process of a host is created later with pid =
+    max(all current pids) + 1..9, i.e. above them -- and a suspicious pid is always the pid of such a later process (a red
+    shell: the only events that carry a pid, ExploitAction.py:264-275).  Checked here on what the engine itself produces under
+    the blue policies that make pids go stale (Remove / Restore heavy): every entry of every sus list exceeds the blue and green
+    session pids of its host, for whole episodes."""
+    import json
+    n, T = 48, 300
+    ora = OracleVecEnv(n, steps=T); ora.reset(seeds=6100)
+    rs = np.random.default_rng(3)
+    mask = ora.mask()
+    for t in range(T - 1):
+        a = np.zeros((n, 5), np.int32)
+        for b in range(5):
+            nh, nc = (48, 24) if b == 4 else (16, 8)
+            kind = rs.integers(0, 3, size=n)                      # Remove / Restore / DeployDecoy on a random valid host
+            base = np.where(kind == 0, nh + 1, np.where(kind == 1, 2 * nh + 1, 3 * nh + 2 + 2 * nc))
+            off = 82 * b if b < 4 else 328
+            for e in range(n):
+                valid = np.nonzero(mask[e, off + base[e]: off + base[e] + nh])[0]
+                a[e, b] = base[e] + valid[rs.integers(len(valid))]
+        ora.step(a)
+        assert not ora._err.any(), t
+        if t % 25 == 24 or t == T - 2:
+            for e in range(0, n, 5):
+                st = json.loads(ora.true_state_json(e))
+                floor = {h['h']: max(h['blue'], h['green']) for h in st['hosts']}
+                entries = [(h, p) for b in st['blue'] for h, p in b['sus']]
+                assert all(p > floor[h] for h, p in entries), (t, e)
+    assert sum(len(b['sus']) for b in json.loads(ora.true_state_json(0))['blue']) > 0
