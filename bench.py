@@ -178,8 +178,10 @@ def host_api_rates(seed=123, steps=300, eval_eps=3):
         @staticmethod
         def wrap(e):
             return BlueFlatWrapper(e)
+    import contextlib
     t0 = time.perf_counter()
-    scores = run_evaluation(Submission, None, max_eps=eval_eps, seed=seed, mode='sequential', write_to_file=False)
+    with contextlib.redirect_stdout(sys.stderr):        # the harness prints its summary like the reference's; stdout is for the one JSON line
+        scores = run_evaluation(Submission, None, max_eps=eval_eps, seed=seed, mode='sequential', write_to_file=False)
     dt = time.perf_counter() - t0
     n_steps = eval_eps * 499          # the step that raises `done` ends the episode (evaluation.py:108-110)
     out['eval_sequential'] = {'value': 5.0 * n_steps / dt, 'unit': 'agent-env steps/s', 'env_steps_per_sec': n_steps / dt, 'seconds': dt,

@@ -2169,9 +2169,11 @@ CC4_HD void rng_policy_swap(Ctx x, bool back) {
   { uint32_t t = a->u32; a->u32 = b->u32; b->u32 = t; }
   { uint32_t t = a->ndraw; a->ndraw = b->ndraw; b->ndraw = t; }
 }
-CC4_HD void step_green_policy(Ctx x, int g) {
+// pre: block 0 of the agent's policy stream when the caller has it already (rng_preload), else null
+CC4_HD void step_green_policy(Ctx x, int g, const uint32_t* pre = nullptr) {
   if (x.s->policy & GP_SLEEP_BIT) { x.w->green_act[g] = 2; return; }   // green_agent_class=SleepAgent: no draw, Sleep
   rng_set_stream(x.r, ST_GREEN_POL + (uint32_t)g);
+  if (pre) rng_preload(x.r, pre);
   x.w->green_act[g] = (uint8_t)rng_below(x.r, 3);  // choice([GreenAccessService, GreenLocalWork, Sleep])
 }
 // One red agent's policy (AgentInterface.get_action, SC:236-248) followed by its own duration-queue tick (SC:251-265; a tick
@@ -2195,13 +2197,15 @@ CC4_HD bool rsc_draws(const EnvState* s, int r) {
   if (!A.h.active || A.h.nsess == 0) return false;
   return rsw_id(rs_at(s, A, 0)) != 0 && rsw_id(rs_at(s, A, A.h.nsess - 1)) != 0 && rs_find_id(s, A, 0) < 0;
 }
-CC4_HD int step_red_policy_tick(Ctx x, int r, bool observed = false) {
+// pre: block 0 of the agent's policy stream when the caller has it already (rng_preload), else null
+CC4_HD int step_red_policy_tick(Ctx x, int r, bool observed = false, const uint32_t* pre = nullptr) {
   EnvState* s = x.s;
   RedAgent& A = s->red[r];
   CC4_FT0(x, r);
   RedHdr H = A.h;
   Act a; a.type = RA_SLEEP; a.host = 0; a.arg = 0; a.ticks = 1; a.sid = 0; a.busy = 0;
   rng_set_stream(x.r, ST_RED_POL + (uint32_t)r);
+  if (pre) rng_preload(x.r, pre);
   CC4_FT(x, r, 0);
   if (H.active && (s->policy & 3) == RP_RANDOM) { a = random_red_get_action(x, r, H); red_validate(x, r, H, a); }
   else if (H.active && (s->policy & 3) != RP_SLEEP) { a = fsm_get_action(x, r, H, observed); CC4_AT0(x); red_validate(x, r, H, a); CC4_AT(x, 7); }   // AgentInterface.get_action (:120-143); SleepAgent -> Sleep
@@ -2526,6 +2530,31 @@ CC4_HD int env_flat_obs_sorted(const EnvState* s, const HostDyn* hd, int v, int*
   const int b = v - 573;
   *idx = b < 4 ? b * OBS_SHORT : 4 * OBS_SHORT;
   return s->phase;
+}
+// The OBS_FAST values as a table (the device kernels read it instead of redoing the index arithmetic for every value of every
+// step): entry v = position in the vector | source byte << 10 | bit mask << 18; the value is (byte & mask) != 0.  Source byte
+// 0..136: the event bits of host h; 137 + 8 j + i: message bit i of blue agent j (EnvState.msg[j][i]).  Same enumeration as
+// env_flat_obs_sorted (tests/test_host_logic.py checks the two against each other).
+CC4_HD uint32_t obs_fast_entry(int v) {
+  if (v >= 224) {
+    const int w = v - 224, b = w >> 5, m = w & 31, jj = m / MSG_LEN;
+    const int idx = (b < 4 ? b * OBS_SHORT + OBS_SHORT : 4 * OBS_SHORT + OBS_LONG) - 32 + m;
+    const int src = MAXH + MSG_LEN * (jj < b ? jj : jj + 1) + m % MSG_LEN;
+    return (uint32_t)idx | ((uint32_t)src << 10) | (1u << 18);
+  }
+  const int sb = v >> 5, r = v & 31, k = 27 + (r & 15) + ((r >> 4) ? 16 : 0);
+  const int b = sb < 4 ? sb : 4, i = sb < 4 ? 0 : sb - 4;
+  const int idx = (b < 4 ? b * OBS_SHORT : 4 * OBS_SHORT) + 1 + 59 * i + k;
+  const int sn = blue_subnet_sorted(b, i);
+  const int hs = k < 43 ? k - 27 : k - 43;
+  const int h = hs < MAX_SERVERS ? h_make(sn, 11 + hs) : h_make(sn, 1 + (hs - MAX_SERVERS));
+  const uint32_t mask = k < 43 ? (uint32_t)(EV_CUR_PROC | EV_OLD_PROC) : (uint32_t)(EV_CUR_CONN | EV_OLD_CONN);
+  return (uint32_t)idx | ((uint32_t)h << 10) | (mask << 18);
+}
+CC4_HD int obs_fast_value(uint32_t entry, const EnvState* s, const HostDyn* hd, const uint8_t* evb) {
+  const int src = (int)((entry >> 10) & 0xFF);
+  const uint32_t byte = src < MAXH ? (evb ? evb[src] : hd[src].ev) : (&s->msg[0][0])[src - MAXH];
+  return (byte & (entry >> 18)) != 0 ? 1 : 0;
 }
 template <typename T>
 CC4_HD void env_flat_obs(const EnvState* s, const HostDyn* hd, T* out) {

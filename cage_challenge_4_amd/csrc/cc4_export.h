@@ -10,7 +10,7 @@
 //              "svcs":[[kind,active,reliability percent,pid]...] (Host.services order), "ev":event bits,
 //              "files":HF_* bits (1 cmd.sh, 2 escalate.sh, 4 escalate.sh appended last),
 //              "blue":pid of the blue session process (0 none),"green":pid of the green session process (0 none)}...],
-//    "red":[{"active":0/1,"sessions":[[id,host,pid,flags]...] (state.sessions[red_agent_r] order; flags = RS_* bits)}...x6],
+//    "red":[{"active":0/1,"start":host the scenario generator drew for the agent,"sessions":[[id,host,pid,flags]...] (state.sessions[red_agent_r] order; flags = RS_* bits)}...x6],
 //    "blue":[{"parent":host id of the VelociraptorServer,"busy":1 while a multi-tick action is in progress,"traffic_ok":outcome of the last Block/Allow (1 TRUE, 3 FALSE),"sus":[[host,pid]...]}...x5],
 //    "last_blue":[[BA_* type,host or to-subnet,from-subnet]...x5],"last_red":[[RA_* type,host,subnet,executed (0 = dropped by filter_actions)]...x6] (the actions
 //    that resolved in the last step, i.e. CybORG.get_last_action),
@@ -66,7 +66,7 @@ inline std::string export_true_state(const EnvState& s, const EnvCold& cold, boo
   o += "],\"red\":[";
   for (int r = 0; r < NRED; ++r) {
     const RedAgent& A = s.red[r];
-    add("%s{\"active\":%u,\"sessions\":[", r ? "," : "", (unsigned)A.h.active);
+    add("%s{\"active\":%u,\"start\":%u,\"sessions\":[", r ? "," : "", (unsigned)A.h.active, (unsigned)A.h.start_host);
     for (int i = 0; i < A.h.nsess; ++i) { const RSess& q = s.spool[A.sord[i]]; add("%s[%u,%u,%u,%u]", i ? "," : "", (unsigned)q.id, (unsigned)q.host, (unsigned)q.pid, (unsigned)q.flags); }
     o += "]}";
   }

@@ -109,6 +109,25 @@ __device__ __forceinline__ uint8_t pack_obs_byte(const uint8_t* vals, int j) {
 // are never used) -- so lane j computes output j+1 directly and the consumption is replayed on the 128 ready words with a
 // few wave-wide compares per draw instead of a 128-bit multiply per draw on the walking lane.  Bit-exact with the serial
 // walk (rng_below / rng_interval in cc4_rng.h), including has_uint32 / uinteger buffering and the advance counter.
+__device__ uint32_t g_obs_fast[OBS_FAST];          // obs_fast_entry(v) for v = 0 .. OBS_FAST-1 (cc4_engine.h), filled by cc4_create
+// The observation values that can change with every step, from the table: position, source byte and mask come with one load
+// instead of a dozen divisions per value.  evb: the hosts' event bytes when the host table is not in LDS (null: read hd[h].ev).
+template <int nt>
+__device__ __forceinline__ void encode_obs_fast(const EnvState* s, const HostDyn* hd, const uint8_t* evb, int32_t* o, uint8_t* obs_bytes, bool pack, int t) {
+  constexpr int NV = (OBS_FAST + nt - 1) / nt;
+  uint32_t ent[NV];
+#pragma unroll
+  for (int k = 0; k < NV; ++k) { const int v = t + k * nt; ent[k] = v < OBS_FAST ? g_obs_fast[v] : 0u; }
+#pragma unroll
+  for (int k = 0; k < NV; ++k) {
+    const int v = t + k * nt;
+    if (v >= OBS_FAST) continue;
+    const int val = obs_fast_value(ent[k], s, hd, evb);
+    const int i = (int)(ent[k] & 0x3FF);
+    o[i] = val;
+    if (pack) obs_bytes[i] = (uint8_t)val;
+  }
+}
 struct PcgJump { uint64_t a_hi, a_lo, b_hi, b_lo; };
 __device__ PcgJump g_pcg_jump[WAVE + 1];          // [k]: k = 0 .. 64 steps ahead
 __device__ __forceinline__ uint64_t bcast64(uint64_t v) {
@@ -599,7 +618,8 @@ __global__ __launch_bounds__(WAVE) void k_step(StepArgs a) {
     int32_t* o = a.obs + (size_t)e * OBS_TOTAL;
     const bool pack = a.obs8 != nullptr;
     const int nv = (do_reset || a.full_obs || pack || s->obs_dirty) ? OBS_TOTAL : OBS_FAST;
-    for (int v = lane; v < nv; v += WAVE) { int i; const int val = env_flat_obs_sorted(s, hd, v, &i, ev_lds); o[i] = val; if (pack) obs_lds[i] = (uint8_t)val; }
+    encode_obs_fast<WAVE>(s, hd, ev_lds, o, obs_lds, pack, lane);
+    for (int v = OBS_FAST + lane; v < nv; v += WAVE) { int i; const int val = env_flat_obs_sorted(s, hd, v, &i, ev_lds); o[i] = val; if (pack) obs_lds[i] = (uint8_t)val; }
   }
   __syncthreads();
   unsigned long long t_out = a.prof ? clock64() : 0;
@@ -898,7 +918,8 @@ __global__ __launch_bounds__(PT, MINW) void k_step_philox(StepArgs a) {
     // the values that can change with every step (host events, messages) always; blocks, comms policy, subnet one-hots and phase
     // words only when the step changed them (EnvState.obs_dirty), after a reset, or when the caller asks (the buffer persists)
     const int nv = (do_reset || a.full_obs || pack || s->obs_dirty) ? OBS_TOTAL : OBS_FAST;
-    for (int v = tid; v < nv; v += PT) { int i; int val = env_flat_obs_sorted(s, hd, v, &i); o[i] = val; if (pack) obs_bytes[i] = (uint8_t)val; }   // kind-sorted enumeration: uniform branches per wave
+    encode_obs_fast<PT>(s, hd, nullptr, o, obs_bytes, pack, tid);
+    for (int v = OBS_FAST + tid; v < nv; v += PT) { int i; int val = env_flat_obs_sorted(s, hd, v, &i); o[i] = val; if (pack) obs_bytes[i] = (uint8_t)val; }   // kind-sorted enumeration: uniform branches per wave
   }
   __syncthreads();    // the row is final: RedSessionCheck and the step bookkeeping ran beside the encode
   if (tid == 0) a.err[e] = s->err;
@@ -992,36 +1013,67 @@ __global__ __launch_bounds__(WAVE) void k_step_philox1(StepArgs a) {
       Ctx x0{s, cold_e, &rl, hd, &work, lane == 0 ? prof : nullptr};
       x0.lg = lg;
       if (lane == 0) CC4_TICK(x0, 0);
+      // ---- the block bank.  A Philox block costs a wave the same ~110 vector instructions whether one lane needs it or
+      // sixty-four do, and block 0 of every stream of the step is known from (key, step, episode, stream id) alone.  The streams
+      // that have a lane of their own per agent (green policy / action of agents 0..63) are computed where they are used, one
+      // pass each; the rest -- green agents 64.., the six red policies and actions, the five blue actions and, in the bench, the
+      // five in-kernel blue action draws: 49 requests, six sequential passes when each is computed by the lane that resolves its
+      // agent -- share ONE pass here, one request per lane, and reach their agents' lanes through ds_bpermute when their phase
+      // comes (bank_fetch; same words as computing them in place: rng_preload).
+      enum : int { BK_GPOL = 0, BK_GEXE = 16, BK_RPOL = 32, BK_REXE = 38, BK_BEXE = 44, BK_BRAND = 49, BK_END = 54 };
+      uint32_t bank[4];
+      {
+        uint32_t st = 0;
+        if (lane < BK_GEXE) st = ST_GREEN_POL + (uint32_t)(WAVE + lane - BK_GPOL);
+        else if (lane < BK_RPOL) st = ST_GREEN_EXE + (uint32_t)(WAVE + lane - BK_GEXE);
+        else if (lane < BK_REXE) st = ST_RED_POL + (uint32_t)(lane - BK_RPOL);
+        else if (lane < BK_BEXE) st = ST_RED_EXE + (uint32_t)(lane - BK_REXE);
+        else if (lane < BK_BRAND) st = ST_BLUE_EXE + (uint32_t)(lane - BK_BEXE);
+        bank[0] = 0u; bank[1] = st; bank[2] = (uint32_t)rl.inc_lo; bank[3] = (uint32_t)rl.inc_hi;      // rng_block(&rl, st, 0, .)
+        uint32_t k0 = (uint32_t)rl.s_lo, k1 = (uint32_t)(rl.s_lo >> 32);
+        if (a.rand_out && lane >= BK_BRAND && lane < BK_END) {   // random_blue_action(seed0, t, e, b): another key and counter layout
+          const uint64_t key = a.rand_seed0 + (uint64_t)e;
+          bank[0] = a.rand_t; bank[1] = (uint32_t)(lane - BK_BRAND); bank[2] = 0xB10Eu; bank[3] = 0u; k0 = (uint32_t)key; k1 = (uint32_t)(key >> 32);
+        }
+        philox4x32_10(bank, k0, k1);
+      }
+      // the four words lane `lane + shift` holds, on every lane (call with all lanes active: an inactive source lane reads as 0)
+      auto bank_fetch = [&](int shift, uint32_t out[4]) {
+        const int addr = ((lane + shift) & (WAVE - 1)) << 2;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) out[k] = (uint32_t)__builtin_amdgcn_ds_bpermute(addr, (int)bank[k]);
+      };
       const bool is_red = lane < NRED;
       unsigned long long* ap = (a.prof && is_red) ? a.prof + PROF_SLOTS * (size_t)e + 16 + 8 * lane : nullptr;
       Ctx xr{s, cold_e, &rl, hd, &work, nullptr, ap, lg};
       Ctx xg{s, cold_e, &rl, hd, &work, nullptr, nullptr, lg};
       // ---- P0-P3a: every agent's policy / submission and its own duration-queue tick (SC:236-265)
+      uint32_t pre_rp[4];
+      bank_fetch(BK_RPOL, pre_rp);                                               // red r (lane r) <- lane BK_RPOL + r
+      const uint32_t brand = (uint32_t)__builtin_amdgcn_ds_bpermute(((lane + BK_BRAND - 8) & (WAVE - 1)) << 2, (int)bank[0]);   // blue b (lane 8 + b) <- lane BK_BRAND + b
       if (is_red) {
         unsigned long long t0 = ap ? clock64() : 0;
-        const int dropped = step_red_policy_tick(xr, lane);
+        const int dropped = step_red_policy_tick(xr, lane, false, pre_rp);
         if (ap) ap[0] += clock64() - t0;
         if (dropped) atomicSub(&s->n_actions, 1);
       } else if (lane >= 8 && lane < 8 + NBLUE) {
         const int b = lane - 8;
         int32_t act = a.actions ? a.actions[e * NBLUE + b] : -1;
-        if (a.rand_out) { act = random_blue_action(a.rand_seed0, a.rand_t, e, b); a.rand_out[e * NBLUE + b] = act; }
+        if (a.rand_out) { act = (int32_t)(((uint64_t)brand * (uint32_t)(b == 4 ? ACT_LONG : ACT_SHORT)) >> 32); a.rand_out[e * NBLUE + b] = act; }   // == random_blue_action
         step_blue_submit(xg, b, act);
         step_tick_blue(xg, b);
         step_messages(s, a.msgs ? a.msgs + e * NBLUE * MSG_LEN : nullptr, b);   // read back by this step's observation encode only
       }
-      for (int g = lane; g < ng; g += WAVE) step_green_policy(xg, g);
+      if (lane < ng) step_green_policy(xg, lane);                               // agents 0..63: their block is computed here, by all of them at once
+      if (lane + WAVE < ng) step_green_policy(xg, lane + WAVE, bank);            // agents 64..: from the bank (their lane's own request)
       __syncthreads();
       CC4_TICK(x0, 2);
       // ---- P3b blue actions: side by side when they are independent (no Monitor, no pending pid events)
       if (blue_exec_independent(s)) {
         if (lane == 0) CC4_TICK(x0, 3);
-        if (lane < NBLUE) {
-          // block 0 of the agent's action stream ahead of the switch on the action type: the lanes compute it in lock-step
-          // instead of once per divergent path
-          uint32_t c[4]; rng_block(&rl, ST_BLUE_EXE + (uint32_t)lane, 0, c);
-          step_blue_exec_agent(xg, lane, c);
-        }
+        uint32_t c[4];
+        bank_fetch(BK_BEXE, c);                                                   // blue b (lane b) <- lane BK_BEXE + b
+        if (lane < NBLUE) step_blue_exec_agent(xg, lane, c);
         __syncthreads();
         if (lane == 0) CC4_TICK(x0, 5);
       } else {
@@ -1031,10 +1083,13 @@ __global__ __launch_bounds__(WAVE) void k_step_philox1(StepArgs a) {
       // ---- P4 green actions, one agent per lane
       {
         int pen = 0;
-        for (int g = lane; g < ng; g += WAVE) {
-          uint32_t c[4]; rng_block(&rl, ST_GREEN_EXE + (uint32_t)g, 0, c);      // ahead of the AccessService / LocalWork split (see above)
-          pen += step_green_exec(xg, g, c);
+        uint32_t c2[4];
+        bank_fetch(BK_GEXE, c2);                                                  // green 64 + k (lane k) <- lane BK_GEXE + k
+        if (lane < ng) {
+          uint32_t c[4]; rng_block(&rl, ST_GREEN_EXE + (uint32_t)lane, 0, c);    // ahead of the AccessService / LocalWork split: one block for all
+          pen += step_green_exec(xg, lane, c);
         }
+        if (lane + WAVE < ng) pen += step_green_exec(xg, lane + WAVE, c2);
         if (pen) atomicAdd(&s->brm, pen);
       }
       __syncthreads();
@@ -1043,10 +1098,11 @@ __global__ __launch_bounds__(WAVE) void k_step_philox1(StepArgs a) {
       if (lane == 0) { step_phishing(x0); CC4_TICK(x0, 1); rs_reserve(x0); conflict_lds = (int)red_conflict_mask(s); if (prof && conflict_lds) prof[4] += 1000000; }
       __syncthreads();
       const uint32_t serial_red = (uint32_t)conflict_lds;
+      uint32_t pre_re[4];
+      bank_fetch(BK_REXE, pre_re);                                                // red r (lane r) <- lane BK_REXE + r
       if (is_red && !((serial_red >> lane) & 1u)) {
         unsigned long long t0 = ap ? clock64() : 0;
-        uint32_t c[4]; rng_block(&rl, ST_RED_EXE + (uint32_t)lane, 0, c);
-        step_red_exec_agent(xr, lane, c);
+        step_red_exec_agent(xr, lane, pre_re);
         if (ap) ap[1] += clock64() - t0;
       }
       __syncthreads();
@@ -1096,7 +1152,8 @@ __global__ __launch_bounds__(WAVE) void k_step_philox1(StepArgs a) {
     int32_t* o = a.obs + (size_t)e * OBS_TOTAL;
     const bool pack = a.obs8 != nullptr;
     const int nv = (do_reset || a.full_obs || pack || s->obs_dirty) ? OBS_TOTAL : OBS_FAST;
-    for (int v = lane; v < nv; v += WAVE) { int i; const int val = env_flat_obs_sorted(s, hd, v, &i, ev_lds); o[i] = val; if (pack) obs_bytes[i] = (uint8_t)val; }
+    encode_obs_fast<WAVE>(s, hd, ev_lds, o, obs_bytes, pack, lane);
+    for (int v = OBS_FAST + lane; v < nv; v += WAVE) { int i; const int val = env_flat_obs_sorted(s, hd, v, &i, ev_lds); o[i] = val; if (pack) obs_bytes[i] = (uint8_t)val; }
   }
   __syncthreads();
   if (lane == 0) a.err[e] = s->err;
@@ -1425,6 +1482,9 @@ int cc4_create(const cc4_config* cfg, cc4_handle** out) {
       B = B * M + 1; A = A * M;
     }
     HIPCHK(h, hipMemcpyToSymbol(HIP_SYMBOL(g_pcg_jump), tab, sizeof(tab)));
+    uint32_t ot[OBS_FAST];
+    for (int v = 0; v < OBS_FAST; ++v) ot[v] = obs_fast_entry(v);
+    HIPCHK(h, hipMemcpyToSymbol(HIP_SYMBOL(g_obs_fast), ot, sizeof(ot)));
   }
   {
     hipDeviceProp_t prop;
@@ -1476,7 +1536,7 @@ int cc4_create(const cc4_config* cfg, cc4_handle** out) {
 void cc4_destroy(cc4_handle* h) {
   if (!h) return;
   (void)hipSetDevice(h->cfg.device_id);
-  for (int g = h->ngroups - 1; g >= 0; --g) if (h->gstream[g]) (void)hipStreamSynchronize(h->gstream[g]);
+  for (int g = cc4_handle::MAX_GROUPS - 1; g >= 0; --g) if (h->gstream[g]) (void)hipStreamSynchronize(h->gstream[g]);
   if (h->comm_stream) (void)hipStreamSynchronize(h->comm_stream);
   if (h->comm) ncclCommDestroy(h->comm);
   for (int b = 0; b < cc4_handle::OBS_RING; ++b) { for (int g = 0; g < 4; ++g) if (h->ev_step[b][g]) (void)hipEventDestroy(h->ev_step[b][g]); if (h->ev_comm[b]) (void)hipEventDestroy(h->ev_comm[b]); }
@@ -1788,6 +1848,23 @@ int cc4_comm_init(cc4_handle* h, int32_t rank, int32_t world, const void* id128)
   ncclResult_t r = ncclCommInitRank(&h->comm, world, id, rank);
   if (r != ncclSuccess) { h->err = std::string("ncclCommInitRank: ") + ncclGetErrorString(r); return -1; }
   h->rank = rank; h->world = world;
+  if (!getenv("CC4_GROUPS")) {
+    // With the exchange every launch carries a completion event and the host guards the observation ring, so a launch costs the
+    // host several times what it costs without; small shards then run into the host.  Measured on MI355X with the exchange on a
+    // one-rank communicator (r03, profiles/r03_exchange_groups_world1.txt; M agent-env steps/s, 1 / 2 / 3 launches per step):
+    // 1024 episodes 159 / 104 / 111, 8192: 478 / 498 / 607.
+    const int ng = h->cfg.num_envs >= 4096 ? 3 : 1;
+    if (ng != h->ngroups) {
+      if (sync_all(h)) return -1;
+      const int old = h->ngroups;
+      configure_groups(h, ng);
+      for (int g = old; g < h->ngroups; ++g) {
+        if (!h->gstream[g]) HIPCHK(h, hipStreamCreateWithFlags(&h->gstream[g], hipStreamNonBlocking));
+        if (!h->gev[g]) HIPCHK(h, hipEventCreateWithFlags(&h->gev[g], hipEventDisableTiming));
+      }
+      h->main_ahead = true;
+    }
+  }
   size_t nb = (size_t)h->cfg.num_envs * OBS_PACKED;
   HIPCHK(h, hipStreamCreateWithFlags(&h->comm_stream, hipStreamNonBlocking));
   for (int b = 0; b < cc4_handle::OBS_RING; ++b) {

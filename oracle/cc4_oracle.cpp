@@ -153,6 +153,14 @@ void cc4o_obs_variants(void* h, int i, int32_t* by_pos, int32_t* by_kind) {
   for (int k = 0; k < OBS_TOTAL; ++k) by_pos[k] = env_flat_obs_at(s, s->hd, k);
   for (int v = 0; v < OBS_TOTAL; ++v) { int idx = -1; int val = env_flat_obs_sorted(s, s->hd, v, &idx); by_kind[idx] = val; }
 }
+// the table form of the fast part (obs_fast_entry / obs_fast_value: what the device kernels encode from), values beyond OBS_FAST = -1
+void cc4o_obs_by_table(void* h, int i, int32_t* out) {
+  const EnvState* s = &((Oracle*)h)->st[i];
+  for (int k = 0; k < OBS_TOTAL; ++k) out[k] = -1;
+  uint8_t evb[MAXH];
+  for (int k = 0; k < MAXH; ++k) evb[k] = s->hd[k].ev;
+  for (int v = 0; v < OBS_FAST; ++v) { const uint32_t e = obs_fast_entry(v); out[e & 0x3FF] = obs_fast_value(e, s, s->hd, (v & 1) ? evb : nullptr); }
+}
 float cc4o_reward(void* h, int i) { return ((Oracle*)h)->st[i].reward; }
 int cc4o_done(void* h, int i) { return ((Oracle*)h)->st[i].done; }
 uint32_t cc4o_err(void* h, int i) { return ((Oracle*)h)->st[i].err; }

@@ -759,10 +759,15 @@ def test_bench_line_contract():
     assert not d['config']['engine_error_flags'] and d['config']['timed_regions'] >= 1
     r = d['roofline']
     assert r['bound'] == 'hbm' and r['unit'] == 'GB/s' and r['peak'] == 8000.0 and abs(r['frac'] - r['achieved'] / r['peak']) < 1e-9
-    assert r['kernel'] == 'k_step_philox1' and 0 < r['launch_ms'] <= d['ms_per_step'] * 1.02
-    assert abs(r['achieved'] - r['algorithmic_bytes_per_launch'] / (r['launch_ms'] * 1e-3) / 1e9) < 1e-6 * r['achieved']
-    assert r['traffic'] is None or ('profiles/' in r['traffic_source'])
+    # 8192 episodes: three concurrent launches of the one-wave kernel per step (episode groups on three streams)
+    assert r['kernel'] == 'k_step_philox1' and r['launches_per_step'] == 3 and 0 < r['launch_ms'] <= d['ms_per_step'] * 1.02
+    assert abs(r['algorithmic_bytes_per_step'] - r['launches_per_step'] * r['algorithmic_bytes_per_launch']) < 1e-6 * r['algorithmic_bytes_per_step']
+    assert abs(r['achieved'] - r['launches_per_step'] * r['algorithmic_bytes_per_launch'] / (r['launch_ms'] * 1e-3) / 1e9) < 1e-6 * r['achieved']
+    assert r['traffic'] is None or ('profiles/' in r['traffic_source'] and 'k_step_philox1' in r['traffic_source'])
     assert abs(d['value'] - 5.0 * 8192 / (d['ms_per_step'] * 1e-3)) < 1e-6 * d['value']
+    pr = d['config']['per_rank']
+    assert len(pr) == 1 and pr[0]['rank'] == 0 and pr[0]['envs'] == 8192 and pr[0]['host_launch_us_per_step'] > 0
+    assert d['single_env_facade']['env_steps_per_sec'] > 34 and d['eval_sequential']['env_steps_per_sec'] > 34      # the reference's own rate
     c = d['cpu_baseline']
     assert c['kind'] == 'port' and c['cores'] >= 1 and c['value'] > 0 and 'sample' in c and c['one_core']['cores'] == 1
     assert c['reference_python']['kind'] == 'reference' and c['reference_python']['value'] == 172.0

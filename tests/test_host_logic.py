@@ -77,9 +77,14 @@ def test_flat_obs_enumerations_agree():
     o.reset(seeds=5)
     o.lib.cc4o_obs_variants.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]
     for t in range(40):
-        obs, _, _, _ = o.step(random_actions(5, t, 4))
+        obs, _, _, _ = o.step(random_actions(5, t, 4), np.random.default_rng(t).integers(0, 2, size=(4, 5, 8)).astype(np.uint8))
         for i in range(4):
             a = np.full(578, -1, np.int32)
             b = np.full(578, -1, np.int32)
             o.lib.cc4o_obs_variants(o._h, i, a.ctypes.data_as(ctypes.c_void_p), b.ctypes.data_as(ctypes.c_void_p))
             assert np.array_equal(a, obs[i]) and np.array_equal(b, obs[i]), (t, i)
+            c = np.full(578, -7, np.int32)                       # the table form of the values that can change every step
+            o.lib.cc4o_obs_by_table.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]
+            o.lib.cc4o_obs_by_table(o._h, i, c.ctypes.data_as(ctypes.c_void_p))
+            fast = c >= 0
+            assert fast.sum() == 384 and np.array_equal(c[fast], obs[i][fast]), (t, i)
