@@ -81,6 +81,23 @@ class AllowTrafficZone(_ControlTraffic):
 BLUE_ACTIONS = (Sleep, Monitor, Analyse, Remove, Restore, DeployDecoy, BlockTrafficZone, AllowTrafficZone)
 
 
+SUBNET_ORDER = ('restricted_zone_a_subnet', 'operational_zone_a_subnet', 'restricted_zone_b_subnet', 'operational_zone_b_subnet',
+                'contractor_network_subnet', 'public_access_zone_subnet', 'admin_network_subnet', 'office_network_subnet')
+BLUE_RAW_ACTION = 0x10000        # csrc/cc4_engine.h: BLUE_RAW_ACTION | BA_* type << 8 | host id
+_BA = {'Analyse': 2, 'Remove': 3, 'Restore': 4, 'DeployDecoy': 5}
+
+
+def raw_host_action(name, host, labels):
+    """(type, host id) code of a host action the fixed list cannot express, or None: `host` must be the router of one of the
+    subnets the agent's list covers."""
+    if name not in _BA or not host.endswith('_router'):
+        return None
+    sn = host[:-len('_router')]
+    if sn not in SUBNET_ORDER or not any(sn + '_' in lab for lab in labels):
+        return None
+    return BLUE_RAW_ACTION | (_BA[name] << 8) | (SUBNET_ORDER.index(sn) * 17)
+
+
 def action_index(action, labels):
     """Index of `action` (an int, an object of the classes above, or anything with the same class name and attributes) in
     an agent's fixed action list, given the list's labels (BlueFixedActionWrapper.action_labels).  An action that names a
@@ -95,6 +112,11 @@ def action_index(action, labels):
         for lab in (f'{name} {host}', f'[Invalid] {name} {host}'):
             if lab in labels:
                 return labels.index(lab)
+        # a host the agent's fixed list has no slot for -- the routers of its zone: the reference forwards the object and the
+        # simulator executes it (cc4BlueRandomAgent picks routers too); the engine takes it as (type, host id) (cc4.h cc4_step)
+        raw = raw_host_action(name, host, labels)
+        if raw is not None:
+            return raw
         raise ValueError(f'{name} {host}: not an action of this agent')
     src, dst = getattr(action, 'from_subnet', None), getattr(action, 'to_subnet', None)
     if src is not None and dst is not None:

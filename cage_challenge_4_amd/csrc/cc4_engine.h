@@ -49,14 +49,14 @@ CC4_HD void set_err(Ctx x, uint32_t f) {
   x.s->err |= f;
 #endif
 }
-// OR event bits into HostDyn.ev (byte 2 of the aligned word {nproc,nsvc,ev,pad}); atomic on device because green
-// agents resolved on different lanes may raise events on the same server
+// OR event bits into EnvState.hev[h] (one byte per host, four hosts per word); atomic on the device because agents resolved on
+// different lanes may raise events on the same host
 CC4_HD void ev_or(Ctx x, int h, uint32_t bits) {
 #if defined(__HIP_DEVICE_COMPILE__)
-  uint32_t* w = reinterpret_cast<uint32_t*>(&x.hd[h].nproc);
-  __hip_atomic_fetch_or(w, bits << 16, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+  uint32_t* w = reinterpret_cast<uint32_t*>(x.s->hev) + (h >> 2);
+  __hip_atomic_fetch_or(w, bits << (8 * (h & 3)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 #else
-  x.hd[h].ev |= (uint8_t)bits;
+  x.s->hev[h] |= (uint8_t)bits;
 #endif
 }
 // optional event log (EnvCold.evlog, enabled through cc4_enable_event_log): the content of the HostEvents entry behind an
@@ -577,7 +577,7 @@ CC4_HD void gen_host(Ctx x, int h, uint32_t* used) {  // _generate_linux_host (E
   HostDyn& st = x.hd[h];
   st.nproc = 0; st.nsf = 0;
   bit_set(s->exists, h);
-  st.ev = (uint8_t)rng_below(x.r, 2);  // OSDistribution choice (ESG.py:488-494): 0 UBUNTU, 1 KALI; parked in ev until the backup is written
+  st.gtmp = (uint8_t)rng_below(x.r, 2);  // OSDistribution choice (ESG.py:488-494): 0 UBUNTU, 1 KALI; parked in gtmp until the backup is written
   if (h_is_router(h)) return;
   // _generate_linux_host_services (ESG.py:530-562); services dict order = SSHD, [OTSERVICE], chosen add-ons
   int n = 0;
@@ -618,7 +618,7 @@ CC4_HD void host_backup(Ctx x, int h, int ip_octet) {
   HostStatic st;
   for (int i = 0; i < 8; ++i) st.procs[i] = d.procs[i];
   for (int i = 0; i < 5; ++i) st.svcs[i] = d.svcs[i];
-  st.nproc = (uint8_t)d.nproc; st.nsvc = (uint8_t)hd_nsvc(d); st.exists = (uint8_t)(1 | ((d.ev & 1) << 1)); st.ip_octet = (uint8_t)ip_octet;
+  st.nproc = (uint8_t)d.nproc; st.nsvc = (uint8_t)hd_nsvc(d); st.exists = (uint8_t)(1 | ((d.gtmp & 1) << 1)); st.ip_octet = (uint8_t)ip_octet;
   if (d.nproc > PIN - 1 || hd_nsvc(d) > 5) set_err(x, E_PROC_OVERFLOW);   // slot PIN-1 carried the address during generation
   __builtin_memcpy(&x.c->hs[h], &st, sizeof(HostStatic));
 }
@@ -629,7 +629,8 @@ CC4_HD void host_restore(Ctx x, int h) {  // Host.restore (Host.py:373-429)
   __builtin_memcpy(&st, &x.c->hs[h], sizeof(HostStatic));   // 8-byte aligned POD -> 7 wide loads in flight
   for (int i = 0; i < 8; ++i) d.procs[i] = st.procs[i];
   for (int i = 0; i < 5; ++i) d.svcs[i] = st.svcs[i];
-  d.nproc = st.nproc; d.ev = 0; d.nsf = st.nsvc;   // the cold part of the list is simply abandoned; Host.files is cleared
+  d.nproc = st.nproc; d.gtmp = 0; d.nsf = st.nsvc;   // the cold part of the list is simply abandoned; Host.files is cleared
+  x.s->hev[h] = 0;                                  // self.events = HostEvents()
   eph_clear(x, h);
   pend_drop_host(x, h);
 }
@@ -701,7 +702,7 @@ CC4_HD void reset_gen_host(Ctx x, int h) {
   if (!bit_get(s->exists, h)) return;
   rng_set_stream(x.r, ST_GEN_HOST + (uint32_t)h);
   HostDyn& st = x.hd[h];
-  st.ev = (uint8_t)rng_below(x.r, 2);   // OSDistribution, parked in ev until the backup
+  st.gtmp = (uint8_t)rng_below(x.r, 2);   // OSDistribution, parked in gtmp until the backup
   if (h_is_router(h)) return;
   int n = 0;
   auto put = [&](int kind, int pid) {
@@ -736,7 +737,7 @@ CC4_HD void reset_pid_flag(Ctx x, int h, uint32_t* ws) {
   HostDyn& st = x.hd[h];
   uint32_t m = 0;
   for (int i = 0; i < hd_nsvc(st); ++i) { int v = st.svcs[i].pid - 1000; if (bit_get(ws + RESET_WS_DUP, v)) m |= 1u << i; }
-  if (m) { st.ev = (uint8_t)(st.ev | (m << 1)); (void)or_shared(&ws[RESET_WS_HOSTS + (h >> 5)], 1u << (h & 31)); }
+  if (m) { st.gtmp = (uint8_t)(st.gtmp | (m << 1)); (void)or_shared(&ws[RESET_WS_HOSTS + (h >> 5)], 1u << (h & 31)); }
 }
 // phase 3c, one thread: contested pids in host / service order -- the first holder keeps the value, later ones draw again
 CC4_HD void reset_pid_resolve(Ctx x, uint32_t* ws) {
@@ -745,8 +746,8 @@ CC4_HD void reset_pid_resolve(Ctx x, uint32_t* ws) {
     while (hm) {
       const int h = w * 32 + ctz32(hm); hm &= hm - 1;
       HostDyn& st = x.hd[h];
-      uint32_t cm = (uint32_t)st.ev >> 1;
-      st.ev &= 1;
+      uint32_t cm = (uint32_t)st.gtmp >> 1;
+      st.gtmp &= 1;
       Rng t; bool forked = false;
       while (cm) {
         const int i = ctz32(cm); cm &= cm - 1;
@@ -800,7 +801,7 @@ CC4_HD void reset_host_sessions(Ctx x, int h) {
   if (h != H_INTERNET && h_is_user(h)) (void)start_session_proc(x, h, K_SESS_GREEN);
   if (h == s->red[0].h.start_host) (void)start_session_proc(x, h, K_SESS_RED);
   host_backup(x, h, x.hd[h].procs[PIN - 1].pid);
-  x.hd[h].procs[PIN - 1].pid = 0; x.hd[h].ev = 0;
+  x.hd[h].procs[PIN - 1].pid = 0; x.hd[h].gtmp = 0;
 }
 // phase 6, one thread: red_agent_0's session, initial observations, counters
 CC4_HD void reset_finish(Ctx x, ResetCarry k, int steps, uint32_t topo_seed, bool rng_is_copy) {
@@ -985,7 +986,7 @@ CC4_HD void env_reset(Ctx x, uint64_t seed, int rng_mode, int steps, bool contin
   int red0_pid = start_session_proc(x, s->red[0].h.start_host, K_SESS_RED);
   // host.create_backup() for every host (State.py:137-138) -> dynamic state := static
   for (int h = 0; h < MAXH; ++h) {
-    if (bit_get(s->exists, h)) { host_backup(x, h, x.hd[h].procs[PIN - 1].pid); x.hd[h].procs[PIN - 1].pid = 0; x.hd[h].ev = 0; }
+    if (bit_get(s->exists, h)) { host_backup(x, h, x.hd[h].procs[PIN - 1].pid); x.hd[h].procs[PIN - 1].pid = 0; x.hd[h].gtmp = 0; }
     eph_clear(x, h);
   }
   s->npend = 0;
@@ -1019,10 +1020,21 @@ CC4_HD void env_reset(Ctx x, uint64_t seed, int rng_mode, int steps, bool contin
 
 // ------------------------------------------------------------------ blue actions
 // wrapper index -> action (Agents/Wrappers/BlueFixedActionWrapper.py:233-309)
+enum : int { BLUE_RAW_ACTION = 0x10000 };   // idx = BLUE_RAW_ACTION | BA_* type << 8 | host id: see blue_decode
 CC4_HD Act blue_decode(const EnvState* s, int b, int idx) {
   Act a; a.type = BA_SLEEP; a.host = 0; a.arg = 0; a.ticks = 1; a.sid = 0; a.busy = 0;
   int nsub = blue_nsub(b), nh = ZONE_HOSTS * nsub, nc = 8 * nsub;
   int total = 4 * nh + 2 + 2 * nc;
+  if (idx >= BLUE_RAW_ACTION) {
+    // a host action given as (type, host id) instead of a slot of the wrapper's list: what CybORG.step / parallel_step forward
+    // when they are handed an Action OBJECT (env.py:95-161) -- the list has no slot for a zone's router, the simulator takes one
+    // (as it does from cc4BlueRandomAgent).  A host outside the agent's subnets or the episode's topology is not in its action
+    // space: InvalidAction (SimulationController.py:1068-1112), which resolves like Sleep.
+    const int t = (idx >> 8) & 0xF, h = idx & 0xFF;
+    if (t < BA_ANALYSE || t > BA_DECOY || h >= H_INTERNET || !bit_get(s->exists, h) || blue_of_subnet(h_subnet(h)) != b) return a;
+    a.type = (uint8_t)t; a.host = (uint8_t)h;
+    return a;
+  }
   if (idx < 0 || idx >= total) return a;  // padding / "no action submitted" -> Sleep
   int t, j = 0;
   if (idx < nh) { t = BA_ANALYSE; j = idx; }
@@ -1069,11 +1081,11 @@ CC4_HD void blue_monitor(Ctx x, int b) {
     for (int sl = 0; sl < SLOTS; ++sl) {
       int h = h_make(sn, sl);
       if (!bit_get(s->exists, h)) continue;
-      uint8_t ev = x.hd[h].ev;
+      uint8_t ev = s->hev[h];
       uint8_t nev = 0;
       if (ev & EV_CUR_CONN) nev |= EV_OLD_CONN;
       if (ev & EV_CUR_PROC) nev |= EV_OLD_PROC;
-      x.hd[h].ev = nev;
+      s->hev[h] = nev;
     }
   }
   // session.add_sus_pids for process_creation events that carry a pid
@@ -2369,9 +2381,9 @@ CC4_HD uint8_t monitor_roll(int h, uint8_t ev) {
 CC4_HD int step_monitor_host(Ctx x, int h) {  // returns the host's event bits afterwards
   EnvState* s = x.s;
   if (!bit_get(s->exists, h)) return 0;                     // rows of hosts that do not exist stay zero
-  const uint8_t ev = x.hd[h].ev;
+  const uint8_t ev = s->hev[h];
   const uint8_t nev = monitor_roll(h, ev);
-  if (nev != ev) x.hd[h].ev = nev;
+  if (nev != ev) s->hev[h] = nev;
   return nev;
 }
 CC4_HD void step_monitor_pend(Ctx x) {  // session.add_sus_pids for the pid-carrying process_creation events
@@ -2449,7 +2461,7 @@ CC4_HD void env_step(Ctx x, const int32_t* actions, const uint8_t* messages /* [
 // phase word + 32 message bits.  The device encodes the parts on separate lanes; the host loops over them.
 enum : int { OBS_PARTS = 12 };
 template <typename T>
-CC4_HD void env_flat_obs_part(const EnvState* s, const HostDyn* hd, T* out, int part) {
+CC4_HD void env_flat_obs_part(const EnvState* s, T* out, int part) {
   if (part < 7) {
     int b = part < 4 ? part : 4, i = part < 4 ? 0 : part - 4;
     int o = (b < 4 ? b * OBS_SHORT : 4 * OBS_SHORT) + 1 + 59 * i;
@@ -2464,7 +2476,7 @@ CC4_HD void env_flat_obs_part(const EnvState* s, const HostDyn* hd, T* out, int 
     }
     for (int hs = 0; hs < ZONE_HOSTS; ++hs) {
       int h = hs < MAX_SERVERS ? h_make(sn, 11 + hs) : h_make(sn, 1 + (hs - MAX_SERVERS));
-      int ev = bit_get(s->exists, h) ? hd[h].ev : 0;
+      int ev = bit_get(s->exists, h) ? s->hev[h] : 0;
       out[o + 27 + hs] = (T)((ev & (EV_CUR_PROC | EV_OLD_PROC)) != 0);
       out[o + 43 + hs] = (T)((ev & (EV_CUR_CONN | EV_OLD_CONN)) != 0);
     }
@@ -2478,7 +2490,7 @@ CC4_HD void env_flat_obs_part(const EnvState* s, const HostDyn* hd, T* out, int 
   }
 }
 // the same vector, one value at a time (value `idx` of the 578): what the device encodes with one value per thread
-CC4_HD int env_flat_obs_at(const EnvState* s, const HostDyn* hd, int idx) {
+CC4_HD int env_flat_obs_at(const EnvState* s, int idx) {
   const int b = idx < 4 * OBS_SHORT ? idx / OBS_SHORT : 4;
   const int j = idx - (b < 4 ? b * OBS_SHORT : 4 * OBS_SHORT);
   const int len = b < 4 ? OBS_SHORT : OBS_LONG;
@@ -2494,7 +2506,7 @@ CC4_HD int env_flat_obs_at(const EnvState* s, const HostDyn* hd, int idx) {
   if (k < 27) return !((comms_adjacent(s->phase, sn) >> sorted_subnet(k - 18)) & 1u);
   const int hs = k < 43 ? k - 27 : k - 43;
   const int h = hs < MAX_SERVERS ? h_make(sn, 11 + hs) : h_make(sn, 1 + (hs - MAX_SERVERS));
-  const int ev = hd[h].ev;   // rows of hosts that do not exist stay zero (env_reset), so no existence test is needed
+  const int ev = s->hev[h];   // bytes of hosts that do not exist stay zero (env_reset), so no existence test is needed
   return k < 43 ? ((ev & (EV_CUR_PROC | EV_OLD_PROC)) != 0) : ((ev & (EV_CUR_CONN | EV_OLD_CONN)) != 0);
 }
 // The same 578 values enumerated kind by kind (v = 0..577), so that the lanes of a wave take the same branch, the values that
@@ -2503,8 +2515,7 @@ CC4_HD int env_flat_obs_at(const EnvState* s, const HostDyn* hd, int idx) {
 //   [384,447) blocked bits, [447,510) comms policy, [510,573) subnet one-hot, [573,578) the 5 phase words (EnvState.obs_dirty).
 // *idx = position in the vector.
 enum : int { OBS_FAST = 384 };
-// evb: the hosts' event bytes when the caller holds a copy of them (the numpy-stream kernel, whose host table is in HBM)
-CC4_HD int env_flat_obs_sorted(const EnvState* s, const HostDyn* hd, int v, int* idx, const uint8_t* evb = nullptr) {
+CC4_HD int env_flat_obs_sorted(const EnvState* s, int v, int* idx) {
   if (v >= 224 && v < OBS_FAST) {
     const int w = v - 224, b = w >> 5, m = w & 31, jj = m / MSG_LEN;
     *idx = (b < 4 ? b * OBS_SHORT + OBS_SHORT : 4 * OBS_SHORT + OBS_LONG) - 32 + m;
@@ -2520,7 +2531,7 @@ CC4_HD int env_flat_obs_sorted(const EnvState* s, const HostDyn* hd, int v, int*
     if (k >= 27) {
       const int hs = k < 43 ? k - 27 : k - 43;
       const int h = hs < MAX_SERVERS ? h_make(sn, 11 + hs) : h_make(sn, 1 + (hs - MAX_SERVERS));
-      const int ev = evb ? evb[h] : hd[h].ev;   // rows of hosts that do not exist stay zero (env_reset)
+      const int ev = s->hev[h];   // bytes of hosts that do not exist stay zero (env_reset)
       return k < 43 ? ((ev & (EV_CUR_PROC | EV_OLD_PROC)) != 0) : ((ev & (EV_CUR_CONN | EV_OLD_CONN)) != 0);
     }
     if (k < 9) return sorted_subnet(k) == sn;
@@ -2533,7 +2544,7 @@ CC4_HD int env_flat_obs_sorted(const EnvState* s, const HostDyn* hd, int v, int*
 }
 // The OBS_FAST values as a table (the device kernels read it instead of redoing the index arithmetic for every value of every
 // step): entry v = position in the vector | source byte << 10 | bit mask << 18; the value is (byte & mask) != 0.  Source byte
-// 0..136: the event bits of host h; 137 + 8 j + i: message bit i of blue agent j (EnvState.msg[j][i]).  Same enumeration as
+// 0..136: the event bits of host h (EnvState.hev); 137 + 8 j + i: message bit i of blue agent j (EnvState.msg[j][i]).  Same enumeration as
 // env_flat_obs_sorted (tests/test_host_logic.py checks the two against each other).
 CC4_HD uint32_t obs_fast_entry(int v) {
   if (v >= 224) {
@@ -2551,14 +2562,14 @@ CC4_HD uint32_t obs_fast_entry(int v) {
   const uint32_t mask = k < 43 ? (uint32_t)(EV_CUR_PROC | EV_OLD_PROC) : (uint32_t)(EV_CUR_CONN | EV_OLD_CONN);
   return (uint32_t)idx | ((uint32_t)h << 10) | (mask << 18);
 }
-CC4_HD int obs_fast_value(uint32_t entry, const EnvState* s, const HostDyn* hd, const uint8_t* evb) {
+CC4_HD int obs_fast_value(uint32_t entry, const EnvState* s) {
   const int src = (int)((entry >> 10) & 0xFF);
-  const uint32_t byte = src < MAXH ? (evb ? evb[src] : hd[src].ev) : (&s->msg[0][0])[src - MAXH];
+  const uint32_t byte = src < MAXH ? s->hev[src] : (&s->msg[0][0])[src - MAXH];
   return (byte & (entry >> 18)) != 0 ? 1 : 0;
 }
 template <typename T>
-CC4_HD void env_flat_obs(const EnvState* s, const HostDyn* hd, T* out) {
-  for (int p = 0; p < OBS_PARTS; ++p) env_flat_obs_part<T>(s, hd, out, p);
+CC4_HD void env_flat_obs(const EnvState* s, T* out) {
+  for (int p = 0; p < OBS_PARTS; ++p) env_flat_obs_part<T>(s, out, p);
 }
 
 }  // namespace cc4

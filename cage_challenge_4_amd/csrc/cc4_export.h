@@ -61,7 +61,7 @@ inline std::string export_true_state(const EnvState& s, const EnvCold& cold, boo
     o += "],\"svcs\":[";
     for (int i = 0; i < hd_nsvc(d); ++i)
       add("%s[%u,%u,%u,%u]", i ? "," : "", (unsigned)d.svcs[i].kind, (unsigned)((d.svcs[i].st & SV_ACTIVE) ? 1 : 0), (unsigned)(d.svcs[i].st & 0x7F) * 20u, (unsigned)d.svcs[i].pid);
-    add("],\"ev\":%u,\"files\":%u,\"blue\":%u,\"green\":%u}", (unsigned)d.ev, (unsigned)hd_files(d), blue_pid, green_pid);
+    add("],\"ev\":%u,\"files\":%u,\"blue\":%u,\"green\":%u}", (unsigned)s.hev[h], (unsigned)hd_files(d), blue_pid, green_pid);
   }
   o += "],\"red\":[";
   for (int r = 0; r < NRED; ++r) {

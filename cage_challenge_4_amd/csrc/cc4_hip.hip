@@ -111,18 +111,24 @@ __device__ __forceinline__ uint8_t pack_obs_byte(const uint8_t* vals, int j) {
 // walk (rng_below / rng_interval in cc4_rng.h), including has_uint32 / uinteger buffering and the advance counter.
 __device__ uint32_t g_obs_fast[OBS_FAST];          // obs_fast_entry(v) for v = 0 .. OBS_FAST-1 (cc4_engine.h), filled by cc4_create
 // The observation values that can change with every step, from the table: position, source byte and mask come with one load
-// instead of a dozen divisions per value.  evb: the hosts' event bytes when the host table is not in LDS (null: read hd[h].ev).
+// instead of a dozen divisions per value.
 template <int nt>
-__device__ __forceinline__ void encode_obs_fast(const EnvState* s, const HostDyn* hd, const uint8_t* evb, int32_t* o, uint8_t* obs_bytes, bool pack, int t) {
+__device__ __forceinline__ void encode_obs_fast(const EnvState* s, int32_t* o, uint8_t* obs_bytes, bool pack, int t) {
   constexpr int NV = (OBS_FAST + nt - 1) / nt;
   uint32_t ent[NV];
 #pragma unroll
+#ifdef CC4_OBS_TABLE
   for (int k = 0; k < NV; ++k) { const int v = t + k * nt; ent[k] = v < OBS_FAST ? g_obs_fast[v] : 0u; }
+#else
+  // computed, not loaded: the kernels wait on memory, not on the vector unit (r03 A/B: the table form of this loop -- one L2 load
+  // per value instead of a dozen shifts and multiplies -- made the encode phase longer: 5.5k -> 6.9k cycles at 8192 episodes)
+  for (int k = 0; k < NV; ++k) { const int v = t + k * nt; ent[k] = v < OBS_FAST ? obs_fast_entry(v) : 0u; }
+#endif
 #pragma unroll
   for (int k = 0; k < NV; ++k) {
     const int v = t + k * nt;
     if (v >= OBS_FAST) continue;
-    const int val = obs_fast_value(ent[k], s, hd, evb);
+    const int val = obs_fast_value(ent[k], s);
     const int i = (int)(ent[k] & 0x3FF);
     o[i] = val;
     if (pack) obs_bytes[i] = (uint8_t)val;
@@ -473,9 +479,8 @@ __global__ __launch_bounds__(WAVE) void k_step(StepArgs a) {
   // the hosts' event bits (what the observation encode reads) and the encoded observation
   __shared__ uint64_t win_lds[GW_OUT];
   constexpr int OBS_LDS = (OBS_TOTAL + 2 + 7) & ~7;
-  static_assert(OBS_LDS + MAXH + 3 <= (int)sizeof(uint64_t) * GW_OUT, "observation + event bytes fit the window area");
+  static_assert(OBS_LDS <= (int)sizeof(uint64_t) * GW_OUT, "the byte copy of the observation fits the window area");
   uint8_t* const obs_lds = reinterpret_cast<uint8_t*>(win_lds);
-  uint8_t* const ev_lds = obs_lds + OBS_LDS;
   __shared__ int ok_lds;
   __shared__ StepWork work;
   const int e = a.e0 + (int)blockIdx.x, lane = threadIdx.x;
@@ -574,22 +579,8 @@ __global__ __launch_bounds__(WAVE) void k_step(StepArgs a) {
   }
   __syncthreads();
   if (ok_lds) {
-    {
-      // end-turn Monitor roll-over; the host table is in HBM here: all of a lane's event bytes are requested before the first
-      // one is rolled (a plain loop waits for each round trip in turn behind the store of the previous host)
-      constexpr int NK = (MAXH + WAVE - 1) / WAVE;
-      uint8_t evv[NK];
-#pragma unroll
-      for (int k = 0; k < NK; ++k) { const int h = lane + k * WAVE; evv[k] = (h < MAXH && bit_get(s->exists, h)) ? hd[h].ev : (uint8_t)0; }
-#pragma unroll
-      for (int k = 0; k < NK; ++k) {
-        const int h = lane + k * WAVE;
-        if (h >= MAXH) continue;
-        const uint8_t nev = bit_get(s->exists, h) ? monitor_roll(h, evv[k]) : (uint8_t)0;
-        if (nev != evv[k]) hd[h].ev = nev;
-        ev_lds[h] = nev;
-      }
-    }
+    // end-turn Monitor roll-over: the hosts' event bytes are part of the staged row (EnvState.hev)
+    for (int h = lane; h < MAXH; h += WAVE) s->hev[h] = monitor_roll(h, s->hev[h]);
     if (lane == 0) step_monitor_pend(x);
     __syncthreads();
     {
@@ -610,7 +601,6 @@ __global__ __launch_bounds__(WAVE) void k_step(StepArgs a) {
   }
   if (lane == 0) { s->rng = rl; a.reward[e] = s->reward; a.done[e] = s->done; a.err[e] = s->err; }
   unsigned long long t_obs = a.prof ? clock64() : 0;
-  if (!ok_lds) { for (int h = lane; h < MAXH; h += WAVE) ev_lds[h] = hd[h].ev; __syncthreads(); }   // after a reset / a refused step
   {
     // straight to HBM, kind-sorted (uniform branches); the output buffer persists between steps, so the values that only a
     // Block/Allow or a new mission phase changes are written when that happened (EnvState.obs_dirty), after a reset, or when the
@@ -618,8 +608,8 @@ __global__ __launch_bounds__(WAVE) void k_step(StepArgs a) {
     int32_t* o = a.obs + (size_t)e * OBS_TOTAL;
     const bool pack = a.obs8 != nullptr;
     const int nv = (do_reset || a.full_obs || pack || s->obs_dirty) ? OBS_TOTAL : OBS_FAST;
-    encode_obs_fast<WAVE>(s, hd, ev_lds, o, obs_lds, pack, lane);
-    for (int v = OBS_FAST + lane; v < nv; v += WAVE) { int i; const int val = env_flat_obs_sorted(s, hd, v, &i, ev_lds); o[i] = val; if (pack) obs_lds[i] = (uint8_t)val; }
+    encode_obs_fast<WAVE>(s, o, obs_lds, pack, lane);
+    for (int v = OBS_FAST + lane; v < nv; v += WAVE) { int i; const int val = env_flat_obs_sorted(s, v, &i); o[i] = val; if (pack) obs_lds[i] = (uint8_t)val; }
   }
   __syncthreads();
   unsigned long long t_out = a.prof ? clock64() : 0;
@@ -783,6 +773,19 @@ __global__ __launch_bounds__(PT, MINW) void k_step_philox(StepArgs a) {
       const int ragent = lane * RW + wave;
       const bool is_red = wave < RW && lane < (NRED + RW - 1) / RW && ragent < NRED;
       unsigned long long* ap = (a.prof && is_red) ? a.prof + PROF_SLOTS * (size_t)e + 16 + 8 * ragent : nullptr;
+      // The red actions and the RedSessionChecks run in phases in which all four waves are free: agent r on wave r % 4, lane
+      // r / 4 (two waves carry two agents, two carry one).  Measured on MI355X (r03, three launches per step; M agent-env steps/s
+      // with the agents on 2 / 3 / 4 waves in these phases): 1024 episodes 177.4 / 179.3 / 180.8, 2048: 297.2 / 309.1 / 312.1,
+      // 4096: 440 / 444 / 443.  (The policy phase stays on two waves, three agents side by side: its other two waves carry the
+      // blue submissions and the green draws; all four there: 176.8 / 293.3 / 426.7.)
+#ifndef CC4_RED_WAVES_EXEC
+#define CC4_RED_WAVES_EXEC 4
+#endif
+      constexpr int RWX = CC4_RED_WAVES_EXEC;
+      const int xagent = lane * RWX + wave;
+      const bool is_redx = wave < RWX && lane < (NRED + RWX - 1) / RWX && xagent < NRED;
+      unsigned long long* apx = (a.prof && is_redx) ? a.prof + PROF_SLOTS * (size_t)e + 16 + 8 * xagent : nullptr;
+      Ctx xrx{s, cold_e, &rl, hd, &work, nullptr, apx, lg};
       Ctx xr{s, cold_e, &rl, hd, &work, nullptr, ap, lg};
       // ---- P0-P3a: every agent's policy / submission followed by its own duration-queue tick (SC:236-265), all on the
       // agent's thread: red r on wave r%PW lane r/PW, blue on wave PW-1 lanes 2..6, green draws on lanes >= 8 of the waves
@@ -805,8 +808,8 @@ __global__ __launch_bounds__(PT, MINW) void k_step_philox(StepArgs a) {
         // block 0 of the agent's action stream, for the lane that will resolve the action
         { uint32_t c[4]; rng_block(&rl, ST_BLUE_EXE + (uint32_t)b, 0, c); reinterpret_cast<uint4*>(reset_ws)[MAXG + NRED + b] = make_uint4(c[0], c[1], c[2], c[3]); }
       }
-      else if (wave == 2 && lane < NRED) {   // block 0 of the six red action streams, side by side on idle lanes of a wave with slack
-        uint32_t c[4]; rng_block(&rl, ST_RED_EXE + (uint32_t)lane, 0, c); reinterpret_cast<uint4*>(reset_ws)[MAXG + lane] = make_uint4(c[0], c[1], c[2], c[3]);
+      else if (wave == 2 && lane >= 1 && lane <= NRED) {   // block 0 of the six red action streams, side by side on idle lanes of a wave with slack
+        uint32_t c[4]; rng_block(&rl, ST_RED_EXE + (uint32_t)(lane - 1), 0, c); reinterpret_cast<uint4*>(reset_ws)[MAXG + lane - 1] = make_uint4(c[0], c[1], c[2], c[3]);
       }
       else if (lane >= 8 && wave >= 2) {
         static_assert(PW == 4 && MAXG <= 2 * (WAVE - 8), "every green agent has its own lane on wave 2 or 3: one pass, one ballot per type");
@@ -876,11 +879,11 @@ __global__ __launch_bounds__(PT, MINW) void k_step_philox(StepArgs a) {
       if (tid == 0) { step_phishing(x0); CC4_TICK(x0, 1); rs_reserve(x0); conflict_lds = (int)red_conflict_mask(s); if (prof && conflict_lds) prof[4] += 1000000; }
       __syncthreads();
       const uint32_t serial_red = (uint32_t)conflict_lds;
-      if (is_red && !((serial_red >> ragent) & 1u)) {
-        unsigned long long t0 = ap ? clock64() : 0;
-        const int ty = s->rexec[ragent].type;
-        { const uint4 blk = reinterpret_cast<const uint4*>(reset_ws)[MAXG + ragent]; const uint32_t pre[4] = {blk.x, blk.y, blk.z, blk.w}; step_red_exec_agent(xr, ragent, pre); }
-        if (ap) { unsigned long long dt = clock64() - t0; ap[1] += dt; unsigned long long* tp = a.prof + PROF_SLOTS * (size_t)e + 64 + 2 * (ty & 15); atomicAdd(tp, dt); atomicAdd(tp + 1, 1ull); }
+      if (is_redx && !((serial_red >> xagent) & 1u)) {
+        unsigned long long t0 = apx ? clock64() : 0;
+        const int ty = s->rexec[xagent].type;
+        { const uint4 blk = reinterpret_cast<const uint4*>(reset_ws)[MAXG + xagent]; const uint32_t pre[4] = {blk.x, blk.y, blk.z, blk.w}; step_red_exec_agent(xrx, xagent, pre); }
+        if (apx) { unsigned long long dt = clock64() - t0; apx[1] += dt; unsigned long long* tp = a.prof + PROF_SLOTS * (size_t)e + 64 + 2 * (ty & 15); atomicAdd(tp, dt); atomicAdd(tp + 1, 1ull); }
       }
       __syncthreads();
       if (serial_red) {   // same-host actions (and everything when some agent withdraws): agent order on thread 0
@@ -900,7 +903,7 @@ __global__ __launch_bounds__(PT, MINW) void k_step_philox(StepArgs a) {
       // ---- P8 end-turn RedSessionCheck (one red agent per wave), and on the last thread the Monitor's sus-pid hand-over and
       // the step's bookkeeping: disjoint data (red agent tables / blue lists, counters, reward).  The observation encode below
       // reads none of it, so there is no barrier in between.
-      if (is_red) { unsigned long long t0 = ap ? clock64() : 0; step_rsc(xr, ragent); if (ap) ap[2] += clock64() - t0; }
+      if (is_redx) { unsigned long long t0 = apx ? clock64() : 0; step_rsc(xrx, xagent); if (apx) apx[2] += clock64() - t0; }
       if (tid == PT - 1) {
         Ctx xe{s, cold_e, &rl, hd, &work, nullptr, nullptr, lg};
         step_monitor_pend(xe);
@@ -918,8 +921,8 @@ __global__ __launch_bounds__(PT, MINW) void k_step_philox(StepArgs a) {
     // the values that can change with every step (host events, messages) always; blocks, comms policy, subnet one-hots and phase
     // words only when the step changed them (EnvState.obs_dirty), after a reset, or when the caller asks (the buffer persists)
     const int nv = (do_reset || a.full_obs || pack || s->obs_dirty) ? OBS_TOTAL : OBS_FAST;
-    encode_obs_fast<PT>(s, hd, nullptr, o, obs_bytes, pack, tid);
-    for (int v = OBS_FAST + tid; v < nv; v += PT) { int i; int val = env_flat_obs_sorted(s, hd, v, &i); o[i] = val; if (pack) obs_bytes[i] = (uint8_t)val; }   // kind-sorted enumeration: uniform branches per wave
+    encode_obs_fast<PT>(s, o, obs_bytes, pack, tid);
+    for (int v = OBS_FAST + tid; v < nv; v += PT) { int i; int val = env_flat_obs_sorted(s, v, &i); o[i] = val; if (pack) obs_bytes[i] = (uint8_t)val; }   // kind-sorted enumeration: uniform branches per wave
   }
   __syncthreads();    // the row is final: RedSessionCheck and the step bookkeeping ran beside the encode
   if (tid == 0) a.err[e] = s->err;
@@ -947,7 +950,6 @@ __global__ __launch_bounds__(WAVE) void k_step_philox1(StepArgs a) {
   // byte copy of the observations, only for the packed exchange row; the debug phase timers borrow the area (a profiled handle
   // has no communicator): with it, agent part + statics fit 8 KB and 20 episodes are resident per CU
   __shared__ alignas(8) uint8_t obs_bytes[(OBS_TOTAL + 2 + 7) & ~7];
-  __shared__ uint8_t ev_lds[MAXH + 3];           // the hosts' event bytes after the end-turn roll-over: what the observation encode reads
   __shared__ StepWork work;
   __shared__ int conflict_lds;
   unsigned long long* const prof_lds = reinterpret_cast<unsigned long long*>(obs_bytes);
@@ -967,7 +969,6 @@ __global__ __launch_bounds__(WAVE) void k_step_philox1(StepArgs a) {
   HostDyn* const hd = a.st[e].hd;                   // the host table stays in HBM / L2
   if (prof && lane == 0) prof[11] += clock64() - t_begin;
   const bool do_reset = a.autoreset && s->done;
-  bool rolled = false;                              // ev_lds holds the event bytes (the end-turn roll-over ran)
   if (do_reset) {
     // new episode on the same key (CybORG.reset(seed=None)): the phases of env_reset_counter_mode, hosts on lanes; the pid
     // bitmaps of the generation live in HBM here (LDS bounds this kernel's residency, and this path runs once per episode)
@@ -1116,23 +1117,9 @@ __global__ __launch_bounds__(WAVE) void k_step_philox1(StepArgs a) {
         step_reassign(x0, red_foreign_agents(s));
         CC4_TICK(x0, 8);
       }
-      {
-        // P7 end-turn Monitor roll-over; the host table is in HBM here: all of a lane's event bytes are requested before the
-        // first one is rolled
-        constexpr int NK = (MAXH + WAVE - 1) / WAVE;
-        uint8_t evv[NK];
-#pragma unroll
-        for (int k = 0; k < NK; ++k) { const int h = lane + k * WAVE; evv[k] = (h < MAXH && bit_get(s->exists, h)) ? hd[h].ev : (uint8_t)0; }
-#pragma unroll
-        for (int k = 0; k < NK; ++k) {
-          const int h = lane + k * WAVE;
-          if (h >= MAXH) continue;
-          const uint8_t nev = bit_get(s->exists, h) ? monitor_roll(h, evv[k]) : (uint8_t)0;
-          if (nev != evv[k]) hd[h].ev = nev;
-          ev_lds[h] = nev;
-        }
-        rolled = true;
-      }
+      // P7 end-turn Monitor roll-over: the hosts' event bytes are part of the staged row (EnvState.hev).  (Lane 0's reassignment above
+      // moves sessions, not events.)
+      for (int h = lane; h < MAXH; h += WAVE) s->hev[h] = monitor_roll(h, s->hev[h]);
       __syncthreads();
       CC4_TICK(x0, 9);
       // ---- P8 end-turn RedSessionCheck on the red lanes; the Monitor's sus-pid hand-over and the step's bookkeeping on the last
@@ -1147,13 +1134,12 @@ __global__ __launch_bounds__(WAVE) void k_step_philox1(StepArgs a) {
   }
   __syncthreads();
   unsigned long long t_obs = a.prof ? clock64() : 0;
-  if (!rolled) { for (int h = lane; h < MAXH; h += WAVE) ev_lds[h] = hd[h].ev; __syncthreads(); }   // after a reset / a refused step
   {
     int32_t* o = a.obs + (size_t)e * OBS_TOTAL;
     const bool pack = a.obs8 != nullptr;
     const int nv = (do_reset || a.full_obs || pack || s->obs_dirty) ? OBS_TOTAL : OBS_FAST;
-    encode_obs_fast<WAVE>(s, hd, ev_lds, o, obs_bytes, pack, lane);
-    for (int v = OBS_FAST + lane; v < nv; v += WAVE) { int i; const int val = env_flat_obs_sorted(s, hd, v, &i, ev_lds); o[i] = val; if (pack) obs_bytes[i] = (uint8_t)val; }
+    encode_obs_fast<WAVE>(s, o, obs_bytes, pack, lane);
+    for (int v = OBS_FAST + lane; v < nv; v += WAVE) { int i; const int val = env_flat_obs_sorted(s, v, &i); o[i] = val; if (pack) obs_bytes[i] = (uint8_t)val; }
   }
   __syncthreads();
   if (lane == 0) a.err[e] = s->err;
@@ -1211,7 +1197,7 @@ __global__ __launch_bounds__(WAVE) void k_reset(ResetArgs a) {
     env_reset(x, a.seeds ? a.seeds[e] : 0, 0, a.steps, a.seeds == nullptr, a.policy, a.topo);
   }
   if (lane == 0) {
-    env_flat_obs<uint8_t>(s, hd, obs_lds);
+    env_flat_obs<uint8_t>(s, obs_lds);
     blue_action_mask(s, mask_lds);
     a.reward[e] = 0.f; a.done[e] = s->done; a.err[e] = s->err;
   }
@@ -1230,6 +1216,12 @@ __global__ void k_random_actions(int32_t* actions, int n, uint64_t seed0, uint32
   if (i >= n * NBLUE) return;
   int e = i / NBLUE, b = i % NBLUE;
   actions[i] = random_blue_action(seed0, t, e, b);
+}
+
+// debug: keeps a stream busy for about `cycles` clock ticks (cc4_debug_comm_delay_us: a slow exchange on demand)
+__global__ void k_spin(long long cycles) {
+  const long long t0 = wall_clock64();
+  while (wall_clock64() - t0 < cycles) __builtin_amdgcn_s_sleep(32);
 }
 
 // one block per gathered row: 148 packed bytes -> 578 byte values (thread j unpacks byte j into values 4j .. 4j+3)
@@ -1293,6 +1285,7 @@ struct cc4_handle {
   uint8_t* d_all_obs8[OBS_RING] = {};
   long long gather_seq[OBS_RING] = {};           // sequence number of the last all-gather that read buffer b (0 = none)
   long long gathers_issued = 0, gathers_waited = 0;
+  long long comm_delay_ticks = 0;                // debug: spin this long on the communication stream ahead of every all-gather
   long long gather_stalls = 0;                   // a step launch found the all-gather it had to wait for still running
   long long stat_steps = 0; double stat_launch_us = 0, stat_gather_us = 0;   // cc4_host_stats
   hipStream_t comm_stream = nullptr;
@@ -1893,6 +1886,7 @@ int cc4_allgather_obs(cc4_handle* h, uint8_t** d_all_obs8) {
   } else {
     for (int g = 0; g < h->ngroups; ++g) HIPCHK(h, hipStreamWaitEvent(h->comm_stream, h->ev_step[buf][g], 0));
   }
+  if (h->comm_delay_ticks > 0) { hipLaunchKernelGGL(k_spin, dim3(1), dim3(1), 0, h->comm_stream, h->comm_delay_ticks); HIPCHK(h, hipGetLastError()); }
   size_t cnt = (size_t)h->cfg.num_envs * OBS_PACKED;
   ncclResult_t r = ncclAllGather(h->d_obs8[buf], h->d_all_obs8[buf], cnt, ncclUint8, h->comm, h->comm_stream);
   if (r != ncclSuccess) { h->err = std::string("ncclAllGather: ") + ncclGetErrorString(r); return -1; }
@@ -1901,6 +1895,16 @@ int cc4_allgather_obs(cc4_handle* h, uint8_t** d_all_obs8) {
   h->gather_buf = buf;
   HIPCHK(h, hipEventRecord(h->ev_comm[q % cc4_handle::OBS_RING], h->comm_stream));
   if (d_all_obs8) *d_all_obs8 = h->d_all_obs8[buf];
+  return 0;
+}
+// debug / test hook: every all-gather is preceded by a kernel that keeps the communication stream busy for about `us`
+// microseconds -- an exchange slower than the step, which is what makes the observation ring's reuse guard work for its living
+int cc4_debug_comm_delay_us(cc4_handle* h, int us) {
+  HIPCHK(h, hipSetDevice(h->cfg.device_id));
+  int khz = 100000;   // wall_clock64 ticks at the constant 100 MHz reference clock
+  (void)hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, h->cfg.device_id);
+  if (khz <= 0) khz = 100000;
+  h->comm_delay_ticks = (long long)us * khz / 1000;
   return 0;
 }
 int cc4_allgather_wait(cc4_handle* h) {

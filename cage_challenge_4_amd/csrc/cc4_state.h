@@ -78,7 +78,8 @@ struct alignas(16) HostDyn {        // 64 bytes = four 16-byte vectors
   Proc procs[PIN];                  // entries 0 .. PIN-1 of Host.processes; the rest in the cold row (cold_povf)
   Svc svcs[MAXSV];
   uint16_t nproc;                   // length of the whole list (hot + cold part)
-  uint8_t ev;                       // EV_* bits (byte 2 of the aligned word: ev_or)
+  uint8_t gtmp;                     // scratch of the scenario generation (OS distribution, contested-pid marks); 0 outside a reset.
+                                    // (The host's event bits live in EnvState.hev: they change every step, this row does not.)
   uint8_t nsf;                      // low nibble: number of services; high nibble: HF_* bits
 };
 static_assert(sizeof(HostDyn) == 64, "HostDyn is four 16-byte vectors");
@@ -203,6 +204,11 @@ struct alignas(16) EnvState {
   BlueAgent blue[NBLUE];
   RSess spool[RS_POOL];              // red session records of all six agents
   RedAgent red[NRED];
+  // HostEvents of every host as EV_* bits (network_connections / process_creation of this step, and of the last one after the
+  // end-turn Monitor rolled them over).  Every step raises a few dozen of them (ev_or), the Monitor rolls all 137 and the
+  // observation encode reads all 137 -- in the part of the row that is staged in LDS, these are LDS operations; while they were a
+  // byte of each HostDyn row, the kernels that leave the host table in HBM touched all 137 rows every step for them.
+  alignas(4) uint8_t hev[MAXH + 7];
   alignas(16) HostDyn hd[MAXH];      // last member: the numpy-stream kernel stages only the part in front of it
 };
 static_assert(offsetof(EnvState, hd) % 16 == 0 && sizeof(EnvState) == offsetof(EnvState, hd) + sizeof(HostDyn) * MAXH, "the host table closes the row");

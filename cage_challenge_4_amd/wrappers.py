@@ -161,8 +161,10 @@ class CybORG:
             b = self.agents_blue.index(a)
             labels = self._action_labels()[a]['labels']
             idx = A.action_index(v, labels)
-            idx = range(len(labels))[idx]                   # list semantics: a negative index counts from the end, out of range raises IndexError
-            acts[0, b] = idx if idx < (242 if b == 4 else 82) else labels.index('Sleep')   # an explicit Sleep, not "no action" (-1)
+            if idx < A.BLUE_RAW_ACTION:                     # (an action object naming a router comes back as a (type, host) code)
+                idx = range(len(labels))[idx]               # list semantics: a negative index counts from the end, out of range raises IndexError
+                idx = idx if idx < (242 if b == 4 else 82) else labels.index('Sleep')   # an explicit Sleep, not "no action" (-1)
+            acts[0, b] = idx
         msg = np.zeros((1, 5, MESSAGE_LENGTH), np.uint8)
         for b, a in enumerate(self.agents_blue):
             m = np.asarray((messages or {}).get(a, EMPTY_MESSAGE)).astype(bool)
@@ -401,6 +403,9 @@ class BlueFixedActionWrapper:
             # an index into the agent's action list (Python list semantics: negative counts from the end, out of range raises
             # IndexError), or an action object, which the reference forwards as it is (BlueFixedActionWrapper.py:142-148)
             v = A.action_index(v, labels)
+            if v >= A.BLUE_RAW_ACTION:                      # an action object naming a zone router: (type, host id) code
+                acts[0, b] = v
+                continue
             v = range(len(labels))[v]
             # a padded slot ('[Padding] Sleep') is an explicit Sleep() submitted by the agent (BlueFixedActionWrapper.py:142-148,
             # 320-332) -- never -1, which means "no action submitted" and hands the agent to the scenario's built-in blue policy

@@ -114,7 +114,7 @@ void cc4o_step_batch(void* h, const int32_t* actions /* [n][5] or null */, const
       was_reset = true;
     } else env_step(x, actions ? actions + 5 * i : nullptr, msgs ? msgs + 5 * MSG_LEN * i : nullptr);
     const EnvState* s = &o->st[i];
-    env_flat_obs<int32_t>(s, s->hd, obs + (size_t)OBS_TOTAL * i);
+    env_flat_obs<int32_t>(s, obs + (size_t)OBS_TOTAL * i);
     rew[i] = was_reset ? 0.f : s->reward; done[i] = s->done; err[i] = s->err;
   }
 }
@@ -146,20 +146,18 @@ void cc4o_topology(void* h, int i, uint8_t* out) {
   for (int k = 0; k < NSUB; ++k) { out[k] = s.cidr_octet[k]; out[9 + k] = s.n_users[k]; out[18 + k] = s.n_servers[k]; }
   for (int k = 0; k < MAXH; ++k) { out[27 + 2 * k] = bit_get(s.exists, k) ? 1 : 0; out[28 + 2 * k] = o->cold(i)->hs[k].ip_octet; }
 }
-void cc4o_obs(void* h, int i, int32_t* out) { const EnvState* s = &((Oracle*)h)->st[i]; env_flat_obs<int32_t>(s, s->hd, out); }
+void cc4o_obs(void* h, int i, int32_t* out) { const EnvState* s = &((Oracle*)h)->st[i]; env_flat_obs<int32_t>(s, out); }
 // the two per-value enumerations of the same vector (by position / by kind), for the host-logic test
 void cc4o_obs_variants(void* h, int i, int32_t* by_pos, int32_t* by_kind) {
   const EnvState* s = &((Oracle*)h)->st[i];
-  for (int k = 0; k < OBS_TOTAL; ++k) by_pos[k] = env_flat_obs_at(s, s->hd, k);
-  for (int v = 0; v < OBS_TOTAL; ++v) { int idx = -1; int val = env_flat_obs_sorted(s, s->hd, v, &idx); by_kind[idx] = val; }
+  for (int k = 0; k < OBS_TOTAL; ++k) by_pos[k] = env_flat_obs_at(s, k);
+  for (int v = 0; v < OBS_TOTAL; ++v) { int idx = -1; int val = env_flat_obs_sorted(s, v, &idx); by_kind[idx] = val; }
 }
 // the table form of the fast part (obs_fast_entry / obs_fast_value: what the device kernels encode from), values beyond OBS_FAST = -1
 void cc4o_obs_by_table(void* h, int i, int32_t* out) {
   const EnvState* s = &((Oracle*)h)->st[i];
   for (int k = 0; k < OBS_TOTAL; ++k) out[k] = -1;
-  uint8_t evb[MAXH];
-  for (int k = 0; k < MAXH; ++k) evb[k] = s->hd[k].ev;
-  for (int v = 0; v < OBS_FAST; ++v) { const uint32_t e = obs_fast_entry(v); out[e & 0x3FF] = obs_fast_value(e, s, s->hd, (v & 1) ? evb : nullptr); }
+  for (int v = 0; v < OBS_FAST; ++v) { const uint32_t e = obs_fast_entry(v); out[e & 0x3FF] = obs_fast_value(e, s); }
 }
 float cc4o_reward(void* h, int i) { return ((Oracle*)h)->st[i].reward; }
 int cc4o_done(void* h, int i) { return ((Oracle*)h)->st[i].done; }
@@ -191,7 +189,7 @@ int cc4o_layout(char* buf, int cap) {
 #define F(m) n += snprintf(buf + n, cap - n, #m " %zu\n", offsetof(EnvState, m))
   F(rng); F(step_count); F(steps); F(phase); F(phase_len); F(err); F(reward); F(done); F(blocks); F(cidr_octet); F(n_users);
   F(n_servers); F(green_host); F(pend); F(npend); F(exists); F(red_hosts); F(spool_used); F(msg); F(bexec); F(rexec); F(brm);
-  F(blue); F(spool); F(red); F(hd);
+  F(blue); F(spool); F(red); F(hev); F(hd);
 #undef F
 #define G(m) n += snprintf(buf + n, cap - n, "red." #m " %zu\n", offsetof(RedAgent, m))
   G(sord); G(known_sid); G(fsm_order); G(fsm_st4); G(fsm_hn); G(as_ip); G(as_hn); G(obs);
@@ -220,7 +218,7 @@ int cc4o_dump(void* h, int i, char* buf, int cap) {
     for (int k = 0; k < d.nproc; ++k) { const Proc pr = export_proc(s, cold, hh, k); P(" (%d,%d,%d)", pr.pid, pr.kind, pr.flags & 1); }
     P(" svcs");
     for (int k = 0; k < hd_nsvc(d); ++k) P(" (%d,%d,%d,%d)", d.svcs[k].kind, (d.svcs[k].st & SV_ACTIVE) ? 1 : 0, (d.svcs[k].st & 0x7F) * 20, d.svcs[k].pid);
-    P(" ev %d%d%d%d\n", (d.ev & EV_CUR_CONN) ? 1 : 0, (d.ev & EV_CUR_PROC) ? 1 : 0, (d.ev & EV_OLD_CONN) ? 1 : 0, (d.ev & EV_OLD_PROC) ? 1 : 0);
+    { const int ev = s.hev[hh]; P(" ev %d%d%d%d\n", (ev & EV_CUR_CONN) ? 1 : 0, (ev & EV_CUR_PROC) ? 1 : 0, (ev & EV_OLD_CONN) ? 1 : 0, (ev & EV_OLD_PROC) ? 1 : 0); }
   }
   for (int r = 0; r < NRED; ++r) {
     const RedAgent& a = s.red[r];

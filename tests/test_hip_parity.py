@@ -300,6 +300,41 @@ def test_rccl_allgather_world_size_one():
     dev.close()
 
 
+@pytest.mark.parametrize('n,groups', [(768, '3'), (512, '1')])
+def test_observation_ring_survives_a_slow_exchange(n, groups, monkeypatch):
+    """VERDICT r02 #8c: the step kernels write their packed observations into a ring of 8 buffers that overlapped all-gathers read;
+    a host-side guard keeps a launch from overwriting a buffer whose all-gather has not finished.  With cc4_debug_comm_delay_us
+    every all-gather is preceded by ~150 us of idling on the communication stream -- several steps' worth -- so the guard has to
+    wait again and again (cc4_host_stats counts it), and nothing may be lost: the gathered observations after every burst of
+    steps equal the oracle's, with one launch per step and with three (episode groups on three streams)."""
+    import ctypes, os
+    os.environ.setdefault('NCCL_SOCKET_IFNAME', 'lo')
+    monkeypatch.setenv('CC4_GROUPS', groups)
+    from cage_challenge_4_amd import distributed as D
+    dev = _dev(n, steps=120, rng_mode=1, autoreset=True); dev.reset(seeds=77)
+    assert dev.launches_per_step == int(groups)
+    ident = (ctypes.c_uint8 * 128)()
+    assert dev.lib.cc4_comm_unique_id(ident) == 0
+    dev._chk(dev.lib.cc4_comm_init(dev._h, 0, 1, ident), 'cc4_comm_init')
+    assert dev.launches_per_step == int(groups)                 # CC4_GROUPS pins the grouping through cc4_comm_init
+    dev.reset(seeds=77)
+    dev._chk(dev.lib.cc4_debug_comm_delay_us(dev._h, 150), 'cc4_debug_comm_delay_us')
+    ora = OracleVecEnv(n, steps=120, rng_mode=1, autoreset=True); ora.reset_batch(77)
+    t = 0
+    for burst in (1, 3, 9, 17, 40, 64):
+        dev.run_random_steps(77, t, burst, timed=(burst % 2 == 1))          # step + all-gather per step, nothing waits in between
+        for k in range(burst):
+            o = ora.step_batch(random_actions(77, t + k, n))
+        t += burst
+        dev._fetch()
+        assert np.array_equal(dev._obs, o[0]) and np.array_equal(dev._rew, o[1]), burst
+        assert np.array_equal(D.allgathered_obs_host(dev, 1), o[0].astype(np.uint8)), burst      # the LAST step's gather, intact
+    st = dev.host_stats()
+    assert st['gathers'] == t and st['gather_stalls'] >= 10, st      # the guard really had to wait for the slow exchange
+    dev._chk(dev.lib.cc4_debug_comm_delay_us(dev._h, 0), 'cc4_debug_comm_delay_us')
+    dev.close()
+
+
 def test_snapshot_restore_replays_identically(philox_kernel):
     """SURVEY 8(f)-4 (snapshot tooling): state + cold row of one episode captured, the episode advanced, restored and advanced
     again -> identical trajectory; the other episodes of the batch are unaffected."""

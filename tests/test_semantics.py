@@ -263,13 +263,12 @@ def test_monitor_sees_events_on_the_server_host_and_on_client_hosts(oracle_lib):
     topo = o.topology(0)
     exists = lambda h: bool(topo[27 + 2 * h])                              # noqa: E731
     blue_base, blue_size = off['blue'], off['sizeof.BlueAgent']
-    hd_size = off['sizeof.HostDyn']                                        # its last four bytes: nproc (u16), ev, nsvc | files << 4
     for b in range(4):                                                      # agents 0..3 own subnet b
         parent = int(st[blue_base + b * blue_size + 34])                   # BlueAgent.parent_host (csrc/cc4_state.h)
         assert parent // 17 == b and exists(parent)
         other = next(h for h in range(b * 17 + 1, b * 17 + 17) if exists(h) and h != parent)
         for h, bit in ((parent, 1), (other, 2)):                           # EV_CUR_CONN on one, EV_CUR_PROC on the other
-            st[off['hd'] + h * hd_size + hd_size - 2] |= bit
+            st[off['hev'] + h] |= bit                                      # EnvState.hev: one byte of EV_* bits per host
         obs = o.step(np.full((1, 5), -1, np.int32))[0][0]
         blk = obs[b * 92 + 1: b * 92 + 60]
 

@@ -2,7 +2,7 @@
 # Collects the round's profiles on the GPU box into gpurun_out/prof/ (copied to profiles/rNN_* afterwards).
 # usage: bash tools/profile_round.sh [tag]      (run through gpurun)
 set -u
-TAG=${1:-r02}
+TAG=${1:-r03}
 OUT=gpurun_out/prof
 mkdir -p $OUT
 export TMPDIR=/tmp
@@ -15,14 +15,16 @@ python tools/rocpd_summary.py stats $OUT/stats1024 $OUT/${TAG}_kernel_stats_1024
 # 2. HBM traffic: separate --pmc passes (FETCH_SIZE, WRITE_SIZE), kernel-trace only
 for N in 8192 1024; do
   rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $OUT/fetch$N -- $BENCH --total-envs $N --min-seconds 0.05 > /dev/null 2> $OUT/fetch$N.err
-  rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $OUT/write$N -- $BENCH --total-envs $N --min-seconds 0.05 > /dev/null 2> $OUT/write$N.err
-  python tools/rocpd_summary.py pmc $OUT/fetch$N $OUT/write$N k_step_philox $OUT/${TAG}_pmc_${N}env.json $N > /dev/null
+  rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $OUT/write$N -- $BENCH --total-envs $N --min-seconds 0.05 > $OUT/bench_pmc$N.json 2> $OUT/write$N.err
+  KN=$(python -c "import json,sys; d=[json.loads(l) for l in open('$OUT/bench_pmc$N.json') if l.startswith('{')][0]; print(d['roofline']['kernel'])")
+  LPS=$(python -c "import json,sys; d=[json.loads(l) for l in open('$OUT/bench_pmc$N.json') if l.startswith('{')][0]; print(d['roofline']['launches_per_step'])")
+  python tools/rocpd_summary.py pmc_step $OUT/fetch$N $OUT/write$N $KN $OUT/${TAG}_pmc.json $N $LPS > /dev/null
 done
 # 3. instruction mix / issue utilisation at 8192 episodes (separate passes)
 rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS -d $OUT/mixA -- $BENCH --min-seconds 0.05 > /dev/null 2> $OUT/mixA.err
 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU -d $OUT/mixB -- $BENCH --min-seconds 0.05 > /dev/null 2> $OUT/mixB.err
 rocprofv3 --kernel-trace --pmc SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_INSTS_BRANCH SQ_INSTS_SMEM -d $OUT/mixC -- $BENCH --min-seconds 0.05 > /dev/null 2> $OUT/mixC.err
-python tools/rocpd_summary.py counters k_step_philox $OUT/${TAG}_pmc_instruction_mix_8192env.json $OUT/mixA $OUT/mixB $OUT/mixC > /dev/null
+python tools/rocpd_summary.py counters k_step_philox1 $OUT/${TAG}_pmc_instruction_mix_8192env.json $OUT/mixA $OUT/mixB $OUT/mixC > /dev/null
 # 4. in-kernel phase cycles and launch tail
 python tools/phase_profile.py 1024 300 1 > $OUT/${TAG}_phase_cycles_philox_1024env.txt 2>&1
 python tools/phase_profile.py 8192 200 1 > $OUT/${TAG}_phase_cycles_philox_8192env.txt 2>&1
