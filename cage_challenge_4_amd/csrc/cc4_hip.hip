@@ -1016,17 +1016,17 @@ __global__ __launch_bounds__(WAVE) void k_step_philox1(StepArgs a) {
       if (lane == 0) CC4_TICK(x0, 0);
       // ---- the block bank.  A Philox block costs a wave the same ~110 vector instructions whether one lane needs it or
       // sixty-four do, and block 0 of every stream of the step is known from (key, step, episode, stream id) alone.  The streams
-      // that have a lane of their own per agent (green policy / action of agents 0..63) are computed where they are used, one
-      // pass each; the rest -- green agents 64.., the six red policies and actions, the five blue actions and, in the bench, the
-      // five in-kernel blue action draws: 49 requests, six sequential passes when each is computed by the lane that resolves its
-      // agent -- share ONE pass here, one request per lane, and reach their agents' lanes through ds_bpermute when their phase
-      // comes (bank_fetch; same words as computing them in place: rng_preload).
+      // that have a lane of their own per agent (green policy of agents 0..63, the actions of the compacted green list) are
+      // computed where they are used, one pass each; the rest -- the policy draws of green agents 64.., the six red policies and
+      // actions, the five blue actions and, in the bench, the five in-kernel blue action draws: 38 requests, five sequential
+      // passes when each is computed by the lane that resolves its agent -- share ONE pass here, one request per lane, and reach
+      // their agents' lanes through ds_bpermute when their phase comes (bank_fetch; same words as computing them in place:
+      // rng_preload).
       enum : int { BK_GPOL = 0, BK_GEXE = 16, BK_RPOL = 32, BK_REXE = 38, BK_BEXE = 44, BK_BRAND = 49, BK_END = 54 };
       uint32_t bank[4];
       {
         uint32_t st = 0;
         if (lane < BK_GEXE) st = ST_GREEN_POL + (uint32_t)(WAVE + lane - BK_GPOL);
-        else if (lane < BK_RPOL) st = ST_GREEN_EXE + (uint32_t)(WAVE + lane - BK_GEXE);
         else if (lane < BK_REXE) st = ST_RED_POL + (uint32_t)(lane - BK_RPOL);
         else if (lane < BK_BEXE) st = ST_RED_EXE + (uint32_t)(lane - BK_REXE);
         else if (lane < BK_BRAND) st = ST_BLUE_EXE + (uint32_t)(lane - BK_BEXE);
@@ -1083,14 +1083,24 @@ __global__ __launch_bounds__(WAVE) void k_step_philox1(StepArgs a) {
       }
       // ---- P4 green actions, one agent per lane
       {
+        // A third of the up to 80 agents sleeps, so the ones with an action nearly always fit the wave's 64 lanes: they are
+        // compacted (ballot + prefix count, agent order) into a list and resolved in ONE pass instead of two (the second of
+        // which had 16 lanes at most and cost the wave as much as the first).  Per-agent streams make the order immaterial.
         int pen = 0;
-        uint32_t c2[4];
-        bank_fetch(BK_GEXE, c2);                                                  // green 64 + k (lane k) <- lane BK_GEXE + k
-        if (lane < ng) {
-          uint32_t c[4]; rng_block(&rl, ST_GREEN_EXE + (uint32_t)lane, 0, c);    // ahead of the AccessService / LocalWork split: one block for all
-          pen += step_green_exec(xg, lane, c);
+        const uint32_t act0 = lane < ng ? work.green_act[lane] : 2u, act1 = lane + WAVE < ng ? work.green_act[lane + WAVE] : 2u;
+        const unsigned long long m0 = __ballot(act0 < 2u), m1 = __ballot(act1 < 2u);
+        const unsigned long long lt = (1ull << lane) - 1ull;
+        const int n0 = __popcll(m0), nact = n0 + __popcll(m1);
+        uint8_t* const glist = reinterpret_cast<uint8_t*>(work.scratch);           // the ordered sections' scratch is idle in this phase
+        static_assert(sizeof(work.scratch) >= MAXG, "the green list fits the scratch words");
+        if (act0 < 2u) glist[__popcll(m0 & lt)] = (uint8_t)lane;
+        if (act1 < 2u) glist[n0 + __popcll(m1 & lt)] = (uint8_t)(lane + WAVE);
+        __syncthreads();
+        for (int i = lane; i < nact; i += WAVE) {
+          const int g = glist[i];
+          uint32_t c[4]; rng_block(&rl, ST_GREEN_EXE + (uint32_t)g, 0, c);        // ahead of the AccessService / LocalWork split: one block for all
+          pen += step_green_exec(xg, g, c);
         }
-        if (lane + WAVE < ng) pen += step_green_exec(xg, lane + WAVE, c2);
         if (pen) atomicAdd(&s->brm, pen);
       }
       __syncthreads();
