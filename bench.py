@@ -392,7 +392,7 @@ def main():
                          'algorithmic_bytes_per_step': bytes_per_env * n_local,
                          'note': f'a step = {lps} concurrent launch(es) of {env.step_kernel} on separate streams, {n_local / lps:.0f} episodes each; '
                                  'achieved = launches_per_step x algorithmic_bytes_per_launch / launch_ms; traffic is per step too',
-                         'useful_bytes_per_launch': useful * n_local, 'useful_frac': useful * n_local / (launch_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
+                         'useful_bytes_per_step': useful * n_local, 'useful_frac': useful * n_local / (launch_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
                          'useful_note': f'live bytes only: agent part {hot} B + 64 B x {mean_hosts:.1f} existing hosts (of 137 grid positions), in and out'},
         }
         out['config']['per_rank'] = per_rank

@@ -36,6 +36,8 @@ constexpr int OBS_PACKED = CC4_OBS_PACKED_BYTES;   // every flat-observation val
 static_assert(OBS_PACKED % 4 == 0 && OBS_PACKED * 4 >= OBS_TOTAL, "packed observation row: whole words, four values per byte");
 constexpr int PROF_SLOTS = 128;   // 16 phase slots, 8 per red agent (16..63), then (cycles, count) per red action type (64..)
 
+constexpr int cc4_handle_max_groups = 8;   // cc4_handle::MAX_GROUPS
+
 struct StepArgs {
   EnvState* st; EnvCold* cold;
   const int32_t* actions; const uint8_t* msgs;
@@ -1291,6 +1293,7 @@ struct cc4_handle {
   // overlaps later steps, and the compute stream waits for the communication stream only once per OBS_WAIT_EVERY steps
   // (a cross-stream wait in front of every launch costs the stream ~10 us)
   static constexpr int OBS_RING = 8, OBS_WAIT_EVERY = 4;
+  static constexpr int MAX_GROUPS = cc4_handle_max_groups;          // launches per step (episode groups, below); CC4_GROUPS may ask for up to this many
   uint8_t* d_obs8[OBS_RING] = {};
   uint8_t* d_all_obs8[OBS_RING] = {};
   long long gather_seq[OBS_RING] = {};           // sequence number of the last all-gather that read buffer b (0 = none)
@@ -1299,7 +1302,7 @@ struct cc4_handle {
   long long gather_stalls = 0;                   // a step launch found the all-gather it had to wait for still running
   long long stat_steps = 0; double stat_launch_us = 0, stat_gather_us = 0;   // cc4_host_stats
   hipStream_t comm_stream = nullptr;
-  hipEvent_t ev_step[OBS_RING][4] = {}, ev_comm[OBS_RING] = {};   // ev_step[b][g]: group g's launch that wrote buffer b; ev_comm[q % OBS_RING]: all-gather number q has completed
+  hipEvent_t ev_step[OBS_RING][MAX_GROUPS] = {}, ev_comm[OBS_RING] = {};   // ev_step[b][g]: group g's launch that wrote buffer b; ev_comm[q % OBS_RING]: all-gather number q has completed
   int obs_buf = 0;                               // buffer written by the most recent step
   int gather_buf = -1;                           // buffer of the most recent all-gather (-1: none issued)
   bool step_event_attached = false;              // ev_step[obs_buf] was recorded by the launch of that step itself
@@ -1308,7 +1311,6 @@ struct cc4_handle {
   // one group's launch drains -- its last blocks running on a half-empty chip -- the other group's launch fills the free
   // slots, and the chip stays full across step boundaries.  Measured on MI355X (r03, 8192 episodes, counter mode): one launch
   // per step 507 M agent-env steps/s, two groups of 4096 on two streams 639 M (a single 32768-episode launch per step: 605 M).
-  static constexpr int MAX_GROUPS = 4;
   int ngroups = 1;
   int cus = 256;                                 // compute units of the device
   int glo[MAX_GROUPS + 1] = {};                  // group g = episodes [glo[g], glo[g + 1])
@@ -1331,6 +1333,43 @@ struct cc4_handle {
 };
 
 static thread_local std::string g_create_err;
+
+// The ROCm runtime multiplexes HIP streams onto GPU_MAX_HW_QUEUES hardware queues (default 4), and two streams that share a
+// queue run their kernels one after the other.  Three launches per step fit the default; a fourth stream needs more queues
+// (measured, r03 profiles/r03_hwq_sweep.txt: 8192 episodes, 3 / 4 launches per step: 715 / 445 M with 4 queues, 717 / 742 M with
+// 8).  The variable is read when the runtime initialises, so it is set when this library is loaded (never overriding the
+// user's choice) -- and whether four streams really run side by side in THIS process is measured, not assumed
+// (streams_run_concurrently): a process that initialised HIP earlier keeps three launches per step.
+__attribute__((constructor)) static void cc4_runtime_env() { setenv("GPU_MAX_HW_QUEUES", "8", 0); }
+
+__global__ void k_spin(long long cycles);
+static int streams_run_concurrently(int n) {   // 1: n kernels on n streams overlap; 0: they do not (or the probe failed)
+  static int cached[cc4_handle_max_groups + 1] = {};
+  if (n < 2 || n > cc4_handle_max_groups) return n < 2;
+  if (cached[n]) return cached[n] > 0;
+  int khz = 100000, dev = 0;
+  (void)hipGetDevice(&dev);
+  (void)hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, dev);
+  if (khz <= 0) khz = 100000;
+  const long long ticks = 400LL * khz / 1000;            // 400 us per kernel
+  hipStream_t st[cc4_handle_max_groups] = {};
+  bool ok = true;
+  for (int i = 0; i < n && ok; ++i) ok = hipStreamCreateWithFlags(&st[i], hipStreamNonBlocking) == hipSuccess;
+  double one = 0, all = 0;
+  if (ok) {
+    for (int pass = 0; pass < 2 && ok; ++pass) {           // pass 0: one stream (also warms the kernel up), pass 1: all of them
+      const int m = pass ? n : 1;
+      auto t0 = std::chrono::steady_clock::now();
+      for (int i = 0; i < m; ++i) hipLaunchKernelGGL(k_spin, dim3(1), dim3(1), 0, st[i], ticks);
+      for (int i = 0; i < m && ok; ++i) ok = hipStreamSynchronize(st[i]) == hipSuccess;
+      const double us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
+      (pass ? all : one) = us;
+    }
+  }
+  for (int i = 0; i < n; ++i) if (st[i]) (void)hipStreamDestroy(st[i]);
+  cached[n] = (ok && all < 1.5 * (one > 400.0 ? one : 400.0)) ? 1 : -1;
+  return cached[n] > 0;
+}
 
 #define HIPCHK(h, call)                                                                        \
   do {                                                                                         \
@@ -1356,6 +1395,9 @@ static void configure_groups(cc4_handle* h, int ng) {
   // four-wave kernel: one round of <= 5 blocks per CU runs the unconstrained build; else the build whose residency fills whole
   // rounds best (exactly 8 per CU -- 2048 episodes on 256 CUs -- is one round of the 8-block build)
   h->philox_minw = bpc <= 5 ? 1 : (bpc == 8 ? 8 : 7);
+  // ... and with several launches per step what counts is what they put on a CU together (r03 profiles: three launches, register
+  // budget 1 / 7 / 8: 1024 episodes 176 / 174 / 164 M, 2048: 295 / 302 / 278, 4096: 355 / 442 / 417)
+  if (ng > 1) h->philox_minw = bpc_all <= 5 ? 1 : 7;
   if (const char* v = getenv("CC4_PHILOX_MINW")) h->philox_minw = atoi(v);   // tuning override: 1, 7 or 8
   // The one-wave-per-episode build when a single launch puts more than eight episodes on a CU, or the launches of a step
   // together more than sixteen.  Measured on MI355X (M agent-env steps/s, four waves / one wave per episode; r02, one launch per
@@ -1500,6 +1542,9 @@ int cc4_create(const cc4_config* cfg, cc4_handle** out) {
     // 8192: 503 / 629 / 659, 16384: 570 / 710 / 701; numpy stream, 8192 episodes: 272 / 352 / 363.  A fourth stream halves the
     // rate (the runtime's hardware queues), so three it is.  CC4_GROUPS overrides (1 .. 4).
     int ng = cfg->num_envs >= 1024 ? 3 : (cfg->num_envs >= 512 ? 2 : 1);
+    // a fourth launch where four streams really overlap in this process (see streams_run_concurrently): 8192 episodes 717 ->
+    // 742 M, 2048: 310 -> 314 M, 1024: 179 -> 182 M
+    if (ng == 3 && streams_run_concurrently(4)) ng = 4;
     if (const char* v = getenv("CC4_GROUPS")) ng = atoi(v);
     configure_groups(h, ng);
   }
@@ -1542,7 +1587,7 @@ void cc4_destroy(cc4_handle* h) {
   for (int g = cc4_handle::MAX_GROUPS - 1; g >= 0; --g) if (h->gstream[g]) (void)hipStreamSynchronize(h->gstream[g]);
   if (h->comm_stream) (void)hipStreamSynchronize(h->comm_stream);
   if (h->comm) ncclCommDestroy(h->comm);
-  for (int b = 0; b < cc4_handle::OBS_RING; ++b) { for (int g = 0; g < 4; ++g) if (h->ev_step[b][g]) (void)hipEventDestroy(h->ev_step[b][g]); if (h->ev_comm[b]) (void)hipEventDestroy(h->ev_comm[b]); }
+  for (int b = 0; b < cc4_handle::OBS_RING; ++b) { for (int g = 0; g < cc4_handle::MAX_GROUPS; ++g) if (h->ev_step[b][g]) (void)hipEventDestroy(h->ev_step[b][g]); if (h->ev_comm[b]) (void)hipEventDestroy(h->ev_comm[b]); }
   if (h->comm_stream) (void)hipStreamDestroy(h->comm_stream);
   void* ptrs[] = {h->d_state, h->d_cold, h->d_actions, h->d_msgs, h->d_seeds, h->d_envmask, h->d_obs, h->d_reward,
                   h->d_done, h->d_err, h->d_mask, h->d_rng, h->d_reset_ws};
@@ -1856,7 +1901,7 @@ int cc4_comm_init(cc4_handle* h, int32_t rank, int32_t world, const void* id128)
     // host several times what it costs without; small shards then run into the host.  Measured on MI355X with the exchange on a
     // one-rank communicator (r03, profiles/r03_exchange_groups_world1.txt; M agent-env steps/s, 1 / 2 / 3 launches per step):
     // 1024 episodes 159 / 104 / 111, 8192: 478 / 498 / 607.
-    const int ng = h->cfg.num_envs >= 4096 ? 3 : 1;
+    const int ng = h->cfg.num_envs >= 4096 ? (h->ngroups >= 3 ? h->ngroups : 3) : 1;
     if (ng != h->ngroups) {
       if (sync_all(h)) return -1;
       const int old = h->ngroups;
