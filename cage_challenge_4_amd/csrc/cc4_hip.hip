@@ -1900,8 +1900,8 @@ int cc4_comm_init(cc4_handle* h, int32_t rank, int32_t world, const void* id128)
     // With the exchange every launch carries a completion event and the host guards the observation ring, so a launch costs the
     // host several times what it costs without; small shards then run into the host.  Measured on MI355X with the exchange on a
     // one-rank communicator (r03, profiles/r03_exchange_groups_world1.txt; M agent-env steps/s, 1 / 2 / 3 launches per step):
-    // 1024 episodes 159 / 104 / 111, 8192: 478 / 498 / 607.
-    const int ng = h->cfg.num_envs >= 4096 ? (h->ngroups >= 3 ? h->ngroups : 3) : 1;
+    // 1024 episodes 159 / 104 / 111, 2048: 242 / 179 / 220, 4096: 380 / 282 / 420, 8192: 478 / 498 / 607.
+    const int ng = h->cfg.num_envs >= 4096 ? 3 : 1;      // (8192 episodes with the exchange, 3 / 4 launches per step: 563 / 509 M)
     if (ng != h->ngroups) {
       if (sync_all(h)) return -1;
       const int old = h->ngroups;
