@@ -199,9 +199,12 @@ def load_pmc_traffic(envs, kernel, launches_per_step):
             with open(p) as f:
                 d = json.load(f)
             v = d.get(f'hbm_bytes_per_step_{envs}env')
-            if v is None or d.get(f'kernel_{envs}env') != kernel or d.get(f'launches_per_step_{envs}env') != launches_per_step:
+            if v is None or d.get(f'kernel_{envs}env') != kernel:      # never another kernel's figure
                 continue
-            return v, f'profiles/{name} (rocprofv3 --pmc passes of this bench command on {kernel}, {launches_per_step} launches per step; a committed figure, not measured in this run)'
+            # (the bytes a step moves do not depend on how many launches it is cut into: under --pmc the runtime serialises the
+            # launches and the library falls back to three per step; the same episodes, the same rows)
+            return v, (f"profiles/{name} (rocprofv3 --pmc passes of this bench command on {kernel}, {d.get(f'launches_per_step_{envs}env')} serialised launches per step; "
+                       'a committed figure, not measured in this run)')
         except Exception:
             pass
     return None, None

@@ -8,7 +8,7 @@ import os
 
 # more hardware queues than the runtime's default four, so that four step launches can run side by side (read when HIP
 # initialises; libcc4 sets the same default when it is loaded and measures whether it took effect -- csrc/cc4_hip.hip)
-os.environ.setdefault('GPU_MAX_HW_QUEUES', '8')
+os.environ.setdefault('GPU_MAX_HW_QUEUES', '16')
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('CC4_LIB') or os.path.join(_HERE, 'libcc4.so')   # CC4_LIB: another build of the same library (kernel experiments)
 

@@ -1317,6 +1317,7 @@ struct cc4_handle {
   hipStream_t gstream[MAX_GROUPS] = {};          // gstream[0] == stream
   hipEvent_t gev[MAX_GROUPS] = {};               // group stream -> main stream ordering (join_groups)
   hipEvent_t mev = nullptr;                      // main stream -> group streams ordering (fork_groups)
+  bool auto_groups = true;                       // the number of groups is the library's choice (no CC4_GROUPS)
   bool groups_busy = false;                      // a group stream other than the main one may hold unfinished step launches
   bool main_ahead = false;                       // the main stream holds work the group streams have not been ordered behind
   unsigned long long* d_prof = nullptr;
@@ -1338,37 +1339,32 @@ static thread_local std::string g_create_err;
 // queue run their kernels one after the other.  Three launches per step fit the default; a fourth stream needs more queues
 // (measured, r03 profiles/r03_hwq_sweep.txt: 8192 episodes, 3 / 4 launches per step: 715 / 445 M with 4 queues, 717 / 742 M with
 // 8).  The variable is read when the runtime initialises, so it is set when this library is loaded (never overriding the
-// user's choice) -- and whether four streams really run side by side in THIS process is measured, not assumed
-// (streams_run_concurrently): a process that initialised HIP earlier keeps three launches per step.
-__attribute__((constructor)) static void cc4_runtime_env() { setenv("GPU_MAX_HW_QUEUES", "8", 0); }
+// user's choice) -- and whether the four streams of a handle really run side by side is measured on those very streams when the
+// handle is created, not assumed (streams_run_concurrently): a process that initialised HIP earlier, or one whose other streams
+// already occupy the queues (a second handle next to a busy first one), keeps three launches per step.
+__attribute__((constructor)) static void cc4_runtime_env() { setenv("GPU_MAX_HW_QUEUES", "16", 0); }
 
 __global__ void k_spin(long long cycles);
-static int streams_run_concurrently(int n) {   // 1: n kernels on n streams overlap; 0: they do not (or the probe failed)
-  static int cached[cc4_handle_max_groups + 1] = {};
-  if (n < 2 || n > cc4_handle_max_groups) return n < 2;
-  if (cached[n]) return cached[n] > 0;
+// 1 if kernels launched on the n given streams at the same time run side by side, 0 if some of them share a hardware queue and
+// run one after the other (or the probe failed).  ~1 ms.
+static int streams_run_concurrently(hipStream_t* st, int n) {
+  if (n < 2) return 1;
   int khz = 100000, dev = 0;
   (void)hipGetDevice(&dev);
   (void)hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, dev);
   if (khz <= 0) khz = 100000;
-  const long long ticks = 400LL * khz / 1000;            // 400 us per kernel
-  hipStream_t st[cc4_handle_max_groups] = {};
+  const long long ticks = 300LL * khz / 1000;            // 300 us per kernel
   bool ok = true;
-  for (int i = 0; i < n && ok; ++i) ok = hipStreamCreateWithFlags(&st[i], hipStreamNonBlocking) == hipSuccess;
   double one = 0, all = 0;
-  if (ok) {
-    for (int pass = 0; pass < 2 && ok; ++pass) {           // pass 0: one stream (also warms the kernel up), pass 1: all of them
-      const int m = pass ? n : 1;
-      auto t0 = std::chrono::steady_clock::now();
-      for (int i = 0; i < m; ++i) hipLaunchKernelGGL(k_spin, dim3(1), dim3(1), 0, st[i], ticks);
-      for (int i = 0; i < m && ok; ++i) ok = hipStreamSynchronize(st[i]) == hipSuccess;
-      const double us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
-      (pass ? all : one) = us;
-    }
+  for (int pass = 0; pass < 2 && ok; ++pass) {             // pass 0: one stream (also warms the kernel up), pass 1: all of them
+    const int m = pass ? n : 1;
+    auto t0 = std::chrono::steady_clock::now();
+    for (int i = 0; i < m; ++i) hipLaunchKernelGGL(k_spin, dim3(1), dim3(1), 0, st[i], ticks);
+    for (int i = 0; i < m && ok; ++i) ok = hipStreamSynchronize(st[i]) == hipSuccess;
+    const double us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
+    (pass ? all : one) = us;
   }
-  for (int i = 0; i < n; ++i) if (st[i]) (void)hipStreamDestroy(st[i]);
-  cached[n] = (ok && all < 1.5 * (one > 400.0 ? one : 400.0)) ? 1 : -1;
-  return cached[n] > 0;
+  return ok && all < 1.5 * (one > 300.0 ? one : 300.0);
 }
 
 #define HIPCHK(h, call)                                                                        \
@@ -1542,9 +1538,8 @@ int cc4_create(const cc4_config* cfg, cc4_handle** out) {
     // 8192: 503 / 629 / 659, 16384: 570 / 710 / 701; numpy stream, 8192 episodes: 272 / 352 / 363.  A fourth stream halves the
     // rate (the runtime's hardware queues), so three it is.  CC4_GROUPS overrides (1 .. 4).
     int ng = cfg->num_envs >= 1024 ? 3 : (cfg->num_envs >= 512 ? 2 : 1);
-    // a fourth launch where four streams really overlap in this process (see streams_run_concurrently): 8192 episodes 717 ->
-    // 742 M, 2048: 310 -> 314 M, 1024: 179 -> 182 M
-    if (ng == 3 && streams_run_concurrently(4)) ng = 4;
+    // (a fourth launch where four streams really overlap: decided below, once the streams exist)
+    h->auto_groups = getenv("CC4_GROUPS") == nullptr;
     if (const char* v = getenv("CC4_GROUPS")) ng = atoi(v);
     configure_groups(h, ng);
   }
@@ -1555,6 +1550,18 @@ int cc4_create(const cc4_config* cfg, cc4_handle** out) {
     HIPCHK(h, hipEventCreateWithFlags(&h->gev[g], hipEventDisableTiming));
   }
   HIPCHK(h, hipEventCreateWithFlags(&h->mev, hipEventDisableTiming));
+  if (h->auto_groups && h->ngroups == 3) {
+    // a fourth launch per step where this handle's four streams really run side by side (8192 episodes 717 -> 742 M, 2048: 310 ->
+    // 314 M, 1024: 179 -> 183 M; with two of them on one hardware queue: 445 M)
+    HIPCHK(h, hipStreamCreateWithFlags(&h->gstream[3], hipStreamNonBlocking));
+    if (streams_run_concurrently(h->gstream, 4)) {
+      HIPCHK(h, hipEventCreateWithFlags(&h->gev[3], hipEventDisableTiming));
+      configure_groups(h, 4);
+    } else {
+      (void)hipStreamDestroy(h->gstream[3]);
+      h->gstream[3] = nullptr;
+    }
+  }
   size_t n = (size_t)cfg->num_envs;
   HIPCHK(h, hipMalloc(&h->d_state, n * sizeof(EnvState)));
   h->cold_row = cold_row_bytes(cfg->steps);
