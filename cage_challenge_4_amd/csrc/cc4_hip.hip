@@ -946,8 +946,11 @@ __global__ __launch_bounds__(PT, MINW) void k_step_philox(StepArgs a) {
 // their spread over waves.  Like the numpy-stream kernel it stages only the agent part of the row (6 992 B) and leaves the
 // host table in HBM / L2, so 16 episodes are resident per CU (LDS) instead of 7-8.  The build for throughput-bound batches;
 // k_step_philox keeps the shorter single-launch latency of small ones (cc4_create picks; CC4_PHILOX_LEAN overrides).
+#ifndef CC4_LEAN_MINW
+#define CC4_LEAN_MINW 1
+#endif
 template <bool LOG>
-__global__ __launch_bounds__(WAVE) void k_step_philox1(StepArgs a) {
+__global__ __launch_bounds__(WAVE, CC4_LEAN_MINW) void k_step_philox1(StepArgs a) {
   extern __shared__ uint4 lds[];
   // byte copy of the observations, only for the packed exchange row; the debug phase timers borrow the area (a profiled handle
   // has no communicator): with it, agent part + statics fit 8 KB and 20 episodes are resident per CU
