@@ -170,7 +170,7 @@ struct alignas(8) BlueAgent {
   uint8_t last_ok;                   // outcome of the last Block/AllowTrafficZone this agent resolved: 1 TRUE, 3 FALSE (T_*), 0 none
 };
 
-struct alignas(16) EnvState {
+struct alignas(64) EnvState {
   Rng rng;
   int32_t step_count, steps, phase;
   int32_t phase_len[3];
@@ -212,10 +212,13 @@ struct alignas(16) EnvState {
   // end-turn Monitor rolled them over).  Every step raises a few dozen of them (ev_or), the Monitor rolls all 137 and the
   // observation encode reads all 137 -- in the part of the row that is staged in LDS, these are LDS operations; while they were a
   // byte of each HostDyn row, the kernels that leave the host table in HBM touched all 137 rows every step for them.
-  alignas(4) uint8_t hev[MAXH + 7];
-  alignas(16) HostDyn hd[MAXH];      // last member: the numpy-stream kernel stages only the part in front of it
+  alignas(4) uint8_t hev[MAXH + 39];  // (137 bytes + padding that puts the host table on a 64-byte boundary)
+  // 64-byte alignment of the table and of the row (rows are allocated back to back from a 256-byte aligned base): every HostDyn is
+  // exactly one cache line of HBM / L2 -- the kernels that leave the table there read and write single rows -- and the staged part
+  // in front of it is whole lines, so stage-in and stage-out never share a line with a neighbour
+  alignas(64) HostDyn hd[MAXH];      // last member: the numpy-stream kernel stages only the part in front of it
 };
-static_assert(offsetof(EnvState, hd) % 16 == 0 && sizeof(EnvState) == offsetof(EnvState, hd) + sizeof(HostDyn) * MAXH, "the host table closes the row");
+static_assert(offsetof(EnvState, hd) % 64 == 0 && sizeof(EnvState) % 64 == 0 && sizeof(EnvState) == offsetof(EnvState, hd) + sizeof(HostDyn) * MAXH, "the host table closes the row; row and table are whole cache lines");
 
 // Work area of one step / one reset: temporaries the phases hand to each other.  Not part of the episode's state (LDS on the
 // device, the caller's stack on the host); everything in it is dead between steps.
