@@ -78,6 +78,7 @@ class CC4VecEnv:
         self._done = np.zeros(n, np.uint8)
         self._mask = np.zeros((n, L.MASK_PER_ENV), np.uint8)
         self._err = np.zeros(n, np.uint32)
+        self._err_seen = np.zeros(n, np.uint32)      # flags already raised for (strict mode raises once per flag and episode)
 
     # -- lifecycle
     def close(self):
@@ -134,8 +135,14 @@ class CC4VecEnv:
         self._chk(self.lib.cc4_get_err(self._h, self._err.ctypes.data_as(ctypes.c_void_p)), 'cc4_get_err')
         if mask:
             self._chk(self.lib.cc4_get_action_mask(self._h, self._mask.ctypes.data_as(ctypes.c_void_p)), 'cc4_get_action_mask')
+        self._err_seen &= self._err                    # a regenerated episode (reset, autoreset) starts with a clean slate
         if self.strict:
-            raise_on_engine_error(self._err)
+            # a flag stays set in the episode's row until the episode is reset; it is raised ONCE -- a batch of thousands of
+            # episodes is not taken hostage by one of them: the caller may reset that episode (env_mask) or carry on, `err` and
+            # info['err'] keep showing the flag.  (A step past the episode's end raises on every call, as the reference does.)
+            fresh = self._err & ~self._err_seen
+            self._err_seen |= self._err
+            raise_on_engine_error(fresh | (self._err & np.uint32(1 << 7)))
         elif (self._err & (1 << 7)).any():
             raise ValueError("Step number exceeds last mission phase step maximum. "
                              "Use step parameter in EnterpriseScenarioGenerator.")  # State.py:539-540
