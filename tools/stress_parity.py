@@ -20,13 +20,13 @@ for k in range(rounds):
         os.environ['CC4_PHILOX_LEAN'] = str(lean)
         dev = CC4VecEnv(n, steps=EP, rng_mode=mode, autoreset=True, red_policy=rp, blue_policy=bp)
         ora = OracleVecEnv(n, steps=EP, rng_mode=mode, autoreset=True, red_policy=rp, blue_policy=bp)
-        assert np.array_equal(dev.reset(seeds=seed), ora.reset(seeds=seed))
+        assert np.array_equal(dev.reset(seeds=seed), ora.reset_batch(seed))
         ok = True
         for t in range(T):
             a = random_actions(seed, t, n)
             if bp:
                 a[(np.arange(n)[:, None] + np.arange(5)[None, :] + t) % 3 == 0] = -1
-            d = dev.step(a); o = ora.step(a)
+            d = dev.step(a); o = ora.step_batch(a)      # OpenMP over episodes: large batches in seconds
             if not (np.array_equal(d[0], o[0]) and np.array_equal(d[1], o[1]) and np.array_equal(d[2], o[2])):
                 print('MISMATCH round', k, 'mode', mode, 'policy', rp, 'kernel', dev.step_kernel, 'step', t, flush=True); ok = False; bad += 1; break
         if ok:
