@@ -1399,11 +1399,13 @@ static void configure_groups(cc4_handle* h, int ng) {
   if (ng > 1) h->philox_minw = bpc_all <= 5 ? 1 : 7;
   if (const char* v = getenv("CC4_PHILOX_MINW")) h->philox_minw = atoi(v);   // tuning override: 1, 7 or 8
   // The one-wave-per-episode build when a single launch puts more than eight episodes on a CU, or the launches of a step
-  // together more than sixteen.  Measured on MI355X (M agent-env steps/s, four waves / one wave per episode; r02, one launch per
+  // together more than thirteen.  Measured on MI355X (M agent-env steps/s, four waves / one wave per episode; r02, one launch per
   // step): 1024 episodes 168 / 131, 2048: 262 / 238, 2304: 249 / 260, 3072: 294 / 322, 4096: 319 / 395, 8192: 391 / 510;
   // (r03, three launches per step): 1024: 175 / 137, 2048: 295 / 249, 3072: 347 / 345, 4096: 442 / 422, 6144: 455 / 556,
   // 8192: 466 / 659.  (The same kernel with the host table in LDS as well is no faster anywhere.)
-  h->philox_lean = bpc > 8 || bpc_all > 16;
+  // (after the r03 changes to the one-wave kernel -- event bytes staged, rows on cache-line boundaries -- with four launches per
+  // step: 2048 episodes 312 / 276, 3072: 401 / 388, 4096: 442 / 487, 5120: 453 / 560, 6144: 458 / 627)
+  h->philox_lean = bpc > 8 || bpc_all > 13;
   if (const char* v = getenv("CC4_PHILOX_LEAN")) h->philox_lean = atoi(v) != 0;   // tuning / test override
 }
 

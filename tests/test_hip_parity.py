@@ -187,9 +187,8 @@ def test_bench_configuration_matches_oracle_every_step(n, red_policy, blue_polic
     assert 'CC4_PHILOX_LEAN' not in os.environ and 'CC4_PHILOX_MINW' not in os.environ and 'CC4_GROUPS' not in os.environ
     T, steps = 330, 150
     dev = _dev(n, steps=steps, rng_mode=1, autoreset=True, red_policy=red_policy, blue_policy=blue_policy)
-    # 8192 episodes: three or four launches of the one-wave kernel per step (four where the runtime runs four streams side by
-    # side); 4096: as many launches of the four-wave kernel (cc4_create)
-    assert dev.step_kernel == ('k_step_philox1' if n == 8192 else 'k_step_philox') and dev.lib.cc4_launches_per_step(dev._h) in (3, 4)
+    # three or four launches of the one-wave kernel per step (four where the runtime runs four streams side by side)
+    assert dev.step_kernel == 'k_step_philox1' and dev.lib.cc4_launches_per_step(dev._h) in (3, 4)
     ora = OracleVecEnv(n, steps=steps, rng_mode=1, autoreset=True, red_policy=red_policy, blue_policy=blue_policy)
     assert np.array_equal(dev.reset(seeds=1000), ora.reset_batch(1000))
     resets = 0
