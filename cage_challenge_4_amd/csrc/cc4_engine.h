@@ -91,6 +91,8 @@ CC4_HD void bit_set_shared(uint32_t* b, int i) {
   b[i >> 5] |= 1u << (i & 31);
 #endif
 }
+// the HostDyn row of host h is about to be written (StepWork.hdirty; several lanes may mark)
+CC4_HD void hd_touch(Ctx x, int h);
 CC4_HD void bit_clr_shared(uint32_t* b, int i) {
 #if defined(__HIP_DEVICE_COMPILE__)
   __hip_atomic_fetch_and(&b[i >> 5], ~(1u << (i & 31)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -98,6 +100,7 @@ CC4_HD void bit_clr_shared(uint32_t* b, int i) {
   b[i >> 5] &= ~(1u << (i & 31));
 #endif
 }
+CC4_HD void hd_touch(Ctx x, int h) { bit_set_shared(x.w->hdirty, h); }
 CC4_HD uint32_t or_shared(uint32_t* p, uint32_t v) {   // returns the previous word
 #if defined(__HIP_DEVICE_COMPILE__)
   return __hip_atomic_fetch_or(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -209,7 +212,7 @@ CC4_HD int pw_pid(uint32_t v) { return (int)(v & 0xFFFF); }
 CC4_HD int pw_kind(uint32_t v) { return (int)((v >> 16) & 0xFF); }
 CC4_HD int pw_flags(uint32_t v) { return (int)(v >> 24); }
 CC4_HD uint32_t proc_get(Ctx x, int h, int i) { return proc_round_ptr(x, h, i & ~7)[i & 7]; }
-CC4_HD void proc_put(Ctx x, int h, int i, uint32_t v) { const_cast<uint32_t*>(proc_round_ptr(x, h, i & ~7))[i & 7] = v; }
+CC4_HD void proc_put(Ctx x, int h, int i, uint32_t v) { hd_touch(x, h); const_cast<uint32_t*>(proc_round_ptr(x, h, i & ~7))[i & 7] = v; }
 // Host.create_pid (Simulator/Host.py:198-200)
 CC4_HD int create_pid(Ctx x, int h) {
   int mx = 0;
@@ -251,6 +254,7 @@ CC4_HD int proc_ports(Ctx x, int h) {
 // records idx+1 .. n-1 move down by one: per round, the round and the first record of the next one are read before the
 // round is rewritten
 CC4_HD void remove_proc_at(Ctx x, int h, int idx) {
+  hd_touch(x, h);
   HostDyn& d = x.hd[h];
   const int n = d.nproc;
   for (int i0 = idx & ~7; i0 < n; i0 += 8) {
@@ -623,6 +627,7 @@ CC4_HD void host_backup(Ctx x, int h, int ip_octet) {
   __builtin_memcpy(&x.c->hs[h], &st, sizeof(HostStatic));
 }
 CC4_HD void host_restore(Ctx x, int h) {  // Host.restore (Host.py:373-429)
+  hd_touch(x, h);
   HostDyn& d = x.hd[h];
   // the backup image lives in the cold row (HBM): fetch its 56 bytes with independent wide loads, then unpack
   HostStatic st;
@@ -1134,7 +1139,7 @@ CC4_HD void kill_process(Ctx x, int h, int pi, uint32_t pw) {
   if (si >= 0) {  // service process respawns under a new pid
     int np = create_pid(x, h);
     add_proc(x, h, np, kind, pw_flags(pw));
-    d.svcs[si].pid = (uint16_t)np;
+    d.svcs[si].pid = (uint16_t)np;     // (the row is marked: remove_proc_at / add_proc above)
   }
   if (owner < 0) return;
   if (owner < 2) { set_err(x, E_BLUE_GREEN_SESSION_KILLED); return; }
@@ -1534,6 +1539,7 @@ CC4_HD void red_privesc(Ctx x, int r, const Act& a) {
       if (ss < 0 || !(rsw_flags(rs_at(s, A, ss)) & RS_ABSTRACT)) { red_result(x, r, a, T_FALSE); return; } }
     const int tslot = A.sord[target];
     s->spool[tslot].flags |= RS_ROOT;  // EscalateAction.__upgrade_session (EscalateAction.py:57-87)
+    hd_touch(x, h);
     hd_set_files(x.hd[h], hd_files(x.hd[h]) | HF_ESC | HF_ESC_LAST);   // ... which also drops File('escalate.sh', density 0.9) on the host (:70-77)
     int pi = find_proc(x, h, s->spool[tslot].pid);
     if (pi >= 0) proc_put(x, h, pi, proc_get(x, h, pi) | ((uint32_t)PF_ROOT << 24));
@@ -1558,6 +1564,7 @@ CC4_HD void red_impact(Ctx x, int r, const Act& a) {
   for (int i = 0; i < hd_nsvc(d); ++i) if (d.svcs[i].kind == K_OT && (d.svcs[i].st & SV_ACTIVE)) { si = i; break; }
   if (si < 0) { red_result(x, r, a, T_FALSE); return; }
   if (rs_find_id(s, A, a.sid) < 0) { red_result(x, r, a, T_FALSE); return; }  // StopService needs self.session too
+  hd_touch(x, h);
   d.svcs[si].st &= (uint8_t)~SV_ACTIVE;                      // Host.stop_service (Host.py:295-300)
   int pi = find_proc(x, h, d.svcs[si].pid);                   // State.remove_process (State.py:390-418)
   if (pi >= 0) remove_proc_at(x, h, pi);
@@ -1572,6 +1579,7 @@ CC4_HD void red_degrade(Ctx x, int r, const Act& a) {
   if (rs_on_host(s, A, h).first_root < 0) { red_result(x, r, a, T_FALSE); return; }   // no session, or none of them root
   HostDyn& d = x.hd[h];
   int n = 0;
+  hd_touch(x, h);
   for (int i = 0; i < hd_nsvc(d); ++i) if (d.svcs[i].st & SV_ACTIVE) {
     n++;
     int rel = d.svcs[i].st & 0x7F;

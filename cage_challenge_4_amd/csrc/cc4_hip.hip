@@ -638,7 +638,7 @@ __global__ __launch_bounds__(WAVE) void k_step(StepArgs a) {
 #define CC4_PW 4
 #endif
 constexpr int PW = CC4_PW;         // waves per episode block; red agent r runs on wave r % PW, lane r / PW
-static_assert(PW >= 4 && PW <= 6, "waves 0/1 run the two green action lists, waves 2.. the green draws, wave PW-1 the blue submissions");
+static_assert(PW == 4 || PW == 8, "waves 0/1 run the two green action lists, waves PW-2 and PW-1 the green draws, wave PW-1 the blue submissions");
 constexpr int PT = PW * WAVE;      // threads per episode block (256)
 
 __device__ __forceinline__ void stage_in_n(uint4* __restrict__ lds, const uint4* __restrict__ src, int tid) {
@@ -714,6 +714,7 @@ __global__ __launch_bounds__(PT, MINW) void k_step_philox(StepArgs a) {
   if (tid == 0) conflict_lds = 0;
   if (tid >= 64 && tid < 64 + 4 + NRED) (&work.phish_mask[0])[tid - 64] = 0;   // phish_mask[4] and pend_r[NRED] are adjacent
   static_assert(offsetof(StepWork, pend_r) == offsetof(StepWork, phish_mask) + 16, "phish_mask and pend_r are cleared as one run of words");
+  if (tid >= 128 && tid < 128 + 5) work.hdirty[tid - 128] = 0;
   __syncthreads();
   EnvState* s = reinterpret_cast<EnvState*>(lds);
   HostDyn* const hd = s->hd;
@@ -810,12 +811,13 @@ __global__ __launch_bounds__(PT, MINW) void k_step_philox(StepArgs a) {
         // block 0 of the agent's action stream, for the lane that will resolve the action
         { uint32_t c[4]; rng_block(&rl, ST_BLUE_EXE + (uint32_t)b, 0, c); reinterpret_cast<uint4*>(reset_ws)[MAXG + NRED + b] = make_uint4(c[0], c[1], c[2], c[3]); }
       }
-      else if (wave == 2 && lane >= 1 && lane <= NRED) {   // block 0 of the six red action streams, side by side on idle lanes of a wave with slack
+      else if (wave == PW - 2 && lane >= 1 && lane <= NRED) {   // block 0 of the six red action streams, side by side on idle lanes of a wave with slack
         uint32_t c[4]; rng_block(&rl, ST_RED_EXE + (uint32_t)(lane - 1), 0, c); reinterpret_cast<uint4*>(reset_ws)[MAXG + lane - 1] = make_uint4(c[0], c[1], c[2], c[3]);
       }
-      else if (lane >= 8 && wave >= 2) {
-        static_assert(PW == 4 && MAXG <= 2 * (WAVE - 8), "every green agent has its own lane on wave 2 or 3: one pass, one ballot per type");
-        const int g = (wave - 2) * (WAVE - 8) + (lane - 8);
+      else if (lane >= 8 && wave >= PW - 2) {
+        static_assert(RW <= PW - 2 && MAXG <= 2 * (WAVE - 8), "every green agent has its own lane on one of the last two waves (no red agent there): one pass, one ballot per type");
+        const int gw = wave - (PW - 2);
+        const int g = gw * (WAVE - 8) + (lane - 8);
         if (g < ng) {
           Ctx xg{s, cold_e, &rl, hd, &work, nullptr, nullptr, lg};
           step_green_policy(xg, g);
@@ -826,8 +828,8 @@ __global__ __launch_bounds__(PT, MINW) void k_step_philox(StepArgs a) {
           const unsigned long long below = (1ull << lane) - 1ull;
           if (t < 2) {
             const unsigned long long m = t == 0 ? m0 : m1;
-            glist[t][wave - 2][__popcll(m & below)] = (uint8_t)g;
-            if ((m & below) == 0) glist_n[t][wave - 2] = __popcll(m);      // the first lane of the type publishes the count
+            glist[t][gw][__popcll(m & below)] = (uint8_t)g;
+            if ((m & below) == 0) glist_n[t][gw] = __popcll(m);      // the first lane of the type publishes the count
             // the first block of the agent's action stream, computed here -- behind the red policies -- and handed to the
             // lane that resolves the action (the generation work area is idle during a step)
             uint32_t c[4];
@@ -931,8 +933,13 @@ __global__ __launch_bounds__(PT, MINW) void k_step_philox(StepArgs a) {
   if (a.obs8) { uint8_t* o8 = a.obs8 + (size_t)e * OBS_PACKED; for (int j = tid; j < OBS_PACKED; j += PT) o8[j] = pack_obs_byte(obs_bytes, j); }
   unsigned long long t_out = a.prof ? clock64() : 0;
   if (prof && tid == 0) prof[12] += t_out - t_obs;
+  // write-back: the agent part always; of the host table (55 % of the row) only the rows this step wrote -- a HostDyn is exactly one
+  // 64-byte line, written here by four adjacent lanes, and a step touches a handful of the 137 (hd_touch; everything after a reset)
   uint4* dst = reinterpret_cast<uint4*>(a.st + e);
-  for (int i = tid; i < ROW_VEC; i += PT) dst[i] = lds[i];
+  static_assert(sizeof(HostDyn) == 64 && offsetof(EnvState, hd) % 64 == 0 && HOT_VEC + 4 * MAXH == ROW_VEC, "one line per host row, the table closes the row");
+  for (int i = tid; i < HOT_VEC; i += PT) dst[i] = lds[i];
+  if (do_reset) { for (int i = HOT_VEC + tid; i < ROW_VEC; i += PT) dst[i] = lds[i]; }
+  else for (int k = tid; k < 4 * MAXH; k += PT) if ((work.hdirty[k >> 7] >> ((k >> 2) & 31)) & 1u) dst[HOT_VEC + k] = lds[HOT_VEC + k];
   if (prof && tid == 0) { prof[13] += clock64() - t_out; prof[14] += clock64() - t_begin; }
   if (prof) { __syncthreads(); if (tid < 15) a.prof[PROF_SLOTS * (size_t)e + tid] += prof_lds[tid]; }
 }

@@ -229,6 +229,8 @@ struct alignas(16) StepWork {
   uint32_t pend_r[NRED];             // this step's pid-carrying event of red agent r (0 = none); merged into pend[] in agent order
   uint8_t rs_slot[NRED + 2];         // pool slot reserved for the session red agent r's exploit may create this step (rs_reserve)
   uint8_t green_act[MAXG];           // this step's green choice
+  uint32_t hdirty[5];                // bit h: the HostDyn row of host h was written this step (hd_touch): the kernel that stages the host
+                                     // table writes back only these rows -- one cache line each -- and a step touches a handful of the 137
 };
 
 // optional per-step event log (decoded Monitor observations with ports / peers / pids).  One record per

@@ -85,6 +85,25 @@ void cc4o_step(void* h, int i, const int32_t* actions, const uint8_t* msgs) {
   x.lg = o->evlog ? &o->cold(i)->evlog : nullptr;
   env_step(x, actions, msgs);
 }
+// cc4o_step that also checks the engine's dirty-row marks (StepWork.hdirty, hd_touch): returns the number of HostDyn rows the
+// step changed WITHOUT marking them (must be 0: the four-wave kernel writes back only marked rows), *marked = rows marked
+int cc4o_step_check_marks(void* h, int i, const int32_t* actions, const uint8_t* msgs, int* marked) {
+  Oracle* o = (Oracle*)h;
+  StepWork w; memset(&w, 0, sizeof(w));
+  Ctx x{&o->st[i], o->cold(i), &o->st[i].rng, o->st[i].hd, &w};
+  x.lg = o->evlog ? &o->cold(i)->evlog : nullptr;
+  HostDyn before[MAXH];
+  memcpy(before, o->st[i].hd, sizeof(before));
+  env_step(x, actions, msgs);
+  int bad = 0, m = 0;
+  for (int k = 0; k < MAXH; ++k) {
+    const bool mk = (w.hdirty[k >> 5] >> (k & 31)) & 1u;
+    m += mk;
+    if (!mk && memcmp(&before[k], &o->st[i].hd[k], sizeof(HostDyn)) != 0) ++bad;
+  }
+  if (marked) *marked = m;
+  return bad;
+}
 // whole-batch step, OpenMP over envs when built with -fopenmp (bench.py cpu_baseline)
 void cc4o_step_all(void* h, const int32_t* actions /* [n][5] */) {
   Oracle* o = (Oracle*)h;

@@ -32,6 +32,7 @@ def load():
     lib.cc4o_reset.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_uint64, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int]
     lib.cc4o_step.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]
     lib.cc4o_step_all.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
+    lib.cc4o_step_check_marks.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
     lib.cc4o_step_batch.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
                                     ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
     lib.cc4o_obs.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]
@@ -102,8 +103,14 @@ class OracleVecEnv:
                 continue
             a = None if actions is None else np.ascontiguousarray(actions[i], np.int32)
             m = None if messages is None else np.ascontiguousarray(messages[i], np.uint8)
-            self.lib.cc4o_step(self._h, i, None if a is None else a.ctypes.data_as(ctypes.c_void_p),
-                               None if m is None else m.ctypes.data_as(ctypes.c_void_p))
+            ap = None if a is None else a.ctypes.data_as(ctypes.c_void_p)
+            mp = None if m is None else m.ctypes.data_as(ctypes.c_void_p)
+            if getattr(self, 'check_marks', False):   # the engine's dirty-row marks (StepWork.hdirty) cover every HostDyn row the step changed
+                mk = ctypes.c_int(0)
+                self.unmarked_rows = getattr(self, 'unmarked_rows', 0) + self.lib.cc4o_step_check_marks(self._h, i, ap, mp, ctypes.byref(mk))
+                self.marked_rows = getattr(self, 'marked_rows', 0) + mk.value
+            else:
+                self.lib.cc4o_step(self._h, i, ap, mp)
             self._collect(i)
         return self._obs, self._rew, self._done, {'err': self._err}
 

@@ -363,6 +363,35 @@ def test_a_suspicious_pid_never_names_a_blue_or_green_session_process(oracle_lib
     assert sum(len(b['sus']) for b in json.loads(ora.true_state_json(0))['blue']) > 0
 
 
+@pytest.mark.parametrize('rng_mode', [0, 1])
+def test_every_host_row_a_step_changes_is_marked_dirty(oracle_lib, rng_mode):
+    """k_step_philox (the four-wave kernel, the whole row in LDS) writes back the agent part and only those 64-byte host-table
+    rows (HostDyn) the engine marked in StepWork.hdirty (hd_touch at each write site).  A row changed without a mark would be
+    lost on the GPU only and only steps later -- so the marks are checked here on the CPU build of the same engine source:
+    cc4o_step_check_marks compares every HostDyn row before and after each step.  Action mix: the blue actions that write the
+    table (Remove / Restore / DeployDecoy) against the red FSM and green traffic, whole episodes; and the marks must be
+    selective (a handful of the 137 rows per step), or the kernel would gain nothing from them."""
+    n, T = 32, 260
+    ora = OracleVecEnv(n, steps=T, rng_mode=rng_mode); ora.reset(seeds=7300)
+    ora.check_marks = True
+    rs = np.random.default_rng(5)
+    mask = ora.mask()
+    for t in range(T - 1):
+        a = np.zeros((n, 5), np.int32)
+        for b in range(5):
+            nh, nc = (48, 24) if b == 4 else (16, 8)
+            kind = rs.integers(0, 4, size=n)                      # Sleep-ish / Remove / Restore / DeployDecoy on a random valid host
+            base = np.where(kind <= 1, nh + 1, np.where(kind == 2, 2 * nh + 1, 3 * nh + 2 + 2 * nc))
+            off = 82 * b if b < 4 else 328
+            for e in range(n):
+                valid = np.nonzero(mask[e, off + base[e]: off + base[e] + nh])[0]
+                a[e, b] = 0 if (kind[e] == 0 and t % 3) else base[e] + valid[rs.integers(len(valid))]
+        ora.step(a)
+    assert ora.unmarked_rows == 0, ora.unmarked_rows
+    per_step = ora.marked_rows / (n * (T - 1))
+    assert 0.5 < per_step < 12, per_step
+
+
 def _engine_marginals(env_cls, n, seed0, chunk=2000, **kw):
     import gen_marginals as GM
     acc = GM.empty()
