@@ -638,7 +638,7 @@ __global__ __launch_bounds__(WAVE) void k_step(StepArgs a) {
 #define CC4_PW 4
 #endif
 constexpr int PW = CC4_PW;         // waves per episode block; red agent r runs on wave r % PW, lane r / PW
-static_assert(PW == 4 || PW == 8, "waves 0/1 run the two green action lists, waves PW-2 and PW-1 the green draws, wave PW-1 the blue submissions");
+static_assert(PW >= 4 && PW <= 8, "waves 0/1 run the two green action lists, waves PW-2 and PW-1 the green draws, wave PW-1 the blue submissions");
 constexpr int PT = PW * WAVE;      // threads per episode block (256)
 
 __device__ __forceinline__ void stage_in_n(uint4* __restrict__ lds, const uint4* __restrict__ src, int tid) {
@@ -815,7 +815,7 @@ __global__ __launch_bounds__(PT, MINW) void k_step_philox(StepArgs a) {
         uint32_t c[4]; rng_block(&rl, ST_RED_EXE + (uint32_t)(lane - 1), 0, c); reinterpret_cast<uint4*>(reset_ws)[MAXG + lane - 1] = make_uint4(c[0], c[1], c[2], c[3]);
       }
       else if (lane >= 8 && wave >= PW - 2) {
-        static_assert(RW <= PW - 2 && MAXG <= 2 * (WAVE - 8), "every green agent has its own lane on one of the last two waves (no red agent there): one pass, one ballot per type");
+        static_assert((RW <= PW - 2 || RW >= NRED) && MAXG <= 2 * (WAVE - 8), "every green agent has its own lane (8..63) on one of the last two waves, which carry no red agent or one on lane 0: one pass, one ballot per type");
         const int gw = wave - (PW - 2);
         const int g = gw * (WAVE - 8) + (lane - 8);
         if (g < ng) {
@@ -1482,7 +1482,10 @@ static int launch_step(cc4_handle* h, const int32_t* d_actions, const uint8_t* d
       else if (h->evlog_on) hipExtLaunchKernelGGL((k_step_philox<true, 1>), grid, dim3(PT), sizeof(EnvState), st, nullptr, stop, 0, a);
       else if (h->philox_minw == 8) hipExtLaunchKernelGGL((k_step_philox<false, 8>), grid, dim3(PT), sizeof(EnvState), st, nullptr, stop, 0, a);
       else if (h->philox_minw == 7) hipExtLaunchKernelGGL((k_step_philox<false, 7>), grid, dim3(PT), sizeof(EnvState), st, nullptr, stop, 0, a);
-      else hipExtLaunchKernelGGL((k_step_philox<false, 1>), grid, dim3(PT), sizeof(EnvState), st, nullptr, stop, 0, a);
+#ifndef CC4_SMALL_MINW
+#define CC4_SMALL_MINW 1
+#endif
+      else hipExtLaunchKernelGGL((k_step_philox<false, CC4_SMALL_MINW>), grid, dim3(PT), sizeof(EnvState), st, nullptr, stop, 0, a);
     } else {
       if (h->evlog_on) hipExtLaunchKernelGGL(k_step<true>, grid, dim3(WAVE), offsetof(EnvState, hd), st, nullptr, stop, 0, a);
       else hipExtLaunchKernelGGL(k_step<false>, grid, dim3(WAVE), offsetof(EnvState, hd), st, nullptr, stop, 0, a);
