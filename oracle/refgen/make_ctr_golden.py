@@ -3,7 +3,7 @@ running under oracle/refgen/philox_proxy.PhiloxProxy: scenario from the numpy st
 wrapper.reset()), dynamics on the counter streams of `key` (episode word 1: what cc4_set_seed leaves).  Data only: seed, key,
 per-step blue action indices, and the reference's outputs (flat observations, team reward, done, action mask).
 
-usage: python make_ctr_golden.py          # writes tests/golden/ctrstep_*.npz
+usage: python make_ctr_golden.py [long]   # writes tests/golden/ctrstep_*.npz (long: the two 1000-step episodes)
 """
 import os, sys
 import numpy as np
@@ -63,6 +63,10 @@ def record(seed, steps, blue, red='fsm', green='enterprise', key=None, msgs=Fals
 
 if __name__ == '__main__':
     os.makedirs(OUT, exist_ok=True)
+    if len(sys.argv) > 1 and sys.argv[1] == 'long':      # EnterpriseScenarioGenerator(steps=1000): the containers sized from the episode length
+        record(777, 1000, 'decoy_one')
+        record(778, 1000, 'random', red='random')
+        sys.exit(0)
     record(123, 500, 'random')
     record(7, 500, 'sleep', key=99991)
     record(3, 500, 'random', msgs=True)
