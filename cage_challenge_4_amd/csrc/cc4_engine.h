@@ -212,16 +212,40 @@ CC4_HD int pw_pid(uint32_t v) { return (int)(v & 0xFFFF); }
 CC4_HD int pw_kind(uint32_t v) { return (int)((v >> 16) & 0xFF); }
 CC4_HD int pw_flags(uint32_t v) { return (int)(v >> 24); }
 CC4_HD uint32_t proc_get(Ctx x, int h, int i) { return proc_round_ptr(x, h, i & ~7)[i & 7]; }
+// The list's length together with its first round, both from the host's own row (one cache line) and requested at once: a scan
+// that reads the length first and the records after it spends two dependent round trips on what is nearly always (19 hosts in 20
+// never exceed PIN processes) a one-round list.  Slots past the end are allocated and masked by the index test.
+struct P8N { uint32_t v[8]; int n; int nsf; };   // nsf: HostDyn.nsf (service count | file flags), same line
+CC4_HD P8 p8_of(const P8N& a) { P8 q; CC4_UNROLL for (int k = 0; k < 8; ++k) q.v[k] = a.v[k]; return q; }
+CC4_HD P8N proc_head(Ctx x, int h) {
+  const HostDyn& d = x.hd[h];
+  P8N r;
+  const uint32_t* p = reinterpret_cast<const uint32_t*>(d.procs);
+  CC4_UNROLL for (int k = 0; k < 8; ++k) r.v[k] = p[k];
+  r.n = d.nproc;
+  r.nsf = d.nsf;
+  return r;
+}
 CC4_HD void proc_put(Ctx x, int h, int i, uint32_t v) { hd_touch(x, h); const_cast<uint32_t*>(proc_round_ptr(x, h, i & ~7))[i & 7] = v; }
 // Host.create_pid (Simulator/Host.py:198-200)
-CC4_HD int create_pid(Ctx x, int h) {
+CC4_HD int create_pid(Ctx x, int h, const P8N& hd0) {   // hd0: proc_head(x, h), when the caller holds it already
   int mx = 0;
-  const int n = x.hd[h].nproc;
-  for (int i0 = 0; i0 < n; i0 += 8) {
+  const int n = hd0.n;
+  CC4_UNROLL for (int k = 0; k < 8; ++k) if (k < n && pw_pid(hd0.v[k]) > mx) mx = pw_pid(hd0.v[k]);
+  for (int i0 = 8; i0 < n; i0 += 8) {
     const P8 q = proc_load8(x, h, i0);
     CC4_UNROLL for (int k = 0; k < 8; ++k) if (i0 + k < n && pw_pid(q.v[k]) > mx) mx = pw_pid(q.v[k]);
   }
   return mx + 1 + (int)rng_below(x.r, 9);
+}
+CC4_HD int create_pid(Ctx x, int h) { return create_pid(x, h, proc_head(x, h)); }
+// n: the list's current length (HostDyn.nproc), which the caller holds
+CC4_HD bool add_proc_n(Ctx x, int h, int n, int pid, int kind, int flags) {
+  HostDyn& d = x.hd[h];
+  if (n >= PIN && n >= PIN + cold_povf_cap(x.s->steps)) { set_err(x, E_PROC_OVERFLOW); return false; }
+  proc_put(x, h, n, (uint32_t)pid | ((uint32_t)kind << 16) | ((uint32_t)flags << 24));
+  d.nproc = (uint16_t)(n + 1);
+  return true;
 }
 CC4_HD bool add_proc(Ctx x, int h, int pid, int kind, int flags) {
   HostDyn& d = x.hd[h];
@@ -231,9 +255,14 @@ CC4_HD bool add_proc(Ctx x, int h, int pid, int kind, int flags) {
   d.nproc = (uint16_t)(n + 1);
   return true;
 }
-CC4_HD int find_proc(Ctx x, int h, int pid) {
-  const int n = x.hd[h].nproc;
-  for (int i0 = 0; i0 < n; i0 += 8) {
+CC4_HD int find_proc(Ctx x, int h, int pid, const P8N& hd0) {   // hd0: proc_head(x, h), when the caller holds it already
+  const int n = hd0.n;
+  {
+    int hit = -1;
+    CC4_UNROLL for (int k = 7; k >= 0; --k) if (k < n && pw_pid(hd0.v[k]) == pid) hit = k;
+    if (hit >= 0) return hit;
+  }
+  for (int i0 = 8; i0 < n; i0 += 8) {
     const P8 q = proc_load8(x, h, i0);
     int hit = -1;
     CC4_UNROLL for (int k = 7; k >= 0; --k) if (i0 + k < n && pw_pid(q.v[k]) == pid) hit = i0 + k;
@@ -241,16 +270,19 @@ CC4_HD int find_proc(Ctx x, int h, int pid) {
   }
   return -1;
 }
+CC4_HD int find_proc(Ctx x, int h, int pid) { return find_proc(x, h, pid, proc_head(x, h)); }
 // the union of the listening-port bits of the host's processes (Host.is_using_port over all ports at once)
-CC4_HD int proc_ports(Ctx x, int h) {
-  const int n = x.hd[h].nproc;
+CC4_HD int proc_ports(Ctx x, int h, const P8N& hd0) {   // hd0: proc_head(x, h), when the caller holds it already
+  const int n = hd0.n;
   int used = 0;
-  for (int i0 = 0; i0 < n; i0 += 8) {
+  CC4_UNROLL for (int k = 0; k < 8; ++k) if (k < n) used |= kind_port(pw_kind(hd0.v[k]));
+  for (int i0 = 8; i0 < n; i0 += 8) {
     const P8 q = proc_load8(x, h, i0);
     CC4_UNROLL for (int k = 0; k < 8; ++k) if (i0 + k < n) used |= kind_port(pw_kind(q.v[k]));
   }
   return used;
 }
+CC4_HD int proc_ports(Ctx x, int h) { return proc_ports(x, h, proc_head(x, h)); }
 // records idx+1 .. n-1 move down by one: per round, the round and the first record of the next one are read before the
 // round is rewritten
 CC4_HD void remove_proc_at(Ctx x, int h, int idx) {
@@ -1115,6 +1147,16 @@ CC4_HD int svc_of_pid(const HostDyn& d, int pid) {
   CC4_UNROLL for (int i = MAXSV - 1; i >= 0; --i) if (i < n && (int)(sv[i] & 0xFFFF) == pid) si = i;
   return si;
 }
+// the host's service table (pid | kind << 16 | st << 24 per entry) and its length, requested together: one round trip to the host's row
+struct SvTab { uint32_t w[MAXSV]; int n; };
+CC4_HD SvTab svc_load(const HostDyn& d) {
+  SvTab t;
+  __builtin_memcpy(t.w, d.svcs, sizeof(t.w));
+  t.n = hd_nsvc(d);
+  return t;
+}
+CC4_HD int svw_kind(uint32_t w) { return (int)((w >> 16) & 0xFF); }
+CC4_HD int svw_st(uint32_t w) { return (int)(w >> 24); }
 // The process `pi` of host h (record word pw) dies, whoever asked: the list entry goes, a service process respawns under a
 // new pid, and the session running in it ends (state.get_session_from_pid, State.py:420-443: a blue or green session is
 // recognised by the process kind Host.add_session gave it, a red one by its (host, pid)).
@@ -1137,8 +1179,9 @@ CC4_HD void kill_process(Ctx x, int h, int pi, uint32_t pw) {
   HostDyn& d = x.hd[h];
   const int si = svc_of_pid(d, pid);
   if (si >= 0) {  // service process respawns under a new pid
-    int np = create_pid(x, h);
-    add_proc(x, h, np, kind, pw_flags(pw));
+    const P8N hd0 = proc_head(x, h);
+    int np = create_pid(x, h, hd0);
+    add_proc_n(x, h, hd0.n, np, kind, pw_flags(pw));
     d.svcs[si].pid = (uint16_t)np;     // (the row is marked: remove_proc_at / add_proc above)
   }
   if (owner < 0) return;
@@ -1199,18 +1242,21 @@ CC4_HD void blue_restore(Ctx x, int h) {
 // DecoyAction.execute (ConcreteActions/DecoyActions/DecoyAction.py:47-114) with DeployDecoy candidates (DeployDecoy.py:8-31)
 CC4_HD void blue_decoy(Ctx x, int h) {
   uint32_t cand = 8;  // bit i <=> K_DEC_APACHE + i is compatible; vsftpd checks port 21, which nothing uses (DecoyVsftpd.py:17-20)
-  const int used = proc_ports(x, h);   // Host.is_using_port per factory
+  // everything the action reads of the host -- process list head and length, service table -- is one cache line: one round trip
+  HostDyn& d = x.hd[h];
+  const P8N hd0 = proc_head(x, h);
+  const SvTab sv = svc_load(d);
+  const int used = proc_ports(x, h, hd0);   // Host.is_using_port per factory
   if (!(used & PB_80)) cand |= 1;
   if (!(used & PB_443)) cand |= 2;
   if (!(used & PB_25)) cand |= 4;
   int kind = K_DEC_APACHE + nth_bit(cand, (int)rng_below(x.r, (uint32_t)popc32(cand)));
-  int pid = create_pid(x, h);
-  if (!add_proc(x, h, pid, kind, 0)) return;
+  int pid = create_pid(x, h, hd0);
+  if (!add_proc_n(x, h, hd0.n, pid, kind, 0)) return;
   ev_log(x, 250, h, 2, kind, 0, 0xFF, 0, pid);   // the action's own observation: obs.add_process(pid, parent_pid=1, ...) (DecoyAction.py:105-113)
-  HostDyn& d = x.hd[h];
   int si = -1;
-  const int nsv = hd_nsvc(d);
-  for (int i = 0; i < nsv; ++i) if (d.svcs[i].kind == kind) { si = i; break; }
+  const int nsv = sv.n;
+  CC4_UNROLL for (int i = MAXSV - 1; i >= 0; --i) if (i < nsv && svw_kind(sv.w[i]) == kind) si = i;   // the first one
   if (si < 0) {
     if (nsv >= MAXSV) { set_err(x, E_UNREACHABLE); return; }   // excluded by the port checks (see MAXSV)
     si = nsv; hd_set_nsvc(d, nsv + 1);
@@ -1282,8 +1328,9 @@ CC4_HD void phishing(Ctx x, int gh) {
       }
     }
   }
-  int pid = create_pid(x, gh);
-  if (!add_proc(x, gh, pid, K_SESS_RED, 0)) return;
+  const P8N hd0 = proc_head(x, gh);
+  int pid = create_pid(x, gh, hd0);
+  if (!add_proc_n(x, gh, hd0.n, pid, K_SESS_RED, 0)) return;
   rs_add(x, src, gh, pid, RS_ABSTRACT);
 }
 // What a green agent's action reads from the state, as one 8-byte word that can be computed ahead of the (ordered) resolution
@@ -1406,9 +1453,11 @@ CC4_HD void red_scan(Ctx x, int r, const Act& a, double rate) {
   if (subnet_blocked(x, h_subnet(src), h_subnet(tgt))) { red_result(x, r, a, T_FALSE); return; }
   double fixed = rng_random(x.r);
   int ports = 0;
-  const int np = x.hd[tgt].nproc;
+  const P8N hd0 = proc_head(x, tgt);   // length and first round in one round trip
+  const int np = hd0.n;
   for (int i0 = 0; i0 < np; i0 += 8) {
-    const P8 q = proc_load8(x, tgt, i0);
+    P8 q = p8_of(hd0);
+    if (i0) q = proc_load8(x, tgt, i0);
     CC4_UNROLL for (int k8 = 0; k8 < 8; ++k8) {
       if (i0 + k8 >= np) continue;
       int k = pw_kind(q.v[k8]);
@@ -1425,11 +1474,12 @@ CC4_HD void red_scan(Ctx x, int r, const Act& a, double rate) {
   red_result(x, r, a, T_TRUE);
 }
 // ExploitAction._create_new_session (ExploitActions/ExploitAction.py:212-262): returns new session index or -1
-CC4_HD int exploit_new_session(Ctx x, int r, int parent_sid, int tgt) {
+// hd0: proc_head(x, tgt) as the action read it (nothing has written the target's row since)
+CC4_HD int exploit_new_session(Ctx x, int r, int parent_sid, int tgt, const P8N& hd0) {
   (void)parent_sid;
-  int pid = create_pid(x, tgt);
-  if (!add_proc(x, tgt, pid, K_SHELL, 0)) return -1;
-  hd_set_files(x.hd[tgt], (hd_files(x.hd[tgt]) | HF_CMD) & ~HF_ESC_LAST);   // target_host.files.append(File('cmd.sh', density 0.9)) (ExploitAction.py:230-238)
+  int pid = create_pid(x, tgt, hd0);
+  if (!add_proc_n(x, tgt, hd0.n, pid, K_SHELL, 0)) return -1;
+  x.hd[tgt].nsf = (uint8_t)((hd0.nsf & 0x0F) | ((((hd0.nsf >> 4) | HF_CMD) & ~HF_ESC_LAST) << 4));   // target_host.files.append(File('cmd.sh', density 0.9)) (ExploitAction.py:230-238)
   return rs_add(x, r, tgt, pid, RS_CHILD, x.w->rs_slot[r]);   // Session(parent=self.session) (ExploitAction.py:250-259); slot reserved by rs_reserve
 }
 // ExploitRemoteService.execute (AbstractActions/ExploitRemoteService.py:149-202) + selector (:37-69)
@@ -1442,6 +1492,9 @@ CC4_HD void red_exploit(Ctx x, int r, const Act& a) {
   const uint64_t sw = rs_word(s, slot);
   if (!(rsw_flags(sw) & RS_ABSTRACT)) { red_result(x, r, a, T_FALSE); return; }
   int src = rsw_host(sw), tgt = a.host;
+  // two independent round trips side by side: the session's port knowledge of the target (cold row, HBM) and the target's
+  // process list head (host table: length and first round)
+  const P8N thd0 = proc_head(x, tgt);
   int known = x.c->kports[slot][tgt];
   if (!(known & PB_HAS)) { red_result(x, r, a, T_FALSE); return; }
   if (subnet_blocked(x, h_subnet(src), h_subnet(tgt))) { red_result(x, r, a, T_FALSE); return; }
@@ -1463,7 +1516,7 @@ CC4_HD void red_exploit(Ctx x, int r, const Act& a) {
     sel = nth_bit(opts, (int)rng_below(x.r, (uint32_t)popc32(opts)));
     (void)rng_random(x.r);  // `elif random() < odds_of_top_choice` with odds 0
   }
-  const int tnp = x.hd[tgt].nproc;
+  const int tnp = thd0.n;
   if (sel == X_SSH) {
     // SSHBruteForce.execute (ExploitActions/SSHBruteForce.py:24-84)
     uint8_t* work = reinterpret_cast<uint8_t*>(x.w->scratch + 6 * r);   // 24 bytes per red agent
@@ -1471,7 +1524,8 @@ CC4_HD void red_exploit(Ctx x, int r, const Act& a) {
     for (int i = 0; i < nh; ++i) if (0.050000000000000044 < rng_random(x.r)) { ev_conn(x, work[12 + i]); ev_log(x, 200 + r, work[12 + i], 0, tgt, 0, src, 22, 0); }  // 1 - 0.95 in float64
     int vp = -1;
     for (int i0 = 0; i0 < tnp && vp < 0; i0 += 8) {
-      const P8 q = proc_load8(x, tgt, i0);
+      P8 q = p8_of(thd0);
+      if (i0) q = proc_load8(x, tgt, i0);
       CC4_UNROLL for (int k = 7; k >= 0; --k) if (i0 + k < tnp && pw_kind(q.v[k]) == K_SSHD) vp = i0 + k;
     }
     if (vp < 0) { red_result(x, r, a, T_FALSE); return; }
@@ -1479,7 +1533,7 @@ CC4_HD void red_exploit(Ctx x, int r, const Act& a) {
     const int bf_port = eph_port(x, tgt);         // local_port
     ev_conn(x, tgt);                              // _create_brute_force_event: 10 connection events
     ev_log(x, 200 + r, tgt, 0, tgt, 22, src, bf_port, 0, 10);
-    int ni = exploit_new_session(x, r, a.sid, tgt);
+    int ni = exploit_new_session(x, r, a.sid, tgt, thd0);
     if (ni < 0) { red_result(x, r, a, T_FALSE); return; }
     const uint64_t nw = rs_at(s, A, ni);
     ev_proc_red(x, r, tgt, rsw_pid(nw));       // _create_new_session_event (always for SSH)
@@ -1499,7 +1553,8 @@ CC4_HD void red_exploit(Ctx x, int r, const Act& a) {
                         : sel == X_SQLI ? (1u << K_MYSQL)                                                       // MYSQL @3390
                         : ((1u << K_SMTP) | (1u << K_DEC_HARAKA));                                              // SMTP @25
     for (int i0 = 0; i0 < tnp && vp < 0; i0 += 8) {
-      const P8 q = proc_load8(x, tgt, i0);
+      P8 q = p8_of(thd0);
+      if (i0) q = proc_load8(x, tgt, i0);
       CC4_UNROLL for (int k = 7; k >= 0; --k) if (i0 + k < tnp && ((want >> pw_kind(q.v[k])) & 1u)) { vp = i0 + k; vk = pw_kind(q.v[k]); }
     }
   }
@@ -1513,7 +1568,7 @@ CC4_HD void red_exploit(Ctx x, int r, const Act& a) {
   if (0.0 >= rng_random(x.r)) { red_result(x, r, a, T_FALSE); return; }  // (1 - success_rate) >= random()
   const int lport = eph_port(x, tgt, 2);  // local_port
   if (decoy) { ev_conn(x, tgt); int ep = eph_port(x, tgt, 3); ev_log(x, 200 + r, tgt, 0, tgt, lport, src, ep, 0); red_result(x, r, a, T_FALSE); return; }
-  int ni = exploit_new_session(x, r, a.sid, tgt);
+  int ni = exploit_new_session(x, r, a.sid, tgt, thd0);
   if (ni < 0) { red_result(x, r, a, T_FALSE); return; }
   const uint64_t nw = rs_at(s, A, ni);
   if (rng_random(x.r) > 0.050000000000000044) { ev_proc_red(x, r, tgt, rsw_pid(nw)); ev_log(x, 200 + r, tgt, 1, 0xFF, 0, 0xFF, 0, rsw_pid(nw)); }
@@ -1560,13 +1615,15 @@ CC4_HD void red_impact(Ctx x, int r, const Act& a) {
   int h = a.host;
   if (rs_on_host(s, A, h).first_root < 0) { red_result(x, r, a, T_FALSE); return; }   // no session, or none of them root
   HostDyn& d = x.hd[h];
+  const SvTab sv = svc_load(d);
   int si = -1;
-  for (int i = 0; i < hd_nsvc(d); ++i) if (d.svcs[i].kind == K_OT && (d.svcs[i].st & SV_ACTIVE)) { si = i; break; }
+  uint32_t sw = 0;   // the entry found (kept beside its index: a run-time index into the table would put the table into scratch memory)
+  CC4_UNROLL for (int i = MAXSV - 1; i >= 0; --i) if (i < sv.n && svw_kind(sv.w[i]) == K_OT && (svw_st(sv.w[i]) & SV_ACTIVE)) { si = i; sw = sv.w[i]; }   // the first one
   if (si < 0) { red_result(x, r, a, T_FALSE); return; }
   if (rs_find_id(s, A, a.sid) < 0) { red_result(x, r, a, T_FALSE); return; }  // StopService needs self.session too
   hd_touch(x, h);
-  d.svcs[si].st &= (uint8_t)~SV_ACTIVE;                      // Host.stop_service (Host.py:295-300)
-  int pi = find_proc(x, h, d.svcs[si].pid);                   // State.remove_process (State.py:390-418)
+  d.svcs[si].st = (uint8_t)(svw_st(sw) & ~SV_ACTIVE);          // Host.stop_service (Host.py:295-300)
+  int pi = find_proc(x, h, (int)(sw & 0xFFFF));                 // State.remove_process (State.py:390-418)
   if (pi >= 0) remove_proc_at(x, h, pi);
   obs_put(x, r, false, h, 0, false);
   red_result(x, r, a, T_TRUE);
@@ -1580,9 +1637,10 @@ CC4_HD void red_degrade(Ctx x, int r, const Act& a) {
   HostDyn& d = x.hd[h];
   int n = 0;
   hd_touch(x, h);
-  for (int i = 0; i < hd_nsvc(d); ++i) if (d.svcs[i].st & SV_ACTIVE) {
+  const SvTab sv = svc_load(d);
+  CC4_UNROLL for (int i = 0; i < MAXSV; ++i) if (i < sv.n && (svw_st(sv.w[i]) & SV_ACTIVE)) {
     n++;
-    int rel = d.svcs[i].st & 0x7F;
+    int rel = svw_st(sv.w[i]) & 0x7F;
     if (rel > 0) rel--;                                       // Service.degrade_service_reliability (Service.py:33-40)
     d.svcs[i].st = (uint8_t)(SV_ACTIVE | rel);
   }
@@ -1596,9 +1654,11 @@ CC4_HD void red_deception(Ctx x, int r, const Act& a) {
   RedAgent& A = s->red[r];
   if (rs_find_id(s, A, a.sid) < 0) { red_result(x, r, a, T_FALSE); return; }
   int tgt = a.host;
-  const int np = x.hd[tgt].nproc;
+  const P8N hd0 = proc_head(x, tgt);   // length and first round in one round trip
+  const int np = hd0.n;
   for (int i0 = 0; i0 < np; i0 += 8) {
-    const P8 q = proc_load8(x, tgt, i0);
+    P8 q = p8_of(hd0);
+    if (i0) q = proc_load8(x, tgt, i0);
     CC4_UNROLL for (int k = 0; k < 8; ++k) {
       if (i0 + k >= np) continue;
       bool decoy = kind_is_decoy(pw_kind(q.v[k]));

@@ -854,7 +854,9 @@ __global__ __launch_bounds__(PT, MINW) void k_step_philox(StepArgs a) {
           Ctx xb{s, cold_e, &rl, hd, &work, nullptr, nullptr, lg};
           const uint4 blk = reinterpret_cast<const uint4*>(reset_ws)[MAXG + NRED + bagent];
           const uint32_t pre[4] = {blk.x, blk.y, blk.z, blk.w};
+          const unsigned long long tb0 = a.prof ? clock64() : 0;
           step_blue_exec_agent(xb, bagent, pre);
+          if (a.prof) { unsigned long long* tp = a.prof + PROF_SLOTS * (size_t)e + 108 + 2 * (s->bexec[bagent].type & 7); atomicAdd(tp, (unsigned long long)(clock64() - tb0)); atomicAdd(tp + 1, 1ull); }   // debug: blue action cycles by type
         }
         __syncthreads();
         if (tid == 0) CC4_TICK(x0, 5);

@@ -28,4 +28,10 @@ if tt[:, 1].sum() > 0:
     for i in range(16):
         if tt[i, 1] > 0:
             print(f'  {ty[i]:10s} {tt[i, 1] / (n * K):6.3f}  {tt[i, 0] / tt[i, 1]:8.0f}')
+bt = out[:, 108:124].astype(np.float64).reshape(n, 8, 2).sum(0)
+if bt[:, 1].sum() > 0:
+    print('blue action execution (four-wave kernel, independent case): type, count per episode-step, mean cycles')
+    for i, nm in enumerate(['Sleep', 'Monitor', 'Analyse', 'Remove', 'Restore', 'DeployDecoy', 'Block', 'Allow']):
+        if bt[i, 1] > 0:
+            print(f'  {nm:11s} {bt[i, 1] / (n * K):6.3f}  {bt[i, 0] / bt[i, 1]:8.0f}')
 print('green action waves (AccessService list, LocalWork list): mean cycles', (out[:, 96].mean() / K).round(), (out[:, 97].mean() / K).round())
