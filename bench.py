@@ -403,7 +403,7 @@ def main():
         if not dist_on and not args.no_alt:
             out.update(host_api_rates())
         if not dist_on and not args.no_cpu_baseline:
-            out['cpu_baseline'] = cpu_baseline(1024, args.seed0)
+            out['cpu_baseline'] = cpu_baseline(4096, args.seed0)   # ~15 s of CPU work (16 cores x ~0.8 s + one core x ~1.5 s)
         print(json.dumps(out), flush=True)
     env.close()
     plane.close()
