@@ -277,7 +277,9 @@ def main():
                 res['err'] = repr(ex)
         th = threading.Thread(target=_setup, daemon=True)
         th.start()
-        th.join(float(os.environ.get('CC4_RCCL_SETUP_TIMEOUT', '240')))
+        # (a fresh box pages librccl.so in on first use: ncclCommInitRank has been seen to take 200-250 s there, seconds afterwards --
+        # profiles/r03_exchange_streams_ab.txt; a fallback taken while the setup thread is still alive also runs beside its streams)
+        th.join(float(os.environ.get('CC4_RCCL_SETUP_TIMEOUT', '900')))
         ok = plane.allreduce([1.0 if res.get('ok') else 0.0], 'min')
         if int(ok[0]) == 0:
             exchange_note = 'none (RCCL setup failed or timed out on a rank: %s)' % res.get('err', 'ok here' if res.get('ok') else 'timeout')

@@ -1579,6 +1579,11 @@ int cc4_create(const cc4_config* cfg, cc4_handle** out) {
       h->gstream[3] = nullptr;
     }
   }
+  if (!h->auto_groups && getenv("CC4_EXP_PROBE")) {   // experiment: explicit groups, but the streams / probe of the automatic path exist as well
+    hipStream_t tmp[4];
+    for (int g = 0; g < 4; ++g) { if (g < h->ngroups) tmp[g] = h->gstream[g]; else HIPCHK(h, hipStreamCreateWithFlags(&tmp[g], hipStreamNonBlocking)); }
+    if (atoi(getenv("CC4_EXP_PROBE")) > 1) (void)streams_run_concurrently(tmp, 4);
+  }
   size_t n = (size_t)cfg->num_envs;
   HIPCHK(h, hipMalloc(&h->d_state, n * sizeof(EnvState)));
   h->cold_row = cold_row_bytes(cfg->steps);
@@ -1925,7 +1930,8 @@ int cc4_comm_init(cc4_handle* h, int32_t rank, int32_t world, const void* id128)
     // host several times what it costs without; small shards then run into the host.  Measured on MI355X with the exchange on a
     // one-rank communicator (r03, profiles/r03_exchange_groups_world1.txt; M agent-env steps/s, 1 / 2 / 3 launches per step):
     // 1024 episodes 159 / 104 / 111, 2048: 242 / 179 / 220, 4096: 380 / 282 / 420, 8192: 478 / 498 / 607.
-    const int ng = h->cfg.num_envs >= 4096 ? 3 : 1;      // (8192 episodes with the exchange, 3 / 4 launches per step: 563 / 509 M)
+    int ng = h->cfg.num_envs >= 4096 ? 3 : 1;      // (8192 episodes with the exchange, 3 / 4 launches per step: 563 / 509 M)
+    if (const char* v = getenv("CC4_EXCHANGE_GROUPS")) { ng = atoi(v); if (ng <= 0 || ng > h->ngroups) ng = h->ngroups; }   // tuning override: 0 = keep the handle's groups
     if (ng != h->ngroups) {
       if (sync_all(h)) return -1;
       const int old = h->ngroups;
