@@ -45,7 +45,7 @@ class FilePlane(SoloPlane):
     read all files of operation q knows every rank has finished operation q - 1, and removes its own file of that one."""
     kind = 'file'
 
-    def __init__(self, rank, world, key, root=None, timeout=900.0):
+    def __init__(self, rank, world, key, root=None, timeout=2000.0):   # longer than bench.py's RCCL setup watchdog (900 s)
         self.rank, self.world, self.timeout = int(rank), int(world), float(timeout)
         root = root or os.environ.get('CC4_CONTROL_PLANE_DIR') or ('/dev/shm' if os.path.isdir('/dev/shm') else '/tmp')
         self.dir = os.path.join(root, f'cc4_plane_{key}')
