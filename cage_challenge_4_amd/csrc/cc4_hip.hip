@@ -1310,6 +1310,7 @@ struct cc4_handle {
   uint8_t* d_all_obs8[OBS_RING] = {};
   long long gather_seq[OBS_RING] = {};           // sequence number of the last all-gather that read buffer b (0 = none)
   long long gathers_issued = 0, gathers_waited = 0;
+  hipEvent_t tev_start[cc4_handle_max_groups] = {}, tev_stop[cc4_handle_max_groups] = {};   // timing events the NEXT launch of a group carries (cc4_run_random_steps)
   long long comm_delay_ticks = 0;                // debug: spin this long on the communication stream ahead of every all-gather
   long long gather_stalls = 0;                   // a step launch found the all-gather it had to wait for still running
   long long stat_steps = 0; double stat_launch_us = 0, stat_gather_us = 0;   // cc4_host_stats
@@ -1475,22 +1476,24 @@ static int launch_step(cc4_handle* h, const int32_t* d_actions, const uint8_t* d
     hipStream_t st = h->gstream[g];
     // with a communicator, the launch carries ev_step[buf][g] as its stop event: the event rides on the kernel's own completion
     // signal, where a separate hipEventRecord would put a marker packet between two step kernels (~5 us of idle stream time)
-    hipEvent_t stop = h->comm ? h->ev_step[buf][g] : nullptr;
+    hipEvent_t stop = h->comm ? h->ev_step[buf][g] : h->tev_stop[g];
+    hipEvent_t start = h->comm ? nullptr : h->tev_start[g];        // timing rides on the kernels' own signals too: no marker packets
+    h->tev_start[g] = h->tev_stop[g] = nullptr;
     if (h->cfg.rng_mode == 1) {
       if (h->philox_lean) {
-        if (h->evlog_on) hipExtLaunchKernelGGL(k_step_philox1<true>, grid, dim3(WAVE), offsetof(EnvState, hd), st, nullptr, stop, 0, a);
-        else hipExtLaunchKernelGGL(k_step_philox1<false>, grid, dim3(WAVE), offsetof(EnvState, hd), st, nullptr, stop, 0, a);
+        if (h->evlog_on) hipExtLaunchKernelGGL(k_step_philox1<true>, grid, dim3(WAVE), offsetof(EnvState, hd), st, start, stop, 0, a);
+        else hipExtLaunchKernelGGL(k_step_philox1<false>, grid, dim3(WAVE), offsetof(EnvState, hd), st, start, stop, 0, a);
       }
-      else if (h->evlog_on) hipExtLaunchKernelGGL((k_step_philox<true, 1>), grid, dim3(PT), sizeof(EnvState), st, nullptr, stop, 0, a);
-      else if (h->philox_minw == 8) hipExtLaunchKernelGGL((k_step_philox<false, 8>), grid, dim3(PT), sizeof(EnvState), st, nullptr, stop, 0, a);
-      else if (h->philox_minw == 7) hipExtLaunchKernelGGL((k_step_philox<false, 7>), grid, dim3(PT), sizeof(EnvState), st, nullptr, stop, 0, a);
+      else if (h->evlog_on) hipExtLaunchKernelGGL((k_step_philox<true, 1>), grid, dim3(PT), sizeof(EnvState), st, start, stop, 0, a);
+      else if (h->philox_minw == 8) hipExtLaunchKernelGGL((k_step_philox<false, 8>), grid, dim3(PT), sizeof(EnvState), st, start, stop, 0, a);
+      else if (h->philox_minw == 7) hipExtLaunchKernelGGL((k_step_philox<false, 7>), grid, dim3(PT), sizeof(EnvState), st, start, stop, 0, a);
 #ifndef CC4_SMALL_MINW
 #define CC4_SMALL_MINW 1
 #endif
-      else hipExtLaunchKernelGGL((k_step_philox<false, CC4_SMALL_MINW>), grid, dim3(PT), sizeof(EnvState), st, nullptr, stop, 0, a);
+      else hipExtLaunchKernelGGL((k_step_philox<false, CC4_SMALL_MINW>), grid, dim3(PT), sizeof(EnvState), st, start, stop, 0, a);
     } else {
-      if (h->evlog_on) hipExtLaunchKernelGGL(k_step<true>, grid, dim3(WAVE), offsetof(EnvState, hd), st, nullptr, stop, 0, a);
-      else hipExtLaunchKernelGGL(k_step<false>, grid, dim3(WAVE), offsetof(EnvState, hd), st, nullptr, stop, 0, a);
+      if (h->evlog_on) hipExtLaunchKernelGGL(k_step<true>, grid, dim3(WAVE), offsetof(EnvState, hd), st, start, stop, 0, a);
+      else hipExtLaunchKernelGGL(k_step<false>, grid, dim3(WAVE), offsetof(EnvState, hd), st, start, stop, 0, a);
     }
     HIPCHK(h, hipGetLastError());
   }
@@ -1763,8 +1766,17 @@ int cc4_run_random_steps(cc4_handle* h, uint64_t seed0, uint32_t t0, int32_t k, 
   const bool hp = getenv("CC4_HOST_PROF") != nullptr;
   double t_launch = 0, t_ag = 0;
   const long long stalls0 = h->gather_stalls;
+  // Without a communicator the two timing events of a stream ride on its first and its last launch of the call (start / stop
+  // event of hipExtLaunchKernelGGL: the kernels' own start and completion timestamps) -- marker packets from hipEventRecord cost
+  // the streams 0.5 us per step at k = 500 and 1.2 us per step at k = 20 (tools/short_region_probe.py).  CC4_TIMING_MARKERS=1
+  // keeps the marker form; with a communicator the launches' stop events belong to the exchange and the markers stay.
+  const bool attach = ms_step_kernels && !h->comm && !getenv("CC4_TIMING_MARKERS");
   for (int i = 0; i < k; ++i) {
-    if (ms_step_kernels && i % TIMED_CHUNK == 0) {
+    if (attach) {
+      if (i == 0) for (int g = 0; g < G; ++g) h->tev_start[g] = ev(0, g, 0);
+      if (i == k - 1) for (int g = 0; g < G; ++g) h->tev_stop[g] = ev(0, g, 1);
+    }
+    if (ms_step_kernels && !attach && i % TIMED_CHUNK == 0) {
       if (G > 1 && h->main_ahead) {     // the group streams' first event must not be recorded ahead of what their first launch waits for
         HIPCHK(h, hipEventRecord(h->mev, h->stream));
         for (int g = 1; g < G; ++g) HIPCHK(h, hipStreamWaitEvent(h->gstream[g], h->mev, 0));
@@ -1775,7 +1787,7 @@ int cc4_run_random_steps(cc4_handle* h, uint64_t seed0, uint32_t t0, int32_t k, 
     auto c0 = std::chrono::steady_clock::now();
     if (launch_step(h, nullptr, nullptr, true, seed0, t0 + (uint32_t)i)) return -1;   // actions drawn in-kernel
     auto c1 = std::chrono::steady_clock::now();
-    if (ms_step_kernels && (i % TIMED_CHUNK == TIMED_CHUNK - 1 || i == k - 1))
+    if (ms_step_kernels && !attach && (i % TIMED_CHUNK == TIMED_CHUNK - 1 || i == k - 1))
       for (int g = 0; g < G; ++g) HIPCHK(h, hipEventRecord(ev(i / TIMED_CHUNK, g, 1), h->gstream[g]));
     auto c2 = std::chrono::steady_clock::now();
     if (h->comm) { if (cc4_allgather_obs(h, nullptr)) return -1; }                       // overlaps the next step
@@ -1785,13 +1797,22 @@ int cc4_run_random_steps(cc4_handle* h, uint64_t seed0, uint32_t t0, int32_t k, 
   }
   h->stat_steps += k; h->stat_launch_us += t_launch; h->stat_gather_us += t_ag;
   if (hp) fprintf(stderr, "[cc4 host prof] k=%d launch_step %.2f us/step (%d launches per step), allgather enqueue %.2f us/step, %lld buffer-reuse stalls\n", k, t_launch / k, G, t_ag / k, h->gather_stalls - stalls0);
+  auto p0 = std::chrono::steady_clock::now();
   if (h->comm) HIPCHK(h, hipStreamSynchronize(h->comm_stream));
   if (sync_all(h)) return -1;
+  auto p1 = std::chrono::steady_clock::now();
+  if (hp) {
+    auto q0 = std::chrono::steady_clock::now();
+    if (sync_all(h)) return -1;
+    auto q1 = std::chrono::steady_clock::now();
+    fprintf(stderr, "[cc4 host prof] enqueue loop done -> all streams synchronised: %.1f us; a second sync_all on idle streams: %.1f us\n",
+            std::chrono::duration<double, std::micro>(p1 - p0).count(), std::chrono::duration<double, std::micro>(q1 - q0).count());
+  }
   if (ms_step_kernels) {
     float worst = 0.f;
     for (int g = 0; g < G; ++g) {
       float total = 0.f;
-      for (int c = 0; c < nchunks; ++c) {
+      for (int c = 0; c < (attach ? 1 : nchunks); ++c) {
         float ms = 0.f;
         HIPCHK(h, hipEventElapsedTime(&ms, ev(c, g, 0), ev(c, g, 1)));
         total += ms;
@@ -1799,6 +1820,7 @@ int cc4_run_random_steps(cc4_handle* h, uint64_t seed0, uint32_t t0, int32_t k, 
       if (total > worst) worst = total;
     }
     *ms_step_kernels = worst;
+    if (hp) fprintf(stderr, "[cc4 host prof] reading the timing events: %.1f us\n", std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - p1).count());
   }
   return 0;
 }
