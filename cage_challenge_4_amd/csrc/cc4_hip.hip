@@ -1764,7 +1764,7 @@ int cc4_run_random_steps(cc4_handle* h, uint64_t seed0, uint32_t t0, int32_t k, 
   }
   auto ev = [&](int chunk, int g, int which) { return h->evs[(size_t)(2 * (chunk * G + g) + which)]; };
   const bool hp = getenv("CC4_HOST_PROF") != nullptr;
-  double t_launch = 0, t_ag = 0;
+  double t_launch = 0, t_ag = 0, t_first = 0;
   const long long stalls0 = h->gather_stalls;
   // Without a communicator the two timing events of a stream ride on its first and its last launch of the call (start / stop
   // event of hipExtLaunchKernelGGL: the kernels' own start and completion timestamps) -- marker packets from hipEventRecord cost
@@ -1793,10 +1793,11 @@ int cc4_run_random_steps(cc4_handle* h, uint64_t seed0, uint32_t t0, int32_t k, 
     if (h->comm) { if (cc4_allgather_obs(h, nullptr)) return -1; }                       // overlaps the next step
     auto c3 = std::chrono::steady_clock::now();
     t_launch += std::chrono::duration<double, std::micro>(c1 - c0).count();
+    if (i == 0) t_first = std::chrono::duration<double, std::micro>(c1 - c0).count();
     t_ag += std::chrono::duration<double, std::micro>(c3 - c2).count();
   }
   h->stat_steps += k; h->stat_launch_us += t_launch; h->stat_gather_us += t_ag;
-  if (hp) fprintf(stderr, "[cc4 host prof] k=%d launch_step %.2f us/step (%d launches per step), allgather enqueue %.2f us/step, %lld buffer-reuse stalls\n", k, t_launch / k, G, t_ag / k, h->gather_stalls - stalls0);
+  if (hp) fprintf(stderr, "[cc4 host prof] k=%d launch_step %.2f us/step (%d launches per step), allgather enqueue %.2f us/step, %lld buffer-reuse stalls; the call's first launch_step %.1f us\n", k, t_launch / k, G, t_ag / k, h->gather_stalls - stalls0, t_first);
   auto p0 = std::chrono::steady_clock::now();
   if (h->comm) HIPCHK(h, hipStreamSynchronize(h->comm_stream));
   if (sync_all(h)) return -1;
