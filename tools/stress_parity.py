@@ -1,6 +1,6 @@
 #!/usr/bin/env python
 """Race hunt: repeated full-batch parity runs (HIP path vs CPU oracle, every step, every episode) with different seeds,
-policies and RNG modes.  usage: stress_parity.py [rounds] [envs] [steps] [episode_steps]"""
+policies and RNG modes.  usage: stress_parity.py [rounds] [envs] [steps] [episode_steps] [seed_base]"""
 import os, sys
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -11,12 +11,13 @@ rounds = int(sys.argv[1]) if len(sys.argv) > 1 else 6
 n = int(sys.argv[2]) if len(sys.argv) > 2 else 1024
 T = int(sys.argv[3]) if len(sys.argv) > 3 else 220
 EP = int(sys.argv[4]) if len(sys.argv) > 4 else 150   # episode length (autoreset after it)
+SEED_BASE = int(sys.argv[5]) if len(sys.argv) > 5 else 50000
 bad = 0
 for k in range(rounds):
     # (rng mode, red policy, counter-mode kernel: 0 = four wavefronts per episode, 1 = one)
     # ... and, last field, the built-in blue policy (acts for the agents whose action index is negative: every third here)
     for mode, rp, lean, bp in ((1, 0, 0, 0), (1, 0, 1, 0), (1, 3, 1, 1), (0, 0, 0, 0), (1, 2, 0, 1), (1, 2, 1, 0), (0, 3, 0, 1), (0, 2, 0, 0)):
-        seed = 50000 + 1000 * k + 17 * mode + rp
+        seed = SEED_BASE + 1000 * k + 17 * mode + rp
         os.environ['CC4_PHILOX_LEAN'] = str(lean)
         dev = CC4VecEnv(n, steps=EP, rng_mode=mode, autoreset=True, red_policy=rp, blue_policy=bp)
         ora = OracleVecEnv(n, steps=EP, rng_mode=mode, autoreset=True, red_policy=rp, blue_policy=bp)
