@@ -100,17 +100,35 @@ class FilePlane(SoloPlane):
         return [json.loads(b.decode()) for b in self.exchange(json.dumps(obj).encode())]
 
     def close(self):
-        self.barrier()                       # nobody still reads when the files go
-        for q in (self.seq - 1, self.seq - 2):
+        """Final barrier, then the files go -- but a rank's file of the LAST operation may not be removed by that rank: a peer may
+        still be about to read it (that race, lost, left the peer spinning in its last barrier until the timeout).  So every other
+        rank reports `done_r` once it is through, and rank 0 -- after all of them did, or leaving everything in place after 10 s --
+        removes the directory's files."""
+        self.barrier()
+        if self.rank != 0:
+            mine = os.path.join(self.dir, f'done_{self.rank}')
             try:
-                os.remove(self._path(q, self.rank))
+                with open(mine + '.tmp', 'wb') as f:
+                    f.write(b'1')
+                os.replace(mine + '.tmp', mine)
             except OSError:
                 pass
-        if self.rank == 0:
-            try:
-                os.rmdir(self.dir)
-            except OSError:
-                pass
+            return
+        t0 = time.monotonic()
+        want = [os.path.join(self.dir, f'done_{r}') for r in range(1, self.world)]
+        while not all(os.path.exists(p) for p in want):
+            if time.monotonic() - t0 > 10.0:
+                return
+            time.sleep(0.001)
+        try:
+            for name in os.listdir(self.dir):
+                try:
+                    os.remove(os.path.join(self.dir, name))
+                except OSError:
+                    pass
+            os.rmdir(self.dir)
+        except OSError:
+            pass
 
 
 class GlooPlane(SoloPlane):

@@ -33,3 +33,44 @@ def test_two_ranks_over_the_torch_free_control_plane(oracle_lib, tmp_path):
     assert all(p.returncode == 0 for p in procs), '\n'.join(o[0][-1500:] + o[1][-1500:] for o in outs)
     assert 'PLANE_OK' in outs[0][0]
     assert not [f for f in os.listdir(tmp_path) if os.listdir(os.path.join(tmp_path, f))]      # the ranks cleaned up behind them
+
+
+def _plane_close_worker(r, w, key, late, out):
+    import time
+    from cage_challenge_4_amd.distributed import FilePlane
+    p = FilePlane(r, w, key, timeout=20.0)
+    for _ in range(20):
+        p.barrier()
+    v = p.allreduce([r], 'sum')
+    if r == late:
+        time.sleep(0.05)          # one rank late into the last barrier: its peers must not take their files of it away
+    p.close()
+    out.put((r, v[0]))
+
+
+def test_file_plane_close_does_not_strand_a_late_rank():
+    """FilePlane.close used to remove a rank's file of the final barrier as soon as that rank was through; a peer that had not
+    read it yet then span until the plane's timeout (seen on the GPU box: `bench.py --gpus 2` printed its line and one rank never
+    exited).  Now the other ranks report `done_r` and rank 0 removes the files."""
+    import multiprocessing as mp
+    import os
+    import time
+    ctx = mp.get_context('spawn')
+    for trial in range(6):
+        q = ctx.Queue()
+        key = f'closetest_{os.getpid()}_{trial}'
+        ps = [ctx.Process(target=_plane_close_worker, args=(r, 3, key, trial % 3, q)) for r in range(3)]
+        t0 = time.time()
+        for p in ps:
+            p.start()
+        for p in ps:
+            p.join(60)
+        alive = [p for p in ps if p.is_alive()]
+        for p in alive:
+            p.kill()
+        assert not alive, f'trial {trial}: {len(alive)} rank(s) stuck in close()'
+        got = sorted(q.get(timeout=5) for _ in range(3))
+        assert got == [(0, 3.0), (1, 3.0), (2, 3.0)]
+        root = '/dev/shm' if os.path.isdir('/dev/shm') else '/tmp'
+        assert not os.path.exists(os.path.join(root, f'cc4_plane_{key}'))
+        assert time.time() - t0 < 60
