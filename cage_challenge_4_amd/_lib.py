@@ -29,6 +29,17 @@ class CC4Config(ctypes.Structure):
                 ('green_policy', ctypes.c_int32), ('topology_seed', ctypes.c_int32), ('blue_policy', ctypes.c_int32)]
 
 
+class AgentAction(ctypes.Structure):
+    """cc4_agent_action (include/cc4.h): one submitted red / green action of cc4_step_ex."""
+    _fields_ = [('type', ctypes.c_int8), ('host', ctypes.c_uint8), ('arg', ctypes.c_uint8), ('ticks', ctypes.c_uint8),
+                ('session', ctypes.c_uint16), ('flags', ctypes.c_uint8), ('pad', ctypes.c_uint8),
+                ('rate0', ctypes.c_double), ('rate1', ctypes.c_double)]
+
+
+NUM_RED, MAX_GREEN = 6, 80
+AGENT_ACTION_DTYPE = [('type', 'i1'), ('host', 'u1'), ('arg', 'u1'), ('ticks', 'u1'), ('session', 'u2'), ('flags', 'u1'), ('pad', 'u1'),
+                      ('rate0', 'f8'), ('rate1', 'f8')]          # numpy view of the same 24-byte record
+
 # every entry point declared in include/cc4.h : (restype, argtypes)
 _P = ctypes.c_void_p
 SIGNATURES = {
@@ -38,6 +49,8 @@ SIGNATURES = {
     'cc4_last_error': (ctypes.c_char_p, [_P]),
     'cc4_reset': (ctypes.c_int, [_P, _P, _P]),
     'cc4_step': (ctypes.c_int, [_P, _P, _P]),
+    'cc4_step_ex': (ctypes.c_int, [_P, _P, _P, _P, _P]),
+    'cc4_edit_state': (ctypes.c_int, [_P, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32]),
     'cc4_get_obs': (ctypes.c_int, [_P, _P]),
     'cc4_get_reward_done': (ctypes.c_int, [_P, _P, _P]),
     'cc4_get_action_mask': (ctypes.c_int, [_P, _P]),
@@ -50,6 +63,7 @@ SIGNATURES = {
     'cc4_reward_device': (ctypes.c_int, [_P, ctypes.POINTER(_P)]),
     'cc4_done_device': (ctypes.c_int, [_P, ctypes.POINTER(_P)]),
     'cc4_actions_device': (ctypes.c_int, [_P, ctypes.POINTER(_P)]),
+    'cc4_get_actions': (ctypes.c_int, [_P, _P]),
     'cc4_random_actions_device': (ctypes.c_int, [_P, ctypes.c_uint64, ctypes.c_uint32]),
     'cc4_synchronize': (ctypes.c_int, [_P]),
     'cc4_run_random_steps': (ctypes.c_int, [_P, ctypes.c_uint64, ctypes.c_uint32, ctypes.c_int32, ctypes.POINTER(ctypes.c_float)]),

@@ -15,7 +15,11 @@ namespace cc4 {
 // gpre: per green agent, what its action needs from the state (green_prepare), computed ahead by other lanes; null: computed
 // where it is needed
 struct Ctx { EnvState* s; EnvCold* c; Rng* r; HostDyn* hd; StepWork* w; unsigned long long* prof = nullptr;
-             unsigned long long* aprof = nullptr; EvLog* lg = nullptr; const uint64_t* gpre = nullptr; };
+             unsigned long long* aprof = nullptr; EvLog* lg = nullptr; const uint64_t* gpre = nullptr;
+             // this episode's externally submitted red / green actions (ExtAct[EXT_PER_ENV], cc4_state.h), or null: the builds of the
+             // step that serve them are the "full" ones (the same template parameter as the event log), so that on the fast path
+             // every test of it folds away
+             const ExtAct* ext = nullptr; };
 
 // optional phase timing (device only, debug builds of the kernel pass a buffer): prof[i] += cycles since last tick
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -1070,6 +1074,16 @@ CC4_HD Act blue_decode(const EnvState* s, int b, int idx) {
     // (as it does from cc4BlueRandomAgent).  A host outside the agent's subnets or the episode's topology is not in its action
     // space: InvalidAction (SimulationController.py:1068-1112), which resolves like Sleep.
     const int t = (idx >> 8) & 0xF, h = idx & 0xFF;
+    if (t == BA_BLOCK || t == BA_ALLOW) {
+      // Block/AllowTrafficZone(from_subnet, to_subnet) as an object may name ANY pair: neither parameter is an ActionSpace key, so
+      // the validity check lets it through (SC:1094-1096; Tests/test_cc4/test_BlueRewardMachine.py:133-137 has blue_agent_0 block
+      // every subnet); host id field = to-subnet | from-subnet << 4
+      const int to = h & 0xF, from = h >> 4;
+      if (to >= NSUB || from >= NSUB) return a;
+      a.type = (uint8_t)t; a.host = (uint8_t)to; a.arg = (uint8_t)from;
+      return a;
+    }
+    if (t == BA_MONITOR) { a.type = BA_MONITOR; return a; }
     if (t < BA_ANALYSE || t > BA_DECOY || h >= H_INTERNET || !bit_get(s->exists, h) || blue_of_subnet(h_subnet(h)) != b) return a;
     a.type = (uint8_t)t; a.host = (uint8_t)h;
     return a;
@@ -1349,7 +1363,14 @@ CC4_HD uint64_t green_prepare(Ctx x, int g, int act) {
     const int nsvc = hd_nsvc(d);
     CC4_UNROLL for (int i = 0; i < MAXSV; ++i) if (i < nsvc) w |= (uint64_t)(sv[i] >> 24) << (8 * i);
   } else if (act == 0) {
-    const uint32_t allowed = green_allowed_mask(s->phase, h_subnet(gh));
+    // agent_interface.allowed_subnets of the mission phase (EnterpriseGreenAgent hands them to the action), or the list a submitted
+    // GreenAccessService came with (ExtAct.sid as a subnet mask: a green action's session_id is always 0)
+    // (a source subnet outside the list reaches only itself: GreenAccessService.py:96-103)
+    uint32_t allowed = green_allowed_mask(s->phase, h_subnet(gh));
+    if (x.ext && x.ext[NRED + g].type == XG_ACCESS && x.ext[NRED + g].sid) {
+      allowed = (uint32_t)x.ext[NRED + g].sid;
+      if (!((allowed >> h_subnet(gh)) & 1u)) allowed = 1u << h_subnet(gh);
+    }
     uint64_t ns;   // server counts of subnets 0..7 (the internet subnet has none), one batch of loads
     __builtin_memcpy(&ns, s->n_servers, 8);
     int n = 0;
@@ -1372,19 +1393,19 @@ CC4_HD uint32_t green_lw_active(uint64_t pre) {
   return act;
 }
 // GreenLocalWork.execute (GreenActions/GreenLocalWork.py:60-125). returns success.  pre: green_prepare's word
-CC4_HD bool green_local_work(Ctx x, int gh, uint64_t pre, bool* want_phish) {
+CC4_HD bool green_local_work(Ctx x, int gh, uint64_t pre, bool* want_phish, double fp_rate = 0.01, double phish_rate = 0.01) {
   const uint32_t act = green_lw_active(pre);
   if (!act) return false;
   const int c = nth_bit(act, (int)rng_below(x.r, (uint32_t)popc32(act)));   // choice over the active services, table order
   const uint32_t st = (uint32_t)(pre >> (8 * c)) & 0xFF;
   int rel = (int)(st & 0x7F) * 20;
   if ((int)rng_below(x.r, 100) >= rel) return false;
-  if (rng_random(x.r) < 0.01) { int port = eph_port(x, gh); ev_proc(x, gh, 0); ev_log(x, gh, gh, 1, gh, port, 0xFF, 0, 0); }   // pc = {local_address, local_port} (GreenLocalWork.py:112-115)
-  if (rng_random(x.r) < 0.01) *want_phish = true;  // PhishingEmail sub-action: executed by the caller (ordering, see P5)
+  if (rng_random(x.r) < fp_rate) { int port = eph_port(x, gh); ev_proc(x, gh, 0); ev_log(x, gh, gh, 1, gh, port, 0xFF, 0, 0); }   // pc = {local_address, local_port} (GreenLocalWork.py:112-115)
+  if (rng_random(x.r) < phish_rate) *want_phish = true;  // PhishingEmail sub-action: executed by the caller (ordering, see P5)
   return true;
 }
 // GreenAccessService.execute (GreenActions/GreenAccessService.py:137-217). returns success.  pre: green_prepare's word
-CC4_HD bool green_access_service(Ctx x, int gh, uint64_t pre) {
+CC4_HD bool green_access_service(Ctx x, int gh, uint64_t pre, double fp_rate = 0.01) {
   int own = h_subnet(gh);
   const int n = (int)(pre >> 56);
   const int c = (int)rng_below(x.r, (uint32_t)n);
@@ -1394,7 +1415,7 @@ CC4_HD bool green_access_service(Ctx x, int gh, uint64_t pre) {
   int ds = sn;
   // events land on the destination server (`from_host` in the reference, GreenAccessService.py:176-214)
   if (subnet_blocked(x, ds, own) || subnet_blocked(x, own, ds)) { ev_conn(x, dest); ev_log(x, gh, dest, 0, dest, 0, gh, 8800, 0); return false; }
-  if (rng_random(x.r) < 0.01) { ev_conn(x, dest); ev_log(x, gh, dest, 0, gh, 0, dest, dest_port, 0); }
+  if (rng_random(x.r) < fp_rate) { ev_conn(x, dest); ev_log(x, gh, dest, 0, gh, 0, dest, dest_port, 0); }
   return true;
 }
 
@@ -1654,6 +1675,9 @@ CC4_HD void red_deception(Ctx x, int r, const Act& a) {
   RedAgent& A = s->red[r];
   if (rs_find_id(s, A, a.sid) < 0) { red_result(x, r, a, T_FALSE); return; }
   int tgt = a.host;
+  // detection_rate / fp_rate (DiscoverDeception.py:40-41), or the ones the action object came with (ExtAct)
+  const double det_rate = (x.ext && (a.busy & AQ_RATE0)) ? x.c->xrate[r][0] : 0.5;
+  const double fp_rate = (x.ext && (a.busy & AQ_RATE1)) ? x.c->xrate[r][1] : 0.1;
   const P8N hd0 = proc_head(x, tgt);   // length and first round in one round trip
   const int np = hd0.n;
   for (int i0 = 0; i0 < np; i0 += 8) {
@@ -1663,8 +1687,8 @@ CC4_HD void red_deception(Ctx x, int r, const Act& a) {
       if (i0 + k >= np) continue;
       bool decoy = kind_is_decoy(pw_kind(q.v[k]));
       bool rep = false;
-      if (rng_random(x.r) <= 0.5 && decoy) rep = true;
-      else if (rng_random(x.r) <= 0.1 && !decoy) rep = true;
+      if (rng_random(x.r) <= det_rate && decoy) rep = true;
+      else if (rng_random(x.r) <= fp_rate && !decoy) rep = true;
       if (rep) obs_put(x, r, false, tgt, OE_IFACE, false);
     }
   }
@@ -1754,8 +1778,9 @@ CC4_HD void red_withdraw(Ctx x, int r, const Act& a) {
 CC4_HD void red_execute(Ctx x, int r, const Act& a) {
   switch (a.type) {
     case RA_DRS: red_drs(x, r, a); break;
-    case RA_AGGR: red_scan(x, r, a, 0.75); break;
-    case RA_STEALTH: red_scan(x, r, a, 0.25); break;
+    // detection_rate: the class's own, or the one the action object came with (ExtAct: the reference's tests set it to 0 and 1)
+    case RA_AGGR: red_scan(x, r, a, (x.ext && (a.busy & AQ_RATE0)) ? x.c->xrate[r][0] : 0.75); break;
+    case RA_STEALTH: red_scan(x, r, a, (x.ext && (a.busy & AQ_RATE0)) ? x.c->xrate[r][0] : 0.25); break;
     case RA_DECEPTION: red_deception(x, r, a); break;
     case RA_EXPLOIT: red_exploit(x, r, a); break;
     case RA_PRIVESC: red_privesc(x, r, a); break;
@@ -2183,6 +2208,7 @@ CC4_HD bool step_phase(Ctx x, bool init_accumulators = true) {
   }
   rng_begin_step(&s->rng, (uint32_t)s->step_count);
   if (x.lg) { x.lg->n = 0; x.lg->step = (uint32_t)s->step_count; }
+  if (x.ext) { x.c->gfail[0] = 0; x.c->gfail[1] = 0; x.c->gfail[2] = 0; }
   s->action_cost = 0.f;
   if (init_accumulators) {
     s->brm = 0; s->n_restore = 0;
@@ -2221,6 +2247,10 @@ CC4_HD Act blue_random_policy(Ctx x, int b) {
 CC4_HD void step_blue_submit(Ctx x, int b, int action_index) {
   EnvState* s = x.s;
   const bool builtin = action_index < 0 && (s->policy & BP_RANDOM_BIT);
+  // `action.duration` set by the caller (the reference's scripted tests shorten Analyse / Restore / DeployDecoy to one tick) rides
+  // in bits 20.. of a non-negative index
+  const int dur = action_index >= 0 ? (action_index >> BLUE_DUR_SHIFT) & 0xFF : 0;
+  if (action_index >= 0) action_index &= BLUE_IDX_MASK;
   Act a = builtin ? blue_random_policy(x, b) : blue_decode(s, b, action_index);
   // Restore.cost = -1, charged on submission even while busy -- for SUBMITTED actions only: the sum runs over the step's
   // `actions` argument, which a default agent's choice never enters (SC:236-240,310)
@@ -2231,7 +2261,7 @@ CC4_HD void step_blue_submit(Ctx x, int b, int action_index) {
     s->n_restore++;
 #endif
   }
-  a.ticks = (uint8_t)blue_duration(a.type);
+  a.ticks = (uint8_t)(dur ? dur : blue_duration(a.type));
   if (!s->blue[b].queue.busy) { s->blue[b].queue = a; s->blue[b].queue.busy = 1; }
 }
 // The policies' generator while a set_seed split is in force (EnvState.rng2; numpy-stream mode only -- in the counter mode
@@ -2253,6 +2283,26 @@ CC4_HD void rng_policy_swap(Ctx x, bool back) {
 }
 // pre: block 0 of the agent's policy stream when the caller has it already (rng_preload), else null
 CC4_HD void step_green_policy(Ctx x, int g, const uint32_t* pre = nullptr) {
+  if (x.ext && x.ext[NRED + g].type != XA_NONE) {   // the step's `actions` dict holds this agent's action: its policy is not asked (SC:236-240)
+    const ExtAct& ea = x.ext[NRED + g];
+    int t = ea.type;
+    if ((t == XG_ACCESS || t == XG_LOCAL) && !(ea.flags & XF_SKIP_VALID)) {
+      // replace_action_if_invalid (SC:1068-1112) over the action's attributes that are ActionSpace keys: the class (a SleepAgent
+      // green agent's action space holds Sleep only, EnterpriseScenarioGenerator.py:742-743), ip_address (the agent's own host is
+      // what it may act from), and -- GreenAccessService -- every entry of allowed_subnets must be in the agent's CURRENT list
+      // (ActionSpace.get_action_space carries 'allowed_subnets', ActionSpace.py:115): a list from before a mission-phase change
+      // turns the action into an InvalidAction.  The phase of this step = max(stored, from the step count): the same value
+      // whether or not step_phase has stored it yet.
+      const EnvState* s = x.s;
+      const int own = h_subnet(s->green_host[g]);
+      int ph = step_phase_of(s->step_count, s->phase_len[0], s->phase_len[1], s->phase_len[2]);
+      if (ph < s->phase) ph = s->phase;
+      if ((s->policy & GP_SLEEP_BIT) || ea.host != s->green_host[g] || (t == XG_ACCESS && (ea.sid & ~green_allowed_mask(ph, own)))) t = XG_INVALID;
+    }
+    // InvalidAction: Observation(False), nothing the reward reads -- resolved like Sleep (3: step_end reports its success as False)
+    x.w->green_act[g] = (uint8_t)(t == XG_ACCESS ? 0 : (t == XG_LOCAL ? 1 : (t == XG_INVALID ? 3 : 2)));
+    return;
+  }
   if (x.s->policy & GP_SLEEP_BIT) { x.w->green_act[g] = 2; return; }   // green_agent_class=SleepAgent: no draw, Sleep
   rng_set_stream(x.r, ST_GREEN_POL + (uint32_t)g);
   if (pre) rng_preload(x.r, pre);
@@ -2269,6 +2319,7 @@ CC4_HD void step_red_observe(Ctx x, int r) {
   RedAgent& A = s->red[r];
   const int pol = s->policy & 3;
   if (!A.h.active || pol == RP_RANDOM || pol == RP_SLEEP) return;
+  if (x.ext && x.ext[r].type != XA_NONE) return;   // an action was submitted for this agent: get_action is not called, nothing is observed
   RedHdr H = A.h;
   fsm_observe(x, r, H);
   A.h = H;
@@ -2289,10 +2340,22 @@ CC4_HD int step_red_policy_tick(Ctx x, int r, bool observed = false, const uint3
   rng_set_stream(x.r, ST_RED_POL + (uint32_t)r);
   if (pre) rng_preload(x.r, pre);
   CC4_FT(x, r, 0);
-  if (H.active && (s->policy & 3) == RP_RANDOM) { a = random_red_get_action(x, r, H); red_validate(x, r, H, a); }
+  const ExtAct* ea = (x.ext && x.ext[r].type != XA_NONE) ? &x.ext[r] : nullptr;
+  if (ea) {
+    // actions.get(agent_name) (SC:236-240): the submitted action is taken whether or not the agent is active, the agent object is
+    // not asked -- no draw, no FSM observation, no step count -- and it goes through the same validity check (SC:241-242)
+    a.type = (uint8_t)ea->type; a.host = ea->host; a.arg = ea->arg; a.sid = ea->sid;
+    a.ticks = (uint8_t)(ea->ticks ? ea->ticks : red_duration(a.type));
+    if (!(ea->flags & XF_SKIP_VALID)) red_validate(x, r, H, a);
+    if (a.type < RA_SLEEP && (ea->flags & (XF_RATE0 | XF_RATE1))) a.busy = (uint16_t)((ea->flags & XF_RATE0 ? AQ_RATE0 : 0) | (ea->flags & XF_RATE1 ? AQ_RATE1 : 0));
+  }
+  else if (H.active && (s->policy & 3) == RP_RANDOM) { a = random_red_get_action(x, r, H); red_validate(x, r, H, a); }
   else if (H.active && (s->policy & 3) != RP_SLEEP) { a = fsm_get_action(x, r, H, observed); CC4_AT0(x); red_validate(x, r, H, a); CC4_AT(x, 7); }   // AgentInterface.get_action (:120-143); SleepAgent -> Sleep
   CC4_FT(x, r, 1);
-  if (!H.queue.busy) { H.queue = a; H.queue.busy = 1; }
+  if (!H.queue.busy) {
+    H.queue = a; H.queue.busy = (uint16_t)(AQ_BUSY | a.busy);
+    if (x.ext && (a.busy & (AQ_RATE0 | AQ_RATE1))) { x.c->xrate[r][0] = ea->rate0; x.c->xrate[r][1] = ea->rate1; }
+  }
   // ---- tick: a new step's observation starts empty
   H.nobs = 0; H.obs_success = 0; H.obs_act_type = RA_NONE; H.new_sess_host = 0xFF; H.rsc_listed = 0;
   for (int w = 0; w < 5; ++w) { A.obs_has[0][w] = 0; A.obs_has[1][w] = 0; }
@@ -2365,11 +2428,17 @@ CC4_HD int step_green_exec(Ctx x, int g, const uint32_t* pre = nullptr) {
   const int act = x.w->green_act[g];
   if (act >= 2) return 0;
   const uint64_t gp = x.gpre ? x.gpre[g] : green_prepare(x, g, act);
-  if (act == 0) return green_access_service(x, gh, gp) ? 0 : reward_table(s->phase, own, RW_ASF);
+  const ExtAct* ea = (x.ext && x.ext[NRED + g].type != XA_NONE) ? &x.ext[NRED + g] : nullptr;   // its own rates, if it came with any
+  if (act == 0) {
+    const bool ok = green_access_service(x, gh, gp, (ea && (ea->flags & XF_RATE0)) ? ea->rate0 : 0.01);
+    if (x.ext && !ok) bit_set_shared(x.c->gfail, g);
+    return ok ? 0 : reward_table(s->phase, own, RW_ASF);
+  }
   if (act == 1) {
     bool want_phish = false;
-    bool ok = green_local_work(x, gh, gp, &want_phish);
+    bool ok = green_local_work(x, gh, gp, &want_phish, (ea && (ea->flags & XF_RATE0)) ? ea->rate0 : 0.01, (ea && (ea->flags & XF_RATE1)) ? ea->rate1 : 0.01);
     if (want_phish) bit_set_shared(x.w->phish_mask, g);   // green agents may be resolved on different lanes
+    if (x.ext && !ok) bit_set_shared(x.c->gfail, g);
     return ok ? 0 : reward_table(s->phase, own, RW_LWF);
   }
   return 0;
@@ -2488,6 +2557,7 @@ CC4_HD void step_end(Ctx x, const uint8_t* messages, bool copy_msgs = true) {
       brm += reward_table(s->phase, h_subnet(s->red[r].h.exec_host), RW_RIA);  // charged for any executed Impact (App. B.2)
   s->action_cost = -(float)s->n_restore;
   s->reward = (float)brm + s->action_cost;
+  if (x.ext) for (int g = 0; g < s->n_green; ++g) if (x.w->green_act[g] == 3) bit_set_shared(x.c->gfail, g);   // submitted green actions that were invalid
   if (copy_msgs) for (int b = 0; b < NBLUE; ++b) step_messages(s, messages, b);
   s->brm = 0; s->n_restore = 0; s->n_actions = NBLUE + s->n_green + NRED;   // the next step's accumulators (see step_phase)
   rng_park(&s->rng);
@@ -2523,6 +2593,83 @@ CC4_HD void env_step(Ctx x, const int32_t* actions, const uint8_t* messages /* [
   for (int r = 0; r < NRED; ++r) step_rsc(x, r);
   CC4_TICK(x, 10);
   step_end(x, messages);
+}
+
+// ------------------------------------------------------------------ direct edits of an episode between steps
+// What the reference's own scripted tests do by hand to env.environment_controller.state before they step (no simulator API):
+//   SE_SET_PHASE        state.mission_phase = a0                          (Tests/test_cc4/test_BlueRewardMachine.py:48,70,113,142)
+//   SE_ADD_SERVICE      pid = host.create_pid(); host.processes.append(Process(pid, ...)); host.add_service(name, Service(pid))
+//                       on host a0, service kind a1 (K_*), process owned by root if a2   (test_Red/test_Impact.py:89-101, test_BlueRewardMachine.py:38-42)
+//   SE_SET_RELIABILITY  every service of host a0: _percent_reliable = a1 (a multiple of 20)   (test_BlueRewardMachine.py:75-77)
+//   SE_CLEAR_HOST       host a0: processes = [], services = {}            (test_blue_actions.py:223-224)
+//   SE_DEPLOY_DECOY     Decoy<kind a1>(hostname a0).execute(state): one specific decoy factory instead of DeployDecoy's random
+//                       choice (test_Red/test_DiscoverDeception.py:43,94,142,190); returns 1 on success, 0 when the factory's port is taken
+// Returns >= 0, or -1 for an unknown op / bad argument.  (Host code: libcc4 applies them to a row fetched with cc4_get_state.)
+//   SE_ADD_RED_SESSION  state.add_session(Session(hostname a1, username, agent red_agent_<a0>, parent, session_type='shell', pid=None)):
+//                       a plain shell session -- a2 bit 0: username root / SYSTEM, bit 1: parent is not None -- with the ident
+//                       State.add_session would pick (max + 1; the tests pass exactly those) and a fresh 'shell' process
+//                       (test_Red/test_Withdraw.py:10-17, test_RedSessionCheck.py:10-23); returns the ident
+enum : int { SE_SET_PHASE = 0, SE_ADD_SERVICE = 1, SE_SET_RELIABILITY = 2, SE_CLEAR_HOST = 3, SE_DEPLOY_DECOY = 4, SE_ADD_RED_SESSION = 5 };
+inline int state_edit(Ctx x, int op, int a0, int a1, int a2) {
+  EnvState* s = x.s;
+  auto host_ok = [&](int h) { return h >= 0 && h < MAXH && bit_get(s->exists, h); };
+  switch (op) {
+    case SE_SET_PHASE:
+      if (a0 < 0 || a0 > 2) return -1;
+      s->phase = a0; s->obs_dirty = 1;
+      return 0;
+    case SE_ADD_SERVICE: {
+      if (!host_ok(a0) || a1 < K_SSHD || a1 > K_DEC_VSFTPD) return -1;
+      HostDyn& d = x.hd[a0];
+      const int nsv = hd_nsvc(d);
+      int si = -1;
+      for (int i = nsv - 1; i >= 0; --i) if (d.svcs[i].kind == a1) si = i;   // add_service on an existing name replaces the entry
+      if (si < 0 && nsv >= MAXSV) return -1;
+      const int pid = create_pid(x, a0);
+      if (!add_proc(x, a0, pid, K_PLAIN, a2 ? PF_ROOT : 0)) return -1;   // Process(pid=pid, process_name=...): no open_ports
+      if (si < 0) { si = nsv; hd_set_nsvc(d, nsv + 1); }
+      d.svcs[si].kind = (uint8_t)a1; d.svcs[si].pid = (uint16_t)pid; d.svcs[si].st = (uint8_t)(SV_ACTIVE | 5);
+      return pid;
+    }
+    case SE_SET_RELIABILITY: {
+      if (!host_ok(a0) || a1 < 0 || a1 > 100 || a1 % 20) return -1;
+      HostDyn& d = x.hd[a0];
+      for (int i = 0; i < hd_nsvc(d); ++i) d.svcs[i].st = (uint8_t)((d.svcs[i].st & SV_ACTIVE) | (a1 / 20));
+      return 0;
+    }
+    case SE_CLEAR_HOST: {
+      if (!host_ok(a0)) return -1;
+      HostDyn& d = x.hd[a0];
+      d.nproc = 0; hd_set_nsvc(d, 0);
+      for (int i = 0; i < PIN; ++i) { d.procs[i].pid = 0; d.procs[i].kind = 0; d.procs[i].flags = 0; }
+      for (int i = 0; i < MAXSV; ++i) { d.svcs[i].pid = 0; d.svcs[i].kind = 0; d.svcs[i].st = 0; }
+      return 0;
+    }
+    case SE_DEPLOY_DECOY: {
+      if (!host_ok(a0) || a1 < K_DEC_APACHE || a1 > K_DEC_VSFTPD) return -1;
+      HostDyn& d = x.hd[a0];
+      const int used = proc_ports(x, a0);   // DecoyFactory.is_host_compatible: the factory's port is free (vsftpd checks 21: always)
+      const int need = a1 == K_DEC_APACHE ? PB_80 : (a1 == K_DEC_TOMCAT ? PB_443 : (a1 == K_DEC_HARAKA ? PB_25 : 0));
+      if (used & need) return 0;
+      const int pid = create_pid(x, a0);
+      if (!add_proc(x, a0, pid, a1, 0)) return -1;
+      const int nsv = hd_nsvc(d);
+      int si = -1;
+      for (int i = nsv - 1; i >= 0; --i) if (d.svcs[i].kind == a1) si = i;
+      if (si < 0) { if (nsv >= MAXSV) return -1; si = nsv; hd_set_nsvc(d, nsv + 1); }
+      d.svcs[si].kind = (uint8_t)a1; d.svcs[si].pid = (uint16_t)pid; d.svcs[si].st = (uint8_t)(SV_ACTIVE | 5);
+      return 1;
+    }
+    case SE_ADD_RED_SESSION: {
+      if (a0 < 0 || a0 >= NRED || !host_ok(a1)) return -1;
+      const int pid = create_pid(x, a1);                      // Host.add_session: pid = create_pid(), Process(name=session_type, username)
+      if (!add_proc(x, a1, pid, K_SHELL, (a2 & 1) ? PF_ROOT : 0)) return -1;
+      const int idx = rs_add(x, a0, a1, pid, ((a2 & 1) ? RS_ROOT : 0) | ((a2 & 2) ? RS_CHILD : 0));
+      if (idx < 0) return -1;
+      return rsw_id(rs_at(s, s->red[a0], idx));
+    }
+    default: return -1;
+  }
 }
 
 // ------------------------------------------------------------------ BlueFlatWrapper.observation_change (BlueFlatWrapper.py:172-256)

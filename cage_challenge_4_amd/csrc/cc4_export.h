@@ -10,7 +10,14 @@
 //              "svcs":[[kind,active,reliability percent,pid]...] (Host.services order), "ev":event bits,
 //              "files":HF_* bits (1 cmd.sh, 2 escalate.sh, 4 escalate.sh appended last),
 //              "blue":pid of the blue session process (0 none),"green":pid of the green session process (0 none)}...],
-//    "red":[{"active":0/1,"start":host the scenario generator drew for the agent,"sessions":[[id,host,pid,flags]...] (state.sessions[red_agent_r] order; flags = RS_* bits)}...x6],
+//    "red":[{"active":0/1,"start":host the scenario generator drew for the agent,"sessions":[[id,host,pid,flags]...] (state.sessions[red_agent_r] order; flags = RS_* bits),
+//            "obs_success":TernaryEnum of the last step's observations[0] (1 TRUE 2 UNKNOWN 3 FALSE 4 IN_PROGRESS),"obs_action":[RA_* type,host,subnet] of it (11 = none),
+//            "rsc_listed":1 if the end-of-turn RedSessionCheck listed every session,"busy":1 while a multi-tick action is queued,
+//            "new_session":[host (255 none), id] the session this step's exploit created,
+//            "obs":[[host, OE_* flags]...] the keys of the last step's combined observation in insertion order (OE_KEY_IP 1: keyed by ip, else by hostname;
+//            OE_SESS 2 / OE_IFACE 4 / OE_SYSHN 8: it holds 'Sessions' / 'Interface' / 'System info'),
+//            "known_sessions":[ids],"as_subnet":mask,"as_ip":[5 words],"as_hostname":[5 words] the ActionSpace's True entries}...x6],
+//    "green_fail":[3 words: bit g = green_agent_g's action of the last step returned success False (full builds of the step: cc4_step_ex / event log)],
 //    "blue":[{"parent":host id of the VelociraptorServer,"busy":1 while a multi-tick action is in progress,"traffic_ok":outcome of the last Block/Allow (1 TRUE, 3 FALSE),"sus":[[host,pid]...]}...x5],
 //    "last_blue":[[BA_* type,host or to-subnet,from-subnet]...x5],"last_red":[[RA_* type,host,subnet,executed (0 = dropped by filter_actions)]...x6] (the actions
 //    that resolved in the last step, i.e. CybORG.get_last_action),
@@ -68,7 +75,15 @@ inline std::string export_true_state(const EnvState& s, const EnvCold& cold, boo
     const RedAgent& A = s.red[r];
     add("%s{\"active\":%u,\"start\":%u,\"sessions\":[", r ? "," : "", (unsigned)A.h.active, (unsigned)A.h.start_host);
     for (int i = 0; i < A.h.nsess; ++i) { const RSess& q = s.spool[A.sord[i]]; add("%s[%u,%u,%u,%u]", i ? "," : "", (unsigned)q.id, (unsigned)q.host, (unsigned)q.pid, (unsigned)q.flags); }
-    o += "]}";
+    // the agent's observation of the last step (what CybORG.get_observation('red_agent_r') is built from) and its ActionSpace
+    add("],\"obs_success\":%u,\"obs_action\":[%u,%u,%u],\"rsc_listed\":%u,\"busy\":%u,\"new_session\":[%u,%u],\"obs\":[", (unsigned)A.h.obs_success, (unsigned)A.h.obs_act_type,
+        (unsigned)A.h.obs_act_host, (unsigned)A.h.obs_act_arg, (unsigned)A.h.rsc_listed, (unsigned)(A.h.queue.busy ? 1 : 0), (unsigned)A.h.new_sess_host, (unsigned)A.h.new_sess_id);
+    for (int i = 0; i < A.h.nobs; ++i) add("%s[%u,%u]", i ? "," : "", (unsigned)A.obs[i].host, (unsigned)A.obs[i].flags);
+    o += "],\"known_sessions\":[";
+    for (int i = 0; i < A.h.nknown; ++i) add("%s%u", i ? "," : "", (unsigned)A.known_sid[i]);
+    add("],\"as_subnet\":%u,\"as_ip\":[%u,%u,%u,%u,%u],\"as_hostname\":[%u,%u,%u,%u,%u]", (unsigned)A.h.as_subnet, A.as_ip[0], A.as_ip[1], A.as_ip[2], A.as_ip[3], A.as_ip[4],
+        A.as_hn[0], A.as_hn[1], A.as_hn[2], A.as_hn[3], A.as_hn[4]);
+    o += "}";
   }
   o += "],\"blue\":[";
   for (int k = 0; k < NBLUE; ++k) {
@@ -89,6 +104,7 @@ inline std::string export_true_state(const EnvState& s, const EnvCold& cold, boo
           (unsigned)e.lport, (unsigned)e.raddr, (unsigned)e.rport, (unsigned)e.pid, (unsigned)e.rep);
     }
   }
+  add("],\"green_fail\":[%u,%u,%u", cold.gfail[0], cold.gfail[1], cold.gfail[2]);
   o += "],\"green_hosts\":[";
   for (int g = 0; g < s.n_green; ++g) add("%s%u", g ? "," : "", (unsigned)s.green_host[g]);
   o += "]}";

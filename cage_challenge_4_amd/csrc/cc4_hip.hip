@@ -52,6 +52,8 @@ struct StepArgs {
   unsigned long long* prof;   // optional [n][PROF_SLOTS] cycle counters (cc4_debug_profile): 16 phase slots + 8 per red agent
   uint32_t* reset_ws;         // k_step_philox1: [n][RESET_WS_WORDS] work area of the in-kernel scenario generation (the other
                               // kernels keep it in LDS; an episode regenerates once in steps-per-episode launches)
+  const ExtAct* ext;          // [n][EXT_PER_ENV] externally submitted red / green actions of this step (cc4_step_ex), or null; read by the
+                              // full builds of the step kernels only (template parameter LOG)
   int e0;                     // first episode of this launch: block b steps episode e0 + b (a step of a large batch is issued as
                               // several launches on separate streams: see cc4_handle::ngroups); n = one past its last episode
 };
@@ -94,8 +96,9 @@ __device__ __forceinline__ void stage_out(uint4* __restrict__ dst, const uint4* 
   for (; i < NVEC; i += WAVE) dst[i] = lds[i];
 }
 
-// LOG: record the HostEvents entries of the step (cc4_enable_event_log).  A template parameter rather than a run-time flag: even
-// a never-taken logging branch at the eleven event sites costs the serial walk 10 %.
+// LOG: the full build of a step kernel -- it records the HostEvents entries of the step (cc4_enable_event_log) and takes externally
+// submitted red / green actions (cc4_step_ex: StepArgs.ext).  A template parameter rather than a run-time flag: even a never-taken
+// logging branch at the eleven event sites costs the serial walk 10 %.
 // byte j of an episode's packed observation row: values 4j .. 4j+3 (from a byte-per-value row in LDS), 2 bits each, low bits first
 __device__ __forceinline__ uint8_t pack_obs_byte(const uint8_t* vals, int j) {
   uint32_t b = 0;
@@ -504,7 +507,9 @@ __global__ __launch_bounds__(WAVE) void k_step(StepArgs a) {
   rl.mode = 0;
   rl.pad = 0;
   Ctx x{s, cold_e, &rl, hd, &work, lane == 0 ? prof : nullptr};
-  x.lg = LOG ? &cold_e->evlog : nullptr;
+  x.lg = (LOG && cold_e->evlog.enabled) ? &cold_e->evlog : nullptr;
+  const ExtAct* const xt = (LOG && a.ext) ? a.ext + (size_t)e * EXT_PER_ENV : nullptr;   // this episode's submitted red / green actions
+  x.ext = xt;
   if (prof && lane == 0) prof[11] += clock64() - t_begin;
   const bool do_reset = a.autoreset && s->done;
   // The ordered walk is lane 0's; between its stretches the whole wave does what needs no order: the two draw-only phases
@@ -538,9 +543,10 @@ __global__ __launch_bounds__(WAVE) void k_step(StepArgs a) {
   __syncthreads();
   if (ok_lds) {
     bool drawn = false;
-    if (!(s->policy & GP_SLEEP_BIT)) drawn = wave_green_policy(rl, s->n_green, work.green_act, lane);
+    // (with submitted green actions in play the agents that have one do not draw: the walking lane asks them one by one)
+    if (!(s->policy & GP_SLEEP_BIT) && !xt) drawn = wave_green_policy(rl, s->n_green, work.green_act, lane);
     // the observation half of the six red policies draws nothing and touches only its own agent: side by side on six lanes
-    if (lane < NRED) { Ctx xo{s, cold_e, &rl, hd, &work}; step_red_observe(xo, lane); }
+    if (lane < NRED) { Ctx xo{s, cold_e, &rl, hd, &work}; xo.ext = xt; step_red_observe(xo, lane); }
     __syncthreads();
     if (lane == 0) {
       if (!drawn) for (int g = 0; g < s->n_green; ++g) step_green_policy(x, g);   // SleepAgent greens, or the 2^-32 re-draw case
@@ -752,7 +758,8 @@ __global__ __launch_bounds__(PT, MINW) void k_step_philox(StepArgs a) {
     const bool step_ok = step_phase_of(st_now, s->phase_len[0], s->phase_len[1], s->phase_len[2]) >= 0;
     if (tid == 0) {
       Ctx x{s, cold_e, &s->rng, hd, &work, prof};
-      x.lg = LOG ? &cold_e->evlog : nullptr;
+      x.lg = (LOG && cold_e->evlog.enabled) ? &cold_e->evlog : nullptr;
+      x.ext = (LOG && a.ext) ? a.ext + (size_t)e * EXT_PER_ENV : nullptr;
       CC4_TICK0(x);
       (void)step_phase(x, false);
     }
@@ -766,9 +773,10 @@ __global__ __launch_bounds__(PT, MINW) void k_step_philox(StepArgs a) {
       rng_fork(&rl, &s->rng, ST_RESET);
       rl.mode = 1;
       rng_begin_step(&rl, (uint32_t)st_now);   // not read from the row: thread 0 may still be storing it there
-      EvLog* const lg = LOG ? &cold_e->evlog : nullptr;
+      EvLog* const lg = (LOG && cold_e->evlog.enabled) ? &cold_e->evlog : nullptr;
+      const ExtAct* const xt = (LOG && a.ext) ? a.ext + (size_t)e * EXT_PER_ENV : nullptr;   // this episode's submitted red / green actions
       Ctx x0{s, cold_e, &rl, hd, &work, tid == 0 ? prof : nullptr};         // thread 0
-      x0.lg = lg;
+      x0.lg = lg; x0.ext = xt;
 #ifndef CC4_RED_WAVES
 #define CC4_RED_WAVES 2
 #endif
@@ -790,6 +798,7 @@ __global__ __launch_bounds__(PT, MINW) void k_step_philox(StepArgs a) {
       unsigned long long* apx = (a.prof && is_redx) ? a.prof + PROF_SLOTS * (size_t)e + 16 + 8 * xagent : nullptr;
       Ctx xrx{s, cold_e, &rl, hd, &work, nullptr, apx, lg};
       Ctx xr{s, cold_e, &rl, hd, &work, nullptr, ap, lg};
+      xrx.ext = xt; xr.ext = xt;
       // ---- P0-P3a: every agent's policy / submission followed by its own duration-queue tick (SC:236-265), all on the
       // agent's thread: red r on wave r%PW lane r/PW, blue on wave PW-1 lanes 2..6, green draws on lanes >= 8 of the waves
       // that carry a single red agent.  A tick touches only its own agent (queue, observation reset, filter_actions
@@ -820,6 +829,7 @@ __global__ __launch_bounds__(PT, MINW) void k_step_philox(StepArgs a) {
         const int g = gw * (WAVE - 8) + (lane - 8);
         if (g < ng) {
           Ctx xg{s, cold_e, &rl, hd, &work, nullptr, nullptr, lg};
+          xg.ext = xt;
           step_green_policy(xg, g);
           const int t = work.green_act[g];
           // compaction by action type with a wavefront ballot + prefix count (agent order, no LDS atomics): each drawing wave
@@ -872,6 +882,7 @@ __global__ __launch_bounds__(PT, MINW) void k_step_philox(StepArgs a) {
         for (int i = lane; i < n0 + n1; i += WAVE) {
           int g = i < n0 ? glist[wave][0][i] : glist[wave][1][i - n0];
           Ctx xg{s, cold_e, &rl, hd, &work, nullptr, nullptr, lg};
+          xg.ext = xt;
           const uint4 blk = reinterpret_cast<const uint4*>(reset_ws)[g];
           const uint32_t pre[4] = {blk.x, blk.y, blk.z, blk.w};
           pen += step_green_exec(xg, g, pre);
@@ -912,6 +923,7 @@ __global__ __launch_bounds__(PT, MINW) void k_step_philox(StepArgs a) {
       if (is_redx) { unsigned long long t0 = apx ? clock64() : 0; step_rsc(xrx, xagent); if (apx) apx[2] += clock64() - t0; }
       if (tid == PT - 1) {
         Ctx xe{s, cold_e, &rl, hd, &work, nullptr, nullptr, lg};
+        xe.ext = xt;
         step_monitor_pend(xe);
         step_end(xe, nullptr, false);
         a.reward[e] = s->reward; a.done[e] = s->done;
@@ -1012,7 +1024,8 @@ __global__ __launch_bounds__(WAVE, CC4_LEAN_MINW) void k_step_philox1(StepArgs a
     const bool step_ok = step_phase_of(st_now, s->phase_len[0], s->phase_len[1], s->phase_len[2]) >= 0;
     if (lane == 0) {
       Ctx x{s, cold_e, &s->rng, hd, &work, prof};
-      x.lg = LOG ? &cold_e->evlog : nullptr;
+      x.lg = (LOG && cold_e->evlog.enabled) ? &cold_e->evlog : nullptr;
+      x.ext = (LOG && a.ext) ? a.ext + (size_t)e * EXT_PER_ENV : nullptr;
       CC4_TICK0(x);
       (void)step_phase(x, false);
     }
@@ -1024,9 +1037,10 @@ __global__ __launch_bounds__(WAVE, CC4_LEAN_MINW) void k_step_philox1(StepArgs a
       rng_fork(&rl, &s->rng, ST_RESET);
       rl.mode = 1;
       rng_begin_step(&rl, (uint32_t)st_now);   // not read from the row: lane 0 may still be storing it there
-      EvLog* const lg = LOG ? &cold_e->evlog : nullptr;
+      EvLog* const lg = (LOG && cold_e->evlog.enabled) ? &cold_e->evlog : nullptr;
+      const ExtAct* const xt = (LOG && a.ext) ? a.ext + (size_t)e * EXT_PER_ENV : nullptr;   // this episode's submitted red / green actions
       Ctx x0{s, cold_e, &rl, hd, &work, lane == 0 ? prof : nullptr};
-      x0.lg = lg;
+      x0.lg = lg; x0.ext = xt;
       if (lane == 0) CC4_TICK(x0, 0);
       // ---- the block bank.  A Philox block costs a wave the same ~110 vector instructions whether one lane needs it or
       // sixty-four do, and block 0 of every stream of the step is known from (key, step, episode, stream id) alone.  The streams
@@ -1062,6 +1076,7 @@ __global__ __launch_bounds__(WAVE, CC4_LEAN_MINW) void k_step_philox1(StepArgs a
       unsigned long long* ap = (a.prof && is_red) ? a.prof + PROF_SLOTS * (size_t)e + 16 + 8 * lane : nullptr;
       Ctx xr{s, cold_e, &rl, hd, &work, nullptr, ap, lg};
       Ctx xg{s, cold_e, &rl, hd, &work, nullptr, nullptr, lg};
+      xr.ext = xt; xg.ext = xt;
       // ---- P0-P3a: every agent's policy / submission and its own duration-queue tick (SC:236-265)
       uint32_t pre_rp[4];
       bank_fetch(BK_RPOL, pre_rp);                                               // red r (lane r) <- lane BK_RPOL + r
@@ -1337,6 +1352,12 @@ struct cc4_handle {
   uint32_t* d_reset_ws = nullptr;    // k_step_philox1's generation work area, [num_envs][RESET_WS_WORDS]
   uint8_t* d_unpacked = nullptr;                 // [world*N][578] bytes: cc4_unpack_obs_device
   int evlog_on = 0;               // cc4_enable_event_log
+  // externally submitted red / green actions (cc4_step_ex).  Once a handle has taken any, its steps run the full builds of the
+  // kernels (an action queued for several ticks carries its own rates into later steps), with d_ext all XA_NONE for the steps
+  // that submit nothing
+  ExtAct* d_ext = nullptr;        // [num_envs][EXT_PER_ENV]
+  bool ext_seen = false, ext_dirty = false;   // dirty: d_ext holds the records of an earlier step
+  std::vector<ExtAct> h_ext;
   bool full_obs_next = true;      // the next step launch rewrites every observation value (fresh handle, restored state)
   bool philox_lean = false;       // k_step_philox1 (one wave per episode) instead of k_step_philox (cc4_create)
   int philox_minw = 1;            // which register budget of k_step_philox this batch size runs (1, 7 or 8 blocks per CU; cc4_create)
@@ -1442,7 +1463,13 @@ static int sync_all(cc4_handle* h) {
 
 // rand: draw the blue actions inside the step kernel from (seed0, t) and record them in the handle's action buffer
 static int launch_step(cc4_handle* h, const int32_t* d_actions, const uint8_t* d_msgs, bool rand = false, uint64_t seed0 = 0,
-                       uint32_t t = 0) {
+                       uint32_t t = 0, bool ext_uploaded = false) {
+  if (h->ext_seen && h->ext_dirty && !ext_uploaded) {     // this step submits no red / green action: every record says so
+    if (join_groups(h)) return -1;
+    HIPCHK(h, hipMemsetAsync(h->d_ext, 0xFF, (size_t)h->cfg.num_envs * EXT_PER_ENV * sizeof(ExtAct), h->stream));
+    h->ext_dirty = false;
+  }
+  const bool full = h->evlog_on || h->ext_seen;
   // the byte-observation buffer about to be overwritten may still be read by an overlapped all-gather
   int buf = h->comm ? (h->obs_buf + 1) % cc4_handle::OBS_RING : 0;
   if (h->comm && h->gather_seq[buf] > h->gathers_waited) {
@@ -1468,7 +1495,7 @@ static int launch_step(cc4_handle* h, const int32_t* d_actions, const uint8_t* d
              h->comm ? h->d_obs8[buf] : nullptr, rand ? h->d_actions : nullptr, seed0, t,
              h->cfg.num_envs, h->cfg.autoreset, h->cfg.steps, h->cfg.rng_mode,
              (h->cfg.red_policy & 3) | (h->cfg.green_policy ? GP_SLEEP_BIT : 0) | (h->cfg.blue_policy ? BP_RANDOM_BIT : 0), h->full_obs_next ? 1 : 0,
-             (uint32_t)h->cfg.topology_seed, h->d_prof, h->d_reset_ws, 0};
+             (uint32_t)h->cfg.topology_seed, h->d_prof, h->d_reset_ws, h->ext_seen ? h->d_ext : nullptr, 0};
   h->full_obs_next = false;
   for (int g = 0; g < h->ngroups; ++g) {
     a.e0 = h->glo[g]; a.n = h->glo[g + 1];
@@ -1481,10 +1508,10 @@ static int launch_step(cc4_handle* h, const int32_t* d_actions, const uint8_t* d
     h->tev_start[g] = h->tev_stop[g] = nullptr;
     if (h->cfg.rng_mode == 1) {
       if (h->philox_lean) {
-        if (h->evlog_on) hipExtLaunchKernelGGL(k_step_philox1<true>, grid, dim3(WAVE), offsetof(EnvState, hd), st, start, stop, 0, a);
+        if (full) hipExtLaunchKernelGGL(k_step_philox1<true>, grid, dim3(WAVE), offsetof(EnvState, hd), st, start, stop, 0, a);
         else hipExtLaunchKernelGGL(k_step_philox1<false>, grid, dim3(WAVE), offsetof(EnvState, hd), st, start, stop, 0, a);
       }
-      else if (h->evlog_on) hipExtLaunchKernelGGL((k_step_philox<true, 1>), grid, dim3(PT), sizeof(EnvState), st, start, stop, 0, a);
+      else if (full) hipExtLaunchKernelGGL((k_step_philox<true, 1>), grid, dim3(PT), sizeof(EnvState), st, start, stop, 0, a);
       else if (h->philox_minw == 8) hipExtLaunchKernelGGL((k_step_philox<false, 8>), grid, dim3(PT), sizeof(EnvState), st, start, stop, 0, a);
       else if (h->philox_minw == 7) hipExtLaunchKernelGGL((k_step_philox<false, 7>), grid, dim3(PT), sizeof(EnvState), st, start, stop, 0, a);
 #ifndef CC4_SMALL_MINW
@@ -1492,7 +1519,7 @@ static int launch_step(cc4_handle* h, const int32_t* d_actions, const uint8_t* d
 #endif
       else hipExtLaunchKernelGGL((k_step_philox<false, CC4_SMALL_MINW>), grid, dim3(PT), sizeof(EnvState), st, start, stop, 0, a);
     } else {
-      if (h->evlog_on) hipExtLaunchKernelGGL(k_step<true>, grid, dim3(WAVE), offsetof(EnvState, hd), st, start, stop, 0, a);
+      if (full) hipExtLaunchKernelGGL(k_step<true>, grid, dim3(WAVE), offsetof(EnvState, hd), st, start, stop, 0, a);
       else hipExtLaunchKernelGGL(k_step<false>, grid, dim3(WAVE), offsetof(EnvState, hd), st, start, stop, 0, a);
     }
     HIPCHK(h, hipGetLastError());
@@ -1622,7 +1649,7 @@ void cc4_destroy(cc4_handle* h) {
   for (int b = 0; b < cc4_handle::OBS_RING; ++b) { for (int g = 0; g < cc4_handle::MAX_GROUPS; ++g) if (h->ev_step[b][g]) (void)hipEventDestroy(h->ev_step[b][g]); if (h->ev_comm[b]) (void)hipEventDestroy(h->ev_comm[b]); }
   if (h->comm_stream) (void)hipStreamDestroy(h->comm_stream);
   void* ptrs[] = {h->d_state, h->d_cold, h->d_actions, h->d_msgs, h->d_seeds, h->d_envmask, h->d_obs, h->d_reward,
-                  h->d_done, h->d_err, h->d_mask, h->d_rng, h->d_reset_ws};
+                  h->d_done, h->d_err, h->d_mask, h->d_rng, h->d_reset_ws, h->d_ext};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   for (int b = 0; b < cc4_handle::OBS_RING; ++b) { if (h->d_obs8[b]) (void)hipFree(h->d_obs8[b]); if (h->d_all_obs8[b]) (void)hipFree(h->d_all_obs8[b]); }
   if (h->d_unpacked) (void)hipFree(h->d_unpacked);
@@ -1663,6 +1690,59 @@ int cc4_step(cc4_handle* h, const int32_t* actions, const uint8_t* messages) {
   if (messages) HIPCHK(h, hipMemcpyAsync(h->d_msgs, messages, n * NBLUE * MSG_LEN, hipMemcpyHostToDevice, h->stream));
   if (launch_step(h, actions ? h->d_actions : nullptr, messages ? h->d_msgs : nullptr)) return -1;
   return sync_all(h);
+}
+
+// cc4_step plus the red / green entries of the step's `actions` dict (SimulationController.py:236-240)
+int cc4_step_ex(cc4_handle* h, const int32_t* actions, const uint8_t* messages, const cc4_agent_action* red, const cc4_agent_action* green) {
+  static_assert(sizeof(cc4_agent_action) == sizeof(ExtAct) && offsetof(cc4_agent_action, session) == offsetof(ExtAct, sid) &&
+                offsetof(cc4_agent_action, rate0) == offsetof(ExtAct, rate0) && offsetof(cc4_agent_action, flags) == offsetof(ExtAct, flags),
+                "cc4_agent_action (include/cc4.h) is ExtAct (csrc/cc4_state.h)");
+  if (!red && !green) return cc4_step(h, actions, messages);
+  HIPCHK(h, hipSetDevice(h->cfg.device_id));
+  if (join_groups(h)) return -1;
+  const size_t n = (size_t)h->cfg.num_envs;
+  if (!h->d_ext) HIPCHK(h, hipMalloc(&h->d_ext, n * EXT_PER_ENV * sizeof(ExtAct)));
+  h->h_ext.resize(n * EXT_PER_ENV);
+  memset(h->h_ext.data(), 0xFF, h->h_ext.size() * sizeof(ExtAct));      // type -1 everywhere: nothing submitted
+  for (size_t e = 0; e < n; ++e) {
+    if (red) memcpy(&h->h_ext[e * EXT_PER_ENV], red + e * NRED, NRED * sizeof(ExtAct));
+    if (green) memcpy(&h->h_ext[e * EXT_PER_ENV + NRED], green + e * MAXG, MAXG * sizeof(ExtAct));
+  }
+  for (size_t i = 0; i < h->h_ext.size(); ++i) {     // what the kernels index with must be in range; everything else is the engine's validity check
+    ExtAct& a = h->h_ext[i];
+    const bool is_red = (i % EXT_PER_ENV) < (size_t)NRED;
+    if (a.type == XA_NONE) continue;
+    if (a.type < 0 || (is_red ? a.type > RA_INVALID : a.type > XG_INVALID) || a.host >= MAXH || (is_red && a.type == RA_DRS && a.arg >= NSUB) ||
+        (is_red && a.type == RA_WITHDRAW && a.arg >= MAXH) || (!is_red && a.ticks > 1)) {
+      h->err = "cc4_step_ex: action record " + std::to_string(i % EXT_PER_ENV) + " of episode " + std::to_string(i / EXT_PER_ENV) + " is out of range (type / host / subnet; a green action takes one tick)";
+      return -2;
+    }
+  }
+  HIPCHK(h, hipMemcpyAsync(h->d_ext, h->h_ext.data(), h->h_ext.size() * sizeof(ExtAct), hipMemcpyHostToDevice, h->stream));
+  h->ext_seen = true; h->ext_dirty = true;
+  if (actions) HIPCHK(h, hipMemcpyAsync(h->d_actions, actions, n * NBLUE * sizeof(int32_t), hipMemcpyHostToDevice, h->stream));
+  if (messages) HIPCHK(h, hipMemcpyAsync(h->d_msgs, messages, n * NBLUE * MSG_LEN, hipMemcpyHostToDevice, h->stream));
+  if (launch_step(h, actions ? h->d_actions : nullptr, messages ? h->d_msgs : nullptr, false, 0, 0, true)) return -1;
+  return sync_all(h);
+}
+
+// direct edits of one episode between steps (state_edit, csrc/cc4_engine.h): the row and its cold part come to the host, the
+// engine's own host build edits them, they go back
+int cc4_edit_state(cc4_handle* h, int32_t env, int32_t op, int32_t a0, int32_t a1, int32_t a2) {
+  if (env < 0 || env >= h->cfg.num_envs) { h->err = "cc4_edit_state: env out of range"; return -2; }
+  EnvState* st = (EnvState*)malloc(sizeof(EnvState));
+  EnvCold* cold = (EnvCold*)malloc(h->cold_row);
+  int rc = cc4_get_state(h, env, st);
+  if (rc == 0) rc = cc4_get_cold(h, env, cold);
+  if (rc == 0) {
+    StepWork w; memset(&w, 0, sizeof(w));
+    Ctx x{st, cold, &st->rng, st->hd, &w};
+    rc = state_edit(x, op, a0, a1, a2);
+    if (rc < 0) { h->err = "cc4_edit_state: unknown op or bad argument"; rc = -2; }
+    else { int r2 = cc4_set_state(h, env, st); if (r2 == 0) r2 = cc4_set_cold(h, env, cold); if (r2) rc = r2; }
+  }
+  free(st); free(cold);
+  return rc;
 }
 
 int cc4_step_device(cc4_handle* h, const int32_t* d_actions, const uint8_t* d_messages) {
@@ -1735,6 +1815,15 @@ int cc4_obs_device(cc4_handle* h, int32_t** p) { *p = h->d_obs; return 0; }
 int cc4_reward_device(cc4_handle* h, float** p) { *p = h->d_reward; return 0; }
 int cc4_done_device(cc4_handle* h, uint8_t** p) { *p = h->d_done; return 0; }
 int cc4_actions_device(cc4_handle* h, int32_t** p) { *p = h->d_actions; return 0; }
+// host copy of the handle's device action buffer: the indices cc4_step uploaded, or the ones the last step of
+// cc4_run_random_steps / cc4_random_actions_device drew on the device
+int cc4_get_actions(cc4_handle* h, int32_t* out) {
+  HIPCHK(h, hipSetDevice(h->cfg.device_id));
+  if (join_groups(h)) return -1;
+  HIPCHK(h, hipMemcpyAsync(out, h->d_actions, (size_t)h->cfg.num_envs * NBLUE * sizeof(int32_t), hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  return 0;
+}
 
 int cc4_random_actions_device(cc4_handle* h, uint64_t seed0, uint32_t t) {
   HIPCHK(h, hipSetDevice(h->cfg.device_id));
@@ -1750,6 +1839,7 @@ int cc4_synchronize(cc4_handle* h) {
 }
 int cc4_run_random_steps(cc4_handle* h, uint64_t seed0, uint32_t t0, int32_t k, float* ms_step_kernels) {
   HIPCHK(h, hipSetDevice(h->cfg.device_id));
+  if (k <= 0) { if (ms_step_kernels) *ms_step_kernels = 0.f; return 0; }   // nothing to launch, no timing event to read
   // Timing: HIP events on the launch streams around chunks of TIMED_CHUNK consecutive steps (an event pair around every single
   // launch costs the stream ~5 us of idle time per step); per stream, the sum over the chunks is the on-stream time of its k
   // launches, read back after the loop -- no host synchronisation inside the timed region.  With several episode groups
@@ -1846,7 +1936,8 @@ int cc4_set_state(cc4_handle* h, int32_t env, const void* buf) {
   if (env < 0 || env >= h->cfg.num_envs) { h->err = "cc4_set_state: env out of range"; return -2; }
   {   // the cold containers of this handle were sized from cfg.steps; the row says how long ITS episode is (EnvState.steps)
     const int st_steps = static_cast<const EnvState*>(buf)->steps;
-    if (st_steps > 0 && cold_row_bytes(st_steps) != h->cold_row) {
+    // (0 = a never-reset, all-zero row; a negative length would turn into negative container capacities on the device)
+    if (st_steps < 0 || (st_steps > 0 && cold_row_bytes(st_steps) != h->cold_row)) {
       h->err = "cc4_set_state: the row belongs to an episode of " + std::to_string(st_steps) + " steps, whose cold containers differ from this handle's (steps=" + std::to_string(h->cfg.steps) + ")";
       return -2;
     }

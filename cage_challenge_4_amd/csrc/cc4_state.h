@@ -55,6 +55,8 @@ enum : int {
   K_DEC_APACHE = 5, K_DEC_TOMCAT = 6, K_DEC_HARAKA = 7, K_DEC_VSFTPD = 8,
   K_SESS_BLUE = 9, K_SESS_GREEN = 10, K_SESS_RED = 11,  // Process(name=session_type) of Host.add_session
   K_SHELL = 12,                                          // cmd.sh of ExploitAction._create_new_session
+  K_PLAIN = 13,                                          // a process without listening ports (state_edit SE_ADD_SERVICE: the hand-made
+                                                         // Process(pid, name) of the reference's tests has no open_ports, so no scan sees it)
 };
 // listening-port bit codes
 enum : int { PB_22 = 1, PB_80 = 2, PB_3390 = 4, PB_25 = 8, PB_1 = 16, PB_443 = 32, PB_HAS = 128 };
@@ -114,7 +116,29 @@ enum : int { RP_FSM = 0, RP_SLEEP = 1, RP_DISCOVERY = 2, RP_RANDOM = 3, GP_SLEEP
 enum : int { T_TRUE = 1, T_UNKNOWN = 2, T_FALSE = 3, T_IN_PROGRESS = 4 };
 
 struct alignas(8) Act { uint8_t type; uint8_t host; uint8_t arg; uint8_t ticks; uint16_t sid; uint16_t busy; };
-// Act.host: target host (blue/red) ; Act.arg: subnet (DRS) or from-subnet (Block/Allow) ; Act.busy: 1 if queued
+// Act.host: target host (blue/red) ; Act.arg: subnet (DRS) or from-subnet (Block/Allow) ; Act.busy: bit 0 queued, bits 1-2: the
+// action came with its own rates (AQ_RATE0 / AQ_RATE1: EnvCold.xrate[agent], see ExtAct)
+enum : int { AQ_BUSY = 1, AQ_RATE0 = 2, AQ_RATE1 = 4 };
+
+// One externally submitted red or green action of a step: SimulationController.step takes `actions[agent_name]` for ANY agent
+// and asks the scenario's agent object only for the agents the dict has no entry for (SimulationController.py:236-240;
+// CybORG.step(agent, action), env.py:125-161).  The blue agents' actions arrive as wrapper indices (cc4_step); these records are
+// the red and green entries of the dict: [0, NRED) red_agent_r, [NRED, NRED + MAXG) green_agent_g.
+//   type   XA_NONE: no entry -- the agent's own policy acts (and draws).  Red: RA_* (RA_INVALID = an action the agent's action
+//          space does not hold: InvalidAction, SimulationController.py:1085-1091).  Green: XG_*.
+//   host   ip_address / hostname parameter as a host id; arg: DiscoverRemoteSystems subnet index, Withdraw hostname host id
+//   sid    session parameter;  ticks: `action.duration` when the caller set one (the reference's tests do), 0 = the class's own
+//   flags  XF_RATE0 / XF_RATE1: rate0 / rate1 replace the action's probability attributes -- Aggressive / StealthServiceDiscovery
+//          detection_rate (rate0); DiscoverDeception detection_rate (rate0), fp_rate (rate1); GreenLocalWork fp_detection_rate
+//          (rate0), phishing_error_rate (rate1); GreenAccessService fp_detection_rate (rate0).
+//          XF_SKIP_VALID: skip_valid_action_check=True (SimulationController.py:241)
+enum : int { XA_NONE = -1, XG_ACCESS = 0, XG_LOCAL = 1, XG_SLEEP = 2, XG_INVALID = 3 };
+enum : int { XF_RATE0 = 1, XF_RATE1 = 2, XF_SKIP_VALID = 4 };
+struct alignas(8) ExtAct { int8_t type; uint8_t host; uint8_t arg; uint8_t ticks; uint16_t sid; uint8_t flags; uint8_t pad; double rate0, rate1; };
+static_assert(sizeof(ExtAct) == 24, "ExtAct mirrors cc4_agent_action (include/cc4.h)");
+enum : int { EXT_PER_ENV = NRED + MAXG };
+// a blue wrapper index may carry `action.duration` as well: bits 20..27 (0 = the class's own duration)
+enum : int { BLUE_DUR_SHIFT = 20, BLUE_IDX_MASK = (1 << BLUE_DUR_SHIFT) - 1 };
 
 // red observation entry (one dict key of the agent's combined Observation)
 enum : int { OE_KEY_IP = 1, OE_SESS = 2, OE_IFACE = 4, OE_SYSHN = 8 };
@@ -263,6 +287,10 @@ struct alignas(16) EnvCold {
   uint32_t eph[MAXH][EPH_WORDS];     // Host.ephemeral_ports as a bitmap (port-49152)
   EvLog evlog;                       // events of the last step when EvLog.enabled (cc4_enable_event_log)
   uint8_t kports[RS_POOL][MAXH + 7]; // RedAbstractSession.ports[ip]: PB_* bits | PB_HAS; row = pool slot of the session
+  double xrate[NRED][2];             // the probability attributes an externally submitted red action was queued with (ExtAct.rate0 / rate1:
+                                     // valid while the agent's queued / executing Act carries AQ_RATE0 / AQ_RATE1)
+  uint32_t gfail[4];                 // bit g: green_agent_g's action of the last step returned Observation(False) (what CybORG.step /
+                                     // parallel_step report as its 'success'; written by the full builds of the step only; word 3 unused)
 };
 static_assert(sizeof(EnvCold) % 16 == 0, "the containers behind the fixed part start 16-byte aligned");
 // Suspicious pids per blue agent: one per pid-carrying process_creation event in its zone, i.e. per successful red exploit

@@ -107,7 +107,12 @@ class TrueState:
             ip = IPv4Address(f'10.0.{d["cidr"][s]}.{hd["ip"]}')
             self.ip_map[name] = ip
             procs = []
+            svc_kind_of = {pid_: k_ for k_, _a, _rel, pid_ in hd['svcs']}
             for pid, kind, root in hd['procs']:
+                if kind == 13:            # K_PLAIN: a port-less process added by cc4_edit_state op 1; it carries its service's name
+                    p = {'PID': pid, 'process_name': KIND_NAME[svc_kind_of.get(pid, 1)], 'username': 'root' if root else 'user'}
+                    procs.append(p)
+                    continue
                 p = {'PID': pid, 'process_name': KIND_NAME[kind], 'username': 'root' if root else 'user'}
                 if KIND_PORT[kind] is not None:
                     p['Connections'] = [{'local_port': KIND_PORT[kind], 'local_address': IPv4Address('0.0.0.0')}]
@@ -378,3 +383,108 @@ class TrueStateTableWrapper:
                 s = by_pid.get(p['PID'])
                 tables[sn].add_row([hostname, p['PID'], p.get('process_name', '-'), p.get('username', '-'), s['agent'] if s else '-', s['session_id'] if s else '-'])
         return tables
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Red dict observations: what CybORG.get_observation('red_agent_r') / Results.observation hold after a step
+# (env.py:270-283; what a red agent's get_action consumes, FiniteStateRedAgent.py:190-250).  The engine keeps, per red agent and step,
+# the ordered keys of the combined observation with what each holds (RedAgent.obs: ip- or hostname-keyed; 'Sessions' /
+# 'Interface' / 'System info'), `success` and the action of observations[0], whether the end-of-turn RedSessionCheck listed the
+# agent's sessions (RedSessionCheck.py:57-65: one hostname-keyed entry per session with Sessions / Interface{ip, Subnet} /
+# System info), and the session an exploit created.  From that and the true state this rebuilds the dict: 'success', 'action',
+# every key with its 'Interface' (ip_address, plus Subnet where the reference reports it: Pingsweep and the session listing),
+# 'Sessions' (session_id, agent, username, Type), 'System info' {'Hostname'}, and for a service discovery the target's open ports
+# as 'Processes' [{'Connections': [{'local_port', 'local_address'}]}] (Portscan.py:44-64).  Not rebuilt: the connection / process
+# details of an exploit's own observation and the process descriptions DegradeServices / DiscoverDeception attach (ephemeral
+# ports, paths, versions) -- nothing on the hot path or in the built-in agents reads them.
+OE_KEY_IP, OE_SESS, OE_IFACE, OE_SYSHN = 1, 2, 4, 8
+TERNARY = {0: 'UNKNOWN', 1: 'TRUE', 2: 'UNKNOWN', 3: 'FALSE', 4: 'IN_PROGRESS'}
+
+
+def _session_entry(r, sid, flags):
+    return {'session_id': sid, 'agent': f'red_agent_{r}', 'username': 'root' if flags & RS_ROOT else ('ubuntu' if flags & RS_ORIG else 'user'),
+            'Type': 'RED_ABSTRACT_SESSION' if flags & RS_ABSTRACT else 'SHELL'}
+
+
+def red_observations(ts):
+    """{agent: observation dict} of the six red agents for the step the TrueState was taken after."""
+    d = ts.raw
+    ip_of = {hd['h']: IPv4Address(f'10.0.{d["cidr"][hd["h"] // 17]}.{hd["ip"]}') for hd in d['hosts']}
+    procs_of = {hd['h']: hd['procs'] for hd in d['hosts']}
+    out = {}
+    for r, ag in enumerate(d['red']):
+        agent = f'red_agent_{r}'
+        obs = {'success': TERNARY[ag['obs_success']]}
+        atype = ag['obs_action'][0]
+        ex_type, _h, _a, executed = d['last_red'][r]
+        # 'action' of observations[0]: the agent's own action when it executed (Sleep and InvalidAction included); the end-of-turn
+        # RedSessionCheck when the action was dropped by filter_actions; absent while a multi-tick action runs or nothing was observed
+        if ag['obs_success'] not in (0, 4):
+            if atype != 11 or (executed and ex_type in (9, 10)):
+                obs['action'] = ts.last_action[agent]
+            elif not executed:
+                obs['action'] = LastAction('RedSessionCheck', agent)
+        sess_on = {}
+        for sid, h, pid, fl in ag['sessions']:
+            sess_on.setdefault(h, []).append(_session_entry(r, sid, fl))
+        new_h, new_id = ag.get('new_session', [255, 0])
+        for h, fl in ag['obs']:
+            if h not in ip_of:
+                continue
+            key = str(ip_of[h]) if fl & OE_KEY_IP else hostname_of(h)
+            e = obs.setdefault(key, {})
+            if fl & OE_IFACE:
+                itf = {'ip_address': ip_of[h]}
+                if atype == 0 and fl & OE_KEY_IP:                     # Pingsweep reports the subnet with every address
+                    itf['Subnet'] = ts.cidr[SUBNETS[h // 17]]
+                e['Interface'] = [itf]
+            if fl & OE_SESS:
+                if fl & OE_KEY_IP and h == new_h:                     # the exploit's own report of the session it opened
+                    sid_now = new_id
+                    if not any(s_[0] == new_id and s_[1] == h for s_ in ag['sessions']):
+                        # the session landed in another agent's zone and different_subnet_agent_reassignment handed it over within
+                        # the same step (SC:820-903): the report shows the ident it has there (the last session that agent got on the host)
+                        for other in d['red']:
+                            if other is not ag:
+                                here = [s_ for s_ in other['sessions'] if s_[1] == h]
+                                if here:
+                                    sid_now = here[-1][0]
+                    e['Sessions'] = [{'session_id': sid_now, 'agent': agent, 'username': 'user', 'Type': 'SHELL'}]
+                else:
+                    e['Sessions'] = [dict(s) for s in sess_on.get(h, [])]
+            if fl & OE_SYSHN:
+                e['System info'] = {'Hostname': hostname_of(h)}
+            if atype in (1, 2) and fl & OE_KEY_IP and h == ag['obs_action'][1] and ag['obs_success'] == 1:
+                e['Processes'] = [{'Connections': [{'local_port': KIND_PORT[k], 'local_address': ip_of[h]}]}
+                                  for _pid, k, _root in procs_of[h] if k < len(KIND_PORT) and KIND_PORT[k] is not None]
+        if ag['rsc_listed']:
+            for sid, h, pid, fl in ag['sessions']:
+                e = obs.setdefault(hostname_of(h), {})
+                e['Interface'] = [{'ip_address': ip_of[h], 'Subnet': ts.cidr[SUBNETS[h // 17]]}]
+                lst = e.setdefault('Sessions', [])
+                if not any(s['session_id'] == sid for s in lst):
+                    lst.append(_session_entry(r, sid, fl))
+                e['System info'] = {'Hostname': hostname_of(h)}
+        out[agent] = obs
+    return out
+
+
+def red_obs_skeleton(obs):
+    """The part of a red dict observation red_observations() rebuilds, in canonical form (works on the reference's dicts as well):
+    {'success', 'action' (str or None), 'hosts': {key: {'ips': [[ip, has Subnet]...], 'sessions': [[id, username]...], 'hostname', 'ports'}}}."""
+    sk = {'success': getattr(obs.get('success'), 'name', obs.get('success')), 'action': None if obs.get('action') is None else str(obs['action']).split(' ')[0],
+          'hosts': {}}
+    for key, v in obs.items():
+        if key in ('success', 'action', 'message') or not isinstance(v, dict):
+            continue
+        e = {}
+        if 'Interface' in v:
+            e['ips'] = sorted([str(i['ip_address']), 'Subnet' in i] for i in v['Interface'] if 'ip_address' in i)
+        if 'Sessions' in v:
+            e['sessions'] = sorted([int(s['session_id']), str(s.get('username'))] for s in v['Sessions'])
+        if 'System info' in v and 'Hostname' in v['System info']:
+            e['hostname'] = str(v['System info']['Hostname'])
+        if sk['action'] in ('AggressiveServiceDiscovery', 'StealthServiceDiscovery') and 'Processes' in v:
+            e['ports'] = sorted(int(c['local_port']) for p in v['Processes'] for c in p.get('Connections', []) if 'local_port' in c and 'remote_port' not in c)
+        sk['hosts'][str(key)] = e
+    return sk

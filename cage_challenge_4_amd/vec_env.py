@@ -128,6 +128,46 @@ class CC4VecEnv:
         obs, rew, done = self._fetch()
         return obs, rew, done, {'err': self._err}
 
+    def agent_actions(self, kind):
+        """An all-CC4_ACT_NONE array of cc4_agent_action records for step_ex: [N, 6] ('red') or [N, 80] ('green'); numpy
+        structured dtype with the fields of include/cc4.h (type, host, arg, ticks, session, flags, rate0, rate1)."""
+        a = np.zeros((self.num_envs, L.NUM_RED if kind == 'red' else L.MAX_GREEN), dtype=L.AGENT_ACTION_DTYPE)
+        a['type'] = -1
+        return a
+
+    def step_ex(self, actions=None, messages=None, red=None, green=None):
+        """cc4_step_ex: a step that also takes the red / green entries of the reference's `actions` dict (SimulationController.py:
+        236-240) as agent_actions() arrays.  The blue indices may carry `action.duration` in bits 20..27."""
+        ap = mp = rp = gp = None
+        if actions is not None:
+            actions = np.ascontiguousarray(actions, dtype=np.int32)
+            assert actions.shape == (self.num_envs, L.NUM_BLUE)
+            ap = actions.ctypes.data_as(ctypes.c_void_p)
+        if messages is not None:
+            messages = np.ascontiguousarray(messages, dtype=np.uint8)
+            assert messages.shape == (self.num_envs, L.NUM_BLUE, L.MSG_LEN)
+            mp = messages.ctypes.data_as(ctypes.c_void_p)
+        if red is not None:
+            red = np.ascontiguousarray(red, dtype=L.AGENT_ACTION_DTYPE)
+            assert red.shape == (self.num_envs, L.NUM_RED) and red.dtype.itemsize == 24
+            rp = red.ctypes.data_as(ctypes.c_void_p)
+        if green is not None:
+            green = np.ascontiguousarray(green, dtype=L.AGENT_ACTION_DTYPE)
+            assert green.shape == (self.num_envs, L.MAX_GREEN) and green.dtype.itemsize == 24
+            gp = green.ctypes.data_as(ctypes.c_void_p)
+        self._chk(self.lib.cc4_step_ex(self._h, ap, mp, rp, gp), 'cc4_step_ex')
+        obs, rew, done = self._fetch()
+        return obs, rew, done, {'err': self._err}
+
+    def edit_state(self, env, op, a0=0, a1=0, a2=0):
+        """cc4_edit_state: a direct edit of one episode between steps (what the reference's scripted tests do to
+        env.environment_controller.state by hand): op 0 mission phase, 1 add service, 2 service reliability, 3 clear host,
+        4 deploy one decoy kind (include/cc4.h).  Returns the op's result (>= 0)."""
+        rc = int(self.lib.cc4_edit_state(self._h, int(env), int(op), int(a0), int(a1), int(a2)))
+        if rc < 0:
+            self._chk(rc, 'cc4_edit_state')
+        return rc
+
     def _fetch(self, mask=False):
         self._chk(self.lib.cc4_get_obs(self._h, self._obs.ctypes.data_as(ctypes.c_void_p)), 'cc4_get_obs')
         self._chk(self.lib.cc4_get_reward_done(self._h, self._rew.ctypes.data_as(ctypes.c_void_p),
@@ -240,6 +280,13 @@ class CC4VecEnv:
         self._chk(self.lib.cc4_run_random_steps(self._h, ctypes.c_uint64(seed0), ctypes.c_uint32(t0), int(k),
                                                 ctypes.byref(ms) if timed else None), 'cc4_run_random_steps')
         return float(ms.value)
+
+    def device_actions(self):
+        """cc4_get_actions: host copy of the handle's device action buffer ([N, 5]; after run_random_steps: the indices the last
+        step drew in-kernel)."""
+        out = np.zeros((self.num_envs, L.NUM_BLUE), np.int32)
+        self._chk(self.lib.cc4_get_actions(self._h, out.ctypes.data_as(ctypes.c_void_p)), 'cc4_get_actions')
+        return out
 
     def synchronize(self):
         self._chk(self.lib.cc4_synchronize(self._h), 'cc4_synchronize')

@@ -85,6 +85,31 @@ void cc4o_step(void* h, int i, const int32_t* actions, const uint8_t* msgs) {
   x.lg = o->evlog ? &o->cold(i)->evlog : nullptr;
   env_step(x, actions, msgs);
 }
+// cc4_step_ex (include/cc4.h): the step with the red / green entries of the `actions` dict; ext = EXT_PER_ENV records
+// (NRED red, then MAXG green; type XA_NONE = nothing submitted for that agent), or null
+void cc4o_step_ex(void* h, int i, const int32_t* actions, const uint8_t* msgs, const ExtAct* ext) {
+  Oracle* o = (Oracle*)h;
+  StepWork w; memset(&w, 0, sizeof(w));
+  Ctx x{&o->st[i], o->cold(i), &o->st[i].rng, o->st[i].hd, &w};
+  x.lg = o->evlog ? &o->cold(i)->evlog : nullptr;
+  // once an episode has taken a submitted action its later steps keep serving the rates a queued action came with
+  // (libcc4: the handle stays on the full builds of its step kernels)
+  static const ExtAct none[EXT_PER_ENV] = {};
+  static ExtAct all_none[EXT_PER_ENV];
+  static bool init = false;
+  if (!init) { memset(all_none, 0xFF, sizeof(all_none)); init = true; }
+  (void)none;
+  x.ext = ext ? ext : all_none;
+  env_step(x, actions, msgs);
+}
+size_t cc4o_ext_bytes() { return sizeof(ExtAct) * EXT_PER_ENV; }
+// cc4_edit_state (include/cc4.h)
+int cc4o_edit_state(void* h, int i, int op, int a0, int a1, int a2) {
+  Oracle* o = (Oracle*)h;
+  StepWork w; memset(&w, 0, sizeof(w));
+  Ctx x{&o->st[i], o->cold(i), &o->st[i].rng, o->st[i].hd, &w};
+  return state_edit(x, op, a0, a1, a2);
+}
 // cc4o_step that also checks the engine's dirty-row marks (StepWork.hdirty, hd_touch): returns the number of HostDyn rows the
 // step changed WITHOUT marking them (must be 0: the four-wave kernel writes back only marked rows), *marked = rows marked
 int cc4o_step_check_marks(void* h, int i, const int32_t* actions, const uint8_t* msgs, int* marked) {
@@ -248,7 +273,7 @@ int cc4o_dump(void* h, int i, char* buf, int cap) {
     P(" fsmstep %d fsm", a.h.fsm_step);
     for (int k = 0; k < a.h.fsm_n; ++k) { int hh = a.fsm_order[k]; P(" (%d,%d,%d)", hh, fsm_get(a, hh), bit_get(a.fsm_hn, hh) ? 1 : 0); }
     for (int hh = 0; hh < MAXH; ++hh) if (fsm_get(a, hh) == FS_F) P(" (%d,%d,%d)", hh, FS_F, bit_get(a.fsm_hn, hh) ? 1 : 0);  // 'F' hosts after the live list
-    P(" subnets %u busy %d qt %d\n", a.h.as_subnet, a.h.queue.busy, a.h.queue.busy ? a.h.queue.type : -1);
+    P(" subnets %u busy %d qt %d\n", a.h.as_subnet, a.h.queue.busy ? 1 : 0, a.h.queue.busy ? a.h.queue.type : -1);
   }
   for (int b = 0; b < NBLUE; ++b) {
     const BlueAgent& a = s.blue[b];

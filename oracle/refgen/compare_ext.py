@@ -1,0 +1,302 @@
+"""Differential test of EXTERNALLY SUBMITTED red / green / blue actions: reference CybORG (this container only) vs the CPU oracle.
+
+SimulationController.step takes `actions[agent_name]` for any agent and asks the scenario's agent object only for the agents the
+dict has no entry for (SimulationController.py:236-240).  Here every step submits, for a random subset of the red and green agents,
+an Action object built from what the REFERENCE's own ActionSpace / state currently hold (valid parameters most of the time, unknown
+or stale ones now and then), with `duration`, `detection_rate`, `fp_rate`, `fp_detection_rate`, `phishing_error_rate` overrides
+mixed in; the blue agents get wrapper indices, some with a `duration` of their own.  The oracle gets the same step through
+cc4o_step_ex (ExtAct records, csrc/cc4_state.h).  After every step: flat observations, reward, done, generator position, the full
+canonical state dump (ref_dump.py), and the `success` every submitting agent got back.
+
+usage: python compare_ext.py <seed> [steps] [red: fsm|sleep|discovery|random] [green: enterprise|sleep] [p_red] [p_green] [max_steps]"""
+import sys, os, ctypes
+import numpy as np
+sys.path.insert(0, os.path.dirname(__file__))
+import ref_shim  # noqa
+from ref_dump import dump, host_index, subnet_index
+from compare import lib, canon_ref, RED, GREEN
+from CybORG import CybORG
+from CybORG.Simulator.Scenarios import EnterpriseScenarioGenerator
+from CybORG.Agents import SleepAgent
+from CybORG.Agents.Wrappers import BlueFlatWrapper
+from CybORG.Simulator.Actions import (DiscoverRemoteSystems, AggressiveServiceDiscovery, StealthServiceDiscovery, DiscoverDeception,
+                                      ExploitRemoteService, PrivilegeEscalate, Impact, DegradeServices, Withdraw, Sleep, Monitor)
+from CybORG.Simulator.Actions.GreenActions import GreenAccessService, GreenLocalWork
+
+RA = {'DiscoverRemoteSystems': 0, 'AggressiveServiceDiscovery': 1, 'StealthServiceDiscovery': 2, 'DiscoverDeception': 3,
+      'ExploitRemoteService': 4, 'PrivilegeEscalate': 5, 'Impact': 6, 'DegradeServices': 7, 'Withdraw': 8, 'Sleep': 9, 'Invalid': 10}
+TERN = {'TRUE': 1, 'UNKNOWN': 2, 'FALSE': 3, 'IN_PROGRESS': 4}
+NRED, MAXG = 6, 80
+
+
+class ExtAct(ctypes.Structure):   # csrc/cc4_state.h ExtAct == include/cc4.h cc4_agent_action
+    _fields_ = [('type', ctypes.c_int8), ('host', ctypes.c_uint8), ('arg', ctypes.c_uint8), ('ticks', ctypes.c_uint8),
+                ('sid', ctypes.c_uint16), ('flags', ctypes.c_uint8), ('pad', ctypes.c_uint8), ('rate0', ctypes.c_double), ('rate1', ctypes.c_double)]
+
+
+lib.cc4o_step_ex.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
+lib.cc4o_true_state.restype = ctypes.c_longlong
+lib.cc4o_true_state.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_char_p, ctypes.c_size_t]
+
+
+def empty_ext():
+    arr = (ExtAct * (NRED + MAXG))()
+    ctypes.memset(arr, 0xFF, ctypes.sizeof(arr))
+    return arr
+
+
+def encode(action, rec, st, kind):
+    """Action object -> ExtAct record (what wrappers.py does on the product side).  kind: 'red' | 'green'."""
+    rec.flags = 0; rec.host = 0; rec.arg = 0; rec.sid = 0; rec.rate0 = 0.0; rec.rate1 = 0.0; rec.pad = 0
+    name = type(action).__name__
+    cls_default = type(action)(**{k: v for k, v in action.get_params().items()}) if False else None  # noqa
+    dur = getattr(action, 'duration', 1)
+    if kind == 'red':
+        if name not in RA:
+            rec.type = 10; rec.ticks = 0
+            return
+        rec.type = RA[name]
+        default_dur = {0: 1, 1: 1, 2: 3, 3: 2, 4: 4, 5: 2, 6: 2, 7: 2, 8: 1, 9: 1}[rec.type]
+        rec.ticks = 0 if dur == default_dur else dur
+        if name == 'Sleep':
+            return
+        rec.sid = int(action.session)
+        if name == 'DiscoverRemoteSystems':
+            rec.arg = [subnet_index(n) for n, c in st.subnet_name_to_cidr.items() if c == action.subnet][0]
+        elif name in ('PrivilegeEscalate', 'Impact', 'DegradeServices'):
+            rec.host = host_index(action.hostname)
+        elif name == 'Withdraw':
+            rec.host = host_index(st.ip_addresses[action.ip_address]); rec.arg = host_index(action.hostname)
+        else:
+            rec.host = host_index(st.ip_addresses[action.ip_address])
+        if name in ('AggressiveServiceDiscovery', 'StealthServiceDiscovery'):
+            if action.detection_rate != {'AggressiveServiceDiscovery': 0.75, 'StealthServiceDiscovery': 0.25}[name]:
+                rec.flags |= 1; rec.rate0 = float(action.detection_rate)
+        if name == 'DiscoverDeception':
+            if action.detection_rate != 0.5:
+                rec.flags |= 1; rec.rate0 = float(action.detection_rate)
+            if action.fp_rate != 0.1:
+                rec.flags |= 2; rec.rate1 = float(action.fp_rate)
+    else:
+        rec.ticks = 0
+        if name == 'GreenLocalWork':
+            rec.type = 1; rec.host = host_index(st.ip_addresses[action.ip_address])
+            if action.fp_detection_rate != 0.01:
+                rec.flags |= 1; rec.rate0 = float(action.fp_detection_rate)
+            if action.phishing_error_rate != 0.01:
+                rec.flags |= 2; rec.rate1 = float(action.phishing_error_rate)
+        elif name == 'GreenAccessService':
+            rec.type = 0; rec.host = host_index(st.ip_addresses[action.ip_address])
+            m = 0
+            for sn in action.allowed_subnets:
+                m |= 1 << subnet_index(sn)
+            rec.sid = m
+            if action.fp_detection_rate != 0.01:
+                rec.flags |= 1; rec.rate0 = float(action.fp_detection_rate)
+        elif name == 'Sleep':
+            rec.type = 2
+        else:
+            rec.type = 3
+
+
+class ExtPolicy:
+    """Random submitted actions, built from the reference's own state."""
+    def __init__(self, env, seed, p_red, p_green):
+        self.env = env
+        self.rng = np.random.default_rng(seed ^ 0xE57)
+        self.p_red, self.p_green = p_red, p_green
+
+    def red_action(self, agent):
+        ec = self.env.environment_controller
+        st = ec.state
+        sp = ec.agent_interfaces[agent].action_space
+        r = self.rng
+        known_ips = [ip for ip, v in sp.ip_address.items() if v]
+        all_ips = list(st.ip_addresses.keys())
+        known_hn = [h for h, v in sp.hostname.items() if v]
+        all_hn = list(st.hosts.keys())
+        known_sub = [c for c, v in sp.subnet.items() if v]
+        all_sub = list(st.subnet_name_to_cidr.values())
+        sess = list(st.sessions[agent].keys())
+        sess_hosts = [s.hostname for s in st.sessions[agent].values()]
+
+        def pick(known, everything, p_known=0.85):
+            if known and r.random() < p_known:
+                return known[r.integers(len(known))]
+            return everything[r.integers(len(everything))]
+        sid = int(sess[r.integers(len(sess))]) if sess and r.random() < 0.9 else int(r.integers(0, 6))
+        c = r.integers(10)
+        ag = ec.agent_interfaces[agent].agent
+        if hasattr(ag, 'host_states'):
+            # An FSM agent that later reads the observation of a hostname-keyed action (PrivilegeEscalate / Impact / DegradeServices
+            # report under the hostname, without an Interface entry) on a host whose hostname it has never seen files it under
+            # host_states[None] (FiniteStateRedAgent.py:213-238) and goes on to act on "ip None": a corner of the reference the
+            # engine flags (E_UNREACHABLE) instead of following.  The fuzz keeps such actions to hostnames the agent's FSM knows.
+            fsm_names = [d['hostname'] for d in ag.host_states.values() if d.get('hostname')]
+            if c in (5, 6, 7):
+                if not fsm_names:
+                    c = 9
+                else:
+                    sess_hosts = [h for h in sess_hosts if h in fsm_names]
+                    known_hn = [h for h in known_hn if h in fsm_names] or fsm_names
+                    all_hn = known_hn
+        if c == 0:
+            a = DiscoverRemoteSystems(subnet=pick(known_sub, all_sub), session=sid, agent=agent)
+        elif c == 1:
+            a = AggressiveServiceDiscovery(session=sid, agent=agent, ip_address=pick(known_ips, all_ips))
+        elif c == 2:
+            a = StealthServiceDiscovery(session=sid, agent=agent, ip_address=pick(known_ips, all_ips))
+        elif c == 3:
+            a = DiscoverDeception(session=sid, agent=agent, ip_address=pick(known_ips, all_ips))
+        elif c == 4:
+            a = ExploitRemoteService(ip_address=pick(known_ips, all_ips), session=sid, agent=agent)
+        elif c == 5:
+            a = PrivilegeEscalate(hostname=pick(sess_hosts or known_hn, all_hn), session=sid, agent=agent)
+        elif c == 6:
+            a = Impact(hostname=pick(sess_hosts or known_hn, all_hn), session=sid, agent=agent)
+        elif c == 7:
+            a = DegradeServices(hostname=pick(sess_hosts or known_hn, all_hn), session=sid, agent=agent)
+        elif c == 8:
+            hn = pick(sess_hosts or known_hn, all_hn)
+            a = Withdraw(session=sid, agent=agent, ip_address=st.hostname_ip_map[hn] if r.random() < 0.8 else pick(known_ips, all_ips), hostname=hn)
+        else:
+            a = Sleep() if r.random() < 0.7 else Monitor(session=0, agent=agent)     # a blue class: not in a red agent's action space
+        if r.random() < 0.5 and not isinstance(a, (Sleep, Monitor)):
+            a.duration = int(r.integers(1, 4))
+        if isinstance(a, (AggressiveServiceDiscovery, StealthServiceDiscovery)) and r.random() < 0.4:
+            a.detection_rate = float(r.choice([0.0, 1.0, 0.5]))
+        if isinstance(a, DiscoverDeception) and r.random() < 0.5:
+            a.detection_rate = float(r.choice([0.0, 1.0, 0.3])); a.fp_rate = float(r.choice([0.0, 1.0, 0.2]))
+        return a
+
+    def green_action(self, agent, green_sleep):
+        ec = self.env.environment_controller
+        st = ec.state
+        ai = ec.agent_interfaces[agent]
+        ip = st.hostname_ip_map[st.sessions[agent][0].hostname]
+        r = self.rng
+        c = r.integers(3)
+        if c == 0:
+            a = GreenLocalWork(agent=agent, session_id=0, ip_address=ip, fp_detection_rate=float(r.choice([0.01, 0.0, 1.0, 0.3])),
+                               phishing_error_rate=float(r.choice([0.01, 0.0, 1.0, 0.2])))
+        elif c == 1:
+            a = GreenAccessService(agent=agent, session_id=0, src_ip=ip, allowed_subnets=ai.allowed_subnets,
+                                   fp_detection_rate=float(r.choice([0.01, 0.0, 1.0])))
+        else:
+            a = Sleep()
+        return a
+
+
+def run(seed, steps=200, red='fsm', green='enterprise', p_red=0.4, p_green=0.1, max_steps=None, verbose=True):
+    sg = EnterpriseScenarioGenerator(blue_agent_class=SleepAgent, green_agent_class=GREEN[green][0], red_agent_class=RED[red][0], steps=steps)
+    pol = RED[red][1] | (0x10 if GREEN[green][1] else 0)
+    env = CybORG(sg, seed=seed)
+    w = BlueFlatWrapper(env)
+    H = ctypes.c_void_p(lib.cc4o_create2(1, steps))
+    lib.cc4o_reset(H, 0, ctypes.c_uint64(seed), 0, steps, 0, pol)
+    obs, info = w.reset()
+    lib.cc4o_reset(H, 0, ctypes.c_uint64(seed), 0, steps, 1, pol)
+    ec = env.environment_controller
+    arng = np.random.default_rng(seed ^ 0xB10E)
+    xp = ExtPolicy(env, seed, p_red, p_green)
+    buf = ctypes.create_string_buffer(1 << 20)
+    import json
+    n_sub = n_inv = 0
+    for t in range(max_steps or steps):
+        a = np.array([arng.integers(82), arng.integers(82), arng.integers(82), arng.integers(82), arng.integers(242)], np.int32)
+        acts = {f'blue_agent_{b}': int(a[b]) for b in range(5)}
+        for b in range(5):                                  # a blue action with its own duration now and then
+            if arng.random() < 0.15:
+                act = w._action_space[f'blue_agent_{b}']['actions'][int(a[b])]
+                import copy
+                act = copy.copy(act)
+                d = int(arng.integers(1, 4))
+                act.duration = d
+                acts[f'blue_agent_{b}'] = act
+                a[b] = int(a[b]) | (d << 20)
+        ext = empty_ext()
+        submitted = {}
+        for r in range(NRED):
+            if xp.rng.random() < p_red:
+                agent = f'red_agent_{r}'
+                act = xp.red_action(agent)
+                encode(act, ext[r], ec.state, 'red')
+                acts[agent] = act; submitted[agent] = ('red', r)
+        ng = sum(1 for n_ in ec.agent_interfaces if 'green' in n_)
+        for g in range(ng):
+            if xp.rng.random() < p_green:
+                agent = f'green_agent_{g}'
+                act = xp.green_action(agent, green == 'sleep')
+                encode(act, ext[NRED + g], ec.state, 'green')
+                acts[agent] = act; submitted[agent] = ('green', g)
+        obs, rew, term, trunc, info = w.step(acts)
+        lib.cc4o_step_ex(H, 0, a.ctypes.data_as(ctypes.c_void_p), None, ext)
+        ok = True
+        tag = f'step {t}'
+        o = np.zeros(578, np.int32)
+        lib.cc4o_obs(H, 0, o.ctypes.data_as(ctypes.c_void_p))
+        ro = np.concatenate([obs[f'blue_agent_{b}'] for b in range(5)]).astype(np.int32)
+        if not np.array_equal(o, ro):
+            print(tag, 'OBS MISMATCH at', np.nonzero(o != ro)[0][:20]); ok = False
+        stt = ec.np_random.bit_generator.state
+        rs = (ctypes.c_uint64 * 7)()
+        lib.cc4o_rng_state(H, 0, rs)
+        if (rs[0] << 64 | rs[1]) != stt['state']['state'] or rs[4] != stt['has_uint32'] or (rs[4] and rs[5] != stt['uinteger']):
+            print(tag, 'RNG MISMATCH'); ok = False
+        rr = lib.cc4o_reward(H, 0)
+        if abs(rr - rew['blue_agent_0']) > 1e-6:
+            print(tag, 'REWARD MISMATCH', rr, rew['blue_agent_0']); ok = False
+        n = lib.cc4o_dump(H, 0, buf, len(buf))
+        mine = buf.raw[:n].decode()
+        ref = canon_ref(dump(env))
+        if mine != ref:
+            ok = False
+            for x_, y_ in zip(mine.split('\n'), ref.split('\n')):
+                if x_ != y_:
+                    print(tag, 'STATE DIFF\n  mine:', x_, '\n  ref :', y_)
+        if lib.cc4o_err(H, 0):
+            print(tag, 'ERR FLAGS', hex(lib.cc4o_err(H, 0))); ok = False
+        need = lib.cc4o_true_state(H, 0, None, 0)
+        jb = ctypes.create_string_buffer(need)
+        lib.cc4o_true_state(H, 0, jb, need)
+        ts = json.loads(jb.value.decode())
+        for agent, (kind, k) in submitted.items():
+            n_sub += 1
+            ro_ = env.get_observation(agent)
+            suc = TERN[ro_['success'].name]
+            if kind == 'red':
+                n_inv += 'Invalid' in str(ro_.get('action'))
+                # (0 = the step left the agent no observation at all -- its action was dropped by filter_actions and it holds no
+                # session for a RedSessionCheck: get_last_observation then hands out an empty Observation(), success UNKNOWN)
+                if (ts['red'][k]['obs_success'] or 2) != suc:
+                    print(tag, agent, 'SUCCESS MISMATCH mine', ts['red'][k]['obs_success'], 'ref', suc, acts[agent]); ok = False
+            else:
+                fail = (ts['green_fail'][k >> 5] >> (k & 31)) & 1
+                if isinstance(acts[agent], Sleep):
+                    exp_fail = 0
+                else:
+                    exp_fail = int(suc == 3)
+                if fail != exp_fail:
+                    print(tag, agent, 'GREEN SUCCESS MISMATCH mine fail', fail, 'ref', ro_['success'], acts[agent]); ok = False
+        if not ok:
+            if verbose:
+                print('blue', a.tolist())
+                for agent in submitted:
+                    print(' submitted', agent, acts[agent], getattr(acts[agent], 'duration', None))
+                for r in range(6):
+                    print(' red', r, ec.action.get(f'red_agent_{r}'))
+            return t
+    if verbose:
+        print('OK seed', seed, 'red', red, 'green', green, 'submitted', n_sub, 'invalid', n_inv)
+    return None
+
+
+if __name__ == '__main__':
+    seed = int(sys.argv[1])
+    steps = int(sys.argv[2]) if len(sys.argv) > 2 else 200
+    red = sys.argv[3] if len(sys.argv) > 3 else 'fsm'
+    green = sys.argv[4] if len(sys.argv) > 4 else 'enterprise'
+    p_red = float(sys.argv[5]) if len(sys.argv) > 5 else 0.4
+    p_green = float(sys.argv[6]) if len(sys.argv) > 6 else 0.1
+    mx = int(sys.argv[7]) if len(sys.argv) > 7 else None
+    sys.exit(0 if run(seed, steps, red, green, p_red, p_green, mx) is None else 1)

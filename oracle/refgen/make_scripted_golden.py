@@ -1,0 +1,644 @@
+"""Records the reference's own SCRIPTED tests as fixtures: tests/golden/scripted_*.json  (TEST INFRASTRUCTURE).
+
+CybORG/Tests/test_cc4/{test_blocking_red, test_blue_actions, test_BlueRewardMachine}.py and test_Red/{test_Impact,
+test_DegradeServices, test_DiscoverDeception, test_Withdraw, test_RedSessionCheck}.py drive the simulator with hand-built Action
+objects for red, green and blue agents (SleepAgent everywhere else), shorten actions with `action.duration = 1`, pin
+probabilities (`detection_rate`, `fp_rate`, `fp_detection_rate`, `phishing_error_rate`) to 0 or 1 and poke
+env.environment_controller.state by hand.  Each test is re-expressed here as (seed, script of state edits and steps) and run on
+the REAL reference (imported from /root/reference: this container only); what the reference does at every step is recorded --
+flat blue observations, team reward, done, numpy stream position, `success` of every submitting agent, the active red agents,
+the malware files per host and a digest of the full canonical state dump (ref_dump.py) -- together with the step's input in the
+engine's terms (cc4_step_ex records, cc4_edit_state ops).  The oracle replays the script in lockstep while recording, so a
+fixture that the restatement cannot reproduce is reported here, not later.  tests/test_scripted.py replays the fixtures on the
+oracle (CPU) and on all three HIP step kernels (GPU).
+
+Where a test pokes something the engine has no notion of (a Process named after the agent, a service keyed by a bare string) the
+re-expression uses the canonical object of the same meaning (ProcessName.OTSERVICE, as test_Impact.py:89-101 does); where a test
+calls action.execute(state) directly, the action goes through a step instead (SleepAgents everywhere: nothing else happens in it).
+
+usage: python make_scripted_golden.py [name-filter]"""
+import sys, os, json, hashlib, ctypes, copy
+import numpy as np
+sys.path.insert(0, os.path.dirname(__file__))
+sys.path.insert(0, os.path.join(os.path.dirname(__file__), '..', '..'))
+import ref_shim  # noqa
+import ref_dump
+from ref_dump import dump, host_index, subnet_index
+from compare import lib, canon_ref, RED, GREEN
+from compare_ext import ExtAct, empty_ext, encode, TERN, NRED, MAXG
+from CybORG import CybORG
+from CybORG.Simulator.Scenarios import EnterpriseScenarioGenerator
+from CybORG.Agents import SleepAgent, EnterpriseGreenAgent, FiniteStateRedAgent
+from CybORG.Agents.Wrappers import BlueFlatWrapper
+from CybORG.Shared.Enums import ProcessName, ProcessType
+from CybORG.Shared.Session import Session
+from CybORG.Simulator.Process import Process
+from CybORG.Simulator.Service import Service
+from CybORG.Simulator.Actions import (DiscoverRemoteSystems, AggressiveServiceDiscovery, StealthServiceDiscovery, DiscoverDeception,
+                                      ExploitRemoteService, PrivilegeEscalate, Impact, DegradeServices, Sleep, Monitor, Analyse,
+                                      Restore, Remove, DeployDecoy)
+from CybORG.Simulator.Actions.ConcreteActions.Withdraw import Withdraw
+from CybORG.Simulator.Actions.ConcreteActions.ControlTraffic import BlockTrafficZone, AllowTrafficZone
+from CybORG.Simulator.Actions.ConcreteActions.DecoyActions import DecoyHarakaSMPT, DecoyApache, DecoyTomcat, DecoyVsftpd
+from CybORG.Simulator.Actions.GreenActions.GreenLocalWork import GreenLocalWork
+from CybORG.Simulator.Actions.GreenActions.GreenAccessService import GreenAccessService
+
+from CybORG.Shared.Enums import SessionType
+ref_dump.KIND['shell'] = ref_dump.KIND[SessionType.SHELL] = 12   # Process(name=session_type='shell') of a poked plain session: the engine's K_SHELL
+OUT = os.path.join(os.path.dirname(__file__), '..', '..', 'tests', 'golden')
+lib.cc4o_step_ex.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
+lib.cc4o_edit_state.argtypes = [ctypes.c_void_p] + [ctypes.c_int] * 5
+BA = {'Sleep': 0, 'Monitor': 1, 'Analyse': 2, 'Remove': 3, 'Restore': 4, 'DeployDecoy': 5, 'BlockTrafficZone': 6, 'AllowTrafficZone': 7}
+BLUE_DUR = {'Sleep': 1, 'Monitor': 1, 'Analyse': 2, 'Remove': 3, 'Restore': 5, 'DeployDecoy': 2, 'BlockTrafficZone': 1, 'AllowTrafficZone': 1}
+ALL_SUBNETS = ['admin_network_subnet', 'contractor_network_subnet', 'office_network_subnet', 'operational_zone_a_subnet',
+               'operational_zone_b_subnet', 'public_access_zone_subnet', 'restricted_zone_a_subnet', 'restricted_zone_b_subnet']
+
+
+def sha(txt):
+    return hashlib.sha256(txt.encode()).hexdigest()[:32]
+
+
+class Case:
+    """One environment: the reference and the oracle in lockstep; everything done to them is recorded."""
+    def __init__(self, seed, steps=100, red='sleep', green='sleep', resets=0, note=''):
+        sg = EnterpriseScenarioGenerator(blue_agent_class=SleepAgent, green_agent_class=GREEN[green][0], red_agent_class=RED[red][0], steps=steps)
+        self.pol = RED[red][1] | (0x10 if GREEN[green][1] else 0)
+        self.env = CybORG(sg, seed=seed)
+        self.w = BlueFlatWrapper(self.env)
+        self.H = ctypes.c_void_p(lib.cc4o_create2(1, steps))
+        lib.cc4o_reset(self.H, 0, ctypes.c_uint64(seed), 0, steps, 0, self.pol)
+        self.w.reset()                                                     # == CybORG(seed); cyborg.reset()
+        lib.cc4o_reset(self.H, 0, ctypes.c_uint64(seed), 0, steps, 1, self.pol)
+        self.steps = steps
+        self.rec = {'seed': seed, 'steps': steps, 'red_policy': RED[red][1], 'green_policy': GREEN[green][1], 'resets': 0, 'note': note, 'script': []}
+        for _ in range(resets):
+            self.reset_again()
+        self.ec = self.env.environment_controller
+        self.st = self.ec.state
+        self._check('reset')
+
+    def reset_again(self):
+        """another env.reset() on the running stream (the reference's tests loop on it until a host lacks a service)"""
+        self.w.reset()
+        lib.cc4o_reset(self.H, 0, 0, 0, self.steps, 1, self.pol)
+        self.rec['resets'] += 1
+        self.ec = self.env.environment_controller
+        self.st = self.ec.state
+
+    # ---- helpers over the reference's state
+    def ip(self, hostname):
+        return self.st.hostname_ip_map[hostname]
+
+    def cidr(self, subnet):
+        return self.st.subnet_name_to_cidr[subnet]
+
+    def green_of(self, hostname):
+        return [a for a, s in self.st.hosts[hostname].sessions.items() if len(s) > 0 and 'green' in a][0]
+
+    def _dump_pair(self):
+        buf = ctypes.create_string_buffer(1 << 20)
+        n = lib.cc4o_dump(self.H, 0, buf, len(buf))
+        return buf.raw[:n].decode(), canon_ref(dump(self.env))
+
+    def _check(self, tag):
+        st = self.env.environment_controller.np_random.bit_generator.state
+        rs = (ctypes.c_uint64 * 7)()
+        lib.cc4o_rng_state(self.H, 0, rs)
+        if (rs[0] << 64 | rs[1]) != st['state']['state'] or rs[4] != st['has_uint32'] or (rs[4] and rs[5] != st['uinteger']):
+            raise SystemExit(f'{tag}: the oracle\'s generator is not where the reference\'s is')
+        mine, ref = self._dump_pair()
+        if mine != ref:
+            for a, b in zip(mine.split('\n'), ref.split('\n')):
+                if a != b:
+                    print(tag, 'STATE DIFF\n  mine:', a, '\n  ref :', b)
+            raise SystemExit(f'{tag}: the oracle does not reproduce the reference')
+        return ref
+
+    # ---- state edits: (op, a0, a1, a2) for cc4_edit_state + the same poke on the reference
+    def edit(self, op, a0, a1, a2, ref_fn):
+        ref_fn()
+        rc = lib.cc4o_edit_state(self.H, 0, op, a0, a1, a2)
+        assert rc >= 0, (op, a0, a1, a2)
+        ref = self._check(f'edit {op}')
+        self.rec['script'].append({'edit': [op, a0, a1, a2], 'rc': rc, 'dump': sha(ref), 'rng': self._rng()})
+        return rc
+
+    def set_phase(self, mp):
+        self.edit(0, mp, 0, 0, lambda: setattr(self.st, 'mission_phase', mp))
+
+    def add_ot_service(self, hostname, root=False):
+        host = self.st.hosts[hostname]
+
+        def fn():                                          # test_Red/test_Impact.py:89-101
+            pid = host.create_pid()
+            host.processes.append(Process(pid=pid, process_name=ProcessName.OTSERVICE, process_type=ProcessType.UNKNOWN, username='root' if root else 'user'))
+            host.add_service(service_name=ProcessName.OTSERVICE, service=Service(process=pid))
+        self.edit(1, host_index(hostname), 1, int(root), fn)
+
+    def degrade_fully(self, hostname):
+        def fn():                                          # test_BlueRewardMachine.py:75-77
+            for service in self.st.hosts[hostname].services.values():
+                service._percent_reliable = 0
+        self.edit(2, host_index(hostname), 0, 0, fn)
+
+    def clear_host(self, hostname):
+        def fn():                                          # test_blue_actions.py:223-224
+            self.st.hosts[hostname].processes = []
+            self.st.hosts[hostname].services = {}
+        self.edit(3, host_index(hostname), 0, 0, fn)
+
+    def deploy_decoy(self, hostname, cls, kind, agent):
+        out = {}
+
+        def fn():                                          # test_Red/test_DiscoverDeception.py:43
+            out['ok'] = bool(cls(agent=agent, session=0, hostname=hostname).execute(self.st).data['success'])
+        rc = self.edit(4, host_index(hostname), kind, 0, fn)
+        assert rc == int(out['ok'])
+        return out['ok']
+
+    def add_red_session(self, agent, hostname, user, parent, ident):
+        def fn():                                          # test_Red/test_Withdraw.py:10-17
+            self.st.add_session(Session(hostname=hostname, username=user, agent=agent, parent=parent, session_type='shell', ident=ident, pid=None))
+        rc = self.edit(5, int(agent[-1]), host_index(hostname), (1 if user in ('root', 'SYSTEM') else 0) | (2 if parent is not None else 0), fn)
+        assert rc == ident, (rc, ident)
+
+    # ---- the step
+    def _rng(self):
+        st = self.ec.np_random.bit_generator.state
+        return [str(st['state']['state']), int(st['has_uint32']), int(st['uinteger']) if st['has_uint32'] else 0]
+
+    def blue_code(self, agent, action):
+        name = type(action).__name__
+        labels = self.w.action_labels(agent)
+        if name in ('Sleep', 'Monitor'):
+            code = labels.index(name)
+        elif name in ('BlockTrafficZone', 'AllowTrafficZone'):
+            code = 0x10000 | (BA[name] << 8) | subnet_index(action.to_subnet) | (subnet_index(action.from_subnet) << 4)
+        else:
+            lab = f'{name} {action.hostname}'
+            code = labels.index(lab) if lab in labels else (0x10000 | (BA[name] << 8) | host_index(action.hostname))
+        if action.duration != BLUE_DUR[name]:
+            code |= int(action.duration) << 20
+        return code
+
+    def step(self, actions=None, skip_valid=False):
+        """actions: {agent: reference Action object}.  Returns the reference's per-agent dict observations of the submitting agents."""
+        actions = dict(actions or {})
+        blue = [-1] * 5
+        ext = empty_ext()
+        recs = {'red': [], 'green': []}
+        for agent, act in actions.items():
+            if agent.startswith('blue'):
+                blue[int(agent[-1])] = self.blue_code(agent, act)
+            else:
+                kind = 'red' if agent.startswith('red') else 'green'
+                k = int(agent.split('_')[-1])
+                rec = ext[k if kind == 'red' else NRED + k]
+                encode(act, rec, self.st, kind)
+                if skip_valid:
+                    rec.flags |= 4
+                recs[kind].append([k, rec.type, rec.host, rec.arg, rec.ticks, rec.sid, rec.flags, rec.rate0, rec.rate1])
+        obs, rew, term, trunc, info = self.w.step(actions, skip_valid_action_check=skip_valid)
+        a = np.array(blue, np.int32)
+        lib.cc4o_step_ex(self.H, 0, a.ctypes.data_as(ctypes.c_void_p), None, ext)
+        ref = self._check(f'step {len(self.rec["script"])}')
+        o = np.zeros(578, np.int32)
+        lib.cc4o_obs(self.H, 0, o.ctypes.data_as(ctypes.c_void_p))
+        ro = np.concatenate([obs[f'blue_agent_{b}'] for b in range(5)]).astype(np.int32)
+        assert np.array_equal(o, ro), 'flat observation mismatch'
+        assert abs(lib.cc4o_reward(self.H, 0) - rew['blue_agent_0']) < 1e-6, ('reward', lib.cc4o_reward(self.H, 0), rew['blue_agent_0'])
+        assert lib.cc4o_err(self.H, 0) == 0
+        need = lib.cc4o_true_state(self.H, 0, None, 0)
+        jb = ctypes.create_string_buffer(need)
+        lib.cc4o_true_state(self.H, 0, jb, need)
+        ts = json.loads(jb.value.decode())
+        success = {}
+        out_obs = {}
+        for agent in actions:
+            ro_ = self.env.get_observation(agent)
+            out_obs[agent] = ro_
+            success[agent] = TERN[ro_['success'].name]
+            if agent.startswith('red'):
+                assert (ts['red'][int(agent[-1])]['obs_success'] or 2) == success[agent], (agent, ts['red'][int(agent[-1])]['obs_success'], success[agent])
+            elif agent.startswith('green'):
+                g = int(agent.split('_')[-1])
+                fail = (ts['green_fail'][g >> 5] >> (g & 31)) & 1
+                assert fail == int(success[agent] == 3 and not isinstance(actions[agent], Sleep)), (agent, fail, success[agent])
+        from cage_challenge_4_amd.true_state import decode, red_observations, red_obs_skeleton
+        mine_obs = red_observations(decode(ts))
+        red_obs = {}
+        for agent in actions:
+            if agent.startswith('red'):
+                red_obs[agent] = red_obs_skeleton(out_obs[agent])
+                got = red_obs_skeleton(mine_obs[agent])
+                if got != red_obs[agent]:
+                    print('RED OBS SKELETON', agent, actions[agent], '\n  mine:', json.dumps(got, sort_keys=True), '\n  ref :', json.dumps(red_obs[agent], sort_keys=True))
+                    raise SystemExit('red observation skeleton mismatch')
+        files = {}
+        for hn, host in self.st.hosts.items():
+            if host.files:
+                files[str(host_index(hn))] = [f.name for f in host.files]
+        for hd in ts['hosts']:
+            names = [n for n, bit in (('cmd.sh', 1), ('escalate.sh', 2)) if hd['files'] & bit]
+            if len(names) == 2 and not hd['files'] & 4:
+                names.reverse()
+            want = files.get(str(hd['h']), [])
+            want_u = []
+            for n in want:                       # Observation.add_file_info re-appends a repeated name: only the last position survives
+                if n in want_u:
+                    want_u.remove(n)
+                want_u.append(n)
+            assert names == want_u, ('files', hd['h'], names, want)
+        self.rec['script'].append({
+            'step': {'blue': blue, 'red': recs['red'], 'green': recs['green']},
+            'expect': {'obs': ''.join(str(int(v)) for v in ro), 'reward': float(rew['blue_agent_0']), 'done': int(bool(term['blue_agent_0'])),
+                       'rng': self._rng(), 'dump': sha(ref), 'success': success,
+                       'active_red': [r for r in range(6) if self.ec.agent_interfaces[f'red_agent_{r}'].active],
+                       'files': {k: v for k, v in files.items()}, 'red_obs': red_obs,
+                       'brm': rew_component(self.env)}})
+        return out_obs
+
+
+def rew_component(env):
+    r = env.environment_controller.reward.get('Blue', {})
+    return float(r.get('BlueRewardMachine', 0))
+
+
+FIXTURES = {}
+
+
+def fixture(name, source):
+    def deco(fn):
+        FIXTURES[name] = (source, fn)
+        return fn
+    return deco
+
+
+# ------------------------------------------------------------------------------------------------ shared set-ups
+RED0, RED1, BLUE0 = 'red_agent_0', 'red_agent_1', 'blue_agent_0'
+CNS0 = 'contractor_network_subnet_server_host_0'
+
+
+def root_shell_on_cns0(c):
+    """test_blocking_red.py:25-77: DiscoverRemoteSystems -> AggressiveServiceDiscovery -> ExploitRemoteService -> PrivilegeEscalate,
+    each with duration = 1."""
+    ip = c.ip(CNS0)
+    seq = [DiscoverRemoteSystems(subnet=c.cidr('contractor_network_subnet'), session=0, agent=RED0),
+           AggressiveServiceDiscovery(session=0, agent=RED0, ip_address=ip),
+           ExploitRemoteService(ip_address=ip, session=0, agent=RED0),
+           PrivilegeEscalate(hostname=CNS0, session=0, agent=RED0)]
+    for a in seq:
+        a.duration = 1
+        c.step({RED0: a})
+
+
+def one(action, duration=None, **attrs):
+    if duration is not None:
+        action.duration = duration
+    for k, v in attrs.items():
+        setattr(action, k, v)
+    return action
+
+
+# ------------------------------------------------------------------------------------------------ test_blocking_red.py
+@fixture('blocking_red_aggressive', 'CybORG/Tests/test_cc4/test_blocking_red.py:79-103 (3 target subnets)')
+def _():
+    for target in ('public_access_zone_subnet', 'restricted_zone_a_subnet', 'restricted_zone_b_subnet'):
+        c = Case(100, note=target)
+        root_shell_on_cns0(c)
+        o = c.step({BLUE0: BlockTrafficZone(session=0, agent=BLUE0, from_subnet='contractor_network_subnet', to_subnet=target)})
+        assert o[BLUE0]['success'] == True        # noqa: E712  (TernaryEnum ==)
+        o = c.step({RED0: AggressiveServiceDiscovery(session=0, agent=RED0, ip_address=c.ip(target + '_server_host_0'))})
+        assert 'InvalidAction' not in str(o[RED0]['action']) and o[RED0]['success'] == False   # noqa: E712
+        yield c
+
+
+@fixture('blocking_red_exploit', 'CybORG/Tests/test_cc4/test_blocking_red.py:106-134 (3 target subnets)')
+def _():
+    for target in ('public_access_zone_subnet', 'restricted_zone_a_subnet', 'restricted_zone_b_subnet'):
+        c = Case(100, note=target)
+        root_shell_on_cns0(c)
+        tip = c.ip(target + '_server_host_0')
+        o = c.step({RED0: AggressiveServiceDiscovery(session=0, agent=RED0, ip_address=tip)})
+        assert o[RED0]['success'] == True         # noqa: E712
+        o = c.step({BLUE0: BlockTrafficZone(session=0, agent=BLUE0, from_subnet='contractor_network_subnet', to_subnet=target)})
+        assert o[BLUE0]['success'] == True        # noqa: E712
+        o = c.step({RED0: one(ExploitRemoteService(ip_address=tip, session=0, agent=RED0), 1)})
+        assert 'InvalidAction' not in str(o[RED0]['action']) and o[RED0]['success'] == False   # noqa: E712
+        yield c
+
+
+# ------------------------------------------------------------------------------------------------ test_blue_actions.py
+TS = 'restricted_zone_a_subnet'
+TH = TS + '_server_host_0'
+
+
+@fixture('blue_monitor', 'CybORG/Tests/test_cc4/test_blue_actions.py:19-33')
+def _():
+    c = Case(100)
+    root_shell_on_cns0(c)
+    o = c.step({RED0: one(AggressiveServiceDiscovery(session=0, agent=RED0, ip_address=c.ip(TH)), detection_rate=1)})
+    assert TH in c.env.get_observation(BLUE0).keys()
+    yield c
+
+
+def shell_on_rzas0(c, kind='root'):
+    """test_blue_actions.py:108-141"""
+    tip = c.ip(TH)
+    o = c.step({RED0: AggressiveServiceDiscovery(session=0, agent=RED0, ip_address=tip)})
+    assert o[RED0]['success'] == True             # noqa: E712
+    o = c.step({RED0: one(ExploitRemoteService(ip_address=tip, session=0, agent=RED0), 1)})
+    assert o[RED0]['success'] == True             # noqa: E712
+    if kind == 'root':
+        o = c.step({RED1: one(PrivilegeEscalate(hostname=TH, session=0, agent=RED1), 1)})
+        assert o[RED1]['success'] == True         # noqa: E712
+
+
+@fixture('blue_analyse', 'CybORG/Tests/test_cc4/test_blue_actions.py:46-106')
+def _():
+    c = Case(100)
+    root_shell_on_cns0(c)
+    tip = c.ip(TH)
+
+    def analyse(nfiles):
+        o = c.step({BLUE0: one(Analyse(session=0, agent=BLUE0, hostname=TH), 1)})[BLUE0]
+        assert 'Analyse' in str(o['action']) and o['success'] == True      # noqa: E712
+        assert len(o.get(TH, {}).get('Files', [])) == nfiles
+    o = c.step({RED0: AggressiveServiceDiscovery(session=0, agent=RED0, ip_address=tip)})
+    assert o[RED0]['success'] == True             # noqa: E712
+    analyse(0)
+    o = c.step({RED0: one(ExploitRemoteService(ip_address=tip, session=0, agent=RED0), 1)})
+    assert o[RED0]['success'] == True             # noqa: E712
+    analyse(1)
+    o = c.step({RED1: one(PrivilegeEscalate(hostname=TH, session=0, agent=RED1), 1)})
+    assert o[RED1]['success'] == True             # noqa: E712
+    analyse(2)
+    yield c
+
+
+@fixture('blue_restore', 'CybORG/Tests/test_cc4/test_blue_actions.py:143-154')
+def _():
+    c = Case(100)
+    root_shell_on_cns0(c)
+    shell_on_rzas0(c)
+    o = c.step({BLUE0: one(Restore(session=0, agent=BLUE0, hostname=TH), 1)})
+    assert o[BLUE0]['success'] == True and RED1 not in c.env.active_agents       # noqa: E712
+    yield c
+
+
+@fixture('blue_remove', 'CybORG/Tests/test_cc4/test_blue_actions.py:156-171 and :173-188 (user shell removed, root shell survives)')
+def _():
+    for kind in ('user', 'root'):
+        c = Case(100, note=kind + ' shell')
+        root_shell_on_cns0(c)
+        shell_on_rzas0(c, kind)
+        red_here = lambda: [a for a, s in c.st.hosts[TH].sessions.items() if 'red' in a and len(s) > 0]   # noqa: E731
+        assert red_here()
+        o = c.step({BLUE0: one(Remove(session=0, agent=BLUE0, hostname=TH), 1)})
+        assert o[BLUE0]['success'] == True        # noqa: E712
+        assert (red_here() == []) == (kind == 'user')
+        yield c
+
+
+@fixture('blue_deploy_decoy', 'CybORG/Tests/test_cc4/test_blue_actions.py:190-211')
+def _():
+    c = Case(100)
+    root_shell_on_cns0(c)
+    n0 = len(c.st.hosts[TH].services)
+    o = c.step({BLUE0: one(DeployDecoy(session=0, agent=BLUE0, hostname=TH), 1)})
+    assert o[BLUE0]['success'] and TH in o[BLUE0] and len(c.st.hosts[TH].services) == n0 + 1
+    o = c.step({RED0: one(DiscoverDeception(session=0, agent=RED0, ip_address=c.ip(TH)), 1)})
+    yield c
+
+
+@fixture('blue_deploy_decoy_red_usage', 'CybORG/Tests/test_cc4/test_blue_actions.py:214-247')
+def _():
+    c = Case(100)
+    root_shell_on_cns0(c)
+    tip = c.ip(TH)
+    c.clear_host(TH)
+    o = c.step({BLUE0: one(DeployDecoy(session=0, agent=BLUE0, hostname=TH), 1)})
+    assert o[BLUE0]['success'] and len(c.st.hosts[TH].processes) == 1
+    o = c.step({RED0: one(StealthServiceDiscovery(session=0, agent=RED0, ip_address=tip), 1, detection_rate=0)})
+    assert o[RED0]['success']
+    bo = c.env.get_observation(BLUE0)
+    assert bo[TH]['Processes'][0]['Connections'][0]['local_address'] == tip
+    o = c.step({RED0: one(ExploitRemoteService(ip_address=tip, session=0, agent=RED0), 1)})
+    assert o[RED0]['success'] == False            # noqa: E712
+    yield c
+
+
+# ------------------------------------------------------------------------------------------------ test_BlueRewardMachine.py
+@fixture('brm_red_impact', 'CybORG/Tests/test_cc4/test_BlueRewardMachine.py:25-62 (three mission phases)')
+def _():
+    c = Case(3)
+    hn = c.st.sessions[RED0][0].hostname
+    c.add_ot_service(hn, root=True)
+    for mp, want in zip(range(3), (-5, 0, 0)):
+        c.set_phase(mp)
+        c.step({RED0: one(Impact(hostname=hn, agent=RED0, session=0), 1)})
+        assert c.rec['script'][-1]['expect']['brm'] == want, (mp, c.rec['script'][-1]['expect'])
+    yield c
+
+
+@fixture('brm_green_local_work', 'CybORG/Tests/test_cc4/test_BlueRewardMachine.py:64-100 (8 subnets x 3 mission phases)')
+def _():
+    from CybORG.Shared.BlueRewardMachine import BlueRewardMachine
+    for sn in ALL_SUBNETS:
+        for mp in range(3):
+            c = Case(100, note=f'{sn} phase {mp}')
+            c.set_phase(mp)
+            gh = sn + '_user_host_0'
+            c.degrade_fully(gh)
+            ga = c.green_of(gh)
+            # the test enables the class in the SleepAgent's action space by hand (:83); the step's own switch for that is skip_valid_action_check
+            o = c.step({ga: GreenLocalWork(agent=ga, session_id=0, ip_address=c.ip(gh), fp_detection_rate=0.0, phishing_error_rate=0.0)}, skip_valid=True)
+            assert o[ga]['success'] == False      # noqa: E712
+            assert c.rec['script'][-1]['expect']['brm'] == BlueRewardMachine('').get_phase_rewards(mp)[sn]['LWF']
+            yield c
+
+
+@fixture('brm_green_access_service', 'CybORG/Tests/test_cc4/test_BlueRewardMachine.py:102-158 (8 subnets x 3 mission phases)')
+def _():
+    from CybORG.Shared.BlueRewardMachine import BlueRewardMachine
+    for sn in ALL_SUBNETS:
+        for mp in range(3):
+            c = Case(3, note=f'{sn} phase {mp}')
+            c.set_phase(mp)
+            gh = sn + '_user_host_0'
+            ga = c.green_of(gh)
+            allowed = c.ec.agent_interfaces[ga].allowed_subnets
+            mk = lambda: GreenAccessService(agent=ga, session_id=0, src_ip=c.ip(gh), allowed_subnets=allowed, fp_detection_rate=0.0)   # noqa: E731
+            o = c.step({ga: mk()}, skip_valid=True)
+            assert o[ga]['success'] == True       # noqa: E712
+            for other in ALL_SUBNETS:
+                o = c.step({BLUE0: BlockTrafficZone(session=0, agent=BLUE0, to_subnet=sn, from_subnet=other)})
+                assert o[BLUE0]['success'] == True    # noqa: E712
+            c.set_phase(mp)
+            o = c.step({ga: mk()}, skip_valid=True)
+            assert 'GreenAccessService' in str(o[ga]['action']) and o[ga]['success'] == False   # noqa: E712
+            assert c.rec['script'][-1]['expect']['brm'] == BlueRewardMachine('').get_phase_rewards(mp)[sn]['ASF']
+            yield c
+
+
+# ------------------------------------------------------------------------------------------------ test_Red/test_Impact.py, test_DegradeServices.py
+def agent_with_shell(c, priv=True):
+    """test_Red/test_Impact.py:103-150"""
+    ip = c.ip(CNS0)
+    seq = [DiscoverRemoteSystems(subnet=c.cidr('contractor_network_subnet'), session=0, agent=RED0),
+           AggressiveServiceDiscovery(ip_address=ip, session=0, agent=RED0), ExploitRemoteService(ip_address=ip, session=0, agent=RED0)]
+    if priv:
+        seq.append(PrivilegeEscalate(hostname=CNS0, session=0, agent=RED0))
+    for a in seq:
+        o = c.step({RED0: one(a, 1)})
+        assert o[RED0]['success'] != False        # noqa: E712
+
+
+@fixture('red_impact', 'CybORG/Tests/test_cc4/test_Red/test_Impact.py:18-72 (with / without privilege, service removal, no OT service)')
+def _():
+    for ot, priv, want in ((True, True, 1), (True, False, 3), (False, True, 3)):
+        c = Case(123, note=f'OT service {ot}, root shell {priv}')
+        if ot:
+            c.add_ot_service(CNS0)
+        agent_with_shell(c, priv)
+        o = c.step({RED0: one(Impact(hostname=CNS0, session=0, agent=RED0), 1)})
+        assert TERN[o[RED0]['success'].name] == want
+        if ot and priv:
+            assert c.st.hosts[CNS0].services[ProcessName.OTSERVICE].active is False
+        yield c
+
+
+@fixture('red_degrade_services', 'CybORG/Tests/test_cc4/test_Red/test_DegradeServices.py:19-57')
+def _():
+    for priv in (True, False):
+        c = Case(123, note=f'root shell {priv}')
+        agent_with_shell(c, priv)
+        before = [s._percent_reliable for s in c.st.hosts[CNS0].services.values()]
+        o = c.step({RED0: one(DegradeServices(hostname=CNS0, session=0, agent=RED0), 1)})
+        assert TERN[o[RED0]['success'].name] == (1 if priv else 3)
+        after = [s._percent_reliable for s in c.st.hosts[CNS0].services.values()]
+        assert after == ([b - 20 for b in before] if priv else before)
+        yield c
+
+
+# ------------------------------------------------------------------------------------------------ test_Red/test_DiscoverDeception.py
+@fixture('red_discover_deception', 'CybORG/Tests/test_cc4/test_Red/test_DiscoverDeception.py:22-208 (four decoy factories x fp_rate 0 / 1)')
+def _():
+    for cls, kind, svc, where in ((DecoyApache, 5, ProcessName.APACHE2, RED0), (DecoyHarakaSMPT, 7, ProcessName.SMTP, BLUE0),
+                                  (DecoyTomcat, 6, None, BLUE0), (DecoyVsftpd, 8, None, BLUE0)):
+        for fp in (0, 1):
+            c = Case(0, note=f'{cls.__name__} fp_rate {fp}')
+            hn = c.st.sessions[where][0].hostname
+            while svc is not None and svc in c.st.hosts[hn].services.keys():       # :38-40: reset until the host lacks the real service
+                c.reset_again()
+                hn = c.st.sessions[where][0].hostname
+            assert c.deploy_decoy(hn, cls, kind, where)
+            # (the test calls action.execute(state) itself: no validity check -- red_agent_0 has not discovered blue_agent_0's host)
+            o = c.step({RED0: one(DiscoverDeception(agent=RED0, session=0, ip_address=c.ip(hn)), 1, detection_rate=1.0, fp_rate=fp)}, skip_valid=True)
+            assert o[RED0]['success'] == True     # noqa: E712
+            procs = o[RED0].get(hn, {}).get('Processes', [])
+            dec = [p for p in procs if 'decoy' in p.get('Properties', []) and p.get('service_name') in ('apache2', 'haraka', 'Tomcat.exe', 'vsftpd')]
+            assert dec, procs
+            assert (len(procs) > len(dec)) == (fp == 1 and len(c.st.hosts[hn].processes) > 1)
+            yield c
+
+
+# ------------------------------------------------------------------------------------------------ test_Red/test_Withdraw.py
+@fixture('red_withdraw_only_host', 'CybORG/Tests/test_cc4/test_Red/test_Withdraw.py:112-147')
+def _():
+    c = Case(124)
+    hn = c.st.sessions[RED0][0].hostname
+    for i in range(14):
+        if i == 10:
+            c.step({RED0: Withdraw(session=0, agent=RED0, ip_address=c.ip(hn), hostname=hn)}, skip_valid=True)
+            assert c.st.sessions_count[RED0] == 0 and not c.ec.agent_interfaces[RED0].active
+        else:
+            c.step({})
+    assert not any(c.ec.agent_interfaces[f'red_agent_{r}'].active for r in range(6))
+    yield c
+
+
+@fixture('red_withdraw_num_sessions', 'CybORG/Tests/test_cc4/test_Red/test_Withdraw.py:29-109 (1 / 3 / 5 sessions x user / root x red_agent_0 / 1)')
+def _():
+    for agent in (RED0, RED1):
+        for user in ('user', 'root'):             # ('SYSTEM' is 'root' to every check the simulator makes)
+            for num in (1, 3, 5):
+                c = Case(124, note=f'{agent} {user} x{num}')
+                allowed = c.ec.agent_interfaces[agent].allowed_subnets[0]
+                if c.st.sessions_count[agent] > 0:
+                    local = c.st.sessions[agent][0].hostname
+                    target = [h for h in c.st.hosts if allowed in h and h != local][0]
+                else:
+                    target = [h for h in c.st.hosts if allowed in h][0]
+                    local = target
+                base = 1 if agent == RED0 else 0
+                for i in range(18):
+                    if i == 5:
+                        for k in range(base, num + base):
+                            c.add_red_session(agent, target, user, None if k == 0 else 0, k)
+                    if i == 15:
+                        c.step({agent: Withdraw(session=0, agent=agent, ip_address=c.ip(local), hostname=target)}, skip_valid=True)
+                        assert str(c.env.get_last_action(agent)[0]) == f'Withdraw {target}'
+                        assert c.ec.agent_interfaces[agent].active == (agent == RED0)
+                        assert (c.st.sessions_count[agent] > 0) == (agent == RED0)
+                    else:
+                        c.step({})
+                    if i == 5:
+                        assert c.ec.agent_interfaces[agent].active and c.st.sessions_count[agent] == num + base
+                yield c
+
+
+# ------------------------------------------------------------------------------------------------ test_Red/test_RedSessionCheck.py
+@fixture('red_agent_activation', 'CybORG/Tests/test_cc4/test_Red/test_RedSessionCheck.py:79-101 (sessions appear on a dormant agent: it wakes up)')
+def _():
+    c = Case(124)
+    hn = list(c.ec.hostname_ip_map.keys())[0]
+    for i in range(12):
+        if i == 5:
+            for k in range(3):
+                c.add_red_session(RED1, hn, 'user', None if k == 0 else 0, k)
+        c.step({RED1: Sleep()})
+        if i >= 5:
+            assert c.ec.agent_interfaces[RED1].active and c.st.sessions_count[RED1] == 3
+    yield c
+
+
+# ------------------------------------------------------------------------------------------------ mixed: a scripted red agent among live ones
+@fixture('mixed_scripted_red_among_fsm', 'a scripted red_agent_0 (the walk of test_blocking_red.py:25-77, then Degrade / Impact / Withdraw) among '
+         'FiniteStateRedAgents and EnterpriseGreenAgents: the submitted actions bypass red_agent_0\'s own policy, everybody else runs theirs')
+def _():
+    c = Case(2024, steps=100, red='fsm', green='enterprise')
+    root_shell_on_cns0(c)
+    for a in (DegradeServices(hostname=CNS0, session=0, agent=RED0), Impact(hostname=CNS0, session=0, agent=RED0),
+              DiscoverRemoteSystems(subnet=c.cidr('restricted_zone_a_subnet'), session=0, agent=RED0)):
+        c.step({RED0: a})
+        c.step({})
+        c.step({})
+    for t in range(30):
+        c.step({RED0: Sleep()} if t % 3 else {})
+    yield c
+
+
+def main():
+    flt = sys.argv[1] if len(sys.argv) > 1 else ''
+    total = 0
+    for name, (source, fn) in FIXTURES.items():
+        if flt not in name:
+            continue
+        cases = [c.rec for c in fn()]
+        doc = {'name': name, 'source': source, 'numpy': np.__version__,
+               'format': 'script entries: {"edit": [op, a0, a1, a2], "rc", "dump", "rng"} = cc4_edit_state | {"step": {"blue": [5 cc4_step_ex codes], '
+                         '"red" / "green": [[agent index, type, host, arg, ticks, session, flags, rate0, rate1]...]}, "expect": {...}}; '
+                         'reset: cc4_reset(seed), cc4_reset(NULL) x (1 + resets); rng = [PCG64 state, has_uint32, uinteger]; dump = sha256[:32] of the canonical state dump (oracle/refgen/ref_dump.py, cc4o_dump)',
+               'cases': cases}
+        path = os.path.join(OUT, f'scripted_{name}.json')
+        with open(path, 'w') as f:
+            json.dump(doc, f, separators=(',', ':'))
+        nst = sum(1 for c in cases for e in c['script'] if 'step' in e)
+        total += len(cases)
+        print(f'{name}: {len(cases)} case(s), {nst} steps -> {os.path.relpath(path)} ({os.path.getsize(path) // 1024} KB)')
+    print('cases:', total)
+
+
+if __name__ == '__main__':
+    main()

@@ -47,7 +47,8 @@ def dump(env):
     ip2h = {str(ip): host_index(h) for ip, h in st.ip_addresses.items()}
     for hostname, host in st.hosts.items():
         h = host_index(hostname)
-        procs = ' '.join(f"({p.pid},{KIND[p.name]},{1 if p.user in ('root', 'SYSTEM') else 0})" for p in host.processes)
+        # (a hand-made service process without open_ports -- the reference's tests add such -- is the engine's K_PLAIN = 13)
+        procs = ' '.join(f"({p.pid},{13 if (KIND[p.name] < 9 and not p.open_ports) else KIND[p.name]},{1 if p.user in ('root', 'SYSTEM') else 0})" for p in host.processes)
         svcs = ' '.join(f"({KIND[k]},{1 if v.active else 0},{v._percent_reliable},{v.process})" for k, v in host.services.items())
         e = host.events
         ev = f"{int(len(e.network_connections) > 0)}{int(len(e.process_creation) > 0)}{int(len(e.old_network_connections) > 0)}{int(len(e.old_process_creation) > 0)}"

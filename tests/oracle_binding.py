@@ -53,6 +53,10 @@ def load():
     return lib
 
 
+AGENT_ACTION_DTYPE = [('type', 'i1'), ('host', 'u1'), ('arg', 'u1'), ('ticks', 'u1'), ('session', 'u2'), ('flags', 'u1'), ('pad', 'u1'),
+                      ('rate0', 'f8'), ('rate1', 'f8')]          # ExtAct (csrc/cc4_state.h) == cc4_agent_action (include/cc4.h)
+
+
 class OracleVecEnv:
     """Same call shape as cage_challenge_4_amd.CC4VecEnv, stepping episodes serially on the host."""
     def __init__(self, num_envs, steps=500, rng_mode=0, autoreset=False, device_id=0, red_policy=0, green_policy=0, topology_seed=0,
@@ -113,6 +117,35 @@ class OracleVecEnv:
                 self.lib.cc4o_step(self._h, i, ap, mp)
             self._collect(i)
         return self._obs, self._rew, self._done, {'err': self._err}
+
+    def agent_actions(self, kind):
+        a = np.zeros((self.num_envs, 6 if kind == 'red' else 80), dtype=AGENT_ACTION_DTYPE)
+        a['type'] = -1
+        return a
+
+    def step_ex(self, actions=None, messages=None, red=None, green=None):
+        """Same call shape as CC4VecEnv.step_ex (cc4_step_ex): the step with submitted red / green actions (cc4o_step_ex)."""
+        self.lib.cc4o_step_ex.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
+        for i in range(self.num_envs):
+            a = None if actions is None else np.ascontiguousarray(actions[i], np.int32)
+            m = None if messages is None else np.ascontiguousarray(messages[i], np.uint8)
+            ext = np.zeros(86, dtype=AGENT_ACTION_DTYPE)
+            ext['type'] = -1
+            if red is not None:
+                ext[:6] = red[i]
+            if green is not None:
+                ext[6:] = green[i]
+            self.lib.cc4o_step_ex(self._h, i, None if a is None else a.ctypes.data_as(ctypes.c_void_p),
+                                  None if m is None else m.ctypes.data_as(ctypes.c_void_p), ext.ctypes.data_as(ctypes.c_void_p))
+            self._collect(i)
+        return self._obs, self._rew, self._done, {'err': self._err}
+
+    def edit_state(self, env, op, a0=0, a1=0, a2=0):
+        self.lib.cc4o_edit_state.argtypes = [ctypes.c_void_p] + [ctypes.c_int] * 5
+        rc = int(self.lib.cc4o_edit_state(self._h, int(env), int(op), int(a0), int(a1), int(a2)))
+        if rc < 0:
+            raise RuntimeError(f'cc4o_edit_state({op}, {a0}, {a1}, {a2}) failed')
+        return rc
 
     def step_batch(self, actions=None, messages=None):
         """step() for the whole batch in one native call (cc4o_step_batch: OpenMP over episodes, incl. the autoreset): same

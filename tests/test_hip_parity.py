@@ -210,6 +210,40 @@ def test_bench_configuration_matches_oracle_every_step(n, red_policy, blue_polic
     dev.close()
 
 
+def test_timed_bench_path_matches_oracle():
+    """the exact region bench.py times -- cc4_run_random_steps on k_step_philox1, 8192 episodes, the handle's own
+    launch grouping, no override, no communicator: the blue actions are drawn IN the step kernel on the bank lanes (BK_BRAND) --
+    against the oracle driven with the host restatement of the same draws (random_actions), in bursts of K = 1, 20 and 137 steps
+    (the driver's --steps 20 among them) across a scenario regeneration: observations, rewards, dones, error flags and the
+    contents of the device action buffer (the actions of the burst's last step) after every burst, then generator words and the
+    packed state of all episodes."""
+    import ctypes, os
+    assert 'CC4_PHILOX_LEAN' not in os.environ and 'CC4_PHILOX_MINW' not in os.environ and 'CC4_GROUPS' not in os.environ
+    n, steps, seed0 = 8192, 150, 4242
+    dev = _dev(n, steps=steps, rng_mode=1, autoreset=True)
+    assert dev.step_kernel == 'k_step_philox1' and dev.launches_per_step in (3, 4)
+    ora = OracleVecEnv(n, steps=steps, rng_mode=1, autoreset=True)
+    assert np.array_equal(dev.reset(seeds=seed0), ora.reset_batch(seed0))
+    t = 0
+    for K in (1, 20, 137, 20, 1, 20):
+        dev.run_random_steps(seed0, t, K, timed=(K != 1))
+        for k in range(K):
+            a = random_actions(seed0, t + k, n)
+            o = ora.step_batch(a)
+        t += K
+        dev.synchronize()
+        dev._fetch()
+        bad = np.nonzero((dev._obs != o[0]).any(axis=1) | (dev._rew != o[1]) | (dev._done.astype(bool) != o[2]) | (dev._err != o[3]['err']))[0]
+        assert bad.size == 0, (K, t, bad[:10].tolist())
+        assert np.array_equal(dev.device_actions(), a), (K, t)
+    assert t > steps                                     # every episode was regenerated once inside a timed burst
+    assert np.array_equal(dev.rng_state(), ora.rng_state())
+    for i in range(n):
+        a_, b_ = dev.get_state(i), ora.get_state(i)
+        assert np.array_equal(a_, b_), f'packed state differs env {i} at byte offsets {np.nonzero(a_ != b_)[0][:20].tolist()}'
+    dev.close()
+
+
 def test_device_random_action_kernel_matches_host_restatement():
     import ctypes
     n = 1024
