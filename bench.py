@@ -193,7 +193,7 @@ def host_api_rates(seed=123, steps=300, eval_eps=3):
 def load_pmc_traffic(envs, kernel, launches_per_step):
     """HBM bytes per STEP (all launches of a step) from the committed rocprofv3 --pmc passes of this bench command, with their
     source -- only if they were taken on the same kernel with the same number of launches per step; else (None, None)."""
-    for name in ('r03_pmc.json',):
+    for name in ('r04_pmc.json', 'r03_pmc.json'):
         p = os.path.join(ROOT, 'profiles', name)
         try:
             with open(p) as f:
@@ -313,7 +313,10 @@ def main():
     hs = env.host_stats()
     per_rank = plane.gather_obj({'rank': rank, 'envs': n_local, 'kernel': env.step_kernel, 'launches_per_step': env.launches_per_step,
                                  'host_launch_us_per_step': hs['launch_us'] / max(hs['steps'], 1), 'host_allgather_enqueue_us_per_step': hs['gather_us'] / max(hs['steps'], 1),
-                                 'allgathers_issued': hs['gathers'], 'steps_that_waited_for_an_allgather': hs['gather_stalls']})
+                                 'allgathers_issued': hs['gathers'], 'steps_that_waited_for_an_allgather': hs['gather_stalls'],
+                                 # RCCL's own view: a scaling line is only what it says if every rank reports nccl_comm_count == n_gpus and
+                                 # the ranks sit on different devices (uuid / pci)
+                                 **env.comm_info()})
     env._fetch()
     err_any = bool(env.err.any())
     # a sharding-independent digest of where the batch stands after the run (episodes are seeded and driven by their GLOBAL
@@ -390,7 +393,14 @@ def main():
                 'autoreset_launches_in_timed_regions': main_res['autoreset_launches_in_timed_regions'],
             },
             'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBPS, 'unit': 'GB/s',
-                         'frac': achieved / HBM_PEAK_GBPS, 'traffic': traffic, 'traffic_source': traffic_src,
+                         'frac': achieved / HBM_PEAK_GBPS,
+                         # the same algorithmic bytes against the WALL clock of the timed regions (ms_per_step: what `value` is made of) --
+                         # below `frac` by what lies between and around the launches of a region
+                         'frac_wall': bytes_per_env * n_local / (main_res['ms_per_step'] * 1e-3) / 1e9 / HBM_PEAK_GBPS,
+                         # the bytes the HBM counters saw per step (traffic) against the same launch duration: what fraction of the
+                         # 8 TB/s the memory system actually carried
+                         'hbm_counter_frac': (traffic / (launch_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS) if traffic else None,
+                         'traffic': traffic, 'traffic_source': traffic_src,
                          'kernel': env.step_kernel, 'launch_ms': launch_ms, 'launches_per_step': lps,
                          'episodes_per_launch': n_local / lps,
                          'algorithmic_bytes_per_launch': bytes_per_env * n_local / lps,

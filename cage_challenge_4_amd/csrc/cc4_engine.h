@@ -696,6 +696,11 @@ CC4_HD void reset_zero(EnvState* s, HostDyn* hd, EnvCold* c, int t, int nt) {
   uint32_t* b = (uint32_t*)c->hs;
   for (size_t i = (size_t)t; i < sizeof(c->hs) / 4; i += (size_t)nt) b[i] = 0;
 }
+// the 9000-bit set of the generation's pids: lent from the episode's session pool (zero after reset_zero; no session exists before
+// reset_finish), cleared again by all threads (reset_used_clear) once the pids are settled
+static_assert(sizeof(RSess) * RS_POOL >= 4 * 282, "the idle session pool holds the 9000-bit pid set of the generation");
+CC4_HD uint32_t* reset_used_set(EnvState* s) { return reinterpret_cast<uint32_t*>(s->spool); }
+CC4_HD void reset_used_clear(EnvState* s, int t, int nt) { uint32_t* u = reset_used_set(s); for (int i = t; i < 282; i += nt) u[i] = 0; }
 // phase 1, one thread: generator, mission phases, subnets, host counts and addresses (main reset stream)
 CC4_HD ResetCarry reset_topology(Ctx x, uint64_t seed, int steps, bool continue_stream, int policy, uint32_t topo_seed, uint32_t* ws,
                                  bool rng_is_copy) {
@@ -764,43 +769,53 @@ CC4_HD void reset_gen_host(Ctx x, int h) {
   }
   for (int i = 0; i < n; ++i) (void)rng_random(x.r);
   hd_set_nsvc(st, n); st.nproc = (uint16_t)n;
+  // the three add-on candidates in draw order, installed or not, for the uniqueness pass (reset_pid_serial clears them again): a
+  // freshly generated host has at most five services and five processes, slots 5 and 6 are free
+  st.procs[5].pid = (uint16_t)p_apache; st.procs[6].pid = (uint16_t)p_mysql; st.svcs[6].pid = (uint16_t)p_smtp;
 }
-// phase 3a, per host: enter the pids into the network-wide set; a value entered twice is contested
-CC4_HD void reset_pid_mark(Ctx x, int h, uint32_t* ws) {
-  const HostDyn& st = x.hd[h];
-  for (int i = 0; i < hd_nsvc(st); ++i) {
-    int v = st.svcs[i].pid - 1000;
-    if (or_shared(&ws[RESET_WS_SEEN + (v >> 5)], 1u << (v & 31)) & (1u << (v & 31))) (void)or_shared(&ws[RESET_WS_DUP + (v >> 5)], 1u << (v & 31));
-  }
-}
-// phase 3b, per host: which of the host's services hold a contested pid (ev bits 1..5), which hosts have any
-CC4_HD void reset_pid_flag(Ctx x, int h, uint32_t* ws) {
-  HostDyn& st = x.hd[h];
-  uint32_t m = 0;
-  for (int i = 0; i < hd_nsvc(st); ++i) { int v = st.svcs[i].pid - 1000; if (bit_get(ws + RESET_WS_DUP, v)) m |= 1u << i; }
-  if (m) { st.gtmp = (uint8_t)(st.gtmp | (m << 1)); (void)or_shared(&ws[RESET_WS_HOSTS + (h >> 5)], 1u << (h & 31)); }
-}
-// phase 3c, one thread: contested pids in host / service order -- the first holder keeps the value, later ones draw again
-CC4_HD void reset_pid_resolve(Ctx x, uint32_t* ws) {
-  for (int w = 0; w < 5; ++w) {
-    uint32_t hm = ws[RESET_WS_HOSTS + w];
-    while (hm) {
-      const int h = w * 32 + ctz32(hm); hm &= hm - 1;
-      HostDyn& st = x.hd[h];
-      uint32_t cm = (uint32_t)st.gtmp >> 1;
-      st.gtmp &= 1;
-      Rng t; bool forked = false;
-      while (cm) {
-        const int i = ctz32(cm); cm &= cm - 1;
-        const int v = st.svcs[i].pid - 1000;
-        if (bit_get(ws + RESET_WS_DUP, v)) { bit_clr(ws + RESET_WS_DUP, v); continue; }
+// phase 3, one thread: the network-wide pid uniqueness of _generate_pid (ESG.py:564-578), in the REFERENCE'S ORDER.  The reference
+// draws the pids host after host -- SSHD, [OT service], then the three add-on candidates apache / mysql / smtp, installed or not
+// (ESG.py:540-556) -- each against the set of pids drawn so far: a value that is already in the set is drawn again, at once, by the
+// same caller.  Here the hosts drew their candidates side by side (reset_gen_host, each from its own stream); this pass walks
+// them in the same host / draw order with the same running set: the first holder of a value keeps it, a later one draws again --
+// from the re-draw stream of ITS host (ST_GEN_REDRAW + h), so that nothing else the host drew moves -- until it finds a value no
+// EARLIER position holds.  (r03 resolved against the installed pids of all hosts at once: the same marginals, but another
+// trajectory than the reference's whenever a re-draw lands on a later host's value, or an uninstalled candidate collides.)
+// `used`: a 9000-bit set, >= 282 words, zeroed by the caller (the idle session pool of the row lends it: no session exists yet).
+CC4_HD void reset_pid_serial(Ctx x, uint32_t* used) {
+  EnvState* s = x.s;
+  for (int h = 0; h < MAXH; ++h) {
+    if (!bit_get(s->exists, h) || h_is_router(h)) continue;
+    HostDyn& st = x.hd[h];
+    const int n = hd_nsvc(st);
+    const int sub = h_subnet(h);
+    const int nfix = (sub == S_OZA || sub == S_OZB) ? 2 : 1;          // SSHD, [OT]: services 0 .. nfix-1
+    Rng t; bool forked = false;
+    auto settle = [&](int v0, bool* moved) {
+      int v = v0 - 1000;
+      *moved = false;
+      while (bit_get(used, v)) {
         if (!forked) { rng_fork(&t, x.r, ST_GEN_REDRAW + (uint32_t)h); forked = true; }
-        int nv;
-        do nv = (int)rng_below(&t, 9000); while (bit_get(ws + RESET_WS_SEEN, nv));
-        bit_set(ws + RESET_WS_SEEN, nv);
-        st.svcs[i].pid = (uint16_t)(nv + 1000); st.procs[i].pid = (uint16_t)(nv + 1000);
+        v = (int)rng_below(&t, 9000);
+        *moved = true;
       }
+      bit_set(used, v);
+      return v + 1000;
+    };
+    for (int i = 0; i < nfix; ++i) {
+      bool moved;
+      const int v = settle(st.svcs[i].pid, &moved);
+      if (moved) { st.svcs[i].pid = (uint16_t)v; st.procs[i].pid = (uint16_t)v; }
     }
+    // the add-on candidates, parked by reset_gen_host in draw order: apache in procs[5].pid, mysql in procs[6].pid, smtp in svcs[6].pid
+    for (int k = 0; k < 3; ++k) {
+      const int kind = k == 0 ? K_APACHE : (k == 1 ? K_MYSQL : K_SMTP);
+      const int v0 = k == 0 ? st.procs[5].pid : (k == 1 ? st.procs[6].pid : st.svcs[6].pid);
+      bool moved;
+      const int v = settle(v0, &moved);
+      if (moved) for (int i = nfix; i < n; ++i) if (st.svcs[i].kind == kind) { st.svcs[i].pid = (uint16_t)v; st.procs[i].pid = (uint16_t)v; }
+    }
+    st.procs[5].pid = 0; st.procs[6].pid = 0; st.svcs[6].pid = 0;
   }
 }
 // phase 4, one thread: blue parents, green agents, red start hosts (_generate_blue/green/red_agents; main reset stream)
@@ -880,10 +895,9 @@ CC4_HD void env_reset_counter_mode(Ctx x, uint64_t seed, int steps, bool continu
     Rng t; rng_fork(&t, x.r, ST_GEN_HOST);
     Ctx xh = x; xh.r = &t;
     for (int h = 0; h < MAXH; ++h) reset_gen_host(xh, h);
-    for (int h = 0; h < MAXH; ++h) reset_pid_mark(xh, h, ws);
-    for (int h = 0; h < MAXH; ++h) reset_pid_flag(xh, h, ws);
   }
-  reset_pid_resolve(x, ws);
+  reset_pid_serial(x, reset_used_set(x.s));
+  reset_used_clear(x.s, 0, 1);
   reset_agents(x);
   {
     Rng t; rng_fork(&t, x.r, ST_GEN_SESS);
@@ -2297,7 +2311,7 @@ CC4_HD void step_green_policy(Ctx x, int g, const uint32_t* pre = nullptr) {
       const int own = h_subnet(s->green_host[g]);
       int ph = step_phase_of(s->step_count, s->phase_len[0], s->phase_len[1], s->phase_len[2]);
       if (ph < s->phase) ph = s->phase;
-      if ((s->policy & GP_SLEEP_BIT) || ea.host != s->green_host[g] || (t == XG_ACCESS && (ea.sid & ~green_allowed_mask(ph, own)))) t = XG_INVALID;
+      if (((s->policy & GP_SLEEP_BIT) && !(s->policy & GP_OPEN_BIT)) || ea.host != s->green_host[g] || (t == XG_ACCESS && (ea.sid & ~green_allowed_mask(ph, own)))) t = XG_INVALID;
     }
     // InvalidAction: Observation(False), nothing the reward reads -- resolved like Sleep (3: step_end reports its success as False)
     x.w->green_act[g] = (uint8_t)(t == XG_ACCESS ? 0 : (t == XG_LOCAL ? 1 : (t == XG_INVALID ? 3 : 2)));

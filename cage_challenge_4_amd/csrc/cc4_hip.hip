@@ -740,11 +740,9 @@ __global__ __launch_bounds__(PT, MINW) void k_step_philox(StepArgs a) {
     Ctx xh{s, cold_e, &rh, hd, &work};
     if (tid < MAXH) reset_gen_host(xh, tid);
     __syncthreads();
-    if (tid < MAXH) reset_pid_mark(xh, tid, reset_ws);
+    if (tid == 0) { reset_pid_serial(xm, reset_used_set(s)); reset_agents(xm); }      // pid uniqueness in the reference's order (one thread; once per episode)
     __syncthreads();
-    if (tid < MAXH) reset_pid_flag(xh, tid, reset_ws);
-    __syncthreads();
-    if (tid == 0) { reset_pid_resolve(xm, reset_ws); reset_agents(xm); }
+    reset_used_clear(s, tid, PT);
     __syncthreads();
     if (tid < MAXH) reset_host_sessions(xh, tid);
     __syncthreads();
@@ -1009,11 +1007,9 @@ __global__ __launch_bounds__(WAVE, CC4_LEAN_MINW) void k_step_philox1(StepArgs a
     Ctx xh{s, cold_e, &rh, hd, &work};
     for (int h = lane; h < MAXH; h += WAVE) reset_gen_host(xh, h);
     __syncthreads();
-    for (int h = lane; h < MAXH; h += WAVE) reset_pid_mark(xh, h, ws);
+    if (lane == 0) { reset_pid_serial(xm, reset_used_set(s)); reset_agents(xm); }     // pid uniqueness in the reference's order (one lane; once per episode)
     __syncthreads();
-    for (int h = lane; h < MAXH; h += WAVE) reset_pid_flag(xh, h, ws);
-    __syncthreads();
-    if (lane == 0) { reset_pid_resolve(xm, ws); reset_agents(xm); }
+    reset_used_clear(s, lane, WAVE);
     __syncthreads();
     for (int h = lane; h < MAXH; h += WAVE) reset_host_sessions(xh, h);
     __syncthreads();
@@ -1221,11 +1217,9 @@ __global__ __launch_bounds__(WAVE) void k_reset(ResetArgs a) {
     Ctx xh{s, cold_e, &rh, hd, &work};
     for (int h = lane; h < MAXH; h += WAVE) reset_gen_host(xh, h);
     __syncthreads();
-    for (int h = lane; h < MAXH; h += WAVE) reset_pid_mark(xh, h, ws);
+    if (lane == 0) { reset_pid_serial(xm, reset_used_set(s)); reset_agents(xm); }     // pid uniqueness in the reference's order (one lane; once per episode)
     __syncthreads();
-    for (int h = lane; h < MAXH; h += WAVE) reset_pid_flag(xh, h, ws);
-    __syncthreads();
-    if (lane == 0) { reset_pid_resolve(xm, ws); reset_agents(xm); }
+    reset_used_clear(s, lane, WAVE);
     __syncthreads();
     for (int h = lane; h < MAXH; h += WAVE) reset_host_sessions(xh, h);
     __syncthreads();
@@ -1494,7 +1488,7 @@ static int launch_step(cc4_handle* h, const int32_t* d_actions, const uint8_t* d
   StepArgs a{h->d_state, h->d_cold, d_actions, d_msgs, h->d_obs, h->d_reward, h->d_done, h->d_err,
              h->comm ? h->d_obs8[buf] : nullptr, rand ? h->d_actions : nullptr, seed0, t,
              h->cfg.num_envs, h->cfg.autoreset, h->cfg.steps, h->cfg.rng_mode,
-             (h->cfg.red_policy & 3) | (h->cfg.green_policy ? GP_SLEEP_BIT : 0) | (h->cfg.blue_policy ? BP_RANDOM_BIT : 0), h->full_obs_next ? 1 : 0,
+             (h->cfg.red_policy & 3) | (h->cfg.green_policy ? GP_SLEEP_BIT : 0) | (h->cfg.green_policy == 2 ? GP_OPEN_BIT : 0) | (h->cfg.blue_policy ? BP_RANDOM_BIT : 0), h->full_obs_next ? 1 : 0,
              (uint32_t)h->cfg.topology_seed, h->d_prof, h->d_reset_ws, h->ext_seen ? h->d_ext : nullptr, 0};
   h->full_obs_next = false;
   for (int g = 0; g < h->ngroups; ++g) {
@@ -1548,7 +1542,7 @@ const char* cc4_step_kernel(cc4_handle* h) {
 
 int cc4_create(const cc4_config* cfg, cc4_handle** out) {
   if (!cfg || !out || cfg->num_envs <= 0 || cfg->steps <= 0 || cfg->red_policy < 0 || cfg->red_policy > 3 ||
-      cfg->green_policy < 0 || cfg->green_policy > 1 || cfg->blue_policy < 0 || cfg->blue_policy > 1 || cfg->rng_mode < 0 || cfg->rng_mode > 1) { g_create_err = "cc4_create: bad config"; return -2; }
+      cfg->green_policy < 0 || cfg->green_policy > 2 || cfg->blue_policy < 0 || cfg->blue_policy > 1 || cfg->rng_mode < 0 || cfg->rng_mode > 1) { g_create_err = "cc4_create: bad config"; return -2; }
   if (cfg->topology_seed != 0 && cfg->rng_mode != 1) { g_create_err = "cc4_create: topology_seed needs rng_mode 1 (the numpy stream draws scenario and dynamics from one generator)"; return -2; }
   int ndev = 0;
   hipError_t e = hipGetDeviceCount(&ndev);
@@ -1670,7 +1664,7 @@ int cc4_reset(cc4_handle* h, const uint64_t* seeds, const uint8_t* env_mask) {
   if (env_mask) HIPCHK(h, hipMemcpyAsync(h->d_envmask, env_mask, n, hipMemcpyHostToDevice, h->stream));
   ResetArgs a{h->d_state, h->d_cold, seeds ? h->d_seeds : nullptr, env_mask ? h->d_envmask : nullptr, h->d_obs, h->d_reward,
               h->d_done, h->d_err, h->d_mask, h->cfg.num_envs, h->cfg.steps, h->cfg.rng_mode,
-              (h->cfg.red_policy & 3) | (h->cfg.green_policy ? GP_SLEEP_BIT : 0) | (h->cfg.blue_policy ? BP_RANDOM_BIT : 0), (uint32_t)h->cfg.topology_seed,
+              (h->cfg.red_policy & 3) | (h->cfg.green_policy ? GP_SLEEP_BIT : 0) | (h->cfg.green_policy == 2 ? GP_OPEN_BIT : 0) | (h->cfg.blue_policy ? BP_RANDOM_BIT : 0), (uint32_t)h->cfg.topology_seed,
               h->comm ? h->d_obs8[h->obs_buf] : nullptr};
   // with a communicator the reset also writes the packed exchange row of its observations into the current ring buffer; an
   // overlapped all-gather may still be reading that buffer
@@ -2068,6 +2062,25 @@ int cc4_comm_init(cc4_handle* h, int32_t rank, int32_t world, const void* id128)
   }
   HIPCHK(h, hipStreamSynchronize(h->stream));
   HIPCHK(h, hipStreamSynchronize(h->comm_stream));
+  return 0;
+}
+// What a multi-GPU run needs to PROVE its scaling line: RCCL's own view of the communicator (how many ranks it spans, which one this
+// is, which device it is bound to) and the identity of the device this handle runs on.  out[0] ncclCommCount (1 without a
+// communicator), out[1] ncclCommUserRank (0), out[2] ncclCommCuDevice (-1), out[3] the handle's HIP device ordinal, out[4] PCI
+// domain, out[5] PCI bus, out[6] PCI device, out[7] compute units; uuid_hex: 32 hex digits + NUL of hipDeviceProp_t::uuid.
+int cc4_comm_info(cc4_handle* h, int32_t* out, char* uuid_hex) {
+  HIPCHK(h, hipSetDevice(h->cfg.device_id));
+  int count = 1, urank = 0, cudev = -1;
+  if (h->comm) {
+    if (ncclCommCount(h->comm, &count) != ncclSuccess || ncclCommUserRank(h->comm, &urank) != ncclSuccess || ncclCommCuDevice(h->comm, &cudev) != ncclSuccess) {
+      h->err = "cc4_comm_info: RCCL did not answer"; return -1;
+    }
+  }
+  hipDeviceProp_t prop;
+  HIPCHK(h, hipGetDeviceProperties(&prop, h->cfg.device_id));
+  out[0] = count; out[1] = urank; out[2] = cudev; out[3] = h->cfg.device_id;
+  out[4] = prop.pciDomainID; out[5] = prop.pciBusID; out[6] = prop.pciDeviceID; out[7] = prop.multiProcessorCount;
+  if (uuid_hex) { for (int i = 0; i < 16; ++i) snprintf(uuid_hex + 2 * i, 3, "%02x", (unsigned)(unsigned char)prop.uuid.bytes[i]); }
   return 0;
 }
 // All-gather of the observations written by the most recent step (as bytes, [world*N][578]) over RCCL/xGMI on the

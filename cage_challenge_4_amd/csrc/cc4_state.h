@@ -111,6 +111,8 @@ enum : int { RA_DRS = 0, RA_AGGR = 1, RA_STEALTH = 2, RA_DECEPTION = 3, RA_EXPLO
 enum : int { BA_SLEEP = 0, BA_MONITOR = 1, BA_ANALYSE = 2, BA_REMOVE = 3, BA_RESTORE = 4, BA_DECOY = 5, BA_BLOCK = 6, BA_ALLOW = 7 };
 // built-in policies selectable through EnterpriseScenarioGenerator(red_agent_class=, green_agent_class=)
 enum : int { RP_FSM = 0, RP_SLEEP = 1, RP_DISCOVERY = 2, RP_RANDOM = 3, GP_SLEEP_BIT = 0x10,
+             GP_OPEN_BIT = 0x40 /* with GP_SLEEP_BIT: the green agents have no policy of their own here (a host-side agent class submits
+                                   their actions) but, unlike SleepAgent's, their action space holds the green actions (ESG.py:714,742-746) */,
              BP_RANDOM_BIT = 0x20 /* blue_agent_class=cc4BlueRandomAgent: acts for every blue agent no action is submitted for */ };
 // TernaryEnum (Shared/Enums.py:5-25)
 enum : int { T_TRUE = 1, T_UNKNOWN = 2, T_FALSE = 3, T_IN_PROGRESS = 4 };

@@ -44,16 +44,22 @@ class FilePlane(SoloPlane):
     of rank r is the file `q_r` (written under a temporary name, then renamed: readers never see a partial file); a rank that has
     read all files of operation q knows every rank has finished operation q - 1, and removes its own file of that one."""
     kind = 'file'
+    _instances = {}          # directory -> planes created on it by this process: each gets a file-name prefix of its own
 
     def __init__(self, rank, world, key, root=None, timeout=2000.0):   # longer than bench.py's RCCL setup watchdog (900 s)
         self.rank, self.world, self.timeout = int(rank), int(world), float(timeout)
         root = root or os.environ.get('CC4_CONTROL_PLANE_DIR') or ('/dev/shm' if os.path.isdir('/dev/shm') else '/tmp')
         self.dir = os.path.join(root, f'cc4_plane_{key}')
-        os.makedirs(self.dir, exist_ok=True)
+        os.makedirs(self.dir, mode=0o700, exist_ok=True)
+        # Two planes on one directory (a second handle's communicator, a helper that builds its own plane) must not read each
+        # other's operations: plane number k of this process talks to plane number k of every other rank (all ranks run the same
+        # program), under the prefix `p<k>_`.  Operation numbers restart at 0 per plane.
+        self.inst = FilePlane._instances.get(self.dir, 0)
+        FilePlane._instances[self.dir] = self.inst + 1
         self.seq = 0
 
     def _path(self, q, r):
-        return os.path.join(self.dir, f'{q}_{r}')
+        return os.path.join(self.dir, f'p{self.inst}_{q}_{r}')
 
     def exchange(self, payload):
         q = self.seq
@@ -106,7 +112,7 @@ class FilePlane(SoloPlane):
         removes the directory's files."""
         self.barrier()
         if self.rank != 0:
-            mine = os.path.join(self.dir, f'done_{self.rank}')
+            mine = os.path.join(self.dir, f'p{self.inst}_done_{self.rank}')
             try:
                 with open(mine + '.tmp', 'wb') as f:
                     f.write(b'1')
@@ -115,18 +121,20 @@ class FilePlane(SoloPlane):
                 pass
             return
         t0 = time.monotonic()
-        want = [os.path.join(self.dir, f'done_{r}') for r in range(1, self.world)]
+        want = [os.path.join(self.dir, f'p{self.inst}_done_{r}') for r in range(1, self.world)]
         while not all(os.path.exists(p) for p in want):
             if time.monotonic() - t0 > 10.0:
                 return
             time.sleep(0.001)
         try:
             for name in os.listdir(self.dir):
+                if not name.startswith(f'p{self.inst}_'):        # another plane of this job may still be at work in the directory
+                    continue
                 try:
                     os.remove(os.path.join(self.dir, name))
                 except OSError:
                     pass
-            os.rmdir(self.dir)
+            os.rmdir(self.dir)                                    # succeeds once the last plane is gone
         except OSError:
             pass
 
@@ -172,19 +180,43 @@ class GlooPlane(SoloPlane):
             dist.destroy_process_group()
 
 
-def control_plane(kind=None, force=False):
+def _launcher_start_ticks():
+    """Start time of the parent process (the launcher all workers of one launch are children of), in clock ticks since boot
+    (/proc/<pid>/stat field 22): with the pid it names ONE launch -- a later launch that reuses the port and, by pid wrap-around,
+    even the pid cannot find the files a crashed earlier one left behind."""
+    try:
+        with open(f'/proc/{os.getppid()}/stat') as f:
+            return f.read().rsplit(')', 1)[1].split()[19]
+    except (OSError, IndexError):
+        return '0'
+
+
+_PLANE = None
+
+
+def control_plane(kind=None, force=False, fresh=False):
     """The job's control plane from the launcher's environment (RANK, WORLD_SIZE, MASTER_PORT; torch.distributed.run sets
     them).  kind: 'file' (default; no PyTorch) or 'gloo' (CC4_CONTROL_PLANE overrides).  force: a one-rank FilePlane instead of
-    the SoloPlane (exercises the N>1 code path at world size 1)."""
+    the SoloPlane (exercises the N>1 code path at world size 1).  ONE plane per process: later calls return the same object
+    (a second FilePlane on the same directory would start its operation numbers at 0 again); fresh=True builds another one, which
+    gets a file-name prefix of its own."""
+    global _PLANE
+    if _PLANE is not None and not fresh:
+        return _PLANE
     rank, world, _ = env_rank_world()
     kind = os.environ.get('CC4_CONTROL_PLANE', kind or 'file')
     if world == 1 and not force:
-        return SoloPlane()
-    if kind == 'gloo':
-        return GlooPlane(rank, world)
-    # every worker of one launch is a child of the same launcher process: its pid tells launches that reuse a port apart
-    key = os.environ.get('CC4_CONTROL_PLANE_KEY') or f"{os.environ.get('MASTER_PORT', '0')}_{os.environ.get('TORCHELASTIC_RUN_ID', 'none')}_{os.getppid()}"
-    return FilePlane(rank, world, key)
+        plane = SoloPlane()
+    elif kind == 'gloo':
+        plane = GlooPlane(rank, world)
+    else:
+        # every worker of one launch is a child of the same launcher process: its pid and start time tell launches that reuse a port apart
+        key = os.environ.get('CC4_CONTROL_PLANE_KEY') or (f"{os.environ.get('MASTER_PORT', '0')}_{os.environ.get('TORCHELASTIC_RUN_ID', 'none')}_"
+                                                           f"{os.getppid()}_{_launcher_start_ticks()}")
+        plane = FilePlane(rank, world, key)
+    if not fresh:
+        _PLANE = plane
+    return plane
 
 
 def env_rank_world():
@@ -242,7 +274,7 @@ def init_rccl(vec_env, rank, world, plane=None):
             raise RuntimeError('cc4_comm_unique_id failed')
         ident = bytes(buf)
     if world > 1:
-        plane = plane or control_plane()
+        plane = plane or control_plane()          # the process-wide plane (never a second FilePlane with operation numbers of its own)
         ident = plane.bcast_bytes(ident, src=0)
     assert len(ident) == 128
     raw = (ctypes.c_uint8 * 128).from_buffer_copy(ident)

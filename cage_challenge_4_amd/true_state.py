@@ -323,13 +323,13 @@ def blue_observations(ts, combined=2):
         # parameters are validated on submission); Block/AllowTrafficZone report whether the pair's state changed
         # (BlueAgent.last_ok).
         if d['blue'][b].get('busy'):
-            res = {'success': 'IN_PROGRESS'}
+            res = {'success': Ternary('IN_PROGRESS')}
         else:
             ok = {'Sleep': 'UNKNOWN', 'Monitor': 'TRUE', 'Analyse': 'TRUE', 'Remove': 'TRUE', 'Restore': 'TRUE',
                   'DeployDecoy': 'TRUE'}.get(la.name)
             if la.name in ('BlockTrafficZone', 'AllowTrafficZone'):
                 ok = {1: 'TRUE', 3: 'FALSE'}.get(d['blue'][b].get('traffic_ok'))
-            res = {'success': ok, 'action': la}
+            res = {'success': Ternary(ok) if ok is not None else None, 'action': la}
         res.update(obs.data)
         out[agent] = res
     return out
@@ -398,6 +398,43 @@ class TrueStateTableWrapper:
 # details of an exploit's own observation and the process descriptions DegradeServices / DiscoverDeception attach (ephemeral
 # ports, paths, versions) -- nothing on the hot path or in the built-in agents reads them.
 OE_KEY_IP, OE_SESS, OE_IFACE, OE_SYSHN = 1, 2, 4, 8
+
+
+class Ternary(str):
+    """Shared/Enums.py TernaryEnum as the dict observations of this package carry it: a str ('TRUE' / 'FALSE' / 'UNKNOWN' /
+    'IN_PROGRESS') with the enum's .name and .value and its comparison with bools (TRUE == True, FALSE == False; UNKNOWN and
+    IN_PROGRESS equal neither), so that code written against the reference -- obs['success'] == True, success.name -- runs unchanged."""
+    _VALUE = {'TRUE': 1, 'UNKNOWN': 2, 'FALSE': 3, 'IN_PROGRESS': 4}
+
+    @property
+    def name(self):
+        return str(self)
+
+    @property
+    def value(self):
+        return self._VALUE[str(self)]
+
+    def __eq__(self, other):
+        if isinstance(other, bool):
+            return (str(self) == 'TRUE') if other else (str(self) == 'FALSE')
+        n = getattr(other, 'name', other)
+        return str(self) == n
+
+    def __ne__(self, other):
+        return not self.__eq__(other)
+
+    __hash__ = str.__hash__
+
+
+# agent_interface.allowed_subnets of a green agent in mission phase p: its own subnet, then its partners in the phase's pair list
+# (EnterpriseScenarioGenerator.py:281-306 + SimulationController.py:747-765); same table as green_allowed_mask (csrc/cc4_tables.h)
+_GREEN_ALLOWED = ((0xf7, 0x03, 0xfd, 0x0c, 0xf5, 0x35, 0x55, 0x95, 0x100), (0xe1, 0x02, 0xfc, 0x0c, 0xf4, 0x35, 0x55, 0x95, 0x100),
+                  (0xf3, 0x03, 0xe4, 0x08, 0xf1, 0x35, 0x55, 0x95, 0x100))
+
+
+def green_allowed_subnets(phase, subnet):
+    m = _GREEN_ALLOWED[phase][subnet]
+    return [SUBNETS[subnet]] + [SUBNETS[i] for i in range(9) if (m >> i) & 1 and i != subnet]
 TERNARY = {0: 'UNKNOWN', 1: 'TRUE', 2: 'UNKNOWN', 3: 'FALSE', 4: 'IN_PROGRESS'}
 
 
@@ -414,7 +451,7 @@ def red_observations(ts):
     out = {}
     for r, ag in enumerate(d['red']):
         agent = f'red_agent_{r}'
-        obs = {'success': TERNARY[ag['obs_success']]}
+        obs = {'success': Ternary(TERNARY[ag['obs_success']])}
         atype = ag['obs_action'][0]
         ex_type, _h, _a, executed = d['last_red'][r]
         # 'action' of observations[0]: the agent's own action when it executed (Sleep and InvalidAction included); the end-of-turn

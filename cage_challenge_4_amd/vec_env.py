@@ -246,6 +246,14 @@ class CC4VecEnv:
         self._chk(self.lib.cc4_host_stats(self._h, out.ctypes.data_as(ctypes.c_void_p)), 'cc4_host_stats')
         return {'steps': int(out[0]), 'launch_us': float(out[1]), 'gather_us': float(out[2]), 'gathers': int(out[3]), 'gather_stalls': int(out[4])}
 
+    def comm_info(self):
+        """cc4_comm_info: RCCL's view of the communicator (ranks it spans, this rank, its device) + the identity of the handle's device."""
+        out = np.zeros(8, np.int32)
+        uuid = ctypes.create_string_buffer(33)
+        self._chk(self.lib.cc4_comm_info(self._h, out.ctypes.data_as(ctypes.c_void_p), uuid), 'cc4_comm_info')
+        return {'nccl_comm_count': int(out[0]), 'nccl_user_rank': int(out[1]), 'nccl_device': int(out[2]), 'hip_device': int(out[3]),
+                'pci': f'{int(out[4]):04x}:{int(out[5]):02x}:{int(out[6]):02x}', 'compute_units': int(out[7]), 'device_uuid': uuid.value.decode()}
+
     def rng_state(self):
         out = np.zeros((self.num_envs, 7), np.uint64)
         self._chk(self.lib.cc4_get_rng_state(self._h, out.ctypes.data_as(ctypes.c_void_p)), 'cc4_get_rng_state')

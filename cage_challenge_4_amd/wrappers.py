@@ -13,6 +13,7 @@ Mirrors: CybORG/env.py:53-77,218-243; CybORG/Simulator/Scenarios/EnterpriseScena
 CybORG/Agents/Wrappers/BlueFixedActionWrapper.py:26-379; BlueFlatWrapper.py:31-322; BlueEnterpriseWrapper.py:25-122;
 EnterpriseMAE.py:10-72.  Outputs are bit-identical to the reference under the same seed (rng_mode PCG64)."""
 import functools
+import json
 import os
 import ctypes
 import numpy as np
@@ -27,6 +28,7 @@ SUBNET_NAMES = ['restricted_zone_a_subnet', 'operational_zone_a_subnet', 'restri
 BLUE_SUBNETS = [['restricted_zone_a_subnet'], ['operational_zone_a_subnet'], ['restricted_zone_b_subnet'],
                 ['operational_zone_b_subnet'],
                 ['public_access_zone_subnet', 'admin_network_subnet', 'office_network_subnet']]  # ESG.py:643-649
+json_loads = json.loads
 MAX_USER_HOSTS, MAX_SERVER_HOSTS = 10, 6
 NUM_MESSAGES, MESSAGE_LENGTH = 4, 8
 EMPTY_MESSAGE = np.zeros(MESSAGE_LENGTH, dtype=bool)
@@ -74,21 +76,29 @@ class EnterpriseScenarioGenerator:
     MESSAGE_LENGTH = 8
 
     def __init__(self, blue_agent_class=None, red_agent_class=None, green_agent_class=None, steps: int = 100):
+        # The engine runs these policies on the device.  Any OTHER class is instantiated on the host, one object per agent, as the
+        # reference does (ESG.py:95-121, :693-696, :736-748, :805-817): the engine's own policy for that team then sleeps, the object's
+        # get_action(observation, action_space) is called every step with the agent's dict observation, and what it returns is
+        # submitted through cc4_step_ex (the slow path: one host round trip per step -- what a scripted or learning red agent costs
+        # in the reference too).
         blue = {'SleepAgent': 0, 'cc4BlueRandomAgent': 1}
-        bn = 'SleepAgent' if blue_agent_class is None else getattr(blue_agent_class, '__name__', None)
-        if bn not in blue:
-            raise NotImplementedError(f"built-in blue policies (they act for agents no action is submitted for): {list(blue)}")
-        self.blue_policy = blue[bn]
         red = {'FiniteStateRedAgent': 0, 'SleepAgent': 1, 'DiscoveryFSRed': 2, 'RandomSelectRedAgent': 3}
         green = {'EnterpriseGreenAgent': 0, 'SleepAgent': 1}
         # None -> SleepAgent, as the reference's generators do (ESG.py:745-748, :815-817)
+        bn = 'SleepAgent' if blue_agent_class is None else getattr(blue_agent_class, '__name__', None)
         rn = 'SleepAgent' if red_agent_class is None else getattr(red_agent_class, '__name__', None)
         gn = 'SleepAgent' if green_agent_class is None else getattr(green_agent_class, '__name__', None)
-        if rn not in red or gn not in green:
-            raise NotImplementedError(f"built-in policies of the HIP engine: red {list(red)}, green {list(green)} "
-                                      f"(got red={red_agent_class}, green={green_agent_class}); "
-                                      "other policies are SURVEY 8(f) 'next' rows")
-        self.red_policy, self.green_policy = red[rn], green[gn]
+        self.custom = {}                                   # team -> class whose objects act from the host
+        for team, name, table, cls in (('blue', bn, blue, blue_agent_class), ('red', rn, red, red_agent_class), ('green', gn, green, green_agent_class)):
+            builtin = name in table and (cls is None or getattr(cls, '__module__', '').startswith('cage_challenge_4_amd') or name == 'SleepAgent')
+            if not builtin:
+                if not callable(cls) or not hasattr(cls, 'get_action'):
+                    raise TypeError(f'{team}_agent_class={cls!r}: an agent class needs get_action(observation, action_space)')
+                self.custom[team] = cls
+        self.blue_policy = 0 if 'blue' in self.custom else blue[bn]
+        self.red_policy = 1 if 'red' in self.custom else red[rn]
+        # (2: no built-in green policy, but -- unlike a SleepAgent's -- an action space that holds the green actions, ESG.py:714,742-746)
+        self.green_policy = 2 if 'green' in self.custom else green[gn]
         self.blue_agent_class = blue_agent_class
         self.red_agent_class = red_agent_class
         self.green_agent_class = green_agent_class
@@ -103,8 +113,9 @@ class CybORG:
     def __init__(self, scenario_generator, agents=None, seed=None, device_id=0, rng_mode=RNG_PCG64, vec_factory=None):
         assert isinstance(scenario_generator, EnterpriseScenarioGenerator), \
             f'Scenario generator object of type {type(scenario_generator)} must be a subclass of ScenarioGenerator'
-        if agents and not isinstance(agents, str):   # evaluation.py:69 passes the string "sim" here; it selects nothing
-            raise NotImplementedError("per-agent policy overrides are not part of the accelerated path")
+        # env.py:53-77: agents = {agent_name: agent object} overrides the scenario's agent for those agents (evaluation.py:69 passes the
+        # string "sim" here; it selects nothing).  Such objects act from the host, like the objects of a custom agent class.
+        self._agent_overrides = dict(agents) if isinstance(agents, dict) else {}
         self.scenario_generator = scenario_generator
         if seed is None:
             seed = int.from_bytes(os.urandom(8), 'little') >> 1
@@ -129,11 +140,43 @@ class CybORG:
             self.vec.reset(seeds=np.array([seed], np.uint64))  # SimulationController.__init__ creates a scenario
         self.agents = [f'blue_agent_{b}' for b in range(5)]
         self._labels = None
+        self._seed = int(seed)
+        self._make_host_agents()
+
+    def _make_host_agents(self):
+        """The agent objects that act from the host: one per agent of a team with a custom class (constructed as the reference's
+        generator does: (name) or (name, np_random=...) -- the reference hands every such object ITS shared generator; here each
+        gets a numpy Generator of its own, seeded from the episode's seed and the agent's name, because the simulator's stream lives
+        on the device), plus the `agents=` overrides."""
+        import inspect
+        import zlib
+        sg = self.scenario_generator
+        d = json_loads(self.vec.true_state_json(0))
+        names = {'blue': list(self.agents_blue), 'green': [f'green_agent_{g}' for g in range(d['n_green'])],
+                 'red': [f'red_agent_{r}' for r in range(6)]}
+        self._host_agents = {}
+        for team, cls in getattr(sg, 'custom', {}).items():
+            params = inspect.signature(cls.__init__).parameters if hasattr(cls, '__init__') else {}
+            for name in names[team]:
+                kw = {}
+                if 'np_random' in params:
+                    kw['np_random'] = np.random.default_rng([self._seed & 0xFFFFFFFF, zlib.crc32(name.encode())])
+                try:
+                    self._host_agents[name] = cls(name, **kw)
+                except TypeError:
+                    self._host_agents[name] = cls(**kw) if kw else cls()
+        self._host_agents.update(self._agent_overrides)
 
     def reset(self, agent=None, seed=None):
         """env.py:218-243: seed=None keeps the running stream; an int seed starts a fresh Generator."""
         self.vec.reset(seeds=None if seed is None else np.array([seed], np.uint64))
         self._labels = None
+        if seed is not None:
+            self._seed = int(seed)
+        for a in self._host_agents.values():          # AgentInterface.reset -> agent.end_episode (Shared/AgentInterface.py:145-160)
+            if hasattr(a, 'end_episode'):
+                a.end_episode()
+        self._make_host_agents()
 
     @property
     def unwrapped(self):
@@ -150,28 +193,101 @@ class CybORG:
             self._labels = build_action_labels(self.get_cidr_map(), split_mask(self.vec.action_mask))
         return self._labels
 
-    def _submit(self, actions, messages):
-        """actions: {blue agent: wrapper index | action object (cage_challenge_4_amd.actions or any object with the same
-        class name and attributes)}; red and green agents run their built-in policies on the device."""
-        acts = np.full((1, 5), -1, np.int32)
-        for a, v in (actions or {}).items():
-            if a not in self.agents_blue:
-                raise NotImplementedError(f"{a}: only the blue agents take external actions on the accelerated path "
-                                          "(red and green run the scenario's built-in policies on the device)")
-            b = self.agents_blue.index(a)
-            labels = self._action_labels()[a]['labels']
+    def _blue_code(self, agent, v, labels=None):
+        """What cc4_step_ex takes for a blue agent: the index of the action in the agent's fixed list, or a (type, host / subnet
+        pair) code for an action object the list has no slot for, plus the object's `duration` when it is not the class's own."""
+        b = self.agents_blue.index(agent)
+        labels = labels if labels is not None else self._action_labels()[agent]['labels']
+        name = getattr(v, 'name', None) or type(v).__name__
+        if name in ('BlockTrafficZone', 'AllowTrafficZone') and not isinstance(v, (int, np.integer)):
+            try:
+                idx = A.action_index(v, labels)
+            except ValueError:
+                # any pair of subnets is a valid Block / Allow for any blue agent: neither parameter is an ActionSpace key
+                # (SimulationController.py:1094-1096; Tests/test_cc4/test_BlueRewardMachine.py:133-137)
+                to, frm = A._subnet_index(v.to_subnet, ()), A._subnet_index(v.from_subnet, ())
+                if to is None or frm is None:
+                    raise
+                idx = A.BLUE_RAW_ACTION | ((6 if name == 'BlockTrafficZone' else 7) << 8) | to | (frm << 4)
+        else:
             idx = A.action_index(v, labels)
-            if idx < A.BLUE_RAW_ACTION:                     # (an action object naming a router comes back as a (type, host) code)
-                idx = range(len(labels))[idx]               # list semantics: a negative index counts from the end, out of range raises IndexError
-                idx = idx if idx < (242 if b == 4 else 82) else labels.index('Sleep')   # an explicit Sleep, not "no action" (-1)
-            acts[0, b] = idx
+        if idx < A.BLUE_RAW_ACTION:                     # (an action object naming a router comes back as a (type, host) code)
+            idx = range(len(labels))[idx]               # list semantics: a negative index counts from the end, out of range raises IndexError
+            idx = idx if idx < (242 if b == 4 else 82) else labels.index('Sleep')   # an explicit Sleep, not "no action" (-1)
+        dur = getattr(v, 'duration', None)
+        if dur is not None and not isinstance(v, (int, np.integer)) and int(dur) != A.DURATION.get(name, 1):
+            if not 1 <= int(dur) <= 255:
+                raise ValueError(f'{name}: duration {dur} out of range')
+            idx |= int(dur) << 20                       # cc4.h cc4_step_ex: `action.duration` rides in bits 20..27
+        return idx
+
+    def _host_maps(self):
+        ips = self.get_ip_map()
+        t = self.topology()
+        return ({str(ip): h for h, ip in ((hid, ips[host_name(hid)]) for hid in range(137) if t[27 + 2 * hid])},
+                {host_name(hid): hid for hid in range(137) if t[27 + 2 * hid]},
+                [f"10.0.{int(t[i])}.0/24" for i in range(9)])
+
+    def _submit(self, actions, messages, skip_valid_action_check=False, blue_codes=None):
+        """actions: {agent: action}.  A blue agent's action is a wrapper index or an action object; a red or green agent's is an action
+        object (cage_challenge_4_amd.actions, or any object with the same class name and attributes -- the reference's own Action
+        instances map the same way).  Agents without an entry act by the scenario's policy: on the device for the built-in classes, by
+        their host-side object for custom classes / `agents=` overrides (asked here, in agent_interfaces order: blue, green, red)."""
+        actions = dict(actions or {})
+        if self._host_agents:
+            d = json_loads(self.vec.true_state_json(0))
+            for name, obj in self._host_agents.items():
+                if name in actions or (blue_codes is not None and name in self.agents_blue and blue_codes[self.agents_blue.index(name)] >= 0):
+                    continue
+                if name.startswith('green') and int(name.split('_')[-1]) >= d['n_green']:
+                    continue
+                # AgentInterface.get_action (Shared/AgentInterface.py:120-143): an inactive agent sleeps, its object is not asked
+                if name.startswith('red') and not d['red'][int(name[-1])]['active']:
+                    continue
+                act = obj.get_action(self.get_observation(name), self.get_action_space(name))
+                if act is not None:
+                    actions[name] = act
+        acts = np.full((1, 5), -1, np.int32) if blue_codes is None else np.asarray(blue_codes, np.int32).reshape(1, 5).copy()
+        red = green = None
+        maps = None
+        for a, v in actions.items():
+            if a in self.agents_blue:
+                acts[0, self.agents_blue.index(a)] = self._blue_code(a, v)
+                continue
+            kind = 'red' if a.startswith('red_agent_') else ('green' if a.startswith('green_agent_') else None)
+            if kind is None:
+                raise ValueError(f'{a}: no such agent')
+            k = int(a.split('_')[-1])
+            if maps is None:
+                maps = self._host_maps()
+                gh = json_loads(self.vec.true_state_json(0))['green_hosts']
+            if kind == 'red':
+                if not 0 <= k < 6:
+                    raise ValueError(f'{a}: no such agent')
+                red = self.vec.agent_actions('red') if red is None else red
+                rec, own = red[0, k], None
+            else:
+                if not 0 <= k < len(gh):
+                    raise ValueError(f'{a}: no such agent')
+                green = self.vec.agent_actions('green') if green is None else green
+                rec, own = green[0, k], gh[k]
+            if getattr(v, 'agent', a) != a:           # the 'agent' parameter is an ActionSpace key: another agent's name is invalid (SC:1094-1110)
+                fields = (A.RED_INVALID if kind == 'red' else A.GREEN_INVALID, 0, 0, 0, 0, 0, 0.0, 0.0)
+            else:
+                fields = A.encode_agent_action(v, kind, maps[0], maps[1], maps[2], own_host=own, skip_valid=skip_valid_action_check)
+            for f, val in zip(('type', 'host', 'arg', 'ticks', 'session', 'flags', 'rate0', 'rate1'), fields):
+                rec[f] = val
+        self._submitted = {a: v for a, v in actions.items() if a not in self.agents_blue}
         msg = np.zeros((1, 5, MESSAGE_LENGTH), np.uint8)
         for b, a in enumerate(self.agents_blue):
             m = np.asarray((messages or {}).get(a, EMPTY_MESSAGE)).astype(bool)
             assert m.shape == (MESSAGE_LENGTH,), \
                 f'{a} attempting to send message {m} that is not in the message space MultiBinary({MESSAGE_LENGTH})'
             msg[0, b] = m
-        obs, rew, done, vinfo = self.vec.step(acts, msg)
+        if red is None and green is None:
+            obs, rew, done, vinfo = self.vec.step(acts, msg)
+        else:
+            obs, rew, done, vinfo = self.vec.step_ex(acts, msg, red, green)
         raise_on_engine_error(vinfo['err'])               # ValueError past the last step (State.py:539-540); anything else is loud too
         return obs, rew, done
 
@@ -180,27 +296,49 @@ class CybORG:
         agents that acted plus the active ones.  Blue agents get their full dict observation (get_observation); red and
         green agents -- internal policies here -- are listed with their team's reward and the done flag, and an observation
         that only carries 'success'."""
-        self._submit(actions, messages)
+        self._submit(actions, messages, skip_valid_action_check)
         st = self._state()
         rewards = self.get_rewards()
         agents = list(dict.fromkeys(list((actions or {}).keys()) + self.active_agents))
-        obs = {}
-        for a in agents:
-            obs[a] = self.get_observation(a) if a.startswith('blue') else {'success': 'UNKNOWN'}
+        obs = self._all_observations(st, agents)
         team = lambda a: 'Blue' if a.startswith('blue') else ('Red' if a.startswith('red') else 'Green')   # noqa: E731
         return obs, {a: dict(rewards[team(a)]) for a in agents}, {a: bool(st.raw['done']) for a in agents}, {}
 
     def step(self, agent=None, action=None, messages=None, skip_valid_action_check=False):
         """env.py:125-161: the single-agent step of older challenges; returns a Results-like object."""
-        self._submit({} if (agent is None or action is None) else {agent: action}, messages)
+        self._submit({} if (agent is None or action is None) else {agent: action}, messages, skip_valid_action_check)
         if agent is None:
             return Results(observation={})
         st = self._state()
         rew = self.get_rewards()['Blue' if agent.startswith('blue') else ('Red' if agent.startswith('red') else 'Green')]
-        return Results(observation=self.get_observation(agent) if agent.startswith('blue') else {'success': 'UNKNOWN'},
+        return Results(observation=self._all_observations(st, [agent])[agent],
                        done=bool(st.raw['done']), reward=round(sum(rew.values()), 1),
-                       action_space=self.get_action_space(agent) if agent.startswith('blue') else None,
-                       action=[st.last_action[agent]] if agent in st.last_action else None)
+                       action_space=self.get_action_space(agent),
+                       action=[st.last_action[agent]] if agent in st.last_action else [self._submitted.get(agent, A.Sleep())])
+
+    def _all_observations(self, st, agents):
+        """The dict observations of `agents` after the last step: blue from the end-of-turn Monitor's event log, red from the
+        engine's per-agent observation keys (true_state.red_observations), green 'success' / 'action' of its own action."""
+        from .true_state import blue_observations, red_observations, Ternary
+        out, blue, red = {}, None, None
+        for a in agents:
+            if a.startswith('blue'):
+                blue = blue if blue is not None else blue_observations(st)
+                out[a] = blue[a]
+            elif a.startswith('red'):
+                red = red if red is not None else red_observations(st)
+                out[a] = red[a]
+            else:
+                g = int(a.split('_')[-1])
+                sub = getattr(self, '_submitted', {}).get(a)
+                fail = (st.raw['green_fail'][g >> 5] >> (g & 31)) & 1 if 'green_fail' in st.raw else 0
+                if sub is not None:
+                    nm = getattr(sub, 'name', None) or type(sub).__name__
+                    out[a] = {'success': Ternary('UNKNOWN' if nm == 'Sleep' else ('FALSE' if fail else 'TRUE')),
+                              'action': sub if not (fail and nm not in ('GreenLocalWork', 'GreenAccessService')) else A.InvalidAction(action=sub)}
+                else:                       # a device-side green agent: only whether its action failed is kept (the reward reads nothing else)
+                    out[a] = {'success': Ternary('FALSE' if fail else 'UNKNOWN')}
+        return out
 
     def set_seed(self, seed):
         """env.py:316-325: a fresh Generator for all further randomness; the episode itself is untouched."""
@@ -242,6 +380,8 @@ class CybORG:
     def get_action_space(self, agent):
         """env.py:266-283 for a blue agent: the parameter dictionaries of its ActionSpace (Shared/ActionSpace.py:105-126) that
         the fixed-index wrappers are built from: the action classes, its subnets, and the known hostnames / addresses."""
+        if agent.startswith('red_agent_') or agent.startswith('green_agent_'):
+            return self._other_action_space(agent)
         if agent not in self.agents_blue:
             raise ValueError(f'Agent {agent} not in agent list {self.agents_blue}')
         b = self.agents_blue.index(agent)
@@ -258,6 +398,36 @@ class CybORG:
                 'username': {'root': True, 'user': True}, 'password': {},
                 'agent': {agent: True},
                 'hostname': {h: h in mine for h in ips}}
+
+    def _other_action_space(self, agent):
+        """ActionSpace.get_action_space (Shared/ActionSpace.py:105-126) of a red or green agent from the engine's ActionSpace bits
+        (RedAgent.as_ip / as_hn / as_subnet / known sessions): every address / hostname / subnet of the episode, True where known."""
+        from ipaddress import IPv4Network, IPv4Address
+        d = self._state().raw
+        cidr, ips = self.get_cidr_map(), self.get_ip_map()
+        k = int(agent.split('_')[-1])
+        bit = lambda words, h: bool((words[h >> 5] >> (h & 31)) & 1)      # noqa: E731
+        hid = {host_name(h['h']): h['h'] for h in d['hosts']}
+        if agent.startswith('red'):
+            ag = d['red'][k]
+            allowed = [['contractor_network_subnet'], ['restricted_zone_a_subnet'], ['operational_zone_a_subnet'], ['restricted_zone_b_subnet'],
+                       ['operational_zone_b_subnet'], ['public_access_zone_subnet', 'admin_network_subnet', 'office_network_subnet']][k]   # ESG.py:769-776
+            return {'action': {c: True for c in A.RED_ACTIONS}, 'allowed_subnets': allowed,
+                    'subnet': {IPv4Network(cidr[sn]): bool((ag['as_subnet'] >> i) & 1) for i, sn in enumerate(SUBNET_NAMES)},
+                    'ip_address': {IPv4Address(ips[n]): bit(ag['as_ip'], h) for n, h in hid.items()},
+                    'session': {sid: True for sid in ag['known_sessions']},
+                    'username': {}, 'password': {}, 'process': {}, 'port': {}, 'target_session': {sid: True for sid in ag['known_sessions']},
+                    'agent': {agent: True}, 'hostname': {n: bit(ag['as_hostname'], h) for n, h in hid.items()}}
+        gh = d['green_hosts'][k]
+        sn = gh // 17
+        policy = getattr(self.scenario_generator, 'green_policy', 0)
+        from .true_state import green_allowed_subnets
+        return {'action': {c: True for c in (A.GREEN_ACTIONS if policy != 1 else (A.Sleep,))},
+                'allowed_subnets': green_allowed_subnets(d['phase'], sn),
+                'subnet': {IPv4Network(cidr[SUBNET_NAMES[sn]]): True},
+                'ip_address': {IPv4Address(ips[n]): True for n, h in hid.items() if h // 17 == sn},
+                'session': {0: True}, 'username': {}, 'password': {}, 'process': {}, 'port': {}, 'target_session': {},
+                'agent': {agent: True}, 'hostname': {n: True for n, h in hid.items() if h // 17 == sn}}
 
     def get_agent_state(self, agent_name):
         """env.py:202-216: the true state restricted to what the scenario's INFO_DICT lists for the agent ('True' = all)."""
@@ -290,8 +460,8 @@ class CybORG:
         its zone with events, 'Interface' / 'Processes' (connections with addresses and ports, pids) / 'System info', as the
         end-of-turn Monitor reports them (true_state.blue_observations; exact against the reference for Sleep / Monitor /
         Remove / Restore / Block / Allow steps)."""
-        from .true_state import decode, blue_observations
-        return blue_observations(decode(self.vec.true_state_json(0)))[agent]
+        from .true_state import decode
+        return self._all_observations(decode(self.vec.true_state_json(0)), [agent])[agent]
 
     def get_last_action(self, agent):
         """env.py:300-314: the actions of `agent` (blue_agent_b / red_agent_r) that resolved in the last step -- a list, as the
@@ -395,32 +565,22 @@ class BlueFixedActionWrapper:
 
     def step(self, actions=None, messages=None, **kwargs):
         action_dict = {} if actions is None else actions
-        acts = np.full((1, 5), -1, np.int32)
+        acts = [-1] * 5
+        others = {}
         for a, v in action_dict.items():
-            b = self.possible_agents.index(a)
-            n = 242 if b == 4 else 82
-            labels = self._action_space[a]['labels']
-            # an index into the agent's action list (Python list semantics: negative counts from the end, out of range raises
-            # IndexError), or an action object, which the reference forwards as it is (BlueFixedActionWrapper.py:142-148)
-            v = A.action_index(v, labels)
-            if v >= A.BLUE_RAW_ACTION:                      # an action object naming a zone router: (type, host id) code
-                acts[0, b] = v
+            if a not in self.possible_agents:
+                # an action object for a red or green agent: the reference's wrapper forwards it to parallel_step as it is
+                # (BlueFixedActionWrapper.py:142-148 maps ints and passes Action objects through)
+                others[a] = v
                 continue
-            v = range(len(labels))[v]
-            # a padded slot ('[Padding] Sleep') is an explicit Sleep() submitted by the agent (BlueFixedActionWrapper.py:142-148,
-            # 320-332) -- never -1, which means "no action submitted" and hands the agent to the scenario's built-in blue policy
-            acts[0, b] = v if v < n else labels.index('Sleep')
-        messages = {} if messages is None else messages
-        msg = np.zeros((1, 5, MESSAGE_LENGTH), np.uint8)
-        for b, a in enumerate(self.possible_agents):
-            m = np.asarray(messages.get(a, EMPTY_MESSAGE)).astype(bool)
-            assert m.shape == (MESSAGE_LENGTH,), \
-                f'{a} attempting to send message {m} that is not in the message space MultiBinary({MESSAGE_LENGTH})'
-            msg[0, b] = m
-        obs, rew, done, vinfo = self.env.vec.step(acts, msg)
+            # an index into the agent's action list (Python list semantics: negative counts from the end, out of range raises
+            # IndexError), or an action object, which the reference forwards as it is (BlueFixedActionWrapper.py:142-148).  A padded
+            # slot ('[Padding] Sleep') is an explicit Sleep() submitted by the agent (:320-332) -- never -1, which means "no action
+            # submitted" and hands the agent to the scenario's blue policy
+            acts[self.possible_agents.index(a)] = self.env._blue_code(a, v, self._action_space[a]['labels'])
         # State.check_next_phase_on_update_step (State.py:539-540) raises ValueError past the last step; any other engine flag
         # (a container bound, a path the reference would crash on) raises CC4EngineError: never a silently different result
-        raise_on_engine_error(vinfo['err'])
+        obs, rew, done = self.env._submit(others, messages, kwargs.get('skip_valid_action_check', False), blue_codes=acts)
         d = bool(done[0])
         ob = split_obs(obs)
         observations = {a: ob[b][0].astype(np.int64) for b, a in enumerate(self.possible_agents)}

@@ -16,6 +16,14 @@ step path is one of four methods on it.  PhiloxProxy
     as csrc/cc4_rng.h restates them for this mode: bounded integers = buffered Lemire on 32-bit words (a one-option range
     draws nothing), choice(p) = cdf.searchsorted(random(), 'right'), random() = one 32-bit word * 2^-32 (every threshold on
     the path is a multiple of 1/100 or 1/4; cc4_rng.h rng_random), choice(replace=False) of one = one bounded draw.
+  * r04, the SCENARIO GENERATION as well (arm(..., generation=True) before CybORG(...) is built): create_scenario and
+    State.__init__ draw from the engine's generation streams (cc4_engine.h env_reset_counter_mode), again told apart by call
+    site -- _generate_subnet / _generate_hosts / _generate_blue_agents / _generate_red_agents draw from the main reset stream
+    (ST_RESET) in the order they run; everything under _generate_linux_host(hostname, ...) from that host's stream
+    (ST_GEN_HOST + host id), except the second and later iterations of _generate_pid's retry loop, which take the host's
+    re-draw stream (ST_GEN_REDRAW + host id); Host.create_pid under State.__init__ from ST_GEN_SESS + host id.  All of them
+    with the reset step word 0xFFFFFFFF and the episode word the engine bumps at every reset: begin_reset() before
+    CybORG(...) and before every reset().
   * The two draws that exist only for numpy-stream parity are not made in the counter mode and are not
     served from any stream here either: the action-order shuffle (SimulationController.py:418: the order is never used) leaves
     the list alone, Host.get_ephemeral_port (Host.py:175-187: the value is unobservable on this path) gets ports from a
@@ -27,6 +35,27 @@ import numpy as np
 M32 = 0xFFFFFFFF
 ST_BLUE_EXE, ST_GREEN_POL, ST_GREEN_EXE, ST_GREEN_PHISH = 0x100, 0x200, 0x300, 0x400
 ST_RED_POL, ST_RED_EXE, ST_RED_RSC, ST_BLUE_POL = 0x500, 0x600, 0x700, 0xB00
+ST_RESET, ST_GEN_HOST, ST_GEN_REDRAW, ST_GEN_SESS = 0x0, 0x800, 0x900, 0xA00
+RESET_STEP_WORD = 0xFFFFFFFF      # the step word of every generation stream (cc4_rng.h rng_begin_episode)
+GEN_SUBNETS = ('restricted_zone_a_subnet', 'operational_zone_a_subnet', 'restricted_zone_b_subnet', 'operational_zone_b_subnet',
+               'contractor_network_subnet', 'public_access_zone_subnet', 'admin_network_subnet', 'office_network_subnet', 'internet_subnet')
+
+
+def gen_host_index(hostname):
+    """hostname -> the engine's host id (subnet * 17 + slot; csrc/cc4_state.h)."""
+    hostname = str(hostname)
+    if hostname == 'root_internet_host_0':
+        return 136
+    for s, sn in enumerate(GEN_SUBNETS):
+        if hostname.startswith(sn + '_'):
+            rest = hostname[len(sn) + 1:]
+            if rest == 'router':
+                return s * 17
+            if rest.startswith('user_host_'):
+                return s * 17 + 1 + int(rest[len('user_host_'):])
+            if rest.startswith('server_host_'):
+                return s * 17 + 11 + int(rest[len('server_host_'):])
+    raise ValueError(hostname)
 
 
 def philox4x32_10(c, k0, k1):
@@ -57,10 +86,21 @@ class PhiloxProxy:
         self._action_cls = None
 
     # ---- life cycle
-    def arm(self, action_base_class):
-        """From now on: counter streams.  action_base_class: CybORG.Simulator.Actions.Action (to recognise executing actions)."""
+    def arm(self, action_base_class, generation=False):
+        """From now on: counter streams.  action_base_class: CybORG.Simulator.Actions.Action (to recognise executing actions).
+        generation: the scenario generation draws from the counter streams too (begin_reset() before every CybORG(...) / reset())."""
         self._action_cls = action_base_class
         self.armed = True
+        if generation:
+            self.episode = 0                  # rng_seed leaves the episode word 0; every reset bumps it (rng_begin_episode)
+
+    def begin_reset(self):
+        """Call before CybORG(...) is constructed and before every reset(): the engine's reset bumps the episode word and draws with
+        the reset step word."""
+        self.episode += 1
+        self.step = RESET_STEP_WORD
+        self._words.clear()
+        self._blocks.clear()
 
     def begin_step(self, step):
         """Call before every CybORG step with the step number the engine's row holds (EnvState.step_count)."""
@@ -120,6 +160,23 @@ class PhiloxProxy:
                 return 'blue_pol', ST_BLUE_POL + idx
         if 'sort_action_order' in fn_names:
             return 'shuffle', None
+        # ---- scenario generation (create_scenario, State.__init__)
+        if '_generate_linux_host' in fn_names:
+            f = sys._getframe(2)
+            host, redraw = None, False
+            while f is not None:
+                if f.f_code.co_name == '_generate_linux_host':
+                    host = gen_host_index(f.f_locals['hostname'])
+                elif f.f_code.co_name == '_generate_pid':
+                    redraw = 'pid' in f.f_locals          # the loop has been round once already: this is a retry
+                f = f.f_back
+            return ('gen_redraw', ST_GEN_REDRAW + host) if redraw else ('gen_host', ST_GEN_HOST + host)
+        if fn_names[0] == 'create_pid' and 'add_session' in fn_names:
+            host_obj = sys._getframe(2).f_locals['self']
+            return 'gen_sess', ST_GEN_SESS + gen_host_index(host_obj.hostname)
+        for nm in ('_generate_subnet', '_generate_hosts', '_generate_blue_agents', '_generate_red_agents'):
+            if nm in fn_names:
+                return 'gen_main', ST_RESET
         raise RuntimeError('PhiloxProxy: draw from an unrecognised call site: ' + ' <- '.join(fn_names[:8]))
 
     # ---- words of a stream (cc4_rng.h rng_next32 in mode 1: the four words of block 0, then of block 1, ...)

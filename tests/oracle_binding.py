@@ -62,7 +62,7 @@ class OracleVecEnv:
     def __init__(self, num_envs, steps=500, rng_mode=0, autoreset=False, device_id=0, red_policy=0, green_policy=0, topology_seed=0,
                  strict=True, blue_policy=0):
         self.lib = load()
-        self.policy = (red_policy & 3) | (0x10 if green_policy else 0) | (0x20 if blue_policy else 0)
+        self.policy = (red_policy & 3) | (0x10 if green_policy else 0) | (0x40 if green_policy == 2 else 0) | (0x20 if blue_policy else 0)
         self.num_envs = num_envs
         self.steps = steps
         self.rng_mode = rng_mode

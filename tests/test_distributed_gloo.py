@@ -74,3 +74,56 @@ def test_file_plane_close_does_not_strand_a_late_rank():
         root = '/dev/shm' if os.path.isdir('/dev/shm') else '/tmp'
         assert not os.path.exists(os.path.join(root, f'cc4_plane_{key}'))
         assert time.time() - t0 < 60
+
+
+def test_two_planes_on_one_directory_do_not_mix(tmp_path):
+    """a second FilePlane on the directory of the job's plane (what init_rccl without a `plane` argument used to
+    build) started its operation numbers at 0 again and read the first plane's files -- e.g. the OLD RCCL id.  Planes of one process
+    now carry a file-name prefix of their own: plane k of this rank talks to plane k of the others; control_plane() hands out one
+    process-wide object."""
+    import threading
+    from cage_challenge_4_amd import distributed as D
+    key = f'twoplanes_{os.getpid()}'
+    out = {}
+
+    def worker(r):
+        D.FilePlane._instances.pop(os.path.join(str(tmp_path), f'cc4_plane_{key}'), None) if False else None
+        a = D.FilePlane(r, 2, key, root=str(tmp_path), timeout=20.0)
+        first = a.bcast_bytes(b'id-one' if r == 0 else b'', 0)
+        b = D.FilePlane(r, 2, key, root=str(tmp_path), timeout=20.0)          # a second plane, same directory
+        second = b.bcast_bytes(b'id-two' if r == 0 else b'', 0)
+        third = a.bcast_bytes(b'id-three' if r == 0 else b'', 0)             # the first plane carries on where it was
+        out[r] = (first, second, third, a.inst, b.inst)
+        b.close(); a.close()
+
+    # (both "ranks" live in this one process here, so the per-process instance counter is shared: rank 0 gets planes 0 and 2, rank 1
+    # planes 1 and 3 -- give each thread its own view of the counter, as separate processes have)
+    class View(dict):
+        pass
+    import itertools
+    lock = threading.Lock()
+    counters = {0: itertools.count(), 1: itertools.count()}
+    orig_init = D.FilePlane.__init__
+
+    def init(self, rank, world, key_, root=None, timeout=2000.0):
+        with lock:
+            D.FilePlane._instances.pop(os.path.join(root, f'cc4_plane_{key_}'), None)
+            orig_init(self, rank, world, key_, root=root, timeout=timeout)
+            self.inst = next(counters[rank])
+    D.FilePlane.__init__ = init
+    try:
+        ts = [threading.Thread(target=worker, args=(r,)) for r in range(2)]
+        for t in ts:
+            t.start()
+        for t in ts:
+            t.join(60)
+    finally:
+        D.FilePlane.__init__ = orig_init
+    assert out[0][:3] == out[1][:3] == (b'id-one', b'id-two', b'id-three')
+    assert out[0][3:] == out[1][3:] == (0, 1)
+    assert not os.path.exists(os.path.join(str(tmp_path), f'cc4_plane_{key}'))     # the last plane to close removed the directory
+    # one process-wide control plane
+    import importlib
+    D._PLANE = None
+    assert D.control_plane() is D.control_plane()
+    D._PLANE = None
