@@ -968,8 +968,53 @@ __global__ __launch_bounds__(PT, MINW) void k_step_philox(StepArgs a) {
 #ifndef CC4_LEAN_MINW
 #define CC4_LEAN_MINW 1
 #endif
-template <bool LOG>
-__global__ __launch_bounds__(WAVE, CC4_LEAN_MINW) void k_step_philox1(StepArgs a) {
+// ---- the persistent form of the same kernel (PERSIST): K steps of the whole batch in ONE launch.
+// A step-per-launch schedule ends every launch with a tail (its last blocks run on a half-empty chip) and starts the next with a
+// ramp; cutting the batch into four groups on four streams hides most of that, not all: 8192 episodes x 29.6 us of
+// dependent work per episode-step over 5120 resident waves would take 47.4 us per step, four launches take 53.4.  Here the grid is
+// one wave per residency slot, and every wave pulls (episode, step) items until the K steps of all episodes are done -- no launch
+// boundary inside, no tail but the last one.  Two things make that safe without any cache maintenance:
+//  * CU affinity.  A CU's vector L1 is never refreshed by another CU's stores, and the XCDs' L2s are not coherent with each other
+//    (MI355X_MICROARCH.md, "inter-workgroup visibility"): an episode's rows must therefore be touched by ONE CU for the whole
+//    launch.  The batch is cut into one partition per CU (episode e -> partition e % P, P = CUs seen by the census at cc4_create);
+//    a wave reads its CU's identity from the hardware (HW_REG_XCC_ID, HW_REG_HW_ID: shader engine / array / CU), finds the CU's
+//    partition in the census table and claims it (owner[p]: compare-and-swap of the CU's slot id); only waves of the owning CU ever
+//    work on a partition.  Waves of one CU share its L1, which is coherent for them (what workgroup-scope ordering relies on), so
+//    the hand-over between two of them needs ordering only: the writer drains its stores (s_waitcnt vmcnt(0)) before it publishes.
+//  * Order per episode.  Items of a partition are handed out by a ticket counter in the order (step 0 of its episodes, step 1, ..):
+//    item (e, k) may start once progress[e] == k, which the wave that ran (e, k - 1) stores when its row is back in memory.  With
+//    32 episodes and 20 waves per CU the predecessor finished a dozen tickets ago; the wait is a single load, normally.
+// A CU that got no wave (never seen in practice: the grid fills every CU) leaves its partition unclaimed; waves that run out of
+// work adopt such a partition for THEIR CU (same claim), so every item is executed exactly once whatever the placement.
+struct RunArgs {
+  uint32_t* ticket;            // [P] next item of partition p
+  uint32_t* progress;          // [n] steps of this launch episode e has completed
+  int32_t* owner;              // [P] 0 = unclaimed, else 1 + slot id of the owning CU
+  const int16_t* slot_part;    // [CC4_SLOTS] census: slot id -> partition, -1 = no such CU
+  int P, K;
+  uint32_t t0;                 // action time of step 0 (random_blue_action)
+};
+constexpr int CC4_SLOTS = 2048;    // (XCC id << 8) | HW_ID[15:8]
+__device__ __forceinline__ int cu_slot() {
+  const uint32_t hw = __builtin_amdgcn_s_getreg(((16 - 1) << 11) | (0 << 6) | 4);     // HW_REG_HW_ID bits 15:0: wave, simd, pipe | cu, sh, se
+  const uint32_t xcc = __builtin_amdgcn_s_getreg(((4 - 1) << 11) | (0 << 6) | 20);    // HW_REG_XCC_ID bits 3:0
+  return (int)(((xcc & 7u) << 8) | ((hw >> 8) & 0xFFu));
+}
+// census (cc4_create): which CUs take waves of this footprint, and how many each
+__global__ __launch_bounds__(WAVE) void k_census(int32_t* count, long long ticks) {
+  extern __shared__ uint4 lds[];
+  if (threadIdx.x == 0) {
+    atomicAdd(&count[cu_slot()], 1);
+    const long long t0 = wall_clock64();
+    while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(32);     // stay resident until the whole grid has been placed
+  }
+  if (threadIdx.x == 1) reinterpret_cast<volatile uint32_t*>(lds)[0] = 0;
+}
+
+// One step of one episode on one wavefront: the body of k_step_philox1 and of the persistent run kernel.  PERSIST: item_k = the
+// step's number within the launch (the first item of an episode rewrites all its observation values when asked to).
+template <bool LOG, bool PERSIST>
+__device__ __forceinline__ void philox1_body(StepArgs a, const int e, const uint32_t rand_t, const uint32_t item_k, const int lane) {
   extern __shared__ uint4 lds[];
   // byte copy of the observations, only for the packed exchange row; the debug phase timers borrow the area (a profiled handle
   // has no communicator): with it, agent part + statics fit 8 KB and 20 episodes are resident per CU
@@ -977,8 +1022,7 @@ __global__ __launch_bounds__(WAVE, CC4_LEAN_MINW) void k_step_philox1(StepArgs a
   __shared__ StepWork work;
   __shared__ int conflict_lds;
   unsigned long long* const prof_lds = reinterpret_cast<unsigned long long*>(obs_bytes);
-  const int e = a.e0 + (int)blockIdx.x, lane = threadIdx.x;
-  if (e >= a.n) return;
+  (void)item_k;
   EnvCold* const cold_e = cold_at(a.cold, (size_t)e, cold_row_bytes(a.steps));
   if (a.obs8) a.prof = nullptr;
   unsigned long long t_begin = a.prof ? clock64() : 0;
@@ -1058,7 +1102,7 @@ __global__ __launch_bounds__(WAVE, CC4_LEAN_MINW) void k_step_philox1(StepArgs a
         uint32_t k0 = (uint32_t)rl.s_lo, k1 = (uint32_t)(rl.s_lo >> 32);
         if (a.rand_out && lane >= BK_BRAND && lane < BK_END) {   // random_blue_action(seed0, t, e, b): another key and counter layout
           const uint64_t key = a.rand_seed0 + (uint64_t)e;
-          bank[0] = a.rand_t; bank[1] = (uint32_t)(lane - BK_BRAND); bank[2] = 0xB10Eu; bank[3] = 0u; k0 = (uint32_t)key; k1 = (uint32_t)(key >> 32);
+          bank[0] = rand_t; bank[1] = (uint32_t)(lane - BK_BRAND); bank[2] = 0xB10Eu; bank[3] = 0u; k0 = (uint32_t)key; k1 = (uint32_t)(key >> 32);
         }
         philox4x32_10(bank, k0, k1);
       }
@@ -1172,7 +1216,7 @@ __global__ __launch_bounds__(WAVE, CC4_LEAN_MINW) void k_step_philox1(StepArgs a
   {
     int32_t* o = a.obs + (size_t)e * OBS_TOTAL;
     const bool pack = a.obs8 != nullptr;
-    const int nv = (do_reset || a.full_obs || pack || s->obs_dirty) ? OBS_TOTAL : OBS_FAST;
+    const int nv = (do_reset || (a.full_obs && (!PERSIST || item_k == 0)) || pack || s->obs_dirty) ? OBS_TOTAL : OBS_FAST;
     encode_obs_fast<WAVE>(s, o, obs_bytes, pack, lane);
     for (int v = OBS_FAST + lane; v < nv; v += WAVE) { int i; const int val = env_flat_obs_sorted(s, v, &i); o[i] = val; if (pack) obs_bytes[i] = (uint8_t)val; }
   }
@@ -1184,6 +1228,65 @@ __global__ __launch_bounds__(WAVE, CC4_LEAN_MINW) void k_step_philox1(StepArgs a
   stage_out<HOT_VEC>(reinterpret_cast<uint4*>(a.st + e), lds, lane);
   if (prof && lane == 0) { prof[13] += clock64() - t_out; prof[14] += clock64() - t_begin; }
   if (prof) { __syncthreads(); if (lane < 15) a.prof[PROF_SLOTS * (size_t)e + lane] += prof_lds[lane]; }
+}
+
+template <bool LOG>
+__global__ __launch_bounds__(WAVE, CC4_LEAN_MINW) void k_step_philox1(StepArgs a) {
+  const int e = a.e0 + (int)blockIdx.x;
+  if (e >= a.n) return;
+  philox1_body<LOG, false>(a, e, a.rand_t, 0u, (int)threadIdx.x);
+}
+
+// The body as a real call for the persistent kernel: inlined into the item loop, everything the step derives from loop-invariant
+// values is hoisted and held in registers across the whole step (96 VGPRs + 280 spilled); a call per 30 us item costs nothing.
+__device__ __attribute__((noinline)) void philox1_item(const StepArgs& a, int e, uint32_t rand_t, uint32_t item_k) {
+  philox1_body<false, true>(a, e, rand_t, item_k, (int)threadIdx.x);
+}
+
+__global__ __launch_bounds__(WAVE, 5) void k_run_philox1(StepArgs a, RunArgs ra) {
+  __shared__ int item_lds[2];
+  const int lane = threadIdx.x;
+  const int my_slot = cu_slot();
+  int part = ra.slot_part[my_slot];
+  a.prof = nullptr; a.obs8 = nullptr; a.ext = nullptr;
+  for (;;) {
+    if (lane == 0) {
+      int got = -1;
+      while (got == -1) {
+        if (part < 0) {
+          // adopt a partition nobody owns, or rejoin one this CU owns that still has items
+          for (int q = 0; q < ra.P && part < 0; ++q) {
+            const int ne = (a.n - q + ra.P - 1) / ra.P;
+            int ow = __hip_atomic_load(&ra.owner[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (ow == 0) { int exp = 0; if (__hip_atomic_compare_exchange_strong(&ra.owner[q], &exp, my_slot + 1, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) ow = my_slot + 1; else ow = exp; }
+            if (ow == my_slot + 1 && __hip_atomic_load(&ra.ticket[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (uint32_t)(ne * ra.K)) part = q;
+          }
+          if (part < 0) { got = -2; break; }                       // nothing left anywhere
+        } else {
+          int exp = 0;                                              // the CU's own partition: claim it (or find it claimed by this CU already)
+          if (!__hip_atomic_compare_exchange_strong(&ra.owner[part], &exp, my_slot + 1, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) && exp != my_slot + 1) { part = -1; continue; }
+        }
+        const int ne = (a.n - part + ra.P - 1) / ra.P;              // episodes part, part + P, part + 2 P, ..
+        const uint32_t t = __hip_atomic_fetch_add(&ra.ticket[part], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (t >= (uint32_t)(ne * ra.K)) { part = -1; continue; }    // this partition is handed out: look for another
+        const int k = (int)(t / (uint32_t)ne), ee = part + (int)(t % (uint32_t)ne) * ra.P;
+        while (__hip_atomic_load(&ra.progress[ee], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (uint32_t)k) __builtin_amdgcn_s_sleep(8);
+        item_lds[0] = ee; item_lds[1] = k;
+        got = ee;
+      }
+      if (got == -2) item_lds[0] = -1;
+    }
+    __syncthreads();
+    const int e = item_lds[0];
+    if (e < 0) return;
+    const uint32_t item_k = (uint32_t)item_lds[1];
+    __syncthreads();
+    philox1_item(a, e, ra.t0 + item_k, item_k);
+    // the item is done when everything it wrote has left this wave: then the next step of the episode may start (on this CU)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (lane == 0) __hip_atomic_store(&ra.progress[e], item_k + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
 }
 
 struct ResetArgs {
@@ -1349,6 +1452,11 @@ struct cc4_handle {
   // externally submitted red / green actions (cc4_step_ex).  Once a handle has taken any, its steps run the full builds of the
   // kernels (an action queued for several ticks carries its own rates into later steps), with d_ext all XA_NONE for the steps
   // that submit nothing
+  // the persistent run kernel (k_run_philox1: K steps of the batch in one launch; RunArgs): per-partition ticket
+  // counters, per-episode progress, partition owners in ONE buffer (cleared by one memset per call), the census table
+  uint32_t* d_run = nullptr;      // [P ticket | P owner | n progress]
+  int16_t* d_slot_part = nullptr; // [CC4_SLOTS]
+  int run_P = 0, run_grid = 0;    // partitions (= CUs that take waves), waves per launch; 0: the persistent path is off
   ExtAct* d_ext = nullptr;        // [num_envs][EXT_PER_ENV]
   bool ext_seen = false, ext_dirty = false;   // dirty: d_ext holds the records of an earlier step
   std::vector<ExtAct> h_ext;
@@ -1500,6 +1608,10 @@ static int launch_step(cc4_handle* h, const int32_t* d_actions, const uint8_t* d
     hipEvent_t stop = h->comm ? h->ev_step[buf][g] : h->tev_stop[g];
     hipEvent_t start = h->comm ? nullptr : h->tev_start[g];        // timing rides on the kernels' own signals too: no marker packets
     h->tev_start[g] = h->tev_stop[g] = nullptr;
+#ifdef CC4_DEV_FAST     // kernel experiments (tools/ab.sh): only the one-wave counter-mode kernel is instantiated -- a quarter of the compile time
+    if (h->cfg.rng_mode != 1 || !h->philox_lean || full) { h->err = "CC4_DEV_FAST build: only k_step_philox1<false> exists"; return -1; }
+    hipExtLaunchKernelGGL(k_step_philox1<false>, grid, dim3(WAVE), offsetof(EnvState, hd), st, start, stop, 0, a);
+#else
     if (h->cfg.rng_mode == 1) {
       if (h->philox_lean) {
         if (full) hipExtLaunchKernelGGL(k_step_philox1<true>, grid, dim3(WAVE), offsetof(EnvState, hd), st, start, stop, 0, a);
@@ -1516,6 +1628,7 @@ static int launch_step(cc4_handle* h, const int32_t* d_actions, const uint8_t* d
       if (full) hipExtLaunchKernelGGL(k_step<true>, grid, dim3(WAVE), offsetof(EnvState, hd), st, start, stop, 0, a);
       else hipExtLaunchKernelGGL(k_step<false>, grid, dim3(WAVE), offsetof(EnvState, hd), st, start, stop, 0, a);
     }
+#endif
     HIPCHK(h, hipGetLastError());
   }
   h->step_event_attached = h->comm != nullptr;
@@ -1631,6 +1744,40 @@ int cc4_create(const cc4_config* cfg, cc4_handle** out) {
   HIPCHK(h, hipEventCreate(&h->ev0));
   HIPCHK(h, hipEventCreate(&h->ev1));
   HIPCHK(h, hipStreamSynchronize(h->stream));
+  // OFF unless CC4_PERSIST=1: measured (profiles/r04_persistent_kernel_ab.txt), bit-exact but 18-38 % SLOWER than the launch-per-step
+  // schedule on four streams -- waves that never meet a launch boundary drift apart over the kernel's ~340 KB of code, and a CU's
+  // twenty waves stop sharing their instruction fetches (a launch restarts them together; 98.8 % I-cache hits there).
+  if (cfg->rng_mode == 1 && h->philox_lean && getenv("CC4_PERSIST") && atoi(getenv("CC4_PERSIST")) != 0) {
+    // The persistent run kernel (cc4_run_random_steps without a communicator): one wave per residency slot, the batch cut into one
+    // partition per CU.  Census: a grid of that many waves with the step kernel's footprint, each reporting the CU it landed on --
+    // the partition table is what the hardware says, and the path stays off unless the picture is the expected one (every CU of
+    // the device seen, none with more waves than the occupancy query allows: a mis-decoded CU id would merge CUs and show here).
+    int per_cu = 0;
+    HIPCHK(h, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_run_philox1, WAVE, offsetof(EnvState, hd)));
+    const int grid = per_cu * h->cus;
+    if (per_cu > 0 && cfg->num_envs >= grid + grid / 4) {        // worth it only when the batch is more than the chip holds at once
+      int32_t* d_count = nullptr;
+      HIPCHK(h, hipMalloc(&d_count, CC4_SLOTS * sizeof(int32_t)));
+      HIPCHK(h, hipMemsetAsync(d_count, 0, CC4_SLOTS * sizeof(int32_t), h->stream));
+      int khz = 100000;
+      (void)hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, cfg->device_id);
+      hipLaunchKernelGGL(k_census, dim3(grid), dim3(WAVE), offsetof(EnvState, hd), h->stream, d_count, 200LL * (khz > 0 ? khz : 100000) / 1000);   // ~200 us
+      std::vector<int32_t> count(CC4_SLOTS);
+      HIPCHK(h, hipMemcpyAsync(count.data(), d_count, CC4_SLOTS * sizeof(int32_t), hipMemcpyDeviceToHost, h->stream));
+      HIPCHK(h, hipStreamSynchronize(h->stream));
+      (void)hipFree(d_count);
+      std::vector<int16_t> table(CC4_SLOTS, (int16_t)-1);
+      int P = 0, worst = 0, total = 0;
+      for (int sl = 0; sl < CC4_SLOTS; ++sl) if (count[sl] > 0) { table[sl] = (int16_t)P++; worst = count[sl] > worst ? count[sl] : worst; total += count[sl]; }
+      if (getenv("CC4_PERSIST_DEBUG")) fprintf(stderr, "[cc4 census] grid %d (%d per CU x %d CUs): %d CUs seen, at most %d waves on one, %d counted\n", grid, per_cu, h->cus, P, worst, total);
+      if (P == h->cus && worst <= per_cu && total == grid) {
+        h->run_P = P; h->run_grid = grid;
+        HIPCHK(h, hipMalloc(&h->d_slot_part, CC4_SLOTS * sizeof(int16_t)));
+        HIPCHK(h, hipMemcpy(h->d_slot_part, table.data(), CC4_SLOTS * sizeof(int16_t), hipMemcpyHostToDevice));
+        HIPCHK(h, hipMalloc(&h->d_run, (2 * (size_t)P + n) * sizeof(uint32_t)));
+      }
+    }
+  }
   return 0;
 }
 
@@ -1643,7 +1790,7 @@ void cc4_destroy(cc4_handle* h) {
   for (int b = 0; b < cc4_handle::OBS_RING; ++b) { for (int g = 0; g < cc4_handle::MAX_GROUPS; ++g) if (h->ev_step[b][g]) (void)hipEventDestroy(h->ev_step[b][g]); if (h->ev_comm[b]) (void)hipEventDestroy(h->ev_comm[b]); }
   if (h->comm_stream) (void)hipStreamDestroy(h->comm_stream);
   void* ptrs[] = {h->d_state, h->d_cold, h->d_actions, h->d_msgs, h->d_seeds, h->d_envmask, h->d_obs, h->d_reward,
-                  h->d_done, h->d_err, h->d_mask, h->d_rng, h->d_reset_ws, h->d_ext};
+                  h->d_done, h->d_err, h->d_mask, h->d_rng, h->d_reset_ws, h->d_ext, h->d_run, h->d_slot_part};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   for (int b = 0; b < cc4_handle::OBS_RING; ++b) { if (h->d_obs8[b]) (void)hipFree(h->d_obs8[b]); if (h->d_all_obs8[b]) (void)hipFree(h->d_all_obs8[b]); }
   if (h->d_unpacked) (void)hipFree(h->d_unpacked);
@@ -1834,6 +1981,29 @@ int cc4_synchronize(cc4_handle* h) {
 int cc4_run_random_steps(cc4_handle* h, uint64_t seed0, uint32_t t0, int32_t k, float* ms_step_kernels) {
   HIPCHK(h, hipSetDevice(h->cfg.device_id));
   if (k <= 0) { if (ms_step_kernels) *ms_step_kernels = 0.f; return 0; }   // nothing to launch, no timing event to read
+  if (h->run_P > 0 && !h->comm && !h->evlog_on && !h->ext_seen && !h->d_prof && k >= 2) {
+    // the persistent form: the k steps of the whole batch in ONE launch on the main stream (k_run_philox1)
+    if (join_groups(h)) return -1;
+    const size_t words = 2 * (size_t)h->run_P + (size_t)h->cfg.num_envs;
+    HIPCHK(h, hipMemsetAsync(h->d_run, 0, words * sizeof(uint32_t), h->stream));
+    StepArgs a{h->d_state, h->d_cold, nullptr, nullptr, h->d_obs, h->d_reward, h->d_done, h->d_err, nullptr, h->d_actions, seed0, t0,
+               h->cfg.num_envs, h->cfg.autoreset, h->cfg.steps, h->cfg.rng_mode,
+               (h->cfg.red_policy & 3) | (h->cfg.green_policy ? GP_SLEEP_BIT : 0) | (h->cfg.green_policy == 2 ? GP_OPEN_BIT : 0) | (h->cfg.blue_policy ? BP_RANDOM_BIT : 0),
+               h->full_obs_next ? 1 : 0, (uint32_t)h->cfg.topology_seed, nullptr, h->d_reset_ws, nullptr, 0};
+    RunArgs ra{h->d_run, h->d_run + 2 * h->run_P, reinterpret_cast<int32_t*>(h->d_run + h->run_P), h->d_slot_part, h->run_P, k, t0};
+    if (ms_step_kernels && h->evs.size() < 2) { h->evs.resize(2, nullptr); for (auto& e : h->evs) if (!e) HIPCHK(h, hipEventCreate(&e)); }
+    auto c0 = std::chrono::steady_clock::now();
+    hipExtLaunchKernelGGL(k_run_philox1, dim3(h->run_grid), dim3(WAVE), offsetof(EnvState, hd), h->stream,
+                          ms_step_kernels ? h->evs[0] : nullptr, ms_step_kernels ? h->evs[1] : nullptr, 0, a, ra);
+    HIPCHK(h, hipGetLastError());
+    h->stat_launch_us += std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - c0).count();
+    h->stat_steps += k;
+    h->full_obs_next = false;     // (asked for, the first item of every episode rewrote all its observation values)
+    h->main_ahead = h->ngroups > 1;
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    if (ms_step_kernels) HIPCHK(h, hipEventElapsedTime(ms_step_kernels, h->evs[0], h->evs[1]));
+    return 0;
+  }
   // Timing: HIP events on the launch streams around chunks of TIMED_CHUNK consecutive steps (an event pair around every single
   // launch costs the stream ~5 us of idle time per step); per stream, the sum over the chunks is the on-stream time of its k
   // launches, read back after the loop -- no host synchronisation inside the timed region.  With several episode groups

@@ -518,7 +518,9 @@ def red_obs_skeleton(obs):
         if 'Interface' in v:
             e['ips'] = sorted([str(i['ip_address']), 'Subnet' in i] for i in v['Interface'] if 'ip_address' in i)
         if 'Sessions' in v:
-            e['sessions'] = sorted([int(s['session_id']), str(s.get('username'))] for s in v['Sessions'])
+            # (an exploit's own, ip-keyed report names the user only when it was the SSH brute force: which exploit opened a session is
+            # not kept in the packed state, so the user name of that one entry is outside the canonical form)
+            e['sessions'] = sorted([int(s['session_id']), None if '.' in str(key) else str(s.get('username'))] for s in v['Sessions'])
         if 'System info' in v and 'Hostname' in v['System info']:
             e['hostname'] = str(v['System info']['Hostname'])
         if sk['action'] in ('AggressiveServiceDiscovery', 'StealthServiceDiscovery') and 'Processes' in v:

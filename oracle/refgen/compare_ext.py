@@ -12,6 +12,7 @@ usage: python compare_ext.py <seed> [steps] [red: fsm|sleep|discovery|random] [g
 import sys, os, ctypes
 import numpy as np
 sys.path.insert(0, os.path.dirname(__file__))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..', '..'))
 import ref_shim  # noqa
 from ref_dump import dump, host_index, subnet_index
 from compare import lib, canon_ref, RED, GREEN
@@ -202,6 +203,7 @@ def run(seed, steps=200, red='fsm', green='enterprise', p_red=0.4, p_green=0.1, 
     buf = ctypes.create_string_buffer(1 << 20)
     import json
     n_sub = n_inv = 0
+    obs_soft = [0]
     for t in range(max_steps or steps):
         a = np.array([arng.integers(82), arng.integers(82), arng.integers(82), arng.integers(82), arng.integers(242)], np.int32)
         acts = {f'blue_agent_{b}': int(a[b]) for b in range(5)}
@@ -260,6 +262,22 @@ def run(seed, steps=200, red='fsm', green='enterprise', p_red=0.4, p_green=0.1, 
         jb = ctypes.create_string_buffer(need)
         lib.cc4o_true_state(H, 0, jb, need)
         ts = json.loads(jb.value.decode())
+        from cage_challenge_4_amd.true_state import decode, red_observations, red_obs_skeleton
+        mine_obs = red_observations(decode(ts))
+        for agent, (kind, k) in submitted.items():
+            if kind == 'red':          # the dict observation the agent got back, in the canonical form both sides can be put into
+                a_, b_ = red_obs_skeleton(mine_obs[agent]), red_obs_skeleton(env.get_observation(agent))
+                if a_ != b_:
+                    # Known limit of the rebuilt dict: an entry lists the sessions the agent holds on the host at the END of
+                    # the step (an exploit's own report: the session it opened); the reference's lists those its observations mentioned --
+                    # incl. one that a later action of the same step removed, or a session handed over by another agent's exploit.
+                    # Counted, not failed, when the session lists are the whole difference (1-2 per 2000 submitted actions).
+                    def strip(sk):
+                        return {**sk, 'hosts': {k: {kk: vv for kk, vv in v.items() if kk != 'sessions'} for k, v in sk['hosts'].items()}}
+                    if strip(a_) == strip(b_):
+                        obs_soft[0] += 1
+                    else:
+                        print(tag, agent, 'RED OBS SKELETON MISMATCH', acts[agent], '\n  mine:', json.dumps(a_, sort_keys=True), '\n  ref :', json.dumps(b_, sort_keys=True)); ok = False
         for agent, (kind, k) in submitted.items():
             n_sub += 1
             ro_ = env.get_observation(agent)
@@ -287,7 +305,7 @@ def run(seed, steps=200, red='fsm', green='enterprise', p_red=0.4, p_green=0.1, 
                     print(' red', r, ec.action.get(f'red_agent_{r}'))
             return t
     if verbose:
-        print('OK seed', seed, 'red', red, 'green', green, 'submitted', n_sub, 'invalid', n_inv)
+        print('OK seed', seed, 'red', red, 'green', green, 'submitted', n_sub, 'invalid', n_inv, 'red observations whose end-of-step session list differs', obs_soft[0])
     return None
 
 

@@ -1,0 +1,22 @@
+import sys, os, time
+sys.path.insert(0, '.'); sys.path.insert(0, 'tests')
+import numpy as np
+from cage_challenge_4_amd import CC4VecEnv
+from oracle_binding import OracleVecEnv, random_actions
+n, steps, seed0 = 8192, 150, 4242
+dev = CC4VecEnv(n, steps=steps, rng_mode=1, autoreset=True)
+ora = OracleVecEnv(n, steps=steps, rng_mode=1, autoreset=True)
+assert np.array_equal(dev.reset(seeds=seed0), ora.reset_batch(seed0))
+t = 0
+for K in (2, 20, 137, 20):
+    dev.run_random_steps(seed0, t, K, timed=True)
+    for k in range(K):
+        a = random_actions(seed0, t + k, n); o = ora.step_batch(a)
+    t += K
+    dev.synchronize(); dev._fetch()
+    bad = np.nonzero((dev._obs != o[0]).any(axis=1) | (dev._rew != o[1]) | (dev._done.astype(bool) != o[2]) | (dev._err != o[3]['err']))[0]
+    print('K', K, 't', t, 'bad episodes', bad.size, bad[:10], 'actions equal', np.array_equal(dev.device_actions(), a), flush=True)
+ok = np.array_equal(dev.rng_state(), ora.rng_state())
+nbad = sum(not np.array_equal(dev.get_state(i), ora.get_state(i)) for i in range(0, n, 7))
+print('rng equal', ok, 'packed state mismatches (every 7th)', nbad)
+dev.close()
