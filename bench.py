@@ -305,6 +305,9 @@ def main():
         t_end = args.warmup + len(secs) * args.steps        # launches so far; episodes regenerate on every (episode_steps)-th
         out['autoreset_launches_in_timed_regions'] = t_end // args.episode_steps - args.warmup // args.episode_steps
         out['launches_per_step'] = e.launches_per_step
+        # what cc4_run_random_steps launches: the step kernel once per step and group, or -- a batch the chip holds at once -- ONE launch
+        # of the multi-step kernel per timed region (k_run_philox: every block loops over the steps of its episode, the row stays in LDS)
+        out['run_kernel'] = e.run_kernel
         return out
 
     main_res = measure(env, lo, total_envs)
@@ -344,7 +347,9 @@ def main():
             k4 = e4.step_kernel
             e4.close()
             r4.update({'rng': args.rng, 'kernel': k4, 'unit': 'agent-env steps/s', 'total_envs': 1024,
-                       'note': 'BASELINE configs[1]: 1024 episodes on one GPU = the per-GPU share of the 8-GPU job (latency regime: 4 blocks per CU, one round)'})
+                       'note': 'BASELINE configs[1]: 1024 episodes on one GPU = the per-GPU share of the 8-GPU job (latency regime: 4 blocks per CU, one round); '
+                               'without the exchange a timed region is ONE launch of the multi-step kernel (run_kernel k_run_philox): the batch advances at the '
+                               'mean step time of its episodes, not at the slowest one\'s'})
             subs['envs_1024'] = r4
         if args.rng == 'philox':
             # BASELINE configs 2-4 vs 5: the same workload with ONE topology shared by all episodes (dynamics still keyed per
@@ -401,7 +406,7 @@ def main():
                          # 8 TB/s the memory system actually carried
                          'hbm_counter_frac': (traffic / (launch_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS) if traffic else None,
                          'traffic': traffic, 'traffic_source': traffic_src,
-                         'kernel': env.step_kernel, 'launch_ms': launch_ms, 'launches_per_step': lps,
+                         'kernel': env.step_kernel, 'run_kernel': main_res['run_kernel'], 'launch_ms': launch_ms, 'launches_per_step': lps,
                          'episodes_per_launch': n_local / lps,
                          'algorithmic_bytes_per_launch': bytes_per_env * n_local / lps,
                          'algorithmic_bytes_per_step': bytes_per_env * n_local,

@@ -686,8 +686,11 @@ __device__ __forceinline__ void dma_wait() { asm volatile("s_waitcnt vmcnt(0)" :
 #ifndef CC4_PHILOX_BIG_MINW
 #define CC4_PHILOX_BIG_MINW 7
 #endif
-template <bool LOG, int MINW>
-__global__ __launch_bounds__(PT, MINW) void k_step_philox(StepArgs a) {
+// one step of one episode on a block of four wavefronts: the body of k_step_philox and of its multi-step form k_run_philox
+// RUN (k_run_philox): the row stays in LDS from one step of the episode to the next -- run_flags bit 0: not the first step of the
+// launch (nothing is staged in), bit 1: the last one (the whole row goes back; before it, none of it)
+template <bool LOG, bool RUN = false>
+__device__ __forceinline__ void philox4_body(StepArgs a, const int run_flags = 0) {
   extern __shared__ uint4 lds[];
   __shared__ int conflict_lds;
   __shared__ alignas(16) uint32_t reset_ws[RESET_WS_WORDS];   // pid bitmaps of the scenario generation (autoreset); during a step: the green agents' pre-computed blocks
@@ -706,14 +709,16 @@ __global__ __launch_bounds__(PT, MINW) void k_step_philox(StepArgs a) {
   // the part outside the host table through registers (3 vectors per thread), then the host-table chunks by DMA
   constexpr int NA = HD_V0 + ROW_VEC - HD_V1;   // indexed 0..NA-1: [0,HD_V0) then [HD_V1,ROW_VEC)
   constexpr int NA_U = (NA + PT - 1) / PT;
-  {
-    uint4 va[NA_U];
+  if (!RUN || !(run_flags & 1)) {
+    {
+      uint4 va[NA_U];
 #pragma unroll
-    for (int u = 0; u < NA_U; ++u) { int k = tid + u * PT; k = k < NA ? k : NA - 1; int i = k < HD_V0 ? k : k - HD_V0 + HD_V1; va[u] = src[i]; }
+      for (int u = 0; u < NA_U; ++u) { int k = tid + u * PT; k = k < NA ? k : NA - 1; int i = k < HD_V0 ? k : k - HD_V0 + HD_V1; va[u] = src[i]; }
 #pragma unroll
-    for (int u = 0; u < NA_U; ++u) { int k = tid + u * PT; int i = k < HD_V0 ? k : k - HD_V0 + HD_V1; if (k < NA) lds[i] = va[u]; }
+      for (int u = 0; u < NA_U; ++u) { int k = tid + u * PT; int i = k < HD_V0 ? k : k - HD_V0 + HD_V1; if (k < NA) lds[i] = va[u]; }
+    }
+    for (int c = wave; c < HD_CHUNKS; c += PW) dma_chunk(src + HD_V0 + 64 * c + lane, lds + HD_V0 + 64 * c);
   }
-  for (int c = wave; c < HD_CHUNKS; c += PW) dma_chunk(src + HD_V0 + 64 * c + lane, lds + HD_V0 + 64 * c);
   unsigned long long* prof = a.prof ? prof_lds : nullptr;
   if (prof && tid < 16) prof_lds[tid] = 0;
   if (tid < 4) (&glist_n[0][0])[tid] = 0;
@@ -949,11 +954,43 @@ __global__ __launch_bounds__(PT, MINW) void k_step_philox(StepArgs a) {
   // 64-byte line, written here by four adjacent lanes, and a step touches a handful of the 137 (hd_touch; everything after a reset)
   uint4* dst = reinterpret_cast<uint4*>(a.st + e);
   static_assert(sizeof(HostDyn) == 64 && offsetof(EnvState, hd) % 64 == 0 && HOT_VEC + 4 * MAXH == ROW_VEC, "one line per host row, the table closes the row");
-  for (int i = tid; i < HOT_VEC; i += PT) dst[i] = lds[i];
-  if (do_reset) { for (int i = HOT_VEC + tid; i < ROW_VEC; i += PT) dst[i] = lds[i]; }
-  else for (int k = tid; k < 4 * MAXH; k += PT) if ((work.hdirty[k >> 7] >> ((k >> 2) & 31)) & 1u) dst[HOT_VEC + k] = lds[HOT_VEC + k];
+  if (RUN) {
+    if (run_flags & 2) for (int i = tid; i < ROW_VEC; i += PT) dst[i] = lds[i];     // the launch's last step of the episode: the whole row
+  } else {
+    for (int i = tid; i < HOT_VEC; i += PT) dst[i] = lds[i];
+    if (do_reset) { for (int i = HOT_VEC + tid; i < ROW_VEC; i += PT) dst[i] = lds[i]; }
+    else for (int k = tid; k < 4 * MAXH; k += PT) if ((work.hdirty[k >> 7] >> ((k >> 2) & 31)) & 1u) dst[HOT_VEC + k] = lds[HOT_VEC + k];
+  }
   if (prof && tid == 0) { prof[13] += clock64() - t_out; prof[14] += clock64() - t_begin; }
   if (prof) { __syncthreads(); if (tid < 15) a.prof[PROF_SLOTS * (size_t)e + tid] += prof_lds[tid]; }
+}
+
+template <bool LOG, int MINW>
+__global__ __launch_bounds__(PT, MINW) void k_step_philox(StepArgs a) { philox4_body<LOG>(a); }
+
+// The multi-step form for batches the chip holds at once (at most five episode blocks per CU: the per-GPU share of an 8-GPU job,
+// BASELINE configs[1]): ONE launch runs the K steps of cc4_run_random_steps, every block looping over the steps of ITS episode.
+// A launch per step lasts as long as its slowest episode (70.8k cycles against a mean of 41.5k at 1024 episodes,
+// profiles/r03_tail_whatif.txt) and the chip idles behind it; here an episode's next step starts the moment its last one ends --
+// episodes are independent, so nothing else orders them -- and the batch advances at the MEAN step time.  No ticket, no flag, no
+// cache maintenance: a block only ever reads what it wrote itself (its waves drain their stores, s_waitcnt vmcnt(0), and meet at
+// the block barrier before the next step stages the row in again; the CU's L1 is coherent for its own waves).  Blocks beyond the
+// chip's residency simply start when others have finished all their steps: correct at any batch size, worthwhile below it.
+// And the row never leaves the block: it is staged in before the first step and written back after the last (what a step writes
+// every time are its outputs: observations, reward, done, error word, the drawn actions).
+// The body is a real call: inlined into the step loop its loop-invariant values are hoisted and held across the whole step.
+// (register budget of five blocks per CU, stated for the callee as well: left to itself it takes 212 VGPRs)
+__device__ __attribute__((noinline)) void philox4_item(const StepArgs& a, int run_flags) { philox4_body<false, true>(a, run_flags); }
+__global__ __launch_bounds__(PT, 5) void k_run_philox(StepArgs a, int K, uint32_t t0) {
+  a.prof = nullptr; a.obs8 = nullptr; a.ext = nullptr;
+  const int full0 = a.full_obs;
+  for (int k = 0; k < K; ++k) {
+    a.rand_t = t0 + (uint32_t)k;
+    a.full_obs = k == 0 ? full0 : 0;
+    philox4_item(a, (k > 0 ? 1 : 0) | (k == K - 1 ? 2 : 0));
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+  }
 }
 
 // ---------------------------------------------------------------- Philox mode, one wavefront per episode
@@ -1457,6 +1494,7 @@ struct cc4_handle {
   uint32_t* d_run = nullptr;      // [P ticket | P owner | n progress]
   int16_t* d_slot_part = nullptr; // [CC4_SLOTS]
   int run_P = 0, run_grid = 0;    // partitions (= CUs that take waves), waves per launch; 0: the persistent path is off
+  bool multistep = false;         // k_run_philox: cc4_run_random_steps as ONE launch, every block looping over the steps of its episode
   ExtAct* d_ext = nullptr;        // [num_envs][EXT_PER_ENV]
   bool ext_seen = false, ext_dirty = false;   // dirty: d_ext holds the records of an earlier step
   std::vector<ExtAct> h_ext;
@@ -1609,8 +1647,9 @@ static int launch_step(cc4_handle* h, const int32_t* d_actions, const uint8_t* d
     hipEvent_t start = h->comm ? nullptr : h->tev_start[g];        // timing rides on the kernels' own signals too: no marker packets
     h->tev_start[g] = h->tev_stop[g] = nullptr;
 #ifdef CC4_DEV_FAST     // kernel experiments (tools/ab.sh): only the one-wave counter-mode kernel is instantiated -- a quarter of the compile time
-    if (h->cfg.rng_mode != 1 || !h->philox_lean || full) { h->err = "CC4_DEV_FAST build: only k_step_philox1<false> exists"; return -1; }
-    hipExtLaunchKernelGGL(k_step_philox1<false>, grid, dim3(WAVE), offsetof(EnvState, hd), st, start, stop, 0, a);
+    if (h->cfg.rng_mode != 1 || full) { h->err = "CC4_DEV_FAST build: only k_step_philox1<false> and k_step_philox<false, 1> exist"; return -1; }
+    if (h->philox_lean) hipExtLaunchKernelGGL(k_step_philox1<false>, grid, dim3(WAVE), offsetof(EnvState, hd), st, start, stop, 0, a);
+    else hipExtLaunchKernelGGL((k_step_philox<false, 1>), grid, dim3(PT), sizeof(EnvState), st, start, stop, 0, a);
 #else
     if (h->cfg.rng_mode == 1) {
       if (h->philox_lean) {
@@ -1651,6 +1690,16 @@ const char* cc4_step_kernel(cc4_handle* h) {
   if (!h) return "";
   if (h->cfg.rng_mode != 1) return "k_step";
   return h->philox_lean ? "k_step_philox1" : "k_step_philox";
+}
+
+// the kernel cc4_run_random_steps launches on this handle as it stands (no communicator, no event log): the step kernel, once per
+// step and group -- or one of the one-launch forms
+const char* cc4_run_kernel(cc4_handle* h) {
+  if (!h) return "";
+  const bool plain = !h->comm && !h->evlog_on && !h->ext_seen && !h->d_prof;
+  if (plain && h->multistep) return "k_run_philox";
+  if (plain && h->run_P > 0) return "k_run_philox1";
+  return cc4_step_kernel(h);
 }
 
 int cc4_create(const cc4_config* cfg, cc4_handle** out) {
@@ -1744,6 +1793,14 @@ int cc4_create(const cc4_config* cfg, cc4_handle** out) {
   HIPCHK(h, hipEventCreate(&h->ev0));
   HIPCHK(h, hipEventCreate(&h->ev1));
   HIPCHK(h, hipStreamSynchronize(h->stream));
+  if (cfg->rng_mode == 1 && !h->philox_lean) {
+    // the multi-step form of the four-wave kernel (k_run_philox): for batches the chip holds at once
+    int per_cu = 0;
+    HIPCHK(h, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_run_philox, PT, sizeof(EnvState)));
+    h->multistep = per_cu > 0 && cfg->num_envs <= per_cu * h->cus;
+    if (const char* v = getenv("CC4_MULTISTEP")) h->multistep = atoi(v) != 0;
+    if (getenv("CC4_PERSIST_DEBUG")) fprintf(stderr, "[cc4] k_run_philox: %d blocks per CU resident, multistep %d\n", per_cu, (int)h->multistep);
+  }
   // OFF unless CC4_PERSIST=1: measured (profiles/r04_persistent_kernel_ab.txt), bit-exact but 18-38 % SLOWER than the launch-per-step
   // schedule on four streams -- waves that never meet a launch boundary drift apart over the kernel's ~340 KB of code, and a CU's
   // twenty waves stop sharing their instruction fetches (a launch restarts them together; 98.8 % I-cache hits there).
@@ -1981,6 +2038,26 @@ int cc4_synchronize(cc4_handle* h) {
 int cc4_run_random_steps(cc4_handle* h, uint64_t seed0, uint32_t t0, int32_t k, float* ms_step_kernels) {
   HIPCHK(h, hipSetDevice(h->cfg.device_id));
   if (k <= 0) { if (ms_step_kernels) *ms_step_kernels = 0.f; return 0; }   // nothing to launch, no timing event to read
+  if (h->multistep && !h->comm && !h->evlog_on && !h->ext_seen && !h->d_prof && k >= 2) {
+    // one launch: every block runs the k steps of its episode (k_run_philox)
+    if (join_groups(h)) return -1;
+    StepArgs a{h->d_state, h->d_cold, nullptr, nullptr, h->d_obs, h->d_reward, h->d_done, h->d_err, nullptr, h->d_actions, seed0, t0,
+               h->cfg.num_envs, h->cfg.autoreset, h->cfg.steps, h->cfg.rng_mode,
+               (h->cfg.red_policy & 3) | (h->cfg.green_policy ? GP_SLEEP_BIT : 0) | (h->cfg.green_policy == 2 ? GP_OPEN_BIT : 0) | (h->cfg.blue_policy ? BP_RANDOM_BIT : 0),
+               h->full_obs_next ? 1 : 0, (uint32_t)h->cfg.topology_seed, nullptr, h->d_reset_ws, nullptr, 0};
+    if (ms_step_kernels && h->evs.size() < 2) { h->evs.resize(2, nullptr); for (auto& e : h->evs) if (!e) HIPCHK(h, hipEventCreate(&e)); }
+    auto c0 = std::chrono::steady_clock::now();
+    hipExtLaunchKernelGGL(k_run_philox, dim3(h->cfg.num_envs), dim3(PT), sizeof(EnvState), h->stream,
+                          ms_step_kernels ? h->evs[0] : nullptr, ms_step_kernels ? h->evs[1] : nullptr, 0, a, (int)k, t0);
+    HIPCHK(h, hipGetLastError());
+    h->stat_launch_us += std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - c0).count();
+    h->stat_steps += k;
+    h->full_obs_next = false;
+    h->main_ahead = h->ngroups > 1;
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    if (ms_step_kernels) HIPCHK(h, hipEventElapsedTime(ms_step_kernels, h->evs[0], h->evs[1]));
+    return 0;
+  }
   if (h->run_P > 0 && !h->comm && !h->evlog_on && !h->ext_seen && !h->d_prof && k >= 2) {
     // the persistent form: the k steps of the whole batch in ONE launch on the main stream (k_run_philox1)
     if (join_groups(h)) return -1;

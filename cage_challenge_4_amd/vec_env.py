@@ -236,6 +236,11 @@ class CC4VecEnv:
         return self.lib.cc4_step_kernel(self._h).decode()
 
     @property
+    def run_kernel(self):
+        """cc4_run_kernel: the kernel run_random_steps launches ('k_run_philox' = one launch for all k steps of a small batch)."""
+        return self.lib.cc4_run_kernel(self._h).decode()
+
+    @property
     def launches_per_step(self):
         """cc4_launches_per_step: a step of a large batch is several launches (episode groups on separate streams)."""
         return int(self.lib.cc4_launches_per_step(self._h))

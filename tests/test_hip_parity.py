@@ -210,7 +210,8 @@ def test_bench_configuration_matches_oracle_every_step(n, red_policy, blue_polic
     dev.close()
 
 
-def test_timed_bench_path_matches_oracle():
+@pytest.mark.parametrize('n,kernel,run_kernel', [(8192, 'k_step_philox1', 'k_step_philox1'), (1024, 'k_step_philox', 'k_run_philox')], ids=['8192', '1024-multistep'])
+def test_timed_bench_path_matches_oracle(n, kernel, run_kernel):
     """the exact region bench.py times -- cc4_run_random_steps on k_step_philox1, 8192 episodes, the handle's own
     launch grouping, no override, no communicator: the blue actions are drawn IN the step kernel on the bank lanes (BK_BRAND) --
     against the oracle driven with the host restatement of the same draws (random_actions), in bursts of K = 1, 20 and 137 steps
@@ -219,9 +220,11 @@ def test_timed_bench_path_matches_oracle():
     packed state of all episodes."""
     import ctypes, os
     assert 'CC4_PHILOX_LEAN' not in os.environ and 'CC4_PHILOX_MINW' not in os.environ and 'CC4_GROUPS' not in os.environ
-    n, steps, seed0 = 8192, 150, 4242
+    steps, seed0 = 150, 4242
     dev = _dev(n, steps=steps, rng_mode=1, autoreset=True)
-    assert dev.step_kernel == 'k_step_philox1' and dev.launches_per_step in (3, 4)
+    # (1024 episodes = BASELINE configs[1]: the chip holds the batch at once, and the region is ONE launch of the multi-step kernel
+    # k_run_philox, every block looping over the steps of its episode)
+    assert dev.step_kernel == kernel and dev.run_kernel == run_kernel and dev.launches_per_step in (3, 4)
     ora = OracleVecEnv(n, steps=steps, rng_mode=1, autoreset=True)
     assert np.array_equal(dev.reset(seeds=seed0), ora.reset_batch(seed0))
     t = 0

@@ -1,7 +1,7 @@
 #!/bin/bash
 # Round-end refresh on the GPU box: the profile set (tools/profile_round.sh) and the bench lines kept under profiles/.
 # usage: bash tools/final_refresh.sh TAG   (through gpurun; copy gpurun_out/prof/TAG_* to profiles/ afterwards)
-TAG=${1:-r03}
+TAG=${1:-r04}
 OUT=gpurun_out/prof
 mkdir -p $OUT
 bash tools/profile_round.sh $TAG > $OUT/profile_round.log 2>&1

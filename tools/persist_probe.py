@@ -1,10 +1,13 @@
+"""Parity probe of the one-launch forms of cc4_run_random_steps (k_run_philox: the multi-step four-wave kernel of small batches;
+k_run_philox1 with CC4_PERSIST=1): bursts of K steps across a scenario regeneration against the oracle.  usage: persist_probe.py [n]"""
 import sys, os, time
 sys.path.insert(0, '.'); sys.path.insert(0, 'tests')
 import numpy as np
 from cage_challenge_4_amd import CC4VecEnv
 from oracle_binding import OracleVecEnv, random_actions
-n, steps, seed0 = 8192, 150, 4242
+n, steps, seed0 = (int(sys.argv[1]) if len(sys.argv) > 1 else 8192), 150, 4242
 dev = CC4VecEnv(n, steps=steps, rng_mode=1, autoreset=True)
+print('kernel', dev.step_kernel, 'launches per step', dev.launches_per_step, flush=True)
 ora = OracleVecEnv(n, steps=steps, rng_mode=1, autoreset=True)
 assert np.array_equal(dev.reset(seeds=seed0), ora.reset_batch(seed0))
 t = 0

@@ -2,7 +2,7 @@
 # Collects the round's profiles on the GPU box into gpurun_out/prof/ (copied to profiles/rNN_* afterwards).
 # usage: bash tools/profile_round.sh [tag]      (run through gpurun)
 set -u
-TAG=${1:-r03}
+TAG=${1:-r04}
 OUT=gpurun_out/prof
 mkdir -p $OUT
 export TMPDIR=/tmp
@@ -13,7 +13,7 @@ python tools/rocpd_summary.py stats $OUT/stats8192 $OUT/${TAG}_kernel_stats_8192
 rocprofv3 --kernel-trace --stats -d $OUT/stats1024 -- $BENCH --total-envs 1024 > $OUT/bench_stats1024.json 2> $OUT/stats1024.err
 python tools/rocpd_summary.py stats $OUT/stats1024 $OUT/${TAG}_kernel_stats_1024env.txt > /dev/null
 # 2. HBM traffic: separate --pmc passes (FETCH_SIZE, WRITE_SIZE), kernel-trace only
-for N in 8192 1024; do
+for N in 8192 1024 32768; do
   rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $OUT/fetch$N -- $BENCH --total-envs $N --min-seconds 0.05 > /dev/null 2> $OUT/fetch$N.err
   rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $OUT/write$N -- $BENCH --total-envs $N --min-seconds 0.05 > $OUT/bench_pmc$N.json 2> $OUT/write$N.err
   KN=$(python -c "import json,sys; d=[json.loads(l) for l in open('$OUT/bench_pmc$N.json') if l.startswith('{')][0]; print(d['roofline']['kernel'])")
