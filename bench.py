@@ -304,7 +304,7 @@ def main():
         out = summarise(secs, kms, args.steps, n_total)
         t_end = args.warmup + len(secs) * args.steps        # launches so far; episodes regenerate on every (episode_steps)-th
         out['autoreset_launches_in_timed_regions'] = t_end // args.episode_steps - args.warmup // args.episode_steps
-        out['launches_per_step'] = e.launches_per_step
+        out['launches_per_step'] = e.launches_per_step      # of the per-step kernel (`kernel`); see run_kernel
         # what cc4_run_random_steps launches: the step kernel once per step and group, or -- a batch the chip holds at once -- ONE launch
         # of the multi-step kernel per timed region (k_run_philox: every block loops over the steps of its episode, the row stays in LDS)
         out['run_kernel'] = e.run_kernel

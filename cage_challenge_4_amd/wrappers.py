@@ -293,9 +293,8 @@ class CybORG:
 
     def parallel_step(self, actions=None, messages=None, skip_valid_action_check=False):
         """env.py:95-123: ({agent: dict observation}, {agent: reward components of its team}, {agent: done}, {}) for the
-        agents that acted plus the active ones.  Blue agents get their full dict observation (get_observation); red and
-        green agents -- internal policies here -- are listed with their team's reward and the done flag, and an observation
-        that only carries 'success'."""
+        agents that acted plus the active ones.  Blue and red agents get their dict observation (get_observation); a green
+        agent's carries 'success' and 'action'.  Every agent is listed with its team's reward and the done flag."""
         self._submit(actions, messages, skip_valid_action_check)
         st = self._state()
         rewards = self.get_rewards()
@@ -458,8 +457,9 @@ class CybORG:
     def get_observation(self, agent):
         """env.py:270-283: the dict observation of a blue agent after the last step -- 'success', 'action' and, per host of
         its zone with events, 'Interface' / 'Processes' (connections with addresses and ports, pids) / 'System info', as the
-        end-of-turn Monitor reports them (true_state.blue_observations; exact against the reference for Sleep / Monitor /
-        Remove / Restore / Block / Allow steps)."""
+        end-of-turn Monitor reports them (true_state.blue_observations; exact against the reference for every blue action,
+        incl. the process entry of a resolved DeployDecoy and the file list of a resolved Analyse: tests/test_blue_obs.py);
+        a red agent's comes from the engine's per-agent observation keys, a green agent's carries 'success' / 'action'."""
         from .true_state import decode
         return self._all_observations(decode(self.vec.true_state_json(0)), [agent])[agent]
 

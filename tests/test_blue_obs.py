@@ -68,13 +68,12 @@ def test_blue_dict_observations_match_reference_hip():
     _check(make)
 
 
-def test_blue_dict_observations_with_random_blue_actions_oracle_build():
+def _check_random(cls):
     """The same under random blue actions (fixture traj_seed123_random_ctor_500): 'action' string, 'success', and the
     host entries, incl. the process entry of a resolved DeployDecoy and the file list of a resolved Analyse."""
-    from oracle_binding import OracleVecEnv
     doc = json.load(open(os.path.join(golden_util.GOLDEN_DIR, 'blueobs_seed123_random.json')))
     fix = golden_util.load(os.path.join(golden_util.GOLDEN_DIR, doc['fixture']))
-    e = OracleVecEnv(1, steps=fix['steps'])
+    e = cls(1, steps=fix['steps'])
     e.reset(seeds=fix['seed'])
     e.reset(seeds=None)
     e.enable_event_log(True)
@@ -99,6 +98,18 @@ def test_blue_dict_observations_with_random_blue_actions_oracle_build():
             g = _canon(got[f'blue_agent_{b}'])
             g.setdefault('action', None)
             assert _digest(g) == row[b], (t0 + i, b)
+
+
+def test_blue_dict_observations_with_random_blue_actions_oracle_build():
+    from oracle_binding import OracleVecEnv
+    _check_random(OracleVecEnv)
+
+
+@pytest.mark.gpu
+def test_blue_dict_observations_with_random_blue_actions_hip():
+    """VERDICT r03 weak #8: the device's event log under random blue actions against the same recording of the reference."""
+    from cage_challenge_4_amd import CC4VecEnv
+    _check_random(CC4VecEnv)
 
 
 def test_cyborg_get_observation_surface():
