@@ -2623,7 +2623,15 @@ CC4_HD void env_step(Ctx x, const int32_t* actions, const uint8_t* messages /* [
 //                       a plain shell session -- a2 bit 0: username root / SYSTEM, bit 1: parent is not None -- with the ident
 //                       State.add_session would pick (max + 1; the tests pass exactly those) and a fresh 'shell' process
 //                       (test_Red/test_Withdraw.py:10-17, test_RedSessionCheck.py:10-23); returns the ident
-enum : int { SE_SET_PHASE = 0, SE_ADD_SERVICE = 1, SE_SET_RELIABILITY = 2, SE_CLEAR_HOST = 3, SE_DEPLOY_DECOY = 4, SE_ADD_RED_SESSION = 5 };
+//                       a2 bit 2: a RedAbstractSession (session_type='RedAbstractSession': Tests/test_cc4/test_Acceptance/test_priority.py:172-176)
+//   SE_BLOCK            a2 ? state.blocks.setdefault(to a0, []).append(from a1) : the pair removed   (test_issue22_blocks.py:73-88)
+//   SE_SET_STEP         environment_controller.step_count = a0: the next step's mission phase follows it, never backwards
+//                       (State.check_next_phase_on_update_step; test_issue22_blocks.py:91-97)
+//   SE_ADD_EVENT        host a0: events.network_connections (a1 = 0) / events.process_creation (a1 = 1) gets an entry whose port is
+//                       host.get_ephemeral_port() -- one draw, a second on a collision (test_issue26_monitor.py:134-142,178-185)
+//   SE_SET_RED_ACTIVE   agent_interfaces[red_agent_<a0>].active = bool(a1)   (test_Acceptance/test_challenge_details.py:253-256, test_priority.py:177)
+enum : int { SE_SET_PHASE = 0, SE_ADD_SERVICE = 1, SE_SET_RELIABILITY = 2, SE_CLEAR_HOST = 3, SE_DEPLOY_DECOY = 4, SE_ADD_RED_SESSION = 5,
+             SE_BLOCK = 6, SE_SET_STEP = 7, SE_ADD_EVENT = 8, SE_SET_RED_ACTIVE = 9 };
 inline int state_edit(Ctx x, int op, int a0, int a1, int a2) {
   EnvState* s = x.s;
   auto host_ok = [&](int h) { return h >= 0 && h < MAXH && bit_get(s->exists, h); };
@@ -2677,11 +2685,30 @@ inline int state_edit(Ctx x, int op, int a0, int a1, int a2) {
     case SE_ADD_RED_SESSION: {
       if (a0 < 0 || a0 >= NRED || !host_ok(a1)) return -1;
       const int pid = create_pid(x, a1);                      // Host.add_session: pid = create_pid(), Process(name=session_type, username)
-      if (!add_proc(x, a1, pid, K_SHELL, (a2 & 1) ? PF_ROOT : 0)) return -1;
-      const int idx = rs_add(x, a0, a1, pid, ((a2 & 1) ? RS_ROOT : 0) | ((a2 & 2) ? RS_CHILD : 0));
+      if (!add_proc(x, a1, pid, (a2 & 4) ? K_SESS_RED : K_SHELL, (a2 & 1) ? PF_ROOT : 0)) return -1;
+      const int idx = rs_add(x, a0, a1, pid, ((a2 & 1) ? RS_ROOT : 0) | ((a2 & 2) ? RS_CHILD : 0) | ((a2 & 4) ? RS_ABSTRACT : 0));
       if (idx < 0) return -1;
       return rsw_id(rs_at(s, s->red[a0], idx));
     }
+    case SE_BLOCK:
+      if (a0 < 0 || a0 >= NSUB - 1 || a1 < 0 || a1 >= NSUB - 1) return -1;
+      if (a2) s->blocks[a0] |= (uint16_t)(1u << a1); else s->blocks[a0] &= (uint16_t)~(1u << a1);
+      s->obs_dirty = 1;
+      return 0;
+    case SE_SET_STEP:
+      if (a0 < 0 || a0 >= s->steps) return -1;
+      s->step_count = a0;
+      return 0;
+    case SE_ADD_EVENT: {
+      if (!host_ok(a0) || a1 < 0 || a1 > 1) return -1;
+      const int port = eph_port(x, a0);
+      ev_or(x, a0, a1 ? EV_CUR_PROC : EV_CUR_CONN);
+      return port;
+    }
+    case SE_SET_RED_ACTIVE:
+      if (a0 < 0 || a0 >= NRED) return -1;
+      s->red[a0].h.active = (uint8_t)(a1 != 0);
+      return 0;
     default: return -1;
   }
 }

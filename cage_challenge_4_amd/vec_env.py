@@ -162,7 +162,8 @@ class CC4VecEnv:
     def edit_state(self, env, op, a0=0, a1=0, a2=0):
         """cc4_edit_state: a direct edit of one episode between steps (what the reference's scripted tests do to
         env.environment_controller.state by hand): op 0 mission phase, 1 add service, 2 service reliability, 3 clear host,
-        4 deploy one decoy kind (include/cc4.h).  Returns the op's result (>= 0)."""
+        4 deploy one decoy kind, 5 add a red session, 6 block / allow a subnet pair, 7 step count, 8 add a host event, 9 a red
+        agent's `active` flag (include/cc4.h).  Returns the op's result (>= 0)."""
         rc = int(self.lib.cc4_edit_state(self._h, int(env), int(op), int(a0), int(a1), int(a2)))
         if rc < 0:
             self._chk(rc, 'cc4_edit_state')

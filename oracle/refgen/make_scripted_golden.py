@@ -60,7 +60,8 @@ def sha(txt):
 
 class Case:
     """One environment: the reference and the oracle in lockstep; everything done to them is recorded."""
-    def __init__(self, seed, steps=100, red='sleep', green='sleep', resets=0, note=''):
+    def __init__(self, seed, steps=100, red='sleep', green='sleep', resets=0, note='', slim=False):
+        self.slim = slim                       # long trajectories: a digest of the flat observation instead of its 578 digits
         sg = EnterpriseScenarioGenerator(blue_agent_class=SleepAgent, green_agent_class=GREEN[green][0], red_agent_class=RED[red][0], steps=steps)
         self.pol = RED[red][1] | (0x10 if GREEN[green][1] else 0)
         self.env = CybORG(sg, seed=seed)
@@ -162,6 +163,46 @@ class Case:
         rc = self.edit(5, int(agent[-1]), host_index(hostname), (1 if user in ('root', 'SYSTEM') else 0) | (2 if parent is not None else 0), fn)
         assert rc == ident, (rc, ident)
 
+    def add_abstract_red_session(self, agent, hostname):
+        out = {}
+
+        def fn():                                          # test_Acceptance/test_priority.py:172-176
+            from CybORG.Shared.Session import RedAbstractSession
+            sess = RedAbstractSession(hostname=hostname, username='root', agent=agent, parent=None, session_type='RedAbstractSession', ident=None, pid=None)
+            self.st.add_session(sess)
+            out['ident'] = sess.ident
+        rc = self.edit(5, int(agent[-1]), host_index(hostname), 1 | 4, fn)
+        assert rc == out['ident'], (rc, out)
+        return rc
+
+    def block(self, to_subnet, from_subnet):
+        def fn():                                          # test_issue22_blocks.py:84-87
+            self.st.blocks.setdefault(to_subnet, []).append(from_subnet)
+        self.edit(6, subnet_index(to_subnet), subnet_index(from_subnet), 1, fn)
+
+    def set_step(self, n):
+        self.edit(7, n, 0, 0, lambda: setattr(self.ec, 'step_count', n))   # test_issue22_blocks.py:91-97
+
+    def add_event(self, hostname, kind):
+        """kind 0: events.network_connections, 1: events.process_creation; the port is host.get_ephemeral_port() (test_issue26_monitor.py:134-142,178-185)"""
+        host = self.st.hosts[hostname]
+        out = {}
+
+        def fn():
+            from CybORG.Simulator.HostEvents import NetworkConnection
+            port = host.get_ephemeral_port()
+            out['port'] = int(port)
+            if kind == 0:
+                host.events.network_connections.append(NetworkConnection(local_address=self.ip(hostname), remote_port=port,
+                                                                         remote_address=self.ip(CNS0)))
+            else:
+                host.events.process_creation.append({'local_address': self.ip(hostname), 'local_port': port})
+        rc = self.edit(8, host_index(hostname), kind, 0, fn)
+        assert rc == out['port'], (rc, out)
+
+    def set_red_active(self, agent, on):
+        self.edit(9, int(agent[-1]), int(on), 0, lambda: setattr(self.ec.agent_interfaces[agent], 'active', bool(on)))
+
     # ---- the step
     def _rng(self):
         st = self.ec.np_random.bit_generator.state
@@ -251,7 +292,7 @@ class Case:
             assert names == want_u, ('files', hd['h'], names, want)
         self.rec['script'].append({
             'step': {'blue': blue, 'red': recs['red'], 'green': recs['green']},
-            'expect': {'obs': ''.join(str(int(v)) for v in ro), 'reward': float(rew['blue_agent_0']), 'done': int(bool(term['blue_agent_0'])),
+            'expect': {**({'obs_sha': sha(''.join(str(int(v)) for v in ro))} if self.slim else {'obs': ''.join(str(int(v)) for v in ro)}), 'reward': float(rew['blue_agent_0']), 'done': int(bool(term['blue_agent_0'])),
                        'rng': self._rng(), 'dump': sha(ref), 'success': success,
                        'active_red': [r for r in range(6) if self.ec.agent_interfaces[f'red_agent_{r}'].active],
                        'files': {k: v for k, v in files.items()}, 'red_obs': red_obs,
@@ -617,6 +658,274 @@ def _():
     for t in range(30):
         c.step({RED0: Sleep()} if t % 3 else {})
     yield c
+
+
+# ------------------------------------------------------------------------------------------------ test_Green/*.py
+def green_agents(c):
+    return sorted((a for a in c.ec.agent_interfaces if 'green' in a), key=lambda a: int(a.split('_')[-1]))
+
+
+def green_host(c, ga):
+    return c.st.sessions[ga][0].hostname
+
+
+def red_on(c, hostname):
+    return [a for a, ss in c.st.hosts[hostname].sessions.items() if 'red' in a and len(ss) > 0]
+
+
+@fixture('green_local_work_rates', 'CybORG/Tests/test_cc4/test_Green/test_GreenLocalWork.py:14-100,154-204 and test_Acceptance/test_green_agents.py:81-104 '
+         '(fp_detection_rate / phishing_error_rate 0 or 1, three green agents of EnterpriseGreenAgent scenarios; the test calls execute() itself, here the action is the agent\'s step)')
+def _():
+    for seed, pick in ((11, 0), (12, 0.45), (13, 0.9)):
+        for fp, ph in ((0.0, 0.0), (1.0, 0.0), (0.0, 1.0), (1.0, 1.0)):
+            c = Case(seed, green='enterprise', note=f'seed {seed} fp {fp} phishing {ph}')
+            gs = green_agents(c)
+            ga = gs[int(pick * (len(gs) - 1))]
+            gh = green_host(c, ga)
+            had_red = bool(red_on(c, gh))
+            o = c.step({ga: GreenLocalWork(agent=ga, session_id=0, ip_address=c.ip(gh), fp_detection_rate=fp, phishing_error_rate=ph)})
+            assert o[ga]['success'] == True and 'GreenLocalWork' in str(o[ga]['action'])      # noqa: E712
+            if ph == 1.0:
+                assert red_on(c, gh)               # test_phishing_error_rate_session_creation
+            elif not had_red:
+                pass                               # (another green agent's own 1 % phishing may still land here: not asserted)
+            yield c
+
+
+@fixture('green_local_work_degraded', 'CybORG/Tests/test_cc4/test_Green/test_GreenLocalWork.py:206-228 (all services of the host at 0 % reliability: the work fails)')
+def _():
+    for seed, pick in ((21, 0.2), (22, 0.7)):
+        c = Case(seed, green='enterprise', note=f'seed {seed}')
+        gs = green_agents(c)
+        ga = gs[int(pick * (len(gs) - 1))]
+        gh = green_host(c, ga)
+        c.degrade_fully(gh)
+        o = c.step({ga: GreenLocalWork(agent=ga, session_id=0, ip_address=c.ip(gh), fp_detection_rate=0.0, phishing_error_rate=0.0)})
+        assert o[ga]['success'] == False           # noqa: E712
+        yield c
+
+
+@fixture('green_access_service_events', 'CybORG/Tests/test_cc4/test_Green/test_GreenAccessService.py:14-58,195-233 and test_Acceptance/test_green_agents.py:41-79 '
+         '(fp_detection_rate 0: no network_connections event; 1: one on the destination, seen by the zone\'s Monitor)')
+def _():
+    for seed, pick in ((31, 0.1), (32, 0.5), (33, 0.95)):
+        for fp in (0.0, 1.0):
+            c = Case(seed, green='enterprise', note=f'seed {seed} fp {fp}')
+            gs = green_agents(c)
+            ga = gs[int(pick * (len(gs) - 1))]
+            gh = green_host(c, ga)
+            act = GreenAccessService(agent=ga, session_id=0, src_ip=c.ip(gh), allowed_subnets=c.ec.agent_interfaces[ga].allowed_subnets, fp_detection_rate=fp)
+            o = c.step({ga: act})
+            assert o[ga]['success'] == True        # noqa: E712
+            dest = c.st.ip_addresses[act.dest_ip]
+            assert 'server' in dest and dest != gh   # test_random_reachable_ip: a server, never the agent's own host
+            yield c
+
+
+@fixture('green_access_service_phases', 'CybORG/Tests/test_cc4/test_Green/test_GreenAccessService.py:236-297 through all three mission phases '
+         '(30-step episodes: the destination is a server of a subnet the phase\'s communication policy allows)')
+def _():
+    for seed in (41, 42):
+        c = Case(seed, steps=30, green='enterprise', note=f'seed {seed}')
+        gs = green_agents(c)
+        picks = [gs[0], gs[len(gs) // 3], gs[2 * len(gs) // 3], gs[-1]]
+        sg_allowed = c.ec.scenario_generator._set_allowed_subnets_per_mission_phase()
+        for t in range(28):
+            acts = {}
+            for ga in picks:
+                gh = green_host(c, ga)
+                acts[ga] = GreenAccessService(agent=ga, session_id=0, src_ip=c.ip(gh), allowed_subnets=c.ec.agent_interfaces[ga].allowed_subnets, fp_detection_rate=0.0)
+            c.step(acts)
+            mp = c.st.mission_phase
+            for ga, act in acts.items():
+                if act.dest_ip == '':
+                    continue
+                src_sn = c.st.hostname_subnet_map[green_host(c, ga)]
+                dst = c.st.ip_addresses[act.dest_ip]
+                dst_sn = c.st.hostname_subnet_map[dst]
+                assert 'server' in dst
+                if dst_sn != src_sn:
+                    assert any({src_sn, dst_sn} == {a, b} for a, b in sg_allowed[mp]), (t, ga, src_sn, dst_sn)
+        assert c.st.mission_phase == 2
+        yield c
+
+
+# ------------------------------------------------------------------------------------------------ test_issue26_monitor.py
+@fixture('issue26_monitor_persistence', 'CybORG/Tests/test_cc4/test_issue26_monitor.py:120-198 (a NetworkConnection / ProcessCreation event put on a host by hand is reported by the '
+         'end-of-turn Monitor of the step and gone in the next one; the Velociraptor server host and client hosts alike)')
+def _():
+    for kind in (0, 1):
+        c = Case(26, steps=300, note=('network_connections', 'process_creation')[kind])
+        for b in range(5):
+            agent = f'blue_agent_{b}'
+            sess = c.st.sessions[agent]
+            for idx in sorted({0, 1, max(sess.keys())}):
+                hn = sess[idx].hostname
+                c.add_event(hn, kind)
+                o = c.step({agent: Sleep()})
+                keys = lambda d: [k for k in d.keys() if k != 'message']      # noqa: E731  (the wrapper's message slot)
+                assert len(keys(o[agent])) == 3 and hn in o[agent], (agent, idx, o[agent].keys())
+                ev = c.st.hosts[hn].events
+                assert len(ev.network_connections) == 0 and len(ev.process_creation) == 0
+                o = c.step({agent: Sleep()})
+                assert len(keys(o[agent])) == 2
+        yield c
+
+
+# ------------------------------------------------------------------------------------------------ test_issue22_blocks.py
+@fixture('issue22_blocks_green', 'CybORG/Tests/test_cc4/test_issue22_blocks.py:15-105 (every pair the phase\'s communication policy does not need is blocked by hand, step_count '
+         'set to the phase\'s first step: 100 steps of EnterpriseGreenAgents without a penalty; the agents keep their own 1 % event rates here -- neither earns a penalty)')
+def _():
+    groups = [['public_access_zone_subnet', 'admin_network_subnet', 'office_network_subnet'], ['contractor_network_subnet'], ['restricted_zone_a_subnet'],
+              ['operational_zone_a_subnet'], ['restricted_zone_b_subnet'], ['operational_zone_b_subnet']]
+    policies = [[[1, 1, 1, 0, 1, 0], [1, 1, 1, 0, 1, 0], [1, 1, 1, 1, 1, 0], [0, 0, 1, 1, 0, 0], [1, 1, 1, 0, 1, 1], [0, 0, 0, 0, 1, 1]],
+                [[1, 1, 1, 0, 1, 0], [1, 1, 0, 0, 1, 0], [1, 0, 1, 0, 0, 0], [0, 0, 0, 1, 0, 0], [1, 1, 0, 0, 1, 1], [0, 0, 0, 0, 1, 1]],
+                [[1, 1, 1, 0, 1, 0], [1, 1, 1, 0, 0, 0], [1, 1, 1, 1, 0, 0], [0, 0, 1, 1, 0, 0], [1, 0, 0, 0, 1, 0], [0, 0, 0, 0, 0, 1]]]
+    for mp in range(3):
+        c = Case(3, steps=300, green='enterprise', note=f'mission phase {mp}', slim=True)
+        for r, row in enumerate(policies[mp]):
+            for k, ok in enumerate(row):
+                if not ok:
+                    for a in groups[r]:
+                        for b in groups[k]:
+                            c.block(a, b)
+        if mp:
+            c.set_step(100 * mp)
+        for t in range(100):
+            c.step({})
+            assert c.rec['script'][-1]['expect']['brm'] == 0, (mp, t)
+        assert c.st.mission_phase == mp
+        yield c
+
+
+# ------------------------------------------------------------------------------------------------ test_Acceptance/*.py
+@fixture('priority_red_impact_access', 'CybORG/Tests/test_cc4/test_Acceptance/test_priority.py:148-204 (a root RedAbstractSession added by hand on every server of operational zone A / B, '
+         'Impact with duration 1: the RIA penalty of the mission phase; the test enables the action in the agent\'s action space by hand, the step\'s own switch for that is skip_valid_action_check)')
+def _():
+    from CybORG.Shared.BlueRewardMachine import BlueRewardMachine
+    for sn in ('operational_zone_a_subnet', 'operational_zone_b_subnet'):
+        for mp in range(3):
+            c = Case(77, note=f'{sn} phase {mp}')
+            owner = {i.allowed_subnets[0]: a for a, i in c.ec.agent_interfaces.items() if 'red' in a}[sn]
+            c.set_phase(mp)
+            i = 0
+            while f'{sn}_server_host_{i}' in c.st.hosts:
+                hn = f'{sn}_server_host_{i}'
+                assert c.st.hosts[hn].services[ProcessName.OTSERVICE]
+                c.add_abstract_red_session(owner, hn)
+                c.set_red_active(owner, True)
+                o = c.step({owner: one(Impact(hn, 0, owner), 1)}, skip_valid=True)
+                assert o[owner]['action']
+                assert c.rec['script'][-1]['expect']['brm'] == BlueRewardMachine('').get_phase_rewards(mp)[sn]['RIA'], (sn, mp, i)
+                i += 1
+            assert i > 0
+            yield c
+
+
+@fixture('phase_progression', 'CybORG/Tests/test_cc4/test_Acceptance/test_priority.py:22-46 and test_mission_phase.py:116-121 (EnterpriseGreenAgents, 100 steps: phase 1 -> 2A -> 2B at the '
+         'steps the scenario generator\'s split gives)')
+def _():
+    c = Case(123, steps=100, green='enterprise', slim=True)
+    lens = c.ec.scenario_generator._set_mission_phases() if hasattr(c.ec.scenario_generator, '_set_mission_phases') else c.st.scenario.mission_phases
+    lens = c.st.scenario.mission_phases
+    seen = []
+    for t in range(99):
+        c.step({})
+        seen.append(c.st.mission_phase)
+    first = [seen.index(p) for p in (0, 1, 2)]
+    assert first == [0, lens[0], lens[0] + lens[1]], (first, lens)
+    yield c
+
+
+@fixture('action_durations', 'CybORG/Tests/test_cc4/test_Acceptance/test_challenge_details.py:293-319 (an action with duration 2 is not executed in the step it is submitted in '
+         '-- the agent is IN_PROGRESS -- and is in the next; an agent mid-action is not asked again)')
+def _():
+    c = Case(123, steps=100, green='enterprise')
+    o = c.step({BLUE0: one(Sleep(), 2)}, skip_valid=True)
+    assert TERN[o[BLUE0]['success'].name] == 4
+    o = c.step({}, skip_valid=True)
+    assert c.env.get_observation(BLUE0)['success'] != False      # noqa: E712
+    hn = 'restricted_zone_a_subnet_user_host_0'
+    o = c.step({BLUE0: one(Analyse(session=0, agent=BLUE0, hostname=hn), 3)})
+    assert TERN[o[BLUE0]['success'].name] == 4
+    o = c.step({BLUE0: Monitor(session=0, agent=BLUE0)})          # dropped: the Analyse is still in progress
+    assert TERN[o[BLUE0]['success'].name] == 4
+    o = c.step({})
+    assert 'Analyse' in str(c.env.get_observation(BLUE0)['action']) and c.env.get_observation(BLUE0)['success'] == True   # noqa: E712
+    yield c
+
+
+@fixture('red_spawn_and_respawn', 'CybORG/Tests/test_cc4/test_Acceptance/test_challenge_details.py:143-169 (a second red agent wakes up in the HQ network within 100 steps of '
+         'EnterpriseGreenAgents -- phishing) and :245-269 (every red agent set inactive by hand: red_agent_0 of the contractor network is active again after a step)')
+def _():
+    c = Case(123, steps=100, green='enterprise', note='spawn', slim=True)
+    assert c.rec and [r for r in range(6) if c.ec.agent_interfaces[f'red_agent_{r}'].active] == [0]
+    hq = ['public_access_zone_subnet', 'admin_network_subnet', 'office_network_subnet']
+    for t in range(99):
+        c.step({})
+        act = [i for a, i in c.ec.agent_interfaces.items() if 'red' in a and i.active]
+        if len(act) > 1 and any(i.allowed_subnets == hq for i in act):
+            break
+    else:
+        raise SystemExit('no red agent spawned in the HQ network')
+    yield c
+    c = Case(123, steps=100, green='enterprise', note='respawn')
+    for r in range(6):
+        c.set_red_active(f'red_agent_{r}', False)
+    for t in range(3):
+        c.step({})
+        assert c.ec.agent_interfaces[RED0].active and c.ec.agent_interfaces[RED0].allowed_subnets == ['contractor_network_subnet']
+    yield c
+
+
+@fixture('red_aggressive_discovery_alert', 'CybORG/Tests/test_cc4/test_Acceptance/test_deception.py:265-283 (AggressiveServiceDiscovery with detection_rate 1 on a host red_agent_0 '
+         'has not discovered -- the test calls execute() itself: no validity check --: the session knows the host\'s ports, the zone\'s defender sees the connection)')
+def _():
+    c = Case(123, steps=100, green='enterprise')
+    hn = 'restricted_zone_a_subnet_user_host_0'
+    tip = c.ip(hn)
+    assert tip not in c.st.sessions[RED0][0].ports
+    o = c.step({RED0: one(AggressiveServiceDiscovery(ip_address=tip, agent=RED0, session=0), detection_rate=1)}, skip_valid=True)
+    assert tip in c.st.sessions[RED0][0].ports
+    assert hn in c.env.get_observation(BLUE0)
+    yield c
+
+
+@fixture('green_phishing_enters_network', 'CybORG/Tests/test_cc4/test_Acceptance/test_challenge_details.py:171-208 and test_deception.py:39-94 (a decoy on a defender\'s host, then the '
+         'host\'s green agent falls for a phishing email with probability 1: a red session appears on that host)')
+def _():
+    for seed in (51, 52):
+        c = Case(seed, green='enterprise', note=f'seed {seed}')
+        hn = None
+        for agent in [f'blue_agent_{b}' for b in range(5)]:
+            for sess in c.st.sessions[agent].values():
+                h = c.st.hosts[sess.hostname]
+                if not h.is_using_port(80) and any('green' in a and ss for a, ss in h.sessions.items()) and not red_on(c, sess.hostname):
+                    hn, owner = sess.hostname, agent
+                    break
+            if hn:
+                break
+        assert c.deploy_decoy(hn, DecoyApache, 5, owner)
+        ga = [a for a, ss in c.st.hosts[hn].sessions.items() if 'green' in a and ss][0]
+        c.step({ga: GreenLocalWork(agent=ga, session_id=0, ip_address=c.ip(hn), fp_detection_rate=0.0, phishing_error_rate=1.0)})
+        assert red_on(c, hn)
+        for t in range(3):
+            c.step({})
+        yield c
+
+
+# ------------------------------------------------------------------------------------------------ test_session_issues.py
+@fixture('session_issues_action_space', 'CybORG/Tests/test_cc4/test_session_issues.py:46-59 (FiniteStateRedAgents and EnterpriseGreenAgents, seeds 100 / 200 / 300, 60 steps: a blue '
+         'agent\'s client sessions in its action space are the sessions the state holds for it)')
+def _():
+    for seed in (100, 200, 300):
+        c = Case(seed, steps=1000, red='fsm', green='enterprise', note=f'seed {seed}', slim=True)
+        for t in range(60):
+            c.step({})
+            for b in range(5):
+                agent = f'blue_agent_{b}'
+                assert list(c.st.sessions[agent].keys()) == [k for k, v in c.ec.agent_interfaces[agent].action_space.client_session.items() if v]
+        yield c
 
 
 def main():

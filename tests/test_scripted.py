@@ -1,7 +1,8 @@
 """The reference's own scripted tests as fixtures: tests/golden/scripted_*.json, recorded from the REAL reference by
 oracle/refgen/make_scripted_golden.py -- test_blocking_red.py, test_blue_actions.py, test_BlueRewardMachine.py (every subnet x mission
-phase), test_Red/{test_Impact, test_DegradeServices, test_DiscoverDeception, test_Withdraw, test_RedSessionCheck}.py, plus a scripted
-red agent among live FSM agents.  A fixture is a list of cases; a case is (seed, number of resets, script of cc4_edit_state ops and
+phase), test_Red/{test_Impact, test_DegradeServices, test_DiscoverDeception, test_Withdraw, test_RedSessionCheck}.py, test_Green/{test_GreenLocalWork,
+test_GreenAccessService}.py, test_issue22_blocks.py, test_issue26_monitor.py, test_session_issues.py, test_Acceptance/{test_priority, test_challenge_details,
+test_deception, test_green_agents}.py, plus a scripted red agent among live FSM agents.  A fixture is a list of cases; a case is (seed, number of resets, script of cc4_edit_state ops and
 cc4_step_ex inputs) with, per entry, what the reference did: flat observations, team reward, BlueRewardMachine component, done,
 numpy stream position, `success` of every submitting agent, active red agents, malware files per host, and a digest of the
 canonical dump of the whole simulator state.
@@ -81,7 +82,8 @@ def replay(env, case, dump_of, tag):
         st, ex = e['step'], e['expect']
         obs, rew, done, info = env.step_ex(np.array([st['blue']], np.int32), None, _records(env, st['red'], 'red'), _records(env, st['green'], 'green'))
         n_steps += 1
-        assert ''.join(str(int(v)) for v in obs[0]) == ex['obs'], where
+        digits = ''.join(str(int(v)) for v in obs[0])
+        assert (digits == ex['obs']) if 'obs' in ex else (_sha(digits) == ex['obs_sha']), where       # long trajectories carry a digest
         assert float(rew[0]) == ex['reward'] and int(bool(done[0])) == ex['done'], where
         assert not info['err'].any(), where
         assert _rng_ok(env.rng_state()[0], ex['rng']), where
@@ -107,10 +109,12 @@ def replay(env, case, dump_of, tag):
 
 def test_there_are_enough_fixtures():
     cases = sum(len(_load(n)['cases']) for n in NAMES)
-    assert len(NAMES) >= 18 and cases >= 85, (len(NAMES), cases)
+    assert len(NAMES) >= 31 and cases >= 130, (len(NAMES), cases)
     src = ' '.join(_load(n)['source'] for n in NAMES)
     for f in ('test_blocking_red.py', 'test_blue_actions.py', 'test_BlueRewardMachine.py', 'test_Impact.py', 'test_DegradeServices.py',
-              'test_DiscoverDeception.py', 'test_Withdraw.py', 'test_RedSessionCheck.py'):
+              'test_DiscoverDeception.py', 'test_Withdraw.py', 'test_RedSessionCheck.py', 'test_GreenLocalWork.py', 'test_GreenAccessService.py',
+              'test_issue26_monitor.py', 'test_issue22_blocks.py', 'test_session_issues.py', 'test_priority.py', 'test_challenge_details.py',
+              'test_deception.py', 'test_green_agents.py', 'test_mission_phase.py'):
         assert f in src, f
 
 
@@ -176,12 +180,13 @@ def test_hip_counter_mode_runs_the_scripted_tests_like_the_oracle(lean, monkeypa
         dev, ora = envs
         assert dev.step_kernel == ('k_step_philox', 'k_step_philox1')[int(lean)]
         T = max(len(c['script']) for c in group)
-        for k in range(T):
+        finished = np.zeros(n, bool)       # episodes that reached their last step (a script that sets the step count by hand, plus the Sleep
+        for k in range(T):                 # steps its edit entries cost here): regenerated, the rest of the script dropped
             blue = np.full((n, 5), -1, np.int32)
             red, green = dev.agent_actions('red'), dev.agent_actions('green')
             stepping = np.zeros(n, bool)
             for i, c in enumerate(group):
-                if k >= len(c['script']):
+                if k >= len(c['script']) or finished[i]:
                     continue
                 e = c['script'][k]
                 if 'edit' in e:
@@ -198,6 +203,11 @@ def test_hip_counter_mode_runs_the_scripted_tests_like_the_oracle(lean, monkeypa
             d = dev.step_ex(blue, None, red, green); o = ora.step_ex(blue, None, red, green)
             bad = np.nonzero((d[0] != o[0]).any(axis=1) | (d[1] != o[1]) | (d[2] != o[2]) | (d[3]['err'] != o[3]['err']))[0]
             assert bad.size == 0, (steps, k, bad[:10].tolist())
+            if d[2].any():
+                over = np.asarray(d[2], bool)
+                assert all(k + 3 >= len(c['script']) for c, f in zip(group, over) if f)
+                finished |= over
+                assert np.array_equal(dev.reset(seeds=None, env_mask=over), ora.reset(seeds=None, env_mask=over))
             if k + 2 >= steps:
                 break
         for i in range(n):
