@@ -339,6 +339,15 @@ class CybORG:
                     out[a] = {'success': Ternary('FALSE' if fail else 'UNKNOWN')}
         return out
 
+    def edit_state(self, op, a0=0, a1=0, a2=0):
+        """cc4_edit_state on this episode -- what the reference's tests do to env.environment_controller.state by hand (include/cc4.h lists the
+        ops).  Hostnames and subnet names may be given instead of ids."""
+        def ident(v):
+            if isinstance(v, str):
+                return SUBNET_NAMES.index(v) if v in SUBNET_NAMES else self._host_maps()[1][v]
+            return int(v)
+        return self.vec.edit_state(0, int(op), ident(a0), ident(a1), int(a2))
+
     def set_seed(self, seed):
         """env.py:316-325: a fresh Generator for all further randomness; the episode itself is untouched."""
         self.vec.set_seed(np.array([seed], np.uint64))
@@ -624,6 +633,21 @@ class BlueFixedActionWrapper:
     def get_message_space(self, agent):
         return MultiBinary(MESSAGE_LENGTH)
 
+    # -- the BaseWrapper surface the reference's wrappers inherit (Agents/Wrappers/BaseWrapper.py:32-53)
+    def get_observation(self, agent):
+        """BaseWrapper.py:35-36: the agent's observation after the last step, in this wrapper's form."""
+        return self.env.get_observation(agent)
+
+    def get_last_action(self, agent):
+        return self.env.get_last_action(agent)
+
+    def set_seed(self, seed):
+        self.env.set_seed(seed)
+
+    @property
+    def active_agents(self):
+        return self.env.active_agents
+
     def get_attr(self, attribute):
         if hasattr(self, attribute):
             return getattr(self, attribute)
@@ -657,6 +681,14 @@ class BlueFlatWrapper(BlueFixedActionWrapper):
     def step(self, actions=None, messages=None, **kwargs):
         observations, rewards, terminated, truncated, info = super().step(actions=actions, messages=messages, **kwargs)
         return self._pad(observations), rewards, terminated, truncated, info
+
+    def get_observation(self, agent):
+        """BaseWrapper.get_observation through BlueFlatWrapper.observation_change (BlueFlatWrapper.py:172-256): a blue agent's flat
+        vector after the last step (what the reference's own wrapper tests read between steps: Tests/test_cc4/test_BlueEnterpriseWrapper.py:196-199,338)."""
+        if agent in self.possible_agents:
+            o = split_obs(self.env.vec._obs)[self.possible_agents.index(agent)][0].astype(np.int64)
+            return np.pad(o, (0, 210 - o.shape[0])) if self.is_padded else o
+        return self.env.get_observation(agent)
 
     def observation_space(self, agent_name):
         return self._long_obs_space if (self.is_padded or agent_name == 'blue_agent_4') else self._short_obs_space

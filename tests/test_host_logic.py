@@ -43,11 +43,17 @@ def test_scenario_generator_signature_and_constants():
                                         red_agent_class=W.DiscoveryFSRed)
     assert (sg2.red_policy, sg2.green_policy) == (2, 1)
 
-    class KeyboardAgent:             # not one of the engine's built-in policies
+    class NotAnAgent:                # no get_action: nothing the step could ask
         pass
-    with pytest.raises(NotImplementedError):
+    with pytest.raises(TypeError):
         W.EnterpriseScenarioGenerator(blue_agent_class=W.SleepAgent, green_agent_class=W.EnterpriseGreenAgent,
-                                      red_agent_class=KeyboardAgent)
+                                      red_agent_class=NotAnAgent)
+
+    class KeyboardAgent:             # not one of the engine's built-in policies: its objects act from the host (r04), the device's red policy sleeps
+        def get_action(self, observation, action_space):
+            return None
+    sg3 = W.EnterpriseScenarioGenerator(blue_agent_class=W.SleepAgent, green_agent_class=W.EnterpriseGreenAgent, red_agent_class=KeyboardAgent)
+    assert sg3.custom == {'red': KeyboardAgent} and sg3.red_policy == 1
 
 
 def test_spaces():
