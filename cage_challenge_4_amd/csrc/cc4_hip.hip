@@ -21,6 +21,10 @@
 #include <cstdio>
 #include <cstdlib>
 #include <vector>
+#include <thread>
+#include <mutex>
+#include <condition_variable>
+#include <atomic>
 
 #include "../../include/cc4.h"
 #include "cc4_engine.h"
@@ -1494,6 +1498,8 @@ struct cc4_handle {
   uint32_t* d_run = nullptr;      // [P ticket | P owner | n progress]
   int16_t* d_slot_part = nullptr; // [CC4_SLOTS]
   int run_P = 0, run_grid = 0;    // partitions (= CUs that take waves), waves per launch; 0: the persistent path is off
+  struct EnqPool* pool = nullptr; // one enqueue thread per group stream beyond the first (cc4_run_random_steps; enq_*)
+  bool enq_threads = false;
   bool multistep = false;         // k_run_philox: cc4_run_random_steps as ONE launch, every block looping over the steps of its episode
   ExtAct* d_ext = nullptr;        // [num_envs][EXT_PER_ENV]
   bool ext_seen = false, ext_dirty = false;   // dirty: d_ext holds the records of an earlier step
@@ -1596,12 +1602,99 @@ static int join_groups(cc4_handle* h) {
   return 0;
 }
 static int sync_all(cc4_handle* h) {
-  for (int g = h->ngroups - 1; g >= 0; --g) HIPCHK(h, hipStreamSynchronize(h->gstream[g]));
+  // (!groups_busy: whatever the group streams were given, the main stream already waits for -- join_groups, or the joined end of
+  // cc4_run_random_steps -- and a host wait on an idle stream is not free: ~8 us each inside a short timed region)
+  for (int g = h->ngroups - 1; g >= 1; --g) if (h->groups_busy) HIPCHK(h, hipStreamSynchronize(h->gstream[g]));
+  HIPCHK(h, hipStreamSynchronize(h->stream));
   h->groups_busy = false;
   return 0;
 }
 
 // rand: draw the blue actions inside the step kernel from (seed0, t) and record them in the handle's action buffer
+// one group's launch of a step: the kernel cc4_create picked for this handle, on the group's stream, carrying `start` / `stop` as the
+// launch's own timing events (or null)
+static void launch_group(cc4_handle* h, StepArgs a, int g, bool full, hipEvent_t start, hipEvent_t stop) {
+  a.e0 = h->glo[g]; a.n = h->glo[g + 1];
+  const dim3 grid(a.n - a.e0);
+  hipStream_t st = h->gstream[g];
+#ifdef CC4_DEV_FAST     // kernel experiments (tools/ab.sh): only the one-wave counter-mode kernel is instantiated -- a quarter of the compile time
+  if (h->philox_lean) hipExtLaunchKernelGGL(k_step_philox1<false>, grid, dim3(WAVE), offsetof(EnvState, hd), st, start, stop, 0, a);
+  else hipExtLaunchKernelGGL((k_step_philox<false, 1>), grid, dim3(PT), sizeof(EnvState), st, start, stop, 0, a);
+#else
+  if (h->cfg.rng_mode == 1) {
+    if (h->philox_lean) {
+      if (full) hipExtLaunchKernelGGL(k_step_philox1<true>, grid, dim3(WAVE), offsetof(EnvState, hd), st, start, stop, 0, a);
+      else hipExtLaunchKernelGGL(k_step_philox1<false>, grid, dim3(WAVE), offsetof(EnvState, hd), st, start, stop, 0, a);
+    }
+    else if (full) hipExtLaunchKernelGGL((k_step_philox<true, 1>), grid, dim3(PT), sizeof(EnvState), st, start, stop, 0, a);
+    else if (h->philox_minw == 8) hipExtLaunchKernelGGL((k_step_philox<false, 8>), grid, dim3(PT), sizeof(EnvState), st, start, stop, 0, a);
+    else if (h->philox_minw == 7) hipExtLaunchKernelGGL((k_step_philox<false, 7>), grid, dim3(PT), sizeof(EnvState), st, start, stop, 0, a);
+#ifndef CC4_SMALL_MINW
+#define CC4_SMALL_MINW 1
+#endif
+    else hipExtLaunchKernelGGL((k_step_philox<false, CC4_SMALL_MINW>), grid, dim3(PT), sizeof(EnvState), st, start, stop, 0, a);
+  } else {
+    if (full) hipExtLaunchKernelGGL(k_step<true>, grid, dim3(WAVE), offsetof(EnvState, hd), st, start, stop, 0, a);
+    else hipExtLaunchKernelGGL(k_step<false>, grid, dim3(WAVE), offsetof(EnvState, hd), st, start, stop, 0, a);
+  }
+#endif
+}
+
+// ---- one enqueue thread per group stream (cc4_run_random_steps without a communicator).  The groups of a batch never wait for each
+// other, so their launches need not come from one thread: the first launch on a stream that has been synchronised costs the calling
+// thread ~10 us (3.5 us in the steady state), four in a row delay the last group's first kernel by 30-45 us in every timed region;
+// issued side by side they cost one.  A worker spins for a few milliseconds after a call (a loop of calls keeps it hot), then sleeps.
+struct EnqPool {
+  std::vector<std::thread> th;
+  std::mutex mu; std::condition_variable cv;
+  std::atomic<uint64_t> gen{0};
+  std::atomic<int> pending{0}, failed{0};
+  std::atomic<bool> quit{false};
+  StepArgs a{}; int k = 0; uint32_t t0 = 0; bool full = false, first_full_obs = false, join = false;
+  hipEvent_t start[cc4_handle_max_groups] = {}, stop[cc4_handle_max_groups] = {};
+};
+static void enq_run_group(cc4_handle* h, EnqPool* P, int g) {
+  StepArgs a = P->a;
+  for (int i = 0; i < P->k; ++i) {
+    a.rand_t = P->t0 + (uint32_t)i;
+    a.full_obs = (i == 0 && P->first_full_obs) ? 1 : 0;
+    launch_group(h, a, g, P->full, i == 0 ? P->start[g] : nullptr, i == P->k - 1 ? P->stop[g] : nullptr);
+  }
+  if (g > 0 && P->join && hipEventRecord(h->gev[g], h->gstream[g]) != hipSuccess) P->failed.fetch_add(1);   // the main stream waits for it: one host wait per call
+  if (hipGetLastError() != hipSuccess) P->failed.fetch_add(1);
+}
+static void enq_worker(cc4_handle* h, EnqPool* P, int g) {
+  (void)hipSetDevice(h->cfg.device_id);
+  uint64_t seen = 0;
+  for (;;) {
+    auto t0 = std::chrono::steady_clock::now();
+    int spins = 0;
+    while (P->gen.load(std::memory_order_acquire) == seen && !P->quit.load(std::memory_order_relaxed)) {
+      __builtin_ia32_pause();
+      if ((++spins & 1023) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(3)) {
+        std::unique_lock<std::mutex> lk(P->mu);
+        P->cv.wait(lk, [&] { return P->gen.load(std::memory_order_acquire) != seen || P->quit.load(); });
+      }
+    }
+    if (P->quit.load()) return;
+    seen = P->gen.load(std::memory_order_acquire);
+    enq_run_group(h, P, g);
+    P->pending.fetch_sub(1, std::memory_order_release);
+  }
+}
+static void enq_pool_start(cc4_handle* h) {
+  if (h->pool || h->ngroups < 2) return;
+  h->pool = new EnqPool;
+  for (int g = 1; g < h->ngroups; ++g) h->pool->th.emplace_back(enq_worker, h, h->pool, g);
+}
+static void enq_pool_stop(cc4_handle* h) {
+  if (!h->pool) return;
+  { std::lock_guard<std::mutex> lk(h->pool->mu); h->pool->quit.store(true); }
+  h->pool->cv.notify_all();
+  for (auto& t : h->pool->th) t.join();
+  delete h->pool; h->pool = nullptr;
+}
+
 static int launch_step(cc4_handle* h, const int32_t* d_actions, const uint8_t* d_msgs, bool rand = false, uint64_t seed0 = 0,
                        uint32_t t = 0, bool ext_uploaded = false) {
   if (h->ext_seen && h->ext_dirty && !ext_uploaded) {     // this step submits no red / green action: every record says so
@@ -1637,37 +1730,16 @@ static int launch_step(cc4_handle* h, const int32_t* d_actions, const uint8_t* d
              (h->cfg.red_policy & 3) | (h->cfg.green_policy ? GP_SLEEP_BIT : 0) | (h->cfg.green_policy == 2 ? GP_OPEN_BIT : 0) | (h->cfg.blue_policy ? BP_RANDOM_BIT : 0), h->full_obs_next ? 1 : 0,
              (uint32_t)h->cfg.topology_seed, h->d_prof, h->d_reset_ws, h->ext_seen ? h->d_ext : nullptr, 0};
   h->full_obs_next = false;
+#ifdef CC4_DEV_FAST
+  if (h->cfg.rng_mode != 1 || full) { h->err = "CC4_DEV_FAST build: only k_step_philox1<false> and k_step_philox<false, 1> exist"; return -1; }
+#endif
   for (int g = 0; g < h->ngroups; ++g) {
-    a.e0 = h->glo[g]; a.n = h->glo[g + 1];
-    const dim3 grid(a.n - a.e0);
-    hipStream_t st = h->gstream[g];
     // with a communicator, the launch carries ev_step[buf][g] as its stop event: the event rides on the kernel's own completion
     // signal, where a separate hipEventRecord would put a marker packet between two step kernels (~5 us of idle stream time)
     hipEvent_t stop = h->comm ? h->ev_step[buf][g] : h->tev_stop[g];
     hipEvent_t start = h->comm ? nullptr : h->tev_start[g];        // timing rides on the kernels' own signals too: no marker packets
     h->tev_start[g] = h->tev_stop[g] = nullptr;
-#ifdef CC4_DEV_FAST     // kernel experiments (tools/ab.sh): only the one-wave counter-mode kernel is instantiated -- a quarter of the compile time
-    if (h->cfg.rng_mode != 1 || full) { h->err = "CC4_DEV_FAST build: only k_step_philox1<false> and k_step_philox<false, 1> exist"; return -1; }
-    if (h->philox_lean) hipExtLaunchKernelGGL(k_step_philox1<false>, grid, dim3(WAVE), offsetof(EnvState, hd), st, start, stop, 0, a);
-    else hipExtLaunchKernelGGL((k_step_philox<false, 1>), grid, dim3(PT), sizeof(EnvState), st, start, stop, 0, a);
-#else
-    if (h->cfg.rng_mode == 1) {
-      if (h->philox_lean) {
-        if (full) hipExtLaunchKernelGGL(k_step_philox1<true>, grid, dim3(WAVE), offsetof(EnvState, hd), st, start, stop, 0, a);
-        else hipExtLaunchKernelGGL(k_step_philox1<false>, grid, dim3(WAVE), offsetof(EnvState, hd), st, start, stop, 0, a);
-      }
-      else if (full) hipExtLaunchKernelGGL((k_step_philox<true, 1>), grid, dim3(PT), sizeof(EnvState), st, start, stop, 0, a);
-      else if (h->philox_minw == 8) hipExtLaunchKernelGGL((k_step_philox<false, 8>), grid, dim3(PT), sizeof(EnvState), st, start, stop, 0, a);
-      else if (h->philox_minw == 7) hipExtLaunchKernelGGL((k_step_philox<false, 7>), grid, dim3(PT), sizeof(EnvState), st, start, stop, 0, a);
-#ifndef CC4_SMALL_MINW
-#define CC4_SMALL_MINW 1
-#endif
-      else hipExtLaunchKernelGGL((k_step_philox<false, CC4_SMALL_MINW>), grid, dim3(PT), sizeof(EnvState), st, start, stop, 0, a);
-    } else {
-      if (full) hipExtLaunchKernelGGL(k_step<true>, grid, dim3(WAVE), offsetof(EnvState, hd), st, start, stop, 0, a);
-      else hipExtLaunchKernelGGL(k_step<false>, grid, dim3(WAVE), offsetof(EnvState, hd), st, start, stop, 0, a);
-    }
-#endif
+    launch_group(h, a, g, full, start, stop);
     HIPCHK(h, hipGetLastError());
   }
   h->step_event_attached = h->comm != nullptr;
@@ -1801,6 +1873,9 @@ int cc4_create(const cc4_config* cfg, cc4_handle** out) {
     if (const char* v = getenv("CC4_MULTISTEP")) h->multistep = atoi(v) != 0;
     if (getenv("CC4_PERSIST_DEBUG")) fprintf(stderr, "[cc4] k_run_philox: %d blocks per CU resident, multistep %d\n", per_cu, (int)h->multistep);
   }
+  // one enqueue thread per group stream in cc4_run_random_steps (EnqPool): on where the host has cores to spare; CC4_ENQ_THREADS=0/1 decides otherwise
+  h->enq_threads = std::thread::hardware_concurrency() >= 8;
+  if (const char* v = getenv("CC4_ENQ_THREADS")) h->enq_threads = atoi(v) != 0;
   // OFF unless CC4_PERSIST=1: measured (profiles/r04_persistent_kernel_ab.txt), bit-exact but 18-38 % SLOWER than the launch-per-step
   // schedule on four streams -- waves that never meet a launch boundary drift apart over the kernel's ~340 KB of code, and a CU's
   // twenty waves stop sharing their instruction fetches (a launch restarts them together; 98.8 % I-cache hits there).
@@ -1840,6 +1915,7 @@ int cc4_create(const cc4_config* cfg, cc4_handle** out) {
 
 void cc4_destroy(cc4_handle* h) {
   if (!h) return;
+  enq_pool_stop(h);
   (void)hipSetDevice(h->cfg.device_id);
   for (int g = cc4_handle::MAX_GROUPS - 1; g >= 0; --g) if (h->gstream[g]) (void)hipStreamSynchronize(h->gstream[g]);
   if (h->comm_stream) (void)hipStreamSynchronize(h->comm_stream);
@@ -2079,6 +2155,51 @@ int cc4_run_random_steps(cc4_handle* h, uint64_t seed0, uint32_t t0, int32_t k, 
     h->main_ahead = h->ngroups > 1;
     HIPCHK(h, hipStreamSynchronize(h->stream));
     if (ms_step_kernels) HIPCHK(h, hipEventElapsedTime(ms_step_kernels, h->evs[0], h->evs[1]));
+    return 0;
+  }
+  if (h->enq_threads && !h->pool && h->ngroups > 1 && !h->comm) enq_pool_start(h);     // on first use: most handles never come here
+  if (h->pool && (int)h->pool->th.size() == h->ngroups - 1 && !h->comm && !h->evlog_on && !h->ext_seen && !h->d_prof && k >= 1) {
+    // every group's k launches from its own thread (EnqPool); this thread takes group 0
+    const int G = h->ngroups;
+    EnqPool* P = h->pool;
+    if (ms_step_kernels && (int)h->evs.size() < 2 * G) {
+      size_t old = h->evs.size();
+      h->evs.resize(2 * (size_t)G, nullptr);
+      for (size_t i = old; i < h->evs.size(); ++i) HIPCHK(h, hipEventCreate(&h->evs[i]));
+    }
+    if (h->main_ahead) {
+      HIPCHK(h, hipEventRecord(h->mev, h->stream));
+      for (int g = 1; g < G; ++g) HIPCHK(h, hipStreamWaitEvent(h->gstream[g], h->mev, 0));
+      h->main_ahead = false;
+    }
+    P->a = StepArgs{h->d_state, h->d_cold, nullptr, nullptr, h->d_obs, h->d_reward, h->d_done, h->d_err, nullptr, h->d_actions, seed0, t0,
+                    h->cfg.num_envs, h->cfg.autoreset, h->cfg.steps, h->cfg.rng_mode,
+                    (h->cfg.red_policy & 3) | (h->cfg.green_policy ? GP_SLEEP_BIT : 0) | (h->cfg.green_policy == 2 ? GP_OPEN_BIT : 0) | (h->cfg.blue_policy ? BP_RANDOM_BIT : 0),
+                    0, (uint32_t)h->cfg.topology_seed, nullptr, h->d_reset_ws, nullptr, 0};
+    P->k = k; P->t0 = t0; P->full = false; P->first_full_obs = h->full_obs_next; P->join = !getenv("CC4_ENQ_NOJOIN");
+    for (int g = 0; g < G; ++g) { P->start[g] = ms_step_kernels ? h->evs[2 * g] : nullptr; P->stop[g] = ms_step_kernels ? h->evs[2 * g + 1] : nullptr; }
+    P->failed.store(0);
+    P->pending.store(G - 1, std::memory_order_relaxed);
+    auto c0 = std::chrono::steady_clock::now();
+    { std::lock_guard<std::mutex> lk(P->mu); P->gen.fetch_add(1, std::memory_order_release); }
+    P->cv.notify_all();
+    enq_run_group(h, P, 0);
+    while (P->pending.load(std::memory_order_acquire) != 0) __builtin_ia32_pause();
+    h->stat_launch_us += std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - c0).count();
+    h->stat_steps += k;
+    h->full_obs_next = false;
+    h->groups_busy = true;
+    if (P->failed.load()) { h->err = "cc4_run_random_steps: a step launch failed"; return -1; }
+    if (P->join) {
+      for (int g = 1; g < G; ++g) HIPCHK(h, hipStreamWaitEvent(h->stream, h->gev[g], 0));
+      HIPCHK(h, hipStreamSynchronize(h->stream));
+      h->groups_busy = false;
+    } else if (sync_all(h)) return -1;
+    if (ms_step_kernels) {
+      float worst = 0.f;
+      for (int g = 0; g < G; ++g) { float ms = 0.f; HIPCHK(h, hipEventElapsedTime(&ms, h->evs[2 * g], h->evs[2 * g + 1])); if (ms > worst) worst = ms; }
+      *ms_step_kernels = worst;
+    }
     return 0;
   }
   // Timing: HIP events on the launch streams around chunks of TIMED_CHUNK consecutive steps (an event pair around every single
