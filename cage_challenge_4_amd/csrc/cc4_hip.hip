@@ -1052,6 +1052,36 @@ __global__ __launch_bounds__(WAVE) void k_census(int32_t* count, long long ticks
   if (threadIdx.x == 1) reinterpret_cast<volatile uint32_t*>(lds)[0] = 0;
 }
 
+// the one-wave kernel's in-kernel scenario generation (an episode regenerates once in steps-per-episode launches)
+#if defined(CC4_EXP_RESET_CALL)
+__device__ __attribute__((noinline))
+#else
+__device__ __forceinline__
+#endif
+void philox1_autoreset(const StepArgs& a, const int e, const int lane, EnvState* s, HostDyn* const hd, EnvCold* const cold_e, StepWork& work) {
+    // new episode on the same key (CybORG.reset(seed=None)): the phases of env_reset_counter_mode, hosts on lanes; the pid
+    // bitmaps of the generation live in HBM here (LDS bounds this kernel's residency, and this path runs once per episode)
+    uint32_t* const ws = a.reset_ws + (size_t)e * RESET_WS_WORDS;
+    reset_zero(s, hd, cold_e, lane, WAVE);
+    __syncthreads();
+    Rng rr; ResetCarry carry; carry.env_key = 0;     // lane 0: main reset stream in registers, across the phases
+    Ctx xm{s, cold_e, &rr, hd, &work};
+    if (lane == 0) { rr = s->rng; rr.mode = 1; carry = reset_topology(xm, 0, a.steps, true, a.policy, a.topo, ws, true); }
+    __syncthreads();
+    Rng rh; rng_fork(&rh, &s->rng, ST_GEN_HOST); rh.mode = 1;
+    Ctx xh{s, cold_e, &rh, hd, &work};
+    for (int h = lane; h < MAXH; h += WAVE) reset_gen_host(xh, h);
+    __syncthreads();
+    if (lane == 0) { reset_pid_serial(xm, reset_used_set(s)); reset_agents(xm); }     // pid uniqueness in the reference's order (one lane; once per episode)
+    __syncthreads();
+    reset_used_clear(s, lane, WAVE);
+    __syncthreads();
+    for (int h = lane; h < MAXH; h += WAVE) reset_host_sessions(xh, h);
+    __syncthreads();
+    if (lane == 0) { reset_finish(xm, carry, a.steps, a.topo, true); a.reward[e] = s->reward; a.done[e] = s->done; }
+    __syncthreads();
+}
+
 // One step of one episode on one wavefront: the body of k_step_philox1 and of the persistent run kernel.  PERSIST: item_k = the
 // step's number within the launch (the first item of an episode rewrites all its observation values when asked to).
 template <bool LOG, bool PERSIST>
@@ -1079,27 +1109,7 @@ __device__ __forceinline__ void philox1_body(StepArgs a, const int e, const uint
   if (prof && lane == 0) prof[11] += clock64() - t_begin;
   const bool do_reset = a.autoreset && s->done;
   if (do_reset) {
-    // new episode on the same key (CybORG.reset(seed=None)): the phases of env_reset_counter_mode, hosts on lanes; the pid
-    // bitmaps of the generation live in HBM here (LDS bounds this kernel's residency, and this path runs once per episode)
-    uint32_t* const ws = a.reset_ws + (size_t)e * RESET_WS_WORDS;
-    reset_zero(s, hd, cold_e, lane, WAVE);
-    __syncthreads();
-    Rng rr; ResetCarry carry; carry.env_key = 0;     // lane 0: main reset stream in registers, across the phases
-    Ctx xm{s, cold_e, &rr, hd, &work};
-    if (lane == 0) { rr = s->rng; rr.mode = 1; carry = reset_topology(xm, 0, a.steps, true, a.policy, a.topo, ws, true); }
-    __syncthreads();
-    Rng rh; rng_fork(&rh, &s->rng, ST_GEN_HOST); rh.mode = 1;
-    Ctx xh{s, cold_e, &rh, hd, &work};
-    for (int h = lane; h < MAXH; h += WAVE) reset_gen_host(xh, h);
-    __syncthreads();
-    if (lane == 0) { reset_pid_serial(xm, reset_used_set(s)); reset_agents(xm); }     // pid uniqueness in the reference's order (one lane; once per episode)
-    __syncthreads();
-    reset_used_clear(s, lane, WAVE);
-    __syncthreads();
-    for (int h = lane; h < MAXH; h += WAVE) reset_host_sessions(xh, h);
-    __syncthreads();
-    if (lane == 0) { reset_finish(xm, carry, a.steps, a.topo, true); a.reward[e] = s->reward; a.done[e] = s->done; }
-    __syncthreads();
+    philox1_autoreset(a, e, lane, s, hd, cold_e, work);
   } else {
     const int st_now = s->step_count;
     const bool step_ok = step_phase_of(st_now, s->phase_len[0], s->phase_len[1], s->phase_len[2]) >= 0;
@@ -1573,7 +1583,8 @@ static void configure_groups(cc4_handle* h, int ng) {
   h->philox_minw = bpc <= 5 ? 1 : (bpc == 8 ? 8 : 7);
   // ... and with several launches per step what counts is what they put on a CU together (r03 profiles: three launches, register
   // budget 1 / 7 / 8: 1024 episodes 176 / 174 / 164 M, 2048: 295 / 302 / 278, 4096: 355 / 442 / 417)
-  if (ng > 1) h->philox_minw = bpc_all <= 5 ? 1 : 7;
+  // (r04 flags, four launches: 1536 episodes 269 / 266 / 257, 2048: 329 / 333 / 323, 3072: 364 / 433 / 423, 4096: 369 / 471 / 490 -- one wave: 507)
+  if (ng > 1) h->philox_minw = bpc_all <= 6 ? 1 : 7;
   if (const char* v = getenv("CC4_PHILOX_MINW")) h->philox_minw = atoi(v);   // tuning override: 1, 7 or 8
   // The one-wave-per-episode build when a single launch puts more than eight episodes on a CU, or the launches of a step
   // together more than thirteen.  Measured on MI355X (M agent-env steps/s, four waves / one wave per episode; r02, one launch per

@@ -14,7 +14,11 @@
 #include <stddef.h>
 
 #if defined(__HIPCC__)
+#if defined(CC4_EXP_NO_FORCEINLINE)       // experiment (profiles/r04_compiler_flags_ab.txt): the inliner's own choice
+#define CC4_HD __host__ __device__ inline
+#else
 #define CC4_HD __host__ __device__ __forceinline__
+#endif
 #define CC4_UNROLL _Pragma("unroll")     // small fixed-trip loops over register arrays must be fully unrolled on the device:
 #else                                     // a dynamically indexed local array lives in scratch (global) memory there
 #define CC4_HD inline
