@@ -87,6 +87,9 @@ def summarise(secs, kms, steps, total_envs):
     return {'value': 5.0 * total_envs * steps * n / tot, 'ms_per_step': tot / (n * steps) * 1e3,
             'ms_per_step_median_region': med / steps * 1e3, 'regions': n,
             'region_spread': (max(secs) - min(secs)) / med if n > 1 else 0.0,
+            # the five longest regions as (index, seconds / median): where a short-region run loses time (episodes regenerate in one region
+            # out of steps-per-episode / K; anything else that long is the host's or the box's)
+            'slowest_regions': [[i, round(secs[i] / med, 2)] for i in sorted(range(n), key=lambda i: -secs[i])[:5]],
             'launch_ms': sum(kms) / (n * steps)}
 
 
@@ -393,7 +396,7 @@ def main():
                 'last_step_reward_sum': digest[0], 'last_step_done_count': digest[1],
                 'steps_run': args.warmup + main_res['regions'] * args.steps,
                 'timed_regions': main_res['regions'], 'region_steps': args.steps, 'ms_per_step_median_region': main_res['ms_per_step_median_region'],
-                'region_spread': main_res['region_spread'],
+                'region_spread': main_res['region_spread'], 'slowest_regions': main_res['slowest_regions'],
                 'autoreset_in_timed_region': main_res['autoreset_launches_in_timed_regions'] > 0,
                 'autoreset_launches_in_timed_regions': main_res['autoreset_launches_in_timed_regions'],
             },
