@@ -247,6 +247,32 @@ def test_timed_bench_path_matches_oracle(n, kernel, run_kernel):
     dev.close()
 
 
+@pytest.mark.parametrize('threads', ['0', '1'])
+def test_enqueue_threads_change_nothing(threads, monkeypatch):
+    """cc4_run_random_steps with one enqueue thread per group stream (the default where the host has eight hardware threads)
+    and from the calling thread alone: bursts of 1 / 20 / 3 / 57 steps across a regeneration against the oracle, handles created and
+    destroyed in a row (a worker pool is joined at cc4_destroy)."""
+    monkeypatch.setenv('CC4_ENQ_THREADS', threads)
+    n, steps, seed0 = 4096, 60, 99
+    for rep in range(3):
+        dev = _dev(n, steps=steps, rng_mode=1, autoreset=True)
+        assert dev.launches_per_step in (3, 4) and dev.run_kernel == 'k_step_philox1'
+        ora = OracleVecEnv(n, steps=steps, rng_mode=1, autoreset=True)
+        assert np.array_equal(dev.reset(seeds=seed0 + rep), ora.reset_batch(seed0 + rep))
+        t = 0
+        for K in (1, 20, 3, 57):
+            dev.run_random_steps(seed0, t, K, timed=(K != 3))
+            for k in range(K):
+                o = ora.step_batch(random_actions(seed0, t + k, n))
+            t += K
+            dev.synchronize(); dev._fetch()
+            assert np.array_equal(dev._obs, o[0]) and np.array_equal(dev._rew, o[1]) and np.array_equal(dev._done.astype(bool), o[2]), (rep, K)
+        d = dev.step(random_actions(seed0, t, n)); o = ora.step_batch(random_actions(seed0, t, n))     # a plain step behind the joined end
+        assert np.array_equal(d[0], o[0]) and np.array_equal(d[1], o[1])
+        assert np.array_equal(dev.rng_state(), ora.rng_state())
+        dev.close(); ora.close()
+
+
 def test_device_random_action_kernel_matches_host_restatement():
     import ctypes
     n = 1024
