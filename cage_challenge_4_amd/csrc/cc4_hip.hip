@@ -1328,11 +1328,24 @@ __global__ __launch_bounds__(WAVE, 5) void k_run_philox1(StepArgs a, RunArgs ra)
       if (got == -2) item_lds[0] = -1;
     }
     __syncthreads();
+#if defined(CC4_EXP_PERSIST_INLINE)
+    // the body inlined into the item loop: the item's episode and step number as wave-uniform scalars (read from LDS they would be
+    // vector values, and every address the step derives from them with them), and the lane id opaque per item, so that nothing the
+    // step derives from it is hoisted out of the loop and held in registers across the whole step
+    const int e = __builtin_amdgcn_readfirstlane(item_lds[0]);
+    if (e < 0) return;
+    const uint32_t item_k = (uint32_t)__builtin_amdgcn_readfirstlane(item_lds[1]);
+    __syncthreads();
+    int lane_i = (int)threadIdx.x;
+    asm volatile("" : "+v"(lane_i));
+    philox1_body<false, true>(a, e, ra.t0 + item_k, item_k, lane_i);
+#else
     const int e = item_lds[0];
     if (e < 0) return;
     const uint32_t item_k = (uint32_t)item_lds[1];
     __syncthreads();
     philox1_item(a, e, ra.t0 + item_k, item_k);
+#endif
     // the item is done when everything it wrote has left this wave: then the next step of the episode may start (on this CU)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
