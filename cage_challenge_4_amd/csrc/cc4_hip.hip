@@ -694,7 +694,7 @@ __device__ __forceinline__ void dma_wait() { asm volatile("s_waitcnt vmcnt(0)" :
 // RUN (k_run_philox): the row stays in LDS from one step of the episode to the next -- run_flags bit 0: not the first step of the
 // launch (nothing is staged in), bit 1: the last one (the whole row goes back; before it, none of it)
 template <bool LOG, bool RUN = false>
-__device__ __forceinline__ void philox4_body(StepArgs a, const int run_flags = 0) {
+__device__ __forceinline__ void philox4_body(StepArgs a, const int run_flags = 0, const int tid_in = -1) {
   extern __shared__ uint4 lds[];
   __shared__ int conflict_lds;
   __shared__ alignas(16) uint32_t reset_ws[RESET_WS_WORDS];   // pid bitmaps of the scenario generation (autoreset); during a step: the green agents' pre-computed blocks
@@ -704,7 +704,7 @@ __device__ __forceinline__ void philox4_body(StepArgs a, const int run_flags = 0
   __shared__ uint8_t obs_bytes[OBS_TOTAL + 2];   // byte-per-value copy of the observations, only for the packed exchange row
   __shared__ uint8_t glist[2][2][MAXG];  // green agents by action type (0 AccessService, 1 LocalWork) and drawing wave
   __shared__ unsigned long long prof_lds[16];
-  const int e = a.e0 + (int)blockIdx.x, tid = threadIdx.x, lane = tid & 63;
+  const int e = a.e0 + (int)blockIdx.x, tid = tid_in >= 0 ? tid_in : (int)threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform by construction: kept in an SGPR
   if (e >= a.n) return;
   EnvCold* const cold_e = cold_at(a.cold, (size_t)e, cold_row_bytes(a.steps));
@@ -984,18 +984,31 @@ __global__ __launch_bounds__(PT, MINW) void k_step_philox(StepArgs a) { philox4_
 // every time are its outputs: observations, reward, done, error word, the drawn actions).
 // The body is a real call: inlined into the step loop its loop-invariant values are hoisted and held across the whole step.
 // (register budget of five blocks per CU, stated for the callee as well: left to itself it takes 212 VGPRs)
+// (r04, end of round: the body INLINED -- with the thread id made opaque per step, so that nothing derived from it is hoisted out of the loop
+// and held across the whole step; ~90 VGPRs spill, and it is still 30 % faster than the call: a kernel that contains a call loses a quarter
+// of its rate, profiles/r04_compiler_flags_ab.txt.  -DCC4_EXP_RUN_CALL keeps the call form for the A/B.)
 __device__ __attribute__((noinline)) void philox4_item(const StepArgs& a, int run_flags) { philox4_body<false, true>(a, run_flags); }
-__global__ __launch_bounds__(PT, 5) void k_run_philox(StepArgs a, int K, uint32_t t0) {
+template <int MINB>
+__device__ __forceinline__ void run_philox_loop(StepArgs a, int K, uint32_t t0) {
   a.prof = nullptr; a.obs8 = nullptr; a.ext = nullptr;
   const int full0 = a.full_obs;
   for (int k = 0; k < K; ++k) {
     a.rand_t = t0 + (uint32_t)k;
     a.full_obs = k == 0 ? full0 : 0;
+#if defined(CC4_EXP_RUN_CALL)
     philox4_item(a, (k > 0 ? 1 : 0) | (k == K - 1 ? 2 : 0));
+#else
+    { int tid_i = (int)threadIdx.x; asm volatile("" : "+v"(tid_i));
+      philox4_body<false, true>(a, (k > 0 ? 1 : 0) | (k == K - 1 ? 2 : 0), tid_i); }
+#endif
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
   }
 }
+__global__ __launch_bounds__(PT, 5) void k_run_philox(StepArgs a, int K, uint32_t t0) { run_philox_loop<5>(a, K, t0); }
+// the same with the register budget of eight blocks per CU: batches of up to 8 x CUs episodes (2048 on MI355X) resident at once
+__global__ __launch_bounds__(PT, 8) void k_run_philox8(StepArgs a, int K, uint32_t t0) { run_philox_loop<8>(a, K, t0); }
+// (a build with the budget of four blocks per CU -- 128 registers per lane, 1024 episodes on 256 CUs -- is 0.7 % faster than the one of five: not kept)
 
 // ---------------------------------------------------------------- Philox mode, one wavefront per episode
 // The same step as k_step_philox with the agents on the LANES of a single wave instead of on four waves: red agent r on lane
@@ -1523,6 +1536,7 @@ struct cc4_handle {
   int run_P = 0, run_grid = 0;    // partitions (= CUs that take waves), waves per launch; 0: the persistent path is off
   struct EnqPool* pool = nullptr; // one enqueue thread per group stream beyond the first (cc4_run_random_steps; enq_*)
   bool enq_threads = false;
+  int multistep_minb = 5;         // which build of it: 5 (k_run_philox) or 8 blocks per CU (k_run_philox8)
   bool multistep = false;         // k_run_philox: cc4_run_random_steps as ONE launch, every block looping over the steps of its episode
   ExtAct* d_ext = nullptr;        // [num_envs][EXT_PER_ENV]
   bool ext_seen = false, ext_dirty = false;   // dirty: d_ext holds the records of an earlier step
@@ -1793,7 +1807,7 @@ const char* cc4_step_kernel(cc4_handle* h) {
 const char* cc4_run_kernel(cc4_handle* h) {
   if (!h) return "";
   const bool plain = !h->comm && !h->evlog_on && !h->ext_seen && !h->d_prof;
-  if (plain && h->multistep) return "k_run_philox";
+  if (plain && h->multistep) return h->multistep_minb == 8 ? "k_run_philox8" : "k_run_philox";
   if (plain && h->run_P > 0) return "k_run_philox1";
   return cc4_step_kernel(h);
 }
@@ -1891,11 +1905,18 @@ int cc4_create(const cc4_config* cfg, cc4_handle** out) {
   HIPCHK(h, hipStreamSynchronize(h->stream));
   if (cfg->rng_mode == 1 && !h->philox_lean) {
     // the multi-step form of the four-wave kernel (k_run_philox): for batches the chip holds at once
-    int per_cu = 0;
+    int per_cu = 0, per_cu8 = 0;
     HIPCHK(h, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_run_philox, PT, sizeof(EnvState)));
+    HIPCHK(h, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu8, k_run_philox8, PT, sizeof(EnvState)));
     h->multistep = per_cu > 0 && cfg->num_envs <= per_cu * h->cus;
-    if (const char* v = getenv("CC4_MULTISTEP")) h->multistep = atoi(v) != 0;
-    if (getenv("CC4_PERSIST_DEBUG")) fprintf(stderr, "[cc4] k_run_philox: %d blocks per CU resident, multistep %d\n", per_cu, (int)h->multistep);
+    h->multistep_minb = 5;
+    if (!h->multistep && per_cu8 > per_cu && cfg->num_envs <= per_cu8 * h->cus) { h->multistep = true; h->multistep_minb = 8; }
+    if (const char* v = getenv("CC4_MULTISTEP")) {            // 0: off; 1: on (the build that holds the batch); 5 / 8: that build
+      const int m = atoi(v);
+      h->multistep = m != 0;
+      if (m == 5 || m == 8) h->multistep_minb = m;
+    }
+    if (getenv("CC4_PERSIST_DEBUG")) fprintf(stderr, "[cc4] k_run_philox: %d / %d blocks per CU resident, multistep %d (build %d)\n", per_cu, per_cu8, (int)h->multistep, h->multistep_minb);
   }
   // one enqueue thread per group stream in cc4_run_random_steps (EnqPool): on where the host has cores to spare; CC4_ENQ_THREADS=0/1 decides otherwise
   h->enq_threads = std::thread::hardware_concurrency() >= 8;
@@ -2147,8 +2168,12 @@ int cc4_run_random_steps(cc4_handle* h, uint64_t seed0, uint32_t t0, int32_t k, 
                h->full_obs_next ? 1 : 0, (uint32_t)h->cfg.topology_seed, nullptr, h->d_reset_ws, nullptr, 0};
     if (ms_step_kernels && h->evs.size() < 2) { h->evs.resize(2, nullptr); for (auto& e : h->evs) if (!e) HIPCHK(h, hipEventCreate(&e)); }
     auto c0 = std::chrono::steady_clock::now();
-    hipExtLaunchKernelGGL(k_run_philox, dim3(h->cfg.num_envs), dim3(PT), sizeof(EnvState), h->stream,
-                          ms_step_kernels ? h->evs[0] : nullptr, ms_step_kernels ? h->evs[1] : nullptr, 0, a, (int)k, t0);
+    if (h->multistep_minb == 8)
+      hipExtLaunchKernelGGL(k_run_philox8, dim3(h->cfg.num_envs), dim3(PT), sizeof(EnvState), h->stream,
+                            ms_step_kernels ? h->evs[0] : nullptr, ms_step_kernels ? h->evs[1] : nullptr, 0, a, (int)k, t0);
+    else
+      hipExtLaunchKernelGGL(k_run_philox, dim3(h->cfg.num_envs), dim3(PT), sizeof(EnvState), h->stream,
+                            ms_step_kernels ? h->evs[0] : nullptr, ms_step_kernels ? h->evs[1] : nullptr, 0, a, (int)k, t0);
     HIPCHK(h, hipGetLastError());
     h->stat_launch_us += std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - c0).count();
     h->stat_steps += k;
