@@ -1341,7 +1341,7 @@ __global__ __launch_bounds__(WAVE, 5) void k_run_philox1(StepArgs a, RunArgs ra)
       if (got == -2) item_lds[0] = -1;
     }
     __syncthreads();
-#if defined(CC4_EXP_PERSIST_INLINE)
+#if !defined(CC4_EXP_PERSIST_CALL)
     // the body inlined into the item loop: the item's episode and step number as wave-uniform scalars (read from LDS they would be
     // vector values, and every address the step derives from them with them), and the lane id opaque per item, so that nothing the
     // step derives from it is hoisted out of the loop and held in registers across the whole step
