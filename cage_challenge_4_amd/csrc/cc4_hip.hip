@@ -1366,6 +1366,22 @@ __global__ __launch_bounds__(WAVE, 5) void k_run_philox1(StepArgs a, RunArgs ra)
   }
 }
 
+// The plain multi-step form of the one-wave kernel: one wave per episode, every wave loops over the K steps of ITS episode -- no
+// tickets, no affinity: a wave only reads what it wrote itself.  For batches one launch holds at once (cc4_create; CC4_RUN1=0/1
+// overrides): more waves than residency slots would simply start as slots free up (8192 episodes: 5120 at once, the other 3072
+// behind them on a chip that is no longer full).
+__global__ __launch_bounds__(WAVE, 5) void k_run_philox1m(StepArgs a, int K, uint32_t t0) {
+  a.prof = nullptr; a.obs8 = nullptr; a.ext = nullptr;
+  const int e = (int)blockIdx.x;
+  for (int k = 0; k < K; ++k) {
+    int lane_i = (int)threadIdx.x;
+    asm volatile("" : "+v"(lane_i));
+    philox1_body<false, true>(a, e, t0 + (uint32_t)k, (uint32_t)k, lane_i);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+  }
+}
+
 struct ResetArgs {
   EnvState* st; EnvCold* cold; const uint64_t* seeds; const uint8_t* env_mask;
   int32_t* obs; float* reward; uint8_t* done; uint32_t* err; uint8_t* mask;
@@ -1536,6 +1552,7 @@ struct cc4_handle {
   int run_P = 0, run_grid = 0;    // partitions (= CUs that take waves), waves per launch; 0: the persistent path is off
   struct EnqPool* pool = nullptr; // one enqueue thread per group stream beyond the first (cc4_run_random_steps; enq_*)
   bool enq_threads = false;
+  bool run1m = false;             // cc4_run_random_steps as ONE launch of k_run_philox1m (batches of the one-wave kernel that one launch holds)
   int multistep_minb = 5;         // which build of it: 5 (k_run_philox) or 8 blocks per CU (k_run_philox8)
   bool multistep = false;         // k_run_philox: cc4_run_random_steps as ONE launch, every block looping over the steps of its episode
   ExtAct* d_ext = nullptr;        // [num_envs][EXT_PER_ENV]
@@ -1808,6 +1825,7 @@ const char* cc4_run_kernel(cc4_handle* h) {
   if (!h) return "";
   const bool plain = !h->comm && !h->evlog_on && !h->ext_seen && !h->d_prof;
   if (plain && h->multistep) return h->multistep_minb == 8 ? "k_run_philox8" : "k_run_philox";
+  if (plain && h->run1m) return "k_run_philox1m";
   if (plain && h->run_P > 0) return "k_run_philox1";
   return cc4_step_kernel(h);
 }
@@ -1917,6 +1935,15 @@ int cc4_create(const cc4_config* cfg, cc4_handle** out) {
       if (m == 5 || m == 8) h->multistep_minb = m;
     }
     if (getenv("CC4_PERSIST_DEBUG")) fprintf(stderr, "[cc4] k_run_philox: %d / %d blocks per CU resident, multistep %d (build %d)\n", per_cu, per_cu8, (int)h->multistep, h->multistep_minb);
+  }
+  if (cfg->rng_mode == 1 && h->philox_lean) {
+    // the plain multi-step form of the one-wave kernel (k_run_philox1m) where one launch holds the whole batch: 20 waves per CU
+    // (4096 episodes 507 -> 709 M, 5120: 586 -> 811 M; beyond the residency the second round runs on a half-empty chip and four
+    // streams of per-step launches win: 8192: 740 vs 789 M, 16384: 812 vs 864 M -- profiles/r04_run1m_ab.txt)
+    int per_cu = 0;
+    HIPCHK(h, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_run_philox1m, WAVE, offsetof(EnvState, hd)));
+    h->run1m = per_cu > 0 && cfg->num_envs <= per_cu * h->cus;
+    if (const char* v = getenv("CC4_RUN1")) h->run1m = atoi(v) != 0;
   }
   // one enqueue thread per group stream in cc4_run_random_steps (EnqPool): on where the host has cores to spare; CC4_ENQ_THREADS=0/1 decides otherwise
   h->enq_threads = std::thread::hardware_concurrency() >= 8;
@@ -2176,6 +2203,23 @@ int cc4_run_random_steps(cc4_handle* h, uint64_t seed0, uint32_t t0, int32_t k, 
                             ms_step_kernels ? h->evs[0] : nullptr, ms_step_kernels ? h->evs[1] : nullptr, 0, a, (int)k, t0);
     HIPCHK(h, hipGetLastError());
     h->stat_launch_us += std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - c0).count();
+    h->stat_steps += k;
+    h->full_obs_next = false;
+    h->main_ahead = h->ngroups > 1;
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    if (ms_step_kernels) HIPCHK(h, hipEventElapsedTime(ms_step_kernels, h->evs[0], h->evs[1]));
+    return 0;
+  }
+  if (h->run1m && !h->comm && !h->evlog_on && !h->ext_seen && !h->d_prof && k >= 2) {
+    if (join_groups(h)) return -1;
+    StepArgs a{h->d_state, h->d_cold, nullptr, nullptr, h->d_obs, h->d_reward, h->d_done, h->d_err, nullptr, h->d_actions, seed0, t0,
+               h->cfg.num_envs, h->cfg.autoreset, h->cfg.steps, h->cfg.rng_mode,
+               (h->cfg.red_policy & 3) | (h->cfg.green_policy ? GP_SLEEP_BIT : 0) | (h->cfg.green_policy == 2 ? GP_OPEN_BIT : 0) | (h->cfg.blue_policy ? BP_RANDOM_BIT : 0),
+               h->full_obs_next ? 1 : 0, (uint32_t)h->cfg.topology_seed, nullptr, h->d_reset_ws, nullptr, 0};
+    if (ms_step_kernels && h->evs.size() < 2) { h->evs.resize(2, nullptr); for (auto& e : h->evs) if (!e) HIPCHK(h, hipEventCreate(&e)); }
+    hipExtLaunchKernelGGL(k_run_philox1m, dim3(h->cfg.num_envs), dim3(WAVE), offsetof(EnvState, hd), h->stream,
+                          ms_step_kernels ? h->evs[0] : nullptr, ms_step_kernels ? h->evs[1] : nullptr, 0, a, (int)k, t0);
+    HIPCHK(h, hipGetLastError());
     h->stat_steps += k;
     h->full_obs_next = false;
     h->main_ahead = h->ngroups > 1;

@@ -210,8 +210,9 @@ def test_bench_configuration_matches_oracle_every_step(n, red_policy, blue_polic
     dev.close()
 
 
-@pytest.mark.parametrize('n,kernel,run_kernel', [(8192, 'k_step_philox1', 'k_step_philox1'), (1024, 'k_step_philox', 'k_run_philox'), (2048, 'k_step_philox', 'k_run_philox8')],
-                         ids=['8192', '1024-multistep', '2048-multistep8'])
+@pytest.mark.parametrize('n,kernel,run_kernel', [(8192, 'k_step_philox1', 'k_step_philox1'), (1024, 'k_step_philox', 'k_run_philox'), (2048, 'k_step_philox', 'k_run_philox8'),
+                                                  (4096, 'k_step_philox1', 'k_run_philox1m')],
+                         ids=['8192', '1024-multistep', '2048-multistep8', '4096-multistep1'])
 def test_timed_bench_path_matches_oracle(n, kernel, run_kernel):
     """the exact region bench.py times -- cc4_run_random_steps on k_step_philox1, 8192 episodes, the handle's own
     launch grouping, no override, no communicator: the blue actions are drawn IN the step kernel on the bank lanes (BK_BRAND) --
@@ -254,10 +255,11 @@ def test_enqueue_threads_change_nothing(threads, monkeypatch):
     and from the calling thread alone: bursts of 1 / 20 / 3 / 57 steps across a regeneration against the oracle, handles created and
     destroyed in a row (a worker pool is joined at cc4_destroy)."""
     monkeypatch.setenv('CC4_ENQ_THREADS', threads)
+    monkeypatch.setenv('CC4_RUN1', '0')
     n, steps, seed0 = 4096, 60, 99
     for rep in range(3):
         dev = _dev(n, steps=steps, rng_mode=1, autoreset=True)
-        assert dev.launches_per_step in (3, 4) and dev.run_kernel == 'k_step_philox1'
+        assert dev.launches_per_step in (3, 4) and dev.run_kernel == 'k_step_philox1'      # (CC4_RUN1=0 below: the per-step launches are what the threads serve)
         ora = OracleVecEnv(n, steps=steps, rng_mode=1, autoreset=True)
         assert np.array_equal(dev.reset(seeds=seed0 + rep), ora.reset_batch(seed0 + rep))
         t = 0
