@@ -310,7 +310,7 @@ def main():
         out['launches_per_step'] = e.launches_per_step      # of the per-step kernel (`kernel`); see run_kernel
         # what cc4_run_random_steps launches: the step kernel once per step and group, or -- a batch the chip holds at once -- ONE launch
         # of the multi-step kernel per timed region (k_run_philox: every block loops over the steps of its episode, the row stays in LDS)
-        out['run_kernel'] = e.run_kernel
+        out['run_kernel'] = e.run_kernel_for(args.steps)
         return out
 
     main_res = measure(env, lo, total_envs)
@@ -374,6 +374,11 @@ def main():
         # launch_ms = average launch-to-launch period on the slowest group's stream (HIP events, cc4_run_random_steps) = the
         # kernel's average duration in rocprofv3 --stats; achieved = lps x algorithmic bytes of one launch / launch_ms
         lps = main_res['launches_per_step']
+        # one-launch forms (run_kernel k_run_philox / k_run_philox8 / k_run_philox1m / k_run_philox1: cc4_run_random_steps issues the K steps of
+        # a timed region as ONE launch): launch_ms from the library is that launch's duration / K = the kernel time per step; the launch
+        # itself (what rocprofv3 --stats averages) lasts steps_per_launch times as long and moves steps_per_launch times the bytes
+        one_launch = main_res['run_kernel'] != env.step_kernel
+        spl = args.steps if one_launch else 1
         achieved = bytes_per_env * n_local / (launch_ms * 1e-3) / 1e9
         # live bytes: the agent part + the 64-byte rows of the hosts that exist in the episode (the grid has 137 positions)
         useful = 2 * (hot + 64.0 * mean_hosts) + 4 * 578 + 29
@@ -409,12 +414,18 @@ def main():
                          # 8 TB/s the memory system actually carried
                          'hbm_counter_frac': (traffic / (launch_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS) if traffic else None,
                          'traffic': traffic, 'traffic_source': traffic_src,
-                         'kernel': env.step_kernel, 'run_kernel': main_res['run_kernel'], 'launch_ms': launch_ms, 'launches_per_step': lps,
-                         'episodes_per_launch': n_local / lps,
-                         'algorithmic_bytes_per_launch': bytes_per_env * n_local / lps,
+                         'kernel': main_res['run_kernel'], 'step_kernel': env.step_kernel, 'run_kernel': main_res['run_kernel'],
+                         'step_ms': launch_ms, 'steps_per_launch': spl, 'launch_ms': launch_ms * spl,
+                         'launches_per_step': (1.0 / spl) if one_launch else lps,
+                         'episodes_per_launch': n_local if one_launch else n_local / lps,
+                         'algorithmic_bytes_per_launch': bytes_per_env * n_local * spl if one_launch else bytes_per_env * n_local / lps,
                          'algorithmic_bytes_per_step': bytes_per_env * n_local,
-                         'note': f'a step = {lps} concurrent launch(es) of {env.step_kernel} on separate streams, {n_local / lps:.0f} episodes each; '
-                                 'achieved = launches_per_step x algorithmic_bytes_per_launch / launch_ms; traffic is per step too',
+                         'note': (f'a timed region of {spl} steps = ONE launch of {main_res["run_kernel"]} over all {n_local} episodes (the per-step kernel of this '
+                                  f'handle is {env.step_kernel}); launch_ms = that launch, step_ms = launch_ms / steps_per_launch; '
+                                  'achieved = algorithmic_bytes_per_launch / launch_ms; traffic is per step (PMC passes of the per-step kernel: same body, same bytes)'
+                                  if one_launch else
+                                  f'a step = {lps} concurrent launch(es) of {env.step_kernel} on separate streams, {n_local / lps:.0f} episodes each; '
+                                  'achieved = launches_per_step x algorithmic_bytes_per_launch / launch_ms; traffic is per step too'),
                          'useful_bytes_per_step': useful * n_local, 'useful_frac': useful * n_local / (launch_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
                          'useful_note': f'live bytes only: agent part {hot} B + 64 B x {mean_hosts:.1f} existing hosts (of 137 grid positions), in and out'},
         }

@@ -74,6 +74,7 @@ SIGNATURES = {
     'cc4_hot_bytes': (ctypes.c_size_t, []),
     'cc4_step_kernel': (ctypes.c_char_p, [_P]),
     'cc4_run_kernel': (ctypes.c_char_p, [_P]),
+    'cc4_run_kernel_for': (ctypes.c_char_p, [_P, ctypes.c_int32]),
     'cc4_get_state': (ctypes.c_int, [_P, ctypes.c_int32, _P]),
     'cc4_set_state': (ctypes.c_int, [_P, ctypes.c_int32, _P]),
     'cc4_cold_bytes': (ctypes.c_size_t, [_P]),

@@ -1550,6 +1550,9 @@ struct cc4_handle {
   uint32_t* d_run = nullptr;      // [P ticket | P owner | n progress]
   int16_t* d_slot_part = nullptr; // [CC4_SLOTS]
   int run_P = 0, run_grid = 0;    // partitions (= CUs that take waves), waves per launch; 0: the persistent path is off
+  int persist_state = -1;         // -1 off / unavailable, 0 not set up yet (persist_setup on first use), 1 on
+  int persist_min_k = 32;         // shorter calls keep the per-step launches: the launch's ramp and tail (a CU's partition ends when its slowest episodes do)
+                                  // cost 170-250 us, four steps' worth; K = 20: 700-757 vs 736-745 M over three boxes, K = 32: 812 vs 759 M (CC4_PERSIST_MIN_K)
   struct EnqPool* pool = nullptr; // one enqueue thread per group stream beyond the first (cc4_run_random_steps; enq_*)
   bool enq_threads = false;
   bool run1m = false;             // cc4_run_random_steps as ONE launch of k_run_philox1m (batches of the one-wave kernel that one launch holds)
@@ -1826,8 +1829,15 @@ const char* cc4_run_kernel(cc4_handle* h) {
   const bool plain = !h->comm && !h->evlog_on && !h->ext_seen && !h->d_prof;
   if (plain && h->multistep) return h->multistep_minb == 8 ? "k_run_philox8" : "k_run_philox";
   if (plain && h->run1m) return "k_run_philox1m";
-  if (plain && h->run_P > 0) return "k_run_philox1";
+  if (plain && h->persist_state >= 0) return "k_run_philox1";      // (calls of fewer than persist_min_k steps: the per-step launches)
   return cc4_step_kernel(h);
+}
+const char* cc4_run_kernel_for(cc4_handle* h, int32_t k) {
+  if (!h) return "";
+  const char* r = cc4_run_kernel(h);
+  if (k < 2) return cc4_step_kernel(h);
+  if (!h->multistep && !h->run1m && h->persist_state >= 0 && k < h->persist_min_k) return cc4_step_kernel(h);
+  return r;
 }
 
 int cc4_create(const cc4_config* cfg, cc4_handle** out) {
@@ -1948,40 +1958,16 @@ int cc4_create(const cc4_config* cfg, cc4_handle** out) {
   // one enqueue thread per group stream in cc4_run_random_steps (EnqPool): on where the host has cores to spare; CC4_ENQ_THREADS=0/1 decides otherwise
   h->enq_threads = std::thread::hardware_concurrency() >= 8;
   if (const char* v = getenv("CC4_ENQ_THREADS")) h->enq_threads = atoi(v) != 0;
-  // OFF unless CC4_PERSIST=1: measured (profiles/r04_persistent_kernel_ab.txt), bit-exact but 18-38 % SLOWER than the launch-per-step
-  // schedule on four streams -- waves that never meet a launch boundary drift apart over the kernel's ~340 KB of code, and a CU's
-  // twenty waves stop sharing their instruction fetches (a launch restarts them together; 98.8 % I-cache hits there).
-  if (cfg->rng_mode == 1 && h->philox_lean && getenv("CC4_PERSIST") && atoi(getenv("CC4_PERSIST")) != 0) {
-    // The persistent run kernel (cc4_run_random_steps without a communicator): one wave per residency slot, the batch cut into one
-    // partition per CU.  Census: a grid of that many waves with the step kernel's footprint, each reporting the CU it landed on --
-    // the partition table is what the hardware says, and the path stays off unless the picture is the expected one (every CU of
-    // the device seen, none with more waves than the occupancy query allows: a mis-decoded CU id would merge CUs and show here).
+  // the persistent run kernel of large batches (k_run_philox1): set up on first use (persist_setup); CC4_PERSIST=0 keeps it off
+  h->persist_state = -1;
+  if (cfg->rng_mode == 1 && h->philox_lean && !h->run1m) {
     int per_cu = 0;
     HIPCHK(h, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_run_philox1, WAVE, offsetof(EnvState, hd)));
     const int grid = per_cu * h->cus;
-    if (per_cu > 0 && cfg->num_envs >= grid + grid / 4) {        // worth it only when the batch is more than the chip holds at once
-      int32_t* d_count = nullptr;
-      HIPCHK(h, hipMalloc(&d_count, CC4_SLOTS * sizeof(int32_t)));
-      HIPCHK(h, hipMemsetAsync(d_count, 0, CC4_SLOTS * sizeof(int32_t), h->stream));
-      int khz = 100000;
-      (void)hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, cfg->device_id);
-      hipLaunchKernelGGL(k_census, dim3(grid), dim3(WAVE), offsetof(EnvState, hd), h->stream, d_count, 200LL * (khz > 0 ? khz : 100000) / 1000);   // ~200 us
-      std::vector<int32_t> count(CC4_SLOTS);
-      HIPCHK(h, hipMemcpyAsync(count.data(), d_count, CC4_SLOTS * sizeof(int32_t), hipMemcpyDeviceToHost, h->stream));
-      HIPCHK(h, hipStreamSynchronize(h->stream));
-      (void)hipFree(d_count);
-      std::vector<int16_t> table(CC4_SLOTS, (int16_t)-1);
-      int P = 0, worst = 0, total = 0;
-      for (int sl = 0; sl < CC4_SLOTS; ++sl) if (count[sl] > 0) { table[sl] = (int16_t)P++; worst = count[sl] > worst ? count[sl] : worst; total += count[sl]; }
-      if (getenv("CC4_PERSIST_DEBUG")) fprintf(stderr, "[cc4 census] grid %d (%d per CU x %d CUs): %d CUs seen, at most %d waves on one, %d counted\n", grid, per_cu, h->cus, P, worst, total);
-      if (P == h->cus && worst <= per_cu && total == grid) {
-        h->run_P = P; h->run_grid = grid;
-        HIPCHK(h, hipMalloc(&h->d_slot_part, CC4_SLOTS * sizeof(int16_t)));
-        HIPCHK(h, hipMemcpy(h->d_slot_part, table.data(), CC4_SLOTS * sizeof(int16_t), hipMemcpyHostToDevice));
-        HIPCHK(h, hipMalloc(&h->d_run, (2 * (size_t)P + n) * sizeof(uint32_t)));
-      }
-    }
+    if (per_cu > 0 && cfg->num_envs >= grid + grid / 4) h->persist_state = 0;     // worth it only when the batch is more than the chip holds at once
   }
+  if (const char* v = getenv("CC4_PERSIST")) { if (atoi(v) == 0) h->persist_state = -1; }
+  if (const char* v = getenv("CC4_PERSIST_MIN_K")) h->persist_min_k = atoi(v);
   return 0;
 }
 
@@ -2183,6 +2169,47 @@ int cc4_synchronize(cc4_handle* h) {
   HIPCHK(h, hipSetDevice(h->cfg.device_id));
   return sync_all(h);
 }
+// The persistent run kernel (cc4_run_random_steps without a communicator, batches beyond what one launch holds): one wave per
+// residency slot, the batch cut into one partition per CU.  Census: a grid of that many waves with the step kernel's footprint, each
+// reporting the CU it landed on -- the partition table is what the hardware says, and the path stays off unless the picture is the
+// expected one (every CU of the device seen, none with more waves than the occupancy query allows: a mis-decoded CU id would merge
+// CUs and show here).  Run once per handle, on the first call that could use it.
+// History: r04 built it with the step body as a call and measured it 18-38 % slower than four streams of per-step launches; the call
+// was the brake (a kernel that contains one loses a quarter of its rate).  Inlined (lane id opaque per item) and compiled without
+// machine LICM (which hoisted ~200 registers' worth of loop-invariant values across the item loop and spilled them) it is the faster
+// schedule from ~20 steps per call on: 8192 episodes 795 -> 917 M at K = 500 (profiles/r04_persistent_kernel_ab.txt).
+static int persist_setup(cc4_handle* h) {
+  h->persist_state = -1;
+  const size_t n = (size_t)h->cfg.num_envs;
+  int per_cu = 0;
+  HIPCHK(h, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_run_philox1, WAVE, offsetof(EnvState, hd)));
+  const int grid = per_cu * h->cus;
+  if (per_cu <= 0) return 0;
+  if (join_groups(h)) return -1;
+  int32_t* d_count = nullptr;
+  HIPCHK(h, hipMalloc(&d_count, CC4_SLOTS * sizeof(int32_t)));
+  HIPCHK(h, hipMemsetAsync(d_count, 0, CC4_SLOTS * sizeof(int32_t), h->stream));
+  int khz = 100000;
+  (void)hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, h->cfg.device_id);
+  hipLaunchKernelGGL(k_census, dim3(grid), dim3(WAVE), offsetof(EnvState, hd), h->stream, d_count, 200LL * (khz > 0 ? khz : 100000) / 1000);   // ~200 us
+  std::vector<int32_t> count(CC4_SLOTS);
+  HIPCHK(h, hipMemcpyAsync(count.data(), d_count, CC4_SLOTS * sizeof(int32_t), hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  (void)hipFree(d_count);
+  std::vector<int16_t> table(CC4_SLOTS, (int16_t)-1);
+  int P = 0, worst = 0, total = 0;
+  for (int sl = 0; sl < CC4_SLOTS; ++sl) if (count[sl] > 0) { table[sl] = (int16_t)P++; worst = count[sl] > worst ? count[sl] : worst; total += count[sl]; }
+  if (getenv("CC4_PERSIST_DEBUG")) fprintf(stderr, "[cc4 census] grid %d (%d per CU x %d CUs): %d CUs seen, at most %d waves on one, %d counted\n", grid, per_cu, h->cus, P, worst, total);
+  if (P == h->cus && worst <= per_cu && total == grid) {
+    h->run_P = P; h->run_grid = grid;
+    HIPCHK(h, hipMalloc(&h->d_slot_part, CC4_SLOTS * sizeof(int16_t)));
+    HIPCHK(h, hipMemcpy(h->d_slot_part, table.data(), CC4_SLOTS * sizeof(int16_t), hipMemcpyHostToDevice));
+    HIPCHK(h, hipMalloc(&h->d_run, (2 * (size_t)P + n) * sizeof(uint32_t)));
+    h->persist_state = 1;
+  }
+  return 0;
+}
+
 int cc4_run_random_steps(cc4_handle* h, uint64_t seed0, uint32_t t0, int32_t k, float* ms_step_kernels) {
   HIPCHK(h, hipSetDevice(h->cfg.device_id));
   if (k <= 0) { if (ms_step_kernels) *ms_step_kernels = 0.f; return 0; }   // nothing to launch, no timing event to read
@@ -2227,7 +2254,8 @@ int cc4_run_random_steps(cc4_handle* h, uint64_t seed0, uint32_t t0, int32_t k, 
     if (ms_step_kernels) HIPCHK(h, hipEventElapsedTime(ms_step_kernels, h->evs[0], h->evs[1]));
     return 0;
   }
-  if (h->run_P > 0 && !h->comm && !h->evlog_on && !h->ext_seen && !h->d_prof && k >= 2) {
+  if (h->persist_state == 0 && !h->run1m && !h->multistep && !h->comm && !h->evlog_on && !h->ext_seen && !h->d_prof && k >= h->persist_min_k) { if (persist_setup(h)) return -1; }
+  if (h->persist_state == 1 && h->run_P > 0 && !h->comm && !h->evlog_on && !h->ext_seen && !h->d_prof && k >= h->persist_min_k) {
     // the persistent form: the k steps of the whole batch in ONE launch on the main stream (k_run_philox1)
     if (join_groups(h)) return -1;
     const size_t words = 2 * (size_t)h->run_P + (size_t)h->cfg.num_envs;

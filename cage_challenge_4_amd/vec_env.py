@@ -241,6 +241,10 @@ class CC4VecEnv:
         """cc4_run_kernel: the kernel run_random_steps launches ('k_run_philox' = one launch for all k steps of a small batch)."""
         return self.lib.cc4_run_kernel(self._h).decode()
 
+    def run_kernel_for(self, k):
+        """cc4_run_kernel_for: the kernel a run_random_steps call of k steps launches."""
+        return self.lib.cc4_run_kernel_for(self._h, int(k)).decode()
+
     @property
     def launches_per_step(self):
         """cc4_launches_per_step: a step of a large batch is several launches (episode groups on separate streams)."""

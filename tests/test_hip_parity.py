@@ -210,7 +210,7 @@ def test_bench_configuration_matches_oracle_every_step(n, red_policy, blue_polic
     dev.close()
 
 
-@pytest.mark.parametrize('n,kernel,run_kernel', [(8192, 'k_step_philox1', 'k_step_philox1'), (1024, 'k_step_philox', 'k_run_philox'), (2048, 'k_step_philox', 'k_run_philox8'),
+@pytest.mark.parametrize('n,kernel,run_kernel', [(8192, 'k_step_philox1', 'k_run_philox1'), (1024, 'k_step_philox', 'k_run_philox'), (2048, 'k_step_philox', 'k_run_philox8'),
                                                   (4096, 'k_step_philox1', 'k_run_philox1m')],
                          ids=['8192', '1024-multistep', '2048-multistep8', '4096-multistep1'])
 def test_timed_bench_path_matches_oracle(n, kernel, run_kernel):
@@ -256,6 +256,7 @@ def test_enqueue_threads_change_nothing(threads, monkeypatch):
     destroyed in a row (a worker pool is joined at cc4_destroy)."""
     monkeypatch.setenv('CC4_ENQ_THREADS', threads)
     monkeypatch.setenv('CC4_RUN1', '0')
+    monkeypatch.setenv('CC4_PERSIST', '0')
     n, steps, seed0 = 4096, 60, 99
     for rep in range(3):
         dev = _dev(n, steps=steps, rng_mode=1, autoreset=True)
@@ -860,8 +861,10 @@ def test_bench_line_contract():
     assert not d['config']['engine_error_flags'] and d['config']['timed_regions'] >= 1
     r = d['roofline']
     assert r['bound'] == 'hbm' and r['unit'] == 'GB/s' and r['peak'] == 8000.0 and abs(r['frac'] - r['achieved'] / r['peak']) < 1e-9
-    # 8192 episodes: three or four concurrent launches of the one-wave kernel per step (episode groups on their own streams)
-    assert r['kernel'] == 'k_step_philox1' and r['launches_per_step'] in (3, 4) and 0 < r['launch_ms'] <= d['ms_per_step'] * 1.02
+    # 8192 episodes, 20-step regions: three or four concurrent launches of the one-wave kernel per step (regions of 32 steps and more are ONE
+    # launch of the persistent kernel k_run_philox1: test_bench_line_of_long_regions)
+    assert r['step_kernel'] == 'k_step_philox1' and r['kernel'] == r['run_kernel'] == 'k_step_philox1' and r['steps_per_launch'] == 1
+    assert r['launches_per_step'] in (3, 4) and 0 < r['launch_ms'] <= d['ms_per_step'] * 1.02 and r['step_ms'] == r['launch_ms']
     assert abs(r['algorithmic_bytes_per_step'] - r['launches_per_step'] * r['algorithmic_bytes_per_launch']) < 1e-6 * r['algorithmic_bytes_per_step']
     assert abs(r['achieved'] - r['launches_per_step'] * r['algorithmic_bytes_per_launch'] / (r['launch_ms'] * 1e-3) / 1e9) < 1e-6 * r['achieved']
     assert r['traffic'] is None or ('profiles/' in r['traffic_source'] and 'k_step_philox1' in r['traffic_source'])
@@ -873,3 +876,21 @@ def test_bench_line_contract():
     assert c['kind'] == 'port' and c['cores'] >= 1 and c['value'] > 0 and 'sample' in c and c['one_core']['cores'] == 1
     assert c['reference_python']['kind'] == 'reference' and c['reference_python']['value'] == 172.0
     assert d['alt_rng']['rng'] == 'pcg64' and d['envs_1024']['total_envs'] == 1024 and d['value'] > 50e6
+
+
+def test_bench_line_of_long_regions():
+    """`python bench.py --steps 64`: a timed region of 32 steps or more at 8192 episodes is ONE launch of the persistent kernel; the roofline
+    object says so (kernel, steps_per_launch, launch_ms = the launch, step_ms = launch_ms / steps_per_launch)."""
+    import json, os, subprocess, sys
+    from conftest import ROOT
+    out = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--steps', '64', '--warmup', '5', '--min-seconds', '0.05', '--no-alt', '--no-cpu-baseline'],
+                         capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-3000:]
+    d = json.loads([ln for ln in out.stdout.splitlines() if ln.strip()][0])
+    r = d['roofline']
+    assert not d['config']['engine_error_flags'] and d['steps'] == 64
+    assert r['step_kernel'] == 'k_step_philox1' and r['kernel'] == r['run_kernel'] == 'k_run_philox1' and r['steps_per_launch'] == 64
+    assert 0 < r['step_ms'] <= d['ms_per_step'] * 1.02 and abs(r['launch_ms'] - 64 * r['step_ms']) < 1e-9
+    assert abs(r['algorithmic_bytes_per_launch'] - 64 * r['algorithmic_bytes_per_step']) < 1e-6 * r['algorithmic_bytes_per_launch']
+    assert abs(r['achieved'] - r['algorithmic_bytes_per_launch'] / (r['launch_ms'] * 1e-3) / 1e9) < 1e-6 * r['achieved']
+    assert abs(d['value'] - 5.0 * 8192 / (d['ms_per_step'] * 1e-3)) < 1e-6 * d['value'] and d['value'] > 50e6

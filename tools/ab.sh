@@ -8,7 +8,7 @@ cd "$(dirname "$0")/.."
 mkdir -p build_var
 if [ "$1" = build ]; then
   name=$2; shift 2
-  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O2 -mllvm -amdgpu-unroll-threshold-private=0 -mllvm -amdgpu-unroll-threshold-local=0 -mllvm -amdgpu-atomic-optimizer-strategy=None -mllvm -structurizecfg-skip-uniform-regions=true -mllvm -structurizecfg-relaxed-uniform-regions=true -std=c++17 -ffp-contract=off -shared -fPIC "$@" -o build_var/$name.so cage_challenge_4_amd/csrc/cc4_hip.hip -lrccl
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O2 -mllvm -amdgpu-unroll-threshold-private=0 -mllvm -amdgpu-unroll-threshold-local=0 -mllvm -amdgpu-atomic-optimizer-strategy=None -mllvm -structurizecfg-skip-uniform-regions=true -mllvm -structurizecfg-relaxed-uniform-regions=true -mllvm -disable-machine-licm -std=c++17 -ffp-contract=off -shared -fPIC "$@" -o build_var/$name.so cage_challenge_4_amd/csrc/cc4_hip.hip -lrccl
 else
   shift
   for round in 1 2; do for v in "$@"; do for n in 8192 1024; do
@@ -16,7 +16,7 @@ else
 import sys,json
 for l in sys.stdin:
     if l.startswith('{'):
-        d=json.loads(l); print('$v', $n, round(d['value']/1e6,1), 'M  launch_ms', round(d['roofline']['launch_ms'],4), 'err', d['config']['engine_error_flags'])
+        d=json.loads(l); print('$v', $n, round(d['value']/1e6,1), 'M  step_ms', round(d['roofline']['step_ms'],4), d['roofline']['kernel'], 'err', d['config']['engine_error_flags'])
 "
   done; done; done
 fi

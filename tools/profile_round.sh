@@ -9,13 +9,15 @@ export TMPDIR=/tmp
 BENCH="python bench.py --no-alt --no-cpu-baseline --min-seconds 0.15"
 # 1. kernel trace + stats of the headline command (8192 episodes) and of the 1024-episode batch
 rocprofv3 --kernel-trace --stats -d $OUT/stats8192 -- $BENCH > $OUT/bench_stats8192.json 2> $OUT/stats8192.err
-python tools/rocpd_summary.py stats $OUT/stats8192 $OUT/${TAG}_kernel_stats_8192env.txt > /dev/null
+python tools/rocpd_summary.py stats $OUT/stats8192 $OUT/${TAG}_kernel_stats_8192env.txt > /dev/null      # k_run_philox1: one launch = the 500 steps of a timed region
+CC4_PERSIST=0 rocprofv3 --kernel-trace --stats -d $OUT/stats8192ps -- $BENCH > $OUT/bench_stats8192_per_step.json 2> $OUT/stats8192ps.err
+python tools/rocpd_summary.py stats $OUT/stats8192ps $OUT/${TAG}_kernel_stats_8192env_per_step_launches.txt > /dev/null
 rocprofv3 --kernel-trace --stats -d $OUT/stats1024 -- $BENCH --total-envs 1024 > $OUT/bench_stats1024.json 2> $OUT/stats1024.err
 python tools/rocpd_summary.py stats $OUT/stats1024 $OUT/${TAG}_kernel_stats_1024env.txt > /dev/null      # k_run_philox: one launch = the 500 steps of a timed region
 CC4_MULTISTEP=0 rocprofv3 --kernel-trace --stats -d $OUT/stats1024ps -- $BENCH --total-envs 1024 > $OUT/bench_stats1024_per_step.json 2> $OUT/stats1024ps.err
 python tools/rocpd_summary.py stats $OUT/stats1024ps $OUT/${TAG}_kernel_stats_1024env_per_step_launches.txt > /dev/null
 # 2. HBM traffic: separate --pmc passes (FETCH_SIZE, WRITE_SIZE), kernel-trace only
-export CC4_MULTISTEP=0      # the counters are read per launch of the per-step kernels (a k_run_philox launch is a whole region)
+export CC4_MULTISTEP=0 CC4_PERSIST=0 CC4_RUN1=0     # the counters are read per launch of the per-step kernels (a one-launch form's launch is a whole region; same body, same bytes)
 for N in 8192 1024 32768; do
   rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $OUT/fetch$N -- $BENCH --total-envs $N --min-seconds 0.05 > /dev/null 2> $OUT/fetch$N.err
   rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $OUT/write$N -- $BENCH --total-envs $N --min-seconds 0.05 > $OUT/bench_pmc$N.json 2> $OUT/write$N.err
@@ -23,8 +25,8 @@ for N in 8192 1024 32768; do
   LPS=$(python -c "import json,sys; d=[json.loads(l) for l in open('$OUT/bench_pmc$N.json') if l.startswith('{')][0]; print(d['roofline']['launches_per_step'])")
   python tools/rocpd_summary.py pmc_step $OUT/fetch$N $OUT/write$N $KN $OUT/${TAG}_pmc.json $N $LPS > /dev/null
 done
-unset CC4_MULTISTEP
-# 3. instruction mix / issue utilisation at 8192 episodes (separate passes)
+unset CC4_MULTISTEP CC4_RUN1
+# 3. instruction mix (per-step kernel: CC4_PERSIST=0 stays) / issue utilisation at 8192 episodes (separate passes)
 rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS -d $OUT/mixA -- $BENCH --min-seconds 0.05 > /dev/null 2> $OUT/mixA.err
 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU -d $OUT/mixB -- $BENCH --min-seconds 0.05 > /dev/null 2> $OUT/mixB.err
 rocprofv3 --kernel-trace --pmc SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_INSTS_BRANCH SQ_INSTS_SMEM -d $OUT/mixC -- $BENCH --min-seconds 0.05 > /dev/null 2> $OUT/mixC.err
@@ -35,9 +37,10 @@ python tools/phase_profile.py 8192 200 1 > $OUT/${TAG}_phase_cycles_philox_8192e
 python tools/phase_profile.py 1024 100 0 > $OUT/${TAG}_phase_cycles_pcg64_1024env.txt 2>&1
 python tools/tail_whatif.py 1024 200 > $OUT/${TAG}_tail_whatif.txt 2>&1
 python tools/tail_profile.py 1024 100 1 > $OUT/${TAG}_tail_philox.txt 2>&1
+unset CC4_PERSIST
 # 5. numpy-stream kernel: kernel stats at 8192 episodes, what the lane-parallel green actions do per step
 rocprofv3 --kernel-trace --stats -d $OUT/statspcg -- $BENCH --rng pcg64 > $OUT/bench_statspcg.json 2> $OUT/statspcg.err
 python tools/rocpd_summary.py stats $OUT/statspcg $OUT/${TAG}_kernel_stats_8192env_pcg64.txt > /dev/null
 python tools/green_batches.py 1024 50 > $OUT/${TAG}_green_batches_pcg64_1024env.txt 2>&1
 ls -la $OUT | head -50
-rm -rf $OUT/stats8192 $OUT/stats1024 $OUT/stats1024ps $OUT/statspcg $OUT/fetch* $OUT/write* $OUT/mix?   # the raw databases are large; the summaries stay
+rm -rf $OUT/stats8192 $OUT/stats8192ps $OUT/stats1024 $OUT/stats1024ps $OUT/statspcg $OUT/fetch* $OUT/write* $OUT/mix?   # the raw databases are large; the summaries stay
