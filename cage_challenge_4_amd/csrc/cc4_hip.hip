@@ -1307,6 +1307,94 @@ __device__ __attribute__((noinline)) void philox1_item(const StepArgs& a, int e,
   philox1_body<false, true>(a, e, rand_t, item_k, (int)threadIdx.x);
 }
 
+#if !defined(CC4_EXP_PERSIST_NOSTEAL)
+// Tail of a call: a CU whose own partition is handed out takes items from the partition of another CU OF ITS XCD that has the most left.
+// The XCD's L2 is the coherence point of its CUs (vector stores write through to it), but a CU's L1 is not refreshed by another CU's
+// stores -- so from the moment a partition is shared (bit 31 of its ticket counter, set by the first thief; every ticket handed out
+// afterwards carries it) every item of it starts with an agent-scope acquire (buffer_inv sc1: the CU's L1 dropped), on the owner's waves
+// and the thieves' alike.  Items handed out before the bit was set were all the owner's own and read what that CU wrote itself.
+// Never across XCDs: their L2s do not agree without a write-back.
+constexpr uint32_t TK_SHARED = 0x80000000u;
+__global__ __launch_bounds__(WAVE, 5) void k_run_philox1(StepArgs a, RunArgs ra) {
+  __shared__ int item_lds[4];
+  const int lane = threadIdx.x;
+  const int my_slot = cu_slot();
+  int part = ra.slot_part[my_slot];      // (lane 0's copy is the one that counts)
+  bool mine = false;                     // lane 0: this CU owns `part` (claimed or adopted)
+  bool stealing = false;                 // lane 0: `part` belongs to another CU of this XCD; its shared bit is set
+  a.prof = nullptr; a.obs8 = nullptr; a.ext = nullptr;
+  for (;;) {
+    if (lane == 0) {
+      int res_e = -3, res_k = 0, res_sh = 0;                         // -3: nothing from `part`: search
+      if (part >= 0 && !mine && !stealing) {
+        int exp = 0;                                                  // the CU's own partition: claim it (or find it claimed by this CU already)
+        mine = __hip_atomic_compare_exchange_strong(&ra.owner[part], &exp, my_slot + 1, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) || exp == my_slot + 1;
+        if (!mine) part = -1;                                         // somebody else's by now (adopted): search
+      }
+      if (part >= 0) {
+        const bool thief = !mine;                                     // (a partition this wave steals from: `part` was set by the search below)
+        const int ne = (a.n - part + ra.P - 1) / ra.P;                // episodes part, part + P, part + 2 P, ..
+        const uint32_t tr = __hip_atomic_fetch_add(&ra.ticket[part], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const uint32_t t = tr & ~TK_SHARED;
+        if (t < (uint32_t)(ne * ra.K)) {
+          const int k = (int)(t / (uint32_t)ne), ee = part + (int)(t % (uint32_t)ne) * ra.P;
+          while (__hip_atomic_load(&ra.progress[ee], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (uint32_t)k) __builtin_amdgcn_s_sleep(8);
+          res_e = ee; res_k = k; res_sh = (thief || (tr & TK_SHARED)) ? 1 : 0;
+        }
+      }
+      item_lds[0] = res_e; item_lds[1] = res_k; item_lds[2] = res_sh; item_lds[3] = part;
+    }
+    __syncthreads();
+    const int e = __builtin_amdgcn_readfirstlane(item_lds[0]);
+    if (e == -3) {
+      // search (all lanes): the partition with the most items left among those nobody owns and those owned by a CU of this XCD
+      const int cur = __builtin_amdgcn_readfirstlane(item_lds[3]);
+      __syncthreads();
+      int best_rem = 0, best_q = -1, best_ow = 0;
+      for (int q0 = 0; q0 < ra.P; q0 += WAVE) {
+        const int q = q0 + lane;
+        if (q < ra.P && q != cur) {
+          const int ow = __hip_atomic_load(&ra.owner[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          if (ow == 0 || (((ow - 1) >> 8) == (my_slot >> 8))) {
+            const uint32_t t = __hip_atomic_load(&ra.ticket[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & ~TK_SHARED;
+            const uint32_t tot = (uint32_t)(((a.n - q + ra.P - 1) / ra.P) * ra.K);
+            const int rem = t < tot ? (int)(tot - t) : 0;
+            if (rem > best_rem) { best_rem = rem; best_q = q; best_ow = ow; }
+          }
+        }
+      }
+#pragma unroll
+      for (int off = 32; off >= 1; off >>= 1) {
+        const int r2 = __shfl_xor(best_rem, off), q2 = __shfl_xor(best_q, off), o2 = __shfl_xor(best_ow, off);
+        if (r2 > best_rem || (r2 == best_rem && q2 > best_q)) { best_rem = r2; best_q = q2; best_ow = o2; }
+      }
+      best_rem = __builtin_amdgcn_readfirstlane(best_rem); best_q = __builtin_amdgcn_readfirstlane(best_q); best_ow = __builtin_amdgcn_readfirstlane(best_ow);
+      if (best_rem <= 0) return;                                      // nothing left anywhere this wave may touch
+      part = best_q; mine = false; stealing = false;
+      if (lane == 0) {
+        if (best_ow == 0) {                                           // nobody's: adopt it (the CAS in the item path), no sharing needed unless that fails
+          int exp = 0;
+          mine = __hip_atomic_compare_exchange_strong(&ra.owner[part], &exp, my_slot + 1, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) || exp == my_slot + 1;
+          if (!mine && (((exp - 1) >> 8) != (my_slot >> 8))) part = -1;   // claimed meanwhile by a CU of another XCD: not ours to touch
+        }
+        if (part >= 0 && !mine) { (void)__hip_atomic_fetch_or(&ra.ticket[part], TK_SHARED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); stealing = true; }
+      }
+      continue;
+    }
+    const uint32_t item_k = (uint32_t)__builtin_amdgcn_readfirstlane(item_lds[1]);
+    const int shared = __builtin_amdgcn_readfirstlane(item_lds[2]);
+    __syncthreads();
+    if (shared) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    int lane_i = (int)threadIdx.x;
+    asm volatile("" : "+v"(lane_i));
+    philox1_body<false, true>(a, e, ra.t0 + item_k, item_k, lane_i);
+    // the item is done when everything it wrote has left this wave: then the next step of the episode may start (on this XCD)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (lane == 0) __hip_atomic_store(&ra.progress[e], item_k + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+}
+#else
 __global__ __launch_bounds__(WAVE, 5) void k_run_philox1(StepArgs a, RunArgs ra) {
   __shared__ int item_lds[2];
   const int lane = threadIdx.x;
@@ -1365,6 +1453,8 @@ __global__ __launch_bounds__(WAVE, 5) void k_run_philox1(StepArgs a, RunArgs ra)
     if (lane == 0) __hip_atomic_store(&ra.progress[e], item_k + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
 }
+
+#endif
 
 // The plain multi-step form of the one-wave kernel: one wave per episode, every wave loops over the K steps of ITS episode -- no
 // tickets, no affinity: a wave only reads what it wrote itself.  For batches one launch holds at once (cc4_create; CC4_RUN1=0/1
@@ -1551,8 +1641,8 @@ struct cc4_handle {
   int16_t* d_slot_part = nullptr; // [CC4_SLOTS]
   int run_P = 0, run_grid = 0;    // partitions (= CUs that take waves), waves per launch; 0: the persistent path is off
   int persist_state = -1;         // -1 off / unavailable, 0 not set up yet (persist_setup on first use), 1 on
-  int persist_min_k = 32;         // shorter calls keep the per-step launches: the launch's ramp and tail (a CU's partition ends when its slowest episodes do)
-                                  // cost 170-250 us, four steps' worth; K = 20: 700-757 vs 736-745 M over three boxes, K = 32: 812 vs 759 M (CC4_PERSIST_MIN_K)
+  int persist_min_k = 10;         // shorter calls keep the per-step launches: a launch's ramp and tail cost a few steps' worth (with the tail's items shared
+                                  // among the CUs of an XCD: K = 10: 733 vs 685 M, K = 20: 813 vs 742 M, K = 32: 857 vs 756 M; CC4_PERSIST_MIN_K)
   struct EnqPool* pool = nullptr; // one enqueue thread per group stream beyond the first (cc4_run_random_steps; enq_*)
   bool enq_threads = false;
   bool run1m = false;             // cc4_run_random_steps as ONE launch of k_run_philox1m (batches of the one-wave kernel that one launch holds)

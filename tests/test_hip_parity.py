@@ -861,12 +861,12 @@ def test_bench_line_contract():
     assert not d['config']['engine_error_flags'] and d['config']['timed_regions'] >= 1
     r = d['roofline']
     assert r['bound'] == 'hbm' and r['unit'] == 'GB/s' and r['peak'] == 8000.0 and abs(r['frac'] - r['achieved'] / r['peak']) < 1e-9
-    # 8192 episodes, 20-step regions: three or four concurrent launches of the one-wave kernel per step (regions of 32 steps and more are ONE
-    # launch of the persistent kernel k_run_philox1: test_bench_line_of_long_regions)
-    assert r['step_kernel'] == 'k_step_philox1' and r['kernel'] == r['run_kernel'] == 'k_step_philox1' and r['steps_per_launch'] == 1
-    assert r['launches_per_step'] in (3, 4) and 0 < r['launch_ms'] <= d['ms_per_step'] * 1.02 and r['step_ms'] == r['launch_ms']
-    assert abs(r['algorithmic_bytes_per_step'] - r['launches_per_step'] * r['algorithmic_bytes_per_launch']) < 1e-6 * r['algorithmic_bytes_per_step']
-    assert abs(r['achieved'] - r['launches_per_step'] * r['algorithmic_bytes_per_launch'] / (r['launch_ms'] * 1e-3) / 1e9) < 1e-6 * r['achieved']
+    # 8192 episodes, 20-step regions: ONE launch of the persistent one-wave kernel per region (regions of fewer than 10 steps, or CC4_PERSIST=0:
+    # three or four concurrent launches of k_step_philox1 per step)
+    assert r['step_kernel'] == 'k_step_philox1' and r['kernel'] == r['run_kernel'] == 'k_run_philox1' and r['steps_per_launch'] == 20
+    assert 0 < r['step_ms'] <= d['ms_per_step'] * 1.02 and abs(r['launch_ms'] - 20 * r['step_ms']) < 1e-9
+    assert abs(r['algorithmic_bytes_per_launch'] - 20 * r['algorithmic_bytes_per_step']) < 1e-6 * r['algorithmic_bytes_per_launch']
+    assert abs(r['achieved'] - r['algorithmic_bytes_per_launch'] / (r['launch_ms'] * 1e-3) / 1e9) < 1e-6 * r['achieved']
     assert r['traffic'] is None or ('profiles/' in r['traffic_source'] and 'k_step_philox1' in r['traffic_source'])
     assert abs(d['value'] - 5.0 * 8192 / (d['ms_per_step'] * 1e-3)) < 1e-6 * d['value']
     pr = d['config']['per_rank']
@@ -879,7 +879,7 @@ def test_bench_line_contract():
 
 
 def test_bench_line_of_long_regions():
-    """`python bench.py --steps 64`: a timed region of 32 steps or more at 8192 episodes is ONE launch of the persistent kernel; the roofline
+    """`python bench.py --steps 64`: a timed region of 10 steps or more at 8192 episodes is ONE launch of the persistent kernel; the roofline
     object says so (kernel, steps_per_launch, launch_ms = the launch, step_ms = launch_ms / steps_per_launch)."""
     import json, os, subprocess, sys
     from conftest import ROOT
