@@ -8,11 +8,11 @@ mkdir -p $OUT
 export TMPDIR=/tmp
 BENCH="python bench.py --no-alt --no-cpu-baseline --min-seconds 0.15"
 # 1. kernel trace + stats of the headline command (8192 episodes) and of the 1024-episode batch
-rocprofv3 --kernel-trace --stats -d $OUT/stats8192 -- $BENCH > $OUT/bench_stats8192.json 2> $OUT/stats8192.err
-python tools/rocpd_summary.py stats $OUT/stats8192 $OUT/${TAG}_kernel_stats_8192env.txt > /dev/null      # k_run_philox1: one launch = the 500 steps of a timed region
+rocprofv3 --kernel-trace --stats -d $OUT/stats8192 -- $BENCH --warmup 5 > $OUT/bench_stats8192.json 2> $OUT/stats8192.err
+python tools/rocpd_summary.py stats $OUT/stats8192 $OUT/${TAG}_kernel_stats_8192env.txt > /dev/null      # k_run_philox1: one launch = the 500 steps of a timed region (the 5 warm-up steps are per-step launches)
 CC4_PERSIST=0 rocprofv3 --kernel-trace --stats -d $OUT/stats8192ps -- $BENCH > $OUT/bench_stats8192_per_step.json 2> $OUT/stats8192ps.err
 python tools/rocpd_summary.py stats $OUT/stats8192ps $OUT/${TAG}_kernel_stats_8192env_per_step_launches.txt > /dev/null
-rocprofv3 --kernel-trace --stats -d $OUT/stats1024 -- $BENCH --total-envs 1024 > $OUT/bench_stats1024.json 2> $OUT/stats1024.err
+rocprofv3 --kernel-trace --stats -d $OUT/stats1024 -- $BENCH --total-envs 1024 --warmup 1 > $OUT/bench_stats1024.json 2> $OUT/stats1024.err
 python tools/rocpd_summary.py stats $OUT/stats1024 $OUT/${TAG}_kernel_stats_1024env.txt > /dev/null      # k_run_philox: one launch = the 500 steps of a timed region
 CC4_MULTISTEP=0 rocprofv3 --kernel-trace --stats -d $OUT/stats1024ps -- $BENCH --total-envs 1024 > $OUT/bench_stats1024_per_step.json 2> $OUT/stats1024ps.err
 python tools/rocpd_summary.py stats $OUT/stats1024ps $OUT/${TAG}_kernel_stats_1024env_per_step_launches.txt > /dev/null
