@@ -479,8 +479,10 @@ __device__ __forceinline__ void wave_green_exec(Ctx x, Rng& rl, uint64_t* win, i
   }
 }
 
+// One step of one episode of the numpy-stream mode on one wavefront: the body of k_step and of the persistent kernel k_run_pcg
+// (there a.rand_t / a.full_obs are the item's: set by the caller).
 template <bool LOG>
-__global__ __launch_bounds__(WAVE) void k_step(StepArgs a) {
+__device__ __forceinline__ void pcg_body(StepArgs a, const int e, const int lane) {
   // numpy-PCG64 mode: one shared stream => the agent walk is strictly serial (lane 0); only the RNG-free parts
   // (row staging, end-turn Monitor roll-over over the 137 hosts, observation encode) use the other lanes.
   extern __shared__ uint4 lds[];
@@ -492,8 +494,6 @@ __global__ __launch_bounds__(WAVE) void k_step(StepArgs a) {
   uint8_t* const obs_lds = reinterpret_cast<uint8_t*>(win_lds);
   __shared__ int ok_lds;
   __shared__ StepWork work;
-  const int e = a.e0 + (int)blockIdx.x, lane = threadIdx.x;
-  if (e >= a.n) return;
   EnvCold* const cold_e = cold_at(a.cold, (size_t)e, cold_row_bytes(a.steps));
   unsigned long long t_begin = a.prof ? clock64() : 0;
   const uint4* src = reinterpret_cast<const uint4*>(a.st + e);
@@ -631,6 +631,12 @@ __global__ __launch_bounds__(WAVE) void k_step(StepArgs a) {
   if (a.obs8) { uint8_t* o8 = a.obs8 + (size_t)e * OBS_PACKED; for (int j = lane; j < OBS_PACKED; j += WAVE) o8[j] = pack_obs_byte(obs_lds, j); }
   if (prof && lane == 0) { prof[13] += clock64() - t_out; prof[14] += clock64() - t_begin; }
   if (prof) { __syncthreads(); if (lane < 15) a.prof[PROF_SLOTS * (size_t)e + lane] += prof_lds[lane]; }
+}
+template <bool LOG>
+__global__ __launch_bounds__(WAVE) void k_step(StepArgs a) {
+  const int e = a.e0 + (int)blockIdx.x;
+  if (e >= a.n) return;
+  pcg_body<LOG>(a, e, (int)threadIdx.x);
 }
 
 // ---------------------------------------------------------------- Philox mode: wave- and lane-parallel step
@@ -986,8 +992,7 @@ __global__ __launch_bounds__(PT, MINW) void k_step_philox(StepArgs a) { philox4_
 // (register budget of five blocks per CU, stated for the callee as well: left to itself it takes 212 VGPRs)
 // (r04, end of round: the body INLINED -- with the thread id made opaque per step, so that nothing derived from it is hoisted out of the loop
 // and held across the whole step; ~90 VGPRs spill, and it is still 30 % faster than the call: a kernel that contains a call loses a quarter
-// of its rate, profiles/r04_compiler_flags_ab.txt.  -DCC4_EXP_RUN_CALL keeps the call form for the A/B.)
-__device__ __attribute__((noinline)) void philox4_item(const StepArgs& a, int run_flags) { philox4_body<false, true>(a, run_flags); }
+// of its rate, profiles/r04_compiler_flags_ab.txt, r04_multistep_inline_ab.txt.)
 template <int MINB>
 __device__ __forceinline__ void run_philox_loop(StepArgs a, int K, uint32_t t0) {
   a.prof = nullptr; a.obs8 = nullptr; a.ext = nullptr;
@@ -995,12 +1000,8 @@ __device__ __forceinline__ void run_philox_loop(StepArgs a, int K, uint32_t t0) 
   for (int k = 0; k < K; ++k) {
     a.rand_t = t0 + (uint32_t)k;
     a.full_obs = k == 0 ? full0 : 0;
-#if defined(CC4_EXP_RUN_CALL)
-    philox4_item(a, (k > 0 ? 1 : 0) | (k == K - 1 ? 2 : 0));
-#else
     { int tid_i = (int)threadIdx.x; asm volatile("" : "+v"(tid_i));
       philox4_body<false, true>(a, (k > 0 ? 1 : 0) | (k == K - 1 ? 2 : 0), tid_i); }
-#endif
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
   }
@@ -1301,13 +1302,7 @@ __global__ __launch_bounds__(WAVE, CC4_LEAN_MINW) void k_step_philox1(StepArgs a
   philox1_body<LOG, false>(a, e, a.rand_t, 0u, (int)threadIdx.x);
 }
 
-// The body as a real call for the persistent kernel: inlined into the item loop, everything the step derives from loop-invariant
-// values is hoisted and held in registers across the whole step (96 VGPRs + 280 spilled); a call per 30 us item costs nothing.
-__device__ __attribute__((noinline)) void philox1_item(const StepArgs& a, int e, uint32_t rand_t, uint32_t item_k) {
-  philox1_body<false, true>(a, e, rand_t, item_k, (int)threadIdx.x);
-}
 
-#if !defined(CC4_EXP_PERSIST_NOSTEAL)
 // Tail of a call: a CU whose own partition is handed out takes items from the partition of another CU OF ITS XCD that has the most left.
 // The XCD's L2 is the coherence point of its CUs (vector stores write through to it), but a CU's L1 is not refreshed by another CU's
 // stores -- so from the moment a partition is shared (bit 31 of its ticket counter, set by the first thief; every ticket handed out
@@ -1315,7 +1310,8 @@ __device__ __attribute__((noinline)) void philox1_item(const StepArgs& a, int e,
 // and the thieves' alike.  Items handed out before the bit was set were all the owner's own and read what that CU wrote itself.
 // Never across XCDs: their L2s do not agree without a write-back.
 constexpr uint32_t TK_SHARED = 0x80000000u;
-__global__ __launch_bounds__(WAVE, 5) void k_run_philox1(StepArgs a, RunArgs ra) {
+template <bool PCG>
+__device__ __forceinline__ void persist_loop(StepArgs a, RunArgs ra) {
   __shared__ int item_lds[4];
   const int lane = threadIdx.x;
   const int my_slot = cu_slot();
@@ -1387,73 +1383,23 @@ __global__ __launch_bounds__(WAVE, 5) void k_run_philox1(StepArgs a, RunArgs ra)
     if (shared) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
     int lane_i = (int)threadIdx.x;
     asm volatile("" : "+v"(lane_i));
-    philox1_body<false, true>(a, e, ra.t0 + item_k, item_k, lane_i);
+    if constexpr (PCG) {
+      StepArgs b = a;
+      b.rand_t = ra.t0 + item_k; b.full_obs = (a.full_obs && item_k == 0) ? 1 : 0;
+      pcg_body<false>(b, e, lane_i);
+    } else {
+      philox1_body<false, true>(a, e, ra.t0 + item_k, item_k, lane_i);
+    }
     // the item is done when everything it wrote has left this wave: then the next step of the episode may start (on this XCD)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (lane == 0) __hip_atomic_store(&ra.progress[e], item_k + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
 }
-#else
-__global__ __launch_bounds__(WAVE, 5) void k_run_philox1(StepArgs a, RunArgs ra) {
-  __shared__ int item_lds[2];
-  const int lane = threadIdx.x;
-  const int my_slot = cu_slot();
-  int part = ra.slot_part[my_slot];
-  a.prof = nullptr; a.obs8 = nullptr; a.ext = nullptr;
-  for (;;) {
-    if (lane == 0) {
-      int got = -1;
-      while (got == -1) {
-        if (part < 0) {
-          // adopt a partition nobody owns, or rejoin one this CU owns that still has items
-          for (int q = 0; q < ra.P && part < 0; ++q) {
-            const int ne = (a.n - q + ra.P - 1) / ra.P;
-            int ow = __hip_atomic_load(&ra.owner[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (ow == 0) { int exp = 0; if (__hip_atomic_compare_exchange_strong(&ra.owner[q], &exp, my_slot + 1, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) ow = my_slot + 1; else ow = exp; }
-            if (ow == my_slot + 1 && __hip_atomic_load(&ra.ticket[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (uint32_t)(ne * ra.K)) part = q;
-          }
-          if (part < 0) { got = -2; break; }                       // nothing left anywhere
-        } else {
-          int exp = 0;                                              // the CU's own partition: claim it (or find it claimed by this CU already)
-          if (!__hip_atomic_compare_exchange_strong(&ra.owner[part], &exp, my_slot + 1, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) && exp != my_slot + 1) { part = -1; continue; }
-        }
-        const int ne = (a.n - part + ra.P - 1) / ra.P;              // episodes part, part + P, part + 2 P, ..
-        const uint32_t t = __hip_atomic_fetch_add(&ra.ticket[part], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (t >= (uint32_t)(ne * ra.K)) { part = -1; continue; }    // this partition is handed out: look for another
-        const int k = (int)(t / (uint32_t)ne), ee = part + (int)(t % (uint32_t)ne) * ra.P;
-        while (__hip_atomic_load(&ra.progress[ee], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (uint32_t)k) __builtin_amdgcn_s_sleep(8);
-        item_lds[0] = ee; item_lds[1] = k;
-        got = ee;
-      }
-      if (got == -2) item_lds[0] = -1;
-    }
-    __syncthreads();
-#if !defined(CC4_EXP_PERSIST_CALL)
-    // the body inlined into the item loop: the item's episode and step number as wave-uniform scalars (read from LDS they would be
-    // vector values, and every address the step derives from them with them), and the lane id opaque per item, so that nothing the
-    // step derives from it is hoisted out of the loop and held in registers across the whole step
-    const int e = __builtin_amdgcn_readfirstlane(item_lds[0]);
-    if (e < 0) return;
-    const uint32_t item_k = (uint32_t)__builtin_amdgcn_readfirstlane(item_lds[1]);
-    __syncthreads();
-    int lane_i = (int)threadIdx.x;
-    asm volatile("" : "+v"(lane_i));
-    philox1_body<false, true>(a, e, ra.t0 + item_k, item_k, lane_i);
-#else
-    const int e = item_lds[0];
-    if (e < 0) return;
-    const uint32_t item_k = (uint32_t)item_lds[1];
-    __syncthreads();
-    philox1_item(a, e, ra.t0 + item_k, item_k);
-#endif
-    // the item is done when everything it wrote has left this wave: then the next step of the episode may start (on this CU)
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (lane == 0) __hip_atomic_store(&ra.progress[e], item_k + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  }
-}
-
+__global__ __launch_bounds__(WAVE, 5) void k_run_philox1(StepArgs a, RunArgs ra) { persist_loop<false>(a, ra); }
+#ifndef CC4_DEV_FAST
+// the same schedule around the numpy-stream step (k_step's body): the bit-exact mode's large batches
+__global__ __launch_bounds__(WAVE) void k_run_pcg(StepArgs a, RunArgs ra) { persist_loop<true>(a, ra); }
 #endif
 
 // The plain multi-step form of the one-wave kernel: one wave per episode, every wave loops over the K steps of ITS episode -- no
@@ -1896,6 +1842,14 @@ static int launch_step(cc4_handle* h, const int32_t* d_actions, const uint8_t* d
   return 0;
 }
 
+// the persistent kernel of a handle's mode
+static const void* persist_kernel(const cc4_handle* h) {
+#ifndef CC4_DEV_FAST
+  if (h->cfg.rng_mode == 0) return reinterpret_cast<const void*>(k_run_pcg);
+#endif
+  return reinterpret_cast<const void*>(k_run_philox1);
+}
+
 extern "C" {
 
 const char* cc4_last_error(cc4_handle* h) { return h ? h->err.c_str() : g_create_err.c_str(); }
@@ -1919,7 +1873,7 @@ const char* cc4_run_kernel(cc4_handle* h) {
   const bool plain = !h->comm && !h->evlog_on && !h->ext_seen && !h->d_prof;
   if (plain && h->multistep) return h->multistep_minb == 8 ? "k_run_philox8" : "k_run_philox";
   if (plain && h->run1m) return "k_run_philox1m";
-  if (plain && h->persist_state >= 0) return "k_run_philox1";      // (calls of fewer than persist_min_k steps: the per-step launches)
+  if (plain && h->persist_state >= 0) return h->cfg.rng_mode == 0 ? "k_run_pcg" : "k_run_philox1";      // (calls of fewer than persist_min_k steps: the per-step launches)
   return cc4_step_kernel(h);
 }
 const char* cc4_run_kernel_for(cc4_handle* h, int32_t k) {
@@ -2050,9 +2004,13 @@ int cc4_create(const cc4_config* cfg, cc4_handle** out) {
   if (const char* v = getenv("CC4_ENQ_THREADS")) h->enq_threads = atoi(v) != 0;
   // the persistent run kernel of large batches (k_run_philox1): set up on first use (persist_setup); CC4_PERSIST=0 keeps it off
   h->persist_state = -1;
-  if (cfg->rng_mode == 1 && h->philox_lean && !h->run1m) {
+  bool persist_mode = cfg->rng_mode == 1 && h->philox_lean && !h->run1m;
+#ifndef CC4_DEV_FAST
+  persist_mode = persist_mode || cfg->rng_mode == 0;
+#endif
+  if (persist_mode) {
     int per_cu = 0;
-    HIPCHK(h, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_run_philox1, WAVE, offsetof(EnvState, hd)));
+    HIPCHK(h, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, persist_kernel(h), WAVE, offsetof(EnvState, hd)));
     const int grid = per_cu * h->cus;
     if (per_cu > 0 && cfg->num_envs >= grid + grid / 4) h->persist_state = 0;     // worth it only when the batch is more than the chip holds at once
   }
@@ -2272,16 +2230,21 @@ static int persist_setup(cc4_handle* h) {
   h->persist_state = -1;
   const size_t n = (size_t)h->cfg.num_envs;
   int per_cu = 0;
-  HIPCHK(h, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_run_philox1, WAVE, offsetof(EnvState, hd)));
+  HIPCHK(h, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, persist_kernel(h), WAVE, offsetof(EnvState, hd)));
   const int grid = per_cu * h->cus;
   if (per_cu <= 0) return 0;
   if (join_groups(h)) return -1;
+  // the census waves take the LDS the real kernel's waves will (its static part included): the same number fits a CU
+  hipFuncAttributes fa_run{}, fa_cen{};
+  HIPCHK(h, hipFuncGetAttributes(&fa_run, persist_kernel(h)));
+  HIPCHK(h, hipFuncGetAttributes(&fa_cen, reinterpret_cast<const void*>(k_census)));
+  const size_t census_lds = offsetof(EnvState, hd) + (fa_run.sharedSizeBytes > fa_cen.sharedSizeBytes ? fa_run.sharedSizeBytes - fa_cen.sharedSizeBytes : 0);
   int32_t* d_count = nullptr;
   HIPCHK(h, hipMalloc(&d_count, CC4_SLOTS * sizeof(int32_t)));
   HIPCHK(h, hipMemsetAsync(d_count, 0, CC4_SLOTS * sizeof(int32_t), h->stream));
   int khz = 100000;
   (void)hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, h->cfg.device_id);
-  hipLaunchKernelGGL(k_census, dim3(grid), dim3(WAVE), offsetof(EnvState, hd), h->stream, d_count, 200LL * (khz > 0 ? khz : 100000) / 1000);   // ~200 us
+  hipLaunchKernelGGL(k_census, dim3(grid), dim3(WAVE), census_lds, h->stream, d_count, 200LL * (khz > 0 ? khz : 100000) / 1000);   // ~200 us
   std::vector<int32_t> count(CC4_SLOTS);
   HIPCHK(h, hipMemcpyAsync(count.data(), d_count, CC4_SLOTS * sizeof(int32_t), hipMemcpyDeviceToHost, h->stream));
   HIPCHK(h, hipStreamSynchronize(h->stream));
@@ -2357,6 +2320,12 @@ int cc4_run_random_steps(cc4_handle* h, uint64_t seed0, uint32_t t0, int32_t k, 
     RunArgs ra{h->d_run, h->d_run + 2 * h->run_P, reinterpret_cast<int32_t*>(h->d_run + h->run_P), h->d_slot_part, h->run_P, k, t0};
     if (ms_step_kernels && h->evs.size() < 2) { h->evs.resize(2, nullptr); for (auto& e : h->evs) if (!e) HIPCHK(h, hipEventCreate(&e)); }
     auto c0 = std::chrono::steady_clock::now();
+#ifndef CC4_DEV_FAST
+    if (h->cfg.rng_mode == 0)
+      hipExtLaunchKernelGGL(k_run_pcg, dim3(h->run_grid), dim3(WAVE), offsetof(EnvState, hd), h->stream,
+                            ms_step_kernels ? h->evs[0] : nullptr, ms_step_kernels ? h->evs[1] : nullptr, 0, a, ra);
+    else
+#endif
     hipExtLaunchKernelGGL(k_run_philox1, dim3(h->run_grid), dim3(WAVE), offsetof(EnvState, hd), h->stream,
                           ms_step_kernels ? h->evs[0] : nullptr, ms_step_kernels ? h->evs[1] : nullptr, 0, a, ra);
     HIPCHK(h, hipGetLastError());

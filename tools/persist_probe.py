@@ -1,14 +1,15 @@
 """Parity probe of the one-launch forms of cc4_run_random_steps (k_run_philox: the multi-step four-wave kernel of small batches;
-k_run_philox1 with CC4_PERSIST=1): bursts of K steps across a scenario regeneration against the oracle.  usage: persist_probe.py [n]"""
+k_run_philox1 with CC4_PERSIST=1): bursts of K steps across a scenario regeneration against the oracle.  usage: persist_probe.py [n] [rng mode]"""
 import sys, os, time
 sys.path.insert(0, '.'); sys.path.insert(0, 'tests')
 import numpy as np
 from cage_challenge_4_amd import CC4VecEnv
 from oracle_binding import OracleVecEnv, random_actions
 n, steps, seed0 = (int(sys.argv[1]) if len(sys.argv) > 1 else 8192), 150, 4242
-dev = CC4VecEnv(n, steps=steps, rng_mode=1, autoreset=True)
-print('kernel', dev.step_kernel, 'launches per step', dev.launches_per_step, flush=True)
-ora = OracleVecEnv(n, steps=steps, rng_mode=1, autoreset=True)
+mode = int(sys.argv[2]) if len(sys.argv) > 2 else 1          # 1 counter mode, 0 numpy stream
+dev = CC4VecEnv(n, steps=steps, rng_mode=mode, autoreset=True)
+print('kernel', dev.step_kernel, 'run kernel', dev.run_kernel, 'launches per step', dev.launches_per_step, flush=True)
+ora = OracleVecEnv(n, steps=steps, rng_mode=mode, autoreset=True)
 assert np.array_equal(dev.reset(seeds=seed0), ora.reset_batch(seed0))
 t = 0
 for K in (2, 20, 137, 20):

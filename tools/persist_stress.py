@@ -1,18 +1,19 @@
 """Stress of the persistent kernel's shared tail (items of a partition taken by other CUs of the XCD behind an agent-scope acquire): many short
-calls -- every call ends in a tail -- of varying length against the oracle, several batch sizes.  usage: persist_stress.py [rounds]"""
+calls -- every call ends in a tail -- of varying length against the oracle, several batch sizes.  usage: persist_stress.py [rounds] [rng mode]"""
 import sys, os
 sys.path.insert(0, '.'); sys.path.insert(0, 'tests')
 import numpy as np
 from cage_challenge_4_amd import CC4VecEnv
 from oracle_binding import OracleVecEnv, random_actions
 rounds = int(sys.argv[1]) if len(sys.argv) > 1 else 2
+mode = int(sys.argv[2]) if len(sys.argv) > 2 else 1          # 1 counter mode (k_run_philox1), 0 numpy stream (k_run_pcg)
 bad_total = 0
 for rnd in range(rounds):
     for n in (8192, 6400, 7001, 12288):
         steps, seed0 = 120, 9000 + 17 * rnd + n
-        dev = CC4VecEnv(n, steps=steps, rng_mode=1, autoreset=True)
-        assert dev.run_kernel == 'k_run_philox1', dev.run_kernel
-        ora = OracleVecEnv(n, steps=steps, rng_mode=1, autoreset=True)
+        dev = CC4VecEnv(n, steps=steps, rng_mode=mode, autoreset=True)
+        assert dev.run_kernel == ('k_run_pcg', 'k_run_philox1')[mode], dev.run_kernel
+        ora = OracleVecEnv(n, steps=steps, rng_mode=mode, autoreset=True)
         assert np.array_equal(dev.reset(seeds=seed0), ora.reset_batch(seed0))
         t = 0
         for K in (10, 11, 13, 10, 25, 10, 12, 40, 10, 10, 15, 10, 33, 10, 10, 21, 10):
