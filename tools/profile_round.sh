@@ -39,7 +39,7 @@ python tools/tail_whatif.py 1024 200 > $OUT/${TAG}_tail_whatif.txt 2>&1
 python tools/tail_profile.py 1024 100 1 > $OUT/${TAG}_tail_philox.txt 2>&1
 unset CC4_PERSIST
 # 5. numpy-stream kernel: kernel stats at 8192 episodes, what the lane-parallel green actions do per step
-rocprofv3 --kernel-trace --stats -d $OUT/statspcg -- $BENCH --rng pcg64 > $OUT/bench_statspcg.json 2> $OUT/statspcg.err
+rocprofv3 --kernel-trace --stats -d $OUT/statspcg -- $BENCH --rng pcg64 --warmup 5 > $OUT/bench_statspcg.json 2> $OUT/statspcg.err
 python tools/rocpd_summary.py stats $OUT/statspcg $OUT/${TAG}_kernel_stats_8192env_pcg64.txt > /dev/null
 python tools/green_batches.py 1024 50 > $OUT/${TAG}_green_batches_pcg64_1024env.txt 2>&1
 ls -la $OUT | head -50
