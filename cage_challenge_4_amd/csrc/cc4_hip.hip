@@ -1990,7 +1990,8 @@ int cc4_create(const cc4_config* cfg, cc4_handle** out) {
     }
     if (getenv("CC4_PERSIST_DEBUG")) fprintf(stderr, "[cc4] k_run_philox: %d / %d blocks per CU resident, multistep %d (build %d)\n", per_cu, per_cu8, (int)h->multistep, h->multistep_minb);
   }
-  if (cfg->rng_mode == 1 && h->philox_lean) {
+  if (cfg->rng_mode == 1 && !h->multistep) {
+    // (whichever per-step kernel the handle runs: a batch of 2049-5120 episodes that cc4_step serves with the four-wave kernel is served here by the one-wave loop)
     // the plain multi-step form of the one-wave kernel (k_run_philox1m) where one launch holds the whole batch: 20 waves per CU
     // (4096 episodes 507 -> 709 M, 5120: 586 -> 811 M; beyond the residency the second round runs on a half-empty chip and four
     // streams of per-step launches win: 8192: 740 vs 789 M, 16384: 812 vs 864 M -- profiles/r04_run1m_ab.txt)
@@ -2004,7 +2005,7 @@ int cc4_create(const cc4_config* cfg, cc4_handle** out) {
   if (const char* v = getenv("CC4_ENQ_THREADS")) h->enq_threads = atoi(v) != 0;
   // the persistent run kernel of large batches (k_run_philox1): set up on first use (persist_setup); CC4_PERSIST=0 keeps it off
   h->persist_state = -1;
-  bool persist_mode = cfg->rng_mode == 1 && h->philox_lean && !h->run1m;
+  bool persist_mode = cfg->rng_mode == 1 && !h->multistep && !h->run1m;
 #ifndef CC4_DEV_FAST
   persist_mode = persist_mode || cfg->rng_mode == 0;
 #endif
@@ -2012,7 +2013,7 @@ int cc4_create(const cc4_config* cfg, cc4_handle** out) {
     int per_cu = 0;
     HIPCHK(h, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, persist_kernel(h), WAVE, offsetof(EnvState, hd)));
     const int grid = per_cu * h->cus;
-    if (per_cu > 0 && cfg->num_envs >= grid + grid / 4) h->persist_state = 0;     // worth it only when the batch is more than the chip holds at once
+    if (per_cu > 0 && cfg->num_envs > grid) h->persist_state = 0;     // batches of more than the chip holds at once (with the tail shared, also just more)
   }
   if (const char* v = getenv("CC4_PERSIST")) { if (atoi(v) == 0) h->persist_state = -1; }
   if (const char* v = getenv("CC4_PERSIST_MIN_K")) h->persist_min_k = atoi(v);
