@@ -277,6 +277,34 @@ def test_enqueue_threads_change_nothing(threads, monkeypatch):
         dev.close(); ora.close()
 
 
+@pytest.mark.parametrize('mode,kernel', [(1, 'k_run_philox1'), (0, 'k_run_pcg')], ids=['counter', 'numpy-stream'])
+def test_persistent_kernel_and_its_shared_tail(mode, kernel):
+    """The persistent run kernel of large batches: many short calls -- every call ends in a tail whose items the CUs of an XCD share
+    behind an agent-scope acquire -- of varying length across a regeneration against the oracle; a batch just beyond what one launch holds
+    (partitions of 20-28 episodes for 18-20 waves) and calls too short for it (per-step launches) in between."""
+    n, steps, seed0 = (5632 if mode else 5000), 90, 31337
+    dev = _dev(n, steps=steps, rng_mode=mode, autoreset=True)
+    assert dev.run_kernel == kernel and dev.run_kernel_for(9) == dev.step_kernel and dev.run_kernel_for(10) == kernel
+    ora = OracleVecEnv(n, steps=steps, rng_mode=mode, autoreset=True)
+    assert np.array_equal(dev.reset(seeds=seed0), ora.reset_batch(seed0))
+    t = 0
+    for K in (10, 13, 3, 10, 25, 11, 40, 10, 1, 17):
+        dev.run_random_steps(seed0, t, K, timed=(K % 2 == 1))
+        for k in range(K):
+            a = random_actions(seed0, t + k, n)
+            o = ora.step_batch(a)
+        t += K
+        dev.synchronize(); dev._fetch()
+        bad = np.nonzero((dev._obs != o[0]).any(axis=1) | (dev._rew != o[1]) | (dev._done.astype(bool) != o[2]) | (dev._err != o[3]['err']))[0]
+        assert bad.size == 0, (K, t, bad[:10].tolist())
+        assert np.array_equal(dev.device_actions(), a), (K, t)
+    assert t > steps
+    assert np.array_equal(dev.rng_state(), ora.rng_state())
+    for i in range(0, n, 3):
+        assert np.array_equal(dev.get_state(i), ora.get_state(i)), i
+    dev.close(); ora.close()
+
+
 def test_device_random_action_kernel_matches_host_restatement():
     import ctypes
     n = 1024
