@@ -299,6 +299,16 @@ def test_persistent_kernel_and_its_shared_tail(mode, kernel):
         assert bad.size == 0, (K, t, bad[:10].tolist())
         assert np.array_equal(dev.device_actions(), a), (K, t)
     assert t > steps
+    for k in range(3):                                   # plain steps with the caller's actions behind the one-launch calls, then another call
+        a = random_actions(seed0 + 1, t + k, n)
+        d = dev.step(a); o = ora.step_batch(a)
+        assert np.array_equal(d[0], o[0]) and np.array_equal(d[1], o[1]) and np.array_equal(d[2], o[2]), k
+    t += 3
+    dev.run_random_steps(seed0, t, 12, timed=True)
+    for k in range(12):
+        o = ora.step_batch(random_actions(seed0, t + k, n))
+    dev.synchronize(); dev._fetch()
+    assert np.array_equal(dev._obs, o[0]) and np.array_equal(dev._rew, o[1])
     assert np.array_equal(dev.rng_state(), ora.rng_state())
     for i in range(0, n, 3):
         assert np.array_equal(dev.get_state(i), ora.get_state(i)), i
