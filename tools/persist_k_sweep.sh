@@ -1,7 +1,7 @@
 export CC4_LIB=$PWD/$1
 export CC4_RUN1=0
 for k in 10 20 32 50 100 500; do for mode in persist streams; do
-  if [ $mode = persist ]; then export CC4_PERSIST=1; else unset CC4_PERSIST; fi
+  if [ $mode = persist ]; then unset CC4_PERSIST; else export CC4_PERSIST=0; fi
   python bench.py --no-alt --no-cpu-baseline --steps $k --warmup 5 --total-envs 8192 2>/dev/null | python -c "
 import sys,json
 for l in sys.stdin:
