@@ -302,6 +302,7 @@ def main():
 
     def measure(e, first, n_total):
         key = args.seed0 + first            # action key = seed0 + global episode index
+        run_kernel = e.run_kernel_for(args.steps)     # (asked before the timed regions: a persistent kernel's one-off census happens here)
         secs, kms = timed_regions(lambda t0, k, timed: e.run_random_steps(key, t0, k, timed=timed), args.steps, args.warmup,
                                   args.min_seconds, e.synchronize, plane.barrier, reduce_max)
         out = summarise(secs, kms, args.steps, n_total)
@@ -310,7 +311,7 @@ def main():
         out['launches_per_step'] = e.launches_per_step      # of the per-step kernel (`kernel`); see run_kernel
         # what cc4_run_random_steps launches: the step kernel once per step and group, or -- a batch the chip holds at once -- ONE launch
         # of the multi-step kernel per timed region (k_run_philox: every block loops over the steps of its episode, the row stays in LDS)
-        out['run_kernel'] = e.run_kernel_for(args.steps)
+        out['run_kernel'] = run_kernel
         return out
 
     main_res = measure(env, lo, total_envs)

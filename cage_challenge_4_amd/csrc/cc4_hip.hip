@@ -1876,8 +1876,12 @@ const char* cc4_run_kernel(cc4_handle* h) {
   if (plain && h->persist_state >= 0) return h->cfg.rng_mode == 0 ? "k_run_pcg" : "k_run_philox1";      // (calls of fewer than persist_min_k steps: the per-step launches)
   return cc4_step_kernel(h);
 }
+static int persist_setup(cc4_handle* h);
 const char* cc4_run_kernel_for(cc4_handle* h, int32_t k) {
   if (!h) return "";
+  // (the persistent kernel's census runs on first use: asking which kernel a call of k steps will launch is such a use -- the answer depends on it,
+  // and a caller that asks before its timed region keeps the census out of it)
+  if (h->persist_state == 0 && !h->run1m && !h->multistep && !h->comm && !h->evlog_on && !h->ext_seen && !h->d_prof && k >= h->persist_min_k && hipSetDevice(h->cfg.device_id) == hipSuccess) (void)persist_setup(h);
   const char* r = cc4_run_kernel(h);
   if (k < 2) return cc4_step_kernel(h);
   if (!h->multistep && !h->run1m && h->persist_state >= 0 && k < h->persist_min_k) return cc4_step_kernel(h);
