@@ -55,6 +55,8 @@ SIGNATURES = {
     'cc4_get_reward_done': (ctypes.c_int, [_P, _P, _P]),
     'cc4_get_action_mask': (ctypes.c_int, [_P, _P]),
     'cc4_get_err': (ctypes.c_int, [_P, _P]),
+    'cc4_fetch': (ctypes.c_int, [_P, _P, _P, _P, _P]),
+    'cc4_step_fetch': (ctypes.c_int, [_P, _P, _P, _P, _P, _P, _P]),
     'cc4_get_rng_state': (ctypes.c_int, [_P, _P]),
     'cc4_set_seed': (ctypes.c_int, [_P, _P]),
     'cc4_set_rng_state': (ctypes.c_int, [_P, _P]),
@@ -70,6 +72,7 @@ SIGNATURES = {
     'cc4_launches_per_step': (ctypes.c_int, [_P]),
     'cc4_debug_comm_delay_us': (ctypes.c_int, [_P, ctypes.c_int]),
     'cc4_host_stats': (ctypes.c_int, [_P, _P]),
+    'cc4_verify_stats': (ctypes.c_int, [_P, _P]),
     'cc4_state_bytes': (ctypes.c_size_t, []),
     'cc4_hot_bytes': (ctypes.c_size_t, []),
     'cc4_step_kernel': (ctypes.c_char_p, [_P]),

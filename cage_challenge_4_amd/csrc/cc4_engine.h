@@ -945,9 +945,7 @@ CC4_HD void env_reset(Ctx x, uint64_t seed, int rng_mode, int steps, bool contin
   }
   // bitmap of used_pids over 1000..9999: by default lent from the session pool, which stays empty until red_agent_0's
   // session is added at the very end (records 8 .. 151; zeroed again below)
-#ifndef CC4_EXP_OCC
   static_assert(8 + 288 * 4 / sizeof(RSess) <= RS_POOL, "the used-pid bitmap fits the idle session pool");
-#endif
   uint32_t* used = pid_ws ? pid_ws : reinterpret_cast<uint32_t*>(&s->spool[8]);
   for (int i = 0; i < 288; ++i) used[i] = 0;
 

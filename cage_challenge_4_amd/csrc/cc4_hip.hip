@@ -1048,6 +1048,9 @@ struct RunArgs {
   const int16_t* slot_part;    // [CC4_SLOTS] census: slot id -> partition, -1 = no such CU
   int P, K;
   uint32_t t0;                 // action time of step 0 (random_blue_action)
+  int order;                   // memory ordering of the hand-over between two items of an episode (CC4_PERSIST_ORDER, persist_loop):
+                               // 0 = ordering only (same CU: the waves of a CU share its L1), 1 = every item starts with an agent-scope acquire,
+                               // 2 = ... and ends with an agent-scope release
 };
 constexpr int CC4_SLOTS = 2048;    // (XCC id << 8) | HW_ID[15:8]
 __device__ __forceinline__ int cu_slot() {
@@ -1335,6 +1338,7 @@ __device__ __forceinline__ void persist_loop(StepArgs a, RunArgs ra) {
         if (t < (uint32_t)(ne * ra.K)) {
           const int k = (int)(t / (uint32_t)ne), ee = part + (int)(t % (uint32_t)ne) * ra.P;
           while (__hip_atomic_load(&ra.progress[ee], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (uint32_t)k) __builtin_amdgcn_s_sleep(8);
+          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");      // nothing the item reads may be read ahead of the flag (compiler and wave)
           res_e = ee; res_k = k; res_sh = (thief || (tr & TK_SHARED)) ? 1 : 0;
         }
       }
@@ -1380,7 +1384,7 @@ __device__ __forceinline__ void persist_loop(StepArgs a, RunArgs ra) {
     const uint32_t item_k = (uint32_t)__builtin_amdgcn_readfirstlane(item_lds[1]);
     const int shared = __builtin_amdgcn_readfirstlane(item_lds[2]);
     __syncthreads();
-    if (shared) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    if (shared || ra.order >= 1) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
     int lane_i = (int)threadIdx.x;
     asm volatile("" : "+v"(lane_i));
     if constexpr (PCG) {
@@ -1391,7 +1395,11 @@ __device__ __forceinline__ void persist_loop(StepArgs a, RunArgs ra) {
       philox1_body<false, true>(a, e, ra.t0 + item_k, item_k, lane_i);
     }
     // the item is done when everything it wrote has left this wave: then the next step of the episode may start (on this XCD)
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    // Release: every lane drains its own stores (workgroup-scope release = s_waitcnt vmcnt(0) on gfx950 without tgsplit: the vector L1 is
+    // write-through, so a drained store is in the XCD's L2), the barrier collects the lanes, lane 0 publishes.  The consumer is a wave of
+    // the same CU (same L1) unless the partition is shared, in which case it drops its L1 first (agent-scope acquire above).
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    if (ra.order >= 2) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
     __syncthreads();
     if (lane == 0) __hip_atomic_store(&ra.progress[e], item_k + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
@@ -1534,6 +1542,29 @@ __global__ void k_rng_state(const EnvState* st, uint64_t* out, int n) {
 }
 
 // ---------------------------------------------------------------- handle
+// CC4_PERSIST_VERIFY: a digest per episode of everything a call of cc4_run_random_steps leaves behind -- hot row, cold row, observations,
+// reward / done / error word, the drawn actions -- in three words (hot, cold, outputs), so that a mismatch says where
+__global__ __launch_bounds__(WAVE) void k_digest(const EnvState* st, const EnvCold* cold, size_t cold_row, const int32_t* obs, const float* reward,
+                                                 const uint8_t* done, const uint32_t* err, const int32_t* actions, uint64_t* out, int n) {
+  const int e = blockIdx.x, lane = threadIdx.x;
+  if (e >= n) return;
+  auto mix = [](uint64_t h, uint64_t v) { h ^= v + 0x9E3779B97F4A7C15ull + (h << 6) + (h >> 2); return h * 0xD6E8FEB86659FD93ull; };
+  auto hash_vecs = [&](const uint4* p, size_t nv) {
+    uint64_t h = 0x1234567ull + (uint64_t)lane;
+    for (size_t i = lane; i < nv; i += WAVE) { const uint4 v = p[i]; h = mix(h, ((uint64_t)v.x << 32) | v.y); h = mix(h, ((uint64_t)v.z << 32) | v.w); }
+    for (int off = 32; off >= 1; off >>= 1) h += __shfl_xor(h, off);     // order-independent across lanes, position-dependent within one
+    return h;
+  };
+  const uint64_t h_hot = hash_vecs(reinterpret_cast<const uint4*>(st + e), sizeof(EnvState) / 16);
+  const uint64_t h_cold = hash_vecs(reinterpret_cast<const uint4*>(cold_at(const_cast<EnvCold*>(cold), (size_t)e, cold_row)), cold_row / 16);
+  uint64_t h = 0x89ABCDEFull + (uint64_t)lane;
+  for (int i = lane; i < OBS_TOTAL; i += WAVE) h = mix(h, (uint64_t)(uint32_t)obs[(size_t)e * OBS_TOTAL + i]);
+  if (lane < NBLUE) h = mix(h, (uint64_t)(uint32_t)actions[e * NBLUE + lane]);
+  if (lane == 8) { h = mix(h, (uint64_t)__float_as_uint(reward[e])); h = mix(h, ((uint64_t)done[e] << 32) | err[e]); }
+  for (int off = 32; off >= 1; off >>= 1) h += __shfl_xor(h, off);
+  if (lane == 0) { out[3 * (size_t)e] = h_hot; out[3 * (size_t)e + 1] = h_cold; out[3 * (size_t)e + 2] = h; }
+}
+
 struct cc4_handle {
   cc4_config cfg;
   hipStream_t stream = nullptr;
@@ -1542,6 +1573,11 @@ struct cc4_handle {
   int32_t* d_actions = nullptr; uint8_t* d_msgs = nullptr; uint64_t* d_seeds = nullptr; uint8_t* d_envmask = nullptr;
   int32_t* d_obs = nullptr; float* d_reward = nullptr; uint8_t* d_done = nullptr; uint32_t* d_err = nullptr;
   uint8_t* d_mask = nullptr; uint64_t* d_rng = nullptr;
+  // d_obs | d_reward | d_err | d_done are ONE allocation (base d_obs), d_actions | d_msgs another (base d_actions): cc4_step_fetch moves
+  // a step's inputs and outputs with one copy each; small batches go through pinned staging buffers (a copy to or from pageable
+  // memory is staged by the runtime anyway, synchronously and per call)
+  size_t out_bytes = 0, in_bytes = 0;
+  uint8_t* pin_out = nullptr; uint8_t* pin_in = nullptr;
   // byte observations and gathered observations ([world*N][578]) in a ring of OBS_RING buffers: the all-gather of step t
   // overlaps later steps, and the compute stream waits for the communication stream only once per OBS_WAIT_EVERY steps
   // (a cross-stream wait in front of every launch costs the stream ~10 us)
@@ -1587,6 +1623,14 @@ struct cc4_handle {
   int16_t* d_slot_part = nullptr; // [CC4_SLOTS]
   int run_P = 0, run_grid = 0;    // partitions (= CUs that take waves), waves per launch; 0: the persistent path is off
   int persist_state = -1;         // -1 off / unavailable, 0 not set up yet (persist_setup on first use), 1 on
+  int persist_order = 0;          // RunArgs.order (CC4_PERSIST_ORDER)
+  bool persist_refused = false;   // persist_setup found an unexpected picture (said so on stderr; cc4_run_kernel reports the per-step kernel)
+  // CC4_PERSIST_VERIFY=1: every one-launch call of cc4_run_random_steps is repeated with per-step launches on a shadow handle that starts
+  // from a copy of this handle's rows, and the two results are compared episode by episode (verify_*)
+  bool verify = false, is_shadow = false;
+  cc4_handle* shadow = nullptr;
+  uint64_t* d_digest = nullptr;   // [num_envs] per-episode digest
+  long long verify_calls = 0, verify_mismatches = 0;
   int persist_min_k = 10;         // shorter calls keep the per-step launches: a launch's ramp and tail cost a few steps' worth (with the tail's items shared
                                   // among the CUs of an XCD: K = 10: 733 vs 685 M, K = 20: 813 vs 742 M, K = 32: 857 vs 756 M; CC4_PERSIST_MIN_K)
   struct EnqPool* pool = nullptr; // one enqueue thread per group stream beyond the first (cc4_run_random_steps; enq_*)
@@ -1737,13 +1781,15 @@ static void launch_group(cc4_handle* h, StepArgs a, int g, bool full, hipEvent_t
 // ---- one enqueue thread per group stream (cc4_run_random_steps without a communicator).  The groups of a batch never wait for each
 // other, so their launches need not come from one thread: the first launch on a stream that has been synchronised costs the calling
 // thread ~10 us (3.5 us in the steady state), four in a row delay the last group's first kernel by 30-45 us in every timed region;
-// issued side by side they cost one.  A worker spins for a few milliseconds after a call (a loop of calls keeps it hot), then sleeps.
+// issued side by side they cost one.  A worker spins for 200 us after a call (CC4_ENQ_SPIN_US; a loop of calls keeps it hot), then sleeps.
 struct EnqPool {
   std::vector<std::thread> th;
   std::mutex mu; std::condition_variable cv;
   std::atomic<uint64_t> gen{0};
   std::atomic<int> pending{0}, failed{0};
   std::atomic<bool> quit{false};
+  int spin_us = 200;            // how long a worker spins for the next call before it parks on the condition variable (CC4_ENQ_SPIN_US): a loop of
+                                // calls with nothing in between keeps it hot, a caller that does host work between bursts gets its cores back
   StepArgs a{}; int k = 0; uint32_t t0 = 0; bool full = false, first_full_obs = false, join = false;
   hipEvent_t start[cc4_handle_max_groups] = {}, stop[cc4_handle_max_groups] = {};
 };
@@ -1765,7 +1811,7 @@ static void enq_worker(cc4_handle* h, EnqPool* P, int g) {
     int spins = 0;
     while (P->gen.load(std::memory_order_acquire) == seen && !P->quit.load(std::memory_order_relaxed)) {
       __builtin_ia32_pause();
-      if ((++spins & 1023) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(3)) {
+      if ((++spins & 255) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::microseconds(P->spin_us)) {
         std::unique_lock<std::mutex> lk(P->mu);
         P->cv.wait(lk, [&] { return P->gen.load(std::memory_order_acquire) != seen || P->quit.load(); });
       }
@@ -1779,6 +1825,7 @@ static void enq_worker(cc4_handle* h, EnqPool* P, int g) {
 static void enq_pool_start(cc4_handle* h) {
   if (h->pool || h->ngroups < 2) return;
   h->pool = new EnqPool;
+  if (const char* v = getenv("CC4_ENQ_SPIN_US")) h->pool->spin_us = atoi(v) > 0 ? atoi(v) : 0;
   for (int g = 1; g < h->ngroups; ++g) h->pool->th.emplace_back(enq_worker, h, h->pool, g);
 }
 static void enq_pool_stop(cc4_handle* h) {
@@ -1961,14 +2008,16 @@ int cc4_create(const cc4_config* cfg, cc4_handle** out) {
   h->cold_row = cold_row_bytes(cfg->steps);
   HIPCHK(h, hipMalloc(&h->d_cold, n * h->cold_row));
   if (cfg->rng_mode == 1) HIPCHK(h, hipMalloc(&h->d_reset_ws, n * RESET_WS_WORDS * sizeof(uint32_t)));   // the one-wave kernel's generation work area
-  HIPCHK(h, hipMalloc(&h->d_actions, n * NBLUE * sizeof(int32_t)));
-  HIPCHK(h, hipMalloc(&h->d_msgs, n * NBLUE * MSG_LEN));
+  h->in_bytes = n * NBLUE * sizeof(int32_t) + n * NBLUE * MSG_LEN;
+  HIPCHK(h, hipMalloc(&h->d_actions, h->in_bytes));
+  h->d_msgs = reinterpret_cast<uint8_t*>(h->d_actions) + n * NBLUE * sizeof(int32_t);
   HIPCHK(h, hipMalloc(&h->d_seeds, n * sizeof(uint64_t)));
   HIPCHK(h, hipMalloc(&h->d_envmask, n));
-  HIPCHK(h, hipMalloc(&h->d_obs, n * OBS_TOTAL * sizeof(int32_t)));
-  HIPCHK(h, hipMalloc(&h->d_reward, n * sizeof(float)));
-  HIPCHK(h, hipMalloc(&h->d_done, n));
-  HIPCHK(h, hipMalloc(&h->d_err, n * sizeof(uint32_t)));
+  h->out_bytes = n * OBS_TOTAL * sizeof(int32_t) + n * sizeof(float) + n * sizeof(uint32_t) + n;
+  HIPCHK(h, hipMalloc(&h->d_obs, h->out_bytes));
+  h->d_reward = reinterpret_cast<float*>(h->d_obs + n * OBS_TOTAL);
+  h->d_err = reinterpret_cast<uint32_t*>(h->d_reward + n);
+  h->d_done = reinterpret_cast<uint8_t*>(h->d_err + n);
   HIPCHK(h, hipMalloc(&h->d_mask, n * MASK_TOTAL));
   HIPCHK(h, hipMalloc(&h->d_rng, n * 7 * sizeof(uint64_t)));
   HIPCHK(h, hipMemsetAsync(h->d_state, 0, n * sizeof(EnvState), h->stream));
@@ -2021,6 +2070,8 @@ int cc4_create(const cc4_config* cfg, cc4_handle** out) {
   }
   if (const char* v = getenv("CC4_PERSIST")) { if (atoi(v) == 0) h->persist_state = -1; }
   if (const char* v = getenv("CC4_PERSIST_MIN_K")) h->persist_min_k = atoi(v);
+  if (const char* v = getenv("CC4_PERSIST_ORDER")) h->persist_order = atoi(v);
+  if (const char* v = getenv("CC4_PERSIST_VERIFY")) h->verify = atoi(v) != 0;
   return 0;
 }
 
@@ -2033,9 +2084,13 @@ void cc4_destroy(cc4_handle* h) {
   if (h->comm) ncclCommDestroy(h->comm);
   for (int b = 0; b < cc4_handle::OBS_RING; ++b) { for (int g = 0; g < cc4_handle::MAX_GROUPS; ++g) if (h->ev_step[b][g]) (void)hipEventDestroy(h->ev_step[b][g]); if (h->ev_comm[b]) (void)hipEventDestroy(h->ev_comm[b]); }
   if (h->comm_stream) (void)hipStreamDestroy(h->comm_stream);
-  void* ptrs[] = {h->d_state, h->d_cold, h->d_actions, h->d_msgs, h->d_seeds, h->d_envmask, h->d_obs, h->d_reward,
-                  h->d_done, h->d_err, h->d_mask, h->d_rng, h->d_reset_ws, h->d_ext, h->d_run, h->d_slot_part};
+  void* ptrs[] = {h->d_state, h->d_cold, h->d_actions, h->d_seeds, h->d_envmask, h->d_obs,
+                  h->d_mask, h->d_rng, h->d_reset_ws, h->d_ext, h->d_run, h->d_slot_part};     // (d_msgs, d_reward, d_err, d_done live inside d_actions / d_obs)
   for (void* p : ptrs) if (p) (void)hipFree(p);
+  if (h->shadow) { cc4_destroy(h->shadow); h->shadow = nullptr; (void)hipSetDevice(h->cfg.device_id); }
+  if (h->d_digest) (void)hipFree(h->d_digest);
+  if (h->pin_in) (void)hipHostFree(h->pin_in);
+  if (h->pin_out) (void)hipHostFree(h->pin_out);
   for (int b = 0; b < cc4_handle::OBS_RING; ++b) { if (h->d_obs8[b]) (void)hipFree(h->d_obs8[b]); if (h->d_all_obs8[b]) (void)hipFree(h->d_all_obs8[b]); }
   if (h->d_unpacked) (void)hipFree(h->d_unpacked);
   for (hipEvent_t e : h->evs) if (e) (void)hipEventDestroy(e);
@@ -2075,6 +2130,56 @@ int cc4_step(cc4_handle* h, const int32_t* actions, const uint8_t* messages) {
   if (messages) HIPCHK(h, hipMemcpyAsync(h->d_msgs, messages, n * NBLUE * MSG_LEN, hipMemcpyHostToDevice, h->stream));
   if (launch_step(h, actions ? h->d_actions : nullptr, messages ? h->d_msgs : nullptr)) return -1;
   return sync_all(h);
+}
+
+// The outputs of the last step (or reset) in one copy and one host synchronisation: observations, reward, done and error flags live in
+// one device allocation.  Batches of up to PIN_MAX_ENVS episodes come through a pinned staging buffer (the copy is a real asynchronous
+// DMA; a copy into pageable memory is staged by the runtime, call by call).  Any of the four pointers may be null.
+constexpr int PIN_MAX_ENVS = 4096;
+static int fetch_outputs(cc4_handle* h, int32_t* obs, float* reward, uint8_t* done, uint32_t* err) {
+  if (join_groups(h)) return -1;
+  const size_t n = (size_t)h->cfg.num_envs;
+  const size_t b_obs = n * OBS_TOTAL * sizeof(int32_t), b_rew = n * sizeof(float), b_err = n * sizeof(uint32_t);
+  if (h->cfg.num_envs <= PIN_MAX_ENVS) {
+    if (!h->pin_out) HIPCHK(h, hipHostMalloc(reinterpret_cast<void**>(&h->pin_out), h->out_bytes, hipHostMallocDefault));
+    const size_t lo = obs ? 0 : b_obs;                         // (a caller that wants no observations does not pay for them)
+    HIPCHK(h, hipMemcpyAsync(h->pin_out + lo, reinterpret_cast<const uint8_t*>(h->d_obs) + lo, h->out_bytes - lo, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    if (obs) memcpy(obs, h->pin_out, b_obs);
+    if (reward) memcpy(reward, h->pin_out + b_obs, b_rew);
+    if (err) memcpy(err, h->pin_out + b_obs + b_rew, b_err);
+    if (done) memcpy(done, h->pin_out + b_obs + b_rew + b_err, n);
+    return 0;
+  }
+  if (obs) HIPCHK(h, hipMemcpyAsync(obs, h->d_obs, b_obs, hipMemcpyDeviceToHost, h->stream));
+  if (reward) HIPCHK(h, hipMemcpyAsync(reward, h->d_reward, b_rew, hipMemcpyDeviceToHost, h->stream));
+  if (err) HIPCHK(h, hipMemcpyAsync(err, h->d_err, b_err, hipMemcpyDeviceToHost, h->stream));
+  if (done) HIPCHK(h, hipMemcpyAsync(done, h->d_done, n, hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  return 0;
+}
+int cc4_fetch(cc4_handle* h, int32_t* obs, float* reward, uint8_t* done, uint32_t* err) {
+  HIPCHK(h, hipSetDevice(h->cfg.device_id));
+  return fetch_outputs(h, obs, reward, done, err);
+}
+// cc4_step + cc4_fetch with one host synchronisation in all: inputs up in one copy, the step's launches, outputs down in one copy
+int cc4_step_fetch(cc4_handle* h, const int32_t* actions, const uint8_t* messages, int32_t* obs, float* reward, uint8_t* done, uint32_t* err) {
+  HIPCHK(h, hipSetDevice(h->cfg.device_id));
+  if (join_groups(h)) return -1;
+  const size_t n = (size_t)h->cfg.num_envs;
+  const size_t b_act = n * NBLUE * sizeof(int32_t), b_msg = n * NBLUE * MSG_LEN;
+  if (h->cfg.num_envs <= PIN_MAX_ENVS && (actions || messages)) {
+    if (!h->pin_in) HIPCHK(h, hipHostMalloc(reinterpret_cast<void**>(&h->pin_in), h->in_bytes, hipHostMallocDefault));
+    if (actions) memcpy(h->pin_in, actions, b_act);
+    if (messages) memcpy(h->pin_in + b_act, messages, b_msg);
+    const size_t lo = actions ? 0 : b_act, hi = messages ? b_act + b_msg : b_act;
+    HIPCHK(h, hipMemcpyAsync(reinterpret_cast<uint8_t*>(h->d_actions) + lo, h->pin_in + lo, hi - lo, hipMemcpyHostToDevice, h->stream));
+  } else {
+    if (actions) HIPCHK(h, hipMemcpyAsync(h->d_actions, actions, b_act, hipMemcpyHostToDevice, h->stream));
+    if (messages) HIPCHK(h, hipMemcpyAsync(h->d_msgs, messages, b_msg, hipMemcpyHostToDevice, h->stream));
+  }
+  if (launch_step(h, actions ? h->d_actions : nullptr, messages ? h->d_msgs : nullptr)) return -1;
+  return fetch_outputs(h, obs, reward, done, err);
 }
 
 // cc4_step plus the red / green entries of the step's `actions` dict (SimulationController.py:236-240)
@@ -2258,7 +2363,18 @@ static int persist_setup(cc4_handle* h) {
   int P = 0, worst = 0, total = 0;
   for (int sl = 0; sl < CC4_SLOTS; ++sl) if (count[sl] > 0) { table[sl] = (int16_t)P++; worst = count[sl] > worst ? count[sl] : worst; total += count[sl]; }
   if (getenv("CC4_PERSIST_DEBUG")) fprintf(stderr, "[cc4 census] grid %d (%d per CU x %d CUs): %d CUs seen, at most %d waves on one, %d counted\n", grid, per_cu, h->cus, P, worst, total);
-  if (P == h->cus && worst <= per_cu && total == grid) {
+  // The hand-over between two items of an episode relies on what gfx942 / gfx950 do in their default (non-tgsplit) mode: the waves of a
+  // CU share one write-through vector L1 (validated on MI355X in SPX mode, the only partition mode of this pool).  Any other
+  // architecture keeps the per-step launches -- and says so.
+  hipDeviceProp_t prop;
+  HIPCHK(h, hipGetDeviceProperties(&prop, h->cfg.device_id));
+  const bool arch_ok = strncmp(prop.gcnArchName, "gfx942", 6) == 0 || strncmp(prop.gcnArchName, "gfx950", 6) == 0;
+  if (!(arch_ok && P == h->cus && worst <= per_cu && total == grid)) {
+    fprintf(stderr, "[cc4] the persistent run kernel stays OFF for this handle (per-step launches instead): %s; census: %d of %d CUs seen, at most %d waves on one (expected <= %d), %d of %d waves counted\n",
+            arch_ok ? "the census of compute units disagrees with the device properties" : "architecture is neither gfx942 nor gfx950", P, h->cus, worst, per_cu, total, grid);
+    h->persist_refused = true;
+  }
+  if (arch_ok && P == h->cus && worst <= per_cu && total == grid) {
     h->run_P = P; h->run_grid = grid;
     HIPCHK(h, hipMalloc(&h->d_slot_part, CC4_SLOTS * sizeof(int16_t)));
     HIPCHK(h, hipMemcpy(h->d_slot_part, table.data(), CC4_SLOTS * sizeof(int16_t), hipMemcpyHostToDevice));
@@ -2268,7 +2384,63 @@ static int persist_setup(cc4_handle* h) {
   return 0;
 }
 
+static int run_random_steps_impl(cc4_handle* h, uint64_t seed0, uint32_t t0, int32_t k, float* ms_step_kernels);
+// CC4_PERSIST_VERIFY=1 (a self-check mode, not a fast one): a call that takes a one-launch form -- the persistent kernels, whose hand-over
+// between the steps of an episode leans on how a CU's L1 behaves, and the plain multi-step kernels -- is run a second time
+// from the same starting rows with per-step launches on a shadow handle, and the two outcomes are compared episode by episode.
+static int verify_digest(cc4_handle* h, std::vector<uint64_t>& out) {
+  const int n = h->cfg.num_envs;
+  if (!h->d_digest) HIPCHK(h, hipMalloc(&h->d_digest, 3 * (size_t)n * sizeof(uint64_t)));
+  if (join_groups(h)) return -1;
+  hipLaunchKernelGGL(k_digest, dim3(n), dim3(WAVE), 0, h->stream, h->d_state, h->d_cold, h->cold_row, h->d_obs, h->d_reward, h->d_done, h->d_err, h->d_actions, h->d_digest, n);
+  HIPCHK(h, hipGetLastError());
+  out.resize(3 * (size_t)n);
+  HIPCHK(h, hipMemcpyAsync(out.data(), h->d_digest, out.size() * sizeof(uint64_t), hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  return 0;
+}
 int cc4_run_random_steps(cc4_handle* h, uint64_t seed0, uint32_t t0, int32_t k, float* ms_step_kernels) {
+  if (!h->verify || h->is_shadow || k < 2) return run_random_steps_impl(h, seed0, t0, k, ms_step_kernels);
+  HIPCHK(h, hipSetDevice(h->cfg.device_id));
+  if (strncmp(cc4_run_kernel_for(h, k), "k_run_", 6) != 0) return run_random_steps_impl(h, seed0, t0, k, ms_step_kernels);
+  if (!h->shadow) {
+    cc4_handle* sh = nullptr;
+    if (cc4_create(&h->cfg, &sh) != 0) { h->err = std::string("CC4_PERSIST_VERIFY: the shadow handle could not be created: ") + cc4_last_error(sh); if (sh) cc4_destroy(sh); return -1; }
+    sh->is_shadow = true; sh->verify = false; sh->persist_state = -1; sh->multistep = false; sh->run1m = false;
+    h->shadow = sh;
+  }
+  cc4_handle* sh = h->shadow;
+  const size_t n = (size_t)h->cfg.num_envs;
+  if (join_groups(h) || join_groups(sh)) return -1;
+  HIPCHK(h, hipStreamSynchronize(sh->stream));
+  HIPCHK(h, hipMemcpyAsync(sh->d_state, h->d_state, n * sizeof(EnvState), hipMemcpyDeviceToDevice, h->stream));
+  HIPCHK(h, hipMemcpyAsync(sh->d_cold, h->d_cold, n * h->cold_row, hipMemcpyDeviceToDevice, h->stream));
+  HIPCHK(h, hipMemcpyAsync(sh->d_obs, h->d_obs, h->out_bytes, hipMemcpyDeviceToDevice, h->stream));
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  sh->full_obs_next = h->full_obs_next; sh->main_ahead = sh->ngroups > 1;
+  int rc = run_random_steps_impl(h, seed0, t0, k, ms_step_kernels);
+  if (rc) return rc;
+  rc = run_random_steps_impl(sh, seed0, t0, k, nullptr);
+  if (rc) { h->err = "CC4_PERSIST_VERIFY: the shadow run failed: " + sh->err; return rc; }
+  std::vector<uint64_t> a, b;
+  if (verify_digest(h, a)) return -1;
+  if (verify_digest(sh, b)) { h->err = "CC4_PERSIST_VERIFY: " + sh->err; return -1; }
+  h->verify_calls++;
+  for (size_t e = 0; e < n; ++e) {
+    const bool hot = a[3 * e] != b[3 * e], cold = a[3 * e + 1] != b[3 * e + 1], outp = a[3 * e + 2] != b[3 * e + 2];
+    if (hot || cold || outp) {
+      h->verify_mismatches++;
+      h->err = "CC4_PERSIST_VERIFY: " + std::string(cc4_run_kernel_for(h, k)) + " and the per-step launches disagree after " + std::to_string(k) + " steps: first episode " +
+               std::to_string(e) + " (" + (hot ? "hot row " : "") + (cold ? "cold row " : "") + (outp ? "outputs" : "") + ")";
+      fprintf(stderr, "[cc4] %s\n", h->err.c_str());
+      return -5;
+    }
+  }
+  return 0;
+}
+// out[0] calls checked, out[1] calls that disagreed (CC4_PERSIST_VERIFY)
+int cc4_verify_stats(cc4_handle* h, int64_t* out /* [2] */) { out[0] = h->verify_calls; out[1] = h->verify_mismatches; return 0; }
+static int run_random_steps_impl(cc4_handle* h, uint64_t seed0, uint32_t t0, int32_t k, float* ms_step_kernels) {
   HIPCHK(h, hipSetDevice(h->cfg.device_id));
   if (k <= 0) { if (ms_step_kernels) *ms_step_kernels = 0.f; return 0; }   // nothing to launch, no timing event to read
   if (h->multistep && !h->comm && !h->evlog_on && !h->ext_seen && !h->d_prof && k >= 2) {
@@ -2322,7 +2494,7 @@ int cc4_run_random_steps(cc4_handle* h, uint64_t seed0, uint32_t t0, int32_t k, 
                h->cfg.num_envs, h->cfg.autoreset, h->cfg.steps, h->cfg.rng_mode,
                (h->cfg.red_policy & 3) | (h->cfg.green_policy ? GP_SLEEP_BIT : 0) | (h->cfg.green_policy == 2 ? GP_OPEN_BIT : 0) | (h->cfg.blue_policy ? BP_RANDOM_BIT : 0),
                h->full_obs_next ? 1 : 0, (uint32_t)h->cfg.topology_seed, nullptr, h->d_reset_ws, nullptr, 0};
-    RunArgs ra{h->d_run, h->d_run + 2 * h->run_P, reinterpret_cast<int32_t*>(h->d_run + h->run_P), h->d_slot_part, h->run_P, k, t0};
+    RunArgs ra{h->d_run, h->d_run + 2 * h->run_P, reinterpret_cast<int32_t*>(h->d_run + h->run_P), h->d_slot_part, h->run_P, k, t0, h->persist_order};
     if (ms_step_kernels && h->evs.size() < 2) { h->evs.resize(2, nullptr); for (auto& e : h->evs) if (!e) HIPCHK(h, hipEventCreate(&e)); }
     auto c0 = std::chrono::steady_clock::now();
 #ifndef CC4_DEV_FAST

@@ -32,12 +32,9 @@ enum : int {
   MAXSV = 7,            // services per host: sshd, OT, {apache | decoy apache} + decoy vsftpd (both port 80), mysql,
                         // decoy tomcat, {smtp | decoy haraka} -- the port checks of DecoyAction exclude any eighth
   MAX_RS = 64,          // sessions per red agent (its ordered list of pool slots)
-#ifdef CC4_EXP_OCC        // occupancy experiment (tools/ab.sh): a smaller agent part, NOT a product configuration
-  RS_POOL = 96, MAX_KS = 32,
-#else
-  RS_POOL = 192,        // red session records per episode, shared by the six agents
+  RS_POOL = 192,        // red session records per episode, shared by the six agents (r03's occupancy experiment with 96 / MAX_KS 32:
+                        // profiles/r03_occupancy_experiment.txt; both generation bitmaps are lent from this pool and need >= 152 records)
   MAX_KS = 96,          // known server-session ids per red agent (ActionSpace.server_session)
-#endif
   MAX_OBS = 32,         // red observation entries per agent per step (a subnet sweep adds 16, every other source <= 4)
   MAX_PEND = 8,         // process_creation events carrying a pid, per step (one per red agent)
   EPH_WORDS = 340,      // 10880-bit bitmap >= 60000-49152 ephemeral ports (Host.py:183); 1360 B = 85 x 16 B

@@ -79,6 +79,9 @@ class CC4VecEnv:
         self._mask = np.zeros((n, L.MASK_PER_ENV), np.uint8)
         self._err = np.zeros(n, np.uint32)
         self._err_seen = np.zeros(n, np.uint32)      # flags already raised for (strict mode raises once per flag and episode)
+        self._any_seen = False
+        vp = ctypes.c_void_p
+        self._p_out = (self._obs.ctypes.data_as(vp), self._rew.ctypes.data_as(vp), self._done.ctypes.data_as(vp), self._err.ctypes.data_as(vp))
 
     # -- lifecycle
     def close(self):
@@ -124,8 +127,11 @@ class CC4VecEnv:
             messages = np.ascontiguousarray(messages, dtype=np.uint8)
             assert messages.shape == (self.num_envs, L.NUM_BLUE, L.MSG_LEN)
             mp = messages.ctypes.data_as(ctypes.c_void_p)
-        self._chk(self.lib.cc4_step(self._h, ap, mp), 'cc4_step')
-        obs, rew, done = self._fetch()
+        # cc4_step + cc4_fetch in one call: inputs up in one copy, the launch, the four results down in one copy, one host wait
+        rc = self.lib.cc4_step_fetch(self._h, ap, mp, *self._p_out)
+        if rc:
+            self._chk(rc, 'cc4_step_fetch')
+        obs, rew, done = self._check_err()
         return obs, rew, done, {'err': self._err}
 
     def agent_actions(self, kind):
@@ -170,12 +176,14 @@ class CC4VecEnv:
         return rc
 
     def _fetch(self, mask=False):
-        self._chk(self.lib.cc4_get_obs(self._h, self._obs.ctypes.data_as(ctypes.c_void_p)), 'cc4_get_obs')
-        self._chk(self.lib.cc4_get_reward_done(self._h, self._rew.ctypes.data_as(ctypes.c_void_p),
-                                               self._done.ctypes.data_as(ctypes.c_void_p)), 'cc4_get_reward_done')
-        self._chk(self.lib.cc4_get_err(self._h, self._err.ctypes.data_as(ctypes.c_void_p)), 'cc4_get_err')
+        self._chk(self.lib.cc4_fetch(self._h, *self._p_out), 'cc4_fetch')      # observations, reward, done, error flags: one copy
         if mask:
             self._chk(self.lib.cc4_get_action_mask(self._h, self._mask.ctypes.data_as(ctypes.c_void_p)), 'cc4_get_action_mask')
+        return self._check_err()
+
+    def _check_err(self):
+        if not self._any_seen and not self._err.any():      # the common case: no flag anywhere, none remembered
+            return self._obs, self._rew, self._done.astype(bool)
         self._err_seen &= self._err                    # a regenerated episode (reset, autoreset) starts with a clean slate
         if self.strict:
             # a flag stays set in the episode's row until the episode is reset; it is raised ONCE -- a batch of thousands of
@@ -183,6 +191,7 @@ class CC4VecEnv:
             # info['err'] keep showing the flag.  (A step past the episode's end raises on every call, as the reference does.)
             fresh = self._err & ~self._err_seen
             self._err_seen |= self._err
+            self._any_seen = bool(self._err_seen.any())
             raise_on_engine_error(fresh | (self._err & np.uint32(1 << 7)))
         elif (self._err & (1 << 7)).any():
             raise ValueError("Step number exceeds last mission phase step maximum. "

@@ -75,12 +75,15 @@ class EnterpriseScenarioGenerator:
     MAX_BANDWIDTH = 100
     MESSAGE_LENGTH = 8
 
-    def __init__(self, blue_agent_class=None, red_agent_class=None, green_agent_class=None, steps: int = 100):
-        # The engine runs these policies on the device.  Any OTHER class is instantiated on the host, one object per agent, as the
-        # reference does (ESG.py:95-121, :693-696, :736-748, :805-817): the engine's own policy for that team then sleeps, the object's
-        # get_action(observation, action_space) is called every step with the agent's dict observation, and what it returns is
-        # submitted through cc4_step_ex (the slow path: one host round trip per step -- what a scripted or learning red agent costs
-        # in the reference too).
+    def __init__(self, blue_agent_class=None, red_agent_class=None, green_agent_class=None, steps: int = 100, host_agents=False):
+        # The engine runs these policies on the device, selected by CLASS NAME: the reference's own classes
+        # (CybORG.Agents.FiniteStateRedAgent, ...) and this package's markers select the same device policy, bit-exact under the seed.
+        # A class of ANOTHER name is instantiated on the host, one object per agent, as the reference does (ESG.py:95-121, :693-696,
+        # :736-748, :805-817): the engine's own policy for that team then sleeps, the object's get_action(observation, action_space) is
+        # called every step with the agent's dict observation, and what it returns is submitted through cc4_step_ex (the slow path: one
+        # host round trip per step -- what a scripted or learning red agent costs in the reference too).  host_agents=True (or a class
+        # attribute cc4_host_agent = True) sends a class to the host path although its name is a built-in's -- e.g. a user's modified
+        # FiniteStateRedAgent; a foreign class whose name collides WITHOUT that opt-in runs the device policy and is told so (a warning).
         blue = {'SleepAgent': 0, 'cc4BlueRandomAgent': 1}
         red = {'FiniteStateRedAgent': 0, 'SleepAgent': 1, 'DiscoveryFSRed': 2, 'RandomSelectRedAgent': 3}
         green = {'EnterpriseGreenAgent': 0, 'SleepAgent': 1}
@@ -90,7 +93,12 @@ class EnterpriseScenarioGenerator:
         gn = 'SleepAgent' if green_agent_class is None else getattr(green_agent_class, '__name__', None)
         self.custom = {}                                   # team -> class whose objects act from the host
         for team, name, table, cls in (('blue', bn, blue, blue_agent_class), ('red', rn, red, red_agent_class), ('green', gn, green, green_agent_class)):
-            builtin = name in table and (cls is None or getattr(cls, '__module__', '').startswith('cage_challenge_4_amd') or name == 'SleepAgent')
+            builtin = name in table and not (host_agents and cls is not None and name != 'SleepAgent') and not getattr(cls, 'cc4_host_agent', False)
+            if builtin and cls is not None and name != 'SleepAgent' and not getattr(cls, '__module__', '').startswith(('cage_challenge_4_amd', 'CybORG')):
+                import warnings
+                warnings.warn(f'{team}_agent_class={cls.__module__}.{name}: the name selects the engine\'s built-in {name} policy on the device; '
+                              f'pass host_agents=True (or set {name}.cc4_host_agent = True) to run this class\'s own get_action on the host',
+                              stacklevel=2)
             if not builtin:
                 if not callable(cls) or not hasattr(cls, 'get_action'):
                     raise TypeError(f'{team}_agent_class={cls!r}: an agent class needs get_action(observation, action_space)')
@@ -147,14 +155,18 @@ class CybORG:
         """The agent objects that act from the host: one per agent of a team with a custom class (constructed as the reference's
         generator does: (name) or (name, np_random=...) -- the reference hands every such object ITS shared generator; here each
         gets a numpy Generator of its own, seeded from the episode's seed and the agent's name, because the simulator's stream lives
-        on the device), plus the `agents=` overrides."""
+        on the device), plus the `agents=` overrides.  Called at construction and at every reset: the reference's reset builds a fresh
+        scenario, agent objects included (SimulationController.reset -> _create_agents, SC:153-209), after end_episode() on the old
+        ones -- so a learning agent that must survive resets is passed through `agents=`, which is kept."""
+        sg = self.scenario_generator
+        self._host_agents = {}
+        if not getattr(sg, 'custom', None) and not self._agent_overrides:
+            return                                          # the default: every policy runs on the device -- nothing to build, no state to fetch
         import inspect
         import zlib
-        sg = self.scenario_generator
         d = json_loads(self.vec.true_state_json(0))
         names = {'blue': list(self.agents_blue), 'green': [f'green_agent_{g}' for g in range(d['n_green'])],
                  'red': [f'red_agent_{r}' for r in range(6)]}
-        self._host_agents = {}
         for team, cls in getattr(sg, 'custom', {}).items():
             params = inspect.signature(cls.__init__).parameters if hasattr(cls, '__init__') else {}
             for name in names[team]:
@@ -198,6 +210,9 @@ class CybORG:
         pair) code for an action object the list has no slot for, plus the object's `duration` when it is not the class's own."""
         b = self.agents_blue.index(agent)
         labels = labels if labels is not None else self._action_labels()[agent]['labels']
+        if type(v) is int or isinstance(v, np.integer):    # the hot case: an index into the agent's list (no object, no duration)
+            idx = range(len(labels))[int(v)]                # list semantics: a negative index counts from the end, out of range raises IndexError
+            return idx if idx < (242 if b == 4 else 82) else labels.index('Sleep')   # a padded slot is an explicit Sleep, not "no action" (-1)
         name = getattr(v, 'name', None) or type(v).__name__
         if name in ('BlockTrafficZone', 'AllowTrafficZone') and not isinstance(v, (int, np.integer)):
             try:
@@ -278,12 +293,14 @@ class CybORG:
             for f, val in zip(('type', 'host', 'arg', 'ticks', 'session', 'flags', 'rate0', 'rate1'), fields):
                 rec[f] = val
         self._submitted = {a: v for a, v in actions.items() if a not in self.agents_blue}
-        msg = np.zeros((1, 5, MESSAGE_LENGTH), np.uint8)
-        for b, a in enumerate(self.agents_blue):
-            m = np.asarray((messages or {}).get(a, EMPTY_MESSAGE)).astype(bool)
-            assert m.shape == (MESSAGE_LENGTH,), \
-                f'{a} attempting to send message {m} that is not in the message space MultiBinary({MESSAGE_LENGTH})'
-            msg[0, b] = m
+        msg = None                                         # no messages: the engine reads zeros (the reference's EMPTY_MESSAGE)
+        if messages:
+            msg = np.zeros((1, 5, MESSAGE_LENGTH), np.uint8)
+            for b, a in enumerate(self.agents_blue):
+                m = np.asarray(messages.get(a, EMPTY_MESSAGE)).astype(bool)
+                assert m.shape == (MESSAGE_LENGTH,), \
+                    f'{a} attempting to send message {m} that is not in the message space MultiBinary({MESSAGE_LENGTH})'
+                msg[0, b] = m
         if red is None and green is None:
             obs, rew, done, vinfo = self.vec.step(acts, msg)
         else:
@@ -370,9 +387,7 @@ class CybORG:
         does not have: the reference raises AttributeError for every agent, and so does this mirror."""
         raise AttributeError("'AgentInterface' object has no attribute 'reward_calculator'")
 
-    @property
-    def agents_blue(self):
-        return [f'blue_agent_{b}' for b in range(5)]
+    agents_blue = [f'blue_agent_{b}' for b in range(5)]     # (read-only: every use indexes or iterates it)
 
     @property
     def active_agents(self):
@@ -591,13 +606,15 @@ class BlueFixedActionWrapper:
         # (a container bound, a path the reference would crash on) raises CC4EngineError: never a silently different result
         obs, rew, done = self.env._submit(others, messages, kwargs.get('skip_valid_action_check', False), blue_codes=acts)
         d = bool(done[0])
-        ob = split_obs(obs)
-        observations = {a: ob[b][0].astype(np.int64) for b, a in enumerate(self.possible_agents)}
-        rewards = {a: float(rew[0]) for a in self.possible_agents}
-        terminated = {a: d for a in self.possible_agents}
-        truncated = {a: d for a in self.possible_agents}
-        info = {a: {'action_mask': self._action_space[a]['mask']} for a in self.possible_agents}
-        self.agents = [a for a in self.possible_agents if not d]
+        row = obs[0].astype(np.int64)                       # one conversion; the agents' vectors are disjoint slices of it
+        agents = self.possible_agents
+        observations = {a: row[o:o + n] for a, o, n in zip(agents, L.OBS_OFF, L.OBS_LEN)}
+        r = float(rew[0])
+        rewards = dict.fromkeys(agents, r)
+        terminated = dict.fromkeys(agents, d)
+        truncated = dict.fromkeys(agents, d)
+        info = {a: {'action_mask': self._action_space[a]['mask']} for a in agents}
+        self.agents = [] if d else agents
         return observations, rewards, terminated, truncated, info
 
     def get_action_space(self, agent):
