@@ -125,8 +125,9 @@ def cpu_baseline(envs, seed0, budget_s=10.0):
     probe = run(0, 10)
     k = int(max(10, min(400, budget_s / max(probe / 10, 1e-6))))
     dt = run(10, k)
-    out = {'value': 5.0 * envs * k / dt, 'unit': 'agent-env steps/s', 'cores': cores, 'kind': 'port',
-           'sample': f'{envs} episodes x {k} steps (steps 10..{10 + k} of the same seeded workload), OpenMP over episodes'}
+    out = {'value': 5.0 * envs * k / dt, 'unit': 'agent-env steps/s', 'cores': cores, 'kind': 'port', 'cpu': cpu_model(),
+           'sample': f'{envs} episodes x {k} steps (steps 10..{10 + k} of the same seeded workload: the first {envs} episodes of the headline batch -- episodes '
+                     f'are independent, so the rate per episode is the 8192-episode rate), OpenMP over episodes on {cores} threads of: {cpu_model()}'}
     # one core: the rest of the same episodes' life, a shorter stretch
     ora.lib.cc4o_set_threads(1)
     t1 = 10 + k
@@ -193,10 +194,11 @@ def host_api_rates(seed=123, steps=300, eval_eps=3):
     return out
 
 
-def load_pmc_traffic(envs, kernel, launches_per_step):
-    """HBM bytes per STEP (all launches of a step) from the committed rocprofv3 --pmc passes of this bench command, with their
-    source -- only if they were taken on the same kernel with the same number of launches per step; else (None, None)."""
-    for name in ('r04_pmc.json', 'r03_pmc.json'):
+def load_pmc_traffic(envs, kernel):
+    """HBM bytes per STEP from the committed rocprofv3 --pmc passes of this bench command (profiles/r05_pmc.json, tools/profile_round.sh),
+    with their source -- only if they were taken on the very kernel the timed regions launched (`kernel`: the one-launch forms are
+    profiled as what they are: bytes of a launch / steps of the launch); else (None, None)."""
+    for name in ('r05_pmc.json',):
         p = os.path.join(ROOT, 'profiles', name)
         try:
             with open(p) as f:
@@ -204,13 +206,59 @@ def load_pmc_traffic(envs, kernel, launches_per_step):
             v = d.get(f'hbm_bytes_per_step_{envs}env')
             if v is None or d.get(f'kernel_{envs}env') != kernel:      # never another kernel's figure
                 continue
-            # (the bytes a step moves do not depend on how many launches it is cut into: under --pmc the runtime serialises the
-            # launches and the library falls back to three per step; the same episodes, the same rows)
-            return v, (f"profiles/{name} (rocprofv3 --pmc passes of this bench command on {kernel}, {d.get(f'launches_per_step_{envs}env')} serialised launches per step; "
-                       'a committed figure, not measured in this run)')
+            spl = d.get(f'steps_per_launch_{envs}env')
+            how = (f'one launch = {spl} steps; bytes of the launch / {spl}' if spl else f"{d.get(f'launches_per_step_{envs}env')} serialised launches per step")
+            return v, f'profiles/{name} (rocprofv3 --pmc passes of this bench command on {kernel}: {how}; a committed figure, not measured in this run)'
         except Exception:
             pass
     return None, None
+
+
+def cpu_model():
+    try:
+        for line in open('/proc/cpuinfo'):
+            if line.startswith('model name'):
+                return line.split(':', 1)[1].strip()
+    except Exception:
+        pass
+    return 'unknown CPU'
+
+
+def exchange_world1(make_env, measure, D, args, lo, timeout_s=90.0):
+    """The same timed regions with the exchange ON, on a one-rank RCCL communicator: the configuration every rank of
+    BASELINE configs[3] runs -- 1024 episodes -- and the headline batch.  With a communicator cc4_run_random_steps stays one launch: the
+    communication stream follows the kernel's per-step counters and all-gathers every step's packed rows (include/cc4.h
+    cc4_exchange_info).  RCCL's first initialisation on a fresh box pages in a 570 MB library (seconds to minutes): the whole leg runs
+    under a watchdog and reports 'skipped' instead of holding the line up."""
+    import threading
+    import numpy as np
+    from cage_challenge_4_amd import RNG_PHILOX
+    out, box = {}, {}
+
+    def leg():
+        try:
+            for n in (1024, 8192):
+                e = make_env(n, RNG_PHILOX, lo if n == 8192 else 0)
+                D.init_rccl(e, 0, 1)
+                e.reset(seeds=np.uint64(args.seed0) + np.arange(n, dtype=np.uint64))
+                r = measure(e, 0, n, min_seconds=min(args.min_seconds, 0.2))
+                xi = e.exchange_info()
+                hs = e.host_stats()
+                r.update({'unit': 'agent-env steps/s', 'total_envs': n, 'exchange': xi, 'allgathers_issued': hs['gathers'],
+                          'note': 'RCCL all-gather of every step\'s observations (2 bits per value) on a one-rank communicator, issued from the communication '
+                                  'stream behind the one-launch kernel\'s per-step counters' if xi['in_kernel'] else 'per-step launches, an all-gather behind each'})
+                out[f'envs_{n}'] = r
+                e.close()
+            box['ok'] = True
+        except Exception as ex:      # noqa: BLE001
+            box['err'] = repr(ex)
+    th = threading.Thread(target=leg, daemon=True)
+    th.start()
+    th.join(timeout_s)
+    if not box.get('ok'):
+        out['skipped'] = box.get('err') or f'RCCL setup did not finish within {timeout_s:.0f} s on this box (library paging in)'
+        out['_stalled'] = th.is_alive()
+    return out
 
 
 def main():
@@ -300,11 +348,12 @@ def main():
     def reduce_max(v):
         return plane.allreduce(v, 'max')
 
-    def measure(e, first, n_total):
+    def measure(e, first, n_total, runner=None, min_seconds=None):
         key = args.seed0 + first            # action key = seed0 + global episode index
         run_kernel = e.run_kernel_for(args.steps)     # (asked before the timed regions: a persistent kernel's one-off census happens here)
-        secs, kms = timed_regions(lambda t0, k, timed: e.run_random_steps(key, t0, k, timed=timed), args.steps, args.warmup,
-                                  args.min_seconds, e.synchronize, plane.barrier, reduce_max)
+        runner = runner or (lambda t0, k, timed: e.run_random_steps(key, t0, k, timed=timed))
+        secs, kms = timed_regions(runner, args.steps, args.warmup,
+                                  args.min_seconds if min_seconds is None else min_seconds, e.synchronize, plane.barrier, reduce_max)
         out = summarise(secs, kms, args.steps, n_total)
         t_end = args.warmup + len(secs) * args.steps        # launches so far; episodes regenerate on every (episode_steps)-th
         out['autoreset_launches_in_timed_regions'] = t_end // args.episode_steps - args.warmup // args.episode_steps
@@ -324,6 +373,7 @@ def main():
                                  # RCCL's own view: a scaling line is only what it says if every rank reports nccl_comm_count == n_gpus and
                                  # the ranks sit on different devices (uuid / pci)
                                  **env.comm_info()})
+    xinfo = env.exchange_info() if dist_on and not exchange_note else {}
     env._fetch()
     err_any = bool(env.err.any())
     # a sharding-independent digest of where the batch stands after the run (episodes are seeded and driven by their GLOBAL
@@ -350,6 +400,10 @@ def main():
             r4 = measure(e4, 0, 1024)
             k4 = e4.step_kernel
             e4.close()
+            r4['roofline'] = ({'bound': 'latency', 'us_per_step': r4['launch_ms'] * 1e3,
+                               'note': f"{r4['run_kernel']} keeps the episode's row in LDS from the first step of a launch to the last: the bytes of the contract "
+                                       'figure do not move, so no HBM fraction is quoted -- the figure is the mean step time of an episode'}
+                              if r4['run_kernel'] in ('k_run_philox', 'k_run_philox8') else None)
             r4.update({'rng': args.rng, 'kernel': k4, 'unit': 'agent-env steps/s', 'total_envs': 1024,
                        'note': 'BASELINE configs[1]: 1024 episodes on one GPU = the per-GPU share of the 8-GPU job (latency regime: 4 blocks per CU, one round); '
                                'without the exchange a timed region is ONE launch of the multi-step kernel (run_kernel k_run_philox): the batch advances at the '
@@ -363,6 +417,18 @@ def main():
             e3.close()
             r3.update({'unit': 'agent-env steps/s', 'note': 'uniform topology: every episode draws its scenario from one shared key (cc4_config.topology_seed)'})
             subs['uniform_topology'] = r3
+        if args.rng == 'philox':
+            # What a learner's loop pays (VERDICT r04 missing #2): the actions are ON the device, written by a kernel of the caller's (here
+            # k_random_actions standing in for a policy network's argmax), and cc4_step_device consumes them -- a launch of the step
+            # kernel per step and episode group, no host synchronisation inside the region, observations readable after every step
+            e5 = make_env(n_local, RNG_PHILOX, lo)
+            r5 = measure(e5, lo, total_envs, runner=lambda t0, k, timed: e5.run_policy_steps(args.seed0 + lo, t0, k), min_seconds=min(args.min_seconds, 0.2))
+            r5.update({'unit': 'agent-env steps/s', 'kernel': e5.step_kernel, 'run_kernel': e5.step_kernel, 'launches_per_step': e5.launches_per_step + 1,
+                       'note': 'per step: k_random_actions -> the handle\'s device action buffer, then cc4_step_device (the per-step launches of the step kernel); '
+                               'the consumable rate -- a policy can read every step\'s observations and write the next actions on the device'})
+            e5.close()
+            subs['policy_in_loop'] = r5
+            subs['exchange_world1'] = exchange_world1(make_env, measure, D, args, lo)
     if rank == 0:
         bytes_per_env = int(env.lib.cc4_algorithmic_bytes_per_env_step())
         hot = int(env.lib.cc4_hot_bytes())
@@ -383,7 +449,7 @@ def main():
         achieved = bytes_per_env * n_local / (launch_ms * 1e-3) / 1e9
         # live bytes: the agent part + the 64-byte rows of the hosts that exist in the episode (the grid has 137 positions)
         useful = 2 * (hot + 64.0 * mean_hosts) + 4 * 578 + 29
-        traffic, traffic_src = load_pmc_traffic(n_local, env.step_kernel, lps) if args.rng == 'philox' else (None, None)
+        traffic, traffic_src = load_pmc_traffic(n_local, main_res['run_kernel'])
         out = {
             'metric': 'agent-env steps/sec (5 blue agents x N envs)',
             'value': main_res['value'],
@@ -397,7 +463,10 @@ def main():
                             f'(82/82/82/82/242 incl. invalid slots), FiniteStateRedAgent, EnterpriseGreenAgent, '
                             f'EnterpriseScenarioGenerator(steps={args.episode_steps}), autoreset incl. scenario regeneration, topology randomised per episode and reset',
                 'envs_per_gpu': n_local, 'total_envs': total_envs, 'rng': args.rng,
-                'exchange': exchange_note or ('RCCL all-gather of the observations of every step (2 bits per value, 148 B per episode) on a second stream, overlapped with the next step' if dist_on else 'none'),
+                'exchange': exchange_note or (('RCCL all-gather of the observations of every step (2 bits per value, 148 B per episode) on a second stream, '
+                                               + ('issued behind the per-step counters of the one-launch kernel (a ring of 16 step slabs; include/cc4.h cc4_exchange_info)'
+                                                  if xinfo.get('in_kernel') else 'overlapped with the next step\'s launch')) if dist_on else 'none'),
+                'exchange_info': xinfo if dist_on else None,
                 'env_steps_per_sec': main_res['value'] / 5.0, 'engine_error_flags': err_any,
                 'last_step_reward_sum': digest[0], 'last_step_done_count': digest[1],
                 'steps_run': args.warmup + main_res['regions'] * args.steps,
@@ -423,7 +492,7 @@ def main():
                          'algorithmic_bytes_per_step': bytes_per_env * n_local,
                          'note': (f'a timed region of {spl} steps = ONE launch of {main_res["run_kernel"]} over all {n_local} episodes (the per-step kernel of this '
                                   f'handle is {env.step_kernel}); launch_ms = that launch, step_ms = launch_ms / steps_per_launch; '
-                                  'achieved = algorithmic_bytes_per_launch / launch_ms; traffic is per step (PMC passes of the per-step kernel: same body, same bytes)'
+                                  'achieved = algorithmic_bytes_per_launch / launch_ms; traffic is per step (PMC passes of this very kernel: bytes of a launch / steps of the launch)'
                                   if one_launch else
                                   f'a step = {lps} concurrent launch(es) of {env.step_kernel} on separate streams, {n_local / lps:.0f} episodes each; '
                                   'achieved = launches_per_step x algorithmic_bytes_per_launch / launch_ms; traffic is per step too'),
@@ -439,7 +508,7 @@ def main():
         print(json.dumps(out), flush=True)
     env.close()
     plane.close()
-    if exchange_note:                 # a stalled RCCL setup thread must not keep the process alive
+    if exchange_note or subs.get('exchange_world1', {}).get('_stalled'):                 # a stalled RCCL setup thread must not keep the process alive
         sys.stdout.flush()
         os._exit(0)
 

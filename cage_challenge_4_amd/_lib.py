@@ -92,6 +92,9 @@ SIGNATURES = {
     'cc4_allgather_obs': (ctypes.c_int, [_P, ctypes.POINTER(_P)]),
     'cc4_comm_info': (ctypes.c_int, [_P, _P, ctypes.c_char_p]),
     'cc4_allgather_wait': (ctypes.c_int, [_P]),
+    'cc4_exchange_info': (ctypes.c_int, [_P, _P]),
+    'cc4_debug_gather_log': (ctypes.c_int, [_P, ctypes.c_int32]),
+    'cc4_get_gather_log': (ctypes.c_int, [_P, _P, ctypes.c_int32, ctypes.c_int32]),
     'cc4_get_allgathered_obs': (ctypes.c_int, [_P, _P]),
     'cc4_unpack_obs_device': (ctypes.c_int, [_P, ctypes.POINTER(_P)]),
     'cc4_get_unpacked_obs': (ctypes.c_int, [_P, _P]),

@@ -111,6 +111,54 @@ __device__ __forceinline__ uint8_t pack_obs_byte(const uint8_t* vals, int j) {
   return (uint8_t)b;
 }
 
+// An episode's packed observation row (OBS_PACKED bytes = 37 words) to memory, one word per thread, as SYSTEM-scope (write-through) stores:
+// the reader is the exchange -- a copy engine, an RCCL kernel on any XCD, a peer GPU -- and, when the writer is a one-launch kernel, there is
+// no kernel boundary that would write the XCD's L2 back first (tools/micro/ring_protocol.hip: plain stores arrive stale, these do not).
+__device__ __forceinline__ void store_packed_row(uint8_t* o8, const uint8_t* vals, int t, int nt) {
+  uint32_t* o32 = reinterpret_cast<uint32_t*>(o8);
+  for (int w = t; w < OBS_PACKED / 4; w += nt) {
+    const uint32_t v = (uint32_t)pack_obs_byte(vals, 4 * w) | ((uint32_t)pack_obs_byte(vals, 4 * w + 1) << 8) |
+                       ((uint32_t)pack_obs_byte(vals, 4 * w + 2) << 16) | ((uint32_t)pack_obs_byte(vals, 4 * w + 3) << 24);
+    __hip_atomic_store(o32 + w, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
+}
+// The per-step hand-off out of the one-launch kernels (cc4_run_random_steps with a communicator).  Step k of the launch writes
+// its packed rows into slab k % ring and, once an episode's row is in memory, counts it in done[k]; the communication stream waits for
+// done[k] == n (hipStreamWaitValue32), gathers the slab, and publishes gathered = k + 1 (hipStreamWriteValue32); step k + ring of any
+// episode waits for gathered > k before it overwrites the slab.  The exchange lags the stepping by up to `ring` steps, with no launch
+// boundary in the compute queue.  A wait that lasts longer than wait_ticks gives up, raises *timeout (the host falls back to per-step
+// launches and says so) and every later wait of the launch returns at once: a stuck exchange never hangs the kernel.
+struct XchgArgs {
+  uint8_t* slab;                 // [ring][n][OBS_PACKED], or null: no exchange
+  uint32_t* done;                // [K]
+  uint32_t* gathered;            // [1]
+  uint32_t* timeout;             // [1]
+  int ring;
+  long long wait_ticks;          // wall_clock64 ticks (100 MHz)
+};
+// lane / thread 0 only
+__device__ __forceinline__ void xchg_wait_slab(const XchgArgs& x, uint32_t k) {
+  if (k < (uint32_t)x.ring) return;
+  const uint32_t need = k - (uint32_t)x.ring + 1u;
+  if (__hip_atomic_load(x.gathered, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) >= need) return;
+  if (__hip_atomic_load(x.timeout, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM)) return;
+  // Thousands of waves polling one uncached word starve the very write they wait for (tools/micro/ring_protocol.hip: a saturated chip
+  // of spinning pollers took 57 us per exchange step instead of < 16): the interval between two polls of a wave doubles from ~3 us to ~50 us.
+  const long long w0 = wall_clock64();
+  int naps = 1;
+  while (__hip_atomic_load(x.gathered, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) < need) {
+    for (int i = 0; i < naps; ++i) __builtin_amdgcn_s_sleep(127);
+    if (naps < 16) naps <<= 1;
+    if (wall_clock64() - w0 > x.wait_ticks || __hip_atomic_load(x.timeout, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM)) {
+      __hip_atomic_store(x.timeout, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      return;
+    }
+  }
+}
+__device__ __forceinline__ void xchg_count(const XchgArgs& x, uint32_t k) {     // after the block's stores have drained (s_waitcnt vmcnt(0) + barrier)
+  (void)__hip_atomic_fetch_add(x.done + k, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
 // ---------------------------------------------------------------- numpy stream: the two draw-only phases across the wave
 // PCG64 is a 128-bit LCG, so the state k steps ahead is A_k * state + B_k * increment (A_k = M^k, B_k = 1 + M + .. + M^(k-1),
 // mod 2^128; table filled by cc4_create).  Two phases of a step only CONSUME the stream -- the green agents' policy draws
@@ -628,7 +676,7 @@ __device__ __forceinline__ void pcg_body(StepArgs a, const int e, const int lane
   if (prof && lane == 0) prof[12] += t_out - t_obs;
   uint4* dst = reinterpret_cast<uint4*>(a.st + e);
   stage_out<HOT_VEC>(dst, lds, lane);
-  if (a.obs8) { uint8_t* o8 = a.obs8 + (size_t)e * OBS_PACKED; for (int j = lane; j < OBS_PACKED; j += WAVE) o8[j] = pack_obs_byte(obs_lds, j); }
+  if (a.obs8) store_packed_row(a.obs8 + (size_t)e * OBS_PACKED, obs_lds, lane, WAVE);
   if (prof && lane == 0) { prof[13] += clock64() - t_out; prof[14] += clock64() - t_begin; }
   if (prof) { __syncthreads(); if (lane < 15) a.prof[PROF_SLOTS * (size_t)e + lane] += prof_lds[lane]; }
 }
@@ -957,7 +1005,7 @@ __device__ __forceinline__ void philox4_body(StepArgs a, const int run_flags = 0
   }
   __syncthreads();    // the row is final: RedSessionCheck and the step bookkeeping ran beside the encode
   if (tid == 0) a.err[e] = s->err;
-  if (a.obs8) { uint8_t* o8 = a.obs8 + (size_t)e * OBS_PACKED; for (int j = tid; j < OBS_PACKED; j += PT) o8[j] = pack_obs_byte(obs_bytes, j); }
+  if (a.obs8) store_packed_row(a.obs8 + (size_t)e * OBS_PACKED, obs_bytes, tid, PT);
   unsigned long long t_out = a.prof ? clock64() : 0;
   if (prof && tid == 0) prof[12] += t_out - t_obs;
   // write-back: the agent part always; of the host table (55 % of the row) only the rows this step wrote -- a HostDyn is exactly one
@@ -994,21 +1042,27 @@ __global__ __launch_bounds__(PT, MINW) void k_step_philox(StepArgs a) { philox4_
 // and held across the whole step; ~90 VGPRs spill, and it is still 30 % faster than the call: a kernel that contains a call loses a quarter
 // of its rate, profiles/r04_compiler_flags_ab.txt, r04_multistep_inline_ab.txt.)
 template <int MINB>
-__device__ __forceinline__ void run_philox_loop(StepArgs a, int K, uint32_t t0) {
+__device__ __forceinline__ void run_philox_loop(StepArgs a, int K, uint32_t t0, const XchgArgs x) {
   a.prof = nullptr; a.obs8 = nullptr; a.ext = nullptr;
   const int full0 = a.full_obs;
   for (int k = 0; k < K; ++k) {
     a.rand_t = t0 + (uint32_t)k;
     a.full_obs = k == 0 ? full0 : 0;
+    if (x.slab) {      // with the exchange: this step's slab of the ring, free once its previous occupant (step k - ring) has been gathered
+      if (threadIdx.x == 0) xchg_wait_slab(x, (uint32_t)k);
+      a.obs8 = x.slab + (size_t)(k % x.ring) * (size_t)a.n * OBS_PACKED;
+      __syncthreads();
+    }
     { int tid_i = (int)threadIdx.x; asm volatile("" : "+v"(tid_i));
       philox4_body<false, true>(a, (k > 0 ? 1 : 0) | (k == K - 1 ? 2 : 0), tid_i); }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
+    if (x.slab && threadIdx.x == 0) xchg_count(x, (uint32_t)k);
   }
 }
-__global__ __launch_bounds__(PT, 5) void k_run_philox(StepArgs a, int K, uint32_t t0) { run_philox_loop<5>(a, K, t0); }
+__global__ __launch_bounds__(PT, 5) void k_run_philox(StepArgs a, int K, uint32_t t0, XchgArgs x) { run_philox_loop<5>(a, K, t0, x); }
 // the same with the register budget of eight blocks per CU: batches of up to 8 x CUs episodes (2048 on MI355X) resident at once
-__global__ __launch_bounds__(PT, 8) void k_run_philox8(StepArgs a, int K, uint32_t t0) { run_philox_loop<8>(a, K, t0); }
+__global__ __launch_bounds__(PT, 8) void k_run_philox8(StepArgs a, int K, uint32_t t0, XchgArgs x) { run_philox_loop<8>(a, K, t0, x); }
 // (a build with the budget of four blocks per CU -- 128 registers per lane, 1024 episodes on 256 CUs -- is 0.7 % faster than the one of five: not kept)
 
 // ---------------------------------------------------------------- Philox mode, one wavefront per episode
@@ -1290,7 +1344,7 @@ __device__ __forceinline__ void philox1_body(StepArgs a, const int e, const uint
   }
   __syncthreads();
   if (lane == 0) a.err[e] = s->err;
-  if (a.obs8) { uint8_t* o8 = a.obs8 + (size_t)e * OBS_PACKED; for (int j = lane; j < OBS_PACKED; j += WAVE) o8[j] = pack_obs_byte(obs_bytes, j); }
+  if (a.obs8) store_packed_row(a.obs8 + (size_t)e * OBS_PACKED, obs_bytes, lane, WAVE);
   unsigned long long t_out = a.prof ? clock64() : 0;
   if (prof && lane == 0) prof[12] += t_out - t_obs;
   stage_out<HOT_VEC>(reinterpret_cast<uint4*>(a.st + e), lds, lane);
@@ -1314,7 +1368,7 @@ __global__ __launch_bounds__(WAVE, CC4_LEAN_MINW) void k_step_philox1(StepArgs a
 // Never across XCDs: their L2s do not agree without a write-back.
 constexpr uint32_t TK_SHARED = 0x80000000u;
 template <bool PCG>
-__device__ __forceinline__ void persist_loop(StepArgs a, RunArgs ra) {
+__device__ __forceinline__ void persist_loop(StepArgs a, RunArgs ra, const XchgArgs x) {
   __shared__ int item_lds[4];
   const int lane = threadIdx.x;
   const int my_slot = cu_slot();
@@ -1339,6 +1393,7 @@ __device__ __forceinline__ void persist_loop(StepArgs a, RunArgs ra) {
           const int k = (int)(t / (uint32_t)ne), ee = part + (int)(t % (uint32_t)ne) * ra.P;
           while (__hip_atomic_load(&ra.progress[ee], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (uint32_t)k) __builtin_amdgcn_s_sleep(8);
           __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");      // nothing the item reads may be read ahead of the flag (compiler and wave)
+          if (x.slab) xchg_wait_slab(x, (uint32_t)k);                  // the exchange: slab k % ring must have been gathered (tickets are step-major: normally long ago)
           res_e = ee; res_k = k; res_sh = (thief || (tr & TK_SHARED)) ? 1 : 0;
         }
       }
@@ -1390,9 +1445,12 @@ __device__ __forceinline__ void persist_loop(StepArgs a, RunArgs ra) {
     if constexpr (PCG) {
       StepArgs b = a;
       b.rand_t = ra.t0 + item_k; b.full_obs = (a.full_obs && item_k == 0) ? 1 : 0;
+      if (x.slab) b.obs8 = x.slab + (size_t)(item_k % (uint32_t)x.ring) * (size_t)a.n * OBS_PACKED;
       pcg_body<false>(b, e, lane_i);
     } else {
-      philox1_body<false, true>(a, e, ra.t0 + item_k, item_k, lane_i);
+      StepArgs b = a;
+      if (x.slab) b.obs8 = x.slab + (size_t)(item_k % (uint32_t)x.ring) * (size_t)a.n * OBS_PACKED;
+      philox1_body<false, true>(b, e, ra.t0 + item_k, item_k, lane_i);
     }
     // the item is done when everything it wrote has left this wave: then the next step of the episode may start (on this XCD)
     // Release: every lane drains its own stores (workgroup-scope release = s_waitcnt vmcnt(0) on gfx950 without tgsplit: the vector L1 is
@@ -1401,28 +1459,37 @@ __device__ __forceinline__ void persist_loop(StepArgs a, RunArgs ra) {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     if (ra.order >= 2) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
     __syncthreads();
-    if (lane == 0) __hip_atomic_store(&ra.progress[e], item_k + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (lane == 0) {
+      __hip_atomic_store(&ra.progress[e], item_k + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (x.slab) xchg_count(x, item_k);
+    }
   }
 }
-__global__ __launch_bounds__(WAVE, 5) void k_run_philox1(StepArgs a, RunArgs ra) { persist_loop<false>(a, ra); }
+__global__ __launch_bounds__(WAVE, 5) void k_run_philox1(StepArgs a, RunArgs ra, XchgArgs x) { persist_loop<false>(a, ra, x); }
 #ifndef CC4_DEV_FAST
 // the same schedule around the numpy-stream step (k_step's body): the bit-exact mode's large batches
-__global__ __launch_bounds__(WAVE) void k_run_pcg(StepArgs a, RunArgs ra) { persist_loop<true>(a, ra); }
+__global__ __launch_bounds__(WAVE) void k_run_pcg(StepArgs a, RunArgs ra, XchgArgs x) { persist_loop<true>(a, ra, x); }
 #endif
 
 // The plain multi-step form of the one-wave kernel: one wave per episode, every wave loops over the K steps of ITS episode -- no
 // tickets, no affinity: a wave only reads what it wrote itself.  For batches one launch holds at once (cc4_create; CC4_RUN1=0/1
 // overrides): more waves than residency slots would simply start as slots free up (8192 episodes: 5120 at once, the other 3072
 // behind them on a chip that is no longer full).
-__global__ __launch_bounds__(WAVE, 5) void k_run_philox1m(StepArgs a, int K, uint32_t t0) {
+__global__ __launch_bounds__(WAVE, 5) void k_run_philox1m(StepArgs a, int K, uint32_t t0, XchgArgs x) {
   a.prof = nullptr; a.obs8 = nullptr; a.ext = nullptr;
   const int e = (int)blockIdx.x;
   for (int k = 0; k < K; ++k) {
+    if (x.slab) {
+      if (threadIdx.x == 0) xchg_wait_slab(x, (uint32_t)k);
+      a.obs8 = x.slab + (size_t)(k % x.ring) * (size_t)a.n * OBS_PACKED;
+      __syncthreads();
+    }
     int lane_i = (int)threadIdx.x;
     asm volatile("" : "+v"(lane_i));
     philox1_body<false, true>(a, e, t0 + (uint32_t)k, (uint32_t)k, lane_i);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
+    if (x.slab && threadIdx.x == 0) xchg_count(x, (uint32_t)k);
   }
 }
 
@@ -1479,7 +1546,7 @@ __global__ __launch_bounds__(WAVE) void k_reset(ResetArgs a) {
   for (int i = lane; i < OBS_TOTAL; i += WAVE) o[i] = obs_lds[i];
   uint8_t* m = a.mask + (size_t)e * MASK_TOTAL;
   for (int i = lane; i < MASK_TOTAL; i += WAVE) m[i] = mask_lds[i];
-  if (a.obs8) { uint8_t* o8 = a.obs8 + (size_t)e * OBS_PACKED; for (int j = lane; j < OBS_PACKED; j += WAVE) o8[j] = pack_obs_byte(obs_lds, j); }
+  if (a.obs8) store_packed_row(a.obs8 + (size_t)e * OBS_PACKED, obs_lds, lane, WAVE);
 }
 
 // uniform blue action indices over each agent's full range: Philox key (seed0, env),
@@ -1578,6 +1645,11 @@ struct cc4_handle {
   // memory is staged by the runtime anyway, synchronously and per call)
   size_t out_bytes = 0, in_bytes = 0;
   uint8_t* pin_out = nullptr; uint8_t* pin_in = nullptr;
+  // Handles of up to SMALL_IO_ENVS episodes (the single-episode wrapper surface) keep both blocks in pinned HOST memory the device reads
+  // and writes directly: the step kernel fetches its five action indices over PCIe and posts its results there, so a step is a launch and
+  // one host wait -- no copy engine in either direction (each DMA costs ~10 us of latency for a few hundred bytes).  CC4_SMALL_IO=0: off.
+  static constexpr int SMALL_IO_ENVS = 16;
+  bool small_io = false;
   // byte observations and gathered observations ([world*N][578]) in a ring of OBS_RING buffers: the all-gather of step t
   // overlaps later steps, and the compute stream waits for the communication stream only once per OBS_WAIT_EVERY steps
   // (a cross-stream wait in front of every launch costs the stream ~10 us)
@@ -1624,6 +1696,22 @@ struct cc4_handle {
   int run_P = 0, run_grid = 0;    // partitions (= CUs that take waves), waves per launch; 0: the persistent path is off
   int persist_state = -1;         // -1 off / unavailable, 0 not set up yet (persist_setup on first use), 1 on
   int persist_order = 0;          // RunArgs.order (CC4_PERSIST_ORDER)
+  int run_margin = 0;             // episode blocks per CU the one-launch forms leave free (choose_run_form)
+  // the per-step hand-off out of the one-launch kernels (XchgArgs): with a communicator, cc4_run_random_steps stays ONE launch and the
+  // communication stream follows the kernel's per-step counters (xchg_*)
+  static constexpr int XRING = 16;
+  bool xchg_on = false;           // cc4_comm_init; CC4_EXCHANGE_INKERNEL=0 keeps the per-step launches
+  int xchg_chunk = 1;             // steps per wait / publish on the communication stream (CC4_EXCHANGE_CHUNK; their all-gathers go out as one RCCL group)
+  uint8_t* d_xslab = nullptr;     // [XRING][n][OBS_PACKED]
+  uint8_t* d_xall = nullptr;      // [XRING][world * n][OBS_PACKED]
+  uint32_t* d_xflags = nullptr;   // [0] gathered, [1] timeout, [2 ..] done[k]
+  int xflags_cap = 0;             // steps the done[] part holds
+  hipEvent_t xev = nullptr;
+  long long xchg_calls = 0, xchg_timeouts = 0;
+  int xchg_watchdog_ms = 2000;
+  uint8_t* last_gathered = nullptr;   // gathered rows of the most recent all-gather, whichever path issued it
+  uint8_t* d_xlog = nullptr;      // debug (cc4_debug_gather_log): every gathered slab in issue order, [xlog_cap][world * n][OBS_PACKED]
+  int xlog_cap = 0, xlog_n = 0;
   bool persist_refused = false;   // persist_setup found an unexpected picture (said so on stderr; cc4_run_kernel reports the per-step kernel)
   // CC4_PERSIST_VERIFY=1: every one-launch call of cc4_run_random_steps is repeated with per-step launches on a shadow handle that starts
   // from a copy of this handle's rows, and the two results are compared episode by episode (verify_*)
@@ -1897,6 +1985,60 @@ static const void* persist_kernel(const cc4_handle* h) {
   return reinterpret_cast<const void*>(k_run_philox1);
 }
 
+
+// Which form cc4_run_random_steps takes on this handle (decided at cc4_create, again at cc4_comm_init): the multi-step form of the four-wave
+// kernel (k_run_philox / k_run_philox8) for batches the chip holds at once, the plain multi-step form of the one-wave kernel (k_run_philox1m)
+// up to 20 episodes per CU, the persistent kernel beyond.  `margin` = episode blocks per CU the multi-step kernels leave free,
+// `persist_margin` = waves per CU the persistent kernel's grid leaves free (see cc4_comm_init).
+static int choose_run_form(cc4_handle* h, int margin, int persist_margin = -1) {
+  const cc4_config* cfg = &h->cfg;
+  if (persist_margin < 0) persist_margin = margin;
+  h->multistep = false; h->run1m = false;
+  if (cfg->rng_mode == 1 && !h->philox_lean) {
+    // the multi-step form of the four-wave kernel (k_run_philox): for batches the chip holds at once
+    int per_cu = 0, per_cu8 = 0;
+    HIPCHK(h, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_run_philox, PT, sizeof(EnvState)));
+    HIPCHK(h, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu8, k_run_philox8, PT, sizeof(EnvState)));
+    h->multistep = per_cu - margin > 0 && cfg->num_envs <= (per_cu - margin) * h->cus;
+    h->multistep_minb = 5;
+    if (!h->multistep && per_cu8 > per_cu && cfg->num_envs <= (per_cu8 - margin) * h->cus) { h->multistep = true; h->multistep_minb = 8; }
+    if (const char* v = getenv("CC4_MULTISTEP")) {            // 0: off; 1: on (the build that holds the batch); 5 / 8: that build
+      const int m = atoi(v);
+      h->multistep = m != 0;
+      if (m == 5 || m == 8) h->multistep_minb = m;
+    }
+    if (getenv("CC4_PERSIST_DEBUG")) fprintf(stderr, "[cc4] k_run_philox: %d / %d blocks per CU resident (margin %d), multistep %d (build %d)\n", per_cu, per_cu8, margin, (int)h->multistep, h->multistep_minb);
+  }
+  if (cfg->rng_mode == 1 && !h->multistep) {
+    // (whichever per-step kernel the handle runs: a batch of 2049-5120 episodes that cc4_step serves with the four-wave kernel is served here by the one-wave loop)
+    // the plain multi-step form of the one-wave kernel (k_run_philox1m) where one launch holds the whole batch: 20 waves per CU
+    // (4096 episodes 507 -> 709 M, 5120: 586 -> 811 M; beyond the residency the second round runs on a half-empty chip and four
+    // streams of per-step launches win: 8192: 740 vs 789 M, 16384: 812 vs 864 M -- profiles/r04_run1m_ab.txt)
+    int per_cu = 0;
+    HIPCHK(h, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_run_philox1m, WAVE, offsetof(EnvState, hd)));
+    h->run1m = per_cu - margin > 0 && cfg->num_envs <= (per_cu - margin) * h->cus;
+    if (const char* v = getenv("CC4_RUN1")) h->run1m = atoi(v) != 0;
+  }
+  // one enqueue thread per group stream in cc4_run_random_steps (EnqPool): on where the host has cores to spare; CC4_ENQ_THREADS=0/1 decides otherwise
+  h->enq_threads = std::thread::hardware_concurrency() >= 8;
+  if (const char* v = getenv("CC4_ENQ_THREADS")) h->enq_threads = atoi(v) != 0;
+  // the persistent run kernel of large batches (k_run_philox1): set up on first use (persist_setup); CC4_PERSIST=0 keeps it off
+  h->persist_state = -1;
+  h->run_margin = persist_margin;
+  bool persist_mode = cfg->rng_mode == 1 && !h->multistep && !h->run1m;
+#ifndef CC4_DEV_FAST
+  persist_mode = persist_mode || cfg->rng_mode == 0;
+#endif
+  if (persist_mode) {
+    int per_cu = 0;
+    HIPCHK(h, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, persist_kernel(h), WAVE, offsetof(EnvState, hd)));
+    const int grid = (per_cu - persist_margin) * h->cus;
+    if (per_cu - persist_margin > 0 && cfg->num_envs > grid) h->persist_state = 0;     // batches of more than the chip holds at once (with the tail shared, also just more)
+  }
+  if (const char* v = getenv("CC4_PERSIST")) { if (atoi(v) == 0) h->persist_state = -1; }
+  return 0;
+}
+
 extern "C" {
 
 const char* cc4_last_error(cc4_handle* h) { return h ? h->err.c_str() : g_create_err.c_str(); }
@@ -1917,7 +2059,7 @@ const char* cc4_step_kernel(cc4_handle* h) {
 // step and group -- or one of the one-launch forms
 const char* cc4_run_kernel(cc4_handle* h) {
   if (!h) return "";
-  const bool plain = !h->comm && !h->evlog_on && !h->ext_seen && !h->d_prof;
+  const bool plain = (!h->comm || h->xchg_on) && !h->evlog_on && !h->ext_seen && !h->d_prof;
   if (plain && h->multistep) return h->multistep_minb == 8 ? "k_run_philox8" : "k_run_philox";
   if (plain && h->run1m) return "k_run_philox1m";
   if (plain && h->persist_state >= 0) return h->cfg.rng_mode == 0 ? "k_run_pcg" : "k_run_philox1";      // (calls of fewer than persist_min_k steps: the per-step launches)
@@ -1928,7 +2070,7 @@ const char* cc4_run_kernel_for(cc4_handle* h, int32_t k) {
   if (!h) return "";
   // (the persistent kernel's census runs on first use: asking which kernel a call of k steps will launch is such a use -- the answer depends on it,
   // and a caller that asks before its timed region keeps the census out of it)
-  if (h->persist_state == 0 && !h->run1m && !h->multistep && !h->comm && !h->evlog_on && !h->ext_seen && !h->d_prof && k >= h->persist_min_k && hipSetDevice(h->cfg.device_id) == hipSuccess) (void)persist_setup(h);
+  if (h->persist_state == 0 && !h->run1m && !h->multistep && (!h->comm || h->xchg_on) && !h->evlog_on && !h->ext_seen && !h->d_prof && k >= h->persist_min_k && hipSetDevice(h->cfg.device_id) == hipSuccess) (void)persist_setup(h);
   const char* r = cc4_run_kernel(h);
   if (k < 2) return cc4_step_kernel(h);
   if (!h->multistep && !h->run1m && h->persist_state >= 0 && k < h->persist_min_k) return cc4_step_kernel(h);
@@ -2009,11 +2151,22 @@ int cc4_create(const cc4_config* cfg, cc4_handle** out) {
   HIPCHK(h, hipMalloc(&h->d_cold, n * h->cold_row));
   if (cfg->rng_mode == 1) HIPCHK(h, hipMalloc(&h->d_reset_ws, n * RESET_WS_WORDS * sizeof(uint32_t)));   // the one-wave kernel's generation work area
   h->in_bytes = n * NBLUE * sizeof(int32_t) + n * NBLUE * MSG_LEN;
+  h->small_io = cfg->num_envs <= cc4_handle::SMALL_IO_ENVS;
+  if (const char* v = getenv("CC4_SMALL_IO")) h->small_io = h->small_io && atoi(v) != 0;
+  if (h->small_io) {
+    HIPCHK(h, hipHostMalloc(reinterpret_cast<void**>(&h->pin_in), h->in_bytes, hipHostMallocDefault));
+    HIPCHK(h, hipHostGetDevicePointer(reinterpret_cast<void**>(&h->d_actions), h->pin_in, 0));
+    memset(h->pin_in, 0, h->in_bytes);
+  } else
   HIPCHK(h, hipMalloc(&h->d_actions, h->in_bytes));
   h->d_msgs = reinterpret_cast<uint8_t*>(h->d_actions) + n * NBLUE * sizeof(int32_t);
   HIPCHK(h, hipMalloc(&h->d_seeds, n * sizeof(uint64_t)));
   HIPCHK(h, hipMalloc(&h->d_envmask, n));
   h->out_bytes = n * OBS_TOTAL * sizeof(int32_t) + n * sizeof(float) + n * sizeof(uint32_t) + n;
+  if (h->small_io) {
+    HIPCHK(h, hipHostMalloc(reinterpret_cast<void**>(&h->pin_out), h->out_bytes, hipHostMallocDefault));
+    HIPCHK(h, hipHostGetDevicePointer(reinterpret_cast<void**>(&h->d_obs), h->pin_out, 0));
+  } else
   HIPCHK(h, hipMalloc(&h->d_obs, h->out_bytes));
   h->d_reward = reinterpret_cast<float*>(h->d_obs + n * OBS_TOTAL);
   h->d_err = reinterpret_cast<uint32_t*>(h->d_reward + n);
@@ -2028,47 +2181,7 @@ int cc4_create(const cc4_config* cfg, cc4_handle** out) {
   HIPCHK(h, hipEventCreate(&h->ev0));
   HIPCHK(h, hipEventCreate(&h->ev1));
   HIPCHK(h, hipStreamSynchronize(h->stream));
-  if (cfg->rng_mode == 1 && !h->philox_lean) {
-    // the multi-step form of the four-wave kernel (k_run_philox): for batches the chip holds at once
-    int per_cu = 0, per_cu8 = 0;
-    HIPCHK(h, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_run_philox, PT, sizeof(EnvState)));
-    HIPCHK(h, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu8, k_run_philox8, PT, sizeof(EnvState)));
-    h->multistep = per_cu > 0 && cfg->num_envs <= per_cu * h->cus;
-    h->multistep_minb = 5;
-    if (!h->multistep && per_cu8 > per_cu && cfg->num_envs <= per_cu8 * h->cus) { h->multistep = true; h->multistep_minb = 8; }
-    if (const char* v = getenv("CC4_MULTISTEP")) {            // 0: off; 1: on (the build that holds the batch); 5 / 8: that build
-      const int m = atoi(v);
-      h->multistep = m != 0;
-      if (m == 5 || m == 8) h->multistep_minb = m;
-    }
-    if (getenv("CC4_PERSIST_DEBUG")) fprintf(stderr, "[cc4] k_run_philox: %d / %d blocks per CU resident, multistep %d (build %d)\n", per_cu, per_cu8, (int)h->multistep, h->multistep_minb);
-  }
-  if (cfg->rng_mode == 1 && !h->multistep) {
-    // (whichever per-step kernel the handle runs: a batch of 2049-5120 episodes that cc4_step serves with the four-wave kernel is served here by the one-wave loop)
-    // the plain multi-step form of the one-wave kernel (k_run_philox1m) where one launch holds the whole batch: 20 waves per CU
-    // (4096 episodes 507 -> 709 M, 5120: 586 -> 811 M; beyond the residency the second round runs on a half-empty chip and four
-    // streams of per-step launches win: 8192: 740 vs 789 M, 16384: 812 vs 864 M -- profiles/r04_run1m_ab.txt)
-    int per_cu = 0;
-    HIPCHK(h, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_run_philox1m, WAVE, offsetof(EnvState, hd)));
-    h->run1m = per_cu > 0 && cfg->num_envs <= per_cu * h->cus;
-    if (const char* v = getenv("CC4_RUN1")) h->run1m = atoi(v) != 0;
-  }
-  // one enqueue thread per group stream in cc4_run_random_steps (EnqPool): on where the host has cores to spare; CC4_ENQ_THREADS=0/1 decides otherwise
-  h->enq_threads = std::thread::hardware_concurrency() >= 8;
-  if (const char* v = getenv("CC4_ENQ_THREADS")) h->enq_threads = atoi(v) != 0;
-  // the persistent run kernel of large batches (k_run_philox1): set up on first use (persist_setup); CC4_PERSIST=0 keeps it off
-  h->persist_state = -1;
-  bool persist_mode = cfg->rng_mode == 1 && !h->multistep && !h->run1m;
-#ifndef CC4_DEV_FAST
-  persist_mode = persist_mode || cfg->rng_mode == 0;
-#endif
-  if (persist_mode) {
-    int per_cu = 0;
-    HIPCHK(h, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, persist_kernel(h), WAVE, offsetof(EnvState, hd)));
-    const int grid = per_cu * h->cus;
-    if (per_cu > 0 && cfg->num_envs > grid) h->persist_state = 0;     // batches of more than the chip holds at once (with the tail shared, also just more)
-  }
-  if (const char* v = getenv("CC4_PERSIST")) { if (atoi(v) == 0) h->persist_state = -1; }
+  if (choose_run_form(h, 0)) return -1;
   if (const char* v = getenv("CC4_PERSIST_MIN_K")) h->persist_min_k = atoi(v);
   if (const char* v = getenv("CC4_PERSIST_ORDER")) h->persist_order = atoi(v);
   if (const char* v = getenv("CC4_PERSIST_VERIFY")) h->verify = atoi(v) != 0;
@@ -2084,8 +2197,8 @@ void cc4_destroy(cc4_handle* h) {
   if (h->comm) ncclCommDestroy(h->comm);
   for (int b = 0; b < cc4_handle::OBS_RING; ++b) { for (int g = 0; g < cc4_handle::MAX_GROUPS; ++g) if (h->ev_step[b][g]) (void)hipEventDestroy(h->ev_step[b][g]); if (h->ev_comm[b]) (void)hipEventDestroy(h->ev_comm[b]); }
   if (h->comm_stream) (void)hipStreamDestroy(h->comm_stream);
-  void* ptrs[] = {h->d_state, h->d_cold, h->d_actions, h->d_seeds, h->d_envmask, h->d_obs,
-                  h->d_mask, h->d_rng, h->d_reset_ws, h->d_ext, h->d_run, h->d_slot_part};     // (d_msgs, d_reward, d_err, d_done live inside d_actions / d_obs)
+  void* ptrs[] = {h->d_state, h->d_cold, h->small_io ? nullptr : (void*)h->d_actions, h->d_seeds, h->d_envmask, h->small_io ? nullptr : (void*)h->d_obs,
+                  h->d_mask, h->d_rng, h->d_reset_ws, h->d_ext, h->d_run, h->d_slot_part};     // (d_msgs, d_reward, d_err, d_done live inside d_actions / d_obs; small handles: pinned host memory, freed below)
   for (void* p : ptrs) if (p) (void)hipFree(p);
   if (h->shadow) { cc4_destroy(h->shadow); h->shadow = nullptr; (void)hipSetDevice(h->cfg.device_id); }
   if (h->d_digest) (void)hipFree(h->d_digest);
@@ -2093,6 +2206,8 @@ void cc4_destroy(cc4_handle* h) {
   if (h->pin_out) (void)hipHostFree(h->pin_out);
   for (int b = 0; b < cc4_handle::OBS_RING; ++b) { if (h->d_obs8[b]) (void)hipFree(h->d_obs8[b]); if (h->d_all_obs8[b]) (void)hipFree(h->d_all_obs8[b]); }
   if (h->d_unpacked) (void)hipFree(h->d_unpacked);
+  for (void* p : {(void*)h->d_xslab, (void*)h->d_xall, (void*)h->d_xflags, (void*)h->d_xlog}) if (p) (void)hipFree(p);
+  if (h->xev) (void)hipEventDestroy(h->xev);
   for (hipEvent_t e : h->evs) if (e) (void)hipEventDestroy(e);
   if (h->ev0) (void)hipEventDestroy(h->ev0);
   if (h->ev1) (void)hipEventDestroy(h->ev1);
@@ -2126,8 +2241,8 @@ int cc4_step(cc4_handle* h, const int32_t* actions, const uint8_t* messages) {
   HIPCHK(h, hipSetDevice(h->cfg.device_id));
   if (join_groups(h)) return -1;
   size_t n = (size_t)h->cfg.num_envs;
-  if (actions) HIPCHK(h, hipMemcpyAsync(h->d_actions, actions, n * NBLUE * sizeof(int32_t), hipMemcpyHostToDevice, h->stream));
-  if (messages) HIPCHK(h, hipMemcpyAsync(h->d_msgs, messages, n * NBLUE * MSG_LEN, hipMemcpyHostToDevice, h->stream));
+  if (actions) HIPCHK(h, hipMemcpyAsync(h->d_actions, actions, n * NBLUE * sizeof(int32_t), hipMemcpyDefault, h->stream));
+  if (messages) HIPCHK(h, hipMemcpyAsync(h->d_msgs, messages, n * NBLUE * MSG_LEN, hipMemcpyDefault, h->stream));
   if (launch_step(h, actions ? h->d_actions : nullptr, messages ? h->d_msgs : nullptr)) return -1;
   return sync_all(h);
 }
@@ -2140,10 +2255,7 @@ static int fetch_outputs(cc4_handle* h, int32_t* obs, float* reward, uint8_t* do
   if (join_groups(h)) return -1;
   const size_t n = (size_t)h->cfg.num_envs;
   const size_t b_obs = n * OBS_TOTAL * sizeof(int32_t), b_rew = n * sizeof(float), b_err = n * sizeof(uint32_t);
-  if (h->cfg.num_envs <= PIN_MAX_ENVS) {
-    if (!h->pin_out) HIPCHK(h, hipHostMalloc(reinterpret_cast<void**>(&h->pin_out), h->out_bytes, hipHostMallocDefault));
-    const size_t lo = obs ? 0 : b_obs;                         // (a caller that wants no observations does not pay for them)
-    HIPCHK(h, hipMemcpyAsync(h->pin_out + lo, reinterpret_cast<const uint8_t*>(h->d_obs) + lo, h->out_bytes - lo, hipMemcpyDeviceToHost, h->stream));
+  if (h->small_io) {                                          // the kernels wrote into pinned host memory: wait, then read it
     HIPCHK(h, hipStreamSynchronize(h->stream));
     if (obs) memcpy(obs, h->pin_out, b_obs);
     if (reward) memcpy(reward, h->pin_out + b_obs, b_rew);
@@ -2151,10 +2263,21 @@ static int fetch_outputs(cc4_handle* h, int32_t* obs, float* reward, uint8_t* do
     if (done) memcpy(done, h->pin_out + b_obs + b_rew + b_err, n);
     return 0;
   }
-  if (obs) HIPCHK(h, hipMemcpyAsync(obs, h->d_obs, b_obs, hipMemcpyDeviceToHost, h->stream));
-  if (reward) HIPCHK(h, hipMemcpyAsync(reward, h->d_reward, b_rew, hipMemcpyDeviceToHost, h->stream));
-  if (err) HIPCHK(h, hipMemcpyAsync(err, h->d_err, b_err, hipMemcpyDeviceToHost, h->stream));
-  if (done) HIPCHK(h, hipMemcpyAsync(done, h->d_done, n, hipMemcpyDeviceToHost, h->stream));
+  if (h->cfg.num_envs <= PIN_MAX_ENVS) {
+    if (!h->pin_out) HIPCHK(h, hipHostMalloc(reinterpret_cast<void**>(&h->pin_out), h->out_bytes, hipHostMallocDefault));
+    const size_t lo = obs ? 0 : b_obs;                         // (a caller that wants no observations does not pay for them)
+    HIPCHK(h, hipMemcpyAsync(h->pin_out + lo, reinterpret_cast<const uint8_t*>(h->d_obs) + lo, h->out_bytes - lo, hipMemcpyDefault, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    if (obs) memcpy(obs, h->pin_out, b_obs);
+    if (reward) memcpy(reward, h->pin_out + b_obs, b_rew);
+    if (err) memcpy(err, h->pin_out + b_obs + b_rew, b_err);
+    if (done) memcpy(done, h->pin_out + b_obs + b_rew + b_err, n);
+    return 0;
+  }
+  if (obs) HIPCHK(h, hipMemcpyAsync(obs, h->d_obs, b_obs, hipMemcpyDefault, h->stream));
+  if (reward) HIPCHK(h, hipMemcpyAsync(reward, h->d_reward, b_rew, hipMemcpyDefault, h->stream));
+  if (err) HIPCHK(h, hipMemcpyAsync(err, h->d_err, b_err, hipMemcpyDefault, h->stream));
+  if (done) HIPCHK(h, hipMemcpyAsync(done, h->d_done, n, hipMemcpyDefault, h->stream));
   HIPCHK(h, hipStreamSynchronize(h->stream));
   return 0;
 }
@@ -2168,15 +2291,19 @@ int cc4_step_fetch(cc4_handle* h, const int32_t* actions, const uint8_t* message
   if (join_groups(h)) return -1;
   const size_t n = (size_t)h->cfg.num_envs;
   const size_t b_act = n * NBLUE * sizeof(int32_t), b_msg = n * NBLUE * MSG_LEN;
-  if (h->cfg.num_envs <= PIN_MAX_ENVS && (actions || messages)) {
+  if (h->small_io) {                                          // (every earlier launch has completed: each call of this surface ends with a host wait)
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    if (actions) memcpy(h->pin_in, actions, b_act);
+    if (messages) memcpy(h->pin_in + b_act, messages, b_msg);
+  } else if (h->cfg.num_envs <= PIN_MAX_ENVS && (actions || messages)) {
     if (!h->pin_in) HIPCHK(h, hipHostMalloc(reinterpret_cast<void**>(&h->pin_in), h->in_bytes, hipHostMallocDefault));
     if (actions) memcpy(h->pin_in, actions, b_act);
     if (messages) memcpy(h->pin_in + b_act, messages, b_msg);
     const size_t lo = actions ? 0 : b_act, hi = messages ? b_act + b_msg : b_act;
-    HIPCHK(h, hipMemcpyAsync(reinterpret_cast<uint8_t*>(h->d_actions) + lo, h->pin_in + lo, hi - lo, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(h, hipMemcpyAsync(reinterpret_cast<uint8_t*>(h->d_actions) + lo, h->pin_in + lo, hi - lo, hipMemcpyDefault, h->stream));
   } else {
-    if (actions) HIPCHK(h, hipMemcpyAsync(h->d_actions, actions, b_act, hipMemcpyHostToDevice, h->stream));
-    if (messages) HIPCHK(h, hipMemcpyAsync(h->d_msgs, messages, b_msg, hipMemcpyHostToDevice, h->stream));
+    if (actions) HIPCHK(h, hipMemcpyAsync(h->d_actions, actions, b_act, hipMemcpyDefault, h->stream));
+    if (messages) HIPCHK(h, hipMemcpyAsync(h->d_msgs, messages, b_msg, hipMemcpyDefault, h->stream));
   }
   if (launch_step(h, actions ? h->d_actions : nullptr, messages ? h->d_msgs : nullptr)) return -1;
   return fetch_outputs(h, obs, reward, done, err);
@@ -2210,8 +2337,8 @@ int cc4_step_ex(cc4_handle* h, const int32_t* actions, const uint8_t* messages, 
   }
   HIPCHK(h, hipMemcpyAsync(h->d_ext, h->h_ext.data(), h->h_ext.size() * sizeof(ExtAct), hipMemcpyHostToDevice, h->stream));
   h->ext_seen = true; h->ext_dirty = true;
-  if (actions) HIPCHK(h, hipMemcpyAsync(h->d_actions, actions, n * NBLUE * sizeof(int32_t), hipMemcpyHostToDevice, h->stream));
-  if (messages) HIPCHK(h, hipMemcpyAsync(h->d_msgs, messages, n * NBLUE * MSG_LEN, hipMemcpyHostToDevice, h->stream));
+  if (actions) HIPCHK(h, hipMemcpyAsync(h->d_actions, actions, n * NBLUE * sizeof(int32_t), hipMemcpyDefault, h->stream));
+  if (messages) HIPCHK(h, hipMemcpyAsync(h->d_msgs, messages, n * NBLUE * MSG_LEN, hipMemcpyDefault, h->stream));
   if (launch_step(h, actions ? h->d_actions : nullptr, messages ? h->d_msgs : nullptr, false, 0, 0, true)) return -1;
   return sync_all(h);
 }
@@ -2243,7 +2370,7 @@ int cc4_step_device(cc4_handle* h, const int32_t* d_actions, const uint8_t* d_me
 int cc4_get_obs(cc4_handle* h, int32_t* obs) {
   HIPCHK(h, hipSetDevice(h->cfg.device_id));
   if (join_groups(h)) return -1;
-  HIPCHK(h, hipMemcpyAsync(obs, h->d_obs, (size_t)h->cfg.num_envs * OBS_TOTAL * sizeof(int32_t), hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(h, hipMemcpyAsync(obs, h->d_obs, (size_t)h->cfg.num_envs * OBS_TOTAL * sizeof(int32_t), hipMemcpyDefault, h->stream));
   HIPCHK(h, hipStreamSynchronize(h->stream));
   return 0;
 }
@@ -2251,8 +2378,8 @@ int cc4_get_reward_done(cc4_handle* h, float* reward, uint8_t* done) {
   HIPCHK(h, hipSetDevice(h->cfg.device_id));
   if (join_groups(h)) return -1;
   size_t n = (size_t)h->cfg.num_envs;
-  if (reward) HIPCHK(h, hipMemcpyAsync(reward, h->d_reward, n * sizeof(float), hipMemcpyDeviceToHost, h->stream));
-  if (done) HIPCHK(h, hipMemcpyAsync(done, h->d_done, n, hipMemcpyDeviceToHost, h->stream));
+  if (reward) HIPCHK(h, hipMemcpyAsync(reward, h->d_reward, n * sizeof(float), hipMemcpyDefault, h->stream));
+  if (done) HIPCHK(h, hipMemcpyAsync(done, h->d_done, n, hipMemcpyDefault, h->stream));
   HIPCHK(h, hipStreamSynchronize(h->stream));
   return 0;
 }
@@ -2266,7 +2393,7 @@ int cc4_get_action_mask(cc4_handle* h, uint8_t* mask) {
 int cc4_get_err(cc4_handle* h, uint32_t* err) {
   HIPCHK(h, hipSetDevice(h->cfg.device_id));
   if (join_groups(h)) return -1;
-  HIPCHK(h, hipMemcpyAsync(err, h->d_err, (size_t)h->cfg.num_envs * sizeof(uint32_t), hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(h, hipMemcpyAsync(err, h->d_err, (size_t)h->cfg.num_envs * sizeof(uint32_t), hipMemcpyDefault, h->stream));
   HIPCHK(h, hipStreamSynchronize(h->stream));
   return 0;
 }
@@ -2310,7 +2437,7 @@ int cc4_actions_device(cc4_handle* h, int32_t** p) { *p = h->d_actions; return 0
 int cc4_get_actions(cc4_handle* h, int32_t* out) {
   HIPCHK(h, hipSetDevice(h->cfg.device_id));
   if (join_groups(h)) return -1;
-  HIPCHK(h, hipMemcpyAsync(out, h->d_actions, (size_t)h->cfg.num_envs * NBLUE * sizeof(int32_t), hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(h, hipMemcpyAsync(out, h->d_actions, (size_t)h->cfg.num_envs * NBLUE * sizeof(int32_t), hipMemcpyDefault, h->stream));
   HIPCHK(h, hipStreamSynchronize(h->stream));
   return 0;
 }
@@ -2341,6 +2468,7 @@ static int persist_setup(cc4_handle* h) {
   const size_t n = (size_t)h->cfg.num_envs;
   int per_cu = 0;
   HIPCHK(h, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, persist_kernel(h), WAVE, offsetof(EnvState, hd)));
+  per_cu -= h->run_margin;            // (with ranks to talk to: a slot per CU stays free for RCCL's kernels)
   const int grid = per_cu * h->cus;
   if (per_cu <= 0) return 0;
   if (join_groups(h)) return -1;
@@ -2376,14 +2504,80 @@ static int persist_setup(cc4_handle* h) {
   }
   if (arch_ok && P == h->cus && worst <= per_cu && total == grid) {
     h->run_P = P; h->run_grid = grid;
-    HIPCHK(h, hipMalloc(&h->d_slot_part, CC4_SLOTS * sizeof(int16_t)));
+    if (!h->d_slot_part) HIPCHK(h, hipMalloc(&h->d_slot_part, CC4_SLOTS * sizeof(int16_t)));
     HIPCHK(h, hipMemcpy(h->d_slot_part, table.data(), CC4_SLOTS * sizeof(int16_t), hipMemcpyHostToDevice));
+    if (h->d_run) { (void)hipFree(h->d_run); h->d_run = nullptr; }
     HIPCHK(h, hipMalloc(&h->d_run, (2 * (size_t)P + n) * sizeof(uint32_t)));
     h->persist_state = 1;
   }
   return 0;
 }
 
+// ---- the exchange around a one-launch kernel (XchgArgs).  Before the launch: the call's flags cleared on the main stream, the
+// communication stream ordered behind that.  After the launch: per chunk of steps, on the communication stream, wait for the chunk's last
+// step to be complete (done[k] == episodes: the kernel counts an episode once its packed row is in memory), all-gather the chunk's
+// slabs, publish gathered = k + 1.  After the main stream's synchronisation: the communication stream drained, the watchdog flag read.
+static int xchg_begin(cc4_handle* h, int k, XchgArgs* x) {
+  if (k > h->xflags_cap) {
+    if (h->d_xflags) { HIPCHK(h, hipStreamSynchronize(h->comm_stream)); (void)hipFree(h->d_xflags); h->d_xflags = nullptr; }
+    const int cap = k < 1024 ? 1024 : k;
+    HIPCHK(h, hipMalloc(&h->d_xflags, (2 + (size_t)cap) * sizeof(uint32_t)));
+    h->xflags_cap = cap;
+  }
+  HIPCHK(h, hipMemsetAsync(h->d_xflags, 0, (2 + (size_t)k) * sizeof(uint32_t), h->stream));
+  HIPCHK(h, hipEventRecord(h->xev, h->stream));
+  HIPCHK(h, hipStreamWaitEvent(h->comm_stream, h->xev, 0));
+  int khz = 100000;
+  (void)hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, h->cfg.device_id);
+  *x = XchgArgs{h->d_xslab, h->d_xflags + 2, h->d_xflags, h->d_xflags + 1, cc4_handle::XRING, (long long)h->xchg_watchdog_ms * (khz > 0 ? khz : 100000)};
+  return 0;
+}
+static int xchg_enqueue(cc4_handle* h, int k, const XchgArgs& x) {
+  const size_t row = (size_t)h->cfg.num_envs * OBS_PACKED;
+  const int C = h->xchg_chunk;
+  for (int c0 = 0; c0 < k; c0 += C) {
+    const int hi = (c0 + C < k ? c0 + C : k) - 1;
+    HIPCHK(h, hipStreamWaitValue32(h->comm_stream, x.done + hi, (uint32_t)h->cfg.num_envs, hipStreamWaitValueGte, 0xFFFFFFFFu));
+    if (h->comm_delay_ticks > 0) { hipLaunchKernelGGL(k_spin, dim3(1), dim3(1), 0, h->comm_stream, h->comm_delay_ticks); HIPCHK(h, hipGetLastError()); }
+    if (hi > c0) (void)ncclGroupStart();
+    for (int j = c0; j <= hi; ++j) {
+      const int slot = j % cc4_handle::XRING;
+      ncclResult_t r = ncclAllGather(h->d_xslab + slot * row, h->d_xall + slot * row * (size_t)h->world, row, ncclUint8, h->comm, h->comm_stream);
+      if (r != ncclSuccess) { h->err = std::string("ncclAllGather: ") + ncclGetErrorString(r); return -1; }
+    }
+    if (hi > c0) { ncclResult_t r = ncclGroupEnd(); if (r != ncclSuccess) { h->err = std::string("ncclGroupEnd: ") + ncclGetErrorString(r); return -1; } }
+    if (h->d_xlog) for (int j = c0; j <= hi && h->xlog_n < h->xlog_cap; ++j, ++h->xlog_n)     // debug: keep every gathered slab (cc4_debug_gather_log)
+      HIPCHK(h, hipMemcpyAsync(h->d_xlog + (size_t)h->xlog_n * row * h->world, h->d_xall + (j % cc4_handle::XRING) * row * (size_t)h->world, row * h->world, hipMemcpyDeviceToDevice, h->comm_stream));
+    HIPCHK(h, hipStreamWriteValue32(h->comm_stream, x.gathered, (uint32_t)(hi + 1), 0));
+  }
+  h->gathers_issued += k;
+  return 0;
+}
+static int xchg_end(cc4_handle* h, int k) {
+  const size_t row = (size_t)h->cfg.num_envs * OBS_PACKED;
+  HIPCHK(h, hipStreamSynchronize(h->comm_stream));
+  h->gathers_waited = h->gathers_issued;
+  uint32_t flag = 0;
+  HIPCHK(h, hipMemcpy(&flag, h->d_xflags + 1, sizeof(flag), hipMemcpyDeviceToHost));
+  h->xchg_calls++;
+  const int last = (k - 1) % cc4_handle::XRING;
+  h->last_gathered = h->d_xall + last * row * (size_t)h->world;
+  h->gather_buf = -2;                               // (not one of the per-step ring's buffers: last_gathered says where)
+  // the per-step path's current buffer holds the observations of the last step as well: an explicit cc4_allgather_obs, or a per-step
+  // launch that follows, finds what it expects
+  HIPCHK(h, hipMemcpyAsync(h->d_obs8[h->obs_buf], h->d_xslab + last * row, row, hipMemcpyDeviceToDevice, h->stream));
+  h->step_event_attached = false;
+  if (flag) {
+    // an item waited longer than the watchdog for its slab: the exchange did not keep up at all (e.g. its kernels found no room beside the
+    // one-launch kernel).  The episodes are intact -- a wait that gives up only stops protecting slabs, so gathers of this call may have
+    // carried a later step's rows -- and the handle goes back to per-step launches, loudly.
+    h->xchg_timeouts++;
+    h->xchg_on = false;
+    fprintf(stderr, "[cc4] the in-kernel exchange timed out (a step waited > %d ms for the all-gather of %d steps earlier): this handle returns to per-step launches with the exchange\n",
+            h->xchg_watchdog_ms, cc4_handle::XRING);
+  }
+  return 0;
+}
 static int run_random_steps_impl(cc4_handle* h, uint64_t seed0, uint32_t t0, int32_t k, float* ms_step_kernels);
 // CC4_PERSIST_VERIFY=1 (a self-check mode, not a fast one): a call that takes a one-launch form -- the persistent kernels, whose hand-over
 // between the steps of an episode leans on how a CU's L1 behaves, and the plain multi-step kernels -- is run a second time
@@ -2415,7 +2609,7 @@ int cc4_run_random_steps(cc4_handle* h, uint64_t seed0, uint32_t t0, int32_t k, 
   HIPCHK(h, hipStreamSynchronize(sh->stream));
   HIPCHK(h, hipMemcpyAsync(sh->d_state, h->d_state, n * sizeof(EnvState), hipMemcpyDeviceToDevice, h->stream));
   HIPCHK(h, hipMemcpyAsync(sh->d_cold, h->d_cold, n * h->cold_row, hipMemcpyDeviceToDevice, h->stream));
-  HIPCHK(h, hipMemcpyAsync(sh->d_obs, h->d_obs, h->out_bytes, hipMemcpyDeviceToDevice, h->stream));
+  HIPCHK(h, hipMemcpyAsync(sh->d_obs, h->d_obs, h->out_bytes, hipMemcpyDefault, h->stream));
   HIPCHK(h, hipStreamSynchronize(h->stream));
   sh->full_obs_next = h->full_obs_next; sh->main_ahead = sh->ngroups > 1;
   int rc = run_random_steps_impl(h, seed0, t0, k, ms_step_kernels);
@@ -2443,74 +2637,50 @@ int cc4_verify_stats(cc4_handle* h, int64_t* out /* [2] */) { out[0] = h->verify
 static int run_random_steps_impl(cc4_handle* h, uint64_t seed0, uint32_t t0, int32_t k, float* ms_step_kernels) {
   HIPCHK(h, hipSetDevice(h->cfg.device_id));
   if (k <= 0) { if (ms_step_kernels) *ms_step_kernels = 0.f; return 0; }   // nothing to launch, no timing event to read
-  if (h->multistep && !h->comm && !h->evlog_on && !h->ext_seen && !h->d_prof && k >= 2) {
-    // one launch: every block runs the k steps of its episode (k_run_philox)
+  const bool plain = (!h->comm || h->xchg_on) && !h->evlog_on && !h->ext_seen && !h->d_prof;
+  if (plain && h->persist_state == 0 && !h->run1m && !h->multistep && k >= h->persist_min_k) { if (persist_setup(h)) return -1; }
+  const int form = !plain ? 0 : (h->multistep && k >= 2) ? 1 : (h->run1m && k >= 2) ? 2 : (h->persist_state == 1 && h->run_P > 0 && k >= h->persist_min_k) ? 3 : 0;
+  if (form) {
+    // ONE launch for the k steps: 1 = every block loops over the steps of its episode (k_run_philox / k_run_philox8), 2 = the same on one wave
+    // per episode (k_run_philox1m), 3 = the persistent form (k_run_philox1 / k_run_pcg: one wave per residency slot pulling (episode, step) items)
     if (join_groups(h)) return -1;
     StepArgs a{h->d_state, h->d_cold, nullptr, nullptr, h->d_obs, h->d_reward, h->d_done, h->d_err, nullptr, h->d_actions, seed0, t0,
                h->cfg.num_envs, h->cfg.autoreset, h->cfg.steps, h->cfg.rng_mode,
                (h->cfg.red_policy & 3) | (h->cfg.green_policy ? GP_SLEEP_BIT : 0) | (h->cfg.green_policy == 2 ? GP_OPEN_BIT : 0) | (h->cfg.blue_policy ? BP_RANDOM_BIT : 0),
                h->full_obs_next ? 1 : 0, (uint32_t)h->cfg.topology_seed, nullptr, h->d_reset_ws, nullptr, 0};
+    XchgArgs x{};
+    const bool exchange = h->comm != nullptr;
+    if (exchange && xchg_begin(h, k, &x)) return -1;
     if (ms_step_kernels && h->evs.size() < 2) { h->evs.resize(2, nullptr); for (auto& e : h->evs) if (!e) HIPCHK(h, hipEventCreate(&e)); }
+    hipEvent_t e0 = ms_step_kernels ? h->evs[0] : nullptr, e1 = ms_step_kernels ? h->evs[1] : nullptr;
     auto c0 = std::chrono::steady_clock::now();
-    if (h->multistep_minb == 8)
-      hipExtLaunchKernelGGL(k_run_philox8, dim3(h->cfg.num_envs), dim3(PT), sizeof(EnvState), h->stream,
-                            ms_step_kernels ? h->evs[0] : nullptr, ms_step_kernels ? h->evs[1] : nullptr, 0, a, (int)k, t0);
-    else
-      hipExtLaunchKernelGGL(k_run_philox, dim3(h->cfg.num_envs), dim3(PT), sizeof(EnvState), h->stream,
-                            ms_step_kernels ? h->evs[0] : nullptr, ms_step_kernels ? h->evs[1] : nullptr, 0, a, (int)k, t0);
-    HIPCHK(h, hipGetLastError());
-    h->stat_launch_us += std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - c0).count();
-    h->stat_steps += k;
-    h->full_obs_next = false;
-    h->main_ahead = h->ngroups > 1;
-    HIPCHK(h, hipStreamSynchronize(h->stream));
-    if (ms_step_kernels) HIPCHK(h, hipEventElapsedTime(ms_step_kernels, h->evs[0], h->evs[1]));
-    return 0;
-  }
-  if (h->run1m && !h->comm && !h->evlog_on && !h->ext_seen && !h->d_prof && k >= 2) {
-    if (join_groups(h)) return -1;
-    StepArgs a{h->d_state, h->d_cold, nullptr, nullptr, h->d_obs, h->d_reward, h->d_done, h->d_err, nullptr, h->d_actions, seed0, t0,
-               h->cfg.num_envs, h->cfg.autoreset, h->cfg.steps, h->cfg.rng_mode,
-               (h->cfg.red_policy & 3) | (h->cfg.green_policy ? GP_SLEEP_BIT : 0) | (h->cfg.green_policy == 2 ? GP_OPEN_BIT : 0) | (h->cfg.blue_policy ? BP_RANDOM_BIT : 0),
-               h->full_obs_next ? 1 : 0, (uint32_t)h->cfg.topology_seed, nullptr, h->d_reset_ws, nullptr, 0};
-    if (ms_step_kernels && h->evs.size() < 2) { h->evs.resize(2, nullptr); for (auto& e : h->evs) if (!e) HIPCHK(h, hipEventCreate(&e)); }
-    hipExtLaunchKernelGGL(k_run_philox1m, dim3(h->cfg.num_envs), dim3(WAVE), offsetof(EnvState, hd), h->stream,
-                          ms_step_kernels ? h->evs[0] : nullptr, ms_step_kernels ? h->evs[1] : nullptr, 0, a, (int)k, t0);
-    HIPCHK(h, hipGetLastError());
-    h->stat_steps += k;
-    h->full_obs_next = false;
-    h->main_ahead = h->ngroups > 1;
-    HIPCHK(h, hipStreamSynchronize(h->stream));
-    if (ms_step_kernels) HIPCHK(h, hipEventElapsedTime(ms_step_kernels, h->evs[0], h->evs[1]));
-    return 0;
-  }
-  if (h->persist_state == 0 && !h->run1m && !h->multistep && !h->comm && !h->evlog_on && !h->ext_seen && !h->d_prof && k >= h->persist_min_k) { if (persist_setup(h)) return -1; }
-  if (h->persist_state == 1 && h->run_P > 0 && !h->comm && !h->evlog_on && !h->ext_seen && !h->d_prof && k >= h->persist_min_k) {
-    // the persistent form: the k steps of the whole batch in ONE launch on the main stream (k_run_philox1)
-    if (join_groups(h)) return -1;
-    const size_t words = 2 * (size_t)h->run_P + (size_t)h->cfg.num_envs;
-    HIPCHK(h, hipMemsetAsync(h->d_run, 0, words * sizeof(uint32_t), h->stream));
-    StepArgs a{h->d_state, h->d_cold, nullptr, nullptr, h->d_obs, h->d_reward, h->d_done, h->d_err, nullptr, h->d_actions, seed0, t0,
-               h->cfg.num_envs, h->cfg.autoreset, h->cfg.steps, h->cfg.rng_mode,
-               (h->cfg.red_policy & 3) | (h->cfg.green_policy ? GP_SLEEP_BIT : 0) | (h->cfg.green_policy == 2 ? GP_OPEN_BIT : 0) | (h->cfg.blue_policy ? BP_RANDOM_BIT : 0),
-               h->full_obs_next ? 1 : 0, (uint32_t)h->cfg.topology_seed, nullptr, h->d_reset_ws, nullptr, 0};
-    RunArgs ra{h->d_run, h->d_run + 2 * h->run_P, reinterpret_cast<int32_t*>(h->d_run + h->run_P), h->d_slot_part, h->run_P, k, t0, h->persist_order};
-    if (ms_step_kernels && h->evs.size() < 2) { h->evs.resize(2, nullptr); for (auto& e : h->evs) if (!e) HIPCHK(h, hipEventCreate(&e)); }
-    auto c0 = std::chrono::steady_clock::now();
+    if (form == 1) {
+      if (h->multistep_minb == 8) hipExtLaunchKernelGGL(k_run_philox8, dim3(h->cfg.num_envs), dim3(PT), sizeof(EnvState), h->stream, e0, e1, 0, a, (int)k, t0, x);
+      else hipExtLaunchKernelGGL(k_run_philox, dim3(h->cfg.num_envs), dim3(PT), sizeof(EnvState), h->stream, e0, e1, 0, a, (int)k, t0, x);
+    } else if (form == 2) {
+      hipExtLaunchKernelGGL(k_run_philox1m, dim3(h->cfg.num_envs), dim3(WAVE), offsetof(EnvState, hd), h->stream, e0, e1, 0, a, (int)k, t0, x);
+    } else {
+      const size_t words = 2 * (size_t)h->run_P + (size_t)h->cfg.num_envs;
+      HIPCHK(h, hipMemsetAsync(h->d_run, 0, words * sizeof(uint32_t), h->stream));
+      RunArgs ra{h->d_run, h->d_run + 2 * h->run_P, reinterpret_cast<int32_t*>(h->d_run + h->run_P), h->d_slot_part, h->run_P, k, t0, h->persist_order};
 #ifndef CC4_DEV_FAST
-    if (h->cfg.rng_mode == 0)
-      hipExtLaunchKernelGGL(k_run_pcg, dim3(h->run_grid), dim3(WAVE), offsetof(EnvState, hd), h->stream,
-                            ms_step_kernels ? h->evs[0] : nullptr, ms_step_kernels ? h->evs[1] : nullptr, 0, a, ra);
-    else
+      if (h->cfg.rng_mode == 0) hipExtLaunchKernelGGL(k_run_pcg, dim3(h->run_grid), dim3(WAVE), offsetof(EnvState, hd), h->stream, e0, e1, 0, a, ra, x);
+      else
 #endif
-    hipExtLaunchKernelGGL(k_run_philox1, dim3(h->run_grid), dim3(WAVE), offsetof(EnvState, hd), h->stream,
-                          ms_step_kernels ? h->evs[0] : nullptr, ms_step_kernels ? h->evs[1] : nullptr, 0, a, ra);
+      hipExtLaunchKernelGGL(k_run_philox1, dim3(h->run_grid), dim3(WAVE), offsetof(EnvState, hd), h->stream, e0, e1, 0, a, ra, x);
+    }
     HIPCHK(h, hipGetLastError());
     h->stat_launch_us += std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - c0).count();
     h->stat_steps += k;
-    h->full_obs_next = false;     // (asked for, the first item of every episode rewrote all its observation values)
+    h->full_obs_next = false;     // (asked for, the first step of every episode rewrote all its observation values)
     h->main_ahead = h->ngroups > 1;
+    if (exchange) {
+      auto g0 = std::chrono::steady_clock::now();
+      if (xchg_enqueue(h, k, x)) return -1;
+      h->stat_gather_us += std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - g0).count();
+    }
     HIPCHK(h, hipStreamSynchronize(h->stream));
+    if (exchange && xchg_end(h, k)) return -1;
     if (ms_step_kernels) HIPCHK(h, hipEventElapsedTime(ms_step_kernels, h->evs[0], h->evs[1]));
     return 0;
   }
@@ -2785,9 +2955,54 @@ int cc4_comm_init(cc4_handle* h, int32_t rank, int32_t world, const void* id128)
     for (int g = 0; g < h->ngroups; ++g) HIPCHK(h, hipEventCreateWithFlags(&h->ev_step[b][g], hipEventDisableTiming));
     HIPCHK(h, hipEventCreateWithFlags(&h->ev_comm[b], hipEventDisableTiming));
   }
+  // the ring of step slabs the one-launch kernels write (XchgArgs) and its gathered twin
+  HIPCHK(h, hipMalloc(&h->d_xslab, nb * cc4_handle::XRING));
+  HIPCHK(h, hipMalloc(&h->d_xall, nb * (size_t)world * cc4_handle::XRING));
+  HIPCHK(h, hipEventCreateWithFlags(&h->xev, hipEventDisableTiming));
+  int can_wait = 0;
+  (void)hipDeviceGetAttribute(&can_wait, hipDeviceAttributeCanUseStreamWaitValue, h->cfg.device_id);
+  h->xchg_on = can_wait != 0;
+  if (const char* v = getenv("CC4_EXCHANGE_INKERNEL")) h->xchg_on = h->xchg_on && atoi(v) != 0;
+  if (const char* v = getenv("CC4_EXCHANGE_CHUNK")) { h->xchg_chunk = atoi(v); if (h->xchg_chunk < 1) h->xchg_chunk = 1; if (h->xchg_chunk > cc4_handle::XRING / 2) h->xchg_chunk = cc4_handle::XRING / 2; }
+  if (const char* v = getenv("CC4_EXCHANGE_WATCHDOG_MS")) { h->xchg_watchdog_ms = atoi(v) > 0 ? atoi(v) : 2000; }
   HIPCHK(h, hipStreamSynchronize(h->stream));
   HIPCHK(h, hipStreamSynchronize(h->comm_stream));
+  // the one-launch forms again, now that a step of one episode waits for the slowest episode of sixteen steps earlier: the multi-step kernels
+  // must hold the whole batch with a block per CU to spare (at exactly full residency one block that is placed late stalls everybody until
+  // the watchdog: tools/micro/ring_protocol.hip), and with peers RCCL's kernels need that room on every form (the persistent kernel's waves
+  // pull items, so on one rank it keeps every slot)
+  if (h->xchg_on) { if (choose_run_form(h, 1, world > 1 ? 1 : 0)) return -1; }
   return 0;
+}
+// the in-kernel exchange of this handle: out[0] on (1) / off (0), out[1] ring depth in steps, out[2] steps per publish (CC4_EXCHANGE_CHUNK),
+// out[3] calls of cc4_run_random_steps it served, out[4] calls whose watchdog fired (the handle then returns to per-step launches)
+int cc4_exchange_info(cc4_handle* h, int32_t* out /* [5] */) {
+  out[0] = h->xchg_on ? 1 : 0; out[1] = cc4_handle::XRING; out[2] = h->xchg_chunk; out[3] = (int32_t)h->xchg_calls; out[4] = (int32_t)h->xchg_timeouts;
+  return 0;
+}
+// debug / test hook: keep the gathered rows of the next `steps` steps cc4_run_random_steps exchanges from inside a one-launch kernel
+// ([steps][world * N] packed rows, in step order), so that a test can check EVERY step's all-gather, not only the last of a burst.
+// steps = 0 frees the log.
+int cc4_debug_gather_log(cc4_handle* h, int32_t steps) {
+  if (!h->comm) { h->err = "cc4_debug_gather_log: cc4_comm_init was not called"; return -2; }
+  HIPCHK(h, hipSetDevice(h->cfg.device_id));
+  HIPCHK(h, hipStreamSynchronize(h->comm_stream));
+  if (h->d_xlog) { (void)hipFree(h->d_xlog); h->d_xlog = nullptr; }
+  h->xlog_cap = 0; h->xlog_n = 0;
+  if (steps > 0) {
+    HIPCHK(h, hipMalloc(&h->d_xlog, (size_t)steps * h->world * h->cfg.num_envs * OBS_PACKED));
+    h->xlog_cap = steps;
+  }
+  return 0;
+}
+// host copy of the log: out [count][world * N][CC4_OBS_PACKED_BYTES]; returns the number of steps logged so far (< 0: error)
+int cc4_get_gather_log(cc4_handle* h, uint8_t* out, int32_t first, int32_t count) {
+  if (!h->d_xlog || first < 0 || count < 0 || first + count > h->xlog_n) { h->err = "cc4_get_gather_log: no log, or the range was not logged"; return -2; }
+  HIPCHK(h, hipSetDevice(h->cfg.device_id));
+  HIPCHK(h, hipStreamSynchronize(h->comm_stream));
+  const size_t row = (size_t)h->world * h->cfg.num_envs * OBS_PACKED;
+  if (count) HIPCHK(h, hipMemcpy(out, h->d_xlog + (size_t)first * row, (size_t)count * row, hipMemcpyDeviceToHost));
+  return h->xlog_n;
 }
 // What a multi-GPU run needs to PROVE its scaling line: RCCL's own view of the communicator (how many ranks it spans, which one this
 // is, which device it is bound to) and the identity of the device this handle runs on.  out[0] ncclCommCount (1 without a
@@ -2830,6 +3045,7 @@ int cc4_allgather_obs(cc4_handle* h, uint8_t** d_all_obs8) {
   const long long q = ++h->gathers_issued;
   h->gather_seq[buf] = q;
   h->gather_buf = buf;
+  h->last_gathered = h->d_all_obs8[buf];
   HIPCHK(h, hipEventRecord(h->ev_comm[q % cc4_handle::OBS_RING], h->comm_stream));
   if (d_all_obs8) *d_all_obs8 = h->d_all_obs8[buf];
   return 0;
@@ -2853,12 +3069,12 @@ int cc4_allgather_wait(cc4_handle* h) {
 // host copy of the gathered observations of the most recent cc4_allgather_obs (tests / debugging)
 int cc4_get_allgathered_obs(cc4_handle* h, uint8_t* out /* [world*N][578] */) {
   if (!h->comm) { h->err = "cc4_get_allgathered_obs: cc4_comm_init was not called"; return -2; }
-  if (h->gather_buf < 0) { h->err = "cc4_get_allgathered_obs: no all-gather has been issued"; return -2; }
+  if (!h->last_gathered) { h->err = "cc4_get_allgathered_obs: no all-gather has been issued"; return -2; }
   HIPCHK(h, hipSetDevice(h->cfg.device_id));
   HIPCHK(h, hipStreamSynchronize(h->comm_stream));
   const size_t rows = (size_t)h->world * h->cfg.num_envs;
   std::vector<uint8_t> packed(rows * OBS_PACKED);
-  HIPCHK(h, hipMemcpy(packed.data(), h->d_all_obs8[h->gather_buf], packed.size(), hipMemcpyDeviceToHost));
+  HIPCHK(h, hipMemcpy(packed.data(), h->last_gathered, packed.size(), hipMemcpyDeviceToHost));
   for (size_t r = 0; r < rows; ++r)      // unpack to one byte per value for the host caller
     for (int i = 0; i < OBS_TOTAL; ++i) out[r * OBS_TOTAL + i] = (uint8_t)((packed[r * OBS_PACKED + (i >> 2)] >> (2 * (i & 3))) & 3u);
   return 0;
@@ -2869,11 +3085,11 @@ int cc4_get_allgathered_obs(cc4_handle* h, uint8_t* out /* [world*N][578] */) {
 // cc4_allgather_wait() (or after any later operation ordered behind ev_comm of that gather).
 int cc4_unpack_obs_device(cc4_handle* h, uint8_t** d_obs_u8) {
   if (!h->comm) { h->err = "cc4_unpack_obs_device: cc4_comm_init was not called"; return -2; }
-  if (h->gather_buf < 0) { h->err = "cc4_unpack_obs_device: no all-gather has been issued"; return -2; }
+  if (!h->last_gathered) { h->err = "cc4_unpack_obs_device: no all-gather has been issued"; return -2; }
   HIPCHK(h, hipSetDevice(h->cfg.device_id));
   const size_t rows = (size_t)h->world * h->cfg.num_envs;
   if (!h->d_unpacked) HIPCHK(h, hipMalloc(&h->d_unpacked, rows * OBS_TOTAL));
-  hipLaunchKernelGGL(k_unpack_obs, dim3((unsigned)rows), dim3(192), 0, h->comm_stream, h->d_all_obs8[h->gather_buf], h->d_unpacked, (int)rows);
+  hipLaunchKernelGGL(k_unpack_obs, dim3((unsigned)rows), dim3(192), 0, h->comm_stream, h->last_gathered, h->d_unpacked, (int)rows);
   HIPCHK(h, hipGetLastError());
   if (d_obs_u8) *d_obs_u8 = h->d_unpacked;
   return 0;

@@ -265,6 +265,30 @@ class CC4VecEnv:
         self._chk(self.lib.cc4_host_stats(self._h, out.ctypes.data_as(ctypes.c_void_p)), 'cc4_host_stats')
         return {'steps': int(out[0]), 'launch_us': float(out[1]), 'gather_us': float(out[2]), 'gathers': int(out[3]), 'gather_stalls': int(out[4])}
 
+    def exchange_info(self):
+        """cc4_exchange_info: the exchange inside the one-launch kernels (on / off, ring depth, steps per publish, calls served, watchdog firings)."""
+        out = np.zeros(5, np.int32)
+        self._chk(self.lib.cc4_exchange_info(self._h, out.ctypes.data_as(ctypes.c_void_p)), 'cc4_exchange_info')
+        return {'in_kernel': bool(out[0]), 'ring': int(out[1]), 'chunk': int(out[2]), 'calls': int(out[3]), 'watchdog_timeouts': int(out[4])}
+
+    def verify_stats(self):
+        """cc4_verify_stats (CC4_PERSIST_VERIFY=1): (one-launch calls checked against per-step launches, calls that disagreed)."""
+        out = (ctypes.c_int64 * 2)()
+        self._chk(self.lib.cc4_verify_stats(self._h, out), 'cc4_verify_stats')
+        return int(out[0]), int(out[1])
+
+    def gather_log(self, steps):
+        """cc4_debug_gather_log: keep the gathered rows of the next `steps` in-kernel-exchanged steps (0: free the log)."""
+        self._chk(self.lib.cc4_debug_gather_log(self._h, int(steps)), 'cc4_debug_gather_log')
+
+    def get_gather_log(self, world, first, count):
+        """[count, world * N, 148] packed rows of steps first .. first + count - 1 of the log (distributed.unpack_obs decodes them)."""
+        out = np.zeros((count, world * self.num_envs, 148), np.uint8)
+        rc = self.lib.cc4_get_gather_log(self._h, out.ctypes.data_as(ctypes.c_void_p), int(first), int(count))
+        if rc < 0:
+            self._chk(rc, 'cc4_get_gather_log')
+        return out
+
     def comm_info(self):
         """cc4_comm_info: RCCL's view of the communicator (ranks it spans, this rank, its device) + the identity of the handle's device."""
         out = np.zeros(8, np.int32)
@@ -307,6 +331,19 @@ class CC4VecEnv:
         self._chk(self.lib.cc4_run_random_steps(self._h, ctypes.c_uint64(seed0), ctypes.c_uint32(t0), int(k),
                                                 ctypes.byref(ms) if timed else None), 'cc4_run_random_steps')
         return float(ms.value)
+
+    def run_policy_steps(self, seed0, t0, k):
+        """A learner's loop without the learner: per step a kernel writes the [N, 5] action indices into the handle's device buffer
+        (cc4_random_actions_device -- k_random_actions standing in for a policy) and cc4_step_device consumes them; no host synchronisation,
+        every step's observations stay readable on the device (cc4_obs_device).  Same draws as run_random_steps."""
+        p = ctypes.c_void_p()
+        self._chk(self.lib.cc4_actions_device(self._h, ctypes.byref(p)), 'cc4_actions_device')
+        s0 = ctypes.c_uint64(seed0)
+        for i in range(int(k)):
+            rc = self.lib.cc4_random_actions_device(self._h, s0, ctypes.c_uint32(t0 + i)) or self.lib.cc4_step_device(self._h, p, None)
+            if rc:
+                self._chk(rc, 'cc4_step_device')
+        return 0.0
 
     def device_actions(self):
         """cc4_get_actions: host copy of the handle's device action buffer ([N, 5]; after run_random_steps: the indices the last

@@ -176,16 +176,17 @@ def test_full_batch_matches_oracle_every_step(rng_mode, philox_kernel):
     dev.close()
 
 
-@pytest.mark.parametrize('n,red_policy,blue_policy', [(8192, 0, 0), (4096, 0, 0), (8192, 2, 0), (8192, 3, 1)],
+@pytest.mark.parametrize('n,red_policy,blue_policy,T,steps', [(8192, 0, 0, 330, 150), (4096, 0, 0, 170, 75), (8192, 2, 0, 170, 75), (8192, 3, 1, 170, 75)],
                          ids=['8192-fsm', '4096-fsm', '8192-discovery', '8192-randomselect-builtinblue'])
-def test_bench_configuration_matches_oracle_every_step(n, red_policy, blue_policy):
+def test_bench_configuration_matches_oracle_every_step(n, red_policy, blue_policy, T, steps):
     """the configuration bench.py times -- counter mode, autoreset, the kernel cc4_create picks for the batch
     size with NO override (at 8192 episodes k_step_philox1 at its natural residency -- generation work area in HBM, host rows in
     L2 with atomics -- as three concurrent launches on three streams) -- against the oracle for ALL episodes at EVERY step (observations, rewards, dones, error flags)
     across two scenario regenerations, then the generator words and the packed state of every episode."""
     import os
     assert 'CC4_PHILOX_LEAN' not in os.environ and 'CC4_PHILOX_MINW' not in os.environ and 'CC4_GROUPS' not in os.environ
-    T, steps = 330, 150
+    # (two regenerations each; the headline configuration runs 150-step episodes, the variants 75-step ones: the suite's wall time is the
+    # oracle's, DESIGN 5)
     dev = _dev(n, steps=steps, rng_mode=1, autoreset=True, red_policy=red_policy, blue_policy=blue_policy)
     # three or four launches of the one-wave kernel per step (four where the runtime runs four streams side by side)
     assert dev.step_kernel == 'k_step_philox1' and dev.lib.cc4_launches_per_step(dev._h) in (3, 4)
@@ -222,7 +223,8 @@ def test_timed_bench_path_matches_oracle(n, kernel, run_kernel):
     packed state of all episodes."""
     import ctypes, os
     assert 'CC4_PHILOX_LEAN' not in os.environ and 'CC4_PHILOX_MINW' not in os.environ and 'CC4_GROUPS' not in os.environ
-    steps, seed0 = 150, 4242
+    steps, seed0 = (150, 4242) if n == 8192 else (90, 4242)
+    bursts = (1, 20, 137, 20, 1, 20) if n == 8192 else (1, 20, 57, 20, 1)
     dev = _dev(n, steps=steps, rng_mode=1, autoreset=True)
     # (1024 episodes = BASELINE configs[1]: the chip holds the batch at once, and the region is ONE launch of the multi-step kernel
     # k_run_philox, every block looping over the steps of its episode)
@@ -230,7 +232,7 @@ def test_timed_bench_path_matches_oracle(n, kernel, run_kernel):
     ora = OracleVecEnv(n, steps=steps, rng_mode=1, autoreset=True)
     assert np.array_equal(dev.reset(seeds=seed0), ora.reset_batch(seed0))
     t = 0
-    for K in (1, 20, 137, 20, 1, 20):
+    for K in bursts:
         dev.run_random_steps(seed0, t, K, timed=(K != 1))
         for k in range(K):
             a = random_actions(seed0, t + k, n)
@@ -252,19 +254,19 @@ def test_timed_bench_path_matches_oracle(n, kernel, run_kernel):
 @pytest.mark.parametrize('threads', ['0', '1'])
 def test_enqueue_threads_change_nothing(threads, monkeypatch):
     """cc4_run_random_steps with one enqueue thread per group stream (the default where the host has eight hardware threads)
-    and from the calling thread alone: bursts of 1 / 20 / 3 / 57 steps across a regeneration against the oracle, handles created and
+    and from the calling thread alone: bursts of 1 / 20 / 3 / 27 steps across a regeneration against the oracle, handles created and
     destroyed in a row (a worker pool is joined at cc4_destroy)."""
     monkeypatch.setenv('CC4_ENQ_THREADS', threads)
     monkeypatch.setenv('CC4_RUN1', '0')
     monkeypatch.setenv('CC4_PERSIST', '0')
-    n, steps, seed0 = 4096, 60, 99
-    for rep in range(3):
+    n, steps, seed0 = 4096, 40, 99
+    for rep in range(2):
         dev = _dev(n, steps=steps, rng_mode=1, autoreset=True)
         assert dev.launches_per_step in (3, 4) and dev.run_kernel == 'k_step_philox1'      # (CC4_RUN1=0 below: the per-step launches are what the threads serve)
         ora = OracleVecEnv(n, steps=steps, rng_mode=1, autoreset=True)
         assert np.array_equal(dev.reset(seeds=seed0 + rep), ora.reset_batch(seed0 + rep))
         t = 0
-        for K in (1, 20, 3, 57):
+        for K in (1, 20, 3, 27):
             dev.run_random_steps(seed0, t, K, timed=(K != 3))
             for k in range(K):
                 o = ora.step_batch(random_actions(seed0, t + k, n))
@@ -405,23 +407,35 @@ def test_rccl_allgather_world_size_one():
     dev.close()
 
 
-@pytest.mark.parametrize('n,groups', [(768, '3'), (512, '1')])
-def test_observation_ring_survives_a_slow_exchange(n, groups, monkeypatch):
-    """VERDICT r02 #8c: the step kernels write their packed observations into a ring of 8 buffers that overlapped all-gathers read;
-    a host-side guard keeps a launch from overwriting a buffer whose all-gather has not finished.  With cc4_debug_comm_delay_us
-    every all-gather is preceded by ~150 us of idling on the communication stream -- several steps' worth -- so the guard has to
-    wait again and again (cc4_host_stats counts it), and nothing may be lost: the gathered observations after every burst of
-    steps equal the oracle's, with one launch per step and with three (episode groups on three streams)."""
+def _pack(obs):
+    """[M, 578] values 0..2 -> [M, 148] bytes: value i in bits 2 * (i & 3) of byte i >> 2 (include/cc4.h CC4_OBS_PACKED_BYTES)."""
+    v = np.zeros((obs.shape[0], 592), np.uint8)
+    v[:, :578] = obs
+    v = v.reshape(obs.shape[0], 148, 4)
+    return (v[:, :, 0] | (v[:, :, 1] << 2) | (v[:, :, 2] << 4) | (v[:, :, 3] << 6)).astype(np.uint8)
+
+
+def _one_rank_comm(dev):
     import ctypes, os
     os.environ.setdefault('NCCL_SOCKET_IFNAME', 'lo')
-    monkeypatch.setenv('CC4_GROUPS', groups)
-    from cage_challenge_4_amd import distributed as D
-    dev = _dev(n, steps=120, rng_mode=1, autoreset=True); dev.reset(seeds=77)
-    assert dev.launches_per_step == int(groups)
     ident = (ctypes.c_uint8 * 128)()
     assert dev.lib.cc4_comm_unique_id(ident) == 0
     dev._chk(dev.lib.cc4_comm_init(dev._h, 0, 1, ident), 'cc4_comm_init')
-    assert dev.launches_per_step == int(groups)                 # CC4_GROUPS pins the grouping through cc4_comm_init
+
+
+@pytest.mark.parametrize('n,groups', [(768, '3')])
+def test_observation_ring_survives_a_slow_exchange(n, groups, monkeypatch):
+    """VERDICT r02 #8c, the per-step exchange (CC4_EXCHANGE_INKERNEL=0: what a handle falls back to): the step kernels write their packed
+    observations into a ring of 8 buffers that overlapped all-gathers read; a host-side guard keeps a launch from overwriting a buffer whose
+    all-gather has not finished.  With cc4_debug_comm_delay_us every all-gather is preceded by ~150 us of idling on the communication
+    stream -- several steps' worth -- so the guard has to wait again and again (cc4_host_stats counts it), and nothing may be lost."""
+    monkeypatch.setenv('CC4_GROUPS', groups)
+    monkeypatch.setenv('CC4_EXCHANGE_INKERNEL', '0')
+    from cage_challenge_4_amd import distributed as D
+    dev = _dev(n, steps=120, rng_mode=1, autoreset=True); dev.reset(seeds=77)
+    assert dev.launches_per_step == int(groups)
+    _one_rank_comm(dev)
+    assert dev.launches_per_step == int(groups) and not dev.exchange_info()['in_kernel']      # CC4_GROUPS pins the grouping through cc4_comm_init
     dev.reset(seeds=77)
     dev._chk(dev.lib.cc4_debug_comm_delay_us(dev._h, 150), 'cc4_debug_comm_delay_us')
     ora = OracleVecEnv(n, steps=120, rng_mode=1, autoreset=True); ora.reset_batch(77)
@@ -438,6 +452,121 @@ def test_observation_ring_survives_a_slow_exchange(n, groups, monkeypatch):
     assert st['gathers'] == t and st['gather_stalls'] >= 10, st      # the guard really had to wait for the slow exchange
     dev._chk(dev.lib.cc4_debug_comm_delay_us(dev._h, 0), 'cc4_debug_comm_delay_us')
     dev.close()
+
+
+@pytest.mark.parametrize('n,mode,run_kernel,delay_us', [(1024, 1, 'k_run_philox', 0), (1024, 1, 'k_run_philox', 150), (2048, 1, 'k_run_philox1m', 0),
+                                                        (8192, 1, 'k_run_philox1', 0), (5632, 1, 'k_run_philox1', 200), (5000, 0, 'k_run_pcg', 0)],
+                         ids=['1024', '1024-slow-exchange', '2048', '8192', '5632-slow-exchange', '5000-numpy-stream'])
+def test_exchange_from_inside_the_one_launch_kernels_gathers_every_step(n, mode, run_kernel, delay_us):
+    """with a communicator cc4_run_random_steps stays ONE launch -- step k writes its packed rows into slab k mod 16 of a
+    ring and counts finished episodes, the communication stream waits for the count (hipStreamWaitValue32), all-gathers the slab and
+    publishes how far it got (hipStreamWriteValue32), step k + 16 waits for that.  Checked here on a one-rank communicator: the gathered
+    rows of EVERY step (cc4_debug_gather_log), not only the last of a burst, equal the oracle's -- also with an exchange several times
+    slower than the steps, which makes the kernel wait for its slabs --, then observations, rewards, generator words and packed state."""
+    from cage_challenge_4_amd import distributed as D
+    steps, seed0 = 60, 2024
+    dev = _dev(n, steps=steps, rng_mode=mode, autoreset=True); dev.reset(seeds=seed0)
+    _one_rank_comm(dev)
+    xi = dev.exchange_info()
+    assert xi['in_kernel'] and xi['ring'] == 16 and dev.run_kernel_for(20) == run_kernel, (xi, dev.run_kernel_for(20))
+    dev.reset(seeds=seed0)
+    if delay_us:
+        dev._chk(dev.lib.cc4_debug_comm_delay_us(dev._h, delay_us), 'cc4_debug_comm_delay_us')
+    ora = OracleVecEnv(n, steps=steps, rng_mode=mode, autoreset=True); ora.reset_batch(seed0)
+    t = 0
+    for K in (20, 37, 20):                                                   # across a regeneration; bursts longer than the ring
+        dev.gather_log(K)
+        dev.run_random_steps(seed0, t, K, timed=True)
+        want = []
+        for k in range(K):
+            o = ora.step_batch(random_actions(seed0, t + k, n))
+            want.append(_pack(o[0].astype(np.uint8)))
+        got = dev.get_gather_log(1, 0, K)
+        for k in range(K):
+            bad = np.nonzero((got[k] != want[k]).any(axis=1))[0]
+            assert bad.size == 0, (K, t + k, bad[:10].tolist())
+        t += K
+        dev._fetch()
+        assert np.array_equal(dev._obs, o[0]) and np.array_equal(dev._rew, o[1]) and np.array_equal(dev._err, o[3]['err']), K
+        assert np.array_equal(D.allgathered_obs_host(dev, 1), o[0].astype(np.uint8)), K
+    xi = dev.exchange_info()
+    assert xi['calls'] == 3 and xi['watchdog_timeouts'] == 0 and xi['in_kernel'], xi
+    # a per-step launch with the caller's actions and an explicit all-gather behind the one-launch calls
+    a = random_actions(seed0 + 1, t, n)
+    d = dev.step(a); o = ora.step_batch(a)
+    assert np.array_equal(d[0], o[0]) and np.array_equal(d[1], o[1])
+    assert D.allgather_obs_device(dev); D.allgather_wait(dev)
+    assert np.array_equal(D.allgathered_obs_host(dev, 1), o[0].astype(np.uint8))
+    assert np.array_equal(dev.rng_state(), ora.rng_state())
+    for i in range(0, n, 5):
+        assert np.array_equal(dev.get_state(i), ora.get_state(i)), i
+    dev.close(); ora.close()
+
+
+def test_exchange_watchdog_returns_the_handle_to_per_step_launches(monkeypatch):
+    """An exchange that never catches up -- every all-gather held back by 30 ms, watchdog 5 ms -- must not hang the one-launch kernel: the
+    waiting step gives up, the call completes with every episode intact, stderr says so, and the handle runs per-step launches from then on."""
+    monkeypatch.setenv('CC4_EXCHANGE_WATCHDOG_MS', '5')
+    from cage_challenge_4_amd import distributed as D
+    n, seed0 = 512, 7
+    dev = _dev(n, steps=200, rng_mode=1, autoreset=True); dev.reset(seeds=seed0)
+    _one_rank_comm(dev); dev.reset(seeds=seed0)
+    assert dev.exchange_info()['in_kernel'] and dev.run_kernel_for(40) == 'k_run_philox'
+    dev._chk(dev.lib.cc4_debug_comm_delay_us(dev._h, 30000), 'cc4_debug_comm_delay_us')
+    ora = OracleVecEnv(n, steps=200, rng_mode=1, autoreset=True); ora.reset_batch(seed0)
+    dev.run_random_steps(seed0, 0, 40, timed=False)
+    for k in range(40):
+        o = ora.step_batch(random_actions(seed0, k, n))
+    dev._fetch()
+    assert np.array_equal(dev._obs, o[0]) and np.array_equal(dev._rew, o[1])            # the episodes never depended on the exchange
+    xi = dev.exchange_info()
+    assert xi['watchdog_timeouts'] == 1 and not xi['in_kernel'] and dev.run_kernel_for(40) == dev.step_kernel, xi
+    dev._chk(dev.lib.cc4_debug_comm_delay_us(dev._h, 0), 'cc4_debug_comm_delay_us')
+    dev.run_random_steps(seed0, 40, 5, timed=False)                                      # per-step launches + per-step all-gathers now
+    for k in range(40, 45):
+        o = ora.step_batch(random_actions(seed0, k, n))
+    dev._fetch()
+    assert np.array_equal(dev._obs, o[0]) and np.array_equal(D.allgathered_obs_host(dev, 1), o[0].astype(np.uint8))
+    dev.close(); ora.close()
+
+
+@pytest.mark.parametrize('n', [8192, 5632])
+def test_persistent_kernel_self_check_mode(n, monkeypatch):
+    """CC4_PERSIST_VERIFY=1: the persistent kernel hands an episode from one wave to the next of the same CU with
+    workgroup-scope ordering only (agent-scope ordering costs 40 % -- profiles/r05_persist_order_ab.txt); in this mode the library
+    repeats every one-launch call with per-step launches on a shadow handle and compares hot rows, cold rows and outputs of all episodes.
+    5632 episodes: partitions of 22 for 20 waves -- every call ends in a tail shared across the CUs of an XCD."""
+    monkeypatch.setenv('CC4_PERSIST_VERIFY', '1')
+    dev = _dev(n, steps=100, rng_mode=1, autoreset=True, strict=False); dev.reset(seeds=99)
+    assert dev.run_kernel_for(20) == 'k_run_philox1'
+    t = 0
+    for K in (20, 10, 37, 20, 64):
+        dev.run_random_steps(99, t, K, timed=(K == 20)); t += K
+    assert dev.verify_stats() == (5, 0)
+    dev.run_random_steps(99, t, 5, timed=False)                                           # too short for the one-launch form: nothing to verify
+    assert dev.verify_stats() == (5, 0)
+    dev.close()
+
+
+def test_two_real_ranks_gather_the_unsharded_batch(tmp_path):
+    """Two processes on two devices, a real two-rank RCCL communicator (the first time two GPUs are visible: the 1-GPU boxes of the pool
+    skip): every step's gathered rows == the oracle's unsharded batch, from inside the one-launch kernel and from per-step launches;
+    cc4_comm_info reports two ranks on two devices."""
+    import os, subprocess, sys
+    from cage_challenge_4_amd import _lib
+    if int(_lib.load().cc4_device_count()) < 2:
+        pytest.skip('needs two GPUs')
+    from conftest import ROOT
+    worker = os.path.join(ROOT, 'tests', '_rccl_worker.py')
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE='2', MASTER_ADDR='127.0.0.1', MASTER_PORT='29611', NCCL_SOCKET_IFNAME='lo',
+                   HSA_ENABLE_IPC_MODE_LEGACY='0', CC4_CONTROL_PLANE_KEY=f'rccl2_{os.getpid()}', CC4_CONTROL_PLANE_DIR=str(tmp_path))
+        env.pop('CC4_EXCHANGE_INKERNEL', None)
+        procs.append(subprocess.Popen([sys.executable, worker], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env))
+    outs = [p.communicate(timeout=1500) for p in procs]
+    assert all(p.returncode == 0 for p in procs), '\n'.join(o[0][-2500:] + o[1][-2500:] for o in outs)
+    assert 'RCCL_OK 2' in outs[0][0]
 
 
 def test_snapshot_restore_replays_identically(philox_kernel):

@@ -3,6 +3,7 @@
 usage: rocpd_summary.py stats <dir-with-db> <out.txt>
        rocpd_summary.py pmc <fetch-dir> <write-dir> <kernel-substr> <out.json> [launch_envs]
        rocpd_summary.py pmc_step <fetch-dir> <write-dir> <exact-kernel-name> <out.json> <envs> <launches-per-step>   (merges into out.json)
+       rocpd_summary.py pmc_run <fetch-dir> <write-dir> <exact-kernel-name> <out.json> <envs> <steps-per-launch>     (one-launch kernels; merges)
        rocpd_summary.py counters <kernel-substr> <out.json> <dir> [<dir> ...]   (per-launch averages of every counter found)"""
 import glob
 import json
@@ -74,6 +75,31 @@ def pmc_step(fd, wd, kern, out, envs, lps):
     print(json.dumps({k: v for k, v in res.items() if str(envs) in k}, indent=1))
 
 
+def pmc_run(fd, wd, kern, out, envs, spl):
+    """r05 form, the one-launch kernels profiled as what they are: one launch = `spl` steps of the whole batch, so HBM bytes per STEP =
+    bytes of the launch / spl.  Only the launches of exactly `kern` count (k_run_philox1 is not k_run_philox1m).  Merges into `out`."""
+    import os
+    res = json.load(open(out)) if os.path.exists(out) else {}
+    per = {}
+    kname = None
+    for name, d in (('FETCH_SIZE', fd), ('WRITE_SIZE', wd)):
+        con = db(d)
+        r = list(con.execute("select count(*), avg(value), min(value), max(value), min(kernel_name) from counters_collection "
+                             "where counter_name=? and (kernel_name like ? or kernel_name = ?)", (name, f'%{kern}(%', kern)))[0]
+        per[name] = {'launches': r[0], 'avg_KB': r[1], 'min_KB': r[2], 'max_KB': r[3]}
+        kname = r[4]
+    hbm = (2.0 * per['FETCH_SIZE']['avg_KB'] + per['WRITE_SIZE']['avg_KB']) * 1024.0
+    res['correction'] = 'hbm_bytes = (2*FETCH_SIZE + WRITE_SIZE) * 1024 (MI355X_MICROARCH.md: FETCH_SIZE is halved on gfx950 for 16-B coalesced reads; WRITE_SIZE calibrated on a known-size memset)'
+    res[f'{envs}env'] = per
+    res[f'hbm_bytes_per_launch_{envs}env'] = hbm
+    res[f'steps_per_launch_{envs}env'] = spl
+    res[f'hbm_bytes_per_step_{envs}env'] = hbm / spl
+    res[f'kernel_{envs}env'] = kern
+    res[f'kernel_symbol_{envs}env'] = kname
+    json.dump(res, open(out, 'w'), indent=1)
+    print(json.dumps({k: v for k, v in res.items() if str(envs) in k}, indent=1))
+
+
 def counters(kern, out, dirs):
     res = {}
     for d in dirs:
@@ -87,6 +113,8 @@ def counters(kern, out, dirs):
 
 
 if __name__ == '__main__':
+    if sys.argv[1] == 'pmc_run':
+        pmc_run(sys.argv[2], sys.argv[3], sys.argv[4], sys.argv[5], int(sys.argv[6]), int(sys.argv[7]))
     if sys.argv[1] == 'pmc_step':
         pmc_step(sys.argv[2], sys.argv[3], sys.argv[4], sys.argv[5], int(sys.argv[6]), int(sys.argv[7]))
     elif sys.argv[1] == 'counters':
