@@ -252,9 +252,18 @@ def exchange_world1(make_env, measure, D, args, lo, timeout_s=90.0):
             box['ok'] = True
         except Exception as ex:      # noqa: BLE001
             box['err'] = repr(ex)
+    # RCCL prints its banner on fd 1 from C++ (lazily, and flushes it when the process exits): stdout is for the one JSON line
+    import ctypes
+    sys.stdout.flush()
+    saved_fd = os.dup(1)
+    os.dup2(2, 1)
     th = threading.Thread(target=leg, daemon=True)
     th.start()
     th.join(timeout_s)
+    ctypes.CDLL(None).fflush(None)
+    sys.stdout.flush()
+    os.dup2(saved_fd, 1)
+    os.close(saved_fd)
     if not box.get('ok'):
         out['skipped'] = box.get('err') or f'RCCL setup did not finish within {timeout_s:.0f} s on this box (library paging in)'
         out['_stalled'] = th.is_alive()
@@ -425,7 +434,12 @@ def main():
             r5 = measure(e5, lo, total_envs, runner=lambda t0, k, timed: e5.run_policy_steps(args.seed0 + lo, t0, k), min_seconds=min(args.min_seconds, 0.2))
             r5.update({'unit': 'agent-env steps/s', 'kernel': e5.step_kernel, 'run_kernel': e5.step_kernel, 'launches_per_step': e5.launches_per_step + 1,
                        'note': 'per step: k_random_actions -> the handle\'s device action buffer, then cc4_step_device (the per-step launches of the step kernel); '
-                               'the consumable rate -- a policy can read every step\'s observations and write the next actions on the device'})
+                               'a policy over the WHOLE batch is a barrier across the episode groups at every step; `grouped` is the same policy applied per group'})
+            r6 = measure(e5, lo, total_envs, runner=lambda t0, k, timed: e5.run_policy_steps_grouped(args.seed0 + lo, t0, k), min_seconds=min(args.min_seconds, 0.2))
+            r6.update({'unit': 'agent-env steps/s', 'kernel': e5.step_kernel, 'run_kernel': e5.step_kernel,
+                       'note': 'the same with the policy applied per episode group on the group\'s own stream (cc4_group_info / cc4_step_group_device): a policy is '
+                               'batch-independent, so nothing orders the groups against each other and their launches keep overlapping across steps'})
+            r5['grouped'] = r6
             e5.close()
             subs['policy_in_loop'] = r5
             subs['exchange_world1'] = exchange_world1(make_env, measure, D, args, lo)
@@ -464,7 +478,7 @@ def main():
                             f'EnterpriseScenarioGenerator(steps={args.episode_steps}), autoreset incl. scenario regeneration, topology randomised per episode and reset',
                 'envs_per_gpu': n_local, 'total_envs': total_envs, 'rng': args.rng,
                 'exchange': exchange_note or (('RCCL all-gather of the observations of every step (2 bits per value, 148 B per episode) on a second stream, '
-                                               + ('issued behind the per-step counters of the one-launch kernel (a ring of 16 step slabs; include/cc4.h cc4_exchange_info)'
+                                               + ('issued behind the per-step counters of the one-launch kernel (a ring of 32 step slabs, gathered in chunks of 8; include/cc4.h cc4_exchange_info)'
                                                   if xinfo.get('in_kernel') else 'overlapped with the next step\'s launch')) if dist_on else 'none'),
                 'exchange_info': xinfo if dist_on else None,
                 'env_steps_per_sec': main_res['value'] / 5.0, 'engine_error_flags': err_any,

@@ -70,6 +70,9 @@ SIGNATURES = {
     'cc4_synchronize': (ctypes.c_int, [_P]),
     'cc4_run_random_steps': (ctypes.c_int, [_P, ctypes.c_uint64, ctypes.c_uint32, ctypes.c_int32, ctypes.POINTER(ctypes.c_float)]),
     'cc4_launches_per_step': (ctypes.c_int, [_P]),
+    'cc4_group_info': (ctypes.c_int, [_P, ctypes.c_int32, _P, _P, _P]),
+    'cc4_step_group_device': (ctypes.c_int, [_P, ctypes.c_int32, _P, _P]),
+    'cc4_random_actions_group_device': (ctypes.c_int, [_P, ctypes.c_int32, ctypes.c_uint64, ctypes.c_uint32]),
     'cc4_debug_comm_delay_us': (ctypes.c_int, [_P, ctypes.c_int]),
     'cc4_host_stats': (ctypes.c_int, [_P, _P]),
     'cc4_verify_stats': (ctypes.c_int, [_P, _P]),

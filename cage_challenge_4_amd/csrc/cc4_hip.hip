@@ -1117,8 +1117,12 @@ __global__ __launch_bounds__(WAVE) void k_census(int32_t* count, long long ticks
   extern __shared__ uint4 lds[];
   if (threadIdx.x == 0) {
     atomicAdd(&count[cu_slot()], 1);
+    const int arrived_at = CC4_SLOTS;                                       // count[CC4_SLOTS]: waves that have reported
+    atomicAdd(&count[arrived_at], 1);
+    // stay resident until the WHOLE grid is (every wave has reported), or for `ticks` if it never is -- then late waves land on CUs that
+    // early ones have left, a CU shows more waves than fit, and the census says so
     const long long t0 = wall_clock64();
-    while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(32);     // stay resident until the whole grid has been placed
+    while (__hip_atomic_load(&count[arrived_at], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (int)gridDim.x && wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(32);
   }
   if (threadIdx.x == 1) reinterpret_cast<volatile uint32_t*>(lds)[0] = 0;
 }
@@ -1369,7 +1373,9 @@ __global__ __launch_bounds__(WAVE, CC4_LEAN_MINW) void k_step_philox1(StepArgs a
 constexpr uint32_t TK_SHARED = 0x80000000u;
 template <bool PCG>
 __device__ __forceinline__ void persist_loop(StepArgs a, RunArgs ra, const XchgArgs x) {
-  __shared__ int item_lds[4];
+  // (the item travels from lane 0 to the wave through v_readfirstlane, not through LDS: with 16 bytes more of static LDS the wave's
+  // footprint is 8192 B, and twenty of those do NOT fit a CU's 160 KB beside what the hardware keeps for itself -- the census then sees
+  // waves doubling up and the path stays off; 8176 B, the footprint of k_step_philox1, does)
   const int lane = threadIdx.x;
   const int my_slot = cu_slot();
   int part = ra.slot_part[my_slot];      // (lane 0's copy is the one that counts)
@@ -1377,8 +1383,8 @@ __device__ __forceinline__ void persist_loop(StepArgs a, RunArgs ra, const XchgA
   bool stealing = false;                 // lane 0: `part` belongs to another CU of this XCD; its shared bit is set
   a.prof = nullptr; a.obs8 = nullptr; a.ext = nullptr;
   for (;;) {
+    int res_e = -3, res_k = 0, res_sh = 0, res_part = -1;            // -3: nothing from `part`: search
     if (lane == 0) {
-      int res_e = -3, res_k = 0, res_sh = 0;                         // -3: nothing from `part`: search
       if (part >= 0 && !mine && !stealing) {
         int exp = 0;                                                  // the CU's own partition: claim it (or find it claimed by this CU already)
         mine = __hip_atomic_compare_exchange_strong(&ra.owner[part], &exp, my_slot + 1, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) || exp == my_slot + 1;
@@ -1397,14 +1403,12 @@ __device__ __forceinline__ void persist_loop(StepArgs a, RunArgs ra, const XchgA
           res_e = ee; res_k = k; res_sh = (thief || (tr & TK_SHARED)) ? 1 : 0;
         }
       }
-      item_lds[0] = res_e; item_lds[1] = res_k; item_lds[2] = res_sh; item_lds[3] = part;
+      res_part = part;
     }
-    __syncthreads();
-    const int e = __builtin_amdgcn_readfirstlane(item_lds[0]);
+    const int e = __builtin_amdgcn_readfirstlane(res_e);              // (all lanes are active here: the first active lane is lane 0)
     if (e == -3) {
       // search (all lanes): the partition with the most items left among those nobody owns and those owned by a CU of this XCD
-      const int cur = __builtin_amdgcn_readfirstlane(item_lds[3]);
-      __syncthreads();
+      const int cur = __builtin_amdgcn_readfirstlane(res_part);
       int best_rem = 0, best_q = -1, best_ow = 0;
       for (int q0 = 0; q0 < ra.P; q0 += WAVE) {
         const int q = q0 + lane;
@@ -1436,9 +1440,8 @@ __device__ __forceinline__ void persist_loop(StepArgs a, RunArgs ra, const XchgA
       }
       continue;
     }
-    const uint32_t item_k = (uint32_t)__builtin_amdgcn_readfirstlane(item_lds[1]);
-    const int shared = __builtin_amdgcn_readfirstlane(item_lds[2]);
-    __syncthreads();
+    const uint32_t item_k = (uint32_t)__builtin_amdgcn_readfirstlane(res_k);
+    const int shared = __builtin_amdgcn_readfirstlane(res_sh);
     if (shared || ra.order >= 1) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
     int lane_i = (int)threadIdx.x;
     asm volatile("" : "+v"(lane_i));
@@ -1551,8 +1554,8 @@ __global__ __launch_bounds__(WAVE) void k_reset(ResetArgs a) {
 
 // uniform blue action indices over each agent's full range: Philox key (seed0, env),
 // counter (t, agent, 0xB10E, 0)
-__global__ void k_random_actions(int32_t* actions, int n, uint64_t seed0, uint32_t t) {
-  int i = blockIdx.x * blockDim.x + threadIdx.x;
+__global__ void k_random_actions(int32_t* actions, int n, uint64_t seed0, uint32_t t, int e0 = 0) {      // episodes e0 .. n - 1
+  int i = e0 * NBLUE + blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n * NBLUE) return;
   int e = i / NBLUE, b = i % NBLUE;
   actions[i] = random_blue_action(seed0, t, e, b);
@@ -1699,9 +1702,10 @@ struct cc4_handle {
   int run_margin = 0;             // episode blocks per CU the one-launch forms leave free (choose_run_form)
   // the per-step hand-off out of the one-launch kernels (XchgArgs): with a communicator, cc4_run_random_steps stays ONE launch and the
   // communication stream follows the kernel's per-step counters (xchg_*)
-  static constexpr int XRING = 16;
+  static constexpr int XRING = 32;
   bool xchg_on = false;           // cc4_comm_init; CC4_EXCHANGE_INKERNEL=0 keeps the per-step launches
-  int xchg_chunk = 1;             // steps per wait / publish on the communication stream (CC4_EXCHANGE_CHUNK; their all-gathers go out as one RCCL group)
+  int xchg_chunk = 8;             // steps per wait / publish on the communication stream (CC4_EXCHANGE_CHUNK; their all-gathers go out as ONE RCCL group: the host
+                                  // pays ~25 us to enqueue a wait, an all-gather and a publish -- more than a step of a small batch lasts)
   uint8_t* d_xslab = nullptr;     // [XRING][n][OBS_PACKED]
   uint8_t* d_xall = nullptr;      // [XRING][world * n][OBS_PACKED]
   uint32_t* d_xflags = nullptr;   // [0] gathered, [1] timeout, [2 ..] done[k]
@@ -1730,6 +1734,7 @@ struct cc4_handle {
   bool ext_seen = false, ext_dirty = false;   // dirty: d_ext holds the records of an earlier step
   std::vector<ExtAct> h_ext;
   bool full_obs_next = true;      // the next step launch rewrites every observation value (fresh handle, restored state)
+  uint32_t full_obs_gmask = 0;    // ... per group, for the group-wise launches of cc4_step_group_device
   bool philox_lean = false;       // k_step_philox1 (one wave per episode) instead of k_step_philox (cc4_create)
   int philox_minw = 1;            // which register budget of k_step_philox this batch size runs (1, 7 or 8 blocks per CU; cc4_create)
   ncclComm_t comm = nullptr; int rank = 0, world = 1;
@@ -1843,7 +1848,7 @@ static void launch_group(cc4_handle* h, StepArgs a, int g, bool full, hipEvent_t
   a.e0 = h->glo[g]; a.n = h->glo[g + 1];
   const dim3 grid(a.n - a.e0);
   hipStream_t st = h->gstream[g];
-#ifdef CC4_DEV_FAST     // kernel experiments (tools/ab.sh): only the one-wave counter-mode kernel is instantiated -- a quarter of the compile time
+#ifdef CC4_DEV_FAST     // kernel experiments (tools/ab/ab.sh): only the one-wave counter-mode kernel is instantiated -- a quarter of the compile time
   if (h->philox_lean) hipExtLaunchKernelGGL(k_step_philox1<false>, grid, dim3(WAVE), offsetof(EnvState, hd), st, start, stop, 0, a);
   else hipExtLaunchKernelGGL((k_step_philox<false, 1>), grid, dim3(PT), sizeof(EnvState), st, start, stop, 0, a);
 #else
@@ -2367,6 +2372,55 @@ int cc4_step_device(cc4_handle* h, const int32_t* d_actions, const uint8_t* d_me
   return launch_step(h, d_actions, d_messages);
 }
 
+// ---- group-wise stepping for a policy that lives on the GPU.  A step of a large batch is one launch per episode group, each group on its
+// own stream, and the groups never wait for each other -- unless the caller's policy makes them: a policy kernel over the WHOLE batch
+// between two steps is a barrier across the groups (cc4_step_device behind it: bench.py `policy_in_loop`).  A policy is batch-independent,
+// though: applied per group, on the group's own stream, it keeps the groups' pipelines apart.  cc4_group_info says which episodes a group
+// holds and which stream its launches run on (the caller enqueues its policy kernel for those episodes there); cc4_step_group_device
+// launches that group's step behind it.  Without a communicator, event log or submitted red / green actions.
+int cc4_group_info(cc4_handle* h, int32_t g, int32_t* lo, int32_t* hi, void** hip_stream) {
+  if (g < 0 || g >= h->ngroups) { h->err = "cc4_group_info: no such group"; return -2; }
+  if (lo) *lo = h->glo[g];
+  if (hi) *hi = h->glo[g + 1];
+  if (hip_stream) *hip_stream = reinterpret_cast<void*>(h->gstream[g]);
+  return 0;
+}
+static int group_prologue(cc4_handle* h, int32_t g, const char* who) {
+  if (g < 0 || g >= h->ngroups) { h->err = std::string(who) + ": no such group"; return -2; }
+  if (h->comm || h->evlog_on || h->ext_seen) { h->err = std::string(who) + ": group-wise stepping serves handles without a communicator, event log or submitted red / green actions"; return -2; }
+  HIPCHK(h, hipSetDevice(h->cfg.device_id));
+  if (h->ngroups > 1 && h->main_ahead) {     // e.g. a reset or an upload on the main stream: the group streams start behind it
+    HIPCHK(h, hipEventRecord(h->mev, h->stream));
+    for (int q = 1; q < h->ngroups; ++q) HIPCHK(h, hipStreamWaitEvent(h->gstream[q], h->mev, 0));
+    h->main_ahead = false;
+  }
+  return 0;
+}
+int cc4_step_group_device(cc4_handle* h, int32_t g, const int32_t* d_actions, const uint8_t* d_messages) {
+  if (int rc = group_prologue(h, g, "cc4_step_group_device")) return rc;
+  if (h->full_obs_next) { h->full_obs_gmask = (1u << h->ngroups) - 1u; h->full_obs_next = false; }
+  const bool full_obs = (h->full_obs_gmask >> g) & 1u;
+  h->full_obs_gmask &= ~(1u << g);
+  StepArgs a{h->d_state, h->d_cold, d_actions, d_messages, h->d_obs, h->d_reward, h->d_done, h->d_err, nullptr, nullptr, 0, 0,
+             h->cfg.num_envs, h->cfg.autoreset, h->cfg.steps, h->cfg.rng_mode,
+             (h->cfg.red_policy & 3) | (h->cfg.green_policy ? GP_SLEEP_BIT : 0) | (h->cfg.green_policy == 2 ? GP_OPEN_BIT : 0) | (h->cfg.blue_policy ? BP_RANDOM_BIT : 0), full_obs ? 1 : 0,
+             (uint32_t)h->cfg.topology_seed, h->d_prof, h->d_reset_ws, nullptr, 0};
+  launch_group(h, a, g, false, nullptr, nullptr);
+  HIPCHK(h, hipGetLastError());
+  if (h->ngroups > 1) h->groups_busy = true;
+  return 0;
+}
+// the stand-in policy of bench.py for one group: uniform random action indices for the group's episodes into the handle's device action
+// buffer, on the group's stream (what a policy network's kernel would do there)
+int cc4_random_actions_group_device(cc4_handle* h, int32_t g, uint64_t seed0, uint32_t t) {
+  if (int rc = group_prologue(h, g, "cc4_random_actions_group_device")) return rc;
+  const int tot = (h->glo[g + 1] - h->glo[g]) * NBLUE;
+  hipLaunchKernelGGL(k_random_actions, dim3((tot + 255) / 256), dim3(256), 0, h->gstream[g], h->d_actions, h->glo[g + 1], seed0, t, h->glo[g]);
+  HIPCHK(h, hipGetLastError());
+  if (h->ngroups > 1) h->groups_busy = true;
+  return 0;
+}
+
 int cc4_get_obs(cc4_handle* h, int32_t* obs) {
   HIPCHK(h, hipSetDevice(h->cfg.device_id));
   if (join_groups(h)) return -1;
@@ -2446,7 +2500,7 @@ int cc4_random_actions_device(cc4_handle* h, uint64_t seed0, uint32_t t) {
   HIPCHK(h, hipSetDevice(h->cfg.device_id));
   if (join_groups(h)) return -1;
   int tot = h->cfg.num_envs * NBLUE;
-  hipLaunchKernelGGL(k_random_actions, dim3((tot + 255) / 256), dim3(256), 0, h->stream, h->d_actions, h->cfg.num_envs, seed0, t);
+  hipLaunchKernelGGL(k_random_actions, dim3((tot + 255) / 256), dim3(256), 0, h->stream, h->d_actions, h->cfg.num_envs, seed0, t, 0);
   HIPCHK(h, hipGetLastError());
   return 0;
 }
@@ -2478,11 +2532,11 @@ static int persist_setup(cc4_handle* h) {
   HIPCHK(h, hipFuncGetAttributes(&fa_cen, reinterpret_cast<const void*>(k_census)));
   const size_t census_lds = offsetof(EnvState, hd) + (fa_run.sharedSizeBytes > fa_cen.sharedSizeBytes ? fa_run.sharedSizeBytes - fa_cen.sharedSizeBytes : 0);
   int32_t* d_count = nullptr;
-  HIPCHK(h, hipMalloc(&d_count, CC4_SLOTS * sizeof(int32_t)));
-  HIPCHK(h, hipMemsetAsync(d_count, 0, CC4_SLOTS * sizeof(int32_t), h->stream));
+  HIPCHK(h, hipMalloc(&d_count, (CC4_SLOTS + 1) * sizeof(int32_t)));
+  HIPCHK(h, hipMemsetAsync(d_count, 0, (CC4_SLOTS + 1) * sizeof(int32_t), h->stream));
   int khz = 100000;
   (void)hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, h->cfg.device_id);
-  hipLaunchKernelGGL(k_census, dim3(grid), dim3(WAVE), census_lds, h->stream, d_count, 200LL * (khz > 0 ? khz : 100000) / 1000);   // ~200 us
+  hipLaunchKernelGGL(k_census, dim3(grid), dim3(WAVE), census_lds, h->stream, d_count, 5000LL * (khz > 0 ? khz : 100000) / 1000);   // at most ~5 ms
   std::vector<int32_t> count(CC4_SLOTS);
   HIPCHK(h, hipMemcpyAsync(count.data(), d_count, CC4_SLOTS * sizeof(int32_t), hipMemcpyDeviceToHost, h->stream));
   HIPCHK(h, hipStreamSynchronize(h->stream));

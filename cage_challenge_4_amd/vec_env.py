@@ -345,6 +345,20 @@ class CC4VecEnv:
                 self._chk(rc, 'cc4_step_device')
         return 0.0
 
+    def run_policy_steps_grouped(self, seed0, t0, k):
+        """The same loop with the policy applied per episode group on the group's own stream (cc4_group_info /
+        cc4_random_actions_group_device / cc4_step_group_device): no cross-stream dependency, the groups' pipelines stay apart."""
+        p = ctypes.c_void_p()
+        self._chk(self.lib.cc4_actions_device(self._h, ctypes.byref(p)), 'cc4_actions_device')
+        s0 = ctypes.c_uint64(seed0)
+        groups = range(self.launches_per_step)
+        for i in range(int(k)):
+            for g in groups:
+                rc = self.lib.cc4_random_actions_group_device(self._h, g, s0, ctypes.c_uint32(t0 + i)) or self.lib.cc4_step_group_device(self._h, g, p, None)
+                if rc:
+                    self._chk(rc, 'cc4_step_group_device')
+        return 0.0
+
     def device_actions(self):
         """cc4_get_actions: host copy of the handle's device action buffer ([N, 5]; after run_random_steps: the indices the last
         step drew in-kernel)."""

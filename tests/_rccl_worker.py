@@ -48,7 +48,7 @@ def main():
                 dev.restore(i, snap[i])
             D.init_rccl(dev, rank, world, plane)
         assert dev.exchange_info()['in_kernel'] == inkernel
-        for K in (20, 33, 12):
+        for K in (20, 41, 12):
             if inkernel:
                 dev.gather_log(K)
             # the action key is seed0 + the shard's first global episode: episode e of the batch draws from key seed0 + e on any sharding

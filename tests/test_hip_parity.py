@@ -454,27 +454,27 @@ def test_observation_ring_survives_a_slow_exchange(n, groups, monkeypatch):
     dev.close()
 
 
-@pytest.mark.parametrize('n,mode,run_kernel,delay_us', [(1024, 1, 'k_run_philox', 0), (1024, 1, 'k_run_philox', 150), (2048, 1, 'k_run_philox1m', 0),
-                                                        (8192, 1, 'k_run_philox1', 0), (5632, 1, 'k_run_philox1', 200), (5000, 0, 'k_run_pcg', 0)],
+@pytest.mark.parametrize('n,mode,run_kernel,delay_us', [(1024, 1, 'k_run_philox', 0), (1024, 1, 'k_run_philox', 1500), (2048, 1, 'k_run_philox1m', 0),
+                                                        (8192, 1, 'k_run_philox1', 0), (5632, 1, 'k_run_philox1', 2500), (5000, 0, 'k_run_pcg', 0)],
                          ids=['1024', '1024-slow-exchange', '2048', '8192', '5632-slow-exchange', '5000-numpy-stream'])
 def test_exchange_from_inside_the_one_launch_kernels_gathers_every_step(n, mode, run_kernel, delay_us):
-    """with a communicator cc4_run_random_steps stays ONE launch -- step k writes its packed rows into slab k mod 16 of a
+    """with a communicator cc4_run_random_steps stays ONE launch -- step k writes its packed rows into slab k mod 32 of a
     ring and counts finished episodes, the communication stream waits for the count (hipStreamWaitValue32), all-gathers the slab and
-    publishes how far it got (hipStreamWriteValue32), step k + 16 waits for that.  Checked here on a one-rank communicator: the gathered
+    publishes how far it got (hipStreamWriteValue32) in chunks of 8 steps, step k + 32 waits for that.  Checked here on a one-rank communicator: the gathered
     rows of EVERY step (cc4_debug_gather_log), not only the last of a burst, equal the oracle's -- also with an exchange several times
     slower than the steps, which makes the kernel wait for its slabs --, then observations, rewards, generator words and packed state."""
     from cage_challenge_4_amd import distributed as D
-    steps, seed0 = 60, 2024
+    steps, seed0 = 70, 2024
     dev = _dev(n, steps=steps, rng_mode=mode, autoreset=True); dev.reset(seeds=seed0)
     _one_rank_comm(dev)
     xi = dev.exchange_info()
-    assert xi['in_kernel'] and xi['ring'] == 16 and dev.run_kernel_for(20) == run_kernel, (xi, dev.run_kernel_for(20))
+    assert xi['in_kernel'] and xi['ring'] == 32 and xi['chunk'] == 8 and dev.run_kernel_for(20) == run_kernel, (xi, dev.run_kernel_for(20))
     dev.reset(seeds=seed0)
     if delay_us:
         dev._chk(dev.lib.cc4_debug_comm_delay_us(dev._h, delay_us), 'cc4_debug_comm_delay_us')
     ora = OracleVecEnv(n, steps=steps, rng_mode=mode, autoreset=True); ora.reset_batch(seed0)
     t = 0
-    for K in (20, 37, 20):                                                   # across a regeneration; bursts longer than the ring
+    for K in (20, 45, 20):                                                   # across a regeneration; a burst longer than the ring
         dev.gather_log(K)
         dev.run_random_steps(seed0, t, K, timed=True)
         want = []

@@ -1,8 +1,8 @@
 #!/bin/bash
 # A/B harness for kernel experiments: builds variants of libcc4.so from the working tree with extra -D flags into build_var/
 # (travels with gpurun), and benches them back to back on one box (run-to-run spread on one box is ~0.1 %, between boxes ~3 %).
-#   bash tools/ab.sh build NAME [-DFLAG ...]      (in the build container; several may run in parallel)
-#   bash tools/ab.sh bench NAME [NAME ...]        (through gpurun)
+#   bash tools/ab/ab.sh build NAME [-DFLAG ...]      (in the build container; several may run in parallel)
+#   bash tools/ab/ab.sh bench NAME [NAME ...]        (through gpurun)
 set -u
 cd "$(dirname "$0")/.."
 mkdir -p build_var

@@ -1,5 +1,5 @@
 #!/bin/bash
-# A/B of libcc4.so variants (build_var/NAME.so) over batch sizes: bash tools/ab2.sh "1024 2048" NAME [NAME ...]
+# A/B of libcc4.so variants (build_var/NAME.so) over batch sizes: bash tools/ab/ab2.sh "1024 2048" NAME [NAME ...]
 sizes=$1; shift
 for round in 1 2; do for v in "$@"; do for n in $sizes; do
   CC4_LIB=$PWD/build_var/$v.so python bench.py --no-alt --no-cpu-baseline --total-envs $n --min-seconds 0.4 2>/dev/null | python -c "
