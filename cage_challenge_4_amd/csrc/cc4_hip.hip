@@ -122,6 +122,23 @@ __device__ __forceinline__ void store_packed_row(uint8_t* o8, const uint8_t* val
     __hip_atomic_store(o32 + w, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
   }
 }
+// The same row packed from the int32 observation row the wave has just (re)written in global memory -- the output buffer persists between
+// steps, so it holds every current value although a step only rewrites the ones that changed.  For the one-wave kernels: a byte copy of the
+// 578 values in LDS would cost them a seventh 1280-byte LDS granule and with it two of their twenty resident waves per CU
+// (profiles/r05_lds_residency.txt).  The wave's own stores are drained first (the vector L1 is write-through: they are in the XCD's L2),
+// the loads are agent-scope (served by that L2, never by a stale L1 line).
+__device__ __forceinline__ void pack_row_from_obs(uint8_t* o8, const int32_t* o, int lane) {
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  if (lane < OBS_PACKED / 4) {
+    uint32_t v = 0;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+      const int i = 16 * lane + k;
+      if (i < OBS_TOTAL) v |= ((uint32_t)__hip_atomic_load(o + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & 3u) << (2 * k);
+    }
+    __hip_atomic_store(reinterpret_cast<uint32_t*>(o8) + lane, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
+}
 // The per-step hand-off out of the one-launch kernels (cc4_run_random_steps with a communicator).  Step k of the launch writes
 // its packed rows into slab k % ring and, once an episode's row is in memory, counts it in done[k]; the communication stream waits for
 // done[k] == n (hipStreamWaitValue32), gathers the slab, and publishes gathered = k + 1 (hipStreamWriteValue32); step k + ring of any
@@ -1099,7 +1116,8 @@ struct RunArgs {
   uint32_t* ticket;            // [P] next item of partition p
   uint32_t* progress;          // [n] steps of this launch episode e has completed
   int32_t* owner;              // [P] 0 = unclaimed, else 1 + slot id of the owning CU
-  const int16_t* slot_part;    // [CC4_SLOTS] census: slot id -> partition, -1 = no such CU
+  int32_t* slot_part;          // [CC4_SLOTS + 1] this call's claims: 0 = CU slot not seen yet, -1 = being claimed, else 1 + its partition;
+                               // [CC4_SLOTS] = partitions handed out so far (cleared with the rest of the call's flags)
   int P, K;
   uint32_t t0;                 // action time of step 0 (random_blue_action)
   int order;                   // memory ordering of the hand-over between two items of an episode (CC4_PERSIST_ORDER, persist_loop):
@@ -1112,21 +1130,6 @@ __device__ __forceinline__ int cu_slot() {
   const uint32_t xcc = __builtin_amdgcn_s_getreg(((4 - 1) << 11) | (0 << 6) | 20);    // HW_REG_XCC_ID bits 3:0
   return (int)(((xcc & 7u) << 8) | ((hw >> 8) & 0xFFu));
 }
-// census (cc4_create): which CUs take waves of this footprint, and how many each
-__global__ __launch_bounds__(WAVE) void k_census(int32_t* count, long long ticks) {
-  extern __shared__ uint4 lds[];
-  if (threadIdx.x == 0) {
-    atomicAdd(&count[cu_slot()], 1);
-    const int arrived_at = CC4_SLOTS;                                       // count[CC4_SLOTS]: waves that have reported
-    atomicAdd(&count[arrived_at], 1);
-    // stay resident until the WHOLE grid is (every wave has reported), or for `ticks` if it never is -- then late waves land on CUs that
-    // early ones have left, a CU shows more waves than fit, and the census says so
-    const long long t0 = wall_clock64();
-    while (__hip_atomic_load(&count[arrived_at], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (int)gridDim.x && wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(32);
-  }
-  if (threadIdx.x == 1) reinterpret_cast<volatile uint32_t*>(lds)[0] = 0;
-}
-
 // the one-wave kernel's in-kernel scenario generation (an episode regenerates once in steps-per-episode launches)
 #if defined(CC4_EXP_RESET_CALL)
 __device__ __attribute__((noinline))
@@ -1162,15 +1165,16 @@ void philox1_autoreset(const StepArgs& a, const int e, const int lane, EnvState*
 template <bool LOG, bool PERSIST>
 __device__ __forceinline__ void philox1_body(StepArgs a, const int e, const uint32_t rand_t, const uint32_t item_k, const int lane) {
   extern __shared__ uint4 lds[];
-  // byte copy of the observations, only for the packed exchange row; the debug phase timers borrow the area (a profiled handle
-  // has no communicator): with it, agent part + statics fit 8 KB and 20 episodes are resident per CU
-  __shared__ alignas(8) uint8_t obs_bytes[(OBS_TOTAL + 2 + 7) & ~7];
+  // Static LDS is kept under 512 bytes: agent part (7168 B) + statics then fit SIX 1280-byte LDS granules, 21 waves per CU by LDS and 20
+  // by registers; a seventh granule would leave 18 (profiles/r05_lds_residency.txt: the occupancy query, which divides 160 KB by the
+  // byte count, says 20 either way).  So: no byte copy of the observations for the packed exchange row (pack_row_from_obs reads the
+  // int32 row back), and the debug phase timers exist in the full build only (cc4_debug_profile selects it).
   __shared__ StepWork work;
   __shared__ int conflict_lds;
-  unsigned long long* const prof_lds = reinterpret_cast<unsigned long long*>(obs_bytes);
+  __shared__ unsigned long long prof_lds[LOG ? 16 : 1];
+  if constexpr (!LOG) a.prof = nullptr;
   (void)item_k;
   EnvCold* const cold_e = cold_at(a.cold, (size_t)e, cold_row_bytes(a.steps));
-  if (a.obs8) a.prof = nullptr;
   unsigned long long t_begin = a.prof ? clock64() : 0;
   const uint4* src = reinterpret_cast<const uint4*>(a.st + e);
   stage_in<HOT_VEC>(lds, src, lane);
@@ -1341,14 +1345,13 @@ __device__ __forceinline__ void philox1_body(StepArgs a, const int e, const uint
   unsigned long long t_obs = a.prof ? clock64() : 0;
   {
     int32_t* o = a.obs + (size_t)e * OBS_TOTAL;
-    const bool pack = a.obs8 != nullptr;
-    const int nv = (do_reset || (a.full_obs && (!PERSIST || item_k == 0)) || pack || s->obs_dirty) ? OBS_TOTAL : OBS_FAST;
-    encode_obs_fast<WAVE>(s, o, obs_bytes, pack, lane);
-    for (int v = OBS_FAST + lane; v < nv; v += WAVE) { int i; const int val = env_flat_obs_sorted(s, v, &i); o[i] = val; if (pack) obs_bytes[i] = (uint8_t)val; }
+    const int nv = (do_reset || (a.full_obs && (!PERSIST || item_k == 0)) || s->obs_dirty) ? OBS_TOTAL : OBS_FAST;
+    encode_obs_fast<WAVE>(s, o, nullptr, false, lane);
+    for (int v = OBS_FAST + lane; v < nv; v += WAVE) { int i; const int val = env_flat_obs_sorted(s, v, &i); o[i] = val; }
+    if (a.obs8) pack_row_from_obs(a.obs8 + (size_t)e * OBS_PACKED, o, lane);
   }
   __syncthreads();
   if (lane == 0) a.err[e] = s->err;
-  if (a.obs8) store_packed_row(a.obs8 + (size_t)e * OBS_PACKED, obs_bytes, lane, WAVE);
   unsigned long long t_out = a.prof ? clock64() : 0;
   if (prof && lane == 0) prof[12] += t_out - t_obs;
   stage_out<HOT_VEC>(reinterpret_cast<uint4*>(a.st + e), lds, lane);
@@ -1378,7 +1381,23 @@ __device__ __forceinline__ void persist_loop(StepArgs a, RunArgs ra, const XchgA
   // waves doubling up and the path stays off; 8176 B, the footprint of k_step_philox1, does)
   const int lane = threadIdx.x;
   const int my_slot = cu_slot();
-  int part = ra.slot_part[my_slot];      // (lane 0's copy is the one that counts)
+  // The CU's partition: the first wave of a CU to get here hands the CU the next free partition, its siblings read it.  (No census ahead of
+  // the launch: how many waves a CU takes is the dispatcher's business -- LDS is allocated in 1280-byte granules, so a proxy kernel with
+  // another footprint lands differently --; what the schedule needs is only that a partition is worked on by ONE CU at a time.)
+  int part = -1;                         // (lane 0's copy is the one that counts)
+  if (lane == 0) {
+    int v = __hip_atomic_load(&ra.slot_part[my_slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (v == 0) {
+      int exp = 0;
+      if (__hip_atomic_compare_exchange_strong(&ra.slot_part[my_slot], &exp, -1, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
+        const int p = __hip_atomic_fetch_add(&ra.slot_part[CC4_SLOTS], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        v = p < ra.P ? p + 1 : ra.P + 1;           // (more CU slots than partitions cannot happen: P = the device's CU count; such a CU only helps out)
+        __hip_atomic_store(&ra.slot_part[my_slot], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      } else v = exp;
+    }
+    while (v == -1) { __builtin_amdgcn_s_sleep(4); v = __hip_atomic_load(&ra.slot_part[my_slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+    part = v <= ra.P ? v - 1 : -1;
+  }
   bool mine = false;                     // lane 0: this CU owns `part` (claimed or adopted)
   bool stealing = false;                 // lane 0: `part` belongs to another CU of this XCD; its shared bit is set
   a.prof = nullptr; a.obs8 = nullptr; a.ext = nullptr;
@@ -1695,7 +1714,6 @@ struct cc4_handle {
   // the persistent run kernel (k_run_philox1: K steps of the batch in one launch; RunArgs): per-partition ticket
   // counters, per-episode progress, partition owners in ONE buffer (cleared by one memset per call), the census table
   uint32_t* d_run = nullptr;      // [P ticket | P owner | n progress]
-  int16_t* d_slot_part = nullptr; // [CC4_SLOTS]
   int run_P = 0, run_grid = 0;    // partitions (= CUs that take waves), waves per launch; 0: the persistent path is off
   int persist_state = -1;         // -1 off / unavailable, 0 not set up yet (persist_setup on first use), 1 on
   int persist_order = 0;          // RunArgs.order (CC4_PERSIST_ORDER)
@@ -1716,6 +1734,7 @@ struct cc4_handle {
   uint8_t* last_gathered = nullptr;   // gathered rows of the most recent all-gather, whichever path issued it
   uint8_t* d_xlog = nullptr;      // debug (cc4_debug_gather_log): every gathered slab in issue order, [xlog_cap][world * n][OBS_PACKED]
   int xlog_cap = 0, xlog_n = 0;
+  bool persist_checked = false;   // persist_check ran on this handle
   bool persist_refused = false;   // persist_setup found an unexpected picture (said so on stderr; cc4_run_kernel reports the per-step kernel)
   // CC4_PERSIST_VERIFY=1: every one-launch call of cc4_run_random_steps is repeated with per-step launches on a shadow handle that starts
   // from a copy of this handle's rows, and the two results are compared episode by episode (verify_*)
@@ -1854,7 +1873,7 @@ static void launch_group(cc4_handle* h, StepArgs a, int g, bool full, hipEvent_t
 #else
   if (h->cfg.rng_mode == 1) {
     if (h->philox_lean) {
-      if (full) hipExtLaunchKernelGGL(k_step_philox1<true>, grid, dim3(WAVE), offsetof(EnvState, hd), st, start, stop, 0, a);
+      if (full || h->d_prof) hipExtLaunchKernelGGL(k_step_philox1<true>, grid, dim3(WAVE), offsetof(EnvState, hd), st, start, stop, 0, a);
       else hipExtLaunchKernelGGL(k_step_philox1<false>, grid, dim3(WAVE), offsetof(EnvState, hd), st, start, stop, 0, a);
     }
     else if (full) hipExtLaunchKernelGGL((k_step_philox<true, 1>), grid, dim3(PT), sizeof(EnvState), st, start, stop, 0, a);
@@ -2203,7 +2222,7 @@ void cc4_destroy(cc4_handle* h) {
   for (int b = 0; b < cc4_handle::OBS_RING; ++b) { for (int g = 0; g < cc4_handle::MAX_GROUPS; ++g) if (h->ev_step[b][g]) (void)hipEventDestroy(h->ev_step[b][g]); if (h->ev_comm[b]) (void)hipEventDestroy(h->ev_comm[b]); }
   if (h->comm_stream) (void)hipStreamDestroy(h->comm_stream);
   void* ptrs[] = {h->d_state, h->d_cold, h->small_io ? nullptr : (void*)h->d_actions, h->d_seeds, h->d_envmask, h->small_io ? nullptr : (void*)h->d_obs,
-                  h->d_mask, h->d_rng, h->d_reset_ws, h->d_ext, h->d_run, h->d_slot_part};     // (d_msgs, d_reward, d_err, d_done live inside d_actions / d_obs; small handles: pinned host memory, freed below)
+                  h->d_mask, h->d_rng, h->d_reset_ws, h->d_ext, h->d_run};     // (d_msgs, d_reward, d_err, d_done live inside d_actions / d_obs; small handles: pinned host memory, freed below)
   for (void* p : ptrs) if (p) (void)hipFree(p);
   if (h->shadow) { cc4_destroy(h->shadow); h->shadow = nullptr; (void)hipSetDevice(h->cfg.device_id); }
   if (h->d_digest) (void)hipFree(h->d_digest);
@@ -2509,10 +2528,9 @@ int cc4_synchronize(cc4_handle* h) {
   return sync_all(h);
 }
 // The persistent run kernel (cc4_run_random_steps without a communicator, batches beyond what one launch holds): one wave per
-// residency slot, the batch cut into one partition per CU.  Census: a grid of that many waves with the step kernel's footprint, each
-// reporting the CU it landed on -- the partition table is what the hardware says, and the path stays off unless the picture is the
-// expected one (every CU of the device seen, none with more waves than the occupancy query allows: a mis-decoded CU id would merge
-// CUs and show here).  Run once per handle, on the first call that could use it.
+// residency slot, the batch cut into one partition per CU.  Which CU works on which partition is settled inside the launch (the first
+// wave of a CU claims the next free one); the host checks after a handle's first launch that as many CUs claimed one as the device has
+// (persist_check: a mis-decoded CU id would merge CUs and show there).
 // History: r04 built it with the step body as a call and measured it 18-38 % slower than four streams of per-step launches; the call
 // was the brake (a kernel that contains one loses a quarter of its rate).  Inlined (lane id opaque per item) and compiled without
 // machine LICM (which hoisted ~200 registers' worth of loop-invariant values across the item loop and spilled them) it is the faster
@@ -2522,47 +2540,44 @@ static int persist_setup(cc4_handle* h) {
   const size_t n = (size_t)h->cfg.num_envs;
   int per_cu = 0;
   HIPCHK(h, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, persist_kernel(h), WAVE, offsetof(EnvState, hd)));
+  // (the occupancy query divides 160 KB by the kernel's LDS bytes; the hardware allocates 1280-byte granules -- profiles/r05_lds_residency.txt)
+  hipFuncAttributes fa{};
+  HIPCHK(h, hipFuncGetAttributes(&fa, persist_kernel(h)));
+  const int granules = (int)((offsetof(EnvState, hd) + fa.sharedSizeBytes + 1279) / 1280);
+  if (granules > 0 && 128 / granules < per_cu) per_cu = 128 / granules;
   per_cu -= h->run_margin;            // (with ranks to talk to: a slot per CU stays free for RCCL's kernels)
-  const int grid = per_cu * h->cus;
   if (per_cu <= 0) return 0;
-  if (join_groups(h)) return -1;
-  // the census waves take the LDS the real kernel's waves will (its static part included): the same number fits a CU
-  hipFuncAttributes fa_run{}, fa_cen{};
-  HIPCHK(h, hipFuncGetAttributes(&fa_run, persist_kernel(h)));
-  HIPCHK(h, hipFuncGetAttributes(&fa_cen, reinterpret_cast<const void*>(k_census)));
-  const size_t census_lds = offsetof(EnvState, hd) + (fa_run.sharedSizeBytes > fa_cen.sharedSizeBytes ? fa_run.sharedSizeBytes - fa_cen.sharedSizeBytes : 0);
-  int32_t* d_count = nullptr;
-  HIPCHK(h, hipMalloc(&d_count, (CC4_SLOTS + 1) * sizeof(int32_t)));
-  HIPCHK(h, hipMemsetAsync(d_count, 0, (CC4_SLOTS + 1) * sizeof(int32_t), h->stream));
-  int khz = 100000;
-  (void)hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, h->cfg.device_id);
-  hipLaunchKernelGGL(k_census, dim3(grid), dim3(WAVE), census_lds, h->stream, d_count, 5000LL * (khz > 0 ? khz : 100000) / 1000);   // at most ~5 ms
-  std::vector<int32_t> count(CC4_SLOTS);
-  HIPCHK(h, hipMemcpyAsync(count.data(), d_count, CC4_SLOTS * sizeof(int32_t), hipMemcpyDeviceToHost, h->stream));
-  HIPCHK(h, hipStreamSynchronize(h->stream));
-  (void)hipFree(d_count);
-  std::vector<int16_t> table(CC4_SLOTS, (int16_t)-1);
-  int P = 0, worst = 0, total = 0;
-  for (int sl = 0; sl < CC4_SLOTS; ++sl) if (count[sl] > 0) { table[sl] = (int16_t)P++; worst = count[sl] > worst ? count[sl] : worst; total += count[sl]; }
-  if (getenv("CC4_PERSIST_DEBUG")) fprintf(stderr, "[cc4 census] grid %d (%d per CU x %d CUs): %d CUs seen, at most %d waves on one, %d counted\n", grid, per_cu, h->cus, P, worst, total);
   // The hand-over between two items of an episode relies on what gfx942 / gfx950 do in their default (non-tgsplit) mode: the waves of a
   // CU share one write-through vector L1 (validated on MI355X in SPX mode, the only partition mode of this pool).  Any other
   // architecture keeps the per-step launches -- and says so.
   hipDeviceProp_t prop;
   HIPCHK(h, hipGetDeviceProperties(&prop, h->cfg.device_id));
-  const bool arch_ok = strncmp(prop.gcnArchName, "gfx942", 6) == 0 || strncmp(prop.gcnArchName, "gfx950", 6) == 0;
-  if (!(arch_ok && P == h->cus && worst <= per_cu && total == grid)) {
-    fprintf(stderr, "[cc4] the persistent run kernel stays OFF for this handle (per-step launches instead): %s; census: %d of %d CUs seen, at most %d waves on one (expected <= %d), %d of %d waves counted\n",
-            arch_ok ? "the census of compute units disagrees with the device properties" : "architecture is neither gfx942 nor gfx950", P, h->cus, worst, per_cu, total, grid);
+  if (!(strncmp(prop.gcnArchName, "gfx942", 6) == 0 || strncmp(prop.gcnArchName, "gfx950", 6) == 0)) {
+    fprintf(stderr, "[cc4] the persistent run kernel stays OFF for this handle (per-step launches instead): architecture %s is neither gfx942 nor gfx950\n", prop.gcnArchName);
     h->persist_refused = true;
+    return 0;
   }
-  if (arch_ok && P == h->cus && worst <= per_cu && total == grid) {
-    h->run_P = P; h->run_grid = grid;
-    if (!h->d_slot_part) HIPCHK(h, hipMalloc(&h->d_slot_part, CC4_SLOTS * sizeof(int16_t)));
-    HIPCHK(h, hipMemcpy(h->d_slot_part, table.data(), CC4_SLOTS * sizeof(int16_t), hipMemcpyHostToDevice));
-    if (h->d_run) { (void)hipFree(h->d_run); h->d_run = nullptr; }
-    HIPCHK(h, hipMalloc(&h->d_run, (2 * (size_t)P + n) * sizeof(uint32_t)));
-    h->persist_state = 1;
+  h->run_P = h->cus; h->run_grid = per_cu * h->cus;
+  if (h->d_run) { (void)hipFree(h->d_run); h->d_run = nullptr; }
+  // [P ticket | P owner | n progress | CC4_SLOTS + 1 claims]: one memset per call
+  HIPCHK(h, hipMalloc(&h->d_run, (2 * (size_t)h->run_P + n + CC4_SLOTS + 1) * sizeof(uint32_t)));
+  h->persist_state = 1;
+  h->persist_checked = false;
+  if (getenv("CC4_PERSIST_DEBUG")) fprintf(stderr, "[cc4] persistent kernel: %d LDS granules per wave, %d waves per CU x %d CUs\n", granules, per_cu, h->cus);
+  return 0;
+}
+// After the first launch of the persistent kernel on a handle: did the waves see what the device properties promise -- one partition handed
+// out per compute unit?  Fewer means that CUs took no wave (harmless: their partitions were adopted) or that the CU id read from the
+// hardware registers does not tell CUs apart (NOT harmless: two CUs on one partition).  Either way the path goes off, loudly.
+static int persist_check(cc4_handle* h) {
+  if (h->persist_checked) return 0;
+  h->persist_checked = true;
+  int32_t handed = 0;
+  HIPCHK(h, hipMemcpy(&handed, h->d_run + 2 * (size_t)h->run_P + (size_t)h->cfg.num_envs + CC4_SLOTS, sizeof(handed), hipMemcpyDeviceToHost));
+  if (getenv("CC4_PERSIST_DEBUG")) fprintf(stderr, "[cc4] persistent kernel: %d compute units claimed a partition (device: %d)\n", handed, h->cus);
+  if (handed != h->cus) {
+    fprintf(stderr, "[cc4] the persistent run kernel goes OFF for this handle (per-step launches from now on): its waves saw %d compute units, the device has %d\n", handed, h->cus);
+    h->persist_state = -1; h->persist_refused = true;
   }
   return 0;
 }
@@ -2714,9 +2729,10 @@ static int run_random_steps_impl(cc4_handle* h, uint64_t seed0, uint32_t t0, int
     } else if (form == 2) {
       hipExtLaunchKernelGGL(k_run_philox1m, dim3(h->cfg.num_envs), dim3(WAVE), offsetof(EnvState, hd), h->stream, e0, e1, 0, a, (int)k, t0, x);
     } else {
-      const size_t words = 2 * (size_t)h->run_P + (size_t)h->cfg.num_envs;
+      const size_t words = 2 * (size_t)h->run_P + (size_t)h->cfg.num_envs + CC4_SLOTS + 1;
       HIPCHK(h, hipMemsetAsync(h->d_run, 0, words * sizeof(uint32_t), h->stream));
-      RunArgs ra{h->d_run, h->d_run + 2 * h->run_P, reinterpret_cast<int32_t*>(h->d_run + h->run_P), h->d_slot_part, h->run_P, k, t0, h->persist_order};
+      RunArgs ra{h->d_run, h->d_run + 2 * h->run_P, reinterpret_cast<int32_t*>(h->d_run + h->run_P),
+                 reinterpret_cast<int32_t*>(h->d_run + 2 * (size_t)h->run_P + (size_t)h->cfg.num_envs), h->run_P, k, t0, h->persist_order};
 #ifndef CC4_DEV_FAST
       if (h->cfg.rng_mode == 0) hipExtLaunchKernelGGL(k_run_pcg, dim3(h->run_grid), dim3(WAVE), offsetof(EnvState, hd), h->stream, e0, e1, 0, a, ra, x);
       else
@@ -2734,6 +2750,7 @@ static int run_random_steps_impl(cc4_handle* h, uint64_t seed0, uint32_t t0, int
       h->stat_gather_us += std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - g0).count();
     }
     HIPCHK(h, hipStreamSynchronize(h->stream));
+    if (form == 3 && persist_check(h)) return -1;
     if (exchange && xchg_end(h, k)) return -1;
     if (ms_step_kernels) HIPCHK(h, hipEventElapsedTime(ms_step_kernels, h->evs[0], h->evs[1]));
     return 0;

@@ -245,7 +245,7 @@ static_assert(offsetof(EnvState, hd) % 64 == 0 && sizeof(EnvState) % 64 == 0 && 
 
 // Work area of one step / one reset: temporaries the phases hand to each other.  Not part of the episode's state (LDS on the
 // device, the caller's stack on the host); everything in it is dead between steps.
-struct alignas(16) StepWork {
+struct alignas(4) StepWork {        // (word accesses only; 404 bytes, not padded to 416: LDS is allocated in 1280-byte granules and the kernels sit at the edges)
   uint32_t scratch[64];              // ordered (lane 0) sections: small temporaries that would otherwise be dynamically
                                      // indexed private arrays (= scratch memory on the device)
   uint32_t phish_mask[4];            // bit g: green g's LocalWork asked for a PhishingEmail this step (word 3 unused)
