@@ -1102,9 +1102,9 @@ __global__ __launch_bounds__(PT, 8) void k_run_philox8(StepArgs a, int K, uint32
 // boundary inside, no tail but the last one.  Two things make that safe without any cache maintenance:
 //  * CU affinity.  A CU's vector L1 is never refreshed by another CU's stores, and the XCDs' L2s are not coherent with each other
 //    (MI355X_MICROARCH.md, "inter-workgroup visibility"): an episode's rows must therefore be touched by ONE CU for the whole
-//    launch.  The batch is cut into one partition per CU (episode e -> partition e % P, P = CUs seen by the census at cc4_create);
+//    launch.  The batch is cut into one partition per CU (episode e -> partition e % P, P = the CUs the device showed at first use);
 //    a wave reads its CU's identity from the hardware (HW_REG_XCC_ID, HW_REG_HW_ID: shader engine / array / CU), finds the CU's
-//    partition in the census table and claims it (owner[p]: compare-and-swap of the CU's slot id); only waves of the owning CU ever
+//    partition in the table of the device's CUs (RunArgs.slot_part) and claims it (owner[p]: compare-and-swap of the CU's slot id); only waves of the owning CU ever
 //    work on a partition.  Waves of one CU share its L1, which is coherent for them (what workgroup-scope ordering relies on), so
 //    the hand-over between two of them needs ordering only: the writer drains its stores (s_waitcnt vmcnt(0)) before it publishes.
 //  * Order per episode.  Items of a partition are handed out by a ticket counter in the order (step 0 of its episodes, step 1, ..):
@@ -1116,8 +1116,9 @@ struct RunArgs {
   uint32_t* ticket;            // [P] next item of partition p
   uint32_t* progress;          // [n] steps of this launch episode e has completed
   int32_t* owner;              // [P] 0 = unclaimed, else 1 + slot id of the owning CU
-  int32_t* slot_part;          // [CC4_SLOTS + 1] this call's claims: 0 = CU slot not seen yet, -1 = being claimed, else 1 + its partition;
-                               // [CC4_SLOTS] = partitions handed out so far (cleared with the rest of the call's flags)
+  const int32_t* slot_part;    // [CC4_SLOTS] CU slot id -> 1 + its partition, 0 = no such CU on this device (k_discover at first use: partitions in
+                               // slot order, so the CUs of an XCD own neighbouring partitions and their ticket / progress words share cache lines
+                               // only with each other -- handed out in arrival order they interleave the XCDs, and a 20-step call was 6 % slower)
   int P, K;
   uint32_t t0;                 // action time of step 0 (random_blue_action)
   int order;                   // memory ordering of the hand-over between two items of an episode (CC4_PERSIST_ORDER, persist_loop):
@@ -1130,6 +1131,17 @@ __device__ __forceinline__ int cu_slot() {
   const uint32_t xcc = __builtin_amdgcn_s_getreg(((4 - 1) << 11) | (0 << 6) | 20);    // HW_REG_XCC_ID bits 3:0
   return (int)(((xcc & 7u) << 8) | ((hw >> 8) & 0xFFu));
 }
+// which compute units does this device have?  Many small waves without LDS, each reporting the CU it landed on and idling long enough for
+// the grid to spread over the whole chip.  (Not a census of how many waves of the REAL kernel a CU takes: LDS is allocated in 1280-byte
+// granules, a proxy with another footprint lands differently -- r05 -- and the schedule does not need to know.)
+__global__ __launch_bounds__(WAVE) void k_discover(int32_t* count, long long ticks) {
+  if (threadIdx.x == 0) {
+    atomicAdd(&count[cu_slot()], 1);
+    const long long t0 = wall_clock64();
+    while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(32);
+  }
+}
+
 // the one-wave kernel's in-kernel scenario generation (an episode regenerates once in steps-per-episode launches)
 #if defined(CC4_EXP_RESET_CALL)
 __device__ __attribute__((noinline))
@@ -1376,28 +1388,11 @@ __global__ __launch_bounds__(WAVE, CC4_LEAN_MINW) void k_step_philox1(StepArgs a
 constexpr uint32_t TK_SHARED = 0x80000000u;
 template <bool PCG>
 __device__ __forceinline__ void persist_loop(StepArgs a, RunArgs ra, const XchgArgs x) {
-  // (the item travels from lane 0 to the wave through v_readfirstlane, not through LDS: with 16 bytes more of static LDS the wave's
-  // footprint is 8192 B, and twenty of those do NOT fit a CU's 160 KB beside what the hardware keeps for itself -- the census then sees
-  // waves doubling up and the path stays off; 8176 B, the footprint of k_step_philox1, does)
+  // (the item travels from lane 0 to the wave through v_readfirstlane, not through LDS)
   const int lane = threadIdx.x;
   const int my_slot = cu_slot();
-  // The CU's partition: the first wave of a CU to get here hands the CU the next free partition, its siblings read it.  (No census ahead of
-  // the launch: how many waves a CU takes is the dispatcher's business -- LDS is allocated in 1280-byte granules, so a proxy kernel with
-  // another footprint lands differently --; what the schedule needs is only that a partition is worked on by ONE CU at a time.)
-  int part = -1;                         // (lane 0's copy is the one that counts)
-  if (lane == 0) {
-    int v = __hip_atomic_load(&ra.slot_part[my_slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (v == 0) {
-      int exp = 0;
-      if (__hip_atomic_compare_exchange_strong(&ra.slot_part[my_slot], &exp, -1, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
-        const int p = __hip_atomic_fetch_add(&ra.slot_part[CC4_SLOTS], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        v = p < ra.P ? p + 1 : ra.P + 1;           // (more CU slots than partitions cannot happen: P = the device's CU count; such a CU only helps out)
-        __hip_atomic_store(&ra.slot_part[my_slot], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      } else v = exp;
-    }
-    while (v == -1) { __builtin_amdgcn_s_sleep(4); v = __hip_atomic_load(&ra.slot_part[my_slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-    part = v <= ra.P ? v - 1 : -1;
-  }
+  // The CU's partition, from the table of the compute units this device showed at first use (a CU that is not in it only helps out)
+  int part = ra.slot_part[my_slot] - 1;  // (lane 0's copy is the one that counts)
   bool mine = false;                     // lane 0: this CU owns `part` (claimed or adopted)
   bool stealing = false;                 // lane 0: `part` belongs to another CU of this XCD; its shared bit is set
   a.prof = nullptr; a.obs8 = nullptr; a.ext = nullptr;
@@ -1712,8 +1707,9 @@ struct cc4_handle {
   // kernels (an action queued for several ticks carries its own rates into later steps), with d_ext all XA_NONE for the steps
   // that submit nothing
   // the persistent run kernel (k_run_philox1: K steps of the batch in one launch; RunArgs): per-partition ticket
-  // counters, per-episode progress, partition owners in ONE buffer (cleared by one memset per call), the census table
+  // counters, per-episode progress, partition owners in ONE buffer (cleared by one memset per call), the CU table
   uint32_t* d_run = nullptr;      // [P ticket | P owner | n progress]
+  int32_t* d_slot_part = nullptr; // [CC4_SLOTS] CU slot id -> 1 + partition (persist_setup)
   int run_P = 0, run_grid = 0;    // partitions (= CUs that take waves), waves per launch; 0: the persistent path is off
   int persist_state = -1;         // -1 off / unavailable, 0 not set up yet (persist_setup on first use), 1 on
   int persist_order = 0;          // RunArgs.order (CC4_PERSIST_ORDER)
@@ -1734,7 +1730,6 @@ struct cc4_handle {
   uint8_t* last_gathered = nullptr;   // gathered rows of the most recent all-gather, whichever path issued it
   uint8_t* d_xlog = nullptr;      // debug (cc4_debug_gather_log): every gathered slab in issue order, [xlog_cap][world * n][OBS_PACKED]
   int xlog_cap = 0, xlog_n = 0;
-  bool persist_checked = false;   // persist_check ran on this handle
   bool persist_refused = false;   // persist_setup found an unexpected picture (said so on stderr; cc4_run_kernel reports the per-step kernel)
   // CC4_PERSIST_VERIFY=1: every one-launch call of cc4_run_random_steps is repeated with per-step launches on a shadow handle that starts
   // from a copy of this handle's rows, and the two results are compared episode by episode (verify_*)
@@ -2092,8 +2087,8 @@ const char* cc4_run_kernel(cc4_handle* h) {
 static int persist_setup(cc4_handle* h);
 const char* cc4_run_kernel_for(cc4_handle* h, int32_t k) {
   if (!h) return "";
-  // (the persistent kernel's census runs on first use: asking which kernel a call of k steps will launch is such a use -- the answer depends on it,
-  // and a caller that asks before its timed region keeps the census out of it)
+  // (the persistent kernel's discovery pass runs on first use: asking which kernel a call of k steps will launch is such a use -- the answer depends on it,
+  // and a caller that asks before its timed region keeps it out of that region)
   if (h->persist_state == 0 && !h->run1m && !h->multistep && (!h->comm || h->xchg_on) && !h->evlog_on && !h->ext_seen && !h->d_prof && k >= h->persist_min_k && hipSetDevice(h->cfg.device_id) == hipSuccess) (void)persist_setup(h);
   const char* r = cc4_run_kernel(h);
   if (k < 2) return cc4_step_kernel(h);
@@ -2222,7 +2217,7 @@ void cc4_destroy(cc4_handle* h) {
   for (int b = 0; b < cc4_handle::OBS_RING; ++b) { for (int g = 0; g < cc4_handle::MAX_GROUPS; ++g) if (h->ev_step[b][g]) (void)hipEventDestroy(h->ev_step[b][g]); if (h->ev_comm[b]) (void)hipEventDestroy(h->ev_comm[b]); }
   if (h->comm_stream) (void)hipStreamDestroy(h->comm_stream);
   void* ptrs[] = {h->d_state, h->d_cold, h->small_io ? nullptr : (void*)h->d_actions, h->d_seeds, h->d_envmask, h->small_io ? nullptr : (void*)h->d_obs,
-                  h->d_mask, h->d_rng, h->d_reset_ws, h->d_ext, h->d_run};     // (d_msgs, d_reward, d_err, d_done live inside d_actions / d_obs; small handles: pinned host memory, freed below)
+                  h->d_mask, h->d_rng, h->d_reset_ws, h->d_ext, h->d_run, h->d_slot_part};     // (d_msgs, d_reward, d_err, d_done live inside d_actions / d_obs; small handles: pinned host memory, freed below)
   for (void* p : ptrs) if (p) (void)hipFree(p);
   if (h->shadow) { cc4_destroy(h->shadow); h->shadow = nullptr; (void)hipSetDevice(h->cfg.device_id); }
   if (h->d_digest) (void)hipFree(h->d_digest);
@@ -2528,9 +2523,9 @@ int cc4_synchronize(cc4_handle* h) {
   return sync_all(h);
 }
 // The persistent run kernel (cc4_run_random_steps without a communicator, batches beyond what one launch holds): one wave per
-// residency slot, the batch cut into one partition per CU.  Which CU works on which partition is settled inside the launch (the first
-// wave of a CU claims the next free one); the host checks after a handle's first launch that as many CUs claimed one as the device has
-// (persist_check: a mis-decoded CU id would merge CUs and show there).
+// residency slot, the batch cut into one partition per CU.  Which CUs the device has is found once per handle (k_discover: many small
+// waves reporting HW_REG_XCC_ID / HW_REG_HW_ID; the path stays off unless exactly as many CUs show up as the device properties
+// promise -- a mis-decoded id would merge CUs and show here); how many waves of the run kernel a CU takes is the dispatcher's business.
 // History: r04 built it with the step body as a call and measured it 18-38 % slower than four streams of per-step launches; the call
 // was the brake (a kernel that contains one loses a quarter of its rate).  Inlined (lane id opaque per item) and compiled without
 // machine LICM (which hoisted ~200 registers' worth of loop-invariant values across the item loop and spilled them) it is the faster
@@ -2557,31 +2552,34 @@ static int persist_setup(cc4_handle* h) {
     h->persist_refused = true;
     return 0;
   }
-  h->run_P = h->cus; h->run_grid = per_cu * h->cus;
-  if (h->d_run) { (void)hipFree(h->d_run); h->d_run = nullptr; }
-  // [P ticket | P owner | n progress | CC4_SLOTS + 1 claims]: one memset per call
-  HIPCHK(h, hipMalloc(&h->d_run, (2 * (size_t)h->run_P + n + CC4_SLOTS + 1) * sizeof(uint32_t)));
-  h->persist_state = 1;
-  h->persist_checked = false;
-  if (getenv("CC4_PERSIST_DEBUG")) fprintf(stderr, "[cc4] persistent kernel: %d LDS granules per wave, %d waves per CU x %d CUs\n", granules, per_cu, h->cus);
-  return 0;
-}
-// After the first launch of the persistent kernel on a handle: did the waves see what the device properties promise -- one partition handed
-// out per compute unit?  Fewer means that CUs took no wave (harmless: their partitions were adopted) or that the CU id read from the
-// hardware registers does not tell CUs apart (NOT harmless: two CUs on one partition).  Either way the path goes off, loudly.
-static int persist_check(cc4_handle* h) {
-  if (h->persist_checked) return 0;
-  h->persist_checked = true;
-  int32_t handed = 0;
-  HIPCHK(h, hipMemcpy(&handed, h->d_run + 2 * (size_t)h->run_P + (size_t)h->cfg.num_envs + CC4_SLOTS, sizeof(handed), hipMemcpyDeviceToHost));
-  if (getenv("CC4_PERSIST_DEBUG")) fprintf(stderr, "[cc4] persistent kernel: %d compute units claimed a partition (device: %d)\n", handed, h->cus);
-  if (handed != h->cus) {
-    fprintf(stderr, "[cc4] the persistent run kernel goes OFF for this handle (per-step launches from now on): its waves saw %d compute units, the device has %d\n", handed, h->cus);
-    h->persist_state = -1; h->persist_refused = true;
+  if (join_groups(h)) return -1;
+  int32_t* d_count = nullptr;
+  HIPCHK(h, hipMalloc(&d_count, CC4_SLOTS * sizeof(int32_t)));
+  HIPCHK(h, hipMemsetAsync(d_count, 0, CC4_SLOTS * sizeof(int32_t), h->stream));
+  int khz = 100000;
+  (void)hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, h->cfg.device_id);
+  hipLaunchKernelGGL(k_discover, dim3(24 * h->cus), dim3(WAVE), 0, h->stream, d_count, 100LL * (khz > 0 ? khz : 100000) / 1000);   // ~100 us each
+  std::vector<int32_t> count(CC4_SLOTS);
+  HIPCHK(h, hipMemcpyAsync(count.data(), d_count, CC4_SLOTS * sizeof(int32_t), hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  (void)hipFree(d_count);
+  std::vector<int32_t> table(CC4_SLOTS, 0);
+  int P = 0;
+  for (int sl = 0; sl < CC4_SLOTS; ++sl) if (count[sl] > 0) table[sl] = ++P;        // 1 + partition, in slot order: an XCD's CUs own neighbouring partitions
+  if (getenv("CC4_PERSIST_DEBUG")) fprintf(stderr, "[cc4] persistent kernel: %d compute units seen (device: %d), %d LDS granules per wave, %d waves per CU\n", P, h->cus, granules, per_cu);
+  if (P != h->cus) {       // a CU id that does not tell CUs apart would put two CUs on one partition: never run on a guess
+    fprintf(stderr, "[cc4] the persistent run kernel stays OFF for this handle (per-step launches instead): its discovery pass saw %d compute units, the device has %d\n", P, h->cus);
+    h->persist_refused = true;
+    return 0;
   }
+  h->run_P = P; h->run_grid = per_cu * h->cus;
+  if (!h->d_slot_part) HIPCHK(h, hipMalloc(&h->d_slot_part, CC4_SLOTS * sizeof(int32_t)));
+  HIPCHK(h, hipMemcpy(h->d_slot_part, table.data(), CC4_SLOTS * sizeof(int32_t), hipMemcpyHostToDevice));
+  if (h->d_run) { (void)hipFree(h->d_run); h->d_run = nullptr; }
+  HIPCHK(h, hipMalloc(&h->d_run, (2 * (size_t)P + n) * sizeof(uint32_t)));       // [P ticket | P owner | n progress]: one memset per call
+  h->persist_state = 1;
   return 0;
 }
-
 // ---- the exchange around a one-launch kernel (XchgArgs).  Before the launch: the call's flags cleared on the main stream, the
 // communication stream ordered behind that.  After the launch: per chunk of steps, on the communication stream, wait for the chunk's last
 // step to be complete (done[k] == episodes: the kernel counts an episode once its packed row is in memory), all-gather the chunk's
@@ -2729,10 +2727,9 @@ static int run_random_steps_impl(cc4_handle* h, uint64_t seed0, uint32_t t0, int
     } else if (form == 2) {
       hipExtLaunchKernelGGL(k_run_philox1m, dim3(h->cfg.num_envs), dim3(WAVE), offsetof(EnvState, hd), h->stream, e0, e1, 0, a, (int)k, t0, x);
     } else {
-      const size_t words = 2 * (size_t)h->run_P + (size_t)h->cfg.num_envs + CC4_SLOTS + 1;
+      const size_t words = 2 * (size_t)h->run_P + (size_t)h->cfg.num_envs;
       HIPCHK(h, hipMemsetAsync(h->d_run, 0, words * sizeof(uint32_t), h->stream));
-      RunArgs ra{h->d_run, h->d_run + 2 * h->run_P, reinterpret_cast<int32_t*>(h->d_run + h->run_P),
-                 reinterpret_cast<int32_t*>(h->d_run + 2 * (size_t)h->run_P + (size_t)h->cfg.num_envs), h->run_P, k, t0, h->persist_order};
+      RunArgs ra{h->d_run, h->d_run + 2 * h->run_P, reinterpret_cast<int32_t*>(h->d_run + h->run_P), h->d_slot_part, h->run_P, k, t0, h->persist_order};
 #ifndef CC4_DEV_FAST
       if (h->cfg.rng_mode == 0) hipExtLaunchKernelGGL(k_run_pcg, dim3(h->run_grid), dim3(WAVE), offsetof(EnvState, hd), h->stream, e0, e1, 0, a, ra, x);
       else
@@ -2750,7 +2747,6 @@ static int run_random_steps_impl(cc4_handle* h, uint64_t seed0, uint32_t t0, int
       h->stat_gather_us += std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - g0).count();
     }
     HIPCHK(h, hipStreamSynchronize(h->stream));
-    if (form == 3 && persist_check(h)) return -1;
     if (exchange && xchg_end(h, k)) return -1;
     if (ms_step_kernels) HIPCHK(h, hipEventElapsedTime(ms_step_kernels, h->evs[0], h->evs[1]));
     return 0;
