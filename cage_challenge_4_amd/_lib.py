@@ -89,6 +89,8 @@ SIGNATURES = {
     'cc4_get_topology': (ctypes.c_int, [_P, ctypes.c_int32, _P]),
     'cc4_get_true_state': (ctypes.c_int64, [_P, ctypes.c_int32, ctypes.c_char_p, ctypes.c_size_t]),
     'cc4_enable_event_log': (ctypes.c_int, [_P, ctypes.c_int32]),
+    'cc4_keep_previous': (ctypes.c_int, [_P, ctypes.c_int32]),
+    'cc4_replay_logged': (ctypes.c_int, [_P]),
     'cc4_debug_profile': (ctypes.c_int, [_P, ctypes.c_int, _P]),
     'cc4_comm_unique_id': (ctypes.c_int, [_P]),
     'cc4_comm_init': (ctypes.c_int, [_P, ctypes.c_int32, ctypes.c_int32, _P]),

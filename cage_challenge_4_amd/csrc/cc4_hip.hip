@@ -128,14 +128,17 @@ __device__ __forceinline__ void store_packed_row(uint8_t* o8, const uint8_t* val
 // (profiles/r05_lds_residency.txt).  The wave's own stores are drained first (the vector L1 is write-through: they are in the XCD's L2),
 // the loads are agent-scope (served by that L2, never by a stale L1 line).
 __device__ __forceinline__ void pack_row_from_obs(uint8_t* o8, const int32_t* o, int lane) {
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  // call with the wave's stores drained (s_waitcnt vmcnt(0)): then plain loads see them -- the row was written by this wave, by earlier
+  // waves of this CU (same L1; a stolen partition's item starts with an L1 invalidate), or before the launch
+  static_assert((OBS_TOTAL * 4) % 8 == 0, "rows of the int32 observation buffer are 8-byte aligned: two values per load");
   if (lane < OBS_PACKED / 4) {
+    const uint2* o2 = reinterpret_cast<const uint2*>(o + 16 * lane);
+    uint2 w[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) w[k] = (16 * lane + 2 * k < OBS_TOTAL) ? o2[k] : make_uint2(0u, 0u);     // (578 is even: a pair is inside the row or outside)
     uint32_t v = 0;
 #pragma unroll
-    for (int k = 0; k < 16; ++k) {
-      const int i = 16 * lane + k;
-      if (i < OBS_TOTAL) v |= ((uint32_t)__hip_atomic_load(o + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & 3u) << (2 * k);
-    }
+    for (int k = 0; k < 8; ++k) v |= ((w[k].x & 3u) << (4 * k)) | ((w[k].y & 3u) << (4 * k + 2));
     __hip_atomic_store(reinterpret_cast<uint32_t*>(o8) + lane, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
   }
 }
@@ -152,6 +155,9 @@ struct XchgArgs {
   uint32_t* timeout;             // [1]
   int ring;
   long long wait_ticks;          // wall_clock64 ticks (100 MHz)
+  uint32_t* gcnt;                // [groups][ring]: episodes of a group that finished step k (slot k % ring), see xchg_count
+  uint32_t* timeout_host;        // the same flag in pinned host memory, WRITTEN only (the host reads it without a copy; the waits poll the
+                                 // device word: a thousand blocks polling a word across PCIe cost a 1024-episode batch 12 us per step)
 };
 // lane / thread 0 only
 __device__ __forceinline__ void xchg_wait_slab(const XchgArgs& x, uint32_t k) {
@@ -168,12 +174,23 @@ __device__ __forceinline__ void xchg_wait_slab(const XchgArgs& x, uint32_t k) {
     if (naps < 16) naps <<= 1;
     if (wall_clock64() - w0 > x.wait_ticks || __hip_atomic_load(x.timeout, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM)) {
       __hip_atomic_store(x.timeout, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      __hip_atomic_store(x.timeout_host, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
       return;
     }
   }
 }
-__device__ __forceinline__ void xchg_count(const XchgArgs& x, uint32_t k) {     // after the block's stores have drained (s_waitcnt vmcnt(0) + barrier)
-  (void)__hip_atomic_fetch_add(x.done + k, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+// One episode has finished step k and its packed row is in memory (the wave's stores have drained).  Counted in two levels: thousands of
+// system-scope atomics on ONE word serialise at ~12 ns each (8192 episodes: 100 us per step -- twice the step), so an episode bumps the
+// counter of its group (a partition of the persistent kernel, 32 neighbouring episodes of the multi-step kernels) and the group's last
+// episode adds the whole group to done[k].  The group counter of slot k % ring is reused by step k + ring, which cannot start before step
+// k is complete everywhere (xchg_wait_slab).
+__device__ __forceinline__ void xchg_count(const XchgArgs& x, uint32_t k, int group, int group_size) {
+  uint32_t* c = x.gcnt + (size_t)group * (size_t)x.ring + (k % (uint32_t)x.ring);
+  const uint32_t before = __hip_atomic_fetch_add(c, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (before + 1u == (uint32_t)group_size) {
+    __hip_atomic_store(c, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    (void)__hip_atomic_fetch_add(x.done + k, (uint32_t)group_size, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
 }
 
 // ---------------------------------------------------------------- numpy stream: the two draw-only phases across the wave
@@ -1074,7 +1091,7 @@ __device__ __forceinline__ void run_philox_loop(StepArgs a, int K, uint32_t t0, 
       philox4_body<false, true>(a, (k > 0 ? 1 : 0) | (k == K - 1 ? 2 : 0), tid_i); }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    if (x.slab && threadIdx.x == 0) xchg_count(x, (uint32_t)k);
+    if (x.slab && threadIdx.x == 0) { const int e = a.e0 + (int)blockIdx.x, g = e >> 5; xchg_count(x, (uint32_t)k, g, a.n - (g << 5) < 32 ? a.n - (g << 5) : 32); }
   }
 }
 __global__ __launch_bounds__(PT, 5) void k_run_philox(StepArgs a, int K, uint32_t t0, XchgArgs x) { run_philox_loop<5>(a, K, t0, x); }
@@ -1360,13 +1377,16 @@ __device__ __forceinline__ void philox1_body(StepArgs a, const int e, const uint
     const int nv = (do_reset || (a.full_obs && (!PERSIST || item_k == 0)) || s->obs_dirty) ? OBS_TOTAL : OBS_FAST;
     encode_obs_fast<WAVE>(s, o, nullptr, false, lane);
     for (int v = OBS_FAST + lane; v < nv; v += WAVE) { int i; const int val = env_flat_obs_sorted(s, v, &i); o[i] = val; }
-    if (a.obs8) pack_row_from_obs(a.obs8 + (size_t)e * OBS_PACKED, o, lane);
   }
   __syncthreads();
   if (lane == 0) a.err[e] = s->err;
   unsigned long long t_out = a.prof ? clock64() : 0;
   if (prof && lane == 0) prof[12] += t_out - t_obs;
   stage_out<HOT_VEC>(reinterpret_cast<uint4*>(a.st + e), lds, lane);
+  if (a.obs8) {     // the per-step launches' packed exchange row (the one-launch loops pack behind their own end-of-step drain instead)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    pack_row_from_obs(a.obs8 + (size_t)e * OBS_PACKED, a.obs + (size_t)e * OBS_TOTAL, lane);
+  }
   if (prof && lane == 0) { prof[13] += clock64() - t_out; prof[14] += clock64() - t_begin; }
   if (prof) { __syncthreads(); if (lane < 15) a.prof[PROF_SLOTS * (size_t)e + lane] += prof_lds[lane]; }
 }
@@ -1465,9 +1485,7 @@ __device__ __forceinline__ void persist_loop(StepArgs a, RunArgs ra, const XchgA
       if (x.slab) b.obs8 = x.slab + (size_t)(item_k % (uint32_t)x.ring) * (size_t)a.n * OBS_PACKED;
       pcg_body<false>(b, e, lane_i);
     } else {
-      StepArgs b = a;
-      if (x.slab) b.obs8 = x.slab + (size_t)(item_k % (uint32_t)x.ring) * (size_t)a.n * OBS_PACKED;
-      philox1_body<false, true>(b, e, ra.t0 + item_k, item_k, lane_i);
+      philox1_body<false, true>(a, e, ra.t0 + item_k, item_k, lane_i);      // (a.obs8 is null: the packed row is written below, behind the drain)
     }
     // the item is done when everything it wrote has left this wave: then the next step of the episode may start (on this XCD)
     // Release: every lane drains its own stores (workgroup-scope release = s_waitcnt vmcnt(0) on gfx950 without tgsplit: the vector L1 is
@@ -1476,9 +1494,13 @@ __device__ __forceinline__ void persist_loop(StepArgs a, RunArgs ra, const XchgA
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     if (ra.order >= 2) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
     __syncthreads();
+    if (x.slab) {      // the exchange: this episode's packed row of step item_k into the step's slab (before the episode's next step may touch the row it is read from)
+      if constexpr (!PCG) pack_row_from_obs(x.slab + ((size_t)(item_k % (uint32_t)x.ring) * (size_t)a.n + (size_t)e) * OBS_PACKED, a.obs + (size_t)e * OBS_TOTAL, lane);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
     if (lane == 0) {
       __hip_atomic_store(&ra.progress[e], item_k + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      if (x.slab) xchg_count(x, item_k);
+      if (x.slab) { const int pq = e % ra.P; xchg_count(x, item_k, pq, (a.n - pq + ra.P - 1) / ra.P); }
     }
   }
 }
@@ -1498,7 +1520,6 @@ __global__ __launch_bounds__(WAVE, 5) void k_run_philox1m(StepArgs a, int K, uin
   for (int k = 0; k < K; ++k) {
     if (x.slab) {
       if (threadIdx.x == 0) xchg_wait_slab(x, (uint32_t)k);
-      a.obs8 = x.slab + (size_t)(k % x.ring) * (size_t)a.n * OBS_PACKED;
       __syncthreads();
     }
     int lane_i = (int)threadIdx.x;
@@ -1506,7 +1527,11 @@ __global__ __launch_bounds__(WAVE, 5) void k_run_philox1m(StepArgs a, int K, uin
     philox1_body<false, true>(a, e, t0 + (uint32_t)k, (uint32_t)k, lane_i);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    if (x.slab && threadIdx.x == 0) xchg_count(x, (uint32_t)k);
+    if (x.slab) {
+      pack_row_from_obs(x.slab + ((size_t)(k % x.ring) * (size_t)a.n + (size_t)e) * OBS_PACKED, a.obs + (size_t)e * OBS_TOTAL, (int)threadIdx.x);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      if (threadIdx.x == 0) { const int g = e >> 5; xchg_count(x, (uint32_t)k, g, a.n - (g << 5) < 32 ? a.n - (g << 5) : 32); }
+    }
   }
 }
 
@@ -1667,6 +1692,12 @@ struct cc4_handle {
   // one host wait -- no copy engine in either direction (each DMA costs ~10 us of latency for a few hundred bytes).  CC4_SMALL_IO=0: off.
   static constexpr int SMALL_IO_ENVS = 16;
   bool small_io = false;
+  // cc4_keep_previous / cc4_replay_logged (small handles): the rows as they stood before the last step, so that the step can be repeated
+  // with the event log on when -- and only when -- somebody asks what happened in it (the single-episode wrapper surface: flat
+  // observations need no log, and the logging build of the numpy-stream kernel walks its green actions serially: +30 us per step)
+  bool keep_prev = false, prev_valid = false;
+  EnvState* d_prev_state = nullptr; EnvCold* d_prev_cold = nullptr; uint8_t* d_prev_out = nullptr;
+  const int32_t* prev_actions = nullptr; const uint8_t* prev_msgs = nullptr; bool prev_full_obs = false, prev_ext = false;
   // byte observations and gathered observations ([world*N][578]) in a ring of OBS_RING buffers: the all-gather of step t
   // overlaps later steps, and the compute stream waits for the communication stream only once per OBS_WAIT_EVERY steps
   // (a cross-stream wait in front of every launch costs the stream ~10 us)
@@ -1722,7 +1753,10 @@ struct cc4_handle {
                                   // pays ~25 us to enqueue a wait, an all-gather and a publish -- more than a step of a small batch lasts)
   uint8_t* d_xslab = nullptr;     // [XRING][n][OBS_PACKED]
   uint8_t* d_xall = nullptr;      // [XRING][world * n][OBS_PACKED]
-  uint32_t* d_xflags = nullptr;   // [0] gathered, [1] timeout, [2 ..] done[k]
+  uint32_t* d_xflags = nullptr;   // [0] gathered, [1] timeout (what the waits poll), [2 ..] done[k]
+  uint32_t* d_xgcnt = nullptr;    // [groups][XRING] group counters (xchg_count)
+  uint32_t* h_xtimeout = nullptr; // pinned host word the kernel raises when a wait gives up (read without a copy)
+  uint32_t* d_xtimeout = nullptr; // its device address
   int xflags_cap = 0;             // steps the done[] part holds
   hipEvent_t xev = nullptr;
   long long xchg_calls = 0, xchg_timeouts = 0;
@@ -1833,6 +1867,7 @@ static void configure_groups(cc4_handle* h, int ng) {
 
 // Every API call other than the step launches works on the main stream: order it behind whatever the group streams still
 // hold (device-side waits, no host synchronisation), and remember that the next step launches must be ordered behind it.
+extern "C" __global__ void k_set_evlog(EnvCold* cold, size_t row_bytes, int n, uint32_t on);
 static int join_groups(cc4_handle* h) {
   if (h->ngroups > 1) {
     if (h->groups_busy) {
@@ -1971,6 +2006,13 @@ static int launch_step(cc4_handle* h, const int32_t* d_actions, const uint8_t* d
     HIPCHK(h, hipEventRecord(h->mev, h->stream));
     for (int g = 1; g < h->ngroups; ++g) HIPCHK(h, hipStreamWaitEvent(h->gstream[g], h->mev, 0));
     h->main_ahead = false;
+  }
+  if (h->keep_prev) {      // the rows as they stand before this step (cc4_replay_logged); a small handle: one launch per step, main stream
+    const size_t n = (size_t)h->cfg.num_envs;
+    HIPCHK(h, hipMemcpyAsync(h->d_prev_state, h->d_state, n * sizeof(EnvState), hipMemcpyDeviceToDevice, h->stream));
+    HIPCHK(h, hipMemcpyAsync(h->d_prev_cold, h->d_cold, n * h->cold_row, hipMemcpyDeviceToDevice, h->stream));
+    h->prev_actions = d_actions; h->prev_msgs = d_msgs; h->prev_full_obs = h->full_obs_next; h->prev_ext = h->ext_seen;
+    h->prev_valid = !rand;
   }
   StepArgs a{h->d_state, h->d_cold, d_actions, d_msgs, h->d_obs, h->d_reward, h->d_done, h->d_err,
              h->comm ? h->d_obs8[buf] : nullptr, rand ? h->d_actions : nullptr, seed0, t,
@@ -2220,12 +2262,14 @@ void cc4_destroy(cc4_handle* h) {
                   h->d_mask, h->d_rng, h->d_reset_ws, h->d_ext, h->d_run, h->d_slot_part};     // (d_msgs, d_reward, d_err, d_done live inside d_actions / d_obs; small handles: pinned host memory, freed below)
   for (void* p : ptrs) if (p) (void)hipFree(p);
   if (h->shadow) { cc4_destroy(h->shadow); h->shadow = nullptr; (void)hipSetDevice(h->cfg.device_id); }
+  for (void* p : {(void*)h->d_prev_state, (void*)h->d_prev_cold, (void*)h->d_prev_out}) if (p) (void)hipFree(p);
   if (h->d_digest) (void)hipFree(h->d_digest);
   if (h->pin_in) (void)hipHostFree(h->pin_in);
   if (h->pin_out) (void)hipHostFree(h->pin_out);
   for (int b = 0; b < cc4_handle::OBS_RING; ++b) { if (h->d_obs8[b]) (void)hipFree(h->d_obs8[b]); if (h->d_all_obs8[b]) (void)hipFree(h->d_all_obs8[b]); }
   if (h->d_unpacked) (void)hipFree(h->d_unpacked);
-  for (void* p : {(void*)h->d_xslab, (void*)h->d_xall, (void*)h->d_xflags, (void*)h->d_xlog}) if (p) (void)hipFree(p);
+  for (void* p : {(void*)h->d_xslab, (void*)h->d_xall, (void*)h->d_xflags, (void*)h->d_xlog, (void*)h->d_xgcnt}) if (p) (void)hipFree(p);
+  if (h->h_xtimeout) (void)hipHostFree(h->h_xtimeout);
   if (h->xev) (void)hipEventDestroy(h->xev);
   for (hipEvent_t e : h->evs) if (e) (void)hipEventDestroy(e);
   if (h->ev0) (void)hipEventDestroy(h->ev0);
@@ -2251,6 +2295,7 @@ int cc4_reset(cc4_handle* h, const uint64_t* seeds, const uint8_t* env_mask) {
   if (h->comm && h->gathers_issued > h->gathers_waited) { HIPCHK(h, hipStreamSynchronize(h->comm_stream)); h->gathers_waited = h->gathers_issued; }
   hipLaunchKernelGGL(k_reset, dim3(h->cfg.num_envs), dim3(WAVE), 0, h->stream, a);
   HIPCHK(h, hipGetLastError());
+  h->prev_valid = false;            // (cc4_replay_logged: no step to repeat)
   h->step_event_attached = false;   // the buffer's event must be recorded again before the next all-gather
   HIPCHK(h, hipStreamSynchronize(h->stream));
   return 0;
@@ -2592,11 +2637,19 @@ static int xchg_begin(cc4_handle* h, int k, XchgArgs* x) {
     h->xflags_cap = cap;
   }
   HIPCHK(h, hipMemsetAsync(h->d_xflags, 0, (2 + (size_t)k) * sizeof(uint32_t), h->stream));
+  const size_t groups = (size_t)h->cfg.num_envs / 32 + 1 > (size_t)h->cus ? (size_t)h->cfg.num_envs / 32 + 1 : (size_t)h->cus;
+  if (!h->d_xgcnt) HIPCHK(h, hipMalloc(&h->d_xgcnt, groups * cc4_handle::XRING * sizeof(uint32_t)));
+  HIPCHK(h, hipMemsetAsync(h->d_xgcnt, 0, groups * cc4_handle::XRING * sizeof(uint32_t), h->stream));
+  if (!h->h_xtimeout) {
+    HIPCHK(h, hipHostMalloc(reinterpret_cast<void**>(&h->h_xtimeout), sizeof(uint32_t), hipHostMallocDefault));
+    HIPCHK(h, hipHostGetDevicePointer(reinterpret_cast<void**>(&h->d_xtimeout), h->h_xtimeout, 0));
+  }
+  *h->h_xtimeout = 0;
   HIPCHK(h, hipEventRecord(h->xev, h->stream));
   HIPCHK(h, hipStreamWaitEvent(h->comm_stream, h->xev, 0));
   int khz = 100000;
   (void)hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, h->cfg.device_id);
-  *x = XchgArgs{h->d_xslab, h->d_xflags + 2, h->d_xflags, h->d_xflags + 1, cc4_handle::XRING, (long long)h->xchg_watchdog_ms * (khz > 0 ? khz : 100000)};
+  *x = XchgArgs{h->d_xslab, h->d_xflags + 2, h->d_xflags, h->d_xflags + 1, cc4_handle::XRING, (long long)h->xchg_watchdog_ms * (khz > 0 ? khz : 100000), h->d_xgcnt, h->d_xtimeout};
   return 0;
 }
 static int xchg_enqueue(cc4_handle* h, int k, const XchgArgs& x) {
@@ -2624,8 +2677,7 @@ static int xchg_end(cc4_handle* h, int k) {
   const size_t row = (size_t)h->cfg.num_envs * OBS_PACKED;
   HIPCHK(h, hipStreamSynchronize(h->comm_stream));
   h->gathers_waited = h->gathers_issued;
-  uint32_t flag = 0;
-  HIPCHK(h, hipMemcpy(&flag, h->d_xflags + 1, sizeof(flag), hipMemcpyDeviceToHost));
+  const uint32_t flag = *reinterpret_cast<volatile uint32_t*>(h->h_xtimeout);      // (both streams are drained: the kernel's system-scope store has landed)
   h->xchg_calls++;
   const int last = (k - 1) % cc4_handle::XRING;
   h->last_gathered = h->d_xall + last * row * (size_t)h->world;
@@ -2952,6 +3004,62 @@ int cc4_enable_event_log(cc4_handle* h, int32_t enable) {
   HIPCHK(h, hipGetLastError());
   HIPCHK(h, hipStreamSynchronize(h->stream));
   h->evlog_on = enable ? 1 : 0;
+  return 0;
+}
+__global__ void k_copy_evlog(EnvCold* dst, const EnvCold* src, size_t row_bytes, int n) {
+  const int e = blockIdx.x;
+  if (e >= n) return;
+  const uint32_t* s = reinterpret_cast<const uint32_t*>(&cold_at(const_cast<EnvCold*>(src), (size_t)e, row_bytes)->evlog);
+  uint32_t* d = reinterpret_cast<uint32_t*>(&cold_at(dst, (size_t)e, row_bytes)->evlog);
+  for (int i = threadIdx.x; i < (int)(sizeof(EvLog) / 4); i += blockDim.x) d[i] = s[i];
+}
+// The event log on demand (handles of up to 16 episodes without a communicator).  cc4_keep_previous(1): every step launch is preceded by a
+// device-side copy of the episodes' rows.  cc4_replay_logged: the LAST step again, on that copy, with the logging build of the step kernel
+// and the same inputs (the action / message / submitted-action buffers still hold them) -- the copy ends where the live rows are, and its
+// event log is copied into the live cold rows: cc4_get_true_state then reports the HostEvents entries of the last step although the step
+// itself ran the fast build.  With no step since the reset the log is simply empty.  Same generator positions: logging draws nothing in
+// the numpy-stream mode and only side streams in the counter mode.
+int cc4_keep_previous(cc4_handle* h, int32_t on) {
+  if (on && (h->comm || h->cfg.num_envs > 16 || h->cfg.autoreset)) { h->err = "cc4_keep_previous: for handles of up to 16 episodes without a communicator or autoreset"; return -2; }
+  HIPCHK(h, hipSetDevice(h->cfg.device_id));
+  const size_t n = (size_t)h->cfg.num_envs;
+  if (on && !h->d_prev_state) {
+    HIPCHK(h, hipMalloc(&h->d_prev_state, n * sizeof(EnvState)));
+    HIPCHK(h, hipMalloc(reinterpret_cast<void**>(&h->d_prev_cold), n * h->cold_row));
+    HIPCHK(h, hipMalloc(&h->d_prev_out, h->out_bytes));
+  }
+  h->keep_prev = on != 0;
+  h->prev_valid = false;
+  return 0;
+}
+int cc4_replay_logged(cc4_handle* h) {
+  if (!h->keep_prev) { h->err = "cc4_replay_logged: cc4_keep_previous is off"; return -2; }
+  HIPCHK(h, hipSetDevice(h->cfg.device_id));
+  if (join_groups(h)) return -1;
+  const int n = h->cfg.num_envs;
+  if (!h->prev_valid) {      // no step since the reset (or steps whose inputs are gone): an enabled, empty log
+    hipLaunchKernelGGL(k_set_evlog, dim3((n + 255) / 256), dim3(256), 0, h->stream, h->d_cold, h->cold_row, n, 1u);
+    HIPCHK(h, hipGetLastError());
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    return 0;
+  }
+  hipLaunchKernelGGL(k_set_evlog, dim3((n + 255) / 256), dim3(256), 0, h->stream, h->d_prev_cold, h->cold_row, n, 1u);
+  HIPCHK(h, hipGetLastError());
+  int32_t* o = reinterpret_cast<int32_t*>(h->d_prev_out);
+  float* rw = reinterpret_cast<float*>(o + (size_t)n * OBS_TOTAL);
+  uint32_t* er = reinterpret_cast<uint32_t*>(rw + n);
+  uint8_t* dn = reinterpret_cast<uint8_t*>(er + n);
+  StepArgs a{h->d_prev_state, h->d_prev_cold, h->prev_actions, h->prev_msgs, o, rw, dn, er, nullptr, nullptr, 0, 0,
+             n, 0, h->cfg.steps, h->cfg.rng_mode,
+             (h->cfg.red_policy & 3) | (h->cfg.green_policy ? GP_SLEEP_BIT : 0) | (h->cfg.green_policy == 2 ? GP_OPEN_BIT : 0) | (h->cfg.blue_policy ? BP_RANDOM_BIT : 0), 1,
+             (uint32_t)h->cfg.topology_seed, nullptr, h->d_reset_ws, h->prev_ext ? h->d_ext : nullptr, 0};
+  for (int g = 0; g < h->ngroups; ++g) launch_group(h, a, g, true, nullptr, nullptr);
+  HIPCHK(h, hipGetLastError());
+  if (h->ngroups > 1) { h->groups_busy = true; if (join_groups(h)) return -1; }
+  hipLaunchKernelGGL(k_copy_evlog, dim3(n), dim3(64), 0, h->stream, h->d_cold, h->d_prev_cold, h->cold_row, n);
+  HIPCHK(h, hipGetLastError());
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  h->prev_valid = false;          // (the copy has moved on: a second replay would repeat the step from the wrong rows)
   return 0;
 }
 int64_t cc4_get_true_state(cc4_handle* h, int32_t env, char* json, size_t cap) {

@@ -216,6 +216,14 @@ class CC4VecEnv:
         """cc4_enable_event_log: record the HostEvents entries of every step (for decoded blue dict observations)."""
         self._chk(self.lib.cc4_enable_event_log(self._h, int(bool(on))), 'cc4_enable_event_log')
 
+    def keep_previous(self, on=True):
+        """cc4_keep_previous: keep the rows as they stood before every step, so that replay_logged() can produce the last step's event log on demand."""
+        self._chk(self.lib.cc4_keep_previous(self._h, int(bool(on))), 'cc4_keep_previous')
+
+    def replay_logged(self):
+        """cc4_replay_logged: the last step once more on the kept rows with the event log on; true_state_json then carries its events."""
+        self._chk(self.lib.cc4_replay_logged(self._h), 'cc4_replay_logged')
+
     def true_state_json(self, env=0):
         """cc4_get_true_state: the episode's packed state as the JSON document described in csrc/cc4_export.h."""
         need = int(self.lib.cc4_get_true_state(self._h, int(env), None, 0))

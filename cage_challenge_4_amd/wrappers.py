@@ -141,6 +141,7 @@ class CybORG:
                                               green_policy=scenario_generator.green_policy,
                                               blue_policy=scenario_generator.blue_policy)
         self.vec.enable_event_log(True)                        # single episode: keep the per-step event detail for get_observation
+        self._lazy_log, self._events_fresh = False, False     # (the fixed-action wrappers switch to the log on demand: _event_log_on_demand)
         if generator is not None:
             self.vec.set_generators([generator])
             self.vec.reset(seeds=None)                           # the scenario is drawn from the adopted stream
@@ -150,6 +151,26 @@ class CybORG:
         self._labels = None
         self._seed = int(seed)
         self._make_host_agents()
+
+    def _tsjson(self):
+        """The episode's state document.  With the event log on demand (_event_log_on_demand) the last step is first repeated with the
+        log on -- once per step, and only when somebody looks."""
+        if self._lazy_log and not self._events_fresh:
+            self.vec.replay_logged()
+            self._events_fresh = True
+        return self.vec.true_state_json(0)
+
+    def _event_log_on_demand(self):
+        """Called by the fixed-action wrappers: their step() returns flat vectors, which need no event log -- and the logging build of the
+        numpy-stream kernel costs a single episode ~30 us per step.  The log goes OFF; the engine keeps the rows of the previous step
+        (cc4_keep_previous) and repeats that step with the log on the first time get_observation / get_true_state / parallel_step ... ask
+        what happened in it (cc4_replay_logged): the same answers, paid for only when asked.  Not with host-side agent objects (they read
+        their dict observation every step) and not on backends without the replay (the CPU oracle of the tests)."""
+        if self._lazy_log or self._host_agents or not hasattr(self.vec, 'replay_logged'):
+            return
+        self.vec.enable_event_log(False)
+        self.vec.keep_previous(True)
+        self._lazy_log, self._events_fresh = True, False
 
     def _make_host_agents(self):
         """The agent objects that act from the host: one per agent of a team with a custom class (constructed as the reference's
@@ -164,7 +185,7 @@ class CybORG:
             return                                          # the default: every policy runs on the device -- nothing to build, no state to fetch
         import inspect
         import zlib
-        d = json_loads(self.vec.true_state_json(0))
+        d = json_loads(self._tsjson())
         names = {'blue': list(self.agents_blue), 'green': [f'green_agent_{g}' for g in range(d['n_green'])],
                  'red': [f'red_agent_{r}' for r in range(6)]}
         for team, cls in getattr(sg, 'custom', {}).items():
@@ -182,6 +203,7 @@ class CybORG:
     def reset(self, agent=None, seed=None):
         """env.py:218-243: seed=None keeps the running stream; an int seed starts a fresh Generator."""
         self.vec.reset(seeds=None if seed is None else np.array([seed], np.uint64))
+        self._events_fresh = False
         self._labels = None
         if seed is not None:
             self._seed = int(seed)
@@ -197,7 +219,7 @@ class CybORG:
     # ---- the raw CybORG surface around the step (env.py:95-161, 202-216, 266-283, 316-372, 405-415)
     def _state(self):
         from .true_state import decode
-        return decode(self.vec.true_state_json(0))
+        return decode(self._tsjson())
 
     def _action_labels(self):
         """The fixed action lists of the five blue agents (BlueFixedActionWrapper.py:233-309) for this episode's topology."""
@@ -249,8 +271,9 @@ class CybORG:
         instances map the same way).  Agents without an entry act by the scenario's policy: on the device for the built-in classes, by
         their host-side object for custom classes / `agents=` overrides (asked here, in agent_interfaces order: blue, green, red)."""
         actions = dict(actions or {})
+        self._events_fresh = False
         if self._host_agents:
-            d = json_loads(self.vec.true_state_json(0))
+            d = json_loads(self._tsjson())
             for name, obj in self._host_agents.items():
                 if name in actions or (blue_codes is not None and name in self.agents_blue and blue_codes[self.agents_blue.index(name)] >= 0):
                     continue
@@ -275,7 +298,7 @@ class CybORG:
             k = int(a.split('_')[-1])
             if maps is None:
                 maps = self._host_maps()
-                gh = json_loads(self.vec.true_state_json(0))['green_hosts']
+                gh = json_loads(self._tsjson())['green_hosts']
             if kind == 'red':
                 if not 0 <= k < 6:
                     raise ValueError(f'{a}: no such agent')
@@ -455,7 +478,7 @@ class CybORG:
     def get_agent_state(self, agent_name):
         """env.py:202-216: the true state restricted to what the scenario's INFO_DICT lists for the agent ('True' = all)."""
         from .true_state import decode
-        st = decode(self.vec.true_state_json(0))
+        st = decode(self._tsjson())
         if agent_name == 'True' or agent_name not in self.agents_blue:
             return st.as_dict()
         b = self.agents_blue.index(agent_name)
@@ -476,7 +499,7 @@ class CybORG:
         'System info', ...}, 'success': True}, decoded from the packed episode state (true_state.py).  `info`
         (hostname -> wanted fields) only selects hosts."""
         from .true_state import decode
-        return decode(self.vec.true_state_json(0)).as_dict(info)
+        return decode(self._tsjson()).as_dict(info)
 
     def get_observation(self, agent):
         """env.py:270-283: the dict observation of a blue agent after the last step -- 'success', 'action' and, per host of
@@ -485,14 +508,14 @@ class CybORG:
         incl. the process entry of a resolved DeployDecoy and the file list of a resolved Analyse: tests/test_blue_obs.py);
         a red agent's comes from the engine's per-agent observation keys, a green agent's carries 'success' / 'action'."""
         from .true_state import decode
-        return self._all_observations(decode(self.vec.true_state_json(0)), [agent])[agent]
+        return self._all_observations(decode(self._tsjson()), [agent])[agent]
 
     def get_last_action(self, agent):
         """env.py:300-314: the actions of `agent` (blue_agent_b / red_agent_r) that resolved in the last step -- a list, as the
         reference returns (one entry here) -- as objects whose str() equals the reference action's ('Restore <hostname>',
         'ExploitRemoteService <ip>', 'Sleep', ...) and whose .name is the action class name."""
         from .true_state import decode
-        return [decode(self.vec.true_state_json(0)).last_action[agent]]
+        return [decode(self._tsjson()).last_action[agent]]
 
     def get_ip_map(self):
         t = self.topology()
@@ -571,6 +594,8 @@ class BlueFixedActionWrapper:
                 hosts.update(f'{sn}_user_host_{i}' for i in range(MAX_USER_HOSTS))
                 hosts.update(f'{sn}_server_host_{i}' for i in range(MAX_SERVER_HOSTS))
             self._agent_metadata[a] = {'hosts': sorted(hosts), 'subnets': sorted(BLUE_SUBNETS[b])}
+        if hasattr(env, '_event_log_on_demand'):
+            env._event_log_on_demand()
         self._refresh_action_space()
 
     # -- action space bookkeeping (mask comes from the engine, labels are rebuilt from the topology)
