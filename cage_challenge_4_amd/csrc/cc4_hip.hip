@@ -143,14 +143,14 @@ __device__ __forceinline__ void pack_row_from_obs(uint8_t* o8, const int32_t* o,
   }
 }
 // The per-step hand-off out of the one-launch kernels (cc4_run_random_steps with a communicator).  Step k of the launch writes
-// its packed rows into slab k % ring and, once an episode's row is in memory, counts it in done[k]; the communication stream waits for
-// done[k] == n (hipStreamWaitValue32), gathers the slab, and publishes gathered = k + 1 (hipStreamWriteValue32); step k + ring of any
+// its packed rows into slab k % ring and, once an episode's row is in memory, counts it in its group's counter of that step (a no-return
+// atomic: nothing waits for it); on the communication stream a one-block gate kernel (k_xchg_gate) waits until every group has counted
+// every step of a chunk, the chunk's slabs are gathered, and gathered = last + 1 is published (hipStreamWriteValue32); step k + ring of any
 // episode waits for gathered > k before it overwrites the slab.  The exchange lags the stepping by up to `ring` steps, with no launch
 // boundary in the compute queue.  A wait that lasts longer than wait_ticks gives up, raises *timeout (the host falls back to per-step
 // launches and says so) and every later wait of the launch returns at once: a stuck exchange never hangs the kernel.
 struct XchgArgs {
   uint8_t* slab;                 // [ring][n][OBS_PACKED], or null: no exchange
-  uint32_t* done;                // [K]
   uint32_t* gathered;            // [1]
   uint32_t* timeout;             // [1]
   int ring;
@@ -179,17 +179,30 @@ __device__ __forceinline__ void xchg_wait_slab(const XchgArgs& x, uint32_t k) {
     }
   }
 }
-// One episode has finished step k and its packed row is in memory (the wave's stores have drained).  Counted in two levels: thousands of
-// system-scope atomics on ONE word serialise at ~12 ns each (8192 episodes: 100 us per step -- twice the step), so an episode bumps the
-// counter of its group (a partition of the persistent kernel, 32 neighbouring episodes of the multi-step kernels) and the group's last
-// episode adds the whole group to done[k].  The group counter of slot k % ring is reused by step k + ring, which cannot start before step
-// k is complete everywhere (xchg_wait_slab).
-__device__ __forceinline__ void xchg_count(const XchgArgs& x, uint32_t k, int group, int group_size) {
-  uint32_t* c = x.gcnt + (size_t)group * (size_t)x.ring + (k % (uint32_t)x.ring);
-  const uint32_t before = __hip_atomic_fetch_add(c, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  if (before + 1u == (uint32_t)group_size) {
+// One episode's packed row of step k is in memory (the stores that wrote it have drained): counted in the episode's group (a partition of
+// the persistent kernel, 32 neighbouring episodes of the multi-step kernels), slot k % ring.  A no-return agent-scope atomic: the wave
+// does not wait for it.  (r05 on the way here: one system-scope counter per step -- 8192 atomics on one word serialise at ~12 ns each,
+// twice the step --, then two levels with the group's last episode adding the group to it -- two dependent atomics, ~2 us per item.)
+__device__ __forceinline__ void xchg_count(const XchgArgs& x, uint32_t k, int group) {
+  (void)__hip_atomic_fetch_add(x.gcnt + (size_t)group * (size_t)x.ring + (k % (uint32_t)x.ring), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// The gate of a chunk of steps [k_lo, k_hi] on the communication stream: returns when every group has counted all its episodes in every
+// step of the chunk (counts of one episode's consecutive steps may arrive out of order: each wave counts where ITS stores have drained),
+// and hands the counters back (zero) for steps k + ring.  P > 0: the groups are the P partitions of the persistent kernel (episodes
+// g, g + P, ..), else groups of 32 neighbouring episodes.  Gives up after `ticks` and says so in *fail (the host reports it).
+__global__ __launch_bounds__(256) void k_xchg_gate(uint32_t* gcnt, int ring, int groups, int n, int P, int k_lo, int k_hi, long long ticks, uint32_t* fail) {
+  const int t = (int)threadIdx.x, steps = k_hi - k_lo + 1;
+  const long long t0 = wall_clock64();
+  for (int i = t; i < groups * steps; i += (int)blockDim.x) {
+    const int g = i / steps, k = k_lo + i % steps;
+    const int size = P > 0 ? (n - g + P - 1) / P : (n - (g << 5) < 32 ? n - (g << 5) : 32);
+    if (size <= 0) continue;
+    uint32_t* c = gcnt + (size_t)g * (size_t)ring + (k % ring);
+    while (__hip_atomic_load(c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (uint32_t)size) {
+      __builtin_amdgcn_s_sleep(64);
+      if (wall_clock64() - t0 > ticks) { __hip_atomic_store(fail, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); break; }
+    }
     __hip_atomic_store(c, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    (void)__hip_atomic_fetch_add(x.done + k, (uint32_t)group_size, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
   }
 }
 
@@ -1091,7 +1104,7 @@ __device__ __forceinline__ void run_philox_loop(StepArgs a, int K, uint32_t t0, 
       philox4_body<false, true>(a, (k > 0 ? 1 : 0) | (k == K - 1 ? 2 : 0), tid_i); }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    if (x.slab && threadIdx.x == 0) { const int e = a.e0 + (int)blockIdx.x, g = e >> 5; xchg_count(x, (uint32_t)k, g, a.n - (g << 5) < 32 ? a.n - (g << 5) : 32); }
+    if (x.slab && threadIdx.x == 0) xchg_count(x, (uint32_t)k, (a.e0 + (int)blockIdx.x) >> 5);
   }
 }
 __global__ __launch_bounds__(PT, 5) void k_run_philox(StepArgs a, int K, uint32_t t0, XchgArgs x) { run_philox_loop<5>(a, K, t0, x); }
@@ -1416,6 +1429,10 @@ __device__ __forceinline__ void persist_loop(StepArgs a, RunArgs ra, const XchgA
   bool mine = false;                     // lane 0: this CU owns `part` (claimed or adopted)
   bool stealing = false;                 // lane 0: `part` belongs to another CU of this XCD; its shared bit is set
   a.prof = nullptr; a.obs8 = nullptr; a.ext = nullptr;
+  int pend_e = -1; uint32_t pend_k = 0;  // the exchange: the item whose packed row this wave stored last and has not counted yet (its store drains with the next item)
+  auto flush_pending = [&]() {
+    if (x.slab && pend_e >= 0) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); if (lane == 0) xchg_count(x, pend_k, pend_e % ra.P); pend_e = -1; }
+  };
   for (;;) {
     int res_e = -3, res_k = 0, res_sh = 0, res_part = -1;            // -3: nothing from `part`: search
     if (lane == 0) {
@@ -1462,7 +1479,7 @@ __device__ __forceinline__ void persist_loop(StepArgs a, RunArgs ra, const XchgA
         if (r2 > best_rem || (r2 == best_rem && q2 > best_q)) { best_rem = r2; best_q = q2; best_ow = o2; }
       }
       best_rem = __builtin_amdgcn_readfirstlane(best_rem); best_q = __builtin_amdgcn_readfirstlane(best_q); best_ow = __builtin_amdgcn_readfirstlane(best_ow);
-      if (best_rem <= 0) return;                                      // nothing left anywhere this wave may touch
+      if (best_rem <= 0) { flush_pending(); return; }                 // nothing left anywhere this wave may touch
       part = best_q; mine = false; stealing = false;
       if (lane == 0) {
         if (best_ow == 0) {                                           // nobody's: adopt it (the CAS in the item path), no sharing needed unless that fails
@@ -1494,14 +1511,19 @@ __device__ __forceinline__ void persist_loop(StepArgs a, RunArgs ra, const XchgA
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     if (ra.order >= 2) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
     __syncthreads();
-    if (x.slab) {      // the exchange: this episode's packed row of step item_k into the step's slab (before the episode's next step may touch the row it is read from)
-      if constexpr (!PCG) pack_row_from_obs(x.slab + ((size_t)(item_k % (uint32_t)x.ring) * (size_t)a.n + (size_t)e) * OBS_PACKED, a.obs + (size_t)e * OBS_TOTAL, lane);
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (x.slab) {
+      if constexpr (PCG) {     // (the numpy-stream body stored the row itself, from its LDS byte row: drained by the fence above)
+        if (lane == 0) xchg_count(x, item_k, e % ra.P);
+      } else {
+        // the row this wave stored with its PREVIOUS item is in memory (this item's fence drained it): counted.  Then this episode's row of
+        // step item_k, read back from the int32 row before the episode's next step may touch it (the loads feed the store, the store is
+        // issued ahead of the progress word) -- not waited for: it drains with the wave's next item, or when the wave leaves.
+        if (lane == 0 && pend_e >= 0) xchg_count(x, pend_k, pend_e % ra.P);
+        pack_row_from_obs(x.slab + ((size_t)(item_k % (uint32_t)x.ring) * (size_t)a.n + (size_t)e) * OBS_PACKED, a.obs + (size_t)e * OBS_TOTAL, lane);
+        pend_e = e; pend_k = item_k;
+      }
     }
-    if (lane == 0) {
-      __hip_atomic_store(&ra.progress[e], item_k + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      if (x.slab) { const int pq = e % ra.P; xchg_count(x, item_k, pq, (a.n - pq + ra.P - 1) / ra.P); }
-    }
+    if (lane == 0) __hip_atomic_store(&ra.progress[e], item_k + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
 }
 __global__ __launch_bounds__(WAVE, 5) void k_run_philox1(StepArgs a, RunArgs ra, XchgArgs x) { persist_loop<false>(a, ra, x); }
@@ -1528,10 +1550,14 @@ __global__ __launch_bounds__(WAVE, 5) void k_run_philox1m(StepArgs a, int K, uin
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (x.slab) {
+      // the row of step k - 1 is in memory by now (this step's drain covered its store): counted; then this step's row, not waited for
+      if (threadIdx.x == 0 && k > 0) xchg_count(x, (uint32_t)(k - 1), e >> 5);
       pack_row_from_obs(x.slab + ((size_t)(k % x.ring) * (size_t)a.n + (size_t)e) * OBS_PACKED, a.obs + (size_t)e * OBS_TOTAL, (int)threadIdx.x);
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      if (threadIdx.x == 0) { const int g = e >> 5; xchg_count(x, (uint32_t)k, g, a.n - (g << 5) < 32 ? a.n - (g << 5) : 32); }
     }
+  }
+  if (x.slab && K > 0) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (threadIdx.x == 0) xchg_count(x, (uint32_t)(K - 1), e >> 5);
   }
 }
 
@@ -1753,11 +1779,11 @@ struct cc4_handle {
                                   // pays ~25 us to enqueue a wait, an all-gather and a publish -- more than a step of a small batch lasts)
   uint8_t* d_xslab = nullptr;     // [XRING][n][OBS_PACKED]
   uint8_t* d_xall = nullptr;      // [XRING][world * n][OBS_PACKED]
-  uint32_t* d_xflags = nullptr;   // [0] gathered, [1] timeout (what the waits poll), [2 ..] done[k]
+  uint32_t* d_xflags = nullptr;   // [0] gathered, [1] timeout (what the waits poll)
   uint32_t* d_xgcnt = nullptr;    // [groups][XRING] group counters (xchg_count)
   uint32_t* h_xtimeout = nullptr; // pinned host word the kernel raises when a wait gives up (read without a copy)
   uint32_t* d_xtimeout = nullptr; // its device address
-  int xflags_cap = 0;             // steps the done[] part holds
+  int xflags_clean = 0;           // the flags are cleared already (behind the previous call) and xev says when
   hipEvent_t xev = nullptr;
   long long xchg_calls = 0, xchg_timeouts = 0;
   int xchg_watchdog_ms = 2000;
@@ -2630,34 +2656,40 @@ static int persist_setup(cc4_handle* h) {
 // step to be complete (done[k] == episodes: the kernel counts an episode once its packed row is in memory), all-gather the chunk's
 // slabs, publish gathered = k + 1.  After the main stream's synchronisation: the communication stream drained, the watchdog flag read.
 static int xchg_begin(cc4_handle* h, int k, XchgArgs* x) {
-  if (k > h->xflags_cap) {
-    if (h->d_xflags) { HIPCHK(h, hipStreamSynchronize(h->comm_stream)); (void)hipFree(h->d_xflags); h->d_xflags = nullptr; }
-    const int cap = k < 1024 ? 1024 : k;
-    HIPCHK(h, hipMalloc(&h->d_xflags, (2 + (size_t)cap) * sizeof(uint32_t)));
-    h->xflags_cap = cap;
-  }
-  HIPCHK(h, hipMemsetAsync(h->d_xflags, 0, (2 + (size_t)k) * sizeof(uint32_t), h->stream));
+  (void)k;
   const size_t groups = (size_t)h->cfg.num_envs / 32 + 1 > (size_t)h->cus ? (size_t)h->cfg.num_envs / 32 + 1 : (size_t)h->cus;
-  if (!h->d_xgcnt) HIPCHK(h, hipMalloc(&h->d_xgcnt, groups * cc4_handle::XRING * sizeof(uint32_t)));
-  HIPCHK(h, hipMemsetAsync(h->d_xgcnt, 0, groups * cc4_handle::XRING * sizeof(uint32_t), h->stream));
+  if (!h->d_xflags) { HIPCHK(h, hipMalloc(&h->d_xflags, 2 * sizeof(uint32_t))); h->xflags_clean = 0; }
+  if (!h->d_xgcnt) { HIPCHK(h, hipMalloc(&h->d_xgcnt, groups * cc4_handle::XRING * sizeof(uint32_t))); h->xflags_clean = 0; }
   if (!h->h_xtimeout) {
     HIPCHK(h, hipHostMalloc(reinterpret_cast<void**>(&h->h_xtimeout), sizeof(uint32_t), hipHostMallocDefault));
     HIPCHK(h, hipHostGetDevicePointer(reinterpret_cast<void**>(&h->d_xtimeout), h->h_xtimeout, 0));
   }
   *h->h_xtimeout = 0;
-  HIPCHK(h, hipEventRecord(h->xev, h->stream));
+  if (!h->xflags_clean) {       // normally cleared behind the previous call already (xchg_end): nothing of it in front of this call's launch
+    HIPCHK(h, hipMemsetAsync(h->d_xflags, 0, 2 * sizeof(uint32_t), h->stream));
+    HIPCHK(h, hipMemsetAsync(h->d_xgcnt, 0, groups * cc4_handle::XRING * sizeof(uint32_t), h->stream));
+    HIPCHK(h, hipEventRecord(h->xev, h->stream));
+  }
+  h->xflags_clean = 0;
   HIPCHK(h, hipStreamWaitEvent(h->comm_stream, h->xev, 0));
   int khz = 100000;
   (void)hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, h->cfg.device_id);
-  *x = XchgArgs{h->d_xslab, h->d_xflags + 2, h->d_xflags, h->d_xflags + 1, cc4_handle::XRING, (long long)h->xchg_watchdog_ms * (khz > 0 ? khz : 100000), h->d_xgcnt, h->d_xtimeout};
+  *x = XchgArgs{h->d_xslab, h->d_xflags, h->d_xflags + 1, cc4_handle::XRING, (long long)h->xchg_watchdog_ms * (khz > 0 ? khz : 100000), h->d_xgcnt, h->d_xtimeout};
   return 0;
 }
-static int xchg_enqueue(cc4_handle* h, int k, const XchgArgs& x) {
+// form: 3 = the persistent kernel (groups = its partitions), else groups of 32 neighbouring episodes
+static int xchg_enqueue(cc4_handle* h, int k, const XchgArgs& x, int form) {
   const size_t row = (size_t)h->cfg.num_envs * OBS_PACKED;
-  const int C = h->xchg_chunk;
-  for (int c0 = 0; c0 < k; c0 += C) {
-    const int hi = (c0 + C < k ? c0 + C : k) - 1;
-    HIPCHK(h, hipStreamWaitValue32(h->comm_stream, x.done + hi, (uint32_t)h->cfg.num_envs, hipStreamWaitValueGte, 0xFFFFFFFFu));
+  const int C = h->xchg_chunk, n = h->cfg.num_envs;
+  const int P = form == 3 ? h->run_P : 0, groups = form == 3 ? h->run_P : (n + 31) / 32;
+  int khz = 100000;
+  (void)hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, h->cfg.device_id);
+  const long long gate_ticks = 30000LL * (khz > 0 ? khz : 100000);         // 30 s: a step kernel that never gets there (the host would wait for it forever anyway)
+  for (int c0 = 0, hi = 0; c0 < k; c0 = hi + 1) {
+    hi = (c0 + C < k ? c0 + C : k) - 1;
+    if (hi == k - 1 && hi > c0) --hi;       // the call's last step is a chunk of its own: behind the kernel's end only ONE all-gather is left
+    hipLaunchKernelGGL(k_xchg_gate, dim3(1), dim3(256), 0, h->comm_stream, x.gcnt, x.ring, groups, n, P, c0, hi, gate_ticks, x.timeout_host);
+    HIPCHK(h, hipGetLastError());
     if (h->comm_delay_ticks > 0) { hipLaunchKernelGGL(k_spin, dim3(1), dim3(1), 0, h->comm_stream, h->comm_delay_ticks); HIPCHK(h, hipGetLastError()); }
     if (hi > c0) (void)ncclGroupStart();
     for (int j = c0; j <= hi; ++j) {
@@ -2686,6 +2718,16 @@ static int xchg_end(cc4_handle* h, int k) {
   // launch that follows, finds what it expects
   HIPCHK(h, hipMemcpyAsync(h->d_obs8[h->obs_buf], h->d_xslab + last * row, row, hipMemcpyDeviceToDevice, h->stream));
   h->step_event_attached = false;
+  {   // the next call's flags, cleared now: its launch then has nothing in front of it (the group counters came back zero from the gates;
+      // cleared all the same when a watchdog fired: some counts may then never have been collected)
+    HIPCHK(h, hipMemsetAsync(h->d_xflags, 0, 2 * sizeof(uint32_t), h->stream));
+    if (flag) {
+      const size_t groups = (size_t)h->cfg.num_envs / 32 + 1 > (size_t)h->cus ? (size_t)h->cfg.num_envs / 32 + 1 : (size_t)h->cus;
+      HIPCHK(h, hipMemsetAsync(h->d_xgcnt, 0, groups * cc4_handle::XRING * sizeof(uint32_t), h->stream));
+    }
+    HIPCHK(h, hipEventRecord(h->xev, h->stream));
+    h->xflags_clean = 1;
+  }
   if (flag) {
     // an item waited longer than the watchdog for its slab: the exchange did not keep up at all (e.g. its kernels found no room beside the
     // one-launch kernel).  The episodes are intact -- a wait that gives up only stops protecting slabs, so gathers of this call may have
@@ -2795,7 +2837,7 @@ static int run_random_steps_impl(cc4_handle* h, uint64_t seed0, uint32_t t0, int
     h->main_ahead = h->ngroups > 1;
     if (exchange) {
       auto g0 = std::chrono::steady_clock::now();
-      if (xchg_enqueue(h, k, x)) return -1;
+      if (xchg_enqueue(h, k, x, form)) return -1;
       h->stat_gather_us += std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - g0).count();
     }
     HIPCHK(h, hipStreamSynchronize(h->stream));

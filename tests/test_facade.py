@@ -194,3 +194,39 @@ def test_router_actions_given_as_objects_match_the_reference(oracle_lib):
     assert A.action_index(A.Analyse(session=0, agent='blue_agent_0', hostname='restricted_zone_a_subnet_server_host_0'), labels) == 0
     with pytest.raises(ValueError):
         A.action_index(A.Restore(session=0, agent='blue_agent_0', hostname='admin_network_subnet_router'), labels)
+
+
+@pytest.mark.gpu
+def test_event_log_on_demand_equals_the_always_on_log():
+    """The fixed-action wrappers run their episode with the event log OFF (flat observations need none; the logging build of the
+    numpy-stream kernel costs one episode ~30 us per step) and repeat a step with the log on when somebody asks what happened in it
+    (cc4_keep_previous / cc4_replay_logged).  Same answers as an episode that logged all along: every blue agent's dict
+    observation, the true state, last actions -- asked after every step, after every third step, and never (then nothing is replayed) --
+    and the same flat observations, rewards and generator position in all three."""
+    sg = EnterpriseScenarioGenerator(blue_agent_class=SleepAgent, green_agent_class=EnterpriseGreenAgent, red_agent_class=FiniteStateRedAgent, steps=80)
+    raw = CybORG(sg, seed=77)                      # the log stays on
+    envs = [BlueFlatWrapper(CybORG(sg, seed=77)) for _ in range(3)]
+    assert not raw._lazy_log and all(w.env._lazy_log for w in envs)
+    raw.reset(); [w.reset() for w in envs]
+    labels = envs[0].action_labels
+    rng = np.random.default_rng(5)
+    for t in range(70):
+        acts = {a: int(rng.integers(len(labels(a)))) for a in envs[0].possible_agents}
+        codes = [raw._blue_code(a, acts[a], labels(a)) for a in raw.agents_blue]
+        o_raw, r_raw, d_raw = raw._submit({}, None, blue_codes=codes)
+        outs = [w.step(acts) for w in envs]
+        for w, (o, r, *_rest) in zip(envs, outs):
+            assert all(np.array_equal(o[a], outs[0][0][a]) for a in o) and r == outs[0][1]
+        flat = np.concatenate([outs[0][0][a] for a in envs[0].possible_agents])
+        assert np.array_equal(flat, o_raw[0].astype(np.int64)) and float(r_raw[0]) == outs[0][1]['blue_agent_0']
+        want = {a: raw.get_observation(a) for a in raw.agents_blue}
+        for k, w in enumerate(envs[:2]):
+            if k == 0 or t % 3 == 2:
+                got = {a: w.env.get_observation(a) for a in raw.agents_blue}
+                assert str(got) == str(want), (t, k)
+                assert w.env.get_true_state() == raw.get_true_state(), (t, k)
+                assert [str(w.env.get_last_action(a)) for a in raw.agents_blue] == [str(raw.get_last_action(a)) for a in raw.agents_blue], (t, k)
+    assert np.array_equal(raw.vec.rng_state(), envs[0].env.vec.rng_state()) and np.array_equal(raw.vec.rng_state(), envs[2].env.vec.rng_state())
+    for w in envs:
+        w.close()
+    raw.vec.close()
