@@ -159,17 +159,20 @@ struct XchgArgs {
   uint32_t* timeout_host;        // the same flag in pinned host memory, WRITTEN only (the host reads it without a copy; the waits poll the
                                  // device word: a thousand blocks polling a word across PCIe cost a 1024-episode batch 12 us per step)
 };
-// lane / thread 0 only
-__device__ __forceinline__ void xchg_wait_slab(const XchgArgs& x, uint32_t k) {
+// lane / thread 0 only.  `seen` = the highest value of *gathered this wave has read so far (it only grows): the word is read again --
+// an uncached round trip to memory, ~2 us in the middle of the item hand-over -- only when the value at hand does not cover step k.
+__device__ __forceinline__ void xchg_wait_slab(const XchgArgs& x, uint32_t k, uint32_t& seen) {
   if (k < (uint32_t)x.ring) return;
   const uint32_t need = k - (uint32_t)x.ring + 1u;
-  if (__hip_atomic_load(x.gathered, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) >= need) return;
+  if (seen >= need) return;
+  seen = __hip_atomic_load(x.gathered, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  if (seen >= need) return;
   if (__hip_atomic_load(x.timeout, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM)) return;
   // Thousands of waves polling one uncached word starve the very write they wait for (tools/micro/ring_protocol.hip: a saturated chip
   // of spinning pollers took 57 us per exchange step instead of < 16): the interval between two polls of a wave doubles from ~3 us to ~50 us.
   const long long w0 = wall_clock64();
   int naps = 1;
-  while (__hip_atomic_load(x.gathered, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) < need) {
+  while ((seen = __hip_atomic_load(x.gathered, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM)) < need) {
     for (int i = 0; i < naps; ++i) __builtin_amdgcn_s_sleep(127);
     if (naps < 16) naps <<= 1;
     if (wall_clock64() - w0 > x.wait_ticks || __hip_atomic_load(x.timeout, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM)) {
@@ -1092,11 +1095,12 @@ template <int MINB>
 __device__ __forceinline__ void run_philox_loop(StepArgs a, int K, uint32_t t0, const XchgArgs x) {
   a.prof = nullptr; a.obs8 = nullptr; a.ext = nullptr;
   const int full0 = a.full_obs;
+  uint32_t seen = 0;
   for (int k = 0; k < K; ++k) {
     a.rand_t = t0 + (uint32_t)k;
     a.full_obs = k == 0 ? full0 : 0;
     if (x.slab) {      // with the exchange: this step's slab of the ring, free once its previous occupant (step k - ring) has been gathered
-      if (threadIdx.x == 0) xchg_wait_slab(x, (uint32_t)k);
+      if (threadIdx.x == 0) xchg_wait_slab(x, (uint32_t)k, seen);
       a.obs8 = x.slab + (size_t)(k % x.ring) * (size_t)a.n * OBS_PACKED;
       __syncthreads();
     }
@@ -1429,6 +1433,7 @@ __device__ __forceinline__ void persist_loop(StepArgs a, RunArgs ra, const XchgA
   bool mine = false;                     // lane 0: this CU owns `part` (claimed or adopted)
   bool stealing = false;                 // lane 0: `part` belongs to another CU of this XCD; its shared bit is set
   a.prof = nullptr; a.obs8 = nullptr; a.ext = nullptr;
+  uint32_t seen_gathered = 0;
   int pend_e = -1; uint32_t pend_k = 0;  // the exchange: the item whose packed row this wave stored last and has not counted yet (its store drains with the next item)
   auto flush_pending = [&]() {
     if (x.slab && pend_e >= 0) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); if (lane == 0) xchg_count(x, pend_k, pend_e % ra.P); pend_e = -1; }
@@ -1450,7 +1455,7 @@ __device__ __forceinline__ void persist_loop(StepArgs a, RunArgs ra, const XchgA
           const int k = (int)(t / (uint32_t)ne), ee = part + (int)(t % (uint32_t)ne) * ra.P;
           while (__hip_atomic_load(&ra.progress[ee], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (uint32_t)k) __builtin_amdgcn_s_sleep(8);
           __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");      // nothing the item reads may be read ahead of the flag (compiler and wave)
-          if (x.slab) xchg_wait_slab(x, (uint32_t)k);                  // the exchange: slab k % ring must have been gathered (tickets are step-major: normally long ago)
+          if (x.slab) xchg_wait_slab(x, (uint32_t)k, seen_gathered);   // the exchange: slab k % ring must have been gathered (tickets are step-major: normally long ago)
           res_e = ee; res_k = k; res_sh = (thief || (tr & TK_SHARED)) ? 1 : 0;
         }
       }
@@ -1539,9 +1544,10 @@ __global__ __launch_bounds__(WAVE) void k_run_pcg(StepArgs a, RunArgs ra, XchgAr
 __global__ __launch_bounds__(WAVE, 5) void k_run_philox1m(StepArgs a, int K, uint32_t t0, XchgArgs x) {
   a.prof = nullptr; a.obs8 = nullptr; a.ext = nullptr;
   const int e = (int)blockIdx.x;
+  uint32_t seen = 0;
   for (int k = 0; k < K; ++k) {
     if (x.slab) {
-      if (threadIdx.x == 0) xchg_wait_slab(x, (uint32_t)k);
+      if (threadIdx.x == 0) xchg_wait_slab(x, (uint32_t)k, seen);
       __syncthreads();
     }
     int lane_i = (int)threadIdx.x;
