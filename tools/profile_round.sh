@@ -16,15 +16,8 @@ rocprofv3 --kernel-trace --stats -d $OUT/stats1024 -- $BENCH --total-envs 1024 -
 python tools/rocpd_summary.py stats $OUT/stats1024 $OUT/${TAG}_kernel_stats_1024env.txt > /dev/null      # k_run_philox: one launch = the 500 steps of a timed region
 CC4_MULTISTEP=0 rocprofv3 --kernel-trace --stats -d $OUT/stats1024ps -- $BENCH --total-envs 1024 > $OUT/bench_stats1024_per_step.json 2> $OUT/stats1024ps.err
 python tools/rocpd_summary.py stats $OUT/stats1024ps $OUT/${TAG}_kernel_stats_1024env_per_step_launches.txt > /dev/null
-# 2. HBM traffic: separate --pmc passes (FETCH_SIZE, WRITE_SIZE), kernel-trace only -- of the ONE-LAUNCH kernels the timed regions run (r05:
-# VERDICT r04 weak #4): a launch = K steps of the whole batch, bytes per step = bytes of the launch / K (rocpd_summary.py pmc_run)
-for NK in "8192 100" "1024 100" "32768 50"; do
-  set -- $NK; N=$1; K=$2
-  rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $OUT/fetch$N -- $BENCH --total-envs $N --steps $K --warmup 5 --min-seconds 0.05 > /dev/null 2> $OUT/fetch$N.err
-  rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $OUT/write$N -- $BENCH --total-envs $N --steps $K --warmup 5 --min-seconds 0.05 > $OUT/bench_pmc$N.json 2> $OUT/write$N.err
-  KN=$(python -c "import json,sys; d=[json.loads(l) for l in open('$OUT/bench_pmc$N.json') if l.startswith('{')][0]; print(d['roofline']['kernel'])")
-  python tools/rocpd_summary.py pmc_run $OUT/fetch$N $OUT/write$N $KN $OUT/${TAG}_pmc.json $N $K > /dev/null
-done
+# 2. HBM traffic of the one-launch kernels the timed regions run (r05: VERDICT r04 weak #4)
+bash tools/pmc_run_kernels.sh $TAG > /dev/null
 export CC4_PERSIST=0     # (the instruction-mix and phase passes below read the per-step kernel)
 # 3. instruction mix (per-step kernel: CC4_PERSIST=0 stays) / issue utilisation at 8192 episodes (separate passes)
 rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS -d $OUT/mixA -- $BENCH --min-seconds 0.05 > /dev/null 2> $OUT/mixA.err

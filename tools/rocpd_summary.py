@@ -115,7 +115,7 @@ def counters(kern, out, dirs):
 if __name__ == '__main__':
     if sys.argv[1] == 'pmc_run':
         pmc_run(sys.argv[2], sys.argv[3], sys.argv[4], sys.argv[5], int(sys.argv[6]), int(sys.argv[7]))
-    if sys.argv[1] == 'pmc_step':
+    elif sys.argv[1] == 'pmc_step':
         pmc_step(sys.argv[2], sys.argv[3], sys.argv[4], sys.argv[5], int(sys.argv[6]), int(sys.argv[7]))
     elif sys.argv[1] == 'counters':
         counters(sys.argv[2], sys.argv[3], sys.argv[4:])
