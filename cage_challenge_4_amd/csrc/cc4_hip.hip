@@ -1423,6 +1423,12 @@ __global__ __launch_bounds__(WAVE, CC4_LEAN_MINW) void k_step_philox1(StepArgs a
 // and the thieves' alike.  Items handed out before the bit was set were all the owner's own and read what that CU wrote itself.
 // Never across XCDs: their L2s do not agree without a write-back.
 constexpr uint32_t TK_SHARED = 0x80000000u;
+// register budget of the persistent counter-mode kernel in waves per SIMD: 5 (88 VGPRs, nothing spilled: 20 waves per CU) or 6 (80 VGPRs, ten
+// spilled: 24 by registers, 21 by LDS -- six 1280-byte granules per wave).  Measured (profiles/r05_persist_21_waves.txt, 8192 episodes):
+// K = 500: 952 vs 939-948 M, K = 20: 816 vs 809-825 M, 16384 episodes 934 vs 927 M -- inside the box-to-box spread: 5 stays.
+#ifndef CC4_PERSIST_MINW
+#define CC4_PERSIST_MINW 5
+#endif
 template <bool PCG>
 __device__ __forceinline__ void persist_loop(StepArgs a, RunArgs ra, const XchgArgs x) {
   // (the item travels from lane 0 to the wave through v_readfirstlane, not through LDS)
@@ -1531,7 +1537,7 @@ __device__ __forceinline__ void persist_loop(StepArgs a, RunArgs ra, const XchgA
     if (lane == 0) __hip_atomic_store(&ra.progress[e], item_k + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
 }
-__global__ __launch_bounds__(WAVE, 5) void k_run_philox1(StepArgs a, RunArgs ra, XchgArgs x) { persist_loop<false>(a, ra, x); }
+__global__ __launch_bounds__(WAVE, CC4_PERSIST_MINW) void k_run_philox1(StepArgs a, RunArgs ra, XchgArgs x) { persist_loop<false>(a, ra, x); }
 #ifndef CC4_DEV_FAST
 // the same schedule around the numpy-stream step (k_step's body): the bit-exact mode's large batches
 __global__ __launch_bounds__(WAVE) void k_run_pcg(StepArgs a, RunArgs ra, XchgArgs x) { persist_loop<true>(a, ra, x); }
