@@ -1787,7 +1787,7 @@ struct cc4_handle {
   // communication stream follows the kernel's per-step counters (xchg_*)
   static constexpr int XRING = 32;
   bool xchg_on = false;           // cc4_comm_init; CC4_EXCHANGE_INKERNEL=0 keeps the per-step launches
-  int xchg_chunk = 8;             // steps per wait / publish on the communication stream (CC4_EXCHANGE_CHUNK; their all-gathers go out as ONE RCCL group: the host
+  int xchg_chunk = 8;             // steps per gate / publish on the communication stream (CC4_EXCHANGE_CHUNK; their slabs go out in ONE all-gather: the host
                                   // pays ~25 us to enqueue a wait, an all-gather and a publish -- more than a step of a small batch lasts)
   uint8_t* d_xslab = nullptr;     // [XRING][n][OBS_PACKED]
   uint8_t* d_xall = nullptr;      // [XRING][world * n][OBS_PACKED]
@@ -2700,18 +2700,20 @@ static int xchg_enqueue(cc4_handle* h, int k, const XchgArgs& x, int form) {
   for (int c0 = 0, hi = 0; c0 < k; c0 = hi + 1) {
     hi = (c0 + C < k ? c0 + C : k) - 1;
     if (hi == k - 1 && hi > c0) --hi;       // the call's last step is a chunk of its own: behind the kernel's end only ONE all-gather is left
+    if (c0 % cc4_handle::XRING + (hi - c0) >= cc4_handle::XRING) hi = c0 + cc4_handle::XRING - 1 - c0 % cc4_handle::XRING;     // a chunk's slabs are neighbours in the ring
     hipLaunchKernelGGL(k_xchg_gate, dim3(1), dim3(256), 0, h->comm_stream, x.gcnt, x.ring, groups, n, P, c0, hi, gate_ticks, x.timeout_host);
     HIPCHK(h, hipGetLastError());
     if (h->comm_delay_ticks > 0) { hipLaunchKernelGGL(k_spin, dim3(1), dim3(1), 0, h->comm_stream, h->comm_delay_ticks); HIPCHK(h, hipGetLastError()); }
-    if (hi > c0) (void)ncclGroupStart();
-    for (int j = c0; j <= hi; ++j) {
-      const int slot = j % cc4_handle::XRING;
-      ncclResult_t r = ncclAllGather(h->d_xslab + slot * row, h->d_xall + slot * row * (size_t)h->world, row, ncclUint8, h->comm, h->comm_stream);
-      if (r != ncclSuccess) { h->err = std::string("ncclAllGather: ") + ncclGetErrorString(r); return -1; }
-    }
-    if (hi > c0) { ncclResult_t r = ncclGroupEnd(); if (r != ncclSuccess) { h->err = std::string("ncclGroupEnd: ") + ncclGetErrorString(r); return -1; } }
-    if (h->d_xlog) for (int j = c0; j <= hi && h->xlog_n < h->xlog_cap; ++j, ++h->xlog_n)     // debug: keep every gathered slab (cc4_debug_gather_log)
-      HIPCHK(h, hipMemcpyAsync(h->d_xlog + (size_t)h->xlog_n * row * h->world, h->d_xall + (j % cc4_handle::XRING) * row * (size_t)h->world, row * h->world, hipMemcpyDeviceToDevice, h->comm_stream));
+    // ONE all-gather for the chunk's m neighbouring slabs (an ncclAllGather costs the host ~10 us to enqueue, grouped or not: eight of them
+    // per chunk were as much as the eight steps of a 1024-episode batch last).  The gathered block of a chunk is rank-major: rank r's rows of
+    // the chunk's step j at ((r * m + j - c0) * N) -- for a chunk of one step, the call's last among them, plain [world * N] rows.
+    const int s0 = c0 % cc4_handle::XRING, m = hi - c0 + 1;
+    uint8_t* const block = h->d_xall + (size_t)s0 * row * (size_t)h->world;
+    ncclResult_t r = ncclAllGather(h->d_xslab + (size_t)s0 * row, block, (size_t)m * row, ncclUint8, h->comm, h->comm_stream);
+    if (r != ncclSuccess) { h->err = std::string("ncclAllGather: ") + ncclGetErrorString(r); return -1; }
+    if (h->d_xlog) for (int j = c0; j <= hi && h->xlog_n < h->xlog_cap; ++j, ++h->xlog_n)     // debug: keep every step's gathered rows as [world * N] (cc4_debug_gather_log)
+      for (int rk = 0; rk < h->world; ++rk)
+        HIPCHK(h, hipMemcpyAsync(h->d_xlog + ((size_t)h->xlog_n * h->world + rk) * row, block + ((size_t)rk * m + (size_t)(j - c0)) * row, row, hipMemcpyDeviceToDevice, h->comm_stream));
     HIPCHK(h, hipStreamWriteValue32(h->comm_stream, x.gathered, (uint32_t)(hi + 1), 0));
   }
   h->gathers_issued += k;
@@ -2724,7 +2726,7 @@ static int xchg_end(cc4_handle* h, int k) {
   const uint32_t flag = *reinterpret_cast<volatile uint32_t*>(h->h_xtimeout);      // (both streams are drained: the kernel's system-scope store has landed)
   h->xchg_calls++;
   const int last = (k - 1) % cc4_handle::XRING;
-  h->last_gathered = h->d_xall + last * row * (size_t)h->world;
+  h->last_gathered = h->d_xall + last * row * (size_t)h->world;      // (the call's last step is a chunk of its own: plain [world * N] rows)
   h->gather_buf = -2;                               // (not one of the per-step ring's buffers: last_gathered says where)
   // the per-step path's current buffer holds the observations of the last step as well: an explicit cc4_allgather_obs, or a per-step
   // launch that follows, finds what it expects
