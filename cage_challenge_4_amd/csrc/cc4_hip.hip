@@ -1516,9 +1516,13 @@ __device__ __forceinline__ void persist_loop(StepArgs a, RunArgs ra, const XchgA
       philox1_body<false, true>(a, e, ra.t0 + item_k, item_k, lane_i);      // (a.obs8 is null: the packed row is written below, behind the drain)
     }
     // the item is done when everything it wrote has left this wave: then the next step of the episode may start (on this XCD)
-    // Release: every lane drains its own stores (workgroup-scope release = s_waitcnt vmcnt(0) on gfx950 without tgsplit: the vector L1 is
-    // write-through, so a drained store is in the XCD's L2), the barrier collects the lanes, lane 0 publishes.  The consumer is a wave of
-    // the same CU (same L1) unless the partition is shared, in which case it drops its L1 first (agent-scope acquire above).
+    // Release: every lane DRAINS its own stores -- an explicit s_waitcnt vmcnt(0): the vector L1 is write-through, so a drained store is in
+    // the XCD's L2 --, the barrier collects the lanes, lane 0 publishes.  The consumer is a wave of the same CU unless the partition is
+    // shared, in which case it drops its L1 first (agent-scope acquire above).  The workgroup-scope fence beside it only pins the compiler:
+    // without tgsplit the backend emits NO vmcnt wait for it (waves of a work-group share a CU), and the episode's rows and its progress
+    // word sit in different L2 channels -- with the fence alone the word can land first.  (r05 ran that way for a day: one disagreement in
+    // ~60 self-checked calls, CC4_PERSIST_VERIFY, 5632 episodes, hot row of one episode after a 10-step call.)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     if (ra.order >= 2) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
     __syncthreads();
