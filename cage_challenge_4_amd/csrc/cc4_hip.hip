@@ -1156,15 +1156,6 @@ struct RunArgs {
   int P, K;
   uint32_t t0;                 // action time of step 0 (random_blue_action)
   unsigned long long* timeline; // debug (CC4_PERSIST_TIMELINE=1): per wave [entry, first item start, last item end, items] in wall_clock64 ticks, or null
-  // The ready queue (CC4_PERSIST_QUEUE, default on): instead of handing out (episode, step) items in step-major order and letting a wave spin
-  // until its item's predecessor is done, a partition keeps a FIFO of the episodes that are READY -- not being stepped by anybody.  Ticket t of
-  // a partition with ne episodes: t < ne is episode t's first step of the call; ticket ne + i is the i-th episode PUSHED BACK by a wave that
-  // finished one of its steps (slots[i % cap] = i + 1 | next step | episode, one 8-byte word: whoever sees the index sees the rest).  A wave
-  // never holds an item that cannot run; what it may have to wait for is ANY episode of the partition finishing a step.  (The step-major
-  // form lost 6 % of a 20-step call to chains of waves each waiting for the one before: tools/persist_timeline.py)
-  uint32_t* tail;              // [P] episodes pushed back so far
-  unsigned long long* slots;   // [P][cap]
-  int cap;                     // slots per partition (a power of two >= 2 x episodes per partition), 0: step-major tickets + progress words
   int order;                   // memory ordering of the hand-over between two items of an episode (CC4_PERSIST_ORDER, persist_loop):
                                // 0 = ordering only (same CU: the waves of a CU share its L1), 1 = every item starts with an agent-scope acquire,
                                // 2 = ... and ends with an agent-scope release
@@ -1471,20 +1462,10 @@ __device__ __forceinline__ void persist_loop(StepArgs a, RunArgs ra, const XchgA
         const uint32_t tr = __hip_atomic_fetch_add(&ra.ticket[part], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         const uint32_t t = tr & ~TK_SHARED;
         if (t < (uint32_t)(ne * ra.K)) {
-          int k, ee;
-          if (ra.cap) {
-            if (t < (uint32_t)ne) { k = 0; ee = part + (int)t * ra.P; }
-            else {
-              const uint32_t i = t - (uint32_t)ne;
-              unsigned long long* sl = ra.slots + (size_t)part * (size_t)ra.cap + (i & (uint32_t)(ra.cap - 1));
-              unsigned long long w;
-              while ((uint32_t)((w = __hip_atomic_load(sl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) >> 32) != i + 1u) __builtin_amdgcn_s_sleep(8);
-              k = (int)((w >> 16) & 0xFFFFu); ee = part + (int)(w & 0xFFFFu) * ra.P;
-            }
-          } else {
-            k = (int)(t / (uint32_t)ne); ee = part + (int)(t % (uint32_t)ne) * ra.P;
-            while (__hip_atomic_load(&ra.progress[ee], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (uint32_t)k) __builtin_amdgcn_s_sleep(8);
-          }
+          // (a ready queue per partition -- a wave never holds an item whose predecessor is still running -- was built and measured in r05:
+          // bit-exact, 2-3.5 % slower, and the launch's tail stayed: profiles/r05_ready_queue_ab.txt)
+          const int k = (int)(t / (uint32_t)ne), ee = part + (int)(t % (uint32_t)ne) * ra.P;
+          while (__hip_atomic_load(&ra.progress[ee], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (uint32_t)k) __builtin_amdgcn_s_sleep(8);
           __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");      // nothing the item reads may be read ahead of the flag (compiler and wave)
           if (x.slab) xchg_wait_slab(x, (uint32_t)k, seen_gathered);   // the exchange: slab k % ring must have been gathered (tickets are step-major: normally long ago)
           res_e = ee; res_k = k; res_sh = (thief || (tr & TK_SHARED)) ? 1 : 0;
@@ -1564,15 +1545,7 @@ __device__ __forceinline__ void persist_loop(StepArgs a, RunArgs ra, const XchgA
         pend_e = e; pend_k = item_k;
       }
     }
-    if (lane == 0) {
-      if (!ra.cap) __hip_atomic_store(&ra.progress[e], item_k + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      else if ((int)item_k + 1 < ra.K) {      // the episode is ready for its next step: back into its partition's queue
-        const int pq = e % ra.P;
-        const uint32_t i = __hip_atomic_fetch_add(&ra.tail[pq], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __hip_atomic_store(ra.slots + (size_t)pq * (size_t)ra.cap + (i & (uint32_t)(ra.cap - 1)),
-                           ((unsigned long long)(i + 1u) << 32) | ((unsigned long long)(item_k + 1u) << 16) | (unsigned long long)(e / ra.P), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      }
-    }
+    if (lane == 0) __hip_atomic_store(&ra.progress[e], item_k + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (ra.timeline) { tl_last = wall_clock64(); ++tl_items; }
   }
 }
@@ -1819,7 +1792,7 @@ struct cc4_handle {
   uint32_t* d_run = nullptr;      // [P ticket | P owner | n progress]
   int32_t* d_slot_part = nullptr; // [CC4_SLOTS] CU slot id -> 1 + partition (persist_setup)
   unsigned long long* d_timeline = nullptr;   // CC4_PERSIST_TIMELINE: per-wave time stamps of the current persistent launch
-  int run_cap = 0; size_t run_words = 0;     // slots per partition of the ready queue; words of d_run
+  size_t run_words = 0;           // words of d_run
   int run_P = 0, run_grid = 0;    // partitions (= CUs that take waves), waves per launch; 0: the persistent path is off
   int persist_state = -1;         // -1 off / unavailable, 0 not set up yet (persist_setup on first use), 1 on
   int persist_order = 0;          // RunArgs.order (CC4_PERSIST_ORDER)
@@ -2700,10 +2673,7 @@ static int persist_setup(cc4_handle* h) {
   if (!h->d_slot_part) HIPCHK(h, hipMalloc(&h->d_slot_part, CC4_SLOTS * sizeof(int32_t)));
   HIPCHK(h, hipMemcpy(h->d_slot_part, table.data(), CC4_SLOTS * sizeof(int32_t), hipMemcpyHostToDevice));
   if (h->d_run) { (void)hipFree(h->d_run); h->d_run = nullptr; }
-  // [P ticket | P owner | n progress | P tail | P x cap slots (8 bytes each)]: one memset per call
-  int cap = 2; while (cap < 2 * (int)((n + P - 1) / P)) cap <<= 1;
-  h->run_cap = cap;
-  h->run_words = 2 * (size_t)P + n + (size_t)P + 1 + 2 * (size_t)P * cap;       // (+1: the slots start on an 8-byte boundary)
+  h->run_words = 2 * (size_t)P + n;                                            // [P ticket | P owner | n progress]: one memset per call
   HIPCHK(h, hipMalloc(&h->d_run, h->run_words * sizeof(uint32_t)));
   h->persist_state = 1;
   return 0;
@@ -2881,14 +2851,10 @@ static int run_random_steps_impl(cc4_handle* h, uint64_t seed0, uint32_t t0, int
       hipExtLaunchKernelGGL(k_run_philox1m, dim3(h->cfg.num_envs), dim3(WAVE), offsetof(EnvState, hd), h->stream, e0, e1, 0, a, (int)k, t0, x);
     } else {
       HIPCHK(h, hipMemsetAsync(h->d_run, 0, h->run_words * sizeof(uint32_t), h->stream));
-      uint32_t* const q_tail = h->d_run + 2 * (size_t)h->run_P + (size_t)h->cfg.num_envs;
-      size_t q_off = 2 * (size_t)h->run_P + (size_t)h->cfg.num_envs + (size_t)h->run_P; q_off += q_off & 1;
-      const bool queue = h->cfg.num_envs / h->run_P < 65536 && k < 65536 && !(getenv("CC4_PERSIST_QUEUE") && atoi(getenv("CC4_PERSIST_QUEUE")) == 0);
       unsigned long long* d_tl = nullptr;
       if (getenv("CC4_PERSIST_TIMELINE")) { HIPCHK(h, hipMalloc(&d_tl, 4 * sizeof(unsigned long long) * (size_t)h->run_grid)); HIPCHK(h, hipMemsetAsync(d_tl, 0, 4 * sizeof(unsigned long long) * (size_t)h->run_grid, h->stream)); }
       h->d_timeline = d_tl;
-      RunArgs ra{h->d_run, h->d_run + 2 * h->run_P, reinterpret_cast<int32_t*>(h->d_run + h->run_P), h->d_slot_part, h->run_P, k, t0, d_tl,
-                 q_tail, reinterpret_cast<unsigned long long*>(h->d_run + q_off), queue ? h->run_cap : 0, h->persist_order};
+      RunArgs ra{h->d_run, h->d_run + 2 * h->run_P, reinterpret_cast<int32_t*>(h->d_run + h->run_P), h->d_slot_part, h->run_P, k, t0, d_tl, h->persist_order};
 #ifndef CC4_DEV_FAST
       if (h->cfg.rng_mode == 0) hipExtLaunchKernelGGL(k_run_pcg, dim3(h->run_grid), dim3(WAVE), offsetof(EnvState, hd), h->stream, e0, e1, 0, a, ra, x);
       else
