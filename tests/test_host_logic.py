@@ -94,3 +94,59 @@ def test_flat_obs_enumerations_agree():
             o.lib.cc4o_obs_by_table(o._h, i, c.ctypes.data_as(ctypes.c_void_p))
             fast = c >= 0
             assert fast.sum() == 384 and np.array_equal(c[fast], obs[i][fast]), (t, i)
+
+
+def test_builtin_policies_are_selected_by_class_name_and_foreign_classes_can_opt_out():
+    """the reference's own CybORG.Agents.FiniteStateRedAgent (a class of another module with a built-in's name) must select the
+    device policy, not silently fall to the host slow path; a foreign class of that name is told so; host_agents=True (or the class attribute
+    cc4_host_agent) sends it to the host on purpose; a class of another name always acts from the host."""
+    import warnings
+
+    class FiniteStateRedAgent:                     # a user's class that happens to carry a built-in's name
+        def get_action(self, observation, action_space):
+            return None
+    FiniteStateRedAgent.__module__ = 'my_agents'
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter('always')
+        sg = W.EnterpriseScenarioGenerator(red_agent_class=FiniteStateRedAgent)
+    assert sg.custom == {} and sg.red_policy == 0 and any('built-in FiniteStateRedAgent policy' in str(x.message) for x in w)
+    ref_like = type('FiniteStateRedAgent', (), {'get_action': lambda self, o, a: None})
+    ref_like.__module__ = 'CybORG.Agents.SimpleAgents.FiniteStateRedAgent'      # the reference's own class: no warning, the device policy
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter('always')
+        sg = W.EnterpriseScenarioGenerator(red_agent_class=ref_like)
+    assert sg.custom == {} and sg.red_policy == 0 and not w
+    sg = W.EnterpriseScenarioGenerator(red_agent_class=FiniteStateRedAgent, host_agents=True)
+    assert sg.custom == {'red': FiniteStateRedAgent} and sg.red_policy == 1
+    FiniteStateRedAgent.cc4_host_agent = True
+    assert W.EnterpriseScenarioGenerator(red_agent_class=FiniteStateRedAgent).custom == {'red': FiniteStateRedAgent}
+    other = type('ScriptedRed', (), {'get_action': lambda self, o, a: None})
+    assert W.EnterpriseScenarioGenerator(red_agent_class=other).custom == {'red': other}
+    with pytest.raises(TypeError):
+        W.EnterpriseScenarioGenerator(red_agent_class=type('NoPolicy', (), {}))
+
+
+def test_control_plane_never_hands_back_a_plane_of_another_kind(monkeypatch):
+    """control_plane() caches one plane per process; a later call that asks for another kind (a SoloPlane cached at world
+    size 1, then force=True) must raise instead of returning the cached one silently."""
+    from cage_challenge_4_amd import distributed as D
+    monkeypatch.setattr(D, '_PLANE', None)
+    for k in ('RANK', 'WORLD_SIZE', 'CC4_CONTROL_PLANE'):
+        monkeypatch.delenv(k, raising=False)
+    solo = D.control_plane()
+    assert isinstance(solo, D.SoloPlane) and D.control_plane() is solo
+    with pytest.raises(RuntimeError, match="already runs a 'solo' plane"):
+        D.control_plane(force=True)
+    monkeypatch.setattr(D, '_PLANE', None)
+
+
+def test_event_log_stays_on_for_backends_without_the_replay(oracle_lib):
+    """The fixed-action wrappers switch the event log to on-demand only where the engine can repeat a step with the log on
+    (cc4_keep_previous / cc4_replay_logged); on the CPU oracle of the tests it simply stays on, and dict observations keep working."""
+    from oracle_binding import OracleVecEnv
+    sg = W.EnterpriseScenarioGenerator(blue_agent_class=W.SleepAgent, green_agent_class=W.EnterpriseGreenAgent, red_agent_class=W.FiniteStateRedAgent, steps=30)
+    env = W.BlueFlatWrapper(W.CybORG(sg, seed=5, vec_factory=OracleVecEnv))
+    assert not env.env._lazy_log
+    env.reset()
+    env.step({a: 0 for a in env.possible_agents})
+    assert 'success' in env.env.get_observation('blue_agent_0')
