@@ -1101,14 +1101,24 @@ __device__ __forceinline__ void run_philox_loop(StepArgs a, int K, uint32_t t0, 
     a.full_obs = k == 0 ? full0 : 0;
     if (x.slab) {      // with the exchange: this step's slab of the ring, free once its previous occupant (step k - ring) has been gathered
       if (threadIdx.x == 0) xchg_wait_slab(x, (uint32_t)k, seen);
-      a.obs8 = x.slab + (size_t)(k % x.ring) * (size_t)a.n * OBS_PACKED;
       __syncthreads();
     }
     { int tid_i = (int)threadIdx.x; asm volatile("" : "+v"(tid_i));
-      philox4_body<false, true>(a, (k > 0 ? 1 : 0) | (k == K - 1 ? 2 : 0), tid_i); }
+      philox4_body<false, true>(a, (k > 0 ? 1 : 0) | (k == K - 1 ? 2 : 0), tid_i); }      // (a.obs8 stays null: no byte row, incremental encode)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    if (x.slab && threadIdx.x == 0) xchg_count(x, (uint32_t)k, (a.e0 + (int)blockIdx.x) >> 5);
+    if (x.slab) {
+      // as in the one-wave loops: the row of step k - 1 is in memory by now (this step's drain covered its store) and is counted; this step's
+      // row is packed from the int32 row the block has just drained and stored without waiting (a system-scope store takes ~1.5 us to land:
+      // inside the drain it was 1.4 us of every step)
+      const int e = a.e0 + (int)blockIdx.x;
+      if (threadIdx.x == 0 && k > 0) xchg_count(x, (uint32_t)(k - 1), e >> 5);
+      if (threadIdx.x < WAVE) pack_row_from_obs(x.slab + ((size_t)(k % x.ring) * (size_t)a.n + (size_t)e) * OBS_PACKED, a.obs + (size_t)e * OBS_TOTAL, (int)threadIdx.x);
+    }
+  }
+  if (x.slab && K > 0) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (threadIdx.x == 0) xchg_count(x, (uint32_t)(K - 1), (a.e0 + (int)blockIdx.x) >> 5);
   }
 }
 __global__ __launch_bounds__(PT, 5) void k_run_philox(StepArgs a, int K, uint32_t t0, XchgArgs x) { run_philox_loop<5>(a, K, t0, x); }

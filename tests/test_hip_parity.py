@@ -455,9 +455,9 @@ def test_observation_ring_survives_a_slow_exchange(n, groups, monkeypatch):
     dev.close()
 
 
-@pytest.mark.parametrize('n,mode,run_kernel,delay_us', [(1024, 1, 'k_run_philox', 1500), (2048, 1, 'k_run_philox1m', 0),
+@pytest.mark.parametrize('n,mode,run_kernel,delay_us', [(1000, 1, 'k_run_philox', 1500), (2000, 1, 'k_run_philox1m', 0),
                                                         (8192, 1, 'k_run_philox1', 0), (5632, 1, 'k_run_philox1', 2500), (5000, 0, 'k_run_pcg', 0)],
-                         ids=['1024-slow-exchange', '2048', '8192', '5632-slow-exchange', '5000-numpy-stream'])
+                         ids=['1000-slow-exchange', '2000', '8192', '5632-slow-exchange', '5000-numpy-stream'])     # (1000 / 2000: the last group of 32 episodes is a partial one)
 def test_exchange_from_inside_the_one_launch_kernels_gathers_every_step(n, mode, run_kernel, delay_us):
     """with a communicator cc4_run_random_steps stays ONE launch -- step k writes its packed rows into slab k mod 32 of a
     ring and counts finished episodes, the communication stream waits for the count (hipStreamWaitValue32), all-gathers the slab and
