@@ -193,7 +193,9 @@ __device__ __forceinline__ void xchg_count(const XchgArgs& x, uint32_t k, int gr
 // step of the chunk (counts of one episode's consecutive steps may arrive out of order: each wave counts where ITS stores have drained),
 // and hands the counters back (zero) for steps k + ring.  P > 0: the groups are the P partitions of the persistent kernel (episodes
 // g, g + P, ..), else groups of 32 neighbouring episodes.  Gives up after `ticks` and says so in *fail (the host reports it).
-__global__ __launch_bounds__(256) void k_xchg_gate(uint32_t* gcnt, int ring, int groups, int n, int P, int k_lo, int k_hi, long long ticks, uint32_t* fail) {
+// ONE wave, polling at a growing interval (3 us .. 27 us): the gate shares a CU with blocks of the step kernel, and in the multi-step kernels
+// a block is an episode -- whatever slows one CU's blocks sets the pace of the launch (four busily polling waves cost 1024 episodes 1.2 us per step).
+__global__ __launch_bounds__(WAVE) void k_xchg_gate(uint32_t* gcnt, int ring, int groups, int n, int P, int k_lo, int k_hi, long long ticks, uint32_t* fail) {
   const int t = (int)threadIdx.x, steps = k_hi - k_lo + 1;
   const long long t0 = wall_clock64();
   for (int i = t; i < groups * steps; i += (int)blockDim.x) {
@@ -201,8 +203,10 @@ __global__ __launch_bounds__(256) void k_xchg_gate(uint32_t* gcnt, int ring, int
     const int size = P > 0 ? (n - g + P - 1) / P : (n - (g << 5) < 32 ? n - (g << 5) : 32);
     if (size <= 0) continue;
     uint32_t* c = gcnt + (size_t)g * (size_t)ring + (k % ring);
+    int naps = 1;
     while (__hip_atomic_load(c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (uint32_t)size) {
-      __builtin_amdgcn_s_sleep(64);
+      for (int q = 0; q < naps; ++q) __builtin_amdgcn_s_sleep(127);
+      if (naps < 8) naps <<= 1;
       if (wall_clock64() - t0 > ticks) { __hip_atomic_store(fail, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); break; }
     }
     __hip_atomic_store(c, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -798,14 +802,17 @@ __device__ __forceinline__ void dma_wait() { asm volatile("s_waitcnt vmcnt(0)" :
 // RUN (k_run_philox): the row stays in LDS from one step of the episode to the next -- run_flags bit 0: not the first step of the
 // launch (nothing is staged in), bit 1: the last one (the whole row goes back; before it, none of it)
 template <bool LOG, bool RUN = false>
-__device__ __forceinline__ void philox4_body(StepArgs a, const int run_flags = 0, const int tid_in = -1) {
+// obs_row (RUN with the exchange): a byte row of the caller's in LDS that receives all 578 observation values of the step -- the caller packs
+// and stores the exchange row from it behind its own end-of-step drain
+__device__ __forceinline__ void philox4_body(StepArgs a, const int run_flags = 0, const int tid_in = -1, uint8_t* const obs_row = nullptr) {
   extern __shared__ uint4 lds[];
   __shared__ int conflict_lds;
   __shared__ alignas(16) uint32_t reset_ws[RESET_WS_WORDS];   // pid bitmaps of the scenario generation (autoreset); during a step: the green agents' pre-computed blocks
   static_assert(RESET_WS_WORDS >= 4 * (MAXG + NRED + NBLUE), "one 16-byte block per green agent, red action stream and blue action stream");
   __shared__ int glist_n[2][2];       // [action type][drawing wave]
   __shared__ StepWork work;
-  __shared__ uint8_t obs_bytes[OBS_TOTAL + 2];   // byte-per-value copy of the observations, only for the packed exchange row
+  __shared__ uint8_t obs_bytes_own[OBS_TOTAL + 2];   // byte-per-value copy of the observations, only for the packed exchange row
+  uint8_t* const obs_bytes = obs_row ? obs_row : obs_bytes_own;
   __shared__ uint8_t glist[2][2][MAXG];  // green agents by action type (0 AccessService, 1 LocalWork) and drawing wave
   __shared__ unsigned long long prof_lds[16];
   const int e = a.e0 + (int)blockIdx.x, tid = tid_in >= 0 ? tid_in : (int)threadIdx.x, lane = tid & 63;
@@ -1046,10 +1053,10 @@ __device__ __forceinline__ void philox4_body(StepArgs a, const int run_flags = 0
   // flat observations: one value per thread straight to HBM (int32 for the host API, bytes for the all-gather)
   {
     int32_t* o = a.obs + (size_t)e * OBS_TOTAL;
-    const bool pack = a.obs8 != nullptr;   // the exchange copy goes through a byte row in LDS and is packed after the barrier below
+    const bool pack = a.obs8 != nullptr || obs_row != nullptr;   // the exchange copy goes through a byte row in LDS and is packed after the barrier below
     // the values that can change with every step (host events, messages) always; blocks, comms policy, subnet one-hots and phase
     // words only when the step changed them (EnvState.obs_dirty), after a reset, or when the caller asks (the buffer persists)
-    const int nv = (do_reset || a.full_obs || pack || s->obs_dirty) ? OBS_TOTAL : OBS_FAST;
+    const int nv = (do_reset || a.full_obs || a.obs8 || s->obs_dirty) ? OBS_TOTAL : OBS_FAST;      // (a caller's obs_row persists from step to step, like the int32 buffer: only what changed is rewritten)
     encode_obs_fast<PT>(s, o, obs_bytes, pack, tid);
     for (int v = OBS_FAST + tid; v < nv; v += PT) { int i; int val = env_flat_obs_sorted(s, v, &i); o[i] = val; if (pack) obs_bytes[i] = (uint8_t)val; }   // kind-sorted enumeration: uniform branches per wave
   }
@@ -1094,26 +1101,24 @@ __global__ __launch_bounds__(PT, MINW) void k_step_philox(StepArgs a) { philox4_
 template <int MINB>
 __device__ __forceinline__ void run_philox_loop(StepArgs a, int K, uint32_t t0, const XchgArgs x) {
   a.prof = nullptr; a.obs8 = nullptr; a.ext = nullptr;
+  __shared__ uint8_t xrow[OBS_TOTAL + 2];      // the exchange: the step's observation values as bytes (LDS does not bound the four-wave kernels' residency)
   const int full0 = a.full_obs;
   uint32_t seen = 0;
   for (int k = 0; k < K; ++k) {
     a.rand_t = t0 + (uint32_t)k;
-    a.full_obs = k == 0 ? full0 : 0;
-    if (x.slab) {      // with the exchange: this step's slab of the ring, free once its previous occupant (step k - ring) has been gathered
-      if (threadIdx.x == 0) xchg_wait_slab(x, (uint32_t)k, seen);
-      __syncthreads();
-    }
+    a.full_obs = k == 0 ? (full0 | (x.slab ? 1 : 0)) : 0;       // (the byte row starts empty: the launch's first step writes every value)
     { int tid_i = (int)threadIdx.x; asm volatile("" : "+v"(tid_i));
-      philox4_body<false, true>(a, (k > 0 ? 1 : 0) | (k == K - 1 ? 2 : 0), tid_i); }      // (a.obs8 stays null: no byte row, incremental encode)
+      philox4_body<false, true>(a, (k > 0 ? 1 : 0) | (k == K - 1 ? 2 : 0), tid_i, x.slab ? xrow : nullptr); }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    if (x.slab) {
-      // as in the one-wave loops: the row of step k - 1 is in memory by now (this step's drain covered its store) and is counted; this step's
-      // row is packed from the int32 row the block has just drained and stored without waiting (a system-scope store takes ~1.5 us to land:
-      // inside the drain it was 1.4 us of every step)
+    if (x.slab && threadIdx.x < WAVE) {
+      // As in the one-wave loops: the row of step k - 1 is in memory by now (this step's drain covered its store) and is counted; this step's
+      // row goes out from the byte row in LDS -- no global loads, nothing waited for (a system-scope store takes ~1.5 us to land: inside the
+      // drain it was 1.4 us of every step; read back from the int32 row, the loads were).  The slab must be free: its previous occupant, step
+      // k - ring, gathered -- checked here, by the one wave that writes it, not by the block at the top of the step.
       const int e = a.e0 + (int)blockIdx.x;
-      if (threadIdx.x == 0 && k > 0) xchg_count(x, (uint32_t)(k - 1), e >> 5);
-      if (threadIdx.x < WAVE) pack_row_from_obs(x.slab + ((size_t)(k % x.ring) * (size_t)a.n + (size_t)e) * OBS_PACKED, a.obs + (size_t)e * OBS_TOTAL, (int)threadIdx.x);
+      if (threadIdx.x == 0) { if (k > 0) xchg_count(x, (uint32_t)(k - 1), e >> 5); xchg_wait_slab(x, (uint32_t)k, seen); }
+      store_packed_row(x.slab + ((size_t)(k % x.ring) * (size_t)a.n + (size_t)e) * OBS_PACKED, xrow, (int)threadIdx.x, WAVE);
     }
   }
   if (x.slab && K > 0) {
@@ -2726,7 +2731,7 @@ static int xchg_enqueue(cc4_handle* h, int k, const XchgArgs& x, int form) {
     hi = (c0 + C < k ? c0 + C : k) - 1;
     if (hi == k - 1 && hi > c0) --hi;       // the call's last step is a chunk of its own: behind the kernel's end only ONE all-gather is left
     if (c0 % cc4_handle::XRING + (hi - c0) >= cc4_handle::XRING) hi = c0 + cc4_handle::XRING - 1 - c0 % cc4_handle::XRING;     // a chunk's slabs are neighbours in the ring
-    hipLaunchKernelGGL(k_xchg_gate, dim3(1), dim3(256), 0, h->comm_stream, x.gcnt, x.ring, groups, n, P, c0, hi, gate_ticks, x.timeout_host);
+    hipLaunchKernelGGL(k_xchg_gate, dim3(1), dim3(WAVE), 0, h->comm_stream, x.gcnt, x.ring, groups, n, P, c0, hi, gate_ticks, x.timeout_host);
     HIPCHK(h, hipGetLastError());
     if (h->comm_delay_ticks > 0) { hipLaunchKernelGGL(k_spin, dim3(1), dim3(1), 0, h->comm_stream, h->comm_delay_ticks); HIPCHK(h, hipGetLastError()); }
     // ONE all-gather for the chunk's m neighbouring slabs (an ncclAllGather costs the host ~10 us to enqueue, grouped or not: eight of them
