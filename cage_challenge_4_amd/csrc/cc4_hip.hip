@@ -21,6 +21,8 @@
 #include <cstdio>
 #include <cstdlib>
 #include <vector>
+#include <map>
+#include <algorithm>
 #include <thread>
 #include <mutex>
 #include <condition_variable>
@@ -1458,7 +1460,7 @@ __device__ __forceinline__ void persist_loop(StepArgs a, RunArgs ra, const XchgA
   uint32_t seen_gathered = 0;
   unsigned long long tl_first = 0, tl_last = 0, tl_items = 0;
   const unsigned long long tl_entry = ra.timeline ? wall_clock64() : 0;
-  auto tl_flush = [&]() { if (ra.timeline && lane == 0) { unsigned long long* t = ra.timeline + 4 * (size_t)blockIdx.x; t[0] = tl_entry; t[1] = tl_first; t[2] = tl_last; t[3] = tl_items; } };
+  auto tl_flush = [&]() { if (ra.timeline && lane == 0) { unsigned long long* t = ra.timeline + 4 * (size_t)blockIdx.x; t[0] = tl_entry; t[1] = tl_first; t[2] = tl_last; t[3] = tl_items | ((unsigned long long)(my_slot + 1) << 32); } };
   int pend_e = -1; uint32_t pend_k = 0;  // the exchange: the item whose packed row this wave stored last and has not counted yet (its store drains with the next item)
   auto flush_pending = [&]() {
     if (x.slab && pend_e >= 0) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); if (lane == 0) xchg_count(x, pend_k, pend_e % ra.P); pend_e = -1; }
@@ -1477,6 +1479,9 @@ __device__ __forceinline__ void persist_loop(StepArgs a, RunArgs ra, const XchgA
         const uint32_t tr = __hip_atomic_fetch_add(&ra.ticket[part], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         const uint32_t t = tr & ~TK_SHARED;
         if (t < (uint32_t)(ne * ra.K)) {
+          // (r05, both measured and dropped: asking for the next ticket ahead of the previous item's drain -- the CU's other waves fill that gap
+          // already, 813-821 vs 819 M; and shares of the batch per XCD following the XCDs' measured speed -- which XCDs are slow changes from
+          // box to box and call to call, the controller chases noise: 20-step calls 812-822 -> 789-796 M.  profiles/r05_xcd_balance.txt)
           // (a ready queue per partition -- a wave never holds an item whose predecessor is still running -- was built and measured in r05:
           // bit-exact, 2-3.5 % slower, and the launch's tail stayed: profiles/r05_ready_queue_ab.txt)
           const int k = (int)(t / (uint32_t)ne), ee = part + (int)(t % (uint32_t)ne) * ra.P;
@@ -2892,12 +2897,25 @@ static int run_random_steps_impl(cc4_handle* h, uint64_t seed0, uint32_t t0, int
       HIPCHK(h, hipMemcpy(tl.data(), h->d_timeline, tl.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
       (void)hipFree(h->d_timeline); h->d_timeline = nullptr;
       unsigned long long e0 = ~0ull, e1 = 0, f1 = 0, l0 = ~0ull, l1 = 0; double fs = 0, ls = 0, items = 0; int nw = 0, idle = 0;
-      for (int w = 0; w < h->run_grid; ++w) { const unsigned long long* t = &tl[4 * (size_t)w]; if (!t[0]) continue; ++nw; e0 = t[0] < e0 ? t[0] : e0; e1 = t[0] > e1 ? t[0] : e1; if (!t[3]) { ++idle; continue; } f1 = t[1] > f1 ? t[1] : f1; l0 = t[2] < l0 ? t[2] : l0; l1 = t[2] > l1 ? t[2] : l1; fs += (double)t[1]; ls += (double)t[2]; items += (double)t[3]; }
+      for (int w = 0; w < h->run_grid; ++w) { const unsigned long long* t = &tl[4 * (size_t)w]; if (!t[0]) continue; ++nw; e0 = t[0] < e0 ? t[0] : e0; e1 = t[0] > e1 ? t[0] : e1; if (!(uint32_t)t[3]) { ++idle; continue; } f1 = t[1] > f1 ? t[1] : f1; l0 = t[2] < l0 ? t[2] : l0; l1 = t[2] > l1 ? t[2] : l1; fs += (double)t[1]; ls += (double)t[2]; items += (double)(uint32_t)t[3]; }
       const int busy = nw - idle;
       float ms = 0.f; if (ms_step_kernels) (void)hipEventElapsedTime(&ms, h->evs[0], h->evs[1]);
       fprintf(stderr, "[cc4 timeline] k=%d: %d waves reported (%d without an item); entry spread %.1f us; first item starts: mean +%.1f us, last +%.1f us after the first entry; "
                       "last item ends: earliest +%.1f us, mean +%.1f us, latest +%.1f us; items per busy wave %.1f; kernel (events) %.1f us\n",
               k, nw, idle, (e1 - e0) / 100.0, busy ? (fs / busy - (double)e0) / 100.0 : 0.0, (f1 - e0) / 100.0, (l0 - e0) / 100.0, busy ? (ls / busy - (double)e0) / 100.0 : 0.0, (l1 - e0) / 100.0, busy ? items / busy : 0.0, ms * 1000.0);
+      // per CU: when its LAST wave ran dry, and how many items its waves executed (more than its own partition's = it helped out)
+      { std::map<int, std::pair<unsigned long long, double>> cu;
+        for (int w = 0; w < h->run_grid; ++w) { const unsigned long long* t = &tl[4 * (size_t)w]; if (!t[0] || !(uint32_t)t[3]) continue; auto& c = cu[(int)((t[3] >> 32) - 1)]; if (t[2] > c.first) c.first = t[2]; c.second += (double)(uint32_t)t[3]; }
+        std::vector<double> last, its; for (auto& kv : cu) { last.push_back((kv.second.first - e0) / 100.0); its.push_back(kv.second.second); }
+        std::sort(last.begin(), last.end()); std::sort(its.begin(), its.end());
+        if (!last.empty()) { const size_t m = last.size(); fprintf(stderr, "[cc4 timeline]   per CU (%zu): last wave dry at min %.1f / 10%% %.1f / median %.1f / 90%% %.1f / max %.1f us; items executed min %.0f / median %.0f / max %.0f\n", m,
+                                   last[0], last[m / 10], last[m / 2], last[m * 9 / 10], last[m - 1], its[0], its[m / 2], its[m - 1]); } }
+      // per XCD: when its waves ran dry (intra-XCD sharing evens a tail out inside an XCD; what is left between XCDs is not shareable)
+      { double xs[8] = {0}, xi[8] = {0}; unsigned long long xl[8] = {0}, xf[8]; int xn[8] = {0}; for (int i = 0; i < 8; ++i) xf[i] = ~0ull;
+        for (int w = 0; w < h->run_grid; ++w) { const unsigned long long* t = &tl[4 * (size_t)w]; if (!t[0] || !(uint32_t)t[3]) continue; const int xc = (int)(((t[3] >> 32) - 1) >> 8) & 7;
+          xs[xc] += (double)t[2]; xi[xc] += (double)(uint32_t)t[3]; ++xn[xc]; if (t[2] > xl[xc]) xl[xc] = t[2]; if (t[2] < xf[xc]) xf[xc] = t[2]; }
+        for (int i = 0; i < 8; ++i) if (xn[i]) fprintf(stderr, "[cc4 timeline]   XCD %d: %d busy waves, %.0f items; waves ran dry: earliest +%.1f, mean +%.1f, latest +%.1f us\n", i, xn[i], xi[i],
+                                                      (xf[i] - e0) / 100.0, (xs[i] / xn[i] - (double)e0) / 100.0, (xl[i] - e0) / 100.0); }
     }
     if (exchange && xchg_end(h, k)) return -1;
     if (ms_step_kernels) HIPCHK(h, hipEventElapsedTime(ms_step_kernels, h->evs[0], h->evs[1]));
