@@ -432,11 +432,12 @@ def main():
             # kernel per step and episode group, no host synchronisation inside the region, observations readable after every step
             e5 = make_env(n_local, RNG_PHILOX, lo)
             r5 = measure(e5, lo, total_envs, runner=lambda t0, k, timed: e5.run_policy_steps(args.seed0 + lo, t0, k), min_seconds=min(args.min_seconds, 0.2))
-            r5.update({'unit': 'agent-env steps/s', 'kernel': e5.step_kernel, 'run_kernel': e5.step_kernel, 'launches_per_step': e5.launches_per_step + 1,
-                       'note': 'per step: k_random_actions -> the handle\'s device action buffer, then cc4_step_device (the per-step launches of the step kernel); '
-                               'a policy over the WHOLE batch is a barrier across the episode groups at every step; `grouped` is the same policy applied per group'})
+            r5.update({'unit': 'agent-env steps/s', 'kernel': e5.step_kernel, 'run_kernel': e5.step_kernel, 'launches_per_step': 2,
+                       'note': 'per step: k_random_actions -> the handle\'s device action buffer, then cc4_step_device; a policy over the WHOLE batch orders every '
+                               'episode group behind it, so the library steps the batch with ONE launch on the main stream instead of a fork and a join across the '
+                               'group streams per step (r05: 334-393 -> 583 M); `grouped` is the same policy applied per group'})
             r6 = measure(e5, lo, total_envs, runner=lambda t0, k, timed: e5.run_policy_steps_grouped(args.seed0 + lo, t0, k), min_seconds=min(args.min_seconds, 0.2))
-            r6.update({'unit': 'agent-env steps/s', 'kernel': e5.step_kernel, 'run_kernel': e5.step_kernel,
+            r6.update({'unit': 'agent-env steps/s', 'kernel': e5.step_kernel, 'run_kernel': e5.step_kernel, 'launches_per_step': 2 * e5.launches_per_step,
                        'note': 'the same with the policy applied per episode group on the group\'s own stream (cc4_group_info / cc4_step_group_device): a policy is '
                                'batch-independent, so nothing orders the groups against each other and their launches keep overlapping across steps'})
             r5['grouped'] = r6

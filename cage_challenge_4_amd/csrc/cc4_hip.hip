@@ -1799,6 +1799,8 @@ struct cc4_handle {
   hipEvent_t mev = nullptr;                      // main stream -> group streams ordering (fork_groups)
   bool auto_groups = true;                       // the number of groups is the library's choice (no CC4_GROUPS)
   bool groups_busy = false;                      // a group stream other than the main one may hold unfinished step launches
+  bool joined_between = false;                   // something ordered the main stream behind all groups (or waited for them) since the last step launches:
+                                                 // the caller works on the WHOLE batch between steps (launch_step: one launch then, not one per group)
   bool main_ahead = false;                       // the main stream holds work the group streams have not been ordered behind
   unsigned long long* d_prof = nullptr;
   uint32_t* d_reset_ws = nullptr;    // k_step_philox1's generation work area, [num_envs][RESET_WS_WORDS]
@@ -1815,6 +1817,7 @@ struct cc4_handle {
   size_t run_words = 0;           // words of d_run
   int run_P = 0, run_grid = 0;    // partitions (= CUs that take waves), waves per launch; 0: the persistent path is off
   int persist_state = -1;         // -1 off / unavailable, 0 not set up yet (persist_setup on first use), 1 on
+  bool whole_batch_steps = true;  // CC4_WHOLE_BATCH_STEPS=0: the step entry points always launch per group (A/B)
   int persist_order = 0;          // RunArgs.order (CC4_PERSIST_ORDER)
   int run_margin = 0;             // episode blocks per CU the one-launch forms leave free (choose_run_form)
   // the per-step hand-off out of the one-launch kernels (XchgArgs): with a communicator, cc4_run_random_steps stays ONE launch and the
@@ -1950,6 +1953,7 @@ static int join_groups(cc4_handle* h) {
       h->groups_busy = false;
     }
     h->main_ahead = true;
+    h->joined_between = true;
   }
   return 0;
 }
@@ -1959,16 +1963,20 @@ static int sync_all(cc4_handle* h) {
   for (int g = h->ngroups - 1; g >= 1; --g) if (h->groups_busy) HIPCHK(h, hipStreamSynchronize(h->gstream[g]));
   HIPCHK(h, hipStreamSynchronize(h->stream));
   h->groups_busy = false;
+  h->joined_between = true;
   return 0;
 }
 
 // rand: draw the blue actions inside the step kernel from (seed0, t) and record them in the handle's action buffer
 // one group's launch of a step: the kernel cc4_create picked for this handle, on the group's stream, carrying `start` / `stop` as the
 // launch's own timing events (or null)
+static void launch_range(cc4_handle* h, StepArgs a, int e0, int e1, hipStream_t st, bool full, hipEvent_t start, hipEvent_t stop);
 static void launch_group(cc4_handle* h, StepArgs a, int g, bool full, hipEvent_t start, hipEvent_t stop) {
-  a.e0 = h->glo[g]; a.n = h->glo[g + 1];
+  launch_range(h, a, h->glo[g], h->glo[g + 1], h->gstream[g], full, start, stop);
+}
+static void launch_range(cc4_handle* h, StepArgs a, int e0, int e1, hipStream_t st, bool full, hipEvent_t start, hipEvent_t stop) {
+  a.e0 = e0; a.n = e1;
   const dim3 grid(a.n - a.e0);
-  hipStream_t st = h->gstream[g];
 #ifdef CC4_DEV_FAST     // kernel experiments (tools/ab/ab.sh): only the one-wave counter-mode kernel is instantiated -- a quarter of the compile time
   if (h->philox_lean) hipExtLaunchKernelGGL(k_step_philox1<false>, grid, dim3(WAVE), offsetof(EnvState, hd), st, start, stop, 0, a);
   else hipExtLaunchKernelGGL((k_step_philox<false, 1>), grid, dim3(PT), sizeof(EnvState), st, start, stop, 0, a);
@@ -2050,8 +2058,13 @@ static void enq_pool_stop(cc4_handle* h) {
   delete h->pool; h->pool = nullptr;
 }
 
+// api_step: one of the step entry points (cc4_step / _ex / _fetch / _device), as opposed to the loop of cc4_run_random_steps.  When the caller did
+// something with the WHOLE batch since the last step (an upload, a fetch, a policy kernel over all observations: anything that went through
+// join_groups or waited for the streams), the groups cannot run ahead of each other anyway -- a launch per group then pays a fork and a join
+// across streams per step for nothing: ONE launch on the main stream (8192 episodes, k_random_actions + cc4_step_device per step: 334 -> 583 M;
+// a loop of cc4_step_device with nothing in between keeps the groups and their overlap across steps).
 static int launch_step(cc4_handle* h, const int32_t* d_actions, const uint8_t* d_msgs, bool rand = false, uint64_t seed0 = 0,
-                       uint32_t t = 0, bool ext_uploaded = false) {
+                       uint32_t t = 0, bool ext_uploaded = false, bool api_step = false) {
   if (h->ext_seen && h->ext_dirty && !ext_uploaded) {     // this step submits no red / green action: every record says so
     if (join_groups(h)) return -1;
     HIPCHK(h, hipMemsetAsync(h->d_ext, 0xFF, (size_t)h->cfg.num_envs * EXT_PER_ENV * sizeof(ExtAct), h->stream));
@@ -2074,7 +2087,9 @@ static int launch_step(cc4_handle* h, const int32_t* d_actions, const uint8_t* d
     else HIPCHK(h, qs);
     h->gathers_waited = q;
   }
-  if (h->ngroups > 1 && h->main_ahead) {   // e.g. an action upload or a reset on the main stream: the group streams start behind it
+  const bool whole = api_step && h->whole_batch_steps && h->ngroups > 1 && h->joined_between && !h->groups_busy && !h->comm;
+  h->joined_between = false;
+  if (!whole && h->ngroups > 1 && h->main_ahead) {   // e.g. an action upload or a reset on the main stream: the group streams start behind it
     HIPCHK(h, hipEventRecord(h->mev, h->stream));
     for (int g = 1; g < h->ngroups; ++g) HIPCHK(h, hipStreamWaitEvent(h->gstream[g], h->mev, 0));
     h->main_ahead = false;
@@ -2095,6 +2110,16 @@ static int launch_step(cc4_handle* h, const int32_t* d_actions, const uint8_t* d
 #ifdef CC4_DEV_FAST
   if (h->cfg.rng_mode != 1 || full) { h->err = "CC4_DEV_FAST build: only k_step_philox1<false> and k_step_philox<false, 1> exist"; return -1; }
 #endif
+  if (whole) {
+    hipEvent_t stop = h->tev_stop[0], start = h->tev_start[0];
+    for (int g = 0; g < h->ngroups; ++g) h->tev_start[g] = h->tev_stop[g] = nullptr;
+    launch_range(h, a, 0, h->cfg.num_envs, h->stream, full, start, stop);
+    HIPCHK(h, hipGetLastError());
+    h->step_event_attached = false;
+    h->main_ahead = true;            // (the group streams have not been ordered behind this launch)
+    h->obs_buf = buf;
+    return 0;
+  }
   for (int g = 0; g < h->ngroups; ++g) {
     // with a communicator, the launch carries ev_step[buf][g] as its stop event: the event rides on the kernel's own completion
     // signal, where a separate hipEventRecord would put a marker packet between two step kernels (~5 us of idle stream time)
@@ -2317,6 +2342,7 @@ int cc4_create(const cc4_config* cfg, cc4_handle** out) {
   if (choose_run_form(h, 0)) return -1;
   if (const char* v = getenv("CC4_PERSIST_MIN_K")) h->persist_min_k = atoi(v);
   if (const char* v = getenv("CC4_PERSIST_ORDER")) h->persist_order = atoi(v);
+  if (const char* v = getenv("CC4_WHOLE_BATCH_STEPS")) h->whole_batch_steps = atoi(v) != 0;
   if (const char* v = getenv("CC4_PERSIST_VERIFY")) h->verify = atoi(v) != 0;
   return 0;
 }
@@ -2379,7 +2405,7 @@ int cc4_step(cc4_handle* h, const int32_t* actions, const uint8_t* messages) {
   size_t n = (size_t)h->cfg.num_envs;
   if (actions) HIPCHK(h, hipMemcpyAsync(h->d_actions, actions, n * NBLUE * sizeof(int32_t), hipMemcpyDefault, h->stream));
   if (messages) HIPCHK(h, hipMemcpyAsync(h->d_msgs, messages, n * NBLUE * MSG_LEN, hipMemcpyDefault, h->stream));
-  if (launch_step(h, actions ? h->d_actions : nullptr, messages ? h->d_msgs : nullptr)) return -1;
+  if (launch_step(h, actions ? h->d_actions : nullptr, messages ? h->d_msgs : nullptr, false, 0, 0, false, true)) return -1;
   return sync_all(h);
 }
 
@@ -2441,7 +2467,7 @@ int cc4_step_fetch(cc4_handle* h, const int32_t* actions, const uint8_t* message
     if (actions) HIPCHK(h, hipMemcpyAsync(h->d_actions, actions, b_act, hipMemcpyDefault, h->stream));
     if (messages) HIPCHK(h, hipMemcpyAsync(h->d_msgs, messages, b_msg, hipMemcpyDefault, h->stream));
   }
-  if (launch_step(h, actions ? h->d_actions : nullptr, messages ? h->d_msgs : nullptr)) return -1;
+  if (launch_step(h, actions ? h->d_actions : nullptr, messages ? h->d_msgs : nullptr, false, 0, 0, false, true)) return -1;
   return fetch_outputs(h, obs, reward, done, err);
 }
 
@@ -2475,7 +2501,7 @@ int cc4_step_ex(cc4_handle* h, const int32_t* actions, const uint8_t* messages, 
   h->ext_seen = true; h->ext_dirty = true;
   if (actions) HIPCHK(h, hipMemcpyAsync(h->d_actions, actions, n * NBLUE * sizeof(int32_t), hipMemcpyDefault, h->stream));
   if (messages) HIPCHK(h, hipMemcpyAsync(h->d_msgs, messages, n * NBLUE * MSG_LEN, hipMemcpyDefault, h->stream));
-  if (launch_step(h, actions ? h->d_actions : nullptr, messages ? h->d_msgs : nullptr, false, 0, 0, true)) return -1;
+  if (launch_step(h, actions ? h->d_actions : nullptr, messages ? h->d_msgs : nullptr, false, 0, 0, true, true)) return -1;
   return sync_all(h);
 }
 
@@ -2500,7 +2526,7 @@ int cc4_edit_state(cc4_handle* h, int32_t env, int32_t op, int32_t a0, int32_t a
 
 int cc4_step_device(cc4_handle* h, const int32_t* d_actions, const uint8_t* d_messages) {
   HIPCHK(h, hipSetDevice(h->cfg.device_id));
-  return launch_step(h, d_actions, d_messages);
+  return launch_step(h, d_actions, d_messages, false, 0, 0, false, true);
 }
 
 // ---- group-wise stepping for a policy that lives on the GPU.  A step of a large batch is one launch per episode group, each group on its

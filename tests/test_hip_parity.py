@@ -337,6 +337,37 @@ def test_device_random_action_kernel_matches_host_restatement():
     dev.close()
 
 
+@pytest.mark.parametrize('n', [8192, 1500])
+def test_learner_loop_matches_oracle_in_every_launch_form(n, monkeypatch):
+    """The loop a learner runs -- a kernel writes the actions on the device, cc4_step_device consumes them, no host wait in between -- in the
+    three forms the library has for it: a policy over the WHOLE batch (the library then steps the batch with ONE launch on the main stream),
+    the same with CC4_WHOLE_BATCH_STEPS=0 (a launch per episode group, forked from and joined to the main stream every step), and the policy
+    applied per episode group on the group's own stream.  Every form against the oracle at every step, the generator position at the end."""
+    T, seed0 = 8, 4321
+    ora = OracleVecEnv(n, steps=40, rng_mode=1); ora.reset(seeds=77)
+    want = []
+    for t in range(T):
+        o = ora.step_batch(random_actions(seed0, t, n))
+        want.append((o[0].copy(), o[1].copy(), np.asarray(o[2]).astype(bool).copy()))
+    for t in range(T, T + 5):
+        ora.step_batch(random_actions(seed0, t, n))
+    rng_end = ora.rng_state().copy()
+    ora.close()
+    for form in ('whole', 'per-group launches', 'grouped policy'):
+        monkeypatch.setenv('CC4_WHOLE_BATCH_STEPS', '0' if form == 'per-group launches' else '1')
+        dev = _dev(n, steps=40, rng_mode=1); dev.reset(seeds=77)
+        for t in range(T):
+            (dev.run_policy_steps_grouped if form == 'grouped policy' else dev.run_policy_steps)(seed0, t, 1)
+            dev.synchronize(); dev._fetch()
+            o = want[t]
+            bad = np.nonzero((dev._obs != o[0]).any(axis=1) | (dev._rew != o[1]) | (dev._done.astype(bool) != o[2]))[0]
+            assert bad.size == 0, (form, t, bad[:10].tolist())
+        dev.run_policy_steps(seed0, T, 5)                       # five more without a look in between, then the generator position
+        dev.synchronize()
+        assert np.array_equal(dev.rng_state(), rng_end), form
+        dev.close()
+
+
 @pytest.mark.parametrize('rng_mode', [0, 1], ids=['pcg64', 'philox'])
 @pytest.mark.parametrize('n', [1024, 8192])
 def test_full_size_properties(n, rng_mode):
