@@ -1976,15 +1976,16 @@ static void launch_group(cc4_handle* h, StepArgs a, int g, bool full, hipEvent_t
 }
 static void launch_range(cc4_handle* h, StepArgs a, int e0, int e1, hipStream_t st, bool full, hipEvent_t start, hipEvent_t stop) {
   a.e0 = e0; a.n = e1;
+  const size_t lds1 = offsetof(EnvState, hd);     // one-wave kernels: the agent part
   const dim3 grid(a.n - a.e0);
 #ifdef CC4_DEV_FAST     // kernel experiments (tools/ab/ab.sh): only the one-wave counter-mode kernel is instantiated -- a quarter of the compile time
-  if (h->philox_lean) hipExtLaunchKernelGGL(k_step_philox1<false>, grid, dim3(WAVE), offsetof(EnvState, hd), st, start, stop, 0, a);
+  if (h->philox_lean) hipExtLaunchKernelGGL(k_step_philox1<false>, grid, dim3(WAVE), lds1, st, start, stop, 0, a);
   else hipExtLaunchKernelGGL((k_step_philox<false, 1>), grid, dim3(PT), sizeof(EnvState), st, start, stop, 0, a);
 #else
   if (h->cfg.rng_mode == 1) {
     if (h->philox_lean) {
-      if (full || h->d_prof) hipExtLaunchKernelGGL(k_step_philox1<true>, grid, dim3(WAVE), offsetof(EnvState, hd), st, start, stop, 0, a);
-      else hipExtLaunchKernelGGL(k_step_philox1<false>, grid, dim3(WAVE), offsetof(EnvState, hd), st, start, stop, 0, a);
+      if (full || h->d_prof) hipExtLaunchKernelGGL(k_step_philox1<true>, grid, dim3(WAVE), lds1, st, start, stop, 0, a);
+      else hipExtLaunchKernelGGL(k_step_philox1<false>, grid, dim3(WAVE), lds1, st, start, stop, 0, a);
     }
     else if (full) hipExtLaunchKernelGGL((k_step_philox<true, 1>), grid, dim3(PT), sizeof(EnvState), st, start, stop, 0, a);
     else if (h->philox_minw == 8) hipExtLaunchKernelGGL((k_step_philox<false, 8>), grid, dim3(PT), sizeof(EnvState), st, start, stop, 0, a);
@@ -1994,8 +1995,8 @@ static void launch_range(cc4_handle* h, StepArgs a, int e0, int e1, hipStream_t 
 #endif
     else hipExtLaunchKernelGGL((k_step_philox<false, CC4_SMALL_MINW>), grid, dim3(PT), sizeof(EnvState), st, start, stop, 0, a);
   } else {
-    if (full) hipExtLaunchKernelGGL(k_step<true>, grid, dim3(WAVE), offsetof(EnvState, hd), st, start, stop, 0, a);
-    else hipExtLaunchKernelGGL(k_step<false>, grid, dim3(WAVE), offsetof(EnvState, hd), st, start, stop, 0, a);
+    if (full) hipExtLaunchKernelGGL(k_step<true>, grid, dim3(WAVE), lds1, st, start, stop, 0, a);
+    else hipExtLaunchKernelGGL(k_step<false>, grid, dim3(WAVE), lds1, st, start, stop, 0, a);
   }
 #endif
 }
@@ -2113,6 +2114,8 @@ static int launch_step(cc4_handle* h, const int32_t* d_actions, const uint8_t* d
   if (whole) {
     hipEvent_t stop = h->tev_stop[0], start = h->tev_start[0];
     for (int g = 0; g < h->ngroups; ++g) h->tev_start[g] = h->tev_stop[g] = nullptr;
+    // (fewer waves per CU so that the batch runs in whole rounds -- 8192 episodes: 16 per CU, two even rounds instead of 1.6 at 20 -- is slower at every
+    // residency tried: 578 M at 20, 567 at 18, 538 at 16, 503 at 14; tools/ab/ab_whole_residency.sh)
     launch_range(h, a, 0, h->cfg.num_envs, h->stream, full, start, stop);
     HIPCHK(h, hipGetLastError());
     h->step_event_attached = false;
