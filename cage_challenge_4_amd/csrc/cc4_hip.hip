@@ -195,9 +195,9 @@ __device__ __forceinline__ void xchg_count(const XchgArgs& x, uint32_t k, int gr
 // step of the chunk (counts of one episode's consecutive steps may arrive out of order: each wave counts where ITS stores have drained),
 // and hands the counters back (zero) for steps k + ring.  P > 0: the groups are the P partitions of the persistent kernel (episodes
 // g, g + P, ..), else groups of 32 neighbouring episodes.  Gives up after `ticks` and says so in *fail (the host reports it).
-// ONE wave, polling at a growing interval (3 us .. 27 us): the gate shares a CU with blocks of the step kernel, and in the multi-step kernels
+// ONE wave, polling at a growing interval (4 us .. 31 us; the gate of a call's LAST step, behind which the host waits, stays at 4 us): the gate shares a CU with blocks of the step kernel, and in the multi-step kernels
 // a block is an episode -- whatever slows one CU's blocks sets the pace of the launch (four busily polling waves cost 1024 episodes 1.2 us per step).
-__global__ __launch_bounds__(WAVE) void k_xchg_gate(uint32_t* gcnt, int ring, int groups, int n, int P, int k_lo, int k_hi, long long ticks, uint32_t* fail) {
+__global__ __launch_bounds__(WAVE) void k_xchg_gate(uint32_t* gcnt, int ring, int groups, int n, int P, int k_lo, int k_hi, long long ticks, uint32_t* fail, int max_naps) {
   const int t = (int)threadIdx.x, steps = k_hi - k_lo + 1;
   const long long t0 = wall_clock64();
   for (int i = t; i < groups * steps; i += (int)blockDim.x) {
@@ -208,7 +208,7 @@ __global__ __launch_bounds__(WAVE) void k_xchg_gate(uint32_t* gcnt, int ring, in
     int naps = 1;
     while (__hip_atomic_load(c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (uint32_t)size) {
       for (int q = 0; q < naps; ++q) __builtin_amdgcn_s_sleep(127);
-      if (naps < 8) naps <<= 1;
+      if (naps < max_naps) naps <<= 1;
       if (wall_clock64() - t0 > ticks) { __hip_atomic_store(fail, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); break; }
     }
     __hip_atomic_store(c, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1828,6 +1828,8 @@ struct cc4_handle {
                                   // pays ~25 us to enqueue a wait, an all-gather and a publish -- more than a step of a small batch lasts)
   uint8_t* d_xslab = nullptr;     // [XRING][n][OBS_PACKED]
   uint8_t* d_xall = nullptr;      // [XRING][world * n][OBS_PACKED]
+  int khz = 0;                    // wall-clock rate (hipDeviceAttributeWallClockRate), asked once
+  int obs8_from_slab = -1;        // >= 0: the per-step ring's current buffer is to be filled from this slab of the exchange ring (xchg_end), when somebody reads it
   uint32_t* d_xflags = nullptr;   // [0] gathered, [1] timeout (what the waits poll)
   uint32_t* d_xgcnt = nullptr;    // [groups][XRING] group counters (xchg_count)
   uint32_t* h_xtimeout = nullptr; // pinned host word the kernel raises when a wait gives up (read without a copy)
@@ -2135,6 +2137,7 @@ static int launch_step(cc4_handle* h, const int32_t* d_actions, const uint8_t* d
   h->step_event_attached = h->comm != nullptr;
   if (h->ngroups > 1) h->groups_busy = true;
   h->obs_buf = buf;
+  h->obs8_from_slab = -1;           // (this step's packed rows are in the ring buffer it wrote)
   return 0;
 }
 
@@ -2394,6 +2397,11 @@ int cc4_reset(cc4_handle* h, const uint64_t* seeds, const uint8_t* env_mask) {
   // with a communicator the reset also writes the packed exchange row of its observations into the current ring buffer; an
   // overlapped all-gather may still be reading that buffer
   if (h->comm && h->gathers_issued > h->gathers_waited) { HIPCHK(h, hipStreamSynchronize(h->comm_stream)); h->gathers_waited = h->gathers_issued; }
+  if (h->comm && h->obs8_from_slab >= 0) {      // the reset writes the current ring buffer's packed rows itself -- all of them, unless it is masked
+    const size_t row = (size_t)h->cfg.num_envs * OBS_PACKED;
+    if (env_mask) HIPCHK(h, hipMemcpyAsync(h->d_obs8[h->obs_buf], h->d_xslab + (size_t)h->obs8_from_slab * row, row, hipMemcpyDeviceToDevice, h->stream));
+    h->obs8_from_slab = -1;
+  }
   hipLaunchKernelGGL(k_reset, dim3(h->cfg.num_envs), dim3(WAVE), 0, h->stream, a);
   HIPCHK(h, hipGetLastError());
   h->prev_valid = false;            // (cc4_replay_logged: no step to repeat)
@@ -2745,11 +2753,13 @@ static int xchg_begin(cc4_handle* h, int k, XchgArgs* x) {
     HIPCHK(h, hipMemsetAsync(h->d_xflags, 0, 2 * sizeof(uint32_t), h->stream));
     HIPCHK(h, hipMemsetAsync(h->d_xgcnt, 0, groups * cc4_handle::XRING * sizeof(uint32_t), h->stream));
     HIPCHK(h, hipEventRecord(h->xev, h->stream));
+    HIPCHK(h, hipStreamWaitEvent(h->comm_stream, h->xev, 0));
   }
+  // (clean -- the usual case: the previous call's communication stream zeroed both words behind its last publish, xchg_enqueue, and the host
+  // has waited for that stream since -- nothing of this call's is ordered behind anything: no memset, no event, no cross-stream wait)
   h->xflags_clean = 0;
-  HIPCHK(h, hipStreamWaitEvent(h->comm_stream, h->xev, 0));
-  int khz = 100000;
-  (void)hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, h->cfg.device_id);
+  if (h->khz <= 0) { int khz = 100000; (void)hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, h->cfg.device_id); h->khz = khz > 0 ? khz : 100000; }
+  const int khz = h->khz;
   *x = XchgArgs{h->d_xslab, h->d_xflags, h->d_xflags + 1, cc4_handle::XRING, (long long)h->xchg_watchdog_ms * (khz > 0 ? khz : 100000), h->d_xgcnt, h->d_xtimeout};
   return 0;
 }
@@ -2758,14 +2768,12 @@ static int xchg_enqueue(cc4_handle* h, int k, const XchgArgs& x, int form) {
   const size_t row = (size_t)h->cfg.num_envs * OBS_PACKED;
   const int C = h->xchg_chunk, n = h->cfg.num_envs;
   const int P = form == 3 ? h->run_P : 0, groups = form == 3 ? h->run_P : (n + 31) / 32;
-  int khz = 100000;
-  (void)hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, h->cfg.device_id);
-  const long long gate_ticks = 30000LL * (khz > 0 ? khz : 100000);         // 30 s: a step kernel that never gets there (the host would wait for it forever anyway)
+  const long long gate_ticks = 30000LL * (h->khz > 0 ? h->khz : 100000);         // 30 s: a step kernel that never gets there (the host would wait for it forever anyway)
   for (int c0 = 0, hi = 0; c0 < k; c0 = hi + 1) {
     hi = (c0 + C < k ? c0 + C : k) - 1;
     if (hi == k - 1 && hi > c0) --hi;       // the call's last step is a chunk of its own: behind the kernel's end only ONE all-gather is left
     if (c0 % cc4_handle::XRING + (hi - c0) >= cc4_handle::XRING) hi = c0 + cc4_handle::XRING - 1 - c0 % cc4_handle::XRING;     // a chunk's slabs are neighbours in the ring
-    hipLaunchKernelGGL(k_xchg_gate, dim3(1), dim3(WAVE), 0, h->comm_stream, x.gcnt, x.ring, groups, n, P, c0, hi, gate_ticks, x.timeout_host);
+    hipLaunchKernelGGL(k_xchg_gate, dim3(1), dim3(WAVE), 0, h->comm_stream, x.gcnt, x.ring, groups, n, P, c0, hi, gate_ticks, x.timeout_host, hi == k - 1 ? 1 : 8);
     HIPCHK(h, hipGetLastError());
     if (h->comm_delay_ticks > 0) { hipLaunchKernelGGL(k_spin, dim3(1), dim3(1), 0, h->comm_stream, h->comm_delay_ticks); HIPCHK(h, hipGetLastError()); }
     // ONE all-gather for the chunk's m neighbouring slabs (an ncclAllGather costs the host ~10 us to enqueue, grouped or not: eight of them
@@ -2780,6 +2788,10 @@ static int xchg_enqueue(cc4_handle* h, int k, const XchgArgs& x, int form) {
         HIPCHK(h, hipMemcpyAsync(h->d_xlog + ((size_t)h->xlog_n * h->world + rk) * row, block + ((size_t)rk * m + (size_t)(j - c0)) * row, row, hipMemcpyDeviceToDevice, h->comm_stream));
     HIPCHK(h, hipStreamWriteValue32(h->comm_stream, x.gathered, (uint32_t)(hi + 1), 0));
   }
+  // behind the call's last publish (every episode has counted its last step: nobody reads the two words any more) the communication stream
+  // itself hands them back zeroed for the next call -- the host waits for this stream in xchg_end, so the next launch finds them clean
+  HIPCHK(h, hipStreamWriteValue32(h->comm_stream, x.gathered, 0u, 0));
+  HIPCHK(h, hipStreamWriteValue32(h->comm_stream, x.timeout, 0u, 0));
   h->gathers_issued += k;
   return 0;
 }
@@ -2792,20 +2804,13 @@ static int xchg_end(cc4_handle* h, int k) {
   const int last = (k - 1) % cc4_handle::XRING;
   h->last_gathered = h->d_xall + last * row * (size_t)h->world;      // (the call's last step is a chunk of its own: plain [world * N] rows)
   h->gather_buf = -2;                               // (not one of the per-step ring's buffers: last_gathered says where)
-  // the per-step path's current buffer holds the observations of the last step as well: an explicit cc4_allgather_obs, or a per-step
-  // launch that follows, finds what it expects
-  HIPCHK(h, hipMemcpyAsync(h->d_obs8[h->obs_buf], h->d_xslab + last * row, row, hipMemcpyDeviceToDevice, h->stream));
+  // the per-step path's current buffer is to hold the observations of the last step as well -- filled when an explicit cc4_allgather_obs asks
+  // for it (a per-step launch or a reset that follows writes a buffer of its own)
+  h->obs8_from_slab = last;
   h->step_event_attached = false;
-  {   // the next call's flags, cleared now: its launch then has nothing in front of it (the group counters came back zero from the gates;
-      // cleared all the same when a watchdog fired: some counts may then never have been collected)
-    HIPCHK(h, hipMemsetAsync(h->d_xflags, 0, 2 * sizeof(uint32_t), h->stream));
-    if (flag) {
-      const size_t groups = (size_t)h->cfg.num_envs / 32 + 1 > (size_t)h->cus ? (size_t)h->cfg.num_envs / 32 + 1 : (size_t)h->cus;
-      HIPCHK(h, hipMemsetAsync(h->d_xgcnt, 0, groups * cc4_handle::XRING * sizeof(uint32_t), h->stream));
-    }
-    HIPCHK(h, hipEventRecord(h->xev, h->stream));
-    h->xflags_clean = 1;
-  }
+  if (flag) {   // a watchdog fired: some counts may never have been collected -- everything cleared the long way before the next call
+    h->xflags_clean = 0;
+  } else h->xflags_clean = 1;   // (both words zeroed by the communication stream behind its last publish, the group counters by the gates)
   if (flag) {
     // an item waited longer than the watchdog for its slab: the exchange did not keep up at all (e.g. its kernels found no room beside the
     // one-launch kernel).  The episodes are intact -- a wait that gives up only stops protecting slabs, so gathers of this call may have
@@ -2889,7 +2894,11 @@ static int run_random_steps_impl(cc4_handle* h, uint64_t seed0, uint32_t t0, int
                h->full_obs_next ? 1 : 0, (uint32_t)h->cfg.topology_seed, nullptr, h->d_reset_ws, nullptr, 0};
     XchgArgs x{};
     const bool exchange = h->comm != nullptr;
+    static const bool xprof = getenv("CC4_EXCHANGE_PROF") != nullptr;      // debug: where the host's time goes around a one-launch call with the exchange
+    static double xp[6] = {0}; static long xpn = 0;
+    const auto xp0 = std::chrono::steady_clock::now();
     if (exchange && xchg_begin(h, k, &x)) return -1;
+    const auto xp1 = std::chrono::steady_clock::now();
     if (ms_step_kernels && h->evs.size() < 2) { h->evs.resize(2, nullptr); for (auto& e : h->evs) if (!e) HIPCHK(h, hipEventCreate(&e)); }
     hipEvent_t e0 = ms_step_kernels ? h->evs[0] : nullptr, e1 = ms_step_kernels ? h->evs[1] : nullptr;
     auto c0 = std::chrono::steady_clock::now();
@@ -2915,12 +2924,15 @@ static int run_random_steps_impl(cc4_handle* h, uint64_t seed0, uint32_t t0, int
     h->stat_steps += k;
     h->full_obs_next = false;     // (asked for, the first step of every episode rewrote all its observation values)
     h->main_ahead = h->ngroups > 1;
+    const auto xp2 = std::chrono::steady_clock::now();
     if (exchange) {
       auto g0 = std::chrono::steady_clock::now();
       if (xchg_enqueue(h, k, x, form)) return -1;
       h->stat_gather_us += std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - g0).count();
     }
+    const auto xp3 = std::chrono::steady_clock::now();
     HIPCHK(h, hipStreamSynchronize(h->stream));
+    const auto xp4 = std::chrono::steady_clock::now();
     if (h->d_timeline) {      // debug: where a call's time goes between the kernel's entry and its last item (ticks of the 100 MHz wall clock)
       std::vector<unsigned long long> tl(4 * (size_t)h->run_grid);
       HIPCHK(h, hipMemcpy(tl.data(), h->d_timeline, tl.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
@@ -2947,6 +2959,16 @@ static int run_random_steps_impl(cc4_handle* h, uint64_t seed0, uint32_t t0, int
                                                       (xf[i] - e0) / 100.0, (xs[i] / xn[i] - (double)e0) / 100.0, (xl[i] - e0) / 100.0); }
     }
     if (exchange && xchg_end(h, k)) return -1;
+    if (xprof && exchange) {
+      const auto xp5 = std::chrono::steady_clock::now();
+      auto us = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double, std::micro>(b - a).count(); };
+      xp[0] += us(xp0, xp1); xp[1] += us(xp1, xp2); xp[2] += us(xp2, xp3); xp[3] += us(xp3, xp4); xp[4] += us(xp4, xp5); xp[5] += us(xp0, xp5);
+      if (++xpn % 200 == 0) {
+        fprintf(stderr, "[cc4 exchange prof] k=%d, mean of 200 calls (us): begin %.1f, launch %.1f, enqueue of the chunks %.1f, wait for the kernel %.1f, then for the communication stream %.1f; call %.1f\n",
+                k, xp[0] / 200, xp[1] / 200, xp[2] / 200, xp[3] / 200, xp[4] / 200, xp[5] / 200);
+        for (double& v : xp) v = 0;
+      }
+    }
     if (ms_step_kernels) HIPCHK(h, hipEventElapsedTime(ms_step_kernels, h->evs[0], h->evs[1]));
     return 0;
   }
@@ -3353,6 +3375,11 @@ int cc4_allgather_obs(cc4_handle* h, uint8_t** d_all_obs8) {
   if (!h->comm) { h->err = "cc4_allgather_obs: cc4_comm_init was not called"; return -2; }
   HIPCHK(h, hipSetDevice(h->cfg.device_id));
   const int buf = h->obs_buf;
+  if (h->obs8_from_slab >= 0) {    // the last step ran inside a one-launch kernel with the exchange: its packed rows are in the exchange ring
+    const size_t row = (size_t)h->cfg.num_envs * OBS_PACKED;
+    HIPCHK(h, hipMemcpyAsync(h->d_obs8[buf], h->d_xslab + (size_t)h->obs8_from_slab * row, row, hipMemcpyDeviceToDevice, h->stream));
+    h->obs8_from_slab = -1;
+  }
   if (!h->step_event_attached) {   // e.g. the observations of a reset: main-stream work, behind which the group streams' work was joined
     if (join_groups(h)) return -1;
     HIPCHK(h, hipEventRecord(h->ev_step[buf][0], h->stream));

@@ -523,6 +523,9 @@ def test_exchange_from_inside_the_one_launch_kernels_gathers_every_step(n, mode,
         assert np.array_equal(D.allgathered_obs_host(dev, 1), o[0].astype(np.uint8)), K
     xi = dev.exchange_info()
     assert xi['calls'] == 3 and xi['watchdog_timeouts'] == 0 and xi['in_kernel'], xi
+    # an explicit all-gather right behind a one-launch call: the per-step ring's buffer is filled from the exchange ring's last slab on demand
+    assert D.allgather_obs_device(dev); D.allgather_wait(dev)
+    assert np.array_equal(D.allgathered_obs_host(dev, 1), o[0].astype(np.uint8))
     # a per-step launch with the caller's actions and an explicit all-gather behind the one-launch calls
     a = random_actions(seed0 + 1, t, n)
     d = dev.step(a); o = ora.step_batch(a)
