@@ -92,6 +92,7 @@ SIGNATURES = {
     'cc4_keep_previous': (ctypes.c_int, [_P, ctypes.c_int32]),
     'cc4_replay_logged': (ctypes.c_int, [_P]),
     'cc4_debug_profile': (ctypes.c_int, [_P, ctypes.c_int, _P]),
+    'cc4_debug_policy_probe': (ctypes.c_int, [_P, ctypes.c_int32, ctypes.c_int32, _P]),
     'cc4_comm_unique_id': (ctypes.c_int, [_P]),
     'cc4_comm_init': (ctypes.c_int, [_P, ctypes.c_int32, ctypes.c_int32, _P]),
     'cc4_allgather_obs': (ctypes.c_int, [_P, ctypes.POINTER(_P)]),

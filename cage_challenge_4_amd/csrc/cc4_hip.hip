@@ -1440,6 +1440,40 @@ __global__ __launch_bounds__(WAVE, CC4_LEAN_MINW) void k_step_philox1(StepArgs a
 // afterwards carries it) every item of it starts with an agent-scope acquire (buffer_inv sc1: the CU's L1 dropped), on the owner's waves
 // and the thieves' alike.  Items handed out before the bit was set were all the owner's own and read what that CU wrote itself.
 // Never across XCDs: their L2s do not agree without a write-back.
+// ---- experiment: the red policy phase with the agents of G episodes side by side on ONE wave.  Lane 8 g + r runs
+// step_red_policy_tick of agent r of the wave's g-th episode -- what a group schedule would do in the phase that is 31 % of a step -- on the live
+// state of the batch (agent parts staged into LDS as in the step kernel, nothing written back).  G = 1 is today's lane layout.  cyc[block] = the
+// wave's cycles in the phase; the launch duration (events) / episodes = what the phase costs an episode at that grouping and residency.
+template <int G>
+__global__ __launch_bounds__(WAVE) void k_policy_probe(StepArgs a, unsigned long long* cyc) {
+  extern __shared__ uint4 lds[];
+  __shared__ StepWork work[G];
+  const int lane = (int)threadIdx.x, e0 = (int)blockIdx.x * G;
+  for (int g = 0; g < G; ++g) if (e0 + g < a.n) stage_in<HOT_VEC>(lds + g * HOT_VEC, reinterpret_cast<const uint4*>(a.st + e0 + g), lane);
+  for (int i = lane; i < (int)(G * sizeof(StepWork) / 4); i += WAVE) reinterpret_cast<uint32_t*>(&work[0])[i] = 0;
+  __syncthreads();
+  const int g = lane >> 3, r = lane & 7, e = e0 + g;
+  const unsigned long long t0 = clock64();
+  int dropped = 0;
+  if (g < G && r < NRED && e < a.n) {
+    EnvState* s = reinterpret_cast<EnvState*>(lds + g * HOT_VEC);
+    const int st_now = s->step_count;
+    if (!s->done && step_phase_of(st_now, s->phase_len[0], s->phase_len[1], s->phase_len[2]) >= 0) {
+      Rng rl;
+      rng_fork(&rl, &s->rng, ST_RESET);
+      rl.mode = 1;
+      rng_begin_step(&rl, (uint32_t)st_now);
+      uint32_t pre[4];
+      rng_block(&rl, ST_RED_POL + (uint32_t)r, 0, pre);
+      Ctx xr{s, cold_at(a.cold, (size_t)e, cold_row_bytes(a.steps)), &rl, a.st[e].hd, &work[g]};
+      dropped = step_red_policy_tick(xr, r, false, pre);
+    }
+  }
+  __syncthreads();
+  const unsigned long long t1 = clock64();
+  if (lane == 0) cyc[blockIdx.x] = t1 - t0;
+  if (dropped == 12345) cyc[0] = 0;      // (keeps the result alive)
+}
 constexpr uint32_t TK_SHARED = 0x80000000u;
 // register budget of the persistent counter-mode kernel in waves per SIMD: 5 (88 VGPRs, nothing spilled: 20 waves per CU) or 6 (80 VGPRs, ten
 // spilled: 24 by registers, 21 by LDS -- six 1280-byte granules per wave).  Measured (profiles/r05_persist_21_waves.txt, 8192 episodes):
@@ -3254,6 +3288,47 @@ int cc4_debug_profile(cc4_handle* h, int enable, unsigned long long* out) {
   if (enable && !h->d_prof) { HIPCHK(h, hipMalloc(&h->d_prof, bytes)); HIPCHK(h, hipMemsetAsync(h->d_prof, 0, bytes, h->stream)); }
   if (out && h->d_prof) { HIPCHK(h, hipMemcpyAsync(out, h->d_prof, bytes, hipMemcpyDeviceToHost, h->stream)); HIPCHK(h, hipStreamSynchronize(h->stream)); }
   if (!enable && h->d_prof) { (void)hipFree(h->d_prof); h->d_prof = nullptr; }
+  return 0;
+}
+
+// debug: the red policy phase of every episode with G episodes' agents per wave; out[0] = mean launch duration in us, out[1] = mean cycles
+// of a wave in the phase, out[2] = waves per launch.  Reads the batch as it stands, writes nothing back.
+int cc4_debug_policy_probe(cc4_handle* h, int32_t G, int32_t reps, double* out) {
+  HIPCHK(h, hipSetDevice(h->cfg.device_id));
+  if (h->cfg.rng_mode != 1) { h->err = "cc4_debug_policy_probe: counter mode only"; return -2; }
+  if (join_groups(h)) return -1;
+  const int n = h->cfg.num_envs, waves = (n + G - 1) / G;
+  unsigned long long* d_cyc = nullptr;
+  HIPCHK(h, hipMalloc(&d_cyc, (size_t)waves * sizeof(unsigned long long)));
+  StepArgs a{h->d_state, h->d_cold, nullptr, nullptr, h->d_obs, h->d_reward, h->d_done, h->d_err, nullptr, nullptr, 0, 0,
+             n, 0, h->cfg.steps, h->cfg.rng_mode,
+             (h->cfg.red_policy & 3) | (h->cfg.green_policy ? GP_SLEEP_BIT : 0) | (h->cfg.green_policy == 2 ? GP_OPEN_BIT : 0) | (h->cfg.blue_policy ? BP_RANDOM_BIT : 0), 0,
+             (uint32_t)h->cfg.topology_seed, nullptr, h->d_reset_ws, nullptr, 0};
+  hipEvent_t e0, e1;
+  HIPCHK(h, hipEventCreate(&e0)); HIPCHK(h, hipEventCreate(&e1));
+  const size_t dyn = (size_t)G * offsetof(EnvState, hd);
+  auto launch = [&]() {
+    switch (G) {
+      case 1: hipLaunchKernelGGL(k_policy_probe<1>, dim3(waves), dim3(WAVE), dyn, h->stream, a, d_cyc); break;
+      case 2: hipLaunchKernelGGL(k_policy_probe<2>, dim3(waves), dim3(WAVE), dyn, h->stream, a, d_cyc); break;
+      case 4: hipLaunchKernelGGL(k_policy_probe<4>, dim3(waves), dim3(WAVE), dyn, h->stream, a, d_cyc); break;
+      default: hipLaunchKernelGGL(k_policy_probe<8>, dim3(waves), dim3(WAVE), dyn, h->stream, a, d_cyc); break;
+    }
+  };
+  if (G != 1 && G != 2 && G != 4 && G != 8) { h->err = "cc4_debug_policy_probe: G is 1, 2, 4 or 8"; (void)hipFree(d_cyc); return -2; }
+  if (G == 8) HIPCHK(h, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_policy_probe<8>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn));
+  launch();                                                     // warm-up
+  HIPCHK(h, hipGetLastError());
+  HIPCHK(h, hipEventRecord(e0, h->stream));
+  for (int i = 0; i < reps; ++i) launch();
+  HIPCHK(h, hipEventRecord(e1, h->stream));
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  float ms = 0.f; HIPCHK(h, hipEventElapsedTime(&ms, e0, e1));
+  std::vector<unsigned long long> cyc((size_t)waves);
+  HIPCHK(h, hipMemcpy(cyc.data(), d_cyc, cyc.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+  double sum = 0; for (auto c : cyc) sum += (double)c;
+  out[0] = (double)ms * 1000.0 / (reps > 0 ? reps : 1); out[1] = sum / waves; out[2] = waves;
+  (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); (void)hipFree(d_cyc);
   return 0;
 }
 
