@@ -16,10 +16,36 @@ def build():
     subprocess.check_call(['make', '-C', ORACLE_DIR, '-s'])
 
 
+def usable_cores():
+    """Hardware threads this process may really use: affinity mask and the container's CPU quota (cgroup v2 cpu.max).  OpenMP's default is every core it
+    can see; on a box whose cgroup grants 16 of 128, the other 112 threads only spin (the GPU suite waits for the oracle most of its time)."""
+    n = os.cpu_count() or 1
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
+    except Exception:
+        pass
+    try:
+        q, per = open('/sys/fs/cgroup/cpu.max').read().split()
+        if q != 'max':
+            n = max(1, min(n, int(int(q) / int(per))))
+    except Exception:
+        pass
+    return n
+
+
+_LIB = None
+
+
 def load():
+    global _LIB
+    if _LIB is not None:
+        return _LIB
     if not os.path.exists(LIB):
         build()
     lib = ctypes.CDLL(LIB)
+    lib.cc4o_set_threads.argtypes = [ctypes.c_int]
+    if not os.environ.get('OMP_NUM_THREADS'):
+        lib.cc4o_set_threads(usable_cores())
     lib.cc4o_create.restype = ctypes.c_void_p
     lib.cc4o_create.argtypes = [ctypes.c_int]
     lib.cc4o_create2.restype = ctypes.c_void_p
@@ -50,6 +76,7 @@ def load():
     lib.cc4o_dump.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_int]
     lib.cc4o_true_state.restype = ctypes.c_longlong
     lib.cc4o_true_state.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_char_p, ctypes.c_size_t]
+    _LIB = lib
     return lib
 
 
