@@ -176,22 +176,26 @@ def test_full_batch_matches_oracle_every_step(rng_mode, philox_kernel):
     dev.close()
 
 
-@pytest.mark.parametrize('n,red_policy,blue_policy,T,steps', [(8192, 0, 0, 170, 75), (4096, 2, 0, 110, 50), (4096, 3, 1, 110, 50)],
-                         ids=['8192-fsm', '4096-discovery', '4096-randomselect-builtinblue'])
-def test_bench_configuration_matches_oracle_every_step(n, red_policy, blue_policy, T, steps):
+@pytest.mark.parametrize('n,red_policy,blue_policy,T,steps,rng_mode', [(8192, 0, 0, 1100, 500, 1), (8192, 2, 0, 330, 150, 1), (8192, 3, 1, 330, 150, 1), (4096, 0, 0, 330, 150, 1),
+                                                                       (8192, 0, 0, 1100, 500, 0)],
+                         ids=['8192-fsm-500-step-episodes', '8192-discovery', '8192-randomselect-builtinblue', '4096-fsm', '8192-fsm-500-step-episodes-numpy-stream'])
+def test_bench_configuration_matches_oracle_every_step(n, red_policy, blue_policy, T, steps, rng_mode):
     """the configuration bench.py times -- counter mode, autoreset, the kernel cc4_create picks for the batch
     size with NO override (at 8192 episodes k_step_philox1 at its natural residency -- generation work area in HBM, host rows in
     L2 with atomics -- as three concurrent launches on three streams) -- against the oracle for ALL episodes at EVERY step (observations, rewards, dones, error flags)
     across two scenario regenerations, then the generator words and the packed state of every episode."""
     import os
     assert 'CC4_PHILOX_LEAN' not in os.environ and 'CC4_PHILOX_MINW' not in os.environ and 'CC4_GROUPS' not in os.environ
-    # (two regenerations each; the headline configuration -- 8192 episodes, FiniteStateRedAgent -- runs 75-step episodes, the other red
-    # policies and the built-in blue policy 50-step episodes on the N = 2 share, 4096 episodes: the same kernel and launch grouping; the
-    # suite's wall time is the host's -- oracle, action generator, comparisons --, DESIGN 5)
-    dev = _dev(n, steps=steps, rng_mode=1, autoreset=True, red_policy=red_policy, blue_policy=blue_policy)
-    # three or four launches of the one-wave kernel per step (four where the runtime runs four streams side by side)
-    assert dev.step_kernel == 'k_step_philox1' and dev.lib.cc4_launches_per_step(dev._h) in (3, 4)
-    ora = OracleVecEnv(n, steps=steps, rng_mode=1, autoreset=True, red_policy=red_policy, blue_policy=blue_policy)
+    # (two regenerations each; the headline configuration -- 8192 episodes, FiniteStateRedAgent, 500-step episodes: BASELINE configs[2] as written --
+    # for 1100 steps, the other red policies and the built-in blue policy with 150-step episodes; r05 ran these at 75 / 50-step episodes while the
+    # oracle's OpenMP pool oversubscribed the box's cgroup -- tests/oracle_binding.usable_cores.  Since r05 a host-stepped batch is ONE launch per step on
+    # the main stream (the caller fetches every step: launch_step); the launches per episode group run in test_timed_bench_path_matches_oracle's
+    # one-step bursts and in test_learner_loop_matches_oracle_in_every_launch_form)
+    dev = _dev(n, steps=steps, rng_mode=rng_mode, autoreset=True, red_policy=red_policy, blue_policy=blue_policy)
+    # three or four launches of the one-wave kernel per step (four where the runtime runs four streams side by side); the last case: the same
+    # batch on the numpy stream (bench.py's alt_rng: bit-exact with the reference itself), kernel k_step
+    assert dev.step_kernel == ('k_step_philox1' if rng_mode else 'k_step') and dev.lib.cc4_launches_per_step(dev._h) in (3, 4)
+    ora = OracleVecEnv(n, steps=steps, rng_mode=rng_mode, autoreset=True, red_policy=red_policy, blue_policy=blue_policy)
     assert np.array_equal(dev.reset(seeds=1000), ora.reset_batch(1000))
     resets = 0
     for t in range(T):
@@ -224,8 +228,8 @@ def test_timed_bench_path_matches_oracle(n, kernel, run_kernel):
     packed state of all episodes."""
     import ctypes, os
     assert 'CC4_PHILOX_LEAN' not in os.environ and 'CC4_PHILOX_MINW' not in os.environ and 'CC4_GROUPS' not in os.environ
-    steps, seed0 = (120, 4242) if n == 8192 else (60, 4242)
-    bursts = (1, 20, 100, 20, 1, 20) if n == 8192 else (1, 20, 40, 12)
+    steps, seed0 = (150, 4242) if n == 8192 else (100, 4242)
+    bursts = (1, 20, 137, 20, 1, 20, 9, 64) if n == 8192 else (1, 20, 57, 12, 3, 40)
     dev = _dev(n, steps=steps, rng_mode=1, autoreset=True)
     # (1024 episodes = BASELINE configs[1]: the chip holds the batch at once, and the region is ONE launch of the multi-step kernel
     # k_run_philox, every block looping over the steps of its episode)
@@ -261,13 +265,13 @@ def test_enqueue_threads_change_nothing(threads, monkeypatch):
     monkeypatch.setenv('CC4_RUN1', '0')
     monkeypatch.setenv('CC4_PERSIST', '0')
     n, steps, seed0 = 4096, 25, 99
-    for rep in range(2):
+    for rep in range(3):
         dev = _dev(n, steps=steps, rng_mode=1, autoreset=True)
         assert dev.launches_per_step in (3, 4) and dev.run_kernel == 'k_step_philox1'      # (CC4_RUN1=0 below: the per-step launches are what the threads serve)
         ora = OracleVecEnv(n, steps=steps, rng_mode=1, autoreset=True)
         assert np.array_equal(dev.reset(seeds=seed0 + rep), ora.reset_batch(seed0 + rep))
         t = 0
-        for K in (1, 12, 3, 14):
+        for K in (1, 20, 3, 57):
             dev.run_random_steps(seed0, t, K, timed=(K != 3))
             for k in range(K):
                 o = ora.step_batch(random_actions(seed0, t + k, n))
@@ -291,7 +295,7 @@ def test_persistent_kernel_and_its_shared_tail(mode, kernel):
     ora = OracleVecEnv(n, steps=steps, rng_mode=mode, autoreset=True)
     assert np.array_equal(dev.reset(seeds=seed0), ora.reset_batch(seed0))
     t = 0
-    for K in (10, 13, 3, 25, 11, 1, 17, 10):
+    for K in (10, 13, 3, 10, 25, 11, 40, 10, 1, 17):
         dev.run_random_steps(seed0, t, K, timed=(K % 2 == 1))
         for k in range(K):
             a = random_actions(seed0, t + k, n)
@@ -562,6 +566,35 @@ def test_exchange_watchdog_returns_the_handle_to_per_step_launches(monkeypatch):
         o = ora.step_batch(random_actions(seed0, k, n))
     dev._fetch()
     assert np.array_equal(dev._obs, o[0]) and np.array_equal(D.allgathered_obs_host(dev, 1), o[0].astype(np.uint8))
+    dev.close(); ora.close()
+
+
+@pytest.mark.parametrize('n,mode', [(4096, 1), (8192, 1), (5000, 0)], ids=['4096-multistep1', '8192-persistent', '5000-numpy-stream'])
+def test_exchange_soak_random_call_lengths_and_delays(n, mode):
+    """The exchange from inside the one-launch kernels under a random schedule (tests/soak_exchange.py, shortened): calls of 10..90 steps -- every other one
+    longer than the ring of 32 slabs --, every all-gather held up by a random 0..60 us, across regenerations; every step's gathered rows against the oracle."""
+    seed0, steps = 2468, 120
+    dev = _dev(n, steps=steps, rng_mode=mode, autoreset=True); dev.reset(seeds=seed0)
+    _one_rank_comm(dev)
+    ora = OracleVecEnv(n, steps=steps, rng_mode=mode, autoreset=True); ora.reset_batch(seed0)
+    rng = np.random.default_rng(n + mode)
+    t = 0
+    for c in range(8):
+        K = int(rng.integers(10, 91))
+        dev._chk(dev.lib.cc4_debug_comm_delay_us(dev._h, int(rng.integers(0, 61))), 'cc4_debug_comm_delay_us')
+        dev.gather_log(K)
+        dev.run_random_steps(seed0, t, K, timed=False)
+        got = dev.get_gather_log(1, 0, K)
+        for k in range(K):
+            o = ora.step_batch(random_actions(seed0, t + k, n))
+            bad = np.nonzero((got[k] != _pack(o[0].astype(np.uint8))).any(axis=1))[0]
+            assert bad.size == 0, (c, K, t + k, bad[:10].tolist())
+        t += K
+    xi = dev.exchange_info()
+    assert xi['in_kernel'] and xi['calls'] == 8 and xi['watchdog_timeouts'] == 0, xi
+    assert np.array_equal(dev.rng_state(), ora.rng_state())
+    for i in range(0, n, 7):
+        assert np.array_equal(dev.get_state(i), ora.get_state(i)), i
     dev.close(); ora.close()
 
 
