@@ -217,8 +217,8 @@ def test_bench_configuration_matches_oracle_every_step(n, red_policy, blue_polic
 
 
 @pytest.mark.parametrize('n,kernel,run_kernel', [(8192, 'k_step_philox1', 'k_run_philox1'), (1024, 'k_step_philox', 'k_run_philox'), (2048, 'k_step_philox', 'k_run_philox8'),
-                                                  (4096, 'k_step_philox1', 'k_run_philox1m')],
-                         ids=['8192', '1024-multistep', '2048-multistep8', '4096-multistep1'])
+                                                  (4096, 'k_step_philox1', 'k_run_philox1m'), (16384, 'k_step_philox1', 'k_run_philox1')],
+                         ids=['8192', '1024-multistep', '2048-multistep8', '4096-multistep1', '16384-partitions-of-64'])
 def test_timed_bench_path_matches_oracle(n, kernel, run_kernel):
     """the exact region bench.py times -- cc4_run_random_steps on k_step_philox1, 8192 episodes, the handle's own
     launch grouping, no override, no communicator: the blue actions are drawn IN the step kernel on the bank lanes (BK_BRAND) --
