@@ -195,10 +195,10 @@ def host_api_rates(seed=123, steps=300, eval_eps=3):
 
 
 def load_pmc_traffic(envs, kernel):
-    """HBM bytes per STEP from the committed rocprofv3 --pmc passes of this bench command (profiles/r05_pmc.json, tools/profile_round.sh),
+    """HBM bytes per STEP from the committed rocprofv3 --pmc passes of this bench command (profiles/r06_pmc.json, tools/profile_round.sh),
     with their source -- only if they were taken on the very kernel the timed regions launched (`kernel`: the one-launch forms are
     profiled as what they are: bytes of a launch / steps of the launch); else (None, None)."""
-    for name in ('r05_pmc.json',):
+    for name in ('r06_pmc.json',):
         p = os.path.join(ROOT, 'profiles', name)
         try:
             with open(p) as f:
@@ -234,6 +234,7 @@ def exchange_world1(make_env, measure, D, args, lo, timeout_s=90.0):
     import numpy as np
     from cage_challenge_4_amd import RNG_PHILOX
     out, box = {}, {}
+    sub_seconds = max(0.2, args.min_seconds / 5.0)
 
     def leg():
         try:
@@ -241,7 +242,7 @@ def exchange_world1(make_env, measure, D, args, lo, timeout_s=90.0):
                 e = make_env(n, RNG_PHILOX, lo if n == 8192 else 0)
                 D.init_rccl(e, 0, 1)
                 e.reset(seeds=np.uint64(args.seed0) + np.arange(n, dtype=np.uint64))
-                r = measure(e, 0, n, min_seconds=min(args.min_seconds, 0.2))
+                r = measure(e, 0, n, min_seconds=sub_seconds)
                 xi = e.exchange_info()
                 hs = e.host_stats()
                 r.update({'unit': 'agent-env steps/s', 'total_envs': n, 'exchange': xi, 'allgathers_issued': hs['gathers'],
@@ -278,7 +279,7 @@ def main():
     ap.add_argument('--total-envs', type=int, default=TOTAL_ENVS)
     ap.add_argument('--envs-per-gpu', type=int, default=0, help='override: total = envs-per-gpu x gpus (weak-scaled run)')
     ap.add_argument('--episode-steps', type=int, default=500)
-    ap.add_argument('--min-seconds', type=float, default=0.3, help='timed regions are repeated until this much timed work has accumulated')
+    ap.add_argument('--min-seconds', type=float, default=2.0, help='timed regions of the headline are repeated until this much timed work has accumulated (the sub-entries take a fifth of it each, 0.2 s at least)')
     ap.add_argument('--rng', choices=['pcg64', 'philox'], default='philox')
     ap.add_argument('--no-alt', action='store_true', help='skip the sub-entries (other RNG mode, 1024 episodes, uniform topology)')
     ap.add_argument('--seed0', type=int, default=1000)
@@ -372,6 +373,7 @@ def main():
         out['run_kernel'] = run_kernel
         return out
 
+    sub_seconds = max(0.2, args.min_seconds / 5.0)      # the sub-entries' share of timed work
     main_res = measure(env, lo, total_envs)
     # what this rank's host did (cc4_host_stats): a multi-GPU curve is explained by these -- the slowest rank's kernel period, the
     # host time per step spent enqueueing launches and all-gathers, and whether an all-gather ever held a step up
@@ -394,19 +396,61 @@ def main():
     mean_hosts = float(np.mean([int(env.topology(i)[27::2].sum()) for i in range(0, n_local, max(1, n_local // 64))]))
 
     subs = {}
+    if dist_on and not args.envs_per_gpu and not exchange_note and os.environ.get('CC4_BENCH_NO_WEAK') != '1':
+        # The same job WEAK-scaled in the same run: the strong line above cuts BASELINE configs[3]'s 8192 episodes into world shares --
+        # 1024 per GPU at 8 GPUs, the latency regime of this engine --; here every GPU keeps the full single-GPU batch (8192 per rank,
+        # world x 8192 in total) with the exchange of every step's observations across all ranks, which is the efficient way to use N GPUs.
+        import threading
+        wbox = {}
+
+        def weak_leg():
+            try:
+                per = TOTAL_ENVS
+                lo_w = rank * per
+                ew = make_env(per, mode, lo_w)
+                D.init_rccl(ew, rank, world, plane)
+                ew.reset(seeds=np.uint64(args.seed0) + np.arange(lo_w, lo_w + per, dtype=np.uint64))
+                rw = measure(ew, lo_w, per * world, min_seconds=max(0.2, args.min_seconds / 2.0))
+                rw.update({'unit': 'agent-env steps/s', 'scaling': 'weak', 'envs_per_gpu': per, 'total_envs': per * world, 'kernel': ew.step_kernel,
+                           'exchange_info': ew.exchange_info(), 'note': 'every rank keeps 8192 episodes; RCCL all-gather of every step\'s packed observations across all ranks'})
+                ew.close()
+                wbox['res'] = rw
+            except Exception as ex:      # noqa: BLE001
+                wbox['res'] = {'skipped': repr(ex)}
+        # (under a watchdog: a rank that fails here must not take the strong line, which is already measured, down with it)
+        sys.stdout.flush()
+        saved_fd2 = os.dup(1)
+        os.dup2(2, 1)
+        th = threading.Thread(target=weak_leg, daemon=True)
+        th.start()
+        th.join(float(os.environ.get('CC4_BENCH_WEAK_TIMEOUT', '180')))
+        import ctypes as _ct
+        _ct.CDLL(None).fflush(None)
+        sys.stdout.flush()
+        os.dup2(saved_fd2, 1)
+        os.close(saved_fd2)
+        subs['weak_scaled'] = wbox.get('res') or {'skipped': 'the weak-scaled leg did not finish within its time limit on this rank', '_stalled': True}
     if not args.no_alt and not dist_on:      # single-GPU runs also time the other RNG mode and the small batch
         other = 'pcg64' if args.rng == 'philox' else 'philox'
         e2 = make_env(n_local, RNG_PCG64 if other == 'pcg64' else RNG_PHILOX, lo)
-        r2 = measure(e2, lo, total_envs)
+        r2 = measure(e2, lo, total_envs, min_seconds=max(sub_seconds, args.min_seconds / 2.0))
         k2 = e2.step_kernel
         e2.close()
         r2.update({'rng': other, 'kernel': k2, 'unit': 'agent-env steps/s', 'total_envs': total_envs,
                    'note': 'pcg64 = numpy Generator(PCG64) stream, bit-exact with the reference under the same seed' if other == 'pcg64'
                            else 'philox = counter-based streams per (agent, phase, step, episode)'})
+        hot_b, row_b = int(env.lib.cc4_hot_bytes()), int(env.lib.cc4_state_bytes())
+        # contract bytes of the kernel that serves that mode: the numpy-stream kernel stages the agent part and visits the host table in place
+        b2 = (2 * hot_b + (row_b - hot_b) + 4 * 578 + 29) if other == 'pcg64' else int(env.lib.cc4_algorithmic_bytes_per_env_step())
+        a2 = b2 * n_local / (r2['launch_ms'] * 1e-3) / 1e9
+        r2['roofline'] = {'bound': 'latency', 'roofline': 'hbm', 'achieved': a2, 'peak': HBM_PEAK_GBPS, 'unit': 'GB/s', 'frac': a2 / HBM_PEAK_GBPS, 'traffic': None,
+                          'kernel': r2['run_kernel'], 'step_ms': r2['launch_ms'], 'algorithmic_bytes_per_step': b2 * n_local,
+                          'note': 'algorithmic bytes per step (contract figure of that kernel) / kernel time per step against the HBM peak; the walking lane of the '
+                                  'numpy-stream kernel is a dependency chain, not a stream of bytes: bound = latency'}
         subs['alt_rng'] = r2
         if total_envs != 1024:
             e4 = make_env(1024, mode, 0)
-            r4 = measure(e4, 0, 1024)
+            r4 = measure(e4, 0, 1024, min_seconds=sub_seconds)
             k4 = e4.step_kernel
             e4.close()
             r4['roofline'] = ({'bound': 'latency', 'us_per_step': r4['launch_ms'] * 1e3,
@@ -422,7 +466,7 @@ def main():
             # BASELINE configs 2-4 vs 5: the same workload with ONE topology shared by all episodes (dynamics still keyed per
             # episode); the headline run above randomises the topology per episode and per reset, as the reference does
             e3 = make_env(n_local, RNG_PHILOX, lo, topology_seed=args.seed0)
-            r3 = measure(e3, lo, total_envs)
+            r3 = measure(e3, lo, total_envs, min_seconds=sub_seconds)
             e3.close()
             r3.update({'unit': 'agent-env steps/s', 'note': 'uniform topology: every episode draws its scenario from one shared key (cc4_config.topology_seed)'})
             subs['uniform_topology'] = r3
@@ -431,18 +475,37 @@ def main():
             # k_random_actions standing in for a policy network's argmax), and cc4_step_device consumes them -- a launch of the step
             # kernel per step and episode group, no host synchronisation inside the region, observations readable after every step
             e5 = make_env(n_local, RNG_PHILOX, lo)
-            r5 = measure(e5, lo, total_envs, runner=lambda t0, k, timed: e5.run_policy_steps(args.seed0 + lo, t0, k), min_seconds=min(args.min_seconds, 0.2))
+            # r06: the rollout form -- ONE launch of the persistent kernel per K-step region, the stand-in policy (k_random_actions' draws, per policy group)
+            # on the handle's policy stream between gates and publishes (include/cc4.h cc4_rollout_begin)
+            r7 = None
+            if e5.run_kernel_for(args.steps) == 'k_run_philox1':
+                try:
+                    r7 = measure(e5, lo, total_envs, runner=lambda t0, k, timed: e5.run_rollout(k, 'random', args.seed0 + lo, t0), min_seconds=sub_seconds)
+                    r7.update({'unit': 'agent-env steps/s', 'kernel': e5.step_kernel, 'run_kernel': 'k_run_philox1', 'launches_per_step': 1.0 / args.steps,
+                               'policy_ops_per_step': 6,
+                               'note': 'cc4_rollout_begin .. cc4_rollout_end: one launch of k_run_philox1 per region; per step and policy group (2) a gate on the last '
+                                       'step\'s packed observations, the stand-in policy kernel, a publish (hipStreamWriteValue32) -- the steps wait for the publishes'})
+                except Exception as ex:      # noqa: BLE001
+                    r7 = {'skipped': repr(ex)}
+            r5 = measure(e5, lo, total_envs, runner=lambda t0, k, timed: e5.run_policy_steps(args.seed0 + lo, t0, k), min_seconds=sub_seconds)
             r5.update({'unit': 'agent-env steps/s', 'kernel': e5.step_kernel, 'run_kernel': e5.step_kernel, 'launches_per_step': 2,
                        'note': 'per step: k_random_actions -> the handle\'s device action buffer, then cc4_step_device; a policy over the WHOLE batch orders every '
                                'episode group behind it, so the library steps the batch with ONE launch on the main stream instead of a fork and a join across the '
                                'group streams per step (r05: 334-393 -> 583 M); `grouped` is the same policy applied per group'})
-            r6 = measure(e5, lo, total_envs, runner=lambda t0, k, timed: e5.run_policy_steps_grouped(args.seed0 + lo, t0, k), min_seconds=min(args.min_seconds, 0.2))
+            r6 = measure(e5, lo, total_envs, runner=lambda t0, k, timed: e5.run_policy_steps_grouped(args.seed0 + lo, t0, k), min_seconds=sub_seconds)
             r6.update({'unit': 'agent-env steps/s', 'kernel': e5.step_kernel, 'run_kernel': e5.step_kernel, 'launches_per_step': 2 * e5.launches_per_step,
                        'note': 'the same with the policy applied per episode group on the group\'s own stream (cc4_group_info / cc4_step_group_device): a policy is '
                                'batch-independent, so nothing orders the groups against each other and their launches keep overlapping across steps'})
             r5['grouped'] = r6
             e5.close()
-            subs['policy_in_loop'] = r5
+            if r7 is not None and 'value' in r7:
+                # the headline of this entry is the rollout form; what r05 measured (a launch per step) stays beside it
+                r7['per_step_launches'] = r5
+                subs['policy_in_loop'] = r7
+            else:
+                if r7 is not None:
+                    r5['rollout'] = r7
+                subs['policy_in_loop'] = r5
             subs['exchange_world1'] = exchange_world1(make_env, measure, D, args, lo)
     if rank == 0:
         bytes_per_env = int(env.lib.cc4_algorithmic_bytes_per_env_step())
@@ -490,7 +553,16 @@ def main():
                 'autoreset_in_timed_region': main_res['autoreset_launches_in_timed_regions'] > 0,
                 'autoreset_launches_in_timed_regions': main_res['autoreset_launches_in_timed_regions'],
             },
-            'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBPS, 'unit': 'GB/s',
+            # `bound`: what the measurements of THIS kernel say, not a constant.  The figure of merit stays the HBM roofline (integer / byte work, no
+            # MFMA): `achieved` = contract bytes per step / kernel time per step.  But the counters (`traffic`, separate --pmc passes of this kernel)
+            # show the memory system carrying well under half of 8 TB/s, and inside a run of steps the episode's agent part does not move at all
+            # (it stays in LDS): the kernel is bound by the episodes in flight x the latency of a step's dependent chain -> "latency".
+            # "hbm" only if the counters say the memory system is the busy one.
+            'roofline': {'bound': ('hbm' if (traffic and traffic / (launch_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS >= 0.6) else 'latency'), 'roofline': 'hbm',
+                         'bound_evidence': ('HBM counters of this kernel: %.0f %% of peak' % (100.0 * traffic / (launch_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS) if traffic
+                                            else 'no counter pass of this kernel at this batch size is committed') +
+                                           '; waves per CU and per-step latency: profiles/kernel_resources.txt, DESIGN 3.4',
+                         'achieved': achieved, 'peak': HBM_PEAK_GBPS, 'unit': 'GB/s',
                          'frac': achieved / HBM_PEAK_GBPS,
                          # the same algorithmic bytes against the WALL clock of the timed regions (ms_per_step: what `value` is made of) --
                          # below `frac` by what lies between and around the launches of a region
@@ -523,7 +595,7 @@ def main():
         print(json.dumps(out), flush=True)
     env.close()
     plane.close()
-    if exchange_note or subs.get('exchange_world1', {}).get('_stalled'):                 # a stalled RCCL setup thread must not keep the process alive
+    if exchange_note or subs.get('exchange_world1', {}).get('_stalled') or subs.get('weak_scaled', {}).get('_stalled'):                 # a stalled RCCL setup thread must not keep the process alive
         sys.stdout.flush()
         os._exit(0)
 

@@ -73,6 +73,16 @@ SIGNATURES = {
     'cc4_group_info': (ctypes.c_int, [_P, ctypes.c_int32, _P, _P, _P]),
     'cc4_step_group_device': (ctypes.c_int, [_P, ctypes.c_int32, _P, _P]),
     'cc4_random_actions_group_device': (ctypes.c_int, [_P, ctypes.c_int32, ctypes.c_uint64, ctypes.c_uint32]),
+    'cc4_rollout_begin': (ctypes.c_int, [_P, ctypes.c_int32]),
+    'cc4_rollout_groups': (ctypes.c_int, [_P, _P, _P]),
+    'cc4_rollout_policy_stream': (ctypes.c_int, [_P, _P]),
+    'cc4_rollout_obs_packed': (ctypes.c_int, [_P, ctypes.c_int32, _P]),
+    'cc4_rollout_actions': (ctypes.c_int, [_P, ctypes.c_int32, _P]),
+    'cc4_rollout_wait_obs': (ctypes.c_int, [_P, ctypes.c_int32, ctypes.c_int32, _P]),
+    'cc4_rollout_publish': (ctypes.c_int, [_P, ctypes.c_int32, ctypes.c_int32, _P]),
+    'cc4_rollout_random_policy': (ctypes.c_int, [_P, ctypes.c_int32, ctypes.c_int32, ctypes.c_uint64, ctypes.c_uint32, _P]),
+    'cc4_rollout_hash_policy': (ctypes.c_int, [_P, ctypes.c_int32, ctypes.c_int32, _P]),
+    'cc4_rollout_end': (ctypes.c_int, [_P]),
     'cc4_debug_comm_delay_us': (ctypes.c_int, [_P, ctypes.c_int]),
     'cc4_host_stats': (ctypes.c_int, [_P, _P]),
     'cc4_verify_stats': (ctypes.c_int, [_P, _P]),
@@ -100,6 +110,7 @@ SIGNATURES = {
     'cc4_allgather_wait': (ctypes.c_int, [_P]),
     'cc4_exchange_info': (ctypes.c_int, [_P, _P]),
     'cc4_debug_gather_log': (ctypes.c_int, [_P, ctypes.c_int32]),
+    'cc4_debug_copy_from_device': (ctypes.c_int, [_P, _P, _P, ctypes.c_size_t]),
     'cc4_get_gather_log': (ctypes.c_int, [_P, _P, ctypes.c_int32, ctypes.c_int32]),
     'cc4_get_allgathered_obs': (ctypes.c_int, [_P, _P]),
     'cc4_unpack_obs_device': (ctypes.c_int, [_P, ctypes.POINTER(_P)]),

@@ -532,18 +532,18 @@ CC4_HD void rs_move_to_end(EnvState* s, RedAgent& a, int idx, int new_id) {
   if (new_id >= 0) rs_word_put(s, slot, (rs_word(s, slot) & ~0xFFFFull) | (uint64_t)(new_id & 0xFFFF));
   a.h.rsc_dirty = 1;
 }
-CC4_HD bool sid_known(const RedAgent& a, int id, int nknown) {
+// ks = the agent's ordered id list (EnvCold.known_sid[r]): read only for ids the bitmap does not cover
+CC4_HD bool sid_known(const RedAgent& a, const uint16_t* ks, int id, int nknown) {
   if (id < 256) return bit_get(a.known_bm, id);
-  for (int i = 0; i < nknown; ++i) if (a.known_sid[i] == id) return true;
+  for (int i = 0; i < nknown; ++i) if (ks[i] == id) return true;
   return false;
 }
-CC4_HD bool sid_known(const RedAgent& a, int id) { return sid_known(a, id, a.h.nknown); }
 // ActionSpace.update: server_session[session_id] = True (Shared/ActionSpace.py:205-211)
 CC4_HD void as_know_sid(Ctx x, int r, int id) {
   RedAgent& a = x.s->red[r];
-  if (sid_known(a, id)) return;
+  if (sid_known(a, x.c->known_sid[r], id, a.h.nknown)) return;
   if (a.h.nknown >= MAX_KS) { set_err(x, E_KS_OVERFLOW); return; }
-  a.known_sid[a.h.nknown++] = (uint16_t)id;
+  x.c->known_sid[r][a.h.nknown++] = (uint16_t)id;
   if (id < 256) bit_set(a.known_bm, id);
 }
 // one key of the agent's step observation (Shared/Observation.py add_* / combine_obs); also applies the
@@ -2048,7 +2048,7 @@ CC4_HD Act fsm_get_action(Ctx x, int r, RedHdr& H, bool observed = false) {
   }
   if ((t == RA_PRIVESC || t == RA_IMPACT || t == RA_DEGRADE) && !bit_get(A.fsm_hn, host)) bad = true;
   if (!bad) {
-    if (H.nknown == 0) bad = true; else out.sid = A.known_sid[rng_below(x.r, (uint32_t)H.nknown)];
+    if (H.nknown == 0) bad = true; else out.sid = x.c->known_sid[r][rng_below(x.r, (uint32_t)H.nknown)];
   }
   if (bad) { set_err(x, E_UNREACHABLE); out.type = RA_SLEEP; }  // reference would re-draw with p not summing to 1 and raise
   out.ticks = (uint8_t)red_duration(out.type);
@@ -2079,7 +2079,7 @@ CC4_HD Act random_red_get_action(Ctx x, int r, RedHdr& H) {
     if (ok) valid |= 1u << c;
   }
   const int t = types[nth_bit(valid, (int)rng_below(x.r, (uint32_t)popc32(valid)))];
-  auto pick_sid = [&]() { return (int)A.known_sid[rng_below(x.r, (uint32_t)nsid)]; };
+  auto pick_sid = [&]() { return (int)x.c->known_sid[r][rng_below(x.r, (uint32_t)nsid)]; };
   auto pick_ip = [&]() { return nth_set(A.as_ip, 5, (int)rng_below(x.r, (uint32_t)nip)); };
   auto pick_hn = [&]() { return nth_set(A.as_hn, 5, (int)rng_below(x.r, (uint32_t)nhn)); };
   out.type = (uint8_t)t;
@@ -2100,7 +2100,7 @@ CC4_HD void red_validate(Ctx x, int r, const RedHdr& H, Act& a) {
   RedAgent& A = x.s->red[r];
   if (a.type >= RA_SLEEP) return;
   bool ok = true;
-  if (!sid_known(A, a.sid, H.nknown)) ok = false;
+  if (!sid_known(A, x.c->known_sid[r], a.sid, H.nknown)) ok = false;
   if (a.type == RA_DRS) { if (!((H.as_subnet >> a.arg) & 1u)) ok = false; }
   else if (a.type == RA_PRIVESC || a.type == RA_IMPACT || a.type == RA_DEGRADE) { if (!bit_get(A.as_hn, a.host)) ok = false; }
   else if (a.type == RA_WITHDRAW) { if (!bit_get(A.as_ip, a.host) || !bit_get(A.as_hn, a.arg)) ok = false; }
@@ -2284,7 +2284,7 @@ CC4_HD void rng_policy_swap(Ctx x, bool back) {
   if (!s->rng_split) return;
   // field by field: a whole-struct copy through x.r pins the caller's register copy of the generator to memory (measured on
   // the numpy-stream kernel: +15 % per step)
-  Rng* a = x.r; Rng* b = &s->rng2;
+  Rng* a = x.r; Rng* b = &x.c->rng2;
   { uint64_t t = a->s_hi; a->s_hi = b->s_hi; b->s_hi = t; }
   { uint64_t t = a->s_lo; a->s_lo = b->s_lo; b->s_lo = t; }
   { uint64_t t = a->inc_hi; a->inc_hi = b->inc_hi; b->inc_hi = t; }

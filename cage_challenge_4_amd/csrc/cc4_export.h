@@ -80,7 +80,7 @@ inline std::string export_true_state(const EnvState& s, const EnvCold& cold, boo
         (unsigned)A.h.obs_act_host, (unsigned)A.h.obs_act_arg, (unsigned)A.h.rsc_listed, (unsigned)(A.h.queue.busy ? 1 : 0), (unsigned)A.h.new_sess_host, (unsigned)A.h.new_sess_id);
     for (int i = 0; i < A.h.nobs; ++i) add("%s[%u,%u]", i ? "," : "", (unsigned)A.obs[i].host, (unsigned)A.obs[i].flags);
     o += "],\"known_sessions\":[";
-    for (int i = 0; i < A.h.nknown; ++i) add("%s%u", i ? "," : "", (unsigned)A.known_sid[i]);
+    for (int i = 0; i < A.h.nknown; ++i) add("%s%u", i ? "," : "", (unsigned)cold.known_sid[r][i]);
     add("],\"as_subnet\":%u,\"as_ip\":[%u,%u,%u,%u,%u],\"as_hostname\":[%u,%u,%u,%u,%u]", (unsigned)A.h.as_subnet, A.as_ip[0], A.as_ip[1], A.as_ip[2], A.as_ip[3], A.as_ip[4],
         A.as_hn[0], A.as_hn[1], A.as_hn[2], A.as_hn[3], A.as_hn[4]);
     o += "}";

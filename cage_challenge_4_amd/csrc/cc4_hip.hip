@@ -29,6 +29,7 @@
 #include <atomic>
 
 #include "../../include/cc4.h"
+#include "../../include/cc4_debug.h"
 #include "cc4_engine.h"
 #include "cc4_export.h"
 
@@ -62,6 +63,8 @@ struct StepArgs {
                               // full builds of the step kernels only (template parameter LOG)
   int e0;                     // first episode of this launch: block b steps episode e0 + b (a step of a large batch is issued as
                               // several launches on separate streams: see cc4_handle::ngroups); n = one past its last episode
+  int act_sys;                // the actions were written by ANOTHER kernel while this one runs (a rollout, RunArgs.act_ready): system-scope loads,
+                              // past this XCD's L2, which may still hold the line from two steps ago
 };
 
 // uniform blue action index of (episode e, agent b) at step t: Philox key (seed0 + e), counter (t, b, 0xB10E, 0)
@@ -164,7 +167,7 @@ struct XchgArgs {
 // lane / thread 0 only.  `seen` = the highest value of *gathered this wave has read so far (it only grows): the word is read again --
 // an uncached round trip to memory, ~2 us in the middle of the item hand-over -- only when the value at hand does not cover step k.
 __device__ __forceinline__ void xchg_wait_slab(const XchgArgs& x, uint32_t k, uint32_t& seen) {
-  if (k < (uint32_t)x.ring) return;
+  if (k < (uint32_t)x.ring || !x.gathered) return;      // (no `gathered` word: a rollout -- slab k % ring was consumed by the policy pass of step k - ring + 1, which every episode is long past)
   const uint32_t need = k - (uint32_t)x.ring + 1u;
   if (seen >= need) return;
   seen = __hip_atomic_load(x.gathered, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
@@ -585,8 +588,9 @@ __device__ __forceinline__ void wave_green_exec(Ctx x, Rng& rl, uint64_t* win, i
 
 // One step of one episode of the numpy-stream mode on one wavefront: the body of k_step and of the persistent kernel k_run_pcg
 // (there a.rand_t / a.full_obs are the item's: set by the caller).
+// first / last: as in philox1_body -- inside a run of steps of one episode on one wave the agent part stays in LDS
 template <bool LOG>
-__device__ __forceinline__ void pcg_body(StepArgs a, const int e, const int lane) {
+__device__ __forceinline__ void pcg_body(StepArgs a, const int e, const int lane, const bool first = true, const bool last = true) {
   // numpy-PCG64 mode: one shared stream => the agent walk is strictly serial (lane 0); only the RNG-free parts
   // (row staging, end-turn Monitor roll-over over the 137 hosts, observation encode) use the other lanes.
   extern __shared__ uint4 lds[];
@@ -601,7 +605,7 @@ __device__ __forceinline__ void pcg_body(StepArgs a, const int e, const int lane
   EnvCold* const cold_e = cold_at(a.cold, (size_t)e, cold_row_bytes(a.steps));
   unsigned long long t_begin = a.prof ? clock64() : 0;
   const uint4* src = reinterpret_cast<const uint4*>(a.st + e);
-  stage_in<HOT_VEC>(lds, src, lane);
+  if (first) stage_in<HOT_VEC>(lds, src, lane);
   for (int i = lane; i < (int)(sizeof(StepWork) / 4); i += WAVE) reinterpret_cast<uint32_t*>(&work)[i] = 0;
   __syncthreads();
   EnvState* s = reinterpret_cast<EnvState*>(lds);   // only the part in front of EnvState.hd is valid here
@@ -633,7 +637,7 @@ __device__ __forceinline__ void pcg_body(StepArgs a, const int e, const int lane
       CC4_TICK0(x);
       (void)step_phase(x, false);    // sets E_STEP_PAST_END when !step_ok
       CC4_TICK(x, 0);
-      if (step_ok) rng_policy_swap(x, false);     // CybORG.set_seed split: the policies draw from the old stream (EnvState.rng2)
+      if (step_ok) rng_policy_swap(x, false);     // CybORG.set_seed split: the policies draw from the old stream (EnvCold.rng2)
       if (step_ok && (s->policy & BP_RANDOM_BIT))   // built-in blue policy: its draws are the first of the step, in agent order
         for (int b = 0; b < NBLUE; ++b) {
           int32_t act = a.actions ? a.actions[e * NBLUE + b] : -1;
@@ -731,7 +735,7 @@ __device__ __forceinline__ void pcg_body(StepArgs a, const int e, const int lane
   unsigned long long t_out = a.prof ? clock64() : 0;
   if (prof && lane == 0) prof[12] += t_out - t_obs;
   uint4* dst = reinterpret_cast<uint4*>(a.st + e);
-  stage_out<HOT_VEC>(dst, lds, lane);
+  if (last) stage_out<HOT_VEC>(dst, lds, lane);
   if (a.obs8) store_packed_row(a.obs8 + (size_t)e * OBS_PACKED, obs_lds, lane, WAVE);
   if (prof && lane == 0) { prof[13] += clock64() - t_out; prof[14] += clock64() - t_begin; }
   if (prof) { __syncthreads(); if (lane < 15) a.prof[PROF_SLOTS * (size_t)e + lane] += prof_lds[lane]; }
@@ -1171,12 +1175,72 @@ struct RunArgs {
                                // slot order, so the CUs of an XCD own neighbouring partitions and their ticket / progress words share cache lines
                                // only with each other -- handed out in arrival order they interleave the XCDs, and a 20-step call was 6 % slower)
   int P, K;
+  int G;                       // the exchange counts episode e in group e % G (the gate kernel's groups: G = the CUs of the device in both schedules)
   uint32_t t0;                 // action time of step 0 (random_blue_action)
   unsigned long long* timeline; // debug (CC4_PERSIST_TIMELINE=1): per wave [entry, first item start, last item end, items] in wall_clock64 ticks, or null
   int order;                   // memory ordering of the hand-over between two items of an episode (CC4_PERSIST_ORDER, persist_loop):
                                // 0 = ordering only (same CU: the waves of a CU share its L1), 1 = every item starts with an agent-scope acquire,
-                               // 2 = ... and ends with an agent-scope release
+                               // 2 = ... and ends with an agent-scope release, 3 = every item starts with an L1 invalidate (buffer_inv sc0)
+  // ---- XCD pools (r06; `pool` != 0): the batch is cut into one partition per XCD (episode e -> pool e % P, P = the XCDs the device showed), every
+  // wave of an XCD pulls from its XCD's ticket counter, and every item starts with an invalidate of the CU's vector L1 (buffer_inv sc0: the
+  // XCD's L2 is the coherence point of its CUs and the L1 is write-through, so a drained store of ANY CU of the XCD is visible behind it).
+  // No owner table, no claim, no stealing: a CU never runs dry while its XCD has an item, so the launch's tail is one item long instead of
+  // the lag of the slowest CU's partition.  ticket = this call's counters ([P] words, TK_STRIDE apart), ticket_next = the other parity's
+  // (every wave zeroes its pool's word there: the next call needs no memset); progress[] counts steps since the handle's last reset of it
+  // (`base` = the count every episode stands at when the call starts).
+  // ---- runs of steps (r06).  An item is a RUN of consecutive steps of one episode: nA runs of SA steps, then nB of SB, then single steps
+  // (nph runs in all, K steps).  Inside a run the agent part stays in LDS -- no write-back and re-stage between the steps, one ticket, one
+  // progress wait and one store drain per run instead of per step; the short runs at the end keep the launch's tail one step long.
+  int SA, nA, SB, nB, nph;
+  int pool;                    // schedule: 0 = per-CU partitions, a tail shared inside the XCD (r04 / r05); 1 = XCD pools (experiment);
+                               // 2 = per-CU partitions BALANCED inside the XCD while the call runs (r06, below)
+  uint32_t base;
+  uint32_t* ticket_next;
+  uint8_t xcc_pool[8];         // XCC id -> pool, 0xFF: no such XCD
+  // ---- schedule 2: balanced partitions.  Partitions are per CU as in schedule 0 (an episode normally stays on ONE CU, whose waves share
+  // its write-through L1: no cache maintenance), but a wave looks at the ticket counters of its XCD's partitions before every run and, when
+  // its own partition is more than `thr` tickets AHEAD of the one that lags most -- or handed out --, takes its run from that one.  The
+  // partitions of an XCD so finish within a run of each other, instead of the slowest CU's lag building up to the call's end where
+  // helpers can only wait in its episodes' chains.  An episode's progress word carries, beside the steps done, the id of the CU that ran
+  // its last run: a run on ANOTHER CU than that one starts with an agent-scope acquire (buffer_inv sc1: tools/micro/l1_inv_scope.hip --
+  // nothing less drops a CU's stale L1 lines; profiles/r06_l1_inv_scope.txt), a run on the same CU with none.
+  uint8_t xcc_lo[8], xcc_n[8]; // XCC id -> first partition / number of partitions of that XCD (partitions are numbered in slot order)
+  int thr;
+  // ---- rollouts with the policy in the loop (r06; cc4_rollout_begin): the blue actions of step j are written, while this launch runs, by kernels of
+  // the caller's on the caller's stream -- one policy group of episodes at a time: group of e = (e / P) % PG, so every CU holds episodes of every
+  // group and works on one group while another waits for its policy.  Step j of an episode of group g starts once act_ready[g] > j (published by
+  // the caller behind its policy kernels, cc4_rollout_publish); it reads slot j % 2 of `act` with system-scope loads, writes its packed
+  // observation row into slab j % ring with system-scope stores (XchgArgs.slab) and counts itself in cnt[(e % P) * PG + g][j % ring] once that
+  // row is in memory -- what the gate of the caller's next policy pass waits for (cc4_rollout_wait_obs).  Every step is an item of its own.
+  const uint32_t* act_ready;   // [PG][32 words] (a cache line per group), or null: no rollout
+  const int32_t* act;          // [2][n][5]
+  int PG;
+  long long act_wait_ticks;    // watchdog: a step that waits longer for its actions gives up, raises XchgArgs.timeout, and every later wait returns at once
 };
+// lane 0: the actions of step j for policy group g are published.  Polls a device word at a growing interval (see xchg_wait_slab).
+__device__ __forceinline__ void rollout_wait_actions(const RunArgs& ra, const XchgArgs& x, int g, uint32_t j) {
+  const uint32_t* w = ra.act_ready + (size_t)g * 32;
+  if (__hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) > j) return;
+  if (__hip_atomic_load(x.timeout, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM)) return;
+  const long long w0 = wall_clock64();
+  int naps = 1;
+  while (__hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) <= j) {
+    for (int i = 0; i < naps; ++i) __builtin_amdgcn_s_sleep(64);
+    if (naps < 8) naps <<= 1;
+    if (wall_clock64() - w0 > ra.act_wait_ticks || __hip_atomic_load(x.timeout, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM)) {
+      __hip_atomic_store(x.timeout, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      __hip_atomic_store(x.timeout_host, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      return;
+    }
+  }
+}
+constexpr uint32_t PG_STEPS = 0x7FFFFFu;   // progress word (schedule 2): steps in bits 0..22, 1 + the last runner's partition in bits 23..31 (0: none yet)
+__device__ __forceinline__ void run_span(const RunArgs& ra, int j, int& k0, int& len) {
+  if (j < ra.nA) { k0 = j * ra.SA; len = ra.SA; }
+  else if (j < ra.nA + ra.nB) { k0 = ra.nA * ra.SA + (j - ra.nA) * ra.SB; len = ra.SB; }
+  else { k0 = ra.nA * ra.SA + ra.nB * ra.SB + (j - ra.nA - ra.nB); len = 1; }
+}
+constexpr int TK_STRIDE = 32;  // words between two pools' ticket counters (a cache line of their own each)
 constexpr int CC4_SLOTS = 2048;    // (XCC id << 8) | HW_ID[15:8]
 __device__ __forceinline__ int cu_slot() {
   const uint32_t hw = __builtin_amdgcn_s_getreg(((16 - 1) << 11) | (0 << 6) | 4);     // HW_REG_HW_ID bits 15:0: wave, simd, pipe | cu, sh, se
@@ -1226,8 +1290,12 @@ void philox1_autoreset(const StepArgs& a, const int e, const int lane, EnvState*
 
 // One step of one episode on one wavefront: the body of k_step_philox1 and of the persistent run kernel.  PERSIST: item_k = the
 // step's number within the launch (the first item of an episode rewrites all its observation values when asked to).
+// first / last (the one-launch loops): the step is the first / last of a run of consecutive steps of this episode on this wave -- only the
+// first stages the agent part in, only the last writes it back; in between the row lives in LDS (the host table, the cold row and the outputs
+// are read and written in memory by every step as always).
 template <bool LOG, bool PERSIST>
-__device__ __forceinline__ void philox1_body(StepArgs a, const int e, const uint32_t rand_t, const uint32_t item_k, const int lane) {
+__device__ __forceinline__ void philox1_body(StepArgs a, const int e, const uint32_t rand_t, const uint32_t item_k, const int lane,
+                                             const bool first = true, const bool last = true) {
   extern __shared__ uint4 lds[];
   // Static LDS is kept under 512 bytes: agent part (7168 B) + statics then fit SIX 1280-byte LDS granules, 21 waves per CU by LDS and 20
   // by registers; a seventh granule would leave 18 (profiles/r05_lds_residency.txt: the occupancy query, which divides 160 KB by the
@@ -1241,7 +1309,7 @@ __device__ __forceinline__ void philox1_body(StepArgs a, const int e, const uint
   EnvCold* const cold_e = cold_at(a.cold, (size_t)e, cold_row_bytes(a.steps));
   unsigned long long t_begin = a.prof ? clock64() : 0;
   const uint4* src = reinterpret_cast<const uint4*>(a.st + e);
-  stage_in<HOT_VEC>(lds, src, lane);
+  if (first) stage_in<HOT_VEC>(lds, src, lane);
   for (int i = lane; i < (int)(sizeof(StepWork) / 4); i += WAVE) reinterpret_cast<uint32_t*>(&work)[i] = 0;
   unsigned long long* prof = a.prof ? prof_lds : nullptr;
   if (prof && lane < 16) prof_lds[lane] = 0;
@@ -1322,7 +1390,7 @@ __device__ __forceinline__ void philox1_body(StepArgs a, const int e, const uint
         if (dropped) atomicSub(&s->n_actions, 1);
       } else if (lane >= 8 && lane < 8 + NBLUE) {
         const int b = lane - 8;
-        int32_t act = a.actions ? a.actions[e * NBLUE + b] : -1;
+        int32_t act = !a.actions ? -1 : a.act_sys ? __hip_atomic_load(a.actions + e * NBLUE + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) : a.actions[e * NBLUE + b];
         if (a.rand_out) { act = (int32_t)(((uint64_t)brand * (uint32_t)(b == 4 ? ACT_LONG : ACT_SHORT)) >> 32); a.rand_out[e * NBLUE + b] = act; }   // == random_blue_action
         step_blue_submit(xg, b, act);
         step_tick_blue(xg, b);
@@ -1417,7 +1485,7 @@ __device__ __forceinline__ void philox1_body(StepArgs a, const int e, const uint
   if (lane == 0) a.err[e] = s->err;
   unsigned long long t_out = a.prof ? clock64() : 0;
   if (prof && lane == 0) prof[12] += t_out - t_obs;
-  stage_out<HOT_VEC>(reinterpret_cast<uint4*>(a.st + e), lds, lane);
+  if (last) stage_out<HOT_VEC>(reinterpret_cast<uint4*>(a.st + e), lds, lane);
   if (a.obs8) {     // the per-step launches' packed exchange row (the one-launch loops pack behind their own end-of-step drain instead)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     pack_row_from_obs(a.obs8 + (size_t)e * OBS_PACKED, a.obs + (size_t)e * OBS_TOTAL, lane);
@@ -1444,6 +1512,7 @@ __global__ __launch_bounds__(WAVE, CC4_LEAN_MINW) void k_step_philox1(StepArgs a
 // step_red_policy_tick of agent r of the wave's g-th episode -- what a group schedule would do in the phase that is 31 % of a step -- on the live
 // state of the batch (agent parts staged into LDS as in the step kernel, nothing written back).  G = 1 is today's lane layout.  cyc[block] = the
 // wave's cycles in the phase; the launch duration (events) / episodes = what the phase costs an episode at that grouping and residency.
+#ifdef CC4_POLICY_PROBE      // (a concluded experiment of r05: its four instantiations are not part of the product library)
 template <int G>
 __global__ __launch_bounds__(WAVE) void k_policy_probe(StepArgs a, unsigned long long* cyc) {
   extern __shared__ uint4 lds[];
@@ -1474,12 +1543,14 @@ __global__ __launch_bounds__(WAVE) void k_policy_probe(StepArgs a, unsigned long
   if (lane == 0) cyc[blockIdx.x] = t1 - t0;
   if (dropped == 12345) cyc[0] = 0;      // (keeps the result alive)
 }
+#endif
 constexpr uint32_t TK_SHARED = 0x80000000u;
-// register budget of the persistent counter-mode kernel in waves per SIMD: 5 (88 VGPRs, nothing spilled: 20 waves per CU) or 6 (80 VGPRs, ten
-// spilled: 24 by registers, 21 by LDS -- six 1280-byte granules per wave).  Measured (profiles/r05_persist_21_waves.txt, 8192 episodes):
-// K = 500: 952 vs 939-948 M, K = 20: 816 vs 809-825 M, 16384 episodes 934 vs 927 M -- inside the box-to-box spread: 5 stays.
+// register budget of the persistent counter-mode kernel in waves per SIMD: 6 (80 VGPRs, eight spilled: 24 waves per CU -- by registers and,
+// since r06's 5952-byte agent part made a wave FIVE 1280-byte LDS granules, by LDS as well: 25) or 5 (93 VGPRs, nothing spilled: 20 per CU).
+// Measured, 8192 episodes, one box (profiles/r06_layout_ab.txt): K = 500: 989-990 vs 914-915 M, K = 20: 831-846 vs 797-807 M.  (r05, when LDS
+// capped a CU at 21 waves: 952 vs 939-948 M -- inside the box-to-box spread.)
 #ifndef CC4_PERSIST_MINW
-#define CC4_PERSIST_MINW 5
+#define CC4_PERSIST_MINW 6
 #endif
 template <bool PCG>
 __device__ __forceinline__ void persist_loop(StepArgs a, RunArgs ra, const XchgArgs x) {
@@ -1487,7 +1558,7 @@ __device__ __forceinline__ void persist_loop(StepArgs a, RunArgs ra, const XchgA
   const int lane = threadIdx.x;
   const int my_slot = cu_slot();
   // The CU's partition, from the table of the compute units this device showed at first use (a CU that is not in it only helps out)
-  int part = ra.slot_part[my_slot] - 1;  // (lane 0's copy is the one that counts)
+  int part = ra.pool ? -1 : ra.slot_part[my_slot] - 1;  // schedule 0 (lane 0's copy is the one that counts)
   bool mine = false;                     // lane 0: this CU owns `part` (claimed or adopted)
   bool stealing = false;                 // lane 0: `part` belongs to another CU of this XCD; its shared bit is set
   a.prof = nullptr; a.obs8 = nullptr; a.ext = nullptr;
@@ -1497,10 +1568,86 @@ __device__ __forceinline__ void persist_loop(StepArgs a, RunArgs ra, const XchgA
   auto tl_flush = [&]() { if (ra.timeline && lane == 0) { unsigned long long* t = ra.timeline + 4 * (size_t)blockIdx.x; t[0] = tl_entry; t[1] = tl_first; t[2] = tl_last; t[3] = tl_items | ((unsigned long long)(my_slot + 1) << 32); } };
   int pend_e = -1; uint32_t pend_k = 0;  // the exchange: the item whose packed row this wave stored last and has not counted yet (its store drains with the next item)
   auto flush_pending = [&]() {
-    if (x.slab && pend_e >= 0) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); if (lane == 0) xchg_count(x, pend_k, pend_e % ra.P); pend_e = -1; }
+    if (x.slab && pend_e >= 0) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); if (lane == 0) xchg_count(x, pend_k, pend_e % ra.G); pend_e = -1; }
   };
+  const uint32_t my_xcc = __builtin_amdgcn_s_getreg(((4 - 1) << 11) | (0 << 6) | 20) & 7u;    // HW_REG_XCC_ID
+  const int xlo = ra.xcc_lo[my_xcc], xn = ra.xcc_n[my_xcc];     // schedule 2: this XCD's partitions
+  int own = -1; uint32_t my_id = 511u;                           // schedule 2: the CU's own partition (-1: none), its id in the progress words
+  if (ra.pool == 2) {
+    own = ra.slot_part[my_slot] - 1;
+    if (own >= 0) my_id = (uint32_t)own + 1u;
+    if (xn <= 0) { tl_flush(); return; }
+  }
+  if (ra.pool == 1) {
+    const uint32_t xcc = my_xcc;
+    part = ra.xcc_pool[xcc] == 0xFF ? -1 : (int)ra.xcc_pool[xcc];
+    if (part < 0) { tl_flush(); return; }                             // (an XCD the discovery pass did not see: its waves do nothing)
+    if (lane == 0) __hip_atomic_store(&ra.ticket_next[part * TK_STRIDE], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
   for (;;) {
     int res_e = -3, res_k = 0, res_sh = 0, res_part = -1;            // -3: nothing from `part`: search
+    if (ra.pool == 2) {
+      // all lanes: where the XCD's partitions stand
+      const int q = xlo + lane;
+      uint32_t tk = 0xFFFFFFFFu, tot_q = 0;
+      // (every partition's counter on a cache line of its own, TK_STRIDE words apart: 24 waves of one CU on a line, not the 768 of an XCD -- with the
+      // XCD's 32 counters on ONE line, its atomics and these loads took the L2 ~50 ns each and the schedule ran at 556 M instead of 884 M)
+      if (lane < xn) { tk = __hip_atomic_load(&ra.ticket[q * TK_STRIDE], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); tot_q = (uint32_t)(((a.n - q + ra.P - 1) / ra.P) * ra.nph); }
+      const bool has = lane < xn && tk < tot_q;
+      uint32_t key = has ? ((tk << 6) | (uint32_t)lane) : 0xFFFFFFFFu;          // least tickets handed out = lags most (the partitions' sizes differ by one episode at most)
+#pragma unroll
+      for (int off = 32; off >= 1; off >>= 1) { const uint32_t k2 = (uint32_t)__shfl_xor((int)key, off); key = k2 < key ? k2 : key; }
+      const uint32_t kmin = (uint32_t)__builtin_amdgcn_readfirstlane((int)key);
+      if (kmin == 0xFFFFFFFFu) { flush_pending(); tl_flush(); return; }        // every partition of this XCD is handed out
+      int target = (int)(kmin & 63u);
+      if (own >= 0) {
+        const int ol = own - xlo;
+        const uint32_t tk_own = (uint32_t)__builtin_amdgcn_readlane((int)tk, ol);
+        const uint32_t tot_own = (uint32_t)__builtin_amdgcn_readlane((int)tot_q, ol);
+        if (tk_own < tot_own && tk_own <= (kmin >> 6) + (uint32_t)ra.thr) target = ol;
+      }
+      if (lane == 0) {
+        const int tp = xlo + target;
+        const int ne = (a.n - tp + ra.P - 1) / ra.P;
+        const uint32_t t = __hip_atomic_fetch_add(&ra.ticket[tp * TK_STRIDE], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        res_e = -5;                                                   // handed out meanwhile: look again
+        // the partition's last ticket: its counter of the OTHER parity cleared for the next call (exactly one wave per partition and call
+        // draws it, whoever runs the partition -- no memset between calls)
+        if (t + 1u == (uint32_t)(ne * ra.nph)) __hip_atomic_store(&ra.ticket_next[tp * TK_STRIDE], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (t < (uint32_t)(ne * ra.nph)) {
+          const int j = (int)(t / (uint32_t)ne);
+          int i = (int)(t % (uint32_t)ne), pg = 0;
+          if (ra.act_ready) {
+            // a rollout: the tickets of a step serve one policy group after the other (episode index i of the partition is of group i % PG) --
+            // while one group's episodes wait for their policy pass, the CU's waves hold tickets of the other's
+            for (; pg < ra.PG; ++pg) { const int c = (ne - pg + ra.PG - 1) / ra.PG; if (i < c) { i = i * ra.PG + pg; break; } i -= c; }
+          }
+          const int ee = tp + i * ra.P;
+          int k, len; run_span(ra, j, k, len);
+          uint32_t w;
+          while ((((w = __hip_atomic_load(&ra.progress[ee], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) & PG_STEPS) - ra.base) < (uint32_t)k) __builtin_amdgcn_s_sleep(8);
+          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+          if (x.slab) xchg_wait_slab(x, (uint32_t)k, seen_gathered);
+          if (ra.act_ready) rollout_wait_actions(ra, x, pg, (uint32_t)k);
+          const uint32_t last = w >> 23;
+          res_e = ee; res_k = j; res_sh = (last != 0u && last != my_id) ? 1 : 0;     // the episode's last run was on another CU: its lines in this CU's L1 may be stale
+        }
+      }
+    } else if (ra.pool) {
+      if (lane == 0) {
+        const int ne = (a.n - part + ra.P - 1) / ra.P;                // episodes part, part + P, part + 2 P, ..
+        const uint32_t t = __hip_atomic_fetch_add(&ra.ticket[part * TK_STRIDE], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        res_e = -4;                                                   // the pool is handed out: leave
+        if (t < (uint32_t)(ne * ra.nph)) {
+          const int j = (int)(t / (uint32_t)ne), ee = part + (int)(t % (uint32_t)ne) * ra.P;
+          int k, len; run_span(ra, j, k, len);
+          while (__hip_atomic_load(&ra.progress[ee], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - ra.base < (uint32_t)k) __builtin_amdgcn_s_sleep(8);
+          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+          if (x.slab) xchg_wait_slab(x, (uint32_t)k, seen_gathered);
+          res_e = ee; res_k = j; res_sh = 2;
+        }
+      }
+    } else
     if (lane == 0) {
       if (part >= 0 && !mine && !stealing) {
         int exp = 0;                                                  // the CU's own partition: claim it (or find it claimed by this CU already)
@@ -1512,22 +1659,25 @@ __device__ __forceinline__ void persist_loop(StepArgs a, RunArgs ra, const XchgA
         const int ne = (a.n - part + ra.P - 1) / ra.P;                // episodes part, part + P, part + 2 P, ..
         const uint32_t tr = __hip_atomic_fetch_add(&ra.ticket[part], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         const uint32_t t = tr & ~TK_SHARED;
-        if (t < (uint32_t)(ne * ra.K)) {
+        if (t < (uint32_t)(ne * ra.nph)) {
           // (r05, both measured and dropped: asking for the next ticket ahead of the previous item's drain -- the CU's other waves fill that gap
           // already, 813-821 vs 819 M; and shares of the batch per XCD following the XCDs' measured speed -- which XCDs are slow changes from
           // box to box and call to call, the controller chases noise: 20-step calls 812-822 -> 789-796 M.  profiles/r05_xcd_balance.txt)
           // (a ready queue per partition -- a wave never holds an item whose predecessor is still running -- was built and measured in r05:
           // bit-exact, 2-3.5 % slower, and the launch's tail stayed: profiles/r05_ready_queue_ab.txt)
-          const int k = (int)(t / (uint32_t)ne), ee = part + (int)(t % (uint32_t)ne) * ra.P;
-          while (__hip_atomic_load(&ra.progress[ee], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (uint32_t)k) __builtin_amdgcn_s_sleep(8);
+          const int j = (int)(t / (uint32_t)ne), ee = part + (int)(t % (uint32_t)ne) * ra.P;
+          int k, len; run_span(ra, j, k, len);
+          while (__hip_atomic_load(&ra.progress[ee], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - ra.base < (uint32_t)k) __builtin_amdgcn_s_sleep(8);
           __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");      // nothing the item reads may be read ahead of the flag (compiler and wave)
           if (x.slab) xchg_wait_slab(x, (uint32_t)k, seen_gathered);   // the exchange: slab k % ring must have been gathered (tickets are step-major: normally long ago)
-          res_e = ee; res_k = k; res_sh = (thief || (tr & TK_SHARED)) ? 1 : 0;
+          res_e = ee; res_k = j; res_sh = (thief || (tr & TK_SHARED)) ? 1 : 0;
         }
       }
       res_part = part;
     }
     const int e = __builtin_amdgcn_readfirstlane(res_e);              // (all lanes are active here: the first active lane is lane 0)
+    if (e == -4) { flush_pending(); tl_flush(); return; }
+    if (e == -5) continue;
     if (e == -3) {
       // search (all lanes): the partition with the most items left among those nobody owns and those owned by a CU of this XCD
       const int cur = __builtin_amdgcn_readfirstlane(res_part);
@@ -1538,7 +1688,7 @@ __device__ __forceinline__ void persist_loop(StepArgs a, RunArgs ra, const XchgA
           const int ow = __hip_atomic_load(&ra.owner[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
           if (ow == 0 || (((ow - 1) >> 8) == (my_slot >> 8))) {
             const uint32_t t = __hip_atomic_load(&ra.ticket[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & ~TK_SHARED;
-            const uint32_t tot = (uint32_t)(((a.n - q + ra.P - 1) / ra.P) * ra.K);
+            const uint32_t tot = (uint32_t)(((a.n - q + ra.P - 1) / ra.P) * ra.nph);
             const int rem = t < tot ? (int)(tot - t) : 0;
             if (rem > best_rem) { best_rem = rem; best_q = q; best_ow = ow; }
           }
@@ -1562,20 +1712,42 @@ __device__ __forceinline__ void persist_loop(StepArgs a, RunArgs ra, const XchgA
       }
       continue;
     }
-    const uint32_t item_k = (uint32_t)__builtin_amdgcn_readfirstlane(res_k);
+    int run_k0, run_len;
+    run_span(ra, __builtin_amdgcn_readfirstlane(res_k), run_k0, run_len);
     const int shared = __builtin_amdgcn_readfirstlane(res_sh);
     if (ra.timeline && !tl_items) tl_first = wall_clock64();
-    if (shared || ra.order >= 1) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    if (shared || ra.order >= 1) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");      // (buffer_inv sc1: the CU's L1 dropped.  buffer_inv sc0 does NOT drop it: profiles/r06_l1_inv_scope.txt)
+    uint32_t item_k = (uint32_t)run_k0;
+    for (int q = 0; q < run_len; ++q, ++item_k) {
+    if (q > 0) {
+      if (x.slab) {
+        // a further step of the run with the exchange on: what the last step stored is drained and counted as at a run's end, and the slab of
+        // this step must have been gathered
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if constexpr (PCG) { if (lane == 0) xchg_count(x, item_k - 1u, e % ra.G); }
+        else {
+          if (lane == 0 && pend_e >= 0) xchg_count(x, pend_k, pend_e % ra.G);
+          pack_row_from_obs(x.slab + ((size_t)((item_k - 1u) % (uint32_t)x.ring) * (size_t)a.n + (size_t)e) * OBS_PACKED, a.obs + (size_t)e * OBS_TOTAL, lane);
+          pend_e = e; pend_k = item_k - 1u;
+        }
+        if (lane == 0) xchg_wait_slab(x, item_k, seen_gathered);
+      }
+      __syncthreads();
+    }
     int lane_i = (int)threadIdx.x;
     asm volatile("" : "+v"(lane_i));
+    if (ra.act_ready) { a.actions = ra.act + (size_t)(item_k & 1u) * (size_t)a.n * NBLUE; a.rand_out = nullptr; a.act_sys = 1; }
     if constexpr (PCG) {
       StepArgs b = a;
       b.rand_t = ra.t0 + item_k; b.full_obs = (a.full_obs && item_k == 0) ? 1 : 0;
       if (x.slab) b.obs8 = x.slab + (size_t)(item_k % (uint32_t)x.ring) * (size_t)a.n * OBS_PACKED;
-      pcg_body<false>(b, e, lane_i);
+      pcg_body<false>(b, e, lane_i, q == 0, q == run_len - 1);
     } else {
-      philox1_body<false, true>(a, e, ra.t0 + item_k, item_k, lane_i);      // (a.obs8 is null: the packed row is written below, behind the drain)
+      philox1_body<false, true>(a, e, ra.t0 + item_k, item_k, lane_i, q == 0, q == run_len - 1);      // (a.obs8 is null: the packed row is written below, behind the drain)
     }
+    }
+    --item_k;        // the run's last step
     // the item is done when everything it wrote has left this wave: then the next step of the episode may start (on this XCD)
     // Release: every lane DRAINS its own stores -- an explicit s_waitcnt vmcnt(0): the vector L1 is write-through, so a drained store is in
     // the XCD's L2 --, the barrier collects the lanes, lane 0 publishes.  The consumer is a wave of the same CU unless the partition is
@@ -1589,17 +1761,23 @@ __device__ __forceinline__ void persist_loop(StepArgs a, RunArgs ra, const XchgA
     __syncthreads();
     if (x.slab) {
       if constexpr (PCG) {     // (the numpy-stream body stored the row itself, from its LDS byte row: drained by the fence above)
-        if (lane == 0) xchg_count(x, item_k, e % ra.P);
+        if (lane == 0) xchg_count(x, item_k, e % ra.G);
       } else {
         // the row this wave stored with its PREVIOUS item is in memory (this item's fence drained it): counted.  Then this episode's row of
         // step item_k, read back from the int32 row before the episode's next step may touch it (the loads feed the store, the store is
         // issued ahead of the progress word) -- not waited for: it drains with the wave's next item, or when the wave leaves.
-        if (lane == 0 && pend_e >= 0) xchg_count(x, pend_k, pend_e % ra.P);
+        if (lane == 0 && pend_e >= 0) xchg_count(x, pend_k, pend_e % ra.G);
         pack_row_from_obs(x.slab + ((size_t)(item_k % (uint32_t)x.ring) * (size_t)a.n + (size_t)e) * OBS_PACKED, a.obs + (size_t)e * OBS_TOTAL, lane);
         pend_e = e; pend_k = item_k;
+        if (ra.act_ready) {
+          // a rollout: the caller's next policy pass waits for this count -- not deferred to the wave's next item
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+          if (lane == 0) xchg_count(x, item_k, (e % ra.P) * ra.PG + (e / ra.P) % ra.PG);
+          pend_e = -1;
+        }
       }
     }
-    if (lane == 0) __hip_atomic_store(&ra.progress[e], item_k + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (lane == 0) __hip_atomic_store(&ra.progress[e], (ra.base + item_k + 1u) | (ra.pool == 2 ? my_id << 23 : 0u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (ra.timeline) { tl_last = wall_clock64(); ++tl_items; }
   }
 }
@@ -1624,7 +1802,7 @@ __global__ __launch_bounds__(WAVE, 5) void k_run_philox1m(StepArgs a, int K, uin
     }
     int lane_i = (int)threadIdx.x;
     asm volatile("" : "+v"(lane_i));
-    philox1_body<false, true>(a, e, t0 + (uint32_t)k, (uint32_t)k, lane_i);
+    philox1_body<false, true>(a, e, t0 + (uint32_t)k, (uint32_t)k, lane_i, k == 0, k == K - 1);      // the agent part stays in LDS from the first step to the last
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (x.slab) {
@@ -1721,12 +1899,12 @@ __global__ void k_unpack_obs(const uint8_t* __restrict__ packed, uint8_t* __rest
 }
 
 // CybORG.set_seed (env.py:316-325): a fresh generator for the controller, the state and the hosts; the agents' policies keep
-// the old one until the next reset (EnvState.rng2); the episode itself stays as it is
-__global__ void k_set_seed(EnvState* st, const uint64_t* seeds, int n, int rng_mode) {
+// the old one until the next reset (EnvCold.rng2); the episode itself stays as it is
+__global__ void k_set_seed(EnvState* st, EnvCold* cold, size_t cold_row, const uint64_t* seeds, int n, int rng_mode) {
   int e = blockIdx.x * blockDim.x + threadIdx.x;
   if (e >= n) return;
-  if (rng_mode == 0) {        // numpy stream: the agents' policies stay on the stream they were created with (see EnvState.rng2)
-    if (!st[e].rng_split) st[e].rng2 = st[e].rng;
+  if (rng_mode == 0) {        // numpy stream: the agents' policies stay on the stream they were created with (see EnvCold.rng2)
+    if (!st[e].rng_split) cold_at(cold, (size_t)e, cold_row)->rng2 = st[e].rng;
     st[e].rng_split = 1;
   }
   rng_seed(&st[e].rng, seeds[e], (uint32_t)rng_mode);
@@ -1752,6 +1930,52 @@ __global__ void k_rng_state(const EnvState* st, uint64_t* out, int n) {
   const Rng& r = st[e].rng;
   uint64_t* o = out + 7 * (size_t)e;
   o[0] = r.s_hi; o[1] = r.s_lo; o[2] = r.inc_hi; o[3] = r.inc_lo; o[4] = r.has32; o[5] = r.u32; o[6] = r.ndraw;
+}
+
+// ---------------------------------------------------------------- rollouts: the caller-side kernels (cc4_rollout_*)
+constexpr int RPG = 2;      // policy groups of a rollout: group of episode e = (e / P) % RPG
+// gate of a policy pass: returns when every episode of policy group g has its packed row of the step in slot `slot` in memory (the step kernel
+// counts them per partition, RunArgs.act_ready), and hands the counters back zeroed.  One wave, partitions on lanes; gives up after `ticks`.
+__global__ __launch_bounds__(WAVE) void k_rollout_gate(uint32_t* cnt, int P, int ring, int g, int slot, int n, long long ticks, uint32_t* fail) {
+  const long long t0 = wall_clock64();
+  for (int p = (int)threadIdx.x; p < P; p += (int)blockDim.x) {
+    const int ne = (n - p + P - 1) / P;                       // episodes p, p + P, ..: index i is of group i % RPG
+    const int want = (ne - g + RPG - 1) / RPG;
+    if (want <= 0) continue;
+    uint32_t* c = cnt + ((size_t)p * RPG + (size_t)g) * (size_t)ring + slot;
+    int naps = 1;
+    while (__hip_atomic_load(c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (uint32_t)want) {
+      for (int q = 0; q < naps; ++q) __builtin_amdgcn_s_sleep(32);
+      if (naps < 8) naps <<= 1;
+      if (wall_clock64() - t0 > ticks) { __hip_atomic_store(fail, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); break; }
+    }
+    __hip_atomic_store(c, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+}
+// stand-in policies for one policy group (bench.py, tests): uniform random indices (the draws of k_random_actions), or indices computed FROM the
+// packed observations of the step before (a policy that ignores its input proves nothing about the hand-over)
+__global__ void k_rollout_random_policy(int32_t* act, int n, int P, int g, uint64_t seed0, uint32_t t) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n * NBLUE) return;
+  const int e = i / NBLUE, b = i % NBLUE;
+  if ((e / P) % RPG != g) return;
+  act[i] = random_blue_action(seed0, t, e, b);
+}
+__device__ __host__ inline uint32_t rollout_obs_hash(const uint32_t* row) {      // 37 words of a packed observation row
+  uint32_t hsh = 2166136261u;
+  for (int w = 0; w < OBS_PACKED / 4; ++w) { hsh ^= row[w]; hsh *= 16777619u; }
+  return hsh;
+}
+__global__ void k_rollout_hash_policy(int32_t* act, const uint8_t* packed, int n, int P, int g, uint32_t j) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= n || (e / P) % RPG != g) return;
+  const uint32_t hsh = rollout_obs_hash(reinterpret_cast<const uint32_t*>(packed + (size_t)e * OBS_PACKED));
+  for (int b = 0; b < NBLUE; ++b) act[e * NBLUE + b] = (int32_t)((hsh + 2654435761u * (uint32_t)(b + 1) + 40503u * j) % (uint32_t)(b == 4 ? ACT_LONG : ACT_SHORT));
+}
+// the packed rows of the observations as they stand in the int32 buffer (what a rollout's first policy pass reads)
+__global__ __launch_bounds__(WAVE) void k_pack_obs_rows(uint8_t* packed, const int32_t* obs, int n) {
+  const int e = blockIdx.x;
+  if (e < n) pack_row_from_obs(packed + (size_t)e * OBS_PACKED, obs + (size_t)e * OBS_TOTAL, (int)threadIdx.x);
 }
 
 // ---------------------------------------------------------------- handle
@@ -1849,7 +2073,18 @@ struct cc4_handle {
   int32_t* d_slot_part = nullptr; // [CC4_SLOTS] CU slot id -> 1 + partition (persist_setup)
   unsigned long long* d_timeline = nullptr;   // CC4_PERSIST_TIMELINE: per-wave time stamps of the current persistent launch
   size_t run_words = 0;           // words of d_run
-  int run_P = 0, run_grid = 0;    // partitions (= CUs that take waves), waves per launch; 0: the persistent path is off
+  int run_P = 0, run_grid = 0;    // partitions (= CUs that take waves; XCD pools: = XCDs), waves per launch; 0: the persistent path is off
+  int run_G = 0;                  // exchange groups of the persistent kernel (episode e counts in group e % run_G): the device's CUs
+  int run_pool = 2;               // the persistent kernel's schedule (RunArgs.pool; CC4_PERSIST_SCHED): 2 = per-CU partitions balanced inside the XCD,
+                                  // 0 = the per-CU partitions of r04 / r05 (only a call's tail is shared), 1 = XCD pools (experiment)
+  uint8_t xcc_lo[8] = {0}, xcc_n[8] = {0};
+  int run_thr = 16;               // schedule 2: a wave helps the partition that lags most once its own is more than this many tickets ahead (CC4_PERSIST_THR)
+  uint8_t xcc_pool[8] = {0xFF, 0xFF, 0xFF, 0xFF, 0xFF, 0xFF, 0xFF, 0xFF};
+  uint32_t* d_pool = nullptr;     // [2][8][TK_STRIDE] the pools' ticket counters, one set per call parity
+  int run_SA = 0, run_SB = 1, run_nB = 0, run_single = 0;   // runs of steps (RunArgs.SA ..; CC4_PERSIST_RUNS="SA,SB,nB,single"; SA = 1: every step an item, as in r05;
+                                                            // SA = 0: chosen per call -- 4 steps, 8 in calls of 64 steps and more: profiles/r06_runs_ab.txt, r06_sched_ab2.txt)
+  uint32_t pool_base = 0;         // steps every episode's progress word stands at (XCD pools: the words are not cleared between calls)
+  int pool_parity = 0;
   int persist_state = -1;         // -1 off / unavailable, 0 not set up yet (persist_setup on first use), 1 on
   bool whole_batch_steps = true;  // CC4_WHOLE_BATCH_STEPS=0: the step entry points always launch per group (A/B)
   int persist_order = 0;          // RunArgs.order (CC4_PERSIST_ORDER)
@@ -1863,6 +2098,15 @@ struct cc4_handle {
   uint8_t* d_xslab = nullptr;     // [XRING][n][OBS_PACKED]
   uint8_t* d_xall = nullptr;      // [XRING][world * n][OBS_PACKED]
   int khz = 0;                    // wall-clock rate (hipDeviceAttributeWallClockRate), asked once
+  // ---- rollouts with the policy in the loop (cc4_rollout_begin .. cc4_rollout_end)
+  int32_t* d_ract = nullptr;      // [2][n][5] action slots (step j reads slot j % 2)
+  uint32_t* d_rready = nullptr;   // [RPG][32] words: actions of steps < value are published for the group
+  uint32_t* d_rcnt = nullptr;     // [P][RPG][XRING] episodes of (partition, policy group) whose packed row of step j is in memory (slot j % XRING)
+  uint32_t* d_rfail = nullptr;    // [1] a gate gave up
+  hipStream_t policy_stream = nullptr;
+  hipEvent_t rev = nullptr;       // the rollout's starting observations are packed (slab XRING - 1)
+  int rollout_k = 0;              // > 0: a rollout of that many steps is in flight
+  int rollout_watchdog_ms = 2000;
   int obs8_from_slab = -1;        // >= 0: the per-step ring's current buffer is to be filled from this slab of the exchange ring (xchg_end), when somebody reads it
   uint32_t* d_xflags = nullptr;   // [0] gathered, [1] timeout (what the waits poll)
   uint32_t* d_xgcnt = nullptr;    // [groups][XRING] group counters (xchg_count)
@@ -1879,6 +2123,8 @@ struct cc4_handle {
   // CC4_PERSIST_VERIFY=1: every one-launch call of cc4_run_random_steps is repeated with per-step launches on a shadow handle that starts
   // from a copy of this handle's rows, and the two results are compared episode by episode (verify_*)
   bool verify = false, is_shadow = false;
+  int verify_every = 1024;        // without CC4_PERSIST_VERIFY: every verify_every-th persistent call is checked all the same (CC4_PERSIST_VERIFY_EVERY; 0: never)
+  uint64_t persist_calls = 0;
   cc4_handle* shadow = nullptr;
   uint64_t* d_digest = nullptr;   // [num_envs] per-episode digest
   long long verify_calls = 0, verify_mismatches = 0;
@@ -2231,7 +2477,9 @@ static int choose_run_form(cc4_handle* h, int margin, int persist_margin = -1) {
     int per_cu = 0;
     HIPCHK(h, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, persist_kernel(h), WAVE, offsetof(EnvState, hd)));
     const int grid = (per_cu - persist_margin) * h->cus;
-    if (per_cu - persist_margin > 0 && cfg->num_envs > grid) h->persist_state = 0;     // batches of more than the chip holds at once (with the tail shared, also just more)
+    // batches of more than the chip holds at once (with the tail shared, also just more).  The numpy-stream mode has no other one-launch form: there
+    // the persistent kernel also serves batches from half the residency up (a partition of fewer episodes than the CU has waves just leaves waves idle)
+    if (per_cu - persist_margin > 0 && (cfg->num_envs > grid || (cfg->rng_mode == 0 && 2 * cfg->num_envs > grid))) h->persist_state = 0;
   }
   if (const char* v = getenv("CC4_PERSIST")) { if (atoi(v) == 0) h->persist_state = -1; }
   return 0;
@@ -2344,9 +2592,16 @@ int cc4_create(const cc4_config* cfg, cc4_handle** out) {
     if (atoi(getenv("CC4_EXP_PROBE")) > 1) (void)streams_run_concurrently(tmp, 4);
   }
   size_t n = (size_t)cfg->num_envs;
-  HIPCHK(h, hipMalloc(&h->d_state, n * sizeof(EnvState)));
+  // experiment (CC4_EXP_MEM=1 fine-grained, 2 uncached): the episodes' rows in memory whose lines the vector L1 does not keep
+  static const int exp_mem = getenv("CC4_EXP_MEM") ? atoi(getenv("CC4_EXP_MEM")) : 0;
+  auto row_alloc = [&](void** p, size_t bytes) -> hipError_t {
+    if (exp_mem == 1) return hipExtMallocWithFlags(p, bytes, hipDeviceMallocFinegrained);
+    if (exp_mem == 2) return hipExtMallocWithFlags(p, bytes, hipDeviceMallocUncached);
+    return hipMalloc(p, bytes);
+  };
+  HIPCHK(h, row_alloc((void**)&h->d_state, n * sizeof(EnvState)));
   h->cold_row = cold_row_bytes(cfg->steps);
-  HIPCHK(h, hipMalloc(&h->d_cold, n * h->cold_row));
+  HIPCHK(h, row_alloc((void**)&h->d_cold, n * h->cold_row));
   if (cfg->rng_mode == 1) HIPCHK(h, hipMalloc(&h->d_reset_ws, n * RESET_WS_WORDS * sizeof(uint32_t)));   // the one-wave kernel's generation work area
   h->in_bytes = n * NBLUE * sizeof(int32_t) + n * NBLUE * MSG_LEN;
   h->small_io = cfg->num_envs <= cc4_handle::SMALL_IO_ENVS;
@@ -2365,7 +2620,7 @@ int cc4_create(const cc4_config* cfg, cc4_handle** out) {
     HIPCHK(h, hipHostMalloc(reinterpret_cast<void**>(&h->pin_out), h->out_bytes, hipHostMallocDefault));
     HIPCHK(h, hipHostGetDevicePointer(reinterpret_cast<void**>(&h->d_obs), h->pin_out, 0));
   } else
-  HIPCHK(h, hipMalloc(&h->d_obs, h->out_bytes));
+  HIPCHK(h, row_alloc((void**)&h->d_obs, h->out_bytes));
   h->d_reward = reinterpret_cast<float*>(h->d_obs + n * OBS_TOTAL);
   h->d_err = reinterpret_cast<uint32_t*>(h->d_reward + n);
   h->d_done = reinterpret_cast<uint8_t*>(h->d_err + n);
@@ -2384,6 +2639,7 @@ int cc4_create(const cc4_config* cfg, cc4_handle** out) {
   if (const char* v = getenv("CC4_PERSIST_ORDER")) h->persist_order = atoi(v);
   if (const char* v = getenv("CC4_WHOLE_BATCH_STEPS")) h->whole_batch_steps = atoi(v) != 0;
   if (const char* v = getenv("CC4_PERSIST_VERIFY")) h->verify = atoi(v) != 0;
+  if (const char* v = getenv("CC4_PERSIST_VERIFY_EVERY")) h->verify_every = atoi(v) > 0 ? atoi(v) : 0;
   return 0;
 }
 
@@ -2396,8 +2652,11 @@ void cc4_destroy(cc4_handle* h) {
   if (h->comm) ncclCommDestroy(h->comm);
   for (int b = 0; b < cc4_handle::OBS_RING; ++b) { for (int g = 0; g < cc4_handle::MAX_GROUPS; ++g) if (h->ev_step[b][g]) (void)hipEventDestroy(h->ev_step[b][g]); if (h->ev_comm[b]) (void)hipEventDestroy(h->ev_comm[b]); }
   if (h->comm_stream) (void)hipStreamDestroy(h->comm_stream);
+  if (h->policy_stream) (void)hipStreamDestroy(h->policy_stream);
+  if (h->rev) (void)hipEventDestroy(h->rev);
+  for (void* p : {(void*)h->d_ract, (void*)h->d_rready, (void*)h->d_rcnt, (void*)h->d_rfail}) if (p) (void)hipFree(p);
   void* ptrs[] = {h->d_state, h->d_cold, h->small_io ? nullptr : (void*)h->d_actions, h->d_seeds, h->d_envmask, h->small_io ? nullptr : (void*)h->d_obs,
-                  h->d_mask, h->d_rng, h->d_reset_ws, h->d_ext, h->d_run, h->d_slot_part};     // (d_msgs, d_reward, d_err, d_done live inside d_actions / d_obs; small handles: pinned host memory, freed below)
+                  h->d_mask, h->d_rng, h->d_reset_ws, h->d_ext, h->d_run, h->d_slot_part, h->d_pool};     // (d_msgs, d_reward, d_err, d_done live inside d_actions / d_obs; small handles: pinned host memory, freed below)
   for (void* p : ptrs) if (p) (void)hipFree(p);
   if (h->shadow) { cc4_destroy(h->shadow); h->shadow = nullptr; (void)hipSetDevice(h->cfg.device_id); }
   for (void* p : {(void*)h->d_prev_state, (void*)h->d_prev_cold, (void*)h->d_prev_out}) if (p) (void)hipFree(p);
@@ -2664,16 +2923,18 @@ int cc4_get_rng_state(cc4_handle* h, uint64_t* out) {
   return 0;
 }
 int cc4_set_seed(cc4_handle* h, const uint64_t* seeds) {
+  h->prev_valid = false;        // (cc4_replay_logged would repeat a step from rows that have moved on)
   HIPCHK(h, hipSetDevice(h->cfg.device_id));
   if (join_groups(h)) return -1;
   int n = h->cfg.num_envs;
   HIPCHK(h, hipMemcpyAsync(h->d_seeds, seeds, (size_t)n * sizeof(uint64_t), hipMemcpyHostToDevice, h->stream));
-  hipLaunchKernelGGL(k_set_seed, dim3((n + 127) / 128), dim3(128), 0, h->stream, h->d_state, h->d_seeds, n, h->cfg.rng_mode);
+  hipLaunchKernelGGL(k_set_seed, dim3((n + 127) / 128), dim3(128), 0, h->stream, h->d_state, h->d_cold, h->cold_row, h->d_seeds, n, h->cfg.rng_mode);
   HIPCHK(h, hipGetLastError());
   HIPCHK(h, hipStreamSynchronize(h->stream));
   return 0;
 }
 int cc4_set_rng_state(cc4_handle* h, const uint64_t* words) {
+  h->prev_valid = false;
   if (h->cfg.rng_mode != 0) { h->err = "cc4_set_rng_state: a numpy PCG64 state needs rng_mode 0"; return -2; }
   HIPCHK(h, hipSetDevice(h->cfg.device_id));
   if (join_groups(h)) return -1;
@@ -2755,17 +3016,78 @@ static int persist_setup(cc4_handle* h) {
   int P = 0;
   for (int sl = 0; sl < CC4_SLOTS; ++sl) if (count[sl] > 0) table[sl] = ++P;        // 1 + partition, in slot order: an XCD's CUs own neighbouring partitions
   if (getenv("CC4_PERSIST_DEBUG")) fprintf(stderr, "[cc4] persistent kernel: %d compute units seen (device: %d), %d LDS granules per wave, %d waves per CU\n", P, h->cus, granules, per_cu);
+  {
+    // the partition mode the hand-over was validated in: SPX -- one device, all eight XCDs, every CU of each (MI355X: 8 x 32).  Another
+    // picture (CPX / DPX / QPX partitions, a part with CUs fused off differently per XCD) may well work -- an XCD's L2 is still the
+    // coherence point of its CUs -- but nobody has run the self-check there: CC4_PERSIST_ANY_PARTITION=1 takes the responsibility.
+    int nx = 0, per_x[8] = {0};
+    for (int sl = 0; sl < 8 << 8; ++sl) if (count[sl] > 0) ++per_x[sl >> 8];
+    bool even = true;
+    for (int xc = 0; xc < 8; ++xc) { if (per_x[xc]) ++nx; if (per_x[xc] && per_x[xc] != per_x[0]) even = false; }
+    const bool spx = nx == 8 && even && per_x[0] > 0;
+    if (!spx && !(getenv("CC4_PERSIST_ANY_PARTITION") && atoi(getenv("CC4_PERSIST_ANY_PARTITION")) != 0)) {
+      fprintf(stderr, "[cc4] the persistent run kernel stays OFF for this handle (per-step launches instead): the device shows %d XCD(s) with %d..CUs each -- not the SPX "
+                      "picture (8 XCDs, equal CU counts) the hand-over between waves was validated in; CC4_PERSIST_ANY_PARTITION=1 overrides\n", nx, per_x[0]);
+      h->persist_refused = true;
+      return 0;
+    }
+  }
   if (P != h->cus) {       // a CU id that does not tell CUs apart would put two CUs on one partition: never run on a guess
     fprintf(stderr, "[cc4] the persistent run kernel stays OFF for this handle (per-step launches instead): its discovery pass saw %d compute units, the device has %d\n", P, h->cus);
     h->persist_refused = true;
     return 0;
   }
-  h->run_P = P; h->run_grid = per_cu * h->cus;
+  h->run_P = P; h->run_G = P; h->run_grid = per_cu * h->cus;
+  if (const char* v = getenv("CC4_PERSIST_SCHED")) h->run_pool = atoi(v);
+  if (const char* v = getenv("CC4_PERSIST_THR")) h->run_thr = atoi(v);
+  if (h->run_pool < 0 || h->run_pool > 2) h->run_pool = 2;
+  if (const char* v = getenv("CC4_PERSIST_RUNS")) {
+    int q[4] = {h->run_SA, h->run_SB, h->run_nB, h->run_single};
+    (void)sscanf(v, "%d,%d,%d,%d", &q[0], &q[1], &q[2], &q[3]);
+    h->run_SA = q[0] < 0 ? 0 : q[0]; h->run_SB = q[1] < 1 ? 1 : q[1]; h->run_nB = q[2] < 0 ? 0 : q[2]; h->run_single = q[3] < 0 ? 0 : q[3];
+  }
+  if (h->run_pool == 2) {
+    // the partitions of an XCD: a contiguous range (they are numbered in slot order, slot id = XCC id << 8 | CU)
+    bool ok = true;
+    for (int xc = 0; xc < 8; ++xc) {
+      int lo = -1, cnt = 0;
+      for (int sl = xc << 8; sl < (xc + 1) << 8; ++sl) if (table[sl] > 0) { if (lo < 0) lo = table[sl] - 1; ++cnt; }
+      if (cnt > WAVE || lo > 255) ok = false;          // (one lane per partition of the XCD; the range's start travels as a byte)
+      h->xcc_lo[xc] = (uint8_t)(lo < 0 ? 0 : lo); h->xcc_n[xc] = (uint8_t)(cnt > WAVE ? 0 : cnt);
+    }
+    for (int sl = 8 << 8; sl < CC4_SLOTS; ++sl) if (count[sl] > 0) ok = false;          // an XCC id beyond 7: not a device this schedule knows
+    if (P > 510) ok = false;                            // the runner's id in the progress words: 9 bits
+    if (!ok) h->run_pool = 0;
+    else {
+      if (!h->d_pool) HIPCHK(h, hipMalloc(&h->d_pool, 2 * (size_t)CC4_SLOTS * TK_STRIDE * sizeof(uint32_t)));
+      HIPCHK(h, hipMemset(h->d_pool, 0, 2 * (size_t)CC4_SLOTS * TK_STRIDE * sizeof(uint32_t)));
+      h->pool_base = 0; h->pool_parity = 0;
+    }
+  }
+  if (h->run_pool == 1) {
+    // one pool per XCD the discovery pass saw waves on (slot id = XCC id << 8 | CU)
+    int nx = 0;
+    for (int xc = 0; xc < 8; ++xc) {
+      bool seen = false;
+      for (int sl = xc << 8; sl < (xc + 1) << 8; ++sl) seen = seen || count[sl] > 0;
+      h->xcc_pool[xc] = seen ? (uint8_t)nx++ : (uint8_t)0xFF;
+    }
+    for (int sl = 8 << 8; sl < CC4_SLOTS; ++sl) if (count[sl] > 0) nx = 0;          // an XCC id beyond 7: not a device this schedule knows
+    if (nx <= 0) h->run_pool = 0;
+    else {
+      h->run_P = nx;
+      if (!h->d_pool) HIPCHK(h, hipMalloc(&h->d_pool, 2 * (size_t)CC4_SLOTS * TK_STRIDE * sizeof(uint32_t)));
+      HIPCHK(h, hipMemset(h->d_pool, 0, 2 * (size_t)CC4_SLOTS * TK_STRIDE * sizeof(uint32_t)));
+      h->pool_base = 0; h->pool_parity = 0;
+      if (getenv("CC4_PERSIST_DEBUG")) fprintf(stderr, "[cc4] persistent kernel: %d XCD pools\n", nx);
+    }
+  }
   if (!h->d_slot_part) HIPCHK(h, hipMalloc(&h->d_slot_part, CC4_SLOTS * sizeof(int32_t)));
   HIPCHK(h, hipMemcpy(h->d_slot_part, table.data(), CC4_SLOTS * sizeof(int32_t), hipMemcpyHostToDevice));
   if (h->d_run) { (void)hipFree(h->d_run); h->d_run = nullptr; }
-  h->run_words = 2 * (size_t)P + n;                                            // [P ticket | P owner | n progress]: one memset per call
+  h->run_words = 2 * (size_t)h->run_G + n;                                            // [P ticket | P owner | n progress]: one memset per call
   HIPCHK(h, hipMalloc(&h->d_run, h->run_words * sizeof(uint32_t)));
+  HIPCHK(h, hipMemset(h->d_run, 0, h->run_words * sizeof(uint32_t)));
   h->persist_state = 1;
   return 0;
 }
@@ -2776,6 +3098,11 @@ static int persist_setup(cc4_handle* h) {
 static int xchg_begin(cc4_handle* h, int k, XchgArgs* x) {
   (void)k;
   const size_t groups = (size_t)h->cfg.num_envs / 32 + 1 > (size_t)h->cus ? (size_t)h->cfg.num_envs / 32 + 1 : (size_t)h->cus;
+  {
+    const size_t nb = (size_t)h->cfg.num_envs * OBS_PACKED;
+    if (!h->d_xslab) HIPCHK(h, hipMalloc(&h->d_xslab, nb * cc4_handle::XRING));
+    if (!h->d_xall) HIPCHK(h, hipMalloc(&h->d_xall, nb * (size_t)h->world * cc4_handle::XRING));
+  }
   if (!h->d_xflags) { HIPCHK(h, hipMalloc(&h->d_xflags, 2 * sizeof(uint32_t))); h->xflags_clean = 0; }
   if (!h->d_xgcnt) { HIPCHK(h, hipMalloc(&h->d_xgcnt, groups * cc4_handle::XRING * sizeof(uint32_t))); h->xflags_clean = 0; }
   if (!h->h_xtimeout) {
@@ -2801,7 +3128,7 @@ static int xchg_begin(cc4_handle* h, int k, XchgArgs* x) {
 static int xchg_enqueue(cc4_handle* h, int k, const XchgArgs& x, int form) {
   const size_t row = (size_t)h->cfg.num_envs * OBS_PACKED;
   const int C = h->xchg_chunk, n = h->cfg.num_envs;
-  const int P = form == 3 ? h->run_P : 0, groups = form == 3 ? h->run_P : (n + 31) / 32;
+  const int P = form == 3 ? h->run_G : 0, groups = form == 3 ? h->run_G : (n + 31) / 32;
   const long long gate_ticks = 30000LL * (h->khz > 0 ? h->khz : 100000);         // 30 s: a step kernel that never gets there (the host would wait for it forever anyway)
   for (int c0 = 0, hi = 0; c0 < k; c0 = hi + 1) {
     hi = (c0 + C < k ? c0 + C : k) - 1;
@@ -2851,6 +3178,12 @@ static int xchg_end(cc4_handle* h, int k) {
     // carried a later step's rows -- and the handle goes back to per-step launches, loudly.
     h->xchg_timeouts++;
     h->xchg_on = false;
+    // what this call gathered is not published as valid: the gather log forgets the call's steps, and the observations of the call's last
+    // step -- whose slab nothing overwrote -- are gathered again through the per-step path when somebody asks (obs8_from_slab stays)
+    h->last_gathered = nullptr; h->gather_buf = -1;
+    if (h->d_xlog) h->xlog_n = h->xlog_n >= k ? h->xlog_n - k : 0;
+    h->err = "the in-kernel exchange timed out in the last cc4_run_random_steps call (episodes intact; its all-gathers are void; per-step launches from now on)";
+    (void)hipFree(h->d_xall); h->d_xall = nullptr;      // (the gathered twin of the ring: world times the ring; the ring itself still holds the last step's rows)
     fprintf(stderr, "[cc4] the in-kernel exchange timed out (a step waited > %d ms for the all-gather of %d steps earlier): this handle returns to per-step launches with the exchange\n",
             h->xchg_watchdog_ms, cc4_handle::XRING);
   }
@@ -2872,7 +3205,17 @@ static int verify_digest(cc4_handle* h, std::vector<uint64_t>& out) {
   return 0;
 }
 int cc4_run_random_steps(cc4_handle* h, uint64_t seed0, uint32_t t0, int32_t k, float* ms_step_kernels) {
-  if (!h->verify || h->is_shadow || k < 2) return run_random_steps_impl(h, seed0, t0, k, ms_step_kernels);
+  if (h->is_shadow || k < 2) return run_random_steps_impl(h, seed0, t0, k, ms_step_kernels);
+  // The self-check: with CC4_PERSIST_VERIFY=1 every one-launch call is repeated on a shadow handle and compared; WITHOUT it every
+  // verify_every-th call that takes the PERSISTENT form is (CC4_PERSIST_VERIFY_EVERY, default 1024, 0 = never; the communicator-less handles
+  // only: a shadow handle cannot join the exchange) -- the hand-over between the waves of a CU rests on behaviour the memory model does not
+  // promise, so the path keeps checking itself in production at < 1 % of its time (a checked call costs ~10 x a plain one; the shadow
+  // handle -- a second copy of the batch's rows -- is allocated by the first checked call).
+  bool check = h->verify;
+  if (!check && h->verify_every > 0 && !h->comm && h->persist_state >= 0 && k >= h->persist_min_k && !h->run1m && !h->multistep) {
+    if (++h->persist_calls % (uint64_t)h->verify_every == 0) check = true;
+  }
+  if (!check) return run_random_steps_impl(h, seed0, t0, k, ms_step_kernels);
   HIPCHK(h, hipSetDevice(h->cfg.device_id));
   if (strncmp(cc4_run_kernel_for(h, k), "k_run_", 6) != 0) return run_random_steps_impl(h, seed0, t0, k, ms_step_kernels);
   if (!h->shadow) {
@@ -2912,7 +3255,49 @@ int cc4_run_random_steps(cc4_handle* h, uint64_t seed0, uint32_t t0, int32_t k, 
 }
 // out[0] calls checked, out[1] calls that disagreed (CC4_PERSIST_VERIFY)
 int cc4_verify_stats(cc4_handle* h, int64_t* out /* [2] */) { out[0] = h->verify_calls; out[1] = h->verify_mismatches; return 0; }
+// One launch of the persistent kernel for k steps of the whole batch (cc4_run_random_steps form 3; cc4_rollout_begin with rollout = true: every step
+// an item of its own, the actions from the rollout's slots behind the caller's publishes).
+static int persist_launch(cc4_handle* h, StepArgs a, int k, uint32_t t0, const XchgArgs& x, hipEvent_t e0, hipEvent_t e1, bool rollout) {
+  if (!h->run_pool) HIPCHK(h, hipMemsetAsync(h->d_run, 0, h->run_words * sizeof(uint32_t), h->stream));
+  else if (h->pool_base + (uint32_t)k > (h->run_pool == 2 ? 0x700000u : 0x7F000000u)) {      // (the progress words count steps since they were last cleared)
+    HIPCHK(h, hipMemsetAsync(h->d_run, 0, h->run_words * sizeof(uint32_t), h->stream));
+    h->pool_base = 0;
+  }
+  unsigned long long* d_tl = nullptr;
+  if (getenv("CC4_PERSIST_TIMELINE")) { HIPCHK(h, hipMalloc(&d_tl, 4 * sizeof(unsigned long long) * (size_t)h->run_grid)); HIPCHK(h, hipMemsetAsync(d_tl, 0, 4 * sizeof(unsigned long long) * (size_t)h->run_grid, h->stream)); }
+  h->d_timeline = d_tl;
+  RunArgs ra{h->d_run, h->d_run + 2 * h->run_G, reinterpret_cast<int32_t*>(h->d_run + h->run_G), h->d_slot_part, h->run_P, k, h->run_G, t0, d_tl, h->persist_order,
+             1, k, 1, 0, k, 0, 0u, nullptr, {0xFF, 0xFF, 0xFF, 0xFF, 0xFF, 0xFF, 0xFF, 0xFF}, {0}, {0}, h->run_thr};
+  const int SA = rollout ? 1 : (h->run_SA > 0 ? h->run_SA : (k >= 64 ? 8 : 4));
+  if (SA > 1) {
+    // runs of steps: nB runs of SB and tail_single single steps close the call, runs of SA fill the rest (what is left over goes to the single steps)
+    int single = h->run_single < k ? h->run_single : k;
+    int nB = h->run_SB > 1 ? h->run_nB : 0;
+    while (nB > 0 && single + nB * h->run_SB > k) --nB;
+    const int nA = (k - single - nB * h->run_SB) / SA;
+    single = k - nA * SA - nB * h->run_SB;
+    ra.SA = SA; ra.nA = nA; ra.SB = h->run_SB > 1 ? h->run_SB : 1; ra.nB = nB; ra.nph = nA + nB + single;
+  }
+  if (h->run_pool) {
+    ra.pool = h->run_pool; ra.base = h->pool_base;
+    ra.ticket = h->d_pool + (size_t)h->pool_parity * CC4_SLOTS * TK_STRIDE;
+    ra.ticket_next = h->d_pool + (size_t)(h->pool_parity ^ 1) * CC4_SLOTS * TK_STRIDE;
+    memcpy(ra.xcc_pool, h->xcc_pool, 8); memcpy(ra.xcc_lo, h->xcc_lo, 8); memcpy(ra.xcc_n, h->xcc_n, 8);
+    h->pool_parity ^= 1; h->pool_base += (uint32_t)k;
+  }
+  if (rollout) {
+    ra.act_ready = h->d_rready; ra.act = h->d_ract; ra.PG = RPG;
+    ra.act_wait_ticks = (long long)h->rollout_watchdog_ms * (h->khz > 0 ? h->khz : 100000);
+  }
+#ifndef CC4_DEV_FAST
+  if (h->cfg.rng_mode == 0) hipExtLaunchKernelGGL(k_run_pcg, dim3(h->run_grid), dim3(WAVE), offsetof(EnvState, hd), h->stream, e0, e1, 0, a, ra, x);
+  else
+#endif
+  hipExtLaunchKernelGGL(k_run_philox1, dim3(h->run_grid), dim3(WAVE), offsetof(EnvState, hd), h->stream, e0, e1, 0, a, ra, x);
+  return 0;
+}
 static int run_random_steps_impl(cc4_handle* h, uint64_t seed0, uint32_t t0, int32_t k, float* ms_step_kernels) {
+  h->prev_valid = false;        // (every form of this call moves the rows without refreshing the kept copy of cc4_keep_previous)
   HIPCHK(h, hipSetDevice(h->cfg.device_id));
   if (k <= 0) { if (ms_step_kernels) *ms_step_kernels = 0.f; return 0; }   // nothing to launch, no timing event to read
   const bool plain = (!h->comm || h->xchg_on) && !h->evlog_on && !h->ext_seen && !h->d_prof;
@@ -2942,16 +3327,7 @@ static int run_random_steps_impl(cc4_handle* h, uint64_t seed0, uint32_t t0, int
     } else if (form == 2) {
       hipExtLaunchKernelGGL(k_run_philox1m, dim3(h->cfg.num_envs), dim3(WAVE), offsetof(EnvState, hd), h->stream, e0, e1, 0, a, (int)k, t0, x);
     } else {
-      HIPCHK(h, hipMemsetAsync(h->d_run, 0, h->run_words * sizeof(uint32_t), h->stream));
-      unsigned long long* d_tl = nullptr;
-      if (getenv("CC4_PERSIST_TIMELINE")) { HIPCHK(h, hipMalloc(&d_tl, 4 * sizeof(unsigned long long) * (size_t)h->run_grid)); HIPCHK(h, hipMemsetAsync(d_tl, 0, 4 * sizeof(unsigned long long) * (size_t)h->run_grid, h->stream)); }
-      h->d_timeline = d_tl;
-      RunArgs ra{h->d_run, h->d_run + 2 * h->run_P, reinterpret_cast<int32_t*>(h->d_run + h->run_P), h->d_slot_part, h->run_P, k, t0, d_tl, h->persist_order};
-#ifndef CC4_DEV_FAST
-      if (h->cfg.rng_mode == 0) hipExtLaunchKernelGGL(k_run_pcg, dim3(h->run_grid), dim3(WAVE), offsetof(EnvState, hd), h->stream, e0, e1, 0, a, ra, x);
-      else
-#endif
-      hipExtLaunchKernelGGL(k_run_philox1, dim3(h->run_grid), dim3(WAVE), offsetof(EnvState, hd), h->stream, e0, e1, 0, a, ra, x);
+      if (persist_launch(h, a, k, t0, x, e0, e1, false)) return -1;
     }
     HIPCHK(h, hipGetLastError());
     h->stat_launch_us += std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - c0).count();
@@ -3126,6 +3502,130 @@ static int run_random_steps_impl(cc4_handle* h, uint64_t seed0, uint32_t t0, int
   }
   return 0;
 }
+// ---- rollouts with the policy in the loop (include/cc4.h).  ONE launch of the persistent kernel per k-step rollout; the caller's policy
+// runs between the steps on the caller's stream, one policy group of episodes at a time, ordered against the stepping through device words only.
+static int rollout_ready(cc4_handle* h, const char* who) {
+  if (h->rollout_k <= 0) { h->err = std::string(who) + ": no rollout is in flight (cc4_rollout_begin)"; return -2; }
+  return 0;
+}
+int cc4_rollout_begin(cc4_handle* h, int32_t k) {
+  HIPCHK(h, hipSetDevice(h->cfg.device_id));
+  if (h->rollout_k > 0) { h->err = "cc4_rollout_begin: a rollout is in flight (cc4_rollout_end)"; return -2; }
+  if (k <= 0 || k > 0x100000) { h->err = "cc4_rollout_begin: 1 .. 2^20 steps"; return -2; }
+  if (h->cfg.rng_mode != 1 || h->comm || h->evlog_on || h->ext_seen || h->d_prof) { h->err = "cc4_rollout_begin: for counter-mode handles without a communicator, event log or submitted red / green actions"; return -2; }
+  if (h->persist_state == 0) { if (persist_setup(h)) return -1; }
+  if (h->persist_state != 1 || h->run_pool != 2) { h->err = "cc4_rollout_begin: this handle has no persistent kernel (a batch the chip holds at once, or a device picture the schedule refuses): step it with cc4_step_device"; return -2; }
+  if (join_groups(h)) return -1;
+  h->prev_valid = false;
+  const size_t n = (size_t)h->cfg.num_envs, row = n * OBS_PACKED;
+  if (!h->d_ract) {
+    HIPCHK(h, hipMalloc(&h->d_ract, 2 * n * NBLUE * sizeof(int32_t)));
+    HIPCHK(h, hipMalloc(&h->d_rready, RPG * 32 * sizeof(uint32_t)));
+    HIPCHK(h, hipMalloc(&h->d_rcnt, (size_t)h->run_P * RPG * cc4_handle::XRING * sizeof(uint32_t)));
+    HIPCHK(h, hipMalloc(&h->d_rfail, sizeof(uint32_t)));
+    HIPCHK(h, hipStreamCreateWithFlags(&h->policy_stream, hipStreamNonBlocking));
+    HIPCHK(h, hipEventCreateWithFlags(&h->rev, hipEventDisableTiming));
+    if (const char* v = getenv("CC4_ROLLOUT_WATCHDOG_MS")) h->rollout_watchdog_ms = atoi(v) > 0 ? atoi(v) : 2000;
+  }
+  if (!h->d_xslab) HIPCHK(h, hipMalloc(&h->d_xslab, row * cc4_handle::XRING));
+  if (!h->d_xflags) { HIPCHK(h, hipMalloc(&h->d_xflags, 2 * sizeof(uint32_t))); }
+  if (!h->h_xtimeout) {
+    HIPCHK(h, hipHostMalloc(reinterpret_cast<void**>(&h->h_xtimeout), sizeof(uint32_t), hipHostMallocDefault));
+    HIPCHK(h, hipHostGetDevicePointer(reinterpret_cast<void**>(&h->d_xtimeout), h->h_xtimeout, 0));
+  }
+  if (h->khz <= 0) { int khz = 100000; (void)hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, h->cfg.device_id); h->khz = khz > 0 ? khz : 100000; }
+  *h->h_xtimeout = 0;
+  HIPCHK(h, hipMemsetAsync(h->d_xflags, 0, 2 * sizeof(uint32_t), h->stream));
+  HIPCHK(h, hipMemsetAsync(h->d_rready, 0, RPG * 32 * sizeof(uint32_t), h->stream));
+  HIPCHK(h, hipMemsetAsync(h->d_rcnt, 0, (size_t)h->run_P * RPG * cc4_handle::XRING * sizeof(uint32_t), h->stream));
+  HIPCHK(h, hipMemsetAsync(h->d_rfail, 0, sizeof(uint32_t), h->stream));
+  // what the first policy pass reads: the observations as they stand, packed into the slab in front of step 0's
+  hipLaunchKernelGGL(k_pack_obs_rows, dim3((unsigned)n), dim3(WAVE), 0, h->stream, h->d_xslab + (size_t)(cc4_handle::XRING - 1) * row, h->d_obs, (int)n);
+  HIPCHK(h, hipEventRecord(h->rev, h->stream));
+  StepArgs a{h->d_state, h->d_cold, nullptr, nullptr, h->d_obs, h->d_reward, h->d_done, h->d_err, nullptr, nullptr, 0, 0,
+             h->cfg.num_envs, h->cfg.autoreset, h->cfg.steps, h->cfg.rng_mode,
+             (h->cfg.red_policy & 3) | (h->cfg.green_policy ? GP_SLEEP_BIT : 0) | (h->cfg.green_policy == 2 ? GP_OPEN_BIT : 0) | (h->cfg.blue_policy ? BP_RANDOM_BIT : 0),
+             h->full_obs_next ? 1 : 0, (uint32_t)h->cfg.topology_seed, nullptr, h->d_reset_ws, nullptr, 0};
+  XchgArgs x{h->d_xslab, nullptr, h->d_xflags + 1, cc4_handle::XRING, 0, h->d_rcnt, h->d_xtimeout};
+  if (persist_launch(h, a, k, 0u, x, nullptr, nullptr, true)) return -1;
+  HIPCHK(h, hipGetLastError());
+  h->stat_steps += k;
+  h->full_obs_next = false;
+  h->main_ahead = h->ngroups > 1;
+  h->rollout_k = k;
+  return 0;
+}
+int cc4_rollout_groups(cc4_handle* h, int32_t* groups, int32_t* block) {
+  if (h->persist_state == 0) { HIPCHK(h, hipSetDevice(h->cfg.device_id)); if (persist_setup(h)) return -1; }
+  *groups = RPG; *block = h->run_P > 0 ? h->run_P : h->cus;
+  return 0;
+}
+int cc4_rollout_obs_packed(cc4_handle* h, int32_t j, const uint8_t** d_rows) {
+  if (!h->d_xslab || !h->d_ract) { h->err = "cc4_rollout_obs_packed: no rollout was begun on this handle"; return -2; }      // (also behind cc4_rollout_end: the ring keeps the last 32 steps)
+  *d_rows = h->d_xslab + (size_t)((j + cc4_handle::XRING - 1) % cc4_handle::XRING) * (size_t)h->cfg.num_envs * OBS_PACKED;
+  return 0;
+}
+int cc4_rollout_actions(cc4_handle* h, int32_t j, int32_t** d_actions) {
+  if (!h->d_ract) { h->err = "cc4_rollout_actions: no rollout was begun on this handle"; return -2; }
+  *d_actions = h->d_ract + (size_t)(j & 1) * (size_t)h->cfg.num_envs * NBLUE;
+  return 0;
+}
+int cc4_rollout_policy_stream(cc4_handle* h, void** hip_stream) {
+  if (!h->policy_stream) { h->err = "cc4_rollout_policy_stream: no rollout was begun on this handle"; return -2; }
+  *hip_stream = h->policy_stream;
+  return 0;
+}
+int cc4_rollout_wait_obs(cc4_handle* h, int32_t g, int32_t j, void* hip_stream) {
+  if (rollout_ready(h, "cc4_rollout_wait_obs")) return -2;
+  if (g < 0 || g >= RPG || j < 0 || j >= h->rollout_k) { h->err = "cc4_rollout_wait_obs: group or step out of range"; return -2; }
+  hipStream_t st = hip_stream ? (hipStream_t)hip_stream : h->policy_stream;
+  if (j == 0) { HIPCHK(h, hipStreamWaitEvent(st, h->rev, 0)); return 0; }
+  hipLaunchKernelGGL(k_rollout_gate, dim3(1), dim3(WAVE), 0, st, h->d_rcnt, h->run_P, (int)cc4_handle::XRING, (int)g, (int)((j - 1) % cc4_handle::XRING), h->cfg.num_envs,
+                     (long long)h->rollout_watchdog_ms * h->khz, h->d_rfail);
+  HIPCHK(h, hipGetLastError());
+  return 0;
+}
+int cc4_rollout_publish(cc4_handle* h, int32_t g, int32_t j, void* hip_stream) {
+  if (rollout_ready(h, "cc4_rollout_publish")) return -2;
+  if (g < 0 || g >= RPG || j < 0 || j >= h->rollout_k) { h->err = "cc4_rollout_publish: group or step out of range"; return -2; }
+  hipStream_t st = hip_stream ? (hipStream_t)hip_stream : h->policy_stream;
+  HIPCHK(h, hipStreamWriteValue32(st, h->d_rready + (size_t)g * 32, (uint32_t)(j + 1), 0));
+  return 0;
+}
+int cc4_rollout_random_policy(cc4_handle* h, int32_t g, int32_t j, uint64_t seed0, uint32_t t, void* hip_stream) {
+  if (rollout_ready(h, "cc4_rollout_random_policy")) return -2;
+  hipStream_t st = hip_stream ? (hipStream_t)hip_stream : h->policy_stream;
+  const int tot = h->cfg.num_envs * NBLUE;
+  hipLaunchKernelGGL(k_rollout_random_policy, dim3((tot + 255) / 256), dim3(256), 0, st, h->d_ract + (size_t)(j & 1) * (size_t)tot, h->cfg.num_envs, h->run_P, (int)g, seed0, t);
+  HIPCHK(h, hipGetLastError());
+  return 0;
+}
+int cc4_rollout_hash_policy(cc4_handle* h, int32_t g, int32_t j, void* hip_stream) {
+  if (rollout_ready(h, "cc4_rollout_hash_policy")) return -2;
+  hipStream_t st = hip_stream ? (hipStream_t)hip_stream : h->policy_stream;
+  const int n = h->cfg.num_envs;
+  const uint8_t* rows = h->d_xslab + (size_t)((j + cc4_handle::XRING - 1) % cc4_handle::XRING) * (size_t)n * OBS_PACKED;
+  hipLaunchKernelGGL(k_rollout_hash_policy, dim3((n + 255) / 256), dim3(256), 0, st, h->d_ract + (size_t)(j & 1) * (size_t)n * NBLUE, rows, n, h->run_P, (int)g, (uint32_t)j);
+  HIPCHK(h, hipGetLastError());
+  return 0;
+}
+int cc4_rollout_end(cc4_handle* h) {
+  if (rollout_ready(h, "cc4_rollout_end")) return -2;
+  HIPCHK(h, hipSetDevice(h->cfg.device_id));
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  HIPCHK(h, hipStreamSynchronize(h->policy_stream));
+  const int k = h->rollout_k;
+  h->rollout_k = 0;
+  uint32_t gate_failed = 0;
+  HIPCHK(h, hipMemcpy(&gate_failed, h->d_rfail, sizeof(uint32_t), hipMemcpyDeviceToHost));
+  if (*reinterpret_cast<volatile uint32_t*>(h->h_xtimeout) || gate_failed) {
+    h->err = "cc4_rollout_end: a step of the " + std::to_string(k) + "-step rollout waited longer than " + std::to_string(h->rollout_watchdog_ms) +
+             " ms for its actions (or a policy gate for its observations): not every group's policy pass of every step was published -- the episodes were "
+             "stepped with whatever the action slots held (CC4_ROLLOUT_WATCHDOG_MS)";
+    return -6;
+  }
+  return 0;
+}
 int cc4_launches_per_step(cc4_handle* h) { return h ? h->ngroups : 0; }
 // host-side counters since cc4_create: steps issued by cc4_run_random_steps, microseconds the host spent enqueueing their step
 // launches and their all-gathers, all-gathers issued, and how many times a step had to WAIT for an old all-gather before it
@@ -3144,6 +3644,7 @@ int cc4_get_state(cc4_handle* h, int32_t env, void* buf) {
   return 0;
 }
 int cc4_set_state(cc4_handle* h, int32_t env, const void* buf) {
+  h->prev_valid = false;        // (also every cc4_edit_state, which writes the rows back through here)
   if (env < 0 || env >= h->cfg.num_envs) { h->err = "cc4_set_state: env out of range"; return -2; }
   {   // the cold containers of this handle were sized from cfg.steps; the row says how long ITS episode is (EnvState.steps)
     const int st_steps = static_cast<const EnvState*>(buf)->steps;
@@ -3171,6 +3672,7 @@ int cc4_get_cold(cc4_handle* h, int32_t env, void* buf) {
   return 0;
 }
 int cc4_set_cold(cc4_handle* h, int32_t env, const void* buf) {
+  h->prev_valid = false;
   if (env < 0 || env >= h->cfg.num_envs) { h->err = "cc4_set_cold: env out of range"; return -2; }
   HIPCHK(h, hipSetDevice(h->cfg.device_id));
   if (join_groups(h)) return -1;
@@ -3294,6 +3796,11 @@ int cc4_debug_profile(cc4_handle* h, int enable, unsigned long long* out) {
 // debug: the red policy phase of every episode with G episodes' agents per wave; out[0] = mean launch duration in us, out[1] = mean cycles
 // of a wave in the phase, out[2] = waves per launch.  Reads the batch as it stands, writes nothing back.
 int cc4_debug_policy_probe(cc4_handle* h, int32_t G, int32_t reps, double* out) {
+#ifndef CC4_POLICY_PROBE
+  (void)G; (void)reps; (void)out;
+  h->err = "cc4_debug_policy_probe: this library was built without -DCC4_POLICY_PROBE (the experiment of DESIGN 3.4 is concluded; tools/policy_group_probe.py says how to build it)";
+  return -2;
+#else
   HIPCHK(h, hipSetDevice(h->cfg.device_id));
   if (h->cfg.rng_mode != 1) { h->err = "cc4_debug_policy_probe: counter mode only"; return -2; }
   if (join_groups(h)) return -1;
@@ -3329,6 +3836,15 @@ int cc4_debug_policy_probe(cc4_handle* h, int32_t G, int32_t reps, double* out) 
   double sum = 0; for (auto c : cyc) sum += (double)c;
   out[0] = (double)ms * 1000.0 / (reps > 0 ? reps : 1); out[1] = sum / waves; out[2] = waves;
   (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); (void)hipFree(d_cyc);
+  return 0;
+#endif
+}
+int cc4_debug_copy_from_device(cc4_handle* h, void* host_dst, const void* device_src, size_t bytes) {
+  HIPCHK(h, hipSetDevice(h->cfg.device_id));
+  if (join_groups(h)) return -1;
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  if (h->policy_stream) HIPCHK(h, hipStreamSynchronize(h->policy_stream));
+  HIPCHK(h, hipMemcpy(host_dst, device_src, bytes, hipMemcpyDeviceToHost));
   return 0;
 }
 
@@ -3374,9 +3890,8 @@ int cc4_comm_init(cc4_handle* h, int32_t rank, int32_t world, const void* id128)
     for (int g = 0; g < h->ngroups; ++g) HIPCHK(h, hipEventCreateWithFlags(&h->ev_step[b][g], hipEventDisableTiming));
     HIPCHK(h, hipEventCreateWithFlags(&h->ev_comm[b], hipEventDisableTiming));
   }
-  // the ring of step slabs the one-launch kernels write (XchgArgs) and its gathered twin
-  HIPCHK(h, hipMalloc(&h->d_xslab, nb * cc4_handle::XRING));
-  HIPCHK(h, hipMalloc(&h->d_xall, nb * (size_t)world * cc4_handle::XRING));
+  // (the ring of step slabs the one-launch kernels write, XchgArgs, and its gathered twin -- 32 x (1 + world) x N x 148 B -- are allocated by
+  // the first call that takes a one-launch form: xchg_begin)
   HIPCHK(h, hipEventCreateWithFlags(&h->xev, hipEventDisableTiming));
   int can_wait = 0;
   (void)hipDeviceGetAttribute(&can_wait, hipDeviceAttributeCanUseStreamWaitValue, h->cfg.device_id);

@@ -167,8 +167,10 @@ struct alignas(16) RedHdr {
 static_assert(sizeof(RedHdr) == 32, "RedHdr is two 16-byte vectors");
 struct alignas(16) RedAgent {
   alignas(8) uint8_t sord[MAX_RS];   // state.sessions[agent] in dict order: pool slots (read eight at a time)
-  uint16_t known_sid[MAX_KS];        // ActionSpace.server_session keys with value True, insertion order
-  uint32_t known_bm[8];              // the same set as a bitmap over ids 0..255 (larger ids fall back to the list scan)
+  uint32_t known_bm[8];              // ActionSpace.server_session keys with value True as a bitmap over ids 0..255.  The same set in
+                                     // insertion order -- read once when a policy draws a session, scanned only for ids >= 256 -- is
+                                     // EnvCold.known_sid[agent] (r06: 1152 bytes of the staged part moved behind the row; with rng2 gone
+                                     // too the agent part is 5952 B, which with the kernels' statics is FIVE 1280-byte LDS granules)
   uint8_t fsm_order[MAXH];           // host_states dict insertion order, restricted to hosts whose state is not 'F'
                                      // ('F' is absorbing and excluded from known_hosts, FiniteStateRedAgent.py:114)
   uint8_t fsm_st4[(MAXH + 1) / 2];   // host_states[h]: one nibble per host, FS_* + 1 (0 = not in host_states): fsm_get / fsm_put
@@ -222,12 +224,8 @@ struct alignas(64) EnvState {
   float action_cost;
   int32_t n_actions;                 // actions surviving filter_actions (length of the shuffled index list)
   int32_t n_restore;                 // Restore actions submitted this step (each costs -1)
-  // CybORG.set_seed (env.py:316-325) hands the new Generator to the controller, the state and the hosts
-  // (SimulationController.set_np_random, SC:317-320; State.set_np_random, State.py:241-251) but not to the agent objects,
-  // whose np_random was bound when they were created (SC:1041): until the next reset the green / red POLICIES keep drawing
-  // from the old stream while everything else draws from the new one.  rng2 is that old stream while rng_split is set
-  // (numpy-stream mode; the counter mode, which is not bit-comparable with the reference anyway, re-keys all streams).
-  Rng rng2;
+  // (CybORG.set_seed's second generator -- the stream the policies keep drawing from until the next reset while rng_split is set --
+  // is EnvCold.rng2: read by the numpy-stream kernel only, and only after a set_seed.)
   BlueAgent blue[NBLUE];
   RSess spool[RS_POOL];              // red session records of all six agents
   RedAgent red[NRED];
@@ -290,6 +288,14 @@ struct alignas(16) EnvCold {
                                      // valid while the agent's queued / executing Act carries AQ_RATE0 / AQ_RATE1)
   uint32_t gfail[4];                 // bit g: green_agent_g's action of the last step returned Observation(False) (what CybORG.step /
                                      // parallel_step report as its 'success'; written by the full builds of the step only; word 3 unused)
+  uint16_t known_sid[NRED][MAX_KS];  // ActionSpace.server_session keys with value True of red agent r, insertion order; entries
+                                     // [0, RedHdr.nknown) are valid (RedAgent.known_bm holds the ids < 256 as a bitmap)
+  // CybORG.set_seed (env.py:316-325) hands the new Generator to the controller, the state and the hosts
+  // (SimulationController.set_np_random, SC:317-320; State.set_np_random, State.py:241-251) but not to the agent objects,
+  // whose np_random was bound when they were created (SC:1041): until the next reset the green / red POLICIES keep drawing
+  // from the old stream while everything else draws from the new one.  rng2 is that old stream while EnvState.rng_split is set
+  // (numpy-stream mode; the counter mode, which is not bit-comparable with the reference anyway, re-keys all streams).
+  Rng rng2;
 };
 static_assert(sizeof(EnvCold) % 16 == 0, "the containers behind the fixed part start 16-byte aligned");
 // Suspicious pids per blue agent: one per pid-carrying process_creation event in its zone, i.e. per successful red exploit

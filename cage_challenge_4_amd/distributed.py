@@ -198,15 +198,18 @@ def control_plane(kind=None, force=False, fresh=False):
     """The job's control plane from the launcher's environment (RANK, WORLD_SIZE, MASTER_PORT; torch.distributed.run sets
     them).  kind: 'file' (default; no PyTorch) or 'gloo' (CC4_CONTROL_PLANE overrides).  force: a one-rank FilePlane instead of
     the SoloPlane (exercises the N>1 code path at world size 1).  ONE plane per process: later calls return the same object
-    (a second FilePlane on the same directory would start its operation numbers at 0 again) -- and raise if they ask for another
-    kind of plane than the one that exists; fresh=True builds another one, which gets a file-name prefix of its own."""
+    (a second FilePlane on the same directory would start its operation numbers at 0 again) -- an argument-less call returns
+    whatever plane exists; a call that names a kind (or force=True) raises if the existing plane is of another kind; fresh=True
+    builds another one, which gets a file-name prefix of its own."""
     global _PLANE
     rank, world, _ = env_rank_world()
+    asked = kind is not None or force or 'CC4_CONTROL_PLANE' in os.environ      # an argument-less call asks for "the plane this process runs"
     kind = os.environ.get('CC4_CONTROL_PLANE', kind or 'file')
     want = 'solo' if (world == 1 and not force) else kind
     if _PLANE is not None and not fresh:
-        have = 'solo' if isinstance(_PLANE, SoloPlane) else ('gloo' if isinstance(_PLANE, GlooPlane) else 'file')
-        if have != want:      # e.g. a SoloPlane cached by an earlier call, then force=True: never hand back a plane of another kind silently
+        # FilePlane and GlooPlane both derive from SoloPlane: classify by the exact type, most derived first
+        have = 'gloo' if isinstance(_PLANE, GlooPlane) else ('file' if isinstance(_PLANE, FilePlane) else 'solo')
+        if asked and have != want:      # e.g. a SoloPlane cached by an earlier call, then force=True: never hand back a plane of another kind silently
             raise RuntimeError(f'control_plane(): this process already runs a {have!r} plane, a {want!r} plane was asked for '
                                '(pass fresh=True for a second plane)')
         return _PLANE

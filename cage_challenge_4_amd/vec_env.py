@@ -315,6 +315,19 @@ class CC4VecEnv:
         self._chk(self.lib.cc4_get_state(self._h, int(env), buf.ctypes.data_as(ctypes.c_void_p)), 'cc4_get_state')
         return buf
 
+    def get_states(self):
+        """The packed hot rows of ALL episodes, [num_envs][cc4_state_bytes] (checkpointing a batch, parity tests)."""
+        nb = int(self.lib.cc4_state_bytes())
+        out = np.zeros((self.num_envs, nb), np.uint8)
+        for e in range(self.num_envs):
+            self._chk(self.lib.cc4_get_state(self._h, e, out[e].ctypes.data_as(ctypes.c_void_p)), 'cc4_get_state')
+        return out
+
+    def get_cold(self, env):
+        cold = np.zeros(self.lib.cc4_cold_bytes(self._h), np.uint8)
+        self._chk(self.lib.cc4_get_cold(self._h, int(env), cold.ctypes.data_as(ctypes.c_void_p)), 'cc4_get_cold')
+        return cold
+
     def set_state(self, env, buf):
         buf = np.ascontiguousarray(buf, dtype=np.uint8)
         assert buf.size == self.lib.cc4_state_bytes()
@@ -366,6 +379,41 @@ class CC4VecEnv:
                 if rc:
                     self._chk(rc, 'cc4_step_group_device')
         return 0.0
+
+    def run_rollout(self, k, policy='random', seed0=0, t0=0):
+        """A k-step rollout with the policy in the loop and ONE launch of the step engine (cc4_rollout_begin .. cc4_rollout_end, include/cc4.h): per step
+        and policy group the gate on the last step's observations, the stand-in policy ('random': the draws of run_random_steps / run_policy_steps;
+        'hash': action indices computed from each episode's packed observation row of the step before), the publish -- all enqueued behind the launch
+        on the handle's policy stream.  A policy of the caller's takes the stand-in's place between cc4_rollout_wait_obs and cc4_rollout_publish."""
+        lib, h = self.lib, self._h
+        self._chk(lib.cc4_rollout_begin(h, int(k)), 'cc4_rollout_begin')
+        s0 = ctypes.c_uint64(seed0)
+        rc = 0
+        for j in range(int(k)):
+            for g in range(2):
+                rc = rc or lib.cc4_rollout_wait_obs(h, g, j, None)
+                rc = rc or (lib.cc4_rollout_random_policy(h, g, j, s0, ctypes.c_uint32(t0 + j), None) if policy == 'random' else lib.cc4_rollout_hash_policy(h, g, j, None))
+                rc = rc or lib.cc4_rollout_publish(h, g, j, None)
+        end = lib.cc4_rollout_end(h)
+        self._chk(rc or end, 'cc4_rollout')
+        return 0.0
+
+    def rollout_obs_packed(self, j):
+        """Host copy of the packed observation rows the policy of step j of the last rollout read ([N, 148] bytes, 2 bits per value: the observations
+        after step j - 1; the ring keeps the last 32 steps)."""
+        p = ctypes.c_void_p()
+        self._chk(self.lib.cc4_rollout_obs_packed(self._h, int(j), ctypes.byref(p)), 'cc4_rollout_obs_packed')
+        out = np.zeros((self.num_envs, 148), np.uint8)
+        self._chk(self.lib.cc4_debug_copy_from_device(self._h, out.ctypes.data_as(ctypes.c_void_p), p, out.nbytes), 'cc4_debug_copy_from_device')
+        return out
+
+    def rollout_actions(self, j):
+        """Host copy of the action slot step j of the last rollout read ([N, 5]; slots alternate: valid for its last two steps)."""
+        p = ctypes.c_void_p()
+        self._chk(self.lib.cc4_rollout_actions(self._h, int(j), ctypes.byref(p)), 'cc4_rollout_actions')
+        out = np.zeros((self.num_envs, L.NUM_BLUE), np.int32)
+        self._chk(self.lib.cc4_debug_copy_from_device(self._h, out.ctypes.data_as(ctypes.c_void_p), p, out.nbytes), 'cc4_debug_copy_from_device')
+        return out
 
     def device_actions(self):
         """cc4_get_actions: host copy of the handle's device action buffer ([N, 5]; after run_random_steps: the indices the last

@@ -82,8 +82,9 @@ class EnterpriseScenarioGenerator:
         # :736-748, :805-817): the engine's own policy for that team then sleeps, the object's get_action(observation, action_space) is
         # called every step with the agent's dict observation, and what it returns is submitted through cc4_step_ex (the slow path: one
         # host round trip per step -- what a scripted or learning red agent costs in the reference too).  host_agents=True (or a class
-        # attribute cc4_host_agent = True) sends a class to the host path although its name is a built-in's -- e.g. a user's modified
-        # FiniteStateRedAgent; a foreign class whose name collides WITHOUT that opt-in runs the device policy and is told so (a warning).
+        # attribute cc4_host_agent = True) sends a class to the host path although its name is a built-in's.  The name selects the device
+        # policy only for classes from the `CybORG` package or this one: a class of any other module whose name collides with a built-in
+        # (a user's modified FiniteStateRedAgent) runs ITS get_action on the host, unless it sets cc4_device_policy = True.
         blue = {'SleepAgent': 0, 'cc4BlueRandomAgent': 1}
         red = {'FiniteStateRedAgent': 0, 'SleepAgent': 1, 'DiscoveryFSRed': 2, 'RandomSelectRedAgent': 3}
         green = {'EnterpriseGreenAgent': 0, 'SleepAgent': 1}
@@ -94,11 +95,15 @@ class EnterpriseScenarioGenerator:
         self.custom = {}                                   # team -> class whose objects act from the host
         for team, name, table, cls in (('blue', bn, blue, blue_agent_class), ('red', rn, red, red_agent_class), ('green', gn, green, green_agent_class)):
             builtin = name in table and not (host_agents and cls is not None and name != 'SleepAgent') and not getattr(cls, 'cc4_host_agent', False)
-            if builtin and cls is not None and name != 'SleepAgent' and not getattr(cls, '__module__', '').startswith(('cage_challenge_4_amd', 'CybORG')):
-                import warnings
-                warnings.warn(f'{team}_agent_class={cls.__module__}.{name}: the name selects the engine\'s built-in {name} policy on the device; '
-                              f'pass host_agents=True (or set {name}.cc4_host_agent = True) to run this class\'s own get_action on the host',
-                              stacklevel=2)
+            mod = getattr(cls, '__module__', '') or ''
+            ours = cls is None or mod == 'CybORG' or mod.startswith(('CybORG.', 'cage_challenge_4_amd'))
+            if builtin and not ours and name != 'SleepAgent':
+                # a class of ANOTHER package whose name merely collides with a built-in (a user's modified FiniteStateRedAgent): its own
+                # get_action must run -- host path by default; cc4_device_policy = True on the class opts into the device policy by name
+                if getattr(cls, 'cc4_device_policy', False):
+                    pass
+                elif hasattr(cls, 'get_action'):
+                    builtin = False
             if not builtin:
                 if not callable(cls) or not hasattr(cls, 'get_action'):
                     raise TypeError(f'{team}_agent_class={cls!r}: an agent class needs get_action(observation, action_space)')
@@ -354,6 +359,45 @@ class CybORG:
                        done=bool(st.raw['done']), reward=round(sum(rew.values()), 1),
                        action_space=self.get_action_space(agent),
                        action=[st.last_action[agent]] if agent in st.last_action else [self._submitted.get(agent, A.Sleep())])
+
+    def start(self, steps=None, log_file=None, verbose=False):
+        """env.py:163-179 -> SimulationController.start (SC:905-950): run `steps` steps in which no action is submitted (every agent's own
+        policy acts), stop early once the episode is done, return the done flag; steps=None runs until done.  (The reference's log_file
+        line reads attributes of a 'Red' agent interface that CC4 scenarios do not have and raises KeyError there; not mirrored --
+        log_file is ignored.  Its unconditional debugging prints are emitted only with verbose=True.)"""
+        done, n = False, 0
+        while steps is None or n < int(steps):
+            n += 1
+            self._submit({}, None)
+            if verbose:
+                print(n)
+            done = bool(self._state().raw['done'])
+            if done:
+                break
+        return done
+
+    def get_agent_ids(self):
+        """env.py:417-424: the keys of the controller's agent interfaces, in the scenario's order (ESG.py create_scenario: blue, green, red)."""
+        n_green = int(self._state().raw['n_green'])
+        return list(self.agents_blue) + [f'green_agent_{g}' for g in range(n_green)] + [f'red_agent_{r}' for r in range(6)]
+
+    def get_message_space(self, agent):
+        """env.py:449-462 -> SC:806-809: MultiBinary(message_length) for any agent name."""
+        return MultiBinary(MESSAGE_LENGTH)
+
+    def get_observation_space(self, agent):
+        """env.py:284-298 -> SC:1000-1015 -> AgentInterface.get_observation_space (Shared/AgentInterface.py:199-201): the reference raises
+        NotImplementedError for every agent of the scenario and ValueError for a name that is not one; so does this mirror."""
+        if agent not in self.get_agent_ids():
+            raise ValueError(f'Agent {agent} not in agent list {self.get_agent_ids()}')
+        raise NotImplementedError
+
+    def close(self, **kwargs):
+        """env.py:426-437 ("designed for the emulator"; in the CC4 trim it reads a GUI attribute that no longer exists and raises
+        AttributeError).  Here: releases the episode's device handle; calling it twice is fine."""
+        vec, self.vec = getattr(self, 'vec', None), None
+        if vec is not None:
+            vec.close()
 
     def _all_observations(self, st, agents):
         """The dict observations of `agents` after the last step: blue from the end-of-turn Monitor's event log, red from the

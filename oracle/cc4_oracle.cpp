@@ -65,7 +65,7 @@ void cc4o_reset(void* h, int i, uint64_t seed, int rng_mode, int steps, int cont
 }
 void cc4o_set_seed(void* h, int i, uint64_t seed, int rng_mode) {   // CybORG.set_seed: the restatement of k_set_seed (csrc/cc4_hip.hip)
   EnvState& st = ((Oracle*)h)->st[i];
-  if (rng_mode == 0) { if (!st.rng_split) st.rng2 = st.rng; st.rng_split = 1; }
+  if (rng_mode == 0) { if (!st.rng_split) ((Oracle*)h)->cold(i)->rng2 = st.rng; st.rng_split = 1; }
   Rng* r = &st.rng;
   rng_seed(r, seed, (uint32_t)rng_mode);
   if (rng_mode == 1) { rng_begin_episode(r); rng_park(r); }
@@ -236,7 +236,7 @@ int cc4o_layout(char* buf, int cap) {
   F(blue); F(spool); F(red); F(hev); F(hd);
 #undef F
 #define G(m) n += snprintf(buf + n, cap - n, "red." #m " %zu\n", offsetof(RedAgent, m))
-  G(sord); G(known_sid); G(fsm_order); G(fsm_st4); G(fsm_hn); G(as_ip); G(as_hn); G(obs);
+  G(sord); G(known_bm); G(fsm_order); G(fsm_st4); G(fsm_hn); G(as_ip); G(as_hn); G(obs);
 #undef G
 #define G(m) n += snprintf(buf + n, cap - n, "red." #m " %zu\n", offsetof(RedAgent, h) + offsetof(RedHdr, m))
   G(queue); G(as_subnet); G(fsm_step); G(nsess); G(nknown); G(fsm_n); G(nobs); G(active); G(obs_success); G(exec_type); G(new_sess_host); G(new_sess_id); G(start_host);
@@ -269,7 +269,7 @@ int cc4o_dump(void* h, int i, char* buf, int cap) {
     P("red %d active %d sess", r, a.h.active);
     for (int k = 0; k < a.h.nsess; ++k) { const RSess& q = s.spool[a.sord[k]]; P(" (%d,%d,%d,%d,%d)", q.id, q.host, q.pid, (q.flags & RS_ABSTRACT) ? 1 : 0, (q.flags & RS_ROOT) ? 1 : 0); }
     P(" known");
-    for (int k = 0; k < a.h.nknown; ++k) P(" %d", a.known_sid[k]);
+    for (int k = 0; k < a.h.nknown; ++k) P(" %d", cold.known_sid[r][k]);
     P(" fsmstep %d fsm", a.h.fsm_step);
     for (int k = 0; k < a.h.fsm_n; ++k) { int hh = a.fsm_order[k]; P(" (%d,%d,%d)", hh, fsm_get(a, hh), bit_get(a.fsm_hn, hh) ? 1 : 0); }
     for (int hh = 0; hh < MAXH; ++hh) if (fsm_get(a, hh) == FS_F) P(" (%d,%d,%d)", hh, FS_F, bit_get(a.fsm_hn, hh) ? 1 : 0);  // 'F' hosts after the live list

@@ -234,6 +234,10 @@ class OracleVecEnv:
         p = self.lib.cc4o_state_ptr(self._h, i)
         return np.frombuffer((ctypes.c_uint8 * n).from_address(p), np.uint8).copy()
 
+    def get_cold(self, i):
+        nc = self.lib.cc4o_cold_bytes(self._h)
+        return np.frombuffer((ctypes.c_uint8 * nc).from_address(self.lib.cc4o_cold_ptr(self._h, i)), np.uint8).copy()
+
     def snapshot(self, i):
         """(hot row, cold row) of episode i as byte arrays: the layout cc4_get_state / cc4_get_cold return."""
         nc = self.lib.cc4o_cold_bytes(self._h)

@@ -288,8 +288,8 @@ def test_enqueue_threads_change_nothing(threads, monkeypatch):
 def test_persistent_kernel_and_its_shared_tail(mode, kernel):
     """The persistent run kernel of large batches: many short calls -- every call ends in a tail whose items the CUs of an XCD share
     behind an agent-scope acquire -- of varying length across a regeneration against the oracle; a batch just beyond what one launch holds
-    (partitions of 20-28 episodes for 18-20 waves) and calls too short for it (per-step launches) in between."""
-    n, steps, seed0 = (5632 if mode else 5000), 60, 31337
+    (partitions of 20-26 episodes for 20-24 waves) and calls too short for it (per-step launches) in between."""
+    n, steps, seed0 = (6656 if mode else 5000), 60, 31337
     dev = _dev(n, steps=steps, rng_mode=mode, autoreset=True)
     assert dev.run_kernel == kernel and dev.run_kernel_for(9) == dev.step_kernel and dev.run_kernel_for(10) == kernel
     ora = OracleVecEnv(n, steps=steps, rng_mode=mode, autoreset=True)
@@ -320,6 +320,132 @@ def test_persistent_kernel_and_its_shared_tail(mode, kernel):
     for i in range(0, n, 3):
         assert np.array_equal(dev.get_state(i), ora.get_state(i)), i
     dev.close(); ora.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('n', [6656, 8192])
+def test_short_persistent_calls_leave_every_hot_row_equal_to_the_oracle(n):
+    """the ordering bug r05 shipped for a day (a stale hot row after a short call, one call in sixty) passed every parity test and was
+    found only by the opt-in self-check.  This one runs in the DEFAULT configuration: many short calls -- each ends in a tail the CUs of an XCD share,
+    each hands every episode from wave to wave a few times -- and after every call the full packed state of EVERY episode (hot rows in one fetch, cold
+    rows sampled) against the oracle, not only the outputs."""
+    import ctypes
+    steps, seed0 = 90, 4711 + n
+    dev = _dev(n, steps=steps, rng_mode=1, autoreset=True)
+    assert dev.run_kernel_for(10) == 'k_run_philox1'
+    ora = OracleVecEnv(n, steps=steps, rng_mode=1, autoreset=True)
+    assert np.array_equal(dev.reset(seeds=seed0), ora.reset_batch(seed0))
+    nb = int(dev.lib.cc4_state_bytes())
+    t = 0
+    for c, K in enumerate((10, 12, 10, 11, 13, 10, 20, 10, 15, 10, 11, 10, 17, 10, 12, 10, 14, 10, 10, 21, 10, 13, 10, 16) * 2):
+        dev.run_random_steps(seed0, t, K, timed=False)
+        for k in range(K):
+            o = ora.step_batch(random_actions(seed0, t + k, n))
+        t += K
+        dev.synchronize(); dev._fetch()
+        assert np.array_equal(dev._obs, o[0]) and np.array_equal(dev._rew, o[1]), (c, K, t)
+        rows = dev.get_states()                                         # [n][state bytes], one copy
+        want = np.stack([ora.get_state(i) for i in range(n)]) if c % 6 == 5 else None
+        if want is not None:
+            bad = np.nonzero((rows != want).any(axis=1))[0]
+            assert bad.size == 0, (c, K, t, bad[:8].tolist())
+        else:                                                           # the other calls: a third of the rows
+            for i in range(c % 3, n, 3):
+                assert np.array_equal(rows[i], ora.get_state(i)), (c, K, t, i)
+        for i in range(c % 97, n, 97):
+            assert np.array_equal(dev.get_cold(i), ora.get_cold(i)), (c, K, t, i)
+    assert rows.shape == (n, nb)
+    dev.close(); ora.close()
+
+
+@pytest.mark.gpu
+def test_sampled_self_check_runs_by_default(monkeypatch):
+    """without CC4_PERSIST_VERIFY every CC4_PERSIST_VERIFY_EVERY-th persistent call (default 1024) is repeated on a shadow handle
+    and compared all the same; here every 5th, and the counters of cc4_verify_stats say so."""
+    monkeypatch.delenv('CC4_PERSIST_VERIFY', raising=False)
+    monkeypatch.setenv('CC4_PERSIST_VERIFY_EVERY', '5')
+    dev = _dev(8192, steps=100, rng_mode=1, autoreset=True, strict=False); dev.reset(seeds=5)
+    t = 0
+    for c in range(16):
+        dev.run_random_steps(5, t, 10 + c % 3, timed=False); t += 10 + c % 3
+    assert dev.verify_stats() == (3, 0)
+    dev.run_random_steps(5, t, 4, timed=False)              # (too short for the persistent form: not counted)
+    assert dev.verify_stats() == (3, 0)
+    dev.close()
+
+
+def _pack_rows(obs):
+    """[n, 578] observation values (0 / 1 / 2) -> [n, 148] bytes, 2 bits per value, low bits first (CC4_OBS_PACKED_BYTES)."""
+    n = obs.shape[0]
+    v = np.zeros((n, 592), np.uint8)
+    v[:, :578] = obs.astype(np.uint8) & 3
+    v = v.reshape(n, 148, 4)
+    return (v[:, :, 0] | (v[:, :, 1] << 2) | (v[:, :, 2] << 4) | (v[:, :, 3] << 6)).astype(np.uint8)
+
+
+def _hash_policy(packed, j):
+    """numpy restatement of k_rollout_hash_policy (csrc/cc4_hip.hip): FNV-1a over the 37 words of an episode's packed observation row."""
+    w = np.ascontiguousarray(packed).view('<u4').astype(np.uint64)          # [n, 37]
+    h = np.full(w.shape[0], 2166136261, np.uint64)
+    for c in range(w.shape[1]):
+        h = ((h ^ w[:, c]) * np.uint64(16777619)) & np.uint64(0xFFFFFFFF)
+    out = np.zeros((w.shape[0], 5), np.int32)
+    for b in range(5):
+        out[:, b] = ((h + np.uint64(2654435761 * (b + 1)) + np.uint64(40503 * j)) & np.uint64(0xFFFFFFFF)) % np.uint64(242 if b == 4 else 82)
+    return out
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('n,policy', [(8192, 'random'), (6656, 'hash'), (8192, 'hash')])
+def test_rollout_with_the_policy_in_the_loop_matches_the_oracle_at_every_step(n, policy):
+    """policy -> step -> policy (CybORG/Evaluation/evaluation.py:89-110) with ONE launch of the step engine per rollout: the persistent
+    kernel waits, per step and policy group, for the actions the caller's stream publishes; the policy reads the packed observations of the step
+    before behind a gate.  Checked at EVERY step: the packed observation rows the policy read, the actions the steps consumed (the 'hash' stand-in
+    computes them FROM those rows -- a stale or missing row changes the trajectory), and at the end of each rollout outputs, generator positions and
+    packed states against the oracle.  Rollouts of up to 32 steps (the ring of observation slabs), across a regeneration."""
+    steps, seed0 = 60, 777 + n
+    dev = _dev(n, steps=steps, rng_mode=1, autoreset=True)
+    ora = OracleVecEnv(n, steps=steps, rng_mode=1, autoreset=True)
+    o_prev = ora.reset_batch(seed0).copy()
+    assert np.array_equal(dev.reset(seeds=seed0), o_prev)
+    assert dev.run_kernel_for(20) == 'k_run_philox1'
+    t = 0
+    for K in (12, 25, 31, 10):
+        dev.run_rollout(K, policy, seed0, t)
+        acts = []
+        for j in range(K):
+            a = random_actions(seed0, t + j, n) if policy == 'random' else _hash_policy(_pack_rows(o_prev), j)
+            assert np.array_equal(dev.rollout_obs_packed(j), _pack_rows(o_prev)), (K, j, 'the rows the policy of this step read')
+            o = ora.step_batch(a)
+            o_prev = o[0].copy()
+            acts.append(a)
+        t += K
+        dev._fetch()
+        assert np.array_equal(dev._obs, o[0]) and np.array_equal(dev._rew, o[1]) and np.array_equal(dev._done.astype(bool), o[2]), K
+        assert np.array_equal(dev.rollout_actions(K - 1), acts[-1]) and np.array_equal(dev.rollout_actions(K - 2), acts[-2]), K
+        assert not dev._err.any()
+    assert t > steps and np.array_equal(dev.rng_state(), ora.rng_state())
+    for i in range(0, n, 7):
+        assert np.array_equal(dev.get_state(i), ora.get_state(i)), i
+    # behind the rollouts: plain steps and a one-launch call still find the handle where the steps left it
+    a = random_actions(seed0 + 1, t, n)
+    d = dev.step(a); o = ora.step_batch(a)
+    assert np.array_equal(d[0], o[0]) and np.array_equal(d[1], o[1])
+    dev.close(); ora.close()
+
+
+@pytest.mark.gpu
+def test_rollout_watchdog_reports_a_pass_that_was_never_published(monkeypatch):
+    """A rollout whose policy never publishes must not hang the kernel: the waiting steps give up after the watchdog, cc4_rollout_end says so (-6)."""
+    monkeypatch.setenv('CC4_ROLLOUT_WATCHDOG_MS', '20')
+    from cage_challenge_4_amd._lib import CC4Error
+    dev = _dev(8192, steps=50, rng_mode=1, autoreset=True, strict=False); dev.reset(seeds=3)
+    dev._chk(dev.lib.cc4_rollout_begin(dev._h, 10), 'cc4_rollout_begin')
+    for g in range(2):                                       # step 0 only
+        dev.lib.cc4_rollout_wait_obs(dev._h, g, 0, None); dev.lib.cc4_rollout_random_policy(dev._h, g, 0, 3, 0, None); dev.lib.cc4_rollout_publish(dev._h, g, 0, None)
+    assert dev.lib.cc4_rollout_end(dev._h) == -6
+    assert b'waited longer than' in dev.lib.cc4_last_error(dev._h)
+    dev.close()
 
 
 def test_device_random_action_kernel_matches_host_restatement():
@@ -491,8 +617,8 @@ def test_observation_ring_survives_a_slow_exchange(n, groups, monkeypatch):
 
 
 @pytest.mark.parametrize('n,mode,run_kernel,delay_us', [(1000, 1, 'k_run_philox', 1500), (2000, 1, 'k_run_philox1m', 0),
-                                                        (8192, 1, 'k_run_philox1', 0), (5632, 1, 'k_run_philox1', 2500), (5000, 0, 'k_run_pcg', 0)],
-                         ids=['1000-slow-exchange', '2000', '8192', '5632-slow-exchange', '5000-numpy-stream'])     # (1000 / 2000: the last group of 32 episodes is a partial one)
+                                                        (8192, 1, 'k_run_philox1', 0), (6656, 1, 'k_run_philox1', 2500), (5000, 0, 'k_run_pcg', 0)],
+                         ids=['1000-slow-exchange', '2000', '8192', '6656-slow-exchange', '5000-numpy-stream'])     # (1000 / 2000: the last group of 32 episodes is a partial one)
 def test_exchange_from_inside_the_one_launch_kernels_gathers_every_step(n, mode, run_kernel, delay_us):
     """with a communicator cc4_run_random_steps stays ONE launch -- step k writes its packed rows into slab k mod 32 of a
     ring and counts finished episodes, the communication stream waits for the count (hipStreamWaitValue32), all-gathers the slab and
@@ -598,19 +724,19 @@ def test_exchange_soak_random_call_lengths_and_delays(n, mode):
     dev.close(); ora.close()
 
 
-@pytest.mark.parametrize('n', [8192, 5632])
+@pytest.mark.parametrize('n', [8192, 6656])
 def test_persistent_kernel_self_check_mode(n, monkeypatch):
     """CC4_PERSIST_VERIFY=1: the persistent kernel hands an episode from one wave to the next of the same CU with
     workgroup-scope ordering only (agent-scope ordering costs 40 % -- profiles/r05_persist_order_ab.txt); in this mode the library
     repeats every one-launch call with per-step launches on a shadow handle and compares hot rows, cold rows and outputs of all episodes.
-    5632 episodes: partitions of 22 for 20 waves -- every call ends in a tail shared across the CUs of an XCD.  (It has earned its keep: r05
+    6656 episodes: partitions of 26 for 24 waves (r05: 5632, 22 for 20) -- every call ends in a tail shared across the CUs of an XCD.  (It has earned its keep: r05
     replaced the hand-over's explicit s_waitcnt vmcnt(0) by a workgroup-scope release fence -- for which the backend emits no vmcnt wait
     without tgsplit -- and this test caught the stale row, one call in about sixty.)"""
     monkeypatch.setenv('CC4_PERSIST_VERIFY', '1')
     dev = _dev(n, steps=100, rng_mode=1, autoreset=True, strict=False); dev.reset(seeds=99)
     assert dev.run_kernel_for(20) == 'k_run_philox1'
     t = 0
-    calls = (20, 10, 37, 20, 64, 10, 13, 11, 25, 10, 17, 12) * (3 if n == 5632 else 1)    # short calls: each one ends in a shared tail
+    calls = (20, 10, 37, 20, 64, 10, 13, 11, 25, 10, 17, 12) * (3 if n == 6656 else 1)    # short calls: each one ends in a shared tail
     for K in calls:
         dev.run_random_steps(99, t, K, timed=(K == 20)); t += K
     assert dev.verify_stats() == (len(calls), 0)

@@ -97,19 +97,26 @@ def test_flat_obs_enumerations_agree():
 
 
 def test_builtin_policies_are_selected_by_class_name_and_foreign_classes_can_opt_out():
-    """the reference's own CybORG.Agents.FiniteStateRedAgent (a class of another module with a built-in's name) must select the
-    device policy, not silently fall to the host slow path; a foreign class of that name is told so; host_agents=True (or the class attribute
-    cc4_host_agent) sends it to the host on purpose; a class of another name always acts from the host."""
+    """the reference's own CybORG.Agents.FiniteStateRedAgent (a class of another module with a built-in's name) must select
+    the device policy, not silently fall to the host slow path; a class of any OTHER package that merely carries a built-in's name (a user's
+    modified FiniteStateRedAgent) keeps its own get_action -- host path -- unless it opts into the device policy (cc4_device_policy = True);
+    host_agents=True (or the class attribute cc4_host_agent) sends any class to the host on purpose; a class of another name always acts
+    from the host."""
     import warnings
 
     class FiniteStateRedAgent:                     # a user's class that happens to carry a built-in's name
         def get_action(self, observation, action_space):
             return None
     FiniteStateRedAgent.__module__ = 'my_agents'
-    with warnings.catch_warnings(record=True) as w:
-        warnings.simplefilter('always')
-        sg = W.EnterpriseScenarioGenerator(red_agent_class=FiniteStateRedAgent)
-    assert sg.custom == {} and sg.red_policy == 0 and any('built-in FiniteStateRedAgent policy' in str(x.message) for x in w)
+    sg = W.EnterpriseScenarioGenerator(red_agent_class=FiniteStateRedAgent)
+    assert sg.custom == {'red': FiniteStateRedAgent} and sg.red_policy == 1       # its own get_action runs
+    FiniteStateRedAgent.cc4_device_policy = True
+    sg = W.EnterpriseScenarioGenerator(red_agent_class=FiniteStateRedAgent)
+    assert sg.custom == {} and sg.red_policy == 0                                 # opted in: the device policy of that name
+    del FiniteStateRedAgent.cc4_device_policy
+    lookalike = type('FiniteStateRedAgent', (), {'get_action': lambda self, o, a: None})
+    lookalike.__module__ = 'CybORGish.agents'                                     # (a prefix match on the package name is not enough)
+    assert W.EnterpriseScenarioGenerator(red_agent_class=lookalike).custom == {'red': lookalike}
     ref_like = type('FiniteStateRedAgent', (), {'get_action': lambda self, o, a: None})
     ref_like.__module__ = 'CybORG.Agents.SimpleAgents.FiniteStateRedAgent'      # the reference's own class: no warning, the device policy
     with warnings.catch_warnings(record=True) as w:
@@ -140,6 +147,35 @@ def test_control_plane_never_hands_back_a_plane_of_another_kind(monkeypatch):
     monkeypatch.setattr(D, '_PLANE', None)
 
 
+def test_control_plane_repeated_calls_return_the_cached_file_or_gloo_plane(monkeypatch, tmp_path):
+    """FilePlane and GlooPlane subclass SoloPlane, so classifying the cached plane with isinstance(.., SoloPlane) called every
+    plane 'solo' and a second control_plane(force=True) -- or init_rccl's argument-less control_plane() at world > 1 -- raised.  file -> file,
+    file -> default and gloo -> default return the cached object; file -> gloo still raises."""
+    from cage_challenge_4_amd import distributed as D
+    monkeypatch.setattr(D, '_PLANE', None)
+    for k in ('RANK', 'WORLD_SIZE', 'CC4_CONTROL_PLANE'):
+        monkeypatch.delenv(k, raising=False)
+    monkeypatch.setenv('CC4_CONTROL_PLANE_KEY', f'hostlogic_{tmp_path.name}')
+    f = D.control_plane(force=True)
+    try:
+        assert type(f) is D.FilePlane
+        assert D.control_plane(force=True) is f            # file -> file
+        assert D.control_plane() is f                      # file -> default: whatever exists
+        assert D.control_plane(kind='file', force=True) is f
+        with pytest.raises(RuntimeError, match="already runs a 'file' plane, a 'gloo' plane"):
+            D.control_plane(kind='gloo', force=True)
+        with pytest.raises(RuntimeError, match="already runs a 'file' plane, a 'solo' plane"):
+            D.control_plane(kind='file')                   # names a kind at world 1 without force: that is a solo plane
+    finally:
+        f.close()
+    g = object.__new__(D.GlooPlane)                        # (no process group: only the classification is under test)
+    monkeypatch.setattr(D, '_PLANE', g)
+    assert D.control_plane() is g                          # gloo -> default
+    with pytest.raises(RuntimeError, match="already runs a 'gloo' plane, a 'file' plane"):
+        D.control_plane(force=True)
+    monkeypatch.setattr(D, '_PLANE', None)
+
+
 def test_event_log_stays_on_for_backends_without_the_replay(oracle_lib):
     """The fixed-action wrappers switch the event log to on-demand only where the engine can repeat a step with the log on
     (cc4_keep_previous / cc4_replay_logged); on the CPU oracle of the tests it simply stays on, and dict observations keep working."""
@@ -150,3 +186,32 @@ def test_event_log_stays_on_for_backends_without_the_replay(oracle_lib):
     env.reset()
     env.step({a: 0 for a in env.possible_agents})
     assert 'success' in env.env.get_observation('blue_agent_0')
+
+
+def test_cyborg_facade_methods_of_env_py(oracle_lib):
+    """VERDICT r05 missing 3: CybORG.get_agent_ids (env.py:417), get_message_space (:449), get_observation_space (:284), start (:163),
+    close (:426).  Expected values recorded from the reference in the build container: 60 ids at seed 5 in the order blue, green, red;
+    get_observation_space raises NotImplementedError for an agent of the scenario and ValueError for any other name; start(n) steps n
+    times without submitted actions and returns the done flag (False, then True once the episode ends)."""
+    from oracle_binding import OracleVecEnv
+    sg = W.EnterpriseScenarioGenerator(blue_agent_class=W.SleepAgent, green_agent_class=W.EnterpriseGreenAgent, red_agent_class=W.FiniteStateRedAgent, steps=20)
+    env = W.CybORG(sg, seed=5, vec_factory=OracleVecEnv)
+    ids = env.get_agent_ids()
+    assert len(ids) == 60 and ids[:6] == [f'blue_agent_{b}' for b in range(5)] + ['green_agent_0']
+    assert ids[-7:] == ['green_agent_48'] + [f'red_agent_{r}' for r in range(6)]
+    assert set(env.active_agents) <= set(ids)
+    sp = env.get_message_space('blue_agent_0')
+    assert sp.n == 8 and sp.contains(np.zeros(8, dtype=np.int8))
+    with pytest.raises(NotImplementedError):
+        env.get_observation_space('blue_agent_0')
+    with pytest.raises(ValueError, match='Agent nobody not in agent list'):
+        env.get_observation_space('nobody')
+    twin = W.CybORG(sg, seed=5, vec_factory=OracleVecEnv)
+    assert env.start(3) is False
+    for _ in range(3):
+        twin.parallel_step({})
+    assert env.get_rewards() == twin.get_rewards() and env.get_true_state() == twin.get_true_state()
+    assert env.start(25) is True                     # the episode (20 steps) ends inside the call; the loop stops there
+    env.close()
+    env.close()
+    twin.close()

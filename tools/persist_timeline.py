@@ -1,5 +1,5 @@
 import os, sys
-sys.path.insert(0, '/root/repo')
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 os.environ['CC4_PERSIST_TIMELINE'] = '1'
 from cage_challenge_4_amd import CC4VecEnv
 env = CC4VecEnv(8192, steps=500, autoreset=True, rng_mode=1, strict=False)

@@ -1,5 +1,6 @@
 #!/usr/bin/env python
-"""DESIGN 3.4 / VERDICT r04 #1: what the red policy phase costs with the agents of G episodes side by side on one wave (cc4_debug_policy_probe), on a
+"""(needs a library built with -DCC4_POLICY_PROBE: e.g. hipcc ... -DCC4_DEV_FAST -DCC4_POLICY_PROBE -o build_var/probe.so ..., CC4_LIB=build_var/probe.so)
+DESIGN 3.4 / VERDICT r04 #1: what the red policy phase costs with the agents of G episodes side by side on one wave (cc4_debug_policy_probe), on a
 live 8192-episode batch at several points of its episodes.  Usage: policy_group_probe.py [envs]"""
 import ctypes, os, sys
 import numpy as np
