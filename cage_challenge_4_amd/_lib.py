@@ -7,7 +7,7 @@ import ctypes
 import os
 
 # more hardware queues than the runtime's default four, so that four step launches can run side by side (read when HIP
-# initialises; libcc4 sets the same default when it is loaded and measures whether it took effect -- csrc/cc4_hip.hip)
+# initialises; libcc4 sets the same default when it is loaded and measures whether it took effect -- csrc/cc4_api.hip)
 os.environ.setdefault('GPU_MAX_HW_QUEUES', '16')
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('CC4_LIB') or os.path.join(_HERE, 'libcc4.so')   # CC4_LIB: another build of the same library (kernel experiments)
@@ -92,6 +92,7 @@ SIGNATURES = {
     'cc4_run_kernel': (ctypes.c_char_p, [_P]),
     'cc4_run_kernel_for': (ctypes.c_char_p, [_P, ctypes.c_int32]),
     'cc4_get_state': (ctypes.c_int, [_P, ctypes.c_int32, _P]),
+    'cc4_get_states': (ctypes.c_int, [_P, ctypes.c_int32, ctypes.c_int32, _P]),
     'cc4_set_state': (ctypes.c_int, [_P, ctypes.c_int32, _P]),
     'cc4_cold_bytes': (ctypes.c_size_t, [_P]),
     'cc4_get_cold': (ctypes.c_int, [_P, ctypes.c_int32, _P]),

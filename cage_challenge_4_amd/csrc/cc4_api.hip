@@ -1,2006 +1,7 @@
-// cc4_hip.hip -- gfx950 kernels + the C ABI (include/cc4.h) of libcc4.so.
-//
-// Execution model of the numpy-stream kernel (k_step): one 64-lane wavefront per episode.  The wave stages the agent part of the
-// episode's packed EnvState row (everything in front of the host table: 6.9 KB) HBM -> LDS with coalesced 16-byte loads and
-// leaves the host table (8.8 KB, of which a step visits a few dozen rows) in HBM/L2 -- LDS is what bounds the number of
-// resident waves of this kernel, and its one working lane hides memory latency only through them.  Lane 0 walks the
-// strictly ordered transition (the reference's ~57 agent actions share one RNG stream, so the order is the semantics),
-// the wave encodes the 578 flat-observation values, and the agent part goes back LDS -> HBM coalesced.
-// The cold part of the episode (process-list overflow, ephemeral-port bitmaps, per-session port knowledge) stays in HBM
-// and is touched a handful of times per step.  The counter-mode kernel (k_step_philox, below) stages the whole row and
-// runs four wavefronts per episode.
-// No MFMA: the path is integer / indexing.
-#include <hip/hip_runtime.h>
-#include <hip/hip_ext.h>
-#include <rccl/rccl.h>
-#include <stdio.h>
-#include <stdlib.h>
-#include <string.h>
-#include <string>
-#include <chrono>
-#include <cstdio>
-#include <cstdlib>
-#include <vector>
-#include <map>
-#include <algorithm>
-#include <thread>
-#include <mutex>
-#include <condition_variable>
-#include <atomic>
-
-#include "../../include/cc4.h"
-#include "../../include/cc4_debug.h"
-#include "cc4_engine.h"
+// cc4_api.hip -- the host side of libcc4.so: the handle, the launch schedules, the exchange, the C ABI (include/cc4.h, include/cc4_debug.h).
+#include "cc4_kernels.h"
 #include "cc4_export.h"
-
-using namespace cc4;
-
-static_assert(sizeof(EnvState) % 16 == 0 && offsetof(EnvState, hd) % 16 == 0, "EnvState rows are staged with 16-byte accesses");
-constexpr int ROW_VEC = (int)(sizeof(EnvState) / 16);
-constexpr int HOT_VEC = (int)(offsetof(EnvState, hd) / 16);   // the part in front of the host table
-constexpr int WAVE = 64;
-constexpr int OBS_PACKED = CC4_OBS_PACKED_BYTES;   // every flat-observation value is 0, 1 or 2: the exchange moves 2 bits per value
-static_assert(OBS_PACKED % 4 == 0 && OBS_PACKED * 4 >= OBS_TOTAL, "packed observation row: whole words, four values per byte");
-constexpr int PROF_SLOTS = 128;   // 16 phase slots, 8 per red agent (16..63), then (cycles, count) per red action type (64..)
-
-constexpr int cc4_handle_max_groups = 8;   // cc4_handle::MAX_GROUPS
-
-struct StepArgs {
-  EnvState* st; EnvCold* cold;
-  const int32_t* actions; const uint8_t* msgs;
-  int32_t* obs; float* reward; uint8_t* done; uint32_t* err;
-  uint8_t* obs8;               // the same observations packed 2 bits per value, OBS_PACKED bytes per episode (what the multi-GPU
-                               // all-gather moves), or null
-  int32_t* rand_out;           // when non-null: draw the blue actions in-kernel (k_random_actions fused) and record them here
-  uint64_t rand_seed0; uint32_t rand_t;
-  int n, autoreset, steps, rng_mode, policy;
-  int full_obs;               // rewrite every observation value (the output buffer may hold another episode's slowly varying part)
-  uint32_t topo;              // cc4_config.topology_seed
-  unsigned long long* prof;   // optional [n][PROF_SLOTS] cycle counters (cc4_debug_profile): 16 phase slots + 8 per red agent
-  uint32_t* reset_ws;         // k_step_philox1: [n][RESET_WS_WORDS] work area of the in-kernel scenario generation (the other
-                              // kernels keep it in LDS; an episode regenerates once in steps-per-episode launches)
-  const ExtAct* ext;          // [n][EXT_PER_ENV] externally submitted red / green actions of this step (cc4_step_ex), or null; read by the
-                              // full builds of the step kernels only (template parameter LOG)
-  int e0;                     // first episode of this launch: block b steps episode e0 + b (a step of a large batch is issued as
-                              // several launches on separate streams: see cc4_handle::ngroups); n = one past its last episode
-  int act_sys;                // the actions were written by ANOTHER kernel while this one runs (a rollout, RunArgs.act_ready): system-scope loads,
-                              // past this XCD's L2, which may still hold the line from two steps ago
-};
-
-// uniform blue action index of (episode e, agent b) at step t: Philox key (seed0 + e), counter (t, b, 0xB10E, 0)
-__device__ __forceinline__ int32_t random_blue_action(uint64_t seed0, uint32_t t, int e, int b) {
-  uint32_t c[4] = {t, (uint32_t)b, 0xB10Eu, 0u};
-  uint64_t key = seed0 + (uint64_t)e;
-  philox4x32_10(c, (uint32_t)key, (uint32_t)(key >> 32));
-  uint32_t range = b == 4 ? ACT_LONG : ACT_SHORT;
-  return (int32_t)(((uint64_t)c[0] * range) >> 32);
-}
-
-// ---------------------------------------------------------------- kernels
-// HBM -> LDS row staging with 8 independent 16-byte loads in flight per lane (a plain copy loop serialises on vmcnt)
-template <int NVEC>
-__device__ __forceinline__ void stage_in(uint4* __restrict__ lds, const uint4* __restrict__ src, int lane) {
-  constexpr int U = NVEC / WAVE < 8 ? (NVEC / WAVE > 0 ? NVEC / WAVE : 1) : 8;
-  int i = lane;
-  for (; i + (U - 1) * WAVE < NVEC; i += U * WAVE) {
-    uint4 v[U];
-#pragma unroll
-    for (int u = 0; u < U; ++u) v[u] = src[i + u * WAVE];
-#pragma unroll
-    for (int u = 0; u < U; ++u) lds[i + u * WAVE] = v[u];
-  }
-  for (; i < NVEC; i += WAVE) lds[i] = src[i];
-}
-template <int NVEC>
-__device__ __forceinline__ void stage_out(uint4* __restrict__ dst, const uint4* __restrict__ lds, int lane) {
-  constexpr int U = NVEC / WAVE < 8 ? (NVEC / WAVE > 0 ? NVEC / WAVE : 1) : 8;
-  int i = lane;
-  for (; i + (U - 1) * WAVE < NVEC; i += U * WAVE) {
-    uint4 v[U];
-#pragma unroll
-    for (int u = 0; u < U; ++u) v[u] = lds[i + u * WAVE];
-#pragma unroll
-    for (int u = 0; u < U; ++u) dst[i + u * WAVE] = v[u];
-  }
-  for (; i < NVEC; i += WAVE) dst[i] = lds[i];
-}
-
-// LOG: the full build of a step kernel -- it records the HostEvents entries of the step (cc4_enable_event_log) and takes externally
-// submitted red / green actions (cc4_step_ex: StepArgs.ext).  A template parameter rather than a run-time flag: even a never-taken
-// logging branch at the eleven event sites costs the serial walk 10 %.
-// byte j of an episode's packed observation row: values 4j .. 4j+3 (from a byte-per-value row in LDS), 2 bits each, low bits first
-__device__ __forceinline__ uint8_t pack_obs_byte(const uint8_t* vals, int j) {
-  uint32_t b = 0;
-#pragma unroll
-  for (int k = 0; k < 4; ++k) { const int i = 4 * j + k; if (i < OBS_TOTAL) b |= (uint32_t)(vals[i] & 3u) << (2 * k); }
-  return (uint8_t)b;
-}
-
-// An episode's packed observation row (OBS_PACKED bytes = 37 words) to memory, one word per thread, as SYSTEM-scope (write-through) stores:
-// the reader is the exchange -- a copy engine, an RCCL kernel on any XCD, a peer GPU -- and, when the writer is a one-launch kernel, there is
-// no kernel boundary that would write the XCD's L2 back first (tools/micro/ring_protocol.hip: plain stores arrive stale, these do not).
-__device__ __forceinline__ void store_packed_row(uint8_t* o8, const uint8_t* vals, int t, int nt) {
-  uint32_t* o32 = reinterpret_cast<uint32_t*>(o8);
-  for (int w = t; w < OBS_PACKED / 4; w += nt) {
-    const uint32_t v = (uint32_t)pack_obs_byte(vals, 4 * w) | ((uint32_t)pack_obs_byte(vals, 4 * w + 1) << 8) |
-                       ((uint32_t)pack_obs_byte(vals, 4 * w + 2) << 16) | ((uint32_t)pack_obs_byte(vals, 4 * w + 3) << 24);
-    __hip_atomic_store(o32 + w, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-  }
-}
-// The same row packed from the int32 observation row the wave has just (re)written in global memory -- the output buffer persists between
-// steps, so it holds every current value although a step only rewrites the ones that changed.  For the one-wave kernels: a byte copy of the
-// 578 values in LDS would cost them a seventh 1280-byte LDS granule and with it two of their twenty resident waves per CU
-// (profiles/r05_lds_residency.txt).  The wave's own stores are drained first (the vector L1 is write-through: they are in the XCD's L2),
-// the loads are agent-scope (served by that L2, never by a stale L1 line).
-__device__ __forceinline__ void pack_row_from_obs(uint8_t* o8, const int32_t* o, int lane) {
-  // call with the wave's stores drained (s_waitcnt vmcnt(0)): then plain loads see them -- the row was written by this wave, by earlier
-  // waves of this CU (same L1; a stolen partition's item starts with an L1 invalidate), or before the launch
-  static_assert((OBS_TOTAL * 4) % 8 == 0, "rows of the int32 observation buffer are 8-byte aligned: two values per load");
-  if (lane < OBS_PACKED / 4) {
-    const uint2* o2 = reinterpret_cast<const uint2*>(o + 16 * lane);
-    uint2 w[8];
-#pragma unroll
-    for (int k = 0; k < 8; ++k) w[k] = (16 * lane + 2 * k < OBS_TOTAL) ? o2[k] : make_uint2(0u, 0u);     // (578 is even: a pair is inside the row or outside)
-    uint32_t v = 0;
-#pragma unroll
-    for (int k = 0; k < 8; ++k) v |= ((w[k].x & 3u) << (4 * k)) | ((w[k].y & 3u) << (4 * k + 2));
-    __hip_atomic_store(reinterpret_cast<uint32_t*>(o8) + lane, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-  }
-}
-// The per-step hand-off out of the one-launch kernels (cc4_run_random_steps with a communicator).  Step k of the launch writes
-// its packed rows into slab k % ring and, once an episode's row is in memory, counts it in its group's counter of that step (a no-return
-// atomic: nothing waits for it); on the communication stream a one-block gate kernel (k_xchg_gate) waits until every group has counted
-// every step of a chunk, the chunk's slabs are gathered, and gathered = last + 1 is published (hipStreamWriteValue32); step k + ring of any
-// episode waits for gathered > k before it overwrites the slab.  The exchange lags the stepping by up to `ring` steps, with no launch
-// boundary in the compute queue.  A wait that lasts longer than wait_ticks gives up, raises *timeout (the host falls back to per-step
-// launches and says so) and every later wait of the launch returns at once: a stuck exchange never hangs the kernel.
-struct XchgArgs {
-  uint8_t* slab;                 // [ring][n][OBS_PACKED], or null: no exchange
-  uint32_t* gathered;            // [1]
-  uint32_t* timeout;             // [1]
-  int ring;
-  long long wait_ticks;          // wall_clock64 ticks (100 MHz)
-  uint32_t* gcnt;                // [groups][ring]: episodes of a group that finished step k (slot k % ring), see xchg_count
-  uint32_t* timeout_host;        // the same flag in pinned host memory, WRITTEN only (the host reads it without a copy; the waits poll the
-                                 // device word: a thousand blocks polling a word across PCIe cost a 1024-episode batch 12 us per step)
-};
-// lane / thread 0 only.  `seen` = the highest value of *gathered this wave has read so far (it only grows): the word is read again --
-// an uncached round trip to memory, ~2 us in the middle of the item hand-over -- only when the value at hand does not cover step k.
-__device__ __forceinline__ void xchg_wait_slab(const XchgArgs& x, uint32_t k, uint32_t& seen) {
-  if (k < (uint32_t)x.ring || !x.gathered) return;      // (no `gathered` word: a rollout -- slab k % ring was consumed by the policy pass of step k - ring + 1, which every episode is long past)
-  const uint32_t need = k - (uint32_t)x.ring + 1u;
-  if (seen >= need) return;
-  seen = __hip_atomic_load(x.gathered, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-  if (seen >= need) return;
-  if (__hip_atomic_load(x.timeout, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM)) return;
-  // Thousands of waves polling one uncached word starve the very write they wait for (tools/micro/ring_protocol.hip: a saturated chip
-  // of spinning pollers took 57 us per exchange step instead of < 16): the interval between two polls of a wave doubles from ~3 us to ~50 us.
-  const long long w0 = wall_clock64();
-  int naps = 1;
-  while ((seen = __hip_atomic_load(x.gathered, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM)) < need) {
-    for (int i = 0; i < naps; ++i) __builtin_amdgcn_s_sleep(127);
-    if (naps < 16) naps <<= 1;
-    if (wall_clock64() - w0 > x.wait_ticks || __hip_atomic_load(x.timeout, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM)) {
-      __hip_atomic_store(x.timeout, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-      __hip_atomic_store(x.timeout_host, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-      return;
-    }
-  }
-}
-// One episode's packed row of step k is in memory (the stores that wrote it have drained): counted in the episode's group (a partition of
-// the persistent kernel, 32 neighbouring episodes of the multi-step kernels), slot k % ring.  A no-return agent-scope atomic: the wave
-// does not wait for it.  (r05 on the way here: one system-scope counter per step -- 8192 atomics on one word serialise at ~12 ns each,
-// twice the step --, then two levels with the group's last episode adding the group to it -- two dependent atomics, ~2 us per item.)
-__device__ __forceinline__ void xchg_count(const XchgArgs& x, uint32_t k, int group) {
-  (void)__hip_atomic_fetch_add(x.gcnt + (size_t)group * (size_t)x.ring + (k % (uint32_t)x.ring), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-// The gate of a chunk of steps [k_lo, k_hi] on the communication stream: returns when every group has counted all its episodes in every
-// step of the chunk (counts of one episode's consecutive steps may arrive out of order: each wave counts where ITS stores have drained),
-// and hands the counters back (zero) for steps k + ring.  P > 0: the groups are the P partitions of the persistent kernel (episodes
-// g, g + P, ..), else groups of 32 neighbouring episodes.  Gives up after `ticks` and says so in *fail (the host reports it).
-// ONE wave, polling at a growing interval (4 us .. 31 us; the gate of a call's LAST step, behind which the host waits, stays at 4 us): the gate shares a CU with blocks of the step kernel, and in the multi-step kernels
-// a block is an episode -- whatever slows one CU's blocks sets the pace of the launch (four busily polling waves cost 1024 episodes 1.2 us per step).
-__global__ __launch_bounds__(WAVE) void k_xchg_gate(uint32_t* gcnt, int ring, int groups, int n, int P, int k_lo, int k_hi, long long ticks, uint32_t* fail, int max_naps) {
-  const int t = (int)threadIdx.x, steps = k_hi - k_lo + 1;
-  const long long t0 = wall_clock64();
-  for (int i = t; i < groups * steps; i += (int)blockDim.x) {
-    const int g = i / steps, k = k_lo + i % steps;
-    const int size = P > 0 ? (n - g + P - 1) / P : (n - (g << 5) < 32 ? n - (g << 5) : 32);
-    if (size <= 0) continue;
-    uint32_t* c = gcnt + (size_t)g * (size_t)ring + (k % ring);
-    int naps = 1;
-    while (__hip_atomic_load(c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (uint32_t)size) {
-      for (int q = 0; q < naps; ++q) __builtin_amdgcn_s_sleep(127);
-      if (naps < max_naps) naps <<= 1;
-      if (wall_clock64() - t0 > ticks) { __hip_atomic_store(fail, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); break; }
-    }
-    __hip_atomic_store(c, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  }
-}
-
-// ---------------------------------------------------------------- numpy stream: the two draw-only phases across the wave
-// PCG64 is a 128-bit LCG, so the state k steps ahead is A_k * state + B_k * increment (A_k = M^k, B_k = 1 + M + .. + M^(k-1),
-// mod 2^128; table filled by cc4_create).  Two phases of a step only CONSUME the stream -- the green agents' policy draws
-// (one bounded draw each) and the action-order shuffle (SimulationController.py:418: ~90 masked-rejection draws whose results
-// are never used) -- so lane j computes output j+1 directly and the consumption is replayed on the 128 ready words with a
-// few wave-wide compares per draw instead of a 128-bit multiply per draw on the walking lane.  Bit-exact with the serial
-// walk (rng_below / rng_interval in cc4_rng.h), including has_uint32 / uinteger buffering and the advance counter.
-__device__ uint32_t g_obs_fast[OBS_FAST];          // obs_fast_entry(v) for v = 0 .. OBS_FAST-1 (cc4_engine.h), filled by cc4_create
-// The observation values that can change with every step, from the table: position, source byte and mask come with one load
-// instead of a dozen divisions per value.
-template <int nt>
-__device__ __forceinline__ void encode_obs_fast(const EnvState* s, int32_t* o, uint8_t* obs_bytes, bool pack, int t) {
-  constexpr int NV = (OBS_FAST + nt - 1) / nt;
-  uint32_t ent[NV];
-#pragma unroll
-#ifdef CC4_OBS_TABLE
-  for (int k = 0; k < NV; ++k) { const int v = t + k * nt; ent[k] = v < OBS_FAST ? g_obs_fast[v] : 0u; }
-#else
-  // computed, not loaded: the kernels wait on memory, not on the vector unit (r03 A/B: the table form of this loop -- one L2 load
-  // per value instead of a dozen shifts and multiplies -- made the encode phase longer: 5.5k -> 6.9k cycles at 8192 episodes)
-  for (int k = 0; k < NV; ++k) { const int v = t + k * nt; ent[k] = v < OBS_FAST ? obs_fast_entry(v) : 0u; }
-#endif
-#pragma unroll
-  for (int k = 0; k < NV; ++k) {
-    const int v = t + k * nt;
-    if (v >= OBS_FAST) continue;
-    const int val = obs_fast_value(ent[k], s);
-    const int i = (int)(ent[k] & 0x3FF);
-    o[i] = val;
-    if (pack) obs_bytes[i] = (uint8_t)val;
-  }
-}
-struct PcgJump { uint64_t a_hi, a_lo, b_hi, b_lo; };
-__device__ PcgJump g_pcg_jump[WAVE + 1];          // [k]: k = 0 .. 64 steps ahead
-__device__ __forceinline__ uint64_t bcast64(uint64_t v) {
-  return (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)v) | ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(v >> 32)) << 32);
-}
-__device__ __forceinline__ uint32_t rdlane(uint32_t v, int j) { return (uint32_t)__builtin_amdgcn_readlane((int)v, j); }
-__device__ __forceinline__ uint64_t lane64(uint64_t v, int src) {
-  return (uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)v, src) | ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(v >> 32), src) << 32);
-}
-__device__ __forceinline__ void pcg_ahead(const PcgJump& J, uint64_t s_hi, uint64_t s_lo, uint64_t i_hi, uint64_t i_lo, uint64_t* o_hi, uint64_t* o_lo) {
-  // (a * s + b * inc) mod 2^128
-  const uint64_t p_lo = J.a_lo * s_lo, p_hi = __umul64hi(J.a_lo, s_lo) + J.a_hi * s_lo + J.a_lo * s_hi;
-  const uint64_t q_lo = J.b_lo * i_lo, q_hi = __umul64hi(J.b_lo, i_lo) + J.b_hi * i_lo + J.b_lo * i_hi;
-  const uint64_t lo = p_lo + q_lo;
-  *o_lo = lo; *o_hi = p_hi + q_hi + (lo < p_lo ? 1ull : 0ull);
-}
-__device__ __forceinline__ uint64_t pcg_output(uint64_t hi, uint64_t lo) {   // XSL-RR 128/64
-  const uint64_t v = hi ^ lo; const uint32_t rot = (uint32_t)(hi >> 58);
-  return (v >> rot) | (v << ((64u - rot) & 63u));
-}
-// Green policy draws of one step (EnterpriseGreenAgent.get_action: choice of 3 per agent, agent order), all lanes.  `rl` is the
-// walking lane's generator (valid on lane 0, updated there).  Returns false without touching anything when a draw would need
-// Lemire's re-draw (a zero word: 2^-32 per agent) -- the caller then walks the phase serially.
-__device__ __forceinline__ bool wave_green_policy(Rng& rl, int n, uint8_t* green_act, int lane) {
-  const uint64_t s_hi = bcast64(rl.s_hi), s_lo = bcast64(rl.s_lo), i_hi = bcast64(rl.inc_hi), i_lo = bcast64(rl.inc_lo);
-  const uint32_t has32 = (uint32_t)__builtin_amdgcn_readfirstlane((int)rl.has32), u32 = (uint32_t)__builtin_amdgcn_readfirstlane((int)rl.u32);
-  uint64_t h, l;
-  pcg_ahead(g_pcg_jump[lane + 1], s_hi, s_lo, i_hi, i_lo, &h, &l);
-  const uint64_t out = pcg_output(h, l);
-  const uint32_t w0 = (uint32_t)out, w1 = (uint32_t)(out >> 32);
-  const int base = (int)has32;                       // agent 0 takes the buffered half word when there is one
-  const int g0 = base + 2 * lane, g1 = g0 + 1;
-  bool zero = (g0 < n && w0 == 0) || (g1 < n && w1 == 0) || (has32 && u32 == 0);
-  if (__ballot(zero)) return false;
-  // Lemire, range 3: (word * 3) >> 32 (the leftover test can only fail for word == 0)
-  if (g0 < n) green_act[g0] = (uint8_t)(((uint64_t)w0 * 3u) >> 32);
-  if (g1 < n) green_act[g1] = (uint8_t)(((uint64_t)w1 * 3u) >> 32);
-  if (has32 && lane == 0) green_act[0] = (uint8_t)(((uint64_t)u32 * 3u) >> 32);
-  const int fresh = n - base;                        // words taken from new outputs
-  const int K = (fresh + 1) >> 1;                    // outputs consumed
-  if (K > 0) {
-    const uint64_t nh = lane64(h, K - 1), nl = lane64(l, K - 1);
-    const uint32_t nu = (uint32_t)__builtin_amdgcn_readlane((int)w1, K - 1);
-    if (lane == 0) { rl.s_hi = nh; rl.s_lo = nl; rl.u32 = nu; rl.has32 = (uint32_t)(fresh & 1); rl.ndraw += (uint32_t)K; }
-  } else if (lane == 0) rl.has32 = 0;
-  return true;
-}
-// wave64 inclusive scans on the DPP network (row_shr 1/2/4/8 inside the rows of 16, then row_bcast 15 and 31 across rows) and
-// the shift by one lane that turns them into exclusive ones
-__device__ __forceinline__ uint32_t wave_scan_add(uint32_t v) {
-  int x = (int)v;
-  x += __builtin_amdgcn_update_dpp(0, x, 0x111, 0xf, 0xf, false);
-  x += __builtin_amdgcn_update_dpp(0, x, 0x112, 0xf, 0xf, false);
-  x += __builtin_amdgcn_update_dpp(0, x, 0x114, 0xf, 0xf, false);
-  x += __builtin_amdgcn_update_dpp(0, x, 0x118, 0xf, 0xf, false);
-  x += __builtin_amdgcn_update_dpp(0, x, 0x142, 0xa, 0xf, false);
-  x += __builtin_amdgcn_update_dpp(0, x, 0x143, 0xc, 0xf, false);
-  return (uint32_t)x;
-}
-__device__ __forceinline__ int wave_scan_max(int v) {   // v >= -1
-  auto mx = [](int a, int b) { return a > b ? a : b; };
-  int x = v;
-  x = mx(x, __builtin_amdgcn_update_dpp(-1, x, 0x111, 0xf, 0xf, false));
-  x = mx(x, __builtin_amdgcn_update_dpp(-1, x, 0x112, 0xf, 0xf, false));
-  x = mx(x, __builtin_amdgcn_update_dpp(-1, x, 0x114, 0xf, 0xf, false));
-  x = mx(x, __builtin_amdgcn_update_dpp(-1, x, 0x118, 0xf, 0xf, false));
-  x = mx(x, __builtin_amdgcn_update_dpp(-1, x, 0x142, 0xa, 0xf, false));
-  x = mx(x, __builtin_amdgcn_update_dpp(-1, x, 0x143, 0xc, 0xf, false));
-  return x;
-}
-__device__ __forceinline__ uint32_t wave_shr1(uint32_t v, uint32_t lane0) {   // lane k <- lane k - 1, lane 0 <- lane0
-  return (uint32_t)__builtin_amdgcn_update_dpp((int)lane0, (int)v, 0x138, 0xf, 0xf, false);
-}
-// Generator.shuffle of an n-item list, consumption only (rng_shuffle_consume): for i = n-1 .. 1 one masked-rejection draw
-// (random_interval).  All lanes; `rl` as above.  Which i a word is tested against depends on how many words in front of it
-// were accepted: a prefix count that depends on itself, solved by relaxation (every lane tests its two words against its
-// current estimate of i, a wave scan of the accepted counts gives the next estimates; a word's verdict only moves when i
-// crosses its masked value, so a handful of rounds settle a window of 128 words).
-__device__ __forceinline__ void wave_shuffle_consume(Rng& rl, int n, int lane) {
-  if (n <= 1) return;
-  uint64_t s_hi = bcast64(rl.s_hi), s_lo = bcast64(rl.s_lo);
-  const uint64_t i_hi = bcast64(rl.inc_hi), i_lo = bcast64(rl.inc_lo);
-  uint32_t has32 = (uint32_t)__builtin_amdgcn_readfirstlane((int)rl.has32), u32 = (uint32_t)__builtin_amdgcn_readfirstlane((int)rl.u32);
-  uint32_t adv = 0;
-  int i = n - 1;
-  auto mask_of = [](uint32_t m) { return 0xFFFFFFFFu >> __builtin_clz(m); };   // m >= 1: the smallest 2^k - 1 >= m (random_interval's mask)
-  if (has32) {                                       // the buffered half word is the first candidate
-    has32 = 0;
-    if ((u32 & mask_of((uint32_t)i)) <= (uint32_t)i) --i;
-  }
-  while (i >= 1) {
-    // a window of 64 outputs = 128 words: word p = half (p & 1) of output (p >> 1) + 1, i.e. lane p >> 1
-    uint64_t h, l;
-    pcg_ahead(g_pcg_jump[lane + 1], s_hi, s_lo, i_hi, i_lo, &h, &l);
-    const uint64_t out = pcg_output(h, l);
-    const uint32_t w0 = (uint32_t)out, w1 = (uint32_t)(out >> 32);
-    uint32_t f_cur = 3, inc = 0;                     // accepted flags of the lane's two words (first guess: all accepted)
-    for (int round = 0; round < WAVE + 2; ++round) {
-      inc = wave_scan_add((f_cur & 1u) + (f_cur >> 1));
-      const int i0 = i - (int)wave_shr1(inc, 0u);    // the i word 0 of this lane is tested against
-      const uint32_t a0 = (i0 >= 1 && (w0 & mask_of((uint32_t)(i0 >= 1 ? i0 : 1))) <= (uint32_t)i0) ? 1u : 0u;
-      const int i1 = i0 - (int)a0;
-      const uint32_t a1 = (i1 >= 1 && (w1 & mask_of((uint32_t)(i1 >= 1 ? i1 : 1))) <= (uint32_t)i1) ? 1u : 0u;
-      const uint32_t f_new = a0 | (a1 << 1);
-      const bool moved = f_new != f_cur;
-      f_cur = f_new;
-      if (!__ballot(moved)) break;                   // lane k is exact after k + 1 rounds at the latest
-    }
-    const int total = (int)rdlane(inc, WAVE - 1);
-    int cur = 2 * WAVE;                              // first unconsumed word of the window
-    if (total >= i) {                                // the draw for i = 1 ends inside the window: behind the i-th accepted word
-      const uint64_t m = __ballot((int)inc >= i);
-      const int L = __ffsll((unsigned long long)m) - 1;
-      const int before = L ? (int)rdlane(inc, L - 1) : 0;
-      const uint32_t fl = rdlane(f_cur, L);
-      cur = 2 * L + ((before + (int)(fl & 1u) >= i) ? 1 : 2);
-      i = 0;
-    } else i -= total;
-    const int K = (cur + 1) >> 1;                    // outputs of this window that were touched
-    s_hi = lane64(h, K - 1); s_lo = lane64(l, K - 1);
-    u32 = rdlane(w1, K - 1);
-    has32 = (uint32_t)(cur & 1);
-    adv += (uint32_t)K;
-  }
-  if (lane == 0) { rl.s_hi = s_hi; rl.s_lo = s_lo; rl.has32 = has32; rl.u32 = u32; rl.ndraw += adv; }
-}
-
-// ---------------------------------------------------------------- numpy stream: the green actions across the wave
-// GreenAccessService / GreenLocalWork draw from the one shared stream, agent after agent, and every agent's number of draws
-// depends on what it drew -- but on nothing it reads from the state that an earlier green action of the same step could have
-// changed, with two exceptions: an ephemeral port that is already taken (Host.py:175-187 re-draws once) and a phishing email
-// (a red session appears).  So the serial walk (50-odd agents x [a 128-bit multiply per draw + an HBM round trip for the port
-// bitmap and one per event byte]) is replaced by:
-//  (1) the next 128 outputs of the LCG from the closed form, two per lane, into LDS;
-//  (2) where in the stream each agent starts.  That is a prefix sum over the agents' draw counts, which depend on the drawn
-//      values, i.e. on the start: solved by relaxation -- every lane (one agent each) replays its action from its current
-//      start estimate, a wave scan of the counts gives the next estimates, until nothing moves.  Agent 0's start is given,
-//      so agent k is exact after k + 1 rounds at the latest; as an action's draw count rarely depends on the values (a
-//      blocked route, a failed reliability roll, the two 1 % events), three rounds are the rule;
-//  (3) the agents' effects -- the port bitmap test-and-set (one L2 atomic), the event bits, the reward -- on their lanes.
-// A taken port, a phishing email, a Lemire re-draw (n / 2^32 per draw) or the end of the window end a batch: its agents in
-// front of that point are committed, the agent at that point is resolved by the serial code on lane 0 (ports set
-// speculatively by later agents are cleared first), and the next batch starts behind it.  Bit-exact with the serial walk
-// (rng_below / rng_random / has_uint32 buffering in cc4_rng.h).
-constexpr int GW_OUT = 2 * WAVE;                           // outputs per window
-constexpr double P01_SCALED = 0.01 * 9007199254740992.0;   // Generator.random() < 0.01 on the 53-bit integer: exact scaling
-constexpr uint64_t P01_FLOOR = (uint64_t)P01_SCALED;
-static_assert((double)P01_FLOOR * (1.0 / 9007199254740992.0) < 0.01 && (double)(P01_FLOOR + 1) * (1.0 / 9007199254740992.0) >= 0.01,
-              "integer form of rng_random() < 0.01");
-enum : uint32_t { GR_VALID = 1, GR_FAIL = 2, GR_EPH = 4, GR_CONN = 8, GR_PROC = 16, GR_HARD = 32, GR_PHISH = 64 };
-__device__ __forceinline__ void wave_green_exec(Ctx x, Rng& rl, uint64_t* win, int lane, unsigned long long* gstat = nullptr) {
-  EnvState* s = x.s;
-  const int ng = s->n_green;
-  const uint64_t i_hi = bcast64(rl.inc_hi), i_lo = bcast64(rl.inc_lo);
-  int g0 = 0;
-  for (int guard = 0; g0 < ng; ++guard) {
-    if (guard > 2 * MAXG + 8) { if (lane == 0) set_err(x, E_UNREACHABLE); break; }   // every batch advances g0
-    const unsigned long long t0 = gstat ? clock64() : 0;
-    const uint64_t s_hi = bcast64(rl.s_hi), s_lo = bcast64(rl.s_lo);
-    const uint32_t has0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)rl.has32), u0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)rl.u32);
-    // (1) the window: output p (0-based) is computed on lane p & 63 (set p >> 6) and stored at win[p]
-    uint64_t h0, l0, h1, l1;
-    pcg_ahead(g_pcg_jump[lane + 1], s_hi, s_lo, i_hi, i_lo, &h0, &l0);
-    pcg_ahead(g_pcg_jump[WAVE], h0, l0, i_hi, i_lo, &h1, &l1);
-    __syncthreads();           // (one wave per block) the previous batch's window reads are done
-    win[lane] = pcg_output(h0, l0);
-    win[WAVE + lane] = pcg_output(h1, l1);
-    __syncthreads();
-    // what the agents of this batch (lane k <-> agent g0 + k) bring along
-    const int gi = g0 + lane;
-    const bool in = gi < ng;
-    const uint32_t my_act = in ? x.w->green_act[gi] : 2u;
-    const bool active = my_act < 2;
-    // what the action reads from the state (green_prepare: the host's service table -- HBM here --, allowed server counts)
-    const uint64_t pre = active ? green_prepare(x, gi, (int)my_act) : 0ull;
-    const uint32_t gh = in ? s->green_host[gi] : 0u;
-    uint32_t my_blk = 0;       // bit sn: traffic between the agent's subnet and subnet sn is blocked either way
-    if (active && my_act == 0) {
-      const int own = h_subnet((int)gh);
-#pragma unroll
-      for (int sn = 0; sn < NSUB - 1; ++sn) if (((s->blocks[own] >> sn) | (s->blocks[sn] >> own)) & 1u) my_blk |= 1u << sn;
-    }
-    const uint32_t lw_am = green_lw_active(pre);
-    // what decides an agent's draw COUNT, reduced to shifts: the leading 32-bit draws (a = 1 or 2; with two, the first one
-    // picks -- a server / a service -- out of `npick`), for GreenAccessService the picks that end on a blocked route (no
-    // further draw), for GreenLocalWork the reliability (/20) of the pick
-    const bool is_as = active && my_act == 0, is_lw = active && my_act == 1 && lw_am != 0;
-    uint32_t npick = 0; uint64_t pickinfo = 0;
-    if (is_as) {
-      npick = (uint32_t)(pre >> 56);
-#pragma unroll
-      for (int sn = 0; sn < NSUB - 1; ++sn) {
-        const uint32_t before = sn ? (uint32_t)((pre >> (8 * (sn - 1))) & 0xFF) : 0u, tot = (uint32_t)((pre >> (8 * sn)) & 0xFF);
-        if (((my_blk >> sn) & 1u) && tot > before) pickinfo |= ((tot >= 64 ? ~0ull : (1ull << tot) - 1ull)) & ~((1ull << before) - 1ull);
-      }
-    } else if (is_lw) {
-      npick = (uint32_t)popc32(lw_am);
-      int cnt = 0;
-#pragma unroll
-      for (int i = 0; i < MAXSV; ++i) if ((lw_am >> i) & 1u) { pickinfo |= ((pre >> (8 * i)) & 0x7Full) << (8 * cnt); ++cnt; }
-    }
-    const uint32_t lead = (is_as || is_lw) ? (npick > 1 ? 2u : 1u) : 0u;
-    // (2) relaxation.  Per lane: d = outputs taken | 32-bit draws << 16 ; q = window index of the last output a 32-bit draw
-    // fetched (its high half is numpy's buffered `uinteger`), -1: none
-    uint32_t d_cur = 0, sp = 0, sh = 0, su = 0;
-    int q_cur = -1;
-    uint32_t inc = 0; int qinc = -1;    // inclusive scans of the last round
-    int rounds = 0;
-    bool stuck = false;
-    for (;; ++rounds) {
-      inc = wave_scan_add(d_cur); qinc = wave_scan_max(q_cur);
-      const uint32_t ex = wave_shr1(inc, 0u);
-      const int exq = (int)wave_shr1((uint32_t)qinc, 0xFFFFFFFFu);
-      const int pos = (int)(ex & 0xFFFFu);
-      const uint32_t has = (has0 + (ex >> 16)) & 1u;
-      const uint32_t buf = exq < 0 ? u0 : (uint32_t)(win[exq < GW_OUT ? exq : GW_OUT - 1] >> 32);
-      sp = (uint32_t)pos; sh = has; su = buf;
-      uint32_t d_new = 0; int q_new = -1;
-      if (lead) {
-        const uint64_t f0 = win[pos < GW_OUT ? pos : GW_OUT - 1], f1 = win[pos + 1 < GW_OUT ? pos + 1 : GW_OUT - 1];
-        const uint32_t first = has ? buf : (uint32_t)f0, second = has ? (uint32_t)f0 : (uint32_t)(f0 >> 32);
-        uint32_t i = (has && lead == 1) ? 0u : 1u, n32 = lead;
-        uint32_t has2 = has ^ (lead & 1u);
-        if (i) q_new = pos;
-        const uint32_t pick = lead == 2 ? (uint32_t)(((uint64_t)first * npick) >> 32) : 0u;
-        if (is_as) {
-          if (!((pickinfo >> pick) & 1ull)) ++i;                       // not blocked: the 1 % connection-event roll
-        } else {
-          const uint32_t roll = (uint32_t)(((uint64_t)(lead == 2 ? second : first) * 100u) >> 32);
-          if (roll < (uint32_t)((pickinfo >> (8 * pick)) & 0xFF) * 20u) {
-            const uint64_t u1 = i ? f1 : f0;
-            ++i;
-            if ((u1 >> 11) <= P01_FLOOR) { ++n32; if (!has2) { q_new = pos + (int)i; ++i; } has2 ^= 1u; }   // the false-positive event's port
-            ++i;                                                        // the phishing roll
-          }
-        }
-        d_new = i | (n32 << 16);
-      }
-      const bool moved = d_new != d_cur || q_new != q_cur;
-      d_cur = d_new; q_cur = q_new;
-      if (!__ballot(moved)) break;          // the estimates the lanes just used were the fixed point
-      if (rounds > WAVE + 2) { stuck = true; break; }   // cannot happen (lane k is exact after k + 1 rounds): serial walk
-    }
-    // the agents' actions in full, from the starts found
-    uint32_t rec = 0;
-    if (active) {
-      const int pos = (int)sp;
-      uint32_t has = sh, buf = su;
-      int q_new = -1;
-      uint64_t f[5];
-#pragma unroll
-      for (int j = 0; j < 5; ++j) { const int p = pos + j; f[j] = win[p < GW_OUT ? p : GW_OUT - 1]; }
-      int i = 0; uint32_t n32 = 0; bool hard = false;
-      auto fetch = [&]() { uint64_t v = f[0]; if (i == 1) v = f[1]; if (i == 2) v = f[2]; if (i == 3) v = f[3]; if (i >= 4) v = f[4]; ++i; return v; };
-      auto take32 = [&]() { ++n32; if (has) { has = 0; return buf; } const uint64_t o = fetch(); buf = (uint32_t)(o >> 32); q_new = pos + i - 1; has = 1; return (uint32_t)o; };
-      auto below = [&](uint32_t n) { if (n <= 1) return 0u; const uint64_t m = (uint64_t)take32() * n; if ((uint32_t)m < n) hard = true; return (uint32_t)(m >> 32); };
-      uint32_t r = GR_VALID;
-      if (my_act == 0) {       // green_access_service
-        const int c = (int)below((uint32_t)(pre >> 56));
-        int sn;
-        const int dest = green_as_dest(pre, c, &sn);
-        const uint32_t p = below(EPH_RANGE);
-        r |= GR_EPH | ((uint32_t)dest << 8) | (p << 16);
-        if ((my_blk >> sn) & 1u) r |= GR_FAIL | GR_CONN;
-        else if ((fetch() >> 11) <= P01_FLOOR) r |= GR_CONN;
-      } else if (!lw_am) r |= GR_FAIL;   // green_local_work
-      else {
-        const int c = nth_bit(lw_am, (int)below((uint32_t)popc32(lw_am)));
-        const int rel = (int)((pre >> (8 * c)) & 0x7F) * 20;
-        if ((int)below(100) >= rel) r |= GR_FAIL;
-        else {
-          if ((fetch() >> 11) <= P01_FLOOR) { const uint32_t p = below(EPH_RANGE); r |= GR_EPH | GR_PROC | (gh << 8) | (p << 16); }
-          if ((fetch() >> 11) <= P01_FLOOR) r |= GR_PHISH;
-        }
-      }
-      // a Lemire re-draw, a window that may not cover this agent, or (never) a count that differs from the relaxation's
-      if (hard || pos + 5 > GW_OUT || ((uint32_t)i | (n32 << 16)) != d_cur || q_new != q_cur) r |= GR_HARD;
-      rec = r;
-    }
-    if (stuck) rec |= GR_HARD;
-    // where the batch ends: in front of the first agent the serial code has to resolve, behind the first phishing email
-    const int cnt = (ng - g0) < WAVE ? (ng - g0) : WAVE;
-    int kend = cnt;
-    enum { R_NEXT, R_HARD, R_PHISH } reason = R_NEXT;
-    const uint64_t m_hard = __ballot((rec & GR_HARD) != 0), m_phish = __ballot((rec & GR_PHISH) != 0);
-    if (m_hard) { const int k = __ffsll((unsigned long long)m_hard) - 1; if (k < kend) { kend = k; reason = R_HARD; } }
-    if (m_phish) { const int k = __ffsll((unsigned long long)m_phish) - 1; if (k < kend) { kend = k + 1; reason = R_PHISH; } }
-    const unsigned long long t1 = gstat ? clock64() : 0;
-    // (3) ports: one atomic test-and-set per agent; the first agent that finds its port taken ends the batch in front of it
-    const uint32_t eh = (rec >> 8) & 0xFFu, ep = (rec >> 16) & 0x3FFFu;
-    bool coll = false;
-    const bool has_port = lane < kend && (rec & GR_EPH);
-    if (has_port) coll = eph_test_and_set(x.c, (int)eh, ep);
-    const uint64_t cm = __ballot(coll);
-    if (cm) {
-      const int kc = __ffsll((unsigned long long)cm) - 1;
-      if (has_port && !coll && lane >= kc) __hip_atomic_fetch_and(&x.c->eph[eh][ep >> 5], ~(1u << (ep & 31)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-      kend = kc; reason = R_HARD;
-    }
-    if (lane < kend && (rec & GR_VALID)) {
-      if (rec & GR_CONN) ev_or(x, (int)eh, EV_CUR_CONN);
-      if (rec & GR_PROC) ev_or(x, (int)eh, EV_CUR_PROC);
-      if (rec & GR_FAIL) __hip_atomic_fetch_add(&s->brm, reward_table(s->phase, h_subnet((int)gh), my_act == 0 ? RW_ASF : RW_LWF), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-    }
-    // the stream behind the committed agents = where agent kend starts
-    int pos_e = 0; uint32_t has_e = has0, u_e = u0;
-    if (kend > 0) {
-      const uint32_t ie = rdlane(inc, kend - 1);
-      const int qe = (int)rdlane((uint32_t)qinc, kend - 1);
-      pos_e = (int)(ie & 0xFFFFu); has_e = (has0 + (ie >> 16)) & 1u;
-      if (qe >= 0) u_e = (uint32_t)(win[qe] >> 32);
-    }
-    uint64_t n_hi = s_hi, n_lo = s_lo;
-    if (pos_e > 0) {
-      const int j = (pos_e - 1) & 63;
-      n_hi = lane64(h0, j); n_lo = lane64(l0, j);
-      if (pos_e > WAVE) { n_hi = lane64(h1, j); n_lo = lane64(l1, j); }
-    }
-    const unsigned long long t2 = gstat ? clock64() : 0;
-    const int gend = g0 + kend;
-    if (lane == 0) {
-      rl.s_hi = n_hi; rl.s_lo = n_lo; rl.has32 = has_e; rl.u32 = u_e; rl.ndraw += (uint32_t)pos_e;
-      if (reason == R_PHISH) phishing(x, s->green_host[gend - 1]);
-      else if (reason == R_HARD) {
-        s->brm += step_green_exec(x, gend);
-        if (bit_get(x.w->phish_mask, gend)) { bit_clr(x.w->phish_mask, gend); phishing(x, s->green_host[gend]); }
-      }
-    }
-    if (gstat && lane == 0) {
-      gstat[0] += 1; gstat[1] += reason == R_PHISH; gstat[2] += m_hard != 0; gstat[3] += cm != 0;
-      gstat[4] += t1 - t0; gstat[5] += t2 - t1; gstat[6] += clock64() - t2; gstat[7] += rounds + 1;
-    }
-    g0 = reason == R_HARD ? gend + 1 : gend;
-  }
-}
-
-// One step of one episode of the numpy-stream mode on one wavefront: the body of k_step and of the persistent kernel k_run_pcg
-// (there a.rand_t / a.full_obs are the item's: set by the caller).
-// first / last: as in philox1_body -- inside a run of steps of one episode on one wave the agent part stays in LDS
-template <bool LOG>
-__device__ __forceinline__ void pcg_body(StepArgs a, const int e, const int lane, const bool first = true, const bool last = true) {
-  // numpy-PCG64 mode: one shared stream => the agent walk is strictly serial (lane 0); only the RNG-free parts
-  // (row staging, end-turn Monitor roll-over over the 137 hosts, observation encode) use the other lanes.
-  extern __shared__ uint4 lds[];
-  // one LDS area, two lives: the LCG window of the green actions (wave_green_exec), then -- from the end-turn roll-over on --
-  // the hosts' event bits (what the observation encode reads) and the encoded observation
-  __shared__ uint64_t win_lds[GW_OUT];
-  constexpr int OBS_LDS = (OBS_TOTAL + 2 + 7) & ~7;
-  static_assert(OBS_LDS <= (int)sizeof(uint64_t) * GW_OUT, "the byte copy of the observation fits the window area");
-  uint8_t* const obs_lds = reinterpret_cast<uint8_t*>(win_lds);
-  __shared__ int ok_lds;
-  __shared__ StepWork work;
-  EnvCold* const cold_e = cold_at(a.cold, (size_t)e, cold_row_bytes(a.steps));
-  unsigned long long t_begin = a.prof ? clock64() : 0;
-  const uint4* src = reinterpret_cast<const uint4*>(a.st + e);
-  if (first) stage_in<HOT_VEC>(lds, src, lane);
-  for (int i = lane; i < (int)(sizeof(StepWork) / 4); i += WAVE) reinterpret_cast<uint32_t*>(&work)[i] = 0;
-  __syncthreads();
-  EnvState* s = reinterpret_cast<EnvState*>(lds);   // only the part in front of EnvState.hd is valid here
-  HostDyn* const hd = a.st[e].hd;                   // the host table stays in HBM / L2
-  __shared__ unsigned long long prof_lds[16];   // phase counters accumulate in LDS, flushed once at the end
-  unsigned long long* prof = a.prof ? prof_lds : nullptr;
-  if (prof && lane < 16) prof_lds[lane] = 0;
-  // the shared numpy stream is walked on a register copy (this kernel serves the PCG mode only; mode pinned so the Philox
-  // paths fold away) and written back once, before the row leaves LDS
-  Rng rl = s->rng;
-  rl.mode = 0;
-  rl.pad = 0;
-  Ctx x{s, cold_e, &rl, hd, &work, lane == 0 ? prof : nullptr};
-  x.lg = (LOG && cold_e->evlog.enabled) ? &cold_e->evlog : nullptr;
-  const ExtAct* const xt = (LOG && a.ext) ? a.ext + (size_t)e * EXT_PER_ENV : nullptr;   // this episode's submitted red / green actions
-  x.ext = xt;
-  if (prof && lane == 0) prof[11] += clock64() - t_begin;
-  const bool do_reset = a.autoreset && s->done;
-  // The ordered walk is lane 0's; between its stretches the whole wave does what needs no order: the two draw-only phases
-  // (green policy draws, action-order shuffle) straight from the LCG's closed form, and the green actions' state reads.
-  // every lane evaluates the mission-phase check (four words of the row); the accumulators of the step were left initialised by
-  // step_end / the reset, so the blue submissions (lanes 1..5: in-kernel action draw, decode, queue) run beside lane 0's step_phase
-  const bool step_ok = !do_reset && step_phase_of(s->step_count, s->phase_len[0], s->phase_len[1], s->phase_len[2]) >= 0;
-  if (lane == 0) {
-    ok_lds = step_ok ? 1 : 0;
-    if (do_reset) {
-      env_reset(x, 0, 0, a.steps, true, a.policy, a.topo);   // new episode, same stream (CybORG.reset(seed=None)); this kernel serves the numpy-stream mode only
-    } else {
-      CC4_TICK0(x);
-      (void)step_phase(x, false);    // sets E_STEP_PAST_END when !step_ok
-      CC4_TICK(x, 0);
-      if (step_ok) rng_policy_swap(x, false);     // CybORG.set_seed split: the policies draw from the old stream (EnvCold.rng2)
-      if (step_ok && (s->policy & BP_RANDOM_BIT))   // built-in blue policy: its draws are the first of the step, in agent order
-        for (int b = 0; b < NBLUE; ++b) {
-          int32_t act = a.actions ? a.actions[e * NBLUE + b] : -1;
-          if (a.rand_out) { act = random_blue_action(a.rand_seed0, a.rand_t, e, b); a.rand_out[e * NBLUE + b] = act; }
-          step_blue_submit(x, b, act);
-        }
-    }
-  } else if (step_ok && lane <= NBLUE && !(s->policy & BP_RANDOM_BIT)) {
-    const int b = lane - 1;
-    int32_t act = a.actions ? a.actions[e * NBLUE + b] : -1;
-    if (a.rand_out) { act = random_blue_action(a.rand_seed0, a.rand_t, e, b); a.rand_out[e * NBLUE + b] = act; }
-    Ctx xb{s, cold_e, &rl, hd, &work};
-    step_blue_submit(xb, b, act);
-  }
-  __syncthreads();
-  if (ok_lds) {
-    bool drawn = false;
-    // (with submitted green actions in play the agents that have one do not draw: the walking lane asks them one by one)
-    if (!(s->policy & GP_SLEEP_BIT) && !xt) drawn = wave_green_policy(rl, s->n_green, work.green_act, lane);
-    // the observation half of the six red policies draws nothing and touches only its own agent: side by side on six lanes
-    if (lane < NRED) { Ctx xo{s, cold_e, &rl, hd, &work}; xo.ext = xt; step_red_observe(xo, lane); }
-    __syncthreads();
-    if (lane == 0) {
-      if (!drawn) for (int g = 0; g < s->n_green; ++g) step_green_policy(x, g);   // SleepAgent greens, or the 2^-32 re-draw case
-      CC4_TICK(x, 1);
-      for (int r = 0; r < NRED; ++r) s->n_actions -= step_red_policy_tick(x, r, (s->policy & 3) != RP_RANDOM);
-      rng_policy_swap(x, true);
-      CC4_TICK(x, 2);
-      for (int b = 0; b < NBLUE; ++b) step_tick_blue(x, b);
-      CC4_TICK(x, 3);
-    }
-    __syncthreads();
-    wave_shuffle_consume(rl, s->n_actions, lane);   // sort_action_order's shuffle (SC:398-464) only consumes the stream
-    if (lane == 0) { CC4_TICK(x, 4); step_blue_exec(x, true); }
-  }
-  __syncthreads();
-  if (ok_lds) {
-    // the green actions: across the wave (wave_green_exec)
-    if constexpr (!LOG) wave_green_exec(x, rl, win_lds, lane, a.prof ? a.prof + PROF_SLOTS * (size_t)e + 64 : nullptr);
-    else {
-      // with the event log on (log entries are ordered): on the walking lane; what the actions read from the state (service
-      // tables of their hosts -- HBM here --, allowed server counts) is prepared for all agents at once on the idle lanes
-      __shared__ uint64_t gpre_lds[MAXG];
-      for (int g = lane; g < s->n_green; g += WAVE) { const int act = work.green_act[g]; if (act < 2) gpre_lds[g] = green_prepare(x, g, act); }
-      __syncthreads();
-      if (lane == 0) {
-        Ctx xg = x; xg.gpre = gpre_lds;
-        for (int g = 0; g < s->n_green; ++g) {
-          s->brm += step_green_exec(xg, g);
-          if (bit_get(work.phish_mask, g)) { bit_clr(work.phish_mask, g); phishing(x, s->green_host[g]); }
-        }
-      }
-    }
-    if (lane == 0) {
-      CC4_TICK(x, 6);
-      step_red_exec(x);
-      step_reassign(x, red_foreign_agents(s));
-    }
-  }
-  __syncthreads();
-  if (ok_lds) {
-    // end-turn Monitor roll-over: the hosts' event bytes are part of the staged row (EnvState.hev)
-    for (int h = lane; h < MAXH; h += WAVE) s->hev[h] = monitor_roll(h, s->hev[h]);
-    if (lane == 0) step_monitor_pend(x);
-    __syncthreads();
-    {
-      // end-turn RedSessionCheck: it draws only when it has to promote a session to primary; when no agent needs that (the
-      // usual case) the six checks run side by side, else in order on the walking lane
-      const bool need = lane < NRED && rsc_draws(s, lane);
-      const bool serial = __ballot(need) != 0ull;
-      if (!serial && lane < NRED) { Ctx xc{s, cold_e, &rl, hd, &work, nullptr, nullptr, x.lg}; step_rsc(xc, lane); }
-      if (lane == 0) CC4_TICK(x, 9);
-      __syncthreads();
-      if (lane == 0) {
-        if (serial) for (int r = 0; r < NRED; ++r) step_rsc(x, r);
-        CC4_TICK(x, 10);
-        step_end(x, a.msgs ? a.msgs + e * NBLUE * MSG_LEN : nullptr);
-      }
-    }
-    __syncthreads();
-  }
-  if (lane == 0) { s->rng = rl; a.reward[e] = s->reward; a.done[e] = s->done; a.err[e] = s->err; }
-  unsigned long long t_obs = a.prof ? clock64() : 0;
-  {
-    // straight to HBM, kind-sorted (uniform branches); the output buffer persists between steps, so the values that only a
-    // Block/Allow or a new mission phase changes are written when that happened (EnvState.obs_dirty), after a reset, or when the
-    // caller asks -- as in the counter-mode kernels; the byte copy in LDS only feeds the packed exchange row
-    int32_t* o = a.obs + (size_t)e * OBS_TOTAL;
-    const bool pack = a.obs8 != nullptr;
-    const int nv = (do_reset || a.full_obs || pack || s->obs_dirty) ? OBS_TOTAL : OBS_FAST;
-    encode_obs_fast<WAVE>(s, o, obs_lds, pack, lane);
-    for (int v = OBS_FAST + lane; v < nv; v += WAVE) { int i; const int val = env_flat_obs_sorted(s, v, &i); o[i] = val; if (pack) obs_lds[i] = (uint8_t)val; }
-  }
-  __syncthreads();
-  unsigned long long t_out = a.prof ? clock64() : 0;
-  if (prof && lane == 0) prof[12] += t_out - t_obs;
-  uint4* dst = reinterpret_cast<uint4*>(a.st + e);
-  if (last) stage_out<HOT_VEC>(dst, lds, lane);
-  if (a.obs8) store_packed_row(a.obs8 + (size_t)e * OBS_PACKED, obs_lds, lane, WAVE);
-  if (prof && lane == 0) { prof[13] += clock64() - t_out; prof[14] += clock64() - t_begin; }
-  if (prof) { __syncthreads(); if (lane < 15) a.prof[PROF_SLOTS * (size_t)e + lane] += prof_lds[lane]; }
-}
-template <bool LOG>
-__global__ __launch_bounds__(WAVE) void k_step(StepArgs a) {
-  const int e = a.e0 + (int)blockIdx.x;
-  if (e >= a.n) return;
-  pcg_body<LOG>(a, e, (int)threadIdx.x);
-}
-
-// ---------------------------------------------------------------- Philox mode: wave- and lane-parallel step
-// Same phase bodies as the serial walk (cc4_engine.h P0..P9), different schedule.  One block of 4 wavefronts per episode:
-// every (agent, phase) owns a Philox counter stream, so heterogeneous agents can run concurrently.  Work that differs in
-// control flow goes to different WAVES (a wave executes divergent lanes one after the other): the 6 red FSM policies with
-// their queue ticks, the 5 blue actions (disjoint zones), the 6 red actions (those naming the same host are held back and
-// run in order on thread 0), the 6 RedSessionChecks (agent r -> wave r % 4, lane r / 4), and the two green action types
-// (AccessService / LocalWork lists built with LDS counters).  Work that is uniform goes to LANES: row staging, green agents
-// within a type, the 137 Monitor roll-overs, the observation encode (enumerated kind by kind).  Measured on MI355X (r01): 4 waves per
-// episode is the build; 5 and 6 (fewer red agents sharing a wave) run 25-30 % slower at 1024 episodes, DESIGN.md 7.
-// Cross-thread effects are event-bit ORs and the reward sum (LDS atomics); the rare order-dependent spawns (PhishingEmail,
-// cross-subnet session reassignment) are collected and replayed by thread 0 in agent order.
-#ifndef CC4_PW
-#define CC4_PW 4
-#endif
-constexpr int PW = CC4_PW;         // waves per episode block; red agent r runs on wave r % PW, lane r / PW
-static_assert(PW >= 4 && PW <= 8, "waves 0/1 run the two green action lists, waves PW-2 and PW-1 the green draws, wave PW-1 the blue submissions");
-constexpr int PT = PW * WAVE;      // threads per episode block (256)
-
-__device__ __forceinline__ void stage_in_n(uint4* __restrict__ lds, const uint4* __restrict__ src, int tid) {
-  constexpr int U = (ROW_VEC / PT) < 6 ? (ROW_VEC / PT) : 6;   // loads in flight per thread (the whole row in one or two rounds)
-  int i = tid;
-  for (; i + (U - 1) * PT < ROW_VEC; i += U * PT) {
-    uint4 v[U];
-#pragma unroll
-    for (int u = 0; u < U; ++u) v[u] = src[i + u * PT];
-#pragma unroll
-    for (int u = 0; u < U; ++u) lds[i + u * PT] = v[u];
-  }
-  for (; i < ROW_VEC; i += PT) lds[i] = src[i];
-}
-
-// The host table (EnvState.hd, two thirds of the row) is not read before the first action executes.  Its 16-byte vectors
-// go HBM -> LDS directly (global_load_lds_dwordx4: 1 KiB per wave-instruction, no staging registers) and stay in flight
-// while the rest of the row is staged through registers and the policy phase runs; `dma_wait` drains them before the
-// barrier that precedes the first action.  The instruction is issued from inline asm: the compiler would otherwise put a
-// vmcnt(0) in front of every LDS read that might alias the DMA destination, i.e. right away.
-constexpr int HD_V0 = (int)((offsetof(EnvState, hd) + 15) / 16);                             // first 16-byte vector fully inside hd
-constexpr int HD_CHUNKS = (int)(((offsetof(EnvState, hd) + sizeof(HostDyn) * MAXH) / 16 - HD_V0) / 64);   // whole 64-vector chunks
-constexpr int HD_V1 = HD_V0 + 64 * HD_CHUNKS;                                                // one past the DMA'd range
-__device__ __forceinline__ void dma_chunk(const uint4* gsrc_lane, uint4* lds_chunk_base) {
-  const uint32_t dst = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(__attribute__((address_space(3))) void*)lds_chunk_base);
-  uint32_t keep;
-  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
-               : "=&s"(keep) : "v"(gsrc_lane), "s"(dst) : "memory");
-}
-__device__ __forceinline__ void dma_wait() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
-
-// MINW = minimum waves per SIMD the register allocation must allow (= resident episode blocks per CU).  1 lets the compiler
-// take what it likes (86 VGPRs, 106 SGPRs: 5 blocks per CU) and is the fastest single block: the build for batches that fit
-// the chip in one round of <= 5 blocks per CU (the per-GPU share of an 8-GPU job).  7 (72 VGPRs, a dozen spills) and 8 (64
-// VGPRs, ~30 spills) keep more blocks resident: the builds for larger, throughput-bound batches.  cc4_create picks per batch
-// size.  Measured on MI355X (r02, M agent-env steps/s, MINW 1 / 7 / 8): 1536 episodes 185 / 229 / 215, 2048: 222 / 233 / 261
-// (exactly one round of 8), 3072: 253 / 295 / 281, 4096: 275 / 320 / 318, 8192: 320 / 393 / 389, 16384: 332 / 414 / 399;
-// 1024 episodes: 167 with MINW 1 vs 156 with 8.
-#ifndef CC4_PHILOX_BIG_MINW
-#define CC4_PHILOX_BIG_MINW 7
-#endif
-// one step of one episode on a block of four wavefronts: the body of k_step_philox and of its multi-step form k_run_philox
-// RUN (k_run_philox): the row stays in LDS from one step of the episode to the next -- run_flags bit 0: not the first step of the
-// launch (nothing is staged in), bit 1: the last one (the whole row goes back; before it, none of it)
-template <bool LOG, bool RUN = false>
-// obs_row (RUN with the exchange): a byte row of the caller's in LDS that receives all 578 observation values of the step -- the caller packs
-// and stores the exchange row from it behind its own end-of-step drain
-__device__ __forceinline__ void philox4_body(StepArgs a, const int run_flags = 0, const int tid_in = -1, uint8_t* const obs_row = nullptr) {
-  extern __shared__ uint4 lds[];
-  __shared__ int conflict_lds;
-  __shared__ alignas(16) uint32_t reset_ws[RESET_WS_WORDS];   // pid bitmaps of the scenario generation (autoreset); during a step: the green agents' pre-computed blocks
-  static_assert(RESET_WS_WORDS >= 4 * (MAXG + NRED + NBLUE), "one 16-byte block per green agent, red action stream and blue action stream");
-  __shared__ int glist_n[2][2];       // [action type][drawing wave]
-  __shared__ StepWork work;
-  __shared__ uint8_t obs_bytes_own[OBS_TOTAL + 2];   // byte-per-value copy of the observations, only for the packed exchange row
-  uint8_t* const obs_bytes = obs_row ? obs_row : obs_bytes_own;
-  __shared__ uint8_t glist[2][2][MAXG];  // green agents by action type (0 AccessService, 1 LocalWork) and drawing wave
-  __shared__ unsigned long long prof_lds[16];
-  const int e = a.e0 + (int)blockIdx.x, tid = tid_in >= 0 ? tid_in : (int)threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform by construction: kept in an SGPR
-  if (e >= a.n) return;
-  EnvCold* const cold_e = cold_at(a.cold, (size_t)e, cold_row_bytes(a.steps));
-  unsigned long long t_begin = a.prof ? clock64() : 0;
-  const uint4* src = reinterpret_cast<const uint4*>(a.st + e);
-  // the part outside the host table through registers (3 vectors per thread), then the host-table chunks by DMA
-  constexpr int NA = HD_V0 + ROW_VEC - HD_V1;   // indexed 0..NA-1: [0,HD_V0) then [HD_V1,ROW_VEC)
-  constexpr int NA_U = (NA + PT - 1) / PT;
-  if (!RUN || !(run_flags & 1)) {
-    {
-      uint4 va[NA_U];
-#pragma unroll
-      for (int u = 0; u < NA_U; ++u) { int k = tid + u * PT; k = k < NA ? k : NA - 1; int i = k < HD_V0 ? k : k - HD_V0 + HD_V1; va[u] = src[i]; }
-#pragma unroll
-      for (int u = 0; u < NA_U; ++u) { int k = tid + u * PT; int i = k < HD_V0 ? k : k - HD_V0 + HD_V1; if (k < NA) lds[i] = va[u]; }
-    }
-    for (int c = wave; c < HD_CHUNKS; c += PW) dma_chunk(src + HD_V0 + 64 * c + lane, lds + HD_V0 + 64 * c);
-  }
-  unsigned long long* prof = a.prof ? prof_lds : nullptr;
-  if (prof && tid < 16) prof_lds[tid] = 0;
-  if (tid < 4) (&glist_n[0][0])[tid] = 0;
-  if (tid == 0) conflict_lds = 0;
-  if (tid >= 64 && tid < 64 + 4 + NRED) (&work.phish_mask[0])[tid - 64] = 0;   // phish_mask[4] and pend_r[NRED] are adjacent
-  static_assert(offsetof(StepWork, pend_r) == offsetof(StepWork, phish_mask) + 16, "phish_mask and pend_r are cleared as one run of words");
-  if (tid >= 128 && tid < 128 + 5) work.hdirty[tid - 128] = 0;
-  __syncthreads();
-  EnvState* s = reinterpret_cast<EnvState*>(lds);
-  HostDyn* const hd = s->hd;
-  if (prof && tid == 0) prof[11] += clock64() - t_begin;
-  const bool do_reset = a.autoreset && s->done;
-  if (do_reset) {
-    dma_wait();
-    __syncthreads();
-    // new episode on the same key (CybORG.reset(seed=None)): the phases of env_reset_counter_mode, hosts on threads
-    reset_zero(s, hd, cold_e, tid, PT);
-    __syncthreads();
-    Rng rr; ResetCarry carry; carry.env_key = 0;     // thread 0: main reset stream in registers, across the phases
-    Ctx xm{s, cold_e, &rr, hd, &work};
-    if (tid == 0) { rr = s->rng; rr.mode = 1; carry = reset_topology(xm, 0, a.steps, true, a.policy, a.topo, reset_ws, true); }
-    __syncthreads();
-    Rng rh; rng_fork(&rh, &s->rng, ST_GEN_HOST); rh.mode = 1;
-    Ctx xh{s, cold_e, &rh, hd, &work};
-    if (tid < MAXH) reset_gen_host(xh, tid);
-    __syncthreads();
-    if (tid == 0) { reset_pid_serial(xm, reset_used_set(s)); reset_agents(xm); }      // pid uniqueness in the reference's order (one thread; once per episode)
-    __syncthreads();
-    reset_used_clear(s, tid, PT);
-    __syncthreads();
-    if (tid < MAXH) reset_host_sessions(xh, tid);
-    __syncthreads();
-    if (tid == 0) { reset_finish(xm, carry, a.steps, a.topo, true); a.reward[e] = s->reward; a.done[e] = s->done; }
-    __syncthreads();
-  } else {
-    // the mission phase of this step, evaluated by every thread (four words of the row); thread 0 alone stores what
-    // step_phase stores -- nothing the policy phase reads, and the step's accumulators were left initialised by step_end --
-    // so no barrier follows
-    const int st_now = s->step_count;
-    const bool step_ok = step_phase_of(st_now, s->phase_len[0], s->phase_len[1], s->phase_len[2]) >= 0;
-    if (tid == 0) {
-      Ctx x{s, cold_e, &s->rng, hd, &work, prof};
-      x.lg = (LOG && cold_e->evlog.enabled) ? &cold_e->evlog : nullptr;
-      x.ext = (LOG && a.ext) ? a.ext + (size_t)e * EXT_PER_ENV : nullptr;
-      CC4_TICK0(x);
-      (void)step_phase(x, false);
-    }
-    if (step_ok) {
-      Ctx x0p{s, cold_e, nullptr, hd, &work, tid == 0 ? prof : nullptr};
-      const int ng = s->n_green;
-      // one thread-private generator per thread, in registers: every use starts with rng_set_stream(), which fully
-      // determines the stream from (key, step, episode, stream id); mode pinned so the PCG paths fold away
-      if (tid == 0) CC4_TICK(x0p, 0);   // slot 0: step_phase
-      Rng rl;
-      rng_fork(&rl, &s->rng, ST_RESET);
-      rl.mode = 1;
-      rng_begin_step(&rl, (uint32_t)st_now);   // not read from the row: thread 0 may still be storing it there
-      EvLog* const lg = (LOG && cold_e->evlog.enabled) ? &cold_e->evlog : nullptr;
-      const ExtAct* const xt = (LOG && a.ext) ? a.ext + (size_t)e * EXT_PER_ENV : nullptr;   // this episode's submitted red / green actions
-      Ctx x0{s, cold_e, &rl, hd, &work, tid == 0 ? prof : nullptr};         // thread 0
-      x0.lg = lg; x0.ext = xt;
-#ifndef CC4_RED_WAVES
-#define CC4_RED_WAVES 2
-#endif
-      constexpr int RW = CC4_RED_WAVES;                                           // red agent r on wave r % RW, lane r / RW
-      const int ragent = lane * RW + wave;
-      const bool is_red = wave < RW && lane < (NRED + RW - 1) / RW && ragent < NRED;
-      unsigned long long* ap = (a.prof && is_red) ? a.prof + PROF_SLOTS * (size_t)e + 16 + 8 * ragent : nullptr;
-      // The red actions and the RedSessionChecks run in phases in which all four waves are free: agent r on wave r % 4, lane
-      // r / 4 (two waves carry two agents, two carry one).  Measured on MI355X (r03, three launches per step; M agent-env steps/s
-      // with the agents on 2 / 3 / 4 waves in these phases): 1024 episodes 177.4 / 179.3 / 180.8, 2048: 297.2 / 309.1 / 312.1,
-      // 4096: 440 / 444 / 443.  (The policy phase stays on two waves, three agents side by side: its other two waves carry the
-      // blue submissions and the green draws; all four there: 176.8 / 293.3 / 426.7.)
-#ifndef CC4_RED_WAVES_EXEC
-#define CC4_RED_WAVES_EXEC 4
-#endif
-      constexpr int RWX = CC4_RED_WAVES_EXEC;
-      const int xagent = lane * RWX + wave;
-      const bool is_redx = wave < RWX && lane < (NRED + RWX - 1) / RWX && xagent < NRED;
-      unsigned long long* apx = (a.prof && is_redx) ? a.prof + PROF_SLOTS * (size_t)e + 16 + 8 * xagent : nullptr;
-      Ctx xrx{s, cold_e, &rl, hd, &work, nullptr, apx, lg};
-      Ctx xr{s, cold_e, &rl, hd, &work, nullptr, ap, lg};
-      xrx.ext = xt; xr.ext = xt;
-      // ---- P0-P3a: every agent's policy / submission followed by its own duration-queue tick (SC:236-265), all on the
-      // agent's thread: red r on wave r%PW lane r/PW, blue on wave PW-1 lanes 2..6, green draws on lanes >= 8 of the waves
-      // that carry a single red agent.  A tick touches only its own agent (queue, observation reset, filter_actions
-      // against its own session table, which no other agent edits before the barrier below).
-
-      if (is_red) {
-        unsigned long long t0 = ap ? clock64() : 0;
-        const int dropped = step_red_policy_tick(xr, ragent);
-        if (ap) ap[0] += clock64() - t0;
-        if (dropped) atomicSub(&s->n_actions, 1);
-      }
-      else if (wave == PW - 1 && lane >= 2 && lane < 2 + NBLUE) {
-        const int b = lane - 2;
-        int32_t act = a.actions ? a.actions[e * NBLUE + b] : -1;
-        if (a.rand_out) { act = random_blue_action(a.rand_seed0, a.rand_t, e, b); a.rand_out[e * NBLUE + b] = act; }
-        step_blue_submit(x0, b, act);
-        step_tick_blue(x0, b);
-        step_messages(s, a.msgs ? a.msgs + e * NBLUE * MSG_LEN : nullptr, b);   // read back by this step's observation encode only
-        // block 0 of the agent's action stream, for the lane that will resolve the action
-        { uint32_t c[4]; rng_block(&rl, ST_BLUE_EXE + (uint32_t)b, 0, c); reinterpret_cast<uint4*>(reset_ws)[MAXG + NRED + b] = make_uint4(c[0], c[1], c[2], c[3]); }
-      }
-      else if (wave == PW - 2 && lane >= 1 && lane <= NRED) {   // block 0 of the six red action streams, side by side on idle lanes of a wave with slack
-        uint32_t c[4]; rng_block(&rl, ST_RED_EXE + (uint32_t)(lane - 1), 0, c); reinterpret_cast<uint4*>(reset_ws)[MAXG + lane - 1] = make_uint4(c[0], c[1], c[2], c[3]);
-      }
-      else if (lane >= 8 && wave >= PW - 2) {
-        static_assert((RW <= PW - 2 || RW >= NRED) && MAXG <= 2 * (WAVE - 8), "every green agent has its own lane (8..63) on one of the last two waves, which carry no red agent or one on lane 0: one pass, one ballot per type");
-        const int gw = wave - (PW - 2);
-        const int g = gw * (WAVE - 8) + (lane - 8);
-        if (g < ng) {
-          Ctx xg{s, cold_e, &rl, hd, &work, nullptr, nullptr, lg};
-          xg.ext = xt;
-          step_green_policy(xg, g);
-          const int t = work.green_act[g];
-          // compaction by action type with a wavefront ballot + prefix count (agent order, no LDS atomics): each drawing wave
-          // fills its own sub-list; the resolving wave walks the two sub-lists one after the other
-          const unsigned long long m0 = __ballot(t == 0), m1 = __ballot(t == 1);
-          const unsigned long long below = (1ull << lane) - 1ull;
-          if (t < 2) {
-            const unsigned long long m = t == 0 ? m0 : m1;
-            glist[t][gw][__popcll(m & below)] = (uint8_t)g;
-            if ((m & below) == 0) glist_n[t][gw] = __popcll(m);      // the first lane of the type publishes the count
-            // the first block of the agent's action stream, computed here -- behind the red policies -- and handed to the
-            // lane that resolves the action (the generation work area is idle during a step)
-            uint32_t c[4];
-            rng_block(&rl, ST_GREEN_EXE + (uint32_t)g, 0, c);
-            reinterpret_cast<uint4*>(reset_ws)[g] = make_uint4(c[0], c[1], c[2], c[3]);
-          }
-        }
-      }
-      if (a.prof && lane == 63) a.prof[PROF_SLOTS * (size_t)e + 100 + wave] += clock64() - t_begin;   // debug: when each wave reaches the end of the policy phase
-      dma_wait();          // the host table has landed in LDS behind the policy phase
-      __syncthreads();
-      CC4_TICK(x0, 2);
-      // ---- P3b blue execution
-      if (blue_exec_independent(s)) {      // uniform: every thread reads the same five action types
-        if (tid == 0) CC4_TICK(x0, 3);
-#ifndef CC4_BLUE_WAVES
-#define CC4_BLUE_WAVES PW
-#endif
-        constexpr int BW = CC4_BLUE_WAVES;
-        const int bagent = lane * BW + wave;                                      // blue agent b on wave b % BW, lane b / BW
-        if (wave < BW && lane < (NBLUE + BW - 1) / BW && bagent < NBLUE) {
-          Ctx xb{s, cold_e, &rl, hd, &work, nullptr, nullptr, lg};
-          const uint4 blk = reinterpret_cast<const uint4*>(reset_ws)[MAXG + NRED + bagent];
-          const uint32_t pre[4] = {blk.x, blk.y, blk.z, blk.w};
-          const unsigned long long tb0 = a.prof ? clock64() : 0;
-          step_blue_exec_agent(xb, bagent, pre);
-          if (a.prof) { unsigned long long* tp = a.prof + PROF_SLOTS * (size_t)e + 108 + 2 * (s->bexec[bagent].type & 7); atomicAdd(tp, (unsigned long long)(clock64() - tb0)); atomicAdd(tp + 1, 1ull); }   // debug: blue action cycles by type
-        }
-        __syncthreads();
-        if (tid == 0) CC4_TICK(x0, 5);
-      } else {
-        if (tid == 0) step_blue_exec(x0);
-        __syncthreads();
-      }
-      // ---- P4 green actions: wave 0 = AccessService list, wave 1 = LocalWork list (uniform control flow per wave)
-      if (wave < 2) {
-        unsigned long long tg0 = a.prof ? clock64() : 0;
-        int pen = 0;
-        const int n0 = glist_n[wave][0], n1 = glist_n[wave][1];
-        for (int i = lane; i < n0 + n1; i += WAVE) {
-          int g = i < n0 ? glist[wave][0][i] : glist[wave][1][i - n0];
-          Ctx xg{s, cold_e, &rl, hd, &work, nullptr, nullptr, lg};
-          xg.ext = xt;
-          const uint4 blk = reinterpret_cast<const uint4*>(reset_ws)[g];
-          const uint32_t pre[4] = {blk.x, blk.y, blk.z, blk.w};
-          pen += step_green_exec(xg, g, pre);
-        }
-        if (pen) atomicAdd(&s->brm, pen);
-        if (a.prof && lane == 0) a.prof[PROF_SLOTS * (size_t)e + 96 + wave] += clock64() - tg0;   // debug: per-wave green action time
-      }
-      __syncthreads();
-      CC4_TICK(x0, 6);
-      // ---- P5 deferred phishing (ordered), then P6 red actions: one per wave when they name distinct hosts
-      if (tid == 0) { step_phishing(x0); CC4_TICK(x0, 1); rs_reserve(x0); conflict_lds = (int)red_conflict_mask(s); if (prof && conflict_lds) prof[4] += 1000000; }
-      __syncthreads();
-      const uint32_t serial_red = (uint32_t)conflict_lds;
-      if (is_redx && !((serial_red >> xagent) & 1u)) {
-        unsigned long long t0 = apx ? clock64() : 0;
-        const int ty = s->rexec[xagent].type;
-        { const uint4 blk = reinterpret_cast<const uint4*>(reset_ws)[MAXG + xagent]; const uint32_t pre[4] = {blk.x, blk.y, blk.z, blk.w}; step_red_exec_agent(xrx, xagent, pre); }
-        if (apx) { unsigned long long dt = clock64() - t0; apx[1] += dt; unsigned long long* tp = a.prof + PROF_SLOTS * (size_t)e + 64 + 2 * (ty & 15); atomicAdd(tp, dt); atomicAdd(tp + 1, 1ull); }
-      }
-      __syncthreads();
-      if (serial_red) {   // same-host actions (and everything when some agent withdraws): agent order on thread 0
-        if (tid == 0) for (int r = 0; r < NRED; ++r) if ((serial_red >> r) & 1u) step_red_exec_agent(x0, r);
-        __syncthreads();
-      }
-      // ---- pid-event merge and reassignment on thread 0 (the foreign-session test is 5 words per agent); meanwhile P7, the
-      // per-host roll-over of the end-turn Monitor, on all threads (host event flags: nothing the reassignment touches)
-      if (tid == 0) {
-        step_red_merge(x0);
-        CC4_TICK(x0, 7);
-        step_reassign(x0, red_foreign_agents(s));
-      }
-      for (int h = tid; h < MAXH; h += PT) step_monitor_host(x0, h);
-      __syncthreads();
-      CC4_TICK(x0, 9);
-      // ---- P8 end-turn RedSessionCheck (one red agent per wave), and on the last thread the Monitor's sus-pid hand-over and
-      // the step's bookkeeping: disjoint data (red agent tables / blue lists, counters, reward).  The observation encode below
-      // reads none of it, so there is no barrier in between.
-      if (is_redx) { unsigned long long t0 = apx ? clock64() : 0; step_rsc(xrx, xagent); if (apx) apx[2] += clock64() - t0; }
-      if (tid == PT - 1) {
-        Ctx xe{s, cold_e, &rl, hd, &work, nullptr, nullptr, lg};
-        xe.ext = xt;
-        step_monitor_pend(xe);
-        step_end(xe, nullptr, false);
-        a.reward[e] = s->reward; a.done[e] = s->done;
-      }
-      CC4_TICK(x0, 10);
-    } else { dma_wait(); if (tid == 0) { a.reward[e] = s->reward; a.done[e] = s->done; } }
-  }
-  unsigned long long t_obs = a.prof ? clock64() : 0;
-  // flat observations: one value per thread straight to HBM (int32 for the host API, bytes for the all-gather)
-  {
-    int32_t* o = a.obs + (size_t)e * OBS_TOTAL;
-    const bool pack = a.obs8 != nullptr || obs_row != nullptr;   // the exchange copy goes through a byte row in LDS and is packed after the barrier below
-    // the values that can change with every step (host events, messages) always; blocks, comms policy, subnet one-hots and phase
-    // words only when the step changed them (EnvState.obs_dirty), after a reset, or when the caller asks (the buffer persists)
-    const int nv = (do_reset || a.full_obs || a.obs8 || s->obs_dirty) ? OBS_TOTAL : OBS_FAST;      // (a caller's obs_row persists from step to step, like the int32 buffer: only what changed is rewritten)
-    encode_obs_fast<PT>(s, o, obs_bytes, pack, tid);
-    for (int v = OBS_FAST + tid; v < nv; v += PT) { int i; int val = env_flat_obs_sorted(s, v, &i); o[i] = val; if (pack) obs_bytes[i] = (uint8_t)val; }   // kind-sorted enumeration: uniform branches per wave
-  }
-  __syncthreads();    // the row is final: RedSessionCheck and the step bookkeeping ran beside the encode
-  if (tid == 0) a.err[e] = s->err;
-  if (a.obs8) store_packed_row(a.obs8 + (size_t)e * OBS_PACKED, obs_bytes, tid, PT);
-  unsigned long long t_out = a.prof ? clock64() : 0;
-  if (prof && tid == 0) prof[12] += t_out - t_obs;
-  // write-back: the agent part always; of the host table (55 % of the row) only the rows this step wrote -- a HostDyn is exactly one
-  // 64-byte line, written here by four adjacent lanes, and a step touches a handful of the 137 (hd_touch; everything after a reset)
-  uint4* dst = reinterpret_cast<uint4*>(a.st + e);
-  static_assert(sizeof(HostDyn) == 64 && offsetof(EnvState, hd) % 64 == 0 && HOT_VEC + 4 * MAXH == ROW_VEC, "one line per host row, the table closes the row");
-  if (RUN) {
-    if (run_flags & 2) for (int i = tid; i < ROW_VEC; i += PT) dst[i] = lds[i];     // the launch's last step of the episode: the whole row
-  } else {
-    for (int i = tid; i < HOT_VEC; i += PT) dst[i] = lds[i];
-    if (do_reset) { for (int i = HOT_VEC + tid; i < ROW_VEC; i += PT) dst[i] = lds[i]; }
-    else for (int k = tid; k < 4 * MAXH; k += PT) if ((work.hdirty[k >> 7] >> ((k >> 2) & 31)) & 1u) dst[HOT_VEC + k] = lds[HOT_VEC + k];
-  }
-  if (prof && tid == 0) { prof[13] += clock64() - t_out; prof[14] += clock64() - t_begin; }
-  if (prof) { __syncthreads(); if (tid < 15) a.prof[PROF_SLOTS * (size_t)e + tid] += prof_lds[tid]; }
-}
-
-template <bool LOG, int MINW>
-__global__ __launch_bounds__(PT, MINW) void k_step_philox(StepArgs a) { philox4_body<LOG>(a); }
-
-// The multi-step form for batches the chip holds at once (at most five episode blocks per CU: the per-GPU share of an 8-GPU job,
-// BASELINE configs[1]): ONE launch runs the K steps of cc4_run_random_steps, every block looping over the steps of ITS episode.
-// A launch per step lasts as long as its slowest episode (70.8k cycles against a mean of 41.5k at 1024 episodes,
-// profiles/r03_tail_whatif.txt) and the chip idles behind it; here an episode's next step starts the moment its last one ends --
-// episodes are independent, so nothing else orders them -- and the batch advances at the MEAN step time.  No ticket, no flag, no
-// cache maintenance: a block only ever reads what it wrote itself (its waves drain their stores, s_waitcnt vmcnt(0), and meet at
-// the block barrier before the next step stages the row in again; the CU's L1 is coherent for its own waves).  Blocks beyond the
-// chip's residency simply start when others have finished all their steps: correct at any batch size, worthwhile below it.
-// And the row never leaves the block: it is staged in before the first step and written back after the last (what a step writes
-// every time are its outputs: observations, reward, done, error word, the drawn actions).
-// The body is a real call: inlined into the step loop its loop-invariant values are hoisted and held across the whole step.
-// (register budget of five blocks per CU, stated for the callee as well: left to itself it takes 212 VGPRs)
-// (r04, end of round: the body INLINED -- with the thread id made opaque per step, so that nothing derived from it is hoisted out of the loop
-// and held across the whole step; ~90 VGPRs spill, and it is still 30 % faster than the call: a kernel that contains a call loses a quarter
-// of its rate, profiles/r04_compiler_flags_ab.txt, r04_multistep_inline_ab.txt.)
-template <int MINB>
-__device__ __forceinline__ void run_philox_loop(StepArgs a, int K, uint32_t t0, const XchgArgs x) {
-  a.prof = nullptr; a.obs8 = nullptr; a.ext = nullptr;
-  __shared__ uint8_t xrow[OBS_TOTAL + 2];      // the exchange: the step's observation values as bytes (LDS does not bound the four-wave kernels' residency)
-  const int full0 = a.full_obs;
-  uint32_t seen = 0;
-  for (int k = 0; k < K; ++k) {
-    a.rand_t = t0 + (uint32_t)k;
-    a.full_obs = k == 0 ? (full0 | (x.slab ? 1 : 0)) : 0;       // (the byte row starts empty: the launch's first step writes every value)
-    { int tid_i = (int)threadIdx.x; asm volatile("" : "+v"(tid_i));
-      philox4_body<false, true>(a, (k > 0 ? 1 : 0) | (k == K - 1 ? 2 : 0), tid_i, x.slab ? xrow : nullptr); }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (x.slab && threadIdx.x < WAVE) {
-      // As in the one-wave loops: the row of step k - 1 is in memory by now (this step's drain covered its store) and is counted; this step's
-      // row goes out from the byte row in LDS -- no global loads, nothing waited for (a system-scope store takes ~1.5 us to land: inside the
-      // drain it was 1.4 us of every step; read back from the int32 row, the loads were).  The slab must be free: its previous occupant, step
-      // k - ring, gathered -- checked here, by the one wave that writes it, not by the block at the top of the step.
-      const int e = a.e0 + (int)blockIdx.x;
-      if (threadIdx.x == 0) { if (k > 0) xchg_count(x, (uint32_t)(k - 1), e >> 5); xchg_wait_slab(x, (uint32_t)k, seen); }
-      store_packed_row(x.slab + ((size_t)(k % x.ring) * (size_t)a.n + (size_t)e) * OBS_PACKED, xrow, (int)threadIdx.x, WAVE);
-    }
-  }
-  if (x.slab && K > 0) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    if (threadIdx.x == 0) xchg_count(x, (uint32_t)(K - 1), (a.e0 + (int)blockIdx.x) >> 5);
-  }
-}
-__global__ __launch_bounds__(PT, 5) void k_run_philox(StepArgs a, int K, uint32_t t0, XchgArgs x) { run_philox_loop<5>(a, K, t0, x); }
-// the same with the register budget of eight blocks per CU: batches of up to 8 x CUs episodes (2048 on MI355X) resident at once
-__global__ __launch_bounds__(PT, 8) void k_run_philox8(StepArgs a, int K, uint32_t t0, XchgArgs x) { run_philox_loop<8>(a, K, t0, x); }
-// (a build with the budget of four blocks per CU -- 128 registers per lane, 1024 episodes on 256 CUs -- is 0.7 % faster than the one of five: not kept)
-
-// ---------------------------------------------------------------- Philox mode, one wavefront per episode
-// The same step as k_step_philox with the agents on the LANES of a single wave instead of on four waves: red agent r on lane
-// r, blue agent b on lane 8 + b for its submission and on lane b for its action, green agent g on lane g % 64.  A block of
-// four waves spends most of its resident time with three waves parked at a barrier behind the one that carries the red
-// agents; with one wave per episode every resident wave works, and as a wave64 instruction occupies its SIMD for four
-// cycles whatever the number of active lanes, what counts at large batches is the number of instructions per episode, not
-// their spread over waves.  Like the numpy-stream kernel it stages only the agent part of the row (6 992 B) and leaves the
-// host table in HBM / L2, so 16 episodes are resident per CU (LDS) instead of 7-8.  The build for throughput-bound batches;
-// k_step_philox keeps the shorter single-launch latency of small ones (cc4_create picks; CC4_PHILOX_LEAN overrides).
-#ifndef CC4_LEAN_MINW
-#define CC4_LEAN_MINW 1
-#endif
-// ---- the persistent form of the same kernel (PERSIST): K steps of the whole batch in ONE launch.
-// A step-per-launch schedule ends every launch with a tail (its last blocks run on a half-empty chip) and starts the next with a
-// ramp; cutting the batch into four groups on four streams hides most of that, not all: 8192 episodes x 29.6 us of
-// dependent work per episode-step over 5120 resident waves would take 47.4 us per step, four launches take 53.4.  Here the grid is
-// one wave per residency slot, and every wave pulls (episode, step) items until the K steps of all episodes are done -- no launch
-// boundary inside, no tail but the last one.  Two things make that safe without any cache maintenance:
-//  * CU affinity.  A CU's vector L1 is never refreshed by another CU's stores, and the XCDs' L2s are not coherent with each other
-//    (MI355X_MICROARCH.md, "inter-workgroup visibility"): an episode's rows must therefore be touched by ONE CU for the whole
-//    launch.  The batch is cut into one partition per CU (episode e -> partition e % P, P = the CUs the device showed at first use);
-//    a wave reads its CU's identity from the hardware (HW_REG_XCC_ID, HW_REG_HW_ID: shader engine / array / CU), finds the CU's
-//    partition in the table of the device's CUs (RunArgs.slot_part) and claims it (owner[p]: compare-and-swap of the CU's slot id); only waves of the owning CU ever
-//    work on a partition.  Waves of one CU share its L1, which is coherent for them (what workgroup-scope ordering relies on), so
-//    the hand-over between two of them needs ordering only: the writer drains its stores (s_waitcnt vmcnt(0)) before it publishes.
-//  * Order per episode.  Items of a partition are handed out by a ticket counter in the order (step 0 of its episodes, step 1, ..):
-//    item (e, k) may start once progress[e] == k, which the wave that ran (e, k - 1) stores when its row is back in memory.  With
-//    32 episodes and 20 waves per CU the predecessor finished a dozen tickets ago; the wait is a single load, normally.
-// A CU that got no wave (never seen in practice: the grid fills every CU) leaves its partition unclaimed; waves that run out of
-// work adopt such a partition for THEIR CU (same claim), so every item is executed exactly once whatever the placement.
-struct RunArgs {
-  uint32_t* ticket;            // [P] next item of partition p
-  uint32_t* progress;          // [n] steps of this launch episode e has completed
-  int32_t* owner;              // [P] 0 = unclaimed, else 1 + slot id of the owning CU
-  const int32_t* slot_part;    // [CC4_SLOTS] CU slot id -> 1 + its partition, 0 = no such CU on this device (k_discover at first use: partitions in
-                               // slot order, so the CUs of an XCD own neighbouring partitions and their ticket / progress words share cache lines
-                               // only with each other -- handed out in arrival order they interleave the XCDs, and a 20-step call was 6 % slower)
-  int P, K;
-  int G;                       // the exchange counts episode e in group e % G (the gate kernel's groups: G = the CUs of the device in both schedules)
-  uint32_t t0;                 // action time of step 0 (random_blue_action)
-  unsigned long long* timeline; // debug (CC4_PERSIST_TIMELINE=1): per wave [entry, first item start, last item end, items] in wall_clock64 ticks, or null
-  int order;                   // memory ordering of the hand-over between two items of an episode (CC4_PERSIST_ORDER, persist_loop):
-                               // 0 = ordering only (same CU: the waves of a CU share its L1), 1 = every item starts with an agent-scope acquire,
-                               // 2 = ... and ends with an agent-scope release, 3 = every item starts with an L1 invalidate (buffer_inv sc0)
-  // ---- XCD pools (r06; `pool` != 0): the batch is cut into one partition per XCD (episode e -> pool e % P, P = the XCDs the device showed), every
-  // wave of an XCD pulls from its XCD's ticket counter, and every item starts with an invalidate of the CU's vector L1 (buffer_inv sc0: the
-  // XCD's L2 is the coherence point of its CUs and the L1 is write-through, so a drained store of ANY CU of the XCD is visible behind it).
-  // No owner table, no claim, no stealing: a CU never runs dry while its XCD has an item, so the launch's tail is one item long instead of
-  // the lag of the slowest CU's partition.  ticket = this call's counters ([P] words, TK_STRIDE apart), ticket_next = the other parity's
-  // (every wave zeroes its pool's word there: the next call needs no memset); progress[] counts steps since the handle's last reset of it
-  // (`base` = the count every episode stands at when the call starts).
-  // ---- runs of steps (r06).  An item is a RUN of consecutive steps of one episode: nA runs of SA steps, then nB of SB, then single steps
-  // (nph runs in all, K steps).  Inside a run the agent part stays in LDS -- no write-back and re-stage between the steps, one ticket, one
-  // progress wait and one store drain per run instead of per step; the short runs at the end keep the launch's tail one step long.
-  int SA, nA, SB, nB, nph;
-  int pool;                    // schedule: 0 = per-CU partitions, a tail shared inside the XCD (r04 / r05); 1 = XCD pools (experiment);
-                               // 2 = per-CU partitions BALANCED inside the XCD while the call runs (r06, below)
-  uint32_t base;
-  uint32_t* ticket_next;
-  uint8_t xcc_pool[8];         // XCC id -> pool, 0xFF: no such XCD
-  // ---- schedule 2: balanced partitions.  Partitions are per CU as in schedule 0 (an episode normally stays on ONE CU, whose waves share
-  // its write-through L1: no cache maintenance), but a wave looks at the ticket counters of its XCD's partitions before every run and, when
-  // its own partition is more than `thr` tickets AHEAD of the one that lags most -- or handed out --, takes its run from that one.  The
-  // partitions of an XCD so finish within a run of each other, instead of the slowest CU's lag building up to the call's end where
-  // helpers can only wait in its episodes' chains.  An episode's progress word carries, beside the steps done, the id of the CU that ran
-  // its last run: a run on ANOTHER CU than that one starts with an agent-scope acquire (buffer_inv sc1: tools/micro/l1_inv_scope.hip --
-  // nothing less drops a CU's stale L1 lines; profiles/r06_l1_inv_scope.txt), a run on the same CU with none.
-  uint8_t xcc_lo[8], xcc_n[8]; // XCC id -> first partition / number of partitions of that XCD (partitions are numbered in slot order)
-  int thr;
-  // ---- rollouts with the policy in the loop (r06; cc4_rollout_begin): the blue actions of step j are written, while this launch runs, by kernels of
-  // the caller's on the caller's stream -- one policy group of episodes at a time: group of e = (e / P) % PG, so every CU holds episodes of every
-  // group and works on one group while another waits for its policy.  Step j of an episode of group g starts once act_ready[g] > j (published by
-  // the caller behind its policy kernels, cc4_rollout_publish); it reads slot j % 2 of `act` with system-scope loads, writes its packed
-  // observation row into slab j % ring with system-scope stores (XchgArgs.slab) and counts itself in cnt[(e % P) * PG + g][j % ring] once that
-  // row is in memory -- what the gate of the caller's next policy pass waits for (cc4_rollout_wait_obs).  Every step is an item of its own.
-  const uint32_t* act_ready;   // [PG][32 words] (a cache line per group), or null: no rollout
-  const int32_t* act;          // [2][n][5]
-  int PG;
-  long long act_wait_ticks;    // watchdog: a step that waits longer for its actions gives up, raises XchgArgs.timeout, and every later wait returns at once
-};
-// lane 0: the actions of step j for policy group g are published.  Polls a device word at a growing interval (see xchg_wait_slab).
-__device__ __forceinline__ void rollout_wait_actions(const RunArgs& ra, const XchgArgs& x, int g, uint32_t j) {
-  const uint32_t* w = ra.act_ready + (size_t)g * 32;
-  if (__hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) > j) return;
-  if (__hip_atomic_load(x.timeout, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM)) return;
-  const long long w0 = wall_clock64();
-  int naps = 1;
-  while (__hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) <= j) {
-    for (int i = 0; i < naps; ++i) __builtin_amdgcn_s_sleep(64);
-    if (naps < 8) naps <<= 1;
-    if (wall_clock64() - w0 > ra.act_wait_ticks || __hip_atomic_load(x.timeout, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM)) {
-      __hip_atomic_store(x.timeout, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-      __hip_atomic_store(x.timeout_host, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-      return;
-    }
-  }
-}
-constexpr uint32_t PG_STEPS = 0x7FFFFFu;   // progress word (schedule 2): steps in bits 0..22, 1 + the last runner's partition in bits 23..31 (0: none yet)
-__device__ __forceinline__ void run_span(const RunArgs& ra, int j, int& k0, int& len) {
-  if (j < ra.nA) { k0 = j * ra.SA; len = ra.SA; }
-  else if (j < ra.nA + ra.nB) { k0 = ra.nA * ra.SA + (j - ra.nA) * ra.SB; len = ra.SB; }
-  else { k0 = ra.nA * ra.SA + ra.nB * ra.SB + (j - ra.nA - ra.nB); len = 1; }
-}
-constexpr int TK_STRIDE = 32;  // words between two pools' ticket counters (a cache line of their own each)
-constexpr int CC4_SLOTS = 2048;    // (XCC id << 8) | HW_ID[15:8]
-__device__ __forceinline__ int cu_slot() {
-  const uint32_t hw = __builtin_amdgcn_s_getreg(((16 - 1) << 11) | (0 << 6) | 4);     // HW_REG_HW_ID bits 15:0: wave, simd, pipe | cu, sh, se
-  const uint32_t xcc = __builtin_amdgcn_s_getreg(((4 - 1) << 11) | (0 << 6) | 20);    // HW_REG_XCC_ID bits 3:0
-  return (int)(((xcc & 7u) << 8) | ((hw >> 8) & 0xFFu));
-}
-// which compute units does this device have?  Many small waves without LDS, each reporting the CU it landed on and idling long enough for
-// the grid to spread over the whole chip.  (Not a census of how many waves of the REAL kernel a CU takes: LDS is allocated in 1280-byte
-// granules, a proxy with another footprint lands differently -- r05 -- and the schedule does not need to know.)
-__global__ __launch_bounds__(WAVE) void k_discover(int32_t* count, long long ticks) {
-  if (threadIdx.x == 0) {
-    atomicAdd(&count[cu_slot()], 1);
-    const long long t0 = wall_clock64();
-    while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(32);
-  }
-}
-
-// the one-wave kernel's in-kernel scenario generation (an episode regenerates once in steps-per-episode launches)
-#if defined(CC4_EXP_RESET_CALL)
-__device__ __attribute__((noinline))
-#else
-__device__ __forceinline__
-#endif
-void philox1_autoreset(const StepArgs& a, const int e, const int lane, EnvState* s, HostDyn* const hd, EnvCold* const cold_e, StepWork& work) {
-    // new episode on the same key (CybORG.reset(seed=None)): the phases of env_reset_counter_mode, hosts on lanes; the pid
-    // bitmaps of the generation live in HBM here (LDS bounds this kernel's residency, and this path runs once per episode)
-    uint32_t* const ws = a.reset_ws + (size_t)e * RESET_WS_WORDS;
-    reset_zero(s, hd, cold_e, lane, WAVE);
-    __syncthreads();
-    Rng rr; ResetCarry carry; carry.env_key = 0;     // lane 0: main reset stream in registers, across the phases
-    Ctx xm{s, cold_e, &rr, hd, &work};
-    if (lane == 0) { rr = s->rng; rr.mode = 1; carry = reset_topology(xm, 0, a.steps, true, a.policy, a.topo, ws, true); }
-    __syncthreads();
-    Rng rh; rng_fork(&rh, &s->rng, ST_GEN_HOST); rh.mode = 1;
-    Ctx xh{s, cold_e, &rh, hd, &work};
-    for (int h = lane; h < MAXH; h += WAVE) reset_gen_host(xh, h);
-    __syncthreads();
-    if (lane == 0) { reset_pid_serial(xm, reset_used_set(s)); reset_agents(xm); }     // pid uniqueness in the reference's order (one lane; once per episode)
-    __syncthreads();
-    reset_used_clear(s, lane, WAVE);
-    __syncthreads();
-    for (int h = lane; h < MAXH; h += WAVE) reset_host_sessions(xh, h);
-    __syncthreads();
-    if (lane == 0) { reset_finish(xm, carry, a.steps, a.topo, true); a.reward[e] = s->reward; a.done[e] = s->done; }
-    __syncthreads();
-}
-
-// One step of one episode on one wavefront: the body of k_step_philox1 and of the persistent run kernel.  PERSIST: item_k = the
-// step's number within the launch (the first item of an episode rewrites all its observation values when asked to).
-// first / last (the one-launch loops): the step is the first / last of a run of consecutive steps of this episode on this wave -- only the
-// first stages the agent part in, only the last writes it back; in between the row lives in LDS (the host table, the cold row and the outputs
-// are read and written in memory by every step as always).
-template <bool LOG, bool PERSIST>
-__device__ __forceinline__ void philox1_body(StepArgs a, const int e, const uint32_t rand_t, const uint32_t item_k, const int lane,
-                                             const bool first = true, const bool last = true) {
-  extern __shared__ uint4 lds[];
-  // Static LDS is kept under 512 bytes: agent part (7168 B) + statics then fit SIX 1280-byte LDS granules, 21 waves per CU by LDS and 20
-  // by registers; a seventh granule would leave 18 (profiles/r05_lds_residency.txt: the occupancy query, which divides 160 KB by the
-  // byte count, says 20 either way).  So: no byte copy of the observations for the packed exchange row (pack_row_from_obs reads the
-  // int32 row back), and the debug phase timers exist in the full build only (cc4_debug_profile selects it).
-  __shared__ StepWork work;
-  __shared__ int conflict_lds;
-  __shared__ unsigned long long prof_lds[LOG ? 16 : 1];
-  if constexpr (!LOG) a.prof = nullptr;
-  (void)item_k;
-  EnvCold* const cold_e = cold_at(a.cold, (size_t)e, cold_row_bytes(a.steps));
-  unsigned long long t_begin = a.prof ? clock64() : 0;
-  const uint4* src = reinterpret_cast<const uint4*>(a.st + e);
-  if (first) stage_in<HOT_VEC>(lds, src, lane);
-  for (int i = lane; i < (int)(sizeof(StepWork) / 4); i += WAVE) reinterpret_cast<uint32_t*>(&work)[i] = 0;
-  unsigned long long* prof = a.prof ? prof_lds : nullptr;
-  if (prof && lane < 16) prof_lds[lane] = 0;
-  if (lane == 0) conflict_lds = 0;
-  __syncthreads();
-  EnvState* s = reinterpret_cast<EnvState*>(lds);   // only the part in front of EnvState.hd is valid here
-  HostDyn* const hd = a.st[e].hd;                   // the host table stays in HBM / L2
-  if (prof && lane == 0) prof[11] += clock64() - t_begin;
-  const bool do_reset = a.autoreset && s->done;
-  if (do_reset) {
-    philox1_autoreset(a, e, lane, s, hd, cold_e, work);
-  } else {
-    const int st_now = s->step_count;
-    const bool step_ok = step_phase_of(st_now, s->phase_len[0], s->phase_len[1], s->phase_len[2]) >= 0;
-    if (lane == 0) {
-      Ctx x{s, cold_e, &s->rng, hd, &work, prof};
-      x.lg = (LOG && cold_e->evlog.enabled) ? &cold_e->evlog : nullptr;
-      x.ext = (LOG && a.ext) ? a.ext + (size_t)e * EXT_PER_ENV : nullptr;
-      CC4_TICK0(x);
-      (void)step_phase(x, false);
-    }
-    if (step_ok) {
-      const int ng = s->n_green;
-      // one lane-private generator per lane, in registers: every use starts with rng_set_stream(); mode pinned so the PCG
-      // paths fold away
-      Rng rl;
-      rng_fork(&rl, &s->rng, ST_RESET);
-      rl.mode = 1;
-      rng_begin_step(&rl, (uint32_t)st_now);   // not read from the row: lane 0 may still be storing it there
-      EvLog* const lg = (LOG && cold_e->evlog.enabled) ? &cold_e->evlog : nullptr;
-      const ExtAct* const xt = (LOG && a.ext) ? a.ext + (size_t)e * EXT_PER_ENV : nullptr;   // this episode's submitted red / green actions
-      Ctx x0{s, cold_e, &rl, hd, &work, lane == 0 ? prof : nullptr};
-      x0.lg = lg; x0.ext = xt;
-      if (lane == 0) CC4_TICK(x0, 0);
-      // ---- the block bank.  A Philox block costs a wave the same ~110 vector instructions whether one lane needs it or
-      // sixty-four do, and block 0 of every stream of the step is known from (key, step, episode, stream id) alone.  The streams
-      // that have a lane of their own per agent (green policy of agents 0..63, the actions of the compacted green list) are
-      // computed where they are used, one pass each; the rest -- the policy draws of green agents 64.., the six red policies and
-      // actions, the five blue actions and, in the bench, the five in-kernel blue action draws: 38 requests, five sequential
-      // passes when each is computed by the lane that resolves its agent -- share ONE pass here, one request per lane, and reach
-      // their agents' lanes through ds_bpermute when their phase comes (bank_fetch; same words as computing them in place:
-      // rng_preload).
-      enum : int { BK_GPOL = 0, BK_GEXE = 16, BK_RPOL = 32, BK_REXE = 38, BK_BEXE = 44, BK_BRAND = 49, BK_END = 54 };
-      uint32_t bank[4];
-      {
-        uint32_t st = 0;
-        if (lane < BK_GEXE) st = ST_GREEN_POL + (uint32_t)(WAVE + lane - BK_GPOL);
-        else if (lane < BK_REXE) st = ST_RED_POL + (uint32_t)(lane - BK_RPOL);
-        else if (lane < BK_BEXE) st = ST_RED_EXE + (uint32_t)(lane - BK_REXE);
-        else if (lane < BK_BRAND) st = ST_BLUE_EXE + (uint32_t)(lane - BK_BEXE);
-        bank[0] = 0u; bank[1] = st; bank[2] = (uint32_t)rl.inc_lo; bank[3] = (uint32_t)rl.inc_hi;      // rng_block(&rl, st, 0, .)
-        uint32_t k0 = (uint32_t)rl.s_lo, k1 = (uint32_t)(rl.s_lo >> 32);
-        if (a.rand_out && lane >= BK_BRAND && lane < BK_END) {   // random_blue_action(seed0, t, e, b): another key and counter layout
-          const uint64_t key = a.rand_seed0 + (uint64_t)e;
-          bank[0] = rand_t; bank[1] = (uint32_t)(lane - BK_BRAND); bank[2] = 0xB10Eu; bank[3] = 0u; k0 = (uint32_t)key; k1 = (uint32_t)(key >> 32);
-        }
-        philox4x32_10(bank, k0, k1);
-      }
-      // the four words lane `lane + shift` holds, on every lane (call with all lanes active: an inactive source lane reads as 0)
-      auto bank_fetch = [&](int shift, uint32_t out[4]) {
-        const int addr = ((lane + shift) & (WAVE - 1)) << 2;
-#pragma unroll
-        for (int k = 0; k < 4; ++k) out[k] = (uint32_t)__builtin_amdgcn_ds_bpermute(addr, (int)bank[k]);
-      };
-      const bool is_red = lane < NRED;
-      unsigned long long* ap = (a.prof && is_red) ? a.prof + PROF_SLOTS * (size_t)e + 16 + 8 * lane : nullptr;
-      Ctx xr{s, cold_e, &rl, hd, &work, nullptr, ap, lg};
-      Ctx xg{s, cold_e, &rl, hd, &work, nullptr, nullptr, lg};
-      xr.ext = xt; xg.ext = xt;
-      // ---- P0-P3a: every agent's policy / submission and its own duration-queue tick (SC:236-265)
-      uint32_t pre_rp[4];
-      bank_fetch(BK_RPOL, pre_rp);                                               // red r (lane r) <- lane BK_RPOL + r
-      const uint32_t brand = (uint32_t)__builtin_amdgcn_ds_bpermute(((lane + BK_BRAND - 8) & (WAVE - 1)) << 2, (int)bank[0]);   // blue b (lane 8 + b) <- lane BK_BRAND + b
-      if (is_red) {
-        unsigned long long t0 = ap ? clock64() : 0;
-        const int dropped = step_red_policy_tick(xr, lane, false, pre_rp);
-        if (ap) ap[0] += clock64() - t0;
-        if (dropped) atomicSub(&s->n_actions, 1);
-      } else if (lane >= 8 && lane < 8 + NBLUE) {
-        const int b = lane - 8;
-        int32_t act = !a.actions ? -1 : a.act_sys ? __hip_atomic_load(a.actions + e * NBLUE + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) : a.actions[e * NBLUE + b];
-        if (a.rand_out) { act = (int32_t)(((uint64_t)brand * (uint32_t)(b == 4 ? ACT_LONG : ACT_SHORT)) >> 32); a.rand_out[e * NBLUE + b] = act; }   // == random_blue_action
-        step_blue_submit(xg, b, act);
-        step_tick_blue(xg, b);
-        step_messages(s, a.msgs ? a.msgs + e * NBLUE * MSG_LEN : nullptr, b);   // read back by this step's observation encode only
-      }
-      if (lane < ng) step_green_policy(xg, lane);                               // agents 0..63: their block is computed here, by all of them at once
-      if (lane + WAVE < ng) step_green_policy(xg, lane + WAVE, bank);            // agents 64..: from the bank (their lane's own request)
-      __syncthreads();
-      CC4_TICK(x0, 2);
-      // ---- P3b blue actions: side by side when they are independent (no Monitor, no pending pid events)
-      if (blue_exec_independent(s)) {
-        if (lane == 0) CC4_TICK(x0, 3);
-        uint32_t c[4];
-        bank_fetch(BK_BEXE, c);                                                   // blue b (lane b) <- lane BK_BEXE + b
-        if (lane < NBLUE) step_blue_exec_agent(xg, lane, c);
-        __syncthreads();
-        if (lane == 0) CC4_TICK(x0, 5);
-      } else {
-        if (lane == 0) step_blue_exec(x0);
-        __syncthreads();
-      }
-      // ---- P4 green actions, one agent per lane
-      {
-        // A third of the up to 80 agents sleeps, so the ones with an action nearly always fit the wave's 64 lanes: they are
-        // compacted (ballot + prefix count, agent order) into a list and resolved in ONE pass instead of two (the second of
-        // which had 16 lanes at most and cost the wave as much as the first).  Per-agent streams make the order immaterial.
-        int pen = 0;
-        const uint32_t act0 = lane < ng ? work.green_act[lane] : 2u, act1 = lane + WAVE < ng ? work.green_act[lane + WAVE] : 2u;
-        const unsigned long long m0 = __ballot(act0 < 2u), m1 = __ballot(act1 < 2u);
-        const unsigned long long lt = (1ull << lane) - 1ull;
-        const int n0 = __popcll(m0), nact = n0 + __popcll(m1);
-        uint8_t* const glist = reinterpret_cast<uint8_t*>(work.scratch);           // the ordered sections' scratch is idle in this phase
-        static_assert(sizeof(work.scratch) >= MAXG, "the green list fits the scratch words");
-        if (act0 < 2u) glist[__popcll(m0 & lt)] = (uint8_t)lane;
-        if (act1 < 2u) glist[n0 + __popcll(m1 & lt)] = (uint8_t)(lane + WAVE);
-        __syncthreads();
-        for (int i = lane; i < nact; i += WAVE) {
-          const int g = glist[i];
-          uint32_t c[4]; rng_block(&rl, ST_GREEN_EXE + (uint32_t)g, 0, c);        // ahead of the AccessService / LocalWork split: one block for all
-          pen += step_green_exec(xg, g, c);
-        }
-        if (pen) atomicAdd(&s->brm, pen);
-      }
-      __syncthreads();
-      CC4_TICK(x0, 6);
-      // ---- P5 deferred phishing (ordered), then P6 red actions: side by side when they name distinct hosts
-      if (lane == 0) { step_phishing(x0); CC4_TICK(x0, 1); rs_reserve(x0); conflict_lds = (int)red_conflict_mask(s); if (prof && conflict_lds) prof[4] += 1000000; }
-      __syncthreads();
-      const uint32_t serial_red = (uint32_t)conflict_lds;
-      uint32_t pre_re[4];
-      bank_fetch(BK_REXE, pre_re);                                                // red r (lane r) <- lane BK_REXE + r
-      if (is_red && !((serial_red >> lane) & 1u)) {
-        unsigned long long t0 = ap ? clock64() : 0;
-        step_red_exec_agent(xr, lane, pre_re);
-        if (ap) ap[1] += clock64() - t0;
-      }
-      __syncthreads();
-      if (serial_red) {   // same-host actions (and everything when some agent withdraws): agent order on lane 0
-        if (lane == 0) for (int r = 0; r < NRED; ++r) if ((serial_red >> r) & 1u) step_red_exec_agent(x0, r);
-        __syncthreads();
-      }
-      if (lane == 0) {
-        step_red_merge(x0);
-        CC4_TICK(x0, 7);
-        step_reassign(x0, red_foreign_agents(s));
-        CC4_TICK(x0, 8);
-      }
-      // P7 end-turn Monitor roll-over: the hosts' event bytes are part of the staged row (EnvState.hev).  (Lane 0's reassignment above
-      // moves sessions, not events.)
-      for (int h = lane; h < MAXH; h += WAVE) s->hev[h] = monitor_roll(h, s->hev[h]);
-      __syncthreads();
-      CC4_TICK(x0, 9);
-      // ---- P8 end-turn RedSessionCheck on the red lanes; the Monitor's sus-pid hand-over and the step's bookkeeping on the last
-      if (is_red) { unsigned long long t0 = ap ? clock64() : 0; step_rsc(xr, lane); if (ap) ap[2] += clock64() - t0; }
-      if (lane == WAVE - 1) {
-        step_monitor_pend(xg);
-        step_end(xg, nullptr, false);
-        a.reward[e] = s->reward; a.done[e] = s->done;
-      }
-      CC4_TICK(x0, 10);
-    } else if (lane == 0) { a.reward[e] = s->reward; a.done[e] = s->done; }
-  }
-  __syncthreads();
-  unsigned long long t_obs = a.prof ? clock64() : 0;
-  {
-    int32_t* o = a.obs + (size_t)e * OBS_TOTAL;
-    const int nv = (do_reset || (a.full_obs && (!PERSIST || item_k == 0)) || s->obs_dirty) ? OBS_TOTAL : OBS_FAST;
-    encode_obs_fast<WAVE>(s, o, nullptr, false, lane);
-    for (int v = OBS_FAST + lane; v < nv; v += WAVE) { int i; const int val = env_flat_obs_sorted(s, v, &i); o[i] = val; }
-  }
-  __syncthreads();
-  if (lane == 0) a.err[e] = s->err;
-  unsigned long long t_out = a.prof ? clock64() : 0;
-  if (prof && lane == 0) prof[12] += t_out - t_obs;
-  if (last) stage_out<HOT_VEC>(reinterpret_cast<uint4*>(a.st + e), lds, lane);
-  if (a.obs8) {     // the per-step launches' packed exchange row (the one-launch loops pack behind their own end-of-step drain instead)
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    pack_row_from_obs(a.obs8 + (size_t)e * OBS_PACKED, a.obs + (size_t)e * OBS_TOTAL, lane);
-  }
-  if (prof && lane == 0) { prof[13] += clock64() - t_out; prof[14] += clock64() - t_begin; }
-  if (prof) { __syncthreads(); if (lane < 15) a.prof[PROF_SLOTS * (size_t)e + lane] += prof_lds[lane]; }
-}
-
-template <bool LOG>
-__global__ __launch_bounds__(WAVE, CC4_LEAN_MINW) void k_step_philox1(StepArgs a) {
-  const int e = a.e0 + (int)blockIdx.x;
-  if (e >= a.n) return;
-  philox1_body<LOG, false>(a, e, a.rand_t, 0u, (int)threadIdx.x);
-}
-
-
-// Tail of a call: a CU whose own partition is handed out takes items from the partition of another CU OF ITS XCD that has the most left.
-// The XCD's L2 is the coherence point of its CUs (vector stores write through to it), but a CU's L1 is not refreshed by another CU's
-// stores -- so from the moment a partition is shared (bit 31 of its ticket counter, set by the first thief; every ticket handed out
-// afterwards carries it) every item of it starts with an agent-scope acquire (buffer_inv sc1: the CU's L1 dropped), on the owner's waves
-// and the thieves' alike.  Items handed out before the bit was set were all the owner's own and read what that CU wrote itself.
-// Never across XCDs: their L2s do not agree without a write-back.
-// ---- experiment: the red policy phase with the agents of G episodes side by side on ONE wave.  Lane 8 g + r runs
-// step_red_policy_tick of agent r of the wave's g-th episode -- what a group schedule would do in the phase that is 31 % of a step -- on the live
-// state of the batch (agent parts staged into LDS as in the step kernel, nothing written back).  G = 1 is today's lane layout.  cyc[block] = the
-// wave's cycles in the phase; the launch duration (events) / episodes = what the phase costs an episode at that grouping and residency.
-#ifdef CC4_POLICY_PROBE      // (a concluded experiment of r05: its four instantiations are not part of the product library)
-template <int G>
-__global__ __launch_bounds__(WAVE) void k_policy_probe(StepArgs a, unsigned long long* cyc) {
-  extern __shared__ uint4 lds[];
-  __shared__ StepWork work[G];
-  const int lane = (int)threadIdx.x, e0 = (int)blockIdx.x * G;
-  for (int g = 0; g < G; ++g) if (e0 + g < a.n) stage_in<HOT_VEC>(lds + g * HOT_VEC, reinterpret_cast<const uint4*>(a.st + e0 + g), lane);
-  for (int i = lane; i < (int)(G * sizeof(StepWork) / 4); i += WAVE) reinterpret_cast<uint32_t*>(&work[0])[i] = 0;
-  __syncthreads();
-  const int g = lane >> 3, r = lane & 7, e = e0 + g;
-  const unsigned long long t0 = clock64();
-  int dropped = 0;
-  if (g < G && r < NRED && e < a.n) {
-    EnvState* s = reinterpret_cast<EnvState*>(lds + g * HOT_VEC);
-    const int st_now = s->step_count;
-    if (!s->done && step_phase_of(st_now, s->phase_len[0], s->phase_len[1], s->phase_len[2]) >= 0) {
-      Rng rl;
-      rng_fork(&rl, &s->rng, ST_RESET);
-      rl.mode = 1;
-      rng_begin_step(&rl, (uint32_t)st_now);
-      uint32_t pre[4];
-      rng_block(&rl, ST_RED_POL + (uint32_t)r, 0, pre);
-      Ctx xr{s, cold_at(a.cold, (size_t)e, cold_row_bytes(a.steps)), &rl, a.st[e].hd, &work[g]};
-      dropped = step_red_policy_tick(xr, r, false, pre);
-    }
-  }
-  __syncthreads();
-  const unsigned long long t1 = clock64();
-  if (lane == 0) cyc[blockIdx.x] = t1 - t0;
-  if (dropped == 12345) cyc[0] = 0;      // (keeps the result alive)
-}
-#endif
-constexpr uint32_t TK_SHARED = 0x80000000u;
-// register budget of the persistent counter-mode kernel in waves per SIMD: 6 (80 VGPRs, eight spilled: 24 waves per CU -- by registers and,
-// since r06's 5952-byte agent part made a wave FIVE 1280-byte LDS granules, by LDS as well: 25) or 5 (93 VGPRs, nothing spilled: 20 per CU).
-// Measured, 8192 episodes, one box (profiles/r06_layout_ab.txt): K = 500: 989-990 vs 914-915 M, K = 20: 831-846 vs 797-807 M.  (r05, when LDS
-// capped a CU at 21 waves: 952 vs 939-948 M -- inside the box-to-box spread.)
-#ifndef CC4_PERSIST_MINW
-#define CC4_PERSIST_MINW 6
-#endif
-template <bool PCG>
-__device__ __forceinline__ void persist_loop(StepArgs a, RunArgs ra, const XchgArgs x) {
-  // (the item travels from lane 0 to the wave through v_readfirstlane, not through LDS)
-  const int lane = threadIdx.x;
-  const int my_slot = cu_slot();
-  // The CU's partition, from the table of the compute units this device showed at first use (a CU that is not in it only helps out)
-  int part = ra.pool ? -1 : ra.slot_part[my_slot] - 1;  // schedule 0 (lane 0's copy is the one that counts)
-  bool mine = false;                     // lane 0: this CU owns `part` (claimed or adopted)
-  bool stealing = false;                 // lane 0: `part` belongs to another CU of this XCD; its shared bit is set
-  a.prof = nullptr; a.obs8 = nullptr; a.ext = nullptr;
-  uint32_t seen_gathered = 0;
-  unsigned long long tl_first = 0, tl_last = 0, tl_items = 0;
-  const unsigned long long tl_entry = ra.timeline ? wall_clock64() : 0;
-  auto tl_flush = [&]() { if (ra.timeline && lane == 0) { unsigned long long* t = ra.timeline + 4 * (size_t)blockIdx.x; t[0] = tl_entry; t[1] = tl_first; t[2] = tl_last; t[3] = tl_items | ((unsigned long long)(my_slot + 1) << 32); } };
-  int pend_e = -1; uint32_t pend_k = 0;  // the exchange: the item whose packed row this wave stored last and has not counted yet (its store drains with the next item)
-  auto flush_pending = [&]() {
-    if (x.slab && pend_e >= 0) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); if (lane == 0) xchg_count(x, pend_k, pend_e % ra.G); pend_e = -1; }
-  };
-  const uint32_t my_xcc = __builtin_amdgcn_s_getreg(((4 - 1) << 11) | (0 << 6) | 20) & 7u;    // HW_REG_XCC_ID
-  const int xlo = ra.xcc_lo[my_xcc], xn = ra.xcc_n[my_xcc];     // schedule 2: this XCD's partitions
-  int own = -1; uint32_t my_id = 511u;                           // schedule 2: the CU's own partition (-1: none), its id in the progress words
-  if (ra.pool == 2) {
-    own = ra.slot_part[my_slot] - 1;
-    if (own >= 0) my_id = (uint32_t)own + 1u;
-    if (xn <= 0) { tl_flush(); return; }
-  }
-  if (ra.pool == 1) {
-    const uint32_t xcc = my_xcc;
-    part = ra.xcc_pool[xcc] == 0xFF ? -1 : (int)ra.xcc_pool[xcc];
-    if (part < 0) { tl_flush(); return; }                             // (an XCD the discovery pass did not see: its waves do nothing)
-    if (lane == 0) __hip_atomic_store(&ra.ticket_next[part * TK_STRIDE], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  }
-  for (;;) {
-    int res_e = -3, res_k = 0, res_sh = 0, res_part = -1;            // -3: nothing from `part`: search
-    if (ra.pool == 2) {
-      // all lanes: where the XCD's partitions stand
-      const int q = xlo + lane;
-      uint32_t tk = 0xFFFFFFFFu, tot_q = 0;
-      // (every partition's counter on a cache line of its own, TK_STRIDE words apart: 24 waves of one CU on a line, not the 768 of an XCD -- with the
-      // XCD's 32 counters on ONE line, its atomics and these loads took the L2 ~50 ns each and the schedule ran at 556 M instead of 884 M)
-      if (lane < xn) { tk = __hip_atomic_load(&ra.ticket[q * TK_STRIDE], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); tot_q = (uint32_t)(((a.n - q + ra.P - 1) / ra.P) * ra.nph); }
-      const bool has = lane < xn && tk < tot_q;
-      uint32_t key = has ? ((tk << 6) | (uint32_t)lane) : 0xFFFFFFFFu;          // least tickets handed out = lags most (the partitions' sizes differ by one episode at most)
-#pragma unroll
-      for (int off = 32; off >= 1; off >>= 1) { const uint32_t k2 = (uint32_t)__shfl_xor((int)key, off); key = k2 < key ? k2 : key; }
-      const uint32_t kmin = (uint32_t)__builtin_amdgcn_readfirstlane((int)key);
-      if (kmin == 0xFFFFFFFFu) { flush_pending(); tl_flush(); return; }        // every partition of this XCD is handed out
-      int target = (int)(kmin & 63u);
-      if (own >= 0) {
-        const int ol = own - xlo;
-        const uint32_t tk_own = (uint32_t)__builtin_amdgcn_readlane((int)tk, ol);
-        const uint32_t tot_own = (uint32_t)__builtin_amdgcn_readlane((int)tot_q, ol);
-        if (tk_own < tot_own && tk_own <= (kmin >> 6) + (uint32_t)ra.thr) target = ol;
-      }
-      if (lane == 0) {
-        const int tp = xlo + target;
-        const int ne = (a.n - tp + ra.P - 1) / ra.P;
-        const uint32_t t = __hip_atomic_fetch_add(&ra.ticket[tp * TK_STRIDE], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        res_e = -5;                                                   // handed out meanwhile: look again
-        // the partition's last ticket: its counter of the OTHER parity cleared for the next call (exactly one wave per partition and call
-        // draws it, whoever runs the partition -- no memset between calls)
-        if (t + 1u == (uint32_t)(ne * ra.nph)) __hip_atomic_store(&ra.ticket_next[tp * TK_STRIDE], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (t < (uint32_t)(ne * ra.nph)) {
-          const int j = (int)(t / (uint32_t)ne);
-          int i = (int)(t % (uint32_t)ne), pg = 0;
-          if (ra.act_ready) {
-            // a rollout: the tickets of a step serve one policy group after the other (episode index i of the partition is of group i % PG) --
-            // while one group's episodes wait for their policy pass, the CU's waves hold tickets of the other's
-            for (; pg < ra.PG; ++pg) { const int c = (ne - pg + ra.PG - 1) / ra.PG; if (i < c) { i = i * ra.PG + pg; break; } i -= c; }
-          }
-          const int ee = tp + i * ra.P;
-          int k, len; run_span(ra, j, k, len);
-          uint32_t w;
-          while ((((w = __hip_atomic_load(&ra.progress[ee], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) & PG_STEPS) - ra.base) < (uint32_t)k) __builtin_amdgcn_s_sleep(8);
-          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-          if (x.slab) xchg_wait_slab(x, (uint32_t)k, seen_gathered);
-          if (ra.act_ready) rollout_wait_actions(ra, x, pg, (uint32_t)k);
-          const uint32_t last = w >> 23;
-          res_e = ee; res_k = j; res_sh = (last != 0u && last != my_id) ? 1 : 0;     // the episode's last run was on another CU: its lines in this CU's L1 may be stale
-        }
-      }
-    } else if (ra.pool) {
-      if (lane == 0) {
-        const int ne = (a.n - part + ra.P - 1) / ra.P;                // episodes part, part + P, part + 2 P, ..
-        const uint32_t t = __hip_atomic_fetch_add(&ra.ticket[part * TK_STRIDE], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        res_e = -4;                                                   // the pool is handed out: leave
-        if (t < (uint32_t)(ne * ra.nph)) {
-          const int j = (int)(t / (uint32_t)ne), ee = part + (int)(t % (uint32_t)ne) * ra.P;
-          int k, len; run_span(ra, j, k, len);
-          while (__hip_atomic_load(&ra.progress[ee], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - ra.base < (uint32_t)k) __builtin_amdgcn_s_sleep(8);
-          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-          if (x.slab) xchg_wait_slab(x, (uint32_t)k, seen_gathered);
-          res_e = ee; res_k = j; res_sh = 2;
-        }
-      }
-    } else
-    if (lane == 0) {
-      if (part >= 0 && !mine && !stealing) {
-        int exp = 0;                                                  // the CU's own partition: claim it (or find it claimed by this CU already)
-        mine = __hip_atomic_compare_exchange_strong(&ra.owner[part], &exp, my_slot + 1, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) || exp == my_slot + 1;
-        if (!mine) part = -1;                                         // somebody else's by now (adopted): search
-      }
-      if (part >= 0) {
-        const bool thief = !mine;                                     // (a partition this wave steals from: `part` was set by the search below)
-        const int ne = (a.n - part + ra.P - 1) / ra.P;                // episodes part, part + P, part + 2 P, ..
-        const uint32_t tr = __hip_atomic_fetch_add(&ra.ticket[part], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const uint32_t t = tr & ~TK_SHARED;
-        if (t < (uint32_t)(ne * ra.nph)) {
-          // (r05, both measured and dropped: asking for the next ticket ahead of the previous item's drain -- the CU's other waves fill that gap
-          // already, 813-821 vs 819 M; and shares of the batch per XCD following the XCDs' measured speed -- which XCDs are slow changes from
-          // box to box and call to call, the controller chases noise: 20-step calls 812-822 -> 789-796 M.  profiles/r05_xcd_balance.txt)
-          // (a ready queue per partition -- a wave never holds an item whose predecessor is still running -- was built and measured in r05:
-          // bit-exact, 2-3.5 % slower, and the launch's tail stayed: profiles/r05_ready_queue_ab.txt)
-          const int j = (int)(t / (uint32_t)ne), ee = part + (int)(t % (uint32_t)ne) * ra.P;
-          int k, len; run_span(ra, j, k, len);
-          while (__hip_atomic_load(&ra.progress[ee], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - ra.base < (uint32_t)k) __builtin_amdgcn_s_sleep(8);
-          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");      // nothing the item reads may be read ahead of the flag (compiler and wave)
-          if (x.slab) xchg_wait_slab(x, (uint32_t)k, seen_gathered);   // the exchange: slab k % ring must have been gathered (tickets are step-major: normally long ago)
-          res_e = ee; res_k = j; res_sh = (thief || (tr & TK_SHARED)) ? 1 : 0;
-        }
-      }
-      res_part = part;
-    }
-    const int e = __builtin_amdgcn_readfirstlane(res_e);              // (all lanes are active here: the first active lane is lane 0)
-    if (e == -4) { flush_pending(); tl_flush(); return; }
-    if (e == -5) continue;
-    if (e == -3) {
-      // search (all lanes): the partition with the most items left among those nobody owns and those owned by a CU of this XCD
-      const int cur = __builtin_amdgcn_readfirstlane(res_part);
-      int best_rem = 0, best_q = -1, best_ow = 0;
-      for (int q0 = 0; q0 < ra.P; q0 += WAVE) {
-        const int q = q0 + lane;
-        if (q < ra.P && q != cur) {
-          const int ow = __hip_atomic_load(&ra.owner[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          if (ow == 0 || (((ow - 1) >> 8) == (my_slot >> 8))) {
-            const uint32_t t = __hip_atomic_load(&ra.ticket[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & ~TK_SHARED;
-            const uint32_t tot = (uint32_t)(((a.n - q + ra.P - 1) / ra.P) * ra.nph);
-            const int rem = t < tot ? (int)(tot - t) : 0;
-            if (rem > best_rem) { best_rem = rem; best_q = q; best_ow = ow; }
-          }
-        }
-      }
-#pragma unroll
-      for (int off = 32; off >= 1; off >>= 1) {
-        const int r2 = __shfl_xor(best_rem, off), q2 = __shfl_xor(best_q, off), o2 = __shfl_xor(best_ow, off);
-        if (r2 > best_rem || (r2 == best_rem && q2 > best_q)) { best_rem = r2; best_q = q2; best_ow = o2; }
-      }
-      best_rem = __builtin_amdgcn_readfirstlane(best_rem); best_q = __builtin_amdgcn_readfirstlane(best_q); best_ow = __builtin_amdgcn_readfirstlane(best_ow);
-      if (best_rem <= 0) { flush_pending(); tl_flush(); return; }     // nothing left anywhere this wave may touch
-      part = best_q; mine = false; stealing = false;
-      if (lane == 0) {
-        if (best_ow == 0) {                                           // nobody's: adopt it (the CAS in the item path), no sharing needed unless that fails
-          int exp = 0;
-          mine = __hip_atomic_compare_exchange_strong(&ra.owner[part], &exp, my_slot + 1, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) || exp == my_slot + 1;
-          if (!mine && (((exp - 1) >> 8) != (my_slot >> 8))) part = -1;   // claimed meanwhile by a CU of another XCD: not ours to touch
-        }
-        if (part >= 0 && !mine) { (void)__hip_atomic_fetch_or(&ra.ticket[part], TK_SHARED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); stealing = true; }
-      }
-      continue;
-    }
-    int run_k0, run_len;
-    run_span(ra, __builtin_amdgcn_readfirstlane(res_k), run_k0, run_len);
-    const int shared = __builtin_amdgcn_readfirstlane(res_sh);
-    if (ra.timeline && !tl_items) tl_first = wall_clock64();
-    if (shared || ra.order >= 1) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");      // (buffer_inv sc1: the CU's L1 dropped.  buffer_inv sc0 does NOT drop it: profiles/r06_l1_inv_scope.txt)
-    uint32_t item_k = (uint32_t)run_k0;
-    for (int q = 0; q < run_len; ++q, ++item_k) {
-    if (q > 0) {
-      if (x.slab) {
-        // a further step of the run with the exchange on: what the last step stored is drained and counted as at a run's end, and the slab of
-        // this step must have been gathered
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        if constexpr (PCG) { if (lane == 0) xchg_count(x, item_k - 1u, e % ra.G); }
-        else {
-          if (lane == 0 && pend_e >= 0) xchg_count(x, pend_k, pend_e % ra.G);
-          pack_row_from_obs(x.slab + ((size_t)((item_k - 1u) % (uint32_t)x.ring) * (size_t)a.n + (size_t)e) * OBS_PACKED, a.obs + (size_t)e * OBS_TOTAL, lane);
-          pend_e = e; pend_k = item_k - 1u;
-        }
-        if (lane == 0) xchg_wait_slab(x, item_k, seen_gathered);
-      }
-      __syncthreads();
-    }
-    int lane_i = (int)threadIdx.x;
-    asm volatile("" : "+v"(lane_i));
-    if (ra.act_ready) { a.actions = ra.act + (size_t)(item_k & 1u) * (size_t)a.n * NBLUE; a.rand_out = nullptr; a.act_sys = 1; }
-    if constexpr (PCG) {
-      StepArgs b = a;
-      b.rand_t = ra.t0 + item_k; b.full_obs = (a.full_obs && item_k == 0) ? 1 : 0;
-      if (x.slab) b.obs8 = x.slab + (size_t)(item_k % (uint32_t)x.ring) * (size_t)a.n * OBS_PACKED;
-      pcg_body<false>(b, e, lane_i, q == 0, q == run_len - 1);
-    } else {
-      philox1_body<false, true>(a, e, ra.t0 + item_k, item_k, lane_i, q == 0, q == run_len - 1);      // (a.obs8 is null: the packed row is written below, behind the drain)
-    }
-    }
-    --item_k;        // the run's last step
-    // the item is done when everything it wrote has left this wave: then the next step of the episode may start (on this XCD)
-    // Release: every lane DRAINS its own stores -- an explicit s_waitcnt vmcnt(0): the vector L1 is write-through, so a drained store is in
-    // the XCD's L2 --, the barrier collects the lanes, lane 0 publishes.  The consumer is a wave of the same CU unless the partition is
-    // shared, in which case it drops its L1 first (agent-scope acquire above).  The workgroup-scope fence beside it only pins the compiler:
-    // without tgsplit the backend emits NO vmcnt wait for it (waves of a work-group share a CU), and the episode's rows and its progress
-    // word sit in different L2 channels -- with the fence alone the word can land first.  (r05 ran that way for a day: one disagreement in
-    // ~60 self-checked calls, CC4_PERSIST_VERIFY, 5632 episodes, hot row of one episode after a 10-step call.)
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-    if (ra.order >= 2) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-    __syncthreads();
-    if (x.slab) {
-      if constexpr (PCG) {     // (the numpy-stream body stored the row itself, from its LDS byte row: drained by the fence above)
-        if (lane == 0) xchg_count(x, item_k, e % ra.G);
-      } else {
-        // the row this wave stored with its PREVIOUS item is in memory (this item's fence drained it): counted.  Then this episode's row of
-        // step item_k, read back from the int32 row before the episode's next step may touch it (the loads feed the store, the store is
-        // issued ahead of the progress word) -- not waited for: it drains with the wave's next item, or when the wave leaves.
-        if (lane == 0 && pend_e >= 0) xchg_count(x, pend_k, pend_e % ra.G);
-        pack_row_from_obs(x.slab + ((size_t)(item_k % (uint32_t)x.ring) * (size_t)a.n + (size_t)e) * OBS_PACKED, a.obs + (size_t)e * OBS_TOTAL, lane);
-        pend_e = e; pend_k = item_k;
-        if (ra.act_ready) {
-          // a rollout: the caller's next policy pass waits for this count -- not deferred to the wave's next item
-          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-          if (lane == 0) xchg_count(x, item_k, (e % ra.P) * ra.PG + (e / ra.P) % ra.PG);
-          pend_e = -1;
-        }
-      }
-    }
-    if (lane == 0) __hip_atomic_store(&ra.progress[e], (ra.base + item_k + 1u) | (ra.pool == 2 ? my_id << 23 : 0u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (ra.timeline) { tl_last = wall_clock64(); ++tl_items; }
-  }
-}
-__global__ __launch_bounds__(WAVE, CC4_PERSIST_MINW) void k_run_philox1(StepArgs a, RunArgs ra, XchgArgs x) { persist_loop<false>(a, ra, x); }
-#ifndef CC4_DEV_FAST
-// the same schedule around the numpy-stream step (k_step's body): the bit-exact mode's large batches
-__global__ __launch_bounds__(WAVE) void k_run_pcg(StepArgs a, RunArgs ra, XchgArgs x) { persist_loop<true>(a, ra, x); }
-#endif
-
-// The plain multi-step form of the one-wave kernel: one wave per episode, every wave loops over the K steps of ITS episode -- no
-// tickets, no affinity: a wave only reads what it wrote itself.  For batches one launch holds at once (cc4_create; CC4_RUN1=0/1
-// overrides): more waves than residency slots would simply start as slots free up (8192 episodes: 5120 at once, the other 3072
-// behind them on a chip that is no longer full).
-__global__ __launch_bounds__(WAVE, 5) void k_run_philox1m(StepArgs a, int K, uint32_t t0, XchgArgs x) {
-  a.prof = nullptr; a.obs8 = nullptr; a.ext = nullptr;
-  const int e = (int)blockIdx.x;
-  uint32_t seen = 0;
-  for (int k = 0; k < K; ++k) {
-    if (x.slab) {
-      if (threadIdx.x == 0) xchg_wait_slab(x, (uint32_t)k, seen);
-      __syncthreads();
-    }
-    int lane_i = (int)threadIdx.x;
-    asm volatile("" : "+v"(lane_i));
-    philox1_body<false, true>(a, e, t0 + (uint32_t)k, (uint32_t)k, lane_i, k == 0, k == K - 1);      // the agent part stays in LDS from the first step to the last
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (x.slab) {
-      // the row of step k - 1 is in memory by now (this step's drain covered its store): counted; then this step's row, not waited for
-      if (threadIdx.x == 0 && k > 0) xchg_count(x, (uint32_t)(k - 1), e >> 5);
-      pack_row_from_obs(x.slab + ((size_t)(k % x.ring) * (size_t)a.n + (size_t)e) * OBS_PACKED, a.obs + (size_t)e * OBS_TOTAL, (int)threadIdx.x);
-    }
-  }
-  if (x.slab && K > 0) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    if (threadIdx.x == 0) xchg_count(x, (uint32_t)(K - 1), e >> 5);
-  }
-}
-
-struct ResetArgs {
-  EnvState* st; EnvCold* cold; const uint64_t* seeds; const uint8_t* env_mask;
-  int32_t* obs; float* reward; uint8_t* done; uint32_t* err; uint8_t* mask;
-  int n, steps, rng_mode, policy;
-  uint32_t topo;
-  uint8_t* obs8;               // packed exchange row of the reset observations (multi-GPU), or null
-};
-__global__ __launch_bounds__(WAVE) void k_reset(ResetArgs a) {
-  __shared__ uint8_t obs_lds[OBS_TOTAL + 2];
-  __shared__ uint8_t mask_lds[MASK_TOTAL + 2];
-  __shared__ StepWork work;
-  const int e = blockIdx.x, lane = threadIdx.x;
-  if (e >= a.n) return;
-  if (a.env_mask && !a.env_mask[e]) return;
-  EnvCold* const cold_e = cold_at(a.cold, (size_t)e, cold_row_bytes(a.steps));
-  EnvState* s = a.st + e;
-  HostDyn* const hd = s->hd;
-  for (int i = lane; i < (int)(sizeof(StepWork) / 4); i += WAVE) reinterpret_cast<uint32_t*>(&work)[i] = 0;
-  __syncthreads();
-  if (a.rng_mode == 1) {   // counter-based mode: the phases of env_reset_counter_mode, hosts on lanes (the row stays in HBM here)
-    __shared__ uint32_t ws[RESET_WS_WORDS];
-    Ctx xm{s, cold_e, &s->rng, hd, &work};
-    ResetCarry carry; carry.env_key = 0;
-    reset_zero(s, hd, cold_e, lane, WAVE);
-    __syncthreads();
-    if (lane == 0) carry = reset_topology(xm, a.seeds ? a.seeds[e] : 0, a.steps, a.seeds == nullptr, a.policy, a.topo, ws, false);
-    __syncthreads();
-    Rng rh; rng_fork(&rh, &s->rng, ST_GEN_HOST); rh.mode = 1;
-    Ctx xh{s, cold_e, &rh, hd, &work};
-    for (int h = lane; h < MAXH; h += WAVE) reset_gen_host(xh, h);
-    __syncthreads();
-    if (lane == 0) { reset_pid_serial(xm, reset_used_set(s)); reset_agents(xm); }     // pid uniqueness in the reference's order (one lane; once per episode)
-    __syncthreads();
-    reset_used_clear(s, lane, WAVE);
-    __syncthreads();
-    for (int h = lane; h < MAXH; h += WAVE) reset_host_sessions(xh, h);
-    __syncthreads();
-    if (lane == 0) reset_finish(xm, carry, a.steps, a.topo, false);
-    __syncthreads();
-  } else if (lane == 0) {
-    Ctx x{s, cold_e, &s->rng, hd, &work};
-    env_reset(x, a.seeds ? a.seeds[e] : 0, 0, a.steps, a.seeds == nullptr, a.policy, a.topo);
-  }
-  if (lane == 0) {
-    env_flat_obs<uint8_t>(s, obs_lds);
-    blue_action_mask(s, mask_lds);
-    a.reward[e] = 0.f; a.done[e] = s->done; a.err[e] = s->err;
-  }
-  __syncthreads();
-  int32_t* o = a.obs + (size_t)e * OBS_TOTAL;
-  for (int i = lane; i < OBS_TOTAL; i += WAVE) o[i] = obs_lds[i];
-  uint8_t* m = a.mask + (size_t)e * MASK_TOTAL;
-  for (int i = lane; i < MASK_TOTAL; i += WAVE) m[i] = mask_lds[i];
-  if (a.obs8) store_packed_row(a.obs8 + (size_t)e * OBS_PACKED, obs_lds, lane, WAVE);
-}
-
-// uniform blue action indices over each agent's full range: Philox key (seed0, env),
-// counter (t, agent, 0xB10E, 0)
-__global__ void k_random_actions(int32_t* actions, int n, uint64_t seed0, uint32_t t, int e0 = 0) {      // episodes e0 .. n - 1
-  int i = e0 * NBLUE + blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n * NBLUE) return;
-  int e = i / NBLUE, b = i % NBLUE;
-  actions[i] = random_blue_action(seed0, t, e, b);
-}
-
-// debug: keeps a stream busy for about `cycles` clock ticks (cc4_debug_comm_delay_us: a slow exchange on demand)
-__global__ void k_spin(long long cycles) {
-  const long long t0 = wall_clock64();
-  while (wall_clock64() - t0 < cycles) __builtin_amdgcn_s_sleep(32);
-}
-
-// one block per gathered row: 148 packed bytes -> 578 byte values (thread j unpacks byte j into values 4j .. 4j+3)
-__global__ void k_unpack_obs(const uint8_t* __restrict__ packed, uint8_t* __restrict__ out, int rows) {
-  const int r = blockIdx.x, j = threadIdx.x;
-  if (r >= rows || j >= OBS_PACKED) return;
-  const uint32_t b = packed[(size_t)r * OBS_PACKED + j];
-  uint8_t* o = out + (size_t)r * OBS_TOTAL + 4 * j;
-#pragma unroll
-  for (int k = 0; k < 4; ++k) if (4 * j + k < OBS_TOTAL) o[k] = (uint8_t)((b >> (2 * k)) & 3u);
-}
-
-// CybORG.set_seed (env.py:316-325): a fresh generator for the controller, the state and the hosts; the agents' policies keep
-// the old one until the next reset (EnvCold.rng2); the episode itself stays as it is
-__global__ void k_set_seed(EnvState* st, EnvCold* cold, size_t cold_row, const uint64_t* seeds, int n, int rng_mode) {
-  int e = blockIdx.x * blockDim.x + threadIdx.x;
-  if (e >= n) return;
-  if (rng_mode == 0) {        // numpy stream: the agents' policies stay on the stream they were created with (see EnvCold.rng2)
-    if (!st[e].rng_split) cold_at(cold, (size_t)e, cold_row)->rng2 = st[e].rng;
-    st[e].rng_split = 1;
-  }
-  rng_seed(&st[e].rng, seeds[e], (uint32_t)rng_mode);
-  if (rng_mode == 1) { rng_begin_episode(&st[e].rng); rng_park(&st[e].rng); }   // counter mode: the words a reset leaves behind
-}
-
-// an externally built numpy Generator(PCG64) handed over as CybORG(seed=generator) (env.py:73-76): its bit-generator state
-// becomes the episode's stream (words per episode: state high, state low, increment high, increment low, has_uint32, uinteger)
-__global__ void k_set_rng_state(EnvState* st, const uint64_t* w, int n) {
-  int e = blockIdx.x * blockDim.x + threadIdx.x;
-  if (e >= n) return;
-  Rng r;
-  rng_seed(&r, 0, 0);
-  r.s_hi = w[6 * e]; r.s_lo = w[6 * e + 1]; r.inc_hi = w[6 * e + 2]; r.inc_lo = w[6 * e + 3];
-  r.has32 = (uint32_t)w[6 * e + 4]; r.u32 = (uint32_t)w[6 * e + 5];
-  st[e].rng = r;
-  st[e].rng_split = 0;
-}
-
-__global__ void k_rng_state(const EnvState* st, uint64_t* out, int n) {
-  int e = blockIdx.x * blockDim.x + threadIdx.x;
-  if (e >= n) return;
-  const Rng& r = st[e].rng;
-  uint64_t* o = out + 7 * (size_t)e;
-  o[0] = r.s_hi; o[1] = r.s_lo; o[2] = r.inc_hi; o[3] = r.inc_lo; o[4] = r.has32; o[5] = r.u32; o[6] = r.ndraw;
-}
-
-// ---------------------------------------------------------------- rollouts: the caller-side kernels (cc4_rollout_*)
-constexpr int RPG = 2;      // policy groups of a rollout: group of episode e = (e / P) % RPG
-// gate of a policy pass: returns when every episode of policy group g has its packed row of the step in slot `slot` in memory (the step kernel
-// counts them per partition, RunArgs.act_ready), and hands the counters back zeroed.  One wave, partitions on lanes; gives up after `ticks`.
-__global__ __launch_bounds__(WAVE) void k_rollout_gate(uint32_t* cnt, int P, int ring, int g, int slot, int n, long long ticks, uint32_t* fail) {
-  const long long t0 = wall_clock64();
-  for (int p = (int)threadIdx.x; p < P; p += (int)blockDim.x) {
-    const int ne = (n - p + P - 1) / P;                       // episodes p, p + P, ..: index i is of group i % RPG
-    const int want = (ne - g + RPG - 1) / RPG;
-    if (want <= 0) continue;
-    uint32_t* c = cnt + ((size_t)p * RPG + (size_t)g) * (size_t)ring + slot;
-    int naps = 1;
-    while (__hip_atomic_load(c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (uint32_t)want) {
-      for (int q = 0; q < naps; ++q) __builtin_amdgcn_s_sleep(32);
-      if (naps < 8) naps <<= 1;
-      if (wall_clock64() - t0 > ticks) { __hip_atomic_store(fail, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); break; }
-    }
-    __hip_atomic_store(c, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  }
-}
-// stand-in policies for one policy group (bench.py, tests): uniform random indices (the draws of k_random_actions), or indices computed FROM the
-// packed observations of the step before (a policy that ignores its input proves nothing about the hand-over)
-__global__ void k_rollout_random_policy(int32_t* act, int n, int P, int g, uint64_t seed0, uint32_t t) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n * NBLUE) return;
-  const int e = i / NBLUE, b = i % NBLUE;
-  if ((e / P) % RPG != g) return;
-  act[i] = random_blue_action(seed0, t, e, b);
-}
-__device__ __host__ inline uint32_t rollout_obs_hash(const uint32_t* row) {      // 37 words of a packed observation row
-  uint32_t hsh = 2166136261u;
-  for (int w = 0; w < OBS_PACKED / 4; ++w) { hsh ^= row[w]; hsh *= 16777619u; }
-  return hsh;
-}
-__global__ void k_rollout_hash_policy(int32_t* act, const uint8_t* packed, int n, int P, int g, uint32_t j) {
-  const int e = blockIdx.x * blockDim.x + threadIdx.x;
-  if (e >= n || (e / P) % RPG != g) return;
-  const uint32_t hsh = rollout_obs_hash(reinterpret_cast<const uint32_t*>(packed + (size_t)e * OBS_PACKED));
-  for (int b = 0; b < NBLUE; ++b) act[e * NBLUE + b] = (int32_t)((hsh + 2654435761u * (uint32_t)(b + 1) + 40503u * j) % (uint32_t)(b == 4 ? ACT_LONG : ACT_SHORT));
-}
-// the packed rows of the observations as they stand in the int32 buffer (what a rollout's first policy pass reads)
-__global__ __launch_bounds__(WAVE) void k_pack_obs_rows(uint8_t* packed, const int32_t* obs, int n) {
-  const int e = blockIdx.x;
-  if (e < n) pack_row_from_obs(packed + (size_t)e * OBS_PACKED, obs + (size_t)e * OBS_TOTAL, (int)threadIdx.x);
-}
-
-// ---------------------------------------------------------------- handle
-// CC4_PERSIST_VERIFY: a digest per episode of everything a call of cc4_run_random_steps leaves behind -- hot row, cold row, observations,
-// reward / done / error word, the drawn actions -- in three words (hot, cold, outputs), so that a mismatch says where
-__global__ __launch_bounds__(WAVE) void k_digest(const EnvState* st, const EnvCold* cold, size_t cold_row, const int32_t* obs, const float* reward,
-                                                 const uint8_t* done, const uint32_t* err, const int32_t* actions, uint64_t* out, int n) {
-  const int e = blockIdx.x, lane = threadIdx.x;
-  if (e >= n) return;
-  auto mix = [](uint64_t h, uint64_t v) { h ^= v + 0x9E3779B97F4A7C15ull + (h << 6) + (h >> 2); return h * 0xD6E8FEB86659FD93ull; };
-  auto hash_vecs = [&](const uint4* p, size_t nv) {
-    uint64_t h = 0x1234567ull + (uint64_t)lane;
-    for (size_t i = lane; i < nv; i += WAVE) { const uint4 v = p[i]; h = mix(h, ((uint64_t)v.x << 32) | v.y); h = mix(h, ((uint64_t)v.z << 32) | v.w); }
-    for (int off = 32; off >= 1; off >>= 1) h += __shfl_xor(h, off);     // order-independent across lanes, position-dependent within one
-    return h;
-  };
-  const uint64_t h_hot = hash_vecs(reinterpret_cast<const uint4*>(st + e), sizeof(EnvState) / 16);
-  const uint64_t h_cold = hash_vecs(reinterpret_cast<const uint4*>(cold_at(const_cast<EnvCold*>(cold), (size_t)e, cold_row)), cold_row / 16);
-  uint64_t h = 0x89ABCDEFull + (uint64_t)lane;
-  for (int i = lane; i < OBS_TOTAL; i += WAVE) h = mix(h, (uint64_t)(uint32_t)obs[(size_t)e * OBS_TOTAL + i]);
-  if (lane < NBLUE) h = mix(h, (uint64_t)(uint32_t)actions[e * NBLUE + lane]);
-  if (lane == 8) { h = mix(h, (uint64_t)__float_as_uint(reward[e])); h = mix(h, ((uint64_t)done[e] << 32) | err[e]); }
-  for (int off = 32; off >= 1; off >>= 1) h += __shfl_xor(h, off);
-  if (lane == 0) { out[3 * (size_t)e] = h_hot; out[3 * (size_t)e + 1] = h_cold; out[3 * (size_t)e + 2] = h; }
-}
+#include "cc4_kernel_decls.h"
 
 struct cc4_handle {
   cc4_config cfg;
@@ -2159,7 +160,6 @@ static thread_local std::string g_create_err;
 // already occupy the queues (a second handle next to a busy first one), keeps three launches per step.
 __attribute__((constructor)) static void cc4_runtime_env() { setenv("GPU_MAX_HW_QUEUES", "16", 0); }
 
-__global__ void k_spin(long long cycles);
 // 1 if kernels launched on the n given streams at the same time run side by side, 0 if some of them share a hardware queue and
 // run one after the other (or the probe failed).  ~1 ms.
 static int streams_run_concurrently(hipStream_t* st, int n) {
@@ -2224,7 +224,6 @@ static void configure_groups(cc4_handle* h, int ng) {
 
 // Every API call other than the step launches works on the main stream: order it behind whatever the group streams still
 // hold (device-side waits, no host synchronisation), and remember that the next step launches must be ordered behind it.
-extern "C" __global__ void k_set_evlog(EnvCold* cold, size_t row_bytes, int n, uint32_t on);
 static int join_groups(cc4_handle* h) {
   if (h->ngroups > 1) {
     if (h->groups_busy) {
@@ -2260,10 +259,6 @@ static void launch_range(cc4_handle* h, StepArgs a, int e0, int e1, hipStream_t 
   a.e0 = e0; a.n = e1;
   const size_t lds1 = offsetof(EnvState, hd);     // one-wave kernels: the agent part
   const dim3 grid(a.n - a.e0);
-#ifdef CC4_DEV_FAST     // kernel experiments (tools/ab/ab.sh): only the one-wave counter-mode kernel is instantiated -- a quarter of the compile time
-  if (h->philox_lean) hipExtLaunchKernelGGL(k_step_philox1<false>, grid, dim3(WAVE), lds1, st, start, stop, 0, a);
-  else hipExtLaunchKernelGGL((k_step_philox<false, 1>), grid, dim3(PT), sizeof(EnvState), st, start, stop, 0, a);
-#else
   if (h->cfg.rng_mode == 1) {
     if (h->philox_lean) {
       if (full || h->d_prof) hipExtLaunchKernelGGL(k_step_philox1<true>, grid, dim3(WAVE), lds1, st, start, stop, 0, a);
@@ -2280,7 +275,6 @@ static void launch_range(cc4_handle* h, StepArgs a, int e0, int e1, hipStream_t 
     if (full) hipExtLaunchKernelGGL(k_step<true>, grid, dim3(WAVE), lds1, st, start, stop, 0, a);
     else hipExtLaunchKernelGGL(k_step<false>, grid, dim3(WAVE), lds1, st, start, stop, 0, a);
   }
-#endif
 }
 
 // ---- one enqueue thread per group stream (cc4_run_random_steps without a communicator).  The groups of a batch never wait for each
@@ -2390,9 +384,6 @@ static int launch_step(cc4_handle* h, const int32_t* d_actions, const uint8_t* d
              (h->cfg.red_policy & 3) | (h->cfg.green_policy ? GP_SLEEP_BIT : 0) | (h->cfg.green_policy == 2 ? GP_OPEN_BIT : 0) | (h->cfg.blue_policy ? BP_RANDOM_BIT : 0), h->full_obs_next ? 1 : 0,
              (uint32_t)h->cfg.topology_seed, h->d_prof, h->d_reset_ws, h->ext_seen ? h->d_ext : nullptr, 0};
   h->full_obs_next = false;
-#ifdef CC4_DEV_FAST
-  if (h->cfg.rng_mode != 1 || full) { h->err = "CC4_DEV_FAST build: only k_step_philox1<false> and k_step_philox<false, 1> exist"; return -1; }
-#endif
   if (whole) {
     hipEvent_t stop = h->tev_stop[0], start = h->tev_start[0];
     for (int g = 0; g < h->ngroups; ++g) h->tev_start[g] = h->tev_stop[g] = nullptr;
@@ -2423,10 +414,8 @@ static int launch_step(cc4_handle* h, const int32_t* d_actions, const uint8_t* d
 
 // the persistent kernel of a handle's mode
 static const void* persist_kernel(const cc4_handle* h) {
-#ifndef CC4_DEV_FAST
   if (h->cfg.rng_mode == 0) return reinterpret_cast<const void*>(k_run_pcg);
-#endif
-  return reinterpret_cast<const void*>(k_run_philox1);
+  return h->comm ? reinterpret_cast<const void*>(k_run_philox1x) : reinterpret_cast<const void*>(k_run_philox1);
 }
 
 
@@ -2470,9 +459,7 @@ static int choose_run_form(cc4_handle* h, int margin, int persist_margin = -1) {
   h->persist_state = -1;
   h->run_margin = persist_margin;
   bool persist_mode = cfg->rng_mode == 1 && !h->multistep && !h->run1m;
-#ifndef CC4_DEV_FAST
   persist_mode = persist_mode || cfg->rng_mode == 0;
-#endif
   if (persist_mode) {
     int per_cu = 0;
     HIPCHK(h, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, persist_kernel(h), WAVE, offsetof(EnvState, hd)));
@@ -2508,7 +495,7 @@ const char* cc4_run_kernel(cc4_handle* h) {
   const bool plain = (!h->comm || h->xchg_on) && !h->evlog_on && !h->ext_seen && !h->d_prof;
   if (plain && h->multistep) return h->multistep_minb == 8 ? "k_run_philox8" : "k_run_philox";
   if (plain && h->run1m) return "k_run_philox1m";
-  if (plain && h->persist_state >= 0) return h->cfg.rng_mode == 0 ? "k_run_pcg" : "k_run_philox1";      // (calls of fewer than persist_min_k steps: the per-step launches)
+  if (plain && h->persist_state >= 0) return h->cfg.rng_mode == 0 ? "k_run_pcg" : (h->comm ? "k_run_philox1x" : "k_run_philox1");      // (calls of fewer than persist_min_k steps: the per-step launches)
   return cc4_step_kernel(h);
 }
 static int persist_setup(cc4_handle* h);
@@ -2538,19 +525,7 @@ int cc4_create(const cc4_config* cfg, cc4_handle** out) {
   h->cfg = *cfg;
   *out = h;
   HIPCHK(h, hipSetDevice(cfg->device_id));
-  {   // PCG64 jump table of the numpy-stream kernel (see wave_green_policy): A_k = M^k, B_k = 1 + M + .. + M^(k-1) mod 2^128
-    PcgJump tab[WAVE + 1];
-    const unsigned __int128 M = ((unsigned __int128)CC4_PCG_MULT_HI << 64) | CC4_PCG_MULT_LO;
-    unsigned __int128 A = 1, B = 0;
-    for (int k = 0; k <= WAVE; ++k) {
-      tab[k].a_hi = (uint64_t)(A >> 64); tab[k].a_lo = (uint64_t)A; tab[k].b_hi = (uint64_t)(B >> 64); tab[k].b_lo = (uint64_t)B;
-      B = B * M + 1; A = A * M;
-    }
-    HIPCHK(h, hipMemcpyToSymbol(HIP_SYMBOL(g_pcg_jump), tab, sizeof(tab)));
-    uint32_t ot[OBS_FAST];
-    for (int v = 0; v < OBS_FAST; ++v) ot[v] = obs_fast_entry(v);
-    HIPCHK(h, hipMemcpyToSymbol(HIP_SYMBOL(g_obs_fast), ot, sizeof(ot)));
-  }
+  if (cc4_upload_pcg_tables() != hipSuccess) { h->err = "cc4_create: the numpy-stream kernel's jump table could not be uploaded"; return -1; }
   {
     hipDeviceProp_t prop;
     HIPCHK(h, hipGetDeviceProperties(&prop, cfg->device_id));
@@ -3289,11 +1264,10 @@ static int persist_launch(cc4_handle* h, StepArgs a, int k, uint32_t t0, const X
     ra.act_ready = h->d_rready; ra.act = h->d_ract; ra.PG = RPG;
     ra.act_wait_ticks = (long long)h->rollout_watchdog_ms * (h->khz > 0 ? h->khz : 100000);
   }
-#ifndef CC4_DEV_FAST
   if (h->cfg.rng_mode == 0) hipExtLaunchKernelGGL(k_run_pcg, dim3(h->run_grid), dim3(WAVE), offsetof(EnvState, hd), h->stream, e0, e1, 0, a, ra, x);
   else
-#endif
-  hipExtLaunchKernelGGL(k_run_philox1, dim3(h->run_grid), dim3(WAVE), offsetof(EnvState, hd), h->stream, e0, e1, 0, a, ra, x);
+  if (h->comm) hipExtLaunchKernelGGL(k_run_philox1x, dim3(h->run_grid), dim3(WAVE), offsetof(EnvState, hd), h->stream, e0, e1, 0, a, ra, x);
+  else hipExtLaunchKernelGGL(k_run_philox1, dim3(h->run_grid), dim3(WAVE), offsetof(EnvState, hd), h->stream, e0, e1, 0, a, ra, x);
   return 0;
 }
 static int run_random_steps_impl(cc4_handle* h, uint64_t seed0, uint32_t t0, int32_t k, float* ms_step_kernels) {
@@ -3643,6 +1617,14 @@ int cc4_get_state(cc4_handle* h, int32_t env, void* buf) {
   HIPCHK(h, hipStreamSynchronize(h->stream));
   return 0;
 }
+int cc4_get_states(cc4_handle* h, int32_t first, int32_t count, void* buf) {
+  if (first < 0 || count < 0 || first + count > h->cfg.num_envs) { h->err = "cc4_get_states: range out of the batch"; return -2; }
+  HIPCHK(h, hipSetDevice(h->cfg.device_id));
+  if (join_groups(h)) return -1;
+  if (count) HIPCHK(h, hipMemcpyAsync(buf, h->d_state + first, (size_t)count * sizeof(EnvState), hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  return 0;
+}
 int cc4_set_state(cc4_handle* h, int32_t env, const void* buf) {
   h->prev_valid = false;        // (also every cc4_edit_state, which writes the rows back through here)
   if (env < 0 || env >= h->cfg.num_envs) { h->err = "cc4_set_state: env out of range"; return -2; }
@@ -3698,10 +1680,6 @@ int cc4_get_topology(cc4_handle* h, int32_t env, uint8_t* out) {
   return rc;
 }
 
-__global__ void k_set_evlog(EnvCold* cold, size_t row_bytes, int n, uint32_t on) {
-  int e = blockIdx.x * blockDim.x + threadIdx.x;
-  if (e < n) { EnvCold* c = cold_at(cold, (size_t)e, row_bytes); c->evlog.enabled = on; c->evlog.n = 0; }
-}
 int cc4_enable_event_log(cc4_handle* h, int32_t enable) {
   HIPCHK(h, hipSetDevice(h->cfg.device_id));
   if (join_groups(h)) return -1;
@@ -3710,13 +1688,6 @@ int cc4_enable_event_log(cc4_handle* h, int32_t enable) {
   HIPCHK(h, hipStreamSynchronize(h->stream));
   h->evlog_on = enable ? 1 : 0;
   return 0;
-}
-__global__ void k_copy_evlog(EnvCold* dst, const EnvCold* src, size_t row_bytes, int n) {
-  const int e = blockIdx.x;
-  if (e >= n) return;
-  const uint32_t* s = reinterpret_cast<const uint32_t*>(&cold_at(const_cast<EnvCold*>(src), (size_t)e, row_bytes)->evlog);
-  uint32_t* d = reinterpret_cast<uint32_t*>(&cold_at(dst, (size_t)e, row_bytes)->evlog);
-  for (int i = threadIdx.x; i < (int)(sizeof(EvLog) / 4); i += blockDim.x) d[i] = s[i];
 }
 // The event log on demand (handles of up to 16 episodes without a communicator).  cc4_keep_previous(1): every step launch is preceded by a
 // device-side copy of the episodes' rows.  cc4_replay_logged: the LAST step again, on that copy, with the logging build of the step kernel
@@ -4043,3 +2014,4 @@ int cc4_get_unpacked_obs(cc4_handle* h, uint8_t* out /* [world*N][578] */) {
 }
 
 }  // extern "C"
+

@@ -1,6 +1,6 @@
 // cc4_engine.h -- the CC4 episode transition: reset (scenario generation), step, flat observation.
 //
-// Single source for the gfx950 device build (cc4_hip.hip) and for the host build used as the CPU
+// Single source for the gfx950 device build (the cc4_k_*.hip translation units) and for the host build used as the CPU
 // oracle (oracle/cc4_oracle.cpp).  Each function cites the reference lines it restates
 // (paths under /root/reference/CybORG).  See docs/REFERENCE_NOTES.md for the condensed semantics.
 #pragma once

@@ -319,8 +319,7 @@ class CC4VecEnv:
         """The packed hot rows of ALL episodes, [num_envs][cc4_state_bytes] (checkpointing a batch, parity tests)."""
         nb = int(self.lib.cc4_state_bytes())
         out = np.zeros((self.num_envs, nb), np.uint8)
-        for e in range(self.num_envs):
-            self._chk(self.lib.cc4_get_state(self._h, e, out[e].ctypes.data_as(ctypes.c_void_p)), 'cc4_get_state')
+        self._chk(self.lib.cc4_get_states(self._h, 0, self.num_envs, out.ctypes.data_as(ctypes.c_void_p)), 'cc4_get_states')
         return out
 
     def get_cold(self, env):

@@ -1,7 +1,7 @@
 // cc4_oracle.cpp -- CPU oracle for the CC4 step engine.  TEST INFRASTRUCTURE, NOT PRODUCT.
 //
 // Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load the library built from
-// this file (oracle/liboracle.so).  The product path (cage_challenge_4_amd/csrc/cc4_hip.hip -> libcc4.so)
+// this file (oracle/liboracle.so).  The product path (cage_challenge_4_amd/csrc/*.hip -> libcc4.so)
 // never links or calls it and fails loudly without a GPU.
 //
 // What it is: a host (g++) build of the transition restated in cage_challenge_4_amd/csrc/cc4_engine.h
@@ -63,14 +63,14 @@ void cc4o_reset(void* h, int i, uint64_t seed, int rng_mode, int steps, int cont
   uint32_t ws[RESET_WS_WORDS];   // work area of the counter-mode generation (the device kernels use LDS)
   env_reset(x, seed, rng_mode, steps, continue_stream != 0, policy, o->topo, rng_mode == 1 ? ws : nullptr);
 }
-void cc4o_set_seed(void* h, int i, uint64_t seed, int rng_mode) {   // CybORG.set_seed: the restatement of k_set_seed (csrc/cc4_hip.hip)
+void cc4o_set_seed(void* h, int i, uint64_t seed, int rng_mode) {   // CybORG.set_seed: the restatement of k_set_seed (csrc/cc4_k_misc.hip)
   EnvState& st = ((Oracle*)h)->st[i];
   if (rng_mode == 0) { if (!st.rng_split) ((Oracle*)h)->cold(i)->rng2 = st.rng; st.rng_split = 1; }
   Rng* r = &st.rng;
   rng_seed(r, seed, (uint32_t)rng_mode);
   if (rng_mode == 1) { rng_begin_episode(r); rng_park(r); }
 }
-void cc4o_set_rng_state(void* h, int i, const uint64_t* w) {   // restatement of k_set_rng_state (csrc/cc4_hip.hip)
+void cc4o_set_rng_state(void* h, int i, const uint64_t* w) {   // restatement of k_set_rng_state (csrc/cc4_k_misc.hip)
   EnvState& st = ((Oracle*)h)->st[i];
   Rng r; rng_seed(&r, 0, 0);
   r.s_hi = w[0]; r.s_lo = w[1]; r.inc_hi = w[2]; r.inc_lo = w[3]; r.has32 = (uint32_t)w[4]; r.u32 = (uint32_t)w[5];

@@ -269,7 +269,7 @@ class OracleVecEnv:
 
 
 def random_actions(seed0, t, num_envs):
-    """Host restatement of k_random_actions (csrc/cc4_hip.hip): Philox4x32-10 key (seed0+env), counter (t, agent, 0xB10E, 0)."""
+    """Host restatement of k_random_actions (csrc/cc4_k_misc.hip): Philox4x32-10 key (seed0+env), counter (t, agent, 0xB10E, 0)."""
     M0, M1, W0, W1 = 0xD2511F53, 0xCD9E8D57, 0x9E3779B9, 0xBB67AE85
     e = np.arange(num_envs, dtype=np.uint64)[:, None] + np.uint64(seed0)
     b = np.arange(5, dtype=np.uint64)[None, :]

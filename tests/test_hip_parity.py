@@ -384,7 +384,7 @@ def _pack_rows(obs):
 
 
 def _hash_policy(packed, j):
-    """numpy restatement of k_rollout_hash_policy (csrc/cc4_hip.hip): FNV-1a over the 37 words of an episode's packed observation row."""
+    """numpy restatement of k_rollout_hash_policy (csrc/cc4_k_misc.hip): FNV-1a over the 37 words of an episode's packed observation row."""
     w = np.ascontiguousarray(packed).view('<u4').astype(np.uint64)          # [n, 37]
     h = np.full(w.shape[0], 2166136261, np.uint64)
     for c in range(w.shape[1]):
@@ -617,7 +617,7 @@ def test_observation_ring_survives_a_slow_exchange(n, groups, monkeypatch):
 
 
 @pytest.mark.parametrize('n,mode,run_kernel,delay_us', [(1000, 1, 'k_run_philox', 1500), (2000, 1, 'k_run_philox1m', 0),
-                                                        (8192, 1, 'k_run_philox1', 0), (6656, 1, 'k_run_philox1', 2500), (5000, 0, 'k_run_pcg', 0)],
+                                                        (8192, 1, 'k_run_philox1x', 0), (6656, 1, 'k_run_philox1x', 2500), (5000, 0, 'k_run_pcg', 0)],
                          ids=['1000-slow-exchange', '2000', '8192', '6656-slow-exchange', '5000-numpy-stream'])     # (1000 / 2000: the last group of 32 episodes is a partial one)
 def test_exchange_from_inside_the_one_launch_kernels_gathers_every_step(n, mode, run_kernel, delay_us):
     """with a communicator cc4_run_random_steps stays ONE launch -- step k writes its packed rows into slab k mod 32 of a
@@ -1224,7 +1224,9 @@ def test_bench_line_contract():
     assert '8192 vectorised envs' in d['config']['workload'] and d['config']['total_envs'] == 8192
     assert not d['config']['engine_error_flags'] and d['config']['timed_regions'] >= 1
     r = d['roofline']
-    assert r['bound'] == 'hbm' and r['unit'] == 'GB/s' and r['peak'] == 8000.0 and abs(r['frac'] - r['achieved'] / r['peak']) < 1e-9
+    # `bound` is what the measurements say (r06): "hbm" only when the committed counter passes of THIS kernel show the memory system busy, else "latency"
+    assert r['bound'] in ('hbm', 'latency') and r['roofline'] == 'hbm' and r['bound_evidence']
+    assert r['unit'] == 'GB/s' and r['peak'] == 8000.0 and abs(r['frac'] - r['achieved'] / r['peak']) < 1e-9
     # 8192 episodes, 20-step regions: ONE launch of the persistent one-wave kernel per region (regions of fewer than 10 steps, or CC4_PERSIST=0:
     # three or four concurrent launches of k_step_philox1 per step)
     assert r['step_kernel'] == 'k_step_philox1' and r['kernel'] == r['run_kernel'] == 'k_run_philox1' and r['steps_per_launch'] == 20
@@ -1237,7 +1239,7 @@ def test_bench_line_contract():
     assert p['run_kernel'] == 'k_step_philox1' and 50e6 < p['value'] <= p['grouped']['value'] * 1.05 and p['grouped']['value'] < d['value'] * 1.05
     x = d['exchange_world1']
     assert 'skipped' in x or (x['envs_1024']['exchange']['in_kernel'] and x['envs_1024']['run_kernel'] == 'k_run_philox' and
-                              x['envs_8192']['run_kernel'] == 'k_run_philox1' and x['envs_8192']['exchange']['watchdog_timeouts'] == 0 and
+                              x['envs_8192']['run_kernel'] == 'k_run_philox1x' and x['envs_8192']['exchange']['watchdog_timeouts'] == 0 and
                               x['envs_8192']['allgathers_issued'] >= x['envs_8192']['regions'] * 20)
     assert d['envs_1024']['roofline']['bound'] == 'latency' and d['single_env_facade']['us_per_step'] < 120
     assert abs(d['value'] - 5.0 * 8192 / (d['ms_per_step'] * 1e-3)) < 1e-6 * d['value']

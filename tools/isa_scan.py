@@ -1,5 +1,5 @@
 #!/usr/bin/env python
-"""ISA lint for the gfx950 build of cc4_hip.hip.
+"""ISA lint for the gfx950 build of libcc4.so (every translation unit under cage_challenge_4_amd/csrc).
 
 hipcc (ROCm 7.2, -O3) was seen to lower a wave-uniform `cond ? a : b` whose compare stayed on the VALU
 (v_cmp -> vcc) into an `s_cselect` -- which reads SCC, not VCC -- inside one unrolled copy of a loop in k_step; the
@@ -7,13 +7,11 @@ result depended on whatever SALU compare ran last.  The parity tests caught it o
 pattern at build time, without a GPU: every SCC reader (s_cselect / s_cbranch_scc* / s_addc / s_subb / s_cmov) must
 have an SCC writer before it in its straight-line block when a VALU compare (v_cmp) is the only compare in it.
 
-usage: isa_scan.py [file.s]      (no argument: compile cage_challenge_4_amd/csrc/cc4_hip.hip to ISA first)
+usage: isa_scan.py [file.s ...]      (no argument: the ISA files the last build left under cage_challenge_4_amd/csrc/build/)
 """
 import os
 import re
-import subprocess
 import sys
-import tempfile
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SCC_WRITER = re.compile(r'^\s*s_(cmp|cmpk|and_|or_|xor_|andn2|orn2|nand|nor|xnor|add_|sub_|addc|subb|lshl|lshr|ashr|bfe|min_|max_|'
@@ -45,26 +43,21 @@ def scan(text):
     return bad
 
 
-def compile_isa(out):
-    hipcc = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
-    src = os.path.join(ROOT, 'cage_challenge_4_amd', 'csrc', 'cc4_hip.hip')
-    subprocess.check_call([hipcc, '--offload-arch=gfx950', '-O3', '-std=c++17', '-ffp-contract=off', '-S', '--cuda-device-only',
-                           '-o', out, src], stderr=subprocess.DEVNULL)
-
-
 def main():
-    if len(sys.argv) > 1:
-        text = open(sys.argv[1]).read()
-    else:
-        with tempfile.TemporaryDirectory() as d:
-            p = os.path.join(d, 'cc4.s')
-            compile_isa(p)
-            text = open(p).read()
-    bad = scan(text)
-    for b in bad:
-        print('SCC read after VALU compare: line %d: %s   <<  %s' % b)
-    print('isa_scan: %d suspicious SCC reads' % len(bad))
-    return 1 if bad else 0
+    files = sys.argv[1:]
+    if not files:       # the ISA of every translation unit as the last build left it (cage_challenge_4_amd/csrc/build/<unit>/*-gfx950.s: -save-temps)
+        import glob
+        files = sorted(glob.glob(os.path.join(ROOT, 'cage_challenge_4_amd', 'csrc', 'build', '*', '*-gfx950.s')))
+        if not files:
+            raise RuntimeError('no ISA files: build the library first (python __graft_entry__.py)')
+    total = 0
+    for f in files:
+        bad = scan(open(f).read())
+        for b in bad:
+            print(os.path.basename(os.path.dirname(f)) + ': SCC read after VALU compare: line %d: %s   <<  %s' % b)
+        total += len(bad)
+    print('isa_scan: %d suspicious SCC reads in %d file(s)' % (total, len(files)))
+    return 1 if total else 0
 
 
 if __name__ == '__main__':
