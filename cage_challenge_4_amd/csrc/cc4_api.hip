@@ -108,6 +108,7 @@ struct cc4_handle {
   hipEvent_t rev = nullptr;       // the rollout's starting observations are packed (slab XRING - 1)
   int rollout_k = 0;              // > 0: a rollout of that many steps is in flight
   int rollout_watchdog_ms = 2000;
+  int rollout_margin = 1;
   int obs8_from_slab = -1;        // >= 0: the per-step ring's current buffer is to be filled from this slab of the exchange ring (xchg_end), when somebody reads it
   uint32_t* d_xflags = nullptr;   // [0] gathered, [1] timeout (what the waits poll)
   uint32_t* d_xgcnt = nullptr;    // [groups][XRING] group counters (xchg_count)
@@ -1267,7 +1268,11 @@ static int persist_launch(cc4_handle* h, StepArgs a, int k, uint32_t t0, const X
   if (h->cfg.rng_mode == 0) hipExtLaunchKernelGGL(k_run_pcg, dim3(h->run_grid), dim3(WAVE), offsetof(EnvState, hd), h->stream, e0, e1, 0, a, ra, x);
   else
   if (h->comm) hipExtLaunchKernelGGL(k_run_philox1x, dim3(h->run_grid), dim3(WAVE), offsetof(EnvState, hd), h->stream, e0, e1, 0, a, ra, x);
-  else hipExtLaunchKernelGGL(k_run_philox1, dim3(h->run_grid), dim3(WAVE), offsetof(EnvState, hd), h->stream, e0, e1, 0, a, ra, x);
+  else {
+    // a rollout leaves `rollout_margin` waves per CU to the caller's policy kernels and the gates (CC4_ROLLOUT_MARGIN)
+    const int grid = rollout ? h->run_grid - h->rollout_margin * h->cus : h->run_grid;
+    hipExtLaunchKernelGGL(k_run_philox1, dim3(grid > h->cus ? grid : h->cus), dim3(WAVE), offsetof(EnvState, hd), h->stream, e0, e1, 0, a, ra, x);
+  }
   return 0;
 }
 static int run_random_steps_impl(cc4_handle* h, uint64_t seed0, uint32_t t0, int32_t k, float* ms_step_kernels) {
@@ -1500,6 +1505,7 @@ int cc4_rollout_begin(cc4_handle* h, int32_t k) {
     HIPCHK(h, hipStreamCreateWithFlags(&h->policy_stream, hipStreamNonBlocking));
     HIPCHK(h, hipEventCreateWithFlags(&h->rev, hipEventDisableTiming));
     if (const char* v = getenv("CC4_ROLLOUT_WATCHDOG_MS")) h->rollout_watchdog_ms = atoi(v) > 0 ? atoi(v) : 2000;
+    if (const char* v = getenv("CC4_ROLLOUT_MARGIN")) h->rollout_margin = atoi(v) >= 0 ? atoi(v) : 1;
   }
   if (!h->d_xslab) HIPCHK(h, hipMalloc(&h->d_xslab, row * cc4_handle::XRING));
   if (!h->d_xflags) { HIPCHK(h, hipMalloc(&h->d_xflags, 2 * sizeof(uint32_t))); }
@@ -1581,6 +1587,24 @@ int cc4_rollout_hash_policy(cc4_handle* h, int32_t g, int32_t j, void* hip_strea
   const uint8_t* rows = h->d_xslab + (size_t)((j + cc4_handle::XRING - 1) % cc4_handle::XRING) * (size_t)n * OBS_PACKED;
   hipLaunchKernelGGL(k_rollout_hash_policy, dim3((n + 255) / 256), dim3(256), 0, st, h->d_ract + (size_t)(j & 1) * (size_t)n * NBLUE, rows, n, h->run_P, (int)g, (uint32_t)j);
   HIPCHK(h, hipGetLastError());
+  return 0;
+}
+// debug: where a rollout stands / stood -- out[0..1] the groups' published step counts, out[2..3] gate-failed flag and the kernel's timeout flag,
+// out[4 + 2 * slot + g] = sum over the partitions of the count of (policy group g, ring slot), slots 0..3
+int cc4_debug_rollout_state(cc4_handle* h, int64_t* out /* [12] */) {
+  if (!h->d_rcnt) { h->err = "cc4_debug_rollout_state: no rollout was begun on this handle"; return -2; }
+  HIPCHK(h, hipSetDevice(h->cfg.device_id));
+  std::vector<uint32_t> rd(RPG * 32), cnt((size_t)h->run_P * RPG * cc4_handle::XRING);
+  uint32_t fail = 0;
+  HIPCHK(h, hipMemcpy(rd.data(), h->d_rready, rd.size() * 4, hipMemcpyDeviceToHost));
+  HIPCHK(h, hipMemcpy(cnt.data(), h->d_rcnt, cnt.size() * 4, hipMemcpyDeviceToHost));
+  HIPCHK(h, hipMemcpy(&fail, h->d_rfail, 4, hipMemcpyDeviceToHost));
+  out[0] = rd[0]; out[1] = rd[32]; out[2] = fail; out[3] = *reinterpret_cast<volatile uint32_t*>(h->h_xtimeout);
+  for (int slot = 0; slot < 4; ++slot) for (int g = 0; g < RPG; ++g) {
+    int64_t sum = 0;
+    for (int p = 0; p < h->run_P; ++p) sum += cnt[((size_t)p * RPG + g) * cc4_handle::XRING + slot];
+    out[4 + 2 * slot + g] = sum;
+  }
   return 0;
 }
 int cc4_rollout_end(cc4_handle* h) {
