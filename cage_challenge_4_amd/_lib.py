@@ -79,10 +79,12 @@ SIGNATURES = {
     'cc4_rollout_obs_packed': (ctypes.c_int, [_P, ctypes.c_int32, _P]),
     'cc4_rollout_actions': (ctypes.c_int, [_P, ctypes.c_int32, _P]),
     'cc4_rollout_wait_obs': (ctypes.c_int, [_P, ctypes.c_int32, ctypes.c_int32, _P]),
+    'cc4_rollout_sync': (ctypes.c_int, [_P, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, _P]),
     'cc4_rollout_publish': (ctypes.c_int, [_P, ctypes.c_int32, ctypes.c_int32, _P]),
     'cc4_rollout_random_policy': (ctypes.c_int, [_P, ctypes.c_int32, ctypes.c_int32, ctypes.c_uint64, ctypes.c_uint32, _P]),
     'cc4_rollout_hash_policy': (ctypes.c_int, [_P, ctypes.c_int32, ctypes.c_int32, _P]),
     'cc4_rollout_end': (ctypes.c_int, [_P]),
+    'cc4_rollout_standin': (ctypes.c_int, [_P, ctypes.c_int32, ctypes.c_int32, ctypes.c_uint64, ctypes.c_uint32]),
     'cc4_debug_comm_delay_us': (ctypes.c_int, [_P, ctypes.c_int]),
     'cc4_host_stats': (ctypes.c_int, [_P, _P]),
     'cc4_verify_stats': (ctypes.c_int, [_P, _P]),

@@ -101,14 +101,16 @@ struct cc4_handle {
   int khz = 0;                    // wall-clock rate (hipDeviceAttributeWallClockRate), asked once
   // ---- rollouts with the policy in the loop (cc4_rollout_begin .. cc4_rollout_end)
   int32_t* d_ract = nullptr;      // [2][n][5] action slots (step j reads slot j % 2)
-  uint32_t* d_rready = nullptr;   // [RPG][32] words: actions of steps < value are published for the group
+  uint32_t* d_rready = nullptr;   // [P][32] words: word g of partition p's line = actions of steps < value are published for policy group g (every line holds the same)
   uint32_t* d_rcnt = nullptr;     // [P][RPG][XRING] episodes of (partition, policy group) whose packed row of step j is in memory (slot j % XRING)
   uint32_t* d_rfail = nullptr;    // [1] a gate gave up
-  hipStream_t policy_stream = nullptr;
+  hipStream_t policy_stream = nullptr;   // = gpolicy[0]
+  hipStream_t gpolicy[4] = {nullptr, nullptr, nullptr, nullptr};   // one policy stream per policy group: the groups' gate -> policy -> publish chains run side by side
   hipEvent_t rev = nullptr;       // the rollout's starting observations are packed (slab XRING - 1)
   int rollout_k = 0;              // > 0: a rollout of that many steps is in flight
   int rollout_watchdog_ms = 2000;
   int rollout_margin = 1;
+  int rpg = 4;                    // policy groups (CC4_ROLLOUT_GROUPS, 1 .. RPG_MAX)
   int obs8_from_slab = -1;        // >= 0: the per-step ring's current buffer is to be filled from this slab of the exchange ring (xchg_end), when somebody reads it
   uint32_t* d_xflags = nullptr;   // [0] gathered, [1] timeout (what the waits poll)
   uint32_t* d_xgcnt = nullptr;    // [groups][XRING] group counters (xchg_count)
@@ -628,7 +630,7 @@ void cc4_destroy(cc4_handle* h) {
   if (h->comm) ncclCommDestroy(h->comm);
   for (int b = 0; b < cc4_handle::OBS_RING; ++b) { for (int g = 0; g < cc4_handle::MAX_GROUPS; ++g) if (h->ev_step[b][g]) (void)hipEventDestroy(h->ev_step[b][g]); if (h->ev_comm[b]) (void)hipEventDestroy(h->ev_comm[b]); }
   if (h->comm_stream) (void)hipStreamDestroy(h->comm_stream);
-  if (h->policy_stream) (void)hipStreamDestroy(h->policy_stream);
+  for (int g = 0; g < 4; ++g) if (h->gpolicy[g]) (void)hipStreamDestroy(h->gpolicy[g]);
   if (h->rev) (void)hipEventDestroy(h->rev);
   for (void* p : {(void*)h->d_ract, (void*)h->d_rready, (void*)h->d_rcnt, (void*)h->d_rfail}) if (p) (void)hipFree(p);
   void* ptrs[] = {h->d_state, h->d_cold, h->small_io ? nullptr : (void*)h->d_actions, h->d_seeds, h->d_envmask, h->small_io ? nullptr : (void*)h->d_obs,
@@ -1014,9 +1016,8 @@ static int persist_setup(cc4_handle* h) {
     return 0;
   }
   h->run_P = P; h->run_G = P; h->run_grid = per_cu * h->cus;
-  if (const char* v = getenv("CC4_PERSIST_SCHED")) h->run_pool = atoi(v);
   if (const char* v = getenv("CC4_PERSIST_THR")) h->run_thr = atoi(v);
-  if (h->run_pool < 0 || h->run_pool > 2) h->run_pool = 2;
+  h->run_pool = 2;
   if (const char* v = getenv("CC4_PERSIST_RUNS")) {
     int q[4] = {h->run_SA, h->run_SB, h->run_nB, h->run_single};
     (void)sscanf(v, "%d,%d,%d,%d", &q[0], &q[1], &q[2], &q[3]);
@@ -1033,29 +1034,14 @@ static int persist_setup(cc4_handle* h) {
     }
     for (int sl = 8 << 8; sl < CC4_SLOTS; ++sl) if (count[sl] > 0) ok = false;          // an XCC id beyond 7: not a device this schedule knows
     if (P > 510) ok = false;                            // the runner's id in the progress words: 9 bits
-    if (!ok) h->run_pool = 0;
-    else {
+    if (!ok) {
+      fprintf(stderr, "[cc4] the persistent run kernel stays OFF for this handle (per-step launches instead): more than 64 CUs in an XCD, or more than 510 CUs\n");
+      h->persist_refused = true;
+      return 0;
+    } else {
       if (!h->d_pool) HIPCHK(h, hipMalloc(&h->d_pool, 2 * (size_t)CC4_SLOTS * TK_STRIDE * sizeof(uint32_t)));
       HIPCHK(h, hipMemset(h->d_pool, 0, 2 * (size_t)CC4_SLOTS * TK_STRIDE * sizeof(uint32_t)));
       h->pool_base = 0; h->pool_parity = 0;
-    }
-  }
-  if (h->run_pool == 1) {
-    // one pool per XCD the discovery pass saw waves on (slot id = XCC id << 8 | CU)
-    int nx = 0;
-    for (int xc = 0; xc < 8; ++xc) {
-      bool seen = false;
-      for (int sl = xc << 8; sl < (xc + 1) << 8; ++sl) seen = seen || count[sl] > 0;
-      h->xcc_pool[xc] = seen ? (uint8_t)nx++ : (uint8_t)0xFF;
-    }
-    for (int sl = 8 << 8; sl < CC4_SLOTS; ++sl) if (count[sl] > 0) nx = 0;          // an XCC id beyond 7: not a device this schedule knows
-    if (nx <= 0) h->run_pool = 0;
-    else {
-      h->run_P = nx;
-      if (!h->d_pool) HIPCHK(h, hipMalloc(&h->d_pool, 2 * (size_t)CC4_SLOTS * TK_STRIDE * sizeof(uint32_t)));
-      HIPCHK(h, hipMemset(h->d_pool, 0, 2 * (size_t)CC4_SLOTS * TK_STRIDE * sizeof(uint32_t)));
-      h->pool_base = 0; h->pool_parity = 0;
-      if (getenv("CC4_PERSIST_DEBUG")) fprintf(stderr, "[cc4] persistent kernel: %d XCD pools\n", nx);
     }
   }
   if (!h->d_slot_part) HIPCHK(h, hipMalloc(&h->d_slot_part, CC4_SLOTS * sizeof(int32_t)));
@@ -1234,8 +1220,7 @@ int cc4_verify_stats(cc4_handle* h, int64_t* out /* [2] */) { out[0] = h->verify
 // One launch of the persistent kernel for k steps of the whole batch (cc4_run_random_steps form 3; cc4_rollout_begin with rollout = true: every step
 // an item of its own, the actions from the rollout's slots behind the caller's publishes).
 static int persist_launch(cc4_handle* h, StepArgs a, int k, uint32_t t0, const XchgArgs& x, hipEvent_t e0, hipEvent_t e1, bool rollout) {
-  if (!h->run_pool) HIPCHK(h, hipMemsetAsync(h->d_run, 0, h->run_words * sizeof(uint32_t), h->stream));
-  else if (h->pool_base + (uint32_t)k > (h->run_pool == 2 ? 0x700000u : 0x7F000000u)) {      // (the progress words count steps since they were last cleared)
+  if (h->pool_base + (uint32_t)k > 0x700000u) {      // (the progress words count steps since they were last cleared)
     HIPCHK(h, hipMemsetAsync(h->d_run, 0, h->run_words * sizeof(uint32_t), h->stream));
     h->pool_base = 0;
   }
@@ -1262,7 +1247,7 @@ static int persist_launch(cc4_handle* h, StepArgs a, int k, uint32_t t0, const X
     h->pool_parity ^= 1; h->pool_base += (uint32_t)k;
   }
   if (rollout) {
-    ra.act_ready = h->d_rready; ra.act = h->d_ract; ra.PG = RPG;
+    ra.act_ready = h->d_rready; ra.act = h->d_ract; ra.PG = h->rpg;
     ra.act_wait_ticks = (long long)h->rollout_watchdog_ms * (h->khz > 0 ? h->khz : 100000);
   }
   if (h->cfg.rng_mode == 0) hipExtLaunchKernelGGL(k_run_pcg, dim3(h->run_grid), dim3(WAVE), offsetof(EnvState, hd), h->stream, e0, e1, 0, a, ra, x);
@@ -1271,7 +1256,8 @@ static int persist_launch(cc4_handle* h, StepArgs a, int k, uint32_t t0, const X
   else {
     // a rollout leaves `rollout_margin` waves per CU to the caller's policy kernels and the gates (CC4_ROLLOUT_MARGIN)
     const int grid = rollout ? h->run_grid - h->rollout_margin * h->cus : h->run_grid;
-    hipExtLaunchKernelGGL(k_run_philox1, dim3(grid > h->cus ? grid : h->cus), dim3(WAVE), offsetof(EnvState, hd), h->stream, e0, e1, 0, a, ra, x);
+    if (rollout) hipExtLaunchKernelGGL(k_run_philox1r, dim3(grid > h->cus ? grid : h->cus), dim3(WAVE), offsetof(EnvState, hd), h->stream, e0, e1, 0, a, ra, x);
+    else hipExtLaunchKernelGGL(k_run_philox1, dim3(grid), dim3(WAVE), offsetof(EnvState, hd), h->stream, e0, e1, 0, a, ra, x);
   }
   return 0;
 }
@@ -1499,13 +1485,15 @@ int cc4_rollout_begin(cc4_handle* h, int32_t k) {
   const size_t n = (size_t)h->cfg.num_envs, row = n * OBS_PACKED;
   if (!h->d_ract) {
     HIPCHK(h, hipMalloc(&h->d_ract, 2 * n * NBLUE * sizeof(int32_t)));
-    HIPCHK(h, hipMalloc(&h->d_rready, RPG * 32 * sizeof(uint32_t)));
-    HIPCHK(h, hipMalloc(&h->d_rcnt, (size_t)h->run_P * RPG * cc4_handle::XRING * sizeof(uint32_t)));
+    HIPCHK(h, hipMalloc(&h->d_rready, (size_t)CC4_SLOTS * 32 * sizeof(uint32_t)));
+    HIPCHK(h, hipMalloc(&h->d_rcnt, (size_t)h->run_P * RPG_MAX * cc4_handle::XRING * sizeof(uint32_t)));
     HIPCHK(h, hipMalloc(&h->d_rfail, sizeof(uint32_t)));
-    HIPCHK(h, hipStreamCreateWithFlags(&h->policy_stream, hipStreamNonBlocking));
+    for (int g = 0; g < RPG_MAX; ++g) HIPCHK(h, hipStreamCreateWithFlags(&h->gpolicy[g], hipStreamNonBlocking));
+    h->policy_stream = h->gpolicy[0];
     HIPCHK(h, hipEventCreateWithFlags(&h->rev, hipEventDisableTiming));
     if (const char* v = getenv("CC4_ROLLOUT_WATCHDOG_MS")) h->rollout_watchdog_ms = atoi(v) > 0 ? atoi(v) : 2000;
     if (const char* v = getenv("CC4_ROLLOUT_MARGIN")) h->rollout_margin = atoi(v) >= 0 ? atoi(v) : 1;
+    if (const char* v = getenv("CC4_ROLLOUT_GROUPS")) { h->rpg = atoi(v); if (h->rpg < 1) h->rpg = 1; if (h->rpg > RPG_MAX) h->rpg = RPG_MAX; }
   }
   if (!h->d_xslab) HIPCHK(h, hipMalloc(&h->d_xslab, row * cc4_handle::XRING));
   if (!h->d_xflags) { HIPCHK(h, hipMalloc(&h->d_xflags, 2 * sizeof(uint32_t))); }
@@ -1516,8 +1504,9 @@ int cc4_rollout_begin(cc4_handle* h, int32_t k) {
   if (h->khz <= 0) { int khz = 100000; (void)hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, h->cfg.device_id); h->khz = khz > 0 ? khz : 100000; }
   *h->h_xtimeout = 0;
   HIPCHK(h, hipMemsetAsync(h->d_xflags, 0, 2 * sizeof(uint32_t), h->stream));
-  HIPCHK(h, hipMemsetAsync(h->d_rready, 0, RPG * 32 * sizeof(uint32_t), h->stream));
-  HIPCHK(h, hipMemsetAsync(h->d_rcnt, 0, (size_t)h->run_P * RPG * cc4_handle::XRING * sizeof(uint32_t), h->stream));
+  // (debug, CC4_ROLLOUT_PREPUBLISH=1: every pass counts as published from the start -- what the stepping itself costs in a rollout, without the waits)
+  HIPCHK(h, hipMemsetAsync(h->d_rready, getenv("CC4_ROLLOUT_PREPUBLISH") ? 0x7F : 0, (size_t)h->run_P * 32 * sizeof(uint32_t), h->stream));
+  HIPCHK(h, hipMemsetAsync(h->d_rcnt, 0, (size_t)h->run_P * RPG_MAX * cc4_handle::XRING * sizeof(uint32_t), h->stream));
   HIPCHK(h, hipMemsetAsync(h->d_rfail, 0, sizeof(uint32_t), h->stream));
   // what the first policy pass reads: the observations as they stand, packed into the slab in front of step 0's
   hipLaunchKernelGGL(k_pack_obs_rows, dim3((unsigned)n), dim3(WAVE), 0, h->stream, h->d_xslab + (size_t)(cc4_handle::XRING - 1) * row, h->d_obs, (int)n);
@@ -1537,7 +1526,7 @@ int cc4_rollout_begin(cc4_handle* h, int32_t k) {
 }
 int cc4_rollout_groups(cc4_handle* h, int32_t* groups, int32_t* block) {
   if (h->persist_state == 0) { HIPCHK(h, hipSetDevice(h->cfg.device_id)); if (persist_setup(h)) return -1; }
-  *groups = RPG; *block = h->run_P > 0 ? h->run_P : h->cus;
+  *groups = h->rpg; *block = h->run_P > 0 ? h->run_P : h->cus;
   return 0;
 }
 int cc4_rollout_obs_packed(cc4_handle* h, int32_t j, const uint8_t** d_rows) {
@@ -1557,53 +1546,66 @@ int cc4_rollout_policy_stream(cc4_handle* h, void** hip_stream) {
 }
 int cc4_rollout_wait_obs(cc4_handle* h, int32_t g, int32_t j, void* hip_stream) {
   if (rollout_ready(h, "cc4_rollout_wait_obs")) return -2;
-  if (g < 0 || g >= RPG || j < 0 || j >= h->rollout_k) { h->err = "cc4_rollout_wait_obs: group or step out of range"; return -2; }
-  hipStream_t st = hip_stream ? (hipStream_t)hip_stream : h->policy_stream;
+  if (g < 0 || g >= h->rpg || j < 0 || j >= h->rollout_k) { h->err = "cc4_rollout_wait_obs: group or step out of range"; return -2; }
+  hipStream_t st = hip_stream ? (hipStream_t)hip_stream : h->gpolicy[g];
   if (j == 0) { HIPCHK(h, hipStreamWaitEvent(st, h->rev, 0)); return 0; }
-  hipLaunchKernelGGL(k_rollout_gate, dim3(1), dim3(WAVE), 0, st, h->d_rcnt, h->run_P, (int)cc4_handle::XRING, (int)g, (int)((j - 1) % cc4_handle::XRING), h->cfg.num_envs,
+  hipLaunchKernelGGL(k_rollout_gate, dim3(1), dim3(WAVE), 0, st, h->d_rcnt, h->run_P, h->rpg, (int)cc4_handle::XRING, (int)g, (int)((j - 1) % cc4_handle::XRING), h->cfg.num_envs,
                      (long long)h->rollout_watchdog_ms * h->khz, h->d_rfail);
   HIPCHK(h, hipGetLastError());
   return 0;
 }
+int cc4_rollout_sync(cc4_handle* h, int32_t pub_g, int32_t pub_j, int32_t gate_g, int32_t gate_j, void* hip_stream);
 int cc4_rollout_publish(cc4_handle* h, int32_t g, int32_t j, void* hip_stream) {
   if (rollout_ready(h, "cc4_rollout_publish")) return -2;
-  if (g < 0 || g >= RPG || j < 0 || j >= h->rollout_k) { h->err = "cc4_rollout_publish: group or step out of range"; return -2; }
-  hipStream_t st = hip_stream ? (hipStream_t)hip_stream : h->policy_stream;
-  HIPCHK(h, hipStreamWriteValue32(st, h->d_rready + (size_t)g * 32, (uint32_t)(j + 1), 0));
+  if (g < 0 || g >= h->rpg || j < 0 || j >= h->rollout_k) { h->err = "cc4_rollout_publish: group or step out of range"; return -2; }
+  return cc4_rollout_sync(h, g, j, -1, 0, hip_stream);       // (a one-wave kernel: the word is published once per CU partition)
+}
+int cc4_rollout_sync(cc4_handle* h, int32_t pub_g, int32_t pub_j, int32_t gate_g, int32_t gate_j, void* hip_stream) {
+  if (rollout_ready(h, "cc4_rollout_sync")) return -2;
+  if (pub_g >= h->rpg || gate_g >= h->rpg || (pub_g >= 0 && (pub_j < 0 || pub_j >= h->rollout_k)) || (gate_g >= 0 && (gate_j < 0 || gate_j >= h->rollout_k))) { h->err = "cc4_rollout_sync: group or step out of range"; return -2; }
+  hipStream_t st = hip_stream ? (hipStream_t)hip_stream : h->gpolicy[gate_g >= 0 ? gate_g : (pub_g >= 0 ? pub_g : 0)];
+  if (gate_g >= 0 && gate_j == 0) { HIPCHK(h, hipStreamWaitEvent(st, h->rev, 0)); gate_g = -1; }      // (the observations as they stood: behind the event)
+  if (pub_g < 0 && gate_g < 0) return 0;
+  hipLaunchKernelGGL(k_rollout_sync, dim3(1), dim3(WAVE), 0, st, h->d_rready, (int)pub_g, (uint32_t)(pub_j + 1), h->d_rcnt, h->run_P, h->rpg, (int)cc4_handle::XRING, (int)gate_g,
+                     (int)(gate_g >= 0 ? (gate_j - 1) % cc4_handle::XRING : 0), h->cfg.num_envs, (long long)h->rollout_watchdog_ms * h->khz, h->d_rfail);
+  HIPCHK(h, hipGetLastError());
   return 0;
 }
 int cc4_rollout_random_policy(cc4_handle* h, int32_t g, int32_t j, uint64_t seed0, uint32_t t, void* hip_stream) {
   if (rollout_ready(h, "cc4_rollout_random_policy")) return -2;
-  hipStream_t st = hip_stream ? (hipStream_t)hip_stream : h->policy_stream;
+  hipStream_t st = hip_stream ? (hipStream_t)hip_stream : h->gpolicy[g];
   const int tot = h->cfg.num_envs * NBLUE;
-  hipLaunchKernelGGL(k_rollout_random_policy, dim3((tot + 255) / 256), dim3(256), 0, st, h->d_ract + (size_t)(j & 1) * (size_t)tot, h->cfg.num_envs, h->run_P, (int)g, seed0, t);
+  const int grp = ((h->cfg.num_envs + h->run_P - 1) / h->run_P + h->rpg - 1) / h->rpg * h->run_P * NBLUE;      // threads over the group's episodes (whole blocks of P)
+  hipLaunchKernelGGL(k_rollout_random_policy, dim3((grp + WAVE - 1) / WAVE), dim3(WAVE), 0, st, h->d_ract + (size_t)(j & 1) * (size_t)tot, h->cfg.num_envs, h->run_P, h->rpg, (int)g, seed0, t);
   HIPCHK(h, hipGetLastError());
   return 0;
 }
 int cc4_rollout_hash_policy(cc4_handle* h, int32_t g, int32_t j, void* hip_stream) {
   if (rollout_ready(h, "cc4_rollout_hash_policy")) return -2;
-  hipStream_t st = hip_stream ? (hipStream_t)hip_stream : h->policy_stream;
+  hipStream_t st = hip_stream ? (hipStream_t)hip_stream : h->gpolicy[g];
   const int n = h->cfg.num_envs;
   const uint8_t* rows = h->d_xslab + (size_t)((j + cc4_handle::XRING - 1) % cc4_handle::XRING) * (size_t)n * OBS_PACKED;
-  hipLaunchKernelGGL(k_rollout_hash_policy, dim3((n + 255) / 256), dim3(256), 0, st, h->d_ract + (size_t)(j & 1) * (size_t)n * NBLUE, rows, n, h->run_P, (int)g, (uint32_t)j);
+  const int grp = ((n + h->run_P - 1) / h->run_P + h->rpg - 1) / h->rpg * h->run_P;
+  hipLaunchKernelGGL(k_rollout_hash_policy, dim3((grp + WAVE - 1) / WAVE), dim3(WAVE), 0, st, h->d_ract + (size_t)(j & 1) * (size_t)n * NBLUE, rows, n, h->run_P, h->rpg, (int)g, (uint32_t)j);
   HIPCHK(h, hipGetLastError());
   return 0;
 }
-// debug: where a rollout stands / stood -- out[0..1] the groups' published step counts, out[2..3] gate-failed flag and the kernel's timeout flag,
-// out[4 + 2 * slot + g] = sum over the partitions of the count of (policy group g, ring slot), slots 0..3
-int cc4_debug_rollout_state(cc4_handle* h, int64_t* out /* [12] */) {
+// debug: where a rollout stands / stood -- out[0..1] gate-failed flag and the kernel's timeout flag, out[2 + g] the groups' published step counts,
+// out[6 + 4 * slot + g] = sum over the partitions of the count of (policy group g, ring slot), slots 0..3
+int cc4_debug_rollout_state(cc4_handle* h, int64_t* out /* [22] */) {
   if (!h->d_rcnt) { h->err = "cc4_debug_rollout_state: no rollout was begun on this handle"; return -2; }
   HIPCHK(h, hipSetDevice(h->cfg.device_id));
-  std::vector<uint32_t> rd(RPG * 32), cnt((size_t)h->run_P * RPG * cc4_handle::XRING);
+  std::vector<uint32_t> rd(32), cnt((size_t)h->run_P * RPG_MAX * cc4_handle::XRING);
   uint32_t fail = 0;
   HIPCHK(h, hipMemcpy(rd.data(), h->d_rready, rd.size() * 4, hipMemcpyDeviceToHost));
   HIPCHK(h, hipMemcpy(cnt.data(), h->d_rcnt, cnt.size() * 4, hipMemcpyDeviceToHost));
   HIPCHK(h, hipMemcpy(&fail, h->d_rfail, 4, hipMemcpyDeviceToHost));
-  out[0] = rd[0]; out[1] = rd[32]; out[2] = fail; out[3] = *reinterpret_cast<volatile uint32_t*>(h->h_xtimeout);
-  for (int slot = 0; slot < 4; ++slot) for (int g = 0; g < RPG; ++g) {
+  out[0] = fail; out[1] = *reinterpret_cast<volatile uint32_t*>(h->h_xtimeout);
+  for (int g = 0; g < h->rpg; ++g) out[2 + g] = rd[g];
+  for (int slot = 0; slot < 4; ++slot) for (int g = 0; g < h->rpg; ++g) {
     int64_t sum = 0;
-    for (int p = 0; p < h->run_P; ++p) sum += cnt[((size_t)p * RPG + g) * cc4_handle::XRING + slot];
-    out[4 + 2 * slot + g] = sum;
+    for (int p = 0; p < h->run_P; ++p) sum += cnt[((size_t)p * h->rpg + g) * cc4_handle::XRING + slot];
+    out[6 + 4 * slot + g] = sum;
   }
   return 0;
 }
@@ -1611,7 +1613,7 @@ int cc4_rollout_end(cc4_handle* h) {
   if (rollout_ready(h, "cc4_rollout_end")) return -2;
   HIPCHK(h, hipSetDevice(h->cfg.device_id));
   HIPCHK(h, hipStreamSynchronize(h->stream));
-  HIPCHK(h, hipStreamSynchronize(h->policy_stream));
+  for (int g = 0; g < RPG_MAX; ++g) HIPCHK(h, hipStreamSynchronize(h->gpolicy[g]));
   const int k = h->rollout_k;
   h->rollout_k = 0;
   uint32_t gate_failed = 0;
@@ -1623,6 +1625,21 @@ int cc4_rollout_end(cc4_handle* h) {
     return -6;
   }
   return 0;
+}
+// A whole rollout with a stand-in policy (0: random indices, 1: hash of the observations), driven from here: begin, the passes of all steps -- two
+// stream operations each (cc4_rollout_sync, the policy kernel) --, end.  What bench.py times as `policy_in_loop`, and what a trainer written against the C ABI would do.
+int cc4_rollout_standin(cc4_handle* h, int32_t k, int32_t policy, uint64_t seed0, uint32_t t0) {
+  int rc = cc4_rollout_begin(h, k);
+  if (rc) return rc;
+  // every policy group has a stream and a chain of its own: [publish of its pass of step j - 1 + gate of step j] -> policy of step j -> ...
+  for (int j = 0; j < k && !rc; ++j)
+    for (int g = 0; g < h->rpg && !rc; ++g) {
+      rc = cc4_rollout_sync(h, j > 0 ? g : -1, j - 1, g, j, nullptr);
+      if (!rc) rc = policy == 0 ? cc4_rollout_random_policy(h, g, j, seed0, t0 + (uint32_t)j, nullptr) : cc4_rollout_hash_policy(h, g, j, nullptr);
+    }
+  for (int g = 0; g < h->rpg && !rc; ++g) rc = cc4_rollout_sync(h, g, k - 1, -1, 0, nullptr);
+  const int end = cc4_rollout_end(h);
+  return rc ? rc : end;
 }
 int cc4_launches_per_step(cc4_handle* h) { return h ? h->ngroups : 0; }
 // host-side counters since cc4_create: steps issued by cc4_run_random_steps, microseconds the host spent enqueueing their step
@@ -1838,7 +1855,7 @@ int cc4_debug_copy_from_device(cc4_handle* h, void* host_dst, const void* device
   HIPCHK(h, hipSetDevice(h->cfg.device_id));
   if (join_groups(h)) return -1;
   HIPCHK(h, hipStreamSynchronize(h->stream));
-  if (h->policy_stream) HIPCHK(h, hipStreamSynchronize(h->policy_stream));
+  for (int g = 0; g < 4; ++g) if (h->gpolicy[g]) HIPCHK(h, hipStreamSynchronize(h->gpolicy[g]));
   HIPCHK(h, hipMemcpy(host_dst, device_src, bytes, hipMemcpyDeviceToHost));
   return 0;
 }

@@ -145,16 +145,39 @@ __global__ void k_rng_state(const EnvState* st, uint64_t* out, int n) {
 // ---------------------------------------------------------------- rollouts: the caller-side kernels (cc4_rollout_*)
 // gate of a policy pass: returns when every episode of policy group g has its packed row of the step in slot `slot` in memory (the step kernel
 // counts them per partition, RunArgs.act_ready), and hands the counters back zeroed.  One wave, partitions on lanes; gives up after `ticks`.
-__global__ __launch_bounds__(WAVE) void k_rollout_gate(uint32_t* cnt, int P, int ring, int g, int slot, int n, long long ticks, uint32_t* fail) {
+__global__ __launch_bounds__(WAVE) void k_rollout_gate(uint32_t* cnt, int P, int PG, int ring, int g, int slot, int n, long long ticks, uint32_t* fail) {
+  __builtin_amdgcn_s_setprio(3);      // these waves run in what the persistent kernel leaves of a CU, beside 23 of its waves per CU: ahead of them in the SIMDs' issue arbitration
   const long long t0 = wall_clock64();
   for (int p = (int)threadIdx.x; p < P; p += (int)blockDim.x) {
-    const int ne = (n - p + P - 1) / P;                       // episodes p, p + P, ..: index i is of group i % RPG
-    const int want = (ne - g + RPG - 1) / RPG;
+    const int ne = (n - p + P - 1) / P;                       // episodes p, p + P, ..: index i is of group i % PG
+    const int want = (ne - g + PG - 1) / PG;
     if (want <= 0) continue;
-    uint32_t* c = cnt + ((size_t)p * RPG + (size_t)g) * (size_t)ring + slot;
+    uint32_t* c = cnt + ((size_t)p * PG + (size_t)g) * (size_t)ring + slot;
     int naps = 1;
     while (__hip_atomic_load(c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (uint32_t)want) {
-      for (int q = 0; q < naps; ++q) __builtin_amdgcn_s_sleep(32);
+      for (int q = 0; q < naps; ++q) __builtin_amdgcn_s_sleep(8);
+      if (naps < 8) naps <<= 1;
+      if (wall_clock64() - t0 > ticks) { __hip_atomic_store(fail, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); break; }
+    }
+    __hip_atomic_store(c, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+}
+// publish and gate in one launch (cc4_rollout_sync): first the publish of a pass whose policy kernels precede this kernel on the stream (their stores
+// are in memory: a kernel boundary lies between), then the gate of the next pass.  Half the stream operations of the separate calls.
+__global__ __launch_bounds__(WAVE) void k_rollout_sync(uint32_t* ready, int pub_g, uint32_t pub_val, uint32_t* cnt, int P, int PG, int ring, int g, int slot, int n, long long ticks, uint32_t* fail) {
+  __builtin_amdgcn_s_setprio(3);      // these waves run in what the persistent kernel leaves of a CU, beside 23 of its waves per CU: ahead of them in the SIMDs' issue arbitration
+  // the publish: every CU partition's copy of the group's word (RunArgs.act_ready)
+  if (pub_g >= 0) for (int p = (int)threadIdx.x; p < P; p += (int)blockDim.x) __hip_atomic_store(ready + (size_t)p * 32 + pub_g, pub_val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  if (g < 0) return;
+  const long long t0 = wall_clock64();
+  for (int p = (int)threadIdx.x; p < P; p += (int)blockDim.x) {
+    const int ne = (n - p + P - 1) / P;
+    const int want = (ne - g + PG - 1) / PG;
+    if (want <= 0) continue;
+    uint32_t* c = cnt + ((size_t)p * PG + (size_t)g) * (size_t)ring + slot;
+    int naps = 1;
+    while (__hip_atomic_load(c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (uint32_t)want) {
+      for (int q = 0; q < naps; ++q) __builtin_amdgcn_s_sleep(8);
       if (naps < 8) naps <<= 1;
       if (wall_clock64() - t0 > ticks) { __hip_atomic_store(fail, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); break; }
     }
@@ -163,21 +186,25 @@ __global__ __launch_bounds__(WAVE) void k_rollout_gate(uint32_t* cnt, int P, int
 }
 // stand-in policies for one policy group (bench.py, tests): uniform random indices (the draws of k_random_actions), or indices computed FROM the
 // packed observations of the step before (a policy that ignores its input proves nothing about the hand-over)
-__global__ void k_rollout_random_policy(int32_t* act, int n, int P, int g, uint64_t seed0, uint32_t t) {
+// (threads over the GROUP's episodes only -- episode i of group g is e = ((i / P) * PG + g) * P + i % P --: a launch is a quarter of the batch's waves,
+// one dispatch round into the slots the persistent kernel leaves free)
+__device__ __forceinline__ int rollout_group_episode(int i, int P, int PG, int g) { return ((i / P) * PG + g) * P + i % P; }
+__global__ __launch_bounds__(WAVE) void k_rollout_random_policy(int32_t* act, int n, int P, int PG, int g, uint64_t seed0, uint32_t t) {
+  __builtin_amdgcn_s_setprio(3);      // these waves run in what the persistent kernel leaves of a CU, beside 23 of its waves per CU: ahead of them in the SIMDs' issue arbitration
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n * NBLUE) return;
-  const int e = i / NBLUE, b = i % NBLUE;
-  if ((e / P) % RPG != g) return;
-  act[i] = random_blue_action(seed0, t, e, b);
+  const int e = rollout_group_episode(i / NBLUE, P, PG, g), b = i % NBLUE;
+  if (e >= n) return;
+  act[e * NBLUE + b] = random_blue_action(seed0, t, e, b);
 }
 __device__ __host__ inline uint32_t rollout_obs_hash(const uint32_t* row) {      // 37 words of a packed observation row
   uint32_t hsh = 2166136261u;
   for (int w = 0; w < OBS_PACKED / 4; ++w) { hsh ^= row[w]; hsh *= 16777619u; }
   return hsh;
 }
-__global__ void k_rollout_hash_policy(int32_t* act, const uint8_t* packed, int n, int P, int g, uint32_t j) {
-  const int e = blockIdx.x * blockDim.x + threadIdx.x;
-  if (e >= n || (e / P) % RPG != g) return;
+__global__ __launch_bounds__(WAVE) void k_rollout_hash_policy(int32_t* act, const uint8_t* packed, int n, int P, int PG, int g, uint32_t j) {
+  __builtin_amdgcn_s_setprio(3);
+  const int e = rollout_group_episode(blockIdx.x * blockDim.x + threadIdx.x, P, PG, g);
+  if (e >= n) return;
   const uint32_t hsh = rollout_obs_hash(reinterpret_cast<const uint32_t*>(packed + (size_t)e * OBS_PACKED));
   for (int b = 0; b < NBLUE; ++b) act[e * NBLUE + b] = (int32_t)((hsh + 2654435761u * (uint32_t)(b + 1) + 40503u * j) % (uint32_t)(b == 4 ? ACT_LONG : ACT_SHORT));
 }

@@ -10,7 +10,3 @@
 #define CC4_PERSIST_MINW 6
 #endif
 __global__ __launch_bounds__(WAVE, CC4_PERSIST_MINW) void k_run_philox1(StepArgs a, RunArgs ra, XchgArgs x) { persist_loop<false>(a, ra, x); }
-// The same kernel at five waves per SIMD, for handles with a communicator: the all-gathers of the exchange run BESIDE this kernel, and RCCL's kernels
-// need more registers than the 32 per SIMD six 80-register waves leave over (r06: with the six-wave build a 40-step call sat in its slab waits until
-// the watchdog fired -- the all-gather never found a SIMD to run on).  One wave per CU less (cc4_comm_init) then leaves a SIMD at four waves.
-__global__ __launch_bounds__(WAVE, 5) void k_run_philox1x(StepArgs a, RunArgs ra, XchgArgs x) { persist_loop<false>(a, ra, x); }

@@ -25,6 +25,7 @@ __global__ void k_run_philox8(StepArgs a, int K, uint32_t t0, XchgArgs x);
 __global__ void k_run_philox1m(StepArgs a, int K, uint32_t t0, XchgArgs x);
 __global__ void k_run_philox1(StepArgs a, RunArgs ra, XchgArgs x);
 __global__ void k_run_philox1x(StepArgs a, RunArgs ra, XchgArgs x);
+__global__ void k_run_philox1r(StepArgs a, RunArgs ra, XchgArgs x);
 __global__ void k_run_pcg(StepArgs a, RunArgs ra, XchgArgs x);
 // reset and helpers (cc4_k_misc.hip)
 __global__ void k_reset(ResetArgs a);
@@ -36,9 +37,10 @@ __global__ void k_unpack_obs(const uint8_t* __restrict__ packed, uint8_t* __rest
 __global__ void k_set_seed(EnvState* st, EnvCold* cold, size_t cold_row, const uint64_t* seeds, int n, int rng_mode);
 __global__ void k_set_rng_state(EnvState* st, const uint64_t* w, int n);
 __global__ void k_rng_state(const EnvState* st, uint64_t* out, int n);
-__global__ void k_rollout_gate(uint32_t* cnt, int P, int ring, int g, int slot, int n, long long ticks, uint32_t* fail);
-__global__ void k_rollout_random_policy(int32_t* act, int n, int P, int g, uint64_t seed0, uint32_t t);
-__global__ void k_rollout_hash_policy(int32_t* act, const uint8_t* packed, int n, int P, int g, uint32_t j);
+__global__ void k_rollout_gate(uint32_t* cnt, int P, int PG, int ring, int g, int slot, int n, long long ticks, uint32_t* fail);
+__global__ void k_rollout_sync(uint32_t* ready, int pub_g, uint32_t pub_val, uint32_t* cnt, int P, int PG, int ring, int g, int slot, int n, long long ticks, uint32_t* fail);
+__global__ void k_rollout_random_policy(int32_t* act, int n, int P, int PG, int g, uint64_t seed0, uint32_t t);
+__global__ void k_rollout_hash_policy(int32_t* act, const uint8_t* packed, int n, int P, int PG, int g, uint32_t j);
 __global__ void k_pack_obs_rows(uint8_t* packed, const int32_t* obs, int n);
 __global__ void k_digest(const EnvState* st, const EnvCold* cold, size_t cold_row, const int32_t* obs, const float* reward,
                          const uint8_t* done, const uint32_t* err, const int32_t* actions, uint64_t* out, int n);

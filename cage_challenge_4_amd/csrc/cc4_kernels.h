@@ -4,7 +4,8 @@
 //   cc4_k_pcg.hip      numpy-stream mode: k_step<LOG>, k_run_pcg
 //   cc4_k_philox4.hip  counter mode, four wavefronts per episode: k_step_philox<LOG, MINW>, k_run_philox, k_run_philox8
 //   cc4_k_philox1.hip  counter mode, one wavefront per episode: k_step_philox1<LOG>, k_run_philox1m (cc4_philox1_body.h: the step's body)
-//   cc4_k_run1.hip     the persistent kernel of large batches: k_run_philox1, k_run_philox1x (cc4_persist.h: its schedule, shared with k_run_pcg)
+//   cc4_k_run1.hip     the persistent kernel of large batches: k_run_philox1 (cc4_persist.h: its schedule, shared with k_run_pcg)
+//   cc4_k_run1x.hip    its other builds: k_run_philox1x (beside RCCL), k_run_philox1r (rollouts with the policy in the loop)
 //   cc4_k_misc.hip     k_reset and the small helpers (exchange gate, CU discovery, stand-in policies, digest, ...)
 // No MFMA anywhere: the path is integer / indexing.
 #pragma once
@@ -255,8 +256,7 @@ struct RunArgs {
   // (nph runs in all, K steps).  Inside a run the agent part stays in LDS -- no write-back and re-stage between the steps, one ticket, one
   // progress wait and one store drain per run instead of per step; the short runs at the end keep the launch's tail one step long.
   int SA, nA, SB, nB, nph;
-  int pool;                    // schedule: 0 = per-CU partitions, a tail shared inside the XCD (r04 / r05); 1 = XCD pools (experiment);
-                               // 2 = per-CU partitions BALANCED inside the XCD while the call runs (r06, below)
+  int pool;                    // (2: the balanced schedule below -- the only one since r06; r05's tail-only sharing and the XCD pools experiment are in docs/HISTORY.md)
   uint32_t base;
   uint32_t* ticket_next;
   uint8_t xcc_pool[8];         // XCC id -> pool, 0xFF: no such XCD
@@ -275,21 +275,23 @@ struct RunArgs {
   // the caller behind its policy kernels, cc4_rollout_publish); it reads slot j % 2 of `act` with system-scope loads, writes its packed
   // observation row into slab j % ring with system-scope stores (XchgArgs.slab) and counts itself in cnt[(e % P) * PG + g][j % ring] once that
   // row is in memory -- what the gate of the caller's next policy pass waits for (cc4_rollout_wait_obs).  Every step is an item of its own.
-  const uint32_t* act_ready;   // [PG][32 words] (a cache line per group), or null: no rollout
+  const uint32_t* act_ready;   // [P][32 words]: one cache line per CU partition, word g = the steps of policy group g whose actions are published -- the
+                               // publisher writes all P copies, a wave polls its own CU's (thousands of waves polling ONE uncached line starve the very
+                               // store they wait for: ~50 us per pass, profiles/r06_rollout.txt); null: no rollout
   const int32_t* act;          // [2][n][5]
   int PG;
   long long act_wait_ticks;    // watchdog: a step that waits longer for its actions gives up, raises XchgArgs.timeout, and every later wait returns at once
 };
 // lane 0: the actions of step j for policy group g are published.  Polls a device word at a growing interval (see xchg_wait_slab).
-__device__ __forceinline__ void rollout_wait_actions(const RunArgs& ra, const XchgArgs& x, int g, uint32_t j) {
-  const uint32_t* w = ra.act_ready + (size_t)g * 32;
+__device__ __forceinline__ void rollout_wait_actions(const RunArgs& ra, const XchgArgs& x, int line, int g, uint32_t j) {
+  const uint32_t* w = ra.act_ready + (size_t)line * 32 + g;
   if (__hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) > j) return;
   if (__hip_atomic_load(x.timeout, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM)) return;
   const long long w0 = wall_clock64();
   int naps = 1;
   while (__hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) <= j) {
-    for (int i = 0; i < naps; ++i) __builtin_amdgcn_s_sleep(64);
-    if (naps < 8) naps <<= 1;
+    for (int i = 0; i < naps; ++i) __builtin_amdgcn_s_sleep(32);
+    if (naps < 4) naps <<= 1;
     if (wall_clock64() - w0 > ra.act_wait_ticks || __hip_atomic_load(x.timeout, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM)) {
       __hip_atomic_store(x.timeout, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
       __hip_atomic_store(x.timeout_host, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
@@ -311,7 +313,7 @@ __device__ __forceinline__ int cu_slot() {
   return (int)(((xcc & 7u) << 8) | ((hw >> 8) & 0xFFu));
 }
 constexpr uint32_t TK_SHARED = 0x80000000u;
-constexpr int RPG = 2;      // policy groups of a rollout: group of episode e = (e / P) % RPG
+constexpr int RPG_MAX = 4;  // policy groups of a rollout (cc4_handle::rpg of them, CC4_ROLLOUT_GROUPS): group of episode e = (e / P) % groups -- the others step while one group's policy pass is under way
 struct ResetArgs {
   EnvState* st; EnvCold* cold; const uint64_t* seeds; const uint8_t* env_mask;
   int32_t* obs; float* reward; uint8_t* done; uint32_t* err; uint8_t* mask;

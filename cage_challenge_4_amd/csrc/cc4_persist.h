@@ -3,25 +3,21 @@
 #pragma once
 #include "cc4_kernels.h"
 
-// Tail of a call: a CU whose own partition is handed out takes items from the partition of another CU OF ITS XCD that has the most left.
-// The XCD's L2 is the coherence point of its CUs (vector stores write through to it), but a CU's L1 is not refreshed by another CU's
-// stores -- so from the moment a partition is shared (bit 31 of its ticket counter, set by the first thief; every ticket handed out
-// afterwards carries it) every item of it starts with an agent-scope acquire (buffer_inv sc1: the CU's L1 dropped), on the owner's waves
-// and the thieves' alike.  Items handed out before the bit was set were all the owner's own and read what that CU wrote itself.
-// Never across XCDs: their L2s do not agree without a write-back.
-// ---- experiment: the red policy phase with the agents of G episodes side by side on ONE wave.  Lane 8 g + r runs
-// step_red_policy_tick of agent r of the wave's g-th episode -- what a group schedule would do in the phase that is 31 % of a step -- on the live
-// state of the batch (agent parts staged into LDS as in the step kernel, nothing written back).  G = 1 is today's lane layout.  cyc[block] = the
-// wave's cycles in the phase; the launch duration (events) / episodes = what the phase costs an episode at that grouping and residency.
-template <bool PCG>
+// The schedule (RunArgs).  The batch is cut into one partition per CU (episode e -> partition e % P); a partition's tickets hand out RUNS of
+// consecutive steps of its episodes in step-major order; a run of episode e may start once progress[e] says the steps before it are done.  A wave
+// normally serves its own CU's partition -- an episode then stays on one CU, whose waves share a write-through L1: no cache maintenance -- but it
+// looks at the ticket counters of its XCD's partitions before every run and takes the run from the partition that lags most when its own is more
+// than `thr` tickets ahead of it, or handed out.  The progress word carries the CU that ran the episode's last run: a run on ANOTHER CU starts with
+// an agent-scope acquire (buffer_inv sc1; nothing less drops stale L1 lines: tools/micro/l1_inv_scope.hip).  Never across XCDs: their L2s do not
+// agree without a write-back.  The hand-over between two waves: the writer drains its stores (s_waitcnt vmcnt(0): the L1 is write-through, a drained
+// store is in the XCD's L2), then publishes the progress word; the reader reads the word, then the rows.
+// ROLLOUT: the build that serves cc4_rollout_begin (k_run_philox1r) -- the actions-in protocol is compiled into that kernel only (in the others its code
+// cost the headline kernel 30 more spilled registers)
+template <bool PCG, bool ROLLOUT = false>
 __device__ __forceinline__ void persist_loop(StepArgs a, RunArgs ra, const XchgArgs x) {
   // (the item travels from lane 0 to the wave through v_readfirstlane, not through LDS)
   const int lane = threadIdx.x;
   const int my_slot = cu_slot();
-  // The CU's partition, from the table of the compute units this device showed at first use (a CU that is not in it only helps out)
-  int part = ra.pool ? -1 : ra.slot_part[my_slot] - 1;  // schedule 0 (lane 0's copy is the one that counts)
-  bool mine = false;                     // lane 0: this CU owns `part` (claimed or adopted)
-  bool stealing = false;                 // lane 0: `part` belongs to another CU of this XCD; its shared bit is set
   a.prof = nullptr; a.obs8 = nullptr; a.ext = nullptr;
   uint32_t seen_gathered = 0;
   unsigned long long tl_first = 0, tl_last = 0, tl_items = 0;
@@ -32,22 +28,78 @@ __device__ __forceinline__ void persist_loop(StepArgs a, RunArgs ra, const XchgA
     if (x.slab && pend_e >= 0) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); if (lane == 0) xchg_count(x, pend_k, pend_e % ra.G); pend_e = -1; }
   };
   const uint32_t my_xcc = __builtin_amdgcn_s_getreg(((4 - 1) << 11) | (0 << 6) | 20) & 7u;    // HW_REG_XCC_ID
-  const int xlo = ra.xcc_lo[my_xcc], xn = ra.xcc_n[my_xcc];     // schedule 2: this XCD's partitions
-  int own = -1; uint32_t my_id = 511u;                           // schedule 2: the CU's own partition (-1: none), its id in the progress words
-  if (ra.pool == 2) {
-    own = ra.slot_part[my_slot] - 1;
-    if (own >= 0) my_id = (uint32_t)own + 1u;
-    if (xn <= 0) { tl_flush(); return; }
-  }
-  if (ra.pool == 1) {
-    const uint32_t xcc = my_xcc;
-    part = ra.xcc_pool[xcc] == 0xFF ? -1 : (int)ra.xcc_pool[xcc];
-    if (part < 0) { tl_flush(); return; }                             // (an XCD the discovery pass did not see: its waves do nothing)
-    if (lane == 0) __hip_atomic_store(&ra.ticket_next[part * TK_STRIDE], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  }
+  const int xlo = ra.xcc_lo[my_xcc], xn = ra.xcc_n[my_xcc];     // this XCD's partitions
+  // the CU's own partition, from the table of the compute units this device showed at first use (-1: a CU that is not in it only helps out), and
+  // its id in the progress words
+  const int own = ra.slot_part[my_slot] - 1;
+  const uint32_t my_id = own >= 0 ? (uint32_t)own + 1u : 511u;
+  if (xn <= 0) { tl_flush(); return; }
   for (;;) {
-    int res_e = -3, res_k = 0, res_sh = 0, res_part = -1;            // -3: nothing from `part`: search
-    if (ra.pool == 2) {
+    int res_e = -5, res_k = 0, res_sh = 0;                            // -5: look again, -4: leave
+    if (ROLLOUT && ra.act_ready) {
+      // ---- a rollout: every (partition, policy group) has a ticket counter of its own (words 0 .. PG-1 of the partition's ticket line), and a wave
+      // only ever draws a ticket of a group whose NEXT step is published -- it never holds a ticket it cannot run.  (With ONE step-major sequence over
+      // all groups the waves piled up on tickets of unpublished passes while the published group's next tickets lay further down the sequence: the
+      // groups advanced in lock step, 114 us per step whatever their number -- profiles/r06_rollout.txt.)  A CU serves its own partition only.
+      if (own < 0) { flush_pending(); tl_flush(); return; }
+      if (lane == 0) {
+        const int ne = (a.n - own + ra.P - 1) / ra.P;
+        const uint32_t* rdy = ra.act_ready + (size_t)own * 32;
+        uint32_t* tkl = ra.ticket + (size_t)own * TK_STRIDE;
+        int naps = 1;
+        const long long w0 = wall_clock64();
+        res_e = -4;
+        for (;;) {
+          int best_g = -1; uint32_t best_j = 0xFFFFFFFFu; bool left = false;
+          for (int g = 0; g < ra.PG; ++g) {
+            const int ng = (ne - g + ra.PG - 1) / ra.PG;
+            if (ng <= 0) continue;
+            const uint32_t t = __hip_atomic_load(tkl + g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (t >= (uint32_t)(ng * ra.K)) continue;
+            left = true;
+            const uint32_t j = t / (uint32_t)ng;
+            if (j < best_j && __hip_atomic_load(rdy + g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) > j) { best_j = j; best_g = g; }
+          }
+          if (!left) break;                                           // every group of this partition is handed out: leave
+          if (best_g >= 0) {
+            const int ng = (ne - best_g + ra.PG - 1) / ra.PG;
+            const uint32_t t = __hip_atomic_fetch_add(tkl + best_g, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (t + 1u == (uint32_t)(ng * ra.K)) __hip_atomic_store(ra.ticket_next + (size_t)own * TK_STRIDE + best_g, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (t < (uint32_t)(ng * ra.K)) {
+              const int j = (int)(t / (uint32_t)ng), ee = own + ((int)(t % (uint32_t)ng) * ra.PG + best_g) * ra.P;
+              uint32_t w;
+              while ((((w = __hip_atomic_load(&ra.progress[ee], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) & PG_STEPS) - ra.base) < (uint32_t)j) __builtin_amdgcn_s_sleep(8);
+              __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+              rollout_wait_actions(ra, x, own, best_g, (uint32_t)j);   // (another wave may have drawn the last published ticket in between: then this one is of the next step)
+              const uint32_t last = w >> 23;
+              res_e = ee; res_k = j; res_sh = (last != 0u && last != my_id) ? 1 : 0;
+              break;
+            }
+            continue;
+          }
+          // nothing is published that this partition has not handed out: wait (a growing nap, the watchdog of the action waits)
+          for (int q = 0; q < naps; ++q) __builtin_amdgcn_s_sleep(32);
+          if (naps < 4) naps <<= 1;
+          if (__hip_atomic_load(x.timeout, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) || wall_clock64() - w0 > ra.act_wait_ticks) {
+            __hip_atomic_store(x.timeout, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            __hip_atomic_store(x.timeout_host, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            // give up on the policy: run what is left with whatever the slots hold (cc4_rollout_end reports it)
+            for (int g = 0; g < ra.PG && res_e == -4; ++g) {
+              const int ng = (ne - g + ra.PG - 1) / ra.PG;
+              if (ng <= 0) continue;
+              const uint32_t t = __hip_atomic_fetch_add(tkl + g, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+              if (t + 1u == (uint32_t)(ng * ra.K)) __hip_atomic_store(ra.ticket_next + (size_t)own * TK_STRIDE + g, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+              if (t < (uint32_t)(ng * ra.K)) {
+                const int j = (int)(t / (uint32_t)ng), ee = own + ((int)(t % (uint32_t)ng) * ra.PG + g) * ra.P;
+                while (((__hip_atomic_load(&ra.progress[ee], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & PG_STEPS) - ra.base) < (uint32_t)j) __builtin_amdgcn_s_sleep(8);
+                res_e = ee; res_k = j; res_sh = 1;
+              }
+            }
+            if (res_e != -4) break;
+          }
+        }
+      }
+    } else {
       // all lanes: where the XCD's partitions stand
       const int q = xlo + lane;
       uint32_t tk = 0xFFFFFFFFu, tot_q = 0;
@@ -77,102 +129,20 @@ __device__ __forceinline__ void persist_loop(StepArgs a, RunArgs ra, const XchgA
         if (t + 1u == (uint32_t)(ne * ra.nph)) __hip_atomic_store(&ra.ticket_next[tp * TK_STRIDE], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (t < (uint32_t)(ne * ra.nph)) {
           const int j = (int)(t / (uint32_t)ne);
-          int i = (int)(t % (uint32_t)ne), pg = 0;
-          if (ra.act_ready) {
-            // a rollout: the tickets of a step serve one policy group after the other (episode index i of the partition is of group i % PG) --
-            // while one group's episodes wait for their policy pass, the CU's waves hold tickets of the other's
-            for (; pg < ra.PG; ++pg) { const int c = (ne - pg + ra.PG - 1) / ra.PG; if (i < c) { i = i * ra.PG + pg; break; } i -= c; }
-          }
-          const int ee = tp + i * ra.P;
+          const int ee = tp + (int)(t % (uint32_t)ne) * ra.P;
           int k, len; run_span(ra, j, k, len);
           uint32_t w;
           while ((((w = __hip_atomic_load(&ra.progress[ee], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) & PG_STEPS) - ra.base) < (uint32_t)k) __builtin_amdgcn_s_sleep(8);
           __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
           if (x.slab) xchg_wait_slab(x, (uint32_t)k, seen_gathered);
-          if (ra.act_ready) rollout_wait_actions(ra, x, pg, (uint32_t)k);
           const uint32_t last = w >> 23;
           res_e = ee; res_k = j; res_sh = (last != 0u && last != my_id) ? 1 : 0;     // the episode's last run was on another CU: its lines in this CU's L1 may be stale
         }
       }
-    } else if (ra.pool) {
-      if (lane == 0) {
-        const int ne = (a.n - part + ra.P - 1) / ra.P;                // episodes part, part + P, part + 2 P, ..
-        const uint32_t t = __hip_atomic_fetch_add(&ra.ticket[part * TK_STRIDE], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        res_e = -4;                                                   // the pool is handed out: leave
-        if (t < (uint32_t)(ne * ra.nph)) {
-          const int j = (int)(t / (uint32_t)ne), ee = part + (int)(t % (uint32_t)ne) * ra.P;
-          int k, len; run_span(ra, j, k, len);
-          while (__hip_atomic_load(&ra.progress[ee], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - ra.base < (uint32_t)k) __builtin_amdgcn_s_sleep(8);
-          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-          if (x.slab) xchg_wait_slab(x, (uint32_t)k, seen_gathered);
-          res_e = ee; res_k = j; res_sh = 2;
-        }
-      }
-    } else
-    if (lane == 0) {
-      if (part >= 0 && !mine && !stealing) {
-        int exp = 0;                                                  // the CU's own partition: claim it (or find it claimed by this CU already)
-        mine = __hip_atomic_compare_exchange_strong(&ra.owner[part], &exp, my_slot + 1, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) || exp == my_slot + 1;
-        if (!mine) part = -1;                                         // somebody else's by now (adopted): search
-      }
-      if (part >= 0) {
-        const bool thief = !mine;                                     // (a partition this wave steals from: `part` was set by the search below)
-        const int ne = (a.n - part + ra.P - 1) / ra.P;                // episodes part, part + P, part + 2 P, ..
-        const uint32_t tr = __hip_atomic_fetch_add(&ra.ticket[part], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const uint32_t t = tr & ~TK_SHARED;
-        if (t < (uint32_t)(ne * ra.nph)) {
-          // (r05, both measured and dropped: asking for the next ticket ahead of the previous item's drain -- the CU's other waves fill that gap
-          // already, 813-821 vs 819 M; and shares of the batch per XCD following the XCDs' measured speed -- which XCDs are slow changes from
-          // box to box and call to call, the controller chases noise: 20-step calls 812-822 -> 789-796 M.  profiles/r05_xcd_balance.txt)
-          // (a ready queue per partition -- a wave never holds an item whose predecessor is still running -- was built and measured in r05:
-          // bit-exact, 2-3.5 % slower, and the launch's tail stayed: profiles/r05_ready_queue_ab.txt)
-          const int j = (int)(t / (uint32_t)ne), ee = part + (int)(t % (uint32_t)ne) * ra.P;
-          int k, len; run_span(ra, j, k, len);
-          while (__hip_atomic_load(&ra.progress[ee], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - ra.base < (uint32_t)k) __builtin_amdgcn_s_sleep(8);
-          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");      // nothing the item reads may be read ahead of the flag (compiler and wave)
-          if (x.slab) xchg_wait_slab(x, (uint32_t)k, seen_gathered);   // the exchange: slab k % ring must have been gathered (tickets are step-major: normally long ago)
-          res_e = ee; res_k = j; res_sh = (thief || (tr & TK_SHARED)) ? 1 : 0;
-        }
-      }
-      res_part = part;
     }
     const int e = __builtin_amdgcn_readfirstlane(res_e);              // (all lanes are active here: the first active lane is lane 0)
     if (e == -4) { flush_pending(); tl_flush(); return; }
     if (e == -5) continue;
-    if (e == -3) {
-      // search (all lanes): the partition with the most items left among those nobody owns and those owned by a CU of this XCD
-      const int cur = __builtin_amdgcn_readfirstlane(res_part);
-      int best_rem = 0, best_q = -1, best_ow = 0;
-      for (int q0 = 0; q0 < ra.P; q0 += WAVE) {
-        const int q = q0 + lane;
-        if (q < ra.P && q != cur) {
-          const int ow = __hip_atomic_load(&ra.owner[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          if (ow == 0 || (((ow - 1) >> 8) == (my_slot >> 8))) {
-            const uint32_t t = __hip_atomic_load(&ra.ticket[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & ~TK_SHARED;
-            const uint32_t tot = (uint32_t)(((a.n - q + ra.P - 1) / ra.P) * ra.nph);
-            const int rem = t < tot ? (int)(tot - t) : 0;
-            if (rem > best_rem) { best_rem = rem; best_q = q; best_ow = ow; }
-          }
-        }
-      }
-#pragma unroll
-      for (int off = 32; off >= 1; off >>= 1) {
-        const int r2 = __shfl_xor(best_rem, off), q2 = __shfl_xor(best_q, off), o2 = __shfl_xor(best_ow, off);
-        if (r2 > best_rem || (r2 == best_rem && q2 > best_q)) { best_rem = r2; best_q = q2; best_ow = o2; }
-      }
-      best_rem = __builtin_amdgcn_readfirstlane(best_rem); best_q = __builtin_amdgcn_readfirstlane(best_q); best_ow = __builtin_amdgcn_readfirstlane(best_ow);
-      if (best_rem <= 0) { flush_pending(); tl_flush(); return; }     // nothing left anywhere this wave may touch
-      part = best_q; mine = false; stealing = false;
-      if (lane == 0) {
-        if (best_ow == 0) {                                           // nobody's: adopt it (the CAS in the item path), no sharing needed unless that fails
-          int exp = 0;
-          mine = __hip_atomic_compare_exchange_strong(&ra.owner[part], &exp, my_slot + 1, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) || exp == my_slot + 1;
-          if (!mine && (((exp - 1) >> 8) != (my_slot >> 8))) part = -1;   // claimed meanwhile by a CU of another XCD: not ours to touch
-        }
-        if (part >= 0 && !mine) { (void)__hip_atomic_fetch_or(&ra.ticket[part], TK_SHARED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); stealing = true; }
-      }
-      continue;
-    }
     int run_k0, run_len;
     run_span(ra, __builtin_amdgcn_readfirstlane(res_k), run_k0, run_len);
     const int shared = __builtin_amdgcn_readfirstlane(res_sh);
@@ -198,7 +168,7 @@ __device__ __forceinline__ void persist_loop(StepArgs a, RunArgs ra, const XchgA
     }
     int lane_i = (int)threadIdx.x;
     asm volatile("" : "+v"(lane_i));
-    if (ra.act_ready) { a.actions = ra.act + (size_t)(item_k & 1u) * (size_t)a.n * NBLUE; a.rand_out = nullptr; a.act_sys = 1; }
+    if (ROLLOUT && ra.act_ready) { a.actions = ra.act + (size_t)(item_k & 1u) * (size_t)a.n * NBLUE; a.rand_out = nullptr; a.act_sys = 1; }
     if constexpr (PCG) {
       StepArgs b = a;
       b.rand_t = ra.t0 + item_k; b.full_obs = (a.full_obs && item_k == 0) ? 1 : 0;
@@ -230,7 +200,7 @@ __device__ __forceinline__ void persist_loop(StepArgs a, RunArgs ra, const XchgA
         if (lane == 0 && pend_e >= 0) xchg_count(x, pend_k, pend_e % ra.G);
         pack_row_from_obs(x.slab + ((size_t)(item_k % (uint32_t)x.ring) * (size_t)a.n + (size_t)e) * OBS_PACKED, a.obs + (size_t)e * OBS_TOTAL, lane);
         pend_e = e; pend_k = item_k;
-        if (ra.act_ready) {
+        if (ROLLOUT && ra.act_ready) {
           // a rollout: the caller's next policy pass waits for this count -- not deferred to the wave's next item
           asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
           if (lane == 0) xchg_count(x, item_k, (e % ra.P) * ra.PG + (e / ra.P) % ra.PG);
@@ -238,7 +208,7 @@ __device__ __forceinline__ void persist_loop(StepArgs a, RunArgs ra, const XchgA
         }
       }
     }
-    if (lane == 0) __hip_atomic_store(&ra.progress[e], (ra.base + item_k + 1u) | (ra.pool == 2 ? my_id << 23 : 0u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (lane == 0) __hip_atomic_store(&ra.progress[e], (ra.base + item_k + 1u) | (my_id << 23), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (ra.timeline) { tl_last = wall_clock64(); ++tl_items; }
   }
 }

@@ -379,20 +379,26 @@ class CC4VecEnv:
                     self._chk(rc, 'cc4_step_group_device')
         return 0.0
 
-    def run_rollout(self, k, policy='random', seed0=0, t0=0):
+    def run_rollout(self, k, policy='random', seed0=0, t0=0, native=False):
         """A k-step rollout with the policy in the loop and ONE launch of the step engine (cc4_rollout_begin .. cc4_rollout_end, include/cc4.h): per step
         and policy group the gate on the last step's observations, the stand-in policy ('random': the draws of run_random_steps / run_policy_steps;
         'hash': action indices computed from each episode's packed observation row of the step before), the publish -- all enqueued behind the launch
         on the handle's policy stream.  A policy of the caller's takes the stand-in's place between cc4_rollout_wait_obs and cc4_rollout_publish."""
         lib, h = self.lib, self._h
+        if native:       # the same sequence enqueued by the library itself (cc4_rollout_standin): no Python between the stream operations
+            self._chk(lib.cc4_rollout_standin(h, int(k), 0 if policy == 'random' else 1, ctypes.c_uint64(seed0), ctypes.c_uint32(t0)), 'cc4_rollout_standin')
+            return 0.0
         self._chk(lib.cc4_rollout_begin(h, int(k)), 'cc4_rollout_begin')
+        G, blk = ctypes.c_int32(), ctypes.c_int32()
+        rc = lib.cc4_rollout_groups(h, ctypes.byref(G), ctypes.byref(blk))
         s0 = ctypes.c_uint64(seed0)
-        rc = 0
         for j in range(int(k)):
-            for g in range(2):
-                rc = rc or lib.cc4_rollout_wait_obs(h, g, j, None)
+            for g in range(G.value):
+                # on the group's own policy stream: one operation for the publish of its last pass and the gate of this one (cc4_rollout_sync), then the policy
+                rc = rc or lib.cc4_rollout_sync(h, g if j > 0 else -1, j - 1, g, j, None)
                 rc = rc or (lib.cc4_rollout_random_policy(h, g, j, s0, ctypes.c_uint32(t0 + j), None) if policy == 'random' else lib.cc4_rollout_hash_policy(h, g, j, None))
-                rc = rc or lib.cc4_rollout_publish(h, g, j, None)
+        for g in range(G.value):
+            rc = rc or lib.cc4_rollout_sync(h, g, int(k) - 1, -1, 0, None)
         end = lib.cc4_rollout_end(h)
         self._chk(rc or end, 'cc4_rollout')
         return 0.0

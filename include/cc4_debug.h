@@ -25,7 +25,7 @@ int cc4_get_gather_log(cc4_handle* h, uint8_t* out, int32_t first, int32_t count
 int cc4_debug_comm_delay_us(cc4_handle* h, int us);
 
 /* debug: where a rollout stands (see csrc/cc4_api.hip) */
-int cc4_debug_rollout_state(cc4_handle* h, int64_t* out /* [12] */);
+int cc4_debug_rollout_state(cc4_handle* h, int64_t* out /* [22] */);
 /* test hook: `bytes` bytes of device memory of this handle's device -- e.g. an action slot of a rollout (cc4_rollout_actions), packed observation rows
  * (cc4_rollout_obs_packed) -- copied to the host, behind everything enqueued on the handle's streams. */
 int cc4_debug_copy_from_device(cc4_handle* h, void* host_dst, const void* device_src, size_t bytes);

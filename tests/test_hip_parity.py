@@ -410,8 +410,8 @@ def test_rollout_with_the_policy_in_the_loop_matches_the_oracle_at_every_step(n,
     assert np.array_equal(dev.reset(seeds=seed0), o_prev)
     assert dev.run_kernel_for(20) == 'k_run_philox1'
     t = 0
-    for K in (12, 25, 31, 10):
-        dev.run_rollout(K, policy, seed0, t)
+    for c, K in enumerate((12, 25, 31, 10)):
+        dev.run_rollout(K, policy, seed0, t, native=(c % 2 == 1))        # (the passes enqueued from Python / by cc4_rollout_standin)
         acts = []
         for j in range(K):
             a = random_actions(seed0, t + j, n) if policy == 'random' else _hash_policy(_pack_rows(o_prev), j)
@@ -441,7 +441,7 @@ def test_rollout_watchdog_reports_a_pass_that_was_never_published(monkeypatch):
     from cage_challenge_4_amd._lib import CC4Error
     dev = _dev(8192, steps=50, rng_mode=1, autoreset=True, strict=False); dev.reset(seeds=3)
     dev._chk(dev.lib.cc4_rollout_begin(dev._h, 10), 'cc4_rollout_begin')
-    for g in range(2):                                       # step 0 only
+    for g in range(4):                                       # step 0 only
         dev.lib.cc4_rollout_wait_obs(dev._h, g, 0, None); dev.lib.cc4_rollout_random_policy(dev._h, g, 0, 3, 0, None); dev.lib.cc4_rollout_publish(dev._h, g, 0, None)
     assert dev.lib.cc4_rollout_end(dev._h) == -6
     assert b'waited longer than' in dev.lib.cc4_last_error(dev._h)
@@ -1237,6 +1237,9 @@ def test_bench_line_contract():
     # r05: the consumable rates beside the closed loop -- actions written on the device every step, and the exchange on a one-rank communicator
     p = d['policy_in_loop']
     assert p['run_kernel'] == 'k_step_philox1' and 50e6 < p['value'] <= p['grouped']['value'] * 1.05 and p['grouped']['value'] < d['value'] * 1.05
+    # r06: the rollout form beside it -- one launch of the persistent kernel's rollout build per region, the policy behind gates and publishes
+    q = p['rollout']
+    assert 'skipped' in q or (q['run_kernel'] == 'k_run_philox1r' and 50e6 < q['value'] < d['value'] * 1.05 and q['policy_ops_per_step'] >= 2)
     x = d['exchange_world1']
     assert 'skipped' in x or (x['envs_1024']['exchange']['in_kernel'] and x['envs_1024']['run_kernel'] == 'k_run_philox' and
                               x['envs_8192']['run_kernel'] == 'k_run_philox1x' and x['envs_8192']['exchange']['watchdog_timeouts'] == 0 and

@@ -13,9 +13,9 @@ for K in (1, 2, 3):
     rc = lib.cc4_rollout_begin(h, K)
     print('begin', rc, lib.cc4_last_error(h) if rc else '')
     for j in range(K):
-        for g in range(2):
+        for g in range(4):
             a = lib.cc4_rollout_wait_obs(h, g, j, None); b = lib.cc4_rollout_random_policy(h, g, j, ctypes.c_uint64(5), j, None); c = lib.cc4_rollout_publish(h, g, j, None)
             if a or b or c: print('enqueue', j, g, a, b, c, lib.cc4_last_error(h))
     e = lib.cc4_rollout_end(h)
-    st = (ctypes.c_int64 * 12)(); lib.cc4_debug_rollout_state(h, st); print('state', list(st))
+    st = (ctypes.c_int64 * 24)(); lib.cc4_debug_rollout_state(h, st); print('state', list(st))
     print('K', K, 'end rc', e, 'in', round(time.time() - t0, 3), 's', lib.cc4_last_error(h)[:80] if e else '')
