@@ -245,7 +245,8 @@ static int sync_all(cc4_handle* h) {
   // (!groups_busy: whatever the group streams were given, the main stream already waits for -- join_groups, or the joined end of
   // cc4_run_random_steps -- and a host wait on an idle stream is not free: ~8 us each inside a short timed region)
   for (int g = h->ngroups - 1; g >= 1; --g) if (h->groups_busy) HIPCHK(h, hipStreamSynchronize(h->gstream[g]));
-  HIPCHK(h, hipStreamSynchronize(h->stream));
+  // (a query first: behind a call that ended with a synchronisation of its own -- cc4_run_random_steps -- the stream is idle, and asking is cheaper than waiting)
+  if (hipStreamQuery(h->stream) != hipSuccess) { (void)hipGetLastError(); HIPCHK(h, hipStreamSynchronize(h->stream)); }
   h->groups_busy = false;
   h->joined_between = true;
   return 0;
@@ -469,7 +470,8 @@ static int choose_run_form(cc4_handle* h, int margin, int persist_margin = -1) {
     const int grid = (per_cu - persist_margin) * h->cus;
     // batches of more than the chip holds at once (with the tail shared, also just more).  The numpy-stream mode has no other one-launch form: there
     // the persistent kernel also serves batches from half the residency up (a partition of fewer episodes than the CU has waves just leaves waves idle)
-    if (per_cu - persist_margin > 0 && (cfg->num_envs > grid || (cfg->rng_mode == 0 && 2 * cfg->num_envs > grid))) h->persist_state = 0;
+    // (counter mode: what neither multi-step kernel holds -- 5121 .. 6144 episodes at 20 / 24 waves per CU -- is the persistent kernel's as well)
+    if (per_cu - persist_margin > 0 && (cfg->num_envs > grid || 2 * cfg->num_envs > grid)) h->persist_state = 0;
   }
   if (const char* v = getenv("CC4_PERSIST")) { if (atoi(v) == 0) h->persist_state = -1; }
   return 0;
@@ -527,6 +529,19 @@ int cc4_create(const cc4_config* cfg, cc4_handle** out) {
   cc4_handle* h = new cc4_handle();
   h->cfg = *cfg;
   *out = h;
+  // a host thread that waits for a launch spins (the calls of this library are short, and what follows a synchronisation is the next launch): the
+  // wake-up of a blocked wait costs more than a step of a small batch lasts.  CC4_HOST_WAIT=yield|block|auto chooses otherwise; ignored
+  // (hipErrorSetOnActiveProcess) when the process has initialised the device some other way already.
+  {
+    static std::once_flag once;
+    std::call_once(once, [] {
+      const char* v = getenv("CC4_HOST_WAIT");
+      unsigned flags = hipDeviceScheduleSpin;
+      if (v && !strcmp(v, "yield")) flags = hipDeviceScheduleYield; else if (v && !strcmp(v, "block")) flags = hipDeviceScheduleBlockingSync; else if (v && !strcmp(v, "auto")) flags = hipDeviceScheduleAuto;
+      (void)hipSetDeviceFlags(flags);
+      (void)hipGetLastError();
+    });
+  }
   HIPCHK(h, hipSetDevice(cfg->device_id));
   if (cc4_upload_pcg_tables() != hipSuccess) { h->err = "cc4_create: the numpy-stream kernel's jump table could not be uploaded"; return -1; }
   {

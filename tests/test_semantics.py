@@ -1,5 +1,6 @@
 """CPU: behaviours the reference's own tests pin (CybORG/Tests/test_cc4/*), re-expressed against the oracle.
 Each test names the reference test it follows."""
+import os
 import numpy as np
 import pytest
 from oracle_binding import OracleVecEnv
@@ -445,3 +446,20 @@ def test_counter_mode_generation_matches_the_reference_marginals(oracle_lib):
     for i in range(1500):
         GM.accumulate(pcg, GM.desc_from_true_state(env.true_state_json(i)))
     check_generation_marginals(pcg)
+
+
+def test_fsm_agent_reading_a_hostname_keyed_observation_of_an_unknown_host_is_on_the_references_crash_path(oracle_lib):
+    """VERDICT r05 missing 4.  A FiniteStateRedAgent that reads the observation of a SUBMITTED hostname-keyed action (PrivilegeEscalate / Impact /
+    DegradeServices through the `actions` dict) on a host whose hostname it has never seen: the reference files the host under host_states[None]
+    (FiniteStateRedAgent.py:190-236) -- no exception at that step -- and is then on a crash path: the next DiscoverRemoteSystems result it processes
+    raises ipaddress.AddressValueError (IPv4Address(None), :141-143), the phantom being chosen raises TypeError (:297-299 / :113).  Recorded from the
+    reference's own class by oracle/refgen/make_fsm_phantom_golden.py.  The engine flags the step that puts the agent on that path (E_UNREACHABLE,
+    csrc/cc4_engine.h fsm_observe): the wrappers raise CC4EngineError there -- one to a few steps before the reference's agent would have."""
+    import json
+    from conftest import ROOT
+    g = json.load(open(os.path.join(ROOT, 'tests', 'golden', 'fsm_phantom_host.json')))
+    assert g['at_the_observation'] == 'no exception' and g['host_states_keys'][-1] == 'None' and g['phantom']['state'] == 'K'
+    assert g['next_discover_remote_systems_result'] == 'AddressValueError' and g['phantom_chosen'] == 'TypeError'
+    src = open(os.path.join(ROOT, 'cage_challenge_4_amd', 'csrc', 'cc4_engine.h')).read()
+    i = src.index("// ip looked up through a known hostname; unknown -> reference would key host_states[None]")
+    assert 'set_err(x, E_UNREACHABLE)' in src[i:i + 300]
