@@ -276,7 +276,7 @@ static void launch_range(cc4_handle* h, StepArgs a, int e0, int e1, hipStream_t 
 #endif
     else hipExtLaunchKernelGGL((k_step_philox<false, CC4_SMALL_MINW>), grid, dim3(PT), sizeof(EnvState), st, start, stop, 0, a);
   } else {
-    if (full) hipExtLaunchKernelGGL(k_step<true>, grid, dim3(WAVE), lds1, st, start, stop, 0, a);
+    if (full || h->d_prof) hipExtLaunchKernelGGL(k_step<true>, grid, dim3(WAVE), lds1, st, start, stop, 0, a);
     else hipExtLaunchKernelGGL(k_step<false>, grid, dim3(WAVE), lds1, st, start, stop, 0, a);
   }
 }
@@ -529,15 +529,14 @@ int cc4_create(const cc4_config* cfg, cc4_handle** out) {
   cc4_handle* h = new cc4_handle();
   h->cfg = *cfg;
   *out = h;
-  // a host thread that waits for a launch spins (the calls of this library are short, and what follows a synchronisation is the next launch): the
-  // wake-up of a blocked wait costs more than a step of a small batch lasts.  CC4_HOST_WAIT=yield|block|auto chooses otherwise; ignored
-  // (hipErrorSetOnActiveProcess) when the process has initialised the device some other way already.
-  {
+  // how a host thread waits for the device is the runtime's default unless CC4_HOST_WAIT=spin|yield|block says otherwise (spinning by default was
+  // tried in r06: no measurable gain on a 20-step call, and the exchange's soak test failed once under it); ignored (hipErrorSetOnActiveProcess) when
+  // the process has initialised the device some other way already
+  if (const char* v = getenv("CC4_HOST_WAIT")) {
     static std::once_flag once;
-    std::call_once(once, [] {
-      const char* v = getenv("CC4_HOST_WAIT");
-      unsigned flags = hipDeviceScheduleSpin;
-      if (v && !strcmp(v, "yield")) flags = hipDeviceScheduleYield; else if (v && !strcmp(v, "block")) flags = hipDeviceScheduleBlockingSync; else if (v && !strcmp(v, "auto")) flags = hipDeviceScheduleAuto;
+    std::call_once(once, [v] {
+      unsigned flags = hipDeviceScheduleAuto;
+      if (!strcmp(v, "spin")) flags = hipDeviceScheduleSpin; else if (!strcmp(v, "yield")) flags = hipDeviceScheduleYield; else if (!strcmp(v, "block")) flags = hipDeviceScheduleBlockingSync;
       (void)hipSetDeviceFlags(flags);
       (void)hipGetLastError();
     });
@@ -596,6 +595,7 @@ int cc4_create(const cc4_config* cfg, cc4_handle** out) {
   h->cold_row = cold_row_bytes(cfg->steps);
   HIPCHK(h, row_alloc((void**)&h->d_cold, n * h->cold_row));
   if (cfg->rng_mode == 1) HIPCHK(h, hipMalloc(&h->d_reset_ws, n * RESET_WS_WORDS * sizeof(uint32_t)));   // the one-wave kernel's generation work area
+  else HIPCHK(h, hipMalloc(&h->d_reset_ws, n * 128 * sizeof(uint64_t)));                                 // numpy stream: the LCG window of the green actions (wave_green_exec), 1 KB per episode
   h->in_bytes = n * NBLUE * sizeof(int32_t) + n * NBLUE * MSG_LEN;
   h->small_io = cfg->num_envs <= cc4_handle::SMALL_IO_ENVS;
   if (const char* v = getenv("CC4_SMALL_IO")) h->small_io = h->small_io && atoi(v) != 0;
@@ -1932,7 +1932,10 @@ int cc4_comm_init(cc4_handle* h, int32_t rank, int32_t world, const void* id128)
   // must hold the whole batch with a block per CU to spare (at exactly full residency one block that is placed late stalls everybody until
   // the watchdog: tools/micro/ring_protocol.hip), and with peers RCCL's kernels need that room on every form (the persistent kernel's waves
   // pull items, so on one rank it keeps every slot)
-  if (h->xchg_on) { if (choose_run_form(h, 1, world > 1 ? 1 : 0)) return -1; }
+  // (the numpy-stream persistent kernel has ONE build, six waves of 80 registers per SIMD: with a communicator its grid leaves eight waves per CU free, so
+  // that every SIMD keeps room for the all-gather's kernels -- the counter mode runs its five-waves-per-SIMD build, k_run_philox1x, instead)
+  // (counter mode: one wave per CU less also on a one-rank communicator -- r05 ran that case on a full grid, and r06 saw the soak test time out once)
+  if (h->xchg_on) { if (choose_run_form(h, 1, h->cfg.rng_mode == 0 ? 8 : 1)) return -1; }
   return 0;
 }
 // the in-kernel exchange of this handle: out[0] on (1) / off (0), out[1] ring depth in steps, out[2] steps per publish (CC4_EXCHANGE_CHUNK),

@@ -353,12 +353,12 @@ __device__ __forceinline__ void pcg_body(StepArgs a, const int e, const int lane
   // numpy-PCG64 mode: one shared stream => the agent walk is strictly serial (lane 0); only the RNG-free parts
   // (row staging, end-turn Monitor roll-over over the 137 hosts, observation encode) use the other lanes.
   extern __shared__ uint4 lds[];
-  // one LDS area, two lives: the LCG window of the green actions (wave_green_exec), then -- from the end-turn roll-over on --
-  // the hosts' event bits (what the observation encode reads) and the encoded observation
-  __shared__ uint64_t win_lds[GW_OUT];
-  constexpr int OBS_LDS = (OBS_TOTAL + 2 + 7) & ~7;
-  static_assert(OBS_LDS <= (int)sizeof(uint64_t) * GW_OUT, "the byte copy of the observation fits the window area");
-  uint8_t* const obs_lds = reinterpret_cast<uint8_t*>(win_lds);
+  // r06: the 1 KB LCG window of the green actions (wave_green_exec: 128 outputs, written once per batch, read ~9 times per lane at computed
+  // positions) lives in MEMORY now (StepArgs.reset_ws, 1 KB per episode; the CU's L1 / the XCD's L2 serve it): with it, the byte copy of the
+  // observations (the packed exchange row is read back from the int32 row, pack_row_from_obs) and the phase timers (full build only) out of LDS,
+  // agent part + statics are 6 368 B = FIVE 1280-byte granules -- 24 waves per CU at 80 VGPRs instead of 20 at 6 granules / 91 VGPRs.
+  uint64_t* const win_mem = reinterpret_cast<uint64_t*>(a.reset_ws) + (size_t)e * GW_OUT;
+  if constexpr (!LOG) a.prof = nullptr;
   __shared__ int ok_lds;
   __shared__ StepWork work;
   EnvCold* const cold_e = cold_at(a.cold, (size_t)e, cold_row_bytes(a.steps));
@@ -369,7 +369,7 @@ __device__ __forceinline__ void pcg_body(StepArgs a, const int e, const int lane
   __syncthreads();
   EnvState* s = reinterpret_cast<EnvState*>(lds);   // only the part in front of EnvState.hd is valid here
   HostDyn* const hd = a.st[e].hd;                   // the host table stays in HBM / L2
-  __shared__ unsigned long long prof_lds[16];   // phase counters accumulate in LDS, flushed once at the end
+  __shared__ unsigned long long prof_lds[LOG ? 16 : 1];   // phase counters accumulate in LDS, flushed once at the end (full build: cc4_debug_profile selects it)
   unsigned long long* prof = a.prof ? prof_lds : nullptr;
   if (prof && lane < 16) prof_lds[lane] = 0;
   // the shared numpy stream is walked on a register copy (this kernel serves the PCG mode only; mode pinned so the Philox
@@ -435,7 +435,7 @@ __device__ __forceinline__ void pcg_body(StepArgs a, const int e, const int lane
   __syncthreads();
   if (ok_lds) {
     // the green actions: across the wave (wave_green_exec)
-    if constexpr (!LOG) wave_green_exec(x, rl, win_lds, lane, a.prof ? a.prof + PROF_SLOTS * (size_t)e + 64 : nullptr);
+    if constexpr (!LOG) wave_green_exec(x, rl, win_mem, lane, nullptr);
     else {
       // with the event log on (log entries are ordered): on the walking lane; what the actions read from the state (service
       // tables of their hosts -- HBM here --, allowed server counts) is prepared for all agents at once on the idle lanes
@@ -485,17 +485,19 @@ __device__ __forceinline__ void pcg_body(StepArgs a, const int e, const int lane
     // Block/Allow or a new mission phase changes are written when that happened (EnvState.obs_dirty), after a reset, or when the
     // caller asks -- as in the counter-mode kernels; the byte copy in LDS only feeds the packed exchange row
     int32_t* o = a.obs + (size_t)e * OBS_TOTAL;
-    const bool pack = a.obs8 != nullptr;
-    const int nv = (do_reset || a.full_obs || pack || s->obs_dirty) ? OBS_TOTAL : OBS_FAST;
-    encode_obs_fast<WAVE>(s, o, obs_lds, pack, lane);
-    for (int v = OBS_FAST + lane; v < nv; v += WAVE) { int i; const int val = env_flat_obs_sorted(s, v, &i); o[i] = val; if (pack) obs_lds[i] = (uint8_t)val; }
+    const int nv = (do_reset || a.full_obs || s->obs_dirty) ? OBS_TOTAL : OBS_FAST;
+    encode_obs_fast<WAVE>(s, o, nullptr, false, lane);
+    for (int v = OBS_FAST + lane; v < nv; v += WAVE) { int i; const int val = env_flat_obs_sorted(s, v, &i); o[i] = val; }
   }
   __syncthreads();
   unsigned long long t_out = a.prof ? clock64() : 0;
   if (prof && lane == 0) prof[12] += t_out - t_obs;
   uint4* dst = reinterpret_cast<uint4*>(a.st + e);
   if (last) stage_out<HOT_VEC>(dst, lds, lane);
-  if (a.obs8) store_packed_row(a.obs8 + (size_t)e * OBS_PACKED, obs_lds, lane, WAVE);
+  if (a.obs8) {     // the packed exchange row, read back from the int32 row this wave has just (re)written (the buffer persists between steps: it holds every current value)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    pack_row_from_obs(a.obs8 + (size_t)e * OBS_PACKED, a.obs + (size_t)e * OBS_TOTAL, lane);
+  }
   if (prof && lane == 0) { prof[13] += clock64() - t_out; prof[14] += clock64() - t_begin; }
   if (prof) { __syncthreads(); if (lane < 15) a.prof[PROF_SLOTS * (size_t)e + lane] += prof_lds[lane]; }
 }
@@ -507,7 +509,7 @@ __global__ __launch_bounds__(WAVE) void k_step(StepArgs a) {
 }
 
 // the persistent schedule (cc4_persist.h) around the numpy-stream step: the bit-exact mode's large batches
-__global__ __launch_bounds__(WAVE) void k_run_pcg(StepArgs a, RunArgs ra, XchgArgs x) { persist_loop<true>(a, ra, x); }
+__global__ __launch_bounds__(WAVE, 6) void k_run_pcg(StepArgs a, RunArgs ra, XchgArgs x) { persist_loop<true>(a, ra, x); }
 
 
 // the kernels the host side launches (cc4_kernel_decls.h)
