@@ -504,6 +504,7 @@ const char* cc4_run_kernel(cc4_handle* h) {
   return cc4_step_kernel(h);
 }
 static int persist_setup(cc4_handle* h);
+static int ensure_shadow(cc4_handle* h);
 const char* cc4_run_kernel_for(cc4_handle* h, int32_t k) {
   if (!h) return "";
   // (the persistent kernel's discovery pass runs on first use: asking which kernel a call of k steps will launch is such a use -- the answer depends on it,
@@ -1066,6 +1067,10 @@ static int persist_setup(cc4_handle* h) {
   HIPCHK(h, hipMalloc(&h->d_run, h->run_words * sizeof(uint32_t)));
   HIPCHK(h, hipMemset(h->d_run, 0, h->run_words * sizeof(uint32_t)));
   h->persist_state = 1;
+  // the sampled self-check's shadow handle is created HERE, with the path itself (the first persistent call of a handle: normally a warm-up) -- a
+  // cc4_create inside the 1024th call would cost that call ~45 ms; the checks themselves then cost ~6 calls' worth each (copies and digests of the
+  // cold rows), i.e. ~0.6 % of a long run.  CC4_PERSIST_VERIFY_EVERY=0: no sampling, no second copy of the rows.
+  if (!h->is_shadow && !h->comm && (h->verify || h->verify_every > 0)) { if (ensure_shadow(h)) return -1; }
   return 0;
 }
 // ---- the exchange around a one-launch kernel (XchgArgs).  Before the launch: the call's flags cleared on the main stream, the
@@ -1181,6 +1186,16 @@ static int verify_digest(cc4_handle* h, std::vector<uint64_t>& out) {
   HIPCHK(h, hipStreamSynchronize(h->stream));
   return 0;
 }
+// the shadow handle of the self-check: a second copy of the batch's rows, stepped with per-step launches only
+static int ensure_shadow(cc4_handle* h) {
+  if (h->shadow) return 0;
+  cc4_handle* sh = nullptr;
+  if (cc4_create(&h->cfg, &sh) != 0) { h->err = std::string("CC4_PERSIST_VERIFY: the shadow handle could not be created: ") + cc4_last_error(sh); if (sh) cc4_destroy(sh); return -1; }
+  sh->is_shadow = true; sh->verify = false; sh->verify_every = 0; sh->persist_state = -1; sh->multistep = false; sh->run1m = false;
+  h->shadow = sh;
+  HIPCHK(h, hipSetDevice(h->cfg.device_id));
+  return 0;
+}
 int cc4_run_random_steps(cc4_handle* h, uint64_t seed0, uint32_t t0, int32_t k, float* ms_step_kernels) {
   if (h->is_shadow || k < 2) return run_random_steps_impl(h, seed0, t0, k, ms_step_kernels);
   // The self-check: with CC4_PERSIST_VERIFY=1 every one-launch call is repeated on a shadow handle and compared; WITHOUT it every
@@ -1195,12 +1210,7 @@ int cc4_run_random_steps(cc4_handle* h, uint64_t seed0, uint32_t t0, int32_t k, 
   if (!check) return run_random_steps_impl(h, seed0, t0, k, ms_step_kernels);
   HIPCHK(h, hipSetDevice(h->cfg.device_id));
   if (strncmp(cc4_run_kernel_for(h, k), "k_run_", 6) != 0) return run_random_steps_impl(h, seed0, t0, k, ms_step_kernels);
-  if (!h->shadow) {
-    cc4_handle* sh = nullptr;
-    if (cc4_create(&h->cfg, &sh) != 0) { h->err = std::string("CC4_PERSIST_VERIFY: the shadow handle could not be created: ") + cc4_last_error(sh); if (sh) cc4_destroy(sh); return -1; }
-    sh->is_shadow = true; sh->verify = false; sh->persist_state = -1; sh->multistep = false; sh->run1m = false;
-    h->shadow = sh;
-  }
+  if (ensure_shadow(h)) return -1;
   cc4_handle* sh = h->shadow;
   const size_t n = (size_t)h->cfg.num_envs;
   if (join_groups(h) || join_groups(sh)) return -1;

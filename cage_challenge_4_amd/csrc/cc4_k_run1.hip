@@ -9,4 +9,4 @@
 #ifndef CC4_PERSIST_MINW
 #define CC4_PERSIST_MINW 6
 #endif
-__global__ __launch_bounds__(WAVE, CC4_PERSIST_MINW) void k_run_philox1(StepArgs a, RunArgs ra, XchgArgs x) { persist_loop<false>(a, ra, x); }
+__global__ __launch_bounds__(WAVE, CC4_PERSIST_MINW) void k_run_philox1(StepArgs a, RunArgs ra, XchgArgs x) { persist_loop<false, false, false>(a, ra, x); }      // (no exchange, no rollout protocol in this build)

@@ -13,7 +13,9 @@
 // store is in the XCD's L2), then publishes the progress word; the reader reads the word, then the rows.
 // ROLLOUT: the build that serves cc4_rollout_begin (k_run_philox1r) -- the actions-in protocol is compiled into that kernel only (in the others its code
 // cost the headline kernel 30 more spilled registers)
-template <bool PCG, bool ROLLOUT = false>
+// XCHG: the build serves the exchange (the packed rows of every step into the slab ring, counted for the communication stream's gates).  The
+// headline kernel k_run_philox1 is built without it: handles with a communicator launch k_run_philox1x.
+template <bool PCG, bool ROLLOUT = false, bool XCHG = true>
 __device__ __forceinline__ void persist_loop(StepArgs a, RunArgs ra, const XchgArgs x) {
   // (the item travels from lane 0 to the wave through v_readfirstlane, not through LDS)
   const int lane = threadIdx.x;
@@ -25,7 +27,7 @@ __device__ __forceinline__ void persist_loop(StepArgs a, RunArgs ra, const XchgA
   auto tl_flush = [&]() { if (ra.timeline && lane == 0) { unsigned long long* t = ra.timeline + 4 * (size_t)blockIdx.x; t[0] = tl_entry; t[1] = tl_first; t[2] = tl_last; t[3] = tl_items | ((unsigned long long)(my_slot + 1) << 32); } };
   int pend_e = -1; uint32_t pend_k = 0;  // the exchange: the item whose packed row this wave stored last and has not counted yet (its store drains with the next item)
   auto flush_pending = [&]() {
-    if (x.slab && pend_e >= 0) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); if (lane == 0) xchg_count(x, pend_k, pend_e % ra.G); pend_e = -1; }
+    if (XCHG && x.slab && pend_e >= 0) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); if (lane == 0) xchg_count(x, pend_k, pend_e % ra.G); pend_e = -1; }
   };
   const uint32_t my_xcc = __builtin_amdgcn_s_getreg(((4 - 1) << 11) | (0 << 6) | 20) & 7u;    // HW_REG_XCC_ID
   const int xlo = ra.xcc_lo[my_xcc], xn = ra.xcc_n[my_xcc];     // this XCD's partitions
@@ -134,7 +136,7 @@ __device__ __forceinline__ void persist_loop(StepArgs a, RunArgs ra, const XchgA
           uint32_t w;
           while ((((w = __hip_atomic_load(&ra.progress[ee], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) & PG_STEPS) - ra.base) < (uint32_t)k) __builtin_amdgcn_s_sleep(8);
           __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-          if (x.slab) xchg_wait_slab(x, (uint32_t)k, seen_gathered);
+          if (XCHG && x.slab) xchg_wait_slab(x, (uint32_t)k, seen_gathered);
           const uint32_t last = w >> 23;
           res_e = ee; res_k = j; res_sh = (last != 0u && last != my_id) ? 1 : 0;     // the episode's last run was on another CU: its lines in this CU's L1 may be stale
         }
@@ -151,7 +153,7 @@ __device__ __forceinline__ void persist_loop(StepArgs a, RunArgs ra, const XchgA
     uint32_t item_k = (uint32_t)run_k0;
     for (int q = 0; q < run_len; ++q, ++item_k) {
     if (q > 0) {
-      if (x.slab) {
+      if (XCHG && x.slab) {
         // a further step of the run with the exchange on: what the last step stored is drained and counted as at a run's end, and the slab of
         // this step must have been gathered
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -172,7 +174,7 @@ __device__ __forceinline__ void persist_loop(StepArgs a, RunArgs ra, const XchgA
     if constexpr (PCG) {
       StepArgs b = a;
       b.rand_t = ra.t0 + item_k; b.full_obs = (a.full_obs && item_k == 0) ? 1 : 0;
-      if (x.slab) b.obs8 = x.slab + (size_t)(item_k % (uint32_t)x.ring) * (size_t)a.n * OBS_PACKED;
+      if (XCHG && x.slab) b.obs8 = x.slab + (size_t)(item_k % (uint32_t)x.ring) * (size_t)a.n * OBS_PACKED;
       pcg_body<false>(b, e, lane_i, q == 0, q == run_len - 1);
     } else {
       philox1_body<false, true>(a, e, ra.t0 + item_k, item_k, lane_i, q == 0, q == run_len - 1);      // (a.obs8 is null: the packed row is written below, behind the drain)
@@ -190,7 +192,7 @@ __device__ __forceinline__ void persist_loop(StepArgs a, RunArgs ra, const XchgA
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     if (ra.order >= 2) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
     __syncthreads();
-    if (x.slab) {
+    if (XCHG && x.slab) {
       if constexpr (PCG) {     // (the numpy-stream body stored the row itself, from its LDS byte row: drained by the fence above)
         if (lane == 0) xchg_count(x, item_k, e % ra.G);
       } else {
