@@ -108,6 +108,7 @@ struct cc4_handle {
   hipStream_t gpolicy[4] = {nullptr, nullptr, nullptr, nullptr};   // one policy stream per policy group: the groups' gate -> policy -> publish chains run side by side
   hipEvent_t rev = nullptr;       // the rollout's starting observations are packed (slab XRING - 1)
   int rollout_k = 0;              // > 0: a rollout of that many steps is in flight
+  bool rollout_entering = false;  // cc4_rollout_end is draining it (its own calls may pass join_groups)
   int rollout_watchdog_ms = 2000;
   int rollout_margin = 1;
   int rpg = 4;                    // policy groups (CC4_ROLLOUT_GROUPS, 1 .. RPG_MAX)
@@ -228,6 +229,8 @@ static void configure_groups(cc4_handle* h, int ng) {
 // Every API call other than the step launches works on the main stream: order it behind whatever the group streams still
 // hold (device-side waits, no host synchronisation), and remember that the next step launches must be ordered behind it.
 static int join_groups(cc4_handle* h) {
+  // (nearly every entry point comes through here: while a rollout's kernel is running the handle's rows and streams are its alone)
+  if (h->rollout_k > 0 && !h->rollout_entering) { h->err = "a rollout is in flight on this handle: cc4_rollout_end first"; return -1; }
   if (h->ngroups > 1) {
     if (h->groups_busy) {
       for (int g = 1; g < h->ngroups; ++g) {
@@ -962,6 +965,7 @@ int cc4_random_actions_device(cc4_handle* h, uint64_t seed0, uint32_t t) {
   return 0;
 }
 int cc4_synchronize(cc4_handle* h) {
+  if (h->rollout_k > 0) { h->err = "cc4_synchronize: a rollout is in flight on this handle (its kernel ends when every pass is published): cc4_rollout_end"; return -1; }
   HIPCHK(h, hipSetDevice(h->cfg.device_id));
   return sync_all(h);
 }
@@ -1637,10 +1641,14 @@ int cc4_debug_rollout_state(cc4_handle* h, int64_t* out /* [22] */) {
 int cc4_rollout_end(cc4_handle* h) {
   if (rollout_ready(h, "cc4_rollout_end")) return -2;
   HIPCHK(h, hipSetDevice(h->cfg.device_id));
-  HIPCHK(h, hipStreamSynchronize(h->stream));
-  for (int g = 0; g < RPG_MAX; ++g) HIPCHK(h, hipStreamSynchronize(h->gpolicy[g]));
+  h->rollout_entering = true;
+  const hipError_t e1 = hipStreamSynchronize(h->stream);
+  hipError_t e2 = hipSuccess;
+  for (int g = 0; g < RPG_MAX; ++g) { const hipError_t e = hipStreamSynchronize(h->gpolicy[g]); if (e != hipSuccess) e2 = e; }
+  h->rollout_entering = false;
   const int k = h->rollout_k;
   h->rollout_k = 0;
+  HIPCHK(h, e1); HIPCHK(h, e2);
   uint32_t gate_failed = 0;
   HIPCHK(h, hipMemcpy(&gate_failed, h->d_rfail, sizeof(uint32_t), hipMemcpyDeviceToHost));
   if (*reinterpret_cast<volatile uint32_t*>(h->h_xtimeout) || gate_failed) {

@@ -438,13 +438,17 @@ def test_rollout_with_the_policy_in_the_loop_matches_the_oracle_at_every_step(n,
 def test_rollout_watchdog_reports_a_pass_that_was_never_published(monkeypatch):
     """A rollout whose policy never publishes must not hang the kernel: the waiting steps give up after the watchdog, cc4_rollout_end says so (-6)."""
     monkeypatch.setenv('CC4_ROLLOUT_WATCHDOG_MS', '20')
-    from cage_challenge_4_amd._lib import CC4Error
+    import ctypes
     dev = _dev(8192, steps=50, rng_mode=1, autoreset=True, strict=False); dev.reset(seeds=3)
     dev._chk(dev.lib.cc4_rollout_begin(dev._h, 10), 'cc4_rollout_begin')
     for g in range(4):                                       # step 0 only
         dev.lib.cc4_rollout_wait_obs(dev._h, g, 0, None); dev.lib.cc4_rollout_random_policy(dev._h, g, 0, 3, 0, None); dev.lib.cc4_rollout_publish(dev._h, g, 0, None)
+    obs = np.zeros((8192, 578), np.int32)
+    assert dev.lib.cc4_get_obs(dev._h, obs.ctypes.data_as(ctypes.c_void_p)) != 0 and b'a rollout is in flight' in dev.lib.cc4_last_error(dev._h)     # the handle is the rollout's alone
+    assert dev.lib.cc4_synchronize(dev._h) != 0 and dev.lib.cc4_rollout_begin(dev._h, 5) != 0
     assert dev.lib.cc4_rollout_end(dev._h) == -6
     assert b'waited longer than' in dev.lib.cc4_last_error(dev._h)
+    assert dev.lib.cc4_get_obs(dev._h, obs.ctypes.data_as(ctypes.c_void_p)) == 0
     dev.close()
 
 
