@@ -214,6 +214,28 @@ def load_pmc_traffic(envs, kernel):
     return None, None
 
 
+VALU_PEAK_GINSTR = 256 * 4 * 2.4 / 4.0      # wave64 VALU instructions per ns the chip can issue: 256 CUs x 4 SIMDs, one per 4 cycles, 2.4 GHz = 614.4 G/s
+
+
+def load_valu_issue(envs, kernel, steps_per_launch):
+    """VALU issue-slot use of the timed kernel from the committed rocprofv3 --pmc passes (profiles/r06_pmc_valu_busy.json, tools/valu_busy.sh): the entry
+    of this very kernel at this batch size whose launch length is nearest; None if there is none."""
+    try:
+        with open(os.path.join(ROOT, 'profiles', 'r06_pmc_valu_busy.json')) as f:
+            d = json.load(f)
+        c = [v for v in d.values() if isinstance(v, dict) and v.get('kernel') == kernel and v.get('episodes') == envs and v.get('valu_busy')]
+        if not c:
+            return None
+        v = min(c, key=lambda v: abs(v['steps_per_launch'] - steps_per_launch))
+        return {'valu_busy': v['valu_busy'], 'salu_busy': v.get('salu_busy'), 'lds_busy': v.get('lds_busy'),
+                'valu_instructions_per_episode_step': v.get('valu_per_episode_step'), 'active_lanes_per_valu_instruction': v.get('active_lanes_per_valu_instruction'),
+                'steps_per_launch_of_the_counter_pass': v['steps_per_launch'],
+                'source': 'profiles/r06_pmc_valu_busy.json (rocprofv3 --pmc passes of this kernel: SQ_ACTIVE_INST_VALU x 4 / (1024 SIMDs x cycles of the launch); '
+                          'a committed figure of the build before the three-input xor of the Philox rounds, not measured in this run)'}
+    except Exception:
+        return None
+
+
 def cpu_model():
     try:
         for line in open('/proc/cpuinfo'):
@@ -443,17 +465,19 @@ def main():
         # contract bytes of the kernel that serves that mode: the numpy-stream kernel stages the agent part and visits the host table in place
         b2 = (2 * hot_b + (row_b - hot_b) + 4 * 578 + 29) if other == 'pcg64' else int(env.lib.cc4_algorithmic_bytes_per_env_step())
         a2 = b2 * n_local / (r2['launch_ms'] * 1e-3) / 1e9
-        r2['roofline'] = {'bound': 'latency', 'roofline': 'hbm', 'achieved': a2, 'peak': HBM_PEAK_GBPS, 'unit': 'GB/s', 'frac': a2 / HBM_PEAK_GBPS, 'traffic': None,
+        v2 = load_valu_issue(n_local, r2['run_kernel'], args.steps)
+        r2['roofline'] = {'bound': 'valu_issue' if (v2 and v2['valu_busy'] >= 0.8) else 'latency', 'valu_issue': v2, 'roofline': 'hbm', 'achieved': a2, 'peak': HBM_PEAK_GBPS, 'unit': 'GB/s', 'frac': a2 / HBM_PEAK_GBPS, 'traffic': None,
                           'kernel': r2['run_kernel'], 'step_ms': r2['launch_ms'], 'algorithmic_bytes_per_step': b2 * n_local,
                           'note': 'algorithmic bytes per step (contract figure of that kernel) / kernel time per step against the HBM peak; the walking lane of the '
-                                  'numpy-stream kernel is a dependency chain, not a stream of bytes: bound = latency'}
+                                  'numpy-stream kernel is a dependency chain, not a stream of bytes -- at 24 waves per CU the chains of the resident episodes fill the '
+                                  'vector issue slots (valu_issue: twice the instructions of the counter-mode step per episode-step)'}
         subs['alt_rng'] = r2
         if total_envs != 1024:
             e4 = make_env(1024, mode, 0)
             r4 = measure(e4, 0, 1024, min_seconds=sub_seconds)
             k4 = e4.step_kernel
             e4.close()
-            r4['roofline'] = ({'bound': 'latency', 'us_per_step': r4['launch_ms'] * 1e3,
+            r4['roofline'] = ({'bound': 'latency', 'us_per_step': r4['launch_ms'] * 1e3, 'valu_issue': load_valu_issue(1024, r4['run_kernel'], args.steps),
                                'note': f"{r4['run_kernel']} keeps the episode's row in LDS from the first step of a launch to the last: the bytes of the contract "
                                        'figure do not move, so no HBM fraction is quoted -- the figure is the mean step time of an episode'}
                               if r4['run_kernel'] in ('k_run_philox', 'k_run_philox8') else None)
@@ -525,6 +549,14 @@ def main():
         # live bytes: the agent part + the 64-byte rows of the hosts that exist in the episode (the grid has 137 positions)
         useful = 2 * (hot + 64.0 * mean_hosts) + 4 * 578 + 29
         traffic, traffic_src = load_pmc_traffic(n_local, main_res['run_kernel'])
+        hbm_ctr_frac = (traffic / (launch_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS) if traffic else None
+        valu = load_valu_issue(n_local, main_res['run_kernel'], spl)
+        if valu and valu.get('valu_instructions_per_episode_step'):
+            # the committed instruction count of an episode-step against THIS run's kernel time: wave-instructions per ns the chip issued / can issue
+            valu['achieved_ginstr_per_s'] = valu['valu_instructions_per_episode_step'] * n_local / (launch_ms * 1e-3) / 1e9
+            valu['peak_ginstr_per_s'] = VALU_PEAK_GINSTR
+            valu['frac'] = valu['achieved_ginstr_per_s'] / VALU_PEAK_GINSTR
+        bound = 'hbm' if (hbm_ctr_frac or 0.0) >= 0.6 else 'valu_issue' if (valu and valu['valu_busy'] >= 0.8) else 'latency'
         out = {
             'metric': 'agent-env steps/sec (5 blue agents x N envs)',
             'value': main_res['value'],
@@ -550,15 +582,21 @@ def main():
                 'autoreset_in_timed_region': main_res['autoreset_launches_in_timed_regions'] > 0,
                 'autoreset_launches_in_timed_regions': main_res['autoreset_launches_in_timed_regions'],
             },
-            # `bound`: what the measurements of THIS kernel say, not a constant.  The figure of merit stays the HBM roofline (integer / byte work, no
-            # MFMA): `achieved` = contract bytes per step / kernel time per step.  But the counters (`traffic`, separate --pmc passes of this kernel)
-            # show the memory system carrying well under half of 8 TB/s, and inside a run of steps the episode's agent part does not move at all
-            # (it stays in LDS): the kernel is bound by the episodes in flight x the latency of a step's dependent chain -> "latency".
-            # "hbm" only if the counters say the memory system is the busy one.
-            'roofline': {'bound': ('hbm' if (traffic and traffic / (launch_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS >= 0.6) else 'latency'), 'roofline': 'hbm',
-                         'bound_evidence': ('HBM counters of this kernel: %.0f %% of peak' % (100.0 * traffic / (launch_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS) if traffic
-                                            else 'no counter pass of this kernel at this batch size is committed') +
-                                           '; waves per CU and per-step latency: profiles/kernel_resources.txt, DESIGN 3.4',
+            # `bound`: what the counters of THIS kernel say, not a constant.  The figure of merit stays the HBM roofline (integer / byte work, no MFMA):
+            # `achieved` = contract bytes per step / kernel time per step.  But the memory system carries a fifth of 8 TB/s (`traffic`: inside a run of steps
+            # an episode's agent part stays in LDS), while the issue-slot counters of the same kernel show the vector ALUs busy nine cycles in ten at 24 waves
+            # per CU on ~5 active lanes per instruction: "valu_issue" -- the step time is (vector instructions of an episode-step) / (issue slots), and what
+            # moves it now is a shorter instruction stream, not more waves.  "hbm" only if the HBM counters say so; "latency" where neither unit
+            # is busy (the small batches: 1024 episodes keep the VALUs 38 % busy).
+            'roofline': {'bound': bound, 'roofline': 'hbm',
+                         'bound_evidence': ('HBM counters of this kernel: %.0f %% of peak' % (100.0 * hbm_ctr_frac) if traffic
+                                            else 'no HBM counter pass of this kernel at this batch size is committed') +
+                                           ('; VALU issue slots of this kernel: %.0f %% busy (%.0f wave instructions per episode-step on %.1f active lanes): the '
+                                            'step is bound by the NUMBER of vector instructions of an episode, which more resident waves no longer hide'
+                                            % (100.0 * valu['valu_busy'], valu['valu_instructions_per_episode_step'] or 0.0, valu['active_lanes_per_valu_instruction'] or 0.0)
+                                            if valu else '; no issue-slot counter pass of this kernel at this batch size is committed') +
+                                           '; waves per CU: profiles/kernel_resources.txt, DESIGN 3.4',
+                         'valu_issue': valu,
                          'achieved': achieved, 'peak': HBM_PEAK_GBPS, 'unit': 'GB/s',
                          'frac': achieved / HBM_PEAK_GBPS,
                          # the same algorithmic bytes against the WALL clock of the timed regions (ms_per_step: what `value` is made of) --
@@ -566,7 +604,7 @@ def main():
                          'frac_wall': bytes_per_env * n_local / (main_res['ms_per_step'] * 1e-3) / 1e9 / HBM_PEAK_GBPS,
                          # the bytes the HBM counters saw per step (traffic) against the same launch duration: what fraction of the
                          # 8 TB/s the memory system actually carried
-                         'hbm_counter_frac': (traffic / (launch_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS) if traffic else None,
+                         'hbm_counter_frac': hbm_ctr_frac,
                          'traffic': traffic, 'traffic_source': traffic_src,
                          'kernel': main_res['run_kernel'], 'step_kernel': env.step_kernel, 'run_kernel': main_res['run_kernel'],
                          'step_ms': launch_ms, 'steps_per_launch': spl, 'launch_ms': launch_ms * spl,

@@ -149,7 +149,7 @@ __device__ __forceinline__ void philox4_body(StepArgs a, const int run_flags = 0
       if (tid == 0) CC4_TICK(x0p, 0);   // slot 0: step_phase
       Rng rl;
       rng_fork(&rl, &s->rng, ST_RESET);
-      rl.mode = 1;
+      rl.mode = 3;                             // philox, thread-private (cc4_rng.h)
       rng_begin_step(&rl, (uint32_t)st_now);   // not read from the row: thread 0 may still be storing it there
       EvLog* const lg = (LOG && cold_e->evlog.enabled) ? &cold_e->evlog : nullptr;
       const ExtAct* const xt = (LOG && a.ext) ? a.ext + (size_t)e * EXT_PER_ENV : nullptr;   // this episode's submitted red / green actions

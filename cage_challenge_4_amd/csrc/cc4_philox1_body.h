@@ -90,7 +90,7 @@ __device__ __forceinline__ void philox1_body(StepArgs a, const int e, const uint
       // paths fold away
       Rng rl;
       rng_fork(&rl, &s->rng, ST_RESET);
-      rl.mode = 1;
+      rl.mode = 3;                             // philox, lane-private (cc4_rng.h)
       rng_begin_step(&rl, (uint32_t)st_now);   // not read from the row: lane 0 may still be storing it there
       EvLog* const lg = (LOG && cold_e->evlog.enabled) ? &cold_e->evlog : nullptr;
       const ExtAct* const xt = (LOG && a.ext) ? a.ext + (size_t)e * EXT_PER_ENV : nullptr;   // this episode's submitted red / green actions
@@ -119,7 +119,7 @@ __device__ __forceinline__ void philox1_body(StepArgs a, const int e, const uint
           const uint64_t key = a.rand_seed0 + (uint64_t)e;
           bank[0] = rand_t; bank[1] = (uint32_t)(lane - BK_BRAND); bank[2] = 0xB10Eu; bank[3] = 0u; k0 = (uint32_t)key; k1 = (uint32_t)(key >> 32);
         }
-        philox4x32_10(bank, k0, k1);
+        philox4x32_10(bank, k0, k1, true);
       }
       // the four words lane `lane + shift` holds, on every lane (call with all lanes active: an inactive source lane reads as 0)
       auto bank_fetch = [&](int shift, uint32_t out[4]) {
@@ -153,17 +153,34 @@ __device__ __forceinline__ void philox1_body(StepArgs a, const int e, const uint
       if (lane + WAVE < ng) step_green_policy(xg, lane + WAVE, bank);            // agents 64..: from the bank (their lane's own request)
       __syncthreads();
       CC4_TICK(x0, 2);
-      // ---- P3b blue actions: side by side when they are independent (no Monitor, no pending pid events)
-      if (blue_exec_independent(s)) {
+      // ---- P3b blue actions: side by side when they are independent (no Monitor, no pending pid events), else in the reference's order on
+      // lane 0 (ControlTraffic first, then agent order: step_blue_exec).  ONE call site of blue_execute for both forms -- the action bodies are
+      // a quarter of the kernel's code, and a second and third inlined copy of them is what the instruction cache holds least well.
+      {
+        const bool indep = blue_exec_independent(s);
         if (lane == 0) CC4_TICK(x0, 3);
         uint32_t c[4];
         bank_fetch(BK_BEXE, c);                                                   // blue b (lane b) <- lane BK_BEXE + b
-        if (lane < NBLUE) step_blue_exec_agent(xg, lane, c);
+        Ctx xb = xg;
+        if (!indep) xb.prof = x0.prof;
+        const int rounds = indep ? 1 : 2 * NBLUE;
+#pragma nounroll
+        for (int i = 0; i < rounds; ++i) {
+          int b = lane;
+          bool go = lane < NBLUE;
+          if (!indep) {
+            b = i < NBLUE ? i : i - NBLUE;
+            const int ty = s->bexec[b].type;
+            go = lane == 0 && ((ty == BA_BLOCK || ty == BA_ALLOW) == (i < NBLUE));
+          }
+          if (go) {
+            rng_set_stream(&rl, ST_BLUE_EXE + (uint32_t)b);
+            if (indep) rng_preload(&rl, c);
+            blue_execute(xb, b, s->bexec[b]);
+          }
+        }
         __syncthreads();
         if (lane == 0) CC4_TICK(x0, 5);
-      } else {
-        if (lane == 0) step_blue_exec(x0);
-        __syncthreads();
       }
       // ---- P4 green actions, one agent per lane
       {
@@ -195,15 +212,30 @@ __device__ __forceinline__ void philox1_body(StepArgs a, const int e, const uint
       const uint32_t serial_red = (uint32_t)conflict_lds;
       uint32_t pre_re[4];
       bank_fetch(BK_REXE, pre_re);                                                // red r (lane r) <- lane BK_REXE + r
-      if (is_red && !((serial_red >> lane) & 1u)) {
-        unsigned long long t0 = ap ? clock64() : 0;
-        step_red_exec_agent(xr, lane, pre_re);
-        if (ap) ap[1] += clock64() - t0;
-      }
-      __syncthreads();
-      if (serial_red) {   // same-host actions (and everything when some agent withdraws): agent order on lane 0
-        if (lane == 0) for (int r = 0; r < NRED; ++r) if ((serial_red >> r) & 1u) step_red_exec_agent(x0, r);
-        __syncthreads();
+      // round 0: the agents whose actions commute, each on its lane; then the same-host actions (everything when some agent withdraws) in agent
+      // order on lane 0 -- through the same call site (see P3b)
+      {
+        uint32_t todo = serial_red;
+        bool side = true;
+#pragma nounroll
+        for (;;) {
+          int r = lane;
+          bool go = is_red && !((serial_red >> lane) & 1u);
+          Ctx xe = xr;
+          if (!side) { r = __ffs((int)todo) - 1; todo &= todo - 1u; go = lane == 0; xe.prof = x0.prof; xe.aprof = nullptr; }
+          if (go) {
+            unsigned long long t0 = xe.aprof ? clock64() : 0;
+            if (s->rexec[r].type != RA_NONE) {                                      // == step_red_exec_agent
+              rng_set_stream(&rl, ST_RED_EXE + (uint32_t)r);
+              if (side) rng_preload(&rl, pre_re);
+              red_execute(xe, r, s->rexec[r]);
+            }
+            if (xe.aprof) xe.aprof[1] += clock64() - t0;
+          }
+          __syncthreads();
+          side = false;
+          if (!todo) break;
+        }
       }
       if (lane == 0) {
         step_red_merge(x0);

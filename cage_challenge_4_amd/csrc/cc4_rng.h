@@ -40,7 +40,7 @@ struct Rng {
   uint64_t inc_hi, inc_lo;  // PCG64 increment (odd)     | philox: inc_lo = step word
   uint32_t has32;           // numpy pcg64_state.has_uint32
   uint32_t u32;             // numpy pcg64_state.uinteger (buffered high half)
-  uint32_t mode;            // 0 pcg, 1 philox
+  uint32_t mode;            // 0 pcg, 1 philox, 3 philox on a lane-private generator of a wave kernel (philox4x32_10's vec form; never stored in a row)
   uint32_t ndraw;           // pcg: number of 64-bit advances (diagnostics) | philox: current stream id
   uint64_t buf64;           // philox: second 64-bit word of the last 128-bit block
   uint32_t has64, pad;      // philox: buf64 is valid
@@ -109,13 +109,24 @@ CC4_HD void pcg_step(Rng* r) {
 }
 
 // ---- Philox4x32-10 (Salmon et al. 2011; constants as in Random123) ----
-CC4_HD void philox4x32_10(uint32_t c[4], uint32_t k0, uint32_t k1) {
+// vec (device): the words live in vector registers (a lane-private generator, Rng.mode 3).  The step kernels at 24 waves per CU are bound by VALU issue
+// slots (profiles/r06_pmc_valu_busy.json: 91 % busy), and a round is two 32x32->64 products and two THREE-input xors: gfx950's v_bitop3_b32 (truth table
+// 0x96) does each in one slot, the compiler emits two v_xor_b32 (tools/micro/xor3_probe.hip: same words).  Not for wave-uniform generators: there the
+// plain form is scalar code, which an instruction with vector operands would drag onto the VALU.
+CC4_HD uint32_t philox_xor3(uint32_t a, uint32_t b, uint32_t c, bool vec) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  if (vec) return __builtin_amdgcn_bitop3_b32(a, b, c, 0x96);
+#endif
+  (void)vec;
+  return a ^ b ^ c;
+}
+CC4_HD void philox4x32_10(uint32_t c[4], uint32_t k0, uint32_t k1, bool vec = false) {
   for (int i = 0; i < 10; ++i) {
     uint64_t p0 = (uint64_t)0xD2511F53u * c[0];
     uint64_t p1 = (uint64_t)0xCD9E8D57u * c[2];
-    uint32_t n0 = (uint32_t)(p1 >> 32) ^ c[1] ^ k0;
+    uint32_t n0 = philox_xor3((uint32_t)(p1 >> 32), c[1], k0, vec);
     uint32_t n1 = (uint32_t)p1;
-    uint32_t n2 = (uint32_t)(p0 >> 32) ^ c[3] ^ k1;
+    uint32_t n2 = philox_xor3((uint32_t)(p0 >> 32), c[3], k1, vec);
     uint32_t n3 = (uint32_t)p0;
     c[0] = n0; c[1] = n1; c[2] = n2; c[3] = n3;
     k0 += 0x9E3779B9u;
@@ -148,16 +159,16 @@ CC4_HD void rng_seed(Rng* r, uint64_t seed, uint32_t mode) {
 
 // philox mode: called at the start of every env step -> counter = (draw#, step)
 CC4_HD void rng_begin_step(Rng* r, uint32_t step) {
-  if (r->mode == 1) { r->inc_lo = (uint64_t)step; r->s_hi = 0; r->has32 = 0; r->has64 = 0; r->ndraw = 0; }
+  if (r->mode & 1u) { r->inc_lo = (uint64_t)step; r->s_hi = 0; r->has32 = 0; r->has64 = 0; r->ndraw = 0; }
 }
 // philox: switch to stream `id` at draw 0 (each stream is used once per step). pcg: no-op (one shared stream).
 CC4_HD void rng_set_stream(Rng* r, uint32_t id) {
-  if (r->mode == 1) { r->ndraw = id; r->s_hi = 0; r->has32 = 0; r->has64 = 0; }
+  if (r->mode & 1u) { r->ndraw = id; r->s_hi = 0; r->has32 = 0; r->has64 = 0; }
 }
 // philox: between steps only (key, episode) matter; park the scratch words so that the serial walk (which switches
 // streams in place) and the lane-parallel kernel (which forks lane-local generators) leave identical bytes behind
 CC4_HD void rng_park(Rng* r) {
-  if (r->mode == 1) { r->s_hi = 0; r->has32 = 0; r->u32 = 0; r->ndraw = 0; r->has64 = 0; r->buf64 = 0; }
+  if (r->mode & 1u) { r->s_hi = 0; r->has32 = 0; r->u32 = 0; r->ndraw = 0; r->has64 = 0; r->buf64 = 0; }
 }
 // philox: lane-local generator for stream `id` of the current (step, episode) of `parent`
 CC4_HD void rng_fork(Rng* r, const Rng* parent, uint32_t id) {
@@ -166,7 +177,7 @@ CC4_HD void rng_fork(Rng* r, const Rng* parent, uint32_t id) {
 }
 // philox mode: a new episode (reset) bumps the 4th counter word so successive episodes differ
 CC4_HD void rng_begin_episode(Rng* r) {
-  if (r->mode == 1) { r->inc_hi++; r->inc_lo = 0xFFFFFFFFull; r->s_hi = 0; r->has32 = 0; r->has64 = 0; r->ndraw = ST_RESET; }
+  if (r->mode & 1u) { r->inc_hi++; r->inc_lo = 0xFFFFFFFFull; r->s_hi = 0; r->has32 = 0; r->has64 = 0; r->ndraw = ST_RESET; }
 }
 
 CC4_HD uint64_t rng_next64(Rng* r) {
@@ -182,7 +193,7 @@ CC4_HD uint64_t rng_next64(Rng* r) {
     r->has64 = 0; return r->buf64;
   }
   uint32_t c[4] = {(uint32_t)r->s_hi, r->ndraw, (uint32_t)r->inc_lo, (uint32_t)r->inc_hi};
-  philox4x32_10(c, (uint32_t)r->s_lo, (uint32_t)(r->s_lo >> 32));
+  philox4x32_10(c, (uint32_t)r->s_lo, (uint32_t)(r->s_lo >> 32), r->mode == 3u);
   r->s_hi++;
   r->buf64 = (uint64_t)c[2] | ((uint64_t)c[3] << 32);
   r->has64 = 1;
@@ -192,7 +203,7 @@ CC4_HD uint64_t rng_next64(Rng* r) {
 // philox: block `ctr` of stream `stream` of r's (key, step, episode) -- what rng_next64 would compute there
 CC4_HD void rng_block(const Rng* r, uint32_t stream, uint32_t ctr, uint32_t c[4]) {
   c[0] = ctr; c[1] = stream; c[2] = (uint32_t)r->inc_lo; c[3] = (uint32_t)r->inc_hi;
-  philox4x32_10(c, (uint32_t)r->s_lo, (uint32_t)(r->s_lo >> 32));
+  philox4x32_10(c, (uint32_t)r->s_lo, (uint32_t)(r->s_lo >> 32), r->mode == 3u);
 }
 // philox, right after rng_set_stream: block 0 of the stream was computed elsewhere (rng_block; the lane-parallel kernel
 // computes it where a thread has slack); the generator hands out these words instead of computing them
@@ -213,7 +224,7 @@ CC4_HD uint32_t rng_next32(Rng* r);
 CC4_HD double rng_random(Rng* r) {
   // counter-based mode: one 32-bit word per uniform (every threshold on the path is a multiple of 1/100 or 1/4), so that a
   // typical agent-phase (a bounded int, a uniform, two more bounded ints) fits one Philox block instead of two
-  if (r->mode == 1) return (double)rng_next32(r) * (1.0 / 4294967296.0);
+  if (r->mode & 1u) return (double)rng_next32(r) * (1.0 / 4294967296.0);
   return (double)(rng_next64(r) >> 11) * (1.0 / 9007199254740992.0);
 }
 
