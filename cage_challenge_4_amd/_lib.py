@@ -114,6 +114,7 @@ SIGNATURES = {
     'cc4_exchange_info': (ctypes.c_int, [_P, _P]),
     'cc4_debug_gather_log': (ctypes.c_int, [_P, ctypes.c_int32]),
     'cc4_debug_rollout_state': (ctypes.c_int, [_P, _P]),
+    'cc4_debug_stop_phase': (ctypes.c_int, [_P, ctypes.c_int]),
     'cc4_debug_copy_from_device': (ctypes.c_int, [_P, _P, _P, ctypes.c_size_t]),
     'cc4_get_gather_log': (ctypes.c_int, [_P, _P, ctypes.c_int32, ctypes.c_int32]),
     'cc4_get_allgathered_obs': (ctypes.c_int, [_P, _P]),

@@ -62,6 +62,7 @@ struct cc4_handle {
                                                  // the caller works on the WHOLE batch between steps (launch_step: one launch then, not one per group)
   bool main_ahead = false;                       // the main stream holds work the group streams have not been ordered behind
   unsigned long long* d_prof = nullptr;
+  int dbg_stop = 0;                  // cc4_debug_stop_phase
   uint32_t* d_reset_ws = nullptr;    // k_step_philox1's generation work area, [num_envs][RESET_WS_WORDS]
   uint8_t* d_unpacked = nullptr;                 // [world*N][578] bytes: cc4_unpack_obs_device
   int evlog_on = 0;               // cc4_enable_event_log
@@ -263,12 +264,12 @@ static void launch_group(cc4_handle* h, StepArgs a, int g, bool full, hipEvent_t
   launch_range(h, a, h->glo[g], h->glo[g + 1], h->gstream[g], full, start, stop);
 }
 static void launch_range(cc4_handle* h, StepArgs a, int e0, int e1, hipStream_t st, bool full, hipEvent_t start, hipEvent_t stop) {
-  a.e0 = e0; a.n = e1;
+  a.e0 = e0; a.n = e1; a.dbg_stop = h->dbg_stop;
   const size_t lds1 = offsetof(EnvState, hd);     // one-wave kernels: the agent part
   const dim3 grid(a.n - a.e0);
   if (h->cfg.rng_mode == 1) {
     if (h->philox_lean) {
-      if (full || h->d_prof) hipExtLaunchKernelGGL(k_step_philox1<true>, grid, dim3(WAVE), lds1, st, start, stop, 0, a);
+      if (full || h->d_prof || h->dbg_stop) hipExtLaunchKernelGGL(k_step_philox1<true>, grid, dim3(WAVE), lds1, st, start, stop, 0, a);
       else hipExtLaunchKernelGGL(k_step_philox1<false>, grid, dim3(WAVE), lds1, st, start, stop, 0, a);
     }
     else if (full) hipExtLaunchKernelGGL((k_step_philox<true, 1>), grid, dim3(PT), sizeof(EnvState), st, start, stop, 0, a);
@@ -500,7 +501,7 @@ const char* cc4_step_kernel(cc4_handle* h) {
 // step and group -- or one of the one-launch forms
 const char* cc4_run_kernel(cc4_handle* h) {
   if (!h) return "";
-  const bool plain = (!h->comm || h->xchg_on) && !h->evlog_on && !h->ext_seen && !h->d_prof;
+  const bool plain = (!h->comm || h->xchg_on) && !h->evlog_on && !h->ext_seen && !h->d_prof && !h->dbg_stop;
   if (plain && h->multistep) return h->multistep_minb == 8 ? "k_run_philox8" : "k_run_philox";
   if (plain && h->run1m) return "k_run_philox1m";
   if (plain && h->persist_state >= 0) return h->cfg.rng_mode == 0 ? "k_run_pcg" : (h->comm ? "k_run_philox1x" : "k_run_philox1");      // (calls of fewer than persist_min_k steps: the per-step launches)
@@ -1294,7 +1295,7 @@ static int run_random_steps_impl(cc4_handle* h, uint64_t seed0, uint32_t t0, int
   h->prev_valid = false;        // (every form of this call moves the rows without refreshing the kept copy of cc4_keep_previous)
   HIPCHK(h, hipSetDevice(h->cfg.device_id));
   if (k <= 0) { if (ms_step_kernels) *ms_step_kernels = 0.f; return 0; }   // nothing to launch, no timing event to read
-  const bool plain = (!h->comm || h->xchg_on) && !h->evlog_on && !h->ext_seen && !h->d_prof;
+  const bool plain = (!h->comm || h->xchg_on) && !h->evlog_on && !h->ext_seen && !h->d_prof && !h->dbg_stop;
   if (plain && h->persist_state == 0 && !h->run1m && !h->multistep && k >= h->persist_min_k) { if (persist_setup(h)) return -1; }
   const int form = !plain ? 0 : (h->multistep && k >= 2) ? 1 : (h->run1m && k >= 2) ? 2 : (h->persist_state == 1 && h->run_P > 0 && k >= h->persist_min_k) ? 3 : 0;
   if (form) {
@@ -1835,6 +1836,15 @@ int cc4_debug_profile(cc4_handle* h, int enable, unsigned long long* out) {
   if (enable && !h->d_prof) { HIPCHK(h, hipMalloc(&h->d_prof, bytes)); HIPCHK(h, hipMemsetAsync(h->d_prof, 0, bytes, h->stream)); }
   if (out && h->d_prof) { HIPCHK(h, hipMemcpyAsync(out, h->d_prof, bytes, hipMemcpyDeviceToHost, h->stream)); HIPCHK(h, hipStreamSynchronize(h->stream)); }
   if (!enable && h->d_prof) { (void)hipFree(h->d_prof); h->d_prof = nullptr; }
+  return 0;
+}
+
+// measurement (tools/valu_phases.py): from now on the per-step launches of k_step_philox1 (its full build) end behind phase `phase` of the step (1..13,
+// csrc/cc4_philox1_body.h CC4_STOP) and write no row back; 14 = whole steps of the full build; 0 = whole steps of the usual build again.  The caller restores the batch (cc4_set_state / cc4_set_cold) after such a step.
+int cc4_debug_stop_phase(cc4_handle* h, int phase) {
+  if (join_groups(h)) return -1;
+  if (phase < 0 || phase > 14 || !h->philox_lean) { h->err = "cc4_debug_stop_phase: phase 0..14, on a handle whose step kernel is k_step_philox1"; return -2; }
+  h->dbg_stop = phase;
   return 0;
 }
 

@@ -83,7 +83,7 @@ CC4_HD int h_slot(int h) { return h % SLOTS; }
 CC4_HD bool h_is_router(int h) { return h_slot(h) == 0; }          // incl. root_internet_host_0
 CC4_HD bool h_is_user(int h) { int sl = h_slot(h); return sl >= 1 && sl <= 10; }
 CC4_HD bool h_is_server(int h) { return h_slot(h) >= 11; }
-CC4_HD int h_make(int s, int slot) { return s * SLOTS + slot; }
+CC4_HD constexpr int h_make(int s, int slot) { return s * SLOTS + slot; }
 CC4_HD bool bit_get(const uint32_t* b, int i) { return (b[i >> 5] >> (i & 31)) & 1u; }
 CC4_HD void bit_set(uint32_t* b, int i) { b[i >> 5] |= 1u << (i & 31); }
 CC4_HD void bit_clr(uint32_t* b, int i) { b[i >> 5] &= ~(1u << (i & 31)); }
@@ -2802,7 +2802,7 @@ CC4_HD int env_flat_obs_sorted(const EnvState* s, int v, int* idx) {
 // step): entry v = position in the vector | source byte << 10 | bit mask << 18; the value is (byte & mask) != 0.  Source byte
 // 0..136: the event bits of host h (EnvState.hev); 137 + 8 j + i: message bit i of blue agent j (EnvState.msg[j][i]).  Same enumeration as
 // env_flat_obs_sorted (tests/test_host_logic.py checks the two against each other).
-CC4_HD uint32_t obs_fast_entry(int v) {
+CC4_HD constexpr uint32_t obs_fast_entry(int v) {
   if (v >= 224) {
     const int w = v - 224, b = w >> 5, m = w & 31, jj = m / MSG_LEN;
     const int idx = (b < 4 ? b * OBS_SHORT + OBS_SHORT : 4 * OBS_SHORT + OBS_LONG) - 32 + m;

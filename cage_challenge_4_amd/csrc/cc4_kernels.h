@@ -65,6 +65,8 @@ struct StepArgs {
                               // several launches on separate streams: see cc4_handle::ngroups); n = one past its last episode
   int act_sys;                // the actions were written by ANOTHER kernel while this one runs (a rollout, RunArgs.act_ready): system-scope loads,
                               // past this XCD's L2, which may still hold the line from two steps ago
+  int dbg_stop;               // measurement (cc4_debug_stop_phase, full build of k_step_philox1 only): the step ends after its phase number dbg_stop and
+                              // writes no row back -- the instruction counters of such launches, differenced, are the instructions of each phase
 };
 
 // uniform blue action index of (episode e, agent b) at step t: Philox key (seed0 + e), counter (t, b, 0xB10E, 0)
@@ -194,23 +196,45 @@ __device__ __forceinline__ void xchg_wait_slab(const XchgArgs& x, uint32_t k, ui
 __device__ __forceinline__ void xchg_count(const XchgArgs& x, uint32_t k, int group) {
   (void)__hip_atomic_fetch_add(x.gcnt + (size_t)group * (size_t)x.ring + (k % (uint32_t)x.ring), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
-// The observation values that can change with every step: position, source byte and mask of value v from obs_fast_entry(v) (cc4_engine.h).
+// The observation values that can change with every step: position, source byte and mask of value v = obs_fast_entry(v) (cc4_engine.h), as a table the
+// compiler fills (one copy per translation unit, 1.5 KB of constant memory that the vector L1 keeps).  Until r06 the entries were computed per value and
+// step (r03 A/B: a dozen shifts and multiplies beat one load while the kernels waited on memory, not on the vector unit); at 24 waves per CU the step is
+// bound by vector issue slots and those instructions were a sixth of it (profiles/r06_valu_phases.txt: 453 of 2 689 per episode-step).
+// Device entry: byte position in the vector (4 x index, 12 bits) | byte offset of the source byte in the staged row << 12 (hev[] and msg[][] both live in
+// the agent part, below 8 KB) | bit mask << 25 (the event masks are nibbles), so that a value is one LDS byte read, an and, a compare and a store.
+struct ObsFastTab { uint32_t v[OBS_FAST]; };
+constexpr ObsFastTab make_obs_fast_tab() {
+  ObsFastTab t{};
+  for (int v = 0; v < OBS_FAST; ++v) {
+    const uint32_t e = obs_fast_entry(v), src = (e >> 10) & 0xFFu;
+    const uint32_t off = src < (uint32_t)MAXH ? (uint32_t)offsetof(EnvState, hev) + src : (uint32_t)offsetof(EnvState, msg) + (src - (uint32_t)MAXH);
+    t.v[v] = ((e & 0x3FFu) << 2) | (off << 12) | ((e >> 18) << 25);
+  }
+  return t;
+}
+static_assert(offsetof(EnvState, hev) + MAXH <= 8192 && offsetof(EnvState, msg) + NBLUE * MSG_LEN <= 8192, "source offsets fit 13 bits");
+static_assert((EV_CUR_PROC | EV_OLD_PROC | EV_CUR_CONN | EV_OLD_CONN) < 128 && OBS_TOTAL * 4 <= 4096, "mask and byte position fit their fields");
+static __device__ const ObsFastTab obs_fast_tab = make_obs_fast_tab();
 template <int nt>
 __device__ __forceinline__ void encode_obs_fast(const EnvState* s, int32_t* o, uint8_t* obs_bytes, bool pack, int t) {
   constexpr int NV = (OBS_FAST + nt - 1) / nt;
+  constexpr bool EXACT = OBS_FAST % nt == 0;             // one wave: 6 x 64 values, no lane is ever out of range
+  const uint32_t tt = (uint32_t)t;
+  __builtin_assume(tt < (uint32_t)nt);
   uint32_t ent[NV];
 #pragma unroll
-  // computed, not loaded: the kernels wait on memory, not on the vector unit (r03 A/B: a table form of this loop -- one L2 load
-  // per value instead of a dozen shifts and multiplies -- made the encode phase longer: 5.5k -> 6.9k cycles at 8192 episodes)
-  for (int k = 0; k < NV; ++k) { const int v = t + k * nt; ent[k] = v < OBS_FAST ? obs_fast_entry(v) : 0u; }
+  for (int k = 0; k < NV; ++k) { const uint32_t v = tt + (uint32_t)(k * nt); ent[k] = (EXACT || v < (uint32_t)OBS_FAST) ? obs_fast_tab.v[v] : 0u; }   // NV independent loads, one wait
+  const uint8_t* const row = reinterpret_cast<const uint8_t*>(s);
+  char* const ob = reinterpret_cast<char*>(o);
 #pragma unroll
   for (int k = 0; k < NV; ++k) {
-    const int v = t + k * nt;
-    if (v >= OBS_FAST) continue;
-    const int val = obs_fast_value(ent[k], s);
-    const int i = (int)(ent[k] & 0x3FF);
-    o[i] = val;
-    if (pack) obs_bytes[i] = (uint8_t)val;
+    const uint32_t v = tt + (uint32_t)(k * nt);
+    if (!EXACT && v >= (uint32_t)OBS_FAST) continue;
+    const uint32_t byte = row[(ent[k] >> 12) & 0x1FFFu];
+    const int val = (byte & (ent[k] >> 25)) != 0 ? 1 : 0;
+    const uint32_t pos = ent[k] & 0xFFFu;
+    *reinterpret_cast<int32_t*>(ob + pos) = val;
+    if (pack) obs_bytes[pos >> 2] = (uint8_t)val;
   }
 }
 // ---- the persistent form of the same kernel (PERSIST): K steps of the whole batch in ONE launch.

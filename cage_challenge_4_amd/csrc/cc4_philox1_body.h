@@ -46,6 +46,8 @@ void philox1_autoreset(const StepArgs& a, const int e, const int lane, EnvState*
 // first / last (the one-launch loops): the step is the first / last of a run of consecutive steps of this episode on this wave -- only the
 // first stages the agent part in, only the last writes it back; in between the row lives in LDS (the host table, the cold row and the outputs
 // are read and written in memory by every step as always).
+// cc4_debug_stop_phase (full build only; wave-uniform): leave the step behind phase n
+#define CC4_STOP(n) do { if (LOG && a.dbg_stop == (n)) return; } while (0)
 template <bool LOG, bool PERSIST>
 __device__ __forceinline__ void philox1_body(StepArgs a, const int e, const uint32_t rand_t, const uint32_t item_k, const int lane,
                                              const bool first, const bool last) {
@@ -85,6 +87,7 @@ __device__ __forceinline__ void philox1_body(StepArgs a, const int e, const uint
       (void)step_phase(x, false);
     }
     if (step_ok) {
+      CC4_STOP(1);                                                               // staged in, work area zeroed, step_phase
       const int ng = s->n_green;
       // one lane-private generator per lane, in registers: every use starts with rng_set_stream(); mode pinned so the PCG
       // paths fold away
@@ -127,6 +130,7 @@ __device__ __forceinline__ void philox1_body(StepArgs a, const int e, const uint
 #pragma unroll
         for (int k = 0; k < 4; ++k) out[k] = (uint32_t)__builtin_amdgcn_ds_bpermute(addr, (int)bank[k]);
       };
+      CC4_STOP(2);                                                               // + the block bank
       const bool is_red = lane < NRED;
       unsigned long long* ap = (a.prof && is_red) ? a.prof + PROF_SLOTS * (size_t)e + 16 + 8 * lane : nullptr;
       Ctx xr{s, cold_e, &rl, hd, &work, nullptr, ap, lg};
@@ -141,7 +145,7 @@ __device__ __forceinline__ void philox1_body(StepArgs a, const int e, const uint
         const int dropped = step_red_policy_tick(xr, lane, false, pre_rp);
         if (ap) ap[0] += clock64() - t0;
         if (dropped) atomicSub(&s->n_actions, 1);
-      } else if (lane >= 8 && lane < 8 + NBLUE) {
+      } else if (lane >= 8 && lane < 8 + NBLUE && !(LOG && a.dbg_stop == 3)) {
         const int b = lane - 8;
         int32_t act = !a.actions ? -1 : a.act_sys ? __hip_atomic_load(a.actions + e * NBLUE + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) : a.actions[e * NBLUE + b];
         if (a.rand_out) { act = (int32_t)(((uint64_t)brand * (uint32_t)(b == 4 ? ACT_LONG : ACT_SHORT)) >> 32); a.rand_out[e * NBLUE + b] = act; }   // == random_blue_action
@@ -149,10 +153,13 @@ __device__ __forceinline__ void philox1_body(StepArgs a, const int e, const uint
         step_tick_blue(xg, b);
         step_messages(s, a.msgs ? a.msgs + e * NBLUE * MSG_LEN : nullptr, b);   // read back by this step's observation encode only
       }
-      if (lane < ng) step_green_policy(xg, lane);                               // agents 0..63: their block is computed here, by all of them at once
-      if (lane + WAVE < ng) step_green_policy(xg, lane + WAVE, bank);            // agents 64..: from the bank (their lane's own request)
+      if (!(LOG && (a.dbg_stop == 3 || a.dbg_stop == 4))) {
+        if (lane < ng) step_green_policy(xg, lane);                             // agents 0..63: their block is computed here, by all of them at once
+        if (lane + WAVE < ng) step_green_policy(xg, lane + WAVE, bank);          // agents 64..: from the bank (their lane's own request)
+      }
       __syncthreads();
       CC4_TICK(x0, 2);
+      CC4_STOP(3); CC4_STOP(4); CC4_STOP(5);                                     // + red policies and queue ticks / + blue submissions / + green policies
       // ---- P3b blue actions: side by side when they are independent (no Monitor, no pending pid events), else in the reference's order on
       // lane 0 (ControlTraffic first, then agent order: step_blue_exec).  ONE call site of blue_execute for both forms -- the action bodies are
       // a quarter of the kernel's code, and a second and third inlined copy of them is what the instruction cache holds least well.
@@ -182,6 +189,7 @@ __device__ __forceinline__ void philox1_body(StepArgs a, const int e, const uint
         __syncthreads();
         if (lane == 0) CC4_TICK(x0, 5);
       }
+      CC4_STOP(6);                                                               // + blue actions
       // ---- P4 green actions, one agent per lane
       {
         // A third of the up to 80 agents sleeps, so the ones with an action nearly always fit the wave's 64 lanes: they are
@@ -206,10 +214,12 @@ __device__ __forceinline__ void philox1_body(StepArgs a, const int e, const uint
       }
       __syncthreads();
       CC4_TICK(x0, 6);
+      CC4_STOP(7);                                                               // + green actions
       // ---- P5 deferred phishing (ordered), then P6 red actions: side by side when they name distinct hosts
       if (lane == 0) { step_phishing(x0); CC4_TICK(x0, 1); rs_reserve(x0); conflict_lds = (int)red_conflict_mask(s); if (prof && conflict_lds) prof[4] += 1000000; }
       __syncthreads();
       const uint32_t serial_red = (uint32_t)conflict_lds;
+      CC4_STOP(8);                                                               // + phishing, slot reservation, conflict mask (lane 0)
       uint32_t pre_re[4];
       bank_fetch(BK_REXE, pre_re);                                                // red r (lane r) <- lane BK_REXE + r
       // round 0: the agents whose actions commute, each on its lane; then the same-host actions (everything when some agent withdraws) in agent
@@ -237,6 +247,7 @@ __device__ __forceinline__ void philox1_body(StepArgs a, const int e, const uint
           if (!todo) break;
         }
       }
+      CC4_STOP(9);                                                               // + red actions
       if (lane == 0) {
         step_red_merge(x0);
         CC4_TICK(x0, 7);
@@ -245,9 +256,11 @@ __device__ __forceinline__ void philox1_body(StepArgs a, const int e, const uint
       }
       // P7 end-turn Monitor roll-over: the hosts' event bytes are part of the staged row (EnvState.hev).  (Lane 0's reassignment above
       // moves sessions, not events.)
+      CC4_STOP(10);                                                              // + merge, reassignment (lane 0)
       for (int h = lane; h < MAXH; h += WAVE) s->hev[h] = monitor_roll(h, s->hev[h]);
       __syncthreads();
       CC4_TICK(x0, 9);
+      CC4_STOP(11);                                                              // + Monitor roll-over
       // ---- P8 end-turn RedSessionCheck on the red lanes; the Monitor's sus-pid hand-over and the step's bookkeeping on the last
       if (is_red) { unsigned long long t0 = ap ? clock64() : 0; step_rsc(xr, lane); if (ap) ap[2] += clock64() - t0; }
       if (lane == WAVE - 1) {
@@ -259,6 +272,7 @@ __device__ __forceinline__ void philox1_body(StepArgs a, const int e, const uint
     } else if (lane == 0) { a.reward[e] = s->reward; a.done[e] = s->done; }
   }
   __syncthreads();
+  CC4_STOP(12);                                                                  // + RedSessionCheck, Monitor hand-over, end of step
   unsigned long long t_obs = a.prof ? clock64() : 0;
   {
     int32_t* o = a.obs + (size_t)e * OBS_TOTAL;
@@ -267,6 +281,7 @@ __device__ __forceinline__ void philox1_body(StepArgs a, const int e, const uint
     for (int v = OBS_FAST + lane; v < nv; v += WAVE) { int i; const int val = env_flat_obs_sorted(s, v, &i); o[i] = val; }
   }
   __syncthreads();
+  CC4_STOP(13);                                                                  // + observation encode; 0 = the whole step (row written back)
   if (lane == 0) a.err[e] = s->err;
   unsigned long long t_out = a.prof ? clock64() : 0;
   if (prof && lane == 0) prof[12] += t_out - t_obs;

@@ -24,7 +24,7 @@ CC4_HD int blue_nsub(int b) { return b == 4 ? 3 : 1; }
 CC4_HD int blue_subnet_alloc(int b, int i) {  // allowed_subnets order (session creation order): b<4 -> subnet b
   return b == 4 ? (i == 0 ? S_PUB : (i == 1 ? S_ADM : S_OFF)) : b;
 }
-CC4_HD int blue_subnet_sorted(int b, int i) {  // sorted(subnets): wrappers' obs/action order
+CC4_HD constexpr int blue_subnet_sorted(int b, int i) {  // sorted(subnets): wrappers' obs/action order
   return b == 4 ? (i == 0 ? S_ADM : (i == 1 ? S_OFF : S_PUB)) : b;
 }
 CC4_HD int blue_of_subnet(int s) {  // {0,1,2,3,-1,4,4,4,-1}

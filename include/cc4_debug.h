@@ -24,6 +24,10 @@ int cc4_get_gather_log(cc4_handle* h, uint8_t* out, int32_t first, int32_t count
  * microseconds (0: off) -- an exchange slower than the steps, which makes the guard of the observation ring actually wait */
 int cc4_debug_comm_delay_us(cc4_handle* h, int us);
 
+/* measurement (tools/valu_phases.py): the per-step launches of k_step_philox1 end behind phase `phase` (1..13: csrc/cc4_philox1_body.h CC4_STOP) and write no
+ * row back; 14 = whole steps, still of the full build; 0 = off.  Restore the batch (cc4_set_state / cc4_set_cold) after such a step. */
+int cc4_debug_stop_phase(cc4_handle* h, int phase);
+
 /* debug: where a rollout stands (see csrc/cc4_api.hip) */
 int cc4_debug_rollout_state(cc4_handle* h, int64_t* out /* [22] */);
 /* test hook: `bytes` bytes of device memory of this handle's device -- e.g. an action slot of a rollout (cc4_rollout_actions), packed observation rows
