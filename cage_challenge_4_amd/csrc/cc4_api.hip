@@ -265,6 +265,7 @@ static void launch_group(cc4_handle* h, StepArgs a, int g, bool full, hipEvent_t
 }
 static void launch_range(cc4_handle* h, StepArgs a, int e0, int e1, hipStream_t st, bool full, hipEvent_t start, hipEvent_t stop) {
   a.e0 = e0; a.n = e1; a.dbg_stop = h->dbg_stop;
+  if (h->dbg_stop) a.full_obs = 0;     // (a restored batch would get every observation value rewritten: the measurement wants the steady-state encode)
   const size_t lds1 = offsetof(EnvState, hd);     // one-wave kernels: the agent part
   const dim3 grid(a.n - a.e0);
   if (h->cfg.rng_mode == 1) {

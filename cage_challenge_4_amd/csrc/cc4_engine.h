@@ -1076,6 +1076,46 @@ CC4_HD void env_reset(Ctx x, uint64_t seed, int rng_mode, int steps, bool contin
 // ------------------------------------------------------------------ blue actions
 // wrapper index -> action (Agents/Wrappers/BlueFixedActionWrapper.py:233-309)
 enum : int { BLUE_RAW_ACTION = 0x10000 };   // idx = BLUE_RAW_ACTION | BA_* type << 8 | host id: see blue_decode
+// What slot idx of blue agent b's action list names before the episode's topology is consulted (BlueFixedActionWrapper.py:241-300: Analyse x hosts,
+// Monitor, Remove x hosts, Restore x hosts, Sleep, Allow x (8 other subnets per own subnet), Block x same, DeployDecoy x hosts; hosts = the 16 server /
+// user positions of each of the agent's subnets in sorted order): type | host id << 8 for the host actions, type | to-subnet << 8 | from-subnet << 16 for
+// Allow / Block.  A pure function of (b, idx): the device reads it from a table the compiler fills (blue_slot), the host computes it.
+CC4_HD constexpr uint32_t blue_slot_shape(int b, int idx) {
+  const int nsub = blue_nsub(b), nh = ZONE_HOSTS * nsub, nc = 8 * nsub;
+  int t = BA_SLEEP, j = 0;
+  if (idx < 0 || idx >= 4 * nh + 2 + 2 * nc) return (uint32_t)BA_SLEEP;
+  if (idx < nh) { t = BA_ANALYSE; j = idx; }
+  else if (idx == nh) return (uint32_t)BA_MONITOR;
+  else if (idx < 2 * nh + 1) { t = BA_REMOVE; j = idx - nh - 1; }
+  else if (idx < 3 * nh + 1) { t = BA_RESTORE; j = idx - 2 * nh - 1; }
+  else if (idx == 3 * nh + 1) return (uint32_t)BA_SLEEP;
+  else if (idx < 3 * nh + 2 + nc) { t = BA_ALLOW; j = idx - 3 * nh - 2; }
+  else if (idx < 3 * nh + 2 + 2 * nc) { t = BA_BLOCK; j = idx - 3 * nh - 2 - nc; }
+  else { t = BA_DECOY; j = idx - 3 * nh - 2 - 2 * nc; }
+  if (t == BA_ALLOW || t == BA_BLOCK) {
+    const int dst = blue_subnet_sorted(b, j / 8), k = j % 8;
+    // the 8 other subnets in alphabetical order
+    int src = 0, c = 0;
+    for (int i = 0; i < NSUB; ++i) { const int sn = sorted_subnet(i); if (sn == dst) continue; if (c == k) { src = sn; break; } c++; }
+    return (uint32_t)t | ((uint32_t)dst << 8) | ((uint32_t)src << 16);
+  }
+  const int sn = blue_subnet_sorted(b, j / ZONE_HOSTS), hs = j % ZONE_HOSTS;
+  const int h = hs < MAX_SERVERS ? h_make(sn, 11 + hs) : h_make(sn, 1 + (hs - MAX_SERVERS));
+  return (uint32_t)t | ((uint32_t)h << 8);
+}
+#if defined(__HIP_DEVICE_COMPILE__)
+// (the decode's divisions and subnet search were ~60 vector instructions of every step on the blue lanes; the step kernels are bound by vector issue slots)
+struct BlueSlotTab { uint32_t v[NBLUE][ACT_LONG]; };
+constexpr BlueSlotTab make_blue_slot_tab() {
+  BlueSlotTab t{};
+  for (int b = 0; b < NBLUE; ++b) for (int i = 0; i < ACT_LONG; ++i) t.v[b][i] = blue_slot_shape(b, i);
+  return t;
+}
+static __device__ const BlueSlotTab blue_slot_tab = make_blue_slot_tab();
+__device__ __forceinline__ uint32_t blue_slot(int b, int idx) { return blue_slot_tab.v[b][idx]; }      // callers pass 0 <= idx < the agent's list length
+#else
+inline uint32_t blue_slot(int b, int idx) { return blue_slot_shape(b, idx); }
+#endif
 CC4_HD Act blue_decode(const EnvState* s, int b, int idx) {
   Act a; a.type = BA_SLEEP; a.host = 0; a.arg = 0; a.ticks = 1; a.sid = 0; a.busy = 0;
   int nsub = blue_nsub(b), nh = ZONE_HOSTS * nsub, nc = 8 * nsub;
@@ -1101,25 +1141,11 @@ CC4_HD Act blue_decode(const EnvState* s, int b, int idx) {
     return a;
   }
   if (idx < 0 || idx >= total) return a;  // padding / "no action submitted" -> Sleep
-  int t, j = 0;
-  if (idx < nh) { t = BA_ANALYSE; j = idx; }
-  else if (idx == nh) { a.type = BA_MONITOR; return a; }
-  else if (idx < 2 * nh + 1) { t = BA_REMOVE; j = idx - nh - 1; }
-  else if (idx < 3 * nh + 1) { t = BA_RESTORE; j = idx - 2 * nh - 1; }
-  else if (idx == 3 * nh + 1) { return a; }
-  else if (idx < 3 * nh + 2 + nc) { t = BA_ALLOW; j = idx - 3 * nh - 2; }
-  else if (idx < 3 * nh + 2 + 2 * nc) { t = BA_BLOCK; j = idx - 3 * nh - 2 - nc; }
-  else { t = BA_DECOY; j = idx - 3 * nh - 2 - 2 * nc; }
-  if (t == BA_ALLOW || t == BA_BLOCK) {
-    int dst = blue_subnet_sorted(b, j / 8), k = j % 8;
-    // the 8 other subnets in alphabetical order
-    int src = -1, c = 0;
-    for (int i = 0; i < NSUB; ++i) { int sn = sorted_subnet(i); if (sn == dst) continue; if (c == k) { src = sn; break; } c++; }
-    a.type = (uint8_t)t; a.host = (uint8_t)dst; a.arg = (uint8_t)src;
-    return a;
-  }
-  int sn = blue_subnet_sorted(b, j / ZONE_HOSTS), hs = j % ZONE_HOSTS;
-  int h = hs < MAX_SERVERS ? h_make(sn, 11 + hs) : h_make(sn, 1 + (hs - MAX_SERVERS));
+  const uint32_t sh = blue_slot(b, idx);
+  const int t = (int)(sh & 0xFF), h = (int)((sh >> 8) & 0xFF);
+  if (t == BA_SLEEP) return a;
+  if (t == BA_MONITOR) { a.type = BA_MONITOR; return a; }
+  if (t == BA_ALLOW || t == BA_BLOCK) { a.type = (uint8_t)t; a.host = (uint8_t)h; a.arg = (uint8_t)(sh >> 16); return a; }
   if (!bit_get(s->exists, h)) return a;  // "[Invalid] ..." slot -> Sleep() (BlueFixedActionWrapper.py:295-298)
   a.type = (uint8_t)t; a.host = (uint8_t)h;
   return a;

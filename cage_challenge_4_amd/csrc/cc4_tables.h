@@ -16,11 +16,11 @@ namespace cc4 {
 // operational_a, operational_b, public_access, restricted_a, restricted_b
 // (small tables are nibble/byte-packed into immediates: a dynamically indexed local array would be a memory load
 // on the device, and these sit inside the per-agent loops)
-CC4_HD int sorted_subnet(int i) { return (int)((0x205317846ull >> (4 * i)) & 0xF); }   // {ADM,CON,INT,OFF,OZA,OZB,PUB,RZA,RZB}
+CC4_HD constexpr int sorted_subnet(int i) { return (int)((0x205317846ull >> (4 * i)) & 0xF); }   // {ADM,CON,INT,OFF,OZA,OZB,PUB,RZA,RZB}
 CC4_HD int subnet_rank(int s) { return (int)((0x230615847ull >> (4 * s)) & 0xF); }     // inverse permutation
 
 // blue zones, EnterpriseScenarioGenerator.py:643-649 (allowed_subnets order) -- bitmask + ordered list
-CC4_HD int blue_nsub(int b) { return b == 4 ? 3 : 1; }
+CC4_HD constexpr int blue_nsub(int b) { return b == 4 ? 3 : 1; }
 CC4_HD int blue_subnet_alloc(int b, int i) {  // allowed_subnets order (session creation order): b<4 -> subnet b
   return b == 4 ? (i == 0 ? S_PUB : (i == 1 ? S_ADM : S_OFF)) : b;
 }
