@@ -1438,8 +1438,8 @@ CC4_HD bool green_local_work(Ctx x, int gh, uint64_t pre, bool* want_phish, doub
   const uint32_t st = (uint32_t)(pre >> (8 * c)) & 0xFF;
   int rel = (int)(st & 0x7F) * 20;
   if ((int)rng_below(x.r, 100) >= rel) return false;
-  if (rng_random(x.r) < fp_rate) { int port = eph_port(x, gh); ev_proc(x, gh, 0); ev_log(x, gh, gh, 1, gh, port, 0xFF, 0, 0); }   // pc = {local_address, local_port} (GreenLocalWork.py:112-115)
-  if (rng_random(x.r) < phish_rate) *want_phish = true;  // PhishingEmail sub-action: executed by the caller (ordering, see P5)
+  if (rng_random_lt(x.r, fp_rate)) { int port = eph_port(x, gh); ev_proc(x, gh, 0); ev_log(x, gh, gh, 1, gh, port, 0xFF, 0, 0); }   // pc = {local_address, local_port} (GreenLocalWork.py:112-115)
+  if (rng_random_lt(x.r, phish_rate)) *want_phish = true;  // PhishingEmail sub-action: executed by the caller (ordering, see P5)
   return true;
 }
 // GreenAccessService.execute (GreenActions/GreenAccessService.py:137-217). returns success.  pre: green_prepare's word
@@ -1453,7 +1453,7 @@ CC4_HD bool green_access_service(Ctx x, int gh, uint64_t pre, double fp_rate = 0
   int ds = sn;
   // events land on the destination server (`from_host` in the reference, GreenAccessService.py:176-214)
   if (subnet_blocked(x, ds, own) || subnet_blocked(x, own, ds)) { ev_conn(x, dest); ev_log(x, gh, dest, 0, dest, 0, gh, 8800, 0); return false; }
-  if (rng_random(x.r) < fp_rate) { ev_conn(x, dest); ev_log(x, gh, dest, 0, gh, 0, dest, dest_port, 0); }
+  if (rng_random_lt(x.r, fp_rate)) { ev_conn(x, dest); ev_log(x, gh, dest, 0, gh, 0, dest, dest_port, 0); }
   return true;
 }
 
@@ -1510,7 +1510,7 @@ CC4_HD void red_scan(Ctx x, int r, const Act& a, double rate) {
   if (!(rsw_flags(sw) & RS_ABSTRACT)) { red_result(x, r, a, T_FALSE); return; }
   int src = rsw_host(sw), tgt = a.host;
   if (subnet_blocked(x, h_subnet(src), h_subnet(tgt))) { red_result(x, r, a, T_FALSE); return; }
-  double fixed = rng_random(x.r);
+  const bool fixed_le_rate = rng_random_le(x.r, rate);   // fixed = random(); `fixed <= rate` per port below
   int ports = 0;
   const P8N hd0 = proc_head(x, tgt);   // length and first round in one round trip
   const int np = hd0.n;
@@ -1523,7 +1523,7 @@ CC4_HD void red_scan(Ctx x, int r, const Act& a, double rate) {
       int pb = kind_port(k);
       if (!pb) continue;
       ports |= pb;
-      if (fixed <= rate || kind_is_decoy(k)) { ev_conn(x, tgt); int ep = eph_port(x, tgt, (i0 + k8) & 63); ev_log(x, 200 + r, tgt, 0, tgt, port_of_bit(pb), src, ep, 0); }   // Portscan.py:59-64
+      if (fixed_le_rate || kind_is_decoy(k)) { ev_conn(x, tgt); int ep = eph_port(x, tgt, (i0 + k8) & 63); ev_log(x, 200 + r, tgt, 0, tgt, port_of_bit(pb), src, ep, 0); }   // Portscan.py:59-64
     }
   }
   if (ports) {
@@ -1580,7 +1580,7 @@ CC4_HD void red_exploit(Ctx x, int r, const Act& a) {
     // SSHBruteForce.execute (ExploitActions/SSHBruteForce.py:24-84)
     uint8_t* work = reinterpret_cast<uint8_t*>(x.w->scratch + 6 * r);   // 24 bytes per red agent
     int nh = route(src, tgt, work);
-    for (int i = 0; i < nh; ++i) if (0.050000000000000044 < rng_random(x.r)) { ev_conn(x, work[12 + i]); ev_log(x, 200 + r, work[12 + i], 0, tgt, 0, src, 22, 0); }  // 1 - 0.95 in float64
+    for (int i = 0; i < nh; ++i) if (!rng_random_le(x.r, 0.050000000000000044)) { ev_conn(x, work[12 + i]); ev_log(x, 200 + r, work[12 + i], 0, tgt, 0, src, 22, 0); }  // 1 - 0.95 in float64
     int vp = -1;
     for (int i0 = 0; i0 < tnp && vp < 0; i0 += 8) {
       P8 q = p8_of(thd0);
@@ -1624,13 +1624,13 @@ CC4_HD void red_exploit(Ctx x, int r, const Act& a) {
   obs_put(x, r, true, tgt, OE_IFACE, false);
   bool works = (sel == X_SQLI) || decoy;  // rfi only on decoys; real Haraka is 2.8.9 (HarakaRCE.py:19, HTTPRFI.py:18)
   if (!works) { red_result(x, r, a, T_FALSE); return; }
-  if (0.0 >= rng_random(x.r)) { red_result(x, r, a, T_FALSE); return; }  // (1 - success_rate) >= random()
+  if (rng_random_le(x.r, 0.0)) { red_result(x, r, a, T_FALSE); return; }  // (1 - success_rate) >= random()
   const int lport = eph_port(x, tgt, 2);  // local_port
   if (decoy) { ev_conn(x, tgt); int ep = eph_port(x, tgt, 3); ev_log(x, 200 + r, tgt, 0, tgt, lport, src, ep, 0); red_result(x, r, a, T_FALSE); return; }
   int ni = exploit_new_session(x, r, a.sid, tgt, thd0);
   if (ni < 0) { red_result(x, r, a, T_FALSE); return; }
   const uint64_t nw = rs_at(s, A, ni);
-  if (rng_random(x.r) > 0.050000000000000044) { ev_proc_red(x, r, tgt, rsw_pid(nw)); ev_log(x, 200 + r, tgt, 1, 0xFF, 0, 0xFF, 0, rsw_pid(nw)); }
+  if (!rng_random_le(x.r, 0.050000000000000044)) { ev_proc_red(x, r, tgt, rsw_pid(nw)); ev_log(x, 200 + r, tgt, 1, 0xFF, 0, 0xFF, 0, rsw_pid(nw)); }
   obs_put(x, r, true, tgt, OE_SESS | OE_IFACE | OE_SYSHN, false);
   obs_put(x, r, true, src, OE_IFACE, false);
   A.h.new_sess_host = (uint8_t)tgt; A.h.new_sess_id = (uint16_t)rsw_id(nw);
@@ -1725,8 +1725,8 @@ CC4_HD void red_deception(Ctx x, int r, const Act& a) {
       if (i0 + k >= np) continue;
       bool decoy = kind_is_decoy(pw_kind(q.v[k]));
       bool rep = false;
-      if (rng_random(x.r) <= det_rate && decoy) rep = true;
-      else if (rng_random(x.r) <= fp_rate && !decoy) rep = true;
+      if (rng_random_le(x.r, det_rate) && decoy) rep = true;
+      else if (rng_random_le(x.r, fp_rate) && !decoy) rep = true;
       if (rep) obs_put(x, r, false, tgt, OE_IFACE, false);
     }
   }
@@ -2060,8 +2060,7 @@ CC4_HD Act fsm_get_action(Ctx x, int r, RedHdr& H, bool observed = false) {
     case FS_R:  pk = 0x4444u << 16 | (RA_DRS | RA_DEGRADE << 4 | RA_IMPACT << 8 | RA_WITHDRAW << 12); break;    // 1 0 0 0
     default:    pk = 0xF442u << 16 | (RA_DEGRADE | RA_IMPACT << 4 | RA_WITHDRAW << 8); break;                   // RD: .5 .5 0
   }
-  double u = rng_random(x.r);
-  int fl = (int)(u * 4.0);  // exact: scaling by a power of two
+  const int fl = rng_random_quarter(x.r);   // floor(4 u)
   int k = 0;
   for (int i = 0; i < 4; ++i) if ((int)((pk >> (16 + 4 * i)) & 0xF) <= fl) k++;
   int t = (int)((pk >> (4 * k)) & 0xF);

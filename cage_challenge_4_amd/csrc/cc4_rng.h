@@ -228,6 +228,37 @@ CC4_HD double rng_random(Rng* r) {
   return (double)(rng_next64(r) >> 11) * (1.0 / 9007199254740992.0);
 }
 
+// rng_random(r) < t and rng_random(r) <= t as the caller writes them, one draw.  Counter mode: the uniform is k * 2^-32 for the 32-bit word k, and both that
+// product and t * 2^32 are exact in double, so  k * 2^-32 < t  <=>  k < ceil(t * 2^32)  and  k * 2^-32 <= t  <=>  k <= floor(t * 2^32)  -- one integer
+// compare against a constant wherever t is one (every rate on the fast path), instead of a convert, a multiply and a double compare on the vector unit.
+// NaN thresholds compare false, as a double compare does.  The numpy stream keeps its 53-bit doubles.
+CC4_HD bool rng_random_lt(Rng* r, double t) {
+  if (r->mode & 1u) {
+    const uint32_t k = rng_next32(r);
+    const double s = t * 4294967296.0;
+    if (!(s > 0.0)) return false;
+    if (s >= 4294967296.0) return true;
+    const uint64_t f = (uint64_t)s;                                  // floor (s > 0)
+    return (uint64_t)k < f + ((double)f < s ? 1u : 0u);              // ceil
+  }
+  return rng_random(r) < t;
+}
+CC4_HD bool rng_random_le(Rng* r, double t) {
+  if (r->mode & 1u) {
+    const uint32_t k = rng_next32(r);
+    const double s = t * 4294967296.0;
+    if (!(s >= 0.0)) return false;
+    if (s >= 4294967296.0) return true;
+    return (uint64_t)k <= (uint64_t)s;
+  }
+  return rng_random(r) <= t;
+}
+// (int)(rng_random(r) * 4.0): the quarter the uniform falls in
+CC4_HD int rng_random_quarter(Rng* r) {
+  if (r->mode & 1u) return (int)(rng_next32(r) >> 30);
+  return (int)(rng_random(r) * 4.0);    // exact: scaling by a power of two
+}
+
 // Generator.integers(0, n) / Generator.choice(n) for 1 <= n <= 2^32:
 // distributions.c random_bounded_uint64_fill -> buffered_bounded_lemire_uint32 (rng = n-1); rng==0 draws nothing.
 CC4_HD uint32_t rng_below(Rng* r, uint32_t n) {
