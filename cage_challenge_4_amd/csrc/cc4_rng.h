@@ -42,8 +42,8 @@ struct Rng {
   uint32_t u32;             // numpy pcg64_state.uinteger (buffered high half)
   uint32_t mode;            // 0 pcg, 1 philox, 3 philox on a lane-private generator of a wave kernel (philox4x32_10's vec form; never stored in a row)
   uint32_t ndraw;           // pcg: number of 64-bit advances (diagnostics) | philox: current stream id
-  uint64_t buf64;           // philox: second 64-bit word of the last 128-bit block
-  uint32_t has64, pad;      // philox: buf64 is valid
+  uint64_t buf64;           // philox: third and fourth word of the current block
+  uint32_t has64, pad;      // philox: unread words of the current block (philox_next32)
 };
 
 // Philox stream ids: every (agent, phase) of a step draws from its own counter stream, so agents can be resolved on
@@ -168,7 +168,7 @@ CC4_HD void rng_set_stream(Rng* r, uint32_t id) {
 // philox: between steps only (key, episode) matter; park the scratch words so that the serial walk (which switches
 // streams in place) and the lane-parallel kernel (which forks lane-local generators) leave identical bytes behind
 CC4_HD void rng_park(Rng* r) {
-  if (r->mode & 1u) { r->s_hi = 0; r->has32 = 0; r->u32 = 0; r->ndraw = 0; r->has64 = 0; r->buf64 = 0; }
+  if (r->mode & 1u) { r->s_hi = 0; r->has32 = 0; r->u32 = 0; r->ndraw = 0; r->has64 = 0; r->buf64 = 0; r->pad = 0; }
 }
 // philox: lane-local generator for stream `id` of the current (step, episode) of `parent`
 CC4_HD void rng_fork(Rng* r, const Rng* parent, uint32_t id) {
@@ -180,27 +180,31 @@ CC4_HD void rng_begin_episode(Rng* r) {
   if (r->mode & 1u) { r->inc_hi++; r->inc_lo = 0xFFFFFFFFull; r->s_hi = 0; r->has32 = 0; r->has64 = 0; r->ndraw = ST_RESET; }
 }
 
+// Counter mode: the unread words of the stream's current Philox block wait in (u32, pad, buf64 low, buf64 high) in that order, has64 = how many of them;
+// a draw takes u32 and moves the others up.  (Until r06 the block was handed out as two buffered 64-bit halves with the numpy stream's 32-bit buffer on
+// top: three state words to test per draw.  Where the compiler knows the state -- the first draws behind rng_set_stream / rng_preload -- either form folds
+// away; behind a branch or a loop it does not, and the step kernels are bound by vector issue slots: this form is a test of one count and four moves.)
+CC4_HD uint32_t philox_next32(Rng* r) {
+  if (r->has64 == 0) {
+    uint32_t c[4] = {(uint32_t)r->s_hi, r->ndraw, (uint32_t)r->inc_lo, (uint32_t)r->inc_hi};
+    philox4x32_10(c, (uint32_t)r->s_lo, (uint32_t)(r->s_lo >> 32), r->mode == 3u);
+    r->s_hi++;
+    r->u32 = c[0]; r->pad = c[1]; r->buf64 = (uint64_t)c[2] | ((uint64_t)c[3] << 32); r->has64 = 4;
+  }
+  const uint32_t out = r->u32;
+  r->u32 = r->pad; r->pad = (uint32_t)r->buf64; r->buf64 >>= 32; r->has64--;
+  return out;
+}
 CC4_HD uint64_t rng_next64(Rng* r) {
-  if (r->mode == 0) {
-    r->ndraw++;
-    pcg_step(r);
-    uint64_t x = r->s_hi ^ r->s_lo;
-    uint32_t rot = (uint32_t)(r->s_hi >> 58);
-    return (x >> rot) | (x << ((64u - rot) & 63u));
-  }
-  if (r->has64) {                                     // one Philox block = two 64-bit outputs
-    if (r->has64 == 3) { r->has64 = 1; r->s_hi++; return (uint64_t)r->u32 | ((uint64_t)r->pad << 32); }   // rng_preload
-    r->has64 = 0; return r->buf64;
-  }
-  uint32_t c[4] = {(uint32_t)r->s_hi, r->ndraw, (uint32_t)r->inc_lo, (uint32_t)r->inc_hi};
-  philox4x32_10(c, (uint32_t)r->s_lo, (uint32_t)(r->s_lo >> 32), r->mode == 3u);
-  r->s_hi++;
-  r->buf64 = (uint64_t)c[2] | ((uint64_t)c[3] << 32);
-  r->has64 = 1;
-  return (uint64_t)c[0] | ((uint64_t)c[1] << 32);
+  if (r->mode & 1u) { const uint64_t lo = philox_next32(r); return lo | ((uint64_t)philox_next32(r) << 32); }   // (no caller in the counter mode: it draws 32-bit words)
+  r->ndraw++;
+  pcg_step(r);
+  uint64_t x = r->s_hi ^ r->s_lo;
+  uint32_t rot = (uint32_t)(r->s_hi >> 58);
+  return (x >> rot) | (x << ((64u - rot) & 63u));
 }
 
-// philox: block `ctr` of stream `stream` of r's (key, step, episode) -- what rng_next64 would compute there
+// philox: block `ctr` of stream `stream` of r's (key, step, episode) -- what the generator would compute there
 CC4_HD void rng_block(const Rng* r, uint32_t stream, uint32_t ctr, uint32_t c[4]) {
   c[0] = ctr; c[1] = stream; c[2] = (uint32_t)r->inc_lo; c[3] = (uint32_t)r->inc_hi;
   philox4x32_10(c, (uint32_t)r->s_lo, (uint32_t)(r->s_lo >> 32), r->mode == 3u);
@@ -208,10 +212,11 @@ CC4_HD void rng_block(const Rng* r, uint32_t stream, uint32_t ctr, uint32_t c[4]
 // philox, right after rng_set_stream: block 0 of the stream was computed elsewhere (rng_block; the lane-parallel kernel
 // computes it where a thread has slack); the generator hands out these words instead of computing them
 CC4_HD void rng_preload(Rng* r, const uint32_t c[4]) {
-  r->u32 = c[0]; r->pad = c[1]; r->buf64 = (uint64_t)c[2] | ((uint64_t)c[3] << 32); r->has64 = 3; r->has32 = 0;
+  r->u32 = c[0]; r->pad = c[1]; r->buf64 = (uint64_t)c[2] | ((uint64_t)c[3] << 32); r->has64 = 4; r->has32 = 0; r->s_hi = 1;
 }
 // pcg64_next32: low half first, high half buffered (numpy pcg64.h)
 CC4_HD uint32_t rng_next32(Rng* r) {
+  if (r->mode & 1u) return philox_next32(r);
   if (r->has32) { r->has32 = 0; return r->u32; }
   uint64_t n = rng_next64(r);
   r->has32 = 1;
