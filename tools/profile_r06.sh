@@ -27,6 +27,9 @@ rocprofv3 --kernel-trace --pmc SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_INSTS_BRANCH SQ_I
 rocprofv3 --kernel-trace --pmc SQ_IFETCH SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INST_LEVEL_LDS -d $OUT/mixD -- $B2 > /dev/null 2> $OUT/mixD.err
 python tools/rocpd_summary.py counters k_run_philox1 $OUT/${TAG}_pmc_instruction_mix_8192env_k_run_philox1.json $OUT/mixA $OUT/mixB $OUT/mixC $OUT/mixD > /dev/null 2>&1
 rm -rf $OUT/mix?
+# 3b. issue-slot use of the timed kernels, instructions per phase of a step (separate --pmc passes)
+bash tools/valu_busy.sh > /dev/null 2>&1
+bash tools/valu_phases.sh > /dev/null 2>&1
 # 4. the launch's timeline (per-wave time stamps) at the driver's K and the full bench lines
 python tools/persist_timeline.py 2>&1 | grep "cc4 timeline" > $OUT/${TAG}_persist_timeline.txt
 python bench.py --steps 20 --warmup 5 > $OUT/${TAG}_bench_driver_flags.json 2> /dev/null
