@@ -270,7 +270,7 @@ static void launch_range(cc4_handle* h, StepArgs a, int e0, int e1, hipStream_t 
   const dim3 grid(a.n - a.e0);
   if (h->cfg.rng_mode == 1) {
     if (h->philox_lean) {
-      if (full || h->d_prof || h->dbg_stop) hipExtLaunchKernelGGL(k_step_philox1<true>, grid, dim3(WAVE), lds1, st, start, stop, 0, a);
+      if (full || h->d_prof || (h->dbg_stop && !getenv("CC4_DEBUG_STOP_FAST"))) hipExtLaunchKernelGGL(k_step_philox1<true>, grid, dim3(WAVE), lds1, st, start, stop, 0, a);
       else hipExtLaunchKernelGGL(k_step_philox1<false>, grid, dim3(WAVE), lds1, st, start, stop, 0, a);
     }
     else if (full) hipExtLaunchKernelGGL((k_step_philox<true, 1>), grid, dim3(PT), sizeof(EnvState), st, start, stop, 0, a);

@@ -1324,10 +1324,13 @@ CC4_HD void blue_execute(Ctx x, int b, const Act& a) {
     case BA_RESTORE: blue_restore(x, a.host); break;
     case BA_DECOY: blue_decoy(x, a.host); break;
     // Observation(False) when the pair is already blocked / not blocked (ControlTraffic.py:111-113, :176-178)
-    case BA_BLOCK: s->blue[b].last_ok = (uint8_t)(((s->blocks[a.host] >> a.arg) & 1u) ? T_FALSE : T_TRUE);
-                   s->blocks[a.host] |= (uint16_t)(1u << a.arg); s->obs_dirty = 1; break;   // ControlTraffic.py:88-116
-    case BA_ALLOW: s->blue[b].last_ok = (uint8_t)(((s->blocks[a.host] >> a.arg) & 1u) ? T_TRUE : T_FALSE);
-                   s->blocks[a.host] &= (uint16_t)~(1u << a.arg); s->obs_dirty = 1; break;  // ControlTraffic.py:160-185
+    // (obs_dirty only when the pair's bit really changes: under a random policy half of these actions name a pair that is already as asked)
+    case BA_BLOCK: { const bool was = (s->blocks[a.host] >> a.arg) & 1u;
+                   s->blue[b].last_ok = (uint8_t)(was ? T_FALSE : T_TRUE);
+                   if (!was) { s->blocks[a.host] |= (uint16_t)(1u << a.arg); s->obs_dirty |= OD_BLOCKS; } break; }   // ControlTraffic.py:88-116
+    case BA_ALLOW: { const bool was = (s->blocks[a.host] >> a.arg) & 1u;
+                   s->blue[b].last_ok = (uint8_t)(was ? T_TRUE : T_FALSE);
+                   if (was) { s->blocks[a.host] &= (uint16_t)~(1u << a.arg); s->obs_dirty |= OD_BLOCKS; } break; }   // ControlTraffic.py:160-185
     default: break;
   }
 }
@@ -2240,7 +2243,7 @@ CC4_HD bool step_phase(Ctx x, bool init_accumulators = true) {
     const int st = s->step_count;
     const int ph = step_phase_of(st, s->phase_len[0], s->phase_len[1], s->phase_len[2]);
     if (ph < 0) { set_err(x, E_STEP_PAST_END); return false; }
-    s->obs_dirty = (uint8_t)(ph > s->phase);   // a new mission phase changes the phase words and the comms policy of the observation
+    s->obs_dirty = (uint8_t)(ph > s->phase ? OD_PHASE : 0);   // a new mission phase changes the phase words and the comms policy of the observation
     if (ph > s->phase) s->phase = ph;
   }
   rng_begin_step(&s->rng, (uint32_t)s->step_count);
@@ -2661,7 +2664,7 @@ inline int state_edit(Ctx x, int op, int a0, int a1, int a2) {
   switch (op) {
     case SE_SET_PHASE:
       if (a0 < 0 || a0 > 2) return -1;
-      s->phase = a0; s->obs_dirty = 1;
+      s->phase = a0; s->obs_dirty = OD_PHASE;
       return 0;
     case SE_ADD_SERVICE: {
       if (!host_ok(a0) || a1 < K_SSHD || a1 > K_DEC_VSFTPD) return -1;
@@ -2716,7 +2719,7 @@ inline int state_edit(Ctx x, int op, int a0, int a1, int a2) {
     case SE_BLOCK:
       if (a0 < 0 || a0 >= NSUB - 1 || a1 < 0 || a1 >= NSUB - 1) return -1;
       if (a2) s->blocks[a0] |= (uint16_t)(1u << a1); else s->blocks[a0] &= (uint16_t)~(1u << a1);
-      s->obs_dirty = 1;
+      s->obs_dirty = OD_BLOCKS;
       return 0;
     case SE_SET_STEP:
       if (a0 < 0 || a0 >= s->steps) return -1;

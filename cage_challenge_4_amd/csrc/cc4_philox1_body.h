@@ -46,8 +46,13 @@ void philox1_autoreset(const StepArgs& a, const int e, const int lane, EnvState*
 // first / last (the one-launch loops): the step is the first / last of a run of consecutive steps of this episode on this wave -- only the
 // first stages the agent part in, only the last writes it back; in between the row lives in LDS (the host table, the cold row and the outputs
 // are read and written in memory by every step as always).
-// cc4_debug_stop_phase (full build only; wave-uniform): leave the step behind phase n
-#define CC4_STOP(n) do { if (LOG && a.dbg_stop == (n)) return; } while (0)
+// cc4_debug_stop_phase (full build only; wave-uniform): leave the step behind phase n.  A library built with -DCC4_STOP_IN_FAST=1 has the stops in the
+// fast build too (tools/valu_phases.sh measures that variant: on the fast path rates and flags are compile-time constants the full build carries at run time)
+#ifndef CC4_STOP_IN_FAST
+#define CC4_STOP_IN_FAST 0
+#endif
+#define CC4_STOP_ON (LOG || CC4_STOP_IN_FAST)
+#define CC4_STOP(n) do { if (CC4_STOP_ON && a.dbg_stop == (n)) return; } while (0)
 template <bool LOG, bool PERSIST>
 __device__ __forceinline__ void philox1_body(StepArgs a, const int e, const uint32_t rand_t, const uint32_t item_k, const int lane,
                                              const bool first, const bool last) {
@@ -145,7 +150,7 @@ __device__ __forceinline__ void philox1_body(StepArgs a, const int e, const uint
         const int dropped = step_red_policy_tick(xr, lane, false, pre_rp);
         if (ap) ap[0] += clock64() - t0;
         if (dropped) atomicSub(&s->n_actions, 1);
-      } else if (lane >= 8 && lane < 8 + NBLUE && !(LOG && a.dbg_stop == 3)) {
+      } else if (lane >= 8 && lane < 8 + NBLUE && !(CC4_STOP_ON && a.dbg_stop == 3)) {
         const int b = lane - 8;
         int32_t act = !a.actions ? -1 : a.act_sys ? __hip_atomic_load(a.actions + e * NBLUE + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) : a.actions[e * NBLUE + b];
         if (a.rand_out) { act = (int32_t)(((uint64_t)brand * (uint32_t)(b == 4 ? ACT_LONG : ACT_SHORT)) >> 32); a.rand_out[e * NBLUE + b] = act; }   // == random_blue_action
@@ -153,7 +158,7 @@ __device__ __forceinline__ void philox1_body(StepArgs a, const int e, const uint
         step_tick_blue(xg, b);
         step_messages(s, a.msgs ? a.msgs + e * NBLUE * MSG_LEN : nullptr, b);   // read back by this step's observation encode only
       }
-      if (!(LOG && (a.dbg_stop == 3 || a.dbg_stop == 4))) {
+      if (!(CC4_STOP_ON && (a.dbg_stop == 3 || a.dbg_stop == 4))) {
         if (lane < ng) step_green_policy(xg, lane);                             // agents 0..63: their block is computed here, by all of them at once
         if (lane + WAVE < ng) step_green_policy(xg, lane + WAVE, bank);          // agents 64..: from the bank (their lane's own request)
       }
@@ -276,9 +281,16 @@ __device__ __forceinline__ void philox1_body(StepArgs a, const int e, const uint
   unsigned long long t_obs = a.prof ? clock64() : 0;
   {
     int32_t* o = a.obs + (size_t)e * OBS_TOTAL;
-    const int nv = (do_reset || (a.full_obs && (!PERSIST || item_k == 0)) || s->obs_dirty) ? OBS_TOTAL : OBS_FAST;
+    // the slowly varying values by kind (env_flat_obs_sorted's enumeration: 63 blocked bits, 63 comms-policy bits, 63 subnet one-hots, 5 phase words --
+    // one pass of the wave each): what the step changed (EnvState.obs_dirty), everything after a reset or when the caller's buffer is new
+    const uint32_t dirty = (do_reset || (a.full_obs && (!PERSIST || item_k == 0))) ? (uint32_t)OD_ALL : (uint32_t)s->obs_dirty;
     encode_obs_fast<WAVE>(s, o, nullptr, false, lane);
-    for (int v = OBS_FAST + lane; v < nv; v += WAVE) { int i; const int val = env_flat_obs_sorted(s, v, &i); o[i] = val; }
+    if (dirty) {
+      auto put = [&](int v) { int i; const int val = env_flat_obs_sorted(s, v, &i); o[i] = val; };
+      if ((dirty & OD_BLOCKS) && lane < 63) put(OBS_FAST + lane);
+      if (dirty & OD_PHASE) { if (lane < 63) put(OBS_FAST + 63 + lane); if (lane < 5) put(OBS_FAST + 189 + lane); }
+      if ((dirty & ~(uint32_t)(OD_BLOCKS | OD_PHASE)) && lane < 63) put(OBS_FAST + 126 + lane);
+    }
   }
   __syncthreads();
   CC4_STOP(13);                                                                  // + observation encode; 0 = the whole step (row written back)

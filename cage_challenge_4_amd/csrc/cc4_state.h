@@ -73,6 +73,7 @@ struct alignas(4) Svc  { uint16_t pid; uint8_t kind; uint8_t st; };          // 
 enum : int { PF_ROOT = 1, SV_ACTIVE = 0x80 };
 
 enum : int { EV_CUR_CONN = 1, EV_CUR_PROC = 2, EV_OLD_CONN = 4, EV_OLD_PROC = 8 };
+enum : int { OD_BLOCKS = 1, OD_PHASE = 2, OD_ALL = 7 };   // EnvState.obs_dirty (OD_ALL: what a full rewrite covers on top: the subnet one-hots)
 
 // HostDyn.nsf high nibble: the malware files Analyse reports (Host.files; cleared by Restore): cmd.sh present, escalate.sh present, and
 // which of the two was appended last (Observation.add_file_info re-appends a repeated name, so only that order survives)
@@ -204,8 +205,8 @@ struct alignas(64) EnvState {
   uint8_t done, rng_mode, n_green;
   uint8_t policy;                    // bits 0-1 red policy (RP_*), bit 4 green policy (1 = SleepAgent)
   uint8_t rng_split;                 // 1 after CybORG.set_seed: the agents' policies keep drawing from rng2 (see there)
-  uint8_t obs_dirty;                 // this step changed a slowly varying part of the flat observation (blocks, mission phase):
-                                     // the lane-parallel kernel rewrites those values only then (the output buffer persists)
+  uint8_t obs_dirty;                 // this step changed a slowly varying part of the flat observation (OD_BLOCKS: a pair of the block matrix, OD_PHASE:
+                                     // the mission phase): the lane-parallel kernels rewrite those values only then (the output buffer persists)
   uint8_t pad0[2];
   uint16_t blocks[NSUB];             // blocks[to] bit from
   uint8_t cidr_octet[NSUB];

@@ -47,7 +47,8 @@ def run(seq_path):
             seq.append(stop)
         env._chk(env.lib.cc4_debug_stop_phase(env._h, 0), 'cc4_debug_stop_phase')
         t += 1    # (the last stop was 14 = a whole step: the batch is one step further, consistently)
-    json.dump({'episodes': n, 'sequence': seq, 'launches_per_step': env.launches_per_step}, open(seq_path, 'w'))
+    json.dump({'episodes': n, 'sequence': seq, 'launches_per_step': env.launches_per_step, 'warm_steps_per_sample': 70,
+               'fast_build': bool(os.environ.get('CC4_DEBUG_STOP_FAST'))}, open(seq_path, 'w'))
     env.close()
 
 
@@ -57,13 +58,17 @@ def report(seq_path, dirs):
     ctr = {}
     for d in dirs:
         con = sqlite3.connect(max(glob.glob(d + '/**/*.db', recursive=True), key=os.path.getmtime))
-        rows = list(con.execute("select counter_name, dispatch_id, value from counters_collection where kernel_name like '%k_step_philox1<true>%' order by dispatch_id"))
+        rows = list(con.execute("select counter_name, dispatch_id, value from counters_collection where kernel_name like ? order by dispatch_id", ('%k_step_philox1<' + ('false' if os.environ.get('CC4_DEBUG_STOP_FAST') else 'true') + '>%',)))
         for name in sorted({r[0] for r in rows}):
             vals = [r[2] for r in rows if r[0] == name]
+            if seq.get('fast_build'):       # the warm-up steps between the samples are launches of the same (fast) kernel: drop them
+                per = (seq['warm_steps_per_sample'] + len(STOPS)) * lps
+                assert len(vals) == per * (len(order) // len(STOPS)), (name, len(vals), per)
+                vals = [v for i, v in enumerate(vals) if i % per >= seq['warm_steps_per_sample'] * lps]
             assert len(vals) == len(order) * lps, (name, len(vals), len(order), lps)
             ctr[name] = [sum(vals[i * lps:(i + 1) * lps]) for i in range(len(order))]
     samples = len(order) // len(STOPS)
-    print(f'# r06: instructions of each phase of a counter-mode step (k_step_philox1, full build), {n} episodes, {samples} sample steps 70 steps apart;')
+    print(f'# r06: instructions of each phase of a counter-mode step (k_step_philox1, {"FAST build (a library built with -DCC4_STOP_IN_FAST=1)" if seq.get("fast_build") else "full build"}), {n} episodes, {samples} sample steps 70 steps apart;')
     print('# per episode-step.  Method: tools/valu_phases.py (the same step from the same states, ended behind each phase in turn; hardware counters per launch).')
     print('# Episodes that regenerate at the sampled step run the generation instead of the phases: it is in every stop alike and cancels in the differences.')
     names = [c for c in ('SQ_INSTS_VALU', 'SQ_INSTS_SALU', 'SQ_INSTS_LDS', 'SQ_WAVE_CYCLES', 'SQ_ACTIVE_INST_VALU', 'SQ_INSTS_VMEM_RD', 'SQ_INSTS_VMEM_WR', 'SQ_INSTS_BRANCH') if c in ctr]
