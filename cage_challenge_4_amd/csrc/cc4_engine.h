@@ -2550,6 +2550,16 @@ CC4_HD void step_reassign(Ctx x, uint32_t foreign) {   // foreign = red_foreign_
   CC4_TICK(x, 8);
 }
 // the per-host part of Monitor.execute: this step's event bits become last step's on the hosts a blue agent watches
+// ... and four hosts' bytes at a time (word w of EnvState.hev = hosts 4w .. 4w+3): the same function on each byte, the watched hosts as a byte mask
+CC4_HD constexpr uint32_t monitor_watch_mask(int w) {
+  uint32_t m = 0;
+  for (int i = 0; i < 4; ++i) { const int h = 4 * w + i; if (h < MAXH && ((0xf444f3210ull >> (4 * (h / SLOTS))) & 0xF) != 0xF) m |= 0xFFu << (8 * i); }   // blue_of_subnet(h_subnet(h)) >= 0
+  return m;
+}
+CC4_HD uint32_t monitor_roll4(uint32_t ev4, uint32_t watch) {
+  static_assert(EV_OLD_CONN == EV_CUR_CONN << 2 && EV_OLD_PROC == EV_CUR_PROC << 2 && (EV_CUR_CONN | EV_CUR_PROC) == 3, "current bits move up two places");
+  return (ev4 & ~watch) | (((ev4 & 0x03030303u) << 2) & watch);
+}
 CC4_HD uint8_t monitor_roll(int h, uint8_t ev) {
   if (blue_of_subnet(h_subnet(h)) < 0) return ev;
   uint8_t nev = 0;
@@ -2583,7 +2593,10 @@ CC4_HD void step_rsc(Ctx x, int r) {
 // the messages submitted with this step, agent b's row (read back by the observation encode of the same step only, so the
 // lane-parallel kernel stores them when the actions are submitted and step_end skips the copy)
 CC4_HD void step_messages(EnvState* s, const uint8_t* messages, int b) {
-  for (int i = 0; i < MSG_LEN; ++i) s->msg[b][i] = (uint8_t)((messages && messages[b * MSG_LEN + i]) ? 1 : 0);
+  static_assert(MSG_LEN == 8, "a message is one 8-byte word");
+  uint64_t w = 0;
+  if (messages) for (int i = 0; i < MSG_LEN; ++i) w |= (uint64_t)(messages[b * MSG_LEN + i] ? 1 : 0) << (8 * i);
+  __builtin_memcpy(&s->msg[b][0], &w, 8);       // (no messages, the usual case of a vectorised batch: one store instead of eight byte stores)
 }
 CC4_HD void step_end(Ctx x, const uint8_t* messages, bool copy_msgs = true) {
   EnvState* s = x.s;

@@ -459,7 +459,7 @@ __device__ __forceinline__ void pcg_body(StepArgs a, const int e, const int lane
   __syncthreads();
   if (ok_lds) {
     // end-turn Monitor roll-over: the hosts' event bytes are part of the staged row (EnvState.hev)
-    for (int h = lane; h < MAXH; h += WAVE) s->hev[h] = monitor_roll(h, s->hev[h]);
+    monitor_roll_all(s, lane);
     if (lane == 0) step_monitor_pend(x);
     __syncthreads();
     {

@@ -200,6 +200,17 @@ __device__ __forceinline__ void xchg_count(const XchgArgs& x, uint32_t k, int gr
 // compiler fills (one copy per translation unit, 1.5 KB of constant memory that the vector L1 keeps).  Until r06 the entries were computed per value and
 // step (r03 A/B: a dozen shifts and multiplies beat one load while the kernels waited on memory, not on the vector unit); at 24 waves per CU the step is
 // bound by vector issue slots and those instructions were a sixth of it (profiles/r06_valu_phases.txt: 453 of 2 689 per episode-step).
+// Monitor's end-turn roll-over of the hosts' event bytes, four hosts per lane (monitor_roll4): the watched-hosts byte masks of the 35 words
+struct MonitorWatchTab { uint32_t v[(MAXH + 3) / 4]; };
+constexpr MonitorWatchTab make_monitor_watch_tab() { MonitorWatchTab t{}; for (int w = 0; w < (MAXH + 3) / 4; ++w) t.v[w] = monitor_watch_mask(w); return t; }
+static __device__ const MonitorWatchTab monitor_watch_tab = make_monitor_watch_tab();
+__device__ __forceinline__ void monitor_roll_all(EnvState* s, int lane) {
+  static_assert((MAXH + 3) / 4 <= WAVE && offsetof(EnvState, hev) % 4 == 0, "one pass of the wave over aligned words");
+  if (lane < (MAXH + 3) / 4) {
+    uint32_t* const w = reinterpret_cast<uint32_t*>(s->hev) + lane;
+    *w = monitor_roll4(*w, monitor_watch_tab.v[lane]);
+  }
+}
 // Device entry: byte position in the vector (4 x index, 12 bits) | byte offset of the source byte in the staged row << 12 (hev[] and msg[][] both live in
 // the agent part, below 8 KB) | bit mask << 25 (the event masks are nibbles), so that a value is one LDS byte read, an and, a compare and a store.
 struct ObsFastTab { uint32_t v[OBS_FAST]; };

@@ -262,7 +262,7 @@ __device__ __forceinline__ void philox1_body(StepArgs a, const int e, const uint
       // P7 end-turn Monitor roll-over: the hosts' event bytes are part of the staged row (EnvState.hev).  (Lane 0's reassignment above
       // moves sessions, not events.)
       CC4_STOP(10);                                                              // + merge, reassignment (lane 0)
-      for (int h = lane; h < MAXH; h += WAVE) s->hev[h] = monitor_roll(h, s->hev[h]);
+      monitor_roll_all(s, lane);
       __syncthreads();
       CC4_TICK(x0, 9);
       CC4_STOP(11);                                                              // + Monitor roll-over
