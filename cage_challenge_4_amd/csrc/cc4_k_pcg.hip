@@ -485,9 +485,9 @@ __device__ __forceinline__ void pcg_body(StepArgs a, const int e, const int lane
     // Block/Allow or a new mission phase changes are written when that happened (EnvState.obs_dirty), after a reset, or when the
     // caller asks -- as in the counter-mode kernels; the byte copy in LDS only feeds the packed exchange row
     int32_t* o = a.obs + (size_t)e * OBS_TOTAL;
-    const int nv = (do_reset || a.full_obs || s->obs_dirty) ? OBS_TOTAL : OBS_FAST;
+    const uint32_t dirty = (do_reset || a.full_obs) ? (uint32_t)OD_ALL : (uint32_t)s->obs_dirty;
     encode_obs_fast<WAVE>(s, o, nullptr, false, lane);
-    for (int v = OBS_FAST + lane; v < nv; v += WAVE) { int i; const int val = env_flat_obs_sorted(s, v, &i); o[i] = val; }
+    encode_obs_slow(s, o, dirty, lane);
   }
   __syncthreads();
   unsigned long long t_out = a.prof ? clock64() : 0;

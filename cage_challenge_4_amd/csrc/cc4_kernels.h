@@ -248,6 +248,16 @@ __device__ __forceinline__ void encode_obs_fast(const EnvState* s, int32_t* o, u
     if (pack) obs_bytes[pos >> 2] = (uint8_t)val;
   }
 }
+// The slowly varying observation values by kind, one wave (env_flat_obs_sorted's enumeration: 63 blocked bits, 63 comms-policy bits, 63 subnet one-hots,
+// 5 phase words -- one pass of the wave each): `dirty` = what the step changed (EnvState.obs_dirty: OD_BLOCKS, OD_PHASE), OD_ALL after a reset or when the
+// caller's buffer is new (the one-hots never change otherwise)
+__device__ __forceinline__ void encode_obs_slow(const EnvState* s, int32_t* o, uint32_t dirty, int lane) {
+  if (!dirty) return;
+  auto put = [&](int v) { int i; const int val = env_flat_obs_sorted(s, v, &i); o[i] = val; };
+  if ((dirty & OD_BLOCKS) && lane < 63) put(OBS_FAST + lane);
+  if (dirty & OD_PHASE) { if (lane < 63) put(OBS_FAST + 63 + lane); if (lane < 5) put(OBS_FAST + 189 + lane); }
+  if ((dirty & ~(uint32_t)(OD_BLOCKS | OD_PHASE)) && lane < 63) put(OBS_FAST + 126 + lane);
+}
 // ---- the persistent form of the same kernel (PERSIST): K steps of the whole batch in ONE launch.
 // A step-per-launch schedule ends every launch with a tail (its last blocks run on a half-empty chip) and starts the next with a
 // ramp; cutting the batch into four groups on four streams hides most of that, not all: 8192 episodes x 29.6 us of

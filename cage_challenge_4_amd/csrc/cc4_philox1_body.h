@@ -285,12 +285,7 @@ __device__ __forceinline__ void philox1_body(StepArgs a, const int e, const uint
     // one pass of the wave each): what the step changed (EnvState.obs_dirty), everything after a reset or when the caller's buffer is new
     const uint32_t dirty = (do_reset || (a.full_obs && (!PERSIST || item_k == 0))) ? (uint32_t)OD_ALL : (uint32_t)s->obs_dirty;
     encode_obs_fast<WAVE>(s, o, nullptr, false, lane);
-    if (dirty) {
-      auto put = [&](int v) { int i; const int val = env_flat_obs_sorted(s, v, &i); o[i] = val; };
-      if ((dirty & OD_BLOCKS) && lane < 63) put(OBS_FAST + lane);
-      if (dirty & OD_PHASE) { if (lane < 63) put(OBS_FAST + 63 + lane); if (lane < 5) put(OBS_FAST + 189 + lane); }
-      if ((dirty & ~(uint32_t)(OD_BLOCKS | OD_PHASE)) && lane < 63) put(OBS_FAST + 126 + lane);
-    }
+    encode_obs_slow(s, o, dirty, lane);
   }
   __syncthreads();
   CC4_STOP(13);                                                                  // + observation encode; 0 = the whole step (row written back)

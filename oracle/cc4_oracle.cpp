@@ -227,6 +227,27 @@ void cc4o_rng_script(uint64_t seed, int mode, int n, const int32_t* ops, const u
   }
 }
 
+// counter mode: the threshold forms of a uniform draw (cc4_rng.h rng_random_lt / rng_random_le / rng_random_quarter) and the raw words, one op per entry:
+// 0: rng_random_lt(t[i])  1: rng_random_le(t[i])  2: rng_random_quarter  3: rng_next32  4: rng_set_stream((uint32)t[i])
+void cc4o_rng_script2(uint64_t seed, int mode, int n, const int32_t* ops, const double* t, uint64_t* out) {
+  Rng r; rng_seed(&r, seed, (uint32_t)mode);
+  rng_begin_step(&r, 7);
+  for (int i = 0; i < n; ++i) {
+    switch (ops[i]) {
+      case 0: out[i] = rng_random_lt(&r, t[i]) ? 1 : 0; break;
+      case 1: out[i] = rng_random_le(&r, t[i]) ? 1 : 0; break;
+      case 2: out[i] = (uint64_t)rng_random_quarter(&r); break;
+      case 4: rng_set_stream(&r, (uint32_t)t[i]); out[i] = 0; break;
+      default: out[i] = rng_next32(&r); break;
+    }
+  }
+}
+// the device's tables against the functions they are filled from: blue_slot_shape(b, idx) and obs_fast_entry(v)
+uint32_t cc4o_blue_slot_shape(int b, int idx) { return blue_slot_shape(b, idx); }
+uint32_t cc4o_obs_fast_entry(int v) { return obs_fast_entry(v); }
+uint32_t cc4o_monitor_roll4(uint32_t ev4, int w) { return monitor_roll4(ev4, monitor_watch_mask(w)); }
+uint32_t cc4o_monitor_roll(int h, uint32_t ev) { return monitor_roll(h, (uint8_t)ev); }
+
 // "name offset" lines for EnvState members (maps a differing byte offset back to a field when bisecting)
 int cc4o_layout(char* buf, int cap) {
   int n = 0;

@@ -215,3 +215,46 @@ def test_cyborg_facade_methods_of_env_py(oracle_lib):
     env.close()
     env.close()
     twin.close()
+
+
+def test_blue_slot_shape_is_the_wrappers_action_list(oracle_lib):
+    """blue_slot_shape(b, idx) -- the one function the host decodes with and the device's slot table is filled from -- against the list layout of
+    BlueFixedActionWrapper.py:241-300 written out here: Analyse x hosts, Monitor, Remove x hosts, Restore x hosts, Sleep, Allow x 8 per own subnet,
+    Block x same, DeployDecoy x hosts; hosts = 6 server then 10 user positions of each own subnet in sorted order."""
+    import ctypes
+    oracle_lib.cc4o_blue_slot_shape.restype = ctypes.c_uint32
+    oracle_lib.cc4o_blue_slot_shape.argtypes = [ctypes.c_int, ctypes.c_int]
+    SLEEP, MONITOR, ANALYSE, REMOVE, RESTORE, DECOY, BLOCK, ALLOW = range(8)
+    # subnet ids (cc4_state.h): restricted a 0, operational a 1, restricted b 2, operational b 3, contractor 4, public access 5, admin 6, office 7, internet 8
+    sorted_subnets = [6, 4, 8, 7, 1, 3, 5, 0, 2]          # alphabetical: admin, contractor, internet, office, operational a/b, public, restricted a/b
+    for b in range(5):
+        own = [b] if b < 4 else [6, 7, 5]                 # agent 4: admin, office, public access -- sorted
+        hosts = [17 * sn + (11 + k if k < 6 else 1 + k - 6) for sn in own for k in range(16)]
+        pairs = [(dst, src) for dst in own for src in sorted_subnets if src != dst]
+        want = ([(ANALYSE, h) for h in hosts] + [(MONITOR,)] + [(REMOVE, h) for h in hosts] + [(RESTORE, h) for h in hosts] + [(SLEEP,)]
+                + [(ALLOW, d, s) for d, s in pairs] + [(BLOCK, d, s) for d, s in pairs] + [(DECOY, h) for h in hosts])
+        assert len(want) == (82 if b < 4 else 242)
+        for idx, w in enumerate(want):
+            sh = oracle_lib.cc4o_blue_slot_shape(b, idx)
+            got = (sh & 0xFF,) if w[0] in (SLEEP, MONITOR) else ((sh & 0xFF, (sh >> 8) & 0xFF) if len(w) == 2 else (sh & 0xFF, (sh >> 8) & 0xFF, sh >> 16))
+            assert got == w, (b, idx, got, w)
+        assert oracle_lib.cc4o_blue_slot_shape(b, len(want)) == SLEEP and oracle_lib.cc4o_blue_slot_shape(b, -1) == SLEEP
+
+
+def test_monitor_roll_four_hosts_per_word_equals_the_per_host_function(oracle_lib):
+    """monitor_roll4 (the lane-parallel kernels: one 32-bit word = four hosts' event bytes) against monitor_roll host by host, every byte value."""
+    import ctypes
+    oracle_lib.cc4o_monitor_roll4.restype = ctypes.c_uint32
+    oracle_lib.cc4o_monitor_roll4.argtypes = [ctypes.c_uint32, ctypes.c_int]
+    oracle_lib.cc4o_monitor_roll.restype = ctypes.c_uint32
+    oracle_lib.cc4o_monitor_roll.argtypes = [ctypes.c_int, ctypes.c_uint32]
+    rs = np.random.default_rng(5)
+    for w in range(35):
+        for ev4 in [0, 0xFFFFFFFF, 0x0F0F0F0F, 0x01020408] + [int(x) for x in rs.integers(0, 2**32, 40)]:
+            ev4 &= 0x0F0F0F0F                       # the event bytes hold four bits
+            got = oracle_lib.cc4o_monitor_roll4(ev4, w)
+            for i in range(4):
+                h = 4 * w + i
+                b = (ev4 >> (8 * i)) & 0xFF
+                want = oracle_lib.cc4o_monitor_roll(h, b) if h < 137 else b
+                assert (got >> (8 * i)) & 0xFF == want, (w, i, hex(ev4))

@@ -61,3 +61,60 @@ def test_philox_known_answer(oracle_lib):
     got = run_script(oracle_lib, 0, [3], [0], mode=1)   # key 0, counter (0,0,0,0)
     lo, hi = int(got[0]) & 0xFFFFFFFF, int(got[0]) >> 32
     assert (lo, hi) == (0x6627e8d5, 0xe169c58d)
+
+
+def _philox4x32_10(ctr, key):
+    M0, M1, W0, W1 = 0xD2511F53, 0xCD9E8D57, 0x9E3779B9, 0xBB67AE85
+    c = list(ctr); k0, k1 = key
+    for _ in range(10):
+        p0, p1 = M0 * c[0], M1 * c[2]
+        c = [((p1 >> 32) ^ c[1] ^ k0) & 0xFFFFFFFF, p1 & 0xFFFFFFFF, ((p0 >> 32) ^ c[3] ^ k1) & 0xFFFFFFFF, p0 & 0xFFFFFFFF]
+        k0, k1 = (k0 + W0) & 0xFFFFFFFF, (k1 + W1) & 0xFFFFFFFF
+    return c
+
+
+def run_script2(lib, seed, ops, t, mode=1):
+    n = len(ops)
+    ops = np.asarray(ops, np.int32)
+    t = np.asarray(t, np.float64)
+    out = np.zeros(n, np.uint64)
+    lib.cc4o_rng_script2(ctypes.c_uint64(seed), mode, n, ops.ctypes.data_as(ctypes.c_void_p), t.ctypes.data_as(ctypes.c_void_p),
+                         out.ctypes.data_as(ctypes.c_void_p))
+    return out
+
+
+def test_counter_mode_words_are_the_philox_blocks_in_order(oracle_lib):
+    """The generator's four-word queue (r06): stream `id` of step 7 of key `seed` hands out the words of block 0, then block 1, ... of the counter
+    (block, stream, step, episode 0), c[0] first -- whatever mix of draws and stream switches came before."""
+    seed = 0x123456789ABCDEF
+    key = (seed & 0xFFFFFFFF, seed >> 32)
+    ops, t = [], []
+    for stream in (0x500, 0x601, 0x300 + 17):
+        ops += [4] + [3] * 11
+        t += [float(stream)] + [0.0] * 11
+    got = run_script2(oracle_lib, seed, ops, t)
+    i = 0
+    for stream in (0x500, 0x601, 0x300 + 17):
+        i += 1
+        want = sum((_philox4x32_10((blk, stream, 7, 0), key) for blk in range(3)), [])[:11]
+        assert [int(x) for x in got[i:i + 11]] == want
+        i += 11
+
+
+def test_threshold_draws_equal_the_double_comparison(oracle_lib):
+    """rng_random_lt / _le / _quarter (integer compares of the 32-bit word in the counter mode) against the expressions they replace, on the same words:
+    k * 2**-32 < t, <= t, int(4 * k * 2**-32) -- including thresholds that are exact multiples of 2**-32, 0, 1, negatives, > 1 and NaN."""
+    rs = np.random.default_rng(3)
+    n = 4000
+    thr = np.concatenate([rs.random(n - 1000), rs.integers(0, 2**32, 400) / 2.0**32, [0.0, 1.0, -0.5, 1.5, float('nan'), 2.0**-40, 1 - 2.0**-33, 0.01, 0.05, 0.75] * 60])
+    rs.shuffle(thr)
+    seed = 99
+    words = run_script2(oracle_lib, seed, [3] * n, [0.0] * n)
+    u = words.astype(np.float64) * 2.0**-32
+    with np.errstate(invalid='ignore'):
+        assert [int(x) for x in run_script2(oracle_lib, seed, [0] * n, thr)] == [int(a < b) for a, b in zip(u, thr)]
+        assert [int(x) for x in run_script2(oracle_lib, seed, [1] * n, thr)] == [int(a <= b) for a, b in zip(u, thr)]
+    assert [int(x) for x in run_script2(oracle_lib, seed, [2] * n, thr)] == [int(a * 4.0) for a in u]
+    # the words themselves fall exactly on a threshold: k * 2**-32 < k * 2**-32 is false, <= is true
+    exact = words[:200].astype(np.float64) * 2.0**-32
+    assert not any(run_script2(oracle_lib, seed, [0] * 200, exact)) and all(run_script2(oracle_lib, seed, [1] * 200, exact))

@@ -30,6 +30,7 @@ rm -rf $OUT/mix?
 # 3b. issue-slot use of the timed kernels, instructions per phase of a step (separate --pmc passes)
 bash tools/valu_busy.sh > /dev/null 2>&1
 bash tools/valu_phases.sh > /dev/null 2>&1
+[ -f build_var/stopfast.so ] && bash tools/valu_phases_fast.sh > /dev/null 2>&1
 # 4. the launch's timeline (per-wave time stamps) at the driver's K and the full bench lines
 python tools/persist_timeline.py 2>&1 | grep "cc4 timeline" > $OUT/${TAG}_persist_timeline.txt
 python bench.py --steps 20 --warmup 5 > $OUT/${TAG}_bench_driver_flags.json 2> /dev/null
