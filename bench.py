@@ -214,6 +214,9 @@ def load_pmc_traffic(envs, kernel):
     return None, None
 
 
+# "valu_issue" when the committed issue-slot passes of the timed kernel show the vector ALUs at least this busy over the WHOLE launch (the one-launch kernel:
+# 82-86 % in 100-step launches, 77 % in the driver's 20-step launches, whose last round idles a sixth of the slots; the latency-bound small batches: 34 %)
+VALU_BOUND_AT = 0.7
 VALU_PEAK_GINSTR = 256 * 4 * 2.4 / 4.0      # wave64 VALU instructions per ns the chip can issue: 256 CUs x 4 SIMDs, one per 4 cycles, 2.4 GHz = 614.4 G/s
 
 
@@ -472,7 +475,7 @@ def main():
         b2 = (2 * hot_b + (row_b - hot_b) + 4 * 578 + 29) if other == 'pcg64' else int(env.lib.cc4_algorithmic_bytes_per_env_step())
         a2 = b2 * n_local / (r2['launch_ms'] * 1e-3) / 1e9
         v2 = load_valu_issue(n_local, r2['run_kernel'], args.steps)
-        r2['roofline'] = {'bound': 'valu_issue' if (v2 and v2['valu_busy'] >= 0.8) else 'latency', 'valu_issue': v2, 'roofline': 'hbm', 'achieved': a2, 'peak': HBM_PEAK_GBPS, 'unit': 'GB/s', 'frac': a2 / HBM_PEAK_GBPS, 'traffic': None,
+        r2['roofline'] = {'bound': 'valu_issue' if (v2 and v2['valu_busy'] >= VALU_BOUND_AT) else 'latency', 'valu_issue': v2, 'roofline': 'hbm', 'achieved': a2, 'peak': HBM_PEAK_GBPS, 'unit': 'GB/s', 'frac': a2 / HBM_PEAK_GBPS, 'traffic': None,
                           'kernel': r2['run_kernel'], 'step_ms': r2['launch_ms'], 'algorithmic_bytes_per_step': b2 * n_local,
                           'note': 'algorithmic bytes per step (contract figure of that kernel) / kernel time per step against the HBM peak; the walking lane of the '
                                   'numpy-stream kernel is a dependency chain, not a stream of bytes -- at 24 waves per CU the chains of the resident episodes fill the '
@@ -562,7 +565,7 @@ def main():
             valu['achieved_ginstr_per_s'] = valu['valu_instructions_per_episode_step'] * n_local / (launch_ms * 1e-3) / 1e9
             valu['peak_ginstr_per_s'] = VALU_PEAK_GINSTR
             valu['frac'] = valu['achieved_ginstr_per_s'] / VALU_PEAK_GINSTR
-        bound = 'hbm' if (hbm_ctr_frac or 0.0) >= 0.6 else 'valu_issue' if (valu and valu['valu_busy'] >= 0.8) else 'latency'
+        bound = 'hbm' if (hbm_ctr_frac or 0.0) >= 0.6 else 'valu_issue' if (valu and valu['valu_busy'] >= VALU_BOUND_AT) else 'latency'
         out = {
             'metric': 'agent-env steps/sec (5 blue agents x N envs)',
             'value': main_res['value'],

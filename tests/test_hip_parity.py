@@ -1233,7 +1233,7 @@ def test_bench_line_contract():
     assert r['bound'] in ('hbm', 'valu_issue', 'latency') and r['roofline'] == 'hbm' and r['bound_evidence']
     if r['bound'] == 'valu_issue':
         v = r['valu_issue']
-        assert v['valu_busy'] >= 0.8 and 0.5 < v['frac'] <= 1.05 and v['peak_ginstr_per_s'] == pytest.approx(614.4)
+        assert v['valu_busy'] >= 0.7 and 0.5 < v['frac'] <= 1.05 and v['peak_ginstr_per_s'] == pytest.approx(614.4)
     assert r['unit'] == 'GB/s' and r['peak'] == 8000.0 and abs(r['frac'] - r['achieved'] / r['peak']) < 1e-9
     # 8192 episodes, 20-step regions: ONE launch of the persistent one-wave kernel per region (regions of fewer than 10 steps, or CC4_PERSIST=0:
     # three or four concurrent launches of k_step_philox1 per step)
