@@ -791,6 +791,37 @@ def test_snapshot_restore_replays_identically(philox_kernel):
     dev.close()
 
 
+def test_measurement_hook_ends_a_step_behind_a_phase_and_restores_cleanly(monkeypatch):
+    """cc4_debug_stop_phase (tools/valu_phases.py: per-phase instruction counts): phase 14 = a whole step of the full build of k_step_philox1 == the
+    oracle's step; a step ended behind an earlier phase writes no row back (the batch, restored, continues exactly where it stood); 0 = off."""
+    monkeypatch.setenv('CC4_PHILOX_LEAN', '1')
+    for k in ('CC4_PERSIST', 'CC4_MULTISTEP', 'CC4_RUN1'):
+        monkeypatch.setenv(k, '0')
+    n = 96
+    dev = _dev(n, steps=60, rng_mode=1, autoreset=True); ora = OracleVecEnv(n, steps=60, rng_mode=1, autoreset=True)
+    assert np.array_equal(dev.reset(seeds=4400), ora.reset_batch(4400)) and dev.step_kernel == 'k_step_philox1'
+    t = 0
+    for _ in range(70):                                       # across a regeneration
+        dev.run_random_steps(4400, t, 1, timed=False); ora.step_batch(random_actions(4400, t, n)); t += 1
+    snaps = [dev.snapshot(i) for i in range(n)]
+    for stop in (3, 7, 9, 12):
+        assert dev.lib.cc4_debug_stop_phase(dev._h, stop) == 0
+        dev.run_random_steps(4400, t, 1, timed=False); dev.synchronize()
+        for i in range(n):
+            dev.restore(i, snaps[i])
+    assert dev.lib.cc4_debug_stop_phase(dev._h, 14) == 0
+    dev.run_random_steps(4400, t, 1, timed=False); dev.synchronize(); dev._fetch()
+    o = ora.step_batch(random_actions(4400, t, n)); t += 1
+    assert np.array_equal(dev._obs, o[0]) and np.array_equal(dev._rew, o[1]) and np.array_equal(dev._done.astype(bool), o[2])
+    assert dev.lib.cc4_debug_stop_phase(dev._h, 0) == 0 and dev.lib.cc4_debug_stop_phase(dev._h, 15) != 0
+    for _ in range(20):
+        dev.run_random_steps(4400, t, 1, timed=False); o = ora.step_batch(random_actions(4400, t, n)); t += 1
+    dev.synchronize(); dev._fetch()
+    assert np.array_equal(dev._obs, o[0]) and np.array_equal(dev.rng_state(), ora.rng_state())
+    assert all(np.array_equal(dev.get_state(i), ora.get_state(i)) for i in range(n))
+    dev.close(); ora.close()
+
+
 def test_drop_in_wrapper_reproduces_reference_episode():
     """The mirror of BlueFlatWrapper(CybORG(EnterpriseScenarioGenerator(...), seed=123)) replays the golden episode."""
     from cage_challenge_4_amd import (CybORG, EnterpriseScenarioGenerator, SleepAgent, EnterpriseGreenAgent,
