@@ -1114,7 +1114,7 @@ constexpr BlueSlotTab make_blue_slot_tab() {
 static __device__ const BlueSlotTab blue_slot_tab = make_blue_slot_tab();
 __device__ __forceinline__ uint32_t blue_slot(int b, int idx) { return blue_slot_tab.v[b][idx]; }      // callers pass 0 <= idx < the agent's list length
 #else
-inline uint32_t blue_slot(int b, int idx) { return blue_slot_shape(b, idx); }
+CC4_HD uint32_t blue_slot(int b, int idx) { return blue_slot_shape(b, idx); }
 #endif
 CC4_HD Act blue_decode(const EnvState* s, int b, int idx) {
   Act a; a.type = BA_SLEEP; a.host = 0; a.arg = 0; a.ticks = 1; a.sid = 0; a.busy = 0;

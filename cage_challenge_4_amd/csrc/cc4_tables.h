@@ -64,7 +64,7 @@ CC4_HD uint32_t green_allowed_mask(int phase, int s) {
 }
 
 // BlueRewardMachine.get_phase_rewards, Shared/BlueRewardMachine.py:35-65 : [phase][subnet][LWF, ASF, RIA]
-CC4_HD int reward_table(int phase, int s, int what) {
+CC4_HD constexpr int reward_table_fn(int phase, int s, int what) {
   // phase 0: {{-1,-3,-1},{-1,-1,-1},{-1,-3,-1},{-1,-1,-1},{0,-5,-5},{-1,-1,-3},{-1,-1,-3},{-1,-1,-3},{0,0,-1}}
   // phase 1: {{-2,-1,-3},{-10,0,-10},{-1,-1,-1},{-1,-1,-1},{0,0,0},{-1,-1,-3},{-1,-1,-3},{-1,-1,-3},{0,0,0}}
   // phase 2: {{-1,-3,-3},{-1,-1,-1},{-2,-1,-3},{-10,0,-10},{0,0,0},{-1,-1,-3},{-1,-1,-3},{-1,-1,-3},{0,0,0}}
@@ -77,6 +77,20 @@ CC4_HD int reward_table(int phase, int s, int what) {
   return c < 4 ? -c : (c == 4 ? -5 : -10);
 }
 enum : int { RW_LWF = 0, RW_ASF = 1, RW_RIA = 2 };
+#if defined(__HIP_DEVICE_COMPILE__)
+// the device reads the 81 values from a table the compiler fills from the function above (a byte load instead of two 64-bit selects and shifts and a
+// decode: ~20 vector instructions on the green actions' failure paths of nearly every step; the step kernels are bound by vector issue slots)
+struct RewardTab { int8_t v[3 * NSUB * 3]; };
+constexpr RewardTab make_reward_tab() {
+  RewardTab t{};
+  for (int p = 0; p < 3; ++p) for (int s = 0; s < NSUB; ++s) for (int w = 0; w < 3; ++w) t.v[(p * NSUB + s) * 3 + w] = (int8_t)reward_table_fn(p, s, w);
+  return t;
+}
+static __device__ const RewardTab reward_tab = make_reward_tab();
+__device__ __forceinline__ int reward_table(int phase, int s, int what) { return reward_tab.v[(phase * NSUB + s) * 3 + what]; }
+#else
+CC4_HD int reward_table(int phase, int s, int what) { return reward_table_fn(phase, s, what); }
+#endif
 
 // comms-policy graph, Agents/Wrappers/BlueFlatWrapper.py:267-302: adjacency bitmask over subnets for `s`
 CC4_HD uint32_t comms_adjacent(int phase, int s) {
