@@ -226,9 +226,12 @@ constexpr ObsFastTab make_obs_fast_tab() {
 static_assert(offsetof(EnvState, hev) + MAXH <= 8192 && offsetof(EnvState, msg) + NBLUE * MSG_LEN <= 8192, "source offsets fit 13 bits");
 static_assert((EV_CUR_PROC | EV_OLD_PROC | EV_CUR_CONN | EV_OLD_CONN) < 128 && OBS_TOTAL * 4 <= 4096, "mask and byte position fit their fields");
 static __device__ const ObsFastTab obs_fast_tab = make_obs_fast_tab();
+// msgs_clean: the message values ([224, 384) of the enumeration) need no rewrite -- no agent sent a message with this step nor with the step before, whose
+// encode wrote their zeros (the persistent kernels know that of every step of a launch but the first: cc4_run_random_steps carries no messages)
 template <int nt>
-__device__ __forceinline__ void encode_obs_fast(const EnvState* s, int32_t* o, uint8_t* obs_bytes, bool pack, int t) {
+__device__ __forceinline__ void encode_obs_fast(const EnvState* s, int32_t* o, uint8_t* obs_bytes, bool pack, int t, bool msgs_clean = false) {
   constexpr int NV = (OBS_FAST + nt - 1) / nt;
+  constexpr int K_MSG = (224 + nt - 1) / nt;             // rounds from this one on hold message values only
   constexpr bool EXACT = OBS_FAST % nt == 0;             // one wave: 6 x 64 values, no lane is ever out of range
   const uint32_t tt = (uint32_t)t;
   __builtin_assume(tt < (uint32_t)nt);
@@ -241,6 +244,7 @@ __device__ __forceinline__ void encode_obs_fast(const EnvState* s, int32_t* o, u
   for (int k = 0; k < NV; ++k) {
     const uint32_t v = tt + (uint32_t)(k * nt);
     if (!EXACT && v >= (uint32_t)OBS_FAST) continue;
+    if (k >= K_MSG && msgs_clean) continue;              // (wave-uniform)
     const uint32_t byte = row[(ent[k] >> 12) & 0x1FFFu];
     const int val = (byte & (ent[k] >> 25)) != 0 ? 1 : 0;
     const uint32_t pos = ent[k] & 0xFFFu;

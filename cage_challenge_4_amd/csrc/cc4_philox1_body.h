@@ -79,6 +79,9 @@ __device__ __forceinline__ void philox1_body(StepArgs a, const int e, const uint
   HostDyn* const hd = a.st[e].hd;                   // the host table stays in HBM / L2
   if (prof && lane == 0) prof[11] += clock64() - t_begin;
   const bool do_reset = a.autoreset && s->done;
+  // a later step of a one-launch call that carries no messages: the step before (of this very launch) stored the agents' zero message bytes and encoded
+  // their zeros -- neither needs redoing (a regeneration in between rewrites everything, and leaves zeros)
+  const bool msgs_clean = PERSIST && item_k > 0 && !a.msgs;
   if (do_reset) {
     philox1_autoreset(a, e, lane, s, hd, cold_e, work);
   } else {
@@ -156,7 +159,7 @@ __device__ __forceinline__ void philox1_body(StepArgs a, const int e, const uint
         if (a.rand_out) { act = (int32_t)(((uint64_t)brand * (uint32_t)(b == 4 ? ACT_LONG : ACT_SHORT)) >> 32); a.rand_out[e * NBLUE + b] = act; }   // == random_blue_action
         step_blue_submit(xg, b, act);
         step_tick_blue(xg, b);
-        step_messages(s, a.msgs ? a.msgs + e * NBLUE * MSG_LEN : nullptr, b);   // read back by this step's observation encode only
+        if (!msgs_clean) step_messages(s, a.msgs ? a.msgs + e * NBLUE * MSG_LEN : nullptr, b);   // read back by this step's observation encode only
       }
       if (!(CC4_STOP_ON && (a.dbg_stop == 3 || a.dbg_stop == 4))) {
         if (lane < ng) step_green_policy(xg, lane);                             // agents 0..63: their block is computed here, by all of them at once
@@ -284,7 +287,7 @@ __device__ __forceinline__ void philox1_body(StepArgs a, const int e, const uint
     // the slowly varying values by kind (env_flat_obs_sorted's enumeration: 63 blocked bits, 63 comms-policy bits, 63 subnet one-hots, 5 phase words --
     // one pass of the wave each): what the step changed (EnvState.obs_dirty), everything after a reset or when the caller's buffer is new
     const uint32_t dirty = (do_reset || (a.full_obs && (!PERSIST || item_k == 0))) ? (uint32_t)OD_ALL : (uint32_t)s->obs_dirty;
-    encode_obs_fast<WAVE>(s, o, nullptr, false, lane);
+    encode_obs_fast<WAVE>(s, o, nullptr, false, lane, msgs_clean && !do_reset && dirty != (uint32_t)OD_ALL);
     encode_obs_slow(s, o, dirty, lane);
   }
   __syncthreads();
